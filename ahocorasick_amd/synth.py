@@ -1,0 +1,216 @@
+"""Deterministic synthetic dictionaries and haystacks for the BASELINE.json configs.
+
+PRNG = SplitMix64 used counter-style: the i-th draw (i = 0,1,...) of stream `seed` is
+    x = seed + (i+1)*0x9E3779B97F4A7C15;  z = (x ^ x>>30)*0xBF58476D1CE4E5B9;
+    z = (z ^ z>>27)*0x94D049BB133111EB;   z ^= z>>31
+and a bounded draw in [0,k) is ((z>>32)*k)>>32.  Being counter-based, unit i of a haystack depends only on
+(seed, i), so the device generator (csrc/acgpu_synth.hip: acgpu_synth_fill) and this numpy generator agree
+bit-for-bit and a multi-GPU shard can be generated in place.
+"""
+import numpy as np
+
+GOLDEN = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+
+
+def splitmix64_at(seed, idx):
+    """z values for draw indices idx (array of uint64) of stream `seed`."""
+    with np.errstate(over="ignore"):
+        x = np.uint64(seed) + (np.asarray(idx, dtype=np.uint64) + np.uint64(1)) * GOLDEN
+        z = (x ^ (x >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def bounded(z, k):
+    return ((z >> np.uint64(32)) * np.uint64(k)) >> np.uint64(32)
+
+
+_MASK = (1 << 64) - 1
+
+
+def _mix_int(x):
+    z = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & _MASK
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _MASK
+    return z ^ (z >> 31)
+
+
+class Stream:
+    """Sequential view of one SplitMix64 stream (for dictionary generation); pure-int, same values as
+    splitmix64_at(seed, i)."""
+
+    def __init__(self, seed):
+        self.seed = int(seed)
+        self.i = 0
+
+    def draw(self, k):
+        self.i += 1
+        z = _mix_int((self.seed + self.i * 0x9E3779B97F4A7C15) & _MASK)
+        return ((z >> 32) * k) >> 32
+
+    def draws(self, n, k):
+        if n > 64:
+            z = splitmix64_at(self.seed, np.arange(self.i, self.i + n, dtype=np.uint64))
+            self.i += n
+            return bounded(z, k).astype(np.int64)
+        return np.array([self.draw(k) for _ in range(n)], dtype=np.int64)
+
+
+# Haystack "alphabet programs": unit = table[bounded(z, len(table))]
+ALPHA_LOWER = np.arange(ord("a"), ord("z") + 1, dtype=np.uint16)  # iid uniform a-z   (C1, C2, C3)
+ALPHA_AB_75 = np.array([ord("a")] * 3 + [ord("b")], dtype=np.uint16)  # P(a)=0.75      (C4)
+
+
+def haystack(seed, n_units, table=ALPHA_LOWER, start=0, chunk=1 << 24):
+    """Units [start, start+n_units) of the haystack stream `seed` (numpy reference of acgpu_synth_fill)."""
+    table = np.asarray(table, dtype=np.uint16)
+    out = np.empty(n_units, dtype=np.uint16)
+    for lo in range(0, n_units, chunk):
+        hi = min(n_units, lo + chunk)
+        z = splitmix64_at(seed, np.arange(start + lo, start + hi, dtype=np.uint64))
+        out[lo:hi] = table[bounded(z, len(table))]
+    return out
+
+
+def random_keywords(seed, n, min_len, max_len, table=ALPHA_LOWER):
+    """n DISTINCT keywords, length uniform in [min_len, max_len], units uniform over `table`.
+    Returns a list of uint16 arrays (generation order)."""
+    s = Stream(seed)
+    seen = set()
+    out = []
+    table = np.asarray(table, dtype=np.uint16)
+    while len(out) < n:
+        ln = min_len + s.draw(max_len - min_len + 1)
+        u = table[s.draws(ln, len(table))]
+        key = u.tobytes()
+        if key not in seen:
+            seen.add(key)
+            out.append(u)
+    return out
+
+
+def prefix_closed_keywords(seed, n, word_len=1000):
+    """C4 dictionary: every prefix of base words over {a,b} of length word_len; the first base word is
+    a^word_len (the literal a, aa, aaa, ... family), further base words are uniform random; stops at n distinct."""
+    s = Stream(seed)
+    seen = set()
+    out = []
+    first = True
+    ab = np.array([ord("a"), ord("b")], dtype=np.uint16)
+    while len(out) < n:
+        if first:
+            w = np.full(word_len, ord("a"), dtype=np.uint16)
+            first = False
+        else:
+            w = ab[s.draws(word_len, 2)]
+        for ln in range(1, word_len + 1):
+            key = w[:ln].tobytes()
+            if key not in seen:
+                seen.add(key)
+                out.append(w[:ln].copy())
+                if len(out) >= n:
+                    break
+    return out
+
+
+# ---- C5: mixed-script whole-word workload -------------------------------------------------------------
+
+_SCRIPTS = [
+    # (name, code-unit ranges)
+    ("latin", [(0x41, 0x5A), (0x61, 0x7A), (0xC0, 0xD6), (0xD8, 0xF6), (0xF8, 0xFF)]),
+    ("greek", [(0x0391, 0x03A1), (0x03A3, 0x03A9), (0x03B1, 0x03C9)]),
+    ("cyrillic", [(0x0410, 0x044F)]),
+    ("cjk", [(0x4E00, 0x9FFF)]),
+    ("hangul", [(0xAC00, 0xD7A3)]),
+    ("arabic", [(0x0621, 0x063A), (0x0641, 0x064A)]),
+]
+_SEPARATORS = np.array([0x20, ord(","), ord("."), 0x0A, 0x3002, 0x2014], dtype=np.uint16)
+
+
+def _script_tables():
+    return [np.concatenate([np.arange(a, b + 1, dtype=np.uint16) for a, b in rs]) for _, rs in _SCRIPTS]
+
+
+def mixed_script_words(seed, n, min_len=2, max_len=12):
+    """n distinct single-script words (C5 dictionary)."""
+    s = Stream(seed)
+    tabs = _script_tables()
+    seen = set()
+    out = []
+    while len(out) < n:
+        t = tabs[s.draw(len(tabs))]
+        ln = min_len + s.draw(max_len - min_len + 1)
+        u = t[s.draws(ln, len(t))]
+        key = u.tobytes()
+        if key not in seen:
+            seen.add(key)
+            out.append(u)
+    return out
+
+
+def mixed_script_haystack(seed, n_units, words, swapcase_tbl=None):
+    """C5 haystack: tokens (50% dictionary word with random per-unit case flips, 50% random word) separated by
+    1-3 separator units; truncated to exactly n_units.  Sequential stream (host generation)."""
+    s = Stream(seed)
+    tabs = _script_tables()
+    out = np.empty(n_units + 64, dtype=np.uint16)
+    pos = 0
+    nw = len(words)
+    while pos < n_units:
+        if s.draw(2) == 0 and nw:
+            w = words[s.draw(nw)].copy()
+            if swapcase_tbl is not None:
+                flips = s.draws(len(w), 2).astype(bool)
+                w[flips] = swapcase_tbl[w[flips]]
+        else:
+            t = tabs[s.draw(len(tabs))]
+            ln = 2 + s.draw(11)
+            w = t[s.draws(ln, len(t))]
+        nsep = 1 + s.draw(3)
+        sep = _SEPARATORS[s.draws(nsep, len(_SEPARATORS))]
+        tok = np.concatenate([w, sep])
+        take = min(len(tok), n_units + 64 - pos)
+        out[pos:pos + take] = tok[:take]
+        pos += take
+    return out[:n_units].copy()
+
+
+def swapcase_table():
+    """Per-unit case flip used by mixed_script_haystack (upper<->lower where a single-unit mapping exists)."""
+    t = np.arange(65536, dtype=np.uint16)
+    for c in range(65536):
+        if 0xD800 <= c <= 0xDFFF:
+            continue
+        ch = chr(c)
+        sw = ch.swapcase()
+        if len(sw) == 1 and ord(sw) < 65536:
+            t[c] = ord(sw)
+    return t
+
+
+CONFIGS = {
+    # name: dictionary spec, haystack spec
+    "C1": dict(matcher="AhoCorasickSet", dict_seed=1001, hay_seed=2001, n_kw=100, min_len=3, max_len=8,
+               n_units=1 << 19),
+    "C2": dict(matcher="AhoCorasickMap", dict_seed=1002, hay_seed=2002, n_kw=10000, min_len=4, max_len=12,
+               n_units=1 << 29),
+    "C3": dict(matcher="AhoCorasickSet", dict_seed=1002, hay_seed=2003, n_kw=10000, min_len=4, max_len=12,
+               n_units=1 << 29),  # per GPU; shard g uses hay_seed + g
+    "C4": dict(matcher="LongestMatchSet", dict_seed=1004, hay_seed=2004, n_kw=50000, word_len=1000,
+               n_units=1 << 29),
+    "C5": dict(matcher="WholeWordMatchMap", dict_seed=1005, hay_seed=2005, n_kw=100000, min_len=2, max_len=12,
+               n_units=1 << 28),  # per GPU
+}
+
+
+def config_keywords(name):
+    c = CONFIGS[name]
+    if name in ("C1", "C2", "C3"):
+        return random_keywords(c["dict_seed"], c["n_kw"], c["min_len"], c["max_len"])
+    if name == "C4":
+        return prefix_closed_keywords(c["dict_seed"], c["n_kw"], c["word_len"])
+    if name == "C5":
+        return mixed_script_words(c["dict_seed"], c["n_kw"], c["min_len"], c["max_len"])
+    raise KeyError(name)

@@ -1,0 +1,116 @@
+"""Closed-form, brute-force statements of what each reference matcher reports -- TEST INFRASTRUCTURE ONLY.
+
+These follow the *test oracles* of the reference (not its matcher code), so they are an independent check on
+oracle/ac_oracle.c:
+  AC-all   : T/AhoCorasickTest.java:28-38   (every occurrence of every keyword)
+  Longest  : T/LongestMatchTest.java:30-42  (greedy leftmost-longest, keywords sorted by length desc :50-58)
+  WholeWord: T/WholeWordMatchTest.java:60-90 (maximal word-char runs equal to a keyword)
+plus the emission order documented in SURVEY.md Appendix A (end ascending, longest first).
+Pure-Python loops: small cases only.
+"""
+import numpy as np
+
+
+def _units(s):
+    if isinstance(s, str):
+        return tuple(np.frombuffer(s.encode("utf-16-le", "surrogatepass"), dtype=np.uint16).tolist())
+    return tuple(int(x) for x in s)
+
+
+def _fold(u, lower):
+    return u if lower is None else tuple(int(lower[x]) for x in u)
+
+
+def _dictionary(keywords, lower):
+    """folded keyword -> index of the LAST input keyword producing it (S/AhoCorasickMap.java:49-50)."""
+    d = {}
+    for i, k in enumerate(keywords):
+        if k is None:
+            continue
+        u = _fold(_units(k), lower)
+        if len(u) > 0:
+            d[u] = i
+    return d
+
+
+def ac_all(haystack, keywords, case_sensitive=True, lower=None):
+    lo = None if case_sensitive else lower
+    h = _fold(_units(haystack), lo)
+    d = _dictionary(keywords, lo)
+    lens = sorted({len(k) for k in d}, reverse=True)
+    out = []
+    for end in range(1, len(h) + 1):
+        for L in lens:  # longest first == start ascending
+            if L <= end:
+                idx = d.get(h[end - L:end])
+                if idx is not None:
+                    out.append((end - L, end, idx))
+    return out
+
+
+def longest(haystack, keywords, case_sensitive=True, lower=None):
+    lo = None if case_sensitive else lower
+    h = _fold(_units(haystack), lo)
+    d = _dictionary(keywords, lo)
+    lens = sorted({len(k) for k in d}, reverse=True)
+    out = []
+    pos = 0
+    n = len(h)
+    while pos < n:
+        hit = 0
+        for L in lens:
+            if pos + L <= n:
+                idx = d.get(h[pos:pos + L])
+                if idx is not None:
+                    out.append((pos, pos + L, idx))
+                    hit = L
+                    break
+        pos += hit if hit else 1
+    return out
+
+
+def trim(keyword_units, word_chars):
+    """WordCharacters.trim semantics (S/WordCharacters.java:41-62), restated independently."""
+    u = list(keyword_units)
+    flags = [bool(word_chars[c]) for c in u]
+    if not any(flags):
+        return tuple(u)  # untouched when it has no word chars at all
+    first = flags.index(True)
+    last = len(flags) - 1 - flags[::-1].index(True)
+    return tuple(u[first:last + 1])
+
+
+class NonWordCharacters(ValueError):
+    pass
+
+
+def wholeword(haystack, keywords, word_chars, case_sensitive=True, lower=None):
+    """Valid for fold-consistent tables (word_chars[c] == word_chars[lower[c]] for all c), which includes the
+    default table and every case-sensitive use."""
+    lo = None if case_sensitive else lower
+    d = {}
+    for i, k in enumerate(keywords):
+        if k is None:
+            continue
+        u = trim(_units(k), word_chars)
+        if any(not word_chars[c] for c in u):
+            raise NonWordCharacters(i)
+        if len(u) > 0:
+            d[_fold(u, lo)] = i
+    raw = _units(haystack)
+    h = _fold(raw, lo)
+    n = len(raw)
+    out = []
+    i = 0
+    while i < n:
+        if not word_chars[raw[i]]:
+            i += 1
+            continue
+        j = i
+        while j < n and word_chars[raw[j]]:
+            j += 1
+        idx = d.get(h[i:j])
+        if idx is not None:
+            out.append((i, j, idx))
+        i = j
+    return out

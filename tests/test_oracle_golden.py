@@ -1,0 +1,124 @@
+"""Pins oracle/ac_oracle.c (the CPU restatement of the reference) against
+ (1) the reference's deterministic test scenarios (tests/golden/reference_fixtures.json),
+ (2) the exact push/flush sequences of T/MatchQueueTest.java:9-57,
+ (3) the brute-force formulas of the reference tests on seeded random inputs
+     (the reference's own random tests are unseeded: T/Generator.java:61-76)."""
+import numpy as np
+import pytest
+
+from oracle import brute
+from oracle.oracle import FAM_AC, FAM_LONGEST, FAM_WHOLEWORD, IllegalArgumentException, MatchQueue, Oracle, trim
+from tests.helpers import LOWER, WORD, fixture_inputs, rand_case
+
+
+def _as_list(a):
+    return [list(map(int, r)) for r in a]
+
+
+def test_fixtures_all_families(fixtures):
+    for fx in fixtures:
+        hay, kws = fixture_inputs(fx)
+        assert _as_list(Oracle(FAM_AC, kws).match(hay)) == fx["AC"], fx["name"]
+        assert _as_list(Oracle(FAM_LONGEST, kws).match(hay)) == fx["L"], fx["name"]
+        if fx["WW"] == "IllegalArgumentException":
+            with pytest.raises(IllegalArgumentException):
+                Oracle(FAM_WHOLEWORD, kws, word_chars=WORD)
+        else:
+            assert _as_list(Oracle(FAM_WHOLEWORD, kws, word_chars=WORD).match(hay)) == fx["WW"], fx["name"]
+
+
+def test_appendix_b_hand_pins():
+    # SURVEY.md Appendix B (independent brute-force script), typed by hand.
+    ac = Oracle(FAM_AC, ["bc", "cc", "bcc", "ccddee", "ccddeee", "d"]).match("abbccddeef")[:, :2]
+    assert _as_list(ac) == [[2, 4], [2, 5], [3, 5], [5, 6], [6, 7], [3, 9]]
+    lm = Oracle(FAM_LONGEST, ["a", "aa", "aaa", "aaaa"]).match(" aaaaaaa aaababababaabaa ")[:, :2]
+    assert _as_list(lm) == [[1, 5], [5, 8], [9, 12], [13, 14], [15, 16], [17, 18], [19, 21], [22, 24]]
+    ww = Oracle(FAM_WHOLEWORD, ["la", "late", "eve", "evening"], word_chars=WORD).match("late evening")[:, :2]
+    assert _as_list(ww) == [[0, 4], [5, 12]]
+    assert len(Oracle(FAM_AC, ["a" * k for k in range(1, 101)]).match("a" * 100)) == 5050
+
+
+def test_match_queue_sequences():
+    # T/MatchQueueTest.java:10-20  testMatchQueue
+    q = MatchQueue()
+    for ln, idx in [(3, 3), (3, 6), (3, 9), (9, 10)]:
+        q.push(ln, idx)
+    got = q.match_and_clear(10)
+    q.push(7, 10)
+    got += q.match_and_clear(10)
+    assert [(e, e - s) for s, e in got] == [(3, 3), (6, 3), (9, 3), (10, 7)]
+    # :23-31 testMatchQueueExtendingOverlap
+    q = MatchQueue()
+    q.push(3, 3); q.push(4, 4); q.push(2, 5)
+    assert [(e, e - s) for s, e in q.match_and_clear(4)] == [(4, 4)]
+    # :34-43 testMatchQueueSimple
+    q = MatchQueue()
+    q.push(3, 3); q.push(2, 3); q.push(2, 4); q.push(2, 5)
+    assert [(e, e - s) for s, e in q.match_and_clear(5)] == [(3, 3), (5, 2)]
+    # :46-57 testPartialClear
+    q = MatchQueue()
+    for ln, idx in [(3, 3), (3, 6), (3, 9), (9, 10)]:
+        q.push(ln, idx)
+    got = q.match_and_clear(4)
+    q.push(7, 10)
+    got += q.match_and_clear(10)
+    assert [(e, e - s) for s, e in got] == [(3, 3), (10, 7)]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_ac_and_longest_vs_bruteforce(seed):
+    rng = np.random.default_rng(seed)
+    alpha = [ord(c) for c in "ab"] if seed % 2 == 0 else [ord(c) for c in "abcA"]
+    for _ in range(25):
+        hay, kws = rand_case(rng, alpha, int(rng.integers(1, 12)), int(rng.integers(1, 7)), int(rng.integers(0, 200)))
+        for cs in (True, False):
+            kw = dict(case_sensitive=cs, lower=LOWER)
+            assert _as_list(Oracle(FAM_AC, kws, **kw).match(hay)) == [list(m) for m in brute.ac_all(hay, kws, cs, LOWER)]
+            assert _as_list(Oracle(FAM_LONGEST, kws, **kw).match(hay)) == [list(m) for m in
+                                                                          brute.longest(hay, kws, cs, LOWER)]
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzz_wholeword_vs_bruteforce(seed):
+    rng = np.random.default_rng(100 + seed)
+    alpha = [ord(c) for c in "abB -_.9"] + [0x00E9, 0x00C9, 0x4E2D, 0x3002]
+    word_alpha = [c for c in alpha if WORD[c]]
+    for _ in range(40):
+        hay, _ = rand_case(rng, alpha, 1, 1, int(rng.integers(0, 120)))
+        _, kws = rand_case(rng, word_alpha, int(rng.integers(1, 10)), 4, 1)
+        for cs in (True, False):
+            got = Oracle(FAM_WHOLEWORD, kws, case_sensitive=cs, lower=LOWER, word_chars=WORD).match(hay)
+            assert _as_list(got) == [list(m) for m in brute.wholeword(hay, kws, WORD, cs, LOWER)]
+
+
+def test_wholeword_trim_and_rejection():
+    assert trim(" ,abc. ", WORD).tolist() == [ord(c) for c in "abc"]
+    assert trim("...", WORD).tolist() == [ord(".")] * 3  # no word chars: left untouched (S/WordCharacters.java:41-62)
+    with pytest.raises(IllegalArgumentException):
+        Oracle(FAM_WHOLEWORD, ["..."], word_chars=WORD)
+    # trimmed keywords match; empty-after-trim keywords are skipped
+    o = Oracle(FAM_WHOLEWORD, [" abc,", "", None], word_chars=WORD)
+    assert _as_list(o.match("abc abcd abc")) == [[0, 3, 0], [9, 12, 0]]
+
+
+def test_early_stop_and_last_wins():
+    o = Oracle(FAM_AC, ["a", "aa", "aaa", "aaaa"])
+    full = o.match("aaaa")
+    for k in range(1, len(full) + 1):
+        assert _as_list(o.match("aaaa", stop_after=k)) == _as_list(full[:k])
+    # duplicate keyword: last index wins (S/AhoCorasickMap.java:49-50)
+    assert _as_list(Oracle(FAM_AC, ["ab", "x", "ab"]).match("zabz")) == [[1, 3, 2]]
+    # case-insensitive duplicates collapse after folding
+    assert _as_list(Oracle(FAM_AC, ["AB", "ab"], case_sensitive=False, lower=LOWER).match("aB")) == [[0, 2, 1]]
+    lo = Oracle(FAM_LONGEST, ["a", "aa", "aaa", "aaaa"])
+    fl = lo.match(" aaaaaaa aaababababaabaa ")
+    for k in (1, 3, len(fl)):
+        assert _as_list(lo.match(" aaaaaaa aaababababaabaa ", stop_after=k)) == _as_list(fl[:k])
+
+
+def test_reference_shaped_nodes_used():
+    # both node kinds must actually occur (HashmapNode and RangeNode), otherwise the timed baseline is not reference-shaped
+    from ahocorasick_amd import synth
+    kws = synth.random_keywords(7, 2000, 2, 6, table=np.concatenate([synth.ALPHA_LOWER, np.arange(0x4E00, 0x4F00, dtype=np.uint16)]))
+    o = Oracle(FAM_AC, kws)
+    assert o.num_nodes(1) > 0 and o.num_nodes(2) > 0
