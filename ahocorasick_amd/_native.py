@@ -1,0 +1,89 @@
+"""ctypes binding of include/acgpu.h (libacgpu.so).  There is no Python/CPU fallback: if the HIP library is
+missing or no device is usable, every match call fails loudly."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libacgpu.so")
+
+OK, E_INVALID, E_NONWORD, E_NOMEM, E_OVERFLOW, E_HIP, E_NODEVICE, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7
+MODE_ALL, MODE_LONGEST, MODE_WHOLEWORD = 0, 1, 2
+REC_SET, REC_MAP = 8, 12
+
+
+class AcgpuError(RuntimeError):
+    def __init__(self, code, where=""):
+        self.code = code
+        msg = lib().acgpu_strerror(code).decode() if _lib is not None else str(code)
+        if code == E_HIP:
+            msg += " (hipError_t=%d)" % lib().acgpu_last_hip_error()
+        super().__init__("%s: %s [%d]" % (where, msg, code))
+
+
+class Info(ctypes.Structure):
+    _fields_ = [("abi_version", ctypes.c_uint32), ("mode", ctypes.c_uint32), ("case_sensitive", ctypes.c_uint32),
+                ("n_states", ctypes.c_uint32), ("n_classes", ctypes.c_uint32), ("n_keywords", ctypes.c_uint32),
+                ("min_keyword_len", ctypes.c_uint32), ("max_keyword_len", ctypes.c_uint32), ("dense", ctypes.c_uint32),
+                ("entry_bytes", ctypes.c_uint32), ("table_bytes", ctypes.c_uint64), ("lds_states", ctypes.c_uint32),
+                ("fold_consistent", ctypes.c_uint32)]
+
+
+class Shard(ctypes.Structure):
+    _fields_ = [("d_hay", ctypes.c_void_p), ("n_units", ctypes.c_uint64), ("own_begin", ctypes.c_uint64),
+                ("own_end", ctypes.c_uint64), ("text_begin", ctypes.c_int32), ("text_end", ctypes.c_int32),
+                ("chain_entry", ctypes.c_int64), ("chain_exit", ctypes.c_int64)]
+
+
+class Profile(ctypes.Structure):
+    _fields_ = [("scan_ms", ctypes.c_float), ("finalize_ms", ctypes.c_float), ("total_ms", ctypes.c_float),
+                ("scan_units", ctypes.c_uint64), ("n_matches", ctypes.c_uint64), ("scan_kernel", ctypes.c_char * 64)]
+
+
+# every symbol include/acgpu.h declares
+SYMBOLS = ["acgpu_build", "acgpu_free", "acgpu_get_info", "acgpu_match_u16", "acgpu_match_device", "acgpu_synth_fill",
+           "acgpu_set_tunable", "acgpu_strerror", "acgpu_last_hip_error", "acgpu_abi_version", "acgpu_debug_tables"]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "ahocorasick_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C ahocorasick_amd/csrc`).  There is no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        vp, u64, i64, u32, ci = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int64, ctypes.c_uint32, ctypes.c_int
+        L.acgpu_build.restype = ci
+        L.acgpu_build.argtypes = [ci, vp, vp, u32, ci, vp, vp, ctypes.POINTER(vp), ctypes.POINTER(i64)]
+        L.acgpu_free.restype = None
+        L.acgpu_free.argtypes = [vp]
+        L.acgpu_get_info.restype = ci
+        L.acgpu_get_info.argtypes = [vp, ctypes.POINTER(Info)]
+        L.acgpu_match_u16.restype = ci
+        L.acgpu_match_u16.argtypes = [vp, vp, u64, ci, vp, u64, ctypes.POINTER(u64)]
+        L.acgpu_match_device.restype = ci
+        L.acgpu_match_device.argtypes = [vp, ctypes.POINTER(Shard), ci, vp, u64, ctypes.POINTER(u64), vp,
+                                         ctypes.POINTER(Profile)]
+        L.acgpu_synth_fill.restype = ci
+        L.acgpu_synth_fill.argtypes = [vp, u64, u64, u64, vp, u32, vp]
+        L.acgpu_set_tunable.restype = i64
+        L.acgpu_set_tunable.argtypes = [ctypes.c_char_p, i64]
+        L.acgpu_strerror.restype = ctypes.c_char_p
+        L.acgpu_strerror.argtypes = [ci]
+        L.acgpu_last_hip_error.restype = ci
+        L.acgpu_abi_version.restype = u32
+        L.acgpu_debug_tables.restype = ci
+        L.acgpu_debug_tables.argtypes = [vp, vp, vp, vp, vp, vp, vp, ctypes.POINTER(u32)]
+        _lib = L
+    return _lib
+
+
+def check(rc, where):
+    if rc != OK:
+        raise AcgpuError(rc, where)
+
+
+def set_tunable(name, value):
+    return lib().acgpu_set_tunable(name.encode(), int(value))

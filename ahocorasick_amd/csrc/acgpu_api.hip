@@ -1,0 +1,401 @@
+// acgpu_api.hip -- the C ABI of include/acgpu.h: automaton lifetime, device residency of the tables,
+// per-device scratch pool, and the match pipelines (scan -> prefix sum of chunk counts -> permutation).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <new>
+
+#include "acgpu_internal.h"
+#include "acgpu_kernels.h"
+
+using namespace acgpu;
+
+namespace {
+
+thread_local int g_last_hip_error = 0;
+
+#define HIP_TRY(expr)                                  \
+    do {                                               \
+        hipError_t _e = (expr);                        \
+        if (_e != hipSuccess) {                        \
+            g_last_hip_error = (int)_e;                \
+            (void)hipGetLastError();                   \
+            return _e == hipErrorOutOfMemory ? ACGPU_E_NOMEM : (_e == hipErrorNoDevice ? ACGPU_E_NODEVICE : ACGPU_E_HIP); \
+        }                                              \
+    } while (0)
+
+// grow-only device buffer
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return ACGPU_OK;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        size_t want = need + need / 4 + 256;
+        HIP_TRY(hipMalloc(&p, want));
+        bytes = want;
+        return ACGPU_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+struct DeviceState {
+    int device = -1;
+    int n_cu = 256;
+    DevTables T{};
+    std::vector<void *> table_allocs;
+    // scratch pool (one in-flight match per automaton and device)
+    DevBuf counter, chunk_counts, offsets, scan_tmp, scratch, chain;
+    DevBuf stage_hay, stage_out; // acgpu_match_u16 staging
+    unsigned long long *h_counter = nullptr; // pinned
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    ~DeviceState() {
+        for (void *p : table_allocs) (void)hipFree(p);
+        counter.release(); chunk_counts.release(); offsets.release(); scan_tmp.release(); scratch.release();
+        chain.release(); stage_hay.release(); stage_out.release();
+        if (h_counter) (void)hipHostFree(h_counter);
+        for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+    }
+};
+
+template <typename T>
+int upload(DeviceState &d, const std::vector<T> &v, const T **out) {
+    void *p = nullptr;
+    size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
+    HIP_TRY(hipMalloc(&p, bytes));
+    d.table_allocs.push_back(p);
+    if (!v.empty()) HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = reinterpret_cast<const T *>(p);
+    return ACGPU_OK;
+}
+
+} // namespace
+
+struct acgpu_automaton {
+    HostTables t;
+    std::mutex mu;
+    std::map<int, std::unique_ptr<DeviceState>> dev;
+};
+
+namespace {
+
+uint32_t lds_states_for(const HostTables &t) {
+    if (!t.dense) return 0;
+    int64_t budget = tunables().lds_table_bytes;
+    const int64_t max_budget = 160 * 1024 - (int64_t)scan_queue_bytes(scan_block_threads()) - 1024;
+    budget = std::max<int64_t>(0, std::min(budget, max_budget));
+    uint64_t row = (uint64_t)t.n_cls * t.entry_bytes;
+    uint64_t s = row ? (uint64_t)budget / row : 0;
+    return (uint32_t)std::min<uint64_t>(s, t.n_states);
+}
+
+int ensure_device(acgpu_automaton *a, DeviceState **out) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    auto it = a->dev.find(dev);
+    if (it != a->dev.end()) {
+        // the LDS residency tunable may have changed between calls
+        it->second->T.lds_entries = lds_states_for(a->t) * a->t.n_cls;
+        *out = it->second.get();
+        return ACGPU_OK;
+    }
+    std::unique_ptr<DeviceState> d(new (std::nothrow) DeviceState());
+    if (!d) return ACGPU_E_NOMEM;
+    d->device = dev;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    d->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const HostTables &t = a->t;
+    DevTables &T = d->T;
+    int rc;
+    if ((rc = upload(*d, t.cls_lut, &T.cls_lut))) return rc;
+    if ((rc = upload(*d, t.lower, &T.lower))) return rc;
+    if ((rc = upload(*d, t.wflags, &T.wflags))) return rc;
+    if ((rc = upload(*d, t.out_len, &T.out_len))) return rc;
+    if ((rc = upload(*d, t.out_link, &T.out_link))) return rc;
+    if ((rc = upload(*d, t.out_id, &T.out_id))) return rc;
+    if ((rc = upload(*d, t.fail, &T.fail))) return rc;
+    if ((rc = upload(*d, t.depth, &T.depth))) return rc;
+    if ((rc = upload(*d, t.term_id, &T.term_id))) return rc;
+    if ((rc = upload(*d, t.hkeys, &T.hkeys))) return rc;
+    if ((rc = upload(*d, t.hvals, &T.hvals))) return rc;
+    T.dfa = nullptr;
+    if (t.dense) {
+        if (t.entry_bytes == 2) {
+            std::vector<uint16_t> narrow(t.dfa.size());
+            for (size_t i = 0; i < t.dfa.size(); i++) narrow[i] = (uint16_t)t.dfa[i];
+            const uint16_t *p;
+            if ((rc = upload(*d, narrow, &p))) return rc;
+            T.dfa = p;
+        } else {
+            const uint32_t *p;
+            if ((rc = upload(*d, t.dfa, &p))) return rc;
+            T.dfa = p;
+        }
+    }
+    T.hmask = t.hmask;
+    T.n_states = t.n_states; T.n_cls = t.n_cls; T.first_out = t.first_out; T.max_len = t.max_len; T.min_len = t.min_len;
+    T.cls_base = t.cls_base; T.cls_span = t.cls_span; T.range_cls = t.range_cls; T.cs = t.cs; T.dense = t.dense;
+    T.entry_bytes = (int32_t)t.entry_bytes;
+    T.lds_entries = lds_states_for(t) * t.n_cls;
+    HIP_TRY(hipHostMalloc((void **)&d->h_counter, 64, hipHostMallocDefault));
+    for (auto &e : d->ev) HIP_TRY(hipEventCreate(&e));
+    *out = d.get();
+    a->dev[dev] = std::move(d);
+    return ACGPU_OK;
+}
+
+uint32_t round_up8(uint64_t v) { return (uint32_t)((v + 7) & ~7ull); }
+
+// ALL-mode pipeline on one shard.
+int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_kind, void *d_out, uint64_t cap,
+              uint64_t *n_out, hipStream_t stream, acgpu_profile *prof) {
+    const HostTables &t = a->t;
+    const uint64_t own_len = sh->own_end - sh->own_begin;
+    const uint32_t halo = t.max_len > 0 ? t.max_len - 1 : 0;
+    if (!sh->text_begin && sh->own_begin < halo) return ACGPU_E_INVALID; // left halo too short
+    if (prof) {
+        std::memset(prof, 0, sizeof(*prof));
+    }
+    if (own_len == 0 || t.n_states <= 1) {
+        *n_out = 0;
+        return ACGPU_OK;
+    }
+    ScanLaunch L{};
+    L.block = scan_block_threads();
+    L.grid = d.n_cu * (int)std::max<int64_t>(1, tunables().blocks_per_cu);
+    const uint64_t lanes = (uint64_t)L.grid * L.block;
+    uint64_t C = tunables().chunk_units > 0 ? (uint64_t)tunables().chunk_units
+                                            : std::max<uint64_t>({(own_len + lanes - 1) / lanes, 256, 16ull * halo});
+    C = std::max<uint32_t>(8, round_up8(C));
+    L.chunk_units = (uint32_t)C;
+    L.n_chunks = (uint32_t)((own_len + C - 1) / C);
+    // do not launch more workgroups than there are chunks
+    L.grid = (int)std::min<uint64_t>((uint64_t)L.grid, ((uint64_t)L.n_chunks + L.block - 1) / L.block);
+    L.d_hay = sh->d_hay;
+    L.n_units = (uint32_t)sh->n_units;
+    L.own_begin = (uint32_t)sh->own_begin;
+    L.own_end = (uint32_t)sh->own_end;
+    L.cap = cap;
+    L.lds_bytes = scan_queue_bytes(L.block) + (size_t)d.T.lds_entries * t.entry_bytes;
+
+    int rc;
+    if ((rc = d.counter.ensure(64))) return rc;
+    if ((rc = d.chunk_counts.ensure((size_t)L.n_chunks * 4))) return rc;
+    if ((rc = d.offsets.ensure((size_t)L.n_chunks * 8))) return rc;
+    if ((rc = d.scan_tmp.ensure(((size_t)L.n_chunks / 2048 + 2) * 8))) return rc;
+    if ((rc = d.scratch.ensure(std::max<uint64_t>(cap, 1) * sizeof(ScratchRec)))) return rc;
+    L.d_scratch = (ScratchRec *)d.scratch.p;
+    L.d_counter = (unsigned long long *)d.counter.p;
+    L.d_chunk_counts = (uint32_t *)d.chunk_counts.p;
+
+    HIP_TRY(hipMemsetAsync(d.counter.p, 0, 64, stream));
+    if (prof) HIP_TRY(hipEventRecord(d.ev[0], stream));
+    const char *kname = "";
+    HIP_TRY(launch_ac_scan(d.T, L, stream, &kname));
+    if (prof) HIP_TRY(hipEventRecord(d.ev[1], stream));
+    HIP_TRY(launch_exclusive_scan(L.d_chunk_counts, L.n_chunks, (uint64_t *)d.offsets.p, (uint64_t *)d.scan_tmp.p, stream));
+    HIP_TRY(launch_permute(L.d_scratch, L.d_counter, cap, (const uint64_t *)d.offsets.p, L.own_begin, L.chunk_units,
+                           /*by_start=*/0, record_kind, d_out, stream));
+    if (prof) HIP_TRY(hipEventRecord(d.ev[2], stream));
+    HIP_TRY(hipMemcpyAsync(d.h_counter, d.counter.p, 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    *n_out = *d.h_counter;
+    if (prof) {
+        HIP_TRY(hipEventElapsedTime(&prof->scan_ms, d.ev[0], d.ev[1]));
+        HIP_TRY(hipEventElapsedTime(&prof->finalize_ms, d.ev[1], d.ev[2]));
+        HIP_TRY(hipEventElapsedTime(&prof->total_ms, d.ev[0], d.ev[2]));
+        prof->scan_units = own_len + (uint64_t)L.n_chunks * halo;
+        prof->n_matches = *n_out;
+        std::snprintf(prof->scan_kernel, sizeof(prof->scan_kernel), "%s", kname);
+    }
+    return *n_out > cap ? ACGPU_E_OVERFLOW : ACGPU_OK;
+}
+
+int device_for_call(acgpu_automaton *a, DeviceState **d) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        (void)hipGetLastError();
+        return ACGPU_E_NODEVICE;
+    }
+    return ensure_device(a, d);
+}
+
+// validates a shard and runs the pipeline of the automaton's family; caller holds a->mu
+int match_shard(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_kind, void *d_out, uint64_t cap,
+                uint64_t *n_out, hipStream_t stream, acgpu_profile *prof) {
+    if (record_kind != ACGPU_REC_SET && record_kind != ACGPU_REC_MAP) return ACGPU_E_INVALID;
+    if (sh->n_units >= (1ull << 31)) return ACGPU_E_INVALID;
+    if (sh->own_begin > sh->own_end || sh->own_end > sh->n_units) return ACGPU_E_INVALID;
+    if (sh->n_units && (!sh->d_hay || ((uintptr_t)sh->d_hay & 15))) return ACGPU_E_INVALID;
+    if (cap && (!d_out || ((uintptr_t)d_out & 3))) return ACGPU_E_INVALID;
+    *n_out = 0;
+    switch (a->t.mode) {
+    case ACGPU_MODE_ALL: return match_all(a, d, sh, record_kind, d_out, cap, n_out, stream, prof);
+    default: return ACGPU_E_UNSUPPORTED;
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+uint32_t acgpu_abi_version(void) { return ACGPU_ABI_VERSION; }
+
+int acgpu_last_hip_error(void) { return g_last_hip_error; }
+
+const char *acgpu_strerror(int code) {
+    switch (code) {
+    case ACGPU_OK: return "ok";
+    case ACGPU_E_INVALID: return "invalid argument";
+    case ACGPU_E_NONWORD: return "keyword contains non-word characters";
+    case ACGPU_E_NOMEM: return "out of memory";
+    case ACGPU_E_OVERFLOW: return "output capacity too small";
+    case ACGPU_E_HIP: return "HIP runtime error";
+    case ACGPU_E_NODEVICE: return "no HIP device";
+    case ACGPU_E_UNSUPPORTED: return "unsupported";
+    default: return "unknown error";
+    }
+}
+
+int64_t acgpu_set_tunable(const char *name, int64_t value) {
+    if (!name) return -1;
+    Tunables &t = tunables();
+    int64_t *slot = nullptr;
+    if (!std::strcmp(name, "chunk_units")) slot = &t.chunk_units;
+    else if (!std::strcmp(name, "blocks_per_cu")) slot = &t.blocks_per_cu;
+    else if (!std::strcmp(name, "lds_table_bytes")) slot = &t.lds_table_bytes;
+    else if (!std::strcmp(name, "force_sparse")) slot = &t.force_sparse;
+    else if (!std::strcmp(name, "dense_budget_bytes")) slot = &t.dense_budget_bytes;
+    if (!slot) return -1;
+    int64_t prev = *slot;
+    *slot = value;
+    return prev;
+}
+
+int acgpu_build(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uint32_t n_kw, int case_sensitive,
+                const uint16_t *lower_tbl, const uint8_t *wordchar_tbl, acgpu_automaton **out, int64_t *bad_keyword) {
+    if (!out) return ACGPU_E_INVALID;
+    *out = nullptr;
+    acgpu_automaton *a = new (std::nothrow) acgpu_automaton();
+    if (!a) return ACGPU_E_NOMEM;
+    int rc;
+    try {
+        rc = build_tables(mode, kw_units, kw_off, n_kw, case_sensitive, lower_tbl, wordchar_tbl, a->t, bad_keyword);
+    } catch (const std::bad_alloc &) {
+        rc = ACGPU_E_NOMEM;
+    } catch (...) {
+        rc = ACGPU_E_INVALID;
+    }
+    if (rc != ACGPU_OK) {
+        delete a;
+        return rc;
+    }
+    *out = a;
+    return ACGPU_OK;
+}
+
+void acgpu_free(acgpu_automaton *a) {
+    if (!a) return;
+    int cur = -1;
+    bool have = hipGetDevice(&cur) == hipSuccess;
+    for (auto &kv : a->dev) {
+        if (have) (void)hipSetDevice(kv.first);
+        kv.second.reset();
+    }
+    if (have) (void)hipSetDevice(cur);
+    delete a;
+}
+
+int acgpu_get_info(const acgpu_automaton *a, acgpu_info *info) {
+    if (!a || !info) return ACGPU_E_INVALID;
+    const HostTables &t = a->t;
+    std::memset(info, 0, sizeof(*info));
+    info->abi_version = ACGPU_ABI_VERSION;
+    info->mode = (uint32_t)t.mode;
+    info->case_sensitive = t.cs;
+    info->n_states = t.n_states;
+    info->n_classes = t.n_cls;
+    info->n_keywords = t.n_kw;
+    info->min_keyword_len = t.min_len;
+    info->max_keyword_len = t.max_len;
+    info->dense = t.dense;
+    info->entry_bytes = t.entry_bytes;
+    info->table_bytes = t.dense ? (uint64_t)t.dfa.size() * t.entry_bytes : (uint64_t)t.hkeys.size() * 12 + (uint64_t)t.n_states * 4;
+    info->lds_states = lds_states_for(t);
+    info->fold_consistent = t.fold_consistent;
+    return ACGPU_OK;
+}
+
+int acgpu_debug_tables(const acgpu_automaton *a, uint16_t *cls_lut, uint32_t *dfa, uint32_t *out_len, uint32_t *out_link,
+                       uint32_t *out_id, uint32_t *depth, uint32_t *first_out_state) {
+    if (!a) return ACGPU_E_INVALID;
+    const HostTables &t = a->t;
+    if (cls_lut) std::memcpy(cls_lut, t.cls_lut.data(), 65536 * sizeof(uint16_t));
+    if (dfa) {
+        if (!t.dense) return ACGPU_E_UNSUPPORTED;
+        std::memcpy(dfa, t.dfa.data(), t.dfa.size() * sizeof(uint32_t));
+    }
+    if (out_len) std::memcpy(out_len, t.out_len.data(), t.n_states * sizeof(uint32_t));
+    if (out_link) std::memcpy(out_link, t.out_link.data(), t.n_states * sizeof(uint32_t));
+    if (out_id) std::memcpy(out_id, t.out_id.data(), t.n_states * sizeof(uint32_t));
+    if (depth) std::memcpy(depth, t.depth.data(), t.n_states * sizeof(uint32_t));
+    if (first_out_state) *first_out_state = t.first_out;
+    return ACGPU_OK;
+}
+
+int acgpu_match_device(const acgpu_automaton *ca, acgpu_shard *sh, int record_kind, void *d_out, uint64_t cap,
+                       uint64_t *n_out, void *stream_, acgpu_profile *prof) {
+    if (!ca || !sh || !n_out) return ACGPU_E_INVALID;
+    acgpu_automaton *a = const_cast<acgpu_automaton *>(ca);
+    std::lock_guard<std::mutex> lock(a->mu);
+    DeviceState *d = nullptr;
+    int rc = device_for_call(a, &d);
+    if (rc) return rc;
+    return match_shard(a, *d, sh, record_kind, d_out, cap, n_out, reinterpret_cast<hipStream_t>(stream_), prof);
+}
+
+int acgpu_match_u16(const acgpu_automaton *ca, const uint16_t *haystack, uint64_t n_units, int record_kind, void *out,
+                    uint64_t cap, uint64_t *n_out) {
+    if (!ca || !n_out || (n_units && !haystack) || (cap && !out)) return ACGPU_E_INVALID;
+    if (record_kind != ACGPU_REC_SET && record_kind != ACGPU_REC_MAP) return ACGPU_E_INVALID;
+    if (n_units >= (1ull << 31)) return ACGPU_E_INVALID;
+    acgpu_automaton *a = const_cast<acgpu_automaton *>(ca);
+    std::lock_guard<std::mutex> lock(a->mu); // staging buffers are part of the per-device scratch pool
+    DeviceState *d = nullptr;
+    int rc = device_for_call(a, &d);
+    if (rc) return rc;
+    if ((rc = d->stage_hay.ensure(n_units * 2 + 16))) return rc;
+    if ((rc = d->stage_out.ensure(cap * (uint64_t)record_kind + 16))) return rc;
+    if (n_units) HIP_TRY(hipMemcpy(d->stage_hay.p, haystack, n_units * 2, hipMemcpyHostToDevice));
+    acgpu_shard sh{};
+    sh.d_hay = (const uint16_t *)d->stage_hay.p;
+    sh.n_units = n_units;
+    sh.own_begin = 0;
+    sh.own_end = n_units;
+    sh.text_begin = 1;
+    sh.text_end = 1;
+    sh.chain_entry = 0;
+    rc = match_shard(a, *d, &sh, record_kind, d->stage_out.p, cap, n_out, nullptr, nullptr);
+    if (rc != ACGPU_OK) return rc;
+    if (*n_out) HIP_TRY(hipMemcpy(out, d->stage_out.p, *n_out * (uint64_t)record_kind, hipMemcpyDeviceToHost));
+    return ACGPU_OK;
+}
+
+int acgpu_synth_fill(uint16_t *d_dst, uint64_t n_units, uint64_t start_index, uint64_t seed, const uint16_t *table,
+                     uint32_t table_len, void *stream) {
+    if ((n_units && !d_dst) || !table || table_len == 0 || table_len > 64) return ACGPU_E_INVALID;
+    HIP_TRY(launch_synth_fill(d_dst, n_units, start_index, seed, table, table_len, reinterpret_cast<hipStream_t>(stream)));
+    return ACGPU_OK;
+}
+
+} // extern "C"

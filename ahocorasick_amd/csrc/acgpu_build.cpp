@@ -1,0 +1,262 @@
+// acgpu_build.cpp -- host builder: dictionary -> automaton tables.
+//
+// Replaces the constructors of the reference matchers (trie insertion, BFS fail links and
+// compressed output links, S/AhoCorasickSet.java:20-191; Map value rules S/AhoCorasickMap.java:32-50,
+// 129-133; WholeWord trimming/validation S/WholeWordMatchMap.java:246-323).  The reference's node
+// representation (HashmapNode/RangeNode, Thresholder, gap fill) is a results-neutral speed knob of a
+// pointer-chasing CPU loop and is not reproduced: the device works on one flat table.
+#include <algorithm>
+#include <cstring>
+#include <unordered_map>
+
+#include "acgpu_internal.h"
+
+namespace acgpu {
+
+Tunables &tunables() {
+    static Tunables t;
+    return t;
+}
+
+namespace {
+
+struct TrieNode {
+    uint32_t parent;
+    uint16_t unit;
+    uint32_t depth;
+    uint32_t kw; // own keyword id (last wins) or ~0u
+};
+
+// WordCharacters.trim, S/WordCharacters.java:41-62
+void trim_keyword(const uint8_t *word, const uint16_t *w, uint64_t len, uint64_t &ws, uint64_t &we) {
+    ws = 0;
+    we = len;
+    for (uint64_t i = 0; i < len; i++)
+        if (word[w[i]]) { ws = i; break; }
+    for (uint64_t i = len; i-- > 0;)
+        if (word[w[i]]) { we = i + 1; break; }
+}
+
+} // namespace
+
+int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uint32_t n_kw, int case_sensitive,
+                 const uint16_t *lower_tbl, const uint8_t *wordchar_tbl, HostTables &t, int64_t *bad_keyword) {
+    if (mode != ACGPU_MODE_ALL && mode != ACGPU_MODE_LONGEST && mode != ACGPU_MODE_WHOLEWORD) return ACGPU_E_INVALID;
+    if (n_kw && (!kw_units || !kw_off)) return ACGPU_E_INVALID;
+    if (!case_sensitive && !lower_tbl) return ACGPU_E_INVALID;
+    if (mode == ACGPU_MODE_WHOLEWORD && !wordchar_tbl) return ACGPU_E_INVALID;
+
+    t.mode = mode;
+    t.cs = case_sensitive != 0;
+    t.lower.resize(65536);
+    for (uint32_t c = 0; c < 65536; c++) t.lower[c] = t.cs ? (uint16_t)c : lower_tbl[c];
+    if (mode == ACGPU_MODE_WHOLEWORD) {
+        t.wflags.resize(65536);
+        t.fold_consistent = true;
+        for (uint32_t c = 0; c < 65536; c++) {
+            uint8_t raw = wordchar_tbl[c] ? 1 : 0, fold = wordchar_tbl[t.lower[c]] ? 1 : 0;
+            t.wflags[c] = (uint8_t)(raw | (fold << 1));
+            if (raw != fold) t.fold_consistent = false;
+        }
+    }
+
+    // ---- 1. trie insertion (keyword order matters: the LAST duplicate's index wins) ----
+    std::vector<TrieNode> nodes;
+    nodes.push_back({0, 0, 0, ~0u});
+    std::unordered_map<uint64_t, uint32_t> edge; // (node<<16 | unit) -> child
+    edge.reserve(1024);
+    t.min_len = 0;
+    t.max_len = 0;
+    uint32_t n_terminal = 0;
+    for (uint32_t k = 0; k < n_kw; k++) {
+        const uint16_t *w = kw_units + kw_off[k];
+        uint64_t len = kw_off[k + 1] - kw_off[k], ws = 0, we = len;
+        if (mode == ACGPU_MODE_WHOLEWORD) {
+            trim_keyword(wordchar_tbl, w, len, ws, we);
+            for (uint64_t i = ws; i < we; i++) {
+                if (!wordchar_tbl[w[i]]) { // validated on the un-folded units, S/WholeWordMatchMap.java:263-267
+                    if (bad_keyword) *bad_keyword = (int64_t)k;
+                    return ACGPU_E_NONWORD;
+                }
+            }
+        }
+        if (we <= ws) continue; // null / empty keywords are skipped, S/AhoCorasickSet.java:27
+        uint32_t cur = 0;
+        for (uint64_t i = ws; i < we; i++) {
+            uint16_t u = t.lower[w[i]];
+            uint64_t key = ((uint64_t)cur << 16) | u;
+            auto it = edge.find(key);
+            if (it == edge.end()) {
+                uint32_t id = (uint32_t)nodes.size();
+                if (id == 0x7fffffffu) return ACGPU_E_UNSUPPORTED;
+                nodes.push_back({cur, u, nodes[cur].depth + 1, ~0u});
+                edge.emplace(key, id);
+                cur = id;
+            } else {
+                cur = it->second;
+            }
+        }
+        if (nodes[cur].kw == ~0u) n_terminal++;
+        nodes[cur].kw = k;
+        uint32_t L = (uint32_t)(we - ws);
+        if (t.max_len == 0 || L > t.max_len) t.max_len = L;
+        if (t.min_len == 0 || L < t.min_len) t.min_len = L;
+    }
+    const uint32_t N = (uint32_t)nodes.size();
+    t.n_states = N;
+    t.n_kw = n_terminal;
+    t.n_edges = N - 1;
+
+    // ---- 2. children lists (CSR by insertion id), sorted by unit for a deterministic BFS ----
+    std::vector<uint32_t> child_begin(N + 1, 0);
+    for (uint32_t i = 1; i < N; i++) child_begin[nodes[i].parent + 1]++;
+    for (uint32_t i = 0; i < N; i++) child_begin[i + 1] += child_begin[i];
+    std::vector<uint32_t> child_ids(N ? N - 1 : 0);
+    {
+        std::vector<uint32_t> fill(child_begin.begin(), child_begin.end() - 1);
+        for (uint32_t i = 1; i < N; i++) child_ids[fill[nodes[i].parent]++] = i;
+        for (uint32_t i = 0; i < N; i++)
+            std::sort(child_ids.begin() + child_begin[i], child_ids.begin() + child_begin[i + 1],
+                      [&](uint32_t a, uint32_t b) { return nodes[a].unit < nodes[b].unit; });
+    }
+    auto find_child = [&](uint32_t s, uint16_t u) -> uint32_t { // ~0u if absent
+        uint32_t lo = child_begin[s], hi = child_begin[s + 1];
+        while (lo < hi) {
+            uint32_t mid = (lo + hi) >> 1;
+            uint16_t mu = nodes[child_ids[mid]].unit;
+            if (mu < u) lo = mid + 1; else hi = mid;
+        }
+        return (lo < child_begin[s + 1] && nodes[child_ids[lo]].unit == u) ? child_ids[lo] : ~0u;
+    };
+
+    // ---- 3. BFS: fail links and compressed outputs (AC semantics; S/AhoCorasickSet.java:58-121) ----
+    std::vector<uint32_t> bfs;
+    bfs.reserve(N);
+    bfs.push_back(0);
+    std::vector<uint32_t> fail(N, 0), olen(N, 0), olink(N, 0), oid(N, ~0u);
+    const bool want_fail = (mode != ACGPU_MODE_WHOLEWORD); // WholeWord is a plain trie (S/WholeWordMatchMap.java:303-321)
+    for (size_t qi = 0; qi < bfs.size(); qi++) {
+        uint32_t s = bfs[qi];
+        for (uint32_t ci = child_begin[s]; ci < child_begin[s + 1]; ci++) {
+            uint32_t c = child_ids[ci];
+            bfs.push_back(c);
+            uint16_t u = nodes[c].unit;
+            uint32_t f = 0;
+            if (want_fail && s != 0) {
+                uint32_t pf = fail[s];
+                for (;;) {
+                    uint32_t m = find_child(pf, u);
+                    if (m != ~0u) { f = m; break; }
+                    if (pf == 0) { f = 0; break; }
+                    pf = fail[pf];
+                }
+            }
+            fail[c] = f;
+            bool own = nodes[c].kw != ~0u;
+            // the nearest fail ancestor carrying a match is f itself whenever any exists, because every
+            // shallower node already inherited its nearest match (S/AhoCorasickSet.java:110-121)
+            bool g = want_fail && f != 0 && olen[f] > 0;
+            if (own) {
+                olen[c] = nodes[c].depth;
+                oid[c] = nodes[c].kw;
+                olink[c] = g ? f : 0;
+            } else if (g) {
+                olen[c] = olen[f];
+                oid[c] = oid[f];
+                olink[c] = olink[f];
+            }
+        }
+    }
+
+    // ---- 4. renumber: no-output states in BFS order, then output states in BFS order ----
+    std::vector<uint32_t> newid(N);
+    uint32_t n_plain = 0;
+    for (uint32_t s : bfs) if (olen[s] == 0) newid[s] = n_plain++;
+    t.first_out = n_plain;
+    {
+        uint32_t next = n_plain;
+        for (uint32_t s : bfs) if (olen[s] != 0) newid[s] = next++;
+    }
+    t.depth.assign(N, 0); t.fail.assign(N, 0); t.out_len.assign(N, 0); t.out_link.assign(N, 0);
+    t.out_id.assign(N, ~0u); t.term_id.assign(N, ~0u);
+    for (uint32_t s = 0; s < N; s++) {
+        uint32_t n = newid[s];
+        t.depth[n] = nodes[s].depth;
+        t.fail[n] = newid[fail[s]];
+        t.out_len[n] = olen[s];
+        t.out_link[n] = olink[s] ? newid[olink[s]] : 0;
+        t.out_id[n] = oid[s];
+        t.term_id[n] = nodes[s].kw;
+    }
+
+    // ---- 5. hashed goto edges keyed by (state, folded unit) ----
+    {
+        uint64_t cap = 16;
+        while (cap < 2 * (uint64_t)(N ? N - 1 : 0) + 2) cap <<= 1;
+        t.hkeys.assign(cap, kEmptyKey);
+        t.hvals.assign(cap, 0);
+        t.hmask = (uint32_t)(cap - 1);
+        for (uint32_t i = 1; i < N; i++) {
+            uint64_t key = edge_key(newid[nodes[i].parent], nodes[i].unit);
+            uint32_t slot = edge_hash(key) & t.hmask;
+            while (t.hkeys[slot] != kEmptyKey) slot = (slot + 1) & t.hmask;
+            t.hkeys[slot] = key;
+            t.hvals[slot] = newid[i];
+        }
+    }
+
+    // ---- 6. character classes + dense delta table (AC/LONGEST only) ----
+    t.cls_lut.assign(65536, 0);
+    t.n_cls = 1;
+    t.dense = false;
+    t.range_cls = false;
+    if (mode != ACGPU_MODE_WHOLEWORD) {
+        std::vector<uint8_t> used(65536, 0);
+        uint32_t n_used = 0, minu = 65535, maxu = 0;
+        for (uint32_t i = 1; i < N; i++) {
+            uint16_t u = nodes[i].unit;
+            if (!used[u]) { used[u] = 1; n_used++; }
+            if (u < minu) minu = u;
+            if (u > maxu) maxu = u;
+        }
+        std::vector<uint32_t> cls_of(65536, 0);
+        if (n_used > 0 && n_used <= 65535) {
+            if (t.cs && (maxu - minu + 1) <= 63) {
+                t.range_cls = true;
+                t.cls_base = minu;
+                t.cls_span = maxu - minu + 1;
+                t.n_cls = t.cls_span + 1;
+                for (uint32_t u = minu; u <= maxu; u++) cls_of[u] = u - minu + 1;
+            } else {
+                uint32_t c = 0;
+                for (uint32_t u = 0; u < 65536; u++) if (used[u]) cls_of[u] = ++c;
+                t.n_cls = c + 1;
+            }
+            for (uint32_t raw = 0; raw < 65536; raw++) t.cls_lut[raw] = (uint16_t)cls_of[t.lower[raw]];
+            uint64_t entries = (uint64_t)N * t.n_cls;
+            uint32_t eb = (N <= 65536) ? 2 : 4;
+            if (!tunables().force_sparse && entries * eb <= (uint64_t)tunables().dense_budget_bytes &&
+                entries < (1ull << 32)) {
+                t.dense = true;
+                t.entry_bytes = eb;
+                t.dfa.assign(entries, 0);
+                // rows in BFS order: copy the fail row, then overwrite with own goto edges.  Root row: edges or 0.
+                for (uint32_t s : bfs) {
+                    uint32_t n = newid[s];
+                    uint32_t *row = &t.dfa[(uint64_t)n * t.n_cls];
+                    if (s != 0) {
+                        const uint32_t *frow = &t.dfa[(uint64_t)newid[fail[s]] * t.n_cls];
+                        std::memcpy(row, frow, sizeof(uint32_t) * t.n_cls);
+                    }
+                    for (uint32_t ci = child_begin[s]; ci < child_begin[s + 1]; ci++) {
+                        uint32_t c = child_ids[ci];
+                        row[cls_of[nodes[c].unit]] = newid[c];
+                    }
+                }
+            }
+        }
+    }
+    return ACGPU_OK;
+}
+
+} // namespace acgpu

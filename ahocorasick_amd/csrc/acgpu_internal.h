@@ -1,0 +1,88 @@
+// acgpu_internal.h -- shared between the host builder, the C ABI glue and the HIP kernels.
+#pragma once
+#include <cstdint>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/acgpu.h"
+
+namespace acgpu {
+
+constexpr uint64_t kEmptyKey = ~0ull;
+
+// 64-bit finaliser (splitmix) used for the hashed goto edges; identical on host and device.
+#if defined(__HIPCC__)
+#define ACGPU_HD __host__ __device__
+#else
+#define ACGPU_HD
+#endif
+ACGPU_HD inline uint32_t edge_hash(uint64_t key) {
+    key ^= key >> 30;
+    key *= 0xBF58476D1CE4E5B9ull;
+    key ^= key >> 27;
+    key *= 0x94D049BB133111EBull;
+    key ^= key >> 31;
+    return (uint32_t)key;
+}
+ACGPU_HD inline uint64_t edge_key(uint32_t state, uint32_t unit) { return ((uint64_t)state << 16) | (uint64_t)unit; }
+
+// Host-side automaton tables.  State numbering: root = 0; states WITHOUT any output (own or inherited
+// keyword) come first in BFS order, states WITH output after them in BFS order, so that
+// "state >= first_out" is the has-output test and a prefix of the numbering is the shallow, hot part.
+struct HostTables {
+    int mode = 0;
+    bool cs = true;
+    uint32_t n_states = 1, n_cls = 1, n_kw = 0, min_len = 0, max_len = 0;
+    uint32_t first_out = 1;
+    // character classes: class 0 = unit occurs in no keyword.  range_cls (case-sensitive only):
+    // class = unit - cls_base + 1 for unit in [cls_base, cls_base + cls_span), computed arithmetically.
+    bool range_cls = false;
+    uint32_t cls_base = 0, cls_span = 0;
+    std::vector<uint16_t> cls_lut; // 65536: raw unit -> class of its folded unit (dense tables only; a dictionary
+                                   // using > 65535 distinct units is always built sparse and needs no classes)
+    std::vector<uint16_t> lower;   // 65536 fold table (identity when case sensitive)
+    std::vector<uint8_t> wflags;   // WHOLEWORD: bit0 = word[raw], bit1 = word[lower[raw]]
+    bool fold_consistent = true;
+    // per state
+    std::vector<uint32_t> depth, fail, out_len, out_link, out_id, term_id; // term_id: own keyword id or ~0u
+    // dense delta (AC semantics, fail transitions resolved): n_states * n_cls entries
+    bool dense = false;
+    uint32_t entry_bytes = 4;
+    std::vector<uint32_t> dfa;
+    // hashed goto edges keyed by (state, folded unit): open addressing, linear probing
+    std::vector<uint64_t> hkeys;
+    std::vector<uint32_t> hvals;
+    uint32_t hmask = 0;
+    uint64_t n_edges = 0;
+};
+
+int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uint32_t n_kw, int case_sensitive,
+                 const uint16_t *lower_tbl, const uint8_t *wordchar_tbl, HostTables &t, int64_t *bad_keyword);
+
+// Device view handed to kernels by value.
+struct DevTables {
+    const uint16_t *cls_lut;
+    const uint16_t *lower;
+    const uint8_t *wflags;
+    const void *dfa; // uint16_t or uint32_t entries
+    const uint32_t *out_len, *out_link, *out_id, *fail, *depth, *term_id;
+    const uint64_t *hkeys;
+    const uint32_t *hvals;
+    uint32_t hmask;
+    uint32_t n_states, n_cls, first_out, max_len, min_len;
+    uint32_t cls_base, cls_span;
+    int32_t range_cls, cs, dense, entry_bytes;
+    uint32_t lds_entries; // leading dfa entries staged in LDS by the scan kernel
+};
+
+struct Tunables {
+    int64_t chunk_units = 0;      // 0 = auto
+    int64_t blocks_per_cu = 1;
+    int64_t lds_table_bytes = 96 * 1024;
+    int64_t force_sparse = 0;
+    int64_t dense_budget_bytes = 1ll << 30;
+};
+Tunables &tunables();
+
+} // namespace acgpu

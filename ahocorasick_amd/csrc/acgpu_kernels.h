@@ -1,0 +1,49 @@
+// acgpu_kernels.h -- launch wrappers of the gfx950 kernels (implemented in acgpu_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "acgpu_internal.h"
+
+namespace acgpu {
+
+// A match as the scan kernels emit it: 16 bytes, unordered in the scratch buffer.  `rank` is the
+// record's ordinal among the records of its ordering unit ("chunk": a contiguous range of owned
+// positions scanned by one lane), in reference emission order; the finalize pass turns
+// (chunk, rank) into the record's final index through a prefix sum of per-chunk counts.
+struct ScratchRec {
+    int32_t start, end, id;
+    uint32_t rank;
+};
+
+struct ScanLaunch {
+    const uint16_t *d_hay;
+    uint32_t n_units, own_begin, own_end;
+    uint32_t chunk_units; // owned units per chunk (multiple of 8)
+    uint32_t n_chunks;
+    ScratchRec *d_scratch;
+    uint64_t cap;                  // scratch capacity in records
+    unsigned long long *d_counter; // total records emitted (may exceed cap: then nothing past cap is stored)
+    uint32_t *d_chunk_counts;      // n_chunks entries
+    int grid, block;
+    size_t lds_bytes;
+};
+
+// AC-all scan: dense (state x class table, hot rows in LDS) or sparse (hashed goto + fail links).
+hipError_t launch_ac_scan(const DevTables &t, const ScanLaunch &l, hipStream_t stream, const char **kernel_name);
+
+// exclusive prefix sum of d_counts[0..n) into d_offsets (uint64); d_tmp holds >= ceil(n/2048)+1 uint64
+hipError_t launch_exclusive_scan(const uint32_t *d_counts, uint32_t n, uint64_t *d_offsets, uint64_t *d_tmp,
+                                 hipStream_t stream);
+
+// scratch (unordered) -> final records in reference order
+hipError_t launch_permute(const ScratchRec *d_scratch, const unsigned long long *d_counter, uint64_t cap,
+                          const uint64_t *d_offsets, uint32_t own_begin, uint32_t chunk_units, int by_start,
+                          int record_kind, void *d_out, hipStream_t stream);
+
+hipError_t launch_synth_fill(uint16_t *d_dst, uint64_t n, uint64_t start, uint64_t seed, const uint16_t *table,
+                             uint32_t table_len, hipStream_t stream);
+
+int scan_block_threads();
+size_t scan_queue_bytes(int block_threads);
+
+} // namespace acgpu

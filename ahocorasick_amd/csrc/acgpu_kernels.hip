@@ -1,0 +1,373 @@
+// acgpu_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the matching hot path.
+//
+// k_ac_scan   : the reference's per-unit automaton loop (S/AhoCorasickSet.java:204-226) + output
+//               walk (:522-535), re-cast as: one contiguous chunk of the haystack per lane, started at the
+//               root (max_keyword_len-1) units before the chunk so that every match ending inside the
+//               chunk is seen; transition rows of the shallow states staged in LDS; match records
+//               compacted with a wavefront ballot into a per-wave LDS queue and appended to HBM in
+//               batches with one atomic per batch.
+// k_scan_*    : exclusive prefix sum of the per-chunk match counts.
+// k_permute   : scatters the unordered records to their final, reference-ordered slots.
+#include <hip/hip_runtime.h>
+
+#include "acgpu_kernels.h"
+
+namespace acgpu {
+
+constexpr int kWave = 64;
+constexpr int kScanBlock = 1024;                 // 16 waves: one workgroup per CU shares one LDS copy of the hot rows
+constexpr int kQueueCap = 128;                   // records per wave queue
+constexpr int kQueueFlush = kQueueCap - kWave;   // flush when fewer than 64 free slots remain
+
+int scan_block_threads() { return kScanBlock; }
+size_t scan_queue_bytes(int block_threads) { return (size_t)(block_threads / kWave) * kQueueCap * sizeof(ScratchRec); }
+
+__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+
+__device__ __forceinline__ uint64_t lanemask_lt() {
+    uint32_t l = lane_id();
+    return l == 0 ? 0ull : (~0ull >> (64 - l));
+}
+
+// ---- per-wave record queue in LDS ---------------------------------------------------------------------
+struct WaveQueue {
+    ScratchRec *q;  // this wave's kQueueCap slots in LDS
+    uint32_t n;     // wave-uniform fill count
+};
+
+__device__ __forceinline__ void queue_flush(WaveQueue &wq, ScratchRec *scratch, uint64_t cap,
+                                            unsigned long long *counter) {
+    if (wq.n == 0) return;
+    __builtin_amdgcn_wave_barrier();
+    unsigned long long base = 0;
+    if (lane_id() == 0) base = atomicAdd(counter, (unsigned long long)wq.n);
+    base = __shfl(base, 0);
+    for (uint32_t i = lane_id(); i < wq.n; i += kWave) {
+        if (base + i < cap) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(&wq.q[i]);
+            *reinterpret_cast<uint4 *>(&scratch[base + i]) = v;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    wq.n = 0;
+}
+
+// Every lane of the wave must call this (wave-uniform control flow); `t` is the lane's pending output
+// state (0 = nothing to emit).  Walks the compressed output chain: own/inherited longest match first,
+// then each shorter suffix match (S/AhoCorasickSet.java:526-532).
+__device__ __forceinline__ void emit_chain(const DevTables &T, uint32_t t, uint32_t end, uint32_t &rank, WaveQueue &wq,
+                                           ScratchRec *scratch, uint64_t cap, unsigned long long *counter) {
+    for (;;) {
+        const uint64_t m = __ballot(t != 0);
+        if (m == 0) break;
+        if (t != 0) {
+            ScratchRec r;
+            r.end = (int32_t)end;
+            r.start = (int32_t)(end - T.out_len[t]);
+            r.id = (int32_t)T.out_id[t];
+            r.rank = rank++;
+            const uint32_t slot = wq.n + (uint32_t)__popcll(m & lanemask_lt());
+            *reinterpret_cast<uint4 *>(&wq.q[slot]) = *reinterpret_cast<const uint4 *>(&r);
+            t = T.out_link[t];
+        }
+        wq.n += (uint32_t)__popcll(m);
+        if (wq.n > kQueueFlush) queue_flush(wq, scratch, cap, counter);
+    }
+}
+
+// ---- transition functions -------------------------------------------------------------------------------
+template <typename E>
+struct DenseStep {
+    const E *lds;      // first lds_entries entries of the table
+    const E *glob;
+    uint32_t lds_entries, n_cls;
+    const uint16_t *cls_lut;
+    uint32_t cls_base, cls_span;
+    bool range_cls;
+    __device__ __forceinline__ uint32_t operator()(uint32_t s, uint32_t unit) const {
+        uint32_t cls;
+        if (range_cls) {
+            const uint32_t d = unit - cls_base;
+            cls = d < cls_span ? d + 1 : 0;
+        } else {
+            cls = cls_lut[unit];
+        }
+        const uint32_t idx = s * n_cls + cls;
+        return idx < lds_entries ? (uint32_t)lds[idx] : (uint32_t)glob[idx];
+    }
+};
+
+struct SparseStep {
+    const uint64_t *hkeys;
+    const uint32_t *hvals;
+    const uint32_t *fail;
+    const uint16_t *lower;
+    uint32_t hmask;
+    bool cs;
+    __device__ __forceinline__ uint32_t goto_edge(uint32_t s, uint32_t u) const { // ~0u when absent
+        const uint64_t key = edge_key(s, u);
+        uint32_t slot = edge_hash(key) & hmask;
+        for (;;) {
+            const uint64_t k = hkeys[slot];
+            if (k == key) return hvals[slot];
+            if (k == kEmptyKey) return ~0u;
+            slot = (slot + 1) & hmask;
+        }
+    }
+    __device__ __forceinline__ uint32_t operator()(uint32_t s, uint32_t unit) const {
+        const uint32_t u = cs ? unit : (uint32_t)lower[unit];
+        for (;;) { // S/AhoCorasickSet.java:207-221: follow fail links until a node has a transition (root always does)
+            const uint32_t n = goto_edge(s, u);
+            if (n != ~0u) return n;
+            if (s == 0) return 0;
+            s = fail[s];
+        }
+    }
+};
+
+// ---- the scan kernel ------------------------------------------------------------------------------------
+template <typename Step>
+__device__ __forceinline__ void ac_scan_body(const DevTables &T, const ScanLaunch &L, const Step &step, WaveQueue &wq) {
+    const uint32_t halo = T.max_len > 0 ? T.max_len - 1 : 0;
+    const uint32_t lanes_total = gridDim.x * blockDim.x;
+    // all waves run the same number of chunk rounds so that control flow stays wave-uniform
+    const uint32_t rounds = (L.n_chunks + lanes_total - 1) / lanes_total;
+    for (uint32_t round = 0; round < rounds; ++round) {
+        const uint32_t chunk = round * lanes_total + blockIdx.x * blockDim.x + threadIdx.x;
+        const bool valid = chunk < L.n_chunks;
+        const uint32_t cb = valid ? L.own_begin + chunk * L.chunk_units : L.own_end; // first owned unit
+        uint32_t ce = cb + L.chunk_units;                                            // one past the last owned unit
+        if (ce > L.own_end || ce < cb) ce = L.own_end;
+        uint32_t rs = cb > halo ? cb - halo : 0;
+        rs &= ~7u; // 16-byte aligned vector loads; extra warm-up is harmless
+        // wave-uniform trip count: chunk + halo + alignment slack, in 8-unit vectors
+        const uint32_t n_vec = (L.chunk_units + halo + 7 + 7) / 8;
+        uint32_t s = 0;
+        uint32_t rank = 0;
+        for (uint32_t it = 0; it < n_vec; ++it) {
+            const uint32_t v = rs + it * 8;
+            const bool act = valid && v < ce;
+            uint4 w = make_uint4(0, 0, 0, 0);
+            if (act) {
+                if (v + 8 <= L.n_units) {
+                    w = *reinterpret_cast<const uint4 *>(L.d_hay + v);
+                } else { // tail of the buffer: never read past n_units
+                    uint32_t tmp[4] = {0, 0, 0, 0};
+                    for (uint32_t j = 0; j < 8 && v + j < L.n_units; ++j) tmp[j >> 1] |= (uint32_t)L.d_hay[v + j] << (16 * (j & 1));
+                    w = make_uint4(tmp[0], tmp[1], tmp[2], tmp[3]);
+                }
+            }
+            const uint32_t words[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t unit = (words[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+                const uint32_t pos = v + j;
+                s = step(s, unit);
+                const bool has = act && s >= T.first_out && pos >= cb && pos < ce;
+                if (__any(has)) emit_chain(T, has ? s : 0u, pos + 1, rank, wq, L.d_scratch, L.cap, L.d_counter);
+            }
+        }
+        if (valid) L.d_chunk_counts[chunk] = rank;
+    }
+    queue_flush(wq, L.d_scratch, L.cap, L.d_counter);
+}
+
+template <typename E>
+__global__ __launch_bounds__(kScanBlock) void k_ac_scan_dense(DevTables T, ScanLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ScratchRec *queues = reinterpret_cast<ScratchRec *>(smem);
+    E *tab = reinterpret_cast<E *>(smem + (size_t)(kScanBlock / kWave) * kQueueCap * sizeof(ScratchRec));
+    const E *glob = reinterpret_cast<const E *>(T.dfa);
+    for (uint32_t i = threadIdx.x; i < T.lds_entries; i += blockDim.x) tab[i] = glob[i];
+    __syncthreads();
+    WaveQueue wq{queues + (threadIdx.x / kWave) * kQueueCap, 0};
+    DenseStep<E> step{tab, glob, T.lds_entries, T.n_cls, T.cls_lut, T.cls_base, T.cls_span, T.range_cls != 0};
+    ac_scan_body(T, L, step, wq);
+}
+
+__global__ __launch_bounds__(kScanBlock) void k_ac_scan_sparse(DevTables T, ScanLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ScratchRec *queues = reinterpret_cast<ScratchRec *>(smem);
+    WaveQueue wq{queues + (threadIdx.x / kWave) * kQueueCap, 0};
+    SparseStep step{T.hkeys, T.hvals, T.fail, T.lower, T.hmask, T.cs != 0};
+    ac_scan_body(T, L, step, wq);
+}
+
+hipError_t launch_ac_scan(const DevTables &t, const ScanLaunch &l, hipStream_t stream, const char **kernel_name) {
+    hipError_t e;
+    if (t.dense) {
+        if (t.entry_bytes == 2) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ac_scan_dense<uint16_t>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds_bytes);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(k_ac_scan_dense<uint16_t>, dim3(l.grid), dim3(l.block), l.lds_bytes, stream, t, l);
+            if (kernel_name) *kernel_name = "k_ac_scan_dense<unsigned short>";
+        } else {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ac_scan_dense<uint32_t>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds_bytes);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(k_ac_scan_dense<uint32_t>, dim3(l.grid), dim3(l.block), l.lds_bytes, stream, t, l);
+            if (kernel_name) *kernel_name = "k_ac_scan_dense<unsigned int>";
+        }
+    } else {
+        hipLaunchKernelGGL(k_ac_scan_sparse, dim3(l.grid), dim3(l.block), l.lds_bytes, stream, t, l);
+        if (kernel_name) *kernel_name = "k_ac_scan_sparse";
+    }
+    return hipGetLastError();
+}
+
+// ---- exclusive prefix sum of per-chunk counts ------------------------------------------------------------
+constexpr int kScanTile = 2048; // elements per 256-thread block
+
+__device__ __forceinline__ uint64_t wave_inclusive_scan(uint64_t v) {
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const uint64_t o = __shfl_up(v, d);
+        if ((int)lane_id() >= d) v += o;
+    }
+    return v;
+}
+
+// block-wide exclusive scan of one value per thread (256 threads); returns exclusive prefix, total in *total
+__device__ __forceinline__ uint64_t block_exclusive_scan_256(uint64_t v, uint64_t *total) {
+    __shared__ uint64_t wsum[4];
+    const uint64_t inc = wave_inclusive_scan(v);
+    const int w = threadIdx.x / kWave;
+    if (lane_id() == kWave - 1) wsum[w] = inc;
+    __syncthreads();
+    uint64_t base = 0;
+    for (int i = 0; i < w; ++i) base += wsum[i];
+    if (total) *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(256) void k_scan_tile_sums(const uint32_t *counts, uint32_t n, uint64_t *tile_sums) {
+    const uint32_t base = blockIdx.x * kScanTile;
+    uint64_t v = 0;
+    for (int k = 0; k < kScanTile / 256; ++k) {
+        const uint32_t i = base + k * 256 + threadIdx.x;
+        if (i < n) v += counts[i];
+    }
+    uint64_t total;
+    block_exclusive_scan_256(v, &total);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void k_scan_tile_offsets(uint64_t *tile_sums, uint32_t n_tiles) {
+    // single block: exclusive scan in place, 256 tiles per step with a running carry
+    __shared__ uint64_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_tiles; base += 256) {
+        const uint32_t i = base + threadIdx.x;
+        const uint64_t v = i < n_tiles ? tile_sums[i] : 0;
+        uint64_t total;
+        const uint64_t ex = block_exclusive_scan_256(v, &total);
+        const uint64_t carry = carry_s;
+        if (i < n_tiles) tile_sums[i] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tile_sums[n_tiles] = carry_s; // grand total
+}
+
+__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *counts, uint32_t n, const uint64_t *tile_offsets,
+                                                   uint64_t *offsets) {
+    const uint32_t base = blockIdx.x * kScanTile;
+    constexpr int per = kScanTile / 256; // 8 consecutive elements per thread
+    uint32_t c[per];
+    uint64_t v = 0;
+    for (int k = 0; k < per; ++k) {
+        const uint32_t i = base + threadIdx.x * per + k;
+        c[k] = i < n ? counts[i] : 0;
+        v += c[k];
+    }
+    uint64_t ex = block_exclusive_scan_256(v, nullptr) + tile_offsets[blockIdx.x];
+    for (int k = 0; k < per; ++k) {
+        const uint32_t i = base + threadIdx.x * per + k;
+        if (i < n) offsets[i] = ex;
+        ex += c[k];
+    }
+}
+
+hipError_t launch_exclusive_scan(const uint32_t *d_counts, uint32_t n, uint64_t *d_offsets, uint64_t *d_tmp,
+                                 hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const uint32_t n_tiles = (n + kScanTile - 1) / kScanTile;
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(n_tiles), dim3(256), 0, stream, d_counts, n, d_tmp);
+    hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(256), 0, stream, d_tmp, n_tiles);
+    hipLaunchKernelGGL(k_scan_apply, dim3(n_tiles), dim3(256), 0, stream, d_counts, n, (const uint64_t *)d_tmp, d_offsets);
+    return hipGetLastError();
+}
+
+// ---- permutation to reference order ----------------------------------------------------------------------
+template <int REC>
+__global__ __launch_bounds__(256) void k_permute(const ScratchRec *scratch, const unsigned long long *counter, uint64_t cap,
+                                                const uint64_t *offsets, uint32_t own_begin, uint32_t chunk_units,
+                                                int by_start, void *out) {
+    unsigned long long m = *counter;
+    if (m > cap) m = cap; // overflow: the host reports ACGPU_E_OVERFLOW; nothing useful is produced
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint4 raw = *reinterpret_cast<const uint4 *>(&scratch[i]);
+        const int32_t start = (int32_t)raw.x, end = (int32_t)raw.y, id = (int32_t)raw.z;
+        const uint32_t rank = raw.w;
+        // ordering unit: the chunk owning the match's last unit (ALL) or first unit (LONGEST/WHOLEWORD)
+        const uint32_t key = by_start ? (uint32_t)start : (uint32_t)(end - 1);
+        const uint32_t chunk = (key - own_begin) / chunk_units;
+        const uint64_t dst = offsets[chunk] + rank;
+        if (dst >= cap) continue;
+        if (REC == ACGPU_REC_SET) {
+            reinterpret_cast<int2 *>(out)[dst] = make_int2(start, end);
+        } else {
+            int32_t *o = reinterpret_cast<int32_t *>(out) + dst * 3;
+            o[0] = start;
+            o[1] = end;
+            o[2] = id;
+        }
+    }
+}
+
+hipError_t launch_permute(const ScratchRec *d_scratch, const unsigned long long *d_counter, uint64_t cap,
+                          const uint64_t *d_offsets, uint32_t own_begin, uint32_t chunk_units, int by_start,
+                          int record_kind, void *d_out, hipStream_t stream) {
+    const int grid = 2048;
+    if (record_kind == ACGPU_REC_SET)
+        hipLaunchKernelGGL(k_permute<ACGPU_REC_SET>, dim3(grid), dim3(256), 0, stream, d_scratch, d_counter, cap, d_offsets,
+                           own_begin, chunk_units, by_start, d_out);
+    else
+        hipLaunchKernelGGL(k_permute<ACGPU_REC_MAP>, dim3(grid), dim3(256), 0, stream, d_scratch, d_counter, cap, d_offsets,
+                           own_begin, chunk_units, by_start, d_out);
+    return hipGetLastError();
+}
+
+// ---- synthetic haystack generator (ahocorasick_amd/synth.py is its numpy twin) ---------------
+struct SynthTable {
+    uint16_t t[64];
+    uint32_t len;
+};
+
+__global__ __launch_bounds__(256) void k_synth_fill(uint16_t *dst, uint64_t n, uint64_t start, uint64_t seed, SynthTable tab) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t x = seed + (start + i + 1) * 0x9E3779B97F4A7C15ull;
+        uint64_t z = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        const uint32_t k = (uint32_t)(((z >> 32) * (uint64_t)tab.len) >> 32);
+        dst[i] = tab.t[k];
+    }
+}
+
+hipError_t launch_synth_fill(uint16_t *d_dst, uint64_t n, uint64_t start, uint64_t seed, const uint16_t *table,
+                             uint32_t table_len, hipStream_t stream) {
+    if (table_len == 0 || table_len > 64) return hipErrorInvalidValue;
+    SynthTable tab;
+    for (uint32_t i = 0; i < 64; ++i) tab.t[i] = i < table_len ? table[i] : 0;
+    tab.len = table_len;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_synth_fill, dim3(4096), dim3(256), 0, stream, d_dst, n, start, seed, tab);
+    return hipGetLastError();
+}
+
+} // namespace acgpu

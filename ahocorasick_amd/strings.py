@@ -1,0 +1,274 @@
+"""Host-side mirror of the reference's public API (package com.roklenarcic.util.strings) over libacgpu.so.
+
+Same class names, constructor arguments, listener contract and error behaviour as the reference, so the parity
+tests read like the reference's own tests:
+
+  StringSet.match(haystack, SetMatchListener)                  S/StringSet.java:3-5
+  StringMap.match(haystack, MapMatchListener)                  S/StringMap.java:5-9
+  SetMatchListener.match(haystack, start, end) -> bool         S/SetMatchListener.java:6
+  MapMatchListener.match(haystack, start, end, value) -> bool  S/MapMatchListener.java:6
+  AhoCorasickSet(keywords, caseSensitive)                      S/AhoCorasickSet.java:16
+  AhoCorasickMap(keywords, values, caseSensitive)              S/AhoCorasickMap.java:20
+  LongestMatchSet / LongestMatchMap                            S/LongestMatchSet.java:15, S/LongestMatchMap.java
+  WholeWordMatchSet / WholeWordMatchMap (+ wordCharacters[, toggleFlags])   S/WholeWordMatchMap.java:21-53
+
+The matching itself always runs on the GPU through the C ABI (include/acgpu.h); the listener loop runs here, and
+stops at the first listener call that returns False -- which is observationally what the reference does
+(S/AhoCorasickSet.java:223-225).  The Thresholder constructor argument of the reference is accepted and ignored
+(results-neutral node-representation knob).  The streaming match(Readable, ...) overload is out of scope
+(SURVEY.md 8f).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _native as N
+from .unicode_tables import (default_word_chars, java_lower_table, word_chars_from_list, word_chars_with_toggles)
+
+
+class IllegalArgumentException(ValueError):
+    """java.lang.IllegalArgumentException of the WholeWord constructors (S/WholeWordMatchMap.java:263-267)."""
+
+
+def utf16(s):
+    """str -> UTF-16 code units exactly as a Java String holds them (surrogate pairs for supplementary chars)."""
+    if isinstance(s, str):
+        return np.frombuffer(s.encode("utf-16-le", "surrogatepass"), dtype=np.uint16).copy()
+    return np.ascontiguousarray(s, dtype=np.uint16)
+
+
+def _pack(keywords):
+    parts = [utf16(k) if k is not None else np.zeros(0, np.uint16) for k in keywords]
+    off = np.zeros(len(parts) + 1, dtype=np.uint64)
+    if parts:
+        off[1:] = np.cumsum([len(p) for p in parts], dtype=np.uint64)
+    units = np.concatenate(parts) if parts else np.zeros(0, np.uint16)
+    if units.size == 0:
+        units = np.zeros(1, np.uint16)
+    return np.ascontiguousarray(units, dtype=np.uint16), off
+
+
+def _vp(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+class Automaton:
+    """Owns one acgpu_automaton handle."""
+
+    def __init__(self, mode, keywords, case_sensitive, word_chars=None, lower=None):
+        L = N.lib()
+        units, off = _pack(keywords)
+        self.keywords = keywords
+        lower_t = None
+        if not case_sensitive:
+            lower_t = np.ascontiguousarray(java_lower_table() if lower is None else lower, dtype=np.uint16)
+        wc = None if word_chars is None else np.ascontiguousarray(word_chars, dtype=np.uint8)
+        h = ctypes.c_void_p()
+        bad = ctypes.c_int64(-1)
+        rc = L.acgpu_build(mode, _vp(units), _vp(off), len(off) - 1, 1 if case_sensitive else 0, _vp(lower_t), _vp(wc),
+                           ctypes.byref(h), ctypes.byref(bad))
+        if rc == N.E_NONWORD:
+            kw = keywords[bad.value]
+            raise IllegalArgumentException("%s contains non-word characters." % (kw if isinstance(kw, str) else bad.value))
+        N.check(rc, "acgpu_build")
+        self._h = h
+        self.mode = mode
+        self.word_chars = wc
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                N.lib().acgpu_free(h)
+            except Exception:
+                pass
+            self._h = None
+
+    @property
+    def handle(self):
+        return self._h
+
+    def info(self):
+        i = N.Info()
+        N.check(N.lib().acgpu_get_info(self._h, ctypes.byref(i)), "acgpu_get_info")
+        return {f: getattr(i, f) for f, _ in N.Info._fields_}
+
+    def match_host(self, hay_units, with_ids, cap=None):
+        """acgpu_match_u16: haystack in host memory -> (n, 2|3) int32 array in reference call order."""
+        hay = np.ascontiguousarray(hay_units, dtype=np.uint16)
+        n = int(hay.size)
+        kind = N.REC_MAP if with_ids else N.REC_SET
+        cols = kind // 4
+        if cap is None:
+            cap = max(4096, n // 64)
+        buf_in = hay if n else np.zeros(1, np.uint16)
+        while True:
+            out = np.empty((cap, cols), dtype=np.int32)
+            n_out = ctypes.c_uint64(0)
+            rc = N.lib().acgpu_match_u16(self._h, _vp(buf_in), n, kind, _vp(out), cap, ctypes.byref(n_out))
+            if rc == N.E_OVERFLOW:
+                cap = int(n_out.value)
+                continue
+            N.check(rc, "acgpu_match_u16")
+            return out[:n_out.value]
+
+    def match_device(self, d_hay_ptr, n_units, with_ids, d_out_ptr, cap, own=None, text_begin=True, text_end=True,
+                     chain_entry=None, stream=0, profile=False):
+        """acgpu_match_device on raw device pointers.  Returns (n_out, rc, profile_dict|None, chain_exit)."""
+        sh = N.Shard()
+        sh.d_hay = d_hay_ptr
+        sh.n_units = n_units
+        sh.own_begin, sh.own_end = (0, n_units) if own is None else own
+        sh.text_begin = 1 if text_begin else 0
+        sh.text_end = 1 if text_end else 0
+        sh.chain_entry = sh.own_begin if chain_entry is None else chain_entry
+        sh.chain_exit = -1
+        prof = N.Profile() if profile else None
+        n_out = ctypes.c_uint64(0)
+        rc = N.lib().acgpu_match_device(self._h, ctypes.byref(sh), N.REC_MAP if with_ids else N.REC_SET, d_out_ptr, cap,
+                                        ctypes.byref(n_out), ctypes.c_void_p(stream),
+                                        ctypes.byref(prof) if profile else None)
+        pd = None
+        if profile:
+            pd = dict(scan_ms=prof.scan_ms, finalize_ms=prof.finalize_ms, total_ms=prof.total_ms,
+                      scan_units=prof.scan_units, n_matches=prof.n_matches, scan_kernel=prof.scan_kernel.decode())
+        return int(n_out.value), rc, pd, int(sh.chain_exit)
+
+
+# ---- listener plumbing -----------------------------------------------------------------------------------
+
+class SetMatchListener:
+    """S/SetMatchListener.java:3-8"""
+
+    def match(self, haystack, start_position, end_position):
+        raise NotImplementedError
+
+
+class MapMatchListener:
+    """S/MapMatchListener.java:3-8"""
+
+    def match(self, haystack, start_position, end_position, value):
+        raise NotImplementedError
+
+
+def _listener_fn(listener):
+    return listener.match if hasattr(listener, "match") else listener
+
+
+class StringSet:
+    """S/StringSet.java:3-5"""
+    _MODE = None
+
+    def _init(self, keywords, case_sensitive, word_chars=None):
+        self._keywords = list(keywords)
+        self._auto = Automaton(self._MODE, self._keywords, bool(case_sensitive), word_chars=word_chars)
+
+    def match(self, haystack, listener):
+        if haystack is None:
+            raise TypeError("haystack is None")  # the reference throws NullPointerException at haystack.length()
+        recs = self._auto.match_host(utf16(haystack), with_ids=False)
+        fn = _listener_fn(listener)
+        for s, e in recs.tolist():
+            if not fn(haystack, s, e):
+                break
+
+    def find_all(self, haystack):
+        """Convenience (not in the reference): the (n,2) int32 array of (start, end) records."""
+        return self._auto.match_host(utf16(haystack), with_ids=False)
+
+    @property
+    def automaton(self):
+        return self._auto
+
+
+class StringMap:
+    """S/StringMap.java:5-9 (String overload only)"""
+    _MODE = None
+
+    def _init(self, keywords, values, case_sensitive, word_chars=None):
+        # the reference consumes keywords and values pairwise and stops at the shorter one (S/AhoCorasickMap.java:32)
+        pairs = list(zip(keywords, values))
+        self._keywords = [k for k, _ in pairs]
+        self._values = [v for _, v in pairs]
+        self._auto = Automaton(self._MODE, self._keywords, bool(case_sensitive), word_chars=word_chars)
+
+    def match(self, haystack, listener):
+        if haystack is None:
+            raise TypeError("haystack is None")
+        recs = self._auto.match_host(utf16(haystack), with_ids=True)
+        fn = _listener_fn(listener)
+        vals = self._values
+        for s, e, k in recs.tolist():
+            if not fn(haystack, s, e, vals[k]):
+                break
+
+    def find_all(self, haystack):
+        """Convenience (not in the reference): the (n,3) int32 array of (start, end, keyword_index) records."""
+        return self._auto.match_host(utf16(haystack), with_ids=True)
+
+    @property
+    def automaton(self):
+        return self._auto
+
+
+def _word_chars(word_characters, toggle_flags):
+    if word_characters is None:
+        return default_word_chars()
+    if toggle_flags is None:
+        return word_chars_from_list(word_characters)
+    return word_chars_with_toggles(word_characters, toggle_flags)
+
+
+class AhoCorasickSet(StringSet):
+    """S/AhoCorasickSet.java:11-20: every occurrence of every keyword."""
+    _MODE = N.MODE_ALL
+
+    def __init__(self, keywords, case_sensitive, threshold_strategy=None):
+        self._init(keywords, case_sensitive)
+
+
+class AhoCorasickMap(StringMap):
+    """S/AhoCorasickMap.java:14-24"""
+    _MODE = N.MODE_ALL
+
+    def __init__(self, keywords, values, case_sensitive, threshold_strategy=None):
+        self._init(keywords, values, case_sensitive)
+
+
+class LongestMatchSet(StringSet):
+    """S/LongestMatchSet.java:11-19: leftmost-longest, non-overlapping."""
+    _MODE = N.MODE_LONGEST
+
+    def __init__(self, keywords, case_sensitive, threshold_strategy=None):
+        self._init(keywords, case_sensitive)
+
+
+class LongestMatchMap(StringMap):
+    """S/LongestMatchMap.java"""
+    _MODE = N.MODE_LONGEST
+
+    def __init__(self, keywords, values, case_sensitive, threshold_strategy=None):
+        self._init(keywords, values, case_sensitive)
+
+
+class WholeWordMatchSet(StringSet):
+    """S/WholeWordMatchSet.java: keywords that span a whole maximal run of word characters."""
+    _MODE = N.MODE_WHOLEWORD
+
+    def __init__(self, keywords, case_sensitive, word_characters=None, toggle_flags=None, threshold_strategy=None):
+        self._init(keywords, case_sensitive, word_chars=_word_chars(word_characters, toggle_flags))
+
+    def get_word_chars(self):
+        return self._auto.word_chars
+
+
+class WholeWordMatchMap(StringMap):
+    """S/WholeWordMatchMap.java:21-53"""
+    _MODE = N.MODE_WHOLEWORD
+
+    def __init__(self, keywords, values, case_sensitive, word_characters=None, toggle_flags=None,
+                 threshold_strategy=None):
+        self._init(keywords, values, case_sensitive, word_chars=_word_chars(word_characters, toggle_flags))
+
+    def get_word_chars(self):
+        return self._auto.word_chars

@@ -1,0 +1,191 @@
+/*
+ * acgpu.h -- C ABI of the MI355X-native multi-pattern matcher (libacgpu.so).
+ *
+ * This is the drop-in boundary for the hot path of RokLenarcic/AhoCorasick:
+ * the reference has no FFI seam of its own -- its seam is the Java interface
+ * pair StringSet / StringMap (S/StringSet.java:3-5, S/StringMap.java:5-9) and
+ * the listeners (S/SetMatchListener.java:6, S/MapMatchListener.java:6).  A Java
+ * facade implementing those interfaces binds exactly the entry points below
+ * through JNI (INTEGRATION.md shows the stub); tests and bench.py bind them
+ * through ctypes.  S/ = src/main/java/com/roklenarcic/util/strings/.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no C++ or torch types cross this boundary;
+ *  - every function returns ACGPU_OK (0) or a negative ACGPU_E_* code; nothing
+ *    throws across the ABI;
+ *  - keywords and haystacks are UTF-16 code units exactly as a Java String holds
+ *    them; match positions are code-unit indices, `end` exclusive
+ *    (R/README.md:69);
+ *  - an automaton is immutable after acgpu_build and may be shared by threads;
+ *    concurrent matches on one automaton are safe (they serialise on its
+ *    per-device scratch pool);
+ *  - there is NO CPU matching backend: every acgpu_match_* call needs a HIP
+ *    device and fails with ACGPU_E_NODEVICE / ACGPU_E_HIP without one.
+ */
+#ifndef ACGPU_H
+#define ACGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACGPU_ABI_VERSION 1
+
+/* error codes */
+#define ACGPU_OK 0
+#define ACGPU_E_INVALID (-1)     /* bad argument (NULL, misaligned device pointer, bad range ...)   */
+#define ACGPU_E_NONWORD (-2)     /* java.lang.IllegalArgumentException of the WholeWord ctors:
+                                    "<keyword> contains non-word characters."
+                                    (S/WholeWordMatchMap.java:263-267, S/WholeWordMatchSet.java init) */
+#define ACGPU_E_NOMEM (-3)       /* host or device allocation failed                                */
+#define ACGPU_E_OVERFLOW (-4)    /* output capacity too small; *n_out holds the required record count */
+#define ACGPU_E_HIP (-5)         /* HIP runtime error; see acgpu_last_hip_error()                    */
+#define ACGPU_E_NODEVICE (-6)    /* no HIP device visible                                            */
+#define ACGPU_E_UNSUPPORTED (-7) /* combination not implemented by this build                        */
+
+/* matcher families (which reference class an automaton replaces) */
+#define ACGPU_MODE_ALL 0       /* AhoCorasickSet / AhoCorasickMap      S/AhoCorasickSet.java:193-252, S/AhoCorasickMap.java:277-336 */
+#define ACGPU_MODE_LONGEST 1   /* LongestMatchSet / LongestMatchMap    S/LongestMatchSet.java:192-265, S/LongestMatchMap.java:288-360 */
+#define ACGPU_MODE_WHOLEWORD 2 /* WholeWordMatchSet / WholeWordMatchMap S/WholeWordMatchSet.java:47-132, S/WholeWordMatchMap.java:155-240 */
+
+/* output record layouts */
+#define ACGPU_REC_SET 8  /* acgpu_set_match: what SetMatchListener.match(haystack, start, end) receives */
+#define ACGPU_REC_MAP 12 /* acgpu_map_match: MapMatchListener.match(haystack, start, end, value);
+                            keyword_id indexes the caller's value array                             */
+
+typedef struct acgpu_set_match {
+    int32_t start, end;
+} acgpu_set_match;
+
+typedef struct acgpu_map_match {
+    int32_t start, end;
+    int32_t keyword_id; /* index (in the acgpu_build input) of the LAST keyword equal to the matched
+                           (folded) string: reproduces "last value wins", S/AhoCorasickMap.java:49-50 */
+} acgpu_map_match;
+
+typedef struct acgpu_automaton acgpu_automaton;
+
+/*
+ * Replaces the constructors: AhoCorasickSet(Iterable<String>, boolean[, Thresholder])
+ * S/AhoCorasickSet.java:16-191, AhoCorasickMap(...) S/AhoCorasickMap.java:20-206,
+ * LongestMatchSet(...) S/LongestMatchSet.java:15-190, WholeWordMatchMap/Set(...) + init
+ * S/WholeWordMatchMap.java:21-53,246-323.
+ *
+ *  kw_units/kw_off : keyword i is kw_units[kw_off[i] .. kw_off[i+1]).  A null or empty Java
+ *                    keyword is an empty range (both are skipped, S/AhoCorasickSet.java:27).
+ *  case_sensitive  : 0 => every keyword unit and haystack unit is mapped through lower_tbl
+ *                    (Character.toLowerCase(char), S/AhoCorasickSet.java:33,229).
+ *  lower_tbl       : 65536 entries, required when case_sensitive == 0 (the caller's JVM fills
+ *                    it with its own Character.toLowerCase so that parity holds for that JVM).
+ *  wordchar_tbl    : 65536 flags, required for ACGPU_MODE_WHOLEWORD
+ *                    (WordCharacters.generateWordCharsFlags*, S/WordCharacters.java:6-39).
+ *  bad_keyword     : on ACGPU_E_NONWORD receives the index of the offending keyword (may be NULL).
+ * The Thresholder argument of the reference constructors is a results-neutral memory/speed
+ * knob of its node representation and has no counterpart here.
+ */
+int acgpu_build(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uint32_t n_kw, int case_sensitive,
+                const uint16_t *lower_tbl, const uint8_t *wordchar_tbl, acgpu_automaton **out, int64_t *bad_keyword);
+
+void acgpu_free(acgpu_automaton *a);
+
+typedef struct acgpu_info {
+    uint32_t abi_version;
+    uint32_t mode;
+    uint32_t case_sensitive;
+    uint32_t n_states;       /* trie nodes incl. root                                   */
+    uint32_t n_classes;      /* character classes incl. class 0 = "in no keyword"       */
+    uint32_t n_keywords;     /* distinct non-empty (folded, trimmed) keywords           */
+    uint32_t min_keyword_len;
+    uint32_t max_keyword_len;
+    uint32_t dense;          /* 1: dense state x class table, 0: hashed edges + fail links */
+    uint32_t entry_bytes;    /* 2 or 4                                                   */
+    uint64_t table_bytes;    /* bytes of the transition structure resident in HBM        */
+    uint32_t lds_states;     /* states whose rows are staged in LDS by the scan kernel   */
+    uint32_t fold_consistent;/* WHOLEWORD: wordchar[c] == wordchar[lower[c]] for all c   */
+} acgpu_info;
+
+int acgpu_get_info(const acgpu_automaton *a, acgpu_info *info);
+
+/*
+ * Replaces StringSet.match(String, SetMatchListener) / StringMap.match(String, MapMatchListener)
+ * for a haystack in HOST memory: copies it to the current HIP device, scans, and returns every
+ * record the reference would have passed to its listener, in the reference's call order
+ * (ALL: end ascending then start ascending, S/AhoCorasickSet.java:522-535; LONGEST and
+ * WHOLEWORD: position order).  The facade then runs the listener loop itself, stopping at the
+ * first `false` -- observationally identical to the reference's early stop
+ * (S/AhoCorasickSet.java:223-225).
+ *  record_kind : ACGPU_REC_SET or ACGPU_REC_MAP (layout of `out`).
+ *  cap         : capacity of `out` in records.  On ACGPU_E_OVERFLOW nothing useful is in `out`
+ *                and *n_out is the capacity to retry with.
+ *  n_units     : < 2^31 (Java String limit).
+ */
+int acgpu_match_u16(const acgpu_automaton *a, const uint16_t *haystack, uint64_t n_units, int record_kind, void *out,
+                    uint64_t cap, uint64_t *n_out);
+
+/*
+ * Device-resident form of the same call, and the unit of multi-GPU sharding.
+ * The buffer holds an owned range plus halos; positions in the records are relative to the
+ * buffer start.  Ownership: ALL -> a match belongs to the shard that owns its LAST unit (left
+ * halo >= max_keyword_len-1 units needed); WHOLEWORD -> to the shard that owns the first unit of
+ * the word (left halo 1 unit, right halo up to the end of the word or max_keyword_len+1 units);
+ * LONGEST -> to the shard that owns its first unit, given the greedy chain's entry position
+ * (right halo >= max_keyword_len-1 units).
+ */
+typedef struct acgpu_shard {
+    const uint16_t *d_hay; /* device pointer, 16-byte aligned                                   */
+    uint64_t n_units;      /* units in the buffer, < 2^31                                        */
+    uint64_t own_begin;    /* owned range [own_begin, own_end) inside the buffer                 */
+    uint64_t own_end;
+    int32_t text_begin;    /* 1: buffer unit 0 is the first unit of the whole haystack           */
+    int32_t text_end;      /* 1: buffer unit n_units-1 is the last unit of the whole haystack    */
+    int64_t chain_entry;   /* LONGEST in : first greedy-chain position >= own_begin (own_begin on the first shard) */
+    int64_t chain_exit;    /* LONGEST out: first greedy-chain position >= own_end                */
+} acgpu_shard;
+
+/* optional per-call timing of the device work, measured with HIP events on `stream` */
+typedef struct acgpu_profile {
+    float scan_ms;     /* the dominant kernel: one pass over the haystack units                  */
+    float finalize_ms; /* ordering of records (prefix sum of per-chunk counts + permutation)     */
+    float total_ms;    /* first launch to last launch of the call                                */
+    uint64_t scan_units;   /* haystack units the scan kernel processed (owned + halo)            */
+    uint64_t n_matches;
+    char scan_kernel[64];  /* name of the dominant kernel as it appears in rocprofv3             */
+} acgpu_profile;
+
+/*
+ *  d_out  : device pointer to cap records of record_kind (16-byte aligned).
+ *  stream : hipStream_t (NULL = the default stream).  The call enqueues its kernels on `stream`
+ *           and synchronises that stream once, to read back the record count.
+ *  prof   : NULL, or receives HIP-event timings of this call.
+ */
+int acgpu_match_device(const acgpu_automaton *a, acgpu_shard *shard, int record_kind, void *d_out, uint64_t cap,
+                       uint64_t *n_out, void *stream, acgpu_profile *prof);
+
+/*
+ * Synthetic haystack generator of the benchmark: unit i of the stream is
+ * table[((z_i >> 32) * table_len) >> 32] with z_i = SplitMix64 output for counter
+ * start_index + i of `seed` (see ahocorasick_amd/synth.py).  d_dst: device pointer.
+ */
+int acgpu_synth_fill(uint16_t *d_dst, uint64_t n_units, uint64_t start_index, uint64_t seed, const uint16_t *table,
+                     uint32_t table_len, void *stream);
+
+/* tuning knobs (process-wide; mainly for tests and benchmarks).  name: "chunk_units",
+ * "blocks_per_cu", "lds_table_bytes", "force_sparse", "dense_budget_bytes".  Returns the previous value. */
+int64_t acgpu_set_tunable(const char *name, int64_t value);
+
+const char *acgpu_strerror(int code);
+int acgpu_last_hip_error(void);  /* hipError_t of the last ACGPU_E_HIP on this thread */
+uint32_t acgpu_abi_version(void);
+
+/* Test hook: copies the host-side tables of an automaton (NULL pointers are skipped).  Lets
+ * CPU-only tests check the builder without a device.  dfa receives n_states*n_classes uint32
+ * entries when info.dense, per-state arrays receive n_states entries. */
+int acgpu_debug_tables(const acgpu_automaton *a, uint16_t *cls_lut /*65536*/, uint32_t *dfa, uint32_t *out_len,
+                       uint32_t *out_link, uint32_t *out_id, uint32_t *depth, uint32_t *first_out_state);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACGPU_H */

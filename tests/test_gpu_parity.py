@@ -1,0 +1,232 @@
+"""GPU parity tests: the HIP path, called through the C ABI (include/acgpu.h), against the CPU oracle
+(oracle/ac_oracle.c) -- bit-exact records in the reference's listener-call order."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from ahocorasick_amd import (AhoCorasickMap, AhoCorasickSet, IllegalArgumentException, LongestMatchMap, LongestMatchSet,
+                             WholeWordMatchMap, WholeWordMatchSet)
+from ahocorasick_amd import _native as N
+from ahocorasick_amd import synth
+from ahocorasick_amd.strings import Automaton, utf16
+from oracle.oracle import FAM_AC, FAM_LONGEST, FAM_WHOLEWORD, Oracle
+from tests.helpers import LOWER, WORD, fixture_inputs, rand_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _reset_tunables():
+    yield
+    for k, v in [("chunk_units", 0), ("blocks_per_cu", 1), ("lds_table_bytes", 96 * 1024), ("force_sparse", 0)]:
+        N.set_tunable(k, v)
+
+
+def _ids(n):
+    return list(range(n))
+
+
+# ---- the reference's own deterministic scenarios -----------------------------------------------------------
+
+def test_fixtures_ahocorasick(fixtures):
+    for fx in fixtures:
+        hay, kws = fixture_inputs(fx)
+        m = AhoCorasickMap(kws, _ids(len(kws)), True)
+        assert m.find_all(hay).tolist() == fx["AC"], fx["name"]
+        s = AhoCorasickSet(kws, True)
+        assert s.find_all(hay).tolist() == [r[:2] for r in fx["AC"]], fx["name"]
+
+
+def test_listener_contract_and_early_stop():
+    # SetTest-style counting listener + membership assertion (T/SetTest.java:156-165), and early stop (R/README.md:70)
+    kws = ["a", "aa", "aaa", "aaaa"]
+    hay = "aaaa"
+    s = AhoCorasickSet(kws, True)
+    seen = []
+
+    def listener(h, start, end):
+        assert h[start:end] in kws
+        seen.append((start, end))
+        return True
+
+    s.match(hay, listener)
+    assert len(seen) == 10
+    full = Oracle(FAM_AC, kws).match(hay)
+    for k in range(1, 11):
+        got = []
+        s.match(hay, lambda h, a, b: (got.append((a, b)) or len(got) < k))
+        assert got == [tuple(r[:2]) for r in Oracle(FAM_AC, kws).match(hay, stop_after=k).tolist()]
+    assert [tuple(r[:2]) for r in full.tolist()] == seen
+    # Map: values are delivered, last duplicate wins (S/AhoCorasickMap.java:49-50)
+    m = AhoCorasickMap(["ab", "x", "ab"], ["first", "x", "last"], True)
+    vals = []
+    m.match("zabz", lambda h, a, b, v: vals.append((a, b, v)) or True)
+    assert vals == [(1, 3, "last")]
+    with pytest.raises(TypeError):
+        s.match(None, listener)
+
+
+# ---- seeded fuzz against the oracle --------------------------------------------------------------------------
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_ahocorasick_small_alphabets(seed):
+    rng = np.random.default_rng(seed)
+    alpha = [ord(c) for c in "ab"] if seed % 2 == 0 else [ord(c) for c in "abcAB"] + [0x00E9, 0x00C9, 0x0130]
+    for it in range(12):
+        hay, kws = rand_case(rng, alpha, int(rng.integers(1, 20)), int(rng.integers(1, 9)), int(rng.integers(0, 5000)))
+        for cs in (True, False):
+            want = Oracle(FAM_AC, kws, case_sensitive=cs, lower=LOWER).match(hay).tolist()
+            got = AhoCorasickMap(kws, _ids(len(kws)), cs).find_all(hay).tolist()
+            assert got == want, (seed, it, cs)
+
+
+@pytest.mark.parametrize("chunk_units,lds_bytes,sparse", [(8, 96 * 1024, 0), (64, 0, 0), (256, 1024, 0), (64, 0, 1), (0, 0, 1)])
+def test_chunking_lds_and_sparse_variants_agree(chunk_units, lds_bytes, sparse):
+    # every lane starts (max_len-1) units before its chunk: tiny chunks stress the halo logic; lds_bytes=0 forces
+    # every row through HBM/L2; force_sparse exercises the hashed goto + fail-link path
+    N.set_tunable("chunk_units", chunk_units)
+    N.set_tunable("lds_table_bytes", lds_bytes)
+    N.set_tunable("force_sparse", sparse)
+    rng = np.random.default_rng(42)
+    for alpha in ([ord(c) for c in "ab"], list(range(ord("a"), ord("z") + 1)), list(range(0x4E00, 0x4E40))):
+        hay, kws = rand_case(rng, alpha, 40, 7, 20000)
+        want = Oracle(FAM_AC, kws).match(hay).tolist()
+        got = AhoCorasickMap(kws, _ids(len(kws)), True).find_all(hay).tolist()
+        assert got == want
+
+
+def test_full_alphabet_dictionary_sparse():
+    # T/SetTest.java:72-79 (65536 single-unit keywords) + an extended haystack
+    kws = [np.array([i], dtype=np.uint16) for i in range(65536)]
+    m = AhoCorasickMap(kws, _ids(65536), True)
+    assert m.automaton.info()["dense"] == 0
+    hay = np.array([0, 0xFFFF, 0xFFFE, 0xD800, 0x41], dtype=np.uint16)
+    assert m.find_all(hay).tolist() == [[i, i + 1, int(u)] for i, u in enumerate(hay)]
+
+
+def test_random_wide_alphabet_like_reference_full_random():
+    # T/SetTest.java:81-89 uses unseeded 2-3 unit keywords over the whole BMP; seeded here
+    rng = np.random.default_rng(7)
+    kws = []
+    for _ in range(20000):
+        ln = int(rng.integers(2, 4))
+        u = np.where(rng.random(ln) < 0.5, rng.integers(0, 256, ln), rng.integers(0, 65536, ln)).astype(np.uint16)
+        kws.append(u)
+    hay = utf16("The quick red fox, jumps over the lazy brown dog.")
+    hay = np.concatenate([hay, kws[5], hay, kws[77], kws[5][:1]])
+    want = Oracle(FAM_AC, kws).match(hay).tolist()
+    assert AhoCorasickMap(kws, _ids(len(kws)), True).find_all(hay).tolist() == want
+
+
+def test_overflow_protocol():
+    a = Automaton(N.MODE_ALL, ["a", "aa"], True)
+    hay = utf16("a" * 1000)
+    out = np.empty((10, 3), np.int32)
+    n_out = ctypes.c_uint64(0)
+    rc = N.lib().acgpu_match_u16(a.handle, hay.ctypes.data_as(ctypes.c_void_p), hay.size, N.REC_MAP,
+                                 out.ctypes.data_as(ctypes.c_void_p), 10, ctypes.byref(n_out))
+    assert rc == N.E_OVERFLOW and n_out.value == 1999
+    assert len(a.match_host(hay, True, cap=16)) == 1999
+
+
+# ---- BASELINE.json config 1 (plumbing size) end to end -------------------------------------------------------
+
+def test_config_c1_bit_exact():
+    c = synth.CONFIGS["C1"]
+    kws = synth.config_keywords("C1")
+    hay = synth.haystack(c["hay_seed"], c["n_units"])
+    want = Oracle(FAM_AC, kws).match(hay)
+    got = AhoCorasickSet(kws, True).find_all(hay)
+    assert got.shape == want[:, :2].shape and (got == want[:, :2]).all()
+    gotm = AhoCorasickMap(kws, _ids(len(kws)), True).find_all(hay)
+    assert (gotm == want).all()
+
+
+# ---- device-resident entry point, shards and halos -------------------------------------------------------------
+
+def _dev_match(a, d_hay, n, with_ids, cap, **kw):
+    import torch
+    cols = 3 if with_ids else 2
+    d_out = torch.empty((max(cap, 1), cols), dtype=torch.int32, device="cuda")
+    n_out, rc, prof, _ = a.match_device(d_hay.data_ptr(), n, with_ids, d_out.data_ptr(), cap,
+                                        stream=torch.cuda.current_stream().cuda_stream, **kw)
+    assert rc == N.OK, rc
+    return d_out[:n_out].cpu().numpy(), prof
+
+
+def test_synth_fill_matches_numpy_generator():
+    import torch
+    n = 100003
+    for table, seed, start in ((synth.ALPHA_LOWER, 2002, 0), (synth.ALPHA_AB_75, 2004, 12345)):
+        d = torch.empty(n, dtype=torch.int16, device="cuda")
+        tab = np.ascontiguousarray(table, dtype=np.uint16)
+        N.check(N.lib().acgpu_synth_fill(d.data_ptr(), n, start, seed, tab.ctypes.data_as(ctypes.c_void_p), len(tab), None),
+                "synth")
+        torch.cuda.synchronize()
+        got = d.cpu().numpy().view(np.uint16)
+        assert (got == synth.haystack(seed, n, table, start=start)).all()
+
+
+def test_device_entry_and_shard_split_invariance():
+    import torch
+    kws = synth.random_keywords(11, 300, 2, 9)
+    hay = synth.haystack(77, 300000)
+    a = Automaton(N.MODE_ALL, kws, True)
+    want = Oracle(FAM_AC, kws).match(hay)
+    d_hay = torch.from_numpy(hay.view(np.int16)).cuda()
+    got, prof = _dev_match(a, d_hay, hay.size, True, len(want) + 10, profile=True)
+    assert (got == want).all() and prof["n_matches"] == len(want) and prof["scan_ms"] > 0
+    # split into 3 shards owning [0,a) [a,b) [b,n): each sees the whole buffer but owns a slice; concatenation == whole
+    cuts = [0, 99991, 200003, hay.size]
+    parts = []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        p, _ = _dev_match(a, d_hay, hay.size, True, len(want) + 10, own=(lo, hi))
+        parts.append(p)
+    assert (np.concatenate(parts) == want).all()
+    # a shard handed only its own slice + left halo (what a multi-GPU rank holds); positions are buffer-relative
+    halo = a.info()["max_keyword_len"] - 1
+    lo, hi = cuts[1], cuts[2]
+    base = (lo - halo) // 8 * 8  # keep the device pointer 16-byte aligned
+    sub = d_hay[base:hi].clone()
+    p, _ = _dev_match(a, sub, hi - base, True, len(want) + 10, own=(lo - base, hi - base), text_begin=False, text_end=False)
+    p[:, :2] += base
+    assert (p == parts[1]).all()
+
+
+# ---- BASELINE.json config 2 at FULL size: size-independent properties -------------------------------------------
+
+def test_config_c2_full_size_properties():
+    import torch
+    c = synth.CONFIGS["C2"]
+    kws = synth.config_keywords("C2")
+    n = c["n_units"]
+    a = Automaton(N.MODE_ALL, kws, True)
+    d_hay = torch.empty(n, dtype=torch.int16, device="cuda")
+    tab = np.ascontiguousarray(synth.ALPHA_LOWER)
+    N.check(N.lib().acgpu_synth_fill(d_hay.data_ptr(), n, 0, c["hay_seed"], tab.ctypes.data_as(ctypes.c_void_p), len(tab),
+                                     None), "synth")
+    cap = 4_000_000
+    got, prof = _dev_match(a, d_hay, n, True, cap, profile=True)
+    m = len(got)
+    assert 1_300_000 < m < 1_550_000  # expected ~2.64e-3 matches per unit
+    # (1) reference order: end ascending, ties by start ascending
+    end, start = got[:, 1].astype(np.int64), got[:, 0].astype(np.int64)
+    key = end * (1 << 32) + start
+    assert (np.diff(key) > 0).all()
+    # (2) every record is a true occurrence of the keyword it names (sampled: 20000 records + first/last 1000)
+    idx = np.unique(np.concatenate([np.arange(1000), np.arange(m - 1000, m),
+                                    np.random.default_rng(0).integers(0, m, 20000)]))
+    for i in idx.tolist():
+        s, e, k = got[i].tolist()
+        seg = synth.haystack(c["hay_seed"], e - s, start=s)
+        assert (seg == kws[k]).all()
+    # (3) the prefix of the result equals the oracle on the first 2^22 units (bit-exact, incl. order)
+    pre = 1 << 22
+    want = Oracle(FAM_AC, kws).match(synth.haystack(c["hay_seed"], pre))
+    assert (got[:len(want)] == want).all() and got[len(want), 1] > pre
+    # (4) a different chunking / no LDS residency gives the identical record stream (checksum of checksums)
+    N.set_tunable("chunk_units", 1000)
+    N.set_tunable("lds_table_bytes", 0)
+    got2, _ = _dev_match(a, d_hay, n, True, cap)
+    assert got2.shape == got.shape and (got2 == got).all()

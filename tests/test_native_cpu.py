@@ -1,0 +1,109 @@
+"""CPU-side checks of the native library: it loads, exports every symbol include/acgpu.h declares, the host
+builder's tables reproduce the oracle when *simulated in this test* (test code -- the product has no CPU
+matcher), and match calls fail loudly without a device."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from ahocorasick_amd import _native as N
+from ahocorasick_amd.strings import Automaton, IllegalArgumentException, utf16
+from oracle.oracle import FAM_AC, Oracle
+from tests.helpers import LOWER, WORD, fixture_inputs, rand_case
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "acgpu.h")).read()
+    declared = set(re.findall(r"\b(acgpu_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(N.SYMBOLS), declared ^ set(N.SYMBOLS)
+    L = ctypes.CDLL(N.LIB_PATH)
+    for s in declared:
+        assert hasattr(L, s), s
+    assert N.lib().acgpu_abi_version() == 1
+
+
+def _tables(a):
+    info = a.info()
+    ns, nc = info["n_states"], info["n_classes"]
+    cls = np.zeros(65536, np.uint16)
+    dfa = np.zeros(ns * nc, np.uint32) if info["dense"] else None
+    out_len, out_link, out_id, depth = (np.zeros(ns, np.uint32) for _ in range(4))
+    first = ctypes.c_uint32(0)
+    vp = lambda x: x.ctypes.data_as(ctypes.c_void_p) if x is not None else None
+    N.check(N.lib().acgpu_debug_tables(a.handle, vp(cls), vp(dfa), vp(out_len), vp(out_link), vp(out_id), vp(depth),
+                                       ctypes.byref(first)), "debug_tables")
+    return info, cls, (dfa.reshape(ns, nc) if dfa is not None else None), out_len, out_link, out_id, depth, first.value
+
+
+def _simulate_all(a, hay):
+    """Test-only DFA walk over the builder's tables."""
+    info, cls, dfa, out_len, out_link, out_id, depth, first = _tables(a)
+    s = 0
+    out = []
+    for i, u in enumerate(hay.tolist()):
+        s = int(dfa[s, cls[u]])
+        if s >= first:
+            t = s
+            while t:
+                out.append([i + 1 - int(out_len[t]), i + 1, int(out_id[t])])
+                t = int(out_link[t])
+    return out
+
+
+def test_builder_tables_reproduce_oracle_on_fixtures(fixtures):
+    for fx in fixtures:
+        if "keywords_gen" in fx:
+            continue  # 65536 classes: built sparse, covered on the GPU
+        hay, kws = fixture_inputs(fx)
+        a = Automaton(N.MODE_ALL, kws, True)
+        assert _simulate_all(a, hay) == fx["AC"], fx["name"]
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_builder_tables_fuzz(seed):
+    rng = np.random.default_rng(seed)
+    alpha = [ord(c) for c in "abcAB"] + [0x00E9, 0x00C9]
+    for _ in range(20):
+        hay, kws = rand_case(rng, alpha, int(rng.integers(1, 15)), 6, int(rng.integers(0, 300)))
+        for cs in (True, False):
+            a = Automaton(N.MODE_ALL, kws, cs)
+            want = Oracle(FAM_AC, kws, case_sensitive=cs, lower=LOWER).match(hay).tolist()
+            assert _simulate_all(a, hay) == want
+
+
+def test_builder_numbering_and_info():
+    a = Automaton(N.MODE_ALL, ["he", "she", "his", "hers"], True)
+    info, cls, dfa, out_len, out_link, out_id, depth, first = _tables(a)
+    assert info["n_states"] == 10 and info["n_keywords"] == 4
+    assert info["min_keyword_len"] == 2 and info["max_keyword_len"] == 4
+    assert info["dense"] == 1 and info["entry_bytes"] == 2
+    # no-output states first, output states after: the has-output test is "state >= first"
+    assert (out_len[:first] == 0).all() and (out_len[first:] > 0).all()
+    assert depth[0] == 0 and (np.diff(depth[:first]) >= 0).all()
+
+
+def test_wholeword_ctor_rejects_nonword_keywords():
+    with pytest.raises(IllegalArgumentException):
+        Automaton(N.MODE_WHOLEWORD, ["A B"], True, word_chars=WORD)
+    a = Automaton(N.MODE_WHOLEWORD, [" abc,", "", None, "de"], True, word_chars=WORD)
+    assert a.info()["n_keywords"] == 2 and a.info()["fold_consistent"] == 1
+
+
+def test_full_alphabet_dictionary_builds_sparse():
+    kws = [np.array([i], dtype=np.uint16) for i in range(65536)]
+    a = Automaton(N.MODE_ALL, kws, True)
+    info = a.info()
+    assert info["n_states"] == 65537 and info["dense"] == 0
+
+
+def test_match_fails_loudly_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a device is present")
+    a = Automaton(N.MODE_ALL, ["ab"], True)
+    with pytest.raises(N.AcgpuError):
+        a.match_host(utf16("zabz"), with_ids=True)
