@@ -53,6 +53,13 @@ def lib():
             raise ImportError(
                 "ahocorasick_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C ahocorasick_amd/csrc`).  There is no CPU fallback." % LIB_PATH)
+        try:
+            # PyTorch-ROCm bundles its own libamdhip64.so (same SONAME, libamdhip64.so.7).  Loading torch first makes
+            # libacgpu.so bind to that copy; the other order would put two HIP/HSA runtimes in one process and the
+            # second one finds no GPU.  Without torch (JNI / plain C callers) libacgpu.so uses /opt/rocm's runtime.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         vp, u64, i64, u32, ci = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int64, ctypes.c_uint32, ctypes.c_int
         L.acgpu_build.restype = ci

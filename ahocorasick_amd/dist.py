@@ -1,0 +1,184 @@
+"""Multi-GPU sharding of one long haystack: one process per GPU (torch.distributed; backend "nccl" is RCCL over
+xGMI on ROCm, "gloo" in the CPU tests).
+
+The AhoCorasick (all-matches) path shards naturally: rank g owns a contiguous range of the
+haystack, needs the (max_keyword_len-1) units before it (left halo, received from rank g-1), starts at the root,
+and keeps the matches whose LAST unit it owns.  Rank-local order is the reference's order, so the concatenation
+of the per-rank buffers by rank is the reference's listener-call order for the whole haystack.  The only data
+exchange steps are the tiny halo send/recv and the all-gather of the per-shard match buffers (counts first, then
+record buffers padded to the largest count); positions stay shard-local int32 in the gathered buffer and become
+global int64 positions by adding base[g] = g * units_per_rank (global_records()).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def _world(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def round_up8(v):
+    return (int(v) + 7) // 8 * 8
+
+
+class ShardBuffer:
+    """[ pad | own units ] on one device: `pad` = left-halo room rounded up to 8 units so that both the buffer and
+    the owned range start 16-byte aligned (the scan kernel loads 16 bytes per lane)."""
+
+    def __init__(self, n_units, halo, device):
+        self.n_units = int(n_units)
+        self.halo = int(halo)
+        self.pad = round_up8(halo)
+        self.buf = torch.zeros(self.pad + self.n_units, dtype=torch.int16, device=device)
+
+    @property
+    def own(self):
+        return self.buf[self.pad:]
+
+    def halo_view(self):
+        return self.buf[self.pad - self.halo:self.pad]
+
+    def tail_view(self):
+        return self.buf[self.pad + self.n_units - self.halo:]
+
+
+def exchange_halo(sb, group=None):
+    """rank g sends its last `halo` units to rank g+1 and receives its left halo from rank g-1."""
+    rank, world = _world(group)
+    if world == 1 or sb.halo == 0:
+        return
+    ops = []
+    recv = None
+    if rank + 1 < world:
+        ops.append(dist.P2POp(dist.isend, sb.tail_view().contiguous(), rank + 1, group))
+    if rank > 0:
+        recv = torch.empty(sb.halo, dtype=torch.int16, device=sb.buf.device)
+        ops.append(dist.P2POp(dist.irecv, recv, rank - 1, group))
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+    if recv is not None:
+        sb.halo_view().copy_(recv)
+
+
+def allgather_matches(local, n_local, group=None):
+    """local: (cap, cols) int32 record buffer of which the first n_local rows are valid.
+    Returns (gathered (world, max_n, cols) int32, counts (world,) int64 on host)."""
+    rank, world = _world(group)
+    if world == 1:
+        return local[:n_local].unsqueeze(0), np.array([n_local], dtype=np.int64)
+    dev = local.device
+    cnt = torch.tensor([n_local], dtype=torch.int64, device=dev)
+    counts = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts, cnt, group=group)
+    counts_h = counts.cpu().numpy()
+    max_n = int(counts_h.max())
+    cols = local.shape[1]
+    if max_n == 0:
+        return torch.empty((world, 0, cols), dtype=torch.int32, device=dev), counts_h
+    if local.shape[0] >= max_n:
+        send = local[:max_n]
+    else:
+        send = torch.zeros((max_n, cols), dtype=torch.int32, device=dev)
+        send[:n_local] = local[:n_local]
+    out = torch.empty((world, max_n, cols), dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(out.view(-1), send.contiguous().view(-1), group=group)
+    return out, counts_h
+
+
+def global_records(gathered, counts, units_per_rank):
+    """Concatenate per-rank records in rank order with global int64 positions (reference order of the whole text)."""
+    parts = []
+    for g, n in enumerate(counts.tolist()):
+        r = gathered[g, :n].to(torch.int64).clone()
+        r[:, :2] += g * int(units_per_rank)
+        parts.append(r)
+    return torch.cat(parts) if parts else torch.empty((0, gathered.shape[-1]), dtype=torch.int64)
+
+
+class ShardedMatcher:
+    """One rank's end of the sharded AhoCorasick match: device-resident shard, halo exchange, native scan
+    (acgpu_match_device), all-gather of match buffers.
+
+    scan_fn (tests only) replaces the native scan so the plumbing can run under gloo on CPU:
+    scan_fn(buffer_units_np, own_begin, own_end, text_begin) -> (n,cols) int32 records, buffer-relative."""
+
+    def __init__(self, automaton, n_units, with_ids=True, cap=1 << 20, device=None, group=None, scan_fn=None, halo=None):
+        self.auto = automaton
+        self.group = group
+        self.rank, self.world = _world(group)
+        self.with_ids = with_ids
+        self.cols = 3 if with_ids else 2
+        if halo is None:
+            halo = max(0, automaton.info()["max_keyword_len"] - 1)
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if scan_fn is None else torch.device("cpu")
+        self.sb = ShardBuffer(n_units, halo, device)
+        self.cap = int(cap)
+        self.out = torch.empty((self.cap, self.cols), dtype=torch.int32, device=device)
+        self.scan_fn = scan_fn
+        self.last_kernel = ""
+        self.gathered = None
+        self.counts = None
+
+    def own_ptr(self):
+        return self.sb.own.data_ptr()
+
+    def own_units_host(self, k=None):
+        v = self.sb.own if k is None else self.sb.own[:k]
+        return v.cpu().numpy().view(np.uint16)
+
+    def _scan(self, profile):
+        sb = self.sb
+        first = self.rank == 0
+        last = self.rank == self.world - 1
+        if self.scan_fn is not None:
+            if first:
+                recs = self.scan_fn(sb.own.numpy().view(np.uint16), 0, sb.n_units, True)
+            else:
+                recs = self.scan_fn(sb.buf.numpy().view(np.uint16), sb.pad, sb.pad + sb.n_units, False)
+                recs = recs.copy()
+                recs[:, :2] -= sb.pad
+            n = len(recs)
+            if n > self.cap:
+                self.cap = n
+                self.out = torch.empty((self.cap, self.cols), dtype=torch.int32)
+            self.out[:n] = torch.from_numpy(np.ascontiguousarray(recs[:, :self.cols], dtype=np.int32))
+            return n, None
+        from . import _native as N
+        stream = torch.cuda.current_stream().cuda_stream
+        while True:
+            if first:  # the pad in front of rank 0's text is not part of the haystack
+                n, rc, prof, _ = self.auto.match_device(sb.own.data_ptr(), sb.n_units, self.with_ids, self.out.data_ptr(),
+                                                        self.cap, own=(0, sb.n_units), text_begin=True, text_end=last,
+                                                        stream=stream, profile=profile)
+            else:
+                n, rc, prof, _ = self.auto.match_device(sb.buf.data_ptr(), sb.pad + sb.n_units, self.with_ids,
+                                                        self.out.data_ptr(), self.cap, own=(sb.pad, sb.pad + sb.n_units),
+                                                        text_begin=False, text_end=last, stream=stream, profile=profile)
+            if rc == N.E_OVERFLOW:
+                self.cap = int(n * 1.25) + 16
+                self.out = torch.empty((self.cap, self.cols), dtype=torch.int32, device=self.out.device)
+                continue
+            N.check(rc, "acgpu_match_device")
+            break
+        if not first and n:
+            self.out[:n, :2] -= sb.pad  # buffer-relative -> shard-relative
+        if prof:
+            self.last_kernel = prof["scan_kernel"]
+        return n, prof
+
+    def step(self, profile=False):
+        """halo exchange -> scan -> all-gather.  Returns a dict with n_local, n_total and (profile) kernel timings."""
+        exchange_halo(self.sb, self.group)
+        n, prof = self._scan(profile)
+        self.gathered, self.counts = allgather_matches(self.out, n, self.group)
+        r = {"n_local": int(n), "n_total": int(self.counts.sum()), "scan_ms": 0.0, "finalize_ms": 0.0}
+        if prof:
+            r.update(scan_ms=prof["scan_ms"], finalize_ms=prof["finalize_ms"])
+        return r
+
+    def global_records(self):
+        return global_records(self.gathered, self.counts, self.sb.n_units)

@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's headline metric on MI355X: haystack MB/s (+ matches/s) of AhoCorasick*.match().
+
+  python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one pass of the hot path over one batch of synthetic input that is already resident in HBM:
+  N=1 : BASELINE.json config 2 -- AhoCorasickMap, 10k keywords (len 4..12, a-z), 1 GiB (2^29 UTF-16 units)
+        haystack, records (start, end, keyword_id) delivered in reference order on the device.
+  N>1 : config 3 -- AhoCorasickSet, same dictionary, 2^29 units PER GPU (weak scaling, shard g = stream 2003+g),
+        each rank scans its shard with a (max_keyword_len-1) left halo received from rank g-1, then the per-shard
+        match buffers are all-gathered over RCCL/xGMI (counts first, then padded record buffers).
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--units-log2", type=int, default=29, help="haystack units per GPU (default 2^29 = 1 GiB)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-log2", type=int, default=28)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from ahocorasick_amd import _native as N
+    from ahocorasick_amd import synth
+    from ahocorasick_amd.dist import ShardedMatcher
+    from ahocorasick_amd.strings import Automaton
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU matching path)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n_units = 1 << args.units_log2
+    multi = world > 1
+    cfg_name = "C3" if multi else "C2"
+    with_ids = not multi  # C2 = AhoCorasickMap (12-byte records), C3 = AhoCorasickSet (8-byte records)
+    rec_bytes = 12 if with_ids else 8
+    cfg = synth.CONFIGS[cfg_name]
+    kws = synth.config_keywords(cfg_name)
+    t0 = time.time()
+    auto = Automaton(N.MODE_ALL, kws, True)
+    build_s = time.time() - t0
+    info = auto.info()
+    halo = info["max_keyword_len"] - 1
+
+    # synthetic shard, generated in place on the device
+    seed = cfg["hay_seed"] + (rank if multi else 0)
+    tab = np.ascontiguousarray(synth.ALPHA_LOWER)
+    matcher = ShardedMatcher(auto, n_units, with_ids=with_ids, cap=max(1 << 16, n_units // 128))
+    N.check(N.lib().acgpu_synth_fill(matcher.own_ptr(), n_units, 0, seed, tab.ctypes.data_as(ctypes.c_void_p), len(tab),
+                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "synth_fill")
+    torch.cuda.synchronize()
+
+    def step(profile=False):
+        return matcher.step(profile=profile)
+
+    for _ in range(args.warmup):
+        step()
+    if multi:
+        dist.barrier()
+    torch.cuda.synchronize()
+    scan_ms, fin_ms, n_matches_local, n_matches_total = [], [], 0, 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r = step(profile=True)
+        scan_ms.append(r["scan_ms"])
+        fin_ms.append(r["finalize_ms"])
+        n_matches_local, n_matches_total = r["n_local"], r["n_total"]
+    torch.cuda.synchronize()
+    if multi:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if multi:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_units = n_units * world
+    ms_per_step = elapsed / args.steps * 1e3
+    mb_per_s = total_units * 2 / (elapsed / args.steps) / 1e6
+    kernel_ms = float(np.mean(scan_ms))
+    alg_bytes = 2 * n_units + rec_bytes * n_matches_local  # per launch of the dominant kernel (one rank's shard)
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+
+    out = {
+        "metric": "haystack MB/s (UTF-16 bytes scanned per second, records delivered in reference order)",
+        "value": round(mb_per_s, 1),
+        "unit": "MB/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u16",
+        "data": "synthetic",
+        "matches_per_s": round(n_matches_total / (elapsed / args.steps), 1),
+        "config": {
+            "workload": ("BASELINE config 3: AhoCorasickSet, 10k keywords, 2^%d units per GPU, halo + all-gather of match buffers"
+                         % args.units_log2) if multi else
+                        ("BASELINE config 2: AhoCorasickMap, 10k keywords (len 4-12, a-z), 2^%d UTF-16 units (1 GiB at 29)"
+                         % args.units_log2),
+            "keywords": len(kws), "states": info["n_states"], "classes": info["n_classes"],
+            "table": ("dense u%d" % (8 * info["entry_bytes"])) if info["dense"] else "hashed",
+            "lds_states": info["lds_states"], "units_per_gpu": n_units, "matches_per_gpu": n_matches_local,
+            "matches_total": n_matches_total, "record_bytes": rec_bytes, "build_s": round(build_s, 3),
+            "parallelism": "shard%d+halo%d+allgather" % (world, halo) if multi else "single",
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+            "kernel": matcher.last_kernel, "kernel_ms": round(kernel_ms, 4), "finalize_ms": round(float(np.mean(fin_ms)), 4),
+            "algorithmic_bytes": alg_bytes,
+        },
+    }
+
+    if rank == 0 and not multi and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(kws, matcher, min(n_units, 1 << args.cpu_sample_log2))
+    if rank == 0:
+        print(json.dumps(out))
+    if multi:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(kws, matcher, sample_units):
+    """The reference-shaped CPU restatement (oracle/ac_oracle.c, kind "port"), single thread like the reference,
+    no-op listener (R/README.md:144), on a bounded prefix of the same haystack."""
+    from oracle.oracle import FAM_AC, Oracle
+    o = Oracle(FAM_AC, kws)
+    hay = matcher.own_units_host(sample_units)
+    o.count(hay[:1 << 20])  # warm-up
+    t0 = time.perf_counter()
+    n = o.count(hay)
+    dt = time.perf_counter() - t0
+    return {"value": round(hay.size * 2 / dt / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": "port",
+            "sample": "first 2^%d units of the same haystack, %d matches, %.1f s, no-op listener" % (
+                int(np.log2(hay.size)), n, dt),
+            "host_cpus": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()
