@@ -25,7 +25,8 @@ class Info(ctypes.Structure):
                 ("n_states", ctypes.c_uint32), ("n_classes", ctypes.c_uint32), ("n_keywords", ctypes.c_uint32),
                 ("min_keyword_len", ctypes.c_uint32), ("max_keyword_len", ctypes.c_uint32), ("dense", ctypes.c_uint32),
                 ("entry_bytes", ctypes.c_uint32), ("table_bytes", ctypes.c_uint64), ("lds_states", ctypes.c_uint32),
-                ("fold_consistent", ctypes.c_uint32)]
+                ("fold_consistent", ctypes.c_uint32), ("filter_k", ctypes.c_uint32), ("filter_bits", ctypes.c_uint32),
+                ("tile_kernel", ctypes.c_uint32), ("filter_density", ctypes.c_float)]
 
 
 class Shard(ctypes.Structure):

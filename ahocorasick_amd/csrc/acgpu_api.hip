@@ -142,6 +142,13 @@ int ensure_device(acgpu_automaton *a, DeviceState **out) {
             T.dfa = p;
         }
     }
+    if ((rc = upload(*d, t.filt_bits, &T.filt_bits))) return rc;
+    if ((rc = upload(*d, t.kgram_node, &T.kgram_node))) return rc;
+    if ((rc = upload(*d, t.rinfo, &T.rinfo))) return rc;
+    if ((rc = upload(*d, t.rhkeys, &T.rhkeys))) return rc;
+    if ((rc = upload(*d, t.rhvals, &T.rhvals))) return rc;
+    T.rhmask = t.rhmask; T.filt_k = t.filt_k; T.filt_n = t.filt_n; T.filt_other = t.filt_other;
+    T.filt_words = (uint32_t)t.filt_bits.size();
     T.hmask = t.hmask;
     T.n_states = t.n_states; T.n_cls = t.n_cls; T.first_out = t.first_out; T.max_len = t.max_len; T.min_len = t.min_len;
     T.cls_base = t.cls_base; T.cls_span = t.cls_span; T.range_cls = t.range_cls; T.cs = t.cs; T.dense = t.dense;
@@ -155,6 +162,16 @@ int ensure_device(acgpu_automaton *a, DeviceState **out) {
 }
 
 uint32_t round_up8(uint64_t v) { return (uint32_t)((v + 7) & ~7ull); }
+
+// Which ALL-mode kernel serves this dictionary: the position-parallel K-gram tile kernel when the suffix filter
+// exists and is selective, otherwise the general DFA chunk scan (any alphabet, any keyword lengths).
+bool use_tile_kernel(const HostTables &t) {
+    if (t.filt_k == 0) return false;
+    const int64_t f = tunables().force_kernel;
+    if (f == 1) return false;
+    if (f == 2) return true;
+    return t.filt_density <= 0.08;
+}
 
 // ALL-mode pipeline on one shard.
 int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_kind, void *d_out, uint64_t cap,
@@ -170,41 +187,75 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         *n_out = 0;
         return ACGPU_OK;
     }
-    ScanLaunch L{};
-    L.block = scan_block_threads();
-    L.grid = d.n_cu * (int)std::max<int64_t>(1, tunables().blocks_per_cu);
-    const uint64_t lanes = (uint64_t)L.grid * L.block;
-    uint64_t C = tunables().chunk_units > 0 ? (uint64_t)tunables().chunk_units
-                                            : std::max<uint64_t>({(own_len + lanes - 1) / lanes, 256, 16ull * halo});
-    C = std::max<uint32_t>(8, round_up8(C));
-    L.chunk_units = (uint32_t)C;
-    L.n_chunks = (uint32_t)((own_len + C - 1) / C);
-    // do not launch more workgroups than there are chunks
-    L.grid = (int)std::min<uint64_t>((uint64_t)L.grid, ((uint64_t)L.n_chunks + L.block - 1) / L.block);
-    L.d_hay = sh->d_hay;
-    L.n_units = (uint32_t)sh->n_units;
-    L.own_begin = (uint32_t)sh->own_begin;
-    L.own_end = (uint32_t)sh->own_end;
-    L.cap = cap;
-    L.lds_bytes = scan_queue_bytes(L.block) + (size_t)d.T.lds_entries * t.entry_bytes;
-
     int rc;
     if ((rc = d.counter.ensure(64))) return rc;
-    if ((rc = d.chunk_counts.ensure((size_t)L.n_chunks * 4))) return rc;
-    if ((rc = d.offsets.ensure((size_t)L.n_chunks * 8))) return rc;
-    if ((rc = d.scan_tmp.ensure(((size_t)L.n_chunks / 2048 + 2) * 8))) return rc;
     if ((rc = d.scratch.ensure(std::max<uint64_t>(cap, 1) * sizeof(ScratchRec)))) return rc;
-    L.d_scratch = (ScratchRec *)d.scratch.p;
-    L.d_counter = (unsigned long long *)d.counter.p;
-    L.d_chunk_counts = (uint32_t *)d.chunk_counts.p;
-
     HIP_TRY(hipMemsetAsync(d.counter.p, 0, 64, stream));
-    if (prof) HIP_TRY(hipEventRecord(d.ev[0], stream));
     const char *kname = "";
-    HIP_TRY(launch_ac_scan(d.T, L, stream, &kname));
-    if (prof) HIP_TRY(hipEventRecord(d.ev[1], stream));
-    HIP_TRY(launch_exclusive_scan(L.d_chunk_counts, L.n_chunks, (uint64_t *)d.offsets.p, (uint64_t *)d.scan_tmp.p, stream));
-    HIP_TRY(launch_permute(L.d_scratch, L.d_counter, cap, (const uint64_t *)d.offsets.p, L.own_begin, L.chunk_units,
+    uint64_t scanned = 0;
+    uint32_t n_chunks = 0, chunk_units = 0;
+    if (use_tile_kernel(t)) {
+        TileLaunch L{};
+        L.block = tile_block_threads();
+        const int waves_per_block = L.block / 64;
+        uint64_t R = tunables().region_units > 0 ? (uint64_t)tunables().region_units : 16384;
+        R = std::max<uint64_t>(512, (R + 511) / 512 * 512);
+        L.region_units = (uint32_t)R;
+        L.n_regions = (uint32_t)((own_len + R - 1) / R);
+        L.grid = (int)std::min<uint64_t>((uint64_t)d.n_cu, ((uint64_t)L.n_regions + waves_per_block - 1) / waves_per_block);
+        L.d_hay = sh->d_hay;
+        L.n_units = (uint32_t)sh->n_units;
+        L.own_begin = (uint32_t)sh->own_begin;
+        L.own_end = (uint32_t)sh->own_end;
+        L.cap = cap;
+        L.lds_bytes = tile_lds_bytes(d.T, L.block);
+        if ((rc = d.chunk_counts.ensure((size_t)L.n_regions * 4))) return rc;
+        if ((rc = d.offsets.ensure((size_t)L.n_regions * 8))) return rc;
+        if ((rc = d.scan_tmp.ensure(((size_t)L.n_regions / 2048 + 2) * 8))) return rc;
+        L.d_scratch = (ScratchRec *)d.scratch.p;
+        L.d_counter = (unsigned long long *)d.counter.p;
+        L.d_region_counts = (uint32_t *)d.chunk_counts.p;
+        if (prof) HIP_TRY(hipEventRecord(d.ev[0], stream));
+        HIP_TRY(launch_ac_tile(d.T, L, stream, &kname));
+        if (prof) HIP_TRY(hipEventRecord(d.ev[1], stream));
+        n_chunks = L.n_regions;
+        chunk_units = L.region_units;
+        scanned = own_len;
+    } else {
+        ScanLaunch L{};
+        L.block = scan_block_threads();
+        L.grid = d.n_cu * (int)std::max<int64_t>(1, tunables().blocks_per_cu);
+        const uint64_t lanes = (uint64_t)L.grid * L.block;
+        uint64_t C = tunables().chunk_units > 0 ? (uint64_t)tunables().chunk_units
+                                                : std::max<uint64_t>({(own_len + lanes - 1) / lanes, 256, 16ull * halo});
+        C = std::max<uint32_t>(8, round_up8(C));
+        L.chunk_units = (uint32_t)C;
+        L.n_chunks = (uint32_t)((own_len + C - 1) / C);
+        // do not launch more workgroups than there are chunks
+        L.grid = (int)std::min<uint64_t>((uint64_t)L.grid, ((uint64_t)L.n_chunks + L.block - 1) / L.block);
+        L.d_hay = sh->d_hay;
+        L.n_units = (uint32_t)sh->n_units;
+        L.own_begin = (uint32_t)sh->own_begin;
+        L.own_end = (uint32_t)sh->own_end;
+        L.cap = cap;
+        L.lds_bytes = scan_queue_bytes(L.block) + (size_t)d.T.lds_entries * t.entry_bytes;
+        if ((rc = d.chunk_counts.ensure((size_t)L.n_chunks * 4))) return rc;
+        if ((rc = d.offsets.ensure((size_t)L.n_chunks * 8))) return rc;
+        if ((rc = d.scan_tmp.ensure(((size_t)L.n_chunks / 2048 + 2) * 8))) return rc;
+        L.d_scratch = (ScratchRec *)d.scratch.p;
+        L.d_counter = (unsigned long long *)d.counter.p;
+        L.d_chunk_counts = (uint32_t *)d.chunk_counts.p;
+        if (prof) HIP_TRY(hipEventRecord(d.ev[0], stream));
+        HIP_TRY(launch_ac_scan(d.T, L, stream, &kname));
+        if (prof) HIP_TRY(hipEventRecord(d.ev[1], stream));
+        n_chunks = L.n_chunks;
+        chunk_units = L.chunk_units;
+        scanned = own_len + (uint64_t)L.n_chunks * halo;
+    }
+    HIP_TRY(launch_exclusive_scan((const uint32_t *)d.chunk_counts.p, n_chunks, (uint64_t *)d.offsets.p,
+                                  (uint64_t *)d.scan_tmp.p, stream));
+    HIP_TRY(launch_permute((const ScratchRec *)d.scratch.p, (const unsigned long long *)d.counter.p, cap,
+                           (const uint64_t *)d.offsets.p, (uint32_t)sh->own_begin, chunk_units,
                            /*by_start=*/0, record_kind, d_out, stream));
     if (prof) HIP_TRY(hipEventRecord(d.ev[2], stream));
     HIP_TRY(hipMemcpyAsync(d.h_counter, d.counter.p, 8, hipMemcpyDeviceToHost, stream));
@@ -214,7 +265,7 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         HIP_TRY(hipEventElapsedTime(&prof->scan_ms, d.ev[0], d.ev[1]));
         HIP_TRY(hipEventElapsedTime(&prof->finalize_ms, d.ev[1], d.ev[2]));
         HIP_TRY(hipEventElapsedTime(&prof->total_ms, d.ev[0], d.ev[2]));
-        prof->scan_units = own_len + (uint64_t)L.n_chunks * halo;
+        prof->scan_units = scanned;
         prof->n_matches = *n_out;
         std::snprintf(prof->scan_kernel, sizeof(prof->scan_kernel), "%s", kname);
     }
@@ -276,6 +327,9 @@ int64_t acgpu_set_tunable(const char *name, int64_t value) {
     else if (!std::strcmp(name, "lds_table_bytes")) slot = &t.lds_table_bytes;
     else if (!std::strcmp(name, "force_sparse")) slot = &t.force_sparse;
     else if (!std::strcmp(name, "dense_budget_bytes")) slot = &t.dense_budget_bytes;
+    else if (!std::strcmp(name, "force_kernel")) slot = &t.force_kernel;
+    else if (!std::strcmp(name, "region_units")) slot = &t.region_units;
+    else if (!std::strcmp(name, "filter_max_bits")) slot = &t.filter_max_bits;
     if (!slot) return -1;
     int64_t prev = *slot;
     *slot = value;
@@ -333,6 +387,10 @@ int acgpu_get_info(const acgpu_automaton *a, acgpu_info *info) {
     info->table_bytes = t.dense ? (uint64_t)t.dfa.size() * t.entry_bytes : (uint64_t)t.hkeys.size() * 12 + (uint64_t)t.n_states * 4;
     info->lds_states = lds_states_for(t);
     info->fold_consistent = t.fold_consistent;
+    info->filter_k = t.filt_k;
+    info->filter_bits = (uint32_t)(t.filt_bits.size() * 32);
+    info->tile_kernel = use_tile_kernel(t);
+    info->filter_density = (float)t.filt_density;
     return ACGPU_OK;
 }
 

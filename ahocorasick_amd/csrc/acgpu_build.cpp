@@ -210,6 +210,7 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
     t.n_cls = 1;
     t.dense = false;
     t.range_cls = false;
+    std::vector<uint32_t> cls_of(65536, 0); // class of a FOLDED unit (0 = occurs in no keyword)
     if (mode != ACGPU_MODE_WHOLEWORD) {
         std::vector<uint8_t> used(65536, 0);
         uint32_t n_used = 0, minu = 65535, maxu = 0;
@@ -219,7 +220,6 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
             if (u < minu) minu = u;
             if (u > maxu) maxu = u;
         }
-        std::vector<uint32_t> cls_of(65536, 0);
         if (n_used > 0 && n_used <= 65535) {
             if (t.cs && (maxu - minu + 1) <= 63) {
                 t.range_cls = true;
@@ -254,6 +254,85 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
                     }
                 }
             }
+        }
+    }
+
+    // ---- 7. suffix K-gram filter + reversed trie (ALL mode) ----
+    t.filt_k = 0;
+    if (mode == ACGPU_MODE_ALL && t.n_cls > 1 && t.min_len >= 1 && !t.cls_lut.empty()) {
+        // tile classes: range mode -> min(unit - base, span) (other = span); LUT mode -> cls_lut (other = 0)
+        const uint32_t n = t.n_cls;
+        t.filt_n = n;
+        t.filt_other = t.range_cls ? t.cls_span : 0;
+        auto tcls = [&](uint16_t folded_unit) -> uint32_t {
+            if (t.range_cls) return (uint32_t)folded_unit - t.cls_base; // only called on keyword units: inside the range
+            return cls_of[folded_unit];
+        };
+        uint32_t K = 0;
+        uint64_t pw = 1;
+        while (K < t.min_len && K < 8 && pw * n <= (uint64_t)tunables().filter_max_bits) { pw *= n; K++; }
+        if (K >= 1) {
+            // reversed trie: walking a terminal node's parent chain in the forward trie spells the reversed keyword
+            struct RNode { uint32_t parent; uint16_t unit; uint32_t depth; uint32_t kw; bool has_child; };
+            std::vector<RNode> rn;
+            rn.push_back({0, 0, 0, ~0u, false});
+            std::unordered_map<uint64_t, uint32_t> redge;
+            redge.reserve(N * 2);
+            for (uint32_t s = 1; s < N; s++) {
+                if (nodes[s].kw == ~0u) continue;
+                uint32_t cur = 0;
+                for (uint32_t p = s; p != 0; p = nodes[p].parent) {
+                    uint64_t key = ((uint64_t)cur << 16) | nodes[p].unit;
+                    auto it = redge.find(key);
+                    if (it == redge.end()) {
+                        uint32_t id = (uint32_t)rn.size();
+                        rn.push_back({cur, nodes[p].unit, rn[cur].depth + 1, ~0u, false});
+                        rn[cur].has_child = true;
+                        redge.emplace(key, id);
+                        cur = id;
+                    } else {
+                        cur = it->second;
+                    }
+                }
+                rn[cur].kw = nodes[s].kw;
+            }
+            const uint32_t RN = (uint32_t)rn.size();
+            t.n_rstates = RN;
+            t.rinfo.assign(RN, 0);
+            for (uint32_t i = 0; i < RN; i++)
+                t.rinfo[i] = (rn[i].has_child ? 0x80000000u : 0u) | (rn[i].kw == ~0u ? 0u : rn[i].kw + 1);
+            uint64_t cap = 16;
+            while (cap < 2 * (uint64_t)RN + 2) cap <<= 1;
+            t.rhkeys.assign(cap, kEmptyKey);
+            t.rhvals.assign(cap, 0);
+            t.rhmask = (uint32_t)(cap - 1);
+            for (uint32_t i = 1; i < RN; i++) {
+                uint64_t key = edge_key(rn[i].parent, rn[i].unit);
+                uint32_t slot = edge_hash(key) & t.rhmask;
+                while (t.rhkeys[slot] != kEmptyKey) slot = (slot + 1) & t.rhmask;
+                t.rhkeys[slot] = key;
+                t.rhvals[slot] = i;
+            }
+            // K-gram bitmap and K-gram -> depth-K reverse node
+            t.filt_bits.assign((pw + 31) / 32, 0);
+            t.kgram_node.assign(pw, 0);
+            uint64_t n_set = 0;
+            for (uint32_t i = 1; i < RN; i++) {
+                if (rn[i].depth != K) continue;
+                // path root -> i spells text[e-1], text[e-2], ..., text[e-K]; index has text[e-1] least significant
+                uint64_t idx = 0, mul = 1;
+                std::vector<uint32_t> path;
+                for (uint32_t p = i; p != 0; p = rn[p].parent) path.push_back(tcls(rn[p].unit));
+                // path is now [text[e-K], ..., text[e-1]] (deepest first)
+                for (size_t j = path.size(); j-- > 0;) { idx += mul * path[j]; mul *= n; }
+                t.filt_bits[idx >> 5] |= 1u << (idx & 31);
+                t.kgram_node[idx] = i;
+                n_set++;
+            }
+            double denom = 1;
+            for (uint32_t j = 0; j < K; j++) denom *= (double)(n > 1 ? n - 1 : 1);
+            t.filt_density = (double)n_set / denom;
+            t.filt_k = K;
         }
     }
     return ACGPU_OK;

@@ -55,6 +55,22 @@ struct HostTables {
     std::vector<uint32_t> hvals;
     uint32_t hmask = 0;
     uint64_t n_edges = 0;
+    // ---- suffix k-gram filter + reversed trie (ALL mode, position-parallel kernel) ----
+    // A match can end at text position e only if the K units before e form the K-suffix of some keyword
+    // (K <= min keyword length).  filt_bits has one bit per K-gram of tile classes (direct index, last unit least
+    // significant); kgram_node maps a set K-gram to the depth-K node of the trie of REVERSED keywords, from which the
+    // verification walk continues leftwards through the hashed reverse edges.
+    uint32_t filt_k = 0;      // 0 = filter not available for this dictionary
+    uint32_t filt_n = 0;      // tile classes (radix of the K-gram index)
+    uint32_t filt_other = 0;  // tile class of a unit that occurs in no keyword
+    double filt_density = 0;  // set bits / (filt_n-1)^K
+    std::vector<uint32_t> filt_bits;   // ceil(filt_n^K / 32) words
+    std::vector<uint32_t> kgram_node;  // filt_n^K entries, 0 = none
+    std::vector<uint32_t> rinfo;       // per reverse node: bit31 = has children, low 31 bits = keyword id + 1 (0 = not terminal)
+    std::vector<uint64_t> rhkeys;
+    std::vector<uint32_t> rhvals;
+    uint32_t rhmask = 0;
+    uint32_t n_rstates = 0;
 };
 
 int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uint32_t n_kw, int case_sensitive,
@@ -74,6 +90,11 @@ struct DevTables {
     uint32_t cls_base, cls_span;
     int32_t range_cls, cs, dense, entry_bytes;
     uint32_t lds_entries; // leading dfa entries staged in LDS by the scan kernel
+    // k-gram filter / reversed trie
+    const uint32_t *filt_bits, *kgram_node, *rinfo;
+    const uint64_t *rhkeys;
+    const uint32_t *rhvals;
+    uint32_t rhmask, filt_k, filt_n, filt_other, filt_words;
 };
 
 struct Tunables {
@@ -82,6 +103,9 @@ struct Tunables {
     int64_t lds_table_bytes = 96 * 1024;
     int64_t force_sparse = 0;
     int64_t dense_budget_bytes = 1ll << 30;
+    int64_t force_kernel = 0;     // 0 auto, 1 = DFA chunk scan, 2 = k-gram tile scan (when the filter exists)
+    int64_t region_units = 0;     // tile kernel: owned units per wave region (0 = auto)
+    int64_t filter_max_bits = 690000;  // bitmap must fit LDS next to the candidate queues (86 KB)
 };
 Tunables &tunables();
 

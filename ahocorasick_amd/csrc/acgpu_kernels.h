@@ -31,6 +31,24 @@ struct ScanLaunch {
 // AC-all scan: dense (state x class table, hot rows in LDS) or sparse (hashed goto + fail links).
 hipError_t launch_ac_scan(const DevTables &t, const ScanLaunch &l, hipStream_t stream, const char **kernel_name);
 
+// Position-parallel AC-all scan (suffix K-gram filter in LDS + reversed-trie verification).  Ordering unit
+// ("chunk" for the permute pass) = one wave region of region_units owned units.
+struct TileLaunch {
+    const uint16_t *d_hay;
+    uint32_t n_units, own_begin, own_end;
+    uint32_t region_units; // multiple of 512
+    uint32_t n_regions;
+    ScratchRec *d_scratch;
+    uint64_t cap;
+    unsigned long long *d_counter;
+    uint32_t *d_region_counts;
+    int grid, block;
+    size_t lds_bytes;
+};
+hipError_t launch_ac_tile(const DevTables &t, const TileLaunch &l, hipStream_t stream, const char **kernel_name);
+size_t tile_lds_bytes(const DevTables &t, int block_threads);
+int tile_block_threads();
+
 // exclusive prefix sum of d_counts[0..n) into d_offsets (uint64); d_tmp holds >= ceil(n/2048)+1 uint64
 hipError_t launch_exclusive_scan(const uint32_t *d_counts, uint32_t n, uint64_t *d_offsets, uint64_t *d_tmp,
                                  hipStream_t stream);

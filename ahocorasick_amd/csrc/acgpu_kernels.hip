@@ -10,24 +10,17 @@
 // k_permute   : scatters the unordered records to their final, reference-ordered slots.
 #include <hip/hip_runtime.h>
 
+#include "acgpu_device.h"
 #include "acgpu_kernels.h"
 
 namespace acgpu {
 
-constexpr int kWave = 64;
 constexpr int kScanBlock = 1024;                 // 16 waves: one workgroup per CU shares one LDS copy of the hot rows
 constexpr int kQueueCap = 128;                   // records per wave queue
 constexpr int kQueueFlush = kQueueCap - kWave;   // flush when fewer than 64 free slots remain
 
 int scan_block_threads() { return kScanBlock; }
 size_t scan_queue_bytes(int block_threads) { return (size_t)(block_threads / kWave) * kQueueCap * sizeof(ScratchRec); }
-
-__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
-
-__device__ __forceinline__ uint64_t lanemask_lt() {
-    uint32_t l = lane_id();
-    return l == 0 ? 0ull : (~0ull >> (64 - l));
-}
 
 // ---- per-wave record queue in LDS ---------------------------------------------------------------------
 struct WaveQueue {
@@ -105,14 +98,7 @@ struct SparseStep {
     uint32_t hmask;
     bool cs;
     __device__ __forceinline__ uint32_t goto_edge(uint32_t s, uint32_t u) const { // ~0u when absent
-        const uint64_t key = edge_key(s, u);
-        uint32_t slot = edge_hash(key) & hmask;
-        for (;;) {
-            const uint64_t k = hkeys[slot];
-            if (k == key) return hvals[slot];
-            if (k == kEmptyKey) return ~0u;
-            slot = (slot + 1) & hmask;
-        }
+        return hashed_goto(hkeys, hvals, hmask, s, u);
     }
     __device__ __forceinline__ uint32_t operator()(uint32_t s, uint32_t unit) const {
         const uint32_t u = cs ? unit : (uint32_t)lower[unit];
@@ -218,15 +204,6 @@ hipError_t launch_ac_scan(const DevTables &t, const ScanLaunch &l, hipStream_t s
 
 // ---- exclusive prefix sum of per-chunk counts ------------------------------------------------------------
 constexpr int kScanTile = 2048; // elements per 256-thread block
-
-__device__ __forceinline__ uint64_t wave_inclusive_scan(uint64_t v) {
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        const uint64_t o = __shfl_up(v, d);
-        if ((int)lane_id() >= d) v += o;
-    }
-    return v;
-}
 
 // block-wide exclusive scan of one value per thread (256 threads); returns exclusive prefix, total in *total
 __device__ __forceinline__ uint64_t block_exclusive_scan_256(uint64_t v, uint64_t *total) {

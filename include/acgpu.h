@@ -104,6 +104,10 @@ typedef struct acgpu_info {
     uint64_t table_bytes;    /* bytes of the transition structure resident in HBM        */
     uint32_t lds_states;     /* states whose rows are staged in LDS by the scan kernel   */
     uint32_t fold_consistent;/* WHOLEWORD: wordchar[c] == wordchar[lower[c]] for all c   */
+    uint32_t filter_k;       /* ALL: length of the suffix K-gram filter, 0 = none          */
+    uint32_t filter_bits;    /* ALL: size of the K-gram bitmap in bits                      */
+    uint32_t tile_kernel;    /* ALL: 1 if the position-parallel K-gram kernel will be used  */
+    float filter_density;    /* ALL: fraction of K-grams (over keyword units) that pass     */
 } acgpu_info;
 
 int acgpu_get_info(const acgpu_automaton *a, acgpu_info *info);
@@ -172,7 +176,8 @@ int acgpu_synth_fill(uint16_t *d_dst, uint64_t n_units, uint64_t start_index, ui
                      uint32_t table_len, void *stream);
 
 /* tuning knobs (process-wide; mainly for tests and benchmarks).  name: "chunk_units",
- * "blocks_per_cu", "lds_table_bytes", "force_sparse", "dense_budget_bytes".  Returns the previous value. */
+ * "blocks_per_cu", "lds_table_bytes", "force_sparse", "dense_budget_bytes", "force_kernel" (0 auto, 1 DFA chunk
+ * scan, 2 K-gram tile scan), "region_units", "filter_max_bits".  Returns the previous value, -1 for an unknown name. */
 int64_t acgpu_set_tunable(const char *name, int64_t value);
 
 const char *acgpu_strerror(int code);

@@ -19,8 +19,17 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _reset_tunables():
     yield
-    for k, v in [("chunk_units", 0), ("blocks_per_cu", 1), ("lds_table_bytes", 96 * 1024), ("force_sparse", 0)]:
+    for k, v in [("chunk_units", 0), ("blocks_per_cu", 1), ("lds_table_bytes", 96 * 1024), ("force_sparse", 0),
+                 ("force_kernel", 0), ("region_units", 0)]:
         N.set_tunable(k, v)
+
+
+@pytest.fixture(params=["dfa_chunk_scan", "kgram_tile_scan"])
+def ac_kernel(request):
+    """Runs a test once per ALL-mode kernel (the tile kernel only exists for dictionaries with a K-gram filter;
+    force_kernel=2 falls back to the DFA scan otherwise, which the first parameter already covers)."""
+    N.set_tunable("force_kernel", 1 if request.param == "dfa_chunk_scan" else 2)
+    return request.param
 
 
 def _ids(n):
@@ -29,7 +38,7 @@ def _ids(n):
 
 # ---- the reference's own deterministic scenarios -----------------------------------------------------------
 
-def test_fixtures_ahocorasick(fixtures):
+def test_fixtures_ahocorasick(fixtures, ac_kernel):
     for fx in fixtures:
         hay, kws = fixture_inputs(fx)
         m = AhoCorasickMap(kws, _ids(len(kws)), True)
@@ -70,7 +79,7 @@ def test_listener_contract_and_early_stop():
 # ---- seeded fuzz against the oracle --------------------------------------------------------------------------
 
 @pytest.mark.parametrize("seed", range(6))
-def test_fuzz_ahocorasick_small_alphabets(seed):
+def test_fuzz_ahocorasick_small_alphabets(seed, ac_kernel):
     rng = np.random.default_rng(seed)
     alpha = [ord(c) for c in "ab"] if seed % 2 == 0 else [ord(c) for c in "abcAB"] + [0x00E9, 0x00C9, 0x0130]
     for it in range(12):
@@ -96,6 +105,29 @@ def test_chunking_lds_and_sparse_variants_agree(chunk_units, lds_bytes, sparse):
         assert got == want
 
 
+@pytest.mark.parametrize("region_units,min_len", [(512, 1), (512, 2), (1024, 3), (512, 4), (4096, 6), (0, 8)])
+def test_tile_kernel_regions_and_filter_lengths(region_units, min_len):
+    # the K-gram filter length follows the shortest keyword (K <= min_len); small regions stress the region seams
+    N.set_tunable("force_kernel", 2)
+    N.set_tunable("region_units", region_units)
+    rng = np.random.default_rng(1000 + min_len)
+    for alpha in ([ord(c) for c in "ab"], list(range(ord("a"), ord("h") + 1)), [ord(c) for c in "abAB"] + [0x00E9, 0x00C9]):
+        hay, kws = rand_case(rng, alpha, 30, min_len + 5, 30011, min_len=min_len)
+        for cs in (True, False):
+            m = AhoCorasickMap(kws, _ids(len(kws)), cs)
+            info = m.automaton.info()
+            assert info["filter_k"] >= 1 and info["filter_k"] <= min(info["min_keyword_len"], 8) and info["tile_kernel"] == 1
+            want = Oracle(FAM_AC, kws, case_sensitive=cs, lower=LOWER).match(hay).tolist()
+            assert m.find_all(hay).tolist() == want
+
+
+def test_kernel_selection_defaults():
+    c2 = Automaton(N.MODE_ALL, synth.config_keywords("C2"), True).info()
+    assert c2["filter_k"] == 4 and c2["tile_kernel"] == 1 and c2["filter_density"] < 0.05
+    dense_dict = Automaton(N.MODE_ALL, ["a", "b", "ab"], True).info()
+    assert dense_dict["tile_kernel"] == 0  # every position passes a 1-gram filter: the DFA scan is the better kernel
+
+
 def test_full_alphabet_dictionary_sparse():
     # T/SetTest.java:72-79 (65536 single-unit keywords) + an extended haystack
     kws = [np.array([i], dtype=np.uint16) for i in range(65536)]
@@ -105,7 +137,7 @@ def test_full_alphabet_dictionary_sparse():
     assert m.find_all(hay).tolist() == [[i, i + 1, int(u)] for i, u in enumerate(hay)]
 
 
-def test_random_wide_alphabet_like_reference_full_random():
+def test_random_wide_alphabet_like_reference_full_random(ac_kernel):
     # T/SetTest.java:81-89 uses unseeded 2-3 unit keywords over the whole BMP; seeded here
     rng = np.random.default_rng(7)
     kws = []
@@ -119,7 +151,7 @@ def test_random_wide_alphabet_like_reference_full_random():
     assert AhoCorasickMap(kws, _ids(len(kws)), True).find_all(hay).tolist() == want
 
 
-def test_overflow_protocol():
+def test_overflow_protocol(ac_kernel):
     a = Automaton(N.MODE_ALL, ["a", "aa"], True)
     hay = utf16("a" * 1000)
     out = np.empty((10, 3), np.int32)
@@ -132,7 +164,7 @@ def test_overflow_protocol():
 
 # ---- BASELINE.json config 1 (plumbing size) end to end -------------------------------------------------------
 
-def test_config_c1_bit_exact():
+def test_config_c1_bit_exact(ac_kernel):
     c = synth.CONFIGS["C1"]
     kws = synth.config_keywords("C1")
     hay = synth.haystack(c["hay_seed"], c["n_units"])
@@ -168,7 +200,7 @@ def test_synth_fill_matches_numpy_generator():
         assert (got == synth.haystack(seed, n, table, start=start)).all()
 
 
-def test_device_entry_and_shard_split_invariance():
+def test_device_entry_and_shard_split_invariance(ac_kernel):
     import torch
     kws = synth.random_keywords(11, 300, 2, 9)
     hay = synth.haystack(77, 300000)
@@ -225,8 +257,12 @@ def test_config_c2_full_size_properties():
     pre = 1 << 22
     want = Oracle(FAM_AC, kws).match(synth.haystack(c["hay_seed"], pre))
     assert (got[:len(want)] == want).all() and got[len(want), 1] > pre
-    # (4) a different chunking / no LDS residency gives the identical record stream (checksum of checksums)
-    N.set_tunable("chunk_units", 1000)
-    N.set_tunable("lds_table_bytes", 0)
-    got2, _ = _dev_match(a, d_hay, n, True, cap)
-    assert got2.shape == got.shape and (got2 == got).all()
+    # (4) the two independent kernels (K-gram tile scan / DFA chunk scan), other region and chunk sizes, and no LDS
+    #     residency all give the identical record stream
+    assert prof["scan_kernel"].startswith("k_ac_tile")
+    for knobs in ({"force_kernel": 1}, {"force_kernel": 1, "chunk_units": 1000, "lds_table_bytes": 0},
+                  {"force_kernel": 2, "region_units": 512 * 7}):
+        for k, v in knobs.items():
+            N.set_tunable(k, v)
+        got2, prof2 = _dev_match(a, d_hay, n, True, cap, profile=True)
+        assert got2.shape == got.shape and (got2 == got).all(), (knobs, prof2["scan_kernel"])
