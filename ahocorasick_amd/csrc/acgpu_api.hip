@@ -144,7 +144,9 @@ int ensure_device(acgpu_automaton *a, DeviceState **out) {
     }
     if ((rc = upload(*d, t.filt_bits, &T.filt_bits))) return rc;
     if ((rc = upload(*d, t.kgram_node, &T.kgram_node))) return rc;
-    if ((rc = upload(*d, t.rinfo, &T.rinfo))) return rc;
+    if ((rc = upload(*d, t.rterm, &T.rterm))) return rc;
+    if ((rc = upload(*d, t.rtab, &T.rtab))) return rc;
+    T.rdense = t.rdense;
     if ((rc = upload(*d, t.rhkeys, &T.rhkeys))) return rc;
     if ((rc = upload(*d, t.rhvals, &T.rhvals))) return rc;
     T.rhmask = t.rhmask; T.filt_k = t.filt_k; T.filt_n = t.filt_n; T.filt_other = t.filt_other;
@@ -189,7 +191,9 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
     }
     int rc;
     if ((rc = d.counter.ensure(64))) return rc;
-    if ((rc = d.scratch.ensure(std::max<uint64_t>(cap, 1) * sizeof(ScratchRec)))) return rc;
+    // the tile kernel reserves scratch slots 256 at a time per wave: head-room for the unused tails
+    const uint64_t scratch_cap = std::max<uint64_t>(cap, 1) + (uint64_t)d.n_cu * (tile_block_threads() / 64) * tile_reserve_slots();
+    if ((rc = d.scratch.ensure(scratch_cap * sizeof(ScratchRec)))) return rc;
     HIP_TRY(hipMemsetAsync(d.counter.p, 0, 64, stream));
     const char *kname = "";
     uint64_t scanned = 0;
@@ -207,7 +211,7 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         L.n_units = (uint32_t)sh->n_units;
         L.own_begin = (uint32_t)sh->own_begin;
         L.own_end = (uint32_t)sh->own_end;
-        L.cap = cap;
+        L.cap = scratch_cap;
         L.lds_bytes = tile_lds_bytes(d.T, L.block);
         if ((rc = d.chunk_counts.ensure((size_t)L.n_regions * 4))) return rc;
         if ((rc = d.offsets.ensure((size_t)L.n_regions * 8))) return rc;
@@ -237,7 +241,7 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         L.n_units = (uint32_t)sh->n_units;
         L.own_begin = (uint32_t)sh->own_begin;
         L.own_end = (uint32_t)sh->own_end;
-        L.cap = cap;
+        L.cap = scratch_cap; // every slot below min(counter, scratch_cap) must be written: the permute pass reads them all
         L.lds_bytes = scan_queue_bytes(L.block) + (size_t)d.T.lds_entries * t.entry_bytes;
         if ((rc = d.chunk_counts.ensure((size_t)L.n_chunks * 4))) return rc;
         if ((rc = d.offsets.ensure((size_t)L.n_chunks * 8))) return rc;
@@ -254,11 +258,13 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
     }
     HIP_TRY(launch_exclusive_scan((const uint32_t *)d.chunk_counts.p, n_chunks, (uint64_t *)d.offsets.p,
                                   (uint64_t *)d.scan_tmp.p, stream));
-    HIP_TRY(launch_permute((const ScratchRec *)d.scratch.p, (const unsigned long long *)d.counter.p, cap,
+    HIP_TRY(launch_permute((const ScratchRec *)d.scratch.p, (const unsigned long long *)d.counter.p, scratch_cap,
                            (const uint64_t *)d.offsets.p, (uint32_t)sh->own_begin, chunk_units,
-                           /*by_start=*/0, record_kind, d_out, stream));
+                           /*by_start=*/0, record_kind, d_out, cap, stream));
     if (prof) HIP_TRY(hipEventRecord(d.ev[2], stream));
-    HIP_TRY(hipMemcpyAsync(d.h_counter, d.counter.p, 8, hipMemcpyDeviceToHost, stream));
+    // exact record count = grand total of the per-chunk counts (the slot counter also counts reservation holes)
+    HIP_TRY(hipMemcpyAsync(d.h_counter, (const uint64_t *)d.scan_tmp.p + scan_tiles_for(n_chunks), 8, hipMemcpyDeviceToHost,
+                           stream));
     HIP_TRY(hipStreamSynchronize(stream));
     *n_out = *d.h_counter;
     if (prof) {

@@ -297,21 +297,33 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
                 rn[cur].kw = nodes[s].kw;
             }
             const uint32_t RN = (uint32_t)rn.size();
+            if (RN > kRefIdMask) return ACGPU_E_UNSUPPORTED;
             t.n_rstates = RN;
-            t.rinfo.assign(RN, 0);
-            for (uint32_t i = 0; i < RN; i++)
-                t.rinfo[i] = (rn[i].has_child ? 0x80000000u : 0u) | (rn[i].kw == ~0u ? 0u : rn[i].kw + 1);
-            uint64_t cap = 16;
-            while (cap < 2 * (uint64_t)RN + 2) cap <<= 1;
-            t.rhkeys.assign(cap, kEmptyKey);
-            t.rhvals.assign(cap, 0);
-            t.rhmask = (uint32_t)(cap - 1);
-            for (uint32_t i = 1; i < RN; i++) {
-                uint64_t key = edge_key(rn[i].parent, rn[i].unit);
-                uint32_t slot = edge_hash(key) & t.rhmask;
-                while (t.rhkeys[slot] != kEmptyKey) slot = (slot + 1) & t.rhmask;
-                t.rhkeys[slot] = key;
-                t.rhvals[slot] = i;
+            t.rterm.assign(RN, ~0u);
+            auto ref = [&](uint32_t i) -> uint32_t {
+                return i | (rn[i].has_child ? kRefHasChildren : 0u) | (rn[i].kw != ~0u ? kRefTerminal : 0u);
+            };
+            for (uint32_t i = 0; i < RN; i++) t.rterm[i] = rn[i].kw;
+            t.rdense = (uint64_t)RN * n * 4 <= (uint64_t)tunables().rdense_budget_bytes && !tunables().force_sparse;
+            if (t.rdense) {
+                t.rtab.assign((size_t)RN * n, 0);
+                for (uint32_t i = 1; i < RN; i++) t.rtab[(size_t)rn[i].parent * n + tcls(rn[i].unit)] = ref(i);
+                t.rhkeys.assign(16, kEmptyKey);
+                t.rhvals.assign(16, 0);
+                t.rhmask = 15;
+            } else {
+                uint64_t cap = 16;
+                while (cap < 2 * (uint64_t)RN + 2) cap <<= 1;
+                t.rhkeys.assign(cap, kEmptyKey);
+                t.rhvals.assign(cap, 0);
+                t.rhmask = (uint32_t)(cap - 1);
+                for (uint32_t i = 1; i < RN; i++) {
+                    uint64_t key = edge_key(rn[i].parent, rn[i].unit);
+                    uint32_t slot = edge_hash(key) & t.rhmask;
+                    while (t.rhkeys[slot] != kEmptyKey) slot = (slot + 1) & t.rhmask;
+                    t.rhkeys[slot] = key;
+                    t.rhvals[slot] = ref(i);
+                }
             }
             // K-gram bitmap and K-gram -> depth-K reverse node
             t.filt_bits.assign((pw + 31) / 32, 0);
@@ -326,7 +338,7 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
                 // path is now [text[e-K], ..., text[e-1]] (deepest first)
                 for (size_t j = path.size(); j-- > 0;) { idx += mul * path[j]; mul *= n; }
                 t.filt_bits[idx >> 5] |= 1u << (idx & 31);
-                t.kgram_node[idx] = i;
+                t.kgram_node[idx] = ref(i);
                 n_set++;
             }
             double denom = 1;

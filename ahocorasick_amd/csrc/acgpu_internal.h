@@ -10,6 +10,7 @@
 namespace acgpu {
 
 constexpr uint64_t kEmptyKey = ~0ull;
+constexpr uint32_t kRefHasChildren = 0x80000000u, kRefTerminal = 0x40000000u, kRefIdMask = 0x3fffffffu;
 
 // 64-bit finaliser (splitmix) used for the hashed goto edges; identical on host and device.
 #if defined(__HIPCC__)
@@ -65,9 +66,13 @@ struct HostTables {
     uint32_t filt_other = 0;  // tile class of a unit that occurs in no keyword
     double filt_density = 0;  // set bits / (filt_n-1)^K
     std::vector<uint32_t> filt_bits;   // ceil(filt_n^K / 32) words
-    std::vector<uint32_t> kgram_node;  // filt_n^K entries, 0 = none
-    std::vector<uint32_t> rinfo;       // per reverse node: bit31 = has children, low 31 bits = keyword id + 1 (0 = not terminal)
-    std::vector<uint64_t> rhkeys;
+    // Reverse-trie node references carry two flags so that the common verification walk needs no per-node load:
+    // bit31 = node has children, bit30 = node is terminal (a keyword ends... starts here); low 30 bits = node id.
+    std::vector<uint32_t> kgram_node;  // filt_n^K entries: flagged ref of the depth-K node, 0 = none
+    std::vector<uint32_t> rterm;       // per reverse node: keyword id (valid when the terminal flag is set)
+    bool rdense = false;
+    std::vector<uint32_t> rtab;        // dense: n_rstates * filt_n flagged child refs indexed by tile class (0 = none)
+    std::vector<uint64_t> rhkeys;      // hashed: (node, folded unit) -> flagged child ref
     std::vector<uint32_t> rhvals;
     uint32_t rhmask = 0;
     uint32_t n_rstates = 0;
@@ -91,10 +96,11 @@ struct DevTables {
     int32_t range_cls, cs, dense, entry_bytes;
     uint32_t lds_entries; // leading dfa entries staged in LDS by the scan kernel
     // k-gram filter / reversed trie
-    const uint32_t *filt_bits, *kgram_node, *rinfo;
+    const uint32_t *filt_bits, *kgram_node, *rterm, *rtab;
     const uint64_t *rhkeys;
     const uint32_t *rhvals;
     uint32_t rhmask, filt_k, filt_n, filt_other, filt_words;
+    int32_t rdense;
 };
 
 struct Tunables {
@@ -105,6 +111,7 @@ struct Tunables {
     int64_t dense_budget_bytes = 1ll << 30;
     int64_t force_kernel = 0;     // 0 auto, 1 = DFA chunk scan, 2 = k-gram tile scan (when the filter exists)
     int64_t region_units = 0;     // tile kernel: owned units per wave region (0 = auto)
+    int64_t rdense_budget_bytes = 256ll << 20;
     int64_t filter_max_bits = 690000;  // bitmap must fit LDS next to the candidate queues (86 KB)
 };
 Tunables &tunables();

@@ -281,15 +281,16 @@ hipError_t launch_exclusive_scan(const uint32_t *d_counts, uint32_t n, uint64_t 
 
 // ---- permutation to reference order ----------------------------------------------------------------------
 template <int REC>
-__global__ __launch_bounds__(256) void k_permute(const ScratchRec *scratch, const unsigned long long *counter, uint64_t cap,
-                                                const uint64_t *offsets, uint32_t own_begin, uint32_t chunk_units,
-                                                int by_start, void *out) {
+__global__ __launch_bounds__(256) void k_permute(const ScratchRec *scratch, const unsigned long long *counter,
+                                                uint64_t scratch_cap, const uint64_t *offsets, uint32_t own_begin,
+                                                uint32_t chunk_units, int by_start, void *out, uint64_t cap) {
     unsigned long long m = *counter;
-    if (m > cap) m = cap; // overflow: the host reports ACGPU_E_OVERFLOW; nothing useful is produced
+    if (m > scratch_cap) m = scratch_cap; // overflow: the host reports ACGPU_E_OVERFLOW; nothing useful is produced
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint4 raw = *reinterpret_cast<const uint4 *>(&scratch[i]);
         const int32_t start = (int32_t)raw.x, end = (int32_t)raw.y, id = (int32_t)raw.z;
         const uint32_t rank = raw.w;
+        if (rank == ~0u) continue; // hole left by a slot reservation
         // ordering unit: the chunk owning the match's last unit (ALL) or first unit (LONGEST/WHOLEWORD)
         const uint32_t key = by_start ? (uint32_t)start : (uint32_t)(end - 1);
         const uint32_t chunk = (key - own_begin) / chunk_units;
@@ -306,18 +307,20 @@ __global__ __launch_bounds__(256) void k_permute(const ScratchRec *scratch, cons
     }
 }
 
-hipError_t launch_permute(const ScratchRec *d_scratch, const unsigned long long *d_counter, uint64_t cap,
+hipError_t launch_permute(const ScratchRec *d_scratch, const unsigned long long *d_counter, uint64_t scratch_cap,
                           const uint64_t *d_offsets, uint32_t own_begin, uint32_t chunk_units, int by_start,
-                          int record_kind, void *d_out, hipStream_t stream) {
+                          int record_kind, void *d_out, uint64_t out_cap, hipStream_t stream) {
     const int grid = 2048;
     if (record_kind == ACGPU_REC_SET)
-        hipLaunchKernelGGL(k_permute<ACGPU_REC_SET>, dim3(grid), dim3(256), 0, stream, d_scratch, d_counter, cap, d_offsets,
-                           own_begin, chunk_units, by_start, d_out);
+        hipLaunchKernelGGL(k_permute<ACGPU_REC_SET>, dim3(grid), dim3(256), 0, stream, d_scratch, d_counter, scratch_cap,
+                           d_offsets, own_begin, chunk_units, by_start, d_out, out_cap);
     else
-        hipLaunchKernelGGL(k_permute<ACGPU_REC_MAP>, dim3(grid), dim3(256), 0, stream, d_scratch, d_counter, cap, d_offsets,
-                           own_begin, chunk_units, by_start, d_out);
+        hipLaunchKernelGGL(k_permute<ACGPU_REC_MAP>, dim3(grid), dim3(256), 0, stream, d_scratch, d_counter, scratch_cap,
+                           d_offsets, own_begin, chunk_units, by_start, d_out, out_cap);
     return hipGetLastError();
 }
+
+uint32_t scan_tiles_for(uint32_t n) { return (n + kScanTile - 1) / kScanTile; }
 
 // ---- synthetic haystack generator (ahocorasick_amd/synth.py is its numpy twin) ---------------
 struct SynthTable {

@@ -9,14 +9,16 @@
 //            ds_read_b32 per position, no dependence on any other position.
 //   verify : the few surviving positions (about 2 % on the 10k-keyword benchmark dictionary) are compacted,
 //            in text order, into a per-wave LDS queue; 64 at a time, one per lane, they walk the trie of REVERSED
-//            keywords leftwards from the depth-K node (hashed edges in HBM/L2), collecting every keyword that ends
-//            at e -- exactly the keywords on the reference's output chain of the state reached at e.
+//            keywords leftwards from the depth-K node (dense class-indexed rows, or hashed edges for huge
+//            alphabets; L2-resident), collecting every keyword that ends at e -- exactly the keywords on the
+//            reference's output chain of the state reached at e.
 //
 // Work distribution: a wave owns a contiguous REGION of the haystack and streams it as 512-unit tiles, lane l
-// holding units [8l, 8l+8) of the tile (one coalesced 1 KiB load per wave and tile).  Because a wave meets its
-// candidates in text order, a record's rank inside its region is a running wave-uniform count plus a wave prefix
-// sum; the finalize pass (prefix sum over regions + permutation) then yields the reference's emission order
-// (end ascending, longest first) without any sort.
+// holding units [8l, 8l+8) of the tile (one coalesced 1 KiB load per wave and tile, kPrefetch tiles in flight).
+// Because a wave meets its candidates in text order, a record's rank inside its region is a running wave-uniform
+// count plus a wave prefix sum; the finalize pass (prefix sum over regions + permutation) then yields the
+// reference's emission order (end ascending, longest first) without any sort.  Records go straight to HBM into
+// slots the wave reserves 256 at a time with one atomic.
 #include <hip/hip_runtime.h>
 
 #include "acgpu_device.h"
@@ -27,8 +29,11 @@ namespace acgpu {
 constexpr int kTileBlock = 1024;               // 16 waves share one LDS copy of the bitmap
 constexpr int kTileUnits = 512;                // units per wave tile (64 lanes x 8 units)
 constexpr int kCandCap = 64 + kTileUnits;      // a tile adds at most 512 candidates to fewer than 64 pending ones
+constexpr int kPrefetch = 4;                   // tiles in flight per wave
+constexpr uint32_t kReserve = 256;             // scratch slots a wave reserves per atomic
 
 int tile_block_threads() { return kTileBlock; }
+uint32_t tile_reserve_slots() { return kReserve; }
 
 size_t tile_lds_bytes(const DevTables &t, int block_threads) {
     return (size_t)t.filt_words * 4 + (size_t)(block_threads / kWave) * kCandCap * sizeof(uint2);
@@ -40,33 +45,53 @@ struct TileCtx {
     uint2 *cand;        // this wave's candidate queue in LDS: (pos, kgram index)
     uint32_t cand_n;    // wave-uniform
     uint32_t rank_base; // wave-uniform: records emitted so far in the current region
+    unsigned long long res_cur; // wave-uniform: next free reserved scratch slot
+    uint32_t res_left;          // wave-uniform: reserved slots left
 };
+
+__device__ __forceinline__ uint32_t tile_class(const DevTables &T, uint32_t unit) {
+    if (T.range_cls) return min(unit - T.cls_base, T.cls_span); // outside [base, base+span) -> span ("other")
+    return T.cls_lut[unit];
+}
+
+// flagged ref of the child of reverse-trie node `id` on the (raw) unit to its left, 0 = none
+__device__ __forceinline__ uint32_t rchild(const DevTables &T, uint32_t id, uint32_t unit) {
+    if (T.rdense) return T.rtab[id * T.filt_n + tile_class(T, unit)];
+    const uint32_t u = T.cs ? unit : (uint32_t)T.lower[unit];
+    const uint32_t r = hashed_goto(T.rhkeys, T.rhvals, T.rhmask, id, u);
+    return r == ~0u ? 0u : r;
+}
+
+__device__ __forceinline__ void store_rec(const TileLaunch &L, unsigned long long slot, uint32_t start, uint32_t end,
+                                          uint32_t id, uint32_t rank) {
+    if (slot < L.cap) {
+        const uint4 v = make_uint4(start, end, id, rank);
+        *reinterpret_cast<uint4 *>(&L.d_scratch[slot]) = v;
+    }
+}
 
 // Verification of up to 64 queued candidates, one per lane.  Every lane of the wave calls this.
 __device__ __forceinline__ void verify_batch(TileCtx &c, uint32_t head, uint32_t nb) {
     const DevTables &T = c.T;
+    const uint16_t *hay = c.L.d_hay;
     const uint32_t lane = lane_id();
     const bool act = lane < nb;
-    uint32_t e = 0, node = 0, m = 0, one_len = 0, one_id = 0;
+    uint32_t e = 0, m = 0, one_len = 0, one_node = 0, ref0 = 0;
     if (act) {
         const uint2 ent = c.cand[head + lane];
         e = ent.x + 1; // exclusive end
-        node = T.kgram_node[ent.y];
-        uint32_t d = T.filt_k;
+        ref0 = T.kgram_node[ent.y];
+        uint32_t ref = ref0, d = T.filt_k;
         // walk the reversed trie leftwards; every terminal node met is a keyword ending at e (increasing length)
         for (;;) {
-            const uint32_t info = T.rinfo[node];
-            if (info & 0x7fffffffu) {
+            if (ref & kRefTerminal) {
                 ++m;
                 one_len = d;
-                one_id = (info & 0x7fffffffu) - 1;
+                one_node = ref & kRefIdMask;
             }
-            if (!(info >> 31) || e <= d) break; // leaf, or the buffer starts here
-            uint32_t u = c.L.d_hay[e - 1 - d];
-            if (!T.cs) u = T.lower[u];
-            const uint32_t child = hashed_goto(T.rhkeys, T.rhvals, T.rhmask, node, u);
-            if (child == ~0u) break;
-            node = child;
+            if (!(ref & kRefHasChildren) || e <= d) break; // leaf, or the buffer starts here
+            ref = rchild(T, ref & kRefIdMask, hay[e - 1 - d]);
+            if (ref == 0) break;
             ++d;
         }
     }
@@ -74,39 +99,37 @@ __device__ __forceinline__ void verify_batch(TileCtx &c, uint32_t head, uint32_t
     const uint32_t total = __shfl(incl, kWave - 1);
     if (total == 0) return;
     const uint32_t prefix = incl - m;
-    unsigned long long gbase = 0;
-    if (lane == 0) gbase = atomicAdd(c.L.d_counter, (unsigned long long)total);
-    gbase = __shfl(gbase, 0);
-    if (m == 1) {
-        const unsigned long long slot = gbase + prefix;
-        if (slot < c.L.cap) {
-            ScratchRec r{(int32_t)(e - one_len), (int32_t)e, (int32_t)one_id, c.rank_base + prefix};
-            *reinterpret_cast<uint4 *>(&c.L.d_scratch[slot]) = *reinterpret_cast<const uint4 *>(&r);
-        }
+    // slot of the wave's k-th record of this batch: the tail of the current reservation, then a fresh one
+    const unsigned long long old_cur = c.res_cur;
+    const uint32_t old_left = c.res_left;
+    unsigned long long fresh = 0;
+    if (total > old_left) {
+        const uint32_t need = total - old_left;
+        const uint32_t take = need > kReserve ? need : kReserve;
+        if (lane == 0) fresh = atomicAdd(c.L.d_counter, (unsigned long long)take);
+        fresh = __shfl(fresh, 0);
+        c.res_cur = fresh + need;
+        c.res_left = take - need;
+    } else {
+        c.res_cur = old_cur + total;
+        c.res_left = old_left - total;
     }
+    auto slot_of = [&](uint32_t k) -> unsigned long long { return k < old_left ? old_cur + k : fresh + (k - old_left); };
+    if (m == 1) store_rec(c.L, slot_of(prefix), e - one_len, e, T.rterm[one_node], c.rank_base + prefix);
     if (__any(m >= 2)) {
         // several keywords end here: the reference reports the longest first (S/AhoCorasickSet.java:526-532), the walk
-        // meets them shortest first -> second walk, writing the j-th one met to slot (m-1-j)
+        // meets them shortest first -> second walk, giving the j-th one met the (m-1-j)-th place
         if (m >= 2) {
-            uint32_t node2 = T.kgram_node[c.cand[head + lane].y];
-            uint32_t d = T.filt_k, j = 0;
+            uint32_t ref = ref0, d = T.filt_k, j = 0;
             for (;;) {
-                const uint32_t info = T.rinfo[node2];
-                if (info & 0x7fffffffu) {
+                if (ref & kRefTerminal) {
                     const uint32_t k = prefix + (m - 1 - j);
-                    const unsigned long long slot = gbase + k;
-                    if (slot < c.L.cap) {
-                        ScratchRec r{(int32_t)(e - d), (int32_t)e, (int32_t)((info & 0x7fffffffu) - 1), c.rank_base + k};
-                        *reinterpret_cast<uint4 *>(&c.L.d_scratch[slot]) = *reinterpret_cast<const uint4 *>(&r);
-                    }
+                    store_rec(c.L, slot_of(k), e - d, e, T.rterm[ref & kRefIdMask], c.rank_base + k);
                     if (++j == m) break;
                 }
-                if (!(info >> 31) || e <= d) break;
-                uint32_t u = c.L.d_hay[e - 1 - d];
-                if (!T.cs) u = T.lower[u];
-                const uint32_t child = hashed_goto(T.rhkeys, T.rhvals, T.rhmask, node2, u);
-                if (child == ~0u) break;
-                node2 = child;
+                if (!(ref & kRefHasChildren) || e <= d) break;
+                ref = rchild(T, ref & kRefIdMask, hay[e - 1 - d]);
+                if (ref == 0) break;
                 ++d;
             }
         }
@@ -117,7 +140,7 @@ __device__ __forceinline__ void verify_batch(TileCtx &c, uint32_t head, uint32_t
 // drain the candidate queue down to fewer than `keep_below` entries (64 inside a region, 1 at its end)
 __device__ __forceinline__ void drain(TileCtx &c, uint32_t keep_below) {
     uint32_t head = 0;
-    while (c.cand_n - head >= keep_below && c.cand_n > head) {
+    while (c.cand_n > head && c.cand_n - head >= keep_below) {
         const uint32_t nb = min(c.cand_n - head, (uint32_t)kWave);
         verify_batch(c, head, nb);
         head += nb;
@@ -133,6 +156,25 @@ __device__ __forceinline__ void drain(TileCtx &c, uint32_t keep_below) {
     }
 }
 
+// value of x in lane-1; lane 0 receives `carry` (v_mov_b32_dpp wave_shr:1)
+__device__ __forceinline__ uint32_t from_prev_lane(uint32_t x, uint32_t carry) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)x, 0x138, 0xf, 0xf, false);
+}
+
+__device__ __forceinline__ uint4 load_tile(const TileLaunch &L, uint32_t v, uint32_t re) {
+    uint4 w = make_uint4(0, 0, 0, 0);
+    if (v < re) {
+        if (v + 8 <= L.n_units) {
+            w = *reinterpret_cast<const uint4 *>(L.d_hay + v);
+        } else { // tail of the buffer: never read past n_units
+            uint32_t tmp[4] = {0, 0, 0, 0};
+            for (uint32_t j = 0; j < 8 && v + j < L.n_units; ++j) tmp[j >> 1] |= (uint32_t)L.d_hay[v + j] << (16 * (j & 1));
+            w = make_uint4(tmp[0], tmp[1], tmp[2], tmp[3]);
+        }
+    }
+    return w;
+}
+
 template <int K>
 __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch L) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -144,19 +186,13 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
     const uint32_t lane = lane_id();
     const uint32_t wave_in_block = threadIdx.x / kWave;
     const uint32_t waves_total = gridDim.x * (kTileBlock / kWave);
-    TileCtx c{T, L, cand_all + wave_in_block * kCandCap, 0, 0};
+    TileCtx c{T, L, cand_all + wave_in_block * kCandCap, 0, 0, 0ull, 0};
 
     const uint32_t n = T.filt_n;
     uint32_t nK = 1;
 #pragma unroll
     for (int i = 0; i < K; ++i) nK *= n;
-    const bool range_cls = T.range_cls != 0;
-    const uint32_t cls_base = T.cls_base, cls_span = T.cls_span;
-    const uint16_t *cls_lut = T.cls_lut;
-    auto tcls = [&](uint32_t unit) -> uint32_t {
-        if (range_cls) return min(unit - cls_base, cls_span); // units outside [base, base+span) -> span ("other")
-        return cls_lut[unit];
-    };
+    constexpr int NP = K / 2; // dwords of the previous 8 units that hold the K-1 units before the lane's first one
 
     for (uint32_t region = blockIdx.x * (kTileBlock / kWave) + wave_in_block; region < L.n_regions; region += waves_total) {
         const uint32_t rb = L.own_begin + region * L.region_units;
@@ -165,68 +201,78 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
         c.rank_base = 0;
         c.cand_n = 0;
         // tiles start 16-byte aligned; units before rb belong to the previous region (or the halo) and are masked out
-        for (uint32_t tile = rb & ~7u; tile < re; tile += kTileUnits) {
-            const uint32_t v = tile + lane * 8;
-            uint32_t cur[8];
-            uint32_t prv[8]; // the 8 units before v (only the last K-1 are used)
-            {
-                uint4 w = make_uint4(0, 0, 0, 0), p = make_uint4(0, 0, 0, 0);
-                if (v < re) {
-                    if (v + 8 <= L.n_units) {
-                        w = *reinterpret_cast<const uint4 *>(L.d_hay + v);
-                    } else {
-                        uint32_t tmp[4] = {0, 0, 0, 0};
-                        for (uint32_t j = 0; j < 8 && v + j < L.n_units; ++j) tmp[j >> 1] |= (uint32_t)L.d_hay[v + j] << (16 * (j & 1));
-                        w = make_uint4(tmp[0], tmp[1], tmp[2], tmp[3]);
+        const uint32_t t0 = rb & ~7u;
+        // the 8 units before the first tile seed the cross-lane carry (zeros at the very start of the buffer)
+        uint32_t carry[4] = {0, 0, 0, 0};
+        if (K > 1 && t0 >= 8) {
+            const uint4 p = *reinterpret_cast<const uint4 *>(L.d_hay + t0 - 8);
+            carry[0] = p.x; carry[1] = p.y; carry[2] = p.z; carry[3] = p.w;
+        }
+        uint4 ring[kPrefetch];
+#pragma unroll
+        for (int d = 0; d < kPrefetch; ++d) ring[d] = load_tile(L, t0 + d * kTileUnits + lane * 8, re);
+
+        for (uint32_t tile0 = t0; tile0 < re; tile0 += kPrefetch * kTileUnits) {
+#pragma unroll
+            for (int d = 0; d < kPrefetch; ++d) {
+                const uint32_t tile = tile0 + d * kTileUnits;
+                if (tile >= re) break; // wave-uniform
+                const uint4 w = ring[d];
+                ring[d] = load_tile(L, tile + kPrefetch * kTileUnits + lane * 8, re);
+                const uint32_t v = tile + lane * 8;
+                const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+                // the previous lane's dwords give the K-1 units before v; lane 0 takes the previous tile's lane 63
+                uint32_t pp[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int q = 4 - NP; q < 4; ++q) {
+                    pp[q] = from_prev_lane(ww[q], carry[q]);
+                    carry[q] = __builtin_amdgcn_readlane(ww[q], 63);
+                }
+                // classes of units v-(K-1) .. v+7
+                uint32_t a[8 + K - 1];
+#pragma unroll
+                for (int j = 0; j < K - 1; ++j) {
+                    const int u = 8 - (K - 1) + j; // unit index inside the previous 8
+                    a[j] = tile_class(T, (pp[u >> 1] >> (16 * (u & 1))) & 0xffffu);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[K - 1 + j] = tile_class(T, (ww[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+                // K-gram index of position v+j (last unit least significant), rolling
+                uint32_t h = 0;
+#pragma unroll
+                for (int j = 0; j < K; ++j) h = h * n + a[j];
+                uint32_t mask = 0;
+                uint32_t idx[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (j > 0) h = h * n + a[K - 1 + j] - a[j - 1] * nK;
+                    idx[j] = h;
+                    const uint32_t pos = v + j;
+                    const uint32_t word = bits[h >> 5];
+                    const bool ok = ((word >> (h & 31)) & 1u) && pos >= rb && pos < re && pos + 1 >= (uint32_t)K;
+                    mask |= (ok ? 1u : 0u) << j;
+                }
+                // compaction in text order: lane-major, then position within the lane
+                const uint32_t cnt = __popc(mask);
+                const uint32_t incl = wave_inclusive_scan(cnt);
+                const uint32_t total = __shfl(incl, kWave - 1);
+                if (total) {
+                    uint32_t slot = c.cand_n + incl - cnt;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if (mask & (1u << j)) c.cand[slot++] = make_uint2(v + j, idx[j]);
                     }
-                    if (K > 1 && v >= 8) p = *reinterpret_cast<const uint4 *>(L.d_hay + v - 8);
+                    c.cand_n += total;
+                    __builtin_amdgcn_wave_barrier();
+                    if (c.cand_n >= kWave) drain(c, kWave);
                 }
-                const uint32_t ww[4] = {w.x, w.y, w.z, w.w}, pp[4] = {p.x, p.y, p.z, p.w};
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    cur[j] = (ww[j >> 1] >> (16 * (j & 1))) & 0xffffu;
-                    prv[j] = (pp[j >> 1] >> (16 * (j & 1))) & 0xffffu;
-                }
-            }
-            // classes of units v-(K-1) .. v+7
-            uint32_t a[8 + K - 1];
-#pragma unroll
-            for (int j = 0; j < K - 1; ++j) a[j] = tcls(prv[8 - (K - 1) + j]);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) a[K - 1 + j] = tcls(cur[j]);
-            // K-gram index of position v+j (last unit least significant), rolling
-            uint32_t h = 0;
-#pragma unroll
-            for (int j = 0; j < K; ++j) h = h * n + a[j];
-            uint32_t mask = 0;
-            uint32_t idx[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if (j > 0) h = h * n + a[K - 1 + j] - a[j - 1] * nK;
-                idx[j] = h;
-                const uint32_t pos = v + j;
-                const uint32_t word = bits[h >> 5];
-                const bool ok = ((word >> (h & 31)) & 1u) && pos >= rb && pos < re && pos + 1 >= (uint32_t)K;
-                mask |= (ok ? 1u : 0u) << j;
-            }
-            // compaction in text order: lane-major, then position within the lane
-            const uint32_t cnt = __popc(mask);
-            const uint32_t incl = wave_inclusive_scan(cnt);
-            const uint32_t total = __shfl(incl, kWave - 1);
-            if (total) {
-                uint32_t slot = c.cand_n + incl - cnt;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    if (mask & (1u << j)) c.cand[slot++] = make_uint2(v + j, idx[j]);
-                }
-                c.cand_n += total;
-                __builtin_amdgcn_wave_barrier();
-                if (c.cand_n >= kWave) drain(c, kWave);
             }
         }
         drain(c, 1);
         if (lane == 0) L.d_region_counts[region] = c.rank_base;
     }
+    // hand back the unused tail of the last reservation as holes the permute pass skips
+    for (uint32_t i = lane; i < c.res_left; i += kWave) store_rec(L, c.res_cur + i, 0, 0, 0, ~0u);
 }
 
 hipError_t launch_ac_tile(const DevTables &t, const TileLaunch &l, hipStream_t stream, const char **kernel_name) {
