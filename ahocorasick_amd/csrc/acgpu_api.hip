@@ -197,28 +197,35 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
     HIP_TRY(hipMemsetAsync(d.counter.p, 0, 64, stream));
     const char *kname = "";
     uint64_t scanned = 0;
-    uint32_t n_chunks = 0, chunk_units = 0;
+    uint32_t n_chunks = 0, chunk_units = 0, perm_base = (uint32_t)sh->own_begin;
     if (use_tile_kernel(t)) {
         TileLaunch L{};
         L.block = tile_block_threads();
         const int waves_per_block = L.block / 64;
         uint64_t R = tunables().region_units > 0 ? (uint64_t)tunables().region_units : 16384;
-        R = std::max<uint64_t>(512, (R + 511) / 512 * 512);
+        R = std::max<uint64_t>(2048, (R + 2047) / 2048 * 2048);
         L.region_units = (uint32_t)R;
-        L.n_regions = (uint32_t)((own_len + R - 1) / R);
-        L.grid = (int)std::min<uint64_t>((uint64_t)d.n_cu, ((uint64_t)L.n_regions + waves_per_block - 1) / waves_per_block);
+        const uint64_t base8 = sh->own_begin & ~7ull; // regions are laid out from the 16-byte aligned start
+        L.n_regions = (uint32_t)((sh->own_end - base8 + R - 1) / R);
+        const uint64_t waves_max = (uint64_t)d.n_cu * waves_per_block;
+        L.regions_per_wave = (uint32_t)((L.n_regions + waves_max - 1) / waves_max);
+        const uint64_t waves_used = ((uint64_t)L.n_regions + L.regions_per_wave - 1) / L.regions_per_wave;
+        L.grid = (int)((waves_used + waves_per_block - 1) / waves_per_block);
+        perm_base = (uint32_t)base8;
         L.d_hay = sh->d_hay;
         L.n_units = (uint32_t)sh->n_units;
         L.own_begin = (uint32_t)sh->own_begin;
         L.own_end = (uint32_t)sh->own_end;
         L.cap = scratch_cap;
         L.lds_bytes = tile_lds_bytes(d.T, L.block);
+        L.debug = (uint32_t)tunables().tile_debug;
         if ((rc = d.chunk_counts.ensure((size_t)L.n_regions * 4))) return rc;
         if ((rc = d.offsets.ensure((size_t)L.n_regions * 8))) return rc;
         if ((rc = d.scan_tmp.ensure(((size_t)L.n_regions / 2048 + 2) * 8))) return rc;
         L.d_scratch = (ScratchRec *)d.scratch.p;
         L.d_counter = (unsigned long long *)d.counter.p;
         L.d_region_counts = (uint32_t *)d.chunk_counts.p;
+        HIP_TRY(hipMemsetAsync(d.chunk_counts.p, 0, (size_t)L.n_regions * 4, stream));
         if (prof) HIP_TRY(hipEventRecord(d.ev[0], stream));
         HIP_TRY(launch_ac_tile(d.T, L, stream, &kname));
         if (prof) HIP_TRY(hipEventRecord(d.ev[1], stream));
@@ -259,7 +266,7 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
     HIP_TRY(launch_exclusive_scan((const uint32_t *)d.chunk_counts.p, n_chunks, (uint64_t *)d.offsets.p,
                                   (uint64_t *)d.scan_tmp.p, stream));
     HIP_TRY(launch_permute((const ScratchRec *)d.scratch.p, (const unsigned long long *)d.counter.p, scratch_cap,
-                           (const uint64_t *)d.offsets.p, (uint32_t)sh->own_begin, chunk_units,
+                           (const uint64_t *)d.offsets.p, perm_base, chunk_units,
                            /*by_start=*/0, record_kind, d_out, cap, stream));
     if (prof) HIP_TRY(hipEventRecord(d.ev[2], stream));
     // exact record count = grand total of the per-chunk counts (the slot counter also counts reservation holes)
@@ -335,6 +342,8 @@ int64_t acgpu_set_tunable(const char *name, int64_t value) {
     else if (!std::strcmp(name, "dense_budget_bytes")) slot = &t.dense_budget_bytes;
     else if (!std::strcmp(name, "force_kernel")) slot = &t.force_kernel;
     else if (!std::strcmp(name, "region_units")) slot = &t.region_units;
+    else if (!std::strcmp(name, "tile_debug")) slot = &t.tile_debug;
+    else if (!std::strcmp(name, "rdense_budget_bytes")) slot = &t.rdense_budget_bytes;
     else if (!std::strcmp(name, "filter_max_bits")) slot = &t.filter_max_bits;
     if (!slot) return -1;
     int64_t prev = *slot;

@@ -112,6 +112,7 @@ struct Tunables {
     int64_t force_kernel = 0;     // 0 auto, 1 = DFA chunk scan, 2 = k-gram tile scan (when the filter exists)
     int64_t region_units = 0;     // tile kernel: owned units per wave region (0 = auto)
     int64_t rdense_budget_bytes = 256ll << 20;
+    int64_t tile_debug = 0;       // ablation switches of the tile kernel (see TileLaunch::debug); 0 in production
     int64_t filter_max_bits = 690000;  // bitmap must fit LDS next to the candidate queues (86 KB)
 };
 Tunables &tunables();

@@ -36,14 +36,17 @@ hipError_t launch_ac_scan(const DevTables &t, const ScanLaunch &l, hipStream_t s
 struct TileLaunch {
     const uint16_t *d_hay;
     uint32_t n_units, own_begin, own_end;
-    uint32_t region_units; // multiple of 512
+    uint32_t region_units; // multiple of 2048 (the unrolled tile group); regions start at (own_begin & ~7) + r * region_units
     uint32_t n_regions;
+    uint32_t regions_per_wave; // a wave scans this many consecutive regions
     ScratchRec *d_scratch;
     uint64_t cap;
     unsigned long long *d_counter;
     uint32_t *d_region_counts;
     int grid, block;
     size_t lds_bytes;
+    uint32_t debug; // ablation switches (tunable "tile_debug"): 1 = drop candidates unverified,
+                    // 4 = no filter arithmetic at all (stream + reduce only).  Results are wrong when non-zero.
 };
 hipError_t launch_ac_tile(const DevTables &t, const TileLaunch &l, hipStream_t stream, const char **kernel_name);
 size_t tile_lds_bytes(const DevTables &t, int block_threads);

@@ -142,7 +142,7 @@ __device__ __forceinline__ void drain(TileCtx &c, uint32_t keep_below) {
     uint32_t head = 0;
     while (c.cand_n > head && c.cand_n - head >= keep_below) {
         const uint32_t nb = min(c.cand_n - head, (uint32_t)kWave);
-        verify_batch(c, head, nb);
+        if (!(c.L.debug & 1u)) verify_batch(c, head, nb);
         head += nb;
     }
     if (head) { // move the leftovers (fewer than 64) to the front
@@ -161,21 +161,33 @@ __device__ __forceinline__ uint32_t from_prev_lane(uint32_t x, uint32_t carry) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)x, 0x138, 0xf, 0xf, false);
 }
 
-__device__ __forceinline__ uint4 load_tile(const TileLaunch &L, uint32_t v, uint32_t re) {
-    uint4 w = make_uint4(0, 0, 0, 0);
-    if (v < re) {
-        if (v + 8 <= L.n_units) {
-            w = *reinterpret_cast<const uint4 *>(L.d_hay + v);
-        } else { // tail of the buffer: never read past n_units
-            uint32_t tmp[4] = {0, 0, 0, 0};
-            for (uint32_t j = 0; j < 8 && v + j < L.n_units; ++j) tmp[j >> 1] |= (uint32_t)L.d_hay[v + j] << (16 * (j & 1));
-            w = make_uint4(tmp[0], tmp[1], tmp[2], tmp[3]);
-        }
-    }
-    return w;
+template <bool RANGE>
+__device__ __forceinline__ uint32_t tile_class_t(const DevTables &T, uint32_t unit) {
+    if (RANGE) return min(unit - T.cls_base, T.cls_span);
+    return T.cls_lut[unit];
 }
 
-template <int K>
+// append this lane's candidates (bit j of mask: position v+j, K-gram index idx[j]) to the wave queue in text order
+__device__ __forceinline__ void enqueue(TileCtx &c, uint32_t mask, uint32_t v, const uint32_t (&idx)[8]) {
+    const uint32_t cnt = __popc(mask);
+    const uint32_t incl = wave_inclusive_scan(cnt);
+    const uint32_t total = __shfl(incl, kWave - 1);
+    if (total) {
+        uint32_t slot = c.cand_n + incl - cnt;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (mask & (1u << j)) c.cand[slot++] = make_uint2(v + j, idx[j]);
+        }
+        c.cand_n += total;
+        __builtin_amdgcn_wave_barrier();
+        if (c.cand_n >= kWave) drain(c, kWave);
+    }
+}
+
+// A wave owns a contiguous SPAN of regions.  Region boundaries sit at base8 + r * region_units (base8 = own_begin
+// rounded down to 8 units, region_units a multiple of 512), so a 512-unit tile never straddles two regions and the
+// tile stream -- with its kPrefetch-deep register ring and the cross-lane carry -- runs through the whole span.
+template <int K, bool RANGE>
 __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch L) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *bits = reinterpret_cast<uint32_t *>(smem);
@@ -185,7 +197,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
 
     const uint32_t lane = lane_id();
     const uint32_t wave_in_block = threadIdx.x / kWave;
-    const uint32_t waves_total = gridDim.x * (kTileBlock / kWave);
+    const uint32_t wave_global = blockIdx.x * (kTileBlock / kWave) + wave_in_block;
     TileCtx c{T, L, cand_all + wave_in_block * kCandCap, 0, 0, 0ull, 0};
 
     const uint32_t n = T.filt_n;
@@ -194,32 +206,55 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
     for (int i = 0; i < K; ++i) nK *= n;
     constexpr int NP = K / 2; // dwords of the previous 8 units that hold the K-1 units before the lane's first one
 
-    for (uint32_t region = blockIdx.x * (kTileBlock / kWave) + wave_in_block; region < L.n_regions; region += waves_total) {
-        const uint32_t rb = L.own_begin + region * L.region_units;
-        uint32_t re = rb + L.region_units;
-        if (re > L.own_end || re < rb) re = L.own_end;
-        c.rank_base = 0;
-        c.cand_n = 0;
-        // tiles start 16-byte aligned; units before rb belong to the previous region (or the halo) and are masked out
-        const uint32_t t0 = rb & ~7u;
-        // the 8 units before the first tile seed the cross-lane carry (zeros at the very start of the buffer)
+    const uint32_t first_region = wave_global * L.regions_per_wave;
+    if (first_region >= L.n_regions) return; // wave-uniform
+    const uint32_t last_region = min(first_region + L.regions_per_wave, L.n_regions);
+    const uint32_t base8 = L.own_begin & ~7u;
+    const uint32_t R = L.region_units;
+    const uint32_t span_begin = max(L.own_begin, base8 + first_region * R);
+    uint32_t span_end = base8 + last_region * R;
+    if (span_end > L.own_end || last_region == L.n_regions) span_end = L.own_end;
+    // full 16-byte vectors end at nfull; the (at most 7) units behind it are handled after the tile stream, so the
+    // stream's loads are unconditional (clamped address) and the compiler can use counted s_waitcnt vmcnt(N)
+    const uint32_t nfull = L.n_units & ~7u;
+    const uint32_t hi = min(span_end, nfull);
+    const uint32_t last_vec = nfull >= 8 ? nfull - 8 : 0;
+    const uint16_t *hay = L.d_hay;
+
+    uint32_t region = first_region;
+    uint32_t boundary = base8 + (region + 1) * R; // first tile of the next region
+    uint32_t rb = span_begin;
+    uint32_t re = min(span_end, boundary);
+    uint32_t tile = base8 + first_region * R;
+
+    if (tile < hi) {
         uint32_t carry[4] = {0, 0, 0, 0};
-        if (K > 1 && t0 >= 8) {
-            const uint4 p = *reinterpret_cast<const uint4 *>(L.d_hay + t0 - 8);
+        if (K > 1 && tile >= 8) {
+            const uint4 p = *reinterpret_cast<const uint4 *>(hay + tile - 8);
             carry[0] = p.x; carry[1] = p.y; carry[2] = p.z; carry[3] = p.w;
         }
         uint4 ring[kPrefetch];
 #pragma unroll
-        for (int d = 0; d < kPrefetch; ++d) ring[d] = load_tile(L, t0 + d * kTileUnits + lane * 8, re);
+        for (int d = 0; d < kPrefetch; ++d)
+            ring[d] = *reinterpret_cast<const uint4 *>(hay + min(tile + d * kTileUnits + lane * 8, last_vec));
 
-        for (uint32_t tile0 = t0; tile0 < re; tile0 += kPrefetch * kTileUnits) {
+        for (; tile < hi; tile += kPrefetch * kTileUnits) {
+            if (tile >= boundary) { // wave-uniform: the stream enters the next region (regions hold whole tile groups)
+                drain(c, 1);
+                if (lane == 0) L.d_region_counts[region] = c.rank_base;
+                c.rank_base = 0;
+                ++region;
+                rb = boundary;
+                boundary += R;
+                re = min(span_end, boundary);
+            }
 #pragma unroll
             for (int d = 0; d < kPrefetch; ++d) {
-                const uint32_t tile = tile0 + d * kTileUnits;
-                if (tile >= re) break; // wave-uniform
+                const uint32_t cur = tile + d * kTileUnits;
+                if (cur >= hi) break; // wave-uniform
                 const uint4 w = ring[d];
-                ring[d] = load_tile(L, tile + kPrefetch * kTileUnits + lane * 8, re);
-                const uint32_t v = tile + lane * 8;
+                ring[d] = *reinterpret_cast<const uint4 *>(hay + min(cur + kPrefetch * kTileUnits + lane * 8, last_vec));
+                const uint32_t v = cur + lane * 8;
                 const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
                 // the previous lane's dwords give the K-1 units before v; lane 0 takes the previous tile's lane 63
                 uint32_t pp[4] = {0, 0, 0, 0};
@@ -228,63 +263,92 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                     pp[q] = from_prev_lane(ww[q], carry[q]);
                     carry[q] = __builtin_amdgcn_readlane(ww[q], 63);
                 }
-                // classes of units v-(K-1) .. v+7
-                uint32_t a[8 + K - 1];
-#pragma unroll
-                for (int j = 0; j < K - 1; ++j) {
-                    const int u = 8 - (K - 1) + j; // unit index inside the previous 8
-                    a[j] = tile_class(T, (pp[u >> 1] >> (16 * (u & 1))) & 0xffffu);
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) a[K - 1 + j] = tile_class(T, (ww[j >> 1] >> (16 * (j & 1))) & 0xffffu);
-                // K-gram index of position v+j (last unit least significant), rolling
-                uint32_t h = 0;
-#pragma unroll
-                for (int j = 0; j < K; ++j) h = h * n + a[j];
                 uint32_t mask = 0;
                 uint32_t idx[8];
+                if (L.debug & 4u) { // ablation: stream only
+                    const uint32_t x = ww[0] ^ ww[1] ^ ww[2] ^ ww[3];
+                    mask = (x == 0x12345678u) ? 1u : 0u;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    if (j > 0) h = h * n + a[K - 1 + j] - a[j - 1] * nK;
-                    idx[j] = h;
-                    const uint32_t pos = v + j;
-                    const uint32_t word = bits[h >> 5];
-                    const bool ok = ((word >> (h & 31)) & 1u) && pos >= rb && pos < re && pos + 1 >= (uint32_t)K;
-                    mask |= (ok ? 1u : 0u) << j;
-                }
-                // compaction in text order: lane-major, then position within the lane
-                const uint32_t cnt = __popc(mask);
-                const uint32_t incl = wave_inclusive_scan(cnt);
-                const uint32_t total = __shfl(incl, kWave - 1);
-                if (total) {
-                    uint32_t slot = c.cand_n + incl - cnt;
+                    for (int j = 0; j < 8; ++j) idx[j] = 0;
+                } else {
+                    // classes of units v-(K-1) .. v+7
+                    uint32_t a[8 + K - 1];
+#pragma unroll
+                    for (int j = 0; j < K - 1; ++j) {
+                        const int u = 8 - (K - 1) + j; // unit index inside the previous 8
+                        a[j] = tile_class_t<RANGE>(T, (pp[u >> 1] >> (16 * (u & 1))) & 0xffffu);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) a[K - 1 + j] = tile_class_t<RANGE>(T, (ww[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+                    // K-gram index of position v+j (last unit least significant), rolling; every factor is < 2^24, so
+                    // the full-rate 24-bit multiplies are exact modulo 2^32
+                    uint32_t h = 0;
+#pragma unroll
+                    for (int j = 0; j < K; ++j) h = __umul24(h, n) + a[j];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        if (mask & (1u << j)) c.cand[slot++] = make_uint2(v + j, idx[j]);
+                        if (j > 0) h = __umul24(h, n) + a[K - 1 + j] - __umul24(a[j - 1], nK);
+                        idx[j] = h;
+                        const uint32_t word = bits[h >> 5];
+                        mask |= __builtin_amdgcn_ubfe(word, h, 1) << j; // v_bfe_u32 takes the bit offset from h[4:0]
                     }
-                    c.cand_n += total;
-                    __builtin_amdgcn_wave_barrier();
-                    if (c.cand_n >= kWave) drain(c, kWave);
+                    // positions this lane may report: inside the region, in the vector part of the buffer, and with K
+                    // units to their left in the buffer
+                    const uint32_t lo = max(rb, (uint32_t)(K - 1));
+                    const uint32_t top = min(re, hi);
+                    const uint32_t first = lo > v ? min(lo - v, 8u) : 0u;
+                    const uint32_t last = top > v ? min(top - v, 8u) : 0u;
+                    mask &= ((1u << last) - 1u) & ~((1u << first) - 1u);
                 }
+                enqueue(c, mask, v, idx);
             }
         }
-        drain(c, 1);
-        if (lane == 0) L.d_region_counts[region] = c.rank_base;
     }
+    // the units behind the last full vector of the buffer (fewer than 8), if this span owns them
+    if (span_end > nfull) {
+        const uint32_t t0 = max(nfull, span_begin);
+        if (t0 >= boundary) { // they open a new region
+            drain(c, 1);
+            if (lane == 0) L.d_region_counts[region] = c.rank_base;
+            c.rank_base = 0;
+            ++region;
+        }
+        const uint32_t pos = t0 + lane;
+        uint32_t mask = 0;
+        uint32_t idx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (pos < span_end && pos + 1 >= (uint32_t)K && !(L.debug & 4u)) {
+            uint32_t h = 0;
+            for (int j = K - 1; j >= 0; --j) h = __umul24(h, n) + tile_class_t<RANGE>(T, hay[pos - j]);
+            idx[0] = h;
+            mask = (bits[h >> 5] >> (h & 31)) & 1u;
+        }
+        enqueue(c, mask, pos, idx); // one position per lane: lane order is text order
+    }
+    drain(c, 1);
+    if (lane == 0) L.d_region_counts[region] = c.rank_base;
     // hand back the unused tail of the last reservation as holes the permute pass skips
     for (uint32_t i = lane; i < c.res_left; i += kWave) store_rec(L, c.res_cur + i, 0, 0, 0, ~0u);
 }
 
+template <int K, bool RANGE>
+static hipError_t launch_tile_variant(const DevTables &t, const TileLaunch &l, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ac_tile<K, RANGE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_ac_tile<K, RANGE>), dim3(l.grid), dim3(l.block), l.lds_bytes, stream, t, l);
+    return hipGetLastError();
+}
+
 hipError_t launch_ac_tile(const DevTables &t, const TileLaunch &l, hipStream_t stream, const char **kernel_name) {
-#define ACGPU_TILE_CASE(KK)                                                                                             \
-    case KK: {                                                                                                          \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ac_tile<KK>),                              \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds_bytes);               \
-        if (e != hipSuccess) return e;                                                                                  \
-        hipLaunchKernelGGL(k_ac_tile<KK>, dim3(l.grid), dim3(l.block), l.lds_bytes, stream, t, l);                      \
-        if (kernel_name) *kernel_name = "k_ac_tile<" #KK ">";                                                           \
-        break;                                                                                                          \
-    }
+    static const char *const names[2][9] = {
+        {"", "k_ac_tile<1, false>", "k_ac_tile<2, false>", "k_ac_tile<3, false>", "k_ac_tile<4, false>", "k_ac_tile<5, false>",
+         "k_ac_tile<6, false>", "k_ac_tile<7, false>", "k_ac_tile<8, false>"},
+        {"", "k_ac_tile<1, true>", "k_ac_tile<2, true>", "k_ac_tile<3, true>", "k_ac_tile<4, true>", "k_ac_tile<5, true>",
+         "k_ac_tile<6, true>", "k_ac_tile<7, true>", "k_ac_tile<8, true>"}};
+    if (t.filt_k < 1 || t.filt_k > 8) return hipErrorInvalidValue;
+    if (kernel_name) *kernel_name = names[t.range_cls ? 1 : 0][t.filt_k];
+#define ACGPU_TILE_CASE(KK) \
+    case KK: return t.range_cls ? launch_tile_variant<KK, true>(t, l, stream) : launch_tile_variant<KK, false>(t, l, stream);
     switch (t.filt_k) {
         ACGPU_TILE_CASE(1)
         ACGPU_TILE_CASE(2)
@@ -297,7 +361,6 @@ hipError_t launch_ac_tile(const DevTables &t, const TileLaunch &l, hipStream_t s
     default: return hipErrorInvalidValue;
     }
 #undef ACGPU_TILE_CASE
-    return hipGetLastError();
 }
 
 } // namespace acgpu

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Kernel A/B harness (development tool): times the ALL-mode scan of BASELINE config 2 under several tunable
+settings in ONE process, interleaved rounds, and prints median/min kernel ms per variant."""
+import argparse
+import ctypes
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--units-log2", type=int, default=29)
+    ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--variants", type=str, default="")
+    args = ap.parse_args()
+    import torch
+    from ahocorasick_amd import _native as N, synth
+    from ahocorasick_amd.strings import Automaton
+
+    n = 1 << args.units_log2
+    kws = synth.config_keywords("C2")
+    a = Automaton(N.MODE_ALL, kws, True)
+    d_hay = torch.empty(n, dtype=torch.int16, device="cuda")
+    tab = np.ascontiguousarray(synth.ALPHA_LOWER)
+    N.check(N.lib().acgpu_synth_fill(d_hay.data_ptr(), n, 0, 2002, tab.ctypes.data_as(ctypes.c_void_p), len(tab), None), "synth")
+    torch.cuda.synchronize()
+    cap = n // 128
+    d_out = torch.empty((cap, 3), dtype=torch.int32, device="cuda")
+    variants = json.loads(args.variants) if args.variants else {
+        "tile": {}, "tile_noverify": {"tile_debug": 1}, "tile_nolds": {"tile_debug": 3}, "tile_stream": {"tile_debug": 5},
+        "dfa": {"force_kernel": 1}}
+    defaults = {"force_kernel": 0, "tile_debug": 0, "region_units": 0, "chunk_units": 0, "lds_table_bytes": 96 * 1024,
+                "blocks_per_cu": 1}
+    res = {k: [] for k in variants}
+    info = {}
+    for r in range(args.rounds + 1):
+        for name, knobs in variants.items():
+            for k, v in defaults.items():
+                N.set_tunable(k, v)
+            for k, v in knobs.items():
+                N.set_tunable(k, v)
+            nout, rc, prof, _ = a.match_device(d_hay.data_ptr(), n, True, d_out.data_ptr(), cap,
+                                               stream=torch.cuda.current_stream().cuda_stream, profile=True)
+            if r > 0:
+                res[name].append(prof["scan_ms"])
+            info[name] = (nout, rc, prof["scan_kernel"], prof["finalize_ms"])
+    for name in variants:
+        t = np.array(res[name])
+        gb = 2 * n / 1e9
+        print("%-18s median %.4f ms  min %.4f ms  (%.0f GB/s)  n_out=%d rc=%d %s fin=%.3f" % (
+            name, np.median(t), t.min(), gb / (np.median(t) * 1e-3), info[name][0], info[name][1], info[name][2], info[name][3]))
+
+
+if __name__ == "__main__":
+    main()
