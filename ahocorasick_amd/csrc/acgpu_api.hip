@@ -150,7 +150,7 @@ int ensure_device(acgpu_automaton *a, DeviceState **out) {
     if ((rc = upload(*d, t.rhkeys, &T.rhkeys))) return rc;
     if ((rc = upload(*d, t.rhvals, &T.rhvals))) return rc;
     T.rhmask = t.rhmask; T.filt_k = t.filt_k; T.filt_n = t.filt_n; T.filt_other = t.filt_other;
-    T.filt_words = (uint32_t)t.filt_bits.size();
+    T.filt_words = (uint32_t)t.filt_bits.size(); T.filt_row_bytes = t.filt_row_bytes;
     T.hmask = t.hmask;
     T.n_states = t.n_states; T.n_cls = t.n_cls; T.first_out = t.first_out; T.max_len = t.max_len; T.min_len = t.min_len;
     T.cls_base = t.cls_base; T.cls_span = t.cls_span; T.range_cls = t.range_cls; T.cs = t.cs; T.dense = t.dense;
@@ -344,7 +344,7 @@ int64_t acgpu_set_tunable(const char *name, int64_t value) {
     else if (!std::strcmp(name, "region_units")) slot = &t.region_units;
     else if (!std::strcmp(name, "tile_debug")) slot = &t.tile_debug;
     else if (!std::strcmp(name, "rdense_budget_bytes")) slot = &t.rdense_budget_bytes;
-    else if (!std::strcmp(name, "filter_max_bits")) slot = &t.filter_max_bits;
+    else if (!std::strcmp(name, "filter_max_bytes")) slot = &t.filter_max_bytes;
     if (!slot) return -1;
     int64_t prev = *slot;
     *slot = value;

@@ -258,24 +258,32 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
     }
 
     // ---- 7. suffix K-gram filter + reversed trie (ALL mode) ----
+    // Filter layout: one ROW per (K-1)-gram of tile classes (the K-1 units before the last one), one BIT per class of
+    // the last unit; rows are 4 bytes (n <= 32 classes) or 8 bytes (n <= 64).  A position survives iff its K-gram is
+    // the K-suffix of some keyword (K <= shortest keyword, so every keyword has one).
     t.filt_k = 0;
-    if (mode == ACGPU_MODE_ALL && t.n_cls > 1 && t.min_len >= 1 && !t.cls_lut.empty()) {
+    if (mode == ACGPU_MODE_ALL && t.n_cls > 1 && t.n_cls <= 64 && t.min_len >= 1) {
         // tile classes: range mode -> min(unit - base, span) (other = span); LUT mode -> cls_lut (other = 0)
         const uint32_t n = t.n_cls;
         t.filt_n = n;
         t.filt_other = t.range_cls ? t.cls_span : 0;
+        t.filt_row_bytes = n <= 32 ? 4 : 8;
         auto tcls = [&](uint16_t folded_unit) -> uint32_t {
             if (t.range_cls) return (uint32_t)folded_unit - t.cls_base; // only called on keyword units: inside the range
             return cls_of[folded_unit];
         };
-        uint32_t K = 0;
-        uint64_t pw = 1;
-        while (K < t.min_len && K < 8 && pw * n <= (uint64_t)tunables().filter_max_bits) { pw *= n; K++; }
-        if (K >= 1) {
+        uint32_t K = 1;
+        uint64_t rows = 1; // n^(K-1)
+        while (K < t.min_len && K < 8 && rows * n * t.filt_row_bytes <= (uint64_t)tunables().filter_max_bytes &&
+               rows * n * n < (1ull << 24)) {
+            rows *= n;
+            K++;
+        }
+        {
             // reversed trie: walking a terminal node's parent chain in the forward trie spells the reversed keyword
-            struct RNode { uint32_t parent; uint16_t unit; uint32_t depth; uint32_t kw; bool has_child; };
+            struct RNode { uint32_t parent; uint16_t unit; uint32_t depth; uint32_t kw; uint32_t n_child; uint32_t only_child; };
             std::vector<RNode> rn;
-            rn.push_back({0, 0, 0, ~0u, false});
+            rn.push_back({0, 0, 0, ~0u, 0, 0});
             std::unordered_map<uint64_t, uint32_t> redge;
             redge.reserve(N * 2);
             for (uint32_t s = 1; s < N; s++) {
@@ -286,8 +294,9 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
                     auto it = redge.find(key);
                     if (it == redge.end()) {
                         uint32_t id = (uint32_t)rn.size();
-                        rn.push_back({cur, nodes[p].unit, rn[cur].depth + 1, ~0u, false});
-                        rn[cur].has_child = true;
+                        rn.push_back({cur, nodes[p].unit, rn[cur].depth + 1, ~0u, 0, 0});
+                        rn[cur].n_child++;
+                        rn[cur].only_child = id;
                         redge.emplace(key, id);
                         cur = id;
                     } else {
@@ -297,54 +306,64 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
                 rn[cur].kw = nodes[s].kw;
             }
             const uint32_t RN = (uint32_t)rn.size();
-            if (RN > kRefIdMask) return ACGPU_E_UNSUPPORTED;
-            t.n_rstates = RN;
-            t.rterm.assign(RN, ~0u);
-            auto ref = [&](uint32_t i) -> uint32_t {
-                return i | (rn[i].has_child ? kRefHasChildren : 0u) | (rn[i].kw != ~0u ? kRefTerminal : 0u);
-            };
-            for (uint32_t i = 0; i < RN; i++) t.rterm[i] = rn[i].kw;
-            t.rdense = (uint64_t)RN * n * 4 <= (uint64_t)tunables().rdense_budget_bytes && !tunables().force_sparse;
-            if (t.rdense) {
-                t.rtab.assign((size_t)RN * n, 0);
-                for (uint32_t i = 1; i < RN; i++) t.rtab[(size_t)rn[i].parent * n + tcls(rn[i].unit)] = ref(i);
-                t.rhkeys.assign(16, kEmptyKey);
-                t.rhvals.assign(16, 0);
-                t.rhmask = 15;
-            } else {
-                uint64_t cap = 16;
-                while (cap < 2 * (uint64_t)RN + 2) cap <<= 1;
-                t.rhkeys.assign(cap, kEmptyKey);
-                t.rhvals.assign(cap, 0);
-                t.rhmask = (uint32_t)(cap - 1);
-                for (uint32_t i = 1; i < RN; i++) {
-                    uint64_t key = edge_key(rn[i].parent, rn[i].unit);
-                    uint32_t slot = edge_hash(key) & t.rhmask;
-                    while (t.rhkeys[slot] != kEmptyKey) slot = (slot + 1) & t.rhmask;
-                    t.rhkeys[slot] = key;
-                    t.rhvals[slot] = ref(i);
+            if (RN <= kRefIdMask) {
+                t.n_rstates = RN;
+                t.rterm.assign(RN, ~0u);
+                // flagged reference: children / terminal flags, and for a node with exactly one child the class of that
+                // child's unit (+1) as a hint: a walk whose next unit has another class stops without touching memory
+                auto ref = [&](uint32_t i) -> uint32_t {
+                    uint32_t r = i | (rn[i].n_child ? kRefHasChildren : 0u) | (rn[i].kw != ~0u ? kRefTerminal : 0u);
+                    if (rn[i].n_child == 1) {
+                        uint32_t c = tcls(rn[rn[i].only_child].unit);
+                        if (c + 1 < 64) r |= (c + 1) << kRefHintShift;
+                    }
+                    return r;
+                };
+                for (uint32_t i = 0; i < RN; i++) t.rterm[i] = rn[i].kw;
+                t.rdense = (uint64_t)RN * n * 4 <= (uint64_t)tunables().rdense_budget_bytes && !tunables().force_sparse;
+                if (t.rdense) {
+                    t.rtab.assign((size_t)RN * n, 0);
+                    for (uint32_t i = 1; i < RN; i++) t.rtab[(size_t)rn[i].parent * n + tcls(rn[i].unit)] = ref(i);
+                    t.rhkeys.assign(16, kEmptyKey);
+                    t.rhvals.assign(16, 0);
+                    t.rhmask = 15;
+                } else {
+                    uint64_t cap = 16;
+                    while (cap < 2 * (uint64_t)RN + 2) cap <<= 1;
+                    t.rhkeys.assign(cap, kEmptyKey);
+                    t.rhvals.assign(cap, 0);
+                    t.rhmask = (uint32_t)(cap - 1);
+                    for (uint32_t i = 1; i < RN; i++) {
+                        uint64_t key = edge_key(rn[i].parent, rn[i].unit);
+                        uint32_t slot = edge_hash(key) & t.rhmask;
+                        while (t.rhkeys[slot] != kEmptyKey) slot = (slot + 1) & t.rhmask;
+                        t.rhkeys[slot] = key;
+                        t.rhvals[slot] = ref(i);
+                    }
                 }
-            }
-            // K-gram bitmap and K-gram -> depth-K reverse node
-            t.filt_bits.assign((pw + 31) / 32, 0);
-            t.kgram_node.assign(pw, 0);
-            uint64_t n_set = 0;
-            for (uint32_t i = 1; i < RN; i++) {
-                if (rn[i].depth != K) continue;
-                // path root -> i spells text[e-1], text[e-2], ..., text[e-K]; index has text[e-1] least significant
-                uint64_t idx = 0, mul = 1;
+                // rows of the filter and K-gram -> depth-K reverse node (index: last unit least significant)
+                t.filt_bits.assign(rows * (t.filt_row_bytes / 4), 0);
+                t.kgram_node.assign(rows * n, 0);
+                uint64_t n_set = 0;
                 std::vector<uint32_t> path;
-                for (uint32_t p = i; p != 0; p = rn[p].parent) path.push_back(tcls(rn[p].unit));
-                // path is now [text[e-K], ..., text[e-1]] (deepest first)
-                for (size_t j = path.size(); j-- > 0;) { idx += mul * path[j]; mul *= n; }
-                t.filt_bits[idx >> 5] |= 1u << (idx & 31);
-                t.kgram_node[idx] = ref(i);
-                n_set++;
+                for (uint32_t i = 1; i < RN; i++) {
+                    if (rn[i].depth != K) continue;
+                    // root -> i spells text[e-1], text[e-2], ..., text[e-K]; walking up from i meets them deepest first
+                    path.clear();
+                    for (uint32_t p = i; p != 0; p = rn[p].parent) path.push_back(tcls(rn[p].unit)); // [text[e-K] .. text[e-1]]
+                    uint64_t hi = 0;
+                    for (size_t j = 0; j + 1 < path.size(); j++) hi = hi * n + path[j];
+                    const uint32_t last = path.back();
+                    if (t.filt_row_bytes == 4) t.filt_bits[hi] |= 1u << last;
+                    else t.filt_bits[hi * 2 + (last >> 5)] |= 1u << (last & 31);
+                    t.kgram_node[hi * n + last] = ref(i);
+                    n_set++;
+                }
+                double denom = 1;
+                for (uint32_t j = 0; j < K; j++) denom *= (double)(n > 1 ? n - 1 : 1);
+                t.filt_density = (double)n_set / denom;
+                t.filt_k = K;
             }
-            double denom = 1;
-            for (uint32_t j = 0; j < K; j++) denom *= (double)(n > 1 ? n - 1 : 1);
-            t.filt_density = (double)n_set / denom;
-            t.filt_k = K;
         }
     }
     return ACGPU_OK;

@@ -10,7 +10,8 @@
 namespace acgpu {
 
 constexpr uint64_t kEmptyKey = ~0ull;
-constexpr uint32_t kRefHasChildren = 0x80000000u, kRefTerminal = 0x40000000u, kRefIdMask = 0x3fffffffu;
+constexpr uint32_t kRefHasChildren = 0x80000000u, kRefTerminal = 0x40000000u, kRefIdMask = 0x00ffffffu;
+constexpr uint32_t kRefHintShift = 24, kRefHintMask = 0x3fu; // class+1 of an only child, 0 = no hint
 
 // 64-bit finaliser (splitmix) used for the hashed goto edges; identical on host and device.
 #if defined(__HIPCC__)
@@ -65,9 +66,11 @@ struct HostTables {
     uint32_t filt_n = 0;      // tile classes (radix of the K-gram index)
     uint32_t filt_other = 0;  // tile class of a unit that occurs in no keyword
     double filt_density = 0;  // set bits / (filt_n-1)^K
-    std::vector<uint32_t> filt_bits;   // ceil(filt_n^K / 32) words
-    // Reverse-trie node references carry two flags so that the common verification walk needs no per-node load:
-    // bit31 = node has children, bit30 = node is terminal (a keyword ends... starts here); low 30 bits = node id.
+    std::vector<uint32_t> filt_bits;   // filt_n^(K-1) rows of filt_row_bytes
+    // Reverse-trie node references carry flags so that the common verification walk needs no per-node load:
+    // bit31 = node has children, bit30 = node is terminal (a keyword starts here), bits 29..24 = only-child class hint,
+    // low 24 bits = node id.
+    uint32_t filt_row_bytes = 4;
     std::vector<uint32_t> kgram_node;  // filt_n^K entries: flagged ref of the depth-K node, 0 = none
     std::vector<uint32_t> rterm;       // per reverse node: keyword id (valid when the terminal flag is set)
     bool rdense = false;
@@ -99,7 +102,7 @@ struct DevTables {
     const uint32_t *filt_bits, *kgram_node, *rterm, *rtab;
     const uint64_t *rhkeys;
     const uint32_t *rhvals;
-    uint32_t rhmask, filt_k, filt_n, filt_other, filt_words;
+    uint32_t rhmask, filt_k, filt_n, filt_other, filt_words, filt_row_bytes;
     int32_t rdense;
 };
 
@@ -113,7 +116,7 @@ struct Tunables {
     int64_t region_units = 0;     // tile kernel: owned units per wave region (0 = auto)
     int64_t rdense_budget_bytes = 256ll << 20;
     int64_t tile_debug = 0;       // ablation switches of the tile kernel (see TileLaunch::debug); 0 in production
-    int64_t filter_max_bits = 690000;  // bitmap must fit LDS next to the candidate queues (86 KB)
+    int64_t filter_max_bytes = 88000;  // the filter rows must fit LDS next to the candidate queues
 };
 Tunables &tunables();
 

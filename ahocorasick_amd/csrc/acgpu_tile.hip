@@ -21,32 +21,38 @@
 // slots the wave reserves 256 at a time with one atomic.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+
 #include "acgpu_device.h"
 #include "acgpu_kernels.h"
 
 namespace acgpu {
 
-constexpr int kTileBlock = 1024;               // 16 waves share one LDS copy of the bitmap
+constexpr int kTileBlock = 1024;               // 16 waves share one LDS copy of the filter rows
 constexpr int kTileUnits = 512;                // units per wave tile (64 lanes x 8 units)
 constexpr int kCandCap = 64 + kTileUnits;      // a tile adds at most 512 candidates to fewer than 64 pending ones
-constexpr int kPrefetch = 4;                   // tiles in flight per wave
+constexpr int kPrefetch = 4;                   // tiles per group; one group of loads is in flight per wave
 constexpr uint32_t kReserve = 256;             // scratch slots a wave reserves per atomic
 
 int tile_block_threads() { return kTileBlock; }
 uint32_t tile_reserve_slots() { return kReserve; }
 
 size_t tile_lds_bytes(const DevTables &t, int block_threads) {
-    return (size_t)t.filt_words * 4 + (size_t)(block_threads / kWave) * kCandCap * sizeof(uint2);
+    return (size_t)t.filt_words * 4 + (size_t)(block_threads / kWave) * kCandCap * sizeof(uint32_t);
 }
 
 struct TileCtx {
     const DevTables &T;
     const TileLaunch &L;
-    uint2 *cand;        // this wave's candidate queue in LDS: (pos, kgram index)
+    uint32_t *cand;     // this wave's candidate queue in LDS: end positions (last unit index), in text order
     uint32_t cand_n;    // wave-uniform
     uint32_t rank_base; // wave-uniform: records emitted so far in the current region
     unsigned long long res_cur; // wave-uniform: next free reserved scratch slot
     uint32_t res_left;          // wave-uniform: reserved slots left
+};
+
+struct __attribute__((packed, aligned(2))) Units8 { // 8 UTF-16 units at any unit address (one global_load_dwordx4)
+    uint32_t d[4];
 };
 
 __device__ __forceinline__ uint32_t tile_class(const DevTables &T, uint32_t unit) {
@@ -54,9 +60,9 @@ __device__ __forceinline__ uint32_t tile_class(const DevTables &T, uint32_t unit
     return T.cls_lut[unit];
 }
 
-// flagged ref of the child of reverse-trie node `id` on the (raw) unit to its left, 0 = none
-__device__ __forceinline__ uint32_t rchild(const DevTables &T, uint32_t id, uint32_t unit) {
-    if (T.rdense) return T.rtab[id * T.filt_n + tile_class(T, unit)];
+// flagged ref of the child of reverse-trie node `id` whose edge is `unit` (raw) / class `cls`, 0 = none
+__device__ __forceinline__ uint32_t rchild(const DevTables &T, uint32_t id, uint32_t unit, uint32_t cls) {
+    if (T.rdense) return T.rtab[id * T.filt_n + cls];
     const uint32_t u = T.cs ? unit : (uint32_t)T.lower[unit];
     const uint32_t r = hashed_goto(T.rhkeys, T.rhvals, T.rhmask, id, u);
     return r == ~0u ? 0u : r;
@@ -70,18 +76,43 @@ __device__ __forceinline__ void store_rec(const TileLaunch &L, unsigned long lon
     }
 }
 
+// One step of the leftward walk from a flagged node ref: returns the child's ref or 0.  The only-child hint lets a
+// mismatching unit end the walk without a memory access.
+__device__ __forceinline__ uint32_t walk_step(const DevTables &T, uint32_t ref, uint32_t unit) {
+    const uint32_t cls = tile_class(T, unit);
+    const uint32_t hint = (ref >> kRefHintShift) & kRefHintMask;
+    if (hint != 0 && hint - 1 != cls) return 0;
+    return rchild(T, ref & kRefIdMask, unit, cls);
+}
+
 // Verification of up to 64 queued candidates, one per lane.  Every lane of the wave calls this.
 __device__ __forceinline__ void verify_batch(TileCtx &c, uint32_t head, uint32_t nb) {
     const DevTables &T = c.T;
     const uint16_t *hay = c.L.d_hay;
     const uint32_t lane = lane_id();
+    const uint32_t K = T.filt_k;
     const bool act = lane < nb;
     uint32_t e = 0, m = 0, one_len = 0, one_node = 0, ref0 = 0;
+    uint32_t win[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // units e-8 .. e-1 (zeros before the buffer start)
     if (act) {
-        const uint2 ent = c.cand[head + lane];
-        e = ent.x + 1; // exclusive end
-        ref0 = T.kgram_node[ent.y];
-        uint32_t ref = ref0, d = T.filt_k;
+        const uint32_t pos = c.cand[head + lane];
+        e = pos + 1; // exclusive end
+        if (e >= 8) {
+            const Units8 u = *reinterpret_cast<const Units8 *>(hay + e - 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) win[j] = (u.d[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+        } else {
+            for (uint32_t j = 0; j < e; ++j) win[8 - e + j] = hay[j];
+        }
+        // K-gram index (last unit least significant) -> flagged ref of the depth-K node of the reversed trie
+        uint32_t idx = 0, left_unit = 0; // left_unit: the unit just left of the K-gram (first step of the walk)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j >= 8 - (int)K) idx = idx * T.filt_n + tile_class(T, win[j]);
+            if (j == 7 - (int)K) left_unit = win[j];
+        }
+        ref0 = T.kgram_node[idx];
+        uint32_t ref = ref0, d = K;
         // walk the reversed trie leftwards; every terminal node met is a keyword ending at e (increasing length)
         for (;;) {
             if (ref & kRefTerminal) {
@@ -90,7 +121,8 @@ __device__ __forceinline__ void verify_batch(TileCtx &c, uint32_t head, uint32_t
                 one_node = ref & kRefIdMask;
             }
             if (!(ref & kRefHasChildren) || e <= d) break; // leaf, or the buffer starts here
-            ref = rchild(T, ref & kRefIdMask, hay[e - 1 - d]);
+            const uint32_t unit = (d == K && K < 8) ? left_unit : (uint32_t)hay[e - 1 - d];
+            ref = walk_step(T, ref, unit);
             if (ref == 0) break;
             ++d;
         }
@@ -120,7 +152,7 @@ __device__ __forceinline__ void verify_batch(TileCtx &c, uint32_t head, uint32_t
         // several keywords end here: the reference reports the longest first (S/AhoCorasickSet.java:526-532), the walk
         // meets them shortest first -> second walk, giving the j-th one met the (m-1-j)-th place
         if (m >= 2) {
-            uint32_t ref = ref0, d = T.filt_k, j = 0;
+            uint32_t ref = ref0, d = K, j = 0;
             for (;;) {
                 if (ref & kRefTerminal) {
                     const uint32_t k = prefix + (m - 1 - j);
@@ -128,7 +160,7 @@ __device__ __forceinline__ void verify_batch(TileCtx &c, uint32_t head, uint32_t
                     if (++j == m) break;
                 }
                 if (!(ref & kRefHasChildren) || e <= d) break;
-                ref = rchild(T, ref & kRefIdMask, hay[e - 1 - d]);
+                ref = walk_step(T, ref, hay[e - 1 - d]);
                 if (ref == 0) break;
                 ++d;
             }
@@ -147,7 +179,7 @@ __device__ __forceinline__ void drain(TileCtx &c, uint32_t keep_below) {
     }
     if (head) { // move the leftovers (fewer than 64) to the front
         const uint32_t left = c.cand_n - head;
-        uint2 tmp = make_uint2(0, 0);
+        uint32_t tmp = 0;
         if (lane_id() < left) tmp = c.cand[head + lane_id()];
         __builtin_amdgcn_wave_barrier();
         if (lane_id() < left) c.cand[lane_id()] = tmp;
@@ -161,22 +193,35 @@ __device__ __forceinline__ uint32_t from_prev_lane(uint32_t x, uint32_t carry) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)x, 0x138, 0xf, 0xf, false);
 }
 
+// wave64 inclusive prefix sum with DPP row shifts and row broadcasts (6 dependent v_add_u32_dpp)
+__device__ __forceinline__ uint32_t wave_inclusive_scan_dpp(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true); // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true); // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true); // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true); // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1 and 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2 and 3
+    return x;
+}
+
 template <bool RANGE>
 __device__ __forceinline__ uint32_t tile_class_t(const DevTables &T, uint32_t unit) {
     if (RANGE) return min(unit - T.cls_base, T.cls_span);
     return T.cls_lut[unit];
 }
 
-// append this lane's candidates (bit j of mask: position v+j, K-gram index idx[j]) to the wave queue in text order
-__device__ __forceinline__ void enqueue(TileCtx &c, uint32_t mask, uint32_t v, const uint32_t (&idx)[8]) {
+// append this lane's candidates (bit j of mask: position v+j) to the wave queue in text order
+__device__ __forceinline__ void enqueue(TileCtx &c, uint32_t mask, uint32_t v) {
     const uint32_t cnt = __popc(mask);
-    const uint32_t incl = wave_inclusive_scan(cnt);
-    const uint32_t total = __shfl(incl, kWave - 1);
+    const uint32_t incl = wave_inclusive_scan_dpp(cnt);
+    const uint32_t total = __builtin_amdgcn_readlane(incl, kWave - 1);
     if (total) {
         uint32_t slot = c.cand_n + incl - cnt;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (mask & (1u << j)) c.cand[slot++] = make_uint2(v + j, idx[j]);
+        while (__any(mask != 0)) { // as many rounds as the busiest lane has candidates (2-3 at 2 % density)
+            if (mask != 0) {
+                c.cand[slot++] = v + (uint32_t)__builtin_ctz(mask);
+                mask &= mask - 1;
+            }
         }
         c.cand_n += total;
         __builtin_amdgcn_wave_barrier();
@@ -185,14 +230,15 @@ __device__ __forceinline__ void enqueue(TileCtx &c, uint32_t mask, uint32_t v, c
 }
 
 // A wave owns a contiguous SPAN of regions.  Region boundaries sit at base8 + r * region_units (base8 = own_begin
-// rounded down to 8 units, region_units a multiple of 512), so a 512-unit tile never straddles two regions and the
-// tile stream -- with its kPrefetch-deep register ring and the cross-lane carry -- runs through the whole span.
-template <int K, bool RANGE>
+// rounded down to 8 units, region_units a multiple of the 2048-unit tile group), so a tile group never straddles two
+// regions and the tile stream -- with its double-buffered register groups and the cross-lane carry -- runs through the
+// whole span.
+template <int K, bool RANGE, bool WIDE>
 __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch L) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *bits = reinterpret_cast<uint32_t *>(smem);
-    uint2 *cand_all = reinterpret_cast<uint2 *>(smem + (size_t)T.filt_words * 4);
-    for (uint32_t i = threadIdx.x; i < T.filt_words; i += blockDim.x) bits[i] = T.filt_bits[i];
+    uint32_t *rows32 = reinterpret_cast<uint32_t *>(smem); // filter rows at LDS offset 0: a scaled row index IS the address
+    uint32_t *cand_all = reinterpret_cast<uint32_t *>(smem + (size_t)T.filt_words * 4);
+    for (uint32_t i = threadIdx.x; i < T.filt_words; i += blockDim.x) rows32[i] = T.filt_bits[i];
     __syncthreads();
 
     const uint32_t lane = lane_id();
@@ -200,10 +246,11 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
     const uint32_t wave_global = blockIdx.x * (kTileBlock / kWave) + wave_in_block;
     TileCtx c{T, L, cand_all + wave_in_block * kCandCap, 0, 0, 0ull, 0};
 
+    constexpr uint32_t ROWB = WIDE ? 8 : 4;
     const uint32_t n = T.filt_n;
-    uint32_t nK = 1;
+    uint32_t nK1s = ROWB; // ROWB * n^(K-1): weight of the unit that leaves the (K-1)-gram window
 #pragma unroll
-    for (int i = 0; i < K; ++i) nK *= n;
+    for (int i = 0; i < K - 1; ++i) nK1s *= n;
     constexpr int NP = K / 2; // dwords of the previous 8 units that hold the K-1 units before the lane's first one
 
     const uint32_t first_region = wave_global * L.regions_per_wave;
@@ -215,7 +262,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
     uint32_t span_end = base8 + last_region * R;
     if (span_end > L.own_end || last_region == L.n_regions) span_end = L.own_end;
     // full 16-byte vectors end at nfull; the (at most 7) units behind it are handled after the tile stream, so the
-    // stream's loads are unconditional (clamped address) and the compiler can use counted s_waitcnt vmcnt(N)
+    // stream's loads are unconditional (clamped address)
     const uint32_t nfull = L.n_units & ~7u;
     const uint32_t hi = min(span_end, nfull);
     const uint32_t last_vec = nfull >= 8 ? nfull - 8 : 0;
@@ -233,10 +280,12 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
             const uint4 p = *reinterpret_cast<const uint4 *>(hay + tile - 8);
             carry[0] = p.x; carry[1] = p.y; carry[2] = p.z; carry[3] = p.w;
         }
-        uint4 ring[kPrefetch];
+        // double-buffered tile groups: while the kPrefetch tiles of the current group are filtered out of registers, the
+        // loads of the next group are in flight (4 KiB per wave); they are awaited together at the next group's start
+        uint4 nxt[kPrefetch];
 #pragma unroll
         for (int d = 0; d < kPrefetch; ++d)
-            ring[d] = *reinterpret_cast<const uint4 *>(hay + min(tile + d * kTileUnits + lane * 8, last_vec));
+            nxt[d] = *reinterpret_cast<const uint4 *>(hay + min(tile + d * kTileUnits + lane * 8, last_vec));
 
         for (; tile < hi; tile += kPrefetch * kTileUnits) {
             if (tile >= boundary) { // wave-uniform: the stream enters the next region (regions hold whole tile groups)
@@ -248,12 +297,23 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                 boundary += R;
                 re = min(span_end, boundary);
             }
+            uint4 grp[kPrefetch];
+#pragma unroll
+            for (int d = 0; d < kPrefetch; ++d) grp[d] = nxt[d];
+#pragma unroll
+            for (int d = 0; d < kPrefetch; ++d)
+                nxt[d] = *reinterpret_cast<const uint4 *>(
+                    hay + min(tile + (kPrefetch + d) * kTileUnits + lane * 8, last_vec));
+            // positions a lane may report: inside the region, in the vector part of the buffer, with K units to their
+            // left in the buffer.  Only groups at the edges of a region need the per-lane mask.
+            const uint32_t lo = max(rb, (uint32_t)(K - 1));
+            const uint32_t top = min(re, hi);
+            const bool edge = tile < lo || tile + kPrefetch * kTileUnits > top; // wave-uniform
 #pragma unroll
             for (int d = 0; d < kPrefetch; ++d) {
                 const uint32_t cur = tile + d * kTileUnits;
                 if (cur >= hi) break; // wave-uniform
-                const uint4 w = ring[d];
-                ring[d] = *reinterpret_cast<const uint4 *>(hay + min(cur + kPrefetch * kTileUnits + lane * 8, last_vec));
+                const uint4 w = grp[d];
                 const uint32_t v = cur + lane * 8;
                 const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
                 // the previous lane's dwords give the K-1 units before v; lane 0 takes the previous tile's lane 63
@@ -264,12 +324,9 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                     carry[q] = __builtin_amdgcn_readlane(ww[q], 63);
                 }
                 uint32_t mask = 0;
-                uint32_t idx[8];
                 if (L.debug & 4u) { // ablation: stream only
                     const uint32_t x = ww[0] ^ ww[1] ^ ww[2] ^ ww[3];
                     mask = (x == 0x12345678u) ? 1u : 0u;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) idx[j] = 0;
                 } else {
                     // classes of units v-(K-1) .. v+7
                     uint32_t a[8 + K - 1];
@@ -280,27 +337,32 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                     }
 #pragma unroll
                     for (int j = 0; j < 8; ++j) a[K - 1 + j] = tile_class_t<RANGE>(T, (ww[j >> 1] >> (16 * (j & 1))) & 0xffffu);
-                    // K-gram index of position v+j (last unit least significant), rolling; every factor is < 2^24, so
-                    // the full-rate 24-bit multiplies are exact modulo 2^32
-                    uint32_t h = 0;
+                    // byte offset of the filter row of position v+j = ROWB * index of its (K-1)-gram a[j .. j+K-2],
+                    // rolling; every factor is < 2^24, so the full-rate 24-bit multiplies are exact modulo 2^32
+                    uint32_t hs = 0;
 #pragma unroll
-                    for (int j = 0; j < K; ++j) h = __umul24(h, n) + a[j];
+                    for (int j = 0; j < K - 1; ++j) hs = __umul24(hs, n) + a[j] * ROWB;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        if (j > 0) h = __umul24(h, n) + a[K - 1 + j] - __umul24(a[j - 1], nK);
-                        idx[j] = h;
-                        const uint32_t word = bits[h >> 5];
-                        mask |= __builtin_amdgcn_ubfe(word, h, 1) << j; // v_bfe_u32 takes the bit offset from h[4:0]
+                        if (j > 0 && K > 1) // v_mul_u32_u24 + v_lshl_add_u32 + v_mad_i32_i24
+                            hs = (uint32_t)__mul24((int)a[j - 1], -(int)nK1s) + ((a[j + K - 2] * ROWB) + __umul24(hs, n));
+                        uint32_t bit;
+                        if (WIDE) {
+                            const uint64_t row = *reinterpret_cast<const uint64_t *>(smem + hs);
+                            bit = (uint32_t)(row >> a[K - 1 + j]) & 1u;
+                        } else {
+                            const uint32_t row = *reinterpret_cast<const uint32_t *>(smem + hs);
+                            bit = __builtin_amdgcn_ubfe(row, a[K - 1 + j], 1); // v_bfe_u32 takes the offset from a[4:0]
+                        }
+                        mask |= bit << j;
                     }
-                    // positions this lane may report: inside the region, in the vector part of the buffer, and with K
-                    // units to their left in the buffer
-                    const uint32_t lo = max(rb, (uint32_t)(K - 1));
-                    const uint32_t top = min(re, hi);
-                    const uint32_t first = lo > v ? min(lo - v, 8u) : 0u;
-                    const uint32_t last = top > v ? min(top - v, 8u) : 0u;
-                    mask &= ((1u << last) - 1u) & ~((1u << first) - 1u);
+                    if (edge) {
+                        const uint32_t first = lo > v ? min(lo - v, 8u) : 0u;
+                        const uint32_t last = top > v ? min(top - v, 8u) : 0u;
+                        mask &= ((1u << last) - 1u) & ~((1u << first) - 1u);
+                    }
                 }
-                enqueue(c, mask, v, idx);
+                enqueue(c, mask, v);
             }
         }
     }
@@ -315,14 +377,14 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
         }
         const uint32_t pos = t0 + lane;
         uint32_t mask = 0;
-        uint32_t idx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (pos < span_end && pos + 1 >= (uint32_t)K && !(L.debug & 4u)) {
-            uint32_t h = 0;
-            for (int j = K - 1; j >= 0; --j) h = __umul24(h, n) + tile_class_t<RANGE>(T, hay[pos - j]);
-            idx[0] = h;
-            mask = (bits[h >> 5] >> (h & 31)) & 1u;
+            uint32_t hrow = 0;
+            for (int j = K - 1; j >= 1; --j) hrow = hrow * n + tile_class_t<RANGE>(T, hay[pos - j]);
+            const uint32_t last = tile_class_t<RANGE>(T, hay[pos]);
+            const uint32_t word = rows32[hrow * (ROWB / 4) + (last >> 5)];
+            mask = (word >> (last & 31)) & 1u;
         }
-        enqueue(c, mask, pos, idx); // one position per lane: lane order is text order
+        enqueue(c, mask, pos); // one position per lane: lane order is text order
     }
     drain(c, 1);
     if (lane == 0) L.d_region_counts[region] = c.rank_base;
@@ -330,37 +392,39 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
     for (uint32_t i = lane; i < c.res_left; i += kWave) store_rec(L, c.res_cur + i, 0, 0, 0, ~0u);
 }
 
-template <int K, bool RANGE>
+template <int K, bool RANGE, bool WIDE>
 static hipError_t launch_tile_variant(const DevTables &t, const TileLaunch &l, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ac_tile<K, RANGE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ac_tile<K, RANGE, WIDE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_ac_tile<K, RANGE>), dim3(l.grid), dim3(l.block), l.lds_bytes, stream, t, l);
+    hipLaunchKernelGGL((k_ac_tile<K, RANGE, WIDE>), dim3(l.grid), dim3(l.block), l.lds_bytes, stream, t, l);
     return hipGetLastError();
 }
 
+template <int K>
+static hipError_t launch_tile_k(const DevTables &t, const TileLaunch &l, hipStream_t stream) {
+    const bool wide = t.filt_row_bytes == 8;
+    if (t.range_cls) return wide ? launch_tile_variant<K, true, true>(t, l, stream) : launch_tile_variant<K, true, false>(t, l, stream);
+    return wide ? launch_tile_variant<K, false, true>(t, l, stream) : launch_tile_variant<K, false, false>(t, l, stream);
+}
+
 hipError_t launch_ac_tile(const DevTables &t, const TileLaunch &l, hipStream_t stream, const char **kernel_name) {
-    static const char *const names[2][9] = {
-        {"", "k_ac_tile<1, false>", "k_ac_tile<2, false>", "k_ac_tile<3, false>", "k_ac_tile<4, false>", "k_ac_tile<5, false>",
-         "k_ac_tile<6, false>", "k_ac_tile<7, false>", "k_ac_tile<8, false>"},
-        {"", "k_ac_tile<1, true>", "k_ac_tile<2, true>", "k_ac_tile<3, true>", "k_ac_tile<4, true>", "k_ac_tile<5, true>",
-         "k_ac_tile<6, true>", "k_ac_tile<7, true>", "k_ac_tile<8, true>"}};
+    static char name[64];
     if (t.filt_k < 1 || t.filt_k > 8) return hipErrorInvalidValue;
-    if (kernel_name) *kernel_name = names[t.range_cls ? 1 : 0][t.filt_k];
-#define ACGPU_TILE_CASE(KK) \
-    case KK: return t.range_cls ? launch_tile_variant<KK, true>(t, l, stream) : launch_tile_variant<KK, false>(t, l, stream);
+    std::snprintf(name, sizeof(name), "k_ac_tile<%u, %s, %s>", t.filt_k, t.range_cls ? "true" : "false",
+                  t.filt_row_bytes == 8 ? "true" : "false");
+    if (kernel_name) *kernel_name = name;
     switch (t.filt_k) {
-        ACGPU_TILE_CASE(1)
-        ACGPU_TILE_CASE(2)
-        ACGPU_TILE_CASE(3)
-        ACGPU_TILE_CASE(4)
-        ACGPU_TILE_CASE(5)
-        ACGPU_TILE_CASE(6)
-        ACGPU_TILE_CASE(7)
-        ACGPU_TILE_CASE(8)
+    case 1: return launch_tile_k<1>(t, l, stream);
+    case 2: return launch_tile_k<2>(t, l, stream);
+    case 3: return launch_tile_k<3>(t, l, stream);
+    case 4: return launch_tile_k<4>(t, l, stream);
+    case 5: return launch_tile_k<5>(t, l, stream);
+    case 6: return launch_tile_k<6>(t, l, stream);
+    case 7: return launch_tile_k<7>(t, l, stream);
+    case 8: return launch_tile_k<8>(t, l, stream);
     default: return hipErrorInvalidValue;
     }
-#undef ACGPU_TILE_CASE
 }
 
 } // namespace acgpu

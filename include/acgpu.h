@@ -177,7 +177,7 @@ int acgpu_synth_fill(uint16_t *d_dst, uint64_t n_units, uint64_t start_index, ui
 
 /* tuning knobs (process-wide; mainly for tests and benchmarks).  name: "chunk_units",
  * "blocks_per_cu", "lds_table_bytes", "force_sparse", "dense_budget_bytes", "force_kernel" (0 auto, 1 DFA chunk
- * scan, 2 K-gram tile scan), "region_units", "filter_max_bits".  Returns the previous value, -1 for an unknown name. */
+ * scan, 2 K-gram tile scan), "region_units", "filter_max_bytes".  Returns the previous value, -1 for an unknown name. */
 int64_t acgpu_set_tunable(const char *name, int64_t value);
 
 const char *acgpu_strerror(int code);
