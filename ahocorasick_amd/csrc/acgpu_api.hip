@@ -192,12 +192,14 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
     int rc;
     if ((rc = d.counter.ensure(64))) return rc;
     // the tile kernel reserves scratch slots 256 at a time per wave: head-room for the unused tails
-    const uint64_t scratch_cap = std::max<uint64_t>(cap, 1) + (uint64_t)d.n_cu * (tile_block_threads() / 64) * tile_reserve_slots();
+    const uint64_t scratch_cap = std::min<uint64_t>(
+        std::max<uint64_t>(cap, 1) + (uint64_t)d.n_cu * (tile_block_threads() / 64) * tile_reserve_slots(), 0xffffffe0ull);
     if ((rc = d.scratch.ensure(scratch_cap * sizeof(ScratchRec)))) return rc;
     HIP_TRY(hipMemsetAsync(d.counter.p, 0, 64, stream));
     const char *kname = "";
     uint64_t scanned = 0;
     uint32_t n_chunks = 0, chunk_units = 0, perm_base = (uint32_t)sh->own_begin;
+    const uint32_t *id_map = nullptr;
     if (use_tile_kernel(t)) {
         TileLaunch L{};
         L.block = tile_block_threads();
@@ -212,6 +214,7 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         const uint64_t waves_used = ((uint64_t)L.n_regions + L.regions_per_wave - 1) / L.regions_per_wave;
         L.grid = (int)((waves_used + waves_per_block - 1) / waves_per_block);
         perm_base = (uint32_t)base8;
+        id_map = d.T.rterm;
         L.d_hay = sh->d_hay;
         L.n_units = (uint32_t)sh->n_units;
         L.own_begin = (uint32_t)sh->own_begin;
@@ -267,7 +270,7 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
                                   (uint64_t *)d.scan_tmp.p, stream));
     HIP_TRY(launch_permute((const ScratchRec *)d.scratch.p, (const unsigned long long *)d.counter.p, scratch_cap,
                            (const uint64_t *)d.offsets.p, perm_base, chunk_units,
-                           /*by_start=*/0, record_kind, d_out, cap, stream));
+                           /*by_start=*/0, record_kind, d_out, cap, id_map, stream));
     if (prof) HIP_TRY(hipEventRecord(d.ev[2], stream));
     // exact record count = grand total of the per-chunk counts (the slot counter also counts reservation holes)
     HIP_TRY(hipMemcpyAsync(d.h_counter, (const uint64_t *)d.scan_tmp.p + scan_tiles_for(n_chunks), 8, hipMemcpyDeviceToHost,

@@ -60,7 +60,7 @@ hipError_t launch_exclusive_scan(const uint32_t *d_counts, uint32_t n, uint64_t 
 // (slots whose rank is ~0u are holes left by slot reservations and are skipped)
 hipError_t launch_permute(const ScratchRec *d_scratch, const unsigned long long *d_counter, uint64_t scratch_cap,
                           const uint64_t *d_offsets, uint32_t own_begin, uint32_t chunk_units, int by_start,
-                          int record_kind, void *d_out, uint64_t out_cap, hipStream_t stream);
+                          int record_kind, void *d_out, uint64_t out_cap, const uint32_t *d_id_map, hipStream_t stream);
 uint32_t scan_tiles_for(uint32_t n); // number of prefix-sum tiles; the grand total is d_tmp[scan_tiles_for(n)]
 uint32_t tile_reserve_slots();
 

@@ -283,7 +283,8 @@ hipError_t launch_exclusive_scan(const uint32_t *d_counts, uint32_t n, uint64_t 
 template <int REC>
 __global__ __launch_bounds__(256) void k_permute(const ScratchRec *scratch, const unsigned long long *counter,
                                                 uint64_t scratch_cap, const uint64_t *offsets, uint32_t own_begin,
-                                                uint32_t chunk_units, int by_start, void *out, uint64_t cap) {
+                                                uint32_t chunk_units, int by_start, void *out, uint64_t cap,
+                                                const uint32_t *id_map) {
     unsigned long long m = *counter;
     if (m > scratch_cap) m = scratch_cap; // overflow: the host reports ACGPU_E_OVERFLOW; nothing useful is produced
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -302,21 +303,21 @@ __global__ __launch_bounds__(256) void k_permute(const ScratchRec *scratch, cons
             int32_t *o = reinterpret_cast<int32_t *>(out) + dst * 3;
             o[0] = start;
             o[1] = end;
-            o[2] = id;
+            o[2] = id_map ? (int32_t)id_map[id] : id; // tile-kernel records name the reversed-trie node: map to keyword id
         }
     }
 }
 
 hipError_t launch_permute(const ScratchRec *d_scratch, const unsigned long long *d_counter, uint64_t scratch_cap,
                           const uint64_t *d_offsets, uint32_t own_begin, uint32_t chunk_units, int by_start,
-                          int record_kind, void *d_out, uint64_t out_cap, hipStream_t stream) {
+                          int record_kind, void *d_out, uint64_t out_cap, const uint32_t *d_id_map, hipStream_t stream) {
     const int grid = 2048;
     if (record_kind == ACGPU_REC_SET)
         hipLaunchKernelGGL(k_permute<ACGPU_REC_SET>, dim3(grid), dim3(256), 0, stream, d_scratch, d_counter, scratch_cap,
-                           d_offsets, own_begin, chunk_units, by_start, d_out, out_cap);
+                           d_offsets, own_begin, chunk_units, by_start, d_out, out_cap, d_id_map);
     else
         hipLaunchKernelGGL(k_permute<ACGPU_REC_MAP>, dim3(grid), dim3(256), 0, stream, d_scratch, d_counter, scratch_cap,
-                           d_offsets, own_begin, chunk_units, by_start, d_out, out_cap);
+                           d_offsets, own_begin, chunk_units, by_start, d_out, out_cap, d_id_map);
     return hipGetLastError();
 }
 

@@ -30,7 +30,8 @@ namespace acgpu {
 
 constexpr int kTileBlock = 1024;               // 16 waves share one LDS copy of the filter rows
 constexpr int kTileUnits = 512;                // units per wave tile (64 lanes x 8 units)
-constexpr int kCandCap = 64 + kTileUnits;      // a tile adds at most 512 candidates to fewer than 64 pending ones
+constexpr int kVerifyBatches = 4;              // candidates verified per lane and call (independent load chains in flight)
+constexpr int kCandCap = 1024;                 // candidate queue entries per wave; a tile adds at most 512
 constexpr int kPrefetch = 4;                   // tiles per group; one group of loads is in flight per wave
 constexpr uint32_t kReserve = 256;             // scratch slots a wave reserves per atomic
 
@@ -42,12 +43,12 @@ size_t tile_lds_bytes(const DevTables &t, int block_threads) {
 }
 
 struct TileCtx {
-    const DevTables &T;
-    const TileLaunch &L;
+    const DevTables *Tp;
+    const TileLaunch *Lp;
     uint32_t *cand;     // this wave's candidate queue in LDS: end positions (last unit index), in text order
     uint32_t cand_n;    // wave-uniform
     uint32_t rank_base; // wave-uniform: records emitted so far in the current region
-    unsigned long long res_cur; // wave-uniform: next free reserved scratch slot
+    uint32_t res_cur;   // wave-uniform: next free reserved scratch slot (scratch capacity < 2^32)
     uint32_t res_left;          // wave-uniform: reserved slots left
 };
 
@@ -60,6 +61,12 @@ __device__ __forceinline__ uint32_t tile_class(const DevTables &T, uint32_t unit
     return T.cls_lut[unit];
 }
 
+template <bool RANGE>
+__device__ __forceinline__ uint32_t tile_class_t(const DevTables &T, uint32_t unit) {
+    if (RANGE) return min(unit - T.cls_base, T.cls_span);
+    return T.cls_lut[unit];
+}
+
 // flagged ref of the child of reverse-trie node `id` whose edge is `unit` (raw) / class `cls`, 0 = none
 __device__ __forceinline__ uint32_t rchild(const DevTables &T, uint32_t id, uint32_t unit, uint32_t cls) {
     if (T.rdense) return T.rtab[id * T.filt_n + cls];
@@ -68,9 +75,9 @@ __device__ __forceinline__ uint32_t rchild(const DevTables &T, uint32_t id, uint
     return r == ~0u ? 0u : r;
 }
 
-__device__ __forceinline__ void store_rec(const TileLaunch &L, unsigned long long slot, uint32_t start, uint32_t end,
-                                          uint32_t id, uint32_t rank) {
-    if (slot < L.cap) {
+__device__ __forceinline__ void store_rec(const TileLaunch &L, uint32_t slot, uint32_t start, uint32_t end, uint32_t id,
+                                          uint32_t rank) {
+    if ((uint64_t)slot < L.cap) {
         const uint4 v = make_uint4(start, end, id, rank);
         *reinterpret_cast<uint4 *>(&L.d_scratch[slot]) = v;
     }
@@ -78,119 +85,12 @@ __device__ __forceinline__ void store_rec(const TileLaunch &L, unsigned long lon
 
 // One step of the leftward walk from a flagged node ref: returns the child's ref or 0.  The only-child hint lets a
 // mismatching unit end the walk without a memory access.
+template <bool RANGE>
 __device__ __forceinline__ uint32_t walk_step(const DevTables &T, uint32_t ref, uint32_t unit) {
-    const uint32_t cls = tile_class(T, unit);
+    const uint32_t cls = tile_class_t<RANGE>(T, unit);
     const uint32_t hint = (ref >> kRefHintShift) & kRefHintMask;
     if (hint != 0 && hint - 1 != cls) return 0;
     return rchild(T, ref & kRefIdMask, unit, cls);
-}
-
-// Verification of up to 64 queued candidates, one per lane.  Every lane of the wave calls this.
-__device__ __forceinline__ void verify_batch(TileCtx &c, uint32_t head, uint32_t nb) {
-    const DevTables &T = c.T;
-    const uint16_t *hay = c.L.d_hay;
-    const uint32_t lane = lane_id();
-    const uint32_t K = T.filt_k;
-    const bool act = lane < nb;
-    uint32_t e = 0, m = 0, one_len = 0, one_node = 0, ref0 = 0;
-    uint32_t win[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // units e-8 .. e-1 (zeros before the buffer start)
-    if (act) {
-        const uint32_t pos = c.cand[head + lane];
-        e = pos + 1; // exclusive end
-        if (e >= 8) {
-            const Units8 u = *reinterpret_cast<const Units8 *>(hay + e - 8);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) win[j] = (u.d[j >> 1] >> (16 * (j & 1))) & 0xffffu;
-        } else {
-            for (uint32_t j = 0; j < e; ++j) win[8 - e + j] = hay[j];
-        }
-        // K-gram index (last unit least significant) -> flagged ref of the depth-K node of the reversed trie
-        uint32_t idx = 0, left_unit = 0; // left_unit: the unit just left of the K-gram (first step of the walk)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (j >= 8 - (int)K) idx = idx * T.filt_n + tile_class(T, win[j]);
-            if (j == 7 - (int)K) left_unit = win[j];
-        }
-        ref0 = T.kgram_node[idx];
-        uint32_t ref = ref0, d = K;
-        // walk the reversed trie leftwards; every terminal node met is a keyword ending at e (increasing length)
-        for (;;) {
-            if (ref & kRefTerminal) {
-                ++m;
-                one_len = d;
-                one_node = ref & kRefIdMask;
-            }
-            if (!(ref & kRefHasChildren) || e <= d) break; // leaf, or the buffer starts here
-            const uint32_t unit = (d == K && K < 8) ? left_unit : (uint32_t)hay[e - 1 - d];
-            ref = walk_step(T, ref, unit);
-            if (ref == 0) break;
-            ++d;
-        }
-    }
-    const uint32_t incl = wave_inclusive_scan(m);
-    const uint32_t total = __shfl(incl, kWave - 1);
-    if (total == 0) return;
-    const uint32_t prefix = incl - m;
-    // slot of the wave's k-th record of this batch: the tail of the current reservation, then a fresh one
-    const unsigned long long old_cur = c.res_cur;
-    const uint32_t old_left = c.res_left;
-    unsigned long long fresh = 0;
-    if (total > old_left) {
-        const uint32_t need = total - old_left;
-        const uint32_t take = need > kReserve ? need : kReserve;
-        if (lane == 0) fresh = atomicAdd(c.L.d_counter, (unsigned long long)take);
-        fresh = __shfl(fresh, 0);
-        c.res_cur = fresh + need;
-        c.res_left = take - need;
-    } else {
-        c.res_cur = old_cur + total;
-        c.res_left = old_left - total;
-    }
-    auto slot_of = [&](uint32_t k) -> unsigned long long { return k < old_left ? old_cur + k : fresh + (k - old_left); };
-    if (m == 1) store_rec(c.L, slot_of(prefix), e - one_len, e, T.rterm[one_node], c.rank_base + prefix);
-    if (__any(m >= 2)) {
-        // several keywords end here: the reference reports the longest first (S/AhoCorasickSet.java:526-532), the walk
-        // meets them shortest first -> second walk, giving the j-th one met the (m-1-j)-th place
-        if (m >= 2) {
-            uint32_t ref = ref0, d = K, j = 0;
-            for (;;) {
-                if (ref & kRefTerminal) {
-                    const uint32_t k = prefix + (m - 1 - j);
-                    store_rec(c.L, slot_of(k), e - d, e, T.rterm[ref & kRefIdMask], c.rank_base + k);
-                    if (++j == m) break;
-                }
-                if (!(ref & kRefHasChildren) || e <= d) break;
-                ref = walk_step(T, ref, hay[e - 1 - d]);
-                if (ref == 0) break;
-                ++d;
-            }
-        }
-    }
-    c.rank_base += total;
-}
-
-// drain the candidate queue down to fewer than `keep_below` entries (64 inside a region, 1 at its end)
-__device__ __forceinline__ void drain(TileCtx &c, uint32_t keep_below) {
-    uint32_t head = 0;
-    while (c.cand_n > head && c.cand_n - head >= keep_below) {
-        const uint32_t nb = min(c.cand_n - head, (uint32_t)kWave);
-        if (!(c.L.debug & 1u)) verify_batch(c, head, nb);
-        head += nb;
-    }
-    if (head) { // move the leftovers (fewer than 64) to the front
-        const uint32_t left = c.cand_n - head;
-        uint32_t tmp = 0;
-        if (lane_id() < left) tmp = c.cand[head + lane_id()];
-        __builtin_amdgcn_wave_barrier();
-        if (lane_id() < left) c.cand[lane_id()] = tmp;
-        __builtin_amdgcn_wave_barrier();
-        c.cand_n = left;
-    }
-}
-
-// value of x in lane-1; lane 0 receives `carry` (v_mov_b32_dpp wave_shr:1)
-__device__ __forceinline__ uint32_t from_prev_lane(uint32_t x, uint32_t carry) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)x, 0x138, 0xf, 0xf, false);
 }
 
 // wave64 inclusive prefix sum with DPP row shifts and row broadcasts (6 dependent v_add_u32_dpp)
@@ -204,10 +104,164 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan_dpp(uint32_t x) {
     return x;
 }
 
-template <bool RANGE>
-__device__ __forceinline__ uint32_t tile_class_t(const DevTables &T, uint32_t unit) {
-    if (RANGE) return min(unit - T.cls_base, T.cls_span);
-    return T.cls_lut[unit];
+// Verification of up to kVerifyBatches*64 queued candidates: kVerifyBatches per lane, advanced in lock step so that
+// their dependent loads (text window -> K-gram node -> rare deeper steps) are in flight together.  Every lane of the
+// wave calls this.  Records carry the reversed-trie NODE id; the permute pass translates it to the keyword id.
+template <int K, bool RANGE>
+__device__ __forceinline__ void verify_multi(TileCtx &c, uint32_t head, uint32_t n_cand) {
+    constexpr int NB = kVerifyBatches;
+    const DevTables &T = *c.Tp;
+    const TileLaunch &L = *c.Lp;
+    const uint16_t *hay = L.d_hay;
+    const uint32_t lane = lane_id();
+    bool act[NB];
+    uint32_t e[NB], ref[NB], ref0[NB], left_unit[NB], d[NB], m[NB], one_len[NB], one_node[NB];
+    Units8 win[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const uint32_t q = b * kWave + lane;
+        act[b] = q < n_cand;
+        e[b] = act[b] ? c.cand[head + q] + 1 : 8; // exclusive end
+        m[b] = 0; one_len[b] = 0; one_node[b] = 0; d[b] = K; left_unit[b] = 0;
+    }
+    // text windows: units e-8 .. e-1 in one unaligned 16-byte load (zeros before the buffer start)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        if (e[b] >= 8) {
+            win[b] = *reinterpret_cast<const Units8 *>(hay + e[b] - 8);
+        } else {
+            win[b] = Units8{{0, 0, 0, 0}}; // within 8 units of the buffer start (rare): unit by unit
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (e[b] + j >= 8) win[b].d[j >> 1] |= (uint32_t)hay[e[b] + j - 8] << (16 * (j & 1));
+            }
+        }
+    }
+    // K-gram index (last unit least significant) -> flagged ref of the depth-K node of the reversed trie
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        uint32_t idx = 0;
+#pragma unroll
+        for (int j = 8 - K; j < 8; ++j) idx = __umul24(idx, T.filt_n) + tile_class_t<RANGE>(T, (win[b].d[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+        if (K < 8) left_unit[b] = (win[b].d[(7 - K) >> 1] >> (16 * ((7 - K) & 1))) & 0xffffu;
+        ref[b] = act[b] ? T.kgram_node[idx] : 0u;
+        ref0[b] = ref[b];
+    }
+    // leftward walks in lock step; every terminal node met is a keyword ending at e (increasing length)
+    for (;;) {
+        bool go[NB];
+        bool any_go = false;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (ref[b] & kRefTerminal) {
+                ++m[b];
+                one_len[b] = d[b];
+                one_node[b] = ref[b] & kRefIdMask;
+            }
+            go[b] = (ref[b] & kRefHasChildren) && e[b] > d[b]; // not a leaf, and the buffer does not start here
+            any_go |= go[b];
+        }
+        if (!__any(any_go)) break;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            uint32_t next = 0;
+            if (go[b]) {
+                const uint32_t unit = (d[b] == K && K < 8) ? left_unit[b] : (uint32_t)hay[e[b] - 1 - d[b]];
+                next = walk_step<RANGE>(T, ref[b], unit);
+            }
+            ref[b] = next;
+            ++d[b];
+        }
+    }
+    // record slots and ranks in text order: batch 0's lanes, then batch 1's, ...
+    uint32_t prefix[NB], total = 0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const uint32_t incl = wave_inclusive_scan_dpp(m[b]);
+        prefix[b] = total + incl - m[b];
+        total += __builtin_amdgcn_readlane(incl, kWave - 1);
+    }
+    if (total == 0) return;
+    // slot of the wave's k-th record of this call: the tail of the current reservation, then a fresh one
+    const uint32_t old_cur = c.res_cur;
+    const uint32_t old_left = c.res_left;
+    uint32_t fresh = 0;
+    if (total > old_left) {
+        const uint32_t need = total - old_left;
+        const uint32_t take = need > kReserve ? need : kReserve;
+        unsigned long long got = 0;
+        if (lane == 0) got = atomicAdd(L.d_counter, (unsigned long long)take);
+        // beyond the scratch capacity nothing is stored (the host reports ACGPU_E_OVERFLOW from the exact counts)
+        fresh = (uint32_t)min(got, (unsigned long long)0xfffffff0u - take);
+        fresh = __builtin_amdgcn_readfirstlane(fresh);
+        c.res_cur = fresh + need;
+        c.res_left = take - need;
+    } else {
+        c.res_cur = old_cur + total;
+        c.res_left = old_left - total;
+    }
+    auto slot_of = [&](uint32_t k) -> uint32_t { return k < old_left ? old_cur + k : fresh + (k - old_left); };
+    bool multi = false;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        if (m[b] == 1) store_rec(L, slot_of(prefix[b]), e[b] - one_len[b], e[b], one_node[b], c.rank_base + prefix[b]);
+        multi |= m[b] >= 2;
+    }
+    if (__any(multi)) {
+        // several keywords end at one position: the reference reports the longest first (S/AhoCorasickSet.java:526-532),
+        // the walk meets them shortest first -> second walk, giving the j-th one met the (m-1-j)-th place
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (m[b] >= 2) {
+                uint32_t r = ref0[b], dd = K, j = 0;
+                for (;;) {
+                    if (r & kRefTerminal) {
+                        const uint32_t k = prefix[b] + (m[b] - 1 - j);
+                        store_rec(L, slot_of(k), e[b] - dd, e[b], r & kRefIdMask, c.rank_base + k);
+                        if (++j == m[b]) break;
+                    }
+                    if (!(r & kRefHasChildren) || e[b] <= dd) break;
+                    r = walk_step<RANGE>(T, r, hay[e[b] - 1 - dd]);
+                    if (r == 0) break;
+                    ++dd;
+                }
+            }
+        }
+    }
+    c.rank_base += total;
+}
+
+// drain the candidate queue down to fewer than `keep_below` entries
+template <int K, bool RANGE>
+__device__ __forceinline__ void drain(TileCtx &c, uint32_t keep_below) {
+    uint32_t head = 0;
+    while (c.cand_n > head && c.cand_n - head >= keep_below) {
+        const uint32_t nb = min(c.cand_n - head, (uint32_t)(kVerifyBatches * kWave));
+        if (!(c.Lp->debug & 1u)) verify_multi<K, RANGE>(c, head, nb);
+        head += nb;
+    }
+    if (head) { // move the leftovers (fewer than kVerifyBatches*64) to the front
+        const uint32_t left = c.cand_n - head;
+        uint32_t tmp[kVerifyBatches];
+#pragma unroll
+        for (int b = 0; b < kVerifyBatches; ++b) {
+            const uint32_t q = b * kWave + lane_id();
+            tmp[b] = q < left ? c.cand[head + q] : 0u;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int b = 0; b < kVerifyBatches; ++b) {
+            const uint32_t q = b * kWave + lane_id();
+            if (q < left) c.cand[q] = tmp[b];
+        }
+        __builtin_amdgcn_wave_barrier();
+        c.cand_n = left;
+    }
+}
+
+// value of x in lane-1; lane 0 receives `carry` (v_mov_b32_dpp wave_shr:1)
+__device__ __forceinline__ uint32_t from_prev_lane(uint32_t x, uint32_t carry) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)x, 0x138, 0xf, 0xf, false);
 }
 
 // append this lane's candidates (bit j of mask: position v+j) to the wave queue in text order
@@ -225,7 +279,6 @@ __device__ __forceinline__ void enqueue(TileCtx &c, uint32_t mask, uint32_t v) {
         }
         c.cand_n += total;
         __builtin_amdgcn_wave_barrier();
-        if (c.cand_n >= kWave) drain(c, kWave);
     }
 }
 
@@ -244,7 +297,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
     const uint32_t lane = lane_id();
     const uint32_t wave_in_block = threadIdx.x / kWave;
     const uint32_t wave_global = blockIdx.x * (kTileBlock / kWave) + wave_in_block;
-    TileCtx c{T, L, cand_all + wave_in_block * kCandCap, 0, 0, 0ull, 0};
+    TileCtx c{&T, &L, cand_all + wave_in_block * kCandCap, 0, 0, 0u, 0};
 
     constexpr uint32_t ROWB = WIDE ? 8 : 4;
     const uint32_t n = T.filt_n;
@@ -274,45 +327,66 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
     uint32_t re = min(span_end, boundary);
     uint32_t tile = base8 + first_region * R;
 
-    if (tile < hi) {
-        uint32_t carry[4] = {0, 0, 0, 0};
+    bool vec_todo = tile < hi;          // tile groups left in the vector part of the span
+    bool tail_todo = span_end > nfull;  // the units behind the last full vector of the buffer (fewer than 8)
+    uint32_t d0 = 0;                    // tile of the current group to resume at (after a mid-group drain)
+    uint32_t carry[4] = {0, 0, 0, 0};
+    uint4 nxt[kPrefetch], grp[kPrefetch];
+#pragma unroll
+    for (int d = 0; d < kPrefetch; ++d) nxt[d] = grp[d] = make_uint4(0, 0, 0, 0);
+    if (vec_todo) {
         if (K > 1 && tile >= 8) {
             const uint4 p = *reinterpret_cast<const uint4 *>(hay + tile - 8);
             carry[0] = p.x; carry[1] = p.y; carry[2] = p.z; carry[3] = p.w;
         }
         // double-buffered tile groups: while the kPrefetch tiles of the current group are filtered out of registers, the
         // loads of the next group are in flight (4 KiB per wave); they are awaited together at the next group's start
-        uint4 nxt[kPrefetch];
 #pragma unroll
         for (int d = 0; d < kPrefetch; ++d)
             nxt[d] = *reinterpret_cast<const uint4 *>(hay + min(tile + d * kTileUnits + lane * 8, last_vec));
+    }
 
-        for (; tile < hi; tile += kPrefetch * kTileUnits) {
-            if (tile >= boundary) { // wave-uniform: the stream enters the next region (regions hold whole tile groups)
-                drain(c, 1);
-                if (lane == 0) L.d_region_counts[region] = c.rank_base;
-                c.rank_base = 0;
-                ++region;
-                rb = boundary;
-                boundary += R;
-                re = min(span_end, boundary);
+    // One loop, ONE verification site: every pass first drains the candidate queue as far as its state requires
+    // (completely at a region seam / before the tail / at the end; down to < 256 otherwise), then does one unit of
+    // streaming work.  Keeping the (large) verification code in a single place keeps the kernel small.
+    for (;;) {
+        const bool seam = vec_todo ? (d0 == 0 && tile >= boundary) : true; // wave-uniform
+        const uint32_t keep = seam ? 1u : (uint32_t)(kVerifyBatches * kWave);
+        if (c.cand_n >= keep && c.cand_n != 0) drain<K, RANGE>(c, keep);
+
+        if (vec_todo) {
+            if (d0 == 0) {
+                if (tile >= boundary) { // the stream enters the next region (regions hold whole tile groups)
+                    if (lane == 0) L.d_region_counts[region] = c.rank_base;
+                    c.rank_base = 0;
+                    ++region;
+                    rb = boundary;
+                    boundary += R;
+                    re = min(span_end, boundary);
+                }
+#pragma unroll
+                for (int d = 0; d < kPrefetch; ++d) grp[d] = nxt[d];
+#pragma unroll
+                for (int d = 0; d < kPrefetch; ++d)
+                    nxt[d] = *reinterpret_cast<const uint4 *>(
+                        hay + min(tile + (kPrefetch + d) * kTileUnits + lane * 8, last_vec));
             }
-            uint4 grp[kPrefetch];
-#pragma unroll
-            for (int d = 0; d < kPrefetch; ++d) grp[d] = nxt[d];
-#pragma unroll
-            for (int d = 0; d < kPrefetch; ++d)
-                nxt[d] = *reinterpret_cast<const uint4 *>(
-                    hay + min(tile + (kPrefetch + d) * kTileUnits + lane * 8, last_vec));
             // positions a lane may report: inside the region, in the vector part of the buffer, with K units to their
             // left in the buffer.  Only groups at the edges of a region need the per-lane mask.
             const uint32_t lo = max(rb, (uint32_t)(K - 1));
             const uint32_t top = min(re, hi);
             const bool edge = tile < lo || tile + kPrefetch * kTileUnits > top; // wave-uniform
+            bool resume = false;
 #pragma unroll
             for (int d = 0; d < kPrefetch; ++d) {
+                if ((uint32_t)d < d0) continue; // wave-uniform
                 const uint32_t cur = tile + d * kTileUnits;
                 if (cur >= hi) break; // wave-uniform
+                if (c.cand_n > kCandCap - kTileUnits) { // rare: the queue cannot take a worst-case tile -> drain first
+                    d0 = d;
+                    resume = true;
+                    break;
+                }
                 const uint4 w = grp[d];
                 const uint32_t v = cur + lane * 8;
                 const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
@@ -364,29 +438,35 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                 }
                 enqueue(c, mask, v);
             }
+            if (!resume) {
+                d0 = 0;
+                tile += kPrefetch * kTileUnits;
+                vec_todo = tile < hi;
+            }
+            continue;
         }
+        if (tail_todo) { // the queue is empty here (seam drain above)
+            tail_todo = false;
+            const uint32_t t0 = max(nfull, span_begin);
+            if (t0 >= boundary) { // the tail opens a new region
+                if (lane == 0) L.d_region_counts[region] = c.rank_base;
+                c.rank_base = 0;
+                ++region;
+            }
+            const uint32_t pos = t0 + lane;
+            uint32_t mask = 0;
+            if (pos < span_end && pos + 1 >= (uint32_t)K && !(L.debug & 4u)) {
+                uint32_t hrow = 0;
+                for (int j = K - 1; j >= 1; --j) hrow = hrow * n + tile_class_t<RANGE>(T, hay[pos - j]);
+                const uint32_t last = tile_class_t<RANGE>(T, hay[pos]);
+                const uint32_t word = rows32[hrow * (ROWB / 4) + (last >> 5)];
+                mask = (word >> (last & 31)) & 1u;
+            }
+            enqueue(c, mask, pos); // one position per lane: lane order is text order
+            continue;
+        }
+        break;
     }
-    // the units behind the last full vector of the buffer (fewer than 8), if this span owns them
-    if (span_end > nfull) {
-        const uint32_t t0 = max(nfull, span_begin);
-        if (t0 >= boundary) { // they open a new region
-            drain(c, 1);
-            if (lane == 0) L.d_region_counts[region] = c.rank_base;
-            c.rank_base = 0;
-            ++region;
-        }
-        const uint32_t pos = t0 + lane;
-        uint32_t mask = 0;
-        if (pos < span_end && pos + 1 >= (uint32_t)K && !(L.debug & 4u)) {
-            uint32_t hrow = 0;
-            for (int j = K - 1; j >= 1; --j) hrow = hrow * n + tile_class_t<RANGE>(T, hay[pos - j]);
-            const uint32_t last = tile_class_t<RANGE>(T, hay[pos]);
-            const uint32_t word = rows32[hrow * (ROWB / 4) + (last >> 5)];
-            mask = (word >> (last & 31)) & 1u;
-        }
-        enqueue(c, mask, pos); // one position per lane: lane order is text order
-    }
-    drain(c, 1);
     if (lane == 0) L.d_region_counts[region] = c.rank_base;
     // hand back the unused tail of the last reservation as holes the permute pass skips
     for (uint32_t i = lane; i < c.res_left; i += kWave) store_rec(L, c.res_cur + i, 0, 0, 0, ~0u);
