@@ -54,14 +54,14 @@ struct DeviceState {
     DevTables T{};
     std::vector<void *> table_allocs;
     // scratch pool (one in-flight match per automaton and device)
-    DevBuf counter, chunk_counts, offsets, scan_tmp, scratch, chain;
+    DevBuf counter, chunk_counts, offsets, scan_tmp, scratch, chain, lenbuf, statebuf;
     DevBuf stage_hay, stage_out; // acgpu_match_u16 staging
     unsigned long long *h_counter = nullptr; // pinned
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     ~DeviceState() {
         for (void *p : table_allocs) (void)hipFree(p);
         counter.release(); chunk_counts.release(); offsets.release(); scan_tmp.release(); scratch.release();
-        chain.release(); stage_hay.release(); stage_out.release();
+        chain.release(); lenbuf.release(); statebuf.release(); stage_hay.release(); stage_out.release();
         if (h_counter) (void)hipHostFree(h_counter);
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
     }
@@ -93,7 +93,7 @@ uint32_t lds_states_for(const HostTables &t) {
     int64_t budget = tunables().lds_table_bytes;
     const int64_t max_budget = 160 * 1024 - (int64_t)scan_queue_bytes(scan_block_threads()) - 1024;
     budget = std::max<int64_t>(0, std::min(budget, max_budget));
-    uint64_t row = (uint64_t)t.n_cls * t.entry_bytes;
+    uint64_t row = (uint64_t)t.n_cls * t.entry_bytes + (t.mode == ACGPU_MODE_LONGEST ? 4 : 0);
     uint64_t s = row ? (uint64_t)budget / row : 0;
     return (uint32_t)std::min<uint64_t>(s, t.n_states);
 }
@@ -288,6 +288,95 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
     return *n_out > cap ? ACGPU_E_OVERFLOW : ACGPU_OK;
 }
 
+// LONGEST-mode pipeline on one shard: reverse scan -> chain count -> prefix sum -> chain write.
+int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_kind, void *d_out, uint64_t cap,
+                  uint64_t *n_out, hipStream_t stream, acgpu_profile *prof) {
+    const HostTables &t = a->t;
+    const uint32_t halo = t.max_len > 0 ? t.max_len - 1 : 0;
+    if (!sh->text_end && sh->n_units - sh->own_end < halo) return ACGPU_E_INVALID; // right halo too short
+    if (sh->chain_entry < (int64_t)sh->own_begin) return ACGPU_E_INVALID;
+    if (prof) std::memset(prof, 0, sizeof(*prof));
+    const uint64_t entry = (uint64_t)sh->chain_entry;
+    sh->chain_exit = (int64_t)std::max<uint64_t>(entry, sh->own_end);
+    if (entry >= sh->own_end || t.n_states <= 1) {
+        *n_out = 0;
+        if (entry < sh->own_end) sh->chain_exit = (int64_t)sh->own_end;
+        return ACGPU_OK;
+    }
+    const uint64_t own_len = sh->own_end - sh->own_begin;
+    LongestScanLaunch S{};
+    S.block = 1024;
+    S.grid = d.n_cu;
+    const uint64_t lanes = (uint64_t)S.grid * S.block;
+    uint64_t C = tunables().chunk_units > 0 ? (uint64_t)tunables().chunk_units
+                                            : std::max<uint64_t>({(own_len + lanes - 1) / lanes, 256, 16ull * halo});
+    C = std::max<uint32_t>(8, round_up8(C));
+    S.chunk_units = (uint32_t)C;
+    S.n_chunks = (uint32_t)((own_len + C - 1) / C);
+    S.grid = (int)std::min<uint64_t>((uint64_t)S.grid, ((uint64_t)S.n_chunks + S.block - 1) / S.block);
+    S.d_hay = sh->d_hay;
+    S.n_units = (uint32_t)sh->n_units;
+    S.own_begin = (uint32_t)sh->own_begin;
+    S.own_end = (uint32_t)sh->own_end;
+    S.len_bytes = t.max_len < 65536 ? 2 : 4;
+    const uint32_t lds_states = t.dense && t.n_cls ? d.T.lds_entries / t.n_cls : 0;
+    S.lds_bytes = t.dense ? (size_t)lds_states * 4 + (size_t)d.T.lds_entries * t.entry_bytes : 0;
+    int rc;
+    if ((rc = d.lenbuf.ensure((size_t)sh->n_units * S.len_bytes + 64))) return rc;
+    S.d_len = d.lenbuf.p;
+    S.d_state = nullptr;
+    if (record_kind == ACGPU_REC_MAP) {
+        if ((rc = d.statebuf.ensure((size_t)sh->n_units * 4 + 64))) return rc;
+        S.d_state = (uint32_t *)d.statebuf.p;
+    }
+    LongestChainLaunch Cn{};
+    const uint64_t T_units = std::max<uint64_t>(1024, 4ull * t.max_len);
+    Cn.tile_units = (uint32_t)T_units;
+    Cn.n_tiles = (uint32_t)((sh->own_end - entry + T_units - 1) / T_units);
+    if ((rc = d.counter.ensure(64))) return rc;
+    if ((rc = d.chunk_counts.ensure((size_t)Cn.n_tiles * 4))) return rc;
+    if ((rc = d.offsets.ensure((size_t)Cn.n_tiles * 8))) return rc;
+    if ((rc = d.scan_tmp.ensure(((size_t)Cn.n_tiles / 2048 + 2) * 8))) return rc;
+    Cn.d_len = d.lenbuf.p;
+    Cn.d_state = S.d_state;
+    Cn.d_out_id = d.T.out_id;
+    Cn.len_bytes = S.len_bytes;
+    Cn.own_end = (uint32_t)sh->own_end;
+    Cn.entry = (uint32_t)entry;
+    Cn.max_len = t.max_len;
+    Cn.d_counts = (uint32_t *)d.chunk_counts.p;
+    Cn.d_offsets = (const uint64_t *)d.offsets.p;
+    Cn.d_out = d_out;
+    Cn.cap = cap;
+    Cn.record_kind = record_kind;
+    Cn.d_exit = (unsigned long long *)d.counter.p;
+
+    HIP_TRY(hipMemsetAsync(d.counter.p, 0, 64, stream));
+    if (prof) HIP_TRY(hipEventRecord(d.ev[0], stream));
+    const char *kname = "";
+    HIP_TRY(launch_longest_scan(d.T, S, stream, &kname));
+    if (prof) HIP_TRY(hipEventRecord(d.ev[1], stream));
+    HIP_TRY(launch_longest_chain(Cn, /*write_pass=*/false, stream));
+    HIP_TRY(launch_exclusive_scan(Cn.d_counts, Cn.n_tiles, (uint64_t *)d.offsets.p, (uint64_t *)d.scan_tmp.p, stream));
+    HIP_TRY(launch_longest_chain(Cn, /*write_pass=*/true, stream));
+    if (prof) HIP_TRY(hipEventRecord(d.ev[2], stream));
+    HIP_TRY(hipMemcpyAsync(d.h_counter, (const uint64_t *)d.scan_tmp.p + scan_tiles_for(Cn.n_tiles), 8, hipMemcpyDeviceToHost,
+                           stream));
+    HIP_TRY(hipMemcpyAsync(d.h_counter + 1, d.counter.p, 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    *n_out = d.h_counter[0];
+    sh->chain_exit = (int64_t)d.h_counter[1];
+    if (prof) {
+        HIP_TRY(hipEventElapsedTime(&prof->scan_ms, d.ev[0], d.ev[1]));
+        HIP_TRY(hipEventElapsedTime(&prof->finalize_ms, d.ev[1], d.ev[2]));
+        HIP_TRY(hipEventElapsedTime(&prof->total_ms, d.ev[0], d.ev[2]));
+        prof->scan_units = own_len + (uint64_t)S.n_chunks * halo;
+        prof->n_matches = *n_out;
+        std::snprintf(prof->scan_kernel, sizeof(prof->scan_kernel), "%s", kname);
+    }
+    return *n_out > cap ? ACGPU_E_OVERFLOW : ACGPU_OK;
+}
+
 int device_for_call(acgpu_automaton *a, DeviceState **d) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
@@ -308,6 +397,7 @@ int match_shard(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_
     *n_out = 0;
     switch (a->t.mode) {
     case ACGPU_MODE_ALL: return match_all(a, d, sh, record_kind, d_out, cap, n_out, stream, prof);
+    case ACGPU_MODE_LONGEST: return match_longest(a, d, sh, record_kind, d_out, cap, n_out, stream, prof);
     default: return ACGPU_E_UNSUPPORTED;
     }
 }
@@ -362,6 +452,15 @@ int acgpu_build(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uint
     if (!a) return ACGPU_E_NOMEM;
     int rc;
     try {
+        if (mode == ACGPU_MODE_LONGEST && n_kw && kw_units && kw_off) {
+            // LONGEST runs the automaton of the REVERSED keywords right-to-left (acgpu_longest.hip)
+            std::vector<uint16_t> rev(kw_off[n_kw] ? kw_off[n_kw] : 1);
+            for (uint32_t k = 0; k < n_kw; k++) {
+                const uint64_t lo = kw_off[k], hi = kw_off[k + 1];
+                for (uint64_t i = lo; i < hi; i++) rev[i] = kw_units[hi - 1 - (i - lo)];
+            }
+            rc = build_tables(mode, rev.data(), kw_off, n_kw, case_sensitive, lower_tbl, wordchar_tbl, a->t, bad_keyword);
+        } else
         rc = build_tables(mode, kw_units, kw_off, n_kw, case_sensitive, lower_tbl, wordchar_tbl, a->t, bad_keyword);
     } catch (const std::bad_alloc &) {
         rc = ACGPU_E_NOMEM;

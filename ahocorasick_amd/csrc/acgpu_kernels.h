@@ -71,3 +71,37 @@ int scan_block_threads();
 size_t scan_queue_bytes(int block_threads);
 
 } // namespace acgpu
+
+namespace acgpu {
+// ---- LONGEST (leftmost-longest, non-overlapping) pipeline -------------------------------------------------
+struct LongestScanLaunch {
+    const uint16_t *d_hay;
+    uint32_t n_units, own_begin, own_end;
+    uint32_t chunk_units, n_chunks; // owned START positions per lane chunk (multiple of 8)
+    void *d_len;                    // per unit of the buffer: length of the longest keyword starting there (u16 or u32)
+    uint32_t *d_state;              // optional: automaton state per unit (for the keyword id), or nullptr
+    int len_bytes;                  // 2 or 4
+    int grid, block;
+    size_t lds_bytes;
+};
+hipError_t launch_longest_scan(const DevTables &t, const LongestScanLaunch &l, hipStream_t stream, const char **kernel_name);
+
+struct LongestChainLaunch {
+    const void *d_len;
+    const uint32_t *d_state; // or nullptr (Set records)
+    const uint32_t *d_out_id;
+    int len_bytes;
+    uint32_t own_end;
+    uint32_t entry;       // first greedy-chain position of this shard
+    uint32_t tile_units;  // positions per lane
+    uint32_t n_tiles;
+    uint32_t max_len;
+    uint32_t *d_counts;         // per tile
+    const uint64_t *d_offsets;  // per tile (write pass)
+    void *d_out;
+    uint64_t cap;
+    int record_kind;
+    unsigned long long *d_exit; // first chain position >= own_end
+};
+hipError_t launch_longest_chain(const LongestChainLaunch &l, bool write_pass, hipStream_t stream);
+} // namespace acgpu

@@ -266,3 +266,87 @@ def test_config_c2_full_size_properties():
             N.set_tunable(k, v)
         got2, prof2 = _dev_match(a, d_hay, n, True, cap, profile=True)
         assert got2.shape == got.shape and (got2 == got).all(), (knobs, prof2["scan_kernel"])
+
+
+# ---- LongestMatchSet / LongestMatchMap ------------------------------------------------------------------------------
+
+def test_fixtures_longest(fixtures):
+    for fx in fixtures:
+        hay, kws = fixture_inputs(fx)
+        assert LongestMatchMap(kws, _ids(len(kws)), True).find_all(hay).tolist() == fx["L"], fx["name"]
+        assert LongestMatchSet(kws, True).find_all(hay).tolist() == [r[:2] for r in fx["L"]], fx["name"]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_longest_vs_oracle(seed):
+    rng = np.random.default_rng(500 + seed)
+    alpha = [ord(c) for c in "ab"] if seed % 2 == 0 else [ord(c) for c in "abcAB"] + [0x00E9, 0x00C9]
+    for it in range(12):
+        hay, kws = rand_case(rng, alpha, int(rng.integers(1, 20)), int(rng.integers(1, 9)), int(rng.integers(0, 6000)))
+        for cs in (True, False):
+            want = Oracle(FAM_LONGEST, kws, case_sensitive=cs, lower=LOWER).match(hay).tolist()
+            got = LongestMatchMap(kws, _ids(len(kws)), cs).find_all(hay).tolist()
+            assert got == want, (seed, it, cs)
+
+
+@pytest.mark.parametrize("chunk_units,lds_bytes,sparse", [(8, 96 * 1024, 0), (64, 0, 0), (0, 96 * 1024, 1)])
+def test_longest_variants(chunk_units, lds_bytes, sparse):
+    N.set_tunable("chunk_units", chunk_units)
+    N.set_tunable("lds_table_bytes", lds_bytes)
+    N.set_tunable("force_sparse", sparse)
+    rng = np.random.default_rng(4242)
+    for alpha in ([ord(c) for c in "ab"], list(range(ord("a"), ord("g") + 1)), list(range(0x4E00, 0x4E20))):
+        hay, kws = rand_case(rng, alpha, 60, 9, 50000)
+        want = Oracle(FAM_LONGEST, kws).match(hay).tolist()
+        assert LongestMatchMap(kws, _ids(len(kws)), True).find_all(hay).tolist() == want
+
+
+def test_longest_listener_and_early_stop():
+    kws = ["a", "aa", "aaa", "aaaa"]
+    hay = " aaaaaaa aaababababaabaa "
+    s = LongestMatchSet(kws, True)
+    full = Oracle(FAM_LONGEST, kws).match(hay)
+    for k in (1, 3, len(full)):
+        got = []
+        s.match(hay, lambda h, a, b: (got.append((a, b)) or len(got) < k))
+        assert got == [tuple(r[:2]) for r in Oracle(FAM_LONGEST, kws).match(hay, stop_after=k).tolist()]
+    m = LongestMatchMap(["ab", "abc", "ab"], ["x", "y", "z"], True)
+    vals = []
+    m.match("ab abc", lambda h, a, b, v: vals.append((a, b, v)) or True)
+    assert vals == [(0, 2, "z"), (3, 6, "y")]
+
+
+def test_longest_prefix_closed_dictionary_like_config_c4():
+    # BASELINE config 4 in miniature: every prefix of long {a,b} words (a, aa, aaa, ...), P(a)=0.75 haystack;
+    # max keyword length 200 stresses the right-halo warm-up and the synchronisation-point logic
+    kws = synth.prefix_closed_keywords(1004, 3000, word_len=200)
+    hay = synth.haystack(2004, 1 << 18, table=synth.ALPHA_AB_75)
+    want = Oracle(FAM_LONGEST, kws).match(hay)
+    got = LongestMatchSet(kws, True).find_all(hay)
+    assert got.shape == want[:, :2].shape and (got == want[:, :2]).all()
+    # adversarial: one long run of 'a' (no synchronisation point inside the run)
+    hay2 = np.concatenate([np.full(5000, ord("a"), np.uint16), utf16("bab"), np.full(777, ord("a"), np.uint16)])
+    want2 = Oracle(FAM_LONGEST, kws).match(hay2)
+    got2 = LongestMatchMap(kws, _ids(len(kws)), True).find_all(hay2)
+    assert (got2 == want2).all()
+
+
+def test_longest_shards_with_chain_entry_and_exit():
+    import torch
+    kws = synth.random_keywords(21, 400, 1, 7, table=synth.ALPHA_LOWER[:5])
+    hay = synth.haystack(78, 200000, table=synth.ALPHA_LOWER[:5])
+    a = Automaton(N.MODE_LONGEST, kws, True)
+    want = Oracle(FAM_LONGEST, kws).match(hay)
+    d_hay = torch.from_numpy(hay.view(np.int16)).cuda()
+    cap = len(want) + 10
+    cuts = [0, 70001, 140003, hay.size]
+    parts, entry = [], 0
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        d_out = torch.empty((cap, 3), dtype=torch.int32, device="cuda")
+        n_out, rc, _, chain_exit = a.match_device(d_hay.data_ptr(), hay.size, True, d_out.data_ptr(), cap, own=(lo, hi),
+                                                  chain_entry=max(entry, lo))
+        assert rc == N.OK
+        parts.append(d_out[:n_out].cpu().numpy())
+        entry = chain_exit
+        assert entry >= hi
+    assert (np.concatenate(parts) == want).all()
