@@ -377,6 +377,94 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
     return *n_out > cap ? ACGPU_E_OVERFLOW : ACGPU_OK;
 }
 
+// WHOLEWORD-mode pipeline on one shard.
+int match_wholeword(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_kind, void *d_out, uint64_t cap,
+                    uint64_t *n_out, hipStream_t stream, acgpu_profile *prof) {
+    const HostTables &t = a->t;
+    const uint64_t own_len = sh->own_end - sh->own_begin;
+    if (prof) std::memset(prof, 0, sizeof(*prof));
+    if (own_len == 0) {
+        *n_out = 0;
+        return ACGPU_OK;
+    }
+    int rc;
+    if ((rc = d.counter.ensure(64))) return rc;
+    HIP_TRY(hipMemsetAsync(d.counter.p, 0, 64, stream));
+    if (!t.fold_consistent) {
+        // the reference's mixed folded/raw lookups make token boundaries history dependent: whole text, one lane
+        if (!sh->text_begin || !sh->text_end || sh->own_begin != 0 || sh->own_end != sh->n_units) return ACGPU_E_UNSUPPORTED;
+        if (prof) HIP_TRY(hipEventRecord(d.ev[0], stream));
+        HIP_TRY(launch_ww_sequential(d.T, sh->d_hay, (uint32_t)sh->n_units, d_out, cap, record_kind,
+                                     (unsigned long long *)d.counter.p, stream));
+        if (prof) HIP_TRY(hipEventRecord(d.ev[1], stream));
+        HIP_TRY(hipMemcpyAsync(d.h_counter, d.counter.p, 8, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        *n_out = *d.h_counter;
+        if (prof) {
+            HIP_TRY(hipEventElapsedTime(&prof->scan_ms, d.ev[0], d.ev[1]));
+            prof->total_ms = prof->scan_ms;
+            prof->scan_units = own_len;
+            prof->n_matches = *n_out;
+            std::snprintf(prof->scan_kernel, sizeof(prof->scan_kernel), "k_ww_sequential");
+        }
+        return *n_out > cap ? ACGPU_E_OVERFLOW : ACGPU_OK;
+    }
+    if (!sh->text_begin && sh->own_begin < 1) return ACGPU_E_INVALID;                              // left context: 1 unit
+    if (!sh->text_end && sh->n_units - sh->own_end < (uint64_t)t.max_len + 1) return ACGPU_E_INVALID; // right halo
+    const uint64_t scratch_cap = std::min<uint64_t>(
+        std::max<uint64_t>(cap, 1) + (uint64_t)d.n_cu * (tile_block_threads() / 64) * tile_reserve_slots(), 0xffffffe0ull);
+    if ((rc = d.scratch.ensure(scratch_cap * sizeof(ScratchRec)))) return rc;
+    TileLaunch L{};
+    L.block = tile_block_threads();
+    const int waves_per_block = L.block / 64;
+    uint64_t R = tunables().region_units > 0 ? (uint64_t)tunables().region_units : 16384;
+    R = std::max<uint64_t>(2048, (R + 2047) / 2048 * 2048);
+    L.region_units = (uint32_t)R;
+    const uint64_t base8 = sh->own_begin & ~7ull;
+    L.n_regions = (uint32_t)((sh->own_end - base8 + R - 1) / R);
+    const uint64_t waves_max = (uint64_t)d.n_cu * waves_per_block;
+    L.regions_per_wave = (uint32_t)((L.n_regions + waves_max - 1) / waves_max);
+    const uint64_t waves_used = ((uint64_t)L.n_regions + L.regions_per_wave - 1) / L.regions_per_wave;
+    L.grid = (int)((waves_used + waves_per_block - 1) / waves_per_block);
+    L.d_hay = sh->d_hay;
+    L.n_units = (uint32_t)sh->n_units;
+    L.own_begin = (uint32_t)sh->own_begin;
+    L.own_end = (uint32_t)sh->own_end;
+    L.cap = scratch_cap;
+    L.lds_bytes = ww_lds_bytes(L.block);
+    L.debug = 0;
+    if ((rc = d.chunk_counts.ensure((size_t)L.n_regions * 4))) return rc;
+    if ((rc = d.offsets.ensure((size_t)L.n_regions * 8))) return rc;
+    if ((rc = d.scan_tmp.ensure(((size_t)L.n_regions / 2048 + 2) * 8))) return rc;
+    L.d_scratch = (ScratchRec *)d.scratch.p;
+    L.d_counter = (unsigned long long *)d.counter.p;
+    L.d_region_counts = (uint32_t *)d.chunk_counts.p;
+    HIP_TRY(hipMemsetAsync(d.chunk_counts.p, 0, (size_t)L.n_regions * 4, stream));
+    if (prof) HIP_TRY(hipEventRecord(d.ev[0], stream));
+    const char *kname = "";
+    HIP_TRY(launch_ww_tile(d.T, L, stream, &kname));
+    if (prof) HIP_TRY(hipEventRecord(d.ev[1], stream));
+    HIP_TRY(launch_exclusive_scan((const uint32_t *)d.chunk_counts.p, L.n_regions, (uint64_t *)d.offsets.p,
+                                  (uint64_t *)d.scan_tmp.p, stream));
+    HIP_TRY(launch_permute((const ScratchRec *)d.scratch.p, (const unsigned long long *)d.counter.p, scratch_cap,
+                           (const uint64_t *)d.offsets.p, (uint32_t)base8, L.region_units, /*by_start=*/1, record_kind,
+                           d_out, cap, nullptr, stream));
+    if (prof) HIP_TRY(hipEventRecord(d.ev[2], stream));
+    HIP_TRY(hipMemcpyAsync(d.h_counter, (const uint64_t *)d.scan_tmp.p + scan_tiles_for(L.n_regions), 8,
+                           hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    *n_out = *d.h_counter;
+    if (prof) {
+        HIP_TRY(hipEventElapsedTime(&prof->scan_ms, d.ev[0], d.ev[1]));
+        HIP_TRY(hipEventElapsedTime(&prof->finalize_ms, d.ev[1], d.ev[2]));
+        HIP_TRY(hipEventElapsedTime(&prof->total_ms, d.ev[0], d.ev[2]));
+        prof->scan_units = own_len;
+        prof->n_matches = *n_out;
+        std::snprintf(prof->scan_kernel, sizeof(prof->scan_kernel), "%s", kname);
+    }
+    return *n_out > cap ? ACGPU_E_OVERFLOW : ACGPU_OK;
+}
+
 int device_for_call(acgpu_automaton *a, DeviceState **d) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
@@ -398,6 +486,7 @@ int match_shard(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_
     switch (a->t.mode) {
     case ACGPU_MODE_ALL: return match_all(a, d, sh, record_kind, d_out, cap, n_out, stream, prof);
     case ACGPU_MODE_LONGEST: return match_longest(a, d, sh, record_kind, d_out, cap, n_out, stream, prof);
+    case ACGPU_MODE_WHOLEWORD: return match_wholeword(a, d, sh, record_kind, d_out, cap, n_out, stream, prof);
     default: return ACGPU_E_UNSUPPORTED;
     }
 }

@@ -105,3 +105,11 @@ struct LongestChainLaunch {
 };
 hipError_t launch_longest_chain(const LongestChainLaunch &l, bool write_pass, hipStream_t stream);
 } // namespace acgpu
+
+namespace acgpu {
+// ---- WHOLEWORD pipeline (acgpu_wholeword.hip) -----------------------------------------------------------------
+size_t ww_lds_bytes(int block_threads);
+hipError_t launch_ww_tile(const DevTables &t, const TileLaunch &l, hipStream_t stream, const char **kernel_name);
+hipError_t launch_ww_sequential(const DevTables &t, const uint16_t *d_hay, uint32_t len, void *d_out, uint64_t cap,
+                                int record_kind, unsigned long long *d_counter, hipStream_t stream);
+} // namespace acgpu

@@ -23,17 +23,9 @@
 
 #include <cstdio>
 
-#include "acgpu_device.h"
-#include "acgpu_kernels.h"
+#include "acgpu_tile_common.h"
 
 namespace acgpu {
-
-constexpr int kTileBlock = 1024;               // 16 waves share one LDS copy of the filter rows
-constexpr int kTileUnits = 512;                // units per wave tile (64 lanes x 8 units)
-constexpr int kVerifyBatches = 4;              // candidates verified per lane and call (independent load chains in flight)
-constexpr int kCandCap = 1024;                 // candidate queue entries per wave; a tile adds at most 512
-constexpr int kPrefetch = 4;                   // tiles per group; one group of loads is in flight per wave
-constexpr uint32_t kReserve = 256;             // scratch slots a wave reserves per atomic
 
 int tile_block_threads() { return kTileBlock; }
 uint32_t tile_reserve_slots() { return kReserve; }
@@ -41,16 +33,6 @@ uint32_t tile_reserve_slots() { return kReserve; }
 size_t tile_lds_bytes(const DevTables &t, int block_threads) {
     return (size_t)t.filt_words * 4 + (size_t)(block_threads / kWave) * kCandCap * sizeof(uint32_t);
 }
-
-struct TileCtx {
-    const DevTables *Tp;
-    const TileLaunch *Lp;
-    uint32_t *cand;     // this wave's candidate queue in LDS: end positions (last unit index), in text order
-    uint32_t cand_n;    // wave-uniform
-    uint32_t rank_base; // wave-uniform: records emitted so far in the current region
-    uint32_t res_cur;   // wave-uniform: next free reserved scratch slot (scratch capacity < 2^32)
-    uint32_t res_left;          // wave-uniform: reserved slots left
-};
 
 struct __attribute__((packed, aligned(2))) Units8 { // 8 UTF-16 units at any unit address (one global_load_dwordx4)
     uint32_t d[4];
@@ -75,14 +57,6 @@ __device__ __forceinline__ uint32_t rchild(const DevTables &T, uint32_t id, uint
     return r == ~0u ? 0u : r;
 }
 
-__device__ __forceinline__ void store_rec(const TileLaunch &L, uint32_t slot, uint32_t start, uint32_t end, uint32_t id,
-                                          uint32_t rank) {
-    if ((uint64_t)slot < L.cap) {
-        const uint4 v = make_uint4(start, end, id, rank);
-        *reinterpret_cast<uint4 *>(&L.d_scratch[slot]) = v;
-    }
-}
-
 // One step of the leftward walk from a flagged node ref: returns the child's ref or 0.  The only-child hint lets a
 // mismatching unit end the walk without a memory access.
 template <bool RANGE>
@@ -91,17 +65,6 @@ __device__ __forceinline__ uint32_t walk_step(const DevTables &T, uint32_t ref, 
     const uint32_t hint = (ref >> kRefHintShift) & kRefHintMask;
     if (hint != 0 && hint - 1 != cls) return 0;
     return rchild(T, ref & kRefIdMask, unit, cls);
-}
-
-// wave64 inclusive prefix sum with DPP row shifts and row broadcasts (6 dependent v_add_u32_dpp)
-__device__ __forceinline__ uint32_t wave_inclusive_scan_dpp(uint32_t x) {
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true); // row_shr:1
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true); // row_shr:2
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true); // row_shr:4
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true); // row_shr:8
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1 and 3
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2 and 3
-    return x;
 }
 
 // Verification of up to kVerifyBatches*64 queued candidates: kVerifyBatches per lane, advanced in lock step so that
@@ -182,25 +145,8 @@ __device__ __forceinline__ void verify_multi(TileCtx &c, uint32_t head, uint32_t
         total += __builtin_amdgcn_readlane(incl, kWave - 1);
     }
     if (total == 0) return;
-    // slot of the wave's k-th record of this call: the tail of the current reservation, then a fresh one
-    const uint32_t old_cur = c.res_cur;
-    const uint32_t old_left = c.res_left;
-    uint32_t fresh = 0;
-    if (total > old_left) {
-        const uint32_t need = total - old_left;
-        const uint32_t take = need > kReserve ? need : kReserve;
-        unsigned long long got = 0;
-        if (lane == 0) got = atomicAdd(L.d_counter, (unsigned long long)take);
-        // beyond the scratch capacity nothing is stored (the host reports ACGPU_E_OVERFLOW from the exact counts)
-        fresh = (uint32_t)min(got, (unsigned long long)0xfffffff0u - take);
-        fresh = __builtin_amdgcn_readfirstlane(fresh);
-        c.res_cur = fresh + need;
-        c.res_left = take - need;
-    } else {
-        c.res_cur = old_cur + total;
-        c.res_left = old_left - total;
-    }
-    auto slot_of = [&](uint32_t k) -> uint32_t { return k < old_left ? old_cur + k : fresh + (k - old_left); };
+    const SlotRange sr = reserve_slots(c, total);
+    auto slot_of = [&](uint32_t k) -> uint32_t { return sr.slot(k); };
     bool multi = false;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -256,29 +202,6 @@ __device__ __forceinline__ void drain(TileCtx &c, uint32_t keep_below) {
         }
         __builtin_amdgcn_wave_barrier();
         c.cand_n = left;
-    }
-}
-
-// value of x in lane-1; lane 0 receives `carry` (v_mov_b32_dpp wave_shr:1)
-__device__ __forceinline__ uint32_t from_prev_lane(uint32_t x, uint32_t carry) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)x, 0x138, 0xf, 0xf, false);
-}
-
-// append this lane's candidates (bit j of mask: position v+j) to the wave queue in text order
-__device__ __forceinline__ void enqueue(TileCtx &c, uint32_t mask, uint32_t v) {
-    const uint32_t cnt = __popc(mask);
-    const uint32_t incl = wave_inclusive_scan_dpp(cnt);
-    const uint32_t total = __builtin_amdgcn_readlane(incl, kWave - 1);
-    if (total) {
-        uint32_t slot = c.cand_n + incl - cnt;
-        while (__any(mask != 0)) { // as many rounds as the busiest lane has candidates (2-3 at 2 % density)
-            if (mask != 0) {
-                c.cand[slot++] = v + (uint32_t)__builtin_ctz(mask);
-                mask &= mask - 1;
-            }
-        }
-        c.cand_n += total;
-        __builtin_amdgcn_wave_barrier();
     }
 }
 

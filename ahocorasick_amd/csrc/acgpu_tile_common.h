@@ -1,0 +1,97 @@
+// acgpu_tile_common.h -- pieces shared by the position-parallel tile kernels (acgpu_tile.hip: AhoCorasick all-matches,
+// acgpu_wholeword.hip: WholeWord): per-wave candidate queue in LDS, text-order compaction, DPP scans, record slots.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "acgpu_device.h"
+#include "acgpu_kernels.h"
+
+namespace acgpu {
+
+constexpr int kTileBlock = 1024;               // 16 waves share one LDS copy of the filter rows
+constexpr int kTileUnits = 512;                // units per wave tile (64 lanes x 8 units)
+constexpr int kVerifyBatches = 4;              // candidates verified per lane and call (independent load chains in flight)
+constexpr int kCandCap = 1024;                 // candidate queue entries per wave; a tile adds at most 512
+constexpr int kPrefetch = 4;                   // tiles per group; one group of loads is in flight per wave
+constexpr uint32_t kReserve = 256;             // scratch slots a wave reserves per atomic
+
+struct TileCtx {
+    const DevTables *Tp;
+    const TileLaunch *Lp;
+    uint32_t *cand;     // this wave's candidate queue in LDS: end positions (last unit index), in text order
+    uint32_t cand_n;    // wave-uniform
+    uint32_t rank_base; // wave-uniform: records emitted so far in the current region
+    uint32_t res_cur;   // wave-uniform: next free reserved scratch slot (scratch capacity < 2^32)
+    uint32_t res_left;          // wave-uniform: reserved slots left
+};
+
+__device__ __forceinline__ void store_rec(const TileLaunch &L, uint32_t slot, uint32_t start, uint32_t end, uint32_t id,
+                                          uint32_t rank) {
+    if ((uint64_t)slot < L.cap) {
+        const uint4 v = make_uint4(start, end, id, rank);
+        *reinterpret_cast<uint4 *>(&L.d_scratch[slot]) = v;
+    }
+}
+
+// wave64 inclusive prefix sum with DPP row shifts and row broadcasts (6 dependent v_add_u32_dpp)
+__device__ __forceinline__ uint32_t wave_inclusive_scan_dpp(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true); // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true); // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true); // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true); // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1 and 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2 and 3
+    return x;
+}
+
+// value of x in lane-1; lane 0 receives `carry` (v_mov_b32_dpp wave_shr:1)
+__device__ __forceinline__ uint32_t from_prev_lane(uint32_t x, uint32_t carry) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)x, 0x138, 0xf, 0xf, false);
+}
+
+// append this lane's candidates (bit j of mask: position v+j) to the wave queue in text order
+__device__ __forceinline__ void enqueue(TileCtx &c, uint32_t mask, uint32_t v) {
+    const uint32_t cnt = __popc(mask);
+    const uint32_t incl = wave_inclusive_scan_dpp(cnt);
+    const uint32_t total = __builtin_amdgcn_readlane(incl, kWave - 1);
+    if (total) {
+        uint32_t slot = c.cand_n + incl - cnt;
+        while (__any(mask != 0)) { // as many rounds as the busiest lane has candidates (2-3 at 2 % density)
+            if (mask != 0) {
+                c.cand[slot++] = v + (uint32_t)__builtin_ctz(mask);
+                mask &= mask - 1;
+            }
+        }
+        c.cand_n += total;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+
+// Reserve `total` record slots for this wave (wave-uniform); returns a functor-like pair through references:
+// slot of the k-th record = k < old_left ? old_cur + k : fresh + (k - old_left).
+struct SlotRange {
+    uint32_t old_cur, old_left, fresh;
+    __device__ __forceinline__ uint32_t slot(uint32_t k) const { return k < old_left ? old_cur + k : fresh + (k - old_left); }
+};
+
+__device__ __forceinline__ SlotRange reserve_slots(TileCtx &c, uint32_t total) {
+    SlotRange r{c.res_cur, c.res_left, 0};
+    if (total > r.old_left) {
+        const uint32_t need = total - r.old_left;
+        const uint32_t take = need > kReserve ? need : kReserve;
+        unsigned long long got = 0;
+        if (lane_id() == 0) got = atomicAdd(c.Lp->d_counter, (unsigned long long)take);
+        // beyond the scratch capacity nothing is stored (the host reports ACGPU_E_OVERFLOW from the exact counts)
+        uint32_t fresh = (uint32_t)min(got, (unsigned long long)0xfffffff0u - take);
+        r.fresh = __builtin_amdgcn_readfirstlane(fresh);
+        c.res_cur = r.fresh + need;
+        c.res_left = take - need;
+    } else {
+        c.res_cur = r.old_cur + total;
+        c.res_left = r.old_left - total;
+    }
+    return r;
+}
+
+} // namespace acgpu

@@ -1,0 +1,308 @@
+// acgpu_wholeword.hip -- WholeWordMatchSet/Map on gfx950.
+//
+// The reference (S/WholeWordMatchMap.java:155-240) tokenises the haystack into maximal runs of word characters and
+// reports a run iff its (case-folded) text is a keyword.  With a fold-consistent word-character table
+// (wordchar[c] == wordchar[lower[c]] for every c: every case-sensitive use and the default table) that is a
+// position-parallel problem:
+//
+//   filter : a position starts a run iff it is a word character and its left neighbour is not.  The 65536-bit
+//            word-character table lives in LDS (8 KB); one ds_read_b32 per unit.
+//   verify : run starts are compacted in text order into the per-wave LDS queue; kVerifyBatches*64 at a time they
+//            walk the keyword trie (hashed goto edges, L2-resident) along their run; a run that ends on a terminal
+//            node is a match.  At most one record per run start, ranks by wave prefix sums (as in acgpu_tile.hip).
+//
+// Inconsistent tables (possible only with a custom table in case-insensitive mode, where the reference mixes folded
+// and raw lookups, S/WholeWordMatchMap.java:204,209 vs :221,:226) take k_ww_sequential: a literal single-lane
+// restatement of the reference loop -- slow, but exact.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+
+#include "acgpu_tile_common.h"
+
+namespace acgpu {
+
+size_t ww_lds_bytes(int block_threads) { return 8192 + (size_t)(block_threads / kWave) * kCandCap * sizeof(uint32_t); }
+
+__device__ __forceinline__ uint32_t word_bit(const uint32_t *wbits, uint32_t unit) {
+    return __builtin_amdgcn_ubfe(wbits[unit >> 5], unit, 1);
+}
+
+// Verification of up to kVerifyBatches*64 run starts, kVerifyBatches per lane, advanced in lock step.
+__device__ __forceinline__ void ww_verify(TileCtx &c, const uint32_t *wbits, uint32_t head, uint32_t n_cand) {
+    constexpr int NB = kVerifyBatches;
+    const DevTables &T = *c.Tp;
+    const TileLaunch &L = *c.Lp;
+    const uint16_t *hay = L.d_hay;
+    const uint32_t lane = lane_id();
+    uint32_t s[NB], i[NB], node[NB];
+    bool go[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const uint32_t q = b * kWave + lane;
+        go[b] = q < n_cand;
+        s[b] = go[b] ? c.cand[head + q] : 0u;
+        i[b] = s[b];
+        node[b] = go[b] ? 0u : ~0u; // ~0u: no match
+    }
+    for (;;) { // one unit of every live run per round
+        bool any_go = false;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) any_go |= go[b];
+        if (!__any(any_go)) break;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (go[b]) {
+                if (i[b] >= L.n_units) {
+                    go[b] = false; // the run ends with the buffer
+                } else {
+                    const uint32_t u = hay[i[b]];
+                    if (!word_bit(wbits, u)) {
+                        go[b] = false; // the run ends here: node[b] decides
+                    } else {
+                        const uint32_t f = T.cs ? u : (uint32_t)T.lower[u];
+                        const uint32_t child = hashed_goto(T.hkeys, T.hvals, T.hmask, node[b], f);
+                        if (child == ~0u) { // a word character with no continuation: the run is not a keyword
+                            node[b] = ~0u;
+                            go[b] = false;
+                        } else {
+                            node[b] = child;
+                            ++i[b];
+                        }
+                    }
+                }
+            }
+        }
+    }
+    uint32_t id[NB], m[NB], prefix[NB], total = 0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        id[b] = node[b] != ~0u && node[b] != 0u ? T.term_id[node[b]] : ~0u;
+        m[b] = id[b] != ~0u ? 1u : 0u;
+        const uint32_t incl = wave_inclusive_scan_dpp(m[b]);
+        prefix[b] = total + incl - m[b];
+        total += __builtin_amdgcn_readlane(incl, kWave - 1);
+    }
+    if (total == 0) return;
+    const SlotRange sr = reserve_slots(c, total);
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+        if (m[b]) store_rec(L, sr.slot(prefix[b]), s[b], i[b], id[b], c.rank_base + prefix[b]);
+    c.rank_base += total;
+}
+
+__device__ __forceinline__ void ww_drain(TileCtx &c, const uint32_t *wbits, uint32_t keep_below) {
+    uint32_t head = 0;
+    while (c.cand_n > head && c.cand_n - head >= keep_below) {
+        const uint32_t nb = min(c.cand_n - head, (uint32_t)(kVerifyBatches * kWave));
+        ww_verify(c, wbits, head, nb);
+        head += nb;
+    }
+    if (head) {
+        const uint32_t left = c.cand_n - head;
+        uint32_t tmp[kVerifyBatches];
+#pragma unroll
+        for (int b = 0; b < kVerifyBatches; ++b) {
+            const uint32_t q = b * kWave + lane_id();
+            tmp[b] = q < left ? c.cand[head + q] : 0u;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int b = 0; b < kVerifyBatches; ++b) {
+            const uint32_t q = b * kWave + lane_id();
+            if (q < left) c.cand[q] = tmp[b];
+        }
+        __builtin_amdgcn_wave_barrier();
+        c.cand_n = left;
+    }
+}
+
+// Same span/region/tile-group structure as k_ac_tile (acgpu_tile.hip); only the filter and the verification differ.
+__global__ __launch_bounds__(kTileBlock) void k_ww_tile(DevTables T, TileLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *wbits = reinterpret_cast<uint32_t *>(smem); // 65536 word-character bits
+    uint32_t *cand_all = reinterpret_cast<uint32_t *>(smem + 8192);
+    for (uint32_t w = threadIdx.x; w < 2048; w += blockDim.x) { // pack the raw-unit flag (bit 0 of wflags) into bits
+        uint32_t bits = 0;
+        for (uint32_t k = 0; k < 32; ++k) bits |= (uint32_t)(T.wflags[w * 32 + k] & 1u) << k;
+        wbits[w] = bits;
+    }
+    __syncthreads();
+
+    const uint32_t lane = lane_id();
+    const uint32_t wave_in_block = threadIdx.x / kWave;
+    const uint32_t wave_global = blockIdx.x * (kTileBlock / kWave) + wave_in_block;
+    TileCtx c{&T, &L, cand_all + wave_in_block * kCandCap, 0, 0, 0u, 0};
+
+    const uint32_t first_region = wave_global * L.regions_per_wave;
+    if (first_region >= L.n_regions) return;
+    const uint32_t last_region = min(first_region + L.regions_per_wave, L.n_regions);
+    const uint32_t base8 = L.own_begin & ~7u;
+    const uint32_t R = L.region_units;
+    const uint32_t span_begin = max(L.own_begin, base8 + first_region * R);
+    uint32_t span_end = base8 + last_region * R;
+    if (span_end > L.own_end || last_region == L.n_regions) span_end = L.own_end;
+    const uint32_t nfull = L.n_units & ~7u;
+    const uint32_t hi = min(span_end, nfull);
+    const uint32_t last_vec = nfull >= 8 ? nfull - 8 : 0;
+    const uint16_t *hay = L.d_hay;
+
+    uint32_t region = first_region;
+    uint32_t boundary = base8 + (region + 1) * R;
+    uint32_t rb = span_begin;
+    uint32_t re = min(span_end, boundary);
+    uint32_t tile = base8 + first_region * R;
+
+    bool vec_todo = tile < hi;
+    bool tail_todo = span_end > nfull;
+    uint32_t d0 = 0;
+    uint32_t carry = 0; // word-character bit of the unit just before the current tile
+    uint4 nxt[kPrefetch], grp[kPrefetch];
+#pragma unroll
+    for (int d = 0; d < kPrefetch; ++d) nxt[d] = grp[d] = make_uint4(0, 0, 0, 0);
+    if (vec_todo) {
+        if (tile >= 1) carry = word_bit(wbits, hay[tile - 1]);
+#pragma unroll
+        for (int d = 0; d < kPrefetch; ++d)
+            nxt[d] = *reinterpret_cast<const uint4 *>(hay + min(tile + d * kTileUnits + lane * 8, last_vec));
+    }
+
+    for (;;) {
+        const bool seam = vec_todo ? (d0 == 0 && tile >= boundary) : true;
+        const uint32_t keep = seam ? 1u : (uint32_t)(kVerifyBatches * kWave);
+        if (c.cand_n >= keep && c.cand_n != 0) ww_drain(c, wbits, keep);
+
+        if (vec_todo) {
+            if (d0 == 0) {
+                if (tile >= boundary) {
+                    if (lane == 0) L.d_region_counts[region] = c.rank_base;
+                    c.rank_base = 0;
+                    ++region;
+                    rb = boundary;
+                    boundary += R;
+                    re = min(span_end, boundary);
+                }
+#pragma unroll
+                for (int d = 0; d < kPrefetch; ++d) grp[d] = nxt[d];
+#pragma unroll
+                for (int d = 0; d < kPrefetch; ++d)
+                    nxt[d] = *reinterpret_cast<const uint4 *>(
+                        hay + min(tile + (kPrefetch + d) * kTileUnits + lane * 8, last_vec));
+            }
+            const uint32_t top = min(re, hi);
+            const bool edge = tile < rb || tile + kPrefetch * kTileUnits > top;
+            bool resume = false;
+#pragma unroll
+            for (int d = 0; d < kPrefetch; ++d) {
+                if ((uint32_t)d < d0) continue;
+                const uint32_t cur = tile + d * kTileUnits;
+                if (cur >= hi) break;
+                if (c.cand_n > kCandCap - kTileUnits) {
+                    d0 = d;
+                    resume = true;
+                    break;
+                }
+                const uint4 w = grp[d];
+                const uint32_t v = cur + lane * 8;
+                const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+                uint32_t wm = 0; // word-character bits of the lane's 8 units
+#pragma unroll
+                for (int j = 0; j < 8; ++j) wm |= word_bit(wbits, (ww[j >> 1] >> (16 * (j & 1))) & 0xffffu) << j;
+                const uint32_t prev = from_prev_lane(wm >> 7, carry); // bit of the unit left of v
+                carry = __builtin_amdgcn_readlane(wm, 63) >> 7;
+                uint32_t mask = wm & ~((wm << 1) | (prev & 1u)) & 0xffu; // run starts
+                if (edge) {
+                    const uint32_t first = rb > v ? min(rb - v, 8u) : 0u;
+                    const uint32_t last = top > v ? min(top - v, 8u) : 0u;
+                    mask &= ((1u << last) - 1u) & ~((1u << first) - 1u);
+                }
+                enqueue(c, mask, v);
+            }
+            if (!resume) {
+                d0 = 0;
+                tile += kPrefetch * kTileUnits;
+                vec_todo = tile < hi;
+            }
+            continue;
+        }
+        if (tail_todo) {
+            tail_todo = false;
+            const uint32_t t0 = max(nfull, span_begin);
+            if (t0 >= boundary) {
+                if (lane == 0) L.d_region_counts[region] = c.rank_base;
+                c.rank_base = 0;
+                ++region;
+            }
+            const uint32_t pos = t0 + lane;
+            uint32_t mask = 0;
+            if (pos < span_end) {
+                const uint32_t here = word_bit(wbits, hay[pos]);
+                const uint32_t left = pos > 0 ? word_bit(wbits, hay[pos - 1]) : 0u;
+                mask = here & ~left & 1u;
+            }
+            enqueue(c, mask, pos);
+            continue;
+        }
+        break;
+    }
+    if (lane == 0) L.d_region_counts[region] = c.rank_base;
+    for (uint32_t i = lane; i < c.res_left; i += kWave) store_rec(L, c.res_cur + i, 0, 0, 0, ~0u);
+}
+
+// Literal restatement of S/WholeWordMatchMap.java:155-240 by ONE lane, for word-character tables that are not
+// fold-consistent.  The whole haystack is one shard.  Records come out in order; count in *counter.
+__global__ void k_ww_sequential(DevTables T, const uint16_t *hay, uint32_t len, void *out, uint64_t cap, int record_kind,
+                                unsigned long long *counter) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    unsigned long long n = 0;
+    auto emit = [&](uint32_t start, uint32_t end, uint32_t id) {
+        if (n < cap) {
+            if (record_kind == ACGPU_REC_SET) {
+                reinterpret_cast<int2 *>(out)[n] = make_int2((int)start, (int)end);
+            } else {
+                int32_t *o = reinterpret_cast<int32_t *>(out) + n * 3;
+                o[0] = (int)start; o[1] = (int)end; o[2] = (int)id;
+            }
+        }
+        ++n;
+    };
+    uint32_t node = 0, idx = 0;
+    while (idx < len) {
+        const uint32_t raw = hay[idx];
+        const uint32_t c = T.cs ? raw : (uint32_t)T.lower[raw];
+        const uint32_t next = hashed_goto(T.hkeys, T.hvals, T.hmask, node, c);
+        if (next == ~0u) {
+            if (!(T.wflags[raw] & 2u)) { // !wordChars[c], c = folded unit
+                if (node != 0 && T.term_id[node] != ~0u) emit(idx - T.depth[node], idx, T.term_id[node]);
+            } else {
+                while (++idx < len && (T.wflags[hay[idx]] & 1u)) {
+                }
+            }
+            while (++idx < len && !(T.wflags[hay[idx]] & 1u)) {
+            }
+            node = 0;
+        } else {
+            ++idx;
+            node = next;
+        }
+    }
+    if (node != 0 && T.term_id[node] != ~0u) emit(idx - T.depth[node], idx, T.term_id[node]);
+    *counter = n;
+}
+
+hipError_t launch_ww_tile(const DevTables &t, const TileLaunch &l, hipStream_t stream, const char **kernel_name) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ww_tile), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)l.lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_ww_tile, dim3(l.grid), dim3(l.block), l.lds_bytes, stream, t, l);
+    if (kernel_name) *kernel_name = "k_ww_tile";
+    return hipGetLastError();
+}
+
+hipError_t launch_ww_sequential(const DevTables &t, const uint16_t *d_hay, uint32_t len, void *d_out, uint64_t cap,
+                                int record_kind, unsigned long long *d_counter, hipStream_t stream) {
+    hipLaunchKernelGGL(k_ww_sequential, dim3(1), dim3(64), 0, stream, t, d_hay, len, d_out, cap, record_kind, d_counter);
+    return hipGetLastError();
+}
+
+} // namespace acgpu

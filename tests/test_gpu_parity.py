@@ -350,3 +350,124 @@ def test_longest_shards_with_chain_entry_and_exit():
         entry = chain_exit
         assert entry >= hi
     assert (np.concatenate(parts) == want).all()
+
+
+# ---- WholeWordMatchSet / WholeWordMatchMap ---------------------------------------------------------------------------
+
+def test_fixtures_wholeword(fixtures):
+    for fx in fixtures:
+        hay, kws = fixture_inputs(fx)
+        if fx["WW"] == "IllegalArgumentException":
+            # T/WholeWordMatchTest.java:31-57: keywords with inner non-word characters are rejected by the constructor
+            with pytest.raises(IllegalArgumentException):
+                WholeWordMatchSet(kws, True)
+            with pytest.raises(IllegalArgumentException):
+                WholeWordMatchMap(kws, _ids(len(kws)), True)
+            continue
+        assert WholeWordMatchMap(kws, _ids(len(kws)), True).find_all(hay).tolist() == fx["WW"], fx["name"]
+        assert WholeWordMatchSet(kws, True).find_all(hay).tolist() == [r[:2] for r in fx["WW"]], fx["name"]
+
+
+def test_wholeword_boundaries_like_reference_assertions():
+    # T/WholeWordMatchTest.java:60-70: every reported needle is delimited by non-word characters or the string ends
+    kws = ["The", "quick", "red", "fox", "jumps", "over", "the", "lazy", "brown", "dog", "re", "ox"]
+    hay = "The quick red fox, jumps over the lazy brown dog. redfox ox-re re_d dog"
+    s = WholeWordMatchSet(kws, True)
+    wc = s.get_word_chars()
+    seen = []
+
+    def listener(h, a, b):
+        assert h[a:b] in kws
+        assert b == len(h) or not wc[ord(h[b])]
+        assert a == 0 or not wc[ord(h[a - 1])]
+        seen.append((a, b))
+        return True
+
+    s.match(hay, listener)
+    assert seen == [tuple(r[:2]) for r in Oracle(FAM_WHOLEWORD, kws, word_chars=WORD).match(hay).tolist()] and len(seen) == 11
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_wholeword_vs_oracle(seed):
+    rng = np.random.default_rng(900 + seed)
+    alpha = [ord(c) for c in "abB -_.9"] + [0x00E9, 0x00C9, 0x4E2D, 0x3002, 0x0130]
+    word_alpha = [c for c in alpha if WORD[c]]
+    for it in range(10):
+        hay, _ = rand_case(rng, alpha, 1, 1, int(rng.integers(0, 8000)))
+        _, kws = rand_case(rng, word_alpha, int(rng.integers(1, 25)), 5, 1)
+        kws = kws + [np.concatenate([utf16(" ,"), kws[0], utf16(". ")])]  # trimmed by the constructor
+        for cs in (True, False):
+            want = Oracle(FAM_WHOLEWORD, kws, case_sensitive=cs, lower=LOWER, word_chars=WORD).match(hay).tolist()
+            got = WholeWordMatchMap(kws, _ids(len(kws)), cs).find_all(hay).tolist()
+            assert got == want, (seed, it, cs)
+
+
+def test_wholeword_custom_tables_including_fold_inconsistent():
+    rng = np.random.default_rng(77)
+    alpha = [ord(c) for c in "aAbB xX."]
+    hay, _ = rand_case(rng, alpha, 1, 1, 3000)
+    # (1) explicit word-character list (S/WordCharacters.java:18-24): consistent under folding
+    for wchars, cs in (("aAbB", True), ("aAbB", False), ("aAbBxX", False)):
+        wc = np.zeros(65536, np.uint8)
+        for ch in wchars:
+            wc[ord(ch)] = 1
+        kws = ["a", "ab", "B", "ba", "abba"]
+        want = Oracle(FAM_WHOLEWORD, kws, case_sensitive=cs, lower=LOWER, word_chars=wc).match(hay).tolist()
+        m = WholeWordMatchMap(kws, _ids(len(kws)), cs, word_characters=list(wchars))
+        assert m.automaton.info()["fold_consistent"] == 1
+        assert m.find_all(hay).tolist() == want
+    # (2) a table where 'A','B' are word characters but 'a','b' are not, case-insensitive: the reference mixes folded
+    #     and raw lookups (S/WholeWordMatchMap.java:204,209 vs :221,:226); the sequential kernel restates it literally
+    wc = np.zeros(65536, np.uint8)
+    for ch in "ABx":
+        wc[ord(ch)] = 1
+    kws = ["A", "AB", "BA", "x"]
+    want = Oracle(FAM_WHOLEWORD, kws, case_sensitive=False, lower=LOWER, word_chars=wc).match(hay).tolist()
+    m = WholeWordMatchMap(kws, _ids(len(kws)), False, word_characters=list("ABx"))
+    assert m.automaton.info()["fold_consistent"] == 0
+    assert m.find_all(hay).tolist() == want
+    # (3) default table with toggles (S/WordCharacters.java:26-39)
+    from ahocorasick_amd.unicode_tables import word_chars_with_toggles
+    wc = word_chars_with_toggles([".", "b"], [True, False])  # '.' becomes a word character, 'b' stops being one
+    m = WholeWordMatchMap(["a.b", "ab"], [0, 1], True, word_characters=[".", "b"], toggle_flags=[True, False])
+    want = Oracle(FAM_WHOLEWORD, ["a.b", "ab"], word_chars=wc).match("a.b ab a.b. b").tolist()
+    assert want == [[0, 2, 0], [4, 5, 1], [7, 9, 0]]  # keywords are trimmed to "a." and "a" (S/WordCharacters.java:41-62)
+    assert m.find_all("a.b ab a.b. b").tolist() == want
+    with pytest.raises(IllegalArgumentException):
+        WholeWordMatchSet(["a b"], True, word_characters=[".", "b"], toggle_flags=[True, False])
+
+
+def test_wholeword_mixed_script_like_config_c5():
+    # BASELINE config 5 in miniature: mixed-script dictionary, case-insensitive, default word characters
+    words = synth.mixed_script_words(1005, 5000)
+    hay = synth.mixed_script_haystack(2005, 300000, words, swapcase_tbl=synth.swapcase_table())
+    want = Oracle(FAM_WHOLEWORD, words, case_sensitive=False, lower=LOWER, word_chars=WORD).match(hay)
+    got = WholeWordMatchMap(words, _ids(len(words)), False).find_all(hay)
+    assert len(want) > 10000 and got.shape == want.shape and (got == want).all()
+    for region in (2048, 0):
+        N.set_tunable("region_units", region)
+        assert (WholeWordMatchSet(words, False).find_all(hay) == want[:, :2]).all()
+
+
+def test_wholeword_shards_own_their_word_starts():
+    import torch
+    words = synth.mixed_script_words(31, 2000)
+    hay = synth.mixed_script_haystack(32, 120000, words)
+    a = Automaton(N.MODE_WHOLEWORD, words, True, word_chars=WORD)
+    want = Oracle(FAM_WHOLEWORD, words, word_chars=WORD).match(hay)
+    d_hay = torch.from_numpy(hay.view(np.int16)).cuda()
+    cap = len(want) + 10
+    cuts = [0, 40001, 80003, hay.size]
+    parts = []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        p, _ = _dev_match(a, d_hay, hay.size, True, cap, own=(lo, hi))
+        parts.append(p)
+    assert (np.concatenate(parts) == want).all()
+    # a rank holding only its slice: 1 unit of left context, max_keyword_len+1 units of right halo
+    lo, hi = cuts[1], cuts[2]
+    halo_r = a.info()["max_keyword_len"] + 1
+    base = (lo - 1) // 8 * 8
+    sub = d_hay[base:hi + halo_r].clone()
+    p, _ = _dev_match(a, sub, hi + halo_r - base, True, cap, own=(lo - base, hi - base), text_begin=False, text_end=False)
+    p[:, :2] += base
+    assert (p == parts[1]).all()
