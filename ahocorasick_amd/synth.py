@@ -122,7 +122,7 @@ _SCRIPTS = [
     ("latin", [(0x41, 0x5A), (0x61, 0x7A), (0xC0, 0xD6), (0xD8, 0xF6), (0xF8, 0xFF)]),
     ("greek", [(0x0391, 0x03A1), (0x03A3, 0x03A9), (0x03B1, 0x03C9)]),
     ("cyrillic", [(0x0410, 0x044F)]),
-    ("cjk", [(0x4E00, 0x9FFF)]),
+    ("cjk", [(0x4E00, 0x9FA5)]),  # the Unicode 1.1 URO: letters in every JDK's tables
     ("hangul", [(0xAC00, 0xD7A3)]),
     ("arabic", [(0x0621, 0x063A), (0x0641, 0x064A)]),
 ]

@@ -434,7 +434,7 @@ def test_wholeword_custom_tables_including_fold_inconsistent():
     assert want == [[0, 2, 0], [4, 5, 1], [7, 9, 0]]  # keywords are trimmed to "a." and "a" (S/WordCharacters.java:41-62)
     assert m.find_all("a.b ab a.b. b").tolist() == want
     with pytest.raises(IllegalArgumentException):
-        WholeWordMatchSet(["a b"], True, word_characters=[".", "b"], toggle_flags=[True, False])
+        WholeWordMatchSet(["a c"], True, word_characters=[".", "b"], toggle_flags=[True, False])
 
 
 def test_wholeword_mixed_script_like_config_c5():
