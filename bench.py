@@ -140,6 +140,17 @@ def main():
         },
     }
 
+    # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (counters cannot be read from inside
+    # this process); the committed measurement is attached when it is for this kernel and this size
+    try:
+        with open(os.path.join(ROOT, "profiles", "latest_traffic.json")) as f:
+            tr = json.load(f)
+        if tr["kernel"] == matcher.last_kernel and tr["units_per_gpu"] == n_units:
+            out["roofline"]["traffic"] = tr["traffic_bytes"]
+            out["roofline"]["traffic_source"] = tr["source"]
+    except (OSError, KeyError, ValueError):
+        pass
+
     if rank == 0 and not multi and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(kws, matcher, min(n_units, 1 << args.cpu_sample_log2))
     if rank == 0:
