@@ -1,0 +1,35 @@
+package com.roklenarcic.util.strings.gpu;
+
+import java.util.ArrayList;
+import java.util.List;
+
+import com.roklenarcic.util.strings.SetMatchListener;
+import com.roklenarcic.util.strings.StringSet;
+
+/** Drop-in for com.roklenarcic.util.strings.AhoCorasickSet (same constructor arguments, same listener contract). */
+public class GpuAhoCorasickSet implements StringSet, AutoCloseable {
+    final NativeAutomaton automaton;
+
+    public GpuAhoCorasickSet(final Iterable<String> keywords, boolean caseSensitive) {
+        this(NativeAutomaton.MODE_ALL, keywords, caseSensitive, null);
+    }
+
+    GpuAhoCorasickSet(int mode, final Iterable<String> keywords, boolean caseSensitive, boolean[] wordChars) {
+        List<String> l = new ArrayList<String>();
+        for (String k : keywords) l.add(k); // null keywords are passed through and skipped natively
+        automaton = new NativeAutomaton(mode, l.toArray(new String[l.size()]), caseSensitive, wordChars);
+    }
+
+    public void match(final String haystack, final SetMatchListener listener) {
+        final int[] r = automaton.match(haystack, false); // NullPointerException for a null haystack, like the reference
+        for (int i = 0; i < r.length; i += 2) {
+            if (!listener.match(haystack, r[i], r[i + 1])) {
+                return; // early stop exactly where the reference would stop; listener exceptions propagate
+            }
+        }
+    }
+
+    public void close() {
+        automaton.close();
+    }
+}

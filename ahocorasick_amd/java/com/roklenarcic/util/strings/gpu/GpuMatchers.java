@@ -1,0 +1,62 @@
+package com.roklenarcic.util.strings.gpu;
+
+/** The remaining drop-ins: same shape as GpuAhoCorasickSet/Map with another native mode. */
+public final class GpuMatchers {
+    private GpuMatchers() {
+    }
+
+    /** Drop-in for LongestMatchSet. */
+    public static class GpuLongestMatchSet extends GpuAhoCorasickSet {
+        public GpuLongestMatchSet(final Iterable<String> keywords, boolean caseSensitive) {
+            super(NativeAutomaton.MODE_LONGEST, keywords, caseSensitive, null);
+        }
+    }
+
+    /** Drop-in for LongestMatchMap. */
+    public static class GpuLongestMatchMap<T> extends GpuAhoCorasickMap<T> {
+        public GpuLongestMatchMap(final Iterable<String> keywords, final Iterable<? extends T> values, boolean caseSensitive) {
+            super(NativeAutomaton.MODE_LONGEST, keywords, values, caseSensitive, null);
+        }
+    }
+
+    /** WordCharacters.generateWordCharsFlags() with this JVM's Character.isLetterOrDigit. */
+    static boolean[] defaultWordChars() {
+        boolean[] f = new boolean[65536];
+        f['-'] = true;
+        f['_'] = true;
+        for (int i = 0; i < 65536; i++) {
+            if (Character.isLetterOrDigit((char) i)) f[i] = true;
+        }
+        return f;
+    }
+
+    static boolean[] wordChars(char[] wordCharacters, boolean[] toggleFlags) {
+        if (wordCharacters == null) return defaultWordChars();
+        boolean[] f = toggleFlags == null ? new boolean[65536] : defaultWordChars();
+        for (int i = 0; i < wordCharacters.length; i++) f[wordCharacters[i]] = toggleFlags == null || toggleFlags[i];
+        return f;
+    }
+
+    /** Drop-in for WholeWordMatchSet (all word-character overloads). */
+    public static class GpuWholeWordMatchSet extends GpuAhoCorasickSet {
+        public GpuWholeWordMatchSet(final Iterable<String> keywords, boolean caseSensitive) {
+            this(keywords, caseSensitive, null, null);
+        }
+
+        public GpuWholeWordMatchSet(final Iterable<String> keywords, boolean caseSensitive, char[] wordCharacters, boolean[] toggleFlags) {
+            super(NativeAutomaton.MODE_WHOLEWORD, keywords, caseSensitive, wordChars(wordCharacters, toggleFlags));
+        }
+    }
+
+    /** Drop-in for WholeWordMatchMap. */
+    public static class GpuWholeWordMatchMap<T> extends GpuAhoCorasickMap<T> {
+        public GpuWholeWordMatchMap(final Iterable<String> keywords, final Iterable<? extends T> values, boolean caseSensitive) {
+            this(keywords, values, caseSensitive, null, null);
+        }
+
+        public GpuWholeWordMatchMap(final Iterable<String> keywords, final Iterable<? extends T> values, boolean caseSensitive,
+                char[] wordCharacters, boolean[] toggleFlags) {
+            super(NativeAutomaton.MODE_WHOLEWORD, keywords, values, caseSensitive, wordChars(wordCharacters, toggleFlags));
+        }
+    }
+}

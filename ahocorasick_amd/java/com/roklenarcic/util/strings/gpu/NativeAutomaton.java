@@ -1,0 +1,45 @@
+package com.roklenarcic.util.strings.gpu;
+
+/**
+ * Thin JNI binding of include/acgpu.h (libacgpu.so + libacgpu_jni.so). One instance owns one acgpu_automaton handle.
+ * NOT compiled in the build image (no JDK there); see INTEGRATION.md for the build line.
+ */
+final class NativeAutomaton implements AutoCloseable {
+    static final int MODE_ALL = 0, MODE_LONGEST = 1, MODE_WHOLEWORD = 2;
+
+    static {
+        System.loadLibrary("acgpu_jni");
+    }
+
+    private long handle;
+
+    NativeAutomaton(int mode, String[] keywords, boolean caseSensitive, boolean[] wordChars) {
+        // the tables come from THIS JVM's Character methods, so parity holds for its Unicode version
+        char[] lower = null;
+        if (!caseSensitive) {
+            lower = new char[65536];
+            for (int i = 0; i < 65536; i++) lower[i] = Character.toLowerCase((char) i);
+        }
+        handle = build(mode, keywords, caseSensitive, lower, wordChars);
+    }
+
+    /** (start,end) pairs or (start,end,keywordIndex) triples, flattened, in the reference's listener-call order. */
+    int[] match(String haystack, boolean withIds) {
+        return match(handle, haystack, withIds);
+    }
+
+    @Override
+    public void close() {
+        if (handle != 0) {
+            free(handle);
+            handle = 0;
+        }
+    }
+
+    /** throws IllegalArgumentException("<keyword> contains non-word characters.") on ACGPU_E_NONWORD */
+    private static native long build(int mode, String[] keywords, boolean caseSensitive, char[] lower, boolean[] wordChars);
+
+    private static native int[] match(long handle, String haystack, boolean withIds);
+
+    private static native void free(long handle);
+}
