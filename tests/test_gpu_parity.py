@@ -471,3 +471,76 @@ def test_wholeword_shards_own_their_word_starts():
     p, _ = _dev_match(a, sub, hi + halo_r - base, True, cap, own=(lo - base, hi - base), text_begin=False, text_end=False)
     p[:, :2] += base
     assert (p == parts[1]).all()
+
+
+# ---- BASELINE.json configs 4 and 5 at FULL size: size-independent properties -----------------------------------------
+
+def test_config_c4_full_size_properties():
+    """LongestMatchSet, 50k prefix-closed keywords (max length 1000), 2^29 units with P(a)=0.75."""
+    import torch
+    c = synth.CONFIGS["C4"]
+    kws = synth.config_keywords("C4")
+    n = c["n_units"]
+    a = Automaton(N.MODE_LONGEST, kws, True)
+    d_hay = torch.empty(n, dtype=torch.int16, device="cuda")
+    tab = np.ascontiguousarray(synth.ALPHA_AB_75)
+    N.check(N.lib().acgpu_synth_fill(d_hay.data_ptr(), n, 0, c["hay_seed"], tab.ctypes.data_as(ctypes.c_void_p), len(tab),
+                                     None), "synth")
+    cap = n // 2
+    d_out = torch.empty((cap, 2), dtype=torch.int32, device="cuda")
+    n_out, rc, prof, chain_exit = a.match_device(d_hay.data_ptr(), n, False, d_out.data_ptr(), cap, profile=True,
+                                                 stream=torch.cuda.current_stream().cuda_stream)
+    assert rc == N.OK and chain_exit >= n
+    got = d_out[:n_out]
+    print("C4 full size: %d matches, scan %.3f ms, chain %.3f ms" % (n_out, prof["scan_ms"], prof["finalize_ms"]))
+    # (1) position order, non-overlapping: start[i+1] >= end[i]
+    assert bool((got[1:, 0] >= got[:-1, 1]).all()) and bool((got[:, 1] > got[:, 0]).all())
+    # (2) greedy chain: every unit between two matches starts no keyword -- here every 'a' starts one, so gaps are 'b's
+    #     that start no keyword; and every match is maximal among the a-run family: checked against the oracle prefix
+    pre = 1 << 21
+    want = Oracle(FAM_LONGEST, kws).match(synth.haystack(c["hay_seed"], pre, table=synth.ALPHA_AB_75))[:, :2]
+    k = len(want) - 1  # the last oracle match may be cut by the end of the prefix
+    assert (got[:k].cpu().numpy() == want[:k]).all()
+    # (3) shard invariance at full size: two shards chained through chain_exit give the same stream (checksums)
+    half = n // 2 + 12345
+    d2 = torch.empty((cap, 2), dtype=torch.int32, device="cuda")
+    n1, rc1, _, ex1 = a.match_device(d_hay.data_ptr(), n, False, d2.data_ptr(), cap, own=(0, half))
+    assert rc1 == N.OK
+    first = d2[:n1].clone()
+    n2, rc2, _, ex2 = a.match_device(d_hay.data_ptr(), n, False, d2.data_ptr(), cap, own=(half, n), chain_entry=ex1)
+    assert rc2 == N.OK and n1 + n2 == n_out
+    assert bool((first == got[:n1]).all()) and bool((d2[:n2] == got[n1:]).all())
+
+
+def test_config_c5_full_size_properties():
+    """WholeWordMatchMap, 100k mixed-script words, case-insensitive, 2^28 units (one GPU's share of config 5).
+    The haystack is a host-generated 2^22-unit block of the config-5 token stream repeated 64 times."""
+    import torch
+    c = synth.CONFIGS["C5"]
+    words = synth.config_keywords("C5")
+    block = synth.mixed_script_haystack(c["hay_seed"], 1 << 22, words, swapcase_tbl=synth.swapcase_table())
+    reps = c["n_units"] >> 22
+    a = Automaton(N.MODE_WHOLEWORD, words, False, word_chars=WORD)
+    d_hay = torch.from_numpy(block.view(np.int16)).cuda().repeat(reps)
+    n = d_hay.numel()
+    want = Oracle(FAM_WHOLEWORD, words, case_sensitive=False, lower=LOWER, word_chars=WORD).match(block)
+    cap = (len(want) + 8) * reps
+    got, prof = _dev_match(a, d_hay, n, True, cap, profile=True)
+    print("C5 full size: %d matches, scan %.3f ms" % (len(got), prof["scan_ms"]))
+    # (1) the first block equals the oracle bit for bit (except a word cut by the block seam)
+    k = len(want) - 2
+    assert (got[:k] == want[:k]).all()
+    # (2) position order; every record is delimited by non-word characters (T/WholeWordMatchTest.java:60-70)
+    assert (np.diff(got[:, 0].astype(np.int64)) > 0).all()
+    hay = np.tile(block, reps)
+    ends = got[:, 1].astype(np.int64)
+    starts = got[:, 0].astype(np.int64)
+    assert (WORD[hay[np.minimum(ends, n - 1)]][ends < n] == 0).all()
+    assert (WORD[hay[np.maximum(starts - 1, 0)]][starts > 0] == 0).all()
+    # (3) periodic haystack => periodic matches away from the seams
+    per = 1 << 22
+    inner = got[(got[:, 0] % per > 64) & (got[:, 1] % per < per - 64)]
+    first = inner[inner[:, 0] < per]
+    last = inner[inner[:, 0] >= (reps - 1) * per].copy()
+    last[:, :2] -= (reps - 1) * per
+    assert first.shape == last.shape and (first == last).all()
