@@ -308,8 +308,9 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
     S.block = 1024;
     S.grid = d.n_cu;
     const uint64_t lanes = (uint64_t)S.grid * S.block;
+    // a lane's serial chain is latency bound: prefer many lanes over a small warm-up share (warm-up <= 50 % of a chunk)
     uint64_t C = tunables().chunk_units > 0 ? (uint64_t)tunables().chunk_units
-                                            : std::max<uint64_t>({(own_len + lanes - 1) / lanes, 256, 16ull * halo});
+                                            : std::max<uint64_t>({(own_len + lanes - 1) / lanes, 256, 2ull * halo});
     C = std::max<uint32_t>(8, round_up8(C));
     S.chunk_units = (uint32_t)C;
     S.n_chunks = (uint32_t)((own_len + C - 1) / C);
@@ -356,9 +357,12 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
     const char *kname = "";
     HIP_TRY(launch_longest_scan(d.T, S, stream, &kname));
     if (prof) HIP_TRY(hipEventRecord(d.ev[1], stream));
-    HIP_TRY(launch_longest_chain(Cn, /*write_pass=*/false, stream));
+    if ((rc = d.chain.ensure((size_t)Cn.n_tiles * 4 + 64))) return rc;
+    uint32_t *d_sync = (uint32_t *)d.chain.p;
+    HIP_TRY(launch_longest_sync(Cn, d_sync, stream));
+    HIP_TRY(launch_longest_chain(Cn, d_sync, /*write_pass=*/false, stream));
     HIP_TRY(launch_exclusive_scan(Cn.d_counts, Cn.n_tiles, (uint64_t *)d.offsets.p, (uint64_t *)d.scan_tmp.p, stream));
-    HIP_TRY(launch_longest_chain(Cn, /*write_pass=*/true, stream));
+    HIP_TRY(launch_longest_chain(Cn, d_sync, /*write_pass=*/true, stream));
     if (prof) HIP_TRY(hipEventRecord(d.ev[2], stream));
     HIP_TRY(hipMemcpyAsync(d.h_counter, (const uint64_t *)d.scan_tmp.p + scan_tiles_for(Cn.n_tiles), 8, hipMemcpyDeviceToHost,
                            stream));

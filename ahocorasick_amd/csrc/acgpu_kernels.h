@@ -103,7 +103,8 @@ struct LongestChainLaunch {
     int record_kind;
     unsigned long long *d_exit; // first chain position >= own_end
 };
-hipError_t launch_longest_chain(const LongestChainLaunch &l, bool write_pass, hipStream_t stream);
+hipError_t launch_longest_sync(const LongestChainLaunch &l, uint32_t *d_sync, hipStream_t stream);
+hipError_t launch_longest_chain(const LongestChainLaunch &l, const uint32_t *d_sync, bool write_pass, hipStream_t stream);
 } // namespace acgpu
 
 namespace acgpu {

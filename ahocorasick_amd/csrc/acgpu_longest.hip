@@ -8,12 +8,11 @@
 //                    haystack; after consuming text[pos..] backwards, the longest keyword on the state's output chain
 //                    is the longest keyword starting at pos.  One chunk of start positions per lane, warmed up on
 //                    the (max_keyword_len-1) units to its right; hot rows and their lengths in LDS.
-//  k_longest_chain : the chain.  A position p is a universal synchronisation point when no potential match that
-//                    starts before p reaches beyond p (max_{q<p}(q + L[q]) <= p): EVERY greedy chain, wherever it
-//                    started, lands on p.  One lane per tile sweeps that running maximum, starts at the first
-//                    synchronisation point of its tile and follows the chain up to the first synchronisation point of
-//                    a later tile -- so lanes are independent and their records concatenate in position order.
-//                    Two passes: count, (prefix sum), write.
+//  k_longest_sync  : one synchronisation point per tile -- a position every greedy chain that can enter the tile must
+//                    pass (found by following all candidate chains until they have merged).
+//  k_longest_chain : one lane per tile follows the chain from its synchronisation point to the next tile's, so lanes
+//                    are independent and their records concatenate in position order.  Two passes: count, (prefix
+//                    sum), write.
 #include <hip/hip_runtime.h>
 
 #include "acgpu_device.h"
@@ -176,42 +175,88 @@ hipError_t launch_longest_scan(const DevTables &t, const LongestScanLaunch &l, h
 }
 
 // ---- chain -------------------------------------------------------------------------------------------------
-template <typename LenT, bool WRITE>
-__global__ __launch_bounds__(256) void k_longest_chain(LongestChainLaunch L) {
+// Synchronisation point of tile t (t >= 1): follow, in lock step by position, the greedy chains of EVERY position at
+// which a chain can enter the tile -- the landings q + max(L[q],1) >= tb of the max_len positions before the tile
+// start tb (the true chain's last position before tb is one of those q).  Chains that land on the same position are
+// one chain from there on; when a single one is left, its position lies on every possible chain, hence on the true
+// one.  Stored in S[t] if it falls inside the tile, else ~0u (the tile then belongs to an earlier lane's segment).
+constexpr int kSyncSet = 16;
+
+template <typename LenT>
+__global__ __launch_bounds__(256) void k_longest_sync(LongestChainLaunch L, uint32_t *S) {
+    __shared__ uint32_t set_all[256][kSyncSet + 1];
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= L.n_tiles) return;
     const LenT *len = reinterpret_cast<const LenT *>(L.d_len);
-    const uint32_t entry = L.entry;
-    // tile t covers [tb, te); tile 0 starts at the chain's entry position
-    const uint64_t tb64 = (uint64_t)entry + (uint64_t)t * L.tile_units;
-    if (tb64 >= L.own_end) { // only possible for t == 0 with entry >= own_end
-        if (!WRITE) L.d_counts[t] = 0;
-        if (t == 0 && !WRITE) *L.d_exit = entry;
+    uint32_t *set = set_all[threadIdx.x];
+    if (t == 0) {
+        S[0] = L.entry;
+        return;
+    }
+    const uint64_t tb64 = (uint64_t)L.entry + (uint64_t)t * L.tile_units;
+    if (tb64 >= L.own_end) {
+        S[t] = ~0u;
         return;
     }
     const uint32_t tb = (uint32_t)tb64;
     const uint32_t te = (uint32_t)min((uint64_t)L.own_end, tb64 + L.tile_units);
-    // (A) first synchronisation point in [tb, te): running maximum of q + L[q] over the positions before it
-    uint32_t p = tb;
-    if (t != 0) {
-        const uint32_t w = L.max_len > 1 ? L.max_len - 1 : 0;
-        uint32_t q = tb - entry > w ? tb - w : entry;
-        uint32_t M = 0;
-        for (; q < tb; ++q) M = max(M, q + (uint32_t)len[q]);
-        while (p < te && M > p) {
-            M = max(M, p + (uint32_t)len[p]);
-            ++p;
-        }
-        if (p >= te) { // no synchronisation point in this tile: an earlier lane's chain runs through it
-            if (!WRITE) L.d_counts[t] = 0;
+    uint32_t cnt = 0;
+    bool ok = true;
+    auto insert = [&](uint32_t v) {
+        for (uint32_t i = 0; i < cnt; ++i)
+            if (set[i] == v) return; // two chains merged
+        if (cnt == kSyncSet) {
+            ok = false;
             return;
         }
+        set[cnt++] = v;
+    };
+    const uint32_t w = L.max_len > 0 ? L.max_len : 1;
+    for (uint32_t q = tb - L.entry > w ? tb - w : L.entry; q < tb && ok; ++q) {
+        const uint32_t l = (uint32_t)len[q];
+        const uint32_t land = q + (l > 0 ? l : 1u);
+        if (land >= tb) insert(land);
     }
-    // (B) follow the chain from p; stop at the first chain position >= te that is a synchronisation point (the start of
-    //     a later lane), or when the chain leaves the owned range
-    uint32_t pos = p, M = p, count = 0;
+    while (ok && cnt > 1) {
+        uint32_t mi = 0;
+        for (uint32_t i = 1; i < cnt; ++i)
+            if (set[i] < set[mi]) mi = i;
+        const uint32_t p = set[mi];
+        if (p >= te) { // no merge inside the tile
+            ok = false;
+            break;
+        }
+        set[mi] = set[--cnt];
+        const uint32_t l = (uint32_t)len[p];
+        insert(p + (l > 0 ? l : 1u));
+    }
+    S[t] = (ok && cnt == 1 && set[0] < te) ? set[0] : ~0u;
+}
+
+// One lane per tile with a synchronisation point: follows the chain from S[t] to the next tile's synchronisation point
+// (or out of the owned range), counting or writing the matches met.
+template <typename LenT, bool WRITE>
+__global__ __launch_bounds__(256) void k_longest_chain(LongestChainLaunch L, const uint32_t *S) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= L.n_tiles) return;
+    const LenT *len = reinterpret_cast<const LenT *>(L.d_len);
+    const uint32_t start = S[t];
+    if (start == ~0u || start >= L.own_end) {
+        if (!WRITE) L.d_counts[t] = 0;
+        if (t == 0 && !WRITE) *L.d_exit = L.entry; // entry at/after the end of the owned range
+        return;
+    }
+    uint32_t target = ~0u; // the next synchronisation point on the chain
+    for (uint32_t t2 = t + 1; t2 < L.n_tiles; ++t2) {
+        const uint32_t v = S[t2];
+        if (v != ~0u) {
+            target = v;
+            break;
+        }
+    }
+    uint32_t pos = start, count = 0;
     uint64_t dst = WRITE ? L.d_offsets[t] : 0;
-    for (;;) {
+    while (pos < target && pos < L.own_end) {
         const uint32_t l = (uint32_t)len[pos];
         if (l > 0) {
             if (WRITE && dst < L.cap) {
@@ -227,31 +272,31 @@ __global__ __launch_bounds__(256) void k_longest_chain(LongestChainLaunch L) {
             ++dst;
             ++count;
         }
-        const uint32_t nxt = pos + (l > 0 ? l : 1u);
-        // running maximum over every position the chain steps over (their matches are not taken, but they decide
-        // whether a later position is a synchronisation point)
-        const uint32_t lim = min(nxt, L.own_end);
-        M = max(M, pos + l);
-        for (uint32_t q = pos + 1; q < lim; ++q) M = max(M, q + (uint32_t)len[q]);
-        pos = nxt;
-        if (pos >= L.own_end) {
-            if (!WRITE) *L.d_exit = pos; // exactly one lane's chain crosses the end of the owned range
-            break;
-        }
-        if (pos >= te && M <= pos) break;
+        pos += l > 0 ? l : 1u;
     }
-    if (!WRITE) L.d_counts[t] = count;
+    if (!WRITE) {
+        L.d_counts[t] = count;
+        if (pos >= L.own_end) *L.d_exit = pos; // exactly one lane's segment crosses the end of the owned range
+    }
 }
 
-hipError_t launch_longest_chain(const LongestChainLaunch &l, bool write_pass, hipStream_t stream) {
+hipError_t launch_longest_sync(const LongestChainLaunch &l, uint32_t *d_sync, hipStream_t stream) {
+    if (l.n_tiles == 0) return hipSuccess;
+    const dim3 grid((l.n_tiles + 255) / 256), block(256);
+    if (l.len_bytes == 2) hipLaunchKernelGGL((k_longest_sync<uint16_t>), grid, block, 0, stream, l, d_sync);
+    else hipLaunchKernelGGL((k_longest_sync<uint32_t>), grid, block, 0, stream, l, d_sync);
+    return hipGetLastError();
+}
+
+hipError_t launch_longest_chain(const LongestChainLaunch &l, const uint32_t *d_sync, bool write_pass, hipStream_t stream) {
     if (l.n_tiles == 0) return hipSuccess;
     const dim3 grid((l.n_tiles + 255) / 256), block(256);
     if (l.len_bytes == 2) {
-        if (write_pass) hipLaunchKernelGGL((k_longest_chain<uint16_t, true>), grid, block, 0, stream, l);
-        else hipLaunchKernelGGL((k_longest_chain<uint16_t, false>), grid, block, 0, stream, l);
+        if (write_pass) hipLaunchKernelGGL((k_longest_chain<uint16_t, true>), grid, block, 0, stream, l, d_sync);
+        else hipLaunchKernelGGL((k_longest_chain<uint16_t, false>), grid, block, 0, stream, l, d_sync);
     } else {
-        if (write_pass) hipLaunchKernelGGL((k_longest_chain<uint32_t, true>), grid, block, 0, stream, l);
-        else hipLaunchKernelGGL((k_longest_chain<uint32_t, false>), grid, block, 0, stream, l);
+        if (write_pass) hipLaunchKernelGGL((k_longest_chain<uint32_t, true>), grid, block, 0, stream, l, d_sync);
+        else hipLaunchKernelGGL((k_longest_chain<uint32_t, false>), grid, block, 0, stream, l, d_sync);
     }
     return hipGetLastError();
 }
