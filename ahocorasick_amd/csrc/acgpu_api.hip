@@ -205,7 +205,7 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         L.block = tile_block_threads();
         const int waves_per_block = L.block / 64;
         uint64_t R = tunables().region_units > 0 ? (uint64_t)tunables().region_units : 16384;
-        R = std::max<uint64_t>(2048, (R + 2047) / 2048 * 2048);
+        { const uint64_t g = tile_group_units(); R = std::max<uint64_t>(g, (R + g - 1) / g * g); }
         L.region_units = (uint32_t)R;
         const uint64_t base8 = sh->own_begin & ~7ull; // regions are laid out from the 16-byte aligned start
         L.n_regions = (uint32_t)((sh->own_end - base8 + R - 1) / R);
@@ -422,7 +422,7 @@ int match_wholeword(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int rec
     L.block = tile_block_threads();
     const int waves_per_block = L.block / 64;
     uint64_t R = tunables().region_units > 0 ? (uint64_t)tunables().region_units : 16384;
-    R = std::max<uint64_t>(2048, (R + 2047) / 2048 * 2048);
+    { const uint64_t g = tile_group_units(); R = std::max<uint64_t>(g, (R + g - 1) / g * g); }
     L.region_units = (uint32_t)R;
     const uint64_t base8 = sh->own_begin & ~7ull;
     L.n_regions = (uint32_t)((sh->own_end - base8 + R - 1) / R);

@@ -63,6 +63,7 @@ hipError_t launch_permute(const ScratchRec *d_scratch, const unsigned long long 
                           int record_kind, void *d_out, uint64_t out_cap, const uint32_t *d_id_map, hipStream_t stream);
 uint32_t scan_tiles_for(uint32_t n); // number of prefix-sum tiles; the grand total is d_tmp[scan_tiles_for(n)]
 uint32_t tile_reserve_slots();
+uint32_t tile_group_units(); // regions must hold whole tile groups
 
 hipError_t launch_synth_fill(uint16_t *d_dst, uint64_t n, uint64_t start, uint64_t seed, const uint16_t *table,
                              uint32_t table_len, hipStream_t stream);

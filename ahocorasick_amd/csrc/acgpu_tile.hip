@@ -29,6 +29,7 @@ namespace acgpu {
 
 int tile_block_threads() { return kTileBlock; }
 uint32_t tile_reserve_slots() { return kReserve; }
+uint32_t tile_group_units() { return kPrefetch * kTileUnits; }
 
 size_t tile_lds_bytes(const DevTables &t, int block_threads) {
     return (size_t)t.filt_words * 4 + (size_t)(block_threads / kWave) * kCandCap * sizeof(uint32_t);

@@ -10,9 +10,15 @@ namespace acgpu {
 
 constexpr int kTileBlock = 1024;               // 16 waves share one LDS copy of the filter rows
 constexpr int kTileUnits = 512;                // units per wave tile (64 lanes x 8 units)
-constexpr int kVerifyBatches = 4;              // candidates verified per lane and call (independent load chains in flight)
+#ifndef ACGPU_NB
+#define ACGPU_NB 2
+#endif
+#ifndef ACGPU_PREFETCH
+#define ACGPU_PREFETCH 8
+#endif
+constexpr int kVerifyBatches = ACGPU_NB;              // candidates verified per lane and call (independent load chains in flight)
 constexpr int kCandCap = 1024;                 // candidate queue entries per wave; a tile adds at most 512
-constexpr int kPrefetch = 4;                   // tiles per group; one group of loads is in flight per wave
+constexpr int kPrefetch = ACGPU_PREFETCH;                   // tiles per group; one group of loads is in flight per wave
 constexpr uint32_t kReserve = 256;             // scratch slots a wave reserves per atomic
 
 struct TileCtx {
