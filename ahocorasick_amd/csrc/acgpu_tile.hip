@@ -31,8 +31,12 @@ int tile_block_threads() { return kTileBlock; }
 uint32_t tile_reserve_slots() { return kReserve; }
 uint32_t tile_group_units() { return kPrefetch * kTileUnits; }
 
+constexpr int kFilterWordsMax = 22016; // 88064 bytes of static LDS for the filter rows (tunable filter_max_bytes <= 88000)
+
+// dynamic LDS only: the candidate queues
 size_t tile_lds_bytes(const DevTables &t, int block_threads) {
-    return (size_t)t.filt_words * 4 + (size_t)(block_threads / kWave) * kCandCap * sizeof(uint32_t);
+    (void)t;
+    return (size_t)(block_threads / kWave) * kCandCap * sizeof(uint32_t);
 }
 
 struct __attribute__((packed, aligned(2))) Units8 { // 8 UTF-16 units at any unit address (one global_load_dwordx4)
@@ -206,15 +210,29 @@ __device__ __forceinline__ void drain(TileCtx &c, uint32_t keep_below) {
     }
 }
 
+// hs*n + ROWB*cl_new - cl_old*nK1s in three full-rate VALU ops (every factor < 2^24, exact modulo 2^32)
+template <uint32_t ROWB>
+__device__ __forceinline__ uint32_t roll_row(uint32_t hs, uint32_t n, uint32_t cl_old, int neg_nK1s, uint32_t cl_new) {
+    uint32_t t, u, r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(t) : "v"(hs), "s"(n));
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(u) : "v"(cl_old), "s"(neg_nK1s), "v"(t));
+    if (ROWB == 4) asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(r) : "v"(cl_new), "v"(u));
+    else asm("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(r) : "v"(cl_new), "v"(u));
+    return r;
+}
+
 // A wave owns a contiguous SPAN of regions.  Region boundaries sit at base8 + r * region_units (base8 = own_begin
 // rounded down to 8 units, region_units a multiple of the 2048-unit tile group), so a tile group never straddles two
 // regions and the tile stream -- with its double-buffered register groups and the cross-lane carry -- runs through the
 // whole span.
 template <int K, bool RANGE, bool WIDE>
 __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch L) {
+    // the filter rows are STATIC LDS (offset 0, so a scaled row index is the ds_read address with nothing to add);
+    // the candidate queues are the dynamic part behind it
+    __shared__ __attribute__((aligned(16))) uint32_t rows32[kFilterWordsMax];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *rows32 = reinterpret_cast<uint32_t *>(smem); // filter rows at LDS offset 0: a scaled row index IS the address
-    uint32_t *cand_all = reinterpret_cast<uint32_t *>(smem + (size_t)T.filt_words * 4);
+    const unsigned char *rows8 = reinterpret_cast<const unsigned char *>(rows32);
+    uint32_t *cand_all = reinterpret_cast<uint32_t *>(smem);
     for (uint32_t i = threadIdx.x; i < T.filt_words; i += blockDim.x) rows32[i] = T.filt_bits[i];
     __syncthreads();
 
@@ -228,6 +246,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
     uint32_t nK1s = ROWB; // ROWB * n^(K-1): weight of the unit that leaves the (K-1)-gram window
 #pragma unroll
     for (int i = 0; i < K - 1; ++i) nK1s *= n;
+    const int neg_nK1s = -(int)nK1s;
     constexpr int NP = K / 2; // dwords of the previous 8 units that hold the K-1 units before the lane's first one
 
     const uint32_t first_region = wave_global * L.regions_per_wave;
@@ -342,14 +361,13 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                     for (int j = 0; j < K - 1; ++j) hs = __umul24(hs, n) + a[j] * ROWB;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        if (j > 0 && K > 1) // v_mul_u32_u24 + v_lshl_add_u32 + v_mad_i32_i24
-                            hs = (uint32_t)__mul24((int)a[j - 1], -(int)nK1s) + ((a[j + K - 2] * ROWB) + __umul24(hs, n));
+                        if (j > 0 && K > 1) hs = roll_row<ROWB>(hs, n, a[j - 1], neg_nK1s, a[j + K - 2]);
                         uint32_t bit;
                         if (WIDE) {
-                            const uint64_t row = *reinterpret_cast<const uint64_t *>(smem + hs);
+                            const uint64_t row = *reinterpret_cast<const uint64_t *>(rows8 + hs);
                             bit = (uint32_t)(row >> a[K - 1 + j]) & 1u;
                         } else {
-                            const uint32_t row = *reinterpret_cast<const uint32_t *>(smem + hs);
+                            const uint32_t row = *reinterpret_cast<const uint32_t *>(rows8 + hs);
                             bit = __builtin_amdgcn_ubfe(row, a[K - 1 + j], 1); // v_bfe_u32 takes the offset from a[4:0]
                         }
                         mask |= bit << j;
