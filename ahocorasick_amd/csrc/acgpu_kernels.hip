@@ -125,32 +125,43 @@ __device__ __forceinline__ void ac_scan_body(const DevTables &T, const ScanLaunc
         uint32_t ce = cb + L.chunk_units;                                            // one past the last owned unit
         if (ce > L.own_end || ce < cb) ce = L.own_end;
         uint32_t rs = cb > halo ? cb - halo : 0;
-        rs &= ~7u; // 16-byte aligned vector loads; extra warm-up is harmless
-        // wave-uniform trip count: chunk + halo + alignment slack, in 8-unit vectors
-        const uint32_t n_vec = (L.chunk_units + halo + 7 + 7) / 8;
+        rs &= ~63u; // whole 128-byte lines: a lane requests the 8 vectors of a line back to back, so the line crosses
+                    // the fabric once instead of once per vector; the extra warm-up is harmless
+        // wave-uniform trip count: chunk + halo + alignment slack, in 64-unit lines
+        const uint32_t n_line = (L.chunk_units + halo + 63 + 63) / 64;
         uint32_t s = 0;
         uint32_t rank = 0;
-        for (uint32_t it = 0; it < n_vec; ++it) {
-            const uint32_t v = rs + it * 8;
-            const bool act = valid && v < ce;
-            uint4 w = make_uint4(0, 0, 0, 0);
-            if (act) {
-                if (v + 8 <= L.n_units) {
-                    w = *reinterpret_cast<const uint4 *>(L.d_hay + v);
-                } else { // tail of the buffer: never read past n_units
-                    uint32_t tmp[4] = {0, 0, 0, 0};
-                    for (uint32_t j = 0; j < 8 && v + j < L.n_units; ++j) tmp[j >> 1] |= (uint32_t)L.d_hay[v + j] << (16 * (j & 1));
-                    w = make_uint4(tmp[0], tmp[1], tmp[2], tmp[3]);
-                }
-            }
-            const uint32_t words[4] = {w.x, w.y, w.z, w.w};
+        for (uint32_t it = 0; it < n_line; ++it) {
+            const uint32_t vb = rs + it * 64;
+            uint4 line[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const uint32_t unit = (words[j >> 1] >> (16 * (j & 1))) & 0xffffu;
-                const uint32_t pos = v + j;
-                s = step(s, unit);
-                const bool has = act && s >= T.first_out && pos >= cb && pos < ce;
-                if (__any(has)) emit_chain(T, has ? s : 0u, pos + 1, rank, wq, L.d_scratch, L.cap, L.d_counter);
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t v = vb + k * 8;
+                uint4 w = make_uint4(0, 0, 0, 0);
+                if (valid && v < ce) {
+                    if (v + 8 <= L.n_units) {
+                        w = *reinterpret_cast<const uint4 *>(L.d_hay + v);
+                    } else { // tail of the buffer: never read past n_units
+                        uint32_t tmp[4] = {0, 0, 0, 0};
+                        for (uint32_t j = 0; j < 8 && v + j < L.n_units; ++j) tmp[j >> 1] |= (uint32_t)L.d_hay[v + j] << (16 * (j & 1));
+                        w = make_uint4(tmp[0], tmp[1], tmp[2], tmp[3]);
+                    }
+                }
+                line[k] = w;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t v = vb + k * 8;
+                const bool act = valid && v < ce;
+                const uint32_t words[4] = {line[k].x, line[k].y, line[k].z, line[k].w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t unit = (words[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+                    const uint32_t pos = v + j;
+                    s = step(s, unit);
+                    const bool has = act && s >= T.first_out && pos >= cb && pos < ce;
+                    if (__any(has)) emit_chain(T, has ? s : 0u, pos + 1, rank, wq, L.d_scratch, L.cap, L.d_counter);
+                }
             }
         }
         if (valid) L.d_chunk_counts[chunk] = rank;

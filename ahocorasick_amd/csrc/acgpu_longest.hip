@@ -66,7 +66,7 @@ __device__ __forceinline__ void longest_scan_body(const DevTables &T, const Long
     const uint32_t lanes_total = gridDim.x * blockDim.x;
     LenT *out_len = reinterpret_cast<LenT *>(L.d_len);
     const uint32_t rounds = (L.n_chunks + lanes_total - 1) / lanes_total;
-    const uint32_t n_vec = (L.chunk_units + halo + 14) / 8 + 1; // wave-uniform trip count
+    const uint32_t n_line = (L.chunk_units + halo + 126) / 64 + 1; // wave-uniform trip count, in 128-byte lines
     for (uint32_t round = 0; round < rounds; ++round) {
         const uint32_t chunk = round * lanes_total + blockIdx.x * blockDim.x + threadIdx.x;
         const bool valid = chunk < L.n_chunks;
@@ -75,52 +75,64 @@ __device__ __forceinline__ void longest_scan_body(const DevTables &T, const Long
         if (ce > L.own_end || ce < cb) ce = L.own_end;
         uint32_t top = ce + halo; // scan units [cb, top) right to left
         if (top > L.n_units || top < ce) top = L.n_units;
-        const uint32_t v_first = top > 0 ? ((top - 1) & ~7u) : 0; // highest vector touched
+        const uint32_t l_first = top > 0 ? ((top - 1) & ~63u) : 0; // highest 128-byte line touched
         uint32_t s = 0;
-        for (uint32_t it = 0; it < n_vec; ++it) {
-            const uint32_t v = v_first - it * 8;
-            const bool act = valid && it * 8 <= v_first && v + 8 > cb; // vector intersects [cb, top)
-            uint4 w = make_uint4(0, 0, 0, 0);
-            if (act) {
-                if (v + 8 <= L.n_units) {
-                    w = *reinterpret_cast<const uint4 *>(L.d_hay + v);
-                } else {
-                    uint32_t tmp[4] = {0, 0, 0, 0};
-                    for (uint32_t j = 0; j < 8 && v + j < L.n_units; ++j) tmp[j >> 1] |= (uint32_t)L.d_hay[v + j] << (16 * (j & 1));
-                    w = make_uint4(tmp[0], tmp[1], tmp[2], tmp[3]);
-                }
-            }
-            const uint32_t words[4] = {w.x, w.y, w.z, w.w};
-            uint32_t lens[8], states[8];
+        for (uint32_t it = 0; it < n_line; ++it) {
+            const bool line_ok = valid && it * 64 <= l_first;
+            const uint32_t vb = l_first - (line_ok ? it * 64 : 0);
+            // a lane requests the 8 vectors of a line back to back: the line crosses the fabric once
+            uint4 line[8];
 #pragma unroll
-            for (int j = 7; j >= 0; --j) {
-                const uint32_t unit = (words[j >> 1] >> (16 * (j & 1))) & 0xffffu;
-                const uint32_t pos = v + j;
-                if (act && pos < top) s = step(s, unit); // units at/after `top` are outside the warm-up window or the buffer
-                states[j] = s;
-                lens[j] = s < T.first_out ? 0u : (s < lds_states ? lds_len[s] : T.out_len[s]);
-            }
-            if (act && v < ce) {
-                if (v >= cb && v + 8 <= ce) {
-                    if (sizeof(LenT) == 2) {
-                        const uint4 o = make_uint4(lens[0] | lens[1] << 16, lens[2] | lens[3] << 16, lens[4] | lens[5] << 16,
-                                                   lens[6] | lens[7] << 16);
-                        *reinterpret_cast<uint4 *>(out_len + v) = o;
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t v = vb + k * 8;
+                uint4 w = make_uint4(0, 0, 0, 0);
+                if (line_ok && v + 8 > cb && v < top) {
+                    if (v + 8 <= L.n_units) {
+                        w = *reinterpret_cast<const uint4 *>(L.d_hay + v);
                     } else {
-                        *reinterpret_cast<uint4 *>(out_len + v) = make_uint4(lens[0], lens[1], lens[2], lens[3]);
-                        *reinterpret_cast<uint4 *>(out_len + v + 4) = make_uint4(lens[4], lens[5], lens[6], lens[7]);
+                        uint32_t tmp[4] = {0, 0, 0, 0};
+                        for (uint32_t j = 0; j < 8 && v + j < L.n_units; ++j) tmp[j >> 1] |= (uint32_t)L.d_hay[v + j] << (16 * (j & 1));
+                        w = make_uint4(tmp[0], tmp[1], tmp[2], tmp[3]);
                     }
-                    if (L.d_state) {
-                        *reinterpret_cast<uint4 *>(L.d_state + v) = make_uint4(states[0], states[1], states[2], states[3]);
-                        *reinterpret_cast<uint4 *>(L.d_state + v + 4) = make_uint4(states[4], states[5], states[6], states[7]);
-                    }
-                } else {
+                }
+                line[k] = w;
+            }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const uint32_t pos = v + j;
-                        if (pos >= cb && pos < ce) {
-                            out_len[pos] = (LenT)lens[j];
-                            if (L.d_state) L.d_state[pos] = states[j];
+            for (int k = 7; k >= 0; --k) {
+                const uint32_t v = vb + k * 8;
+                const bool act = line_ok && v + 8 > cb && v < top; // vector intersects [cb, top)
+                const uint32_t words[4] = {line[k].x, line[k].y, line[k].z, line[k].w};
+                uint32_t lens[8], states[8];
+#pragma unroll
+                for (int j = 7; j >= 0; --j) {
+                    const uint32_t unit = (words[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+                    const uint32_t pos = v + j;
+                    if (act && pos < top) s = step(s, unit); // units at/after `top` are outside the warm-up window or the buffer
+                    states[j] = s;
+                    lens[j] = s < T.first_out ? 0u : (s < lds_states ? lds_len[s] : T.out_len[s]);
+                }
+                if (act && v < ce) {
+                    if (v >= cb && v + 8 <= ce) {
+                        if (sizeof(LenT) == 2) {
+                            const uint4 o = make_uint4(lens[0] | lens[1] << 16, lens[2] | lens[3] << 16, lens[4] | lens[5] << 16,
+                                                       lens[6] | lens[7] << 16);
+                            *reinterpret_cast<uint4 *>(out_len + v) = o;
+                        } else {
+                            *reinterpret_cast<uint4 *>(out_len + v) = make_uint4(lens[0], lens[1], lens[2], lens[3]);
+                            *reinterpret_cast<uint4 *>(out_len + v + 4) = make_uint4(lens[4], lens[5], lens[6], lens[7]);
+                        }
+                        if (L.d_state) {
+                            *reinterpret_cast<uint4 *>(L.d_state + v) = make_uint4(states[0], states[1], states[2], states[3]);
+                            *reinterpret_cast<uint4 *>(L.d_state + v + 4) = make_uint4(states[4], states[5], states[6], states[7]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const uint32_t pos = v + j;
+                            if (pos >= cb && pos < ce) {
+                                out_len[pos] = (LenT)lens[j];
+                                if (L.d_state) L.d_state[pos] = states[j];
+                            }
                         }
                     }
                 }
