@@ -93,7 +93,7 @@ uint32_t lds_states_for(const HostTables &t) {
     int64_t budget = tunables().lds_table_bytes;
     const int64_t max_budget = 160 * 1024 - (int64_t)scan_queue_bytes(scan_block_threads()) - 1024;
     budget = std::max<int64_t>(0, std::min(budget, max_budget));
-    uint64_t row = (uint64_t)t.n_cls * t.entry_bytes + (t.mode == ACGPU_MODE_LONGEST ? 4 : 0);
+    uint64_t row = (uint64_t)t.n_cls * t.entry_bytes;
     uint64_t s = row ? (uint64_t)budget / row : 0;
     return (uint32_t)std::min<uint64_t>(s, t.n_states);
 }
@@ -306,22 +306,18 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
     const uint64_t own_len = sh->own_end - sh->own_begin;
     LongestScanLaunch S{};
     S.block = 1024;
-    S.grid = d.n_cu;
-    const uint64_t lanes = (uint64_t)S.grid * S.block;
-    // a lane's serial chain is latency bound: prefer many lanes over a small warm-up share (warm-up <= 50 % of a chunk)
-    uint64_t C = tunables().chunk_units > 0 ? (uint64_t)tunables().chunk_units
-                                            : std::max<uint64_t>({(own_len + lanes - 1) / lanes, 256, 2ull * halo});
-    C = std::max<uint32_t>(8, round_up8(C));
-    S.chunk_units = (uint32_t)C;
-    S.n_chunks = (uint32_t)((own_len + C - 1) / C);
-    S.grid = (int)std::min<uint64_t>((uint64_t)S.grid, ((uint64_t)S.n_chunks + S.block - 1) / S.block);
+    S.grid = 2 * d.n_cu; // two workgroups per CU share the LDS (hot trie rows: at most 72 KB each)
+    S.chunk_units = 0;
+    S.n_chunks = 0;
     S.d_hay = sh->d_hay;
     S.n_units = (uint32_t)sh->n_units;
     S.own_begin = (uint32_t)sh->own_begin;
     S.own_end = (uint32_t)sh->own_end;
     S.len_bytes = t.max_len < 65536 ? 2 : 4;
-    const uint32_t lds_states = t.dense && t.n_cls ? d.T.lds_entries / t.n_cls : 0;
-    S.lds_bytes = t.dense ? (size_t)lds_states * 4 + (size_t)d.T.lds_entries * t.entry_bytes : 0;
+    uint32_t lds_rows = 0;
+    if (t.dense && t.n_cls) lds_rows = (uint32_t)std::min<uint64_t>(t.n_states, (72 * 1024) / ((uint64_t)t.n_cls * 4));
+    S.lds_rows = lds_rows;
+    S.lds_bytes = (size_t)lds_rows * t.n_cls * 4;
     int rc;
     if ((rc = d.lenbuf.ensure((size_t)sh->n_units * S.len_bytes + 64))) return rc;
     S.d_len = d.lenbuf.p;
@@ -340,7 +336,7 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
     if ((rc = d.scan_tmp.ensure(((size_t)Cn.n_tiles / 2048 + 2) * 8))) return rc;
     Cn.d_len = d.lenbuf.p;
     Cn.d_state = S.d_state;
-    Cn.d_out_id = d.T.out_id;
+    Cn.d_out_id = d.T.term_id; // state[] holds the trie node of the longest keyword starting at a position
     Cn.len_bytes = S.len_bytes;
     Cn.own_end = (uint32_t)sh->own_end;
     Cn.entry = (uint32_t)entry;
@@ -374,7 +370,7 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
         HIP_TRY(hipEventElapsedTime(&prof->scan_ms, d.ev[0], d.ev[1]));
         HIP_TRY(hipEventElapsedTime(&prof->finalize_ms, d.ev[1], d.ev[2]));
         HIP_TRY(hipEventElapsedTime(&prof->total_ms, d.ev[0], d.ev[2]));
-        prof->scan_units = own_len + (uint64_t)S.n_chunks * halo;
+        prof->scan_units = own_len;
         prof->n_matches = *n_out;
         std::snprintf(prof->scan_kernel, sizeof(prof->scan_kernel), "%s", kname);
     }
@@ -545,15 +541,6 @@ int acgpu_build(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uint
     if (!a) return ACGPU_E_NOMEM;
     int rc;
     try {
-        if (mode == ACGPU_MODE_LONGEST && n_kw && kw_units && kw_off) {
-            // LONGEST runs the automaton of the REVERSED keywords right-to-left (acgpu_longest.hip)
-            std::vector<uint16_t> rev(kw_off[n_kw] ? kw_off[n_kw] : 1);
-            for (uint32_t k = 0; k < n_kw; k++) {
-                const uint64_t lo = kw_off[k], hi = kw_off[k + 1];
-                for (uint64_t i = lo; i < hi; i++) rev[i] = kw_units[hi - 1 - (i - lo)];
-            }
-            rc = build_tables(mode, rev.data(), kw_off, n_kw, case_sensitive, lower_tbl, wordchar_tbl, a->t, bad_keyword);
-        } else
         rc = build_tables(mode, kw_units, kw_off, n_kw, case_sensitive, lower_tbl, wordchar_tbl, a->t, bad_keyword);
     } catch (const std::bad_alloc &) {
         rc = ACGPU_E_NOMEM;

@@ -234,7 +234,7 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
             }
             for (uint32_t raw = 0; raw < 65536; raw++) t.cls_lut[raw] = (uint16_t)cls_of[t.lower[raw]];
             uint64_t entries = (uint64_t)N * t.n_cls;
-            uint32_t eb = (N <= 65536) ? 2 : 4;
+            uint32_t eb = (N <= 65536 && mode != ACGPU_MODE_LONGEST) ? 2 : 4;
             if (!tunables().force_sparse && entries * eb <= (uint64_t)tunables().dense_budget_bytes &&
                 entries < (1ull << 32)) {
                 t.dense = true;
@@ -244,6 +244,15 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
                 for (uint32_t s : bfs) {
                     uint32_t n = newid[s];
                     uint32_t *row = &t.dfa[(uint64_t)n * t.n_cls];
+                    if (mode == ACGPU_MODE_LONGEST) {
+                        // LONGEST walks the plain keyword trie forward from every position: goto edges only, bit 31 of an
+                        // entry = "the child is the end of a keyword" (0 = no edge; the root is never a child)
+                        for (uint32_t ci = child_begin[s]; ci < child_begin[s + 1]; ci++) {
+                            uint32_t c = child_ids[ci];
+                            row[cls_of[nodes[c].unit]] = newid[c] | (nodes[c].kw != ~0u ? 0x80000000u : 0u);
+                        }
+                        continue;
+                    }
                     if (s != 0) {
                         const uint32_t *frow = &t.dfa[(uint64_t)newid[fail[s]] * t.n_cls];
                         std::memcpy(row, frow, sizeof(uint32_t) * t.n_cls);

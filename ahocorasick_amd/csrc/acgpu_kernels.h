@@ -82,6 +82,7 @@ struct LongestScanLaunch {
     void *d_len;                    // per unit of the buffer: length of the longest keyword starting there (u16 or u32)
     uint32_t *d_state;              // optional: automaton state per unit (for the keyword id), or nullptr
     int len_bytes;                  // 2 or 4
+    uint32_t lds_rows;              // trie rows staged in LDS
     int grid, block;
     size_t lds_bytes;
 };

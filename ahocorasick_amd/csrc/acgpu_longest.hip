@@ -4,10 +4,10 @@
 // non-overlapping matches, i.e. the greedy chain  pos -> pos + max(L[pos], 1)  started at 0, where L[pos] is the
 // length of the longest keyword starting at pos (T/LongestMatchTest.java:30-42 is the same statement).
 //
-//  k_longest_scan  : L[pos] for every unit.  The automaton of the REVERSED keywords is run right-to-left over the
-//                    haystack; after consuming text[pos..] backwards, the longest keyword on the state's output chain
-//                    is the longest keyword starting at pos.  One chunk of start positions per lane, warmed up on
-//                    the (max_keyword_len-1) units to its right; hot rows and their lengths in LDS.
+//  k_longest_walk  : L[pos] for every unit: a forward walk of the keyword trie from every position (position
+//                    parallel, hot trie rows in LDS).  (A right-to-left scan with the automaton of the reversed
+//                    keywords would bound the work per unit, but reversing a prefix-closed dictionary -- config 4 --
+//                    blows 50k trie nodes up to 24M states.)
 //  k_longest_sync  : one synchronisation point per tile -- a position every greedy chain that can enter the tile must
 //                    pass (found by following all candidate chains until they have merged).
 //  k_longest_chain : one lane per tile follows the chain from its synchronisation point to the next tile's, so lanes
@@ -22,143 +22,72 @@ namespace acgpu {
 
 constexpr int kLScanBlock = 1024;
 
-template <typename E>
-struct RevDenseStep {
-    const E *lds, *glob;
-    uint32_t lds_entries, n_cls;
-    const uint16_t *cls_lut;
-    uint32_t cls_base, cls_span;
-    bool range_cls;
-    __device__ __forceinline__ uint32_t operator()(uint32_t s, uint32_t unit) const {
-        uint32_t cls;
-        if (range_cls) {
-            const uint32_t d = unit - cls_base;
-            cls = d < cls_span ? d + 1 : 0;
-        } else {
-            cls = cls_lut[unit];
-        }
-        const uint32_t idx = s * n_cls + cls;
-        return idx < lds_entries ? (uint32_t)lds[idx] : (uint32_t)glob[idx];
-    }
+struct __attribute__((packed, aligned(2))) Units8 { // 8 UTF-16 units at any unit address (one global_load_dwordx4)
+    uint32_t d[4];
 };
 
-struct RevSparseStep {
-    const uint64_t *hkeys;
-    const uint32_t *hvals, *fail;
-    const uint16_t *lower;
-    uint32_t hmask;
-    bool cs;
-    __device__ __forceinline__ uint32_t operator()(uint32_t s, uint32_t unit) const {
-        const uint32_t u = cs ? unit : (uint32_t)lower[unit];
-        for (;;) {
-            const uint32_t n = hashed_goto(hkeys, hvals, hmask, s, u);
-            if (n != ~0u) return n;
-            if (s == 0) return 0;
-            s = fail[s];
-        }
-    }
-};
-
-template <typename Step, typename LenT>
-__device__ __forceinline__ void longest_scan_body(const DevTables &T, const LongestScanLaunch &L, const Step &step,
-                                                  const uint32_t *lds_len, uint32_t lds_states) {
-    const uint32_t halo = T.max_len > 0 ? T.max_len - 1 : 0;
-    const uint32_t lanes_total = gridDim.x * blockDim.x;
-    LenT *out_len = reinterpret_cast<LenT *>(L.d_len);
-    const uint32_t rounds = (L.n_chunks + lanes_total - 1) / lanes_total;
-    const uint32_t n_line = (L.chunk_units + halo + 126) / 64 + 1; // wave-uniform trip count, in 128-byte lines
-    for (uint32_t round = 0; round < rounds; ++round) {
-        const uint32_t chunk = round * lanes_total + blockIdx.x * blockDim.x + threadIdx.x;
-        const bool valid = chunk < L.n_chunks;
-        const uint32_t cb = valid ? L.own_begin + chunk * L.chunk_units : L.own_end; // first owned start position
-        uint32_t ce = cb + L.chunk_units;
-        if (ce > L.own_end || ce < cb) ce = L.own_end;
-        uint32_t top = ce + halo; // scan units [cb, top) right to left
-        if (top > L.n_units || top < ce) top = L.n_units;
-        const uint32_t l_first = top > 0 ? ((top - 1) & ~63u) : 0; // highest 128-byte line touched
-        uint32_t s = 0;
-        for (uint32_t it = 0; it < n_line; ++it) {
-            const bool line_ok = valid && it * 64 <= l_first;
-            const uint32_t vb = l_first - (line_ok ? it * 64 : 0);
-            // a lane requests the 8 vectors of a line back to back: the line crosses the fabric once
-            uint4 line[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const uint32_t v = vb + k * 8;
-                uint4 w = make_uint4(0, 0, 0, 0);
-                if (line_ok && v + 8 > cb && v < top) {
-                    if (v + 8 <= L.n_units) {
-                        w = *reinterpret_cast<const uint4 *>(L.d_hay + v);
-                    } else {
-                        uint32_t tmp[4] = {0, 0, 0, 0};
-                        for (uint32_t j = 0; j < 8 && v + j < L.n_units; ++j) tmp[j >> 1] |= (uint32_t)L.d_hay[v + j] << (16 * (j & 1));
-                        w = make_uint4(tmp[0], tmp[1], tmp[2], tmp[3]);
-                    }
-                }
-                line[k] = w;
-            }
-#pragma unroll
-            for (int k = 7; k >= 0; --k) {
-                const uint32_t v = vb + k * 8;
-                const bool act = line_ok && v + 8 > cb && v < top; // vector intersects [cb, top)
-                const uint32_t words[4] = {line[k].x, line[k].y, line[k].z, line[k].w};
-                uint32_t lens[8], states[8];
-#pragma unroll
-                for (int j = 7; j >= 0; --j) {
-                    const uint32_t unit = (words[j >> 1] >> (16 * (j & 1))) & 0xffffu;
-                    const uint32_t pos = v + j;
-                    if (act && pos < top) s = step(s, unit); // units at/after `top` are outside the warm-up window or the buffer
-                    states[j] = s;
-                    lens[j] = s < T.first_out ? 0u : (s < lds_states ? lds_len[s] : T.out_len[s]);
-                }
-                if (act && v < ce) {
-                    if (v >= cb && v + 8 <= ce) {
-                        if (sizeof(LenT) == 2) {
-                            const uint4 o = make_uint4(lens[0] | lens[1] << 16, lens[2] | lens[3] << 16, lens[4] | lens[5] << 16,
-                                                       lens[6] | lens[7] << 16);
-                            *reinterpret_cast<uint4 *>(out_len + v) = o;
-                        } else {
-                            *reinterpret_cast<uint4 *>(out_len + v) = make_uint4(lens[0], lens[1], lens[2], lens[3]);
-                            *reinterpret_cast<uint4 *>(out_len + v + 4) = make_uint4(lens[4], lens[5], lens[6], lens[7]);
-                        }
-                        if (L.d_state) {
-                            *reinterpret_cast<uint4 *>(L.d_state + v) = make_uint4(states[0], states[1], states[2], states[3]);
-                            *reinterpret_cast<uint4 *>(L.d_state + v + 4) = make_uint4(states[4], states[5], states[6], states[7]);
-                        }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const uint32_t pos = v + j;
-                            if (pos >= cb && pos < ce) {
-                                out_len[pos] = (LenT)lens[j];
-                                if (L.d_state) L.d_state[pos] = states[j];
-                            }
-                        }
-                    }
-                }
-            }
-        }
-    }
-}
-
-template <typename E, typename LenT>
-__global__ __launch_bounds__(kLScanBlock) void k_longest_scan_dense(DevTables T, LongestScanLaunch L) {
+// L[pos] for every owned position: walk the keyword trie forward from pos, remember the deepest node that ends a
+// keyword.  Position parallel (lane i of a wave = position base+i: text loads and the len[] stores are coalesced);
+// the hot (shallow, BFS-first) rows of the class-indexed goto table sit in LDS.
+template <typename LenT, bool DENSE>
+__global__ __launch_bounds__(kLScanBlock) void k_longest_walk(DevTables T, LongestScanLaunch L) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t lds_states = T.n_cls ? T.lds_entries / T.n_cls : 0;
-    uint32_t *lds_len = reinterpret_cast<uint32_t *>(smem);
-    E *tab = reinterpret_cast<E *>(smem + (size_t)lds_states * 4);
-    const E *glob = reinterpret_cast<const E *>(T.dfa);
-    for (uint32_t i = threadIdx.x; i < lds_states; i += blockDim.x) lds_len[i] = T.out_len[i];
-    for (uint32_t i = threadIdx.x; i < T.lds_entries; i += blockDim.x) tab[i] = glob[i];
+    uint32_t *rows = reinterpret_cast<uint32_t *>(smem);
+    const uint32_t *glob = reinterpret_cast<const uint32_t *>(T.dfa);
+    const uint32_t lds_entries = DENSE ? L.lds_rows * T.n_cls : 0;
+    for (uint32_t i = threadIdx.x; i < lds_entries; i += blockDim.x) rows[i] = glob[i];
     __syncthreads();
-    RevDenseStep<E> step{tab, glob, T.lds_entries, T.n_cls, T.cls_lut, T.cls_base, T.cls_span, T.range_cls != 0};
-    longest_scan_body<RevDenseStep<E>, LenT>(T, L, step, lds_len, lds_states);
-}
-
-template <typename LenT>
-__global__ __launch_bounds__(kLScanBlock) void k_longest_scan_sparse(DevTables T, LongestScanLaunch L) {
-    RevSparseStep step{T.hkeys, T.hvals, T.fail, T.lower, T.hmask, T.cs != 0};
-    longest_scan_body<RevSparseStep, LenT>(T, L, step, nullptr, 0);
+    LenT *out_len = reinterpret_cast<LenT *>(L.d_len);
+    const uint16_t *hay = L.d_hay;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t p = L.own_begin + blockIdx.x * blockDim.x + threadIdx.x; p < L.own_end; p += stride) {
+        uint32_t node = 0, best = 0, best_node = 0, i = p;
+        bool alive = true;
+        while (alive && i < L.n_units) {
+            // eight units per load; the walk usually ends inside the first window
+            uint32_t w[4] = {0, 0, 0, 0};
+            if (i + 8 <= L.n_units) {
+                const Units8 u = *reinterpret_cast<const Units8 *>(hay + i);
+                w[0] = u.d[0]; w[1] = u.d[1]; w[2] = u.d[2]; w[3] = u.d[3];
+            } else {
+                for (uint32_t j = 0; j < 8 && i + j < L.n_units; ++j) w[j >> 1] |= (uint32_t)hay[i + j] << (16 * (j & 1));
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (alive && i < L.n_units) {
+                    const uint32_t unit = (w[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+                    uint32_t e;
+                    if (DENSE) {
+                        uint32_t cls;
+                        if (T.range_cls) {
+                            const uint32_t dlt = unit - T.cls_base;
+                            cls = dlt < T.cls_span ? dlt + 1 : 0;
+                        } else {
+                            cls = T.cls_lut[unit];
+                        }
+                        const uint32_t idx = node * T.n_cls + cls;
+                        e = idx < lds_entries ? rows[idx] : glob[idx];
+                    } else {
+                        const uint32_t f = T.cs ? unit : (uint32_t)T.lower[unit];
+                        const uint32_t c = hashed_goto(T.hkeys, T.hvals, T.hmask, node, f);
+                        e = c == ~0u ? 0u : (c | (T.term_id[c] != ~0u ? 0x80000000u : 0u));
+                    }
+                    if (e == 0) {
+                        alive = false;
+                    } else {
+                        node = e & 0x7fffffffu;
+                        ++i;
+                        if (e >> 31) {
+                            best = i - p;
+                            best_node = node;
+                        }
+                    }
+                }
+            }
+        }
+        out_len[p] = (LenT)best;
+        if (L.d_state) L.d_state[p] = best_node;
+    }
 }
 
 hipError_t launch_longest_scan(const DevTables &t, const LongestScanLaunch &l, hipStream_t stream, const char **kernel_name) {
@@ -171,16 +100,11 @@ hipError_t launch_longest_scan(const DevTables &t, const LongestScanLaunch &l, h
         if (kernel_name) *kernel_name = NAME;                                                                           \
     } while (0)
     if (t.dense) {
-        if (t.entry_bytes == 2) {
-            if (l.len_bytes == 2) ACGPU_LAUNCH((k_longest_scan_dense<uint16_t, uint16_t>), "k_longest_scan_dense<unsigned short, unsigned short>");
-            else ACGPU_LAUNCH((k_longest_scan_dense<uint16_t, uint32_t>), "k_longest_scan_dense<unsigned short, unsigned int>");
-        } else {
-            if (l.len_bytes == 2) ACGPU_LAUNCH((k_longest_scan_dense<uint32_t, uint16_t>), "k_longest_scan_dense<unsigned int, unsigned short>");
-            else ACGPU_LAUNCH((k_longest_scan_dense<uint32_t, uint32_t>), "k_longest_scan_dense<unsigned int, unsigned int>");
-        }
+        if (l.len_bytes == 2) ACGPU_LAUNCH((k_longest_walk<uint16_t, true>), "k_longest_walk<unsigned short, true>");
+        else ACGPU_LAUNCH((k_longest_walk<uint32_t, true>), "k_longest_walk<unsigned int, true>");
     } else {
-        if (l.len_bytes == 2) ACGPU_LAUNCH((k_longest_scan_sparse<uint16_t>), "k_longest_scan_sparse<unsigned short>");
-        else ACGPU_LAUNCH((k_longest_scan_sparse<uint32_t>), "k_longest_scan_sparse<unsigned int>");
+        if (l.len_bytes == 2) ACGPU_LAUNCH((k_longest_walk<uint16_t, false>), "k_longest_walk<unsigned short, false>");
+        else ACGPU_LAUNCH((k_longest_walk<uint32_t, false>), "k_longest_walk<unsigned int, false>");
     }
 #undef ACGPU_LAUNCH
     return hipGetLastError();
