@@ -107,3 +107,41 @@ def test_match_fails_loudly_without_device():
     a = Automaton(N.MODE_ALL, ["ab"], True)
     with pytest.raises(N.AcgpuError):
         a.match_host(utf16("zabz"), with_ids=True)
+
+
+def test_abi_argument_checking_without_device():
+    L = N.lib()
+    h = ctypes.c_void_p()
+    bad = ctypes.c_int64(-1)
+    units = np.array([97, 98], np.uint16)
+    off = np.array([0, 2], np.uint64)
+    vp = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+    # unknown mode, missing fold table for case-insensitive, missing word-char table for WHOLEWORD
+    assert L.acgpu_build(7, vp(units), vp(off), 1, 1, None, None, ctypes.byref(h), ctypes.byref(bad)) == N.E_INVALID
+    assert L.acgpu_build(N.MODE_ALL, vp(units), vp(off), 1, 0, None, None, ctypes.byref(h), ctypes.byref(bad)) == N.E_INVALID
+    assert L.acgpu_build(N.MODE_WHOLEWORD, vp(units), vp(off), 1, 1, None, None, ctypes.byref(h), ctypes.byref(bad)) == N.E_INVALID
+    assert L.acgpu_build(N.MODE_ALL, vp(units), vp(off), 1, 1, None, None, None, None) == N.E_INVALID
+    # a good build; info, strerror, unknown tunable
+    assert L.acgpu_build(N.MODE_ALL, vp(units), vp(off), 1, 1, None, None, ctypes.byref(h), ctypes.byref(bad)) == N.OK
+    info = N.Info()
+    assert L.acgpu_get_info(h, ctypes.byref(info)) == N.OK and info.n_states == 3 and info.max_keyword_len == 2
+    assert L.acgpu_get_info(None, ctypes.byref(info)) == N.E_INVALID
+    assert L.acgpu_strerror(N.E_OVERFLOW) == b"output capacity too small"
+    assert L.acgpu_set_tunable(b"no_such_knob", 1) == -1
+    n_out = ctypes.c_uint64(0)
+    assert L.acgpu_match_u16(h, None, 5, N.REC_MAP, None, 0, ctypes.byref(n_out)) == N.E_INVALID
+    assert L.acgpu_match_u16(h, vp(units), 2, 5, None, 0, ctypes.byref(n_out)) == N.E_INVALID  # bad record kind
+    L.acgpu_free(h)
+    L.acgpu_free(None)
+
+
+def test_longest_and_wholeword_automata_build_on_cpu():
+    from ahocorasick_amd import synth
+    a = Automaton(N.MODE_LONGEST, synth.prefix_closed_keywords(1004, 3000, word_len=200), True).info()
+    assert a["n_states"] == 3001 and a["dense"] == 1 and a["entry_bytes"] == 4  # the forward trie, not a reversed automaton
+    words = synth.mixed_script_words(1005, 2000)
+    w = Automaton(N.MODE_WHOLEWORD, words, False, word_chars=WORD).info()
+    assert w["n_keywords"] <= 2000 and w["fold_consistent"] == 1
+    wc = np.zeros(65536, np.uint8)
+    wc[ord("A")] = 1
+    assert Automaton(N.MODE_WHOLEWORD, ["A"], False, word_chars=wc).info()["fold_consistent"] == 0
