@@ -14,7 +14,7 @@
 //            reference's output chain of the state reached at e.
 //
 // Work distribution: a wave owns a contiguous REGION of the haystack and streams it as 512-unit tiles, lane l
-// holding units [8l, 8l+8) of the tile (one coalesced 1 KiB load per wave and tile, kPrefetch tiles in flight).
+// holding 16 consecutive units of a 1024-unit tile (two 16-byte loads per lane), 8 KiB per wave in flight.
 // Because a wave meets its candidates in text order, a record's rank inside its region is a running wave-uniform
 // count plus a wave prefix sum; the finalize pass (prefix sum over regions + permutation) then yields the
 // reference's emission order (end ascending, longest first) without any sort.  Records go straight to HBM into
@@ -29,6 +29,16 @@ namespace acgpu {
 
 int tile_block_threads() { return kTileBlock; }
 uint32_t tile_reserve_slots() { return kReserve; }
+#ifndef ACGPU_VEC
+#define ACGPU_VEC 2
+#endif
+// AhoCorasick tile geometry: a lane holds kAcVec 16-byte vectors = 8*kAcVec consecutive units of a tile, so the per-tile
+// fixed work (prefix sum, cross-lane carry, queue append) is shared by 16 positions per lane instead of 8
+constexpr int kAcVec = ACGPU_VEC;
+constexpr int kAcLaneUnits = 8 * kAcVec;
+constexpr int kAcTileUnits = kWave * kAcLaneUnits;
+constexpr int kAcTiles = kPrefetch / kAcVec;            // tiles per double-buffered group (same bytes in flight)
+constexpr int kAcCandCap = kAcTileUnits + kVerifyBatches * kWave;
 uint32_t tile_group_units() { return kPrefetch * kTileUnits; }
 
 constexpr int kFilterWordsMax = 22016; // 88064 bytes of static LDS for the filter rows (tunable filter_max_bytes <= 88000)
@@ -36,7 +46,7 @@ constexpr int kFilterWordsMax = 22016; // 88064 bytes of static LDS for the filt
 // dynamic LDS only: the candidate queues
 size_t tile_lds_bytes(const DevTables &t, int block_threads) {
     (void)t;
-    return (size_t)(block_threads / kWave) * kCandCap * sizeof(uint32_t);
+    return (size_t)(block_threads / kWave) * kAcCandCap * sizeof(uint32_t);
 }
 
 struct __attribute__((packed, aligned(2))) Units8 { // 8 UTF-16 units at any unit address (one global_load_dwordx4)
@@ -239,7 +249,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
     const uint32_t lane = lane_id();
     const uint32_t wave_in_block = threadIdx.x / kWave;
     const uint32_t wave_global = blockIdx.x * (kTileBlock / kWave) + wave_in_block;
-    TileCtx c{&T, &L, cand_all + wave_in_block * kCandCap, 0, 0, 0u, 0};
+    TileCtx c{&T, &L, cand_all + wave_in_block * kAcCandCap, 0, 0, 0u, 0};
 
     constexpr uint32_t ROWB = WIDE ? 8 : 4;
     const uint32_t n = T.filt_n;
@@ -274,19 +284,24 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
     bool tail_todo = span_end > nfull;  // the units behind the last full vector of the buffer (fewer than 8)
     uint32_t d0 = 0;                    // tile of the current group to resume at (after a mid-group drain)
     uint32_t carry[4] = {0, 0, 0, 0};
-    uint4 nxt[kPrefetch], grp[kPrefetch];
+    uint4 nxt[kAcTiles][kAcVec], grp[kAcTiles][kAcVec];
 #pragma unroll
-    for (int d = 0; d < kPrefetch; ++d) nxt[d] = grp[d] = make_uint4(0, 0, 0, 0);
+    for (int d = 0; d < kAcTiles; ++d)
+#pragma unroll
+        for (int u = 0; u < kAcVec; ++u) nxt[d][u] = grp[d][u] = make_uint4(0, 0, 0, 0);
     if (vec_todo) {
         if (K > 1 && tile >= 8) {
             const uint4 p = *reinterpret_cast<const uint4 *>(hay + tile - 8);
             carry[0] = p.x; carry[1] = p.y; carry[2] = p.z; carry[3] = p.w;
         }
-        // double-buffered tile groups: while the kPrefetch tiles of the current group are filtered out of registers, the
-        // loads of the next group are in flight (4 KiB per wave); they are awaited together at the next group's start
+        // double-buffered tile groups: while the tiles of the current group are filtered out of registers, the loads of
+        // the next group are in flight (8 KiB per wave); they are awaited together at the next group's start
 #pragma unroll
-        for (int d = 0; d < kPrefetch; ++d)
-            nxt[d] = *reinterpret_cast<const uint4 *>(hay + min(tile + d * kTileUnits + lane * 8, last_vec));
+        for (int d = 0; d < kAcTiles; ++d)
+#pragma unroll
+            for (int u = 0; u < kAcVec; ++u)
+                nxt[d][u] = *reinterpret_cast<const uint4 *>(
+                    hay + min(tile + d * kAcTileUnits + lane * kAcLaneUnits + u * 8, last_vec));
     }
 
     // One loop, ONE verification site: every pass first drains the candidate queue as far as its state requires
@@ -308,59 +323,71 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                     re = min(span_end, boundary);
                 }
 #pragma unroll
-                for (int d = 0; d < kPrefetch; ++d) grp[d] = nxt[d];
+                for (int d = 0; d < kAcTiles; ++d)
 #pragma unroll
-                for (int d = 0; d < kPrefetch; ++d)
-                    nxt[d] = *reinterpret_cast<const uint4 *>(
-                        hay + min(tile + (kPrefetch + d) * kTileUnits + lane * 8, last_vec));
+                    for (int u = 0; u < kAcVec; ++u) grp[d][u] = nxt[d][u];
+#pragma unroll
+                for (int d = 0; d < kAcTiles; ++d)
+#pragma unroll
+                    for (int u = 0; u < kAcVec; ++u)
+                        nxt[d][u] = *reinterpret_cast<const uint4 *>(
+                            hay + min(tile + (kAcTiles + d) * kAcTileUnits + lane * kAcLaneUnits + u * 8, last_vec));
             }
             // positions a lane may report: inside the region, in the vector part of the buffer, with K units to their
             // left in the buffer.  Only groups at the edges of a region need the per-lane mask.
             const uint32_t lo = max(rb, (uint32_t)(K - 1));
             const uint32_t top = min(re, hi);
-            const bool edge = tile < lo || tile + kPrefetch * kTileUnits > top; // wave-uniform
+            const bool edge = tile < lo || tile + kAcTiles * kAcTileUnits > top; // wave-uniform
             bool resume = false;
 #pragma unroll
-            for (int d = 0; d < kPrefetch; ++d) {
+            for (int d = 0; d < kAcTiles; ++d) {
                 if ((uint32_t)d < d0) continue; // wave-uniform
-                const uint32_t cur = tile + d * kTileUnits;
+                const uint32_t cur = tile + d * kAcTileUnits;
                 if (cur >= hi) break; // wave-uniform
-                if (c.cand_n > kCandCap - kTileUnits) { // rare: the queue cannot take a worst-case tile -> drain first
+                if (c.cand_n > kAcCandCap - kAcTileUnits) { // rare: the queue cannot take a worst-case tile -> drain first
                     d0 = d;
                     resume = true;
                     break;
                 }
-                const uint4 w = grp[d];
-                const uint32_t v = cur + lane * 8;
-                const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-                // the previous lane's dwords give the K-1 units before v; lane 0 takes the previous tile's lane 63
+                const uint32_t v = cur + lane * kAcLaneUnits;
+                uint32_t ww[4 * kAcVec];
+#pragma unroll
+                for (int u = 0; u < kAcVec; ++u) {
+                    ww[4 * u + 0] = grp[d][u].x; ww[4 * u + 1] = grp[d][u].y;
+                    ww[4 * u + 2] = grp[d][u].z; ww[4 * u + 3] = grp[d][u].w;
+                }
+                // the previous lane's last dwords give the K-1 units before v; lane 0 takes the previous tile's lane 63
                 uint32_t pp[4] = {0, 0, 0, 0};
 #pragma unroll
                 for (int q = 4 - NP; q < 4; ++q) {
-                    pp[q] = from_prev_lane(ww[q], carry[q]);
-                    carry[q] = __builtin_amdgcn_readlane(ww[q], 63);
+                    const uint32_t mine = ww[4 * (kAcVec - 1) + q];
+                    pp[q] = from_prev_lane(mine, carry[q]);
+                    carry[q] = __builtin_amdgcn_readlane(mine, 63);
                 }
                 uint32_t mask = 0;
                 if (L.debug & 4u) { // ablation: stream only
-                    const uint32_t x = ww[0] ^ ww[1] ^ ww[2] ^ ww[3];
+                    uint32_t x = 0;
+#pragma unroll
+                    for (int q = 0; q < 4 * kAcVec; ++q) x ^= ww[q];
                     mask = (x == 0x12345678u) ? 1u : 0u;
                 } else {
-                    // classes of units v-(K-1) .. v+7
-                    uint32_t a[8 + K - 1];
+                    // classes of units v-(K-1) .. v+kAcLaneUnits-1
+                    uint32_t a[kAcLaneUnits + K - 1];
 #pragma unroll
                     for (int j = 0; j < K - 1; ++j) {
                         const int u = 8 - (K - 1) + j; // unit index inside the previous 8
                         a[j] = tile_class_t<RANGE>(T, (pp[u >> 1] >> (16 * (u & 1))) & 0xffffu);
                     }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) a[K - 1 + j] = tile_class_t<RANGE>(T, (ww[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+                    for (int j = 0; j < kAcLaneUnits; ++j)
+                        a[K - 1 + j] = tile_class_t<RANGE>(T, (ww[j >> 1] >> (16 * (j & 1))) & 0xffffu);
                     // byte offset of the filter row of position v+j = ROWB * index of its (K-1)-gram a[j .. j+K-2],
                     // rolling; every factor is < 2^24, so the full-rate 24-bit multiplies are exact modulo 2^32
                     uint32_t hs = 0;
 #pragma unroll
                     for (int j = 0; j < K - 1; ++j) hs = __umul24(hs, n) + a[j] * ROWB;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
+                    for (int j = 0; j < kAcLaneUnits; ++j) {
                         if (j > 0 && K > 1) hs = roll_row<ROWB>(hs, n, a[j - 1], neg_nK1s, a[j + K - 2]);
                         uint32_t bit;
                         if (WIDE) {
@@ -373,8 +400,8 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                         mask |= bit << j;
                     }
                     if (edge) {
-                        const uint32_t first = lo > v ? min(lo - v, 8u) : 0u;
-                        const uint32_t last = top > v ? min(top - v, 8u) : 0u;
+                        const uint32_t first = lo > v ? min(lo - v, (uint32_t)kAcLaneUnits) : 0u;
+                        const uint32_t last = top > v ? min(top - v, (uint32_t)kAcLaneUnits) : 0u;
                         mask &= ((1u << last) - 1u) & ~((1u << first) - 1u);
                     }
                 }
@@ -382,7 +409,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
             }
             if (!resume) {
                 d0 = 0;
-                tile += kPrefetch * kTileUnits;
+                tile += kAcTiles * kAcTileUnits;
                 vec_todo = tile < hi;
             }
             continue;
