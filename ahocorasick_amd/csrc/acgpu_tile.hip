@@ -106,7 +106,8 @@ __device__ __forceinline__ void verify_multi(TileCtx &c, uint32_t head, uint32_t
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         if (e[b] >= 8) {
-            win[b] = *reinterpret_cast<const Units8 *>(hay + e[b] - 8);
+            if (L.debug & 8u) win[b] = Units8{{e[b], e[b] * 3u, e[b] * 5u, e[b] * 7u}}; // ablation: no window load
+            else win[b] = *reinterpret_cast<const Units8 *>(hay + e[b] - 8);
         } else {
             win[b] = Units8{{0, 0, 0, 0}}; // within 8 units of the buffer start (rare): unit by unit
 #pragma unroll
@@ -122,7 +123,7 @@ __device__ __forceinline__ void verify_multi(TileCtx &c, uint32_t head, uint32_t
 #pragma unroll
         for (int j = 8 - K; j < 8; ++j) idx = __umul24(idx, T.filt_n) + tile_class_t<RANGE>(T, (win[b].d[j >> 1] >> (16 * (j & 1))) & 0xffffu);
         if (K < 8) left_unit[b] = (win[b].d[(7 - K) >> 1] >> (16 * ((7 - K) & 1))) & 0xffffu;
-        ref[b] = act[b] ? T.kgram_node[idx] : 0u;
+        ref[b] = act[b] ? ((L.debug & 16u) ? (idx & 1u) : T.kgram_node[idx]) : 0u; // 16: ablation, no K-gram node load
         ref0[b] = ref[b];
     }
     // leftward walks in lock step; every terminal node met is a keyword ending at e (increasing length)
