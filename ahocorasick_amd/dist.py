@@ -52,15 +52,16 @@ def exchange_halo(sb, group=None):
         return
     ops = []
     recv = None
+    # bytes on the wire: RCCL has no 16-bit integer type
     if rank + 1 < world:
-        ops.append(dist.P2POp(dist.isend, sb.tail_view().contiguous(), rank + 1, group))
+        ops.append(dist.P2POp(dist.isend, sb.tail_view().contiguous().view(torch.uint8), rank + 1, group))
     if rank > 0:
-        recv = torch.empty(sb.halo, dtype=torch.int16, device=sb.buf.device)
+        recv = torch.empty(2 * sb.halo, dtype=torch.uint8, device=sb.buf.device)
         ops.append(dist.P2POp(dist.irecv, recv, rank - 1, group))
     for w in dist.batch_isend_irecv(ops):
         w.wait()
     if recv is not None:
-        sb.halo_view().copy_(recv)
+        sb.halo_view().copy_(recv.view(torch.int16))
 
 
 def allgather_matches(local, n_local, group=None):
