@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Randomised GPU-vs-oracle soak test (development tool; the pytest suite holds the fixed regression cases).
+
+Draws random dictionaries / haystacks / tunables / shard splits for all three matcher families and compares the
+device records with oracle/ac_oracle.c bit for bit.  Usage: python tools/fuzz_gpu.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch  # noqa: E402
+
+from ahocorasick_amd import _native as N  # noqa: E402
+from ahocorasick_amd.strings import Automaton  # noqa: E402
+from ahocorasick_amd.unicode_tables import default_word_chars, java_lower_table  # noqa: E402
+from oracle.oracle import FAM_AC, FAM_LONGEST, FAM_WHOLEWORD, Oracle  # noqa: E402
+
+LOWER = java_lower_table()
+WORD = default_word_chars()
+
+ALPHABETS = [
+    [ord(c) for c in "ab"],
+    [ord(c) for c in "abc"],
+    list(range(ord("a"), ord("z") + 1)),
+    list(range(ord("a"), ord("z") + 1)) + list(range(ord("A"), ord("Z") + 1)),            # 52 classes: WIDE rows
+    [ord(c) for c in "abcABC"] + [0x00E9, 0x00C9, 0x0130, 0x4E2D],                           # LUT classes
+    list(range(0x4E00, 0x4E00 + 300)),                                                       # > 64 classes: DFA only
+    [ord(c) for c in "ab -_.,9"] + [0x00E9, 0x00C9, 0x3002],                                 # separators (WholeWord)
+]
+DEFAULTS = {"chunk_units": 0, "lds_table_bytes": 96 * 1024, "force_sparse": 0, "force_kernel": 0, "region_units": 0,
+            "rdense_budget_bytes": 256 << 20}
+
+
+def dev_match(a, d_hay, n, cap, **kw):
+    while True:
+        d_out = torch.empty((max(cap, 1), 3), dtype=torch.int32, device="cuda")
+        n_out, rc, _, ex = a.match_device(d_hay.data_ptr(), n, True, d_out.data_ptr(), cap, **kw)
+        if rc == N.E_OVERFLOW:
+            cap = n_out
+            continue
+        assert rc == N.OK, rc
+        return d_out[:n_out].cpu().numpy(), ex
+
+
+def one_case(rng, it):
+    fam = int(rng.integers(0, 3))
+    alpha = ALPHABETS[int(rng.integers(0, len(ALPHABETS)))]
+    cs = bool(rng.integers(0, 2))
+    n_kw = int(rng.integers(1, 60))
+    min_len = int(rng.integers(1, 6))
+    max_len = min_len + int(rng.integers(0, 9))
+    if fam == 2:
+        kw_alpha = [c for c in alpha if WORD[c]] or [ord("a")]
+    else:
+        kw_alpha = alpha
+    kws = [np.array(rng.choice(kw_alpha, int(rng.integers(min_len, max_len + 1))), dtype=np.uint16) for _ in range(n_kw)]
+    n = int(rng.choice([0, 1, 7, 63, 1000, 4097, 70001, 300007]))
+    hay = np.array(rng.choice(alpha, n), dtype=np.uint16) if n else np.zeros(0, np.uint16)
+    if n > 100 and rng.integers(0, 2):  # plant keywords so that deep matches occur
+        for _ in range(int(rng.integers(1, 50))):
+            k = kws[int(rng.integers(0, n_kw))]
+            p = int(rng.integers(0, n - len(k)))
+            hay[p:p + len(k)] = k
+    knobs = dict(DEFAULTS)
+    if rng.integers(0, 2):
+        knobs["force_kernel"] = int(rng.integers(0, 3))
+    if rng.integers(0, 3) == 0:
+        knobs["chunk_units"] = int(rng.choice([8, 64, 1000]))
+    if rng.integers(0, 3) == 0:
+        knobs["lds_table_bytes"] = int(rng.choice([0, 1024, 96 * 1024]))
+    if rng.integers(0, 4) == 0:
+        knobs["force_sparse"] = 1
+    if rng.integers(0, 3) == 0:
+        knobs["region_units"] = int(rng.choice([4096, 8192]))
+    if rng.integers(0, 4) == 0:
+        knobs["rdense_budget_bytes"] = 0  # hashed reversed trie
+    for k, v in knobs.items():
+        N.set_tunable(k, v)
+    mode = [N.MODE_ALL, N.MODE_LONGEST, N.MODE_WHOLEWORD][fam]
+    ofam = [FAM_AC, FAM_LONGEST, FAM_WHOLEWORD][fam]
+    wc = WORD if fam == 2 else None
+    a = Automaton(mode, kws, cs, word_chars=wc)
+    want = Oracle(ofam, kws, case_sensitive=cs, lower=LOWER, word_chars=wc).match(hay)
+    got = a.match_host(hay, True, cap=64)
+    desc = (it, fam, cs, n_kw, min_len, max_len, n, len(alpha), knobs, a.info()["filter_k"], a.info()["tile_kernel"])
+    assert got.shape == want.shape and (got == want).all(), ("host path", desc)
+    if n >= 1000:
+        # shards of the device-resident buffer
+        d_hay = torch.from_numpy(hay.view(np.int16)).cuda()
+        cuts = sorted(set([0, n] + [int(x) for x in rng.integers(1, n, 2)]))
+        parts, entry = [], 0
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            kw = dict(own=(lo, hi))
+            if fam == 1:
+                kw["chain_entry"] = max(entry, lo)
+            p, ex = dev_match(a, d_hay, n, 64, **kw)
+            entry = ex
+            parts.append(p)
+        cat = np.concatenate(parts) if parts else np.zeros((0, 3), np.int32)
+        assert cat.shape == want.shape and (cat == want).all(), ("shards", cuts, desc)
+    return fam
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+    rng = np.random.default_rng(seed)
+    t0 = time.time()
+    counts = [0, 0, 0]
+    it = 0
+    while time.time() - t0 < budget:
+        counts[one_case(rng, it)] += 1
+        it += 1
+    print("fuzz ok: %d cases (AC %d, Longest %d, WholeWord %d) in %.0f s, seed %d" % (it, *counts, time.time() - t0, seed))
+
+
+if __name__ == "__main__":
+    main()
