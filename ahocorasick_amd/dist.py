@@ -64,28 +64,42 @@ def exchange_halo(sb, group=None):
         sb.halo_view().copy_(recv.view(torch.int16))
 
 
-def allgather_matches(local, n_local, group=None):
-    """local: (cap, cols) int32 record buffer of which the first n_local rows are valid.
-    Returns (gathered (world, max_n, cols) int32, counts (world,) int64 on host)."""
+def allgather_counts(n_local, device, group=None):
+    """(world,) int64 match counts on the host."""
     rank, world = _world(group)
     if world == 1:
-        return local[:n_local].unsqueeze(0), np.array([n_local], dtype=np.int64)
-    dev = local.device
-    cnt = torch.tensor([n_local], dtype=torch.int64, device=dev)
-    counts = torch.empty(world, dtype=torch.int64, device=dev)
+        return np.array([n_local], dtype=np.int64)
+    cnt = torch.tensor([n_local], dtype=torch.int64, device=device)
+    counts = torch.empty(world, dtype=torch.int64, device=device)
     dist.all_gather_into_tensor(counts, cnt, group=group)
-    counts_h = counts.cpu().numpy()
+    return counts.cpu().numpy()
+
+
+def allgather_records(local, n_local, counts_h, group=None, async_op=False):
+    """All-gather of the record buffers, padded to the largest count.  local: (cap, cols) int32, first n_local rows
+    valid.  Returns (gathered (world, max_n, cols) int32, work handle or None)."""
+    rank, world = _world(group)
+    if world == 1:
+        return local[:n_local].unsqueeze(0), None
+    dev = local.device
     max_n = int(counts_h.max())
     cols = local.shape[1]
     if max_n == 0:
-        return torch.empty((world, 0, cols), dtype=torch.int32, device=dev), counts_h
+        return torch.empty((world, 0, cols), dtype=torch.int32, device=dev), None
     if local.shape[0] >= max_n:
         send = local[:max_n]
     else:
         send = torch.zeros((max_n, cols), dtype=torch.int32, device=dev)
         send[:n_local] = local[:n_local]
     out = torch.empty((world, max_n, cols), dtype=torch.int32, device=dev)
-    dist.all_gather_into_tensor(out.view(-1), send.contiguous().view(-1), group=group)
+    work = dist.all_gather_into_tensor(out.view(-1), send.contiguous().view(-1), group=group, async_op=async_op)
+    return out, (work if async_op else None)
+
+
+def allgather_matches(local, n_local, group=None):
+    """Counts, then records.  Returns (gathered (world, max_n, cols) int32, counts (world,) int64 on host)."""
+    counts_h = allgather_counts(n_local, local.device, group)
+    out, _ = allgather_records(local, n_local, counts_h, group)
     return out, counts_h
 
 
@@ -106,7 +120,8 @@ class ShardedMatcher:
     scan_fn (tests only) replaces the native scan so the plumbing can run under gloo on CPU:
     scan_fn(buffer_units_np, own_begin, own_end, text_begin) -> (n,cols) int32 records, buffer-relative."""
 
-    def __init__(self, automaton, n_units, with_ids=True, cap=1 << 20, device=None, group=None, scan_fn=None, halo=None):
+    def __init__(self, automaton, n_units, with_ids=True, cap=1 << 20, device=None, group=None, scan_fn=None, halo=None,
+                 overlap=False):
         self.auto = automaton
         self.group = group
         self.rank, self.world = _world(group)
@@ -118,7 +133,13 @@ class ShardedMatcher:
             device = torch.device("cuda", torch.cuda.current_device()) if scan_fn is None else torch.device("cpu")
         self.sb = ShardBuffer(n_units, halo, device)
         self.cap = int(cap)
-        self.out = torch.empty((self.cap, self.cols), dtype=torch.int32, device=device)
+        # overlap: the all-gather of step k runs (on RCCL's stream) while step k+1 scans into the other record buffer
+        self.overlap = bool(overlap) and self.world > 1
+        self.outs = [torch.empty((self.cap, self.cols), dtype=torch.int32, device=device)
+                     for _ in range(2 if self.overlap else 1)]
+        self.out = self.outs[0]
+        self._k = 0
+        self._pending = None  # (work, gathered, counts) of the all-gather still in flight
         self.scan_fn = scan_fn
         self.last_kernel = ""
         self.gathered = None
@@ -143,9 +164,9 @@ class ShardedMatcher:
                 recs = recs.copy()
                 recs[:, :2] -= sb.pad
             n = len(recs)
-            if n > self.cap:
-                self.cap = n
-                self.out = torch.empty((self.cap, self.cols), dtype=torch.int32)
+            if n > self.out.shape[0]:
+                self.cap = max(self.cap, n)
+                self.out = self.outs[self._slot] = torch.empty((self.cap, self.cols), dtype=torch.int32)
             self.out[:n] = torch.from_numpy(np.ascontiguousarray(recs[:, :self.cols], dtype=np.int32))
             return n, None
         from . import _native as N
@@ -153,15 +174,16 @@ class ShardedMatcher:
         while True:
             if first:  # the pad in front of rank 0's text is not part of the haystack
                 n, rc, prof, _ = self.auto.match_device(sb.own.data_ptr(), sb.n_units, self.with_ids, self.out.data_ptr(),
-                                                        self.cap, own=(0, sb.n_units), text_begin=True, text_end=last,
+                                                        self.out.shape[0], own=(0, sb.n_units), text_begin=True, text_end=last,
                                                         stream=stream, profile=profile)
             else:
                 n, rc, prof, _ = self.auto.match_device(sb.buf.data_ptr(), sb.pad + sb.n_units, self.with_ids,
-                                                        self.out.data_ptr(), self.cap, own=(sb.pad, sb.pad + sb.n_units),
+                                                        self.out.data_ptr(), self.out.shape[0], own=(sb.pad, sb.pad + sb.n_units),
                                                         text_begin=False, text_end=last, stream=stream, profile=profile)
             if rc == N.E_OVERFLOW:
-                self.cap = int(n * 1.25) + 16
-                self.out = torch.empty((self.cap, self.cols), dtype=torch.int32, device=self.out.device)
+                self.cap = max(self.cap, int(n * 1.25) + 16)
+                self.out = self.outs[self._slot] = torch.empty((self.cap, self.cols), dtype=torch.int32,
+                                                               device=self.out.device)
                 continue
             N.check(rc, "acgpu_match_device")
             break
@@ -172,14 +194,38 @@ class ShardedMatcher:
         return n, prof
 
     def step(self, profile=False):
-        """halo exchange -> scan -> all-gather.  Returns a dict with n_local, n_total and (profile) kernel timings."""
+        """halo exchange -> scan -> all-gather.  Returns a dict with n_local, n_total and (profile) kernel timings.
+        With overlap=True the record all-gather is left in flight; `gathered`/`counts` then describe the last
+        COMPLETED step until finish() is called."""
         exchange_halo(self.sb, self.group)
+        self._slot = self._k % len(self.outs)
+        self._k += 1
+        self.out = self.outs[self._slot]
         n, prof = self._scan(profile)
-        self.gathered, self.counts = allgather_matches(self.out, n, self.group)
-        r = {"n_local": int(n), "n_total": int(self.counts.sum()), "scan_ms": 0.0, "finalize_ms": 0.0}
+        counts = allgather_counts(n, self.out.device, self.group)
+        if self.overlap:
+            self._complete_pending()  # the other buffer's gather: makes this stream wait for it, not the host
+            gathered, work = allgather_records(self.out, n, counts, self.group, async_op=True)
+            self._pending = (work, gathered, counts)
+        else:
+            self.gathered, _ = allgather_records(self.out, n, counts, self.group)
+            self.counts = counts
+        r = {"n_local": int(n), "n_total": int(counts.sum()), "scan_ms": 0.0, "finalize_ms": 0.0}
         if prof:
             r.update(scan_ms=prof["scan_ms"], finalize_ms=prof["finalize_ms"])
         return r
+
+    def _complete_pending(self):
+        if self._pending is not None:
+            work, gathered, counts = self._pending
+            if work is not None:
+                work.wait()
+            self.gathered, self.counts = gathered, counts
+            self._pending = None
+
+    def finish(self):
+        """Completes an all-gather left in flight by step() (overlap mode); no-op otherwise."""
+        self._complete_pending()
 
     def global_records(self):
         return global_records(self.gathered, self.counts, self.sb.n_units)

@@ -70,7 +70,9 @@ def main():
     # synthetic shard, generated in place on the device
     seed = cfg["hay_seed"] + (rank if multi else 0)
     tab = np.ascontiguousarray(synth.ALPHA_LOWER)
-    matcher = ShardedMatcher(auto, n_units, with_ids=with_ids, cap=max(1 << 16, n_units // 128))
+    # N>1: the all-gather of step k overlaps the scan of step k+1 (double-buffered record buffers); every gather is
+    # complete before the timed region ends (matcher.finish() + synchronize)
+    matcher = ShardedMatcher(auto, n_units, with_ids=with_ids, cap=max(1 << 16, n_units // 128), overlap=True)
     N.check(N.lib().acgpu_synth_fill(matcher.own_ptr(), n_units, 0, seed, tab.ctypes.data_as(ctypes.c_void_p), len(tab),
                                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "synth_fill")
     torch.cuda.synchronize()
@@ -80,6 +82,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    matcher.finish()
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
@@ -90,6 +93,7 @@ def main():
         scan_ms.append(r["scan_ms"])
         fin_ms.append(r["finalize_ms"])
         n_matches_local, n_matches_total = r["n_local"], r["n_total"]
+    matcher.finish()
     torch.cuda.synchronize()
     if multi:
         dist.barrier()

@@ -19,7 +19,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_per_rank, tmpdir):
+def _worker(rank, world, port, n_per_rank, tmpdir, overlap):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -40,9 +40,11 @@ def _worker(rank, world, port, n_per_rank, tmpdir):
             r[:, :2] += lo
             return r[(r[:, 1] - 1 >= own_begin)]
 
-        m = ShardedMatcher(None, n_per_rank, with_ids=True, cap=16, scan_fn=scan_fn, halo=halo)
+        m = ShardedMatcher(None, n_per_rank, with_ids=True, cap=16, scan_fn=scan_fn, halo=halo, overlap=overlap)
         m.sb.own.copy_(torch.from_numpy(whole[rank * n_per_rank:(rank + 1) * n_per_rank].view(np.int16)))
-        r = m.step()
+        for _ in range(3):  # several steps: exercises the double-buffered, overlapped all-gather
+            r = m.step()
+        m.finish()
         got = m.global_records().numpy()
         want = orc.match(whole).astype(np.int64)
         assert r["n_total"] == len(want)
@@ -55,8 +57,8 @@ def _worker(rank, world, port, n_per_rank, tmpdir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_match_equals_whole_text(world, tmp_path):
+@pytest.mark.parametrize("world,overlap", [(2, False), (3, False), (2, True)])
+def test_sharded_match_equals_whole_text(world, overlap, tmp_path):
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, 4001, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, 4001, str(tmp_path), overlap), nprocs=world, join=True)
     assert all((tmp_path / ("ok%d" % r)).exists() for r in range(world))
