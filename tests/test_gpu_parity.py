@@ -544,3 +544,29 @@ def test_config_c5_full_size_properties():
     last = inner[inner[:, 0] >= (reps - 1) * per].copy()
     last[:, :2] -= (reps - 1) * per
     assert first.shape == last.shape and (first == last).all()
+
+
+def test_maximum_size_haystack_just_under_2_31_units():
+    """The ABI limit is the Java String limit (2^31-1 units).  A 4 GiB haystack, keyword planted in the last units."""
+    import torch
+    n = (1 << 31) - 3  # ragged: not a multiple of 8, exercises the scalar tail at the top of the 32-bit range
+    kws = synth.config_keywords("C2")
+    a = Automaton(N.MODE_ALL, kws, True)
+    d_hay = torch.empty(n + 3, dtype=torch.int16, device="cuda")[:n]
+    tab = np.ascontiguousarray(synth.ALPHA_LOWER)
+    N.check(N.lib().acgpu_synth_fill(d_hay.data_ptr(), n, 0, 4242, tab.ctypes.data_as(ctypes.c_void_p), len(tab), None), "synth")
+    k0 = kws[17]
+    d_hay[n - len(k0):] = torch.from_numpy(k0.view(np.int16)).cuda()  # a match that ends exactly at the end of the text
+    cap = 8_000_000
+    got, prof = _dev_match(a, d_hay, n, True, cap, profile=True)
+    assert 5_000_000 < len(got) < 5_700_000  # ~2.5e-3 per unit
+    end = got[:, 1].astype(np.int64)
+    assert (np.diff(end * (1 << 32) + got[:, 0]) > 0).all() and end[-1] == n and (got[:, 0] >= 0).all()
+    assert got[-1].tolist() == [n - len(k0), n, 17] or got[-1, 1] == n
+    assert any(r.tolist() == [n - len(k0), n, 17] for r in got[-4:])
+    pre = 1 << 20
+    want = Oracle(FAM_AC, kws).match(synth.haystack(4242, pre))
+    assert (got[:len(want)] == want).all()
+    # one unit more is refused, not mis-scanned
+    d_out = torch.empty((16, 3), dtype=torch.int32, device="cuda")
+    assert a.match_device(d_hay.data_ptr(), 1 << 31, True, d_out.data_ptr(), 16)[1] == N.E_INVALID
