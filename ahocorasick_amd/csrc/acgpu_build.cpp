@@ -352,7 +352,7 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
                 }
                 // rows of the filter and K-gram -> depth-K reverse node (index: last unit least significant)
                 t.filt_bits.assign(rows * (t.filt_row_bytes / 4), 0);
-                t.kgram_node.assign(rows * n, 0);
+                t.kgram_node.assign(rows * n * 2, 0); // pairs: {ref of the depth-K node, ref of its only child or 0}
                 uint64_t n_set = 0;
                 std::vector<uint32_t> path;
                 for (uint32_t i = 1; i < RN; i++) {
@@ -365,7 +365,8 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
                     const uint32_t last = path.back();
                     if (t.filt_row_bytes == 4) t.filt_bits[hi] |= 1u << last;
                     else t.filt_bits[hi * 2 + (last >> 5)] |= 1u << (last & 31);
-                    t.kgram_node[hi * n + last] = ref(i);
+                    t.kgram_node[(hi * n + last) * 2] = ref(i);
+                    t.kgram_node[(hi * n + last) * 2 + 1] = rn[i].n_child == 1 ? ref(rn[i].only_child) : 0u;
                     n_set++;
                 }
                 double denom = 1;

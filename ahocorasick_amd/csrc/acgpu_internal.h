@@ -71,7 +71,8 @@ struct HostTables {
     // bit31 = node has children, bit30 = node is terminal (a keyword starts here), bits 29..24 = only-child class hint,
     // low 24 bits = node id.
     uint32_t filt_row_bytes = 4;
-    std::vector<uint32_t> kgram_node;  // filt_n^K entries: flagged ref of the depth-K node, 0 = none
+    std::vector<uint32_t> kgram_node;  // filt_n^K pairs {flagged ref of the depth-K node (0 = none), flagged ref of its
+                                       // only child (0 = none or several)}: the common one-step walk needs no second load
     std::vector<uint32_t> rterm;       // per reverse node: keyword id (valid when the terminal flag is set)
     bool rdense = false;
     std::vector<uint32_t> rtab;        // dense: n_rstates * filt_n flagged child refs indexed by tile class (0 = none)

@@ -47,7 +47,8 @@ struct TileLaunch {
     size_t lds_bytes;
     uint32_t debug; // ablation switches (tunable "tile_debug"): 1 = drop candidates unverified, 4 = no filter arithmetic
                     // at all (stream + reduce only), 8 = verification without the text-window load, 16 = without the
-                    // K-gram node load.  Results are wrong when non-zero; 0 in production.
+                    // K-gram node load, 32 = no record emission, 64 = no walk beyond the K-gram node, 128 = records
+                    // not stored.  Results are wrong when non-zero; 0 in production.
 };
 hipError_t launch_ac_tile(const DevTables &t, const TileLaunch &l, hipStream_t stream, const char **kernel_name);
 size_t tile_lds_bytes(const DevTables &t, int block_threads);

@@ -93,7 +93,7 @@ __device__ __forceinline__ void verify_multi(TileCtx &c, uint32_t head, uint32_t
     const uint16_t *hay = L.d_hay;
     const uint32_t lane = lane_id();
     bool act[NB];
-    uint32_t e[NB], ref[NB], ref0[NB], left_unit[NB], d[NB], m[NB], one_len[NB], one_node[NB];
+    uint32_t e[NB], ref[NB], ref0[NB], child0[NB], left_unit[NB], d[NB], m[NB], one_len[NB], one_node[NB];
     Units8 win[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -123,8 +123,12 @@ __device__ __forceinline__ void verify_multi(TileCtx &c, uint32_t head, uint32_t
 #pragma unroll
         for (int j = 8 - K; j < 8; ++j) idx = __umul24(idx, T.filt_n) + tile_class_t<RANGE>(T, (win[b].d[j >> 1] >> (16 * (j & 1))) & 0xffffu);
         if (K < 8) left_unit[b] = (win[b].d[(7 - K) >> 1] >> (16 * ((7 - K) & 1))) & 0xffffu;
-        ref[b] = act[b] ? ((L.debug & 16u) ? (idx & 1u) : T.kgram_node[idx]) : 0u; // 16: ablation, no K-gram node load
-        ref0[b] = ref[b];
+        uint2 ent = make_uint2(idx & 1u, 0u); // 16: ablation, no K-gram node load
+        if (!(L.debug & 16u)) ent = act[b] ? reinterpret_cast<const uint2 *>(T.kgram_node)[idx] : make_uint2(0u, 0u);
+        if (!act[b]) ent = make_uint2(0u, 0u);
+        ref[b] = ent.x;
+        ref0[b] = ent.x;
+        child0[b] = ent.y; // the depth-K node's only child, travelling with it
     }
     // leftward walks in lock step; every terminal node met is a keyword ending at e (increasing length)
     for (;;) {
@@ -140,13 +144,17 @@ __device__ __forceinline__ void verify_multi(TileCtx &c, uint32_t head, uint32_t
             go[b] = (ref[b] & kRefHasChildren) && e[b] > d[b]; // not a leaf, and the buffer does not start here
             any_go |= go[b];
         }
-        if (!__any(any_go)) break;
+        if (!__any(any_go) || (L.debug & 64u)) break; // 64: ablation, no walk beyond the K-gram node
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             uint32_t next = 0;
             if (go[b]) {
                 const uint32_t unit = (d[b] == K && K < 8) ? left_unit[b] : (uint32_t)hay[e[b] - 1 - d[b]];
-                next = walk_step<RANGE>(T, ref[b], unit);
+                const uint32_t hint = (ref[b] >> kRefHintShift) & kRefHintMask;
+                if (d[b] == K && hint != 0) // first step from a one-child node: no memory access at all
+                    next = (hint - 1 == tile_class_t<RANGE>(T, unit)) ? child0[b] : 0u;
+                else
+                    next = walk_step<RANGE>(T, ref[b], unit);
             }
             ref[b] = next;
             ++d[b];
@@ -160,7 +168,7 @@ __device__ __forceinline__ void verify_multi(TileCtx &c, uint32_t head, uint32_t
         prefix[b] = total + incl - m[b];
         total += __builtin_amdgcn_readlane(incl, kWave - 1);
     }
-    if (total == 0) return;
+    if (total == 0 || (L.debug & 32u)) return; // 32: ablation, no record emission
     const SlotRange sr = reserve_slots(c, total);
     auto slot_of = [&](uint32_t k) -> uint32_t { return sr.slot(k); };
     bool multi = false;
@@ -311,6 +319,14 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
     for (;;) {
         const bool seam = vec_todo ? (d0 == 0 && tile >= boundary) : true; // wave-uniform
         const uint32_t keep = seam ? 1u : (uint32_t)(kVerifyBatches * kWave);
+        if (vec_todo && d0 == 0) {
+            // take over the prefetched group FIRST: this wait also covers the record stores of the previous pass's
+            // verification (gfx950 counts stores in vmcnt), which have had a whole tile group of time to finish
+#pragma unroll
+            for (int d = 0; d < kAcTiles; ++d)
+#pragma unroll
+                for (int u = 0; u < kAcVec; ++u) grp[d][u] = nxt[d][u];
+        }
         if (c.cand_n >= keep && c.cand_n != 0) drain<K, RANGE>(c, keep);
 
         if (vec_todo) {
@@ -323,10 +339,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                     boundary += R;
                     re = min(span_end, boundary);
                 }
-#pragma unroll
-                for (int d = 0; d < kAcTiles; ++d)
-#pragma unroll
-                    for (int u = 0; u < kAcVec; ++u) grp[d][u] = nxt[d][u];
+                // the next group's loads go out AFTER the verification, so that its gathers never wait for them
 #pragma unroll
                 for (int d = 0; d < kAcTiles; ++d)
 #pragma unroll

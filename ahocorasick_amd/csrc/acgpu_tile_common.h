@@ -33,7 +33,7 @@ struct TileCtx {
 
 __device__ __forceinline__ void store_rec(const TileLaunch &L, uint32_t slot, uint32_t start, uint32_t end, uint32_t id,
                                           uint32_t rank) {
-    if ((uint64_t)slot < L.cap) {
+    if ((uint64_t)slot < L.cap && !(L.debug & 128u)) { // 128: ablation, records are not stored
         const uint4 v = make_uint4(start, end, id, rank);
         *reinterpret_cast<uint4 *>(&L.d_scratch[slot]) = v;
     }
