@@ -41,7 +41,8 @@ class Profile(ctypes.Structure):
 
 
 # every symbol include/acgpu.h declares
-SYMBOLS = ["acgpu_build", "acgpu_free", "acgpu_get_info", "acgpu_match_u16", "acgpu_match_device", "acgpu_synth_fill",
+SYMBOLS = ["acgpu_build", "acgpu_free", "acgpu_get_info", "acgpu_match_u16", "acgpu_match_device",
+           "acgpu_match_device_begin", "acgpu_match_device_end", "acgpu_synth_fill",
            "acgpu_set_tunable", "acgpu_strerror", "acgpu_last_hip_error", "acgpu_abi_version", "acgpu_debug_tables"]
 
 _lib = None
@@ -74,6 +75,10 @@ def lib():
         L.acgpu_match_device.restype = ci
         L.acgpu_match_device.argtypes = [vp, ctypes.POINTER(Shard), ci, vp, u64, ctypes.POINTER(u64), vp,
                                          ctypes.POINTER(Profile)]
+        L.acgpu_match_device_begin.restype = ci
+        L.acgpu_match_device_begin.argtypes = [vp, ctypes.POINTER(Shard), ci, vp, u64, vp, ci, ctypes.POINTER(vp)]
+        L.acgpu_match_device_end.restype = ci
+        L.acgpu_match_device_end.argtypes = [vp, vp, ctypes.POINTER(u64), ctypes.POINTER(Profile)]
         L.acgpu_synth_fill.restype = ci
         L.acgpu_synth_fill.argtypes = [vp, u64, u64, u64, vp, u32, vp]
         L.acgpu_set_tunable.restype = i64

@@ -48,6 +48,17 @@ struct DevBuf {
     }
 };
 
+// One asynchronous call in flight (acgpu_match_device_begin/_end): its own events and pinned count slot.
+struct Ticket {
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t done = nullptr;
+    unsigned long long *h_count = nullptr; // pinned, 64 bytes
+    bool busy = false, profiled = false;
+    uint64_t cap = 0, scanned = 0;
+    char kname[64] = {0};
+    void *owner = nullptr; // the DeviceState it belongs to
+};
+
 struct DeviceState {
     int device = -1;
     int n_cu = 256;
@@ -58,12 +69,18 @@ struct DeviceState {
     DevBuf stage_hay, stage_out; // acgpu_match_u16 staging
     unsigned long long *h_counter = nullptr; // pinned
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    Ticket tickets[4];
     ~DeviceState() {
         for (void *p : table_allocs) (void)hipFree(p);
         counter.release(); chunk_counts.release(); offsets.release(); scan_tmp.release(); scratch.release();
         chain.release(); lenbuf.release(); statebuf.release(); stage_hay.release(); stage_out.release();
         if (h_counter) (void)hipHostFree(h_counter);
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+        for (auto &tk : tickets) {
+            for (auto &e : tk.ev) if (e) (void)hipEventDestroy(e);
+            if (tk.done) (void)hipEventDestroy(tk.done);
+            if (tk.h_count) (void)hipHostFree(tk.h_count);
+        }
     }
 };
 
@@ -158,6 +175,12 @@ int ensure_device(acgpu_automaton *a, DeviceState **out) {
     T.lds_entries = lds_states_for(t) * t.n_cls;
     HIP_TRY(hipHostMalloc((void **)&d->h_counter, 64, hipHostMallocDefault));
     for (auto &e : d->ev) HIP_TRY(hipEventCreate(&e));
+    for (auto &tk : d->tickets) {
+        for (auto &e : tk.ev) HIP_TRY(hipEventCreate(&e));
+        HIP_TRY(hipEventCreateWithFlags(&tk.done, hipEventDisableTiming));
+        HIP_TRY(hipHostMalloc((void **)&tk.h_count, 64, hipHostMallocDefault));
+        tk.owner = d.get();
+    }
     *out = d.get();
     a->dev[dev] = std::move(d);
     return ACGPU_OK;
@@ -176,9 +199,12 @@ bool use_tile_kernel(const HostTables &t) {
 }
 
 // ALL-mode pipeline on one shard.
+// With a ticket the call returns after enqueueing (no host synchronisation); acgpu_match_device_end collects it.
 int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_kind, void *d_out, uint64_t cap,
-              uint64_t *n_out, hipStream_t stream, acgpu_profile *prof) {
+              uint64_t *n_out, hipStream_t stream, acgpu_profile *prof, Ticket *tk = nullptr) {
     const HostTables &t = a->t;
+    hipEvent_t *ev = tk ? tk->ev : d.ev;
+    const bool timed = tk ? tk->profiled : prof != nullptr;
     const uint64_t own_len = sh->own_end - sh->own_begin;
     const uint32_t halo = t.max_len > 0 ? t.max_len - 1 : 0;
     if (!sh->text_begin && sh->own_begin < halo) return ACGPU_E_INVALID; // left halo too short
@@ -186,6 +212,12 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         std::memset(prof, 0, sizeof(*prof));
     }
     if (own_len == 0 || t.n_states <= 1) {
+        if (tk) {
+            *tk->h_count = 0;
+            tk->profiled = false;
+            HIP_TRY(hipEventRecord(tk->done, stream));
+            return ACGPU_OK;
+        }
         *n_out = 0;
         return ACGPU_OK;
     }
@@ -229,9 +261,9 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         L.d_counter = (unsigned long long *)d.counter.p;
         L.d_region_counts = (uint32_t *)d.chunk_counts.p;
         HIP_TRY(hipMemsetAsync(d.chunk_counts.p, 0, (size_t)L.n_regions * 4, stream));
-        if (prof) HIP_TRY(hipEventRecord(d.ev[0], stream));
+        if (timed) HIP_TRY(hipEventRecord(ev[0], stream));
         HIP_TRY(launch_ac_tile(d.T, L, stream, &kname));
-        if (prof) HIP_TRY(hipEventRecord(d.ev[1], stream));
+        if (timed) HIP_TRY(hipEventRecord(ev[1], stream));
         n_chunks = L.n_regions;
         chunk_units = L.region_units;
         scanned = own_len;
@@ -259,9 +291,9 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         L.d_scratch = (ScratchRec *)d.scratch.p;
         L.d_counter = (unsigned long long *)d.counter.p;
         L.d_chunk_counts = (uint32_t *)d.chunk_counts.p;
-        if (prof) HIP_TRY(hipEventRecord(d.ev[0], stream));
+        if (timed) HIP_TRY(hipEventRecord(ev[0], stream));
         HIP_TRY(launch_ac_scan(d.T, L, stream, &kname));
-        if (prof) HIP_TRY(hipEventRecord(d.ev[1], stream));
+        if (timed) HIP_TRY(hipEventRecord(ev[1], stream));
         n_chunks = L.n_chunks;
         chunk_units = L.chunk_units;
         scanned = own_len + (uint64_t)L.n_chunks * halo;
@@ -271,8 +303,16 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
     HIP_TRY(launch_permute((const ScratchRec *)d.scratch.p, (const unsigned long long *)d.counter.p, scratch_cap,
                            (const uint64_t *)d.offsets.p, perm_base, chunk_units,
                            /*by_start=*/0, record_kind, d_out, cap, id_map, stream));
-    if (prof) HIP_TRY(hipEventRecord(d.ev[2], stream));
+    if (timed) HIP_TRY(hipEventRecord(ev[2], stream));
     // exact record count = grand total of the per-chunk counts (the slot counter also counts reservation holes)
+    if (tk) {
+        HIP_TRY(hipMemcpyAsync(tk->h_count, (const uint64_t *)d.scan_tmp.p + scan_tiles_for(n_chunks), 8,
+                               hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipEventRecord(tk->done, stream));
+        tk->scanned = scanned;
+        std::snprintf(tk->kname, sizeof(tk->kname), "%s", kname);
+        return ACGPU_OK;
+    }
     HIP_TRY(hipMemcpyAsync(d.h_counter, (const uint64_t *)d.scan_tmp.p + scan_tiles_for(n_chunks), 8, hipMemcpyDeviceToHost,
                            stream));
     HIP_TRY(hipStreamSynchronize(stream));
@@ -617,6 +657,57 @@ int acgpu_match_device(const acgpu_automaton *ca, acgpu_shard *sh, int record_ki
     int rc = device_for_call(a, &d);
     if (rc) return rc;
     return match_shard(a, *d, sh, record_kind, d_out, cap, n_out, reinterpret_cast<hipStream_t>(stream_), prof);
+}
+
+int acgpu_match_device_begin(const acgpu_automaton *ca, acgpu_shard *sh, int record_kind, void *d_out, uint64_t cap,
+                             void *stream_, int want_profile, acgpu_ticket **ticket) {
+    if (!ca || !sh || !ticket) return ACGPU_E_INVALID;
+    *ticket = nullptr;
+    acgpu_automaton *a = const_cast<acgpu_automaton *>(ca);
+    if (a->t.mode != ACGPU_MODE_ALL) return ACGPU_E_UNSUPPORTED; // the other families use the synchronous call
+    std::lock_guard<std::mutex> lock(a->mu);
+    DeviceState *d = nullptr;
+    int rc = device_for_call(a, &d);
+    if (rc) return rc;
+    if (record_kind != ACGPU_REC_SET && record_kind != ACGPU_REC_MAP) return ACGPU_E_INVALID;
+    if (sh->n_units >= (1ull << 31) || sh->own_begin > sh->own_end || sh->own_end > sh->n_units) return ACGPU_E_INVALID;
+    if (sh->n_units && (!sh->d_hay || ((uintptr_t)sh->d_hay & 15))) return ACGPU_E_INVALID;
+    if (cap && (!d_out || ((uintptr_t)d_out & 3))) return ACGPU_E_INVALID;
+    Ticket *tk = nullptr;
+    for (auto &cand : d->tickets)
+        if (!cand.busy) { tk = &cand; break; }
+    if (!tk) return ACGPU_E_INVALID; // too many calls in flight: collect one first
+    tk->profiled = want_profile != 0;
+    tk->cap = cap;
+    uint64_t dummy = 0;
+    rc = match_all(a, *d, sh, record_kind, d_out, cap, &dummy, reinterpret_cast<hipStream_t>(stream_), nullptr, tk);
+    if (rc != ACGPU_OK) return rc;
+    tk->busy = true;
+    *ticket = reinterpret_cast<acgpu_ticket *>(tk);
+    return ACGPU_OK;
+}
+
+int acgpu_match_device_end(const acgpu_automaton *ca, acgpu_ticket *ticket, uint64_t *n_out, acgpu_profile *prof) {
+    if (!ca || !ticket || !n_out) return ACGPU_E_INVALID;
+    acgpu_automaton *a = const_cast<acgpu_automaton *>(ca);
+    Ticket *tk = reinterpret_cast<Ticket *>(ticket);
+    if (!tk->busy) return ACGPU_E_INVALID;
+    HIP_TRY(hipEventSynchronize(tk->done)); // outside the lock: other calls may be enqueued meanwhile
+    std::lock_guard<std::mutex> lock(a->mu);
+    *n_out = *tk->h_count;
+    if (prof) {
+        std::memset(prof, 0, sizeof(*prof));
+        if (tk->profiled) {
+            HIP_TRY(hipEventElapsedTime(&prof->scan_ms, tk->ev[0], tk->ev[1]));
+            HIP_TRY(hipEventElapsedTime(&prof->finalize_ms, tk->ev[1], tk->ev[2]));
+            HIP_TRY(hipEventElapsedTime(&prof->total_ms, tk->ev[0], tk->ev[2]));
+        }
+        prof->scan_units = tk->scanned;
+        prof->n_matches = *n_out;
+        std::snprintf(prof->scan_kernel, sizeof(prof->scan_kernel), "%s", tk->kname);
+    }
+    tk->busy = false;
+    return *n_out > tk->cap ? ACGPU_E_OVERFLOW : ACGPU_OK;
 }
 
 int acgpu_match_u16(const acgpu_automaton *ca, const uint16_t *haystack, uint64_t n_units, int record_kind, void *out,

@@ -135,8 +135,12 @@ class ShardedMatcher:
         self.cap = int(cap)
         # overlap: the all-gather of step k runs (on RCCL's stream) while step k+1 scans into the other record buffer
         self.overlap = bool(overlap) and self.world > 1
+        # single GPU: the same flag pipelines the calls themselves -- step k+1 is enqueued (acgpu_match_device_begin)
+        # before the count of step k is read back, so the GPU never waits for the host between steps
+        self.pipeline = bool(overlap) and self.world == 1 and scan_fn is None
+        self._ticket = None
         self.outs = [torch.empty((self.cap, self.cols), dtype=torch.int32, device=device)
-                     for _ in range(2 if self.overlap else 1)]
+                     for _ in range(2 if (self.overlap or self.pipeline) else 1)]
         self.out = self.outs[0]
         self._k = 0
         self._pending = None  # (work, gathered, counts) of the all-gather still in flight
@@ -197,6 +201,8 @@ class ShardedMatcher:
         """halo exchange -> scan -> all-gather.  Returns a dict with n_local, n_total and (profile) kernel timings.
         With overlap=True the record all-gather is left in flight; `gathered`/`counts` then describe the last
         COMPLETED step until finish() is called."""
+        if self.pipeline:
+            return self._step_pipelined(profile)
         exchange_halo(self.sb, self.group)
         self._slot = self._k % len(self.outs)
         self._k += 1
@@ -215,6 +221,45 @@ class ShardedMatcher:
             r.update(scan_ms=prof["scan_ms"], finalize_ms=prof["finalize_ms"])
         return r
 
+    def _step_pipelined(self, profile):
+        """world == 1: enqueue this step, then collect the PREVIOUS one.  Returns the previous step's result dict
+        (None for the first call); finish() returns the last one."""
+        from . import _native as N
+        sb = self.sb
+        slot = self._k % 2
+        self._k += 1
+        out = self.outs[slot]
+        tk, rc = self.auto.match_device_begin(sb.own.data_ptr(), sb.n_units, self.with_ids, out.data_ptr(), out.shape[0],
+                                              stream=torch.cuda.current_stream().cuda_stream, profile=profile)
+        N.check(rc, "acgpu_match_device_begin")
+        prev = self._collect(profile)
+        self._ticket = (tk, slot, profile)
+        return prev
+
+    def _collect(self, profile):
+        from . import _native as N
+        if self._ticket is None:
+            return None
+        tk, slot, prof_on = self._ticket
+        self._ticket = None
+        n, rc, prof = self.auto.match_device_end(tk, profile=prof_on)
+        if rc == N.E_OVERFLOW:  # rare: grow both buffers and redo that step synchronously
+            self.cap = max(self.cap, int(n * 1.25) + 16)
+            self.outs = [torch.empty((self.cap, self.cols), dtype=torch.int32, device=self.outs[0].device) for _ in self.outs]
+            self.out = self.outs[slot]
+            self._slot = slot
+            n, prof = self._scan(prof_on)
+        else:
+            N.check(rc, "acgpu_match_device_end")
+        self.out = self.outs[slot]
+        self.gathered, self.counts = self.out[:n].unsqueeze(0), np.array([n], dtype=np.int64)
+        if prof:
+            self.last_kernel = prof["scan_kernel"]
+        r = {"n_local": int(n), "n_total": int(n), "scan_ms": 0.0, "finalize_ms": 0.0}
+        if prof:
+            r.update(scan_ms=prof["scan_ms"], finalize_ms=prof["finalize_ms"])
+        return r
+
     def _complete_pending(self):
         if self._pending is not None:
             work, gathered, counts = self._pending
@@ -224,8 +269,12 @@ class ShardedMatcher:
             self._pending = None
 
     def finish(self):
-        """Completes an all-gather left in flight by step() (overlap mode); no-op otherwise."""
+        """Completes what step() left in flight: the overlapped all-gather (world > 1) or the last pipelined call
+        (world == 1; its result dict is returned)."""
+        if self.pipeline:
+            return self._collect(True)
         self._complete_pending()
+        return None
 
     def global_records(self):
         return global_records(self.gathered, self.counts, self.sb.n_units)

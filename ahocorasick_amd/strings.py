@@ -135,6 +135,33 @@ class Automaton:
         return int(n_out.value), rc, pd, int(sh.chain_exit)
 
 
+    def match_device_begin(self, d_hay_ptr, n_units, with_ids, d_out_ptr, cap, own=None, text_begin=True, text_end=True,
+                           stream=0, profile=False):
+        """acgpu_match_device_begin (AhoCorasick family): enqueue without waiting.  Returns (ticket, rc)."""
+        sh = N.Shard()
+        sh.d_hay = d_hay_ptr
+        sh.n_units = n_units
+        sh.own_begin, sh.own_end = (0, n_units) if own is None else own
+        sh.text_begin = 1 if text_begin else 0
+        sh.text_end = 1 if text_end else 0
+        sh.chain_entry = sh.own_begin
+        tk = ctypes.c_void_p()
+        rc = N.lib().acgpu_match_device_begin(self._h, ctypes.byref(sh), N.REC_MAP if with_ids else N.REC_SET, d_out_ptr, cap,
+                                              ctypes.c_void_p(stream), 1 if profile else 0, ctypes.byref(tk))
+        return tk, rc
+
+    def match_device_end(self, ticket, profile=False):
+        """acgpu_match_device_end: waits for that call only.  Returns (n_out, rc, profile_dict|None)."""
+        prof = N.Profile() if profile else None
+        n_out = ctypes.c_uint64(0)
+        rc = N.lib().acgpu_match_device_end(self._h, ticket, ctypes.byref(n_out), ctypes.byref(prof) if profile else None)
+        pd = None
+        if profile:
+            pd = dict(scan_ms=prof.scan_ms, finalize_ms=prof.finalize_ms, total_ms=prof.total_ms,
+                      scan_units=prof.scan_units, n_matches=prof.n_matches, scan_kernel=prof.scan_kernel.decode())
+        return int(n_out.value), rc, pd
+
+
 # ---- listener plumbing -----------------------------------------------------------------------------------
 
 class SetMatchListener:

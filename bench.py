@@ -86,15 +86,19 @@ def main():
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
-    scan_ms, fin_ms, n_matches_local, n_matches_total = [], [], 0, 0
+    # N=1 pipelines the calls (step k+1 is enqueued before the count of step k is read back): step() then returns the
+    # PREVIOUS step's result and finish() the last one; all K steps are complete before the clock stops
+    results = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        r = step(profile=True)
-        scan_ms.append(r["scan_ms"])
-        fin_ms.append(r["finalize_ms"])
-        n_matches_local, n_matches_total = r["n_local"], r["n_total"]
-    matcher.finish()
+        results.append(step(profile=True))
+    results.append(matcher.finish())
     torch.cuda.synchronize()
+    results = [r for r in results if r is not None]
+    assert len(results) == args.steps, (len(results), args.steps)
+    scan_ms = [r["scan_ms"] for r in results]
+    fin_ms = [r["finalize_ms"] for r in results]
+    n_matches_local, n_matches_total = results[-1]["n_local"], results[-1]["n_total"]
     if multi:
         dist.barrier()
     torch.cuda.synchronize()

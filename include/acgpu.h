@@ -168,6 +168,18 @@ int acgpu_match_device(const acgpu_automaton *a, acgpu_shard *shard, int record_
                        uint64_t *n_out, void *stream, acgpu_profile *prof);
 
 /*
+ * Asynchronous form (ACGPU_MODE_ALL): _begin enqueues the whole pipeline on `stream` and returns without waiting;
+ * _end waits for that call only (an event, not the stream) and returns its count / timings.  Up to 4 calls may be in
+ * flight per automaton and device; they must all use the SAME stream (they share the automaton's scratch pool, stream
+ * order keeps them apart).  Lets a host keep the GPU busy across calls: the next scan is queued while the previous
+ * count travels back.  want_profile != 0 records the HIP events that _end turns into acgpu_profile.
+ */
+typedef struct acgpu_ticket acgpu_ticket;
+int acgpu_match_device_begin(const acgpu_automaton *a, acgpu_shard *shard, int record_kind, void *d_out, uint64_t cap,
+                             void *stream, int want_profile, acgpu_ticket **ticket);
+int acgpu_match_device_end(const acgpu_automaton *a, acgpu_ticket *ticket, uint64_t *n_out, acgpu_profile *prof);
+
+/*
  * Synthetic haystack generator of the benchmark: unit i of the stream is
  * table[((z_i >> 32) * table_len) >> 32] with z_i = SplitMix64 output for counter
  * start_index + i of `seed` (see ahocorasick_amd/synth.py).  d_dst: device pointer.

@@ -570,3 +570,30 @@ def test_maximum_size_haystack_just_under_2_31_units():
     # one unit more is refused, not mis-scanned
     d_out = torch.empty((16, 3), dtype=torch.int32, device="cuda")
     assert a.match_device(d_hay.data_ptr(), 1 << 31, True, d_out.data_ptr(), 16)[1] == N.E_INVALID
+
+
+def test_async_begin_end_matches_synchronous_call():
+    import torch
+    kws = synth.random_keywords(11, 300, 2, 9)
+    a = Automaton(N.MODE_ALL, kws, True)
+    hays = [synth.haystack(90 + i, 200000 + 777 * i) for i in range(3)]
+    d_hays = [torch.from_numpy(h.view(np.int16)).cuda() for h in hays]
+    wants = [Oracle(FAM_AC, kws).match(h) for h in hays]
+    cap = max(len(w) for w in wants) + 8
+    outs = [torch.empty((cap, 3), dtype=torch.int32, device="cuda") for _ in hays]
+    st = torch.cuda.current_stream().cuda_stream
+    tickets = []
+    for d, o, h in zip(d_hays, outs, hays):  # three calls in flight on one stream
+        tk, rc = a.match_device_begin(d.data_ptr(), h.size, True, o.data_ptr(), cap, stream=st, profile=True)
+        assert rc == N.OK
+        tickets.append(tk)
+    for tk, o, w in zip(tickets, outs, wants):
+        n, rc, prof = a.match_device_end(tk, profile=True)
+        assert rc == N.OK and n == len(w) and prof["scan_ms"] > 0
+        assert (o[:n].cpu().numpy() == w).all()
+    # overflow is reported by _end with the exact count; LONGEST has no async form
+    tk, rc = a.match_device_begin(d_hays[0].data_ptr(), hays[0].size, True, outs[0].data_ptr(), 5, stream=st)
+    n, rc, _ = a.match_device_end(tk)
+    assert rc == N.E_OVERFLOW and n == len(wants[0])
+    lo = Automaton(N.MODE_LONGEST, kws, True)
+    assert lo.match_device_begin(d_hays[0].data_ptr(), hays[0].size, True, outs[0].data_ptr(), cap)[1] == N.E_UNSUPPORTED
