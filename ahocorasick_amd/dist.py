@@ -1,17 +1,28 @@
 """Multi-GPU sharding of one long haystack: one process per GPU (torch.distributed; backend "nccl" is RCCL over
-xGMI on ROCm, "gloo" in the CPU tests).
+xGMI on ROCm, "gloo" in the CPU tests).  SURVEY.md 8e, one row per matcher family:
 
-The AhoCorasick (all-matches) path shards naturally: rank g owns a contiguous range of the
-haystack, needs the (max_keyword_len-1) units before it (left halo, received from rank g-1), starts at the root,
-and keeps the matches whose LAST unit it owns.  Rank-local order is the reference's order, so the concatenation
-of the per-rank buffers by rank is the reference's listener-call order for the whole haystack.  The only data
-exchange steps are the tiny halo send/recv and the all-gather of the per-shard match buffers (counts first, then
-record buffers padded to the largest count); positions stay shard-local int32 in the gathered buffer and become
-global int64 positions by adding base[g] = g * units_per_rank (global_records()).
+* AhoCorasick (all matches) shards naturally: rank g owns a contiguous range of the haystack, needs the
+  (max_keyword_len-1) units before it (left halo, received from rank g-1), starts at the root, and keeps the matches
+  whose LAST unit it owns.
+* WholeWord: a word belongs to the rank that owns its FIRST unit; left context 1 unit (is the previous unit a word
+  character?), right halo max_keyword_len+1 units from rank g+1 (enough to see that a run is longer than any keyword).
+* Longest: the lengths L[pos] need a right halo of max_keyword_len-1 units and are independent per shard; the greedy
+  chain pos -> pos + max(L[pos],1) needs each shard's entry position = the previous shard's exit.  Every rank first
+  runs its chain speculatively from its own first unit (all ranks in parallel); then ONE int64 travels down the ranks
+  (send/recv, world-1 hops) and a rank whose true entry differs re-runs a short window until the true chain leaves the
+  window where the speculative one did -- from there on both are the same chain.
+
+In all three, rank-local order is the reference's order, so the concatenation of the per-rank buffers by rank is the
+reference's listener-call order for the whole haystack.  The data exchange steps are the tiny halo send/recv, the
+Longest chain hop, and the all-gather of the per-shard match buffers (counts first, then record buffers padded to the
+largest count); positions stay shard-local int32 in the gathered buffer and become global int64 positions by adding
+base[g] = g * units_per_rank (global_records()).
 """
 import numpy as np
 import torch
 import torch.distributed as dist
+
+from ._native import MODE_ALL, MODE_LONGEST, MODE_WHOLEWORD
 
 
 def _world(group=None):
@@ -25,43 +36,63 @@ def round_up8(v):
 
 
 class ShardBuffer:
-    """[ pad | own units ] on one device: `pad` = left-halo room rounded up to 8 units so that both the buffer and
-    the owned range start 16-byte aligned (the scan kernel loads 16 bytes per lane)."""
+    """[ pad | own units | right halo ] on one device: `pad` = left-halo room rounded up to 8 units so that both the
+    buffer and the owned range start 16-byte aligned (the scan kernels load 16 bytes per lane)."""
 
-    def __init__(self, n_units, halo, device):
+    def __init__(self, n_units, halo, device, right_halo=0):
         self.n_units = int(n_units)
         self.halo = int(halo)
+        self.right = int(right_halo)
         self.pad = round_up8(halo)
-        self.buf = torch.zeros(self.pad + self.n_units, dtype=torch.int16, device=device)
+        self.buf = torch.zeros(self.pad + self.n_units + self.right, dtype=torch.int16, device=device)
 
     @property
     def own(self):
-        return self.buf[self.pad:]
+        return self.buf[self.pad:self.pad + self.n_units]
 
     def halo_view(self):
         return self.buf[self.pad - self.halo:self.pad]
 
     def tail_view(self):
-        return self.buf[self.pad + self.n_units - self.halo:]
+        return self.buf[self.pad + self.n_units - self.halo:self.pad + self.n_units]
+
+    def head_view(self):
+        return self.buf[self.pad:self.pad + self.right]
+
+    def right_view(self):
+        return self.buf[self.pad + self.n_units:]
 
 
 def exchange_halo(sb, group=None):
-    """rank g sends its last `halo` units to rank g+1 and receives its left halo from rank g-1."""
+    """rank g sends its last `halo` units to rank g+1 / its first `right` units to rank g-1 and receives its left halo
+    from rank g-1 / its right halo from rank g+1."""
     rank, world = _world(group)
-    if world == 1 or sb.halo == 0:
+    if world == 1 or (sb.halo == 0 and sb.right == 0):
         return
+    if sb.n_units < max(sb.halo, sb.right):
+        raise ValueError("shard of %d units is shorter than its halo (%d, %d)" % (sb.n_units, sb.halo, sb.right))
+    dev = sb.buf.device
     ops = []
-    recv = None
+    recv_l = recv_r = None
     # bytes on the wire: RCCL has no 16-bit integer type
-    if rank + 1 < world:
-        ops.append(dist.P2POp(dist.isend, sb.tail_view().contiguous().view(torch.uint8), rank + 1, group))
-    if rank > 0:
-        recv = torch.empty(2 * sb.halo, dtype=torch.uint8, device=sb.buf.device)
-        ops.append(dist.P2POp(dist.irecv, recv, rank - 1, group))
+    if sb.halo:
+        if rank + 1 < world:
+            ops.append(dist.P2POp(dist.isend, sb.tail_view().contiguous().view(torch.uint8), rank + 1, group))
+        if rank > 0:
+            recv_l = torch.empty(2 * sb.halo, dtype=torch.uint8, device=dev)
+            ops.append(dist.P2POp(dist.irecv, recv_l, rank - 1, group))
+    if sb.right:
+        if rank > 0:
+            ops.append(dist.P2POp(dist.isend, sb.head_view().contiguous().view(torch.uint8), rank - 1, group))
+        if rank + 1 < world:
+            recv_r = torch.empty(2 * sb.right, dtype=torch.uint8, device=dev)
+            ops.append(dist.P2POp(dist.irecv, recv_r, rank + 1, group))
     for w in dist.batch_isend_irecv(ops):
         w.wait()
-    if recv is not None:
-        sb.halo_view().copy_(recv.view(torch.int16))
+    if recv_l is not None:
+        sb.halo_view().copy_(recv_l.view(torch.int16))
+    if recv_r is not None:
+        sb.right_view().copy_(recv_r.view(torch.int16))
 
 
 def allgather_counts(n_local, device, group=None):
@@ -114,40 +145,53 @@ def global_records(gathered, counts, units_per_rank):
 
 
 class ShardedMatcher:
-    """One rank's end of the sharded AhoCorasick match: device-resident shard, halo exchange, native scan
-    (acgpu_match_device), all-gather of match buffers.
+    """One rank's end of the sharded match of one long haystack: device-resident shard, halo exchange, native scan
+    (acgpu_match_device), [Longest: chain hop], all-gather of match buffers.
 
-    scan_fn (tests only) replaces the native scan so the plumbing can run under gloo on CPU:
-    scan_fn(buffer_units_np, own_begin, own_end, text_begin) -> (n,cols) int32 records, buffer-relative."""
+    scan_fn (tests only) replaces the native scan so the plumbing can run under gloo on CPU; it has the contract of
+    acgpu_match_device on one shard:
+    scan_fn(view_units_np, own_begin, own_end, text_begin, text_end, chain_entry) -> ((n,cols) int32 records relative
+    to the view, chain_exit)."""
 
     def __init__(self, automaton, n_units, with_ids=True, cap=1 << 20, device=None, group=None, scan_fn=None, halo=None,
-                 overlap=False):
+                 overlap=False, mode=None, right_halo=None):
         self.auto = automaton
         self.group = group
         self.rank, self.world = _world(group)
         self.with_ids = with_ids
         self.cols = 3 if with_ids else 2
-        if halo is None:
-            halo = max(0, automaton.info()["max_keyword_len"] - 1)
+        self.mode = automaton.mode if automaton is not None else (MODE_ALL if mode is None else mode)
+        if halo is None or (right_halo is None and self.mode != MODE_ALL):
+            max_len = automaton.info()["max_keyword_len"]
+            if self.mode == MODE_ALL:
+                halo, right_halo = max(0, max_len - 1), 0
+            elif self.mode == MODE_WHOLEWORD:
+                halo, right_halo = 1, max_len + 1
+            else:
+                halo, right_halo = 0, max(0, max_len - 1)
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if scan_fn is None else torch.device("cpu")
-        self.sb = ShardBuffer(n_units, halo, device)
+        self.sb = ShardBuffer(n_units, halo, device, right_halo or 0)
         self.cap = int(cap)
         # overlap: the all-gather of step k runs (on RCCL's stream) while step k+1 scans into the other record buffer
         self.overlap = bool(overlap) and self.world > 1
         # single GPU: the same flag pipelines the calls themselves -- step k+1 is enqueued (acgpu_match_device_begin)
         # before the count of step k is read back, so the GPU never waits for the host between steps
-        self.pipeline = bool(overlap) and self.world == 1 and scan_fn is None
+        self.pipeline = bool(overlap) and self.world == 1 and scan_fn is None and self.mode == MODE_ALL
         self._ticket = None
         self.outs = [torch.empty((self.cap, self.cols), dtype=torch.int32, device=device)
                      for _ in range(2 if (self.overlap or self.pipeline) else 1)]
         self.out = self.outs[0]
+        self._slot = 0
+        self._tmp = None  # Longest: records of the repair window
         self._k = 0
         self._pending = None  # (work, gathered, counts) of the all-gather still in flight
         self.scan_fn = scan_fn
         self.last_kernel = ""
         self.gathered = None
         self.counts = None
+        self.chain_repairs = 0  # Longest: window re-runs of the last step (0 = speculation was right)
+        self.chain_window = 4096  # Longest: first repair window in units (x4 until the chains meet)
 
     def own_ptr(self):
         return self.sb.own.data_ptr()
@@ -156,45 +200,107 @@ class ShardedMatcher:
         v = self.sb.own if k is None else self.sb.own[:k]
         return v.cpu().numpy().view(np.uint16)
 
-    def _scan(self, profile):
+    # ---- one native call on (part of) the shard --------------------------------------------------------------
+    def _grow(self, which, need):
+        cap = max(self.cap, int(need * 1.25) + 16)
+        t = torch.empty((cap, self.cols), dtype=torch.int32, device=self.sb.buf.device)
+        if which == "out":
+            self.cap = cap
+            self.out = self.outs[self._slot] = t
+        else:
+            self._tmp = t
+        return t
+
+    def _call(self, which, own_lo, own_hi, entry, profile=False):
+        """Scan the owned sub-range [own_lo, own_hi) (shard-relative) of this rank's buffer into self.out / self._tmp.
+        Records come back shard-relative.  Returns (n, chain_exit (shard-relative), profile dict | None)."""
         sb = self.sb
         first = self.rank == 0
         last = self.rank == self.world - 1
+        v0 = sb.pad if first else 0  # the pad in front of rank 0's text is not part of the haystack
+        v1 = sb.pad + sb.n_units + (0 if last else sb.right)
+        shift = sb.pad - v0  # view position of shard position 0
+        buf = self.out if which == "out" else self._tmp
+        if buf is None:
+            buf = self._grow(which, 1024)
         if self.scan_fn is not None:
-            if first:
-                recs = self.scan_fn(sb.own.numpy().view(np.uint16), 0, sb.n_units, True)
-            else:
-                recs = self.scan_fn(sb.buf.numpy().view(np.uint16), sb.pad, sb.pad + sb.n_units, False)
-                recs = recs.copy()
-                recs[:, :2] -= sb.pad
+            recs, ex = self.scan_fn(sb.buf[v0:v1].numpy().view(np.uint16), own_lo + shift, own_hi + shift, first, last,
+                                    entry + shift)
             n = len(recs)
-            if n > self.out.shape[0]:
-                self.cap = max(self.cap, n)
-                self.out = self.outs[self._slot] = torch.empty((self.cap, self.cols), dtype=torch.int32)
-            self.out[:n] = torch.from_numpy(np.ascontiguousarray(recs[:, :self.cols], dtype=np.int32))
-            return n, None
+            if n > buf.shape[0]:
+                buf = self._grow(which, n)
+            if n:
+                r = np.ascontiguousarray(recs[:, :self.cols], dtype=np.int32).copy()
+                r[:, :2] -= shift
+                buf[:n] = torch.from_numpy(r)
+            return n, int(ex) - shift, None
         from . import _native as N
         stream = torch.cuda.current_stream().cuda_stream
         while True:
-            if first:  # the pad in front of rank 0's text is not part of the haystack
-                n, rc, prof, _ = self.auto.match_device(sb.own.data_ptr(), sb.n_units, self.with_ids, self.out.data_ptr(),
-                                                        self.out.shape[0], own=(0, sb.n_units), text_begin=True, text_end=last,
-                                                        stream=stream, profile=profile)
-            else:
-                n, rc, prof, _ = self.auto.match_device(sb.buf.data_ptr(), sb.pad + sb.n_units, self.with_ids,
-                                                        self.out.data_ptr(), self.out.shape[0], own=(sb.pad, sb.pad + sb.n_units),
-                                                        text_begin=False, text_end=last, stream=stream, profile=profile)
+            n, rc, prof, ex = self.auto.match_device(sb.buf.data_ptr() + 2 * v0, v1 - v0, self.with_ids, buf.data_ptr(),
+                                                     buf.shape[0], own=(own_lo + shift, own_hi + shift), text_begin=first,
+                                                     text_end=last, chain_entry=entry + shift, stream=stream, profile=profile)
             if rc == N.E_OVERFLOW:
-                self.cap = max(self.cap, int(n * 1.25) + 16)
-                self.out = self.outs[self._slot] = torch.empty((self.cap, self.cols), dtype=torch.int32,
-                                                               device=self.out.device)
+                buf = self._grow(which, n)
                 continue
             N.check(rc, "acgpu_match_device")
             break
-        if not first and n:
-            self.out[:n, :2] -= sb.pad  # buffer-relative -> shard-relative
+        if shift and n:
+            buf[:n, :2] -= shift  # view-relative -> shard-relative
         if prof:
             self.last_kernel = prof["scan_kernel"]
+        return n, ex - shift, prof
+
+    def _scan(self, profile):
+        if self.mode == MODE_LONGEST:
+            return self._scan_longest(profile)
+        n, _, prof = self._call("out", 0, self.sb.n_units, 0, profile)
+        return n, prof
+
+    # ---- Longest: speculative chain + one int64 down the ranks -----------------------------------------------
+    def _chain_hop_recv(self):
+        if self.rank == 0:
+            return 0
+        t = torch.empty(1, dtype=torch.int64, device=self.sb.buf.device)
+        dist.recv(t, self.rank - 1, group=self.group)
+        return int(t.item()) - self.rank * self.sb.n_units  # global -> shard-relative
+
+    def _chain_hop_send(self, exit_pos):
+        if self.rank + 1 < self.world:
+            t = torch.tensor([exit_pos + self.rank * self.sb.n_units], dtype=torch.int64, device=self.sb.buf.device)
+            dist.send(t, self.rank + 1, group=self.group)
+
+    def _scan_longest(self, profile):
+        n_own = self.sb.n_units
+        n, ex, prof = self._call("out", 0, n_own, 0, profile)  # speculation: the chain enters at my first unit
+        entry = self._chain_hop_recv()  # true entry >= 0: the previous rank's exit
+        self.chain_repairs = 0
+        if entry != 0:
+            spec = self.out
+            starts = spec[:n, 0].contiguous()
+            w = int(self.chain_window)
+            while True:
+                w_end = min(w, n_own)
+                self.chain_repairs += 1
+                n_t, ex_t, _ = self._call("tmp", 0, w_end, entry)
+                if w_end == n_own:  # the window is the whole shard: nothing of the speculation is kept
+                    idx, ex_s = n, ex_t
+                else:
+                    # where the speculative chain leaves the window: max(w_end, end of its last match starting inside)
+                    idx = int(torch.searchsorted(starts, torch.tensor([w_end], dtype=torch.int32, device=starts.device)).item())
+                    ex_s = max(w_end, int(spec[idx - 1, 1].item())) if idx else w_end
+                if w_end == n_own or ex_t == ex_s:
+                    tail = spec[idx:n].clone()
+                    if n_t + len(tail) > self.out.shape[0]:
+                        self._grow("out", n_t + len(tail))
+                    self.out[:n_t] = self._tmp[:n_t]
+                    self.out[n_t:n_t + len(tail)] = tail
+                    n = n_t + len(tail)
+                    if w_end == n_own:
+                        ex = ex_t
+                    break
+                w *= 4
+        self._chain_hop_send(ex)
         return n, prof
 
     def step(self, profile=False):

@@ -1,4 +1,5 @@
-"""world_size-2 (and 3) gloo tests of the sharding plumbing on CPU: halo exchange + all-gather of match buffers.
+"""world_size-2 (3, 4) gloo tests of the sharding plumbing on CPU for the three matcher families: halo exchange (left
+and right), the Longest chain hop with speculation + window repair, and the all-gather of match buffers.
 The native scan needs a GPU, so the scan step is stood in for by the CPU oracle here (test infrastructure); the
 GPU tests cover the same shard/halo contract through acgpu_match_device (test_device_entry_and_shard_split_invariance)."""
 import os
@@ -19,28 +20,59 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_per_rank, tmpdir, overlap):
+def _worker(rank, world, port, n_per_rank, tmpdir, overlap, family):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from ahocorasick_amd import synth
+        from ahocorasick_amd._native import MODE_ALL, MODE_LONGEST, MODE_WHOLEWORD
         from ahocorasick_amd.dist import ShardedMatcher
-        from oracle.oracle import FAM_AC, Oracle
+        from ahocorasick_amd.unicode_tables import default_word_chars
+        from oracle.oracle import FAM_AC, FAM_LONGEST, FAM_WHOLEWORD, Oracle
 
-        kws = synth.random_keywords(5, 200, 2, 9, table=synth.ALPHA_LOWER[:6])
-        halo = max(len(k) for k in kws) - 1
-        whole = synth.haystack(99, n_per_rank * world, table=synth.ALPHA_LOWER[:6])
-        orc = Oracle(FAM_AC, kws)
+        if family == "ww":
+            table = np.array([ord(c) for c in "abc ,"], dtype=np.uint16)
+            kws = synth.random_keywords(5, 60, 1, 6, table=table[:3])
+            whole = synth.haystack(99, n_per_rank * world, table=table)
+            orc = Oracle(FAM_WHOLEWORD, kws, word_chars=default_word_chars())
+        else:
+            table = synth.ALPHA_LOWER[:6] if family == "ac" else synth.ALPHA_LOWER[:2]
+            kws = synth.random_keywords(5, 200, 2, 9, table=table)
+            whole = synth.haystack(99, n_per_rank * world, table=table)
+            orc = Oracle(FAM_AC if family == "ac" else FAM_LONGEST, kws)
+        max_len = max(len(k) for k in kws)
 
-        def scan_fn(buf, own_begin, own_end, text_begin):
-            # what acgpu_match_device does on one shard: scan from the halo, keep matches whose last unit is owned
-            lo = 0 if text_begin else own_begin - halo
-            r = orc.match(buf[lo:own_end])
+        # stand-ins with the contract of acgpu_match_device on one shard (include/acgpu.h, acgpu_shard)
+        def scan_ac(view, ob, oe, text_begin, text_end, entry):
+            lo = 0 if text_begin else ob - (max_len - 1)  # scan from the halo, keep matches whose last unit is owned
+            r = orc.match(view[lo:oe])
             r[:, :2] += lo
-            return r[(r[:, 1] - 1 >= own_begin)]
+            return r[(r[:, 1] - 1 >= ob)], -1
 
-        m = ShardedMatcher(None, n_per_rank, with_ids=True, cap=16, scan_fn=scan_fn, halo=halo, overlap=overlap)
+        def scan_ww(view, ob, oe, text_begin, text_end, entry):
+            lo = max(ob - 1, 0)  # one unit of left context; a word belongs to the shard that owns its first unit
+            hi = len(view) if text_end else min(len(view), oe + max_len + 1)
+            r = orc.match(view[lo:hi])
+            r[:, :2] += lo
+            return r[(r[:, 0] >= ob) & (r[:, 0] < oe)], -1
+
+        def scan_longest(view, ob, oe, text_begin, text_end, entry):
+            if entry >= oe:
+                return np.zeros((0, 3), np.int32), entry
+            hi = len(view) if text_end else min(len(view), oe + max_len - 1)
+            r = orc.match(view[entry:hi])  # the greedy chain entered at `entry`
+            r[:, :2] += entry
+            r = r[r[:, 0] < oe]
+            ex = max(oe, int(r[-1, 1])) if len(r) else oe
+            return r, ex
+
+        mode, scan_fn, halo, right = {"ac": (MODE_ALL, scan_ac, max_len - 1, 0),
+                                      "ww": (MODE_WHOLEWORD, scan_ww, 1, max_len + 1),
+                                      "longest": (MODE_LONGEST, scan_longest, 0, max_len - 1)}[family]
+        m = ShardedMatcher(None, n_per_rank, with_ids=True, cap=16, scan_fn=scan_fn, halo=halo, right_halo=right,
+                           overlap=overlap, mode=mode)
+        m.chain_window = 16  # Longest: small first repair window so that the convergence test is exercised
         m.sb.own.copy_(torch.from_numpy(whole[rank * n_per_rank:(rank + 1) * n_per_rank].view(np.int16)))
         for _ in range(3):  # several steps: exercises the double-buffered, overlapped all-gather
             r = m.step()
@@ -49,16 +81,24 @@ def _worker(rank, world, port, n_per_rank, tmpdir, overlap):
         want = orc.match(whole).astype(np.int64)
         assert r["n_total"] == len(want)
         assert got.shape == want.shape and (got == want).all()
-        # halo really came from the left neighbour
-        if rank > 0:
+        # halos really came from the neighbours
+        if rank > 0 and halo:
             assert (m.sb.halo_view().numpy().view(np.uint16) == whole[rank * n_per_rank - halo:rank * n_per_rank]).all()
-        open(os.path.join(tmpdir, "ok%d" % rank), "w").write("ok")
+        if rank + 1 < world and right:
+            assert (m.sb.right_view().numpy().view(np.uint16) == whole[(rank + 1) * n_per_rank:(rank + 1) * n_per_rank + right]).all()
+        open(os.path.join(tmpdir, "ok%d" % rank), "w").write("ok %d" % m.chain_repairs)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,overlap", [(2, False), (3, False), (2, True)])
-def test_sharded_match_equals_whole_text(world, overlap, tmp_path):
+@pytest.mark.parametrize("world,overlap,family", [(2, False, "ac"), (3, False, "ac"), (2, True, "ac"), (2, False, "ww"),
+                                                  (3, True, "ww"), (2, False, "longest"), (3, False, "longest"),
+                                                  (4, True, "longest")])
+def test_sharded_match_equals_whole_text(world, overlap, family, tmp_path):
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, 4001, str(tmp_path), overlap), nprocs=world, join=True)
-    assert all((tmp_path / ("ok%d" % r)).exists() for r in range(world))
+    n_per_rank = 4001 if family != "longest" else 1003
+    mp.spawn(_worker, args=(world, port, n_per_rank, str(tmp_path), overlap, family), nprocs=world, join=True)
+    oks = [(tmp_path / ("ok%d" % r)) for r in range(world)]
+    assert all(p.exists() for p in oks)
+    if family == "longest":  # at least one shard boundary falls inside a match, so the repair path ran
+        assert sum(int(p.read_text().split()[1]) for p in oks) > 0

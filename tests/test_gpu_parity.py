@@ -597,3 +597,59 @@ def test_async_begin_end_matches_synchronous_call():
     assert rc == N.E_OVERFLOW and n == len(wants[0])
     lo = Automaton(N.MODE_LONGEST, kws, True)
     assert lo.match_device_begin(d_hays[0].data_ptr(), hays[0].size, True, outs[0].data_ptr(), cap)[1] == N.E_UNSUPPORTED
+
+
+# ---- ShardedMatcher (ahocorasick_amd/dist.py) through the native scan: the ranks of one job emulated in one process ----
+
+def _emulated_ranks(auto, whole, world, chain_window=4096):
+    """What `world` ranks of ShardedMatcher.step() compute, minus the collectives: halos filled from the whole text,
+    the Longest chain hop handed over in Python.  Returns the concatenation with global positions + repair count."""
+    import torch
+    from ahocorasick_amd.dist import ShardedMatcher
+    n = whole.size // world
+    d_whole = torch.from_numpy(whole.view(np.int16)).cuda()
+    box = [0]
+    parts, repairs = [], 0
+    for g in range(world):
+        m = ShardedMatcher(auto, n, with_ids=True, cap=64)
+        m.rank, m.world = g, world
+        m.chain_window = chain_window
+        sb = m.sb
+        sb.own.copy_(d_whole[g * n:(g + 1) * n])
+        if g > 0 and sb.halo:
+            sb.halo_view().copy_(d_whole[g * n - sb.halo:g * n])
+        if g + 1 < world and sb.right:
+            sb.right_view().copy_(d_whole[(g + 1) * n:(g + 1) * n + sb.right])
+        m._chain_hop_recv = lambda g=g: box[0] - g * n if g else 0
+        m._chain_hop_send = lambda ex, g=g: box.__setitem__(0, ex + g * n)
+        cnt, _ = m._scan(False)
+        r = m.out[:cnt].cpu().numpy().astype(np.int64)
+        r[:, :2] += g * n
+        parts.append(r)
+        repairs += m.chain_repairs
+    return np.concatenate(parts), repairs
+
+
+@pytest.mark.parametrize("family", ["ac", "longest", "wholeword"])
+def test_sharded_matcher_native_scan_equals_whole_text(family):
+    world, n = 4, 50000
+    if family == "wholeword":
+        table = np.array([ord(c) for c in "abcdE -,"] + [0x00E9, 0x00C9], dtype=np.uint16)
+        kws = synth.random_keywords(31, 300, 1, 6, table=table[:5])
+        whole = synth.haystack(41, world * n, table=table)
+        auto = Automaton(N.MODE_WHOLEWORD, kws, False, word_chars=WORD)
+        want = Oracle(FAM_WHOLEWORD, kws, case_sensitive=False, lower=LOWER, word_chars=WORD).match(whole)
+    elif family == "longest":
+        kws = synth.random_keywords(32, 300, 2, 40, table=synth.ALPHA_LOWER[:2])
+        whole = synth.haystack(42, world * n, table=synth.ALPHA_LOWER[:2])
+        auto = Automaton(N.MODE_LONGEST, kws, True)
+        want = Oracle(FAM_LONGEST, kws).match(whole)
+    else:
+        kws = synth.random_keywords(33, 500, 2, 11, table=synth.ALPHA_LOWER[:8])
+        whole = synth.haystack(43, world * n, table=synth.ALPHA_LOWER[:8])
+        auto = Automaton(N.MODE_ALL, kws, True)
+        want = Oracle(FAM_AC, kws).match(whole)
+    got, repairs = _emulated_ranks(auto, whole, world, chain_window=32)
+    assert got.shape == want.shape and (got == want.astype(np.int64)).all()
+    if family == "longest":
+        assert repairs > 0  # some shard boundary fell inside a match: the window repair ran on the device
