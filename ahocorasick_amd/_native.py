@@ -43,7 +43,8 @@ class Profile(ctypes.Structure):
 # every symbol include/acgpu.h declares
 SYMBOLS = ["acgpu_build", "acgpu_free", "acgpu_get_info", "acgpu_match_u16", "acgpu_match_device",
            "acgpu_match_device_begin", "acgpu_match_device_end", "acgpu_synth_fill",
-           "acgpu_set_tunable", "acgpu_strerror", "acgpu_last_hip_error", "acgpu_abi_version", "acgpu_debug_tables"]
+           "acgpu_set_tunable", "acgpu_strerror", "acgpu_last_hip_error", "acgpu_abi_version", "acgpu_debug_tables",
+           "acgpu_debug_wordhash"]
 
 _lib = None
 
@@ -89,6 +90,8 @@ def lib():
         L.acgpu_abi_version.restype = u32
         L.acgpu_debug_tables.restype = ci
         L.acgpu_debug_tables.argtypes = [vp, vp, vp, vp, vp, vp, vp, ctypes.POINTER(u32)]
+        L.acgpu_debug_wordhash.restype = ci
+        L.acgpu_debug_wordhash.argtypes = [vp, ctypes.POINTER(u32), vp, ctypes.POINTER(u64), vp, vp, ctypes.POINTER(u32), vp]
         _lib = L
     return _lib
 

@@ -166,6 +166,11 @@ int ensure_device(acgpu_automaton *a, DeviceState **out) {
     T.rdense = t.rdense;
     if ((rc = upload(*d, t.rhkeys, &T.rhkeys))) return rc;
     if ((rc = upload(*d, t.rhvals, &T.rhvals))) return rc;
+    if ((rc = upload(*d, t.ww_slots, &T.ww_slots))) return rc;
+    if ((rc = upload(*d, t.ww_recs, &T.ww_recs))) return rc;
+    if ((rc = upload(*d, t.fold_pgidx, &T.fold_pgidx))) return rc;
+    if ((rc = upload(*d, t.fold_pages, &T.fold_pages))) return rc;
+    T.ww_mask = t.ww_mask; T.fold_n_pages = t.fold_n_pages;
     T.rhmask = t.rhmask; T.filt_k = t.filt_k; T.filt_n = t.filt_n; T.filt_other = t.filt_other;
     T.filt_words = (uint32_t)t.filt_bits.size(); T.filt_row_bytes = t.filt_row_bytes;
     T.hmask = t.hmask;
@@ -471,8 +476,8 @@ int match_wholeword(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int rec
     L.own_begin = (uint32_t)sh->own_begin;
     L.own_end = (uint32_t)sh->own_end;
     L.cap = scratch_cap;
-    L.lds_bytes = ww_lds_bytes(L.block);
-    L.debug = 0;
+    L.lds_bytes = ww_lds_bytes(L.block, ww_fold_pages_in_lds(d.T));
+    L.debug = (uint32_t)tunables().tile_debug | (tunables().force_kernel == 1 ? 256u : 0u); // 256: trie-walk verification
     if ((rc = d.chunk_counts.ensure((size_t)L.n_regions * 4))) return rc;
     if ((rc = d.offsets.ensure((size_t)L.n_regions * 8))) return rc;
     if ((rc = d.scan_tmp.ensure(((size_t)L.n_regions / 2048 + 2) * 8))) return rc;
@@ -645,6 +650,21 @@ int acgpu_debug_tables(const acgpu_automaton *a, uint16_t *cls_lut, uint32_t *df
     if (out_id) std::memcpy(out_id, t.out_id.data(), t.n_states * sizeof(uint32_t));
     if (depth) std::memcpy(depth, t.depth.data(), t.n_states * sizeof(uint32_t));
     if (first_out_state) *first_out_state = t.first_out;
+    return ACGPU_OK;
+}
+
+int acgpu_debug_wordhash(const acgpu_automaton *a, uint32_t *n_slots, uint32_t *slots, uint64_t *n_rec_words, uint32_t *recs,
+                         uint8_t *fold_pgidx, uint32_t *n_pages, uint16_t *fold_pages) {
+    if (!a) return ACGPU_E_INVALID;
+    const HostTables &t = a->t;
+    if (t.mode != ACGPU_MODE_WHOLEWORD) return ACGPU_E_UNSUPPORTED;
+    if (n_slots) *n_slots = (uint32_t)(t.ww_slots.size() / 2);
+    if (slots) std::memcpy(slots, t.ww_slots.data(), t.ww_slots.size() * sizeof(uint32_t));
+    if (n_rec_words) *n_rec_words = t.ww_recs.size();
+    if (recs) std::memcpy(recs, t.ww_recs.data(), t.ww_recs.size() * sizeof(uint32_t));
+    if (fold_pgidx) std::memcpy(fold_pgidx, t.fold_pgidx.data(), 256);
+    if (n_pages) *n_pages = t.fold_n_pages;
+    if (fold_pages) std::memcpy(fold_pages, t.fold_pages.data(), t.fold_pages.size() * sizeof(uint16_t));
     return ACGPU_OK;
 }
 

@@ -205,6 +205,51 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
         }
     }
 
+    // ---- 5b. WholeWord: hash table of whole folded keywords + paged fold table ----
+    if (mode == ACGPU_MODE_WHOLEWORD) {
+        uint64_t cap = 16;
+        while (cap < 2 * (uint64_t)n_terminal + 2) cap <<= 1;
+        t.ww_slots.assign(2 * cap, kWwEmpty);
+        t.ww_mask = (uint32_t)(cap - 1);
+        std::vector<uint16_t> word;
+        for (uint32_t s = 1; s < N; s++) {
+            if (nodes[s].kw == ~0u) continue;
+            const uint32_t len = nodes[s].depth;
+            word.resize(len);
+            for (uint32_t n = s, i = len; n != 0; n = nodes[n].parent) word[--i] = nodes[n].unit;
+            uint32_t h = kWwHashSeed;
+            for (uint32_t i = 0; i < len; i++) h = ww_hash_step(h, word[i]);
+            const uint64_t off16 = t.ww_recs.size() / 4;
+            if (off16 >= kWwEmpty) return ACGPU_E_UNSUPPORTED;
+            const size_t words = 2 + (len + 1) / 2;
+            t.ww_recs.resize(t.ww_recs.size() + (words + 3) / 4 * 4, 0u);
+            uint32_t *rec = &t.ww_recs[off16 * 4];
+            rec[0] = nodes[s].kw;
+            rec[1] = len;
+            for (uint32_t i = 0; i < len; i++) rec[2 + (i >> 1)] |= (uint32_t)word[i] << (16 * (i & 1));
+            uint32_t slot = ww_hash_slot(h, t.ww_mask);
+            while (t.ww_slots[2 * slot + 1] != kWwEmpty) slot = (slot + 1) & t.ww_mask;
+            t.ww_slots[2 * slot] = h;
+            t.ww_slots[2 * slot + 1] = (uint32_t)off16;
+        }
+        t.ww_recs.resize(t.ww_recs.size() + 8, 0u); // the compare may read one 16-byte group past a short record
+        t.fold_pgidx.assign(256, 0);
+        t.fold_pages.clear();
+        t.fold_n_pages = 0;
+        for (uint32_t pg = 0; pg < 256; pg++) {
+            uint16_t delta[256];
+            for (uint32_t i = 0; i < 256; i++) delta[i] = (uint16_t)(t.lower[pg * 256 + i] - (pg * 256 + i));
+            uint32_t found = t.fold_n_pages;
+            for (uint32_t q = 0; q < t.fold_n_pages; q++)
+                if (!std::memcmp(&t.fold_pages[q * 256], delta, sizeof(delta))) { found = q; break; }
+            if (found == t.fold_n_pages) {
+                t.fold_pages.insert(t.fold_pages.end(), delta, delta + 256);
+                t.fold_n_pages++;
+            }
+            t.fold_pgidx[pg] = (uint8_t)found; // at most 256 distinct pages
+        }
+    }
+
     // ---- 6. character classes + dense delta table (AC/LONGEST only) ----
     t.cls_lut.assign(65536, 0);
     t.n_cls = 1;

@@ -29,6 +29,11 @@ ACGPU_HD inline uint32_t edge_hash(uint64_t key) {
 }
 ACGPU_HD inline uint64_t edge_key(uint32_t state, uint32_t unit) { return ((uint64_t)state << 16) | (uint64_t)unit; }
 
+// WholeWord: FNV-1a over the folded units of a whole word, identical on host and device.
+constexpr uint32_t kWwHashSeed = 0x811C9DC5u, kWwHashPrime = 0x01000193u, kWwEmpty = 0xffffffffu;
+ACGPU_HD inline uint32_t ww_hash_step(uint32_t h, uint32_t folded_unit) { return (h ^ folded_unit) * kWwHashPrime; }
+ACGPU_HD inline uint32_t ww_hash_slot(uint32_t h, uint32_t mask) { return (h ^ (h >> 15)) & mask; }
+
 // Host-side automaton tables.  State numbering: root = 0; states WITHOUT any output (own or inherited
 // keyword) come first in BFS order, states WITH output after them in BFS order, so that
 // "state >= first_out" is the has-output test and a prefix of the numbering is the shallow, hot part.
@@ -80,6 +85,18 @@ struct HostTables {
     std::vector<uint32_t> rhvals;
     uint32_t rhmask = 0;
     uint32_t n_rstates = 0;
+    // ---- WholeWord: hash table of whole (folded) keywords + paged fold table ----
+    // A maximal run of word characters matches iff its folded text IS a keyword, so the run is hashed once and looked
+    // up: ww_slots = open-addressing table of {hash, record offset in 16-byte units} (kWwEmpty = free), linear probing;
+    // ww_recs = records {u32 keyword id, u32 length, folded units packed 2 per u32, zero padded}, each 16-byte aligned,
+    // against which a hash hit is compared unit for unit (exact).
+    std::vector<uint32_t> ww_slots; // 2 u32 per slot
+    uint32_t ww_mask = 0;
+    std::vector<uint32_t> ww_recs;
+    // fold table as pages of 256 deltas (lower[u] - u mod 2^16), identical pages shared: fits LDS for real tables
+    std::vector<uint8_t> fold_pgidx;   // 256
+    std::vector<uint16_t> fold_pages;  // fold_n_pages * 256
+    uint32_t fold_n_pages = 0;
 };
 
 int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uint32_t n_kw, int case_sensitive,
@@ -105,6 +122,13 @@ struct DevTables {
     const uint32_t *rhvals;
     uint32_t rhmask, filt_k, filt_n, filt_other, filt_words, filt_row_bytes;
     int32_t rdense;
+    // WholeWord word hash
+    const uint32_t *ww_slots; // uint2 per slot
+    const uint32_t *ww_recs;  // 16-byte aligned records
+    uint32_t ww_mask;
+    const uint8_t *fold_pgidx;
+    const uint16_t *fold_pages;
+    uint32_t fold_n_pages;
 };
 
 struct Tunables {

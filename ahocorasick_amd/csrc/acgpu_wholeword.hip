@@ -7,9 +7,12 @@
 //
 //   filter : a position starts a run iff it is a word character and its left neighbour is not.  The 65536-bit
 //            word-character table lives in LDS (8 KB); one ds_read_b32 per unit.
-//   verify : run starts are compacted in text order into the per-wave LDS queue; kVerifyBatches*64 at a time they
-//            walk the keyword trie (hashed goto edges, L2-resident) along their run; a run that ends on a terminal
-//            node is a match.  At most one record per run start, ranks by wave prefix sums (as in acgpu_tile.hip).
+//   verify : run starts are compacted in text order into the per-wave LDS queue; kVerifyBatches*64 at a time each
+//            lane reads its run 8 units per load, folds it (paged delta table in LDS), hashes it (FNV-1a) up to the
+//            first non-word unit, looks the hash up in the table of whole keywords and compares the folded run with
+//            the keyword record unit for unit -- three dependent memory accesses per word instead of a trie edge
+//            per unit.  At most one record per run start, ranks by wave prefix sums (as in acgpu_tile.hip).
+//            (debug bit 256 selects the older verification that walks the keyword trie through its hashed edges.)
 //
 // Inconsistent tables (possible only with a custom table in case-insensitive mode, where the reference mixes folded
 // and raw lookups, S/WholeWordMatchMap.java:204,209 vs :221,:226) take k_ww_sequential: a literal single-lane
@@ -22,10 +25,194 @@
 
 namespace acgpu {
 
-size_t ww_lds_bytes(int block_threads) { return 8192 + (size_t)(block_threads / kWave) * kCandCap * sizeof(uint32_t); }
-
 __device__ __forceinline__ uint32_t word_bit(const uint32_t *wbits, uint32_t unit) {
     return __builtin_amdgcn_ubfe(wbits[unit >> 5], unit, 1);
+}
+
+constexpr uint32_t kFoldPagesMax = 64; // 32 KB of LDS; Unicode 13 simple lower-casing needs 18 pages
+
+uint32_t ww_fold_pages_in_lds(const DevTables &t) { return (!t.cs && t.fold_n_pages <= kFoldPagesMax) ? t.fold_n_pages : 0u; }
+
+size_t ww_lds_bytes(int block_threads, uint32_t fold_pages) {
+    return 8192 + (fold_pages ? 256 + (size_t)fold_pages * 512 : 0) + (size_t)(block_threads / kWave) * kCandCap * sizeof(uint32_t);
+}
+
+struct __attribute__((packed, aligned(2))) WwUnits8 { // 8 UTF-16 units at any unit address (one global_load_dwordx4)
+    uint32_t d[4];
+};
+
+struct FoldLds {
+    const uint8_t *pgidx;   // 256 page numbers
+    const uint16_t *pages;  // pages of 256 deltas
+};
+
+// FOLD: 0 = case sensitive, 1 = paged delta table in LDS, 2 = the 65536-entry table in global memory
+template <int FOLD>
+__device__ __forceinline__ uint32_t ww_fold(const DevTables &T, const FoldLds &F, uint32_t u) {
+    if (FOLD == 0) return u;
+    if (FOLD == 1) return (u + F.pages[(uint32_t)F.pgidx[u >> 8] * 256u + (u & 255u)]) & 0xffffu;
+    return T.lower[u];
+}
+
+// 8 units starting at unit index p (p < n): one unaligned 16-byte load, or unit by unit at the end of the buffer
+__device__ __forceinline__ WwUnits8 ww_window(const uint16_t *hay, uint32_t p, uint32_t n) {
+    if (p + 8 <= n) return *reinterpret_cast<const WwUnits8 *>(hay + p);
+    WwUnits8 w{{0, 0, 0, 0}};
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (p + j < n) w.d[j >> 1] |= (uint32_t)hay[p + j] << (16 * (j & 1));
+    return w;
+}
+
+// Verification of up to kVerifyBatches*64 run starts by hashing the whole run.
+template <int FOLD>
+__device__ __forceinline__ void ww_verify_hash(TileCtx &c, const uint32_t *wbits, const FoldLds F, uint32_t head, uint32_t n_cand) {
+    constexpr int NB = kVerifyBatches;
+    const DevTables &T = *c.Tp;
+    const TileLaunch &L = *c.Lp;
+    const uint16_t *hay = L.d_hay;
+    const uint32_t lane = lane_id();
+    const uint32_t n = L.n_units;
+    uint32_t s[NB], r[NB], h[NB], fw[NB][8];
+    bool act[NB], run[NB]; // run: every unit so far was a word character
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const uint32_t q = b * kWave + lane;
+        act[b] = q < n_cand;
+        s[b] = act[b] ? c.cand[head + q] : 0u;
+        r[b] = 0;
+        h[b] = kWwHashSeed;
+        run[b] = act[b];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) fw[b][k] = 0;
+    }
+    // units 0..15 of every run: folded units are kept (packed) for the exact comparison
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        WwUnits8 win[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            win[b] = WwUnits8{{0, 0, 0, 0}};
+            if (run[b] && s[b] + 8 * k < n) win[b] = ww_window(hay, s[b] + 8 * k, n);
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const uint32_t valid = run[b] ? min(n - min(s[b] + 8 * k, n), 8u) : 0u;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t u = (win[b].d[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+                const bool isw = run[b] && (uint32_t)j < valid && word_bit(wbits, u) != 0;
+                const uint32_t f = ww_fold<FOLD>(T, F, u);
+                if (isw) {
+                    h[b] = ww_hash_step(h[b], f);
+                    fw[b][(8 * k + j) >> 1] |= f << (16 * (j & 1));
+                    ++r[b];
+                }
+                run[b] = isw;
+            }
+        }
+        bool any_run = false;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) any_run |= run[b];
+        if (!__any(any_run)) break;
+    }
+    // longer runs: hash only (the comparison re-reads the text beyond unit 16)
+    for (uint32_t k = 2;; ++k) {
+        bool any_run = false;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (run[b] && 8 * k > T.max_len) { // longer than every keyword
+                run[b] = false;
+                act[b] = false;
+            }
+            any_run |= run[b];
+        }
+        if (!__any(any_run)) break;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (!run[b]) continue;
+            const uint32_t p = s[b] + 8 * k;
+            if (p >= n) {
+                run[b] = false;
+                continue;
+            }
+            const WwUnits8 w = ww_window(hay, p, n);
+            const uint32_t valid = min(n - p, 8u);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t u = (w.d[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+                const bool isw = run[b] && (uint32_t)j < valid && word_bit(wbits, u) != 0;
+                if (isw) {
+                    h[b] = ww_hash_step(h[b], ww_fold<FOLD>(T, F, u));
+                    ++r[b];
+                }
+                run[b] = isw;
+            }
+        }
+    }
+    // table lookup: linear probing in lock step; a hash hit is compared with the keyword record unit for unit
+    const uint2 *slots = reinterpret_cast<const uint2 *>(T.ww_slots);
+    const uint4 *recs = reinterpret_cast<const uint4 *>(T.ww_recs);
+    uint32_t id[NB], slot[NB];
+    bool probing[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        id[b] = ~0u;
+        probing[b] = act[b] && r[b] != 0 && r[b] <= T.max_len;
+        slot[b] = ww_hash_slot(h[b], T.ww_mask);
+    }
+    for (;;) {
+        bool any_p = false;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) any_p |= probing[b];
+        if (!__any(any_p)) break;
+        uint2 e[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) e[b] = probing[b] ? slots[slot[b]] : make_uint2(0u, kWwEmpty);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (!probing[b]) continue;
+            if (e[b].y == kWwEmpty) {
+                probing[b] = false;
+                continue;
+            }
+            slot[b] = (slot[b] + 1) & T.ww_mask;
+            if (e[b].x != h[b]) continue;
+            const uint4 *rec = recs + e[b].y;
+            const uint4 a = rec[0]; // {id, length, units 0-1, units 2-3}
+            bool same = a.y == r[b] && a.z == fw[b][0] && a.w == fw[b][1];
+            if (same && r[b] > 4) {
+                const uint4 q = rec[1];
+                same = q.x == fw[b][2] && q.y == fw[b][3] && q.z == fw[b][4] && q.w == fw[b][5];
+            }
+            if (same && r[b] > 12) {
+                const uint4 q = rec[2];
+                same = q.x == fw[b][6] && q.y == fw[b][7];
+                if (same && r[b] > 16) {
+                    const uint16_t *ru = reinterpret_cast<const uint16_t *>(rec) + 4; // the record's units
+                    for (uint32_t i = 16; i < r[b] && same; ++i) same = ww_fold<FOLD>(T, F, hay[s[b] + i]) == ru[i];
+                }
+            }
+            if (same) {
+                id[b] = a.x;
+                probing[b] = false;
+            }
+        }
+    }
+    uint32_t m[NB], prefix[NB], total = 0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        m[b] = id[b] != ~0u ? 1u : 0u;
+        const uint32_t incl = wave_inclusive_scan_dpp(m[b]);
+        prefix[b] = total + incl - m[b];
+        total += __builtin_amdgcn_readlane(incl, kWave - 1);
+    }
+    if (total == 0) return;
+    const SlotRange sr = reserve_slots(c, total);
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+        if (m[b]) store_rec(L, sr.slot(prefix[b]), s[b], s[b] + r[b], id[b], c.rank_base + prefix[b]);
+    c.rank_base += total;
 }
 
 // Verification of up to kVerifyBatches*64 run starts, kVerifyBatches per lane, advanced in lock step.
@@ -91,11 +278,13 @@ __device__ __forceinline__ void ww_verify(TileCtx &c, const uint32_t *wbits, uin
     c.rank_base += total;
 }
 
-__device__ __forceinline__ void ww_drain(TileCtx &c, const uint32_t *wbits, uint32_t keep_below) {
+template <int FOLD>
+__device__ __forceinline__ void ww_drain(TileCtx &c, const uint32_t *wbits, const FoldLds F, uint32_t keep_below) {
     uint32_t head = 0;
     while (c.cand_n > head && c.cand_n - head >= keep_below) {
         const uint32_t nb = min(c.cand_n - head, (uint32_t)(kVerifyBatches * kWave));
-        ww_verify(c, wbits, head, nb);
+        if (c.Lp->debug & 256u) ww_verify(c, wbits, head, nb);
+        else ww_verify_hash<FOLD>(c, wbits, F, head, nb);
         head += nb;
     }
     if (head) {
@@ -118,14 +307,22 @@ __device__ __forceinline__ void ww_drain(TileCtx &c, const uint32_t *wbits, uint
 }
 
 // Same span/region/tile-group structure as k_ac_tile (acgpu_tile.hip); only the filter and the verification differ.
+template <int FOLD>
 __global__ __launch_bounds__(kTileBlock) void k_ww_tile(DevTables T, TileLaunch L) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *wbits = reinterpret_cast<uint32_t *>(smem); // 65536 word-character bits
-    uint32_t *cand_all = reinterpret_cast<uint32_t *>(smem + 8192);
+    const uint32_t fold_bytes = FOLD == 1 ? 256u + T.fold_n_pages * 512u : 0u;
+    uint32_t *cand_all = reinterpret_cast<uint32_t *>(smem + 8192 + fold_bytes);
     for (uint32_t w = threadIdx.x; w < 2048; w += blockDim.x) { // pack the raw-unit flag (bit 0 of wflags) into bits
         uint32_t bits = 0;
         for (uint32_t k = 0; k < 32; ++k) bits |= (uint32_t)(T.wflags[w * 32 + k] & 1u) << k;
         wbits[w] = bits;
+    }
+    FoldLds F{smem + 8192, reinterpret_cast<const uint16_t *>(smem + 8192 + 256)};
+    if (FOLD == 1) {
+        for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) smem[8192 + i] = T.fold_pgidx[i];
+        uint16_t *pages = reinterpret_cast<uint16_t *>(smem + 8192 + 256);
+        for (uint32_t i = threadIdx.x; i < T.fold_n_pages * 256u; i += blockDim.x) pages[i] = T.fold_pages[i];
     }
     __syncthreads();
 
@@ -170,7 +367,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ww_tile(DevTables T, TileLaunch 
     for (;;) {
         const bool seam = vec_todo ? (d0 == 0 && tile >= boundary) : true;
         const uint32_t keep = seam ? 1u : (uint32_t)(kVerifyBatches * kWave);
-        if (c.cand_n >= keep && c.cand_n != 0) ww_drain(c, wbits, keep);
+        if (c.cand_n >= keep && c.cand_n != 0) ww_drain<FOLD>(c, wbits, F, keep);
 
         if (vec_todo) {
             if (d0 == 0) {
@@ -291,11 +488,15 @@ __global__ void k_ww_sequential(DevTables T, const uint16_t *hay, uint32_t len, 
 }
 
 hipError_t launch_ww_tile(const DevTables &t, const TileLaunch &l, hipStream_t stream, const char **kernel_name) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ww_tile), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)l.lds_bytes);
+    const int fold = t.cs ? 0 : (ww_fold_pages_in_lds(t) ? 1 : 2);
+    const void *fn = fold == 0 ? reinterpret_cast<const void *>(&k_ww_tile<0>)
+                   : fold == 1 ? reinterpret_cast<const void *>(&k_ww_tile<1>) : reinterpret_cast<const void *>(&k_ww_tile<2>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_ww_tile, dim3(l.grid), dim3(l.block), l.lds_bytes, stream, t, l);
-    if (kernel_name) *kernel_name = "k_ww_tile";
+    if (fold == 0) hipLaunchKernelGGL(k_ww_tile<0>, dim3(l.grid), dim3(l.block), l.lds_bytes, stream, t, l);
+    else if (fold == 1) hipLaunchKernelGGL(k_ww_tile<1>, dim3(l.grid), dim3(l.block), l.lds_bytes, stream, t, l);
+    else hipLaunchKernelGGL(k_ww_tile<2>, dim3(l.grid), dim3(l.block), l.lds_bytes, stream, t, l);
+    if (kernel_name) *kernel_name = fold == 0 ? "k_ww_tile<0>" : fold == 1 ? "k_ww_tile<1>" : "k_ww_tile<2>";
     return hipGetLastError();
 }
 

@@ -145,3 +145,79 @@ def test_longest_and_wholeword_automata_build_on_cpu():
     wc = np.zeros(65536, np.uint8)
     wc[ord("A")] = 1
     assert Automaton(N.MODE_WHOLEWORD, ["A"], False, word_chars=wc).info()["fold_consistent"] == 0
+
+
+# ---- WholeWord: the whole-keyword hash table + paged fold table (what k_ww_tile probes) ----------------------------
+
+def _wordhash_tables(a):
+    n_slots, n_pages, n_words = ctypes.c_uint32(0), ctypes.c_uint32(0), ctypes.c_uint64(0)
+    f = N.lib().acgpu_debug_wordhash
+    N.check(f(a.handle, ctypes.byref(n_slots), None, ctypes.byref(n_words), None, None, ctypes.byref(n_pages), None), "sizes")
+    slots = np.zeros(2 * n_slots.value, np.uint32)
+    recs = np.zeros(n_words.value, np.uint32)
+    pgidx = np.zeros(256, np.uint8)
+    pages = np.zeros(max(n_pages.value, 1) * 256, np.uint16)
+    vp = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+    N.check(f(a.handle, None, vp(slots), None, vp(recs), vp(pgidx), None, vp(pages)), "tables")
+    return slots.reshape(-1, 2), recs, pgidx, pages
+
+
+def _simulate_wholeword(a, hay, word, cs):
+    """Test-only restatement of the kernel's verification: maximal word runs, folded through the paged table, FNV-1a
+    hashed, probed linearly, compared with the keyword record unit for unit."""
+    slots, recs, pgidx, pages = _wordhash_tables(a)
+    mask = len(slots) - 1
+    fold = (lambda u: u) if cs else (lambda u: (u + int(pages[int(pgidx[u >> 8]) * 256 + (u & 255)])) & 0xffff)
+    out, i, n = [], 0, len(hay)
+    h_list = hay.tolist()
+    while i < n:
+        if not word[h_list[i]]:
+            i += 1
+            continue
+        j = i
+        while j < n and word[h_list[j]]:
+            j += 1
+        f = [fold(u) for u in h_list[i:j]]
+        h = 0x811C9DC5
+        for u in f:
+            h = ((h ^ u) * 0x01000193) & 0xffffffff
+        s = (h ^ (h >> 15)) & mask
+        while slots[s, 1] != 0xffffffff:
+            if slots[s, 0] == h:
+                off = int(slots[s, 1]) * 4
+                ln = int(recs[off + 1])
+                units = [(int(recs[off + 2 + (k >> 1)]) >> (16 * (k & 1))) & 0xffff for k in range(ln)]
+                if units == f:
+                    out.append([i, j, int(recs[off])])
+                    break
+            s = (s + 1) & mask
+        i = j
+    return out
+
+
+def test_wordhash_fold_pages_equal_the_fold_table():
+    a = Automaton(N.MODE_WHOLEWORD, ["a"], False, word_chars=WORD)
+    _, _, pgidx, pages = _wordhash_tables(a)
+    u = np.arange(65536)
+    got = (u + pages[pgidx[u >> 8].astype(np.int64) * 256 + (u & 255)]) & 0xffff
+    assert (got == LOWER).all()
+    assert len(pages) // 256 <= 64  # fits the kernel's LDS budget (Unicode 13 simple lower-casing: 18 pages)
+
+
+def test_wordhash_tables_reproduce_oracle(fixtures):
+    from oracle.oracle import FAM_WHOLEWORD
+    for fx in fixtures:
+        if fx["WW"] == "IllegalArgumentException":
+            continue
+        hay, kws = fixture_inputs(fx)
+        a = Automaton(N.MODE_WHOLEWORD, kws, True, word_chars=WORD)
+        assert _simulate_wholeword(a, hay, WORD, True) == fx["WW"], fx["name"]
+    rng = np.random.default_rng(5)
+    alpha = [ord(c) for c in "abAB -_."] + [0x00E9, 0x00C9, 0x0130, 0x3002]
+    for it in range(40):
+        hay, kws = rand_case(rng, alpha, int(rng.integers(1, 40)), int(rng.choice([3, 6, 20])), int(rng.integers(0, 400)))
+        kws = [k for k in kws if all(WORD[c] for c in k.tolist())] or [np.array([97], np.uint16)]
+        for cs in (True, False):
+            a = Automaton(N.MODE_WHOLEWORD, kws, cs, word_chars=WORD)
+            want = Oracle(FAM_WHOLEWORD, kws, case_sensitive=cs, lower=LOWER, word_chars=WORD).match(hay).tolist()
+            assert _simulate_wholeword(a, hay, WORD, cs) == want, (it, cs)
