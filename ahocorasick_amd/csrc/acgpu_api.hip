@@ -170,7 +170,7 @@ int ensure_device(acgpu_automaton *a, DeviceState **out) {
     if ((rc = upload(*d, t.ww_recs, &T.ww_recs))) return rc;
     if ((rc = upload(*d, t.fold_pgidx, &T.fold_pgidx))) return rc;
     if ((rc = upload(*d, t.fold_pages, &T.fold_pages))) return rc;
-    T.ww_mask = t.ww_mask; T.fold_n_pages = t.fold_n_pages;
+    T.ww_mask = t.ww_mask; T.fold_n_pages = t.fold_n_pages; T.fold_direct_n = t.fold_direct_n;
     T.rhmask = t.rhmask; T.filt_k = t.filt_k; T.filt_n = t.filt_n; T.filt_other = t.filt_other;
     T.filt_words = (uint32_t)t.filt_bits.size(); T.filt_row_bytes = t.filt_row_bytes;
     T.hmask = t.hmask;
@@ -476,7 +476,7 @@ int match_wholeword(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int rec
     L.own_begin = (uint32_t)sh->own_begin;
     L.own_end = (uint32_t)sh->own_end;
     L.cap = scratch_cap;
-    L.lds_bytes = ww_lds_bytes(L.block, ww_fold_pages_in_lds(d.T));
+    L.lds_bytes = ww_lds_bytes(L.block, d.T);
     L.debug = (uint32_t)tunables().tile_debug | (tunables().force_kernel == 1 ? 256u : 0u); // 256: trie-walk verification
     if ((rc = d.chunk_counts.ensure((size_t)L.n_regions * 4))) return rc;
     if ((rc = d.offsets.ensure((size_t)L.n_regions * 8))) return rc;

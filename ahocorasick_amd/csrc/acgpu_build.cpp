@@ -217,8 +217,6 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
             const uint32_t len = nodes[s].depth;
             word.resize(len);
             for (uint32_t n = s, i = len; n != 0; n = nodes[n].parent) word[--i] = nodes[n].unit;
-            uint32_t h = kWwHashSeed;
-            for (uint32_t i = 0; i < len; i++) h = ww_hash_step(h, word[i]);
             const uint64_t off16 = t.ww_recs.size() / 4;
             if (off16 >= kWwEmpty) return ACGPU_E_UNSUPPORTED;
             const size_t words = 2 + (len + 1) / 2;
@@ -227,15 +225,19 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
             rec[0] = nodes[s].kw;
             rec[1] = len;
             for (uint32_t i = 0; i < len; i++) rec[2 + (i >> 1)] |= (uint32_t)word[i] << (16 * (i & 1));
-            uint32_t slot = ww_hash_slot(h, t.ww_mask);
+            uint32_t h = kWwHashSeed;
+            const uint32_t packed = (len + 1) / 2;
+            for (uint32_t i = 0; i < std::max(8u, packed); i++) h = ww_hash_step(h, i < packed ? rec[2 + i] : 0u);
+            h = ww_hash_final(h);
+            uint32_t slot = ww_hash_home(h, t.ww_mask);
             while (t.ww_slots[2 * slot + 1] != kWwEmpty) slot = (slot + 1) & t.ww_mask;
             t.ww_slots[2 * slot] = h;
             t.ww_slots[2 * slot + 1] = (uint32_t)off16;
         }
         t.ww_recs.resize(t.ww_recs.size() + 8, 0u); // the compare may read one 16-byte group past a short record
         t.fold_pgidx.assign(256, 0);
-        t.fold_pages.clear();
-        t.fold_n_pages = 0;
+        t.fold_pages.assign(256, 0); // page 0 = identity (no unit of the page folds): the kernel skips its lookup
+        t.fold_n_pages = 1;
         for (uint32_t pg = 0; pg < 256; pg++) {
             uint16_t delta[256];
             for (uint32_t i = 0; i < 256; i++) delta[i] = (uint16_t)(t.lower[pg * 256 + i] - (pg * 256 + i));
@@ -248,6 +250,8 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
             }
             t.fold_pgidx[pg] = (uint8_t)found; // at most 256 distinct pages
         }
+        t.fold_direct_n = 0;
+        for (uint32_t pg = 0; pg < 8; pg++) if (t.fold_pgidx[pg] != 0) t.fold_direct_n = (pg + 1) * 256;
     }
 
     // ---- 6. character classes + dense delta table (AC/LONGEST only) ----

@@ -29,10 +29,20 @@ ACGPU_HD inline uint32_t edge_hash(uint64_t key) {
 }
 ACGPU_HD inline uint64_t edge_key(uint32_t state, uint32_t unit) { return ((uint64_t)state << 16) | (uint64_t)unit; }
 
-// WholeWord: FNV-1a over the folded units of a whole word, identical on host and device.
-constexpr uint32_t kWwHashSeed = 0x811C9DC5u, kWwHashPrime = 0x01000193u, kWwEmpty = 0xffffffffu;
-ACGPU_HD inline uint32_t ww_hash_step(uint32_t h, uint32_t folded_unit) { return (h ^ folded_unit) * kWwHashPrime; }
-ACGPU_HD inline uint32_t ww_hash_slot(uint32_t h, uint32_t mask) { return (h ^ (h >> 15)) & mask; }
+// WholeWord: hash of a whole folded word, identical on host and device.  The folded units are packed two per 32-bit
+// word (zero padded); the hash runs over max(8, ceil(len/2)) of those words, then a murmur3 finaliser.  Slots are probed
+// in aligned groups of 4 starting at the group of (hash & mask).
+constexpr uint32_t kWwHashSeed = 0x811C9DC5u, kWwEmpty = 0xffffffffu;
+ACGPU_HD inline uint32_t ww_hash_step(uint32_t h, uint32_t packed_units) { return h * 33u + packed_units; }
+ACGPU_HD inline uint32_t ww_hash_final(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+ACGPU_HD inline uint32_t ww_hash_home(uint32_t h, uint32_t mask) { return h & mask & ~3u; }
 
 // Host-side automaton tables.  State numbering: root = 0; states WITHOUT any output (own or inherited
 // keyword) come first in BFS order, states WITH output after them in BFS order, so that
@@ -87,7 +97,8 @@ struct HostTables {
     uint32_t n_rstates = 0;
     // ---- WholeWord: hash table of whole (folded) keywords + paged fold table ----
     // A maximal run of word characters matches iff its folded text IS a keyword, so the run is hashed once and looked
-    // up: ww_slots = open-addressing table of {hash, record offset in 16-byte units} (kWwEmpty = free), linear probing;
+    // up: ww_slots = open-addressing table of {hash, record offset in 16-byte units} (kWwEmpty = free), linear probing
+    // from the first slot of the aligned group of 4 the hash points into (the kernel reads a whole group per probe);
     // ww_recs = records {u32 keyword id, u32 length, folded units packed 2 per u32, zero padded}, each 16-byte aligned,
     // against which a hash hit is compared unit for unit (exact).
     std::vector<uint32_t> ww_slots; // 2 u32 per slot
@@ -97,6 +108,7 @@ struct HostTables {
     std::vector<uint8_t> fold_pgidx;   // 256
     std::vector<uint16_t> fold_pages;  // fold_n_pages * 256
     uint32_t fold_n_pages = 0;
+    uint32_t fold_direct_n = 0;        // units below this fold through a direct table (the cased scripts of the low pages)
 };
 
 int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uint32_t n_kw, int case_sensitive,
@@ -128,7 +140,7 @@ struct DevTables {
     uint32_t ww_mask;
     const uint8_t *fold_pgidx;
     const uint16_t *fold_pages;
-    uint32_t fold_n_pages;
+    uint32_t fold_n_pages, fold_direct_n;
 };
 
 struct Tunables {

@@ -7,8 +7,8 @@
 //
 //   filter : a position starts a run iff it is a word character and its left neighbour is not.  The 65536-bit
 //            word-character table lives in LDS (8 KB); one ds_read_b32 per unit.
-//   verify : run starts are compacted in text order into the per-wave LDS queue; kVerifyBatches*64 at a time each
-//            lane reads its run 8 units per load, folds it (paged delta table in LDS), hashes it (FNV-1a) up to the
+//   verify : run starts are compacted in text order into the per-wave LDS queue; kWwBatches*64 at a time each
+//            lane reads its run 8 units per load, folds it (paged delta table in LDS), hashes it (h*33 + packed units, murmur finaliser) up to the
 //            first non-word unit, looks the hash up in the table of whole keywords and compares the folded run with
 //            the keyword record unit for unit -- three dependent memory accesses per word instead of a trie edge
 //            per unit.  At most one record per run start, ranks by wave prefix sums (as in acgpu_tile.hip).
@@ -29,12 +29,19 @@ __device__ __forceinline__ uint32_t word_bit(const uint32_t *wbits, uint32_t uni
     return __builtin_amdgcn_ubfe(wbits[unit >> 5], unit, 1);
 }
 
+#ifndef ACGPU_WW_NB
+#define ACGPU_WW_NB 2
+#endif
+constexpr int kWwBatches = ACGPU_WW_NB;   // run starts verified per lane and call (independent lookup chains in flight)
+constexpr int kWwPrefetch = 4;          // tiles per load group (the verification needs the registers)
 constexpr uint32_t kFoldPagesMax = 64; // 32 KB of LDS; Unicode 13 simple lower-casing needs 18 pages
 
 uint32_t ww_fold_pages_in_lds(const DevTables &t) { return (!t.cs && t.fold_n_pages <= kFoldPagesMax) ? t.fold_n_pages : 0u; }
 
-size_t ww_lds_bytes(int block_threads, uint32_t fold_pages) {
-    return 8192 + (fold_pages ? 256 + (size_t)fold_pages * 512 : 0) + (size_t)(block_threads / kWave) * kCandCap * sizeof(uint32_t);
+size_t ww_lds_bytes(int block_threads, const DevTables &t) {
+    const uint32_t fold_pages = ww_fold_pages_in_lds(t);
+    return 8192 + (fold_pages ? 256 + (size_t)t.fold_direct_n * 2 + (size_t)fold_pages * 512 : 0) +
+           (size_t)(block_threads / kWave) * kCandCap * sizeof(uint32_t);
 }
 
 struct __attribute__((packed, aligned(2))) WwUnits8 { // 8 UTF-16 units at any unit address (one global_load_dwordx4)
@@ -44,13 +51,19 @@ struct __attribute__((packed, aligned(2))) WwUnits8 { // 8 UTF-16 units at any u
 struct FoldLds {
     const uint8_t *pgidx;   // 256 page numbers
     const uint16_t *pages;  // pages of 256 deltas
+    const uint16_t *direct; // lower[u] for u < direct_n: the bicameral scripts of the low pages in ONE read
+    uint32_t direct_n;
 };
 
 // FOLD: 0 = case sensitive, 1 = paged delta table in LDS, 2 = the 65536-entry table in global memory
 template <int FOLD>
 __device__ __forceinline__ uint32_t ww_fold(const DevTables &T, const FoldLds &F, uint32_t u) {
     if (FOLD == 0) return u;
-    if (FOLD == 1) return (u + F.pages[(uint32_t)F.pgidx[u >> 8] * 256u + (u & 255u)]) & 0xffffu;
+    if (FOLD == 1) {
+        if (u < F.direct_n) return F.direct[u];
+        const uint32_t pg = F.pgidx[u >> 8];
+        return pg ? (u + F.pages[pg * 256u + (u & 255u)]) & 0xffffu : u; // page 0: nothing on the page folds
+    }
     return T.lower[u];
 }
 
@@ -64,10 +77,33 @@ __device__ __forceinline__ WwUnits8 ww_window(const uint16_t *hay, uint32_t p, u
     return w;
 }
 
-// Verification of up to kVerifyBatches*64 run starts by hashing the whole run.
+// One 8-unit chunk of a run: word bits, run length inside the chunk (0..8; `valid` = units that exist in the buffer),
+// folded units packed two per word and zeroed beyond the run.
+template <int FOLD>
+__device__ __forceinline__ uint32_t ww_chunk(const DevTables &T, const FoldLds &F, const uint32_t *wbits, const WwUnits8 &w,
+                                             uint32_t valid, uint32_t out[4]) {
+    uint32_t wm = 0, f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t u = (w.d[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+        wm |= word_bit(wbits, u) << j;
+        f[j] = ww_fold<FOLD>(T, F, u);
+    }
+    wm &= (1u << valid) - 1u;
+    const uint32_t rl = (uint32_t)__builtin_ctz(~wm | 0x100u);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t d = f[2 * i] | (f[2 * i + 1] << 16);
+        const int m = (int)rl - 2 * i;
+        out[i] = m >= 2 ? d : (m == 1 ? (d & 0xffffu) : 0u);
+    }
+    return rl;
+}
+
+// Verification of up to kWwBatches*64 run starts by hashing the whole run.
 template <int FOLD>
 __device__ __forceinline__ void ww_verify_hash(TileCtx &c, const uint32_t *wbits, const FoldLds F, uint32_t head, uint32_t n_cand) {
-    constexpr int NB = kVerifyBatches;
+    constexpr int NB = kWwBatches;
     const DevTables &T = *c.Tp;
     const TileLaunch &L = *c.Lp;
     const uint16_t *hay = L.d_hay;
@@ -81,12 +117,11 @@ __device__ __forceinline__ void ww_verify_hash(TileCtx &c, const uint32_t *wbits
         act[b] = q < n_cand;
         s[b] = act[b] ? c.cand[head + q] : 0u;
         r[b] = 0;
-        h[b] = kWwHashSeed;
         run[b] = act[b];
 #pragma unroll
         for (int k = 0; k < 8; ++k) fw[b][k] = 0;
     }
-    // units 0..15 of every run: folded units are kept (packed) for the exact comparison
+    // units 0..15 of every run: the folded units are kept (packed) for the exact comparison
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         WwUnits8 win[NB];
@@ -98,23 +133,20 @@ __device__ __forceinline__ void ww_verify_hash(TileCtx &c, const uint32_t *wbits
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const uint32_t valid = run[b] ? min(n - min(s[b] + 8 * k, n), 8u) : 0u;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const uint32_t u = (win[b].d[j >> 1] >> (16 * (j & 1))) & 0xffffu;
-                const bool isw = run[b] && (uint32_t)j < valid && word_bit(wbits, u) != 0;
-                const uint32_t f = ww_fold<FOLD>(T, F, u);
-                if (isw) {
-                    h[b] = ww_hash_step(h[b], f);
-                    fw[b][(8 * k + j) >> 1] |= f << (16 * (j & 1));
-                    ++r[b];
-                }
-                run[b] = isw;
-            }
+            const uint32_t rl = ww_chunk<FOLD>(T, F, wbits, win[b], valid, &fw[b][4 * k]);
+            r[b] += rl;
+            run[b] = rl == 8;
         }
         bool any_run = false;
 #pragma unroll
         for (int b = 0; b < NB; ++b) any_run |= run[b];
         if (!__any(any_run)) break;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        h[b] = kWwHashSeed;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h[b] = ww_hash_step(h[b], fw[b][i]);
     }
     // longer runs: hash only (the comparison re-reads the text beyond unit 16)
     for (uint32_t k = 2;; ++k) {
@@ -136,56 +168,81 @@ __device__ __forceinline__ void ww_verify_hash(TileCtx &c, const uint32_t *wbits
                 run[b] = false;
                 continue;
             }
-            const WwUnits8 w = ww_window(hay, p, n);
-            const uint32_t valid = min(n - p, 8u);
+            uint32_t out[4];
+            const uint32_t rl = ww_chunk<FOLD>(T, F, wbits, ww_window(hay, p, n), min(n - p, 8u), out);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const uint32_t u = (w.d[j >> 1] >> (16 * (j & 1))) & 0xffffu;
-                const bool isw = run[b] && (uint32_t)j < valid && word_bit(wbits, u) != 0;
-                if (isw) {
-                    h[b] = ww_hash_step(h[b], ww_fold<FOLD>(T, F, u));
-                    ++r[b];
-                }
-                run[b] = isw;
-            }
+            for (int i = 0; i < 4; ++i)
+                if (rl > 2u * i) h[b] = ww_hash_step(h[b], out[i]);
+            r[b] += rl;
+            run[b] = rl == 8;
         }
     }
-    // table lookup: linear probing in lock step; a hash hit is compared with the keyword record unit for unit
-    const uint2 *slots = reinterpret_cast<const uint2 *>(T.ww_slots);
+    // table lookup: one aligned group of 4 slots per probe, in lock step; a hash hit is compared with the keyword
+    // record unit for unit
+    const uint4 *slots4 = reinterpret_cast<const uint4 *>(T.ww_slots);
     const uint4 *recs = reinterpret_cast<const uint4 *>(T.ww_recs);
-    uint32_t id[NB], slot[NB];
+    uint32_t id[NB], grp[NB], t0[NB];
     bool probing[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         id[b] = ~0u;
-        probing[b] = act[b] && r[b] != 0 && r[b] <= T.max_len;
-        slot[b] = ww_hash_slot(h[b], T.ww_mask);
+        probing[b] = act[b] && r[b] != 0 && r[b] <= T.max_len && !(L.debug & 2u); // 2: ablation, no table lookup
+        h[b] = ww_hash_final(h[b]);
+        grp[b] = ww_hash_home(h[b], T.ww_mask);
+        t0[b] = 0; // entries of the group below t0 were already tried
     }
     for (;;) {
         bool any_p = false;
 #pragma unroll
         for (int b = 0; b < NB; ++b) any_p |= probing[b];
         if (!__any(any_p)) break;
-        uint2 e[NB];
+        uint4 e0[NB], e1[NB];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) e[b] = probing[b] ? slots[slot[b]] : make_uint2(0u, kWwEmpty);
+        for (int b = 0; b < NB; ++b) {
+            e0[b] = e1[b] = make_uint4(0u, kWwEmpty, 0u, kWwEmpty);
+            if (probing[b]) {
+                e0[b] = slots4[grp[b] >> 1];
+                e1[b] = slots4[(grp[b] >> 1) + 1];
+            }
+        }
+        uint32_t sel[NB], tsel[NB];
+        bool stop[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const uint32_t hh[4] = {e0[b].x, e0[b].z, e1[b].x, e1[b].z}, oo[4] = {e0[b].y, e0[b].w, e1[b].y, e1[b].w};
+            sel[b] = kWwEmpty;
+            tsel[b] = 0;
+            stop[b] = false; // a free slot ends the probe sequence
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (oo[t] == kWwEmpty) stop[b] = true;
+                else if (!stop[b] && (uint32_t)t >= t0[b] && hh[t] == h[b] && sel[b] == kWwEmpty) {
+                    sel[b] = oo[t];
+                    tsel[b] = t;
+                }
+            }
+        }
+        uint4 a[NB], q1[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            a[b] = q1[b] = make_uint4(0, 0, 0, 0);
+            if (probing[b] && sel[b] != kWwEmpty) {
+                a[b] = recs[sel[b]];      // {id, length, units 0-1, units 2-3}
+                q1[b] = recs[sel[b] + 1]; // units 4-11 (or the next record / padding: both loads leave together)
+            }
+        }
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             if (!probing[b]) continue;
-            if (e[b].y == kWwEmpty) {
-                probing[b] = false;
+            if (sel[b] == kWwEmpty) {
+                if (stop[b]) probing[b] = false; // not a keyword
+                else { grp[b] = (grp[b] + 4) & T.ww_mask; t0[b] = 0; }
                 continue;
             }
-            slot[b] = (slot[b] + 1) & T.ww_mask;
-            if (e[b].x != h[b]) continue;
-            const uint4 *rec = recs + e[b].y;
-            const uint4 a = rec[0]; // {id, length, units 0-1, units 2-3}
-            bool same = a.y == r[b] && a.z == fw[b][0] && a.w == fw[b][1];
-            if (same && r[b] > 4) {
-                const uint4 q = rec[1];
-                same = q.x == fw[b][2] && q.y == fw[b][3] && q.z == fw[b][4] && q.w == fw[b][5];
-            }
+            bool same = a[b].y == r[b] && a[b].z == fw[b][0] && a[b].w == fw[b][1];
+            if (same && r[b] > 4) same = q1[b].x == fw[b][2] && q1[b].y == fw[b][3] && q1[b].z == fw[b][4] && q1[b].w == fw[b][5];
             if (same && r[b] > 12) {
+                const uint4 *rec = recs + sel[b];
                 const uint4 q = rec[2];
                 same = q.x == fw[b][6] && q.y == fw[b][7];
                 if (same && r[b] > 16) {
@@ -194,8 +251,10 @@ __device__ __forceinline__ void ww_verify_hash(TileCtx &c, const uint32_t *wbits
                 }
             }
             if (same) {
-                id[b] = a.x;
+                id[b] = a[b].x;
                 probing[b] = false;
+            } else {
+                t0[b] = tsel[b] + 1; // a different word with the same 32-bit hash: keep looking in this group
             }
         }
     }
@@ -215,9 +274,9 @@ __device__ __forceinline__ void ww_verify_hash(TileCtx &c, const uint32_t *wbits
     c.rank_base += total;
 }
 
-// Verification of up to kVerifyBatches*64 run starts, kVerifyBatches per lane, advanced in lock step.
+// Verification of up to kWwBatches*64 run starts, kWwBatches per lane, advanced in lock step.
 __device__ __forceinline__ void ww_verify(TileCtx &c, const uint32_t *wbits, uint32_t head, uint32_t n_cand) {
-    constexpr int NB = kVerifyBatches;
+    constexpr int NB = kWwBatches;
     const DevTables &T = *c.Tp;
     const TileLaunch &L = *c.Lp;
     const uint16_t *hay = L.d_hay;
@@ -282,22 +341,22 @@ template <int FOLD>
 __device__ __forceinline__ void ww_drain(TileCtx &c, const uint32_t *wbits, const FoldLds F, uint32_t keep_below) {
     uint32_t head = 0;
     while (c.cand_n > head && c.cand_n - head >= keep_below) {
-        const uint32_t nb = min(c.cand_n - head, (uint32_t)(kVerifyBatches * kWave));
+        const uint32_t nb = min(c.cand_n - head, (uint32_t)(kWwBatches * kWave));
         if (c.Lp->debug & 256u) ww_verify(c, wbits, head, nb);
-        else ww_verify_hash<FOLD>(c, wbits, F, head, nb);
+        else if (!(c.Lp->debug & 1u)) ww_verify_hash<FOLD>(c, wbits, F, head, nb); // 1: ablation, run starts are dropped
         head += nb;
     }
     if (head) {
         const uint32_t left = c.cand_n - head;
-        uint32_t tmp[kVerifyBatches];
+        uint32_t tmp[kWwBatches];
 #pragma unroll
-        for (int b = 0; b < kVerifyBatches; ++b) {
+        for (int b = 0; b < kWwBatches; ++b) {
             const uint32_t q = b * kWave + lane_id();
             tmp[b] = q < left ? c.cand[head + q] : 0u;
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int b = 0; b < kVerifyBatches; ++b) {
+        for (int b = 0; b < kWwBatches; ++b) {
             const uint32_t q = b * kWave + lane_id();
             if (q < left) c.cand[q] = tmp[b];
         }
@@ -311,17 +370,19 @@ template <int FOLD>
 __global__ __launch_bounds__(kTileBlock) void k_ww_tile(DevTables T, TileLaunch L) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *wbits = reinterpret_cast<uint32_t *>(smem); // 65536 word-character bits
-    const uint32_t fold_bytes = FOLD == 1 ? 256u + T.fold_n_pages * 512u : 0u;
+    const uint32_t fold_bytes = FOLD == 1 ? 256u + T.fold_direct_n * 2u + T.fold_n_pages * 512u : 0u;
     uint32_t *cand_all = reinterpret_cast<uint32_t *>(smem + 8192 + fold_bytes);
     for (uint32_t w = threadIdx.x; w < 2048; w += blockDim.x) { // pack the raw-unit flag (bit 0 of wflags) into bits
         uint32_t bits = 0;
         for (uint32_t k = 0; k < 32; ++k) bits |= (uint32_t)(T.wflags[w * 32 + k] & 1u) << k;
         wbits[w] = bits;
     }
-    FoldLds F{smem + 8192, reinterpret_cast<const uint16_t *>(smem + 8192 + 256)};
+    uint16_t *direct = reinterpret_cast<uint16_t *>(smem + 8192 + 256);
+    uint16_t *pages = direct + (FOLD == 1 ? T.fold_direct_n : 0u);
+    FoldLds F{smem + 8192, pages, direct, FOLD == 1 ? T.fold_direct_n : 0u};
     if (FOLD == 1) {
         for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) smem[8192 + i] = T.fold_pgidx[i];
-        uint16_t *pages = reinterpret_cast<uint16_t *>(smem + 8192 + 256);
+        for (uint32_t i = threadIdx.x; i < T.fold_direct_n; i += blockDim.x) direct[i] = T.lower[i];
         for (uint32_t i = threadIdx.x; i < T.fold_n_pages * 256u; i += blockDim.x) pages[i] = T.fold_pages[i];
     }
     __syncthreads();
@@ -354,19 +415,19 @@ __global__ __launch_bounds__(kTileBlock) void k_ww_tile(DevTables T, TileLaunch 
     bool tail_todo = span_end > nfull;
     uint32_t d0 = 0;
     uint32_t carry = 0; // word-character bit of the unit just before the current tile
-    uint4 nxt[kPrefetch], grp[kPrefetch];
+    uint4 nxt[kWwPrefetch], grp[kWwPrefetch];
 #pragma unroll
-    for (int d = 0; d < kPrefetch; ++d) nxt[d] = grp[d] = make_uint4(0, 0, 0, 0);
+    for (int d = 0; d < kWwPrefetch; ++d) nxt[d] = grp[d] = make_uint4(0, 0, 0, 0);
     if (vec_todo) {
         if (tile >= 1) carry = word_bit(wbits, hay[tile - 1]);
 #pragma unroll
-        for (int d = 0; d < kPrefetch; ++d)
+        for (int d = 0; d < kWwPrefetch; ++d)
             nxt[d] = *reinterpret_cast<const uint4 *>(hay + min(tile + d * kTileUnits + lane * 8, last_vec));
     }
 
     for (;;) {
         const bool seam = vec_todo ? (d0 == 0 && tile >= boundary) : true;
-        const uint32_t keep = seam ? 1u : (uint32_t)(kVerifyBatches * kWave);
+        const uint32_t keep = seam ? 1u : (uint32_t)(kWwBatches * kWave);
         if (c.cand_n >= keep && c.cand_n != 0) ww_drain<FOLD>(c, wbits, F, keep);
 
         if (vec_todo) {
@@ -380,17 +441,17 @@ __global__ __launch_bounds__(kTileBlock) void k_ww_tile(DevTables T, TileLaunch 
                     re = min(span_end, boundary);
                 }
 #pragma unroll
-                for (int d = 0; d < kPrefetch; ++d) grp[d] = nxt[d];
+                for (int d = 0; d < kWwPrefetch; ++d) grp[d] = nxt[d];
 #pragma unroll
-                for (int d = 0; d < kPrefetch; ++d)
+                for (int d = 0; d < kWwPrefetch; ++d)
                     nxt[d] = *reinterpret_cast<const uint4 *>(
-                        hay + min(tile + (kPrefetch + d) * kTileUnits + lane * 8, last_vec));
+                        hay + min(tile + (kWwPrefetch + d) * kTileUnits + lane * 8, last_vec));
             }
             const uint32_t top = min(re, hi);
-            const bool edge = tile < rb || tile + kPrefetch * kTileUnits > top;
+            const bool edge = tile < rb || tile + kWwPrefetch * kTileUnits > top;
             bool resume = false;
 #pragma unroll
-            for (int d = 0; d < kPrefetch; ++d) {
+            for (int d = 0; d < kWwPrefetch; ++d) {
                 if ((uint32_t)d < d0) continue;
                 const uint32_t cur = tile + d * kTileUnits;
                 if (cur >= hi) break;
@@ -417,7 +478,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ww_tile(DevTables T, TileLaunch 
             }
             if (!resume) {
                 d0 = 0;
-                tile += kPrefetch * kTileUnits;
+                tile += kWwPrefetch * kTileUnits;
                 vec_todo = tile < hi;
             }
             continue;

@@ -203,10 +203,12 @@ int acgpu_debug_tables(const acgpu_automaton *a, uint16_t *cls_lut /*65536*/, ui
                        uint32_t *out_link, uint32_t *out_id, uint32_t *depth, uint32_t *first_out_state);
 
 /* Test hook (ACGPU_MODE_WHOLEWORD): the whole-keyword hash table the device kernel probes.  Sizes are always written;
- * arrays are copied when the pointer is non-NULL.  slots: 2 uint32 per slot {FNV-1a hash of the folded keyword, record
- * offset in 16-byte units; 0xffffffff = free}, linear probing from (h ^ h>>15) & (n_slots-1).  recs: uint32 words,
- * record = {keyword id, length, folded units packed two per word, zero padded to 16 bytes}.  fold_pgidx[256] /
- * fold_pages[n_pages*256]: lower[u] = (u + fold_pages[fold_pgidx[u>>8]*256 + (u&255)]) & 0xffff. */
+ * arrays are copied when the pointer is non-NULL.  slots: 2 uint32 per slot {hash of the folded keyword, record offset
+ * in 16-byte units; 0xffffffff = free}, linear probing from slot (hash & (n_slots-1) & ~3).  recs: uint32 words, record
+ * = {keyword id, length, folded units packed two per word, zero padded to 16 bytes}.  hash: h = 0x811C9DC5; for each of
+ * the max(8, ceil(length/2)) packed words (zero beyond the keyword) h = h*33 + word; then the murmur3 32-bit finaliser.
+ * fold_pgidx[256] / fold_pages[n_pages*256]: lower[u] = (u + fold_pages[fold_pgidx[u>>8]*256 + (u&255)]) & 0xffff;
+ * page 0 is all zero. */
 int acgpu_debug_wordhash(const acgpu_automaton *a, uint32_t *n_slots, uint32_t *slots, uint64_t *n_rec_words, uint32_t *recs,
                          uint8_t *fold_pgidx, uint32_t *n_pages, uint16_t *fold_pages);
 

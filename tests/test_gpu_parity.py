@@ -449,6 +449,37 @@ def test_wholeword_mixed_script_like_config_c5():
         assert (WholeWordMatchSet(words, False).find_all(hay) == want[:, :2]).all()
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_wholeword_long_words_and_hash_table_paths(seed):
+    """Words longer than the 16 units the kernel keeps in registers, many words sharing long prefixes, buffer ends
+    inside a word, case folding on every unit."""
+    rng = np.random.default_rng(100 + seed)
+    alpha = np.array([ord(c) for c in "abAB"] + [0x00E9, 0x00C9, 0x0391, 0x03B1], dtype=np.uint16)
+    kws = []
+    for _ in range(300):
+        ln = int(rng.choice([1, 2, 5, 8, 9, 12, 13, 16, 17, 24, 33, 100]))
+        kws.append(alpha[rng.integers(0, len(alpha), ln)])
+    parts = []
+    for _ in range(3000):
+        k = kws[int(rng.integers(0, len(kws)))].copy()
+        mode = int(rng.integers(0, 4))
+        if mode == 1 and len(k) > 1:
+            k[int(rng.integers(0, len(k)))] = alpha[int(rng.integers(0, len(alpha)))]  # near miss
+        elif mode == 2:
+            k = np.concatenate([k, alpha[rng.integers(0, len(alpha), 1)]])  # one unit longer
+        parts.append(k)
+        parts.append(np.array([32] * int(rng.integers(1, 3)), dtype=np.uint16))
+    hay = np.concatenate(parts[:-1])  # ends inside a word
+    for cs in (True, False):
+        want = Oracle(FAM_WHOLEWORD, kws, case_sensitive=cs, lower=LOWER, word_chars=WORD).match(hay)
+        got = WholeWordMatchMap(kws, _ids(len(kws)), cs).find_all(hay)
+        assert got.shape == want.shape and (got == want).all()
+        N.set_tunable("force_kernel", 1)  # the trie-walk verification agrees
+        got2 = WholeWordMatchMap(kws, _ids(len(kws)), cs).find_all(hay)
+        N.set_tunable("force_kernel", 0)
+        assert (got2 == want).all()
+
+
 def test_wholeword_shards_own_their_word_starts():
     import torch
     words = synth.mixed_script_words(31, 2000)

@@ -164,7 +164,7 @@ def _wordhash_tables(a):
 
 def _simulate_wholeword(a, hay, word, cs):
     """Test-only restatement of the kernel's verification: maximal word runs, folded through the paged table, FNV-1a
-    hashed, probed linearly, compared with the keyword record unit for unit."""
+    hashed (h*33 + packed units, murmur finaliser), probed linearly from the aligned group of 4, compared with the keyword record unit for unit."""
     slots, recs, pgidx, pages = _wordhash_tables(a)
     mask = len(slots) - 1
     fold = (lambda u: u) if cs else (lambda u: (u + int(pages[int(pgidx[u >> 8]) * 256 + (u & 255)])) & 0xffff)
@@ -178,10 +178,17 @@ def _simulate_wholeword(a, hay, word, cs):
         while j < n and word[h_list[j]]:
             j += 1
         f = [fold(u) for u in h_list[i:j]]
+        packed = [f[k] | ((f[k + 1] if k + 1 < len(f) else 0) << 16) for k in range(0, len(f), 2)]
+        packed += [0] * (8 - len(packed))
         h = 0x811C9DC5
-        for u in f:
-            h = ((h ^ u) * 0x01000193) & 0xffffffff
-        s = (h ^ (h >> 15)) & mask
+        for d in packed:
+            h = (h * 33 + d) & 0xffffffff
+        h ^= h >> 16
+        h = (h * 0x85EBCA6B) & 0xffffffff
+        h ^= h >> 13
+        h = (h * 0xC2B2AE35) & 0xffffffff
+        h ^= h >> 16
+        s = h & mask & ~3
         while slots[s, 1] != 0xffffffff:
             if slots[s, 0] == h:
                 off = int(slots[s, 1]) * 4
