@@ -457,7 +457,8 @@ int match_wholeword(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int rec
     if (!sh->text_begin && sh->own_begin < 1) return ACGPU_E_INVALID;                              // left context: 1 unit
     if (!sh->text_end && sh->n_units - sh->own_end < (uint64_t)t.max_len + 1) return ACGPU_E_INVALID; // right halo
     const uint64_t scratch_cap = std::min<uint64_t>(
-        std::max<uint64_t>(cap, 1) + (uint64_t)d.n_cu * (tile_block_threads() / 64) * tile_reserve_slots(), 0xffffffe0ull);
+        std::max<uint64_t>(cap, 1) + (uint64_t)d.n_cu * ww_blocks_per_cu() * (tile_block_threads() / 64) * tile_reserve_slots(),
+        0xffffffe0ull);
     if ((rc = d.scratch.ensure(scratch_cap * sizeof(ScratchRec)))) return rc;
     TileLaunch L{};
     L.block = tile_block_threads();
@@ -467,7 +468,7 @@ int match_wholeword(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int rec
     L.region_units = (uint32_t)R;
     const uint64_t base8 = sh->own_begin & ~7ull;
     L.n_regions = (uint32_t)((sh->own_end - base8 + R - 1) / R);
-    const uint64_t waves_max = (uint64_t)d.n_cu * waves_per_block;
+    const uint64_t waves_max = (uint64_t)d.n_cu * ww_blocks_per_cu() * waves_per_block;
     L.regions_per_wave = (uint32_t)((L.n_regions + waves_max - 1) / waves_max);
     const uint64_t waves_used = ((uint64_t)L.n_regions + L.regions_per_wave - 1) / L.regions_per_wave;
     L.grid = (int)((waves_used + waves_per_block - 1) / waves_per_block);

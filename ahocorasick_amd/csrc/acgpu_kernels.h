@@ -115,6 +115,7 @@ namespace acgpu {
 // ---- WHOLEWORD pipeline (acgpu_wholeword.hip) -----------------------------------------------------------------
 uint32_t ww_fold_pages_in_lds(const DevTables &t); // 0: the fold table is not staged (case sensitive / too many pages)
 size_t ww_lds_bytes(int block_threads, const DevTables &t);
+int ww_blocks_per_cu();
 hipError_t launch_ww_tile(const DevTables &t, const TileLaunch &l, hipStream_t stream, const char **kernel_name);
 hipError_t launch_ww_sequential(const DevTables &t, const uint16_t *d_hay, uint32_t len, void *d_out, uint64_t cap,
                                 int record_kind, unsigned long long *d_counter, hipStream_t stream);

@@ -170,9 +170,15 @@ __global__ __launch_bounds__(256) void k_longest_sync(LongestChainLaunch L, uint
 }
 
 // One lane per tile with a synchronisation point: follows the chain from S[t] to the next tile's synchronisation point
-// (or out of the owned range), counting or writing the matches met.
+// (or out of the owned range), counting or writing the matches met.  The write pass stages a lane's records in LDS and
+// stores them as whole aligned groups (8 Set records = 64 bytes, 4 Map records = 48 bytes, as consecutive 16-byte
+// stores by the same lane), so that the L2 sees full sectors instead of one 8-byte store per line and instruction.
+constexpr int kChainBlock = 256;
+
 template <typename LenT, bool WRITE>
-__global__ __launch_bounds__(256) void k_longest_chain(LongestChainLaunch L, const uint32_t *S) {
+__global__ __launch_bounds__(kChainBlock) void k_longest_chain(LongestChainLaunch L, const uint32_t *S) {
+    __shared__ int2 ring_se[WRITE ? 8 : 1][kChainBlock]; // [slot][lane]: conflict-free for a lane's own slots
+    __shared__ int ring_id[WRITE ? 4 : 1][kChainBlock];
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= L.n_tiles) return;
     const LenT *len = reinterpret_cast<const LenT *>(L.d_len);
@@ -190,25 +196,64 @@ __global__ __launch_bounds__(256) void k_longest_chain(LongestChainLaunch L, con
             break;
         }
     }
+    const bool set_kind = L.record_kind == ACGPU_REC_SET;
+    const uint32_t gmask = set_kind ? 7u : 3u; // records per aligned group - 1
     uint32_t pos = start, count = 0;
     uint64_t dst = WRITE ? L.d_offsets[t] : 0;
+    uint32_t gfirst = (uint32_t)dst & gmask; // first valid slot of the group being filled
+    const uint32_t lane = threadIdx.x;
+    // stores slots [from, to) of the current group one record at a time (group not complete, or beyond cap)
+    auto flush_scalar = [&](uint64_t gbase, uint32_t from, uint32_t to) {
+        for (uint32_t k = from; k < to; ++k) {
+            const uint64_t d = gbase + k;
+            if (d >= L.cap) break;
+            const int2 se = ring_se[k][lane];
+            if (set_kind) {
+                reinterpret_cast<int2 *>(L.d_out)[d] = se;
+            } else {
+                int32_t *o = reinterpret_cast<int32_t *>(L.d_out) + d * 3;
+                o[0] = se.x; o[1] = se.y; o[2] = ring_id[k][lane];
+            }
+        }
+    };
     while (pos < target && pos < L.own_end) {
         const uint32_t l = (uint32_t)len[pos];
         if (l > 0) {
-            if (WRITE && dst < L.cap) {
-                if (L.record_kind == ACGPU_REC_SET) {
-                    reinterpret_cast<int2 *>(L.d_out)[dst] = make_int2((int)pos, (int)(pos + l));
-                } else {
-                    int32_t *o = reinterpret_cast<int32_t *>(L.d_out) + dst * 3;
-                    o[0] = (int)pos;
-                    o[1] = (int)(pos + l);
-                    o[2] = (int)L.d_out_id[L.d_state[pos]];
+            if (WRITE) {
+                const uint32_t k = (uint32_t)dst & gmask;
+                ring_se[k][lane] = make_int2((int)pos, (int)(pos + l));
+                if (!set_kind) ring_id[k][lane] = (int)L.d_out_id[L.d_state[pos]];
+                if (k == gmask) { // the group is full up to its last slot
+                    const uint64_t gbase = dst - gmask;
+                    if (gfirst == 0 && dst < L.cap) {
+                        if (set_kind) {
+                            uint4 *o = reinterpret_cast<uint4 *>(reinterpret_cast<int2 *>(L.d_out) + gbase);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int2 r0 = ring_se[2 * q][lane], r1 = ring_se[2 * q + 1][lane];
+                                o[q] = make_uint4((uint32_t)r0.x, (uint32_t)r0.y, (uint32_t)r1.x, (uint32_t)r1.y);
+                            }
+                        } else {
+                            uint4 *o = reinterpret_cast<uint4 *>(reinterpret_cast<int32_t *>(L.d_out) + gbase * 3);
+                            const int2 r0 = ring_se[0][lane], r1 = ring_se[1][lane], r2 = ring_se[2][lane], r3 = ring_se[3][lane];
+                            o[0] = make_uint4((uint32_t)r0.x, (uint32_t)r0.y, (uint32_t)ring_id[0][lane], (uint32_t)r1.x);
+                            o[1] = make_uint4((uint32_t)r1.y, (uint32_t)ring_id[1][lane], (uint32_t)r2.x, (uint32_t)r2.y);
+                            o[2] = make_uint4((uint32_t)ring_id[2][lane], (uint32_t)r3.x, (uint32_t)r3.y, (uint32_t)ring_id[3][lane]);
+                        }
+                    } else {
+                        flush_scalar(gbase, gfirst, gmask + 1);
+                    }
+                    gfirst = 0;
                 }
             }
             ++dst;
             ++count;
         }
         pos += l > 0 ? l : 1u;
+    }
+    if (WRITE) {
+        const uint32_t k = (uint32_t)dst & gmask;
+        if (k > gfirst) flush_scalar(dst - k, gfirst, k);
     }
     if (!WRITE) {
         L.d_counts[t] = count;
@@ -226,7 +271,7 @@ hipError_t launch_longest_sync(const LongestChainLaunch &l, uint32_t *d_sync, hi
 
 hipError_t launch_longest_chain(const LongestChainLaunch &l, const uint32_t *d_sync, bool write_pass, hipStream_t stream) {
     if (l.n_tiles == 0) return hipSuccess;
-    const dim3 grid((l.n_tiles + 255) / 256), block(256);
+    const dim3 grid((l.n_tiles + kChainBlock - 1) / kChainBlock), block(kChainBlock);
     if (l.len_bytes == 2) {
         if (write_pass) hipLaunchKernelGGL((k_longest_chain<uint16_t, true>), grid, block, 0, stream, l, d_sync);
         else hipLaunchKernelGGL((k_longest_chain<uint16_t, false>), grid, block, 0, stream, l, d_sync);

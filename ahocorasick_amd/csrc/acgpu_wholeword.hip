@@ -33,7 +33,19 @@ __device__ __forceinline__ uint32_t word_bit(const uint32_t *wbits, uint32_t uni
 #define ACGPU_WW_NB 2
 #endif
 constexpr int kWwBatches = ACGPU_WW_NB;   // run starts verified per lane and call (independent lookup chains in flight)
-constexpr int kWwPrefetch = 4;          // tiles per load group (the verification needs the registers)
+#ifndef ACGPU_WW_PREFETCH
+#define ACGPU_WW_PREFETCH 4
+#endif
+#ifndef ACGPU_WW_BLOCKS
+#define ACGPU_WW_BLOCKS 1
+#endif
+constexpr int kWwPrefetch = ACGPU_WW_PREFETCH; // tiles per load group (the verification needs the registers)
+constexpr int kWwBlocksPerCu = ACGPU_WW_BLOCKS; // resident blocks per CU the register budget is set for
+// run starts per tile <= 256 (a start needs a non-word unit before it); the queue holds one verification call's worth
+// (kept until the next call) plus one tile
+constexpr int kWwCandCap = kWwBatches * 64 + 256 + 64;
+
+int ww_blocks_per_cu() { return kWwBlocksPerCu; }
 constexpr uint32_t kFoldPagesMax = 64; // 32 KB of LDS; Unicode 13 simple lower-casing needs 18 pages
 
 uint32_t ww_fold_pages_in_lds(const DevTables &t) { return (!t.cs && t.fold_n_pages <= kFoldPagesMax) ? t.fold_n_pages : 0u; }
@@ -41,7 +53,7 @@ uint32_t ww_fold_pages_in_lds(const DevTables &t) { return (!t.cs && t.fold_n_pa
 size_t ww_lds_bytes(int block_threads, const DevTables &t) {
     const uint32_t fold_pages = ww_fold_pages_in_lds(t);
     return 8192 + (fold_pages ? 256 + (size_t)t.fold_direct_n * 2 + (size_t)fold_pages * 512 : 0) +
-           (size_t)(block_threads / kWave) * kCandCap * sizeof(uint32_t);
+           (size_t)(block_threads / kWave) * kWwCandCap * sizeof(uint32_t);
 }
 
 struct __attribute__((packed, aligned(2))) WwUnits8 { // 8 UTF-16 units at any unit address (one global_load_dwordx4)
@@ -367,7 +379,7 @@ __device__ __forceinline__ void ww_drain(TileCtx &c, const uint32_t *wbits, cons
 
 // Same span/region/tile-group structure as k_ac_tile (acgpu_tile.hip); only the filter and the verification differ.
 template <int FOLD>
-__global__ __launch_bounds__(kTileBlock) void k_ww_tile(DevTables T, TileLaunch L) {
+__global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) void k_ww_tile(DevTables T, TileLaunch L) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *wbits = reinterpret_cast<uint32_t *>(smem); // 65536 word-character bits
     const uint32_t fold_bytes = FOLD == 1 ? 256u + T.fold_direct_n * 2u + T.fold_n_pages * 512u : 0u;
@@ -390,7 +402,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ww_tile(DevTables T, TileLaunch 
     const uint32_t lane = lane_id();
     const uint32_t wave_in_block = threadIdx.x / kWave;
     const uint32_t wave_global = blockIdx.x * (kTileBlock / kWave) + wave_in_block;
-    TileCtx c{&T, &L, cand_all + wave_in_block * kCandCap, 0, 0, 0u, 0};
+    TileCtx c{&T, &L, cand_all + wave_in_block * kWwCandCap, 0, 0, 0u, 0};
 
     const uint32_t first_region = wave_global * L.regions_per_wave;
     if (first_region >= L.n_regions) return;
@@ -455,7 +467,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ww_tile(DevTables T, TileLaunch 
                 if ((uint32_t)d < d0) continue;
                 const uint32_t cur = tile + d * kTileUnits;
                 if (cur >= hi) break;
-                if (c.cand_n > kCandCap - kTileUnits) {
+                if (c.cand_n > kWwCandCap - 256) {
                     d0 = d;
                     resume = true;
                     break;
