@@ -362,7 +362,7 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
     uint32_t lds_rows = 0;
     if (t.dense && t.n_cls) lds_rows = (uint32_t)std::min<uint64_t>(t.n_states, (72 * 1024) / ((uint64_t)t.n_cls * 4));
     S.lds_rows = lds_rows;
-    S.lds_bytes = (size_t)lds_rows * t.n_cls * 4;
+    S.lds_bytes = std::max<size_t>((size_t)lds_rows * t.n_cls * 4, 16);
     int rc;
     if ((rc = d.lenbuf.ensure((size_t)sh->n_units * S.len_bytes + 64))) return rc;
     S.d_len = d.lenbuf.p;

@@ -285,7 +285,7 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
             uint64_t entries = (uint64_t)N * t.n_cls;
             uint32_t eb = (N <= 65536 && mode != ACGPU_MODE_LONGEST) ? 2 : 4;
             if (!tunables().force_sparse && entries * eb <= (uint64_t)tunables().dense_budget_bytes &&
-                entries < (1ull << 32)) {
+                entries < (1ull << 32) && (mode != ACGPU_MODE_LONGEST || entries * 4 < (1ull << 31))) {
                 t.dense = true;
                 t.entry_bytes = eb;
                 t.dfa.assign(entries, 0);

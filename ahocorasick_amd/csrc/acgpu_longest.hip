@@ -27,66 +27,93 @@ struct __attribute__((packed, aligned(2))) Units8 { // 8 UTF-16 units at any uni
 };
 
 // L[pos] for every owned position: walk the keyword trie forward from pos, remember the deepest node that ends a
-// keyword.  Position parallel (lane i of a wave = position base+i: text loads and the len[] stores are coalesced);
-// the hot (shallow, BFS-first) rows of the class-indexed goto table sit in LDS.
+// keyword.  Position parallel (lane i of a wave = position base+i: text loads and the len[] stores are coalesced).
+// DENSE: the hot (shallow, BFS-first) rows of the class-indexed goto table sit in LDS, re-encoded while they are staged
+// as {bit 31: the child ends a keyword, low bits: BYTE offset of the child's row}, so a step is one add, one ds_read and
+// a few selects; rows beyond the LDS budget are read from the table in global memory (rare: deep nodes).
 template <typename LenT, bool DENSE>
 __global__ __launch_bounds__(kLScanBlock) void k_longest_walk(DevTables T, LongestScanLaunch L) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *rows = reinterpret_cast<uint32_t *>(smem);
     const uint32_t *glob = reinterpret_cast<const uint32_t *>(T.dfa);
+    const uint32_t row_bytes = T.n_cls * 4u;
     const uint32_t lds_entries = DENSE ? L.lds_rows * T.n_cls : 0;
-    for (uint32_t i = threadIdx.x; i < lds_entries; i += blockDim.x) rows[i] = glob[i];
+    const uint32_t lds_bytes = lds_entries * 4u;
+    const uint32_t lds_last = lds_bytes ? lds_bytes - 4u : 0u;
+    for (uint32_t i = threadIdx.x; i < lds_entries; i += blockDim.x) {
+        const uint32_t e = glob[i];
+        rows[i] = e ? ((e & 0x80000000u) | ((e & 0x7fffffffu) * row_bytes)) : 0u;
+    }
     __syncthreads();
     LenT *out_len = reinterpret_cast<LenT *>(L.d_len);
     const uint16_t *hay = L.d_hay;
     const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t n = L.n_units;
     for (uint32_t p = L.own_begin + blockIdx.x * blockDim.x + threadIdx.x; p < L.own_end; p += stride) {
-        uint32_t node = 0, best = 0, best_node = 0, i = p;
-        bool alive = true;
-        while (alive && i < L.n_units) {
-            // eight units per load; the walk usually ends inside the first window
-            uint32_t w[4] = {0, 0, 0, 0};
-            if (i + 8 <= L.n_units) {
-                const Units8 u = *reinterpret_cast<const Units8 *>(hay + i);
-                w[0] = u.d[0]; w[1] = u.d[1]; w[2] = u.d[2]; w[3] = u.d[3];
-            } else {
-                for (uint32_t j = 0; j < 8 && i + j < L.n_units; ++j) w[j >> 1] |= (uint32_t)hay[i + j] << (16 * (j & 1));
-            }
+        if (DENSE) {
+            uint32_t off = 0, depth = 0, best = 0, best_off = 0, i = p;
+            bool alive = true;
+            while (alive) {
+                // eight units per load; the walk usually ends inside the first window
+                const uint32_t nvalid = min(n - min(i, n), 8u);
+                uint32_t w[4] = {0, 0, 0, 0};
+                if (nvalid == 8) {
+                    const Units8 u = *reinterpret_cast<const Units8 *>(hay + i);
+                    w[0] = u.d[0]; w[1] = u.d[1]; w[2] = u.d[2]; w[3] = u.d[3];
+                } else {
+                    for (uint32_t j = 0; j < nvalid; ++j) w[j >> 1] |= (uint32_t)hay[i + j] << (16 * (j & 1));
+                }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if (alive && i < L.n_units) {
+                for (int j = 0; j < 8; ++j) {
                     const uint32_t unit = (w[j >> 1] >> (16 * (j & 1))) & 0xffffu;
-                    uint32_t e;
-                    if (DENSE) {
-                        uint32_t cls;
-                        if (T.range_cls) {
-                            const uint32_t dlt = unit - T.cls_base;
-                            cls = dlt < T.cls_span ? dlt + 1 : 0;
-                        } else {
-                            cls = T.cls_lut[unit];
-                        }
-                        const uint32_t idx = node * T.n_cls + cls;
-                        e = idx < lds_entries ? rows[idx] : glob[idx];
+                    uint32_t cls4;
+                    if (T.range_cls) {
+                        const uint32_t dlt = unit - T.cls_base;
+                        cls4 = dlt < T.cls_span ? dlt * 4u + 4u : 0u;
                     } else {
-                        const uint32_t f = T.cs ? unit : (uint32_t)T.lower[unit];
-                        const uint32_t c = hashed_goto(T.hkeys, T.hvals, T.hmask, node, f);
-                        e = c == ~0u ? 0u : (c | (T.term_id[c] != ~0u ? 0x80000000u : 0u));
+                        cls4 = (uint32_t)T.cls_lut[unit] * 4u;
                     }
-                    if (e == 0) {
-                        alive = false;
-                    } else {
-                        node = e & 0x7fffffffu;
-                        ++i;
+                    const uint32_t at = off + cls4;
+                    uint32_t e = rows[min(at, lds_last) >> 2]; // always an LDS read (a dead lane's is ignored)
+                    if (at >= lds_bytes) {                            // deep row: global table, child ids
+                        const uint32_t g = alive ? glob[at >> 2] : 0u;
+                        e = g ? ((g & 0x80000000u) | ((g & 0x7fffffffu) * row_bytes)) : 0u;
+                    }
+                    alive = alive && (uint32_t)j < nvalid && e != 0;
+                    if (alive) {
+                        off = e & 0x7fffffffu;
+                        ++depth;
                         if (e >> 31) {
-                            best = i - p;
-                            best_node = node;
+                            best = depth;
+                            best_off = off;
                         }
                     }
                 }
+                i += 8;
             }
+            out_len[p] = (LenT)best;
+            if (L.d_state) L.d_state[p] = best_off / row_bytes;
+        } else {
+            uint32_t node = 0, best = 0, best_node = 0, i = p;
+            bool alive = true;
+            while (alive && i < n) {
+                const uint32_t unit = hay[i];
+                const uint32_t f = T.cs ? unit : (uint32_t)T.lower[unit];
+                const uint32_t c = hashed_goto(T.hkeys, T.hvals, T.hmask, node, f);
+                if (c == ~0u) {
+                    alive = false;
+                } else {
+                    node = c;
+                    ++i;
+                    if (T.term_id[c] != ~0u) {
+                        best = i - p;
+                        best_node = node;
+                    }
+                }
+            }
+            out_len[p] = (LenT)best;
+            if (L.d_state) L.d_state[p] = best_node;
         }
-        out_len[p] = (LenT)best;
-        if (L.d_state) L.d_state[p] = best_node;
     }
 }
 
