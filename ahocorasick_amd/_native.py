@@ -44,7 +44,7 @@ class Profile(ctypes.Structure):
 SYMBOLS = ["acgpu_build", "acgpu_free", "acgpu_get_info", "acgpu_match_u16", "acgpu_match_device",
            "acgpu_match_device_begin", "acgpu_match_device_end", "acgpu_synth_fill",
            "acgpu_set_tunable", "acgpu_strerror", "acgpu_last_hip_error", "acgpu_abi_version", "acgpu_debug_tables",
-           "acgpu_debug_wordhash"]
+           "acgpu_debug_wordhash", "acgpu_stream_open", "acgpu_stream_feed", "acgpu_stream_close"]
 
 _lib = None
 
@@ -90,6 +90,12 @@ def lib():
         L.acgpu_abi_version.restype = u32
         L.acgpu_debug_tables.restype = ci
         L.acgpu_debug_tables.argtypes = [vp, vp, vp, vp, vp, vp, vp, ctypes.POINTER(u32)]
+        L.acgpu_stream_open.restype = ci
+        L.acgpu_stream_open.argtypes = [vp, ctypes.POINTER(vp)]
+        L.acgpu_stream_feed.restype = ci
+        L.acgpu_stream_feed.argtypes = [vp, vp, u64, ci, ci, vp, u64, ctypes.POINTER(u64), ctypes.POINTER(i64)]
+        L.acgpu_stream_close.restype = None
+        L.acgpu_stream_close.argtypes = [vp]
         L.acgpu_debug_wordhash.restype = ci
         L.acgpu_debug_wordhash.argtypes = [vp, ctypes.POINTER(u32), vp, ctypes.POINTER(u64), vp, vp, ctypes.POINTER(u32), vp]
         _lib = L

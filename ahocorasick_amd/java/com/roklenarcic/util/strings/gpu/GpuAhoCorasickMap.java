@@ -9,7 +9,7 @@ import com.roklenarcic.util.strings.MapMatchListener;
 import com.roklenarcic.util.strings.ReadableMatchListener;
 import com.roklenarcic.util.strings.StringMap;
 
-/** Drop-in for com.roklenarcic.util.strings.AhoCorasickMap&lt;T&gt; (String overload on the GPU). */
+/** Drop-in for com.roklenarcic.util.strings.AhoCorasickMap&lt;T&gt; (both overloads on the GPU). */
 public class GpuAhoCorasickMap<T> implements StringMap<T>, AutoCloseable {
     final NativeAutomaton automaton;
     final List<T> values = new ArrayList<T>();
@@ -39,9 +39,28 @@ public class GpuAhoCorasickMap<T> implements StringMap<T>, AutoCloseable {
         }
     }
 
+    /** Chunked scan through acgpu_stream_*: the listener receives only the value; false stops scan and reading. */
     public void match(final Readable haystack, final ReadableMatchListener<T> listener) throws IOException {
-        // streaming overload: out of scope of the GPU path (SURVEY.md 8f); delegate to the reference class
-        throw new UnsupportedOperationException("use com.roklenarcic.util.strings.AhoCorasickMap for Readable input");
+        final java.nio.CharBuffer buf = java.nio.CharBuffer.allocate(1 << 22);
+        final long stream = automaton.openStream();
+        try {
+            boolean more = true;
+            while (more) {
+                buf.clear();
+                while (buf.hasRemaining() && (more = haystack.read(buf) != -1)) {
+                    // fill the chunk: a Readable may hand out a few characters at a time
+                }
+                buf.flip();
+                final int[] ids = NativeAutomaton.feed(stream, buf.array(), buf.limit(), !more);
+                for (int i = 0; i < ids.length; i++) {
+                    if (!listener.match(values.get(ids[i]))) {
+                        return;
+                    }
+                }
+            }
+        } finally {
+            NativeAutomaton.closeStream(stream);
+        }
     }
 
     public void close() {

@@ -28,6 +28,20 @@ final class NativeAutomaton implements AutoCloseable {
         return match(handle, haystack, withIds);
     }
 
+    /** acgpu_stream_*: the haystack arrives in chunks; returns a stream handle for {@link #feed}. */
+    long openStream() {
+        return streamOpen(handle);
+    }
+
+    /** keyword indices of the records that became decidable with this chunk, in the reference's listener-call order */
+    static int[] feed(long stream, char[] chunk, int length, boolean last) {
+        return streamFeed(stream, chunk, length, last);
+    }
+
+    static void closeStream(long stream) {
+        streamClose(stream);
+    }
+
     @Override
     public void close() {
         if (handle != 0) {
@@ -42,4 +56,10 @@ final class NativeAutomaton implements AutoCloseable {
     private static native int[] match(long handle, String haystack, boolean withIds);
 
     private static native void free(long handle);
+
+    private static native long streamOpen(long handle);
+
+    private static native int[] streamFeed(long stream, char[] chunk, int length, boolean last);
+
+    private static native void streamClose(long stream);
 }

@@ -98,3 +98,47 @@ JNIEXPORT void JNICALL Java_com_roklenarcic_util_strings_gpu_NativeAutomaton_fre
     (void)cls;
     acgpu_free((acgpu_automaton *)(intptr_t)handle);
 }
+
+/* ---- match(Readable, ReadableMatchListener<T>): acgpu_stream_* ---- */
+JNIEXPORT jlong JNICALL Java_com_roklenarcic_util_strings_gpu_NativeAutomaton_streamOpen(JNIEnv *env, jclass cls, jlong handle) {
+    (void)cls;
+    acgpu_stream *s = NULL;
+    int rc = acgpu_stream_open((const acgpu_automaton *)(intptr_t)handle, &s);
+    if (rc != ACGPU_OK) throw_new(env, rc == ACGPU_E_UNSUPPORTED ? "java/lang/UnsupportedOperationException" : "java/lang/IllegalStateException",
+                                  acgpu_strerror(rc));
+    return (jlong)(intptr_t)s;
+}
+
+JNIEXPORT jintArray JNICALL Java_com_roklenarcic_util_strings_gpu_NativeAutomaton_streamFeed(JNIEnv *env, jclass cls, jlong stream,
+                                                                                               jcharArray chunk, jint length,
+                                                                                               jboolean last) {
+    (void)cls;
+    acgpu_stream *s = (acgpu_stream *)(intptr_t)stream;
+    jchar *units = (*env)->GetCharArrayElements(env, chunk, NULL);
+    uint64_t cap = (uint64_t)length / 64 + 4096, n_out = 0;
+    int64_t base = 0;
+    int32_t *buf = (int32_t *)malloc(cap * ACGPU_REC_MAP);
+    int rc = acgpu_stream_feed(s, (const uint16_t *)units, (uint64_t)length, last ? 1 : 0, ACGPU_REC_MAP, buf, cap, &n_out, &base);
+    if (rc == ACGPU_E_OVERFLOW) { /* nothing was consumed: same feed, exact capacity */
+        cap = n_out;
+        buf = (int32_t *)realloc(buf, cap * ACGPU_REC_MAP);
+        rc = acgpu_stream_feed(s, (const uint16_t *)units, (uint64_t)length, last ? 1 : 0, ACGPU_REC_MAP, buf, cap, &n_out, &base);
+    }
+    (*env)->ReleaseCharArrayElements(env, chunk, units, JNI_ABORT);
+    jintArray out = NULL;
+    if (rc == ACGPU_OK) {
+        for (uint64_t i = 0; i < n_out; i++) buf[i] = buf[3 * i + 2]; /* the Readable listener only sees the value */
+        out = (*env)->NewIntArray(env, (jsize)n_out);
+        if (out) (*env)->SetIntArrayRegion(env, out, 0, (jsize)n_out, (const jint *)buf);
+    } else {
+        throw_new(env, "java/lang/IllegalStateException", acgpu_strerror(rc));
+    }
+    free(buf);
+    return out;
+}
+
+JNIEXPORT void JNICALL Java_com_roklenarcic_util_strings_gpu_NativeAutomaton_streamClose(JNIEnv *env, jclass cls, jlong stream) {
+    (void)env;
+    (void)cls;
+    acgpu_stream_close((acgpu_stream *)(intptr_t)stream);
+}

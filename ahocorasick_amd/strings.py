@@ -162,6 +162,65 @@ class Automaton:
         return int(n_out.value), rc, pd
 
 
+class Stream:
+    """acgpu_stream: the haystack arrives in chunks (match(Readable, ...)); feed() returns the records that have become
+    decidable as an (n, 2|3) int64 array with GLOBAL positions (units since the first feed)."""
+
+    def __init__(self, automaton, with_ids=True):
+        self._auto = automaton  # keeps the handle alive
+        self._kind = N.REC_MAP if with_ids else N.REC_SET
+        h = ctypes.c_void_p()
+        N.check(N.lib().acgpu_stream_open(automaton.handle, ctypes.byref(h)), "acgpu_stream_open")
+        self._h = h
+
+    def feed(self, units, final=False, cap=None):
+        u = np.ascontiguousarray(units, dtype=np.uint16)
+        n = int(u.size)
+        cols = self._kind // 4
+        if cap is None:
+            cap = max(4096, n // 64)
+        src = u if n else np.zeros(1, np.uint16)
+        while True:
+            out = np.empty((cap, cols), dtype=np.int32)
+            n_out, base = ctypes.c_uint64(0), ctypes.c_int64(0)
+            rc = N.lib().acgpu_stream_feed(self._h, _vp(src), n, 1 if final else 0, self._kind, _vp(out), cap,
+                                           ctypes.byref(n_out), ctypes.byref(base))
+            if rc == N.E_OVERFLOW:  # nothing was consumed: same feed, larger buffer
+                cap = int(n_out.value)
+                continue
+            N.check(rc, "acgpu_stream_feed")
+            r = out[:n_out.value].astype(np.int64)
+            r[:, :2] += base.value
+            return r
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            N.lib().acgpu_stream_close(h)
+
+    __del__ = close
+
+
+class ReadableMatchListener:
+    """S/ReadableMatchListener.java:3-9"""
+
+    def match(self, value):
+        raise NotImplementedError
+
+
+def _chunks(readable, chunk_chars):
+    """A Java Readable hands out characters until it returns -1; here: an object with read(n) -> str ('' at the end),
+    or any iterable of str / uint16 arrays."""
+    if hasattr(readable, "read"):
+        while True:
+            c = readable.read(chunk_chars)
+            if not c:
+                return
+            yield c
+    else:
+        yield from readable
+
+
 # ---- listener plumbing -----------------------------------------------------------------------------------
 
 class SetMatchListener:
@@ -220,14 +279,35 @@ class StringMap:
         self._auto = Automaton(self._MODE, self._keywords, bool(case_sensitive), word_chars=word_chars)
 
     def match(self, haystack, listener):
+        """match(String, MapMatchListener<T>) -- or, when `haystack` has read() / is an iterable of chunks,
+        match(Readable, ReadableMatchListener<T>) (S/StringMap.java:6-8)."""
         if haystack is None:
             raise TypeError("haystack is None")
+        if not isinstance(haystack, (str, np.ndarray)):
+            return self.match_readable(haystack, listener)
         recs = self._auto.match_host(utf16(haystack), with_ids=True)
         fn = _listener_fn(listener)
         vals = self._values
         for s, e, k in recs.tolist():
             if not fn(haystack, s, e, vals[k]):
                 break
+
+    def match_readable(self, readable, listener, chunk_chars=1 << 22):
+        """S/AhoCorasickMap.java:208-275, S/LongestMatchMap.java:203-286, S/WholeWordMatchMap.java:55-153: the listener
+        receives only the value; returning False stops the scan (and the reading)."""
+        fn = _listener_fn(listener)
+        vals = self._values
+        st = Stream(self._auto, with_ids=True)
+        try:
+            for chunk in _chunks(readable, chunk_chars):
+                for k in st.feed(utf16(chunk))[:, 2].tolist():
+                    if not fn(vals[k]):
+                        return
+            for k in st.feed(np.zeros(0, np.uint16), final=True)[:, 2].tolist():
+                if not fn(vals[k]):
+                    return
+        finally:
+            st.close()
 
     def find_all(self, haystack):
         """Convenience (not in the reference): the (n,3) int32 array of (start, end, keyword_index) records."""

@@ -180,6 +180,30 @@ int acgpu_match_device_begin(const acgpu_automaton *a, acgpu_shard *shard, int r
 int acgpu_match_device_end(const acgpu_automaton *a, acgpu_ticket *ticket, uint64_t *n_out, acgpu_profile *prof);
 
 /*
+ * Replaces StringMap.match(Readable, ReadableMatchListener<T>) (S/StringMap.java:6; S/AhoCorasickMap.java:208-275,
+ * S/LongestMatchMap.java:203-286, S/WholeWordMatchMap.java:55-153): the haystack arrives in chunks of any size (the
+ * reference reads it through a CharBuffer) and may be longer than a Java String.  Every feed returns the records that
+ * have become decidable, in the reference's call order; the concatenation over all feeds is what match(String) would
+ * deliver for the whole text (T/MapTest.java:178-188).  The facade passes record.keyword_id -> value to the listener
+ * (the Readable listener receives only the value) and may stop feeding when the listener returns false.
+ *  feed   : units = the next n_units of the haystack in HOST memory (may be 0); final != 0 marks the end of the
+ *           haystack, after which only close is valid.  Internally the stream keeps the few units a later chunk can
+ *           still change the answer for (ALL: max_keyword_len-1 units of left context; WHOLEWORD: one unit of context
+ *           plus the last max_keyword_len+1 units, whose words are decided by the next feed; LONGEST: the last
+ *           max_keyword_len-1 units plus the position at which the greedy chain continues).
+ *  out    : cap records of record_kind; start/end are int32 relative to *base (the global position, in units since
+ *           the first feed, that record coordinate 0 stands for).  On ACGPU_E_OVERFLOW nothing was consumed: *n_out
+ *           is the capacity to call the SAME feed again with.
+ *  carried units + n_units must stay below 2^31.
+ *  ACGPU_E_UNSUPPORTED: WHOLEWORD with a word-character table that is not fold-consistent (acgpu_info).
+ */
+typedef struct acgpu_stream acgpu_stream;
+int acgpu_stream_open(const acgpu_automaton *a, acgpu_stream **out);
+int acgpu_stream_feed(acgpu_stream *s, const uint16_t *units, uint64_t n_units, int final, int record_kind, void *out,
+                      uint64_t cap, uint64_t *n_out, int64_t *base);
+void acgpu_stream_close(acgpu_stream *s);
+
+/*
  * Synthetic haystack generator of the benchmark: unit i of the stream is
  * table[((z_i >> 32) * table_len) >> 32] with z_i = SplitMix64 output for counter
  * start_index + i of `seed` (see ahocorasick_amd/synth.py).  d_dst: device pointer.

@@ -764,6 +764,85 @@ static void match_wholeword(const oracle *o, const uint16_t *hay, int32_t len, m
     }
 }
 
+/* ---- match(Readable, ReadableMatchListener<T>): the haystack arrives through a CharBuffer of charBufferSize units.
+ * The listener only receives the value (S/ReadableMatchListener.java:7); start/end are reported as -1 here.
+ * AhoCorasickMap.match(Readable) (S/AhoCorasickMap.java:208-275) and LongestMatchMap.match(Readable)
+ * (S/LongestMatchMap.java:203-286) are the String loops with buf.get() in place of charAt(idx), so they are
+ * restated by calling those loops; WholeWordMatchMap.match(Readable) (S/WholeWordMatchMap.java:55-153) has its own
+ * shape -- scroll() (:325-339) with FOLDED word-character lookups in case-insensitive mode -- restated literally
+ * below, including the buffer refills. */
+typedef struct {
+    const uint16_t *hay;
+    int32_t len, next;      /* the Readable: next unit to hand out */
+    int32_t cap;            /* CharBuffer capacity */
+    int32_t base, pos, lim; /* buffer window [base, base+lim) of hay, position pos (relative) */
+} CharBuf;
+
+static int cb_read(CharBuf *b) { /* haystack.read(buf) after buf.clear(), then buf.flip(); -1 at the end */
+    if (b->next >= b->len) return -1;
+    int32_t n = b->len - b->next < b->cap ? b->len - b->next : b->cap;
+    b->base = b->next;
+    b->next += n;
+    b->pos = 0;
+    b->lim = n;
+    return n;
+}
+
+/* scroll: S/WholeWordMatchMap.java:325-339.  Returns 1 at the end of the haystack. */
+static int ww_scroll(const oracle *o, CharBuf *b, int wordChars) {
+    for (;;) {
+        while (b->pos < b->lim) {
+            uint16_t c = b->hay[b->base + b->pos++];
+            if (!o->caseSensitive) c = o->lower[c];
+            if ((o->wordChars[c] != 0) != (wordChars != 0)) {
+                b->pos--;
+                return 0;
+            }
+        }
+        if (cb_read(b) == -1) return 1;
+    }
+}
+
+static void match_wholeword_readable(const oracle *o, const uint16_t *hay, int32_t len, int32_t bufsize, match_listener l,
+                                     void *ctx) {
+    const Node *root = o->root;
+    const Node *currentNode = root;
+    CharBuf b = {hay, len, 0, bufsize, 0, 0, 0};
+    int done = 0;
+    while (!done && cb_read(&b) != -1) {
+        while (b.pos < b.lim) {
+            uint16_t c = b.hay[b.base + b.pos++];
+            if (!o->caseSensitive) c = o->lower[c];
+            const Node *nextNode = get_transition(currentNode, c);
+            if (nextNode == NULL) {
+                if (!o->wordChars[c]) {
+                    if (currentNode->matchLength != 0) {
+                        if (!l(ctx, -1, -1, currentNode->value)) return;
+                    }
+                } else {
+                    if (ww_scroll(o, &b, 1)) {
+                        currentNode = root;
+                        done = 1;
+                        break;
+                    }
+                }
+                currentNode = root;
+                if (ww_scroll(o, &b, 0)) {
+                    done = 1;
+                    break;
+                }
+            } else {
+                currentNode = nextNode;
+            }
+        }
+    }
+    if (currentNode->matchLength != 0) l(ctx, -1, -1, currentNode->value);
+}
+
+/* values only, in listener-call order; bufsize = charBufferSize */
+int64_t oracle_match_readable(const oracle *o, const uint16_t *hay, int32_t len, int32_t bufsize, int32_t *out, int64_t cap,
+                              int64_t stop_after);
+
 static void match_dispatch(const oracle *o, const uint16_t *hay, int32_t len, match_listener l, void *ctx) {
     switch (o->family) {
     case FAM_AC: match_ac(o, hay, len, l, ctx); break;
@@ -795,6 +874,14 @@ static int collect_listener(void *ctx, int32_t start, int32_t end, int32_t value
 int64_t oracle_match(const oracle *o, const uint16_t *hay, int32_t len, int32_t *out, int64_t cap, int64_t stop_after) {
     Collect c = {out, cap, 0, stop_after};
     match_dispatch(o, hay, len, collect_listener, &c);
+    return c.n;
+}
+
+int64_t oracle_match_readable(const oracle *o, const uint16_t *hay, int32_t len, int32_t bufsize, int32_t *out, int64_t cap,
+                              int64_t stop_after) {
+    Collect c = {out, cap, 0, stop_after};
+    if (o->family == FAM_WHOLEWORD) match_wholeword_readable(o, hay, len, bufsize > 0 ? bufsize : 1024, collect_listener, &c);
+    else match_dispatch(o, hay, len, collect_listener, &c);
     return c.n;
 }
 

@@ -49,6 +49,8 @@ def lib():
         L.oracle_free.argtypes = [vp]
         L.oracle_match.restype = i64
         L.oracle_match.argtypes = [vp, vp, i32, vp, i64, i64]
+        L.oracle_match_readable.restype = i64
+        L.oracle_match_readable.argtypes = [vp, vp, i32, i32, vp, i64, i64]
         L.oracle_match_count.restype = i64
         L.oracle_match_count.argtypes = [vp, vp, i32]
         L.oracle_num_nodes.restype = i64
@@ -129,6 +131,20 @@ class Oracle:
             cnt = L.oracle_match(self._h, _ptr(hay), n, _ptr(out), cap, stop_after)
             if cnt <= cap:
                 return out[:cnt].copy()
+            cap = int(cnt)
+
+    def match_readable(self, haystack, bufsize=1024, stop_after=-1):
+        """match(Readable, ReadableMatchListener): the keyword indices (values) in listener-call order."""
+        hay = utf16(haystack)
+        n = int(hay.size)
+        if n == 0:
+            hay = np.zeros(1, np.uint16)
+        cap = max(1024, n // 4)
+        while True:
+            out = np.empty((cap, 3), dtype=np.int32)
+            cnt = lib().oracle_match_readable(self._h, _ptr(hay), n, bufsize, _ptr(out), cap, stop_after)
+            if cnt <= cap:
+                return out[:cnt, 2].copy()
             cap = int(cnt)
 
     def count(self, haystack_units):

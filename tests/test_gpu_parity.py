@@ -684,3 +684,83 @@ def test_sharded_matcher_native_scan_equals_whole_text(family):
     assert got.shape == want.shape and (got == want.astype(np.int64)).all()
     if family == "longest":
         assert repairs > 0  # some shard boundary fell inside a match: the window repair ran on the device
+
+
+# ---- match(Readable, ReadableMatchListener): acgpu_stream_* ------------------------------------------------------------
+
+def _stream_all(auto, hay, cuts, with_ids=True):
+    from ahocorasick_amd import Stream
+    st = Stream(auto, with_ids=with_ids)
+    parts = []
+    edges = [0] + list(cuts) + [hay.size]
+    for i, (lo, hi) in enumerate(zip(edges[:-1], edges[1:])):
+        parts.append(st.feed(hay[lo:hi], final=(i == len(edges) - 2), cap=8))  # cap=8: the overflow/retry protocol
+    st.close()
+    return np.concatenate(parts)
+
+
+@pytest.mark.parametrize("family", ["ac", "longest", "wholeword"])
+@pytest.mark.parametrize("seed", range(3))
+def test_stream_feeds_equal_whole_text(family, seed):
+    """T/MapTest.java:178-188: the Readable overload reports what the String overload reports -- here with positions,
+    for chunkings that include empty chunks, one-unit chunks and chunks shorter than the keywords."""
+    rng = np.random.default_rng(300 + seed)
+    if family == "wholeword":
+        table = np.array([ord(c) for c in "abcdE -,"] + [0x00E9, 0x00C9], dtype=np.uint16)
+        kws = synth.random_keywords(61 + seed, 200, 1, 9, table=table[:5])
+        hay = synth.haystack(71 + seed, 60000, table=table)
+        auto = Automaton(N.MODE_WHOLEWORD, kws, False, word_chars=WORD)
+        want = Oracle(FAM_WHOLEWORD, kws, case_sensitive=False, lower=LOWER, word_chars=WORD).match(hay)
+    elif family == "longest":
+        kws = synth.random_keywords(62 + seed, 300, 2, 30, table=synth.ALPHA_LOWER[:2])
+        hay = synth.haystack(72 + seed, 60000, table=synth.ALPHA_LOWER[:2])
+        auto = Automaton(N.MODE_LONGEST, kws, True)
+        want = Oracle(FAM_LONGEST, kws).match(hay)
+    else:
+        kws = synth.random_keywords(63 + seed, 400, 2, 11, table=synth.ALPHA_LOWER[:8])
+        hay = synth.haystack(73 + seed, 60000, table=synth.ALPHA_LOWER[:8])
+        auto = Automaton(N.MODE_ALL, kws, True)
+        want = Oracle(FAM_AC, kws).match(hay)
+    chunkings = [[], [30000], sorted(rng.integers(0, hay.size, 12).tolist()),
+                 [1, 2, 3, 3, 4, 10, 11, 40, 5000, 5001, 59999], list(range(100, 400, 7))]
+    for cuts in chunkings:
+        got = _stream_all(auto, hay, cuts)
+        assert got.shape == want.shape and (got == want.astype(np.int64)).all(), (family, cuts[:5])
+    got2 = _stream_all(auto, hay, chunkings[2], with_ids=False)
+    assert (got2 == want[:, :2].astype(np.int64)).all()
+
+
+def test_readable_overload_values_and_early_stop():
+    import io
+    m = AhoCorasickMap(["he", "she", "hers"], ["HE", "SHE", "HERS"], True)
+    seen = []
+    m.match(io.StringIO("ushers and she"), lambda v: seen.append(v) or True)  # Readable: value-only listener
+    assert seen == ["SHE", "HE", "HERS", "SHE", "HE"]
+    seen = []
+    m.match_readable(iter(["ush", "", "ers and", " she"]), lambda v: seen.append(v) or len(seen) < 2)
+    assert seen == ["SHE", "HE"]
+    w = WholeWordMatchMap(["Foo", "bar-baz"], [1, 2], False)
+    seen = []
+    w.match(io.StringIO("foo FOO, bar-baz! foobar"), lambda v: seen.append(v) or True)
+    assert seen == [1, 1, 2]
+    lo = LongestMatchMap(["a", "ab", "abc", "bcd"], [1, 2, 3, 4], True)
+    seen = []
+    lo.match_readable(iter(["ab", "cd", "a"]), lambda v: seen.append(v) or True)
+    assert [v - 1 for v in seen] == Oracle(FAM_LONGEST, ["a", "ab", "abc", "bcd"]).match_readable("abcda").tolist() == [2, 0]
+    # the oracle's Readable restatement agrees on a larger case
+    kws = synth.random_keywords(5, 300, 2, 8, table=synth.ALPHA_LOWER[:6])
+    hay = synth.haystack(6, 20000, table=synth.ALPHA_LOWER[:6])
+    big = AhoCorasickMap(kws, _ids(len(kws)), True)
+    seen = []
+    big.match_readable(iter([hay[:7777], hay[7777:]]), lambda v: seen.append(v) or True)
+    assert seen == Oracle(FAM_AC, kws).match_readable(hay).tolist()
+
+
+def test_stream_fold_inconsistent_wholeword_is_refused():
+    from ahocorasick_amd import Stream
+    wc = WORD.copy()
+    wc[ord("a")] = 0  # 'A' is a word character, its lower case is not: the reference's Readable loop is history dependent
+    a = Automaton(N.MODE_WHOLEWORD, ["B"], False, word_chars=wc)
+    with pytest.raises(N.AcgpuError) as e:
+        Stream(a)
+    assert e.value.code == N.E_UNSUPPORTED

@@ -228,3 +228,27 @@ def test_wordhash_tables_reproduce_oracle(fixtures):
             a = Automaton(N.MODE_WHOLEWORD, kws, cs, word_chars=WORD)
             want = Oracle(FAM_WHOLEWORD, kws, case_sensitive=cs, lower=LOWER, word_chars=WORD).match(hay).tolist()
             assert _simulate_wholeword(a, hay, WORD, cs) == want, (it, cs)
+
+
+def test_stream_argument_checks_without_a_device():
+    a = Automaton(N.MODE_ALL, ["ab"], True)
+    L = N.lib()
+    h = ctypes.c_void_p()
+    assert L.acgpu_stream_open(None, ctypes.byref(h)) == N.E_INVALID
+    assert L.acgpu_stream_open(a.handle, ctypes.byref(h)) == N.OK and h
+    n_out, base = ctypes.c_uint64(0), ctypes.c_int64(0)
+    buf = np.zeros(4, np.uint16)
+    out = np.zeros((4, 3), np.int32)
+    vp = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+    # record kind, missing pointers
+    assert L.acgpu_stream_feed(h, vp(buf), 4, 0, 7, vp(out), 4, ctypes.byref(n_out), ctypes.byref(base)) == N.E_INVALID
+    assert L.acgpu_stream_feed(h, None, 4, 0, N.REC_MAP, vp(out), 4, ctypes.byref(n_out), ctypes.byref(base)) == N.E_INVALID
+    # an empty, non-final feed needs no device
+    assert L.acgpu_stream_feed(h, None, 0, 0, N.REC_MAP, vp(out), 4, ctypes.byref(n_out), ctypes.byref(base)) == N.OK
+    assert n_out.value == 0
+    # a real feed fails loudly without a GPU (no CPU fallback)
+    import torch
+    if not torch.cuda.is_available():
+        rc = L.acgpu_stream_feed(h, vp(buf), 4, 1, N.REC_MAP, vp(out), 4, ctypes.byref(n_out), ctypes.byref(base))
+        assert rc in (N.E_NODEVICE, N.E_HIP)
+    L.acgpu_stream_close(h)

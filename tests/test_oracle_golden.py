@@ -122,3 +122,39 @@ def test_reference_shaped_nodes_used():
     kws = synth.random_keywords(7, 2000, 2, 6, table=np.concatenate([synth.ALPHA_LOWER, np.arange(0x4E00, 0x4F00, dtype=np.uint16)]))
     o = Oracle(FAM_AC, kws)
     assert o.num_nodes(1) > 0 and o.num_nodes(2) > 0
+
+
+# ---- match(Readable, ReadableMatchListener): T/MapTest.java:178-188 pins "same number of matches as match(String)" ----
+
+def test_readable_path_reports_the_string_paths_values(fixtures):
+    from tests.helpers import LOWER, WORD, fixture_inputs
+    for fx in fixtures:
+        hay, kws = fixture_inputs(fx)
+        if "keywords_gen" in fx:
+            continue
+        for fam, key in ((FAM_AC, "AC"), (FAM_LONGEST, "L"), (FAM_WHOLEWORD, "WW")):
+            if fx[key] == "IllegalArgumentException":
+                continue
+            o = Oracle(fam, kws, word_chars=WORD if fam == FAM_WHOLEWORD else None)
+            want = [r[2] for r in fx[key]]
+            for bufsize in (1, 3, 4096):
+                assert o.match_readable(hay, bufsize).tolist() == want, (fx["name"], key, bufsize)
+
+
+def test_readable_wholeword_scroll_and_refills_fuzz():
+    """The Readable WholeWord loop (scroll(), buffer refills, folded lookups) gives the String loop's values whenever
+    the word-character table is fold-consistent (always in case-sensitive mode and with the default table)."""
+    from tests.helpers import LOWER, WORD, rand_case
+    rng = np.random.default_rng(17)
+    alpha = [ord(c) for c in "abAB -_.9"] + [0x00E9, 0x00C9, 0x3002]
+    for it in range(150):
+        hay, kws = rand_case(rng, alpha, int(rng.integers(1, 30)), 6, int(rng.integers(0, 200)))
+        kws = [k for k in kws if all(WORD[c] for c in k.tolist())] or [np.array([97], np.uint16)]
+        for cs in (True, False):
+            o = Oracle(FAM_WHOLEWORD, kws, case_sensitive=cs, lower=LOWER, word_chars=WORD)
+            want = o.match(hay)[:, 2].tolist()
+            for bufsize in (1, 2, 5, 64):
+                assert o.match_readable(hay, bufsize).tolist() == want, (it, cs, bufsize)
+    # early stop: the listener's false ends the scan
+    o = Oracle(FAM_WHOLEWORD, ["ab", "b"], word_chars=WORD)
+    assert o.match_readable("ab b ab", 2, stop_after=2).tolist() == [0, 1]
