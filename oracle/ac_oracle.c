@@ -34,6 +34,7 @@
 #define FAM_AC 0        /* S/AhoCorasickSet.java, S/AhoCorasickMap.java       */
 #define FAM_LONGEST 1   /* S/LongestMatchSet.java, S/LongestMatchMap.java     */
 #define FAM_WHOLEWORD 2 /* S/WholeWordMatchSet.java, S/WholeWordMatchMap.java */
+#define FAM_SHORTEST 3  /* S/ShortestMatchSet.java, S/ShortestMatchMap.java   */
 
 #define ORACLE_OK 0
 #define ORACLE_E_ILLEGAL_ARGUMENT (-2) /* java.lang.IllegalArgumentException */
@@ -176,6 +177,27 @@ static Node *hm_get_or_add_child(oracle *o, Node *n, uint16_t key) {
         }
     } while (currentSlot != defaultSlot);
     return NULL; /* IllegalStateException in the reference; unreachable */
+}
+
+/* clear(): S/ShortestMatchSet.java:278-283 (hashmap), :447-450 (range) */
+static int node_clear(Node *n) {
+    if (n->isRange) {
+        free(n->children);
+        n->children = NULL;
+        n->size = 0;
+    } else {
+        Node **c = (Node **)calloc(1, sizeof(Node *));
+        uint16_t *k = (uint16_t *)calloc(1, sizeof(uint16_t));
+        if (!c || !k) { free(c); free(k); return -1; }
+        free(n->children);
+        free(n->keys);
+        n->children = c;
+        n->keys = k;
+        n->capacity = 1;
+        n->modulusMask = 0;
+        n->numEntries = 0;
+    }
+    return 0;
 }
 
 static inline int node_is_empty(const Node *n) { /* :292-294, :463-465 */
@@ -322,6 +344,23 @@ static int visit_fail_and_outputs(oracle *o, NQueue *queue, Node *parent, uint16
                 parentFail = parentFail->failTransition;
             }
         } while (value->failTransition == NULL);
+        if (o->family == FAM_SHORTEST) {
+            /* S/ShortestMatchSet.java:104-118 (Map also copies the value, S/ShortestMatchMap.java:112-125): a node
+             * without an own match takes the nearest fail ancestor's; a node with any match loses its transitions. */
+            if (value->matchLength == 0) {
+                Node *fail = value->failTransition;
+                while (fail != o->root && fail->matchLength == 0) fail = fail->failTransition;
+                value->matchLength = fail->matchLength;
+                value->value = fail->value;
+            }
+            if (value->matchLength != 0) {
+                if (node_clear(value)) return -1;
+                value->failTransition = o->root;
+            }
+            if (!node_is_empty(value))
+                if (q_push(queue, value)) return -1;
+            return 0;
+        }
         /* output compression :110-121 */
         Node *fail = value->failTransition;
         while (fail != o->root && fail->matchLength == 0) fail = fail->failTransition;
@@ -436,11 +475,15 @@ int oracle_build(int family, const uint16_t *kw, const uint64_t *off, uint32_t n
         }
         if (we - ws > 0) {
             Node *cur = o->root;
+            int shadowed = 0;
             for (int64_t i = ws; i < we; i++) {
                 uint16_t c = caseSensitive ? w[i] : o->lower[w[i]];
                 cur = hm_get_or_add_child(o, cur, c);
                 if (!cur) { oracle_free(o); return ORACLE_E_NOMEM; }
+                /* S/ShortestMatchSet.java:33-37: a keyword already on the path (or this same keyword) matches first */
+                if (family == FAM_SHORTEST && cur->matchLength != 0) { shadowed = 1; break; }
             }
+            if (shadowed) continue;
             cur->matchLength = (int32_t)(we - ws);
             cur->value = (int32_t)k;
         }
@@ -843,8 +886,38 @@ static void match_wholeword_readable(const oracle *o, const uint16_t *hay, int32
 int64_t oracle_match_readable(const oracle *o, const uint16_t *hay, int32_t len, int32_t bufsize, int32_t *out, int64_t cap,
                               int64_t stop_after);
 
+/* ShortestMatchSet.match: S/ShortestMatchSet.java:193-262 (Map: S/ShortestMatchMap.java:294-372).  The current node
+ * lags one unit behind: a match found on it is reported when the next unit is looked at, then matching restarts at
+ * the root with that unit. */
+static void match_shortest(const oracle *o, const uint16_t *hay, int32_t len, match_listener l, void *ctx) {
+    const Node *root = o->root;
+    const Node *currentNode = root;
+    int32_t currentNodeMatchLength = currentNode->matchLength;
+    int32_t currentNodeMatchValue = currentNode->value;
+    int32_t idx = 0;
+    while (idx < len) {
+        const uint16_t c = o->caseSensitive ? hay[idx] : o->lower[hay[idx]];
+        if (currentNodeMatchLength != 0) {
+            if (!l(ctx, idx - currentNodeMatchLength, idx, currentNodeMatchValue)) return;
+            currentNode = get_transition(root, c);
+        } else {
+            const Node *nextNode = get_transition(currentNode, c);
+            while (nextNode == NULL) {
+                currentNode = currentNode->failTransition;
+                nextNode = get_transition(currentNode, c);
+            }
+            currentNode = nextNode;
+        }
+        currentNodeMatchLength = currentNode->matchLength;
+        currentNodeMatchValue = currentNode->value;
+        ++idx;
+    }
+    if (currentNodeMatchLength != 0) l(ctx, idx - currentNodeMatchLength, idx, currentNodeMatchValue);
+}
+
 static void match_dispatch(const oracle *o, const uint16_t *hay, int32_t len, match_listener l, void *ctx) {
     switch (o->family) {
+    case FAM_SHORTEST: match_shortest(o, hay, len, l, ctx); break;
     case FAM_AC: match_ac(o, hay, len, l, ctx); break;
     case FAM_LONGEST: match_longest(o, hay, len, l, ctx); break;
     default: match_wholeword(o, hay, len, l, ctx); break;

@@ -5,6 +5,9 @@ oracle/ac_oracle.c:
   AC-all   : T/AhoCorasickTest.java:28-38   (every occurrence of every keyword)
   Longest  : T/LongestMatchTest.java:30-42  (greedy leftmost-longest, keywords sorted by length desc :50-58)
   WholeWord: T/WholeWordMatchTest.java:60-90 (maximal word-char runs equal to a keyword)
+  Shortest : T/ShortestMatchTest.java:30-42 (count only: first keyword, shortest first, matching at each position) and,
+             independently, the closed form "accept a match of the all-matches list iff it starts at or after the end of
+             the last accepted one" (earliest end first, longest among equal ends)
 plus the emission order documented in SURVEY.md Appendix A (end ascending, longest first).
 Pure-Python loops: small cases only.
 """
@@ -113,4 +116,48 @@ def wholeword(haystack, keywords, word_chars, case_sensitive=True, lower=None):
         if idx is not None:
             out.append((i, j, idx))
         i = j
+    return out
+
+
+def shortest_test_count(haystack, keywords):
+    """T/ShortestMatchTest.java:30-42 with prepareKeywords (:51-59: keywords sorted by length, stable)."""
+    h = _units(haystack)
+    needles = [_units(k) for k in sorted([k for k in keywords], key=len)]
+    count = 0
+    i = 0
+    while i < len(h):
+        for nd in needles:
+            if i + len(nd) <= len(h) and h[i:i + len(nd)] == nd:
+                count += 1
+                i += len(nd) - 1
+                break
+        i += 1
+    return count
+
+
+def shortest(haystack, keywords, case_sensitive=True, lower=None):
+    """ShortestMatchSet/Map in closed form: matching restarts at the end of every reported match, so a keyword
+    occurrence is reported iff it starts at or after the end of the previously reported one, taking occurrences by
+    increasing end and, at equal end, the longest first.  Value: the FIRST input keyword producing the folded string
+    (a later duplicate finds the node already matched and is skipped, S/ShortestMatchMap.java:47-49)."""
+    lo = None if case_sensitive else lower
+    h = _fold(_units(haystack), lo)
+    d = {}
+    for i, k in enumerate(keywords):
+        if k is None:
+            continue
+        u = _fold(_units(k), lo)
+        if len(u) > 0 and u not in d:
+            d[u] = i
+    lens = sorted({len(k) for k in d}, reverse=True)
+    out = []
+    s = 0
+    for end in range(1, len(h) + 1):
+        for L in lens:
+            if L <= end and end - L >= s:
+                idx = d.get(h[end - L:end])
+                if idx is not None:
+                    out.append((end - L, end, idx))
+                    s = end
+                    break
     return out

@@ -16,7 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
 
-FAM_AC, FAM_LONGEST, FAM_WHOLEWORD = 0, 1, 2
+FAM_AC, FAM_LONGEST, FAM_WHOLEWORD, FAM_SHORTEST = 0, 1, 2, 3
 E_ILLEGAL_ARGUMENT = -2
 
 
@@ -91,7 +91,7 @@ def _ptr(a):
 
 
 class Oracle:
-    """One reference matcher instance (family = FAM_AC / FAM_LONGEST / FAM_WHOLEWORD)."""
+    """One reference matcher instance (family = FAM_AC / FAM_LONGEST / FAM_WHOLEWORD / FAM_SHORTEST)."""
 
     def __init__(self, family, keywords, case_sensitive=True, lower=None, word_chars=None, packed=None):
         L = lib()

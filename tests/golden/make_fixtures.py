@@ -3,7 +3,8 @@
 Inputs are the deterministic scenarios of the reference's own tests (haystack + keywords, typed in here as DATA:
 T/SetTest.java:61-130 mirrored in T/MapTest.java:68-131, README worked examples R/README.md:88-124).  Expected
 outputs are computed with oracle/brute.py, i.e. with the brute-force formulas the reference tests themselves
-assert against (T/AhoCorasickTest.java:28-38, T/LongestMatchTest.java:30-42, T/WholeWordMatchTest.java:73-90)
+assert against (T/AhoCorasickTest.java:28-38, T/LongestMatchTest.java:30-42, T/WholeWordMatchTest.java:73-90,
+T/ShortestMatchTest.java:30-42)
 plus the documented emission order.  The reference (Java) cannot be executed in this image; see DESIGN.md.
 
 Run:  python tests/golden/make_fixtures.py
@@ -50,6 +51,11 @@ def main():
         e = {"name": name, "source": src, "haystack": hay, "keywords": kws}
         e["AC"] = [list(m) for m in brute.ac_all(hay, kws)]
         e["L"] = [list(m) for m in brute.longest(hay, kws)]
+        # ShortestMatchTest extends SetTest and sorts the keywords by length before building (T/ShortestMatchTest.java:51-59)
+        skws = sorted(kws, key=len)
+        e["S_keywords"] = skws
+        e["S_count"] = brute.shortest_test_count(hay, kws)
+        e["S"] = [list(m) for m in brute.shortest(hay, skws)]
         try:
             e["WW"] = [list(m) for m in brute.wholeword(hay, kws, wc)]
         except brute.NonWordCharacters:
@@ -59,7 +65,7 @@ def main():
     out.append({"name": "fullNode", "source": "T/SetTest.java:72-79", "haystack_units": [0, 0xFFFF, 0xFFFE],
                 "keywords_gen": "all_single_units",
                 "AC": [[0, 1, 0], [1, 2, 0xFFFF], [2, 3, 0xFFFE]], "L": [[0, 1, 0], [1, 2, 0xFFFF], [2, 3, 0xFFFE]],
-                "WW": "IllegalArgumentException"})
+                "WW": "IllegalArgumentException", "S_count": 3, "S": [[0, 1, 0], [1, 2, 0xFFFF], [2, 3, 0xFFFE]]})
     with open(os.path.join(HERE, "reference_fixtures.json"), "w") as f:
         json.dump(out, f, indent=0, ensure_ascii=True)
     print("wrote", len(out), "fixtures")

@@ -158,3 +158,34 @@ def test_readable_wholeword_scroll_and_refills_fuzz():
     # early stop: the listener's false ends the scan
     o = Oracle(FAM_WHOLEWORD, ["ab", "b"], word_chars=WORD)
     assert o.match_readable("ab b ab", 2, stop_after=2).tolist() == [0, 1]
+
+
+# ---- ShortestMatchSet / ShortestMatchMap (S/ShortestMatchSet.java) ------------------------------------------------------
+
+def test_shortest_fixtures_and_reference_test_counts(fixtures):
+    from oracle.oracle import FAM_SHORTEST
+    for fx in fixtures:
+        hay, kws = fixture_inputs(fx)
+        if "keywords_gen" not in fx:
+            kws = fx["S_keywords"]  # T/ShortestMatchTest.java:51-59 sorts the keywords by length
+        got = _as_list(Oracle(FAM_SHORTEST, kws).match(hay))
+        assert got == fx["S"], fx["name"]
+        assert len(got) == fx["S_count"], fx["name"]  # the count T/ShortestMatchTest.java:30-42 expects
+
+
+def test_shortest_literal_restatement_equals_closed_form_fuzz():
+    """Insertion order (longer keyword before its prefix), duplicates (first value wins), inherited suffix matches,
+    case folding: the literal restatement of the constructor and the lagging match loop against the closed form."""
+    from oracle.oracle import FAM_SHORTEST
+    rng = np.random.default_rng(23)
+    for it in range(400):
+        alpha = [[97, 98], [97, 98, 99], [97, 98, 65, 66, 0x00E9, 0x00C9]][it % 3]
+        hay, kws = rand_case(rng, alpha, int(rng.integers(1, 25)), int(rng.choice([2, 4, 7])), int(rng.integers(0, 120)))
+        for cs in (True, False):
+            got = _as_list(Oracle(FAM_SHORTEST, kws, case_sensitive=cs, lower=LOWER).match(hay))
+            want = [list(m) for m in brute.shortest(hay, kws, case_sensitive=cs, lower=LOWER)]
+            assert got == want, (it, cs)
+    # README-style example: the earliest END wins, not the leftmost start (S/ShortestMatchSet.java:8-9)
+    assert _as_list(Oracle(FAM_SHORTEST, ["abcd", "bc", "d"]).match("abcd")) == [[1, 3, 1], [3, 4, 2]]
+    # early stop
+    assert len(Oracle(FAM_SHORTEST, ["a"]).match("aaaa", stop_after=2)) == 2
