@@ -4,9 +4,9 @@ The product is ahocorasick_amd/lib/libacgpu.so (C ABI: include/acgpu.h; HIP kern
 This package is the host-side mirror of the reference's API on top of it.  No CPU fallback exists.
 """
 from .strings import (AhoCorasickMap, AhoCorasickSet, Automaton, IllegalArgumentException, LongestMatchMap,
-                      LongestMatchSet, MapMatchListener, ReadableMatchListener, SetMatchListener, Stream, StringMap,
+                      LongestMatchSet, MapMatchListener, ReadableMatchListener, SetMatchListener, ShortestMatchMap, ShortestMatchSet, Stream, StringMap,
                       StringSet, WholeWordMatchMap, WholeWordMatchSet, utf16)
 
 __all__ = ["AhoCorasickSet", "AhoCorasickMap", "LongestMatchSet", "LongestMatchMap", "WholeWordMatchSet",
-           "WholeWordMatchMap", "StringSet", "StringMap", "SetMatchListener", "MapMatchListener", "ReadableMatchListener", "Stream", "Automaton",
+           "WholeWordMatchMap", "ShortestMatchSet", "ShortestMatchMap", "StringSet", "StringMap", "SetMatchListener", "MapMatchListener", "ReadableMatchListener", "Stream", "Automaton",
            "IllegalArgumentException", "utf16"]

@@ -67,6 +67,7 @@ struct DeviceState {
     // scratch pool (one in-flight match per automaton and device)
     DevBuf counter, chunk_counts, offsets, scan_tmp, scratch, chain, lenbuf, statebuf;
     DevBuf stage_hay, stage_out; // acgpu_match_u16 staging
+    DevBuf short_recs, short_nxt, short_tmp, short_mark; // SHORTEST: all-matches list + selection scratch
     unsigned long long *h_counter = nullptr; // pinned
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     Ticket tickets[4];
@@ -74,6 +75,7 @@ struct DeviceState {
         for (void *p : table_allocs) (void)hipFree(p);
         counter.release(); chunk_counts.release(); offsets.release(); scan_tmp.release(); scratch.release();
         chain.release(); lenbuf.release(); statebuf.release(); stage_hay.release(); stage_out.release();
+        short_recs.release(); short_nxt.release(); short_tmp.release(); short_mark.release();
         if (h_counter) (void)hipHostFree(h_counter);
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         for (auto &tk : tickets) {
@@ -511,6 +513,62 @@ int match_wholeword(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int rec
     return *n_out > cap ? ACGPU_E_OVERFLOW : ACGPU_OK;
 }
 
+// SHORTEST-mode pipeline on one shard: the AhoCorasick pipeline into an internal buffer, then the greedy selection.
+int match_shortest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_kind, void *d_out, uint64_t cap,
+                   uint64_t *n_out, hipStream_t stream, acgpu_profile *prof) {
+    const int64_t entry = sh->chain_entry > 0 ? sh->chain_entry : 0;
+    sh->chain_exit = entry;
+    int rc;
+    uint64_t m = 0;
+    // what the buffer already holds (its size includes 16 spare bytes), or a first guess
+    uint64_t acap = std::max<uint64_t>(d.short_recs.bytes > 16 ? (d.short_recs.bytes - 16) / ACGPU_REC_MAP : 0,
+                                       (sh->own_end - sh->own_begin) / 32 + (1 << 16));
+    acgpu_profile all_prof;
+    for (;;) { // all matches (end ascending, longest first) with keyword ids; retried once with the exact capacity
+        if ((rc = d.short_recs.ensure(acap * ACGPU_REC_MAP + 16))) return rc;
+        rc = match_all(a, d, sh, ACGPU_REC_MAP, d.short_recs.p, acap, &m, stream, prof ? &all_prof : nullptr);
+        if (rc == ACGPU_E_OVERFLOW) {
+            acap = m;
+            continue;
+        }
+        if (rc != ACGPU_OK) return rc;
+        break;
+    }
+    if (prof) *prof = all_prof;
+    *n_out = 0;
+    if (m == 0) return ACGPU_OK;
+    if (m >= 0xfffffff0ull) return ACGPU_E_UNSUPPORTED;
+    const uint32_t M = (uint32_t)m;
+    if ((rc = d.short_nxt.ensure(((size_t)M + 1) * 4))) return rc;
+    if ((rc = d.short_tmp.ensure(((size_t)M + 1) * 4))) return rc;
+    if ((rc = d.short_mark.ensure(((size_t)M + 1) * 4))) return rc;
+    if ((rc = d.offsets.ensure((size_t)M * 8))) return rc;
+    if ((rc = d.scan_tmp.ensure(((size_t)M / 2048 + 2) * 8))) return rc;
+    if ((rc = d.counter.ensure(64))) return rc;
+    if (prof) HIP_TRY(hipEventRecord(d.ev[0], stream));
+    HIP_TRY(launch_shortest_select((const int32_t *)d.short_recs.p, M, entry, (uint32_t *)d.short_nxt.p,
+                                   (uint32_t *)d.short_tmp.p, (uint32_t *)d.short_mark.p, stream));
+    HIP_TRY(launch_exclusive_scan((const uint32_t *)d.short_mark.p, M, (uint64_t *)d.offsets.p, (uint64_t *)d.scan_tmp.p, stream));
+    const uint64_t *d_total = (const uint64_t *)d.scan_tmp.p + scan_tiles_for(M);
+    HIP_TRY(launch_shortest_emit((const int32_t *)d.short_recs.p, M, (const uint32_t *)d.short_mark.p,
+                                 (const uint64_t *)d.offsets.p, d_total, record_kind, d_out, cap, entry,
+                                 (unsigned long long *)d.counter.p, stream));
+    if (prof) HIP_TRY(hipEventRecord(d.ev[1], stream));
+    HIP_TRY(hipMemcpyAsync(d.h_counter, d_total, 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(d.h_counter + 1, d.counter.p, 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    *n_out = d.h_counter[0];
+    sh->chain_exit = (int64_t)d.h_counter[1];
+    if (prof) {
+        float sel_ms = 0;
+        HIP_TRY(hipEventElapsedTime(&sel_ms, d.ev[0], d.ev[1]));
+        prof->finalize_ms += sel_ms; // ordering of the all-matches list + the selection
+        prof->total_ms += sel_ms;
+        prof->n_matches = *n_out;
+    }
+    return *n_out > cap ? ACGPU_E_OVERFLOW : ACGPU_OK;
+}
+
 int device_for_call(acgpu_automaton *a, DeviceState **d) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
@@ -533,6 +591,7 @@ int match_shard(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_
     case ACGPU_MODE_ALL: return match_all(a, d, sh, record_kind, d_out, cap, n_out, stream, prof);
     case ACGPU_MODE_LONGEST: return match_longest(a, d, sh, record_kind, d_out, cap, n_out, stream, prof);
     case ACGPU_MODE_WHOLEWORD: return match_wholeword(a, d, sh, record_kind, d_out, cap, n_out, stream, prof);
+    case ACGPU_MODE_SHORTEST: return match_shortest(a, d, sh, record_kind, d_out, cap, n_out, stream, prof);
     default: return ACGPU_E_UNSUPPORTED;
     }
 }
@@ -690,7 +749,7 @@ int acgpu_stream_feed(acgpu_stream *s, const uint16_t *units, uint64_t n_units, 
     *base = (int64_t)s->carry_pos;
     const uint64_t own_begin = s->own_from - s->carry_pos;
     uint64_t own_end = total, keep_from = 0; // keep_from: first buffer unit the next feed still needs
-    if (t.mode == ACGPU_MODE_ALL) {
+    if (t.mode == ACGPU_MODE_ALL || t.mode == ACGPU_MODE_SHORTEST) {
         const uint64_t halo = t.max_len > 0 ? t.max_len - 1 : 0;
         keep_from = total > halo ? total - halo : 0;
     } else if (t.mode == ACGPU_MODE_WHOLEWORD) {
@@ -709,7 +768,7 @@ int acgpu_stream_feed(acgpu_stream *s, const uint16_t *units, uint64_t n_units, 
     }
     if (!s->carry.empty()) std::memcpy(s->buf.data(), s->carry.data(), s->carry.size() * 2);
     if (n_units) std::memcpy(s->buf.data() + s->carry.size(), units, n_units * 2);
-    uint64_t chain_exit = std::max<uint64_t>(s->chain_entry, s->carry_pos + own_end);
+    uint64_t chain_exit = t.mode == ACGPU_MODE_SHORTEST ? s->chain_entry : std::max<uint64_t>(s->chain_entry, s->carry_pos + own_end);
     if (own_end > own_begin) {
         std::lock_guard<std::mutex> lock(a->mu); // staging buffers are part of the per-device scratch pool
         DeviceState *d = nullptr;
@@ -725,11 +784,14 @@ int acgpu_stream_feed(acgpu_stream *s, const uint16_t *units, uint64_t n_units, 
         sh.own_end = own_end;
         sh.text_begin = s->carry_pos == 0 ? 1 : 0;
         sh.text_end = final ? 1 : 0;
-        sh.chain_entry = (int64_t)std::max<uint64_t>(s->chain_entry > s->carry_pos ? s->chain_entry - s->carry_pos : 0, own_begin);
+        sh.chain_entry = (int64_t)(s->chain_entry > s->carry_pos ? s->chain_entry - s->carry_pos : 0);
+        if (t.mode != ACGPU_MODE_SHORTEST) sh.chain_entry = std::max<int64_t>(sh.chain_entry, (int64_t)own_begin);
         rc = match_shard(a, *d, &sh, record_kind, d->stage_out.p, cap, n_out, nullptr, nullptr);
         if (rc != ACGPU_OK) return rc; // ACGPU_E_OVERFLOW: nothing consumed, *n_out = capacity to retry with
         if (*n_out) HIP_TRY(hipMemcpy(out, d->stage_out.p, *n_out * (uint64_t)record_kind, hipMemcpyDeviceToHost));
         if (t.mode == ACGPU_MODE_LONGEST) chain_exit = s->carry_pos + (uint64_t)sh.chain_exit;
+        // SHORTEST: the last restart; an exit equal to the relative entry means "no match in this feed"
+        if (t.mode == ACGPU_MODE_SHORTEST && *n_out) chain_exit = s->carry_pos + (uint64_t)sh.chain_exit;
     }
     // commit
     s->own_from = s->carry_pos + own_end;

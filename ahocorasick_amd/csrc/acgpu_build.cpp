@@ -41,7 +41,8 @@ void trim_keyword(const uint8_t *word, const uint16_t *w, uint64_t len, uint64_t
 
 int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uint32_t n_kw, int case_sensitive,
                  const uint16_t *lower_tbl, const uint8_t *wordchar_tbl, HostTables &t, int64_t *bad_keyword) {
-    if (mode != ACGPU_MODE_ALL && mode != ACGPU_MODE_LONGEST && mode != ACGPU_MODE_WHOLEWORD) return ACGPU_E_INVALID;
+    if (mode != ACGPU_MODE_ALL && mode != ACGPU_MODE_LONGEST && mode != ACGPU_MODE_WHOLEWORD && mode != ACGPU_MODE_SHORTEST)
+        return ACGPU_E_INVALID;
     if (n_kw && (!kw_units || !kw_off)) return ACGPU_E_INVALID;
     if (!case_sensitive && !lower_tbl) return ACGPU_E_INVALID;
     if (mode == ACGPU_MODE_WHOLEWORD && !wordchar_tbl) return ACGPU_E_INVALID;
@@ -96,8 +97,11 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
                 cur = it->second;
             }
         }
-        if (nodes[cur].kw == ~0u) n_terminal++;
-        nodes[cur].kw = k;
+        const bool dup = nodes[cur].kw != ~0u;
+        if (!dup) n_terminal++;
+        // AhoCorasick/Longest/WholeWord: the LAST duplicate's value wins; Shortest: the first keeps the node
+        // (S/ShortestMatchMap.java:47-49)
+        if (!dup || mode != ACGPU_MODE_SHORTEST) nodes[cur].kw = k;
         uint32_t L = (uint32_t)(we - ws);
         if (t.max_len == 0 || L > t.max_len) t.max_len = L;
         if (t.min_len == 0 || L < t.min_len) t.min_len = L;
@@ -320,7 +324,7 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
     // the last unit; rows are 4 bytes (n <= 32 classes) or 8 bytes (n <= 64).  A position survives iff its K-gram is
     // the K-suffix of some keyword (K <= shortest keyword, so every keyword has one).
     t.filt_k = 0;
-    if (mode == ACGPU_MODE_ALL && t.n_cls > 1 && t.n_cls <= 64 && t.min_len >= 1) {
+    if ((mode == ACGPU_MODE_ALL || mode == ACGPU_MODE_SHORTEST) && t.n_cls > 1 && t.n_cls <= 64 && t.min_len >= 1) {
         // tile classes: range mode -> min(unit - base, span) (other = span); LUT mode -> cls_lut (other = 0)
         const uint32_t n = t.n_cls;
         t.filt_n = n;

@@ -113,6 +113,13 @@ hipError_t launch_longest_chain(const LongestChainLaunch &l, const uint32_t *d_s
 
 namespace acgpu {
 // ---- WHOLEWORD pipeline (acgpu_wholeword.hip) -----------------------------------------------------------------
+// ShortestMatch: greedy selection over the ordered all-matches list (acgpu_shortest.hip)
+hipError_t launch_shortest_select(const int32_t *d_recs, uint32_t M, int64_t entry, uint32_t *d_nxt, uint32_t *d_tmp,
+                                  uint32_t *d_mark, hipStream_t stream);
+hipError_t launch_shortest_emit(const int32_t *d_recs, uint32_t M, const uint32_t *d_mark, const uint64_t *d_offsets,
+                                const uint64_t *d_total, int record_kind, void *d_out, uint64_t cap, int64_t entry,
+                                unsigned long long *d_exit, hipStream_t stream);
+
 uint32_t ww_fold_pages_in_lds(const DevTables &t); // 0: the fold table is not staged (case sensitive / too many pages)
 size_t ww_lds_bytes(int block_threads, const DevTables &t);
 int ww_blocks_per_cu();

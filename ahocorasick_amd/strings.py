@@ -358,6 +358,23 @@ class LongestMatchMap(StringMap):
         self._init(keywords, values, case_sensitive)
 
 
+class ShortestMatchSet(StringSet):
+    """S/ShortestMatchSet.java:8-20: reports a match as soon as any keyword ends, then restarts after it (the
+    reference's "leftmost shortest" matcher; non-overlapping)."""
+    _MODE = N.MODE_SHORTEST
+
+    def __init__(self, keywords, case_sensitive, threshold_strategy=None):
+        self._init(keywords, case_sensitive)
+
+
+class ShortestMatchMap(StringMap):
+    """S/ShortestMatchMap.java:16-24; of equal keywords the FIRST one's value is kept (:47-49)."""
+    _MODE = N.MODE_SHORTEST
+
+    def __init__(self, keywords, values, case_sensitive, threshold_strategy=None):
+        self._init(keywords, values, case_sensitive)
+
+
 class WholeWordMatchSet(StringSet):
     """S/WholeWordMatchSet.java: keywords that span a whole maximal run of word characters."""
     _MODE = N.MODE_WHOLEWORD

@@ -49,6 +49,8 @@ extern "C" {
 #define ACGPU_MODE_ALL 0       /* AhoCorasickSet / AhoCorasickMap      S/AhoCorasickSet.java:193-252, S/AhoCorasickMap.java:277-336 */
 #define ACGPU_MODE_LONGEST 1   /* LongestMatchSet / LongestMatchMap    S/LongestMatchSet.java:192-265, S/LongestMatchMap.java:288-360 */
 #define ACGPU_MODE_WHOLEWORD 2 /* WholeWordMatchSet / WholeWordMatchMap S/WholeWordMatchSet.java:47-132, S/WholeWordMatchMap.java:155-240 */
+#define ACGPU_MODE_SHORTEST 3  /* ShortestMatchSet / ShortestMatchMap   S/ShortestMatchSet.java:193-262, S/ShortestMatchMap.java:294-372;
+                                  keyword_id = FIRST duplicate (S/ShortestMatchMap.java:47-49) */
 
 /* output record layouts */
 #define ACGPU_REC_SET 8  /* acgpu_set_match: what SetMatchListener.match(haystack, start, end) receives */
@@ -135,7 +137,9 @@ int acgpu_match_u16(const acgpu_automaton *a, const uint16_t *haystack, uint64_t
  * halo >= max_keyword_len-1 units needed); WHOLEWORD -> to the shard that owns the first unit of
  * the word (left halo 1 unit, right halo up to the end of the word or max_keyword_len+1 units);
  * LONGEST -> to the shard that owns its first unit, given the greedy chain's entry position
- * (right halo >= max_keyword_len-1 units).
+ * (right halo >= max_keyword_len-1 units); SHORTEST -> to the shard that owns its LAST unit (left halo as ALL), given
+ * the position at which matching last restarted (chain_entry: no match may start before it; chain_exit: the end of
+ * the last match reported, or chain_entry if there was none).
  */
 typedef struct acgpu_shard {
     const uint16_t *d_hay; /* device pointer, 16-byte aligned                                   */
@@ -144,8 +148,9 @@ typedef struct acgpu_shard {
     uint64_t own_end;
     int32_t text_begin;    /* 1: buffer unit 0 is the first unit of the whole haystack           */
     int32_t text_end;      /* 1: buffer unit n_units-1 is the last unit of the whole haystack    */
-    int64_t chain_entry;   /* LONGEST in : first greedy-chain position >= own_begin (own_begin on the first shard) */
-    int64_t chain_exit;    /* LONGEST out: first greedy-chain position >= own_end                */
+    int64_t chain_entry;   /* LONGEST in : first greedy-chain position >= own_begin (own_begin on the first shard);
+                              SHORTEST in: position of the last restart (0 on the first shard)      */
+    int64_t chain_exit;    /* LONGEST out: first greedy-chain position >= own_end; SHORTEST out: see above */
 } acgpu_shard;
 
 /* optional per-call timing of the device work, measured with HIP events on `stream` */

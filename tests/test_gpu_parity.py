@@ -764,3 +764,78 @@ def test_stream_fold_inconsistent_wholeword_is_refused():
     with pytest.raises(N.AcgpuError) as e:
         Stream(a)
     assert e.value.code == N.E_UNSUPPORTED
+
+
+# ---- ShortestMatchSet / ShortestMatchMap (ACGPU_MODE_SHORTEST) ----------------------------------------------------------
+
+def test_fixtures_shortest(fixtures, ac_kernel):
+    from ahocorasick_amd import ShortestMatchMap, ShortestMatchSet
+    for fx in fixtures:
+        hay, kws = fixture_inputs(fx)
+        if "keywords_gen" not in fx:
+            kws = fx["S_keywords"]
+        got = ShortestMatchMap(kws, _ids(len(kws)), True).find_all(hay)
+        assert got.tolist() == fx["S"], fx["name"]
+        assert len(got) == fx["S_count"]  # the count T/ShortestMatchTest.java:30-42 expects
+        assert ShortestMatchSet(kws, True).find_all(hay).tolist() == [r[:2] for r in fx["S"]], fx["name"]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_shortest_vs_oracle(seed, ac_kernel):
+    from oracle.oracle import FAM_SHORTEST
+    rng = np.random.default_rng(500 + seed)
+    alphabets = [[97, 98], [97, 98, 99], [97, 98, 65, 66, 0x00E9, 0x00C9], list(range(97, 123))]
+    for it in range(12):
+        alpha = alphabets[it % len(alphabets)]
+        hay, kws = rand_case(rng, alpha, int(rng.integers(1, 60)), int(rng.choice([1, 3, 8])), int(rng.choice([0, 1, 50, 3000, 70001])),
+                             min_len=1)
+        for cs in (True, False):
+            want = Oracle(FAM_SHORTEST, kws, case_sensitive=cs, lower=LOWER).match(hay)
+            got = Automaton(N.MODE_SHORTEST, kws, cs).match_host(hay, True, cap=16)
+            assert got.shape == want.shape and (got == want).all(), (seed, it, cs)
+
+
+def test_shortest_listener_first_duplicate_and_early_stop():
+    from ahocorasick_amd import ShortestMatchMap, ShortestMatchSet
+    m = ShortestMatchMap(["ab", "abcd", "ab", "d"], ["first", "long", "second", "D"], True)
+    seen = []
+    m.match("abcd ab", lambda h, s, e, v: seen.append((s, e, v)) or True)
+    assert seen == [(0, 2, "first"), (3, 4, "D"), (5, 7, "first")]  # "abcd" never matches: its prefix ends first
+    seen = []
+    ShortestMatchSet(["a"], True).match("aaaa", lambda h, s, e: seen.append((s, e)) or len(seen) < 2)
+    assert seen == [(0, 1), (1, 2)]
+    assert ShortestMatchSet(["abcd", "bc", "d"], True).find_all("abcd").tolist() == [[1, 3], [3, 4]]  # earliest END wins
+
+
+def test_shortest_shards_and_stream_carry_the_restart_position():
+    import torch
+    from oracle.oracle import FAM_SHORTEST
+    kws = synth.random_keywords(44, 300, 1, 9, table=synth.ALPHA_LOWER[:4])
+    hay = synth.haystack(45, 150000, table=synth.ALPHA_LOWER[:4])
+    a = Automaton(N.MODE_SHORTEST, kws, True)
+    want = Oracle(FAM_SHORTEST, kws).match(hay)
+    d_hay = torch.from_numpy(hay.view(np.int16)).cuda()
+    cap = len(want) + 8
+    cuts = [0, 50001, 50002, 110003, hay.size]
+    parts, entry = [], 0
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        d_out = torch.empty((cap, 3), dtype=torch.int32, device="cuda")
+        n_out, rc, _, ex = a.match_device(d_hay.data_ptr(), hay.size, True, d_out.data_ptr(), cap, own=(lo, hi), chain_entry=entry)
+        assert rc == N.OK
+        parts.append(d_out[:n_out].cpu().numpy())
+        assert ex == (parts[-1][-1, 1] if n_out else entry)
+        entry = ex
+    assert (np.concatenate(parts) == want).all()
+    for cuts in ([], [1, 2, 3, 40, 41, 90000], list(range(1000, 1100, 3))):
+        got = _stream_all(a, hay, cuts)
+        assert got.shape == want.shape and (got == want.astype(np.int64)).all()
+
+
+def test_shortest_dense_overlaps_many_matches_per_position():
+    """a^k dictionaries: up to 100 matches end at every position; the selection's group search must stay exact."""
+    from oracle.oracle import FAM_SHORTEST
+    kws = ["a" * k for k in range(2, 60)] + ["b", "ab" * 5]
+    hay = synth.haystack(46, 20000, table=synth.ALPHA_AB_75)
+    want = Oracle(FAM_SHORTEST, kws).match(hay)
+    got = Automaton(N.MODE_SHORTEST, kws, True).match_host(hay, True)
+    assert got.shape == want.shape and (got == want).all()

@@ -16,7 +16,7 @@ import torch  # noqa: E402
 from ahocorasick_amd import _native as N  # noqa: E402
 from ahocorasick_amd.strings import Automaton  # noqa: E402
 from ahocorasick_amd.unicode_tables import default_word_chars, java_lower_table  # noqa: E402
-from oracle.oracle import FAM_AC, FAM_LONGEST, FAM_WHOLEWORD, Oracle  # noqa: E402
+from oracle.oracle import FAM_AC, FAM_LONGEST, FAM_SHORTEST, FAM_WHOLEWORD, Oracle  # noqa: E402
 
 LOWER = java_lower_table()
 WORD = default_word_chars()
@@ -46,7 +46,7 @@ def dev_match(a, d_hay, n, cap, **kw):
 
 
 def one_case(rng, it):
-    fam = int(rng.integers(0, 3))
+    fam = int(rng.integers(0, 4))
     alpha = ALPHABETS[int(rng.integers(0, len(ALPHABETS)))]
     cs = bool(rng.integers(0, 2))
     n_kw = int(rng.integers(1, 60))
@@ -79,8 +79,8 @@ def one_case(rng, it):
         knobs["rdense_budget_bytes"] = 0  # hashed reversed trie
     for k, v in knobs.items():
         N.set_tunable(k, v)
-    mode = [N.MODE_ALL, N.MODE_LONGEST, N.MODE_WHOLEWORD][fam]
-    ofam = [FAM_AC, FAM_LONGEST, FAM_WHOLEWORD][fam]
+    mode = [N.MODE_ALL, N.MODE_LONGEST, N.MODE_WHOLEWORD, N.MODE_SHORTEST][fam]
+    ofam = [FAM_AC, FAM_LONGEST, FAM_WHOLEWORD, FAM_SHORTEST][fam]
     wc = WORD if fam == 2 else None
     a = Automaton(mode, kws, cs, word_chars=wc)
     want = Oracle(ofam, kws, case_sensitive=cs, lower=LOWER, word_chars=wc).match(hay)
@@ -96,6 +96,8 @@ def one_case(rng, it):
             kw = dict(own=(lo, hi))
             if fam == 1:
                 kw["chain_entry"] = max(entry, lo)
+            if fam == 3:
+                kw["chain_entry"] = entry
             p, ex = dev_match(a, d_hay, n, 64, **kw)
             entry = ex
             parts.append(p)
@@ -109,12 +111,12 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
     rng = np.random.default_rng(seed)
     t0 = time.time()
-    counts = [0, 0, 0]
+    counts = [0, 0, 0, 0]
     it = 0
     while time.time() - t0 < budget:
         counts[one_case(rng, it)] += 1
         it += 1
-    print("fuzz ok: %d cases (AC %d, Longest %d, WholeWord %d) in %.0f s, seed %d" % (it, *counts, time.time() - t0, seed))
+    print("fuzz ok: %d cases (AC %d, Longest %d, WholeWord %d, Shortest %d) in %.0f s, seed %d" % (it, *counts, time.time() - t0, seed))
 
 
 if __name__ == "__main__":
