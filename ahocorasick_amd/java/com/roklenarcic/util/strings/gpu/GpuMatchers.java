@@ -19,6 +19,20 @@ public final class GpuMatchers {
         }
     }
 
+    /** Drop-in for ShortestMatchSet. */
+    public static class GpuShortestMatchSet extends GpuAhoCorasickSet {
+        public GpuShortestMatchSet(final Iterable<String> keywords, boolean caseSensitive) {
+            super(NativeAutomaton.MODE_SHORTEST, keywords, caseSensitive, null);
+        }
+    }
+
+    /** Drop-in for ShortestMatchMap (of equal keywords the first one's value is kept, as in the reference). */
+    public static class GpuShortestMatchMap<T> extends GpuAhoCorasickMap<T> {
+        public GpuShortestMatchMap(final Iterable<String> keywords, final Iterable<? extends T> values, boolean caseSensitive) {
+            super(NativeAutomaton.MODE_SHORTEST, keywords, values, caseSensitive, null);
+        }
+    }
+
     /** WordCharacters.generateWordCharsFlags() with this JVM's Character.isLetterOrDigit. */
     static boolean[] defaultWordChars() {
         boolean[] f = new boolean[65536];

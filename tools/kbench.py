@@ -17,13 +17,16 @@ def main():
     ap.add_argument("--units-log2", type=int, default=29)
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--variants", type=str, default="")
-    ap.add_argument("--config", default="C2", choices=["C2", "C4", "C5"])
+    ap.add_argument("--config", default="C2", choices=["C2", "C2S", "C4", "C5"])
     args = ap.parse_args()
     import torch
     from ahocorasick_amd import _native as N, synth
     from ahocorasick_amd.strings import Automaton
 
     n = 1 << args.units_log2
+    shortest = args.config == "C2S"  # config 2's dictionary and haystack through ShortestMatchMap
+    if shortest:
+        args.config = "C2"
     kws = synth.config_keywords(args.config)
     if args.config == "C5":
         from ahocorasick_amd.unicode_tables import default_word_chars
@@ -35,13 +38,13 @@ def main():
         cap = n // 8
         dflt = {"ww": {}, "ww_noverify": {"tile_debug": 1}, "ww_nolookup": {"tile_debug": 2}, "ww_triewalk": {"force_kernel": 1}}
     else:
-        a = Automaton(N.MODE_LONGEST if args.config == "C4" else N.MODE_ALL, kws, True)
+        a = Automaton(N.MODE_LONGEST if args.config == "C4" else (N.MODE_SHORTEST if shortest else N.MODE_ALL), kws, True)
         d_hay = torch.empty(n, dtype=torch.int16, device="cuda")
         tab = np.ascontiguousarray(synth.ALPHA_AB_75 if args.config == "C4" else synth.ALPHA_LOWER)
         N.check(N.lib().acgpu_synth_fill(d_hay.data_ptr(), n, 0, synth.CONFIGS[args.config]["hay_seed"],
                                          tab.ctypes.data_as(ctypes.c_void_p), len(tab), None), "synth")
         cap = n // 2 if args.config == "C4" else n // 128
-        dflt = {"longest": {}} if args.config == "C4" else {
+        dflt = {"longest": {}} if args.config == "C4" else {"shortest": {}} if shortest else {
             "tile": {}, "tile_noverify": {"tile_debug": 1}, "tile_nolds": {"tile_debug": 3}, "tile_stream": {"tile_debug": 5},
             "dfa": {"force_kernel": 1}}
     torch.cuda.synchronize()
