@@ -11,6 +11,9 @@ xGMI on ROCm, "gloo" in the CPU tests).  SURVEY.md 8e, one row per matcher famil
   runs its chain speculatively from its own first unit (all ranks in parallel); then ONE int64 travels down the ranks
   (send/recv, world-1 hops) and a rank whose true entry differs re-runs a short window until the true chain leaves the
   window where the speculative one did -- from there on both are the same chain.
+* Shortest: a match belongs to the rank that owns its LAST unit (left halo as AhoCorasick); which occurrences are
+  reported depends on where matching last restarted (the end of the previous reported match), handed down the ranks
+  like the Longest chain position, with the same speculation (no restriction) and window repair.
 
 In all three, rank-local order is the reference's order, so the concatenation of the per-rank buffers by rank is the
 reference's listener-call order for the whole haystack.  The data exchange steps are the tiny halo send/recv, the
@@ -22,7 +25,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from ._native import MODE_ALL, MODE_LONGEST, MODE_WHOLEWORD
+from ._native import MODE_ALL, MODE_LONGEST, MODE_SHORTEST, MODE_WHOLEWORD
 
 
 def _world(group=None):
@@ -163,7 +166,7 @@ class ShardedMatcher:
         self.mode = automaton.mode if automaton is not None else (MODE_ALL if mode is None else mode)
         if halo is None or (right_halo is None and self.mode != MODE_ALL):
             max_len = automaton.info()["max_keyword_len"]
-            if self.mode == MODE_ALL:
+            if self.mode in (MODE_ALL, MODE_SHORTEST):
                 halo, right_halo = max(0, max_len - 1), 0
             elif self.mode == MODE_WHOLEWORD:
                 halo, right_halo = 1, max_len + 1
@@ -254,6 +257,8 @@ class ShardedMatcher:
     def _scan(self, profile):
         if self.mode == MODE_LONGEST:
             return self._scan_longest(profile)
+        if self.mode == MODE_SHORTEST:
+            return self._scan_shortest(profile)
         n, _, prof = self._call("out", 0, self.sb.n_units, 0, profile)
         return n, prof
 
@@ -301,6 +306,40 @@ class ShardedMatcher:
                     break
                 w *= 4
         self._chain_hop_send(ex)
+        return n, prof
+
+    def _scan_shortest(self, profile):
+        """Shortest: records are owned by their END; the chain state is the position of the last restart (the end of
+        the last reported match, or what came in if this shard reported nothing).  Speculation: no restriction."""
+        n_own, halo = self.sb.n_units, self.sb.halo
+        none = -(self.sb.pad + 1)  # a restart position left of everything this rank can see restricts nothing
+        n, _, prof = self._call("out", 0, n_own, none, profile)
+        entry = max(self._chain_hop_recv(), none) if self.rank else none
+        self.chain_repairs = 0
+        if entry > -halo:  # a restart inside my halo can forbid matches that begin before it
+            spec = self.out
+            ends = spec[:n, 1].contiguous()
+            w = int(self.chain_window)
+            while True:
+                w_end = min(w, n_own)
+                self.chain_repairs += 1
+                n_t, _, _ = self._call("tmp", 0, w_end, entry)
+                # speculative records that end inside the window (ends ascend)
+                idx = n if w_end == n_own else int(torch.searchsorted(
+                    ends, torch.tensor([w_end], dtype=torch.int32, device=ends.device), right=True).item())
+                last_t = int(self._tmp[n_t - 1, 1].item()) if n_t else entry
+                last_s = int(spec[idx - 1, 1].item()) if idx else none
+                floor = w_end - halo  # restart positions at or left of this restrict nothing that ends after the window
+                if w_end == n_own or max(last_t, floor) == max(last_s, floor):
+                    tail = spec[idx:n].clone()
+                    if n_t + len(tail) > self.out.shape[0]:
+                        self._grow("out", n_t + len(tail))
+                    self.out[:n_t] = self._tmp[:n_t]
+                    self.out[n_t:n_t + len(tail)] = tail
+                    n = n_t + len(tail)
+                    break
+                w *= 4
+        self._chain_hop_send(int(self.out[n - 1, 1].item()) if n else entry)
         return n, prof
 
     def step(self, profile=False):

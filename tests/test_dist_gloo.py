@@ -26,10 +26,10 @@ def _worker(rank, world, port, n_per_rank, tmpdir, overlap, family):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from ahocorasick_amd import synth
-        from ahocorasick_amd._native import MODE_ALL, MODE_LONGEST, MODE_WHOLEWORD
+        from ahocorasick_amd._native import MODE_ALL, MODE_LONGEST, MODE_SHORTEST, MODE_WHOLEWORD
         from ahocorasick_amd.dist import ShardedMatcher
         from ahocorasick_amd.unicode_tables import default_word_chars
-        from oracle.oracle import FAM_AC, FAM_LONGEST, FAM_WHOLEWORD, Oracle
+        from oracle.oracle import FAM_AC, FAM_LONGEST, FAM_SHORTEST, FAM_WHOLEWORD, Oracle
 
         if family == "ww":
             table = np.array([ord(c) for c in "abc ,"], dtype=np.uint16)
@@ -37,10 +37,10 @@ def _worker(rank, world, port, n_per_rank, tmpdir, overlap, family):
             whole = synth.haystack(99, n_per_rank * world, table=table)
             orc = Oracle(FAM_WHOLEWORD, kws, word_chars=default_word_chars())
         else:
-            table = synth.ALPHA_LOWER[:6] if family == "ac" else synth.ALPHA_LOWER[:2]
+            table = synth.ALPHA_LOWER[:6] if family == "ac" else synth.ALPHA_LOWER[:2 if family == "longest" else 3]
             kws = synth.random_keywords(5, 200, 2, 9, table=table)
             whole = synth.haystack(99, n_per_rank * world, table=table)
-            orc = Oracle(FAM_AC if family == "ac" else FAM_LONGEST, kws)
+            orc = Oracle({"ac": FAM_AC, "longest": FAM_LONGEST, "shortest": FAM_SHORTEST}[family], kws)
         max_len = max(len(k) for k in kws)
 
         # stand-ins with the contract of acgpu_match_device on one shard (include/acgpu.h, acgpu_shard)
@@ -67,7 +67,22 @@ def _worker(rank, world, port, n_per_rank, tmpdir, overlap, family):
             ex = max(oe, int(r[-1, 1])) if len(r) else oe
             return r, ex
 
+        def scan_shortest(view, ob, oe, text_begin, text_end, entry):
+            # occurrences by increasing end (longest first at equal end), reported iff they start at/after the last
+            # restart; this shard reports those whose last unit it owns.  The oracle run from `lo` with the restart
+            # position forced by cutting the text there.
+            entry = max(entry, 0)
+            lo = 0 if text_begin else max(ob - (max_len - 1), 0)
+            lo = max(lo, entry)
+            r = orc.match(view[lo:oe])  # restarting at lo == "no match may start before lo"
+            r[:, :2] += lo
+            if lo < entry or not len(r):
+                pass
+            r = r[r[:, 1] - 1 >= ob]
+            return r, (int(r[-1, 1]) if len(r) else entry)
+
         mode, scan_fn, halo, right = {"ac": (MODE_ALL, scan_ac, max_len - 1, 0),
+                                      "shortest": (MODE_SHORTEST, scan_shortest, max_len - 1, 0),
                                       "ww": (MODE_WHOLEWORD, scan_ww, 1, max_len + 1),
                                       "longest": (MODE_LONGEST, scan_longest, 0, max_len - 1)}[family]
         m = ShardedMatcher(None, n_per_rank, with_ids=True, cap=16, scan_fn=scan_fn, halo=halo, right_halo=right,
@@ -93,12 +108,12 @@ def _worker(rank, world, port, n_per_rank, tmpdir, overlap, family):
 
 @pytest.mark.parametrize("world,overlap,family", [(2, False, "ac"), (3, False, "ac"), (2, True, "ac"), (2, False, "ww"),
                                                   (3, True, "ww"), (2, False, "longest"), (3, False, "longest"),
-                                                  (4, True, "longest")])
+                                                  (4, True, "longest"), (2, False, "shortest"), (4, False, "shortest")])
 def test_sharded_match_equals_whole_text(world, overlap, family, tmp_path):
     port = _free_port()
-    n_per_rank = 4001 if family != "longest" else 1003
+    n_per_rank = 4001 if family not in ("longest", "shortest") else 1003
     mp.spawn(_worker, args=(world, port, n_per_rank, str(tmp_path), overlap, family), nprocs=world, join=True)
     oks = [(tmp_path / ("ok%d" % r)) for r in range(world)]
     assert all(p.exists() for p in oks)
-    if family == "longest":  # at least one shard boundary falls inside a match, so the repair path ran
+    if family in ("longest", "shortest"):  # at least one shard boundary falls inside a match, so the repair path ran
         assert sum(int(p.read_text().split()[1]) for p in oks) > 0

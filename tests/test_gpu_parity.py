@@ -661,7 +661,7 @@ def _emulated_ranks(auto, whole, world, chain_window=4096):
     return np.concatenate(parts), repairs
 
 
-@pytest.mark.parametrize("family", ["ac", "longest", "wholeword"])
+@pytest.mark.parametrize("family", ["ac", "longest", "wholeword", "shortest"])
 def test_sharded_matcher_native_scan_equals_whole_text(family):
     world, n = 4, 50000
     if family == "wholeword":
@@ -675,6 +675,12 @@ def test_sharded_matcher_native_scan_equals_whole_text(family):
         whole = synth.haystack(42, world * n, table=synth.ALPHA_LOWER[:2])
         auto = Automaton(N.MODE_LONGEST, kws, True)
         want = Oracle(FAM_LONGEST, kws).match(whole)
+    elif family == "shortest":
+        from oracle.oracle import FAM_SHORTEST
+        kws = synth.random_keywords(34, 300, 2, 30, table=synth.ALPHA_LOWER[:3])
+        whole = synth.haystack(44, world * n, table=synth.ALPHA_LOWER[:3])
+        auto = Automaton(N.MODE_SHORTEST, kws, True)
+        want = Oracle(FAM_SHORTEST, kws).match(whole)
     else:
         kws = synth.random_keywords(33, 500, 2, 11, table=synth.ALPHA_LOWER[:8])
         whole = synth.haystack(43, world * n, table=synth.ALPHA_LOWER[:8])
@@ -682,7 +688,7 @@ def test_sharded_matcher_native_scan_equals_whole_text(family):
         want = Oracle(FAM_AC, kws).match(whole)
     got, repairs = _emulated_ranks(auto, whole, world, chain_window=32)
     assert got.shape == want.shape and (got == want.astype(np.int64)).all()
-    if family == "longest":
+    if family in ("longest", "shortest"):
         assert repairs > 0  # some shard boundary fell inside a match: the window repair ran on the device
 
 
