@@ -35,6 +35,7 @@
 #define FAM_LONGEST 1   /* S/LongestMatchSet.java, S/LongestMatchMap.java     */
 #define FAM_WHOLEWORD 2 /* S/WholeWordMatchSet.java, S/WholeWordMatchMap.java */
 #define FAM_SHORTEST 3  /* S/ShortestMatchSet.java, S/ShortestMatchMap.java   */
+#define FAM_WWLONGEST 4 /* S/WholeWordLongestMatchSet.java, S/WholeWordLongestMatchMap.java */
 
 #define ORACLE_OK 0
 #define ORACLE_E_ILLEGAL_ARGUMENT (-2) /* java.lang.IllegalArgumentException */
@@ -49,6 +50,8 @@ struct Node {
     int32_t matchLength;
     int32_t level;
     int32_t value; /* Map flavour: keyword index standing in for T value */
+    /* WholeWordLongest: the last keyword on the path that ended at a word boundary (S/WholeWordLongestMatchMap.java:668-672) */
+    int32_t failMatchLength, failMatchOffset, failValue;
     /* representation */
     int32_t isRange;
     Node **children;
@@ -332,6 +335,23 @@ static int visit_fail_and_outputs(oracle *o, NQueue *queue, Node *parent, uint16
     value = opt;
     update_transition(parent, key, value);
 
+    if (o->family == FAM_WWLONGEST) {
+        /* S/WholeWordLongestMatchSet.java:226-244 (Map: S/WholeWordLongestMatchMap.java:366-384): carry the last
+         * keyword that ended at a word boundary down the path, with its distance from the node. */
+        if (parent->matchLength != 0 && !o->wordChars[key]) {
+            value->failMatchLength = parent->matchLength;
+            value->failMatchOffset = 1;
+            value->failValue = parent->value;
+        } else {
+            value->failMatchLength = parent->failMatchLength;
+            value->failMatchOffset = parent->failMatchOffset + 1;
+            value->failValue = parent->failValue;
+        }
+        if (!node_is_empty(value))
+            if (q_push(queue, value)) return -1;
+        return 0;
+    }
+
     Node *parentFail = parent->failTransition;
     if (parentFail == NULL) {
         value->failTransition = parent; /* depth-1 nodes fail to root :66-70 */
@@ -447,7 +467,7 @@ int oracle_build(int family, const uint16_t *kw, const uint64_t *off, uint32_t n
     if (!o->lower) { oracle_free(o); return ORACLE_E_NOMEM; }
     if (lower) memcpy(o->lower, lower, 65536 * sizeof(uint16_t));
     else for (int i = 0; i < 65536; i++) o->lower[i] = (uint16_t)i;
-    if (family == FAM_WHOLEWORD) {
+    if (family == FAM_WHOLEWORD || family == FAM_WWLONGEST) {
         if (!wordChars) { oracle_free(o); return ORACLE_E_ILLEGAL_ARGUMENT; }
         o->wordChars = (uint8_t *)malloc(65536);
         if (!o->wordChars) { oracle_free(o); return ORACLE_E_NOMEM; }
@@ -455,13 +475,17 @@ int oracle_build(int family, const uint16_t *kw, const uint64_t *off, uint32_t n
     }
 
     /* root: HashmapNode(true) for AC/Longest (:22), plain HashmapNode for WholeWord (S/WholeWordMatchMap.java:254) */
-    o->root = new_hashmap_node(o, family != FAM_WHOLEWORD, 0);
+    o->root = new_hashmap_node(o, family != FAM_WHOLEWORD && family != FAM_WWLONGEST, 0);
     if (!o->root) { oracle_free(o); return ORACLE_E_NOMEM; }
 
     for (uint32_t k = 0; k < n_kw; k++) {
         const uint16_t *w = kw + off[k];
         int64_t len = (int64_t)(off[k + 1] - off[k]);
         int64_t ws = 0, we = len;
+        if (family == FAM_WWLONGEST) {
+            /* S/WholeWordLongestMatchSet.java:190-206: trim only -- non-word characters inside a keyword are allowed */
+            wc_trim(o->wordChars, w, len, &ws, &we);
+        }
         if (family == FAM_WHOLEWORD) {
             /* S/WholeWordMatchMap.java:259-272: trim, validate un-folded chars, skip empty */
             wc_trim(o->wordChars, w, len, &ws, &we);
@@ -537,6 +561,7 @@ int oracle_build(int family, const uint16_t *kw, const uint64_t *off, uint32_t n
                 if (map_entries(o, &queue, n, 0, level)) { rc = -1; goto done; }
             }
         }
+        if (family == FAM_WWLONGEST) goto done; /* a plain trie: no fail transitions, no gap fill */
         /* Depth-first gap fill, restated literally (S/AhoCorasickSet.java:157-190),
          * including the way pop()/push(null) overwrites the popped node's slot;
          * which RangeNodes end up filled is results-neutral (A.2 of SURVEY.md). */
@@ -915,8 +940,51 @@ static void match_shortest(const oracle *o, const uint16_t *hay, int32_t len, ma
     if (currentNodeMatchLength != 0) l(ctx, idx - currentNodeMatchLength, idx, currentNodeMatchValue);
 }
 
+/* WholeWordLongestMatchSet.match: S/WholeWordLongestMatchSet.java:47-178 (Map: S/WholeWordLongestMatchMap.java:180-305).
+ * CI: the transition and the !wordChars[c] test see the folded unit, the two skip loops the raw unit. */
+static void match_wwlongest(const oracle *o, const uint16_t *hay, int32_t len, match_listener l, void *ctx) {
+    const Node *root = o->root;
+    const Node *currentNode = root;
+    const uint8_t *wordChars = o->wordChars;
+    int32_t idx = 0;
+    while (idx < len) {
+        const uint16_t c = o->caseSensitive ? hay[idx] : o->lower[hay[idx]];
+        const Node *nextNode = get_transition(currentNode, c);
+        if (nextNode == NULL) {
+            if (!wordChars[c]) {
+                if (currentNode->matchLength != 0) {
+                    if (!l(ctx, idx - currentNode->matchLength, idx, currentNode->value)) return;
+                } else if (currentNode->failMatchLength != 0) {
+                    const int32_t failMatchEnd = idx - currentNode->failMatchOffset;
+                    if (!l(ctx, failMatchEnd - currentNode->failMatchLength, failMatchEnd, currentNode->failValue)) return;
+                }
+            } else {
+                if (currentNode->failMatchLength != 0) {
+                    const int32_t failMatchEnd = idx - currentNode->failMatchOffset;
+                    if (!l(ctx, failMatchEnd - currentNode->failMatchLength, failMatchEnd, currentNode->failValue)) return;
+                }
+                while (++idx < len && wordChars[hay[idx]]) {
+                }
+            }
+            while (++idx < len && !wordChars[hay[idx]]) {
+            }
+            currentNode = root;
+        } else {
+            ++idx;
+            currentNode = nextNode;
+        }
+    }
+    if (currentNode->matchLength != 0) {
+        l(ctx, idx - currentNode->matchLength, idx, currentNode->value);
+    } else if (currentNode->failMatchLength != 0) {
+        const int32_t failMatchEnd = idx - currentNode->failMatchOffset;
+        l(ctx, failMatchEnd - currentNode->failMatchLength, failMatchEnd, currentNode->failValue);
+    }
+}
+
 static void match_dispatch(const oracle *o, const uint16_t *hay, int32_t len, match_listener l, void *ctx) {
     switch (o->family) {
+    case FAM_WWLONGEST: match_wwlongest(o, hay, len, l, ctx); break;
     case FAM_SHORTEST: match_shortest(o, hay, len, l, ctx); break;
     case FAM_AC: match_ac(o, hay, len, l, ctx); break;
     case FAM_LONGEST: match_longest(o, hay, len, l, ctx); break;

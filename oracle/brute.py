@@ -161,3 +161,74 @@ def shortest(haystack, keywords, case_sensitive=True, lower=None):
                     s = end
                     break
     return out
+
+
+def wwlongest_test_count(haystack, keywords, word_chars):
+    """T/WholeWordLongestMatchTest.java:46-65 with prepareKeywords (:76-84: sorted by length, longest first, stable)
+    and the trimming of instantiateSet (:68-73).  Character.isLetterOrDigit == word_chars minus '-' and '_'."""
+    def lod(c):
+        return bool(word_chars[c]) and c not in (0x2D, 0x5F)
+    h = _units(haystack)
+    needles = [trim(_units(k), word_chars) for k in sorted(keywords, key=len, reverse=True)]
+    count = 0
+    i = 0
+    n = len(h)
+    while i < n:
+        for nd in needles:
+            L = len(nd)
+            if L > 0 and i + L <= n and h[i:i + L] == nd and (i + L == n or not lod(h[i + L])) and (i == 0 or not lod(h[i - 1])):
+                count += 1
+                i += L - 1
+                i += 1
+                while i < n and not word_chars[h[i]]:
+                    i += 1
+                i -= 1
+                break
+        i += 1
+    return count
+
+
+def wwlongest(haystack, keywords, word_chars, case_sensitive=True, lower=None):
+    """WholeWordLongestMatchSet/Map from its definition (fold-consistent tables): from every word start that the scan
+    reaches, follow the text as long as it stays a prefix of some keyword; where it stops (position i), report the
+    whole path if it is a keyword and the next unit is not a word character, else the longest keyword prefix of the
+    path that is followed by a non-word unit of the path; the scan continues at the first word start after i."""
+    lo = None if case_sensitive else lower
+    d = {}
+    prefixes = set()
+    for idx, k in enumerate(keywords):
+        if k is None:
+            continue
+        u = _fold(trim(_units(k), word_chars), lo)
+        if len(u) > 0:
+            d[u] = idx
+            for j in range(1, len(u) + 1):
+                prefixes.add(u[:j])
+    raw = _units(haystack)
+    h = _fold(raw, lo)
+    n = len(raw)
+    out = []
+    p = 0
+    while p < n:
+        i = p
+        while i < n and h[p:i + 1] in prefixes:
+            i += 1
+        # fail match: longest keyword prefix h[p:q] (q < i... q <= i-1) whose next path unit h[q] is a non-word unit
+        hit = None
+        if h[p:i] in d and (i == n or not word_chars[h[i]]):
+            hit = (p, i, d[h[p:i]])
+        else:
+            for q in range(i - 1, p, -1):
+                if h[p:q] in d and not word_chars[h[q]]:
+                    hit = (p, q, d[h[p:q]])
+                    break
+        if hit:
+            out.append(hit)
+        if i < n and word_chars[h[i]]:
+            while i < n and word_chars[raw[i]]:
+                i += 1
+        i += 1 if i < n and not word_chars[raw[i]] else 0
+        while i < n and not word_chars[raw[i]]:
+            i += 1
+        p = max(i, p + 1) if i <= p else i
+    return out

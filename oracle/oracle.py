@@ -16,7 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
 
-FAM_AC, FAM_LONGEST, FAM_WHOLEWORD, FAM_SHORTEST = 0, 1, 2, 3
+FAM_AC, FAM_LONGEST, FAM_WHOLEWORD, FAM_SHORTEST, FAM_WWLONGEST = 0, 1, 2, 3, 4
 E_ILLEGAL_ARGUMENT = -2
 
 

@@ -4,7 +4,7 @@ Inputs are the deterministic scenarios of the reference's own tests (haystack + 
 T/SetTest.java:61-130 mirrored in T/MapTest.java:68-131, README worked examples R/README.md:88-124).  Expected
 outputs are computed with oracle/brute.py, i.e. with the brute-force formulas the reference tests themselves
 assert against (T/AhoCorasickTest.java:28-38, T/LongestMatchTest.java:30-42, T/WholeWordMatchTest.java:73-90,
-T/ShortestMatchTest.java:30-42)
+T/ShortestMatchTest.java:30-42, T/WholeWordLongestMatchTest.java:46-65)
 plus the documented emission order.  The reference (Java) cannot be executed in this image; see DESIGN.md.
 
 Run:  python tests/golden/make_fixtures.py
@@ -56,6 +56,11 @@ def main():
         e["S_keywords"] = skws
         e["S_count"] = brute.shortest_test_count(hay, kws)
         e["S"] = [list(m) for m in brute.shortest(hay, skws)]
+        # WholeWordLongestMatchTest extends SetTest, sorts the keywords longest first (T/WholeWordLongestMatchTest.java:76-84)
+        lkws = sorted(kws, key=len, reverse=True)
+        e["WWL_keywords"] = lkws
+        e["WWL_count"] = brute.wwlongest_test_count(hay, kws, wc)
+        e["WWL"] = [list(m) for m in brute.wwlongest(hay, lkws, wc)]
         try:
             e["WW"] = [list(m) for m in brute.wholeword(hay, kws, wc)]
         except brute.NonWordCharacters:
@@ -65,7 +70,8 @@ def main():
     out.append({"name": "fullNode", "source": "T/SetTest.java:72-79", "haystack_units": [0, 0xFFFF, 0xFFFE],
                 "keywords_gen": "all_single_units",
                 "AC": [[0, 1, 0], [1, 2, 0xFFFF], [2, 3, 0xFFFE]], "L": [[0, 1, 0], [1, 2, 0xFFFF], [2, 3, 0xFFFE]],
-                "WW": "IllegalArgumentException", "S_count": 3, "S": [[0, 1, 0], [1, 2, 0xFFFF], [2, 3, 0xFFFE]]})
+                "WW": "IllegalArgumentException", "S_count": 3, "S": [[0, 1, 0], [1, 2, 0xFFFF], [2, 3, 0xFFFE]]})  # WholeWordLongest: not run (65536 one-unit
+    # keywords of which 16255 are non-word characters: nothing the reference's test asserts)
     with open(os.path.join(HERE, "reference_fixtures.json"), "w") as f:
         json.dump(out, f, indent=0, ensure_ascii=True)
     print("wrote", len(out), "fixtures")

@@ -189,3 +189,33 @@ def test_shortest_literal_restatement_equals_closed_form_fuzz():
     assert _as_list(Oracle(FAM_SHORTEST, ["abcd", "bc", "d"]).match("abcd")) == [[1, 3, 1], [3, 4, 2]]
     # early stop
     assert len(Oracle(FAM_SHORTEST, ["a"]).match("aaaa", stop_after=2)) == 2
+
+
+# ---- WholeWordLongestMatchSet / Map (S/WholeWordLongestMatchSet.java) ---------------------------------------------------
+
+def test_wwlongest_fixtures_and_reference_test_counts(fixtures):
+    from oracle.oracle import FAM_WWLONGEST
+    for fx in fixtures:
+        if "keywords_gen" in fx:
+            continue
+        got = _as_list(Oracle(FAM_WWLONGEST, fx["WWL_keywords"], word_chars=WORD).match(fx["haystack"]))
+        assert got == fx["WWL"], fx["name"]
+        assert len(got) == fx["WWL_count"], fx["name"]  # the count T/WholeWordLongestMatchTest.java:46-65 expects
+
+
+def test_wwlongest_literal_restatement_equals_definition_fuzz():
+    """Multi-word keywords, keywords that are prefixes of others across a word boundary, walks that stop inside a
+    later word (the scan resumes after that word, S/WholeWordLongestMatchSet.java:85-99), case folding."""
+    from oracle.oracle import FAM_WWLONGEST
+    rng = np.random.default_rng(29)
+    alpha = [ord(c) for c in "abAB  -."] + [0x00E9, 0x00C9]
+    for it in range(500):
+        hay, kws = rand_case(rng, alpha, int(rng.integers(1, 25)), int(rng.choice([3, 6, 10])), int(rng.integers(0, 150)))
+        for cs in (True, False):
+            got = _as_list(Oracle(FAM_WWLONGEST, kws, case_sensitive=cs, lower=LOWER, word_chars=WORD).match(hay))
+            want = [list(m) for m in brute.wwlongest(hay, kws, WORD, case_sensitive=cs, lower=LOWER)]
+            assert got == want, (it, cs)
+    # README/T examples: the longer multi-word keyword wins only when it is a whole-word match
+    o = Oracle(FAM_WWLONGEST, ["as", "if", "as if"], word_chars=WORD)
+    assert _as_list(o.match("as if"))[0][:2] == [0, 5] and _as_list(o.match("as in"))[0][:2] == [0, 2]
+    assert len(o.match("as if as if", stop_after=1)) == 1
