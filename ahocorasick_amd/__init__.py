@@ -5,8 +5,9 @@ This package is the host-side mirror of the reference's API on top of it.  No CP
 """
 from .strings import (AhoCorasickMap, AhoCorasickSet, Automaton, IllegalArgumentException, LongestMatchMap,
                       LongestMatchSet, MapMatchListener, ReadableMatchListener, SetMatchListener, ShortestMatchMap, ShortestMatchSet, Stream, StringMap,
-                      StringSet, WholeWordMatchMap, WholeWordMatchSet, utf16)
+                      StringSet, WholeWordLongestMatchMap, WholeWordLongestMatchSet, WholeWordMatchMap, WholeWordMatchSet,
+                      utf16)
 
 __all__ = ["AhoCorasickSet", "AhoCorasickMap", "LongestMatchSet", "LongestMatchMap", "WholeWordMatchSet",
-           "WholeWordMatchMap", "ShortestMatchSet", "ShortestMatchMap", "StringSet", "StringMap", "SetMatchListener", "MapMatchListener", "ReadableMatchListener", "Stream", "Automaton",
+           "WholeWordMatchMap", "ShortestMatchSet", "ShortestMatchMap", "WholeWordLongestMatchSet", "WholeWordLongestMatchMap", "StringSet", "StringMap", "SetMatchListener", "MapMatchListener", "ReadableMatchListener", "Stream", "Automaton",
            "IllegalArgumentException", "utf16"]

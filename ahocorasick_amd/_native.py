@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ACGPU_LIB") or os.path.join(_HERE, "lib", "libacgpu.so")  # ACGPU_LIB: A/B builds
 
 OK, E_INVALID, E_NONWORD, E_NOMEM, E_OVERFLOW, E_HIP, E_NODEVICE, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7
-MODE_ALL, MODE_LONGEST, MODE_WHOLEWORD, MODE_SHORTEST = 0, 1, 2, 3
+MODE_ALL, MODE_LONGEST, MODE_WHOLEWORD, MODE_SHORTEST, MODE_WWLONGEST = 0, 1, 2, 3, 4
 REC_SET, REC_MAP = 8, 12
 
 

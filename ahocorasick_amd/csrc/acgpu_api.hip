@@ -68,6 +68,7 @@ struct DeviceState {
     DevBuf counter, chunk_counts, offsets, scan_tmp, scratch, chain, lenbuf, statebuf;
     DevBuf stage_hay, stage_out; // acgpu_match_u16 staging
     DevBuf short_recs, short_nxt, short_tmp, short_mark; // SHORTEST: all-matches list + selection scratch
+    DevBuf wwl_rs, wwl_mend, wwl_mid, wwl_sel;          // WWLONGEST: walk starts and what each would report
     unsigned long long *h_counter = nullptr; // pinned
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     Ticket tickets[4];
@@ -76,6 +77,7 @@ struct DeviceState {
         counter.release(); chunk_counts.release(); offsets.release(); scan_tmp.release(); scratch.release();
         chain.release(); lenbuf.release(); statebuf.release(); stage_hay.release(); stage_out.release();
         short_recs.release(); short_nxt.release(); short_tmp.release(); short_mark.release();
+        wwl_rs.release(); wwl_mend.release(); wwl_mid.release(); wwl_sel.release();
         if (h_counter) (void)hipHostFree(h_counter);
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         for (auto &tk : tickets) {
@@ -569,6 +571,63 @@ int match_shortest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int reco
     return *n_out > cap ? ACGPU_E_OVERFLOW : ACGPU_OK;
 }
 
+// WWLONGEST-mode pipeline: the whole haystack is one shard.
+int match_wwlongest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_kind, void *d_out, uint64_t cap,
+                    uint64_t *n_out, hipStream_t stream, acgpu_profile *prof) {
+    const HostTables &t = a->t;
+    if (prof) std::memset(prof, 0, sizeof(*prof));
+    if (!t.fold_consistent) return ACGPU_E_UNSUPPORTED;
+    if (!sh->text_begin || !sh->text_end || sh->own_begin != 0 || sh->own_end != sh->n_units) return ACGPU_E_UNSUPPORTED;
+    *n_out = 0;
+    const uint32_t n = (uint32_t)sh->n_units;
+    if (n == 0 || t.n_states <= 1) return ACGPU_OK;
+    int rc;
+    const uint32_t n_tiles = wwl_tiles(n);
+    if ((rc = d.chunk_counts.ensure((size_t)n_tiles * 4))) return rc;
+    if ((rc = d.offsets.ensure((size_t)n_tiles * 8))) return rc;
+    if ((rc = d.scan_tmp.ensure(((size_t)n_tiles / 2048 + 2) * 8))) return rc;
+    if (prof) HIP_TRY(hipEventRecord(d.ev[0], stream));
+    HIP_TRY(launch_wwl_starts(d.T, sh->d_hay, n, d.n_cu, false, (uint32_t *)d.chunk_counts.p, nullptr, nullptr, stream));
+    HIP_TRY(launch_exclusive_scan((const uint32_t *)d.chunk_counts.p, n_tiles, (uint64_t *)d.offsets.p, (uint64_t *)d.scan_tmp.p,
+                                  stream));
+    HIP_TRY(hipMemcpyAsync(d.h_counter, (const uint64_t *)d.scan_tmp.p + scan_tiles_for(n_tiles), 8, hipMemcpyDeviceToHost,
+                           stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    const uint32_t M = (uint32_t)*d.h_counter; // walk starts (>= 1: position 0)
+    if ((rc = d.wwl_rs.ensure(((size_t)M + 1) * 4))) return rc;
+    if ((rc = d.wwl_mend.ensure(((size_t)M + 1) * 4))) return rc;
+    if ((rc = d.wwl_mid.ensure(((size_t)M + 1) * 4))) return rc;
+    if ((rc = d.wwl_sel.ensure(((size_t)M + 1) * 4))) return rc;
+    if ((rc = d.short_nxt.ensure(((size_t)M + 1) * 4))) return rc;
+    if ((rc = d.short_tmp.ensure(((size_t)M + 1) * 4))) return rc;
+    if ((rc = d.short_mark.ensure(((size_t)M + 1) * 4))) return rc;
+    HIP_TRY(launch_wwl_starts(d.T, sh->d_hay, n, d.n_cu, true, nullptr, (const uint64_t *)d.offsets.p, (uint32_t *)d.wwl_rs.p,
+                              stream));
+    HIP_TRY(launch_wwl_walk(d.T, sh->d_hay, n, (const uint32_t *)d.wwl_rs.p, M, (uint32_t *)d.short_nxt.p,
+                            (uint32_t *)d.short_mark.p, (int32_t *)d.wwl_mend.p, (int32_t *)d.wwl_mid.p, stream));
+    if (prof) HIP_TRY(hipEventRecord(d.ev[1], stream));
+    HIP_TRY(launch_chain_mark((uint32_t *)d.short_nxt.p, (uint32_t *)d.short_tmp.p, (uint32_t *)d.short_mark.p, M, stream));
+    HIP_TRY(launch_wwl_select((const uint32_t *)d.short_mark.p, (const int32_t *)d.wwl_mend.p, (uint32_t *)d.wwl_sel.p, M, stream));
+    if ((rc = d.offsets.ensure((size_t)M * 8))) return rc; // (the tile offsets are no longer needed)
+    if ((rc = d.scan_tmp.ensure(((size_t)M / 2048 + 2) * 8))) return rc;
+    HIP_TRY(launch_exclusive_scan((const uint32_t *)d.wwl_sel.p, M, (uint64_t *)d.offsets.p, (uint64_t *)d.scan_tmp.p, stream));
+    HIP_TRY(launch_wwl_emit((const uint32_t *)d.wwl_rs.p, (const uint32_t *)d.wwl_sel.p, (const int32_t *)d.wwl_mend.p,
+                            (const int32_t *)d.wwl_mid.p, (const uint64_t *)d.offsets.p, M, record_kind, d_out, cap, stream));
+    if (prof) HIP_TRY(hipEventRecord(d.ev[2], stream));
+    HIP_TRY(hipMemcpyAsync(d.h_counter, (const uint64_t *)d.scan_tmp.p + scan_tiles_for(M), 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    *n_out = *d.h_counter;
+    if (prof) {
+        HIP_TRY(hipEventElapsedTime(&prof->scan_ms, d.ev[0], d.ev[1]));
+        HIP_TRY(hipEventElapsedTime(&prof->finalize_ms, d.ev[1], d.ev[2]));
+        HIP_TRY(hipEventElapsedTime(&prof->total_ms, d.ev[0], d.ev[2]));
+        prof->scan_units = n;
+        prof->n_matches = *n_out;
+        std::snprintf(prof->scan_kernel, sizeof(prof->scan_kernel), "k_wwl_walk");
+    }
+    return *n_out > cap ? ACGPU_E_OVERFLOW : ACGPU_OK;
+}
+
 int device_for_call(acgpu_automaton *a, DeviceState **d) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
@@ -592,6 +651,7 @@ int match_shard(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_
     case ACGPU_MODE_LONGEST: return match_longest(a, d, sh, record_kind, d_out, cap, n_out, stream, prof);
     case ACGPU_MODE_WHOLEWORD: return match_wholeword(a, d, sh, record_kind, d_out, cap, n_out, stream, prof);
     case ACGPU_MODE_SHORTEST: return match_shortest(a, d, sh, record_kind, d_out, cap, n_out, stream, prof);
+    case ACGPU_MODE_WWLONGEST: return match_wwlongest(a, d, sh, record_kind, d_out, cap, n_out, stream, prof);
     default: return ACGPU_E_UNSUPPORTED;
     }
 }
@@ -728,6 +788,7 @@ int acgpu_stream_open(const acgpu_automaton *a, acgpu_stream **out) {
     if (!a || !out) return ACGPU_E_INVALID;
     *out = nullptr;
     if (a->t.mode == ACGPU_MODE_WHOLEWORD && !a->t.fold_consistent) return ACGPU_E_UNSUPPORTED;
+    if (a->t.mode == ACGPU_MODE_WWLONGEST) return ACGPU_E_UNSUPPORTED; // the scan position depends on every earlier walk
     acgpu_stream *s = new (std::nothrow) acgpu_stream();
     if (!s) return ACGPU_E_NOMEM;
     s->a = const_cast<acgpu_automaton *>(a);

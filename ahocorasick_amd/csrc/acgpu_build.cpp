@@ -41,17 +41,19 @@ void trim_keyword(const uint8_t *word, const uint16_t *w, uint64_t len, uint64_t
 
 int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uint32_t n_kw, int case_sensitive,
                  const uint16_t *lower_tbl, const uint8_t *wordchar_tbl, HostTables &t, int64_t *bad_keyword) {
-    if (mode != ACGPU_MODE_ALL && mode != ACGPU_MODE_LONGEST && mode != ACGPU_MODE_WHOLEWORD && mode != ACGPU_MODE_SHORTEST)
+    if (mode != ACGPU_MODE_ALL && mode != ACGPU_MODE_LONGEST && mode != ACGPU_MODE_WHOLEWORD && mode != ACGPU_MODE_SHORTEST &&
+        mode != ACGPU_MODE_WWLONGEST)
         return ACGPU_E_INVALID;
+    const bool word_mode = mode == ACGPU_MODE_WHOLEWORD || mode == ACGPU_MODE_WWLONGEST;
     if (n_kw && (!kw_units || !kw_off)) return ACGPU_E_INVALID;
     if (!case_sensitive && !lower_tbl) return ACGPU_E_INVALID;
-    if (mode == ACGPU_MODE_WHOLEWORD && !wordchar_tbl) return ACGPU_E_INVALID;
+    if (word_mode && !wordchar_tbl) return ACGPU_E_INVALID;
 
     t.mode = mode;
     t.cs = case_sensitive != 0;
     t.lower.resize(65536);
     for (uint32_t c = 0; c < 65536; c++) t.lower[c] = t.cs ? (uint16_t)c : lower_tbl[c];
-    if (mode == ACGPU_MODE_WHOLEWORD) {
+    if (word_mode) {
         t.wflags.resize(65536);
         t.fold_consistent = true;
         for (uint32_t c = 0; c < 65536; c++) {
@@ -72,6 +74,7 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
     for (uint32_t k = 0; k < n_kw; k++) {
         const uint16_t *w = kw_units + kw_off[k];
         uint64_t len = kw_off[k + 1] - kw_off[k], ws = 0, we = len;
+        if (mode == ACGPU_MODE_WWLONGEST) trim_keyword(wordchar_tbl, w, len, ws, we); // inner non-word units are allowed
         if (mode == ACGPU_MODE_WHOLEWORD) {
             trim_keyword(wordchar_tbl, w, len, ws, we);
             for (uint64_t i = ws; i < we; i++) {
@@ -138,7 +141,7 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
     bfs.reserve(N);
     bfs.push_back(0);
     std::vector<uint32_t> fail(N, 0), olen(N, 0), olink(N, 0), oid(N, ~0u);
-    const bool want_fail = (mode != ACGPU_MODE_WHOLEWORD); // WholeWord is a plain trie (S/WholeWordMatchMap.java:303-321)
+    const bool want_fail = !word_mode; // WholeWord / WholeWordLongest are plain tries (S/WholeWordMatchMap.java:303-321)
     for (size_t qi = 0; qi < bfs.size(); qi++) {
         uint32_t s = bfs[qi];
         for (uint32_t ci = child_begin[s]; ci < child_begin[s + 1]; ci++) {
@@ -191,6 +194,31 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
         t.out_link[n] = olink[s] ? newid[olink[s]] : 0;
         t.out_id[n] = oid[s];
         t.term_id[n] = nodes[s].kw;
+    }
+
+    if (mode == ACGPU_MODE_WWLONGEST) {
+        // the last keyword on the path that was followed by a non-word unit, carried down the trie
+        // (S/WholeWordLongestMatchSet.java:226-244): out_len = its length, out_link = its distance from the node, out_id
+        std::vector<uint32_t> flen(N, 0), foff(N, 0), fid(N, ~0u);
+        for (uint32_t s : bfs) {
+            for (uint32_t ci = child_begin[s]; ci < child_begin[s + 1]; ci++) {
+                const uint32_t c = child_ids[ci];
+                if (nodes[s].kw != ~0u && !wordchar_tbl[nodes[c].unit]) {
+                    flen[c] = nodes[s].depth;
+                    foff[c] = 1;
+                    fid[c] = nodes[s].kw;
+                } else {
+                    flen[c] = flen[s];
+                    foff[c] = foff[s] + 1;
+                    fid[c] = fid[s];
+                }
+            }
+        }
+        for (uint32_t s = 0; s < N; s++) {
+            t.out_len[newid[s]] = flen[s];
+            t.out_link[newid[s]] = foff[s];
+            t.out_id[newid[s]] = fid[s];
+        }
     }
 
     // ---- 5. hashed goto edges keyed by (state, folded unit) ----
@@ -264,7 +292,7 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
     t.dense = false;
     t.range_cls = false;
     std::vector<uint32_t> cls_of(65536, 0); // class of a FOLDED unit (0 = occurs in no keyword)
-    if (mode != ACGPU_MODE_WHOLEWORD) {
+    if (!word_mode) {
         std::vector<uint8_t> used(65536, 0);
         uint32_t n_used = 0, minu = 65535, maxu = 0;
         for (uint32_t i = 1; i < N; i++) {

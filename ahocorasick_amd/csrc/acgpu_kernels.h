@@ -116,9 +116,20 @@ namespace acgpu {
 // ShortestMatch: greedy selection over the ordered all-matches list (acgpu_shortest.hip)
 hipError_t launch_shortest_select(const int32_t *d_recs, uint32_t M, int64_t entry, uint32_t *d_nxt, uint32_t *d_tmp,
                                   uint32_t *d_mark, hipStream_t stream);
+hipError_t launch_chain_mark(uint32_t *d_nxt, uint32_t *d_tmp, uint32_t *d_mark, uint32_t M, hipStream_t stream);
 hipError_t launch_shortest_emit(const int32_t *d_recs, uint32_t M, const uint32_t *d_mark, const uint64_t *d_offsets,
                                 const uint64_t *d_total, int record_kind, void *d_out, uint64_t cap, int64_t entry,
                                 unsigned long long *d_exit, hipStream_t stream);
+
+// WholeWordLongest (acgpu_wwlongest.hip)
+uint32_t wwl_tiles(uint32_t n_units);
+hipError_t launch_wwl_starts(const DevTables &t, const uint16_t *d_hay, uint32_t n, int n_cu, bool fill, uint32_t *d_counts,
+                             const uint64_t *d_offsets, uint32_t *d_rs, hipStream_t stream);
+hipError_t launch_wwl_walk(const DevTables &t, const uint16_t *d_hay, uint32_t n, const uint32_t *d_rs, uint32_t M,
+                           uint32_t *d_nxt, uint32_t *d_mark, int32_t *d_mend, int32_t *d_mid, hipStream_t stream);
+hipError_t launch_wwl_select(const uint32_t *d_mark, const int32_t *d_mend, uint32_t *d_sel, uint32_t M, hipStream_t stream);
+hipError_t launch_wwl_emit(const uint32_t *d_rs, const uint32_t *d_sel, const int32_t *d_mend, const int32_t *d_mid,
+                           const uint64_t *d_offsets, uint32_t M, int record_kind, void *d_out, uint64_t cap, hipStream_t stream);
 
 uint32_t ww_fold_pages_in_lds(const DevTables &t); // 0: the fold table is not staged (case sensitive / too many pages)
 size_t ww_lds_bytes(int block_threads, const DevTables &t);

@@ -111,8 +111,15 @@ hipError_t launch_shortest_select(const int32_t *d_recs, uint32_t M, int64_t ent
     const int32_t e32 = (int32_t)std::min<int64_t>(std::max<int64_t>(entry, 0), 0x7fffffff);
     hipLaunchKernelGGL(k_short_clear, grid, block, 0, stream, d_mark, M);
     hipLaunchKernelGGL(k_short_next, grid, block, 0, stream, d_recs, M, e32, d_nxt, d_mark);
+    return launch_chain_mark(d_nxt, d_tmp, d_mark, M, stream);
+}
+
+// Marks every element of the chain that starts at the elements already marked: nxt[k] in (k, M], nxt[M] = M.
+// d_nxt and d_tmp (M+1 entries each) are both clobbered.
+hipError_t launch_chain_mark(uint32_t *d_nxt, uint32_t *d_tmp, uint32_t *d_mark, uint32_t M, hipStream_t stream) {
+    const dim3 block(256), grid((M + 1 + 255) / 256);
     uint32_t *in = d_nxt, *out = d_tmp;
-    for (uint64_t reach = 1; reach <= M; reach <<= 1) { // after the round with 2^t-step jumps, 2^(t+1) chain records are marked
+    for (uint64_t reach = 1; reach <= M; reach <<= 1) { // after the round with 2^t-step jumps, 2^(t+1) chain elements are marked
         hipLaunchKernelGGL(k_short_round, grid, block, 0, stream, in, out, d_mark, M);
         std::swap(in, out);
     }

@@ -1,0 +1,188 @@
+// acgpu_wwlongest.hip -- WholeWordLongestMatchSet/Map on gfx950.
+//
+// The reference (S/WholeWordLongestMatchSet.java:47-178) walks a plain keyword trie from a word start through word AND
+// non-word units (keywords may contain spaces) for as long as a transition exists; where the walk stops (unit i) it
+// reports the whole path if it is a keyword and unit i is not a word character, else the last keyword on the path that
+// was followed by a non-word unit (the node's carried "fail match", :226-244); then it skips to the first word start
+// after i -- words covered by the walk are not rescanned (:85-99).  In parallel form:
+//
+//   k_wwl_starts (count / fill): the walk starts = position 0 and every word character whose left neighbour is not one,
+//                  compacted in text order into RS[] (65536-bit table in LDS, one tile of 2048 units per block step).
+//   k_wwl_walk   : one lane per walk start: the trie walk (hashed edges, L2 resident), the record it would report, and
+//                  NXT[k] = the first walk start after the stop position (binary search in RS).
+//   chain        : the walk starts the scan really visits are 0, NXT[0], NXT[NXT[0]], ...: marked by pointer doubling
+//                  (launch_chain_mark, shared with acgpu_shortest.hip); the marked starts that report something are
+//                  prefix-summed and scattered in order.
+// Fold-consistent word-character tables only (every case-sensitive use and the default table); the whole haystack is
+// one shard.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "acgpu_device.h"
+#include "acgpu_kernels.h"
+
+namespace acgpu {
+
+namespace {
+
+constexpr int kStartsBlock = 256;
+constexpr uint32_t kStartsTile = kStartsBlock * 8; // units per block step
+
+__device__ __forceinline__ uint32_t wbit(const uint32_t *wbits, uint32_t unit) {
+    return __builtin_amdgcn_ubfe(wbits[unit >> 5], unit, 1);
+}
+
+// FILL == false: counts[tile] = walk starts in the tile.  FILL == true: RS[offsets[tile] + rank] = position.
+template <bool FILL>
+__global__ __launch_bounds__(kStartsBlock) void k_wwl_starts(DevTables T, const uint16_t *hay, uint32_t n, uint32_t n_tiles,
+                                                            uint32_t *counts, const uint64_t *offsets, uint32_t *rs) {
+    __shared__ uint32_t wbits[2048];
+    __shared__ uint32_t wave_tot[kStartsBlock / kWave];
+    for (uint32_t w = threadIdx.x; w < 2048; w += blockDim.x) {
+        uint32_t bits = 0;
+        for (uint32_t k = 0; k < 32; ++k) bits |= (uint32_t)(T.wflags[w * 32 + k] & 1u) << k;
+        wbits[w] = bits;
+    }
+    __syncthreads();
+    const uint32_t lane = lane_id(), wave = threadIdx.x / kWave;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint32_t v = tile * kStartsTile + threadIdx.x * 8;
+        uint32_t wm = 0;
+        if (v + 8 <= n) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(hay + v);
+            const uint32_t ww[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wm |= wbit(wbits, (ww[j >> 1] >> (16 * (j & 1))) & 0xffffu) << j;
+        } else {
+            for (uint32_t j = 0; j < 8 && v + j < n; ++j) wm |= wbit(wbits, hay[v + j]) << j;
+        }
+        const uint32_t prev = (v > 0 && v <= n) ? wbit(wbits, hay[v - 1]) : 0u;
+        uint32_t sm = wm & ~((wm << 1) | prev) & 0xffu;
+        if (v == 0 && n > 0) sm |= 1u; // the scan starts at position 0 whatever stands there
+        const uint32_t cnt = __popc(sm);
+        const uint32_t incl = wave_inclusive_scan(cnt);
+        if (lane == kWave - 1) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t base = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kStartsBlock / kWave; ++w) {
+            if ((uint32_t)w < wave) base += wave_tot[w];
+            total += wave_tot[w];
+        }
+        if (!FILL) {
+            if (threadIdx.x == 0) counts[tile] = total;
+        } else {
+            uint64_t dst = offsets[tile] + base + incl - cnt;
+            while (sm) {
+                rs[dst++] = v + (uint32_t)__builtin_ctz(sm);
+                sm &= sm - 1;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_wwl_walk(DevTables T, const uint16_t *hay, uint32_t n, const uint32_t *rs, uint32_t M,
+                                                  uint32_t *nxt, uint32_t *mark, int32_t *mend, int32_t *mid) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > M) return;
+    if (k == M) {
+        nxt[M] = M;
+        mark[M] = 0;
+        return;
+    }
+    mark[k] = k == 0 ? 1u : 0u; // the scan starts at the first walk start
+    const uint32_t ws = rs[k];
+    uint32_t node = 0, i = ws, stop_unit = 0;
+    while (i < n) {
+        const uint32_t u = hay[i];
+        const uint32_t child = hashed_goto(T.hkeys, T.hvals, T.hmask, node, T.cs ? u : (uint32_t)T.lower[u]);
+        if (child == ~0u) {
+            stop_unit = u;
+            break;
+        }
+        node = child;
+        ++i;
+    }
+    // what the reference reports where the walk stops
+    int32_t end = 0, id = -1;
+    const bool at_end = i >= n;
+    const bool stop_is_word = !at_end && (T.wflags[stop_unit] & 1u);
+    if (!stop_is_word && node != 0 && T.term_id[node] != ~0u) {
+        end = (int32_t)i; // the whole path is a keyword and ends at a word boundary
+        id = (int32_t)T.term_id[node];
+    } else if (T.out_len[node] != 0) { // the carried fail match: ends out_link[node] units before the stop
+        end = (int32_t)(i - T.out_link[node]);
+        id = (int32_t)T.out_id[node];
+    }
+    mend[k] = end;
+    mid[k] = id;
+    // the scan resumes at the first walk start after the stop position
+    uint32_t lo = k + 1, hi = M;
+    while (lo < hi) {
+        const uint32_t mid_k = lo + ((hi - lo) >> 1);
+        if (rs[mid_k] <= i) lo = mid_k + 1;
+        else hi = mid_k;
+    }
+    nxt[k] = lo;
+}
+
+__global__ __launch_bounds__(256) void k_wwl_select(const uint32_t *mark, const int32_t *mend, uint32_t *sel, uint32_t M) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < M) sel[k] = (mark[k] && mend[k] != 0) ? 1u : 0u;
+}
+
+template <int REC>
+__global__ __launch_bounds__(256) void k_wwl_emit(const uint32_t *rs, const uint32_t *sel, const int32_t *mend,
+                                                  const int32_t *mid, const uint64_t *offsets, uint32_t M, void *out,
+                                                  uint64_t cap) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= M || !sel[k]) return;
+    const uint64_t dst = offsets[k];
+    if (dst >= cap) return;
+    if (REC == ACGPU_REC_SET) {
+        reinterpret_cast<int2 *>(out)[dst] = make_int2((int)rs[k], mend[k]);
+    } else {
+        int32_t *o = reinterpret_cast<int32_t *>(out) + dst * 3;
+        o[0] = (int)rs[k]; o[1] = mend[k]; o[2] = mid[k];
+    }
+}
+
+} // namespace
+
+uint32_t wwl_tiles(uint32_t n_units) { return (n_units + kStartsTile - 1) / kStartsTile; }
+
+hipError_t launch_wwl_starts(const DevTables &t, const uint16_t *d_hay, uint32_t n, int n_cu, bool fill, uint32_t *d_counts,
+                             const uint64_t *d_offsets, uint32_t *d_rs, hipStream_t stream) {
+    const uint32_t n_tiles = wwl_tiles(n);
+    if (n_tiles == 0) return hipSuccess;
+    const dim3 block(kStartsBlock), grid(std::min<uint32_t>(n_tiles, (uint32_t)n_cu * 8));
+    if (fill) hipLaunchKernelGGL(k_wwl_starts<true>, grid, block, 0, stream, t, d_hay, n, n_tiles, d_counts, d_offsets, d_rs);
+    else hipLaunchKernelGGL(k_wwl_starts<false>, grid, block, 0, stream, t, d_hay, n, n_tiles, d_counts, d_offsets, d_rs);
+    return hipGetLastError();
+}
+
+hipError_t launch_wwl_walk(const DevTables &t, const uint16_t *d_hay, uint32_t n, const uint32_t *d_rs, uint32_t M,
+                           uint32_t *d_nxt, uint32_t *d_mark, int32_t *d_mend, int32_t *d_mid, hipStream_t stream) {
+    hipLaunchKernelGGL(k_wwl_walk, dim3((M + 1 + 255) / 256), dim3(256), 0, stream, t, d_hay, n, d_rs, M, d_nxt, d_mark, d_mend,
+                       d_mid);
+    return hipGetLastError();
+}
+
+hipError_t launch_wwl_select(const uint32_t *d_mark, const int32_t *d_mend, uint32_t *d_sel, uint32_t M, hipStream_t stream) {
+    hipLaunchKernelGGL(k_wwl_select, dim3((M + 255) / 256), dim3(256), 0, stream, d_mark, d_mend, d_sel, M);
+    return hipGetLastError();
+}
+
+hipError_t launch_wwl_emit(const uint32_t *d_rs, const uint32_t *d_sel, const int32_t *d_mend, const int32_t *d_mid,
+                           const uint64_t *d_offsets, uint32_t M, int record_kind, void *d_out, uint64_t cap, hipStream_t stream) {
+    const dim3 grid((M + 255) / 256), block(256);
+    if (record_kind == ACGPU_REC_SET)
+        hipLaunchKernelGGL(k_wwl_emit<ACGPU_REC_SET>, grid, block, 0, stream, d_rs, d_sel, d_mend, d_mid, d_offsets, M, d_out, cap);
+    else
+        hipLaunchKernelGGL(k_wwl_emit<ACGPU_REC_MAP>, grid, block, 0, stream, d_rs, d_sel, d_mend, d_mid, d_offsets, M, d_out, cap);
+    return hipGetLastError();
+}
+
+} // namespace acgpu

@@ -73,4 +73,28 @@ public final class GpuMatchers {
             super(NativeAutomaton.MODE_WHOLEWORD, keywords, values, caseSensitive, wordChars(wordCharacters, toggleFlags));
         }
     }
+
+    /** Drop-in for WholeWordLongestMatchSet (keywords may contain non-word characters). */
+    public static class GpuWholeWordLongestMatchSet extends GpuAhoCorasickSet {
+        public GpuWholeWordLongestMatchSet(final Iterable<String> keywords, boolean caseSensitive) {
+            this(keywords, caseSensitive, null, null);
+        }
+
+        public GpuWholeWordLongestMatchSet(final Iterable<String> keywords, boolean caseSensitive, char[] wordCharacters,
+                boolean[] toggleFlags) {
+            super(NativeAutomaton.MODE_WWLONGEST, keywords, caseSensitive, wordChars(wordCharacters, toggleFlags));
+        }
+    }
+
+    /** Drop-in for WholeWordLongestMatchMap (String overload; the Readable overload stays on the reference class). */
+    public static class GpuWholeWordLongestMatchMap<T> extends GpuAhoCorasickMap<T> {
+        public GpuWholeWordLongestMatchMap(final Iterable<String> keywords, final Iterable<? extends T> values, boolean caseSensitive) {
+            this(keywords, values, caseSensitive, null, null);
+        }
+
+        public GpuWholeWordLongestMatchMap(final Iterable<String> keywords, final Iterable<? extends T> values, boolean caseSensitive,
+                char[] wordCharacters, boolean[] toggleFlags) {
+            super(NativeAutomaton.MODE_WWLONGEST, keywords, values, caseSensitive, wordChars(wordCharacters, toggleFlags));
+        }
+    }
 }

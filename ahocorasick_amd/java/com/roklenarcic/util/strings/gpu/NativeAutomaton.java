@@ -5,7 +5,7 @@ package com.roklenarcic.util.strings.gpu;
  * NOT compiled in the build image (no JDK there); see INTEGRATION.md for the build line.
  */
 final class NativeAutomaton implements AutoCloseable {
-    static final int MODE_ALL = 0, MODE_LONGEST = 1, MODE_WHOLEWORD = 2, MODE_SHORTEST = 3;
+    static final int MODE_ALL = 0, MODE_LONGEST = 1, MODE_WHOLEWORD = 2, MODE_SHORTEST = 3, MODE_WWLONGEST = 4;
 
     static {
         System.loadLibrary("acgpu_jni");

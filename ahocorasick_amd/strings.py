@@ -396,3 +396,28 @@ class WholeWordMatchMap(StringMap):
 
     def get_word_chars(self):
         return self._auto.word_chars
+
+
+class WholeWordLongestMatchSet(StringSet):
+    """S/WholeWordLongestMatchSet.java:7-45: whole-word matches of keywords that may contain non-word characters
+    ("as if"); of the keywords starting at a word the longest whole-word one wins, and the scan continues after the
+    text it looked at."""
+    _MODE = N.MODE_WWLONGEST
+
+    def __init__(self, keywords, case_sensitive, word_characters=None, toggle_flags=None, threshold_strategy=None):
+        self._init(keywords, case_sensitive, word_chars=_word_chars(word_characters, toggle_flags))
+
+    def get_word_chars(self):
+        return self._auto.word_chars
+
+
+class WholeWordLongestMatchMap(StringMap):
+    """S/WholeWordLongestMatchMap.java:22-54"""
+    _MODE = N.MODE_WWLONGEST
+
+    def __init__(self, keywords, values, case_sensitive, word_characters=None, toggle_flags=None,
+                 threshold_strategy=None):
+        self._init(keywords, values, case_sensitive, word_chars=_word_chars(word_characters, toggle_flags))
+
+    def get_word_chars(self):
+        return self._auto.word_chars

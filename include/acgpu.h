@@ -51,6 +51,10 @@ extern "C" {
 #define ACGPU_MODE_WHOLEWORD 2 /* WholeWordMatchSet / WholeWordMatchMap S/WholeWordMatchSet.java:47-132, S/WholeWordMatchMap.java:155-240 */
 #define ACGPU_MODE_SHORTEST 3  /* ShortestMatchSet / ShortestMatchMap   S/ShortestMatchSet.java:193-262, S/ShortestMatchMap.java:294-372;
                                   keyword_id = FIRST duplicate (S/ShortestMatchMap.java:47-49) */
+#define ACGPU_MODE_WWLONGEST 4 /* WholeWordLongestMatchSet / Map        S/WholeWordLongestMatchSet.java:47-178, S/WholeWordLongestMatchMap.java:180-305;
+                                  keywords are trimmed but may contain non-word characters; the whole haystack must be ONE
+                                  shard (own range = buffer, text_begin = text_end = 1), no streaming form, fold-consistent
+                                  word-character tables only -- ACGPU_E_UNSUPPORTED otherwise */
 
 /* output record layouts */
 #define ACGPU_REC_SET 8  /* acgpu_set_match: what SetMatchListener.match(haystack, start, end) receives */
@@ -81,7 +85,7 @@ typedef struct acgpu_automaton acgpu_automaton;
  *                    (Character.toLowerCase(char), S/AhoCorasickSet.java:33,229).
  *  lower_tbl       : 65536 entries, required when case_sensitive == 0 (the caller's JVM fills
  *                    it with its own Character.toLowerCase so that parity holds for that JVM).
- *  wordchar_tbl    : 65536 flags, required for ACGPU_MODE_WHOLEWORD
+ *  wordchar_tbl    : 65536 flags, required for ACGPU_MODE_WHOLEWORD and ACGPU_MODE_WWLONGEST
  *                    (WordCharacters.generateWordCharsFlags*, S/WordCharacters.java:6-39).
  *  bad_keyword     : on ACGPU_E_NONWORD receives the index of the offending keyword (may be NULL).
  * The Thresholder argument of the reference constructors is a results-neutral memory/speed

@@ -845,3 +845,59 @@ def test_shortest_dense_overlaps_many_matches_per_position():
     want = Oracle(FAM_SHORTEST, kws).match(hay)
     got = Automaton(N.MODE_SHORTEST, kws, True).match_host(hay, True)
     assert got.shape == want.shape and (got == want).all()
+
+
+# ---- WholeWordLongestMatchSet / Map (ACGPU_MODE_WWLONGEST) --------------------------------------------------------------
+
+def test_fixtures_wwlongest(fixtures):
+    from ahocorasick_amd import WholeWordLongestMatchMap, WholeWordLongestMatchSet
+    for fx in fixtures:
+        if "keywords_gen" in fx:
+            continue
+        kws = fx["WWL_keywords"]
+        got = WholeWordLongestMatchMap(kws, _ids(len(kws)), True).find_all(fx["haystack"])
+        assert got.tolist() == fx["WWL"], fx["name"]
+        assert len(got) == fx["WWL_count"]  # the count T/WholeWordLongestMatchTest.java:46-65 expects
+        assert WholeWordLongestMatchSet(kws, True).find_all(fx["haystack"]).tolist() == [r[:2] for r in fx["WWL"]]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_wwlongest_vs_oracle(seed):
+    from oracle.oracle import FAM_WWLONGEST
+    rng = np.random.default_rng(700 + seed)
+    alpha = [ord(c) for c in "abAB  -."] + [0x00E9, 0x00C9]
+    for it in range(10):
+        hay, kws = rand_case(rng, alpha, int(rng.integers(1, 40)), int(rng.choice([3, 6, 12])),
+                             int(rng.choice([0, 1, 2, 60, 5000, 70001])))
+        for cs in (True, False):
+            want = Oracle(FAM_WWLONGEST, kws, case_sensitive=cs, lower=LOWER, word_chars=WORD).match(hay)
+            got = Automaton(N.MODE_WWLONGEST, kws, cs, word_chars=WORD).match_host(hay, True, cap=16)
+            assert got.shape == want.shape and (got == want).all(), (seed, it, cs)
+
+
+def test_wwlongest_listener_examples_and_limits():
+    from ahocorasick_amd import Stream, WholeWordLongestMatchMap, WholeWordLongestMatchSet
+    m = WholeWordLongestMatchMap(["as", "if", "as if"], [1, 2, 3], True)
+    seen = []
+    m.match("as if, as in; ax if", lambda h, s, e, v: seen.append((s, e, v)) or True)
+    assert seen == [(0, 5, 3), (7, 9, 1), (17, 19, 2)]
+    seen = []
+    WholeWordLongestMatchSet(["a"], True).match("a a a", lambda h, s, e: seen.append((s, e)) or len(seen) < 2)
+    assert seen == [(0, 1), (2, 3)]
+    # natural-language sized case: multi-word keywords over a token stream
+    words = [w for w in synth.config_keywords("C5")[:3000]]
+    sp = np.array([32], dtype=np.uint16)
+    kws = words[:2000] + [np.concatenate([words[i], sp, words[i + 1]]) for i in range(0, 1000, 2)]
+    block = synth.mixed_script_haystack(77, 1 << 18, words, swapcase_tbl=synth.swapcase_table())
+    from oracle.oracle import FAM_WWLONGEST
+    want = Oracle(FAM_WWLONGEST, kws, case_sensitive=False, lower=LOWER, word_chars=WORD).match(block)
+    got = Automaton(N.MODE_WWLONGEST, kws, False, word_chars=WORD).match_host(block, True)
+    assert len(want) > 1000 and got.shape == want.shape and (got == want).all()
+    # shards and streams are refused, not mis-scanned
+    import torch
+    a = Automaton(N.MODE_WWLONGEST, ["as if"], True, word_chars=WORD)
+    d = torch.zeros(64, dtype=torch.int16, device="cuda")
+    o = torch.zeros((8, 3), dtype=torch.int32, device="cuda")
+    assert a.match_device(d.data_ptr(), 64, True, o.data_ptr(), 8, own=(8, 64))[1] == N.E_UNSUPPORTED
+    with pytest.raises(N.AcgpuError):
+        Stream(a)

@@ -16,7 +16,7 @@ import torch  # noqa: E402
 from ahocorasick_amd import _native as N  # noqa: E402
 from ahocorasick_amd.strings import Automaton  # noqa: E402
 from ahocorasick_amd.unicode_tables import default_word_chars, java_lower_table  # noqa: E402
-from oracle.oracle import FAM_AC, FAM_LONGEST, FAM_SHORTEST, FAM_WHOLEWORD, Oracle  # noqa: E402
+from oracle.oracle import FAM_AC, FAM_LONGEST, FAM_SHORTEST, FAM_WHOLEWORD, FAM_WWLONGEST, Oracle  # noqa: E402
 
 LOWER = java_lower_table()
 WORD = default_word_chars()
@@ -46,7 +46,7 @@ def dev_match(a, d_hay, n, cap, **kw):
 
 
 def one_case(rng, it):
-    fam = int(rng.integers(0, 4))
+    fam = int(rng.integers(0, 5))
     alpha = ALPHABETS[int(rng.integers(0, len(ALPHABETS)))]
     cs = bool(rng.integers(0, 2))
     n_kw = int(rng.integers(1, 60))
@@ -79,15 +79,15 @@ def one_case(rng, it):
         knobs["rdense_budget_bytes"] = 0  # hashed reversed trie
     for k, v in knobs.items():
         N.set_tunable(k, v)
-    mode = [N.MODE_ALL, N.MODE_LONGEST, N.MODE_WHOLEWORD, N.MODE_SHORTEST][fam]
-    ofam = [FAM_AC, FAM_LONGEST, FAM_WHOLEWORD, FAM_SHORTEST][fam]
-    wc = WORD if fam == 2 else None
+    mode = [N.MODE_ALL, N.MODE_LONGEST, N.MODE_WHOLEWORD, N.MODE_SHORTEST, N.MODE_WWLONGEST][fam]
+    ofam = [FAM_AC, FAM_LONGEST, FAM_WHOLEWORD, FAM_SHORTEST, FAM_WWLONGEST][fam]
+    wc = WORD if fam in (2, 4) else None
     a = Automaton(mode, kws, cs, word_chars=wc)
     want = Oracle(ofam, kws, case_sensitive=cs, lower=LOWER, word_chars=wc).match(hay)
     got = a.match_host(hay, True, cap=64)
     desc = (it, fam, cs, n_kw, min_len, max_len, n, len(alpha), knobs, a.info()["filter_k"], a.info()["tile_kernel"])
     assert got.shape == want.shape and (got == want).all(), ("host path", desc)
-    if n >= 1000:
+    if n >= 1000 and fam != 4:
         # shards of the device-resident buffer
         d_hay = torch.from_numpy(hay.view(np.int16)).cuda()
         cuts = sorted(set([0, n] + [int(x) for x in rng.integers(1, n, 2)]))
@@ -111,12 +111,13 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
     rng = np.random.default_rng(seed)
     t0 = time.time()
-    counts = [0, 0, 0, 0]
+    counts = [0, 0, 0, 0, 0]
     it = 0
     while time.time() - t0 < budget:
         counts[one_case(rng, it)] += 1
         it += 1
-    print("fuzz ok: %d cases (AC %d, Longest %d, WholeWord %d, Shortest %d) in %.0f s, seed %d" % (it, *counts, time.time() - t0, seed))
+    print("fuzz ok: %d cases (AC %d, Longest %d, WholeWord %d, Shortest %d, WholeWordLongest %d) in %.0f s, seed %d" % (
+        it, *counts, time.time() - t0, seed))
 
 
 if __name__ == "__main__":
