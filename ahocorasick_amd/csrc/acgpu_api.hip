@@ -68,6 +68,7 @@ struct DeviceState {
     DevBuf counter, chunk_counts, offsets, scan_tmp, scratch, chain, lenbuf, statebuf;
     DevBuf stage_hay, stage_out; // acgpu_match_u16 staging
     DevBuf short_recs, short_nxt, short_tmp, short_mark; // SHORTEST: all-matches list + selection scratch
+    DevBuf blockmax;                                     // LONGEST: farthest landing per 64 positions
     DevBuf wwl_rs, wwl_mend, wwl_mid, wwl_sel;          // WWLONGEST: walk starts and what each would report
     unsigned long long *h_counter = nullptr; // pinned
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -77,7 +78,7 @@ struct DeviceState {
         counter.release(); chunk_counts.release(); offsets.release(); scan_tmp.release(); scratch.release();
         chain.release(); lenbuf.release(); statebuf.release(); stage_hay.release(); stage_out.release();
         short_recs.release(); short_nxt.release(); short_tmp.release(); short_mark.release();
-        wwl_rs.release(); wwl_mend.release(); wwl_mid.release(); wwl_sel.release();
+        wwl_rs.release(); wwl_mend.release(); wwl_mid.release(); wwl_sel.release(); blockmax.release();
         if (h_counter) (void)hipHostFree(h_counter);
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         for (auto &tk : tickets) {
@@ -370,13 +371,18 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
     int rc;
     if ((rc = d.lenbuf.ensure((size_t)sh->n_units * S.len_bytes + 64))) return rc;
     S.d_len = d.lenbuf.p;
+    if ((rc = d.blockmax.ensure((own_len / 64 + 2) * 4))) return rc;
+    S.d_blockmax = (uint32_t *)d.blockmax.p;
     S.d_state = nullptr;
     if (record_kind == ACGPU_REC_MAP) {
         if ((rc = d.statebuf.ensure((size_t)sh->n_units * 4 + 64))) return rc;
         S.d_state = (uint32_t *)d.statebuf.p;
     }
     LongestChainLaunch Cn{};
-    const uint64_t T_units = std::max<uint64_t>(1024, 4ull * t.max_len);
+    // positions per chain lane: the synchronisation scan skips 64-position blocks that cannot reach the tile, so tiles
+    // can stay small (more lanes, shorter dependent chains) even when keywords are long
+    // (measured at config 4: 4096-8192 positions per lane are best; small inputs get more, shorter lanes)
+    const uint64_t T_units = tunables().region_units > 0 ? (uint64_t)tunables().region_units : (own_len >= (1ull << 24) ? 4096 : 1024);
     Cn.tile_units = (uint32_t)T_units;
     Cn.n_tiles = (uint32_t)((sh->own_end - entry + T_units - 1) / T_units);
     if ((rc = d.counter.ensure(64))) return rc;
@@ -387,7 +393,9 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
     Cn.d_state = S.d_state;
     Cn.d_out_id = d.T.term_id; // state[] holds the trie node of the longest keyword starting at a position
     Cn.len_bytes = S.len_bytes;
+    Cn.own_begin = (uint32_t)sh->own_begin;
     Cn.own_end = (uint32_t)sh->own_end;
+    Cn.d_blockmax = S.d_blockmax;
     Cn.entry = (uint32_t)entry;
     Cn.max_len = t.max_len;
     Cn.d_counts = (uint32_t *)d.chunk_counts.p;

@@ -83,6 +83,7 @@ struct LongestScanLaunch {
     uint32_t chunk_units, n_chunks; // owned START positions per lane chunk (multiple of 8)
     void *d_len;                    // per unit of the buffer: length of the longest keyword starting there (u16 or u32)
     uint32_t *d_state;              // optional: automaton state per unit (for the keyword id), or nullptr
+    uint32_t *d_blockmax;           // per 64 owned positions: max(p + max(L[p],1)) -- lets the chain kernels skip
     int len_bytes;                  // 2 or 4
     uint32_t lds_rows;              // trie rows staged in LDS
     int grid, block;
@@ -95,7 +96,8 @@ struct LongestChainLaunch {
     const uint32_t *d_state; // or nullptr (Set records)
     const uint32_t *d_out_id;
     int len_bytes;
-    uint32_t own_end;
+    uint32_t own_begin, own_end;
+    const uint32_t *d_blockmax; // see LongestScanLaunch
     uint32_t entry;       // first greedy-chain position of this shard
     uint32_t tile_units;  // positions per lane
     uint32_t n_tiles;

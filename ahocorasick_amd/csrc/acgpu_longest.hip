@@ -49,8 +49,14 @@ __global__ __launch_bounds__(kLScanBlock) void k_longest_walk(DevTables T, Longe
     const uint16_t *hay = L.d_hay;
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t n = L.n_units;
-    for (uint32_t p = L.own_begin + blockIdx.x * blockDim.x + threadIdx.x; p < L.own_end; p += stride) {
-        if (DENSE) {
+    // every lane of a wave runs the same number of iterations (64 consecutive positions per wave and iteration), so
+    // that the wave can publish the farthest landing position of its 64 positions
+    for (uint32_t p0 = L.own_begin + blockIdx.x * blockDim.x; p0 < L.own_end; p0 += stride) {
+        const uint32_t p = p0 + threadIdx.x;
+        uint32_t reach = 0;
+        if (p >= L.own_end) {
+            // past the end of the owned range: contributes nothing
+        } else if (DENSE) {
             uint32_t off = 0, depth = 0, best = 0, best_off = 0, i = p;
             bool alive = true;
             while (alive) {
@@ -93,6 +99,7 @@ __global__ __launch_bounds__(kLScanBlock) void k_longest_walk(DevTables T, Longe
             }
             out_len[p] = (LenT)best;
             if (L.d_state) L.d_state[p] = best_off / row_bytes;
+            reach = p + (best ? best : 1u);
         } else {
             uint32_t node = 0, best = 0, best_node = 0, i = p;
             bool alive = true;
@@ -113,7 +120,12 @@ __global__ __launch_bounds__(kLScanBlock) void k_longest_walk(DevTables T, Longe
             }
             out_len[p] = (LenT)best;
             if (L.d_state) L.d_state[p] = best_node;
+            reach = p + (best ? best : 1u);
         }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) reach = max(reach, (uint32_t)__shfl_xor((int)reach, d));
+        const uint32_t wave_p0 = p0 + (threadIdx.x & ~63u);
+        if ((threadIdx.x & 63u) == 0 && wave_p0 < L.own_end) L.d_blockmax[(wave_p0 - L.own_begin) >> 6] = reach;
     }
 }
 
@@ -143,7 +155,10 @@ hipError_t launch_longest_scan(const DevTables &t, const LongestScanLaunch &l, h
 // start tb (the true chain's last position before tb is one of those q).  Chains that land on the same position are
 // one chain from there on; when a single one is left, its position lies on every possible chain, hence on the true
 // one.  Stored in S[t] if it falls inside the tile, else ~0u (the tile then belongs to an earlier lane's segment).
-constexpr int kSyncSet = 16;
+#ifndef ACGPU_SYNC_SET
+#define ACGPU_SYNC_SET 16
+#endif
+constexpr int kSyncSet = ACGPU_SYNC_SET;
 
 template <typename LenT>
 __global__ __launch_bounds__(256) void k_longest_sync(LongestChainLaunch L, uint32_t *S) {
@@ -175,10 +190,18 @@ __global__ __launch_bounds__(256) void k_longest_sync(LongestChainLaunch L, uint
         set[cnt++] = v;
     };
     const uint32_t w = L.max_len > 0 ? L.max_len : 1;
-    for (uint32_t q = tb - L.entry > w ? tb - w : L.entry; q < tb && ok; ++q) {
-        const uint32_t l = (uint32_t)len[q];
-        const uint32_t land = q + (l > 0 ? l : 1u);
-        if (land >= tb) insert(land);
+    uint32_t q = tb - L.entry > w ? tb - w : L.entry;
+    while (q < tb && ok) { // 64 positions at a time; blocks none of whose positions lands at or after tb are skipped
+        const uint32_t b = (q - L.own_begin) >> 6;
+        const uint32_t bend = min(tb, L.own_begin + ((b + 1) << 6));
+        if (L.d_blockmax[b] >= tb) {
+            for (; q < bend && ok; ++q) {
+                const uint32_t l = (uint32_t)len[q];
+                const uint32_t land = q + (l > 0 ? l : 1u);
+                if (land >= tb) insert(land);
+            }
+        }
+        q = bend;
     }
     while (ok && cnt > 1) {
         uint32_t mi = 0;

@@ -34,7 +34,7 @@ __device__ __forceinline__ uint32_t word_bit(const uint32_t *wbits, uint32_t uni
 #endif
 constexpr int kWwBatches = ACGPU_WW_NB;   // run starts verified per lane and call (independent lookup chains in flight)
 #ifndef ACGPU_WW_PREFETCH
-#define ACGPU_WW_PREFETCH 4
+#define ACGPU_WW_PREFETCH 2
 #endif
 #ifndef ACGPU_WW_BLOCKS
 #define ACGPU_WW_BLOCKS 1

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--variants", type=str, default="")
     ap.add_argument("--config", default="C2", choices=["C2", "C2S", "C4", "C5"])
+    ap.add_argument("--set", action="store_true", help="8-byte Set records instead of 12-byte Map records")
     args = ap.parse_args()
     import torch
     from ahocorasick_amd import _native as N, synth
@@ -60,7 +61,7 @@ def main():
                 N.set_tunable(k, v)
             for k, v in knobs.items():
                 N.set_tunable(k, v)
-            nout, rc, prof, _ = a.match_device(d_hay.data_ptr(), n, True, d_out.data_ptr(), cap,
+            nout, rc, prof, _ = a.match_device(d_hay.data_ptr(), n, not args.set, d_out.data_ptr(), cap,
                                                stream=torch.cuda.current_stream().cuda_stream, profile=True)
             if r > 0:
                 res[name].append(prof["scan_ms"])
