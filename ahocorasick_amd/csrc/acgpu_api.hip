@@ -57,6 +57,11 @@ struct Ticket {
     uint64_t cap = 0, scanned = 0;
     char kname[64] = {0};
     void *owner = nullptr; // the DeviceState it belongs to
+    // what _end needs to redo the call when the split form's candidate slices were too small
+    acgpu_shard shard{};
+    int record_kind = 0;
+    void *d_out = nullptr;
+    hipStream_t stream = nullptr;
 };
 
 struct DeviceState {
@@ -69,6 +74,7 @@ struct DeviceState {
     DevBuf stage_hay, stage_out; // acgpu_match_u16 staging
     DevBuf short_recs, short_nxt, short_tmp, short_mark; // SHORTEST: all-matches list + selection scratch
     DevBuf blockmax;                                     // LONGEST: farthest landing per 64 positions
+    DevBuf cands, region_cands;                          // ALL, split form: candidate positions, {first, count} per region
     DevBuf wwl_rs, wwl_mend, wwl_mid, wwl_sel;          // WWLONGEST: walk starts and what each would report
     unsigned long long *h_counter = nullptr; // pinned
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -78,7 +84,7 @@ struct DeviceState {
         counter.release(); chunk_counts.release(); offsets.release(); scan_tmp.release(); scratch.release();
         chain.release(); lenbuf.release(); statebuf.release(); stage_hay.release(); stage_out.release();
         short_recs.release(); short_nxt.release(); short_tmp.release(); short_mark.release();
-        wwl_rs.release(); wwl_mend.release(); wwl_mid.release(); wwl_sel.release(); blockmax.release();
+        wwl_rs.release(); wwl_mend.release(); wwl_mid.release(); wwl_sel.release(); blockmax.release(); cands.release(); region_cands.release();
         if (h_counter) (void)hipHostFree(h_counter);
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         for (auto &tk : tickets) {
@@ -200,18 +206,25 @@ uint32_t round_up8(uint64_t v) { return (uint32_t)((v + 7) & ~7ull); }
 
 // Which ALL-mode kernel serves this dictionary: the position-parallel K-gram tile kernel when the suffix filter
 // exists and is selective, otherwise the general DFA chunk scan (any alphabet, any keyword lengths).
+// force_kernel: 0 = automatic, 1 = DFA chunk scan, 2 = fused tile kernel, 3 = split tile kernels (filter + verification)
 bool use_tile_kernel(const HostTables &t) {
     if (t.filt_k == 0) return false;
     const int64_t f = tunables().force_kernel;
     if (f == 1) return false;
-    if (f == 2) return true;
+    if (f == 2 || f == 3) return true;
     return t.filt_density <= 0.08;
 }
+
+// the split form needs the filter rows to fit the smaller static LDS array of the filter-only kernel
+// (measured at config 2: filter 0.27 ms + verification 0.33 ms against 0.39 ms fused -- the fused kernel verifies a
+// candidate while its text is still in the L2 of the XCD that streamed it; the split form gathers it from HBM again --
+// so the split form is only taken on request)
+bool use_split_form(const DevTables &T) { return tunables().force_kernel == 3 && tile_split_supported(T); }
 
 // ALL-mode pipeline on one shard.
 // With a ticket the call returns after enqueueing (no host synchronisation); acgpu_match_device_end collects it.
 int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_kind, void *d_out, uint64_t cap,
-              uint64_t *n_out, hipStream_t stream, acgpu_profile *prof, Ticket *tk = nullptr) {
+              uint64_t *n_out, hipStream_t stream, acgpu_profile *prof, Ticket *tk = nullptr, bool fused_only = false) {
     const HostTables &t = a->t;
     hipEvent_t *ev = tk ? tk->ev : d.ev;
     const bool timed = tk ? tk->profiled : prof != nullptr;
@@ -234,7 +247,7 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
     int rc;
     if ((rc = d.counter.ensure(64))) return rc;
     // the tile kernel reserves scratch slots 256 at a time per wave: head-room for the unused tails
-    const uint64_t scratch_cap = std::min<uint64_t>(
+    uint64_t scratch_cap = std::min<uint64_t>(
         std::max<uint64_t>(cap, 1) + (uint64_t)d.n_cu * (tile_block_threads() / 64) * tile_reserve_slots(), 0xffffffe0ull);
     if ((rc = d.scratch.ensure(scratch_cap * sizeof(ScratchRec)))) return rc;
     HIP_TRY(hipMemsetAsync(d.counter.p, 0, 64, stream));
@@ -242,6 +255,7 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
     uint64_t scanned = 0;
     uint32_t n_chunks = 0, chunk_units = 0, perm_base = (uint32_t)sh->own_begin;
     const uint32_t *id_map = nullptr;
+    bool split = false;
     if (use_tile_kernel(t)) {
         TileLaunch L{};
         L.block = tile_block_threads();
@@ -271,9 +285,40 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         L.d_counter = (unsigned long long *)d.counter.p;
         L.d_region_counts = (uint32_t *)d.chunk_counts.p;
         HIP_TRY(hipMemsetAsync(d.chunk_counts.p, 0, (size_t)L.n_regions * 4, stream));
+        split = !fused_only && use_split_form(d.T);
+        if (split) {
+            // a wave's slice holds one candidate per 8 units of its span (the filter passes ~2 % on selective
+            // dictionaries); a haystack that needs more is redone with the fused kernel
+            const uint64_t per_wave = (uint64_t)L.regions_per_wave * R / 8 + 2 * 1024;
+            if (per_wave * waves_used >= (1ull << 32)) split = false;
+            else {
+                L.cands_per_wave = (uint32_t)per_wave;
+                if ((rc = d.cands.ensure(per_wave * waves_used * 4 + 64))) return rc;
+                if ((rc = d.region_cands.ensure((size_t)L.n_regions * 8))) return rc;
+                L.d_cands = (uint32_t *)d.cands.p;
+                L.d_region_cands = (uint2 *)d.region_cands.p;
+                HIP_TRY(hipMemsetAsync(d.region_cands.p, 0, (size_t)L.n_regions * 8, stream)); // unwritten = no candidates
+                L.d_overflow = (uint32_t *)d.counter.p + 8;
+                L.verify_grid = (int)std::min<uint64_t>(((uint64_t)L.n_regions + 3) / 4, (uint64_t)d.n_cu * 8);
+                // every verification wave may hold one partly used reservation of scratch slots
+                const uint64_t need = std::min<uint64_t>(std::max<uint64_t>(cap, 1) + (uint64_t)L.verify_grid * 4 * tile_reserve_slots(),
+                                                         0xffffffe0ull);
+                if (need > L.cap) {
+                    if ((rc = d.scratch.ensure(need * sizeof(ScratchRec)))) return rc;
+                    L.cap = scratch_cap = need;
+                    L.d_scratch = (ScratchRec *)d.scratch.p;
+                }
+            }
+        }
         if (timed) HIP_TRY(hipEventRecord(ev[0], stream));
-        HIP_TRY(launch_ac_tile(d.T, L, stream, &kname));
-        if (timed) HIP_TRY(hipEventRecord(ev[1], stream));
+        if (split) {
+            HIP_TRY(launch_ac_filter(d.T, L, stream, &kname));
+            if (timed) HIP_TRY(hipEventRecord(ev[1], stream)); // the verification is accounted with the ordering
+            HIP_TRY(launch_ac_verify(d.T, L, stream));
+        } else {
+            HIP_TRY(launch_ac_tile(d.T, L, stream, &kname));
+            if (timed) HIP_TRY(hipEventRecord(ev[1], stream));
+        }
         n_chunks = L.n_regions;
         chunk_units = L.region_units;
         scanned = own_len;
@@ -318,6 +363,12 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
     if (tk) {
         HIP_TRY(hipMemcpyAsync(tk->h_count, (const uint64_t *)d.scan_tmp.p + scan_tiles_for(n_chunks), 8,
                                hipMemcpyDeviceToHost, stream));
+        tk->h_count[1] = 0;
+        if (split) HIP_TRY(hipMemcpyAsync(tk->h_count + 1, (const uint32_t *)d.counter.p + 8, 4, hipMemcpyDeviceToHost, stream));
+        tk->shard = *sh;
+        tk->record_kind = record_kind;
+        tk->d_out = d_out;
+        tk->stream = stream;
         HIP_TRY(hipEventRecord(tk->done, stream));
         tk->scanned = scanned;
         std::snprintf(tk->kname, sizeof(tk->kname), "%s", kname);
@@ -325,7 +376,11 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
     }
     HIP_TRY(hipMemcpyAsync(d.h_counter, (const uint64_t *)d.scan_tmp.p + scan_tiles_for(n_chunks), 8, hipMemcpyDeviceToHost,
                            stream));
+    d.h_counter[1] = 0;
+    if (split) HIP_TRY(hipMemcpyAsync(d.h_counter + 1, (const uint32_t *)d.counter.p + 8, 4, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    if (split && (uint32_t)d.h_counter[1] != 0) // a candidate slice overflowed: this haystack takes the fused kernel
+        return match_all(a, d, sh, record_kind, d_out, cap, n_out, stream, prof, nullptr, true);
     *n_out = *d.h_counter;
     if (prof) {
         HIP_TRY(hipEventElapsedTime(&prof->scan_ms, d.ev[0], d.ev[1]));
@@ -932,6 +987,12 @@ int acgpu_match_device_end(const acgpu_automaton *ca, acgpu_ticket *ticket, uint
     if (!tk->busy) return ACGPU_E_INVALID;
     HIP_TRY(hipEventSynchronize(tk->done)); // outside the lock: other calls may be enqueued meanwhile
     std::lock_guard<std::mutex> lock(a->mu);
+    if ((uint32_t)tk->h_count[1] != 0) { // the split form's candidate slices were too small: redo with the fused kernel
+        DeviceState *d = reinterpret_cast<DeviceState *>(tk->owner);
+        tk->busy = false;
+        const int rc = match_all(a, *d, &tk->shard, tk->record_kind, tk->d_out, tk->cap, n_out, tk->stream, prof, nullptr, true);
+        return rc;
+    }
     *n_out = *tk->h_count;
     if (prof) {
         std::memset(prof, 0, sizeof(*prof));

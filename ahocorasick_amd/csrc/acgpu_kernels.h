@@ -45,12 +45,25 @@ struct TileLaunch {
     uint32_t *d_region_counts;
     int grid, block;
     size_t lds_bytes;
+    // split form (filter kernel + verification kernel): the filter writes the candidate end positions of its span, in
+    // text order, to its own slice of d_cands and a {first index, count} pair per region; the verification kernel
+    // takes one region per wave.  *d_overflow becomes non-zero if a slice was too small (the call is then redone with
+    // the fused kernel).
+    uint32_t *d_cands;
+    uint32_t cands_per_wave;
+    uint2 *d_region_cands;
+    uint32_t *d_overflow;
+    int verify_grid;
     uint32_t debug; // ablation switches (tunable "tile_debug"): 1 = drop candidates unverified, 4 = no filter arithmetic
                     // at all (stream + reduce only), 8 = verification without the text-window load, 16 = without the
                     // K-gram node load, 32 = no record emission, 64 = no walk beyond the K-gram node, 128 = records
                     // not stored.  Results are wrong when non-zero; 0 in production.
 };
 hipError_t launch_ac_tile(const DevTables &t, const TileLaunch &l, hipStream_t stream, const char **kernel_name);
+// split form: launch_ac_filter, then launch_ac_verify on the same stream (same TileLaunch)
+hipError_t launch_ac_filter(const DevTables &t, const TileLaunch &l, hipStream_t stream, const char **kernel_name);
+hipError_t launch_ac_verify(const DevTables &t, const TileLaunch &l, hipStream_t stream);
+bool tile_split_supported(const DevTables &t);
 size_t tile_lds_bytes(const DevTables &t, int block_threads);
 int tile_block_threads();
 

@@ -42,6 +42,8 @@ constexpr int kAcCandCap = kAcTileUnits + kVerifyBatches * kWave;
 uint32_t tile_group_units() { return kPrefetch * kTileUnits; }
 
 constexpr int kFilterWordsMax = 22016; // 88064 bytes of static LDS for the filter rows (tunable filter_max_bytes <= 88000)
+constexpr int kFilterWordsSplit = 20224; // the filter-only kernel: 79 KiB, so that two workgroups fit one CU's 160 KiB
+bool tile_split_supported(const DevTables &t) { return t.filt_k >= 1 && t.filt_words <= (uint32_t)kFilterWordsSplit; }
 
 // dynamic LDS only: the candidate queues
 size_t tile_lds_bytes(const DevTables &t, int block_threads) {
@@ -244,11 +246,15 @@ __device__ __forceinline__ uint32_t roll_row(uint32_t hs, uint32_t n, uint32_t c
 // rounded down to 8 units, region_units a multiple of the 2048-unit tile group), so a tile group never straddles two
 // regions and the tile stream -- with its double-buffered register groups and the cross-lane carry -- runs through the
 // whole span.
-template <int K, bool RANGE, bool WIDE>
+//
+// SPLIT: the filter-only form.  Nothing is verified here: the candidates of the wave's span go, in text order, to the
+// wave's slice of L.d_cands (the "queue" is that slice and is never drained), with a {first index, count} pair per
+// region for k_ac_verify.  No LDS besides the filter rows.
+template <int K, bool RANGE, bool WIDE, bool SPLIT>
 __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch L) {
     // the filter rows are STATIC LDS (offset 0, so a scaled row index is the ds_read address with nothing to add);
     // the candidate queues are the dynamic part behind it
-    __shared__ __attribute__((aligned(16))) uint32_t rows32[kFilterWordsMax];
+    __shared__ __attribute__((aligned(16))) uint32_t rows32[SPLIT ? kFilterWordsSplit : kFilterWordsMax];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned char *rows8 = reinterpret_cast<const unsigned char *>(rows32);
     uint32_t *cand_all = reinterpret_cast<uint32_t *>(smem);
@@ -258,7 +264,9 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
     const uint32_t lane = lane_id();
     const uint32_t wave_in_block = threadIdx.x / kWave;
     const uint32_t wave_global = blockIdx.x * (kTileBlock / kWave) + wave_in_block;
-    TileCtx c{&T, &L, cand_all + wave_in_block * kAcCandCap, 0, 0, 0u, 0};
+    TileCtx c{&T, &L, SPLIT ? L.d_cands + (size_t)wave_global * L.cands_per_wave : cand_all + wave_in_block * kAcCandCap, 0, 0, 0u, 0};
+    const uint32_t slice_base = SPLIT ? wave_global * L.cands_per_wave : 0u; // (< 2^32: the host sizes the slices)
+    uint32_t region_first = 0; // SPLIT: index (inside the slice) of the current region's first candidate
 
     constexpr uint32_t ROWB = WIDE ? 8 : 4;
     const uint32_t n = T.filt_n;
@@ -318,7 +326,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
     // streaming work.  Keeping the (large) verification code in a single place keeps the kernel small.
     for (;;) {
         const bool seam = vec_todo ? (d0 == 0 && tile >= boundary) : true; // wave-uniform
-        const uint32_t keep = seam ? 1u : (uint32_t)(kVerifyBatches * kWave);
+        const uint32_t keep = SPLIT ? ~0u : (seam ? 1u : (uint32_t)(kVerifyBatches * kWave));
         if (vec_todo && d0 == 0) {
             // take over the prefetched group FIRST: this wait also covers the record stores of the previous pass's
             // verification (gfx950 counts stores in vmcnt), which have had a whole tile group of time to finish
@@ -327,12 +335,17 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
 #pragma unroll
                 for (int u = 0; u < kAcVec; ++u) grp[d][u] = nxt[d][u];
         }
-        if (c.cand_n >= keep && c.cand_n != 0) drain<K, RANGE>(c, keep);
+        if (!SPLIT && c.cand_n >= keep && c.cand_n != 0) drain<K, RANGE>(c, keep);
 
         if (vec_todo) {
             if (d0 == 0) {
                 if (tile >= boundary) { // the stream enters the next region (regions hold whole tile groups)
-                    if (lane == 0) L.d_region_counts[region] = c.rank_base;
+                    if (SPLIT) {
+                        if (lane == 0) L.d_region_cands[region] = make_uint2(slice_base + region_first, c.cand_n - region_first);
+                        region_first = c.cand_n;
+                    } else if (lane == 0) {
+                        L.d_region_counts[region] = c.rank_base;
+                    }
                     c.rank_base = 0;
                     ++region;
                     rb = boundary;
@@ -358,7 +371,12 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                 if ((uint32_t)d < d0) continue; // wave-uniform
                 const uint32_t cur = tile + d * kAcTileUnits;
                 if (cur >= hi) break; // wave-uniform
-                if (c.cand_n > kAcCandCap - kAcTileUnits) { // rare: the queue cannot take a worst-case tile -> drain first
+                if (SPLIT) {
+                    if (c.cand_n + kAcTileUnits > L.cands_per_wave) { // the slice is too small for this haystack
+                        if (lane == 0) atomicOr(L.d_overflow, 1u);
+                        return; // wave-uniform; the host redoes the call with the fused kernel
+                    }
+                } else if (c.cand_n > kAcCandCap - kAcTileUnits) { // rare: the queue cannot take a worst-case tile -> drain first
                     d0 = d;
                     resume = true;
                     break;
@@ -432,9 +450,18 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
             tail_todo = false;
             const uint32_t t0 = max(nfull, span_begin);
             if (t0 >= boundary) { // the tail opens a new region
-                if (lane == 0) L.d_region_counts[region] = c.rank_base;
+                if (SPLIT) {
+                    if (lane == 0) L.d_region_cands[region] = make_uint2(slice_base + region_first, c.cand_n - region_first);
+                    region_first = c.cand_n;
+                } else if (lane == 0) {
+                    L.d_region_counts[region] = c.rank_base;
+                }
                 c.rank_base = 0;
                 ++region;
+            }
+            if (SPLIT && c.cand_n + kWave > L.cands_per_wave) {
+                if (lane == 0) atomicOr(L.d_overflow, 1u);
+                return;
             }
             const uint32_t pos = t0 + lane;
             uint32_t mask = 0;
@@ -450,17 +477,62 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
         }
         break;
     }
+    if (SPLIT) {
+        if (lane == 0) L.d_region_cands[region] = make_uint2(slice_base + region_first, c.cand_n - region_first);
+        return;
+    }
     if (lane == 0) L.d_region_counts[region] = c.rank_base;
     // hand back the unused tail of the last reservation as holes the permute pass skips
     for (uint32_t i = lane; i < c.res_left; i += kWave) store_rec(L, c.res_cur + i, 0, 0, 0, ~0u);
 }
 
+// The verification half of the split form: one region per wave (grid-stride), its candidates read from L.d_cands in
+// batches of kVerifyBatches*64, records ranked inside the region exactly as the fused kernel ranks them.
+template <int K, bool RANGE>
+__global__ __launch_bounds__(256) void k_ac_verify(DevTables T, TileLaunch L) {
+    const uint32_t lane = lane_id();
+    const uint32_t waves = gridDim.x * (blockDim.x / kWave);
+    // a candidate slice overflowed: the region table is incomplete and the host redoes the call with the fused kernel
+    if (__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile const uint32_t *>(L.d_overflow)) != 0) return;
+    TileCtx c{&T, &L, nullptr, 0, 0, 0u, 0};
+    for (uint32_t region = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; region < L.n_regions; region += waves) {
+        const uint2 rc = L.d_region_cands[region];
+        c.cand = L.d_cands + rc.x;
+        c.cand_n = rc.y;
+        c.rank_base = 0;
+        for (uint32_t head = 0; head < rc.y; head += kVerifyBatches * kWave)
+            verify_multi<K, RANGE>(c, head, min(rc.y - head, (uint32_t)(kVerifyBatches * kWave)));
+        if (lane == 0) L.d_region_counts[region] = c.rank_base;
+    }
+    for (uint32_t i = lane; i < c.res_left; i += kWave) store_rec(L, c.res_cur + i, 0, 0, 0, ~0u);
+}
+
 template <int K, bool RANGE, bool WIDE>
 static hipError_t launch_tile_variant(const DevTables &t, const TileLaunch &l, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ac_tile<K, RANGE, WIDE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ac_tile<K, RANGE, WIDE, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_ac_tile<K, RANGE, WIDE>), dim3(l.grid), dim3(l.block), l.lds_bytes, stream, t, l);
+    hipLaunchKernelGGL((k_ac_tile<K, RANGE, WIDE, false>), dim3(l.grid), dim3(l.block), l.lds_bytes, stream, t, l);
+    return hipGetLastError();
+}
+
+template <int K, bool RANGE, bool WIDE>
+static hipError_t launch_filter_variant(const DevTables &t, const TileLaunch &l, hipStream_t stream) {
+    hipLaunchKernelGGL((k_ac_tile<K, RANGE, WIDE, true>), dim3(l.grid), dim3(l.block), 0, stream, t, l);
+    return hipGetLastError();
+}
+
+template <int K>
+static hipError_t launch_filter_k(const DevTables &t, const TileLaunch &l, hipStream_t stream) {
+    const bool wide = t.filt_row_bytes == 8;
+    if (t.range_cls) return wide ? launch_filter_variant<K, true, true>(t, l, stream) : launch_filter_variant<K, true, false>(t, l, stream);
+    return wide ? launch_filter_variant<K, false, true>(t, l, stream) : launch_filter_variant<K, false, false>(t, l, stream);
+}
+
+template <int K>
+static hipError_t launch_verify_k(const DevTables &t, const TileLaunch &l, hipStream_t stream) {
+    if (t.range_cls) hipLaunchKernelGGL((k_ac_verify<K, true>), dim3(l.verify_grid), dim3(256), 0, stream, t, l);
+    else hipLaunchKernelGGL((k_ac_verify<K, false>), dim3(l.verify_grid), dim3(256), 0, stream, t, l);
     return hipGetLastError();
 }
 
@@ -474,7 +546,7 @@ static hipError_t launch_tile_k(const DevTables &t, const TileLaunch &l, hipStre
 hipError_t launch_ac_tile(const DevTables &t, const TileLaunch &l, hipStream_t stream, const char **kernel_name) {
     static char name[64];
     if (t.filt_k < 1 || t.filt_k > 8) return hipErrorInvalidValue;
-    std::snprintf(name, sizeof(name), "k_ac_tile<%u, %s, %s>", t.filt_k, t.range_cls ? "true" : "false",
+    std::snprintf(name, sizeof(name), "k_ac_tile<%u, %s, %s, false>", t.filt_k, t.range_cls ? "true" : "false",
                   t.filt_row_bytes == 8 ? "true" : "false");
     if (kernel_name) *kernel_name = name;
     switch (t.filt_k) {
@@ -486,6 +558,39 @@ hipError_t launch_ac_tile(const DevTables &t, const TileLaunch &l, hipStream_t s
     case 6: return launch_tile_k<6>(t, l, stream);
     case 7: return launch_tile_k<7>(t, l, stream);
     case 8: return launch_tile_k<8>(t, l, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_ac_filter(const DevTables &t, const TileLaunch &l, hipStream_t stream, const char **kernel_name) {
+    static char name[64];
+    if (!tile_split_supported(t) || t.filt_k > 8) return hipErrorInvalidValue;
+    std::snprintf(name, sizeof(name), "k_ac_tile<%u, %s, %s, true>", t.filt_k, t.range_cls ? "true" : "false",
+                  t.filt_row_bytes == 8 ? "true" : "false");
+    if (kernel_name) *kernel_name = name;
+    switch (t.filt_k) {
+    case 1: return launch_filter_k<1>(t, l, stream);
+    case 2: return launch_filter_k<2>(t, l, stream);
+    case 3: return launch_filter_k<3>(t, l, stream);
+    case 4: return launch_filter_k<4>(t, l, stream);
+    case 5: return launch_filter_k<5>(t, l, stream);
+    case 6: return launch_filter_k<6>(t, l, stream);
+    case 7: return launch_filter_k<7>(t, l, stream);
+    case 8: return launch_filter_k<8>(t, l, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_ac_verify(const DevTables &t, const TileLaunch &l, hipStream_t stream) {
+    switch (t.filt_k) {
+    case 1: return launch_verify_k<1>(t, l, stream);
+    case 2: return launch_verify_k<2>(t, l, stream);
+    case 3: return launch_verify_k<3>(t, l, stream);
+    case 4: return launch_verify_k<4>(t, l, stream);
+    case 5: return launch_verify_k<5>(t, l, stream);
+    case 6: return launch_verify_k<6>(t, l, stream);
+    case 7: return launch_verify_k<7>(t, l, stream);
+    case 8: return launch_verify_k<8>(t, l, stream);
     default: return hipErrorInvalidValue;
     }
 }

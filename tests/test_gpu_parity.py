@@ -24,11 +24,12 @@ def _reset_tunables():
         N.set_tunable(k, v)
 
 
-@pytest.fixture(params=["dfa_chunk_scan", "kgram_tile_scan"])
+@pytest.fixture(params=["dfa_chunk_scan", "kgram_tile_scan", "kgram_split_scan"])
 def ac_kernel(request):
-    """Runs a test once per ALL-mode kernel (the tile kernel only exists for dictionaries with a K-gram filter;
-    force_kernel=2 falls back to the DFA scan otherwise, which the first parameter already covers)."""
-    N.set_tunable("force_kernel", 1 if request.param == "dfa_chunk_scan" else 2)
+    """Runs a test once per ALL-mode kernel: the DFA chunk scan, the fused K-gram tile kernel and its split form (filter
+    kernel + verification kernel).  The tile kernels only exist for dictionaries with a K-gram filter; the others take
+    the DFA scan either way, which the first parameter already covers."""
+    N.set_tunable("force_kernel", {"dfa_chunk_scan": 1, "kgram_tile_scan": 2, "kgram_split_scan": 3}[request.param])
     return request.param
 
 
@@ -257,11 +258,11 @@ def test_config_c2_full_size_properties():
     pre = 1 << 22
     want = Oracle(FAM_AC, kws).match(synth.haystack(c["hay_seed"], pre))
     assert (got[:len(want)] == want).all() and got[len(want), 1] > pre
-    # (4) the two independent kernels (K-gram tile scan / DFA chunk scan), other region and chunk sizes, and no LDS
-    #     residency all give the identical record stream
+    # (4) the independent kernels (fused K-gram tile scan / its split form / DFA chunk scan), other region and chunk
+    #     sizes, and no LDS residency all give the identical record stream
     assert prof["scan_kernel"].startswith("k_ac_tile")
     for knobs in ({"force_kernel": 1}, {"force_kernel": 1, "chunk_units": 1000, "lds_table_bytes": 0},
-                  {"force_kernel": 2, "region_units": 512 * 7}):
+                  {"force_kernel": 2, "region_units": 512 * 7}, {"force_kernel": 3}, {"force_kernel": 3, "region_units": 4096}):
         for k, v in knobs.items():
             N.set_tunable(k, v)
         got2, prof2 = _dev_match(a, d_hay, n, True, cap, profile=True)
@@ -901,3 +902,25 @@ def test_wwlongest_listener_examples_and_limits():
     assert a.match_device(d.data_ptr(), 64, True, o.data_ptr(), 8, own=(8, 64))[1] == N.E_UNSUPPORTED
     with pytest.raises(N.AcgpuError):
         Stream(a)
+
+
+def test_split_form_falls_back_when_the_candidate_slices_overflow():
+    """Every 4-gram over {a,b} is a keyword, so every position passes the filter: the split form's candidate slices
+    overflow and the call is redone with the fused kernel -- synchronously and through begin/end."""
+    import torch
+    kws = ["".join(p) for p in __import__("itertools").product("ab", repeat=4)] + ["abababab"]
+    a = Automaton(N.MODE_ALL, kws, True)
+    assert a.info()["filter_k"] == 4
+    hay = synth.haystack(9, 300000, table=synth.ALPHA_LOWER[:2])
+    want = Oracle(FAM_AC, kws).match(hay)
+    N.set_tunable("force_kernel", 3)
+    d_hay = torch.from_numpy(hay.view(np.int16)).cuda()
+    cap = len(want) + 8
+    got, prof = _dev_match(a, d_hay, hay.size, True, cap, profile=True)
+    assert prof["scan_kernel"].endswith("false>")  # the fused kernel delivered the result
+    assert got.shape == want.shape and (got == want).all()
+    out = torch.empty((cap, 3), dtype=torch.int32, device="cuda")
+    tk, rc = a.match_device_begin(d_hay.data_ptr(), hay.size, True, out.data_ptr(), cap, stream=torch.cuda.current_stream().cuda_stream)
+    assert rc == N.OK
+    n, rc, _ = a.match_device_end(tk)
+    assert rc == N.OK and n == len(want) and (out[:n].cpu().numpy() == want).all()

@@ -66,7 +66,7 @@ def one_case(rng, it):
             hay[p:p + len(k)] = k
     knobs = dict(DEFAULTS)
     if rng.integers(0, 2):
-        knobs["force_kernel"] = int(rng.integers(0, 3))
+        knobs["force_kernel"] = int(rng.integers(0, 4))
     if rng.integers(0, 3) == 0:
         knobs["chunk_units"] = int(rng.choice([8, 64, 1000]))
     if rng.integers(0, 3) == 0:

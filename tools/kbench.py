@@ -46,8 +46,8 @@ def main():
                                          tab.ctypes.data_as(ctypes.c_void_p), len(tab), None), "synth")
         cap = n // 2 if args.config == "C4" else n // 128
         dflt = {"longest": {}} if args.config == "C4" else {"shortest": {}} if shortest else {
-            "tile": {}, "tile_noverify": {"tile_debug": 1}, "tile_nolds": {"tile_debug": 3}, "tile_stream": {"tile_debug": 5},
-            "dfa": {"force_kernel": 1}}
+            "tile": {}, "split": {"force_kernel": 3}, "tile_noverify": {"force_kernel": 2, "tile_debug": 1},
+            "tile_stream": {"force_kernel": 2, "tile_debug": 5}, "dfa": {"force_kernel": 1}}
     torch.cuda.synchronize()
     d_out = torch.empty((cap, 3), dtype=torch.int32, device="cuda")
     variants = json.loads(args.variants) if args.variants else dflt
