@@ -280,11 +280,45 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *counts, uint
     }
 }
 
+// k_scan_apply for at most 256 tiles: every block derives its tile's offset from the raw tile sums itself (and block 0
+// leaves the grand total behind them), which saves the single-block launch in between
+__global__ __launch_bounds__(256) void k_scan_apply_few(const uint32_t *counts, uint32_t n, uint64_t *tile_sums, uint32_t n_tiles,
+                                                       uint64_t *offsets) {
+    __shared__ uint64_t tile_base;
+    {
+        const uint64_t s = threadIdx.x < n_tiles ? tile_sums[threadIdx.x] : 0;
+        uint64_t total;
+        const uint64_t ex = block_exclusive_scan_256(s, &total);
+        if (threadIdx.x == blockIdx.x) tile_base = ex;
+        if (blockIdx.x == 0 && threadIdx.x == 0) tile_sums[n_tiles] = total; // grand total
+        __syncthreads();
+    }
+    const uint32_t base = blockIdx.x * kScanTile;
+    constexpr int per = kScanTile / 256;
+    uint32_t c[per];
+    uint64_t v = 0;
+    for (int k = 0; k < per; ++k) {
+        const uint32_t i = base + threadIdx.x * per + k;
+        c[k] = i < n ? counts[i] : 0;
+        v += c[k];
+    }
+    uint64_t ex = block_exclusive_scan_256(v, nullptr) + tile_base;
+    for (int k = 0; k < per; ++k) {
+        const uint32_t i = base + threadIdx.x * per + k;
+        if (i < n) offsets[i] = ex;
+        ex += c[k];
+    }
+}
+
 hipError_t launch_exclusive_scan(const uint32_t *d_counts, uint32_t n, uint64_t *d_offsets, uint64_t *d_tmp,
                                  hipStream_t stream) {
     if (n == 0) return hipSuccess;
     const uint32_t n_tiles = (n + kScanTile - 1) / kScanTile;
     hipLaunchKernelGGL(k_scan_tile_sums, dim3(n_tiles), dim3(256), 0, stream, d_counts, n, d_tmp);
+    if (n_tiles <= 256) {
+        hipLaunchKernelGGL(k_scan_apply_few, dim3(n_tiles), dim3(256), 0, stream, d_counts, n, d_tmp, n_tiles, d_offsets);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(256), 0, stream, d_tmp, n_tiles);
     hipLaunchKernelGGL(k_scan_apply, dim3(n_tiles), dim3(256), 0, stream, d_counts, n, (const uint64_t *)d_tmp, d_offsets);
     return hipGetLastError();
