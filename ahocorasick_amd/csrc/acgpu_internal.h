@@ -153,7 +153,10 @@ struct Tunables {
     int64_t region_units = 0;     // tile kernel: owned units per wave region (0 = auto)
     int64_t rdense_budget_bytes = 256ll << 20;
     int64_t tile_debug = 0;       // ablation switches of the tile kernel (see TileLaunch::debug); 0 in production
-    int64_t filter_max_bytes = 88000;  // the filter rows must fit LDS next to the candidate queues
+#ifndef ACGPU_FILTER_MAX_BYTES
+#define ACGPU_FILTER_MAX_BYTES 88000
+#endif
+    int64_t filter_max_bytes = ACGPU_FILTER_MAX_BYTES;  // the filter rows must fit LDS next to the candidate queues
 };
 Tunables &tunables();
 

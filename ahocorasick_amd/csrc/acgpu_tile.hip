@@ -41,7 +41,10 @@ constexpr int kAcTiles = kPrefetch / kAcVec;            // tiles per double-buff
 constexpr int kAcCandCap = kAcTileUnits + kVerifyBatches * kWave;
 uint32_t tile_group_units() { return kPrefetch * kTileUnits; }
 
-constexpr int kFilterWordsMax = 22016; // 88064 bytes of static LDS for the filter rows (tunable filter_max_bytes <= 88000)
+#ifndef ACGPU_FILTER_WORDS
+#define ACGPU_FILTER_WORDS 22016
+#endif
+constexpr int kFilterWordsMax = ACGPU_FILTER_WORDS; // 88064 bytes of static LDS for the filter rows (tunable filter_max_bytes <= 88000)
 constexpr int kFilterWordsSplit = 20224; // the filter-only kernel: 79 KiB, so that two workgroups fit one CU's 160 KiB
 bool tile_split_supported(const DevTables &t) { return t.filt_k >= 1 && t.filt_words <= (uint32_t)kFilterWordsSplit; }
 
@@ -54,6 +57,17 @@ size_t tile_lds_bytes(const DevTables &t, int block_threads) {
 struct __attribute__((packed, aligned(2))) Units8 { // 8 UTF-16 units at any unit address (one global_load_dwordx4)
     uint32_t d[4];
 };
+
+// the haystack stream: read once
+__device__ __forceinline__ uint4 stream_load(const uint16_t *p) {
+#ifdef ACGPU_STREAM_NT
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    const v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *reinterpret_cast<const uint4 *>(p);
+#endif
+}
 
 __device__ __forceinline__ uint32_t tile_class(const DevTables &T, uint32_t unit) {
     if (T.range_cls) return min(unit - T.cls_base, T.cls_span); // outside [base, base+span) -> span ("other")
@@ -317,8 +331,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
         for (int d = 0; d < kAcTiles; ++d)
 #pragma unroll
             for (int u = 0; u < kAcVec; ++u)
-                nxt[d][u] = *reinterpret_cast<const uint4 *>(
-                    hay + min(tile + d * kAcTileUnits + lane * kAcLaneUnits + u * 8, last_vec));
+                nxt[d][u] = stream_load(hay + min(tile + d * kAcTileUnits + lane * kAcLaneUnits + u * 8, last_vec));
     }
 
     // One loop, ONE verification site: every pass first drains the candidate queue as far as its state requires
@@ -357,8 +370,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                 for (int d = 0; d < kAcTiles; ++d)
 #pragma unroll
                     for (int u = 0; u < kAcVec; ++u)
-                        nxt[d][u] = *reinterpret_cast<const uint4 *>(
-                            hay + min(tile + (kAcTiles + d) * kAcTileUnits + lane * kAcLaneUnits + u * 8, last_vec));
+                        nxt[d][u] = stream_load(hay + min(tile + (kAcTiles + d) * kAcTileUnits + lane * kAcLaneUnits + u * 8, last_vec));
             }
             // positions a lane may report: inside the region, in the vector part of the buffer, with K units to their
             // left in the buffer.  Only groups at the edges of a region need the per-lane mask.
