@@ -1,0 +1,20 @@
+#!/bin/bash
+# Runs on the GPU box (through gpurun): the bench lines and rocprofv3 evidence that profiles/<round>/ keeps.
+# usage: bash tools/collect_profiles.sh <out-dir under gpurun_out/>
+set -u
+OUT=gpurun_out/${1:-final}
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+python3 bench.py --steps 20 --warmup 3 > "$OUT/bench_c2.json" 2> "$OUT/bench_c2.err"
+python3 bench.py --config C4 --steps 5 --warmup 1 > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err"
+python3 bench.py --config C5 --steps 5 --warmup 1 > "$OUT/bench_c5.json" 2> "$OUT/bench_c5.err"
+# per-kernel time: the program itself after "--"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c2" -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/stats_c2.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c4" -- python3 bench.py --config C4 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/stats_c4.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c5" -- python3 bench.py --config C5 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/stats_c5.log" 2>&1
+# HBM traffic counters: separate passes, counters only (no other trace domains)
+V='{"tile":{"force_kernel":2},"noverify":{"force_kernel":2,"tile_debug":1},"stream":{"force_kernel":2,"tile_debug":5}}'
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 tools/kbench.py --rounds 1 --variants "$V" > "$OUT/pmc_fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 tools/kbench.py --rounds 1 --variants "$V" > "$OUT/pmc_write.log" 2>&1
+cat "$OUT/bench_c2.json"
