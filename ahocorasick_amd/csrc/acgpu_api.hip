@@ -421,8 +421,13 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
     S.len_bytes = t.max_len < 65536 ? 2 : 4;
     uint32_t lds_rows = 0;
     if (t.dense && t.n_cls) lds_rows = (uint32_t)std::min<uint64_t>(t.n_states, (72 * 1024) / ((uint64_t)t.n_cls * 4));
+    // range classes (case sensitive, keyword units within a span of 63) take the lean walk; tunable force_kernel=1
+    // keeps the general one
+    S.pairs = t.dense && t.range_cls && t.n_cls == t.cls_span + 1 && tunables().force_kernel != 1 &&
+              (uint64_t)t.n_states * t.n_cls * 4 < (1ull << 31);
+    if (S.pairs) lds_rows = (uint32_t)std::min<uint64_t>(t.n_states, (72 * 1024) / ((uint64_t)t.n_cls * 4) - 2);
     S.lds_rows = lds_rows;
-    S.lds_bytes = std::max<size_t>((size_t)lds_rows * t.n_cls * 4, 16);
+    S.lds_bytes = std::max<size_t>((size_t)(lds_rows + (S.pairs ? 2 : 0)) * t.n_cls * 4, 16);
     int rc;
     if ((rc = d.lenbuf.ensure((size_t)sh->n_units * S.len_bytes + 64))) return rc;
     S.d_len = d.lenbuf.p;

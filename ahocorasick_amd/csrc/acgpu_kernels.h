@@ -99,6 +99,7 @@ struct LongestScanLaunch {
     uint32_t *d_blockmax;           // per 64 owned positions: max(p + max(L[p],1)) -- lets the chain kernels skip
     int len_bytes;                  // 2 or 4
     uint32_t lds_rows;              // trie rows staged in LDS
+    int pairs;                      // 1: the lean range-class walk (k_longest_walk_range)
     int grid, block;
     size_t lds_bytes;
 };

@@ -129,6 +129,100 @@ __global__ __launch_bounds__(kLScanBlock) void k_longest_walk(DevTables T, Longe
     }
 }
 
+// The lean form for range classes (case sensitive, keyword units within a span of 63: config 4, DNA, a-z ...), the one
+// that matters for throughput: the kernel is VALU bound (2.8 G wave-instructions at config 4), so a step is cut down to
+// unit extract, sub + min (column), lshl_add (address), ds_read, and (next row), cmp + cndmask (longest keyword so far):
+//  * the LDS rows are re-encoded while they are staged: column = min(unit - base, span) (the last column = "any other
+//    unit"), entry = {bit 31: the child ends a keyword, low bits: BYTE offset of the child's row};
+//  * a missing transition leads to a DEAD row that loops to itself, so dead lanes need no predicate, and the depth of a
+//    step is the same for every lane of the wave (all start together), i.e. a constant of the unrolled step;
+//  * children beyond the LDS rows lead to a DEEP row (also a self loop); a lane that ends there (never on config 4:
+//    nodes deeper than ~120 units) redoes its walk through the table in global memory.
+template <typename LenT, bool STATE>
+__global__ __launch_bounds__(kLScanBlock) void k_longest_walk_range(DevTables T, LongestScanLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *rows = reinterpret_cast<uint32_t *>(smem);
+    const uint32_t *glob = reinterpret_cast<const uint32_t *>(T.dfa);
+    const uint32_t n = T.n_cls, span = T.cls_span, base = T.cls_base; // n == span + 1
+    const uint32_t row_bytes = n * 4u;
+    const uint32_t real_bytes = L.lds_rows * row_bytes, dead_off = real_bytes, deep_off = real_bytes + row_bytes;
+    for (uint32_t i = threadIdx.x; i < (L.lds_rows + 2) * n; i += blockDim.x) {
+        const uint32_t r = i / n, col = i - r * n;
+        uint32_t e;
+        if (r >= L.lds_rows) {
+            e = r == L.lds_rows ? dead_off : deep_off;
+        } else {
+            const uint32_t g = col < span ? glob[r * n + col + 1] : 0u; // class of column j is j+1; the last column has none
+            if (!g) e = dead_off;
+            else if ((g & 0x7fffffffu) >= L.lds_rows) e = deep_off;
+            else e = (g & 0x80000000u) | ((g & 0x7fffffffu) * row_bytes);
+        }
+        rows[i] = e;
+    }
+    __syncthreads();
+    LenT *out_len = reinterpret_cast<LenT *>(L.d_len);
+    const uint16_t *hay = L.d_hay;
+    const unsigned char *rows8 = reinterpret_cast<const unsigned char *>(rows);
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t nu = L.n_units;
+    for (uint32_t p0 = L.own_begin + blockIdx.x * blockDim.x; p0 < L.own_end; p0 += stride) {
+        const uint32_t p = p0 + threadIdx.x;
+        uint32_t reach = 0;
+        if (p < L.own_end) {
+            uint32_t off = 0, best = 0, best_off = 0, i = p, k0 = 0;
+            for (;;) {
+                const uint32_t nvalid = min(nu - min(i, nu), 8u);
+                uint32_t w[4] = {0, 0, 0, 0};
+                if (nvalid == 8) {
+                    const Units8 u = *reinterpret_cast<const Units8 *>(hay + i);
+                    w[0] = u.d[0]; w[1] = u.d[1]; w[2] = u.d[2]; w[3] = u.d[3];
+                } else {
+                    for (uint32_t j = 0; j < nvalid; ++j) w[j >> 1] |= (uint32_t)hay[i + j] << (16 * (j & 1));
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t unit = (j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xffffu);
+                    uint32_t col = min(unit - base, span);
+                    if (nvalid != 8 && (uint32_t)j >= nvalid) col = span; // past the end of the buffer: no transition
+                    const uint32_t e = *reinterpret_cast<const uint32_t *>(rows8 + off + col * 4u);
+                    off = e & 0x7fffffffu;
+                    if ((int32_t)e < 0) {
+                        best = k0 + (uint32_t)j + 1u;
+                        if (STATE) best_off = off;
+                    }
+                }
+                if (off >= real_bytes) break; // dead or deep
+                i += 8;
+                k0 += 8;
+            }
+            uint32_t best_node = best_off / row_bytes;
+            if (off == deep_off) { // rare: redo the walk through the table in global memory
+                uint32_t node = 0, j = p;
+                best = 0;
+                best_node = 0;
+                while (j < nu) {
+                    const uint32_t dlt = hay[j] - base;
+                    const uint32_t e = glob[node * n + (dlt < span ? dlt + 1u : 0u)];
+                    if (!e) break;
+                    node = e & 0x7fffffffu;
+                    ++j;
+                    if (e >> 31) {
+                        best = j - p;
+                        best_node = node;
+                    }
+                }
+            }
+            out_len[p] = (LenT)best;
+            if (STATE) L.d_state[p] = best_node;
+            reach = p + (best ? best : 1u);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) reach = max(reach, (uint32_t)__shfl_xor((int)reach, d));
+        const uint32_t wave_p0 = p0 + (threadIdx.x & ~63u);
+        if ((threadIdx.x & 63u) == 0 && wave_p0 < L.own_end) L.d_blockmax[(wave_p0 - L.own_begin) >> 6] = reach;
+    }
+}
+
 hipError_t launch_longest_scan(const DevTables &t, const LongestScanLaunch &l, hipStream_t stream, const char **kernel_name) {
 #define ACGPU_LAUNCH(KERNEL, NAME)                                                                                      \
     do {                                                                                                                \
@@ -138,7 +232,15 @@ hipError_t launch_longest_scan(const DevTables &t, const LongestScanLaunch &l, h
         hipLaunchKernelGGL(KERNEL, dim3(l.grid), dim3(l.block), l.lds_bytes, stream, t, l);                             \
         if (kernel_name) *kernel_name = NAME;                                                                           \
     } while (0)
-    if (t.dense) {
+    if (l.pairs) { // (field name kept: the lean range-class form)
+        if (l.d_state) {
+            if (l.len_bytes == 2) ACGPU_LAUNCH((k_longest_walk_range<uint16_t, true>), "k_longest_walk_range<unsigned short, true>");
+            else ACGPU_LAUNCH((k_longest_walk_range<uint32_t, true>), "k_longest_walk_range<unsigned int, true>");
+        } else {
+            if (l.len_bytes == 2) ACGPU_LAUNCH((k_longest_walk_range<uint16_t, false>), "k_longest_walk_range<unsigned short, false>");
+            else ACGPU_LAUNCH((k_longest_walk_range<uint32_t, false>), "k_longest_walk_range<unsigned int, false>");
+        }
+    } else if (t.dense) {
         if (l.len_bytes == 2) ACGPU_LAUNCH((k_longest_walk<uint16_t, true>), "k_longest_walk<unsigned short, true>");
         else ACGPU_LAUNCH((k_longest_walk<uint32_t, true>), "k_longest_walk<unsigned int, true>");
     } else {

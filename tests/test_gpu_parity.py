@@ -924,3 +924,16 @@ def test_split_form_falls_back_when_the_candidate_slices_overflow():
     assert rc == N.OK
     n, rc, _ = a.match_device_end(tk)
     assert rc == N.OK and n == len(want) and (out[:n].cpu().numpy() == want).all()
+
+
+def test_longest_walk_beyond_the_lds_rows_takes_the_global_table():
+    """Keywords deeper than the trie rows that fit LDS (about 6100 rows at 3 classes): those walks are redone through
+    the table in global memory."""
+    kws = ["a" * 7000, "a" * 6500, "ab", "b"]
+    hay = np.concatenate([np.full(7200, ord("a")), np.array([ord("b")] * 3), np.full(6600, ord("a")), np.array([ord("b")]),
+                          np.full(100, ord("a"))]).astype(np.uint16)
+    want = Oracle(FAM_LONGEST, kws).match(hay)
+    got = LongestMatchMap(kws, _ids(len(kws)), True).find_all(hay)
+    assert got.shape == want.shape and (got == want).all()
+    got_set = LongestMatchSet(kws, True).find_all(hay)
+    assert (got_set == want[:, :2]).all()
