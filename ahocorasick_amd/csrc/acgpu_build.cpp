@@ -243,6 +243,11 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
         while (cap < 2 * (uint64_t)n_terminal + 2) cap <<= 1;
         t.ww_slots.assign(2 * cap, kWwEmpty);
         t.ww_mask = (uint32_t)(cap - 1);
+        // Bloom filter: ~16 bits per keyword, at least 1 Kbit, at most 512 Kbit (64 KB of LDS)
+        uint64_t bits = 1024;
+        while (bits < 16 * (uint64_t)n_terminal && bits < (512u << 10)) bits <<= 1;
+        t.ww_bloom.assign(bits / 32, 0u);
+        t.ww_bloom_mask = (uint32_t)(bits - 1);
         std::vector<uint16_t> word;
         for (uint32_t s = 1; s < N; s++) {
             if (nodes[s].kw == ~0u) continue;
@@ -265,6 +270,9 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
             while (t.ww_slots[2 * slot + 1] != kWwEmpty) slot = (slot + 1) & t.ww_mask;
             t.ww_slots[2 * slot] = h;
             t.ww_slots[2 * slot + 1] = (uint32_t)off16;
+            const uint32_t b1 = ww_bloom_bit1(h, t.ww_bloom_mask), b2 = ww_bloom_bit2(h, t.ww_bloom_mask);
+            t.ww_bloom[b1 >> 5] |= 1u << (b1 & 31);
+            t.ww_bloom[b2 >> 5] |= 1u << (b2 & 31);
         }
         t.ww_recs.resize(t.ww_recs.size() + 8, 0u); // the compare may read one 16-byte group past a short record
         t.fold_pgidx.assign(256, 0);

@@ -43,6 +43,9 @@ ACGPU_HD inline uint32_t ww_hash_final(uint32_t h) {
     return h;
 }
 ACGPU_HD inline uint32_t ww_hash_home(uint32_t h, uint32_t mask) { return h & mask & ~3u; }
+// two bit positions of the Bloom filter in front of the table (the filter sits in LDS)
+ACGPU_HD inline uint32_t ww_bloom_bit1(uint32_t h, uint32_t mask) { return (h >> 7) & mask; }
+ACGPU_HD inline uint32_t ww_bloom_bit2(uint32_t h, uint32_t mask) { return ((h >> 19) | (h << 13)) & mask; }
 
 // Host-side automaton tables.  State numbering: root = 0; states WITHOUT any output (own or inherited
 // keyword) come first in BFS order, states WITH output after them in BFS order, so that
@@ -109,6 +112,8 @@ struct HostTables {
     std::vector<uint16_t> fold_pages;  // fold_n_pages * 256
     uint32_t fold_n_pages = 0;
     uint32_t fold_direct_n = 0;        // units below this fold through a direct table (the cased scripts of the low pages)
+    std::vector<uint32_t> ww_bloom;    // 2-hash Bloom filter over the keyword hashes, a power of two of bits (<= 64 KB)
+    uint32_t ww_bloom_mask = 0;        // bits - 1
 };
 
 int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uint32_t n_kw, int case_sensitive,
@@ -141,6 +146,8 @@ struct DevTables {
     const uint8_t *fold_pgidx;
     const uint16_t *fold_pages;
     uint32_t fold_n_pages, fold_direct_n;
+    const uint32_t *ww_bloom;
+    uint32_t ww_bloom_mask;
 };
 
 struct Tunables {

@@ -50,9 +50,11 @@ constexpr uint32_t kFoldPagesMax = 64; // 32 KB of LDS; Unicode 13 simple lower-
 
 uint32_t ww_fold_pages_in_lds(const DevTables &t) { return (!t.cs && t.fold_n_pages <= kFoldPagesMax) ? t.fold_n_pages : 0u; }
 
+static size_t ww_bloom_bytes(const DevTables &t) { return ((size_t)t.ww_bloom_mask + 1) / 8; }
+
 size_t ww_lds_bytes(int block_threads, const DevTables &t) {
     const uint32_t fold_pages = ww_fold_pages_in_lds(t);
-    return 8192 + (fold_pages ? 256 + (size_t)t.fold_direct_n * 2 + (size_t)fold_pages * 512 : 0) +
+    return 8192 + ww_bloom_bytes(t) + (fold_pages ? 256 + (size_t)t.fold_direct_n * 2 + (size_t)fold_pages * 512 : 0) +
            (size_t)(block_threads / kWave) * kWwCandCap * sizeof(uint32_t);
 }
 
@@ -61,6 +63,8 @@ struct __attribute__((packed, aligned(2))) WwUnits8 { // 8 UTF-16 units at any u
 };
 
 struct FoldLds {
+    const uint32_t *bloom;  // Bloom filter over the keyword hashes (not part of folding; travels with the LDS tables)
+    uint32_t bloom_mask;
     const uint8_t *pgidx;   // 256 page numbers
     const uint16_t *pages;  // pages of 256 deltas
     const uint16_t *direct; // lower[u] for u < direct_n: the bicameral scripts of the low pages in ONE read
@@ -198,8 +202,12 @@ __device__ __forceinline__ void ww_verify_hash(TileCtx &c, const uint32_t *wbits
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         id[b] = ~0u;
-        probing[b] = act[b] && r[b] != 0 && r[b] <= T.max_len && !(L.debug & 2u); // 2: ablation, no table lookup
         h[b] = ww_hash_final(h[b]);
+        probing[b] = act[b] && r[b] != 0 && r[b] <= T.max_len && !(L.debug & 2u); // 2: ablation, no table lookup
+        if (!(L.debug & 4u)) { // 4: ablation, no Bloom filter in front of the table
+            const uint32_t b1 = ww_bloom_bit1(h[b], F.bloom_mask), b2 = ww_bloom_bit2(h[b], F.bloom_mask);
+            probing[b] = probing[b] && ((F.bloom[b1 >> 5] >> (b1 & 31)) & (F.bloom[b2 >> 5] >> (b2 & 31)) & 1u);
+        }
         grp[b] = ww_hash_home(h[b], T.ww_mask);
         t0[b] = 0; // entries of the group below t0 were already tried
     }
@@ -383,17 +391,21 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *wbits = reinterpret_cast<uint32_t *>(smem); // 65536 word-character bits
     const uint32_t fold_bytes = FOLD == 1 ? 256u + T.fold_direct_n * 2u + T.fold_n_pages * 512u : 0u;
-    uint32_t *cand_all = reinterpret_cast<uint32_t *>(smem + 8192 + fold_bytes);
+    const uint32_t bloom_bytes = (T.ww_bloom_mask + 1u) / 8u;
+    uint32_t *bloom = reinterpret_cast<uint32_t *>(smem + 8192);
+    unsigned char *fold_base = smem + 8192 + bloom_bytes;
+    uint32_t *cand_all = reinterpret_cast<uint32_t *>(fold_base + fold_bytes);
+    for (uint32_t w = threadIdx.x; w < bloom_bytes / 4; w += blockDim.x) bloom[w] = T.ww_bloom[w];
     for (uint32_t w = threadIdx.x; w < 2048; w += blockDim.x) { // pack the raw-unit flag (bit 0 of wflags) into bits
         uint32_t bits = 0;
         for (uint32_t k = 0; k < 32; ++k) bits |= (uint32_t)(T.wflags[w * 32 + k] & 1u) << k;
         wbits[w] = bits;
     }
-    uint16_t *direct = reinterpret_cast<uint16_t *>(smem + 8192 + 256);
+    uint16_t *direct = reinterpret_cast<uint16_t *>(fold_base + 256);
     uint16_t *pages = direct + (FOLD == 1 ? T.fold_direct_n : 0u);
-    FoldLds F{smem + 8192, pages, direct, FOLD == 1 ? T.fold_direct_n : 0u};
+    FoldLds F{bloom, T.ww_bloom_mask, fold_base, pages, direct, FOLD == 1 ? T.fold_direct_n : 0u};
     if (FOLD == 1) {
-        for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) smem[8192 + i] = T.fold_pgidx[i];
+        for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) fold_base[i] = T.fold_pgidx[i];
         for (uint32_t i = threadIdx.x; i < T.fold_direct_n; i += blockDim.x) direct[i] = T.lower[i];
         for (uint32_t i = threadIdx.x; i < T.fold_n_pages * 256u; i += blockDim.x) pages[i] = T.fold_pages[i];
     }

@@ -37,7 +37,7 @@ def main():
         block = synth.mixed_script_haystack(synth.CONFIGS["C5"]["hay_seed"], blk, kws, swapcase_tbl=synth.swapcase_table())
         d_hay = torch.from_numpy(block.view(np.int16)).cuda().repeat(n // blk)
         cap = n // 8
-        dflt = {"ww": {}, "ww_noverify": {"tile_debug": 1}, "ww_nolookup": {"tile_debug": 2}, "ww_triewalk": {"force_kernel": 1}}
+        dflt = {"ww": {}, "ww_noverify": {"tile_debug": 1}, "ww_nolookup": {"tile_debug": 2}, "ww_nobloom": {"tile_debug": 4}}
     else:
         a = Automaton(N.MODE_LONGEST if args.config == "C4" else (N.MODE_SHORTEST if shortest else N.MODE_ALL), kws, True)
         d_hay = torch.empty(n, dtype=torch.int16, device="cuda")
