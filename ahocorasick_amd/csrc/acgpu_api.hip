@@ -412,7 +412,9 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
     const uint64_t own_len = sh->own_end - sh->own_begin;
     LongestScanLaunch S{};
     S.block = 1024;
-    S.grid = 2 * d.n_cu; // two workgroups per CU share the LDS (hot trie rows: at most 72 KB each)
+    // two workgroups per CU share the LDS (hot trie rows: at most 72 KB each); a short haystack gets fewer (every
+    // workgroup stages the rows before it starts)
+    S.grid = (int)std::min<uint64_t>(2ull * d.n_cu, (own_len + S.block - 1) / S.block);
     S.chunk_units = 0;
     S.n_chunks = 0;
     S.d_hay = sh->d_hay;

@@ -400,8 +400,30 @@ __global__ __launch_bounds__(kChainBlock) void k_longest_chain(LongestChainLaunc
             }
             ++dst;
             ++count;
+            pos += l;
+        } else {
+            // no keyword starts here: skip the run of such positions eight at a time (sparse dictionaries: most of
+            // the haystack), reading 16 bytes of lengths per step
+            ++pos;
+            if (sizeof(LenT) == 2) {
+                const uint32_t limit = min(target, L.own_end);
+                while (pos + 8 <= limit) {
+                    const Units8 z = *reinterpret_cast<const Units8 *>(reinterpret_cast<const uint16_t *>(len) + pos);
+                    const uint32_t any = z.d[0] | z.d[1] | z.d[2] | z.d[3];
+                    if (any) {
+                        // first non-zero 16-bit entry
+                        uint32_t k = 0;
+                        if (z.d[0]) k = (z.d[0] & 0xffffu) ? 0 : 1;
+                        else if (z.d[1]) k = (z.d[1] & 0xffffu) ? 2 : 3;
+                        else if (z.d[2]) k = (z.d[2] & 0xffffu) ? 4 : 5;
+                        else k = (z.d[3] & 0xffffu) ? 6 : 7;
+                        pos += k;
+                        break;
+                    }
+                    pos += 8;
+                }
+            }
         }
-        pos += l > 0 ? l : 1u;
     }
     if (WRITE) {
         const uint32_t k = (uint32_t)dst & gmask;
