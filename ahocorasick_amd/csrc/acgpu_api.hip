@@ -285,7 +285,7 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         L.d_scratch = (ScratchRec *)d.scratch.p;
         L.d_counter = (unsigned long long *)d.counter.p;
         L.d_region_counts = (uint32_t *)d.chunk_counts.p;
-        HIP_TRY(hipMemsetAsync(d.chunk_counts.p, 0, (size_t)L.n_regions * 4, stream));
+        // (every region's count is written by the wave that owns the region: no memset)
         split = !fused_only && use_split_form(d.T);
         if (split) {
             // a wave's slice holds one candidate per 8 units of its span (the filter passes ~2 % on selective

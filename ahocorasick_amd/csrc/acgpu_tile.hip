@@ -13,8 +13,8 @@
 //            alphabets; L2-resident), collecting every keyword that ends at e -- exactly the keywords on the
 //            reference's output chain of the state reached at e.
 //
-// Work distribution: a wave owns a contiguous REGION of the haystack and streams it as 512-unit tiles, lane l
-// holding 16 consecutive units of a 1024-unit tile (two 16-byte loads per lane), 8 KiB per wave in flight.
+// Work distribution: a wave owns a contiguous span of REGIONS of the haystack and streams it as 1024-unit tiles, lane l
+// holding 16 consecutive units of a tile (two 16-byte loads per lane), 8 KiB per wave in flight.
 // Because a wave meets its candidates in text order, a record's rank inside its region is a running wave-uniform
 // count plus a wave prefix sum; the finalize pass (prefix sum over regions + permutation) then yields the
 // reference's emission order (end ascending, longest first) without any sort.  Records go straight to HBM into
