@@ -556,7 +556,7 @@ static hipError_t launch_tile_k(const DevTables &t, const TileLaunch &l, hipStre
 }
 
 hipError_t launch_ac_tile(const DevTables &t, const TileLaunch &l, hipStream_t stream, const char **kernel_name) {
-    static char name[64];
+    static thread_local char name[64];
     if (t.filt_k < 1 || t.filt_k > 8) return hipErrorInvalidValue;
     std::snprintf(name, sizeof(name), "k_ac_tile<%u, %s, %s, false>", t.filt_k, t.range_cls ? "true" : "false",
                   t.filt_row_bytes == 8 ? "true" : "false");
@@ -575,7 +575,7 @@ hipError_t launch_ac_tile(const DevTables &t, const TileLaunch &l, hipStream_t s
 }
 
 hipError_t launch_ac_filter(const DevTables &t, const TileLaunch &l, hipStream_t stream, const char **kernel_name) {
-    static char name[64];
+    static thread_local char name[64];
     if (!tile_split_supported(t) || t.filt_k > 8) return hipErrorInvalidValue;
     std::snprintf(name, sizeof(name), "k_ac_tile<%u, %s, %s, true>", t.filt_k, t.range_cls ? "true" : "false",
                   t.filt_row_bytes == 8 ? "true" : "false");

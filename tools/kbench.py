@@ -17,7 +17,7 @@ def main():
     ap.add_argument("--units-log2", type=int, default=29)
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--variants", type=str, default="")
-    ap.add_argument("--config", default="C2", choices=["C2", "C2S", "C4", "C5"])
+    ap.add_argument("--config", default="C2", choices=["C2", "C2S", "C4", "C5", "C5L"])
     ap.add_argument("--set", action="store_true", help="8-byte Set records instead of 12-byte Map records")
     args = ap.parse_args()
     import torch
@@ -25,6 +25,9 @@ def main():
     from ahocorasick_amd.strings import Automaton
 
     n = 1 << args.units_log2
+    wwl = args.config == "C5L"  # config 5's words (+ 10 % two-word keywords) and haystack through WholeWordLongestMatchMap
+    if wwl:
+        args.config = "C5"
     shortest = args.config == "C2S"  # config 2's dictionary and haystack through ShortestMatchMap
     if shortest:
         args.config = "C2"
@@ -32,12 +35,15 @@ def main():
     if args.config == "C5":
         from ahocorasick_amd.unicode_tables import default_word_chars
         n = min(n, 1 << 28)
-        a = Automaton(N.MODE_WHOLEWORD, kws, False, word_chars=default_word_chars())
+        if wwl:
+            sp = np.array([32], dtype=np.uint16)
+            kws = list(kws) + [np.concatenate([kws[i], sp, kws[i + 1]]) for i in range(0, 20000, 2)]
+        a = Automaton(N.MODE_WWLONGEST if wwl else N.MODE_WHOLEWORD, kws, False, word_chars=default_word_chars())
         blk = min(n, 1 << 22)
         block = synth.mixed_script_haystack(synth.CONFIGS["C5"]["hay_seed"], blk, kws, swapcase_tbl=synth.swapcase_table())
         d_hay = torch.from_numpy(block.view(np.int16)).cuda().repeat(n // blk)
         cap = n // 8
-        dflt = {"ww": {}, "ww_noverify": {"tile_debug": 1}, "ww_nolookup": {"tile_debug": 2}, "ww_nobloom": {"tile_debug": 4}}
+        dflt = {"wwl": {}} if wwl else {"ww": {}, "ww_noverify": {"tile_debug": 1}, "ww_nolookup": {"tile_debug": 2}, "ww_nobloom": {"tile_debug": 4}}
     else:
         a = Automaton(N.MODE_LONGEST if args.config == "C4" else (N.MODE_SHORTEST if shortest else N.MODE_ALL), kws, True)
         d_hay = torch.empty(n, dtype=torch.int16, device="cuda")
