@@ -394,6 +394,72 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
     return *n_out > cap ? ACGPU_E_OVERFLOW : ACGPU_OK;
 }
 
+// LONGEST over a dictionary whose suffix filter is selective: matches are sparse, so leftmost-longest is a selection
+// over the all-matches list (the AhoCorasick tile pipeline into an internal buffer + k_long_next + chain marking)
+// instead of a trie walk from every position.  Returns ACGPU_E_UNSUPPORTED when the haystack turns out to be dense in
+// matches (the caller then takes the walk).
+int match_longest_sparse(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_kind, void *d_out, uint64_t cap,
+                         uint64_t *n_out, hipStream_t stream, acgpu_profile *prof, uint64_t entry) {
+    const HostTables &t = a->t;
+    const uint64_t halo = t.max_len > 0 ? t.max_len - 1 : 0;
+    const uint64_t own_len = sh->own_end - sh->own_begin;
+    acgpu_shard all = *sh; // every occurrence that ENDS in the owned range or its right halo
+    all.own_end = std::min<uint64_t>(sh->n_units, sh->own_end + halo);
+    all.text_begin = 1; // occurrences that begin before the buffer begin before own_begin: not ours anyway
+    int rc;
+    uint64_t m = 0;
+    const uint64_t dense_limit = own_len / 4 + 4096;
+    uint64_t acap = std::max<uint64_t>(d.short_recs.bytes > 16 ? (d.short_recs.bytes - 16) / ACGPU_REC_MAP : 0, own_len / 32 + (1 << 16));
+    acgpu_profile all_prof;
+    for (;;) {
+        if ((rc = d.short_recs.ensure(acap * ACGPU_REC_MAP + 16))) return rc;
+        rc = match_all(a, d, &all, ACGPU_REC_MAP, d.short_recs.p, acap, &m, stream, prof ? &all_prof : nullptr);
+        if (rc == ACGPU_E_OVERFLOW) {
+            if (m > dense_limit) return ACGPU_E_UNSUPPORTED;
+            acap = m;
+            continue;
+        }
+        if (rc != ACGPU_OK) return rc;
+        break;
+    }
+    if (m > dense_limit) return ACGPU_E_UNSUPPORTED;
+    if (prof) *prof = all_prof;
+    *n_out = 0;
+    sh->chain_exit = (int64_t)std::max<uint64_t>(entry, sh->own_end);
+    if (m == 0) return ACGPU_OK;
+    const uint32_t M = (uint32_t)m;
+    if ((rc = d.short_nxt.ensure(((size_t)M + 1) * 4))) return rc;
+    if ((rc = d.short_tmp.ensure(((size_t)M + 1) * 4))) return rc;
+    if ((rc = d.short_mark.ensure(((size_t)M + 1) * 4))) return rc;
+    if ((rc = d.offsets.ensure((size_t)M * 8))) return rc;
+    if ((rc = d.scan_tmp.ensure(((size_t)M / 2048 + 2) * 8))) return rc;
+    if ((rc = d.counter.ensure(64))) return rc;
+    if (prof) HIP_TRY(hipEventRecord(d.ev[0], stream));
+    HIP_TRY(launch_longest_select((const int32_t *)d.short_recs.p, M, (int64_t)entry, (int64_t)sh->own_end, t.max_len,
+                                  (uint32_t *)d.short_nxt.p, (uint32_t *)d.short_tmp.p, (uint32_t *)d.short_mark.p, stream));
+    HIP_TRY(launch_exclusive_scan((const uint32_t *)d.short_mark.p, M, (uint64_t *)d.offsets.p, (uint64_t *)d.scan_tmp.p, stream));
+    const uint64_t *d_total = (const uint64_t *)d.scan_tmp.p + scan_tiles_for(M);
+    HIP_TRY(launch_shortest_emit((const int32_t *)d.short_recs.p, M, (const uint32_t *)d.short_mark.p,
+                                 (const uint64_t *)d.offsets.p, d_total, record_kind, d_out, cap, (int64_t)entry,
+                                 (unsigned long long *)d.counter.p, stream));
+    if (prof) HIP_TRY(hipEventRecord(d.ev[1], stream));
+    HIP_TRY(hipMemcpyAsync(d.h_counter, d_total, 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(d.h_counter + 1, d.counter.p, 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    *n_out = d.h_counter[0];
+    // the chain leaves the owned range at the end of its last match, or walks out of it one unit at a time
+    if (*n_out) sh->chain_exit = (int64_t)std::max<uint64_t>(d.h_counter[1], sh->own_end);
+    if (prof) {
+        float sel_ms = 0;
+        HIP_TRY(hipEventElapsedTime(&sel_ms, d.ev[0], d.ev[1]));
+        prof->finalize_ms += sel_ms;
+        prof->total_ms += sel_ms;
+        prof->scan_units = own_len;
+        prof->n_matches = *n_out;
+    }
+    return *n_out > cap ? ACGPU_E_OVERFLOW : ACGPU_OK;
+}
+
 // LONGEST-mode pipeline on one shard: reverse scan -> chain count -> prefix sum -> chain write.
 int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_kind, void *d_out, uint64_t cap,
                   uint64_t *n_out, hipStream_t stream, acgpu_profile *prof) {
@@ -410,6 +476,11 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
         return ACGPU_OK;
     }
     const uint64_t own_len = sh->own_end - sh->own_begin;
+    if (use_tile_kernel(t) && tunables().force_kernel != 1) { // selective suffix filter: selection over all matches
+        const int src = match_longest_sparse(a, d, sh, record_kind, d_out, cap, n_out, stream, prof, entry);
+        if (src != ACGPU_E_UNSUPPORTED) return src;
+        sh->chain_exit = (int64_t)std::max<uint64_t>(entry, sh->own_end); // dense in matches after all: the walk
+    }
     LongestScanLaunch S{};
     S.block = 1024;
     // two workgroups per CU share the LDS (hot trie rows: at most 72 KB each); a short haystack gets fewer (every

@@ -360,7 +360,10 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
     // the last unit; rows are 4 bytes (n <= 32 classes) or 8 bytes (n <= 64).  A position survives iff its K-gram is
     // the K-suffix of some keyword (K <= shortest keyword, so every keyword has one).
     t.filt_k = 0;
-    if ((mode == ACGPU_MODE_ALL || mode == ACGPU_MODE_SHORTEST) && t.n_cls > 1 && t.n_cls <= 64 && t.min_len >= 1) {
+    // (LONGEST: for dictionaries with a selective filter the matches are sparse, and leftmost-longest is a selection
+    // over the all-matches list instead of a trie walk from every position)
+    if ((mode == ACGPU_MODE_ALL || mode == ACGPU_MODE_SHORTEST || mode == ACGPU_MODE_LONGEST) && t.n_cls > 1 && t.n_cls <= 64 &&
+        t.min_len >= 1) {
         // tile classes: range mode -> min(unit - base, span) (other = span); LUT mode -> cls_lut (other = 0)
         const uint32_t n = t.n_cls;
         t.filt_n = n;

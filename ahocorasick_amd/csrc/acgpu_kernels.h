@@ -132,6 +132,8 @@ namespace acgpu {
 // ShortestMatch: greedy selection over the ordered all-matches list (acgpu_shortest.hip)
 hipError_t launch_shortest_select(const int32_t *d_recs, uint32_t M, int64_t entry, uint32_t *d_nxt, uint32_t *d_tmp,
                                   uint32_t *d_mark, hipStream_t stream);
+hipError_t launch_longest_select(const int32_t *d_recs, uint32_t M, int64_t entry, int64_t limit, uint32_t max_len,
+                                 uint32_t *d_nxt, uint32_t *d_tmp, uint32_t *d_mark, hipStream_t stream);
 hipError_t launch_chain_mark(uint32_t *d_nxt, uint32_t *d_tmp, uint32_t *d_mark, uint32_t M, hipStream_t stream);
 hipError_t launch_shortest_emit(const int32_t *d_recs, uint32_t M, const uint32_t *d_mark, const uint64_t *d_offsets,
                                 const uint64_t *d_total, int record_kind, void *d_out, uint64_t cap, int64_t entry,

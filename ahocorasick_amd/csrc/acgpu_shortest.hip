@@ -68,6 +68,40 @@ __global__ __launch_bounds__(256) void k_short_next(const int32_t *recs, uint32_
     nxt[k] = first_starting_at(recs, M, upper_end(recs, k + 1, M, e), e);
 }
 
+// Longest (leftmost-longest, non-overlapping) over the same end-ordered list: the record the greedy chain takes at
+// position `pos` is the one with the smallest start >= pos (and < limit), the longest among those -- found by scanning
+// forwards from the first record that ends after pos until no later record can start that early (a record starts at most
+// max_len units before its end).
+__device__ __forceinline__ uint32_t leftmost_longest_from(const int32_t *recs, uint32_t M, uint32_t from, int32_t pos,
+                                                          int32_t limit, int32_t max_len) {
+    uint32_t cur = M;
+    int32_t cur_s = 0x7fffffff;
+    for (uint32_t j = from; j < M; ++j) {
+        const int32_t s = recs[3 * (uint64_t)j], e = recs[3 * (uint64_t)j + 1];
+        if (cur != M && e > cur_s + max_len) break;
+        if (s >= pos && s < limit && s <= cur_s) { // same start, later in the list = longer
+            cur = j;
+            cur_s = s;
+        }
+    }
+    return cur;
+}
+
+__global__ __launch_bounds__(256) void k_long_next(const int32_t *recs, uint32_t M, int32_t entry, int32_t limit,
+                                                   int32_t max_len, uint32_t *nxt, uint32_t *mark) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > M) return;
+    if (k == M) {
+        nxt[M] = M;
+        mark[M] = 0;
+        const uint32_t k0 = leftmost_longest_from(recs, M, upper_end(recs, 0, M, entry), entry, limit, max_len);
+        if (k0 < M) atomicExch(&mark[k0], 1u);
+        return;
+    }
+    const int32_t e = recs[3 * (uint64_t)k + 1];
+    nxt[k] = leftmost_longest_from(recs, M, upper_end(recs, k + 1, M, e), e, limit, max_len);
+}
+
 __global__ __launch_bounds__(256) void k_short_clear(uint32_t *mark, uint32_t M) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < M) mark[k] = 0;
@@ -111,6 +145,17 @@ hipError_t launch_shortest_select(const int32_t *d_recs, uint32_t M, int64_t ent
     const int32_t e32 = (int32_t)std::min<int64_t>(std::max<int64_t>(entry, 0), 0x7fffffff);
     hipLaunchKernelGGL(k_short_clear, grid, block, 0, stream, d_mark, M);
     hipLaunchKernelGGL(k_short_next, grid, block, 0, stream, d_recs, M, e32, d_nxt, d_mark);
+    return launch_chain_mark(d_nxt, d_tmp, d_mark, M, stream);
+}
+
+// Longest over the all-matches list: see k_long_next.  limit = own_end (matches must start before it).
+hipError_t launch_longest_select(const int32_t *d_recs, uint32_t M, int64_t entry, int64_t limit, uint32_t max_len,
+                                 uint32_t *d_nxt, uint32_t *d_tmp, uint32_t *d_mark, hipStream_t stream) {
+    if (M == 0) return hipSuccess;
+    const dim3 block(256), grid((M + 1 + 255) / 256);
+    hipLaunchKernelGGL(k_short_clear, grid, block, 0, stream, d_mark, M);
+    hipLaunchKernelGGL(k_long_next, grid, block, 0, stream, d_recs, M, (int32_t)std::min<int64_t>(entry, 0x7fffffff),
+                       (int32_t)std::min<int64_t>(limit, 0x7fffffff), (int32_t)max_len, d_nxt, d_mark);
     return launch_chain_mark(d_nxt, d_tmp, d_mark, M, stream);
 }
 

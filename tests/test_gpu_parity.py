@@ -937,3 +937,56 @@ def test_longest_walk_beyond_the_lds_rows_takes_the_global_table():
     assert got.shape == want.shape and (got == want).all()
     got_set = LongestMatchSet(kws, True).find_all(hay)
     assert (got_set == want[:, :2]).all()
+
+
+def test_longest_over_selective_dictionaries_is_a_selection_of_all_matches():
+    """Dictionaries with a selective suffix filter take the AhoCorasick tile pipeline + leftmost-longest selection
+    instead of the trie walk: same records, shards, streams; a haystack dense in matches falls back to the walk."""
+    import torch
+    kws = synth.random_keywords(81, 3000, 4, 9)
+    hay = synth.haystack(82, 400000)
+    for i in range(0, 4000):  # plant overlapping and nested keywords
+        k = kws[(i * 7) % len(kws)]
+        p = (i * 97) % (hay.size - 16)
+        hay[p:p + len(k)] = k
+    a = Automaton(N.MODE_LONGEST, kws, True)
+    assert a.info()["filter_k"] == 4 and a.info()["tile_kernel"] == 1
+    want = Oracle(FAM_LONGEST, kws).match(hay)
+    d_hay = torch.from_numpy(hay.view(np.int16)).cuda()
+    d_out = torch.empty((len(want) + 64, 3), dtype=torch.int32, device="cuda")
+
+    def dm(**kw):
+        n_out, rc, prof, ex = a.match_device(d_hay.data_ptr(), hay.size, True, d_out.data_ptr(), d_out.shape[0], **kw)
+        assert rc == N.OK
+        return d_out[:n_out].cpu().numpy(), prof, ex
+
+    got, prof, _ = dm(profile=True)
+    assert prof["scan_kernel"].startswith("k_ac_tile")
+    assert got.shape == want.shape and (got == want).all()
+    N.set_tunable("force_kernel", 1)  # the walk gives the same stream
+    got_w, prof_w, _ = dm(profile=True)
+    assert prof_w["scan_kernel"].startswith("k_longest_walk") and (got_w == want).all()
+    N.set_tunable("force_kernel", 0)
+    # shards chained through chain_entry/exit, and streams
+    cuts = [0, 100001, 100002, 250003, hay.size]
+    parts, entry = [], 0
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        p, _, ex = dm(own=(lo, hi), chain_entry=max(entry, lo))
+        parts.append(p)
+        assert ex >= hi
+        entry = ex
+    assert (np.concatenate(parts) == want).all()
+    got_s = _stream_all(a, hay, [1, 5, 7, 20000, 20001, 300000])
+    assert (got_s == want.astype(np.int64)).all()
+    # dense in matches: every 4-gram of the haystack is a keyword -> more records than the sparse path accepts -> the
+    # call falls back to the walk (the filter itself is still selective: 2 % of the 4-grams)
+    dense = np.concatenate([kws[i % len(kws)] for i in range(2000)]).astype(np.uint16)[:8003]
+    kws2 = list(kws) + [dense[i:i + 4] for i in range(0, 8000)]
+    a2 = Automaton(N.MODE_LONGEST, kws2, True)
+    assert a2.info()["tile_kernel"] == 1
+    want2 = Oracle(FAM_LONGEST, kws2).match(dense)
+    d2 = torch.from_numpy(dense.view(np.int16)).cuda()
+    o2 = torch.empty((len(want2) + 8, 3), dtype=torch.int32, device="cuda")
+    n2, rc2, prof2, _ = a2.match_device(d2.data_ptr(), dense.size, True, o2.data_ptr(), o2.shape[0], profile=True)
+    assert rc2 == N.OK and prof2["scan_kernel"].startswith("k_longest_walk")
+    assert n2 == len(want2) and (o2[:n2].cpu().numpy() == want2).all()
