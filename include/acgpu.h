@@ -112,7 +112,8 @@ typedef struct acgpu_info {
     uint32_t fold_consistent;/* WHOLEWORD: wordchar[c] == wordchar[lower[c]] for all c   */
     uint32_t filter_k;       /* ALL: length of the suffix K-gram filter, 0 = none          */
     uint32_t filter_bits;    /* ALL: size of the K-gram bitmap in bits                      */
-    uint32_t tile_kernel;    /* ALL: 1 if the position-parallel K-gram kernel will be used  */
+    uint32_t tile_kernel;    /* ALL/SHORTEST: 1 if the position-parallel K-gram kernel will be used (whenever the filter
+                                exists); LONGEST: 1 if the filter is selective (all-matches pipeline + selection) */
     float filter_density;    /* ALL: fraction of K-grams (over keyword units) that pass     */
 } acgpu_info;
 

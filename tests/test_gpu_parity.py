@@ -126,7 +126,10 @@ def test_kernel_selection_defaults():
     c2 = Automaton(N.MODE_ALL, synth.config_keywords("C2"), True).info()
     assert c2["filter_k"] == 4 and c2["tile_kernel"] == 1 and c2["filter_density"] < 0.05
     dense_dict = Automaton(N.MODE_ALL, ["a", "b", "ab"], True).info()
-    assert dense_dict["tile_kernel"] == 0  # every position passes a 1-gram filter: the DFA scan is the better kernel
+    assert dense_dict["tile_kernel"] == 1  # even a filter that passes every position beats the DFA chunk scan (measured)
+    assert Automaton(N.MODE_LONGEST, ["a", "b", "ab"], True).info()["tile_kernel"] == 0  # Longest: dense -> the walk
+    wide = Automaton(N.MODE_ALL, [chr(0x4E00 + i) + chr(0x4E01 + i) for i in range(200)], True).info()
+    assert wide["filter_k"] == 0 and wide["tile_kernel"] == 0  # more than 63 distinct units: no filter, DFA chunk scan
 
 
 def test_full_alphabet_dictionary_sparse():
