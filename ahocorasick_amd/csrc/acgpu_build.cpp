@@ -362,21 +362,38 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
     t.filt_k = 0;
     // (LONGEST: for dictionaries with a selective filter the matches are sparse, and leftmost-longest is a selection
     // over the all-matches list instead of a trie walk from every position)
-    if ((mode == ACGPU_MODE_ALL || mode == ACGPU_MODE_SHORTEST || mode == ACGPU_MODE_LONGEST) && t.n_cls > 1 && t.n_cls <= 64 &&
-        t.min_len >= 1) {
-        // tile classes: range mode -> min(unit - base, span) (other = span); LUT mode -> cls_lut (other = 0)
-        const uint32_t n = t.n_cls;
+    t.hashk = false;
+    t.tile_lut = t.cls_lut;
+    if ((mode == ACGPU_MODE_ALL || mode == ACGPU_MODE_SHORTEST || mode == ACGPU_MODE_LONGEST) && t.n_cls > 1 && t.min_len >= 1) {
+        // tile classes: range mode -> min(unit - base, span) (other = span); LUT mode -> tile_lut (other = 0)
+        std::vector<uint32_t> bucket_of; // hashk: folded unit -> bucket 1..63
+        if (t.n_cls > 64) {
+            // more than 63 distinct units: 63 buckets, filled round robin in order of decreasing frequency so that the
+            // buckets (and with them the class K-grams) are used evenly
+            t.hashk = true;
+            std::vector<uint32_t> freq(65536, 0);
+            for (uint32_t i = 1; i < N; i++) freq[nodes[i].unit]++;
+            std::vector<uint32_t> order;
+            for (uint32_t u = 0; u < 65536; u++) if (freq[u]) order.push_back(u);
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return freq[a] > freq[b]; });
+            bucket_of.assign(65536, 0);
+            for (size_t i = 0; i < order.size(); i++) bucket_of[order[i]] = 1 + (uint32_t)(i % 63);
+            t.tile_lut.assign(65536, 0);
+            for (uint32_t raw = 0; raw < 65536; raw++) t.tile_lut[raw] = (uint16_t)bucket_of[t.lower[raw]];
+        }
+        const uint32_t n = t.hashk ? 64 : t.n_cls;
         t.filt_n = n;
-        t.filt_other = t.range_cls ? t.cls_span : 0;
+        t.filt_other = (!t.hashk && t.range_cls) ? t.cls_span : 0;
         t.filt_row_bytes = n <= 32 ? 4 : 8;
         auto tcls = [&](uint16_t folded_unit) -> uint32_t {
+            if (t.hashk) return bucket_of[folded_unit];
             if (t.range_cls) return (uint32_t)folded_unit - t.cls_base; // only called on keyword units: inside the range
             return cls_of[folded_unit];
         };
         uint32_t K = 1;
         uint64_t rows = 1; // n^(K-1)
-        while (K < t.min_len && K < 8 && rows * n * t.filt_row_bytes <= (uint64_t)tunables().filter_max_bytes &&
-               rows * n * n < (1ull << 24)) {
+        while (K < t.min_len && K < (t.hashk ? 3u : 8u) && rows * n * t.filt_row_bytes <= (uint64_t)tunables().filter_max_bytes &&
+               rows * n * n <= (1ull << 24)) {
             rows *= n;
             K++;
         }
@@ -421,7 +438,8 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
                     return r;
                 };
                 for (uint32_t i = 0; i < RN; i++) t.rterm[i] = rn[i].kw;
-                t.rdense = (uint64_t)RN * n * 4 <= (uint64_t)tunables().rdense_budget_bytes && !tunables().force_sparse;
+                // (bucketed classes do not name a unit: only the hashed, unit-keyed edges are exact)
+                t.rdense = !t.hashk && (uint64_t)RN * n * 4 <= (uint64_t)tunables().rdense_budget_bytes && !tunables().force_sparse;
                 if (t.rdense) {
                     t.rtab.assign((size_t)RN * n, 0);
                     for (uint32_t i = 1; i < RN; i++) t.rtab[(size_t)rn[i].parent * n + tcls(rn[i].unit)] = ref(i);
@@ -444,7 +462,8 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
                 }
                 // rows of the filter and K-gram -> depth-K reverse node (index: last unit least significant)
                 t.filt_bits.assign(rows * (t.filt_row_bytes / 4), 0);
-                t.kgram_node.assign(rows * n * 2, 0); // pairs: {ref of the depth-K node, ref of its only child or 0}
+                if (!t.hashk) t.kgram_node.assign(rows * n * 2, 0); // pairs: {ref of the depth-K node, ref of its only child or 0}
+                std::vector<std::pair<uint64_t, uint32_t>> kg; // hashk: packed K units (text order) -> ref
                 uint64_t n_set = 0;
                 std::vector<uint32_t> path;
                 for (uint32_t i = 1; i < RN; i++) {
@@ -455,11 +474,33 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
                     uint64_t hi = 0;
                     for (size_t j = 0; j + 1 < path.size(); j++) hi = hi * n + path[j];
                     const uint32_t last = path.back();
-                    if (t.filt_row_bytes == 4) t.filt_bits[hi] |= 1u << last;
-                    else t.filt_bits[hi * 2 + (last >> 5)] |= 1u << (last & 31);
-                    t.kgram_node[(hi * n + last) * 2] = ref(i);
-                    t.kgram_node[(hi * n + last) * 2 + 1] = rn[i].n_child == 1 ? ref(rn[i].only_child) : 0u;
-                    n_set++;
+                    uint32_t *word = t.filt_row_bytes == 4 ? &t.filt_bits[hi] : &t.filt_bits[hi * 2 + (last >> 5)];
+                    const uint32_t bit = 1u << (last & 31);
+                    if (!(*word & bit)) n_set++; // (several K-grams of units can share one K-gram of buckets)
+                    *word |= bit;
+                    if (t.hashk) {
+                        uint64_t key = 0;
+                        // walking up from i meets text[e-K] first: text order, leftmost unit in the lowest 16 bits (K <= 3,
+                        // so a key never equals the all-ones empty marker)
+                        for (uint32_t p = i, sh = 0; p != 0; p = rn[p].parent, sh += 16) key |= (uint64_t)rn[p].unit << sh;
+                        kg.emplace_back(key, ref(i));
+                    } else {
+                        t.kgram_node[(hi * n + last) * 2] = ref(i);
+                        t.kgram_node[(hi * n + last) * 2 + 1] = rn[i].n_child == 1 ? ref(rn[i].only_child) : 0u;
+                    }
+                }
+                if (t.hashk) {
+                    uint64_t cap = 16;
+                    while (cap < 2 * (uint64_t)kg.size() + 2) cap <<= 1;
+                    t.kg_keys.assign(cap, kEmptyKey);
+                    t.kg_vals.assign(cap, 0);
+                    t.kg_mask = (uint32_t)(cap - 1);
+                    for (auto &kv : kg) {
+                        uint32_t slot = edge_hash(kv.first) & t.kg_mask;
+                        while (t.kg_keys[slot] != kEmptyKey) slot = (slot + 1) & t.kg_mask;
+                        t.kg_keys[slot] = kv.first;
+                        t.kg_vals[slot] = kv.second;
+                    }
                 }
                 double denom = 1;
                 for (uint32_t j = 0; j < K; j++) denom *= (double)(n > 1 ? n - 1 : 1);

@@ -98,6 +98,15 @@ struct HostTables {
     std::vector<uint32_t> rhvals;
     uint32_t rhmask = 0;
     uint32_t n_rstates = 0;
+    // Dictionaries with more than 63 distinct (folded) units: the tile classes are 63 BUCKETS of units (tile_lut), so the
+    // filter is a superset test and a class K-gram no longer names one K-gram of units.  The verification then looks the
+    // K units themselves up (kg_keys/kg_vals: packed folded units -> flagged ref of the depth-K reverse node, open
+    // addressing) and walks the reversed trie through its hashed, unit-keyed edges only.
+    bool hashk = false;
+    std::vector<uint16_t> tile_lut;    // 65536: raw unit -> tile class (== cls_lut when the classes are injective)
+    std::vector<uint64_t> kg_keys;
+    std::vector<uint32_t> kg_vals;
+    uint32_t kg_mask = 0;
     // ---- WholeWord: hash table of whole (folded) keywords + paged fold table ----
     // A maximal run of word characters matches iff its folded text IS a keyword, so the run is hashed once and looked
     // up: ww_slots = open-addressing table of {hash, record offset in 16-byte units} (kWwEmpty = free), linear probing
@@ -139,6 +148,11 @@ struct DevTables {
     const uint32_t *rhvals;
     uint32_t rhmask, filt_k, filt_n, filt_other, filt_words, filt_row_bytes;
     int32_t rdense;
+    int32_t hashk;             // 1: bucketed tile classes, K-gram looked up by its units (see HostTables)
+    const uint16_t *tile_lut;  // tile classes of the LUT mode (cls_lut, or the bucket table)
+    const uint64_t *kg_keys;
+    const uint32_t *kg_vals;
+    uint32_t kg_mask;
     // WholeWord word hash
     const uint32_t *ww_slots; // uint2 per slot
     const uint32_t *ww_recs;  // 16-byte aligned records

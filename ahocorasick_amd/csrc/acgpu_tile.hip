@@ -71,13 +71,13 @@ __device__ __forceinline__ uint4 stream_load(const uint16_t *p) {
 
 __device__ __forceinline__ uint32_t tile_class(const DevTables &T, uint32_t unit) {
     if (T.range_cls) return min(unit - T.cls_base, T.cls_span); // outside [base, base+span) -> span ("other")
-    return T.cls_lut[unit];
+    return T.tile_lut[unit];
 }
 
 template <bool RANGE>
 __device__ __forceinline__ uint32_t tile_class_t(const DevTables &T, uint32_t unit) {
     if (RANGE) return min(unit - T.cls_base, T.cls_span);
-    return T.cls_lut[unit];
+    return T.tile_lut[unit];
 }
 
 // flagged ref of the child of reverse-trie node `id` whose edge is `unit` (raw) / class `cls`, 0 = none
@@ -101,7 +101,9 @@ __device__ __forceinline__ uint32_t walk_step(const DevTables &T, uint32_t ref, 
 // Verification of up to kVerifyBatches*64 queued candidates: kVerifyBatches per lane, advanced in lock step so that
 // their dependent loads (text window -> K-gram node -> rare deeper steps) are in flight together.  Every lane of the
 // wave calls this.  Records carry the reversed-trie NODE id; the permute pass translates it to the keyword id.
-template <int K, bool RANGE>
+// HASHK: bucketed tile classes (dictionaries with more than 63 distinct units): the K units themselves, folded and packed
+// in text order, are looked up in kg_keys/kg_vals, and every step of the walk goes through the unit-keyed hashed edges.
+template <int K, bool RANGE, bool HASHK = false>
 __device__ __forceinline__ void verify_multi(TileCtx &c, uint32_t head, uint32_t n_cand) {
     constexpr int NB = kVerifyBatches;
     const DevTables &T = *c.Tp;
@@ -140,7 +142,29 @@ __device__ __forceinline__ void verify_multi(TileCtx &c, uint32_t head, uint32_t
         for (int j = 8 - K; j < 8; ++j) idx = __umul24(idx, T.filt_n) + tile_class_t<RANGE>(T, (win[b].d[j >> 1] >> (16 * (j & 1))) & 0xffffu);
         if (K < 8) left_unit[b] = (win[b].d[(7 - K) >> 1] >> (16 * ((7 - K) & 1))) & 0xffffu;
         uint2 ent = make_uint2(idx & 1u, 0u); // 16: ablation, no K-gram node load
-        if (!(L.debug & 16u)) ent = act[b] ? reinterpret_cast<const uint2 *>(T.kgram_node)[idx] : make_uint2(0u, 0u);
+        if (HASHK) {
+            ent = make_uint2(0u, 0u);
+            if (act[b]) {
+                uint64_t key = 0;
+#pragma unroll
+                for (int j = 8 - K; j < 8; ++j) {
+                    const uint32_t u = (win[b].d[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+                    key |= (uint64_t)(T.cs ? u : (uint32_t)T.lower[u]) << (16 * (j - (8 - K)));
+                }
+                uint32_t slot = edge_hash(key) & T.kg_mask;
+                for (;;) {
+                    const uint64_t kk = T.kg_keys[slot];
+                    if (kk == key) {
+                        ent.x = T.kg_vals[slot];
+                        break;
+                    }
+                    if (kk == kEmptyKey) break; // the buckets matched, the units do not
+                    slot = (slot + 1) & T.kg_mask;
+                }
+            }
+        } else if (!(L.debug & 16u)) {
+            ent = act[b] ? reinterpret_cast<const uint2 *>(T.kgram_node)[idx] : make_uint2(0u, 0u);
+        }
         if (!act[b]) ent = make_uint2(0u, 0u);
         ref[b] = ent.x;
         ref0[b] = ent.x;
@@ -167,7 +191,7 @@ __device__ __forceinline__ void verify_multi(TileCtx &c, uint32_t head, uint32_t
             if (go[b]) {
                 const uint32_t unit = (d[b] == K && K < 8) ? left_unit[b] : (uint32_t)hay[e[b] - 1 - d[b]];
                 const uint32_t hint = (ref[b] >> kRefHintShift) & kRefHintMask;
-                if (d[b] == K && hint != 0) // first step from a one-child node: no memory access at all
+                if (!HASHK && d[b] == K && hint != 0) // first step from a one-child node: no memory access at all
                     next = (hint - 1 == tile_class_t<RANGE>(T, unit)) ? child0[b] : 0u;
                 else
                     next = walk_step<RANGE>(T, ref[b], unit);
@@ -218,12 +242,12 @@ __device__ __forceinline__ void verify_multi(TileCtx &c, uint32_t head, uint32_t
 }
 
 // drain the candidate queue down to fewer than `keep_below` entries
-template <int K, bool RANGE>
+template <int K, bool RANGE, bool HASHK>
 __device__ __forceinline__ void drain(TileCtx &c, uint32_t keep_below) {
     uint32_t head = 0;
     while (c.cand_n > head && c.cand_n - head >= keep_below) {
         const uint32_t nb = min(c.cand_n - head, (uint32_t)(kVerifyBatches * kWave));
-        if (!(c.Lp->debug & 1u)) verify_multi<K, RANGE>(c, head, nb);
+        if (!(c.Lp->debug & 1u)) verify_multi<K, RANGE, HASHK>(c, head, nb);
         head += nb;
     }
     if (head) { // move the leftovers (fewer than kVerifyBatches*64) to the front
@@ -264,7 +288,7 @@ __device__ __forceinline__ uint32_t roll_row(uint32_t hs, uint32_t n, uint32_t c
 // SPLIT: the filter-only form.  Nothing is verified here: the candidates of the wave's span go, in text order, to the
 // wave's slice of L.d_cands (the "queue" is that slice and is never drained), with a {first index, count} pair per
 // region for k_ac_verify.  No LDS besides the filter rows.
-template <int K, bool RANGE, bool WIDE, bool SPLIT>
+template <int K, bool RANGE, bool WIDE, bool SPLIT, bool HASHK = false>
 __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch L) {
     // the filter rows are STATIC LDS (offset 0, so a scaled row index is the ds_read address with nothing to add);
     // the candidate queues are the dynamic part behind it
@@ -348,7 +372,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
 #pragma unroll
                 for (int u = 0; u < kAcVec; ++u) grp[d][u] = nxt[d][u];
         }
-        if (!SPLIT && c.cand_n >= keep && c.cand_n != 0) drain<K, RANGE>(c, keep);
+        if (!SPLIT && c.cand_n >= keep && c.cand_n != 0) drain<K, RANGE, HASHK>(c, keep);
 
         if (vec_todo) {
             if (d0 == 0) {
@@ -500,7 +524,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
 
 // The verification half of the split form: one region per wave (grid-stride), its candidates read from L.d_cands in
 // batches of kVerifyBatches*64, records ranked inside the region exactly as the fused kernel ranks them.
-template <int K, bool RANGE>
+template <int K, bool RANGE, bool HASHK = false>
 __global__ __launch_bounds__(256) void k_ac_verify(DevTables T, TileLaunch L) {
     const uint32_t lane = lane_id();
     const uint32_t waves = gridDim.x * (blockDim.x / kWave);
@@ -513,7 +537,7 @@ __global__ __launch_bounds__(256) void k_ac_verify(DevTables T, TileLaunch L) {
         c.cand_n = rc.y;
         c.rank_base = 0;
         for (uint32_t head = 0; head < rc.y; head += kVerifyBatches * kWave)
-            verify_multi<K, RANGE>(c, head, min(rc.y - head, (uint32_t)(kVerifyBatches * kWave)));
+            verify_multi<K, RANGE, HASHK>(c, head, min(rc.y - head, (uint32_t)(kVerifyBatches * kWave)));
         if (lane == 0) L.d_region_counts[region] = c.rank_base;
     }
     for (uint32_t i = lane; i < c.res_left; i += kWave) store_rec(L, c.res_cur + i, 0, 0, 0, ~0u);
@@ -548,6 +572,20 @@ static hipError_t launch_verify_k(const DevTables &t, const TileLaunch &l, hipSt
     return hipGetLastError();
 }
 
+// bucketed classes: LUT classes, 8-byte rows, K <= 3
+template <int K, bool SPLIT>
+static hipError_t launch_tile_hashk(const DevTables &t, const TileLaunch &l, hipStream_t stream) {
+    if (!SPLIT) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ac_tile<K, false, true, false, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_ac_tile<K, false, true, false, true>), dim3(l.grid), dim3(l.block), l.lds_bytes, stream, t, l);
+    } else {
+        hipLaunchKernelGGL((k_ac_tile<K, false, true, true, true>), dim3(l.grid), dim3(l.block), 0, stream, t, l);
+    }
+    return hipGetLastError();
+}
+
 template <int K>
 static hipError_t launch_tile_k(const DevTables &t, const TileLaunch &l, hipStream_t stream) {
     const bool wide = t.filt_row_bytes == 8;
@@ -561,6 +599,15 @@ hipError_t launch_ac_tile(const DevTables &t, const TileLaunch &l, hipStream_t s
     std::snprintf(name, sizeof(name), "k_ac_tile<%u, %s, %s, false>", t.filt_k, t.range_cls ? "true" : "false",
                   t.filt_row_bytes == 8 ? "true" : "false");
     if (kernel_name) *kernel_name = name;
+    if (t.hashk) {
+        std::snprintf(name, sizeof(name), "k_ac_tile<%u, false, true, false, true>", t.filt_k);
+        switch (t.filt_k) {
+        case 1: return launch_tile_hashk<1, false>(t, l, stream);
+        case 2: return launch_tile_hashk<2, false>(t, l, stream);
+        case 3: return launch_tile_hashk<3, false>(t, l, stream);
+        default: return hipErrorInvalidValue;
+        }
+    }
     switch (t.filt_k) {
     case 1: return launch_tile_k<1>(t, l, stream);
     case 2: return launch_tile_k<2>(t, l, stream);
@@ -580,6 +627,15 @@ hipError_t launch_ac_filter(const DevTables &t, const TileLaunch &l, hipStream_t
     std::snprintf(name, sizeof(name), "k_ac_tile<%u, %s, %s, true>", t.filt_k, t.range_cls ? "true" : "false",
                   t.filt_row_bytes == 8 ? "true" : "false");
     if (kernel_name) *kernel_name = name;
+    if (t.hashk) {
+        std::snprintf(name, sizeof(name), "k_ac_tile<%u, false, true, true, true>", t.filt_k);
+        switch (t.filt_k) {
+        case 1: return launch_tile_hashk<1, true>(t, l, stream);
+        case 2: return launch_tile_hashk<2, true>(t, l, stream);
+        case 3: return launch_tile_hashk<3, true>(t, l, stream);
+        default: return hipErrorInvalidValue;
+        }
+    }
     switch (t.filt_k) {
     case 1: return launch_filter_k<1>(t, l, stream);
     case 2: return launch_filter_k<2>(t, l, stream);
@@ -594,6 +650,15 @@ hipError_t launch_ac_filter(const DevTables &t, const TileLaunch &l, hipStream_t
 }
 
 hipError_t launch_ac_verify(const DevTables &t, const TileLaunch &l, hipStream_t stream) {
+    if (t.hashk) {
+        switch (t.filt_k) {
+        case 1: hipLaunchKernelGGL((k_ac_verify<1, false, true>), dim3(l.verify_grid), dim3(256), 0, stream, t, l); break;
+        case 2: hipLaunchKernelGGL((k_ac_verify<2, false, true>), dim3(l.verify_grid), dim3(256), 0, stream, t, l); break;
+        case 3: hipLaunchKernelGGL((k_ac_verify<3, false, true>), dim3(l.verify_grid), dim3(256), 0, stream, t, l); break;
+        default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     switch (t.filt_k) {
     case 1: return launch_verify_k<1>(t, l, stream);
     case 2: return launch_verify_k<2>(t, l, stream);

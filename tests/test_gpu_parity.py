@@ -129,7 +129,7 @@ def test_kernel_selection_defaults():
     assert dense_dict["tile_kernel"] == 1  # even a filter that passes every position beats the DFA chunk scan (measured)
     assert Automaton(N.MODE_LONGEST, ["a", "b", "ab"], True).info()["tile_kernel"] == 0  # Longest: dense -> the walk
     wide = Automaton(N.MODE_ALL, [chr(0x4E00 + i) + chr(0x4E01 + i) for i in range(200)], True).info()
-    assert wide["filter_k"] == 0 and wide["tile_kernel"] == 0  # more than 63 distinct units: no filter, DFA chunk scan
+    assert wide["filter_k"] == 2 and wide["tile_kernel"] == 1  # more than 63 distinct units: bucketed classes, exact K-gram lookup
 
 
 def test_full_alphabet_dictionary_sparse():
@@ -993,3 +993,34 @@ def test_longest_over_selective_dictionaries_is_a_selection_of_all_matches():
     n2, rc2, prof2, _ = a2.match_device(d2.data_ptr(), dense.size, True, o2.data_ptr(), o2.shape[0], profile=True)
     assert rc2 == N.OK and prof2["scan_kernel"].startswith("k_longest_walk")
     assert n2 == len(want2) and (o2[:n2].cpu().numpy() == want2).all()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_large_alphabets_bucketed_classes(seed, ac_kernel):
+    """More than 63 distinct keyword units (CJK, mixed scripts): the tile classes are 63 buckets, the filter a superset
+    test, the K-gram looked up by its units.  Units that share a bucket, case folding, near misses."""
+    rng = np.random.default_rng(900 + seed)
+    alpha = np.concatenate([np.arange(0x4E00, 0x4E00 + 400), np.arange(0x0391, 0x03AA), np.arange(0x03B1, 0x03CA),
+                            np.arange(ord("a"), ord("z") + 1), np.arange(ord("A"), ord("Z") + 1)]).astype(np.uint16)
+    kws = [alpha[rng.integers(0, len(alpha), int(rng.integers(1 + seed % 3, 9)))] for _ in range(1500)]
+    parts = []
+    for _ in range(20000):
+        mode = int(rng.integers(0, 4))
+        k = kws[int(rng.integers(0, len(kws)))].copy()
+        if mode == 0:
+            parts.append(alpha[rng.integers(0, len(alpha), int(rng.integers(1, 6)))])
+        elif mode == 1 and len(k) > 1:
+            k[int(rng.integers(0, len(k)))] = alpha[int(rng.integers(0, len(alpha)))]  # near miss (often the same bucket)
+            parts.append(k)
+        else:
+            parts.append(k)
+    hay = np.concatenate(parts).astype(np.uint16)
+    for cs in (True, False):
+        a = Automaton(N.MODE_ALL, kws, cs)
+        assert a.info()["n_classes"] > 64 and a.info()["filter_k"] >= 1
+        want = Oracle(FAM_AC, kws, case_sensitive=cs, lower=LOWER).match(hay)
+        got = a.match_host(hay, True, cap=64)
+        assert got.shape == want.shape and (got == want).all(), (seed, cs)
+    from oracle.oracle import FAM_SHORTEST
+    assert (Automaton(N.MODE_SHORTEST, kws, False).match_host(hay, True) ==
+            Oracle(FAM_SHORTEST, kws, case_sensitive=False, lower=LOWER).match(hay)).all()
