@@ -172,6 +172,11 @@ int ensure_device(acgpu_automaton *a, DeviceState **out) {
     }
     if ((rc = upload(*d, t.filt_bits, &T.filt_bits))) return rc;
     if ((rc = upload(*d, t.kgram_node, &T.kgram_node))) return rc;
+    T.l2_bloom = nullptr; T.l2_depth = 0;
+    if (t.l2_depth) {
+        if ((rc = upload(*d, t.l2_bloom, &T.l2_bloom))) return rc;
+        T.l2_depth = t.l2_depth;
+    }
     if ((rc = upload(*d, t.rterm, &T.rterm))) return rc;
     if ((rc = upload(*d, t.rtab, &T.rtab))) return rc;
     T.rdense = t.rdense;

@@ -489,6 +489,26 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
                         t.kgram_node[(hi * n + last) * 2 + 1] = rn[i].n_child == 1 ? ref(rn[i].only_child) : 0u;
                     }
                 }
+                // second-level filter (range classes below 32, K <= 5): every reverse node of depth D, and every terminal
+                // node of a depth in [K, D), is a key
+                t.l2_depth = 0;
+                t.l2_bloom.clear();
+                if (!t.hashk && t.range_cls && n <= 32 && K >= 2 && K <= 5) {
+                    const uint32_t D = std::min<uint32_t>(K + 2, 6);
+                    t.l2_bloom.assign(kL2Words, 0);
+                    for (uint32_t i = 1; i < RN; i++) {
+                        const uint32_t L = rn[i].depth;
+                        if (L < K || L > D || (L < D && rn[i].kw == ~0u)) continue;
+                        uint32_t packed = 0;
+                        for (uint32_t p = i; p != 0; p = rn[p].parent) packed |= tcls(rn[p].unit) << (5u * (rn[p].depth - 1));
+                        const uint32_t h = l2_hash(packed, K);
+                        t.l2_bloom[l2_word(h)] |= l2_bits(h, packed, L, K);
+                    }
+                    uint64_t set = 0;
+                    for (uint32_t w : t.l2_bloom) set += (uint64_t)__builtin_popcount(w);
+                    t.l2_density = (double)set / (32.0 * kL2Words);
+                    t.l2_depth = D;
+                }
                 if (t.hashk) {
                     uint64_t cap = 16;
                     while (cap < 2 * (uint64_t)kg.size() + 2) cap <<= 1;

@@ -47,6 +47,26 @@ ACGPU_HD inline uint32_t ww_hash_home(uint32_t h, uint32_t mask) { return h & ma
 ACGPU_HD inline uint32_t ww_bloom_bit1(uint32_t h, uint32_t mask) { return (h >> 7) & mask; }
 ACGPU_HD inline uint32_t ww_bloom_bit2(uint32_t h, uint32_t mask) { return ((h >> 19) | (h << 13)) & mask; }
 
+// Second-level filter of the tile kernel (L2): a blocked Bloom filter, in LDS, over the class sequence of the last
+// D = min(K+2, 6) units of every keyword (keywords shorter than D: their whole class sequence, under their length), so
+// that a position that passed the K-gram filter is only handed to the gather-bound verification when its last D units
+// still look like a keyword.  `packed` = classes 5 bits each, text[e-1] lowest.  The WORD is chosen by the K-gram alone
+// (one LDS read per candidate); a key of length L in [K, D] sets / tests two bits of it that depend on L and on the
+// L-K units in front of the K-gram.  Full-rate 24-bit multiplies only.  Identical on host and device.
+constexpr uint32_t kL2Words = 6144; // 24 KiB of LDS
+ACGPU_HD inline uint32_t l2_mul24(uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); } // v_mul_u32_u24
+ACGPU_HD inline uint32_t l2_hash(uint32_t packed, uint32_t K) { // of the K-gram (K <= 5: below 2^25, folded to 24 bits)
+    const uint32_t g = packed & ((1u << (5u * K)) - 1u);
+    return l2_mul24(g ^ (g >> 13), 0x9E3779u);
+}
+ACGPU_HD inline uint32_t l2_word(uint32_t h) { return (((h >> 11) & 0x1fffu) * kL2Words) >> 13; }
+ACGPU_HD inline uint32_t l2_bits(uint32_t h, uint32_t packed, uint32_t L, uint32_t K) {
+    // the units in front of the K-gram (none for L == K) and the length, mixed with hash bits the word index does not use
+    const uint32_t ctx = ((packed >> (5u * K)) & ((1u << (5u * (L - K))) - 1u)) | (1u << (5u * (L - K)));
+    const uint32_t x = l2_mul24((h >> 8) ^ (ctx * 0x2545u), 0xC2B2AFu);
+    return (1u << ((x >> 19) & 31u)) | (1u << ((x >> 14) & 31u));
+}
+
 // Host-side automaton tables.  State numbering: root = 0; states WITHOUT any output (own or inherited
 // keyword) come first in BFS order, states WITH output after them in BFS order, so that
 // "state >= first_out" is the has-output test and a prefix of the numbering is the shallow, hot part.
@@ -102,6 +122,10 @@ struct HostTables {
     // filter is a superset test and a class K-gram no longer names one K-gram of units.  The verification then looks the
     // K units themselves up (kg_keys/kg_vals: packed folded units -> flagged ref of the depth-K reverse node, open
     // addressing) and walks the reversed trie through its hashed, unit-keyed edges only.
+    // second-level (Bloom) filter of the tile kernel: see l2_key; l2_depth = D, 0 = not built
+    uint32_t l2_depth = 0;
+    std::vector<uint32_t> l2_bloom; // kL2Words
+    double l2_density = 0;          // fraction of set bits
     bool hashk = false;
     std::vector<uint16_t> tile_lut;    // 65536: raw unit -> tile class (== cls_lut when the classes are injective)
     std::vector<uint64_t> kg_keys;
@@ -149,6 +173,8 @@ struct DevTables {
     uint32_t rhmask, filt_k, filt_n, filt_other, filt_words, filt_row_bytes;
     int32_t rdense;
     int32_t hashk;             // 1: bucketed tile classes, K-gram looked up by its units (see HostTables)
+    const uint32_t *l2_bloom;  // second-level filter (kL2Words words) or nullptr
+    uint32_t l2_depth;
     const uint16_t *tile_lut;  // tile classes of the LUT mode (cls_lut, or the bucket table)
     const uint64_t *kg_keys;
     const uint32_t *kg_vals;

@@ -48,11 +48,21 @@ constexpr int kFilterWordsMax = ACGPU_FILTER_WORDS; // 88064 bytes of static LDS
 constexpr int kFilterWordsSplit = 20224; // the filter-only kernel: 79 KiB, so that two workgroups fit one CU's 160 KiB
 bool tile_split_supported(const DevTables &t) { return t.filt_k >= 1 && t.filt_words <= (uint32_t)kFilterWordsSplit; }
 
+// L2 form (second-level filter in LDS, see l2_key in acgpu_internal.h): smaller static array for the rows, and per wave a
+// queue of SURVIVORS (kL2Cap), a copy of the current tile as packed classes behind an 8-unit halo (kTbBytes) and the list
+// of the tile's first-level candidates (kL2Fresh tile-relative positions); the Bloom words follow
+constexpr int kFilterWordsL2 = 19712;  // 78848 bytes: 27 classes, K = 4
+constexpr int kL2Cap = 320;
+constexpr int kL2Fresh = 128;
+constexpr int kTbBytes = 16 + kAcTileUnits * 2;
+constexpr size_t kL2WaveBytes = kL2Cap * 4 + kTbBytes + kL2Fresh * 2;
+
 // dynamic LDS only: the candidate queues
 size_t tile_lds_bytes(const DevTables &t, int block_threads) {
     (void)t;
     return (size_t)(block_threads / kWave) * kAcCandCap * sizeof(uint32_t);
 }
+size_t tile_l2_lds_bytes(int block_threads) { return (size_t)(block_threads / kWave) * kL2WaveBytes + kL2Words * 4; }
 
 struct __attribute__((packed, aligned(2))) Units8 { // 8 UTF-16 units at any unit address (one global_load_dwordx4)
     uint32_t d[4];
@@ -280,6 +290,23 @@ __device__ __forceinline__ uint32_t roll_row(uint32_t hs, uint32_t n, uint32_t c
     return r;
 }
 
+
+// Packed 16-bit filter arithmetic (PK form of the filter): two units per register all the way.
+//   classes  : min(unit - base, span) for both halves            v_pk_sub_u16 + v_pk_min_u16   (2 ops per 2 units)
+//   row index: Horner over the (K-1)-gram, both positions at once  v_pk_mad_u16                 (K-2 ops per 2 positions)
+// (usable when the row index n^(K-1) fits 16 bits; every intermediate is exact modulo 2^16)
+__device__ __forceinline__ uint32_t pk_class(uint32_t units2, uint32_t base2, uint32_t span2) {
+    uint32_t t, r;
+    asm("v_pk_sub_u16 %0, %1, %2" : "=v"(t) : "v"(units2), "s"(base2));
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(t), "s"(span2));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t n2, uint32_t c) {
+    uint32_t r;
+    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(n2), "v"(c));
+    return r;
+}
+
 // A wave owns a contiguous SPAN of regions.  Region boundaries sit at base8 + r * region_units (base8 = own_begin
 // rounded down to 8 units, region_units a multiple of the 2048-unit tile group), so a tile group never straddles two
 // regions and the tile stream -- with its double-buffered register groups and the cross-lane carry -- runs through the
@@ -288,21 +315,29 @@ __device__ __forceinline__ uint32_t roll_row(uint32_t hs, uint32_t n, uint32_t c
 // SPLIT: the filter-only form.  Nothing is verified here: the candidates of the wave's span go, in text order, to the
 // wave's slice of L.d_cands (the "queue" is that slice and is never drained), with a {first index, count} pair per
 // region for k_ac_verify.  No LDS besides the filter rows.
-template <int K, bool RANGE, bool WIDE, bool SPLIT, bool HASHK = false>
+template <int K, bool RANGE, bool WIDE, bool SPLIT, bool HASHK = false, bool PK = false, bool L2 = false>
 __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch L) {
     // the filter rows are STATIC LDS (offset 0, so a scaled row index is the ds_read address with nothing to add);
     // the candidate queues are the dynamic part behind it
-    __shared__ __attribute__((aligned(16))) uint32_t rows32[SPLIT ? kFilterWordsSplit : kFilterWordsMax];
+    __shared__ __attribute__((aligned(16))) uint32_t rows32[SPLIT ? kFilterWordsSplit : (L2 ? kFilterWordsL2 : kFilterWordsMax)];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned char *rows8 = reinterpret_cast<const unsigned char *>(rows32);
     uint32_t *cand_all = reinterpret_cast<uint32_t *>(smem);
     for (uint32_t i = threadIdx.x; i < T.filt_words; i += blockDim.x) rows32[i] = T.filt_bits[i];
+    constexpr int D2 = K + 2 < 6 ? K + 2 : 6; // depth of the second-level filter
+    constexpr uint32_t kQueueCap = L2 ? kL2Cap : kAcCandCap;
+    const uint32_t wave_in_block = threadIdx.x / kWave;
+    // L2: [queues][tile buffers][fresh lists][Bloom words]
+    unsigned char *tb = smem + (kTileBlock / kWave) * kL2Cap * 4 + wave_in_block * kTbBytes;
+    uint16_t *fresh = reinterpret_cast<uint16_t *>(smem + (kTileBlock / kWave) * (kL2Cap * 4 + kTbBytes)) + wave_in_block * kL2Fresh;
+    uint32_t *bloom = reinterpret_cast<uint32_t *>(smem + (kTileBlock / kWave) * kL2WaveBytes);
+    if (L2) for (uint32_t i = threadIdx.x; i < kL2Words; i += blockDim.x) bloom[i] = T.l2_bloom[i];
     __syncthreads();
 
     const uint32_t lane = lane_id();
-    const uint32_t wave_in_block = threadIdx.x / kWave;
     const uint32_t wave_global = blockIdx.x * (kTileBlock / kWave) + wave_in_block;
-    TileCtx c{&T, &L, SPLIT ? L.d_cands + (size_t)wave_global * L.cands_per_wave : cand_all + wave_in_block * kAcCandCap, 0, 0, 0u, 0};
+    TileCtx c{&T, &L, SPLIT ? L.d_cands + (size_t)wave_global * L.cands_per_wave : cand_all + wave_in_block * kQueueCap, 0, 0, 0u, 0};
+    uint32_t lane0 = 0; // L2: lanes below it have been enqueued already (a dense tile taken in pieces); wave-uniform
     const uint32_t slice_base = SPLIT ? wave_global * L.cands_per_wave : 0u; // (< 2^32: the host sizes the slices)
     uint32_t region_first = 0; // SPLIT: index (inside the slice) of the current region's first candidate
 
@@ -312,7 +347,8 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
 #pragma unroll
     for (int i = 0; i < K - 1; ++i) nK1s *= n;
     const int neg_nK1s = -(int)nK1s;
-    constexpr int NP = K / 2; // dwords of the previous 8 units that hold the K-1 units before the lane's first one
+    // dwords of the previous 8 units that hold the K-1 (L2: D2-1) units before the lane's first one
+    constexpr int NP = L2 ? D2 / 2 : K / 2;
 
     const uint32_t first_region = wave_global * L.regions_per_wave;
     if (first_region >= L.n_regions) return; // wave-uniform
@@ -338,6 +374,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
     bool vec_todo = tile < hi;          // tile groups left in the vector part of the span
     bool tail_todo = span_end > nfull;  // the units behind the last full vector of the buffer (fewer than 8)
     uint32_t d0 = 0;                    // tile of the current group to resume at (after a mid-group drain)
+    bool mid = false;                   // the current group is being resumed (its registers are live, its loads are out)
     uint32_t carry[4] = {0, 0, 0, 0};
     uint4 nxt[kAcTiles][kAcVec], grp[kAcTiles][kAcVec];
 #pragma unroll
@@ -362,9 +399,9 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
     // (completely at a region seam / before the tail / at the end; down to < 256 otherwise), then does one unit of
     // streaming work.  Keeping the (large) verification code in a single place keeps the kernel small.
     for (;;) {
-        const bool seam = vec_todo ? (d0 == 0 && tile >= boundary) : true; // wave-uniform
+        const bool seam = vec_todo ? (!mid && tile >= boundary) : true; // wave-uniform
         const uint32_t keep = SPLIT ? ~0u : (seam ? 1u : (uint32_t)(kVerifyBatches * kWave));
-        if (vec_todo && d0 == 0) {
+        if (vec_todo && !mid) {
             // take over the prefetched group FIRST: this wait also covers the record stores of the previous pass's
             // verification (gfx950 counts stores in vmcnt), which have had a whole tile group of time to finish
 #pragma unroll
@@ -375,7 +412,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
         if (!SPLIT && c.cand_n >= keep && c.cand_n != 0) drain<K, RANGE, HASHK>(c, keep);
 
         if (vec_todo) {
-            if (d0 == 0) {
+            if (!mid) {
                 if (tile >= boundary) { // the stream enters the next region (regions hold whole tile groups)
                     if (SPLIT) {
                         if (lane == 0) L.d_region_cands[region] = make_uint2(slice_base + region_first, c.cand_n - region_first);
@@ -412,11 +449,14 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                         if (lane == 0) atomicOr(L.d_overflow, 1u);
                         return; // wave-uniform; the host redoes the call with the fused kernel
                     }
-                } else if (c.cand_n > kAcCandCap - kAcTileUnits) { // rare: the queue cannot take a worst-case tile -> drain first
+                } else if (!L2 && c.cand_n > kAcCandCap - kAcTileUnits) { // rare: the queue cannot take a worst-case tile -> drain first
                     d0 = d;
                     resume = true;
                     break;
                 }
+                uint32_t carry_in[4]; // L2 decides after the filter whether the tile fits the queue: a redo starts from here
+#pragma unroll
+                for (int q = 0; q < 4; ++q) carry_in[q] = carry[q];
                 const uint32_t v = cur + lane * kAcLaneUnits;
                 uint32_t ww[4 * kAcVec];
 #pragma unroll
@@ -438,6 +478,47 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
 #pragma unroll
                     for (int q = 0; q < 4 * kAcVec; ++q) x ^= ww[q];
                     mask = (x == 0x12345678u) ? 1u : 0u;
+                } else if (PK) {
+                    // dword D of the 8 previous units (D < 4) and of the lane's own units (D >= 4) as packed classes;
+                    // MM[D] = the pair of units (2D-1, 2D), i.e. the misaligned neighbour of CC[D]
+                    constexpr int ND = 4 + 4 * kAcVec;
+                    const uint32_t base2 = T.cls_base * 0x10001u, span2 = T.cls_span * 0x10001u, n2 = n * 0x10001u;
+                    uint32_t CC[ND], MM[ND];
+#pragma unroll
+                    for (int D = 4 - NP; D < 4; ++D) CC[D] = pk_class(pp[D], base2, span2);
+#pragma unroll
+                    for (int D = 4; D < ND; ++D) CC[D] = pk_class(ww[D - 4], base2, span2);
+#pragma unroll
+                    for (int D = 4 - NP + 1; D < ND; ++D) MM[D] = __builtin_amdgcn_alignbit(CC[D], CC[D - 1], 16);
+                    uint32_t acc = 0;
+#pragma unroll
+                    for (int D = 4; D < ND; ++D) {
+                        // positions 2D (low half) and 2D+1 (high half): row = the K-1 units before, bit = own class
+                        const int S0 = 2 * D - (K - 1); // first unit of the low position's (K-1)-gram
+                        uint32_t H = (S0 & 1) ? MM[(S0 + 1) / 2] : CC[S0 / 2];
+#pragma unroll
+                        for (int t = 1; t < K - 1; ++t) {
+                            const int S = S0 + t;
+                            H = pk_mad(H, n2, (S & 1) ? MM[(S + 1) / 2] : CC[S / 2]);
+                        }
+                        const uint32_t row_lo = rows32[H & 0xffffu];
+                        const uint32_t row_hi = rows32[H >> 16];
+                        acc = __builtin_amdgcn_alignbit(row_lo >> (CC[D] & 31u), acc, 1);
+                        acc = __builtin_amdgcn_alignbit(row_hi >> ((CC[D] >> 16) & 31u), acc, 1);
+                    }
+                    mask = acc >> (32 - kAcLaneUnits);
+                    if (L2) { // the tile as packed classes, behind the classes of the 8 units before it
+                        uint4 *dst = reinterpret_cast<uint4 *>(tb + 16 + lane * (kAcLaneUnits * 2));
+#pragma unroll
+                        for (int u = 0; u < kAcVec; ++u) dst[u] = make_uint4(CC[4 + 4 * u], CC[5 + 4 * u], CC[6 + 4 * u], CC[7 + 4 * u]);
+                        if (lane == 0)
+                            *reinterpret_cast<uint4 *>(tb) = make_uint4(NP >= 4 ? CC[0] : 0u, NP >= 3 ? CC[1] : 0u, NP >= 2 ? CC[2] : 0u, CC[3]);
+                    }
+                    if (edge) {
+                        const uint32_t first = lo > v ? min(lo - v, (uint32_t)kAcLaneUnits) : 0u;
+                        const uint32_t last = top > v ? min(top - v, (uint32_t)kAcLaneUnits) : 0u;
+                        mask &= ((1u << last) - 1u) & ~((1u << first) - 1u);
+                    }
                 } else {
                     // classes of units v-(K-1) .. v+kAcLaneUnits-1
                     uint32_t a[kAcLaneUnits + K - 1];
@@ -473,8 +554,86 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                         mask &= ((1u << last) - 1u) & ~((1u << first) - 1u);
                     }
                 }
-                enqueue(c, mask, v);
+                if (L.debug & 512u) mask &= 0x0101u << (lane & 7u); // ablation: one candidate in eight survives (timing only)
+                if (!L2) {
+                    enqueue(c, mask, v);
+                    continue;
+                }
+                // ---- second-level filter: only candidates whose last D2 units still look like a keyword are queued ----
+                if (lane < lane0) mask = 0;
+                const uint32_t cnt = __popc(mask);
+                const uint32_t incl = wave_inclusive_scan_dpp(cnt);
+                const uint32_t total = __builtin_amdgcn_readlane(incl, kWave - 1);
+                if (total == 0) {
+                    lane0 = 0;
+                    continue;
+                }
+                if (total <= (uint32_t)kL2Fresh && c.cand_n + total <= (uint32_t)kL2Cap) {
+                    uint32_t slot = incl - cnt, m = mask;
+                    while (__any(m != 0)) { // tile-relative positions, text order
+                        if (m != 0) {
+                            fresh[slot++] = (uint16_t)(lane * kAcLaneUnits + (uint32_t)__builtin_ctz(m));
+                            m &= m - 1;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    typedef uint16_t __attribute__((may_alias)) u16a; // (written as uint4)
+                    const u16a *tb16 = reinterpret_cast<const u16a *>(tb) + 8; // tb16[p] = class of the tile's unit p
+                    for (uint32_t b = 0; b < total; b += kWave) {
+                        const uint32_t k = b + lane;
+                        const bool act = k < total;
+                        const uint32_t p = act ? (uint32_t)fresh[k] : 0u;
+                        uint32_t packed = 0;
+#pragma unroll
+                        for (int j = 0; j < D2; ++j) packed |= (uint32_t)tb16[(int)p - j] << (5 * j);
+                        bool pass = false;
+                        const uint32_t h = l2_hash(packed, K);
+                        const uint32_t word = bloom[l2_word(h)];
+#pragma unroll
+                        for (int len = K; len <= D2; ++len) {
+                            const uint32_t bits = l2_bits(h, packed, len, K);
+                            pass |= (word & bits) == bits;
+                        }
+                        pass = (pass || (L.debug & 4096u)) && act; // 4096: ablation, the second level passes everything
+                        const uint64_t bal = __ballot(pass);
+                        if (pass) c.cand[c.cand_n + (uint32_t)__popcll(bal & lanemask_lt())] = cur + p;
+                        c.cand_n += (uint32_t)__popcll(bal);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    lane0 = 0;
+                    continue;
+                }
+                if (c.cand_n >= (uint32_t)(kVerifyBatches * kWave)) { // make room first (drain at the loop top), then redo the tile
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) carry[q] = carry_in[q];
+                    d0 = d;
+                    resume = true;
+                    break;
+                }
+                { // dense tile: no second level; as many whole lanes as fit go straight to the queue, the rest after a drain
+                    const uint32_t room = (uint32_t)kL2Cap - c.cand_n; // > 16: a lane holds at most 16 candidates
+                    const uint32_t nl = (uint32_t)__popcll(__ballot(incl <= room)); // incl is monotone: lanes [0, nl) fit
+                    uint32_t slot = c.cand_n + incl - cnt, m = lane < nl ? mask : 0u;
+                    while (__any(m != 0)) {
+                        if (m != 0) {
+                            c.cand[slot++] = v + (uint32_t)__builtin_ctz(m);
+                            m &= m - 1;
+                        }
+                    }
+                    c.cand_n += __builtin_amdgcn_readlane(incl, nl - 1);
+                    __builtin_amdgcn_wave_barrier();
+                    if (nl < (uint32_t)kWave) {
+                        lane0 = nl;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) carry[q] = carry_in[q];
+                        d0 = d;
+                        resume = true;
+                        break;
+                    }
+                    lane0 = 0;
+                }
             }
+            mid = resume;
             if (!resume) {
                 d0 = 0;
                 tile += kAcTiles * kAcTileUnits;
@@ -586,6 +745,39 @@ static hipError_t launch_tile_hashk(const DevTables &t, const TileLaunch &l, hip
     return hipGetLastError();
 }
 
+// the packed 16-bit filter: range classes, 4-byte rows, row index below 2^16 (l.debug & 1024 keeps the scalar filter: A/B)
+static bool tile_pk_usable(const DevTables &t, const TileLaunch &l) {
+    if (!t.range_cls || t.filt_row_bytes != 4 || t.filt_k < 2 || t.hashk || (l.debug & 1024u)) return false;
+    uint64_t rows = 1;
+    for (uint32_t i = 0; i + 1 < t.filt_k; ++i) rows *= t.filt_n;
+    return rows <= 65536 && t.cls_base + t.cls_span <= 65536;
+}
+
+template <int K>
+static hipError_t launch_tile_pk(const DevTables &t, const TileLaunch &l, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ac_tile<K, true, false, false, false, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_ac_tile<K, true, false, false, false, true>), dim3(l.grid), dim3(l.block), l.lds_bytes, stream, t, l);
+    return hipGetLastError();
+}
+
+// the PK form with the second-level filter (l.debug & 2048 keeps the one-level form: A/B)
+static bool tile_l2_usable(const DevTables &t, const TileLaunch &l) {
+    return tile_pk_usable(t, l) && t.l2_bloom != nullptr && t.l2_depth != 0 && t.filt_k <= 5 &&
+           t.filt_words <= (uint32_t)kFilterWordsL2 && !(l.debug & 2048u);
+}
+
+template <int K>
+static hipError_t launch_tile_l2(const DevTables &t, const TileLaunch &l, hipStream_t stream) {
+    const size_t lds = tile_l2_lds_bytes(l.block);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ac_tile<K, true, false, false, false, true, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_ac_tile<K, true, false, false, false, true, true>), dim3(l.grid), dim3(l.block), lds, stream, t, l);
+    return hipGetLastError();
+}
+
 template <int K>
 static hipError_t launch_tile_k(const DevTables &t, const TileLaunch &l, hipStream_t stream) {
     const bool wide = t.filt_row_bytes == 8;
@@ -605,6 +797,29 @@ hipError_t launch_ac_tile(const DevTables &t, const TileLaunch &l, hipStream_t s
         case 1: return launch_tile_hashk<1, false>(t, l, stream);
         case 2: return launch_tile_hashk<2, false>(t, l, stream);
         case 3: return launch_tile_hashk<3, false>(t, l, stream);
+        default: return hipErrorInvalidValue;
+        }
+    }
+    if (tile_l2_usable(t, l)) {
+        std::snprintf(name, sizeof(name), "k_ac_tile<%u, true, false, false, false, true, true>", t.filt_k);
+        switch (t.filt_k) {
+        case 2: return launch_tile_l2<2>(t, l, stream);
+        case 3: return launch_tile_l2<3>(t, l, stream);
+        case 4: return launch_tile_l2<4>(t, l, stream);
+        case 5: return launch_tile_l2<5>(t, l, stream);
+        default: return hipErrorInvalidValue;
+        }
+    }
+    if (tile_pk_usable(t, l)) {
+        std::snprintf(name, sizeof(name), "k_ac_tile<%u, true, false, false, false, true>", t.filt_k);
+        switch (t.filt_k) {
+        case 2: return launch_tile_pk<2>(t, l, stream);
+        case 3: return launch_tile_pk<3>(t, l, stream);
+        case 4: return launch_tile_pk<4>(t, l, stream);
+        case 5: return launch_tile_pk<5>(t, l, stream);
+        case 6: return launch_tile_pk<6>(t, l, stream);
+        case 7: return launch_tile_pk<7>(t, l, stream);
+        case 8: return launch_tile_pk<8>(t, l, stream);
         default: return hipErrorInvalidValue;
         }
     }

@@ -14,7 +14,7 @@ constexpr int kTileUnits = 512;                // units per wave tile (64 lanes 
 #define ACGPU_NB 2
 #endif
 #ifndef ACGPU_PREFETCH
-#define ACGPU_PREFETCH 8
+#define ACGPU_PREFETCH 4
 #endif
 constexpr int kVerifyBatches = ACGPU_NB;              // candidates verified per lane and call (independent load chains in flight)
 constexpr int kCandCap = 1024;                 // candidate queue entries per wave; a tile adds at most 512

@@ -920,7 +920,8 @@ def test_split_form_falls_back_when_the_candidate_slices_overflow():
     d_hay = torch.from_numpy(hay.view(np.int16)).cuda()
     cap = len(want) + 8
     got, prof = _dev_match(a, d_hay, hay.size, True, cap, profile=True)
-    assert prof["scan_kernel"].endswith("false>")  # the fused kernel delivered the result
+    # the fused kernel delivered the result (4th template argument = SPLIT)
+    assert prof["scan_kernel"].split("<")[1].rstrip(">").split(", ")[3] == "false"
     assert got.shape == want.shape and (got == want).all()
     out = torch.empty((cap, 3), dtype=torch.int32, device="cuda")
     tk, rc = a.match_device_begin(d_hay.data_ptr(), hay.size, True, out.data_ptr(), cap, stream=torch.cuda.current_stream().cuda_stream)
