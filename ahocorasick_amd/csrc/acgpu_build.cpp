@@ -499,10 +499,10 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
                     for (uint32_t i = 1; i < RN; i++) {
                         const uint32_t L = rn[i].depth;
                         if (L < K || L > D || (L < D && rn[i].kw == ~0u)) continue;
-                        uint32_t packed = 0;
-                        for (uint32_t p = i; p != 0; p = rn[p].parent) packed |= tcls(rn[p].unit) << (5u * (rn[p].depth - 1));
-                        const uint32_t h = l2_hash(packed, K);
-                        t.l2_bloom[l2_word(h)] |= l2_bits(h, packed, L, K);
+                        uint32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // c[j] = class of text[e-1-j]
+                        for (uint32_t p = i; p != 0; p = rn[p].parent) c[rn[p].depth - 1] = tcls(rn[p].unit);
+                        const uint32_t h = l2_hash(l2_gram(c, K));
+                        t.l2_bloom[l2_word(h)] |= l2_rotr(l2_pattern(h), l2_rot(c, L, K));
                     }
                     uint64_t set = 0;
                     for (uint32_t w : t.l2_bloom) set += (uint64_t)__builtin_popcount(w);

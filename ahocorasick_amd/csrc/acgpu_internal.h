@@ -50,22 +50,30 @@ ACGPU_HD inline uint32_t ww_bloom_bit2(uint32_t h, uint32_t mask) { return ((h >
 // Second-level filter of the tile kernel (L2): a blocked Bloom filter, in LDS, over the class sequence of the last
 // D = min(K+2, 6) units of every keyword (keywords shorter than D: their whole class sequence, under their length), so
 // that a position that passed the K-gram filter is only handed to the gather-bound verification when its last D units
-// still look like a keyword.  `packed` = classes 5 bits each, text[e-1] lowest.  The WORD is chosen by the K-gram alone
-// (one LDS read per candidate); a key of length L in [K, D] sets / tests two bits of it that depend on L and on the
-// L-K units in front of the K-gram.  Full-rate 24-bit multiplies only.  Identical on host and device.
+// still look like a keyword.  c[j] = class (below 32) of text[e-1-j].  The WORD is chosen by the K-gram alone (one LDS
+// read per candidate); a key of length L in [K, D] sets / tests a two-bit pattern of that word, rotated by an amount
+// that depends on L and on the L-K classes in front of the K-gram.  Full-rate 24-bit multiplies only.  Identical on
+// host and device.
 constexpr uint32_t kL2Words = 6144; // 24 KiB of LDS
 ACGPU_HD inline uint32_t l2_mul24(uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); } // v_mul_u32_u24
-ACGPU_HD inline uint32_t l2_hash(uint32_t packed, uint32_t K) { // of the K-gram (K <= 5: below 2^25, folded to 24 bits)
-    const uint32_t g = packed & ((1u << (5u * K)) - 1u);
-    return l2_mul24(g ^ (g >> 13), 0x9E3779u);
+ACGPU_HD inline uint32_t l2_gram(const uint32_t *c, uint32_t K) { // the K-gram, one byte per class, text[e-1] highest
+    uint32_t g = 0;
+    for (uint32_t j = 0; j < K && j < 4; ++j) g |= c[j] << (8u * (3u - j));
+    if (K == 5) g |= ((c[4] & 7u) << 5) | ((c[4] >> 3) << 13); // (the classes leave bits 5-7 of every byte free)
+    return g;
 }
+ACGPU_HD inline uint32_t l2_hash(uint32_t gram) { return l2_mul24(gram ^ (gram >> 13), 0x9E3779u); }
 ACGPU_HD inline uint32_t l2_word(uint32_t h) { return (((h >> 11) & 0x1fffu) * kL2Words) >> 13; }
-ACGPU_HD inline uint32_t l2_bits(uint32_t h, uint32_t packed, uint32_t L, uint32_t K) {
-    // the units in front of the K-gram (none for L == K) and the length, mixed with hash bits the word index does not use
-    const uint32_t ctx = ((packed >> (5u * K)) & ((1u << (5u * (L - K))) - 1u)) | (1u << (5u * (L - K)));
-    const uint32_t x = l2_mul24((h >> 8) ^ (ctx * 0x2545u), 0xC2B2AFu);
-    return (1u << ((x >> 19) & 31u)) | (1u << ((x >> 14) & 31u));
+ACGPU_HD inline uint32_t l2_pattern(uint32_t h) {
+    const uint32_t x = l2_mul24(h >> 8, 0xC2B2AFu);
+    return (1u << (x >> 27)) | (1u << ((x >> 22) & 31u));
 }
+ACGPU_HD inline uint32_t l2_rot(const uint32_t *c, uint32_t L, uint32_t K) { // rotation of the pattern for a key of length L
+    if (L == K) return 0;
+    if (L == K + 1) return (c[K] * 5u + 11u) & 31u;
+    return (c[K] * 5u + c[K + 1] * 9u + 23u) & 31u;
+}
+ACGPU_HD inline uint32_t l2_rotr(uint32_t x, uint32_t r) { return (x >> (r & 31u)) | (x << ((32u - r) & 31u)); }
 
 // Host-side automaton tables.  State numbering: root = 0; states WITHOUT any output (own or inherited
 // keyword) come first in BFS order, states WITH output after them in BFS order, so that

@@ -48,13 +48,15 @@ constexpr int kFilterWordsMax = ACGPU_FILTER_WORDS; // 88064 bytes of static LDS
 constexpr int kFilterWordsSplit = 20224; // the filter-only kernel: 79 KiB, so that two workgroups fit one CU's 160 KiB
 bool tile_split_supported(const DevTables &t) { return t.filt_k >= 1 && t.filt_words <= (uint32_t)kFilterWordsSplit; }
 
-// L2 form (second-level filter in LDS, see l2_key in acgpu_internal.h): smaller static array for the rows, and per wave a
+// L2 form (second-level filter in LDS, see l2_gram in acgpu_internal.h): smaller static array for the rows, and per wave a
 // queue of SURVIVORS (kL2Cap), a copy of the current tile as packed classes behind an 8-unit halo (kTbBytes) and the list
 // of the tile's first-level candidates (kL2Fresh tile-relative positions); the Bloom words follow
 constexpr int kFilterWordsL2 = 19712;  // 78848 bytes: 27 classes, K = 4
 constexpr int kL2Cap = 320;
 constexpr int kL2Fresh = 128;
-constexpr int kTbBytes = 16 + kAcTileUnits * 2;
+constexpr int kL2Vec = 4;              // the L2 form takes 32 units per lane: every per-tile cost is shared by 2048 positions
+constexpr int kL2TileUnits = kWave * 8 * kL2Vec;
+constexpr int kTbBytes = 16 + kL2TileUnits; // one BYTE per class: [8 spare][8 classes before the tile][the tile]
 constexpr size_t kL2WaveBytes = kL2Cap * 4 + kTbBytes + kL2Fresh * 2;
 
 // dynamic LDS only: the candidate queues
@@ -325,6 +327,13 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
     uint32_t *cand_all = reinterpret_cast<uint32_t *>(smem);
     for (uint32_t i = threadIdx.x; i < T.filt_words; i += blockDim.x) rows32[i] = T.filt_bits[i];
     constexpr int D2 = K + 2 < 6 ? K + 2 : 6; // depth of the second-level filter
+    // tile geometry of this variant (the names hide the namespace-scope defaults)
+    constexpr int kAcVec = L2 ? kL2Vec : acgpu::kAcVec;
+    constexpr int kAcLaneUnits = 8 * kAcVec;
+    constexpr int kAcTileUnits = kWave * kAcLaneUnits;
+    constexpr int kAcTiles = kPrefetch / kAcVec;
+    static_assert(kAcTiles >= 1 && kAcLaneUnits <= 32, "tile geometry");
+    constexpr int kAcCandCap = kAcTileUnits + kVerifyBatches * kWave;
     constexpr uint32_t kQueueCap = L2 ? kL2Cap : kAcCandCap;
     const uint32_t wave_in_block = threadIdx.x / kWave;
     // L2: [queues][tile buffers][fresh lists][Bloom words]
@@ -506,18 +515,22 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                         acc = __builtin_amdgcn_alignbit(row_lo >> (CC[D] & 31u), acc, 1);
                         acc = __builtin_amdgcn_alignbit(row_hi >> ((CC[D] >> 16) & 31u), acc, 1);
                     }
-                    mask = acc >> (32 - kAcLaneUnits);
-                    if (L2) { // the tile as packed classes, behind the classes of the 8 units before it
-                        uint4 *dst = reinterpret_cast<uint4 *>(tb + 16 + lane * (kAcLaneUnits * 2));
+                    mask = kAcLaneUnits == 32 ? acc : acc >> ((32 - kAcLaneUnits) & 31);
+                    if (L2) { // the tile as one byte per class (v_perm_b32 takes bytes 0 and 2 of two registers), behind
+                              // the classes of the 8 units before it
+                        uint32_t B8[ND / 2];
 #pragma unroll
-                        for (int u = 0; u < kAcVec; ++u) dst[u] = make_uint4(CC[4 + 4 * u], CC[5 + 4 * u], CC[6 + 4 * u], CC[7 + 4 * u]);
-                        if (lane == 0)
-                            *reinterpret_cast<uint4 *>(tb) = make_uint4(NP >= 4 ? CC[0] : 0u, NP >= 3 ? CC[1] : 0u, NP >= 2 ? CC[2] : 0u, CC[3]);
+                        for (int i = 0; i < ND / 2; ++i)
+                            B8[i] = (2 * i + 1 >= 4 - NP) ? __builtin_amdgcn_perm(CC[2 * i + 1], 2 * i >= 4 - NP ? CC[2 * i] : 0u, 0x06040200u) : 0u;
+                        uint4 *dst = reinterpret_cast<uint4 *>(tb + 16 + lane * kAcLaneUnits);
+#pragma unroll
+                        for (int u = 0; u < kAcVec / 2; ++u) dst[u] = make_uint4(B8[2 + 4 * u], B8[3 + 4 * u], B8[4 + 4 * u], B8[5 + 4 * u]);
+                        if (lane == 0) *reinterpret_cast<uint2 *>(tb + 8) = make_uint2(B8[0], B8[1]);
                     }
                     if (edge) {
                         const uint32_t first = lo > v ? min(lo - v, (uint32_t)kAcLaneUnits) : 0u;
                         const uint32_t last = top > v ? min(top - v, (uint32_t)kAcLaneUnits) : 0u;
-                        mask &= ((1u << last) - 1u) & ~((1u << first) - 1u);
+                        mask &= (uint32_t)((1ull << last) - 1ull) & ~(uint32_t)((1ull << first) - 1ull);
                     }
                 } else {
                     // classes of units v-(K-1) .. v+kAcLaneUnits-1
@@ -577,21 +590,21 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
-                    typedef uint16_t __attribute__((may_alias)) u16a; // (written as uint4)
-                    const u16a *tb16 = reinterpret_cast<const u16a *>(tb) + 8; // tb16[p] = class of the tile's unit p
+                    struct __attribute__((packed, aligned(1), may_alias)) Win8 { uint32_t lo, hi; }; // classes of units p-7 .. p
+                    const unsigned char *tb8 = tb + 16; // tb8[p] = class of the tile's unit p
                     for (uint32_t b = 0; b < total; b += kWave) {
                         const uint32_t k = b + lane;
                         const bool act = k < total;
                         const uint32_t p = act ? (uint32_t)fresh[k] : 0u;
-                        uint32_t packed = 0;
-#pragma unroll
-                        for (int j = 0; j < D2; ++j) packed |= (uint32_t)tb16[(int)p - j] << (5 * j);
-                        bool pass = false;
-                        const uint32_t h = l2_hash(packed, K);
+                        const Win8 w = *reinterpret_cast<const Win8 *>(tb8 + (int)p - 7);
+                        const uint32_t cls[6] = {w.hi >> 24, (w.hi >> 16) & 0xffu, (w.hi >> 8) & 0xffu, w.hi & 0xffu, w.lo >> 24, (w.lo >> 16) & 0xffu};
+                        const uint32_t h = l2_hash(l2_gram(cls, K));
                         const uint32_t word = bloom[l2_word(h)];
+                        const uint32_t pat = l2_pattern(h);
+                        bool pass = false;
 #pragma unroll
                         for (int len = K; len <= D2; ++len) {
-                            const uint32_t bits = l2_bits(h, packed, len, K);
+                            const uint32_t bits = __builtin_amdgcn_alignbit(pat, pat, l2_rot(cls, len, K));
                             pass |= (word & bits) == bits;
                         }
                         pass = (pass || (L.debug & 4096u)) && act; // 4096: ablation, the second level passes everything
