@@ -246,6 +246,8 @@ bool use_split_form(const DevTables &T) { return tunables().force_kernel == 3 &&
 // With a ticket the call returns after enqueueing (no host synchronisation); acgpu_match_device_end collects it.
 int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_kind, void *d_out, uint64_t cap,
               uint64_t *n_out, hipStream_t stream, acgpu_profile *prof, Ticket *tk = nullptr, bool fused_only = false) {
+    // (fused_only: the redo after an overflow of the split form's candidate slices or of a scratch slice -- the fused
+    // kernel, one scratch slice)
     const HostTables &t = a->t;
     hipEvent_t *ev = tk ? tk->ev : d.ev;
     const bool timed = tk ? tk->profiled : prof != nullptr;
@@ -266,12 +268,16 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         return ACGPU_OK;
     }
     int rc;
-    if ((rc = d.counter.ensure(64))) return rc;
-    // the tile kernel reserves scratch slots 256 at a time per wave: head-room for the unused tails
+    const size_t counter_bytes = (size_t)kMaxSlices * kCounterStride * 8;
+    if ((rc = d.counter.ensure(counter_bytes))) return rc;
+    // the tile kernel reserves scratch slots 256 at a time per wave: head-room for the unused tails; a quarter more than
+    // the caller's capacity so that the scratch slices (one per workgroup) tolerate unevenly spread matches
     uint64_t scratch_cap = std::min<uint64_t>(
-        std::max<uint64_t>(cap, 1) + (uint64_t)d.n_cu * (tile_block_threads() / 64) * tile_reserve_slots(), 0xffffffe0ull);
+        std::max<uint64_t>(cap, 1) + cap / 4 + (uint64_t)d.n_cu * (tile_block_threads() / 64) * tile_reserve_slots(), 0xffffffe0ull);
     if ((rc = d.scratch.ensure(scratch_cap * sizeof(ScratchRec)))) return rc;
-    HIP_TRY(hipMemsetAsync(d.counter.p, 0, 64, stream));
+    HIP_TRY(hipMemsetAsync(d.counter.p, 0, counter_bytes, stream));
+    uint32_t n_slices = 1;
+    uint64_t slice_slots = scratch_cap;
     const char *kname = "";
     uint64_t scanned = 0;
     uint32_t n_chunks = 0, chunk_units = 0, perm_base = (uint32_t)sh->own_begin;
@@ -299,6 +305,14 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         L.cap = scratch_cap;
         L.lds_bytes = tile_lds_bytes(d.T, L.block);
         L.debug = (uint32_t)tunables().tile_debug;
+        L.d_overflow = (uint32_t *)d.counter.p + 8;
+        // one scratch slice and slot counter per workgroup (the redo after an overflow takes one slice)
+        if (!fused_only && L.grid > 1 && !(L.debug & 16384u)) { // 16384: A/B, one counter
+            n_slices = (uint32_t)std::min<int>(L.grid, kMaxSlices);
+            slice_slots = scratch_cap / n_slices;
+        }
+        L.n_slices = n_slices;
+        L.slice_slots = (uint32_t)slice_slots;
         if ((rc = d.chunk_counts.ensure((size_t)L.n_regions * 4))) return rc;
         if ((rc = d.offsets.ensure((size_t)L.n_regions * 8))) return rc;
         if ((rc = d.scan_tmp.ensure(((size_t)L.n_regions / 2048 + 2) * 8))) return rc;
@@ -308,6 +322,8 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         // (every region's count is written by the wave that owns the region: no memset)
         split = !fused_only && use_split_form(d.T);
         if (split) {
+            L.n_slices = n_slices = 1; // (the verification kernel's grid is not the filter's)
+            L.slice_slots = (uint32_t)(slice_slots = scratch_cap);
             // a wave's slice holds one candidate per 8 units of its span (the filter passes ~2 % on selective
             // dictionaries); a haystack that needs more is redone with the fused kernel
             const uint64_t per_wave = (uint64_t)L.regions_per_wave * R / 8 + 2 * 1024;
@@ -319,7 +335,6 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
                 L.d_cands = (uint32_t *)d.cands.p;
                 L.d_region_cands = (uint2 *)d.region_cands.p;
                 HIP_TRY(hipMemsetAsync(d.region_cands.p, 0, (size_t)L.n_regions * 8, stream)); // unwritten = no candidates
-                L.d_overflow = (uint32_t *)d.counter.p + 8;
                 L.verify_grid = (int)std::min<uint64_t>(((uint64_t)L.n_regions + 3) / 4, (uint64_t)d.n_cu * 8);
                 // every verification wave may hold one partly used reservation of scratch slots
                 const uint64_t need = std::min<uint64_t>(std::max<uint64_t>(cap, 1) + (uint64_t)L.verify_grid * 4 * tile_reserve_slots(),
@@ -327,6 +342,7 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
                 if (need > L.cap) {
                     if ((rc = d.scratch.ensure(need * sizeof(ScratchRec)))) return rc;
                     L.cap = scratch_cap = need;
+                    L.slice_slots = (uint32_t)(slice_slots = scratch_cap);
                     L.d_scratch = (ScratchRec *)d.scratch.p;
                 }
             }
@@ -376,16 +392,17 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
     }
     HIP_TRY(launch_exclusive_scan((const uint32_t *)d.chunk_counts.p, n_chunks, (uint64_t *)d.offsets.p,
                                   (uint64_t *)d.scan_tmp.p, stream));
-    HIP_TRY(launch_permute((const ScratchRec *)d.scratch.p, (const unsigned long long *)d.counter.p, scratch_cap,
+    HIP_TRY(launch_permute((const ScratchRec *)d.scratch.p, (const unsigned long long *)d.counter.p, n_slices, slice_slots,
                            (const uint64_t *)d.offsets.p, perm_base, chunk_units,
                            /*by_start=*/0, record_kind, d_out, cap, id_map, stream));
+    const bool flagged = split || n_slices > 1; // the overflow word has to be looked at
     if (timed) HIP_TRY(hipEventRecord(ev[2], stream));
     // exact record count = grand total of the per-chunk counts (the slot counter also counts reservation holes)
     if (tk) {
         HIP_TRY(hipMemcpyAsync(tk->h_count, (const uint64_t *)d.scan_tmp.p + scan_tiles_for(n_chunks), 8,
                                hipMemcpyDeviceToHost, stream));
         tk->h_count[1] = 0;
-        if (split) HIP_TRY(hipMemcpyAsync(tk->h_count + 1, (const uint32_t *)d.counter.p + 8, 4, hipMemcpyDeviceToHost, stream));
+        if (flagged) HIP_TRY(hipMemcpyAsync(tk->h_count + 1, (const uint32_t *)d.counter.p + 8, 4, hipMemcpyDeviceToHost, stream));
         tk->shard = *sh;
         tk->record_kind = record_kind;
         tk->d_out = d_out;
@@ -398,9 +415,9 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
     HIP_TRY(hipMemcpyAsync(d.h_counter, (const uint64_t *)d.scan_tmp.p + scan_tiles_for(n_chunks), 8, hipMemcpyDeviceToHost,
                            stream));
     d.h_counter[1] = 0;
-    if (split) HIP_TRY(hipMemcpyAsync(d.h_counter + 1, (const uint32_t *)d.counter.p + 8, 4, hipMemcpyDeviceToHost, stream));
+    if (flagged) HIP_TRY(hipMemcpyAsync(d.h_counter + 1, (const uint32_t *)d.counter.p + 8, 4, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
-    if (split && (uint32_t)d.h_counter[1] != 0) // a candidate slice overflowed: this haystack takes the fused kernel
+    if (flagged && (uint32_t)d.h_counter[1] != 0) // a candidate slice / scratch slice overflowed: fused kernel, one scratch slice
         return match_all(a, d, sh, record_kind, d_out, cap, n_out, stream, prof, nullptr, true);
     *n_out = *d.h_counter;
     if (prof) {
@@ -650,6 +667,9 @@ int match_wholeword(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int rec
     if ((rc = d.scan_tmp.ensure(((size_t)L.n_regions / 2048 + 2) * 8))) return rc;
     L.d_scratch = (ScratchRec *)d.scratch.p;
     L.d_counter = (unsigned long long *)d.counter.p;
+    L.d_overflow = (uint32_t *)d.counter.p + 8;
+    L.n_slices = 1; // one scratch slice, one slot counter
+    L.slice_slots = (uint32_t)scratch_cap;
     L.d_region_counts = (uint32_t *)d.chunk_counts.p;
     HIP_TRY(hipMemsetAsync(d.chunk_counts.p, 0, (size_t)L.n_regions * 4, stream));
     if (prof) HIP_TRY(hipEventRecord(d.ev[0], stream));
@@ -658,7 +678,7 @@ int match_wholeword(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int rec
     if (prof) HIP_TRY(hipEventRecord(d.ev[1], stream));
     HIP_TRY(launch_exclusive_scan((const uint32_t *)d.chunk_counts.p, L.n_regions, (uint64_t *)d.offsets.p,
                                   (uint64_t *)d.scan_tmp.p, stream));
-    HIP_TRY(launch_permute((const ScratchRec *)d.scratch.p, (const unsigned long long *)d.counter.p, scratch_cap,
+    HIP_TRY(launch_permute((const ScratchRec *)d.scratch.p, (const unsigned long long *)d.counter.p, 1, scratch_cap,
                            (const uint64_t *)d.offsets.p, (uint32_t)base8, L.region_units, /*by_start=*/1, record_kind,
                            d_out, cap, nullptr, stream));
     if (prof) HIP_TRY(hipEventRecord(d.ev[2], stream));

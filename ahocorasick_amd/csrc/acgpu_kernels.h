@@ -41,7 +41,12 @@ struct TileLaunch {
     uint32_t regions_per_wave; // a wave scans this many consecutive regions
     ScratchRec *d_scratch;
     uint64_t cap;
-    unsigned long long *d_counter;
+    unsigned long long *d_counter;   // slot counters, one per slice, kCounterStride apart
+    // Record slots come from n_slices equal slices of the scratch (slice = workgroup modulo n_slices), each with its own
+    // counter: the waves of the grid reach their region seams -- and with them their slot reservations -- in lock step,
+    // and thousands of atomics on ONE address are served at under 100 per microsecond.  A slice that fills up sets bit 1
+    // of *d_overflow; the host then redoes the call with one slice.  n_slices = 1: the whole scratch, one counter.
+    uint32_t n_slices, slice_slots;
     uint32_t *d_region_counts;
     int grid, block;
     size_t lds_bytes;
@@ -71,9 +76,12 @@ int tile_block_threads();
 hipError_t launch_exclusive_scan(const uint32_t *d_counts, uint32_t n, uint64_t *d_offsets, uint64_t *d_tmp,
                                  hipStream_t stream);
 
+constexpr uint32_t kCounterStride = 16; // in counters (128 bytes): one cache line per slice counter
+constexpr int kMaxSlices = 512;
+
 // scratch (unordered) -> final records in reference order
 // (slots whose rank is ~0u are holes left by slot reservations and are skipped)
-hipError_t launch_permute(const ScratchRec *d_scratch, const unsigned long long *d_counter, uint64_t scratch_cap,
+hipError_t launch_permute(const ScratchRec *d_scratch, const unsigned long long *d_counter, uint32_t n_slices, uint64_t slice_slots,
                           const uint64_t *d_offsets, uint32_t own_begin, uint32_t chunk_units, int by_start,
                           int record_kind, void *d_out, uint64_t out_cap, const uint32_t *d_id_map, hipStream_t stream);
 uint32_t scan_tiles_for(uint32_t n); // number of prefix-sum tiles; the grand total is d_tmp[scan_tiles_for(n)]

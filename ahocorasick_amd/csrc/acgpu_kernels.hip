@@ -10,6 +10,8 @@
 // k_permute   : scatters the unordered records to their final, reference-ordered slots.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "acgpu_device.h"
 #include "acgpu_kernels.h"
 
@@ -327,11 +329,13 @@ hipError_t launch_exclusive_scan(const uint32_t *d_counts, uint32_t n, uint64_t 
 // ---- permutation to reference order ----------------------------------------------------------------------
 template <int REC>
 __global__ __launch_bounds__(256) void k_permute(const ScratchRec *scratch, const unsigned long long *counter,
-                                                uint64_t scratch_cap, const uint64_t *offsets, uint32_t own_begin,
+                                                uint64_t slice_slots, const uint64_t *offsets, uint32_t own_begin,
                                                 uint32_t chunk_units, int by_start, void *out, uint64_t cap,
                                                 const uint32_t *id_map) {
-    unsigned long long m = *counter;
-    if (m > scratch_cap) m = scratch_cap; // overflow: the host reports ACGPU_E_OVERFLOW; nothing useful is produced
+    // blockIdx.y = slice of the scratch (its own counter, slice_slots slots)
+    unsigned long long m = counter[(size_t)blockIdx.y * kCounterStride];
+    if (m > slice_slots) m = slice_slots; // overflow: the host redoes the call / reports ACGPU_E_OVERFLOW
+    scratch += (size_t)blockIdx.y * slice_slots;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint4 raw = *reinterpret_cast<const uint4 *>(&scratch[i]);
         const int32_t start = (int32_t)raw.x, end = (int32_t)raw.y, id = (int32_t)raw.z;
@@ -353,15 +357,16 @@ __global__ __launch_bounds__(256) void k_permute(const ScratchRec *scratch, cons
     }
 }
 
-hipError_t launch_permute(const ScratchRec *d_scratch, const unsigned long long *d_counter, uint64_t scratch_cap,
+hipError_t launch_permute(const ScratchRec *d_scratch, const unsigned long long *d_counter, uint32_t n_slices, uint64_t slice_slots,
                           const uint64_t *d_offsets, uint32_t own_begin, uint32_t chunk_units, int by_start,
                           int record_kind, void *d_out, uint64_t out_cap, const uint32_t *d_id_map, hipStream_t stream) {
-    const int grid = 2048;
+    if (n_slices < 1) n_slices = 1;
+    const dim3 grid(std::max<uint32_t>(2048u / n_slices, 8u), n_slices);
     if (record_kind == ACGPU_REC_SET)
-        hipLaunchKernelGGL(k_permute<ACGPU_REC_SET>, dim3(grid), dim3(256), 0, stream, d_scratch, d_counter, scratch_cap,
+        hipLaunchKernelGGL(k_permute<ACGPU_REC_SET>, grid, dim3(256), 0, stream, d_scratch, d_counter, slice_slots,
                            d_offsets, own_begin, chunk_units, by_start, d_out, out_cap, d_id_map);
     else
-        hipLaunchKernelGGL(k_permute<ACGPU_REC_MAP>, dim3(grid), dim3(256), 0, stream, d_scratch, d_counter, scratch_cap,
+        hipLaunchKernelGGL(k_permute<ACGPU_REC_MAP>, grid, dim3(256), 0, stream, d_scratch, d_counter, slice_slots,
                            d_offsets, own_begin, chunk_units, by_start, d_out, out_cap, d_id_map);
     return hipGetLastError();
 }

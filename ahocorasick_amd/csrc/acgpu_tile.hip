@@ -492,41 +492,52 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                     // MM[D] = the pair of units (2D-1, 2D), i.e. the misaligned neighbour of CC[D]
                     constexpr int ND = 4 + 4 * kAcVec;
                     const uint32_t base2 = T.cls_base * 0x10001u, span2 = T.cls_span * 0x10001u, n2 = n * 0x10001u;
-                    uint32_t CC[ND], MM[ND];
+                    uint32_t CC[ND], MM[ND], B8[ND / 2];
 #pragma unroll
                     for (int D = 4 - NP; D < 4; ++D) CC[D] = pk_class(pp[D], base2, span2);
 #pragma unroll
-                    for (int D = 4; D < ND; ++D) CC[D] = pk_class(ww[D - 4], base2, span2);
+                    for (int D = 4 - NP + 1; D < 4; ++D) MM[D] = __builtin_amdgcn_alignbit(CC[D], CC[D - 1], 16);
+                    if (L2) { // classes of the 8 units before the tile, one byte each (see below)
 #pragma unroll
-                    for (int D = 4 - NP + 1; D < ND; ++D) MM[D] = __builtin_amdgcn_alignbit(CC[D], CC[D - 1], 16);
-                    uint32_t acc = 0;
-#pragma unroll
-                    for (int D = 4; D < ND; ++D) {
-                        // positions 2D (low half) and 2D+1 (high half): row = the K-1 units before, bit = own class
-                        const int S0 = 2 * D - (K - 1); // first unit of the low position's (K-1)-gram
-                        uint32_t H = (S0 & 1) ? MM[(S0 + 1) / 2] : CC[S0 / 2];
-#pragma unroll
-                        for (int t = 1; t < K - 1; ++t) {
-                            const int S = S0 + t;
-                            H = pk_mad(H, n2, (S & 1) ? MM[(S + 1) / 2] : CC[S / 2]);
-                        }
-                        const uint32_t row_lo = rows32[H & 0xffffu];
-                        const uint32_t row_hi = rows32[H >> 16];
-                        acc = __builtin_amdgcn_alignbit(row_lo >> (CC[D] & 31u), acc, 1);
-                        acc = __builtin_amdgcn_alignbit(row_hi >> ((CC[D] >> 16) & 31u), acc, 1);
-                    }
-                    mask = kAcLaneUnits == 32 ? acc : acc >> ((32 - kAcLaneUnits) & 31);
-                    if (L2) { // the tile as one byte per class (v_perm_b32 takes bytes 0 and 2 of two registers), behind
-                              // the classes of the 8 units before it
-                        uint32_t B8[ND / 2];
-#pragma unroll
-                        for (int i = 0; i < ND / 2; ++i)
+                        for (int i = 0; i < 2; ++i)
                             B8[i] = (2 * i + 1 >= 4 - NP) ? __builtin_amdgcn_perm(CC[2 * i + 1], 2 * i >= 4 - NP ? CC[2 * i] : 0u, 0x06040200u) : 0u;
-                        uint4 *dst = reinterpret_cast<uint4 *>(tb + 16 + lane * kAcLaneUnits);
-#pragma unroll
-                        for (int u = 0; u < kAcVec / 2; ++u) dst[u] = make_uint4(B8[2 + 4 * u], B8[3 + 4 * u], B8[4 + 4 * u], B8[5 + 4 * u]);
                         if (lane == 0) *reinterpret_cast<uint2 *>(tb + 8) = make_uint2(B8[0], B8[1]);
                     }
+                    uint32_t acc = 0;
+                    // one 16-byte vector (8 positions) at a time, start to finish, so that only a few packed classes are
+                    // live at any point (the L2 form sits at the 128-register limit)
+#pragma unroll
+                    for (int u = 0; u < kAcVec; ++u) {
+#pragma unroll
+                        for (int D = 4 + 4 * u; D < 8 + 4 * u; ++D) {
+                            CC[D] = pk_class(ww[D - 4], base2, span2);
+                            MM[D] = __builtin_amdgcn_alignbit(CC[D], CC[D - 1], 16);
+                        }
+#pragma unroll
+                        for (int D = 4 + 4 * u; D < 8 + 4 * u; ++D) {
+                            // positions 2D (low half) and 2D+1 (high half): row = the K-1 units before, bit = own class
+                            const int S0 = 2 * D - (K - 1); // first unit of the low position's (K-1)-gram
+                            uint32_t H = (S0 & 1) ? MM[(S0 + 1) / 2] : CC[S0 / 2];
+#pragma unroll
+                            for (int t = 1; t < K - 1; ++t) {
+                                const int S = S0 + t;
+                                H = pk_mad(H, n2, (S & 1) ? MM[(S + 1) / 2] : CC[S / 2]);
+                            }
+                            const uint32_t row_lo = rows32[H & 0xffffu];
+                            const uint32_t row_hi = rows32[H >> 16];
+                            acc = __builtin_amdgcn_alignbit(row_lo >> (CC[D] & 31u), acc, 1);
+                            acc = __builtin_amdgcn_alignbit(row_hi >> ((CC[D] >> 16) & 31u), acc, 1);
+                        }
+                        if (L2) { // the tile as one byte per class (v_perm_b32 takes bytes 0 and 2 of two registers)
+                            B8[2 + 2 * u] = __builtin_amdgcn_perm(CC[5 + 4 * u], CC[4 + 4 * u], 0x06040200u);
+                            B8[3 + 2 * u] = __builtin_amdgcn_perm(CC[7 + 4 * u], CC[6 + 4 * u], 0x06040200u);
+                            if (u & 1)
+                                reinterpret_cast<uint4 *>(tb + 16 + lane * kAcLaneUnits)[u / 2] =
+                                    make_uint4(B8[2 * u], B8[2 * u + 1], B8[2 * u + 2], B8[2 * u + 3]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    mask = kAcLaneUnits == 32 ? acc : acc >> ((32 - kAcLaneUnits) & 31);
                     if (edge) {
                         const uint32_t first = lo > v ? min(lo - v, (uint32_t)kAcLaneUnits) : 0u;
                         const uint32_t last = top > v ? min(top - v, (uint32_t)kAcLaneUnits) : 0u;
@@ -691,7 +702,8 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
     }
     if (lane == 0) L.d_region_counts[region] = c.rank_base;
     // hand back the unused tail of the last reservation as holes the permute pass skips
-    for (uint32_t i = lane; i < c.res_left; i += kWave) store_rec(L, c.res_cur + i, 0, 0, 0, ~0u);
+    for (uint32_t i = lane; i < c.res_left; i += kWave)
+        if (c.res_cur + i < c.slot_limit) store_rec(L, c.res_cur + i, 0, 0, 0, ~0u);
 }
 
 // The verification half of the split form: one region per wave (grid-stride), its candidates read from L.d_cands in

@@ -29,6 +29,7 @@ struct TileCtx {
     uint32_t rank_base; // wave-uniform: records emitted so far in the current region
     uint32_t res_cur;   // wave-uniform: next free reserved scratch slot (scratch capacity < 2^32)
     uint32_t res_left;          // wave-uniform: reserved slots left
+    uint32_t slot_limit = 0;    // wave-uniform: end of this workgroup's scratch slice (set by the first reservation)
 };
 
 __device__ __forceinline__ void store_rec(const TileLaunch &L, uint32_t slot, uint32_t start, uint32_t end, uint32_t id,
@@ -77,19 +78,32 @@ __device__ __forceinline__ void enqueue(TileCtx &c, uint32_t mask, uint32_t v) {
 // Reserve `total` record slots for this wave (wave-uniform); returns a functor-like pair through references:
 // slot of the k-th record = k < old_left ? old_cur + k : fresh + (k - old_left).
 struct SlotRange {
-    uint32_t old_cur, old_left, fresh;
-    __device__ __forceinline__ uint32_t slot(uint32_t k) const { return k < old_left ? old_cur + k : fresh + (k - old_left); }
+    uint32_t old_cur, old_left, fresh, limit;
+    // slots at or beyond the slice's end do not exist (~0u: store_rec drops the record; the host redoes the call with one
+    // slice or reports ACGPU_E_OVERFLOW) -- but every slot below it is written, which the permute pass relies on
+    __device__ __forceinline__ uint32_t slot(uint32_t k) const {
+        const uint32_t s = k < old_left ? old_cur + k : fresh + (k - old_left);
+        return s < limit ? s : ~0u;
+    }
 };
 
 __device__ __forceinline__ SlotRange reserve_slots(TileCtx &c, uint32_t total) {
-    SlotRange r{c.res_cur, c.res_left, 0};
+    SlotRange r{c.res_cur, c.res_left, 0, c.slot_limit};
     if (total > r.old_left) {
         const uint32_t need = total - r.old_left;
         const uint32_t take = need > kReserve ? need : kReserve;
-        unsigned long long got = 0;
-        if (lane_id() == 0) got = atomicAdd(c.Lp->d_counter, (unsigned long long)take);
-        // beyond the scratch capacity nothing is stored (the host reports ACGPU_E_OVERFLOW from the exact counts)
-        uint32_t fresh = (uint32_t)min(got, (unsigned long long)0xfffffff0u - take);
+        // this workgroup's slice of the scratch and its counter (see TileLaunch::n_slices)
+        const uint32_t slice = c.Lp->n_slices > 1 ? blockIdx.x % c.Lp->n_slices : 0u;
+        const uint32_t S = c.Lp->slice_slots, base = slice * S; // (n_slices * S <= scratch capacity < 2^32)
+        uint32_t fresh = 0;
+        if (lane_id() == 0) {
+            const unsigned long long got = atomicAdd(c.Lp->d_counter + (size_t)slice * kCounterStride, (unsigned long long)take);
+            fresh = got < (unsigned long long)S ? base + (uint32_t)got : base + S;
+            // the slice is full: the host redoes the call with one slice (n_slices == 1: the scratch is full and the host
+            // reports ACGPU_E_OVERFLOW from the exact counts)
+            if (got + take > (unsigned long long)S && c.Lp->n_slices > 1) atomicOr(c.Lp->d_overflow, 2u);
+        }
+        c.slot_limit = r.limit = base + S;
         r.fresh = __builtin_amdgcn_readfirstlane(fresh);
         c.res_cur = r.fresh + need;
         c.res_left = take - need;

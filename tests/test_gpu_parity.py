@@ -1025,3 +1025,29 @@ def test_large_alphabets_bucketed_classes(seed, ac_kernel):
     from oracle.oracle import FAM_SHORTEST
     assert (Automaton(N.MODE_SHORTEST, kws, False).match_host(hay, True) ==
             Oracle(FAM_SHORTEST, kws, case_sensitive=False, lower=LOWER).match(hay)).all()
+
+
+def test_scratch_slice_overflow_is_redone_with_one_slice():
+    """The tile kernel takes record slots from one scratch slice per workgroup.  Here every match lies in the first
+    workgroup's share of the haystack and the capacity is exact, so that slice fills up and the call is redone with one
+    slice -- synchronously and through begin/end; results equal the oracle's and the one-counter form's."""
+    import torch
+    kws = ["".join(p) for k in (2, 3, 4) for p in __import__("itertools").product("ab", repeat=k)]
+    a = Automaton(N.MODE_ALL, kws, True)
+    n = 1 << 22
+    hay = np.full(n, ord("z"), dtype=np.uint16)
+    hay[: 1 << 18] = synth.haystack(5, 1 << 18, table=synth.ALPHA_LOWER[:2])
+    want = Oracle(FAM_AC, kws).match(hay)
+    assert len(want) > 700000
+    d_hay = torch.from_numpy(hay.view(np.int16)).cuda()
+    cap = len(want)
+    got, _ = _dev_match(a, d_hay, n, True, cap)
+    assert got.shape == want.shape and (got == want).all()
+    out = torch.empty((cap, 3), dtype=torch.int32, device="cuda")
+    tk, rc = a.match_device_begin(d_hay.data_ptr(), n, True, out.data_ptr(), cap, stream=torch.cuda.current_stream().cuda_stream)
+    assert rc == N.OK
+    m, rc, _ = a.match_device_end(tk)
+    assert rc == N.OK and m == len(want) and (out[:m].cpu().numpy() == want).all()
+    N.set_tunable("tile_debug", 16384)  # one slot counter for the whole grid
+    got1, _ = _dev_match(a, d_hay, n, True, cap)
+    assert (got1 == want).all()
