@@ -62,7 +62,9 @@ struct TileLaunch {
     uint32_t debug; // ablation switches (tunable "tile_debug"): 1 = drop candidates unverified, 4 = no filter arithmetic
                     // at all (stream + reduce only), 8 = verification without the text-window load, 16 = without the
                     // K-gram node load, 32 = no record emission, 64 = no walk beyond the K-gram node, 128 = records
-                    // not stored.  Results are wrong when non-zero; 0 in production.
+                    // not stored, 512 = one candidate in eight is kept, 4096 = the second-level filter passes everything.
+                    // Kernel selection (results stay right): 1024 = scalar filter instead of the packed one, 2048 = no
+                    // second-level filter, 16384 = one slot counter.  0 in production.
 };
 hipError_t launch_ac_tile(const DevTables &t, const TileLaunch &l, hipStream_t stream, const char **kernel_name);
 // split form: launch_ac_filter, then launch_ac_verify on the same stream (same TileLaunch)

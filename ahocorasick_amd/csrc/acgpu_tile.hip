@@ -37,7 +37,6 @@ uint32_t tile_reserve_slots() { return kReserve; }
 constexpr int kAcVec = ACGPU_VEC;
 constexpr int kAcLaneUnits = 8 * kAcVec;
 constexpr int kAcTileUnits = kWave * kAcLaneUnits;
-constexpr int kAcTiles = kPrefetch / kAcVec;            // tiles per double-buffered group (same bytes in flight)
 constexpr int kAcCandCap = kAcTileUnits + kVerifyBatches * kWave;
 uint32_t tile_group_units() { return kPrefetch * kTileUnits; }
 

@@ -35,8 +35,16 @@ struct TileCtx {
 __device__ __forceinline__ void store_rec(const TileLaunch &L, uint32_t slot, uint32_t start, uint32_t end, uint32_t id,
                                           uint32_t rank) {
     if ((uint64_t)slot < L.cap && !(L.debug & 128u)) { // 128: ablation, records are not stored
+        // non-temporal: the records are read once, by the permute pass, and must not push the just-streamed text (which
+        // the verification gathers from) out of the L2; about 1 % at config 2, same-box A/B against -DACGPU_REC_PLAIN
+#ifndef ACGPU_REC_PLAIN
+        typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+        const v4u v = {start, end, id, rank};
+        __builtin_nontemporal_store(v, reinterpret_cast<v4u *>(&L.d_scratch[slot]));
+#else
         const uint4 v = make_uint4(start, end, id, rank);
         *reinterpret_cast<uint4 *>(&L.d_scratch[slot]) = v;
+#endif
     }
 }
 

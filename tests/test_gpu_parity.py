@@ -1051,3 +1051,28 @@ def test_scratch_slice_overflow_is_redone_with_one_slice():
     N.set_tunable("tile_debug", 16384)  # one slot counter for the whole grid
     got1, _ = _dev_match(a, d_hay, n, True, cap)
     assert (got1 == want).all()
+
+
+def test_long_keywords_branching_suffixes_and_planted_matches():
+    """Long keywords (up to 30 units), keywords that are suffixes of others, keywords that share long suffixes: the
+    reversed-trie walk of the tile kernel in all its shapes.  Every keyword is planted a few times, the first one right at
+    the start of the buffer."""
+    rng = np.random.default_rng(77)
+    alpha = list(range(ord("a"), ord("h") + 1))
+    for min_len, max_len in ((4, 16), (5, 30), (3, 12)):
+        hay, kws = rand_case(rng, alpha, 60, max_len, 60013, min_len=min_len)
+        arr = lambda t: np.array([ord(ch) for ch in t], dtype=np.uint16)
+        kws = list(kws) + [kws[0][-min_len:], kws[1][1:], arr("abcdefgh" * 3), arr("h" + "abcdefgh" * 2)]
+        hay = hay.copy()
+        pos = 0
+        for k in kws:  # plant every keyword a few times, the first at offset 0
+            u = np.asarray(k, dtype=np.uint16)
+            for _ in range(3):
+                if pos + u.size < hay.size:
+                    hay[pos:pos + u.size] = u
+                pos += u.size + int(rng.integers(0, 40))
+        for cs in (True, False):
+            m = AhoCorasickMap(kws, _ids(len(kws)), cs)
+            want = Oracle(FAM_AC, kws, case_sensitive=cs, lower=LOWER).match(hay).tolist()
+            assert len(want) > 3 * len(kws) - 10
+            assert m.find_all(hay).tolist() == want

@@ -4,4 +4,4 @@
 set -e
 name=$1; shift
 cd "$(dirname "$0")/../ahocorasick_amd/csrc"
-make OUT=../lib_$name CXXFLAGS="-O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-pass-failed --offload-arch=gfx950 -I../../include $*"
+make -j8 OUT=../lib_$name CXXFLAGS="-O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-pass-failed --offload-arch=gfx950 -I../../include $*"

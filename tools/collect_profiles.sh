@@ -17,4 +17,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c5" -- pytho
 V='{"tile":{"force_kernel":2},"noverify":{"force_kernel":2,"tile_debug":1},"stream":{"force_kernel":2,"tile_debug":5}}'
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 tools/kbench.py --rounds 1 --variants "$V" > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 tools/kbench.py --rounds 1 --variants "$V" > "$OUT/pmc_write.log" 2>&1
+python3 tools/pmc_traffic.py "$OUT" "$OUT/pmc_traffic.json"
+# SQ instruction / busy counters of the same three builds
+bash tools/pmc_sq.sh "${1:-final}/pmc_sq" "$V" > "$OUT/pmc_sq.txt" 2>&1
 cat "$OUT/bench_c2.json"
