@@ -607,7 +607,7 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
 
 // WHOLEWORD-mode pipeline on one shard.
 int match_wholeword(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_kind, void *d_out, uint64_t cap,
-                    uint64_t *n_out, hipStream_t stream, acgpu_profile *prof) {
+                    uint64_t *n_out, hipStream_t stream, acgpu_profile *prof, bool one_slice = false) {
     const HostTables &t = a->t;
     const uint64_t own_len = sh->own_end - sh->own_begin;
     if (prof) std::memset(prof, 0, sizeof(*prof));
@@ -616,8 +616,9 @@ int match_wholeword(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int rec
         return ACGPU_OK;
     }
     int rc;
-    if ((rc = d.counter.ensure(64))) return rc;
-    HIP_TRY(hipMemsetAsync(d.counter.p, 0, 64, stream));
+    const size_t counter_bytes = (size_t)kMaxSlices * kCounterStride * 8;
+    if ((rc = d.counter.ensure(counter_bytes))) return rc;
+    HIP_TRY(hipMemsetAsync(d.counter.p, 0, counter_bytes, stream));
     if (!t.fold_consistent) {
         // the reference's mixed folded/raw lookups make token boundaries history dependent: whole text, one lane
         if (!sh->text_begin || !sh->text_end || sh->own_begin != 0 || sh->own_end != sh->n_units) return ACGPU_E_UNSUPPORTED;
@@ -639,8 +640,9 @@ int match_wholeword(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int rec
     }
     if (!sh->text_begin && sh->own_begin < 1) return ACGPU_E_INVALID;                              // left context: 1 unit
     if (!sh->text_end && sh->n_units - sh->own_end < (uint64_t)t.max_len + 1) return ACGPU_E_INVALID; // right halo
+    // (a quarter more than the caller's capacity: the scratch is cut into one slice per workgroup, see TileLaunch::n_slices)
     const uint64_t scratch_cap = std::min<uint64_t>(
-        std::max<uint64_t>(cap, 1) + (uint64_t)d.n_cu * ww_blocks_per_cu() * (tile_block_threads() / 64) * tile_reserve_slots(),
+        std::max<uint64_t>(cap, 1) + cap / 4 + (uint64_t)d.n_cu * ww_blocks_per_cu() * (tile_block_threads() / 64) * tile_reserve_slots(),
         0xffffffe0ull);
     if ((rc = d.scratch.ensure(scratch_cap * sizeof(ScratchRec)))) return rc;
     TileLaunch L{};
@@ -668,8 +670,10 @@ int match_wholeword(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int rec
     L.d_scratch = (ScratchRec *)d.scratch.p;
     L.d_counter = (unsigned long long *)d.counter.p;
     L.d_overflow = (uint32_t *)d.counter.p + 8;
-    L.n_slices = 1; // one scratch slice, one slot counter
-    L.slice_slots = (uint32_t)scratch_cap;
+    // one scratch slice and slot counter per workgroup (config 5 emits 15 M records per shard: 60 k reservations that one
+    // counter would serve at under 100 per microsecond); a slice that fills up -> redo with one slice
+    L.n_slices = (one_slice || L.grid < 2 || (L.debug & 16384u)) ? 1u : (uint32_t)std::min<int>(L.grid, kMaxSlices);
+    L.slice_slots = (uint32_t)(scratch_cap / L.n_slices);
     L.d_region_counts = (uint32_t *)d.chunk_counts.p;
     HIP_TRY(hipMemsetAsync(d.chunk_counts.p, 0, (size_t)L.n_regions * 4, stream));
     if (prof) HIP_TRY(hipEventRecord(d.ev[0], stream));
@@ -678,13 +682,17 @@ int match_wholeword(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int rec
     if (prof) HIP_TRY(hipEventRecord(d.ev[1], stream));
     HIP_TRY(launch_exclusive_scan((const uint32_t *)d.chunk_counts.p, L.n_regions, (uint64_t *)d.offsets.p,
                                   (uint64_t *)d.scan_tmp.p, stream));
-    HIP_TRY(launch_permute((const ScratchRec *)d.scratch.p, (const unsigned long long *)d.counter.p, 1, scratch_cap,
+    HIP_TRY(launch_permute((const ScratchRec *)d.scratch.p, (const unsigned long long *)d.counter.p, L.n_slices, L.slice_slots,
                            (const uint64_t *)d.offsets.p, (uint32_t)base8, L.region_units, /*by_start=*/1, record_kind,
                            d_out, cap, nullptr, stream));
     if (prof) HIP_TRY(hipEventRecord(d.ev[2], stream));
     HIP_TRY(hipMemcpyAsync(d.h_counter, (const uint64_t *)d.scan_tmp.p + scan_tiles_for(L.n_regions), 8,
                            hipMemcpyDeviceToHost, stream));
+    d.h_counter[1] = 0;
+    if (L.n_slices > 1) HIP_TRY(hipMemcpyAsync(d.h_counter + 1, (const uint32_t *)d.counter.p + 8, 4, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    if (L.n_slices > 1 && (uint32_t)d.h_counter[1] != 0) // a scratch slice filled up: once more with one slice
+        return match_wholeword(a, d, sh, record_kind, d_out, cap, n_out, stream, prof, true);
     *n_out = *d.h_counter;
     if (prof) {
         HIP_TRY(hipEventElapsedTime(&prof->scan_ms, d.ev[0], d.ev[1]));

@@ -723,7 +723,8 @@ __global__ __launch_bounds__(256) void k_ac_verify(DevTables T, TileLaunch L) {
             verify_multi<K, RANGE, HASHK>(c, head, min(rc.y - head, (uint32_t)(kVerifyBatches * kWave)));
         if (lane == 0) L.d_region_counts[region] = c.rank_base;
     }
-    for (uint32_t i = lane; i < c.res_left; i += kWave) store_rec(L, c.res_cur + i, 0, 0, 0, ~0u);
+    for (uint32_t i = lane; i < c.res_left; i += kWave)
+        if (c.res_cur + i < c.slot_limit) store_rec(L, c.res_cur + i, 0, 0, 0, ~0u); // (not into the next slice)
 }
 
 template <int K, bool RANGE, bool WIDE>

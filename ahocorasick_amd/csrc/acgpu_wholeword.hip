@@ -528,7 +528,8 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
         break;
     }
     if (lane == 0) L.d_region_counts[region] = c.rank_base;
-    for (uint32_t i = lane; i < c.res_left; i += kWave) store_rec(L, c.res_cur + i, 0, 0, 0, ~0u);
+    for (uint32_t i = lane; i < c.res_left; i += kWave)
+        if (c.res_cur + i < c.slot_limit) store_rec(L, c.res_cur + i, 0, 0, 0, ~0u); // (not into the next slice)
 }
 
 // Literal restatement of S/WholeWordMatchMap.java:155-240 by ONE lane, for word-character tables that are not

@@ -1076,3 +1076,24 @@ def test_long_keywords_branching_suffixes_and_planted_matches():
             want = Oracle(FAM_AC, kws, case_sensitive=cs, lower=LOWER).match(hay).tolist()
             assert len(want) > 3 * len(kws) - 10
             assert m.find_all(hay).tolist() == want
+
+
+def test_wholeword_scratch_slice_overflow_is_redone_with_one_slice():
+    """WholeWord takes record slots from one scratch slice per workgroup as well: all words in the first workgroup's share,
+    exact capacity -> that slice fills up and the call is redone with one slice."""
+    import torch
+    words = ["ab", "abc", "b", "cab"]
+    a = Automaton(N.MODE_WHOLEWORD, words, True, word_chars=WORD)
+    n = 1 << 22
+    rng = np.random.default_rng(3)
+    hay = np.full(n, ord(" "), dtype=np.uint16)
+    toks = rng.integers(0, len(words), 1 << 16)
+    text = " ".join(words[i] for i in toks)
+    head = np.array([ord(c) for c in text], dtype=np.uint16)
+    hay[: head.size] = head
+    from oracle.oracle import FAM_WHOLEWORD
+    want = Oracle(FAM_WHOLEWORD, words, word_chars=WORD).match(hay)
+    assert len(want) == 1 << 16
+    d_hay = torch.from_numpy(hay.view(np.int16)).cuda()
+    got, _ = _dev_match(a, d_hay, n, True, len(want))
+    assert got.shape == want.shape and (got == want).all()
