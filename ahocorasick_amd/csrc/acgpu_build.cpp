@@ -381,13 +381,62 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
             t.tile_lut.assign(65536, 0);
             for (uint32_t raw = 0; raw < 65536; raw++) t.tile_lut[raw] = (uint16_t)bucket_of[t.lower[raw]];
         }
-        const uint32_t n = t.hashk ? 64 : t.n_cls;
+        // folded range classes (see HostTables::fold_range)
+        t.fold_range = false;
+        if (!t.cs && !t.hashk && !t.range_cls && !tunables().force_sparse) {
+            uint32_t minu = 65535, maxu = 0;
+            for (uint32_t i = 1; i < N; i++) {
+                minu = std::min<uint32_t>(minu, nodes[i].unit);
+                maxu = std::max<uint32_t>(maxu, nodes[i].unit);
+            }
+            const uint32_t span = maxu - minu + 1;
+            bool ok = N > 1 && span <= 31;
+            for (uint32_t u = minu; ok && u <= maxu; u++) ok = t.lower[u] == u; // the range folds onto itself
+            if (ok) {
+                std::vector<uint32_t> pre; // raw units outside the range that fold into it
+                std::vector<uint32_t> votes(65536, 0);
+                uint32_t delta = 0, best = 0;
+                for (uint32_t raw = 0; raw < 65536; raw++) {
+                    const uint32_t f = t.lower[raw];
+                    if ((raw < minu || raw > maxu) && f >= minu && f <= maxu) {
+                        pre.push_back(raw);
+                        const uint32_t dlt = (f - raw) & 0xffffu;
+                        if (++votes[dlt] > best) { best = votes[dlt]; delta = dlt; }
+                    }
+                }
+                // partner range: unit u of it folds to u + delta (none: the range stands for itself a second time)
+                uint32_t base2 = minu;
+                if (!pre.empty()) {
+                    const int64_t b2 = (int64_t)minu - (int64_t)(int16_t)delta;
+                    ok = b2 >= 0 && b2 + span <= 65536 && (b2 + span <= minu || b2 > maxu);
+                    base2 = (uint32_t)b2;
+                    for (uint32_t i = 0; ok && i < span; i++) ok = t.lower[base2 + i] == minu + i;
+                }
+                // everything else that folds into the range must lie beyond the low zone that holds both ranges
+                uint32_t bits = 0;
+                while (bits < 16 && (1u << bits) <= std::max(maxu, base2 + span - 1)) bits++;
+                const uint32_t himask = (0xffffu << bits) & 0xffffu;
+                for (size_t i = 0; ok && i < pre.size(); i++)
+                    if (pre[i] < base2 || pre[i] >= base2 + span) ok = (pre[i] & himask) != 0;
+                if (ok) {
+                    t.fold_range = true;
+                    t.fr_base = minu; t.fr_span = span; t.fr_base2 = base2; t.fr_himask = himask;
+                    t.tile_lut.assign(65536, (uint16_t)span);
+                    for (uint32_t raw = 0; raw < 65536; raw++) {
+                        const uint32_t f = t.lower[raw];
+                        if (f >= minu && f <= maxu) t.tile_lut[raw] = (uint16_t)(f - minu);
+                    }
+                }
+            }
+        }
+        const uint32_t n = t.hashk ? 64 : t.fold_range ? t.fr_span + 1 : t.n_cls;
         t.filt_n = n;
-        t.filt_other = (!t.hashk && t.range_cls) ? t.cls_span : 0;
+        t.filt_other = t.hashk ? 0 : t.fold_range ? t.fr_span : t.range_cls ? t.cls_span : 0;
         t.filt_row_bytes = n <= 32 ? 4 : 8;
         auto tcls = [&](uint16_t folded_unit) -> uint32_t {
             if (t.hashk) return bucket_of[folded_unit];
-            if (t.range_cls) return (uint32_t)folded_unit - t.cls_base; // only called on keyword units: inside the range
+            if (t.fold_range) return (uint32_t)folded_unit - t.fr_base; // only called on keyword units: inside the range
+            if (t.range_cls) return (uint32_t)folded_unit - t.cls_base;
             return cls_of[folded_unit];
         };
         uint32_t K = 1;
@@ -493,7 +542,7 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
                 // node of a depth in [K, D), is a key
                 t.l2_depth = 0;
                 t.l2_bloom.clear();
-                if (!t.hashk && t.range_cls && n <= 32 && K >= 2 && K <= 5) {
+                if (!t.hashk && (t.range_cls || t.fold_range) && n <= 32 && K >= 2 && K <= 5) {
                     const uint32_t D = std::min<uint32_t>(K + 2, 6);
                     t.l2_bloom.assign(kL2Words, 0);
                     for (uint32_t i = 1; i < RN; i++) {

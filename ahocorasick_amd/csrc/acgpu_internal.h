@@ -130,7 +130,15 @@ struct HostTables {
     // filter is a superset test and a class K-gram no longer names one K-gram of units.  The verification then looks the
     // K units themselves up (kg_keys/kg_vals: packed folded units -> flagged ref of the depth-K reverse node, open
     // addressing) and walks the reversed trie through its hashed, unit-keyed edges only.
-    // second-level (Bloom) filter of the tile kernel: see l2_key; l2_depth = D, 0 = not built
+    // Folded range classes (tile kernel, case-insensitive dictionaries whose folded keyword units span at most 31 code
+    // points): tile class = lower[unit] - fr_base inside the range, fr_span outside ("other").  The raw units that fold
+    // into the range are the range itself, a partner range of the same length (fr_base2: the other case, every unit of
+    // it folds to its opposite number) and a few exceptions (U+0130 -> i, U+212A -> k ...), all of which have a bit of
+    // fr_himask set -- so the packed filter computes classes from the two ranges and takes the class table (tile_lut)
+    // for a tile only when some unit of it has such a bit.
+    bool fold_range = false;
+    uint32_t fr_base = 0, fr_span = 0, fr_base2 = 0, fr_himask = 0;
+    // second-level (Bloom) filter of the tile kernel: see l2_gram; l2_depth = D, 0 = not built
     uint32_t l2_depth = 0;
     std::vector<uint32_t> l2_bloom; // kL2Words
     double l2_density = 0;          // fraction of set bits
@@ -183,6 +191,7 @@ struct DevTables {
     int32_t hashk;             // 1: bucketed tile classes, K-gram looked up by its units (see HostTables)
     const uint32_t *l2_bloom;  // second-level filter (kL2Words words) or nullptr
     uint32_t l2_depth;
+    uint32_t fold_range, fr_base, fr_span, fr_base2, fr_himask; // see HostTables::fold_range
     const uint16_t *tile_lut;  // tile classes of the LUT mode (cls_lut, or the bucket table)
     const uint64_t *kg_keys;
     const uint32_t *kg_vals;

@@ -490,10 +490,31 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                     // dword D of the 8 previous units (D < 4) and of the lane's own units (D >= 4) as packed classes;
                     // MM[D] = the pair of units (2D-1, 2D), i.e. the misaligned neighbour of CC[D]
                     constexpr int ND = 4 + 4 * kAcVec;
-                    const uint32_t base2 = T.cls_base * 0x10001u, span2 = T.cls_span * 0x10001u, n2 = n * 0x10001u;
+                    // RANGE: class = min(unit - base, span).  Otherwise folded range classes (DevTables::fold_range): the
+                    // smaller of that and the same thing for the partner range; a tile in which some unit has a bit of
+                    // fr_himask (the few other units that fold into the range all do) takes the class table instead
+                    const uint32_t base2 = (RANGE ? T.cls_base : T.fr_base) * 0x10001u, span2 = (RANGE ? T.cls_span : T.fr_span) * 0x10001u;
+                    const uint32_t baseB2 = T.fr_base2 * 0x10001u, n2 = n * 0x10001u;
+                    bool by_table = false;
+                    if (!RANGE && T.fr_himask != 0) {
+                        uint32_t any_bits = 0;
+#pragma unroll
+                        for (int D = 4 - NP; D < 4; ++D) any_bits |= pp[D];
+#pragma unroll
+                        for (int q = 0; q < 4 * kAcVec; ++q) any_bits |= ww[q];
+                        by_table = __any((any_bits & (T.fr_himask * 0x10001u)) != 0);
+                    }
+                    auto classes_of = [&](uint32_t units2) -> uint32_t {
+                        if (RANGE) return pk_class(units2, base2, span2);
+                        if (by_table) return (uint32_t)T.tile_lut[units2 & 0xffffu] | ((uint32_t)T.tile_lut[units2 >> 16] << 16);
+                        const uint32_t c1 = pk_class(units2, base2, span2), c2 = pk_class(units2, baseB2, span2);
+                        uint32_t r;
+                        asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(c1), "v"(c2));
+                        return r;
+                    };
                     uint32_t CC[ND], MM[ND], B8[ND / 2];
 #pragma unroll
-                    for (int D = 4 - NP; D < 4; ++D) CC[D] = pk_class(pp[D], base2, span2);
+                    for (int D = 4 - NP; D < 4; ++D) CC[D] = classes_of(pp[D]);
 #pragma unroll
                     for (int D = 4 - NP + 1; D < 4; ++D) MM[D] = __builtin_amdgcn_alignbit(CC[D], CC[D - 1], 16);
                     if (L2) { // classes of the 8 units before the tile, one byte each (see below)
@@ -509,7 +530,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                     for (int u = 0; u < kAcVec; ++u) {
 #pragma unroll
                         for (int D = 4 + 4 * u; D < 8 + 4 * u; ++D) {
-                            CC[D] = pk_class(ww[D - 4], base2, span2);
+                            CC[D] = classes_of(ww[D - 4]);
                             MM[D] = __builtin_amdgcn_alignbit(CC[D], CC[D - 1], 16);
                         }
 #pragma unroll
@@ -772,18 +793,20 @@ static hipError_t launch_tile_hashk(const DevTables &t, const TileLaunch &l, hip
 
 // the packed 16-bit filter: range classes, 4-byte rows, row index below 2^16 (l.debug & 1024 keeps the scalar filter: A/B)
 static bool tile_pk_usable(const DevTables &t, const TileLaunch &l) {
-    if (!t.range_cls || t.filt_row_bytes != 4 || t.filt_k < 2 || t.hashk || (l.debug & 1024u)) return false;
+    if (!(t.range_cls || t.fold_range) || t.filt_row_bytes != 4 || t.filt_k < 2 || t.hashk || (l.debug & 1024u)) return false;
     uint64_t rows = 1;
     for (uint32_t i = 0; i + 1 < t.filt_k; ++i) rows *= t.filt_n;
-    return rows <= 65536 && t.cls_base + t.cls_span <= 65536;
+    if (rows > 65536) return false;
+    if (t.range_cls) return t.cls_base + t.cls_span <= 65536;
+    return t.fr_base + t.fr_span <= 65536 && t.fr_base2 + t.fr_span <= 65536;
 }
 
-template <int K>
+template <int K, bool RANGE>
 static hipError_t launch_tile_pk(const DevTables &t, const TileLaunch &l, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ac_tile<K, true, false, false, false, true>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ac_tile<K, RANGE, false, false, false, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_ac_tile<K, true, false, false, false, true>), dim3(l.grid), dim3(l.block), l.lds_bytes, stream, t, l);
+    hipLaunchKernelGGL((k_ac_tile<K, RANGE, false, false, false, true>), dim3(l.grid), dim3(l.block), l.lds_bytes, stream, t, l);
     return hipGetLastError();
 }
 
@@ -793,13 +816,13 @@ static bool tile_l2_usable(const DevTables &t, const TileLaunch &l) {
            t.filt_words <= (uint32_t)kFilterWordsL2 && !(l.debug & 2048u);
 }
 
-template <int K>
+template <int K, bool RANGE>
 static hipError_t launch_tile_l2(const DevTables &t, const TileLaunch &l, hipStream_t stream) {
     const size_t lds = tile_l2_lds_bytes(l.block);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ac_tile<K, true, false, false, false, true, true>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ac_tile<K, RANGE, false, false, false, true, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_ac_tile<K, true, false, false, false, true, true>), dim3(l.grid), dim3(l.block), lds, stream, t, l);
+    hipLaunchKernelGGL((k_ac_tile<K, RANGE, false, false, false, true, true>), dim3(l.grid), dim3(l.block), lds, stream, t, l);
     return hipGetLastError();
 }
 
@@ -825,26 +848,27 @@ hipError_t launch_ac_tile(const DevTables &t, const TileLaunch &l, hipStream_t s
         default: return hipErrorInvalidValue;
         }
     }
+    const char *rg = t.range_cls ? "true" : "false";
     if (tile_l2_usable(t, l)) {
-        std::snprintf(name, sizeof(name), "k_ac_tile<%u, true, false, false, false, true, true>", t.filt_k);
+        std::snprintf(name, sizeof(name), "k_ac_tile<%u, %s, false, false, false, true, true>", t.filt_k, rg);
         switch (t.filt_k) {
-        case 2: return launch_tile_l2<2>(t, l, stream);
-        case 3: return launch_tile_l2<3>(t, l, stream);
-        case 4: return launch_tile_l2<4>(t, l, stream);
-        case 5: return launch_tile_l2<5>(t, l, stream);
+        case 2: return t.range_cls ? launch_tile_l2<2, true>(t, l, stream) : launch_tile_l2<2, false>(t, l, stream);
+        case 3: return t.range_cls ? launch_tile_l2<3, true>(t, l, stream) : launch_tile_l2<3, false>(t, l, stream);
+        case 4: return t.range_cls ? launch_tile_l2<4, true>(t, l, stream) : launch_tile_l2<4, false>(t, l, stream);
+        case 5: return t.range_cls ? launch_tile_l2<5, true>(t, l, stream) : launch_tile_l2<5, false>(t, l, stream);
         default: return hipErrorInvalidValue;
         }
     }
     if (tile_pk_usable(t, l)) {
-        std::snprintf(name, sizeof(name), "k_ac_tile<%u, true, false, false, false, true>", t.filt_k);
+        std::snprintf(name, sizeof(name), "k_ac_tile<%u, %s, false, false, false, true>", t.filt_k, rg);
         switch (t.filt_k) {
-        case 2: return launch_tile_pk<2>(t, l, stream);
-        case 3: return launch_tile_pk<3>(t, l, stream);
-        case 4: return launch_tile_pk<4>(t, l, stream);
-        case 5: return launch_tile_pk<5>(t, l, stream);
-        case 6: return launch_tile_pk<6>(t, l, stream);
-        case 7: return launch_tile_pk<7>(t, l, stream);
-        case 8: return launch_tile_pk<8>(t, l, stream);
+        case 2: return t.range_cls ? launch_tile_pk<2, true>(t, l, stream) : launch_tile_pk<2, false>(t, l, stream);
+        case 3: return t.range_cls ? launch_tile_pk<3, true>(t, l, stream) : launch_tile_pk<3, false>(t, l, stream);
+        case 4: return t.range_cls ? launch_tile_pk<4, true>(t, l, stream) : launch_tile_pk<4, false>(t, l, stream);
+        case 5: return t.range_cls ? launch_tile_pk<5, true>(t, l, stream) : launch_tile_pk<5, false>(t, l, stream);
+        case 6: return t.range_cls ? launch_tile_pk<6, true>(t, l, stream) : launch_tile_pk<6, false>(t, l, stream);
+        case 7: return t.range_cls ? launch_tile_pk<7, true>(t, l, stream) : launch_tile_pk<7, false>(t, l, stream);
+        case 8: return t.range_cls ? launch_tile_pk<8, true>(t, l, stream) : launch_tile_pk<8, false>(t, l, stream);
         default: return hipErrorInvalidValue;
         }
     }

@@ -1097,3 +1097,33 @@ def test_wholeword_scratch_slice_overflow_is_redone_with_one_slice():
     d_hay = torch.from_numpy(hay.view(np.int16)).cuda()
     got, _ = _dev_match(a, d_hay, n, True, len(want))
     assert got.shape == want.shape and (got == want).all()
+
+
+@pytest.mark.parametrize("min_len", [2, 4, 6])
+def test_case_insensitive_folded_range_classes(min_len):
+    """Case-insensitive dictionaries over a short range of letters take the packed filter with FOLDED range classes: the
+    range, its partner range of the other case, and the class table for tiles that hold units beyond the low zone -- where
+    U+0130 (folds to i) and U+212A (folds to k) live.  Haystacks with and without such units, keywords given in mixed case."""
+    import torch
+    rng = np.random.default_rng(500 + min_len)
+    low = list(range(ord("a"), ord("k") + 1))
+    for hay_alpha in (low + [c - 32 for c in low], low + [c - 32 for c in low] + [0x0130, 0x212A, 0x00E9, 0x4E2D, ord(" ")]):
+        hay, kws = rand_case(rng, low, 40, min_len + 6, 150001, min_len=min_len)
+        hay = np.asarray(hay_alpha, dtype=np.uint16)[rng.integers(0, len(hay_alpha), hay.size)]
+        kws = [np.where(rng.integers(0, 2, k.size) == 1, k - 32, k).astype(np.uint16) for k in kws]  # mixed-case keywords
+        pos = 0
+        for k in kws:  # plant them, some through the fold exceptions
+            u = k.copy()
+            if 0x0130 in hay_alpha:
+                u[(u | 32) == ord("i")] = 0x0130 if pos % 2 else ord("I")
+                u[(u | 32) == ord("k")] = 0x212A if pos % 3 else ord("k")
+            if pos + u.size < hay.size:
+                hay[pos:pos + u.size] = u
+            pos += u.size + 50
+        m = AhoCorasickMap(kws, _ids(len(kws)), False)
+        want = Oracle(FAM_AC, kws, case_sensitive=False, lower=LOWER).match(hay)
+        d_hay = torch.from_numpy(hay.view(np.int16)).cuda()
+        got, prof = _dev_match(m.automaton, d_hay, hay.size, True, len(want) + 8, profile=True)
+        args = prof["scan_kernel"].split("<")[1].rstrip(">").split(", ")
+        assert args[1] == "false" and len(args) >= 6 and args[5] == "true", prof["scan_kernel"]  # folded range + packed filter
+        assert len(want) >= 40 and got.shape == want.shape and (got == want).all()

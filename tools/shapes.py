@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Development tool: scan time of config 2's haystack (2^29 units) under dictionaries of other shapes -- which form of the
+tile kernel each one gets and what it costs."""
+import ctypes, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ahocorasick_amd import _native as N, synth
+from ahocorasick_amd.strings import Automaton
+
+n = 1 << 29
+kws = synth.config_keywords("C2")
+d_hay = torch.empty(n, dtype=torch.int16, device="cuda")
+tab = np.ascontiguousarray(synth.ALPHA_LOWER)
+N.check(N.lib().acgpu_synth_fill(d_hay.data_ptr(), n, 0, synth.CONFIGS["C2"]["hay_seed"], tab.ctypes.data_as(ctypes.c_void_p), len(tab), None), "synth")
+torch.cuda.synchronize()
+cap = n // 64
+d_out = torch.empty((cap, 3), dtype=torch.int32, device="cuda")
+rng = np.random.default_rng(1)
+def upper_some(k):
+    k = np.array(k, dtype=np.uint16).copy()
+    m = rng.integers(0, 2, k.size).astype(bool)
+    k[m] -= 32
+    return k
+shapes = {
+    "C2 case-sensitive (range classes)": (kws, True),
+    "C2 case-insensitive (LUT classes)": (kws, False),
+    "C2 mixed-case keywords, case-sensitive (52 classes, wide rows)": ([upper_some(k) for k in kws], True),
+    "1000 keywords len 3-8 (K=3)": (synth.random_keywords(7, 1000, 3, 8), True),
+    "100 keywords len 2-6 (K=2)": (synth.random_keywords(8, 100, 2, 6), True),
+    "30k keywords len 4-12": (synth.random_keywords(9, 30000, 4, 12), True),
+}
+for name, (k, cs) in shapes.items():
+    a = Automaton(N.MODE_ALL, k, cs)
+    ts = []
+    for r in range(6):
+        nout, rc, prof, _ = a.match_device(d_hay.data_ptr(), n, True, d_out.data_ptr(), cap, stream=torch.cuda.current_stream().cuda_stream, profile=True)
+        if r: ts.append(prof["scan_ms"])
+    info = a.info()
+    print("%-62s %.3f ms  n_out=%d rc=%d K=%d dens=%.4f %s" % (name, float(np.median(ts)), nout, rc, info["filter_k"], info["filter_density"], prof["scan_kernel"]), flush=True)
