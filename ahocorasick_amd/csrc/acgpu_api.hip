@@ -348,6 +348,12 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
                 }
             }
         }
+#ifdef ACGPU_TIMING
+        static DevBuf timing;
+        if ((rc = timing.ensure((size_t)L.grid * 16 * 8 * 8))) return rc;
+        HIP_TRY(hipMemsetAsync(timing.p, 0, (size_t)L.grid * 16 * 8 * 8, stream));
+        L.d_timing = (unsigned long long *)timing.p;
+#endif
         if (timed) HIP_TRY(hipEventRecord(ev[0], stream));
         if (split) {
             HIP_TRY(launch_ac_filter(d.T, L, stream, &kname));
@@ -357,6 +363,17 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
             HIP_TRY(launch_ac_tile(d.T, L, stream, &kname));
             if (timed) HIP_TRY(hipEventRecord(ev[1], stream));
         }
+#ifdef ACGPU_TIMING
+        if (!tk && !split) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            std::vector<unsigned long long> h((size_t)L.grid * 16 * 8);
+            HIP_TRY(hipMemcpy(h.data(), timing.p, h.size() * 8, hipMemcpyDeviceToHost));
+            double sum[8] = {0}, mx0 = 0; size_t nw = 0;
+            for (size_t w = 0; w < h.size() / 8; ++w) { if (!h[w * 8]) continue; nw++; for (int i = 0; i < 8; ++i) sum[i] += (double)h[w * 8 + i]; mx0 = std::max(mx0, (double)h[w * 8]); }
+            if (nw) fprintf(stderr, "[timing] waves %zu  total avg %.0f max %.0f | stream wait %.0f | drain %.0f (%.1f calls) | filter+L2 %.0f | passes %.1f  (s_memtime ticks, 100 MHz)\n",
+                            nw, sum[0] / nw, mx0, sum[1] / nw, sum[2] / nw, sum[5] / nw, sum[3] / nw, sum[4] / nw);
+        }
+#endif
         n_chunks = L.n_regions;
         chunk_units = L.region_units;
         scanned = own_len;

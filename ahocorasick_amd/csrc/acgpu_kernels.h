@@ -59,6 +59,7 @@ struct TileLaunch {
     uint2 *d_region_cands;
     uint32_t *d_overflow;
     int verify_grid;
+    unsigned long long *d_timing; // -DACGPU_TIMING builds only: 8 cycle counters per wave (tools/build_variant.sh timing)
     uint32_t debug; // ablation switches (tunable "tile_debug"): 1 = drop candidates unverified, 4 = no filter arithmetic
                     // at all (stream + reduce only), 8 = verification without the text-window load, 16 = without the
                     // K-gram node load, 32 = no record emission, 64 = no walk beyond the K-gram node, 128 = records

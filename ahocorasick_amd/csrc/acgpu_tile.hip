@@ -324,7 +324,13 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned char *rows8 = reinterpret_cast<const unsigned char *>(rows32);
     uint32_t *cand_all = reinterpret_cast<uint32_t *>(smem);
-    for (uint32_t i = threadIdx.x; i < T.filt_words; i += blockDim.x) rows32[i] = T.filt_bits[i];
+    { // the filter rows, 16 bytes per thread and step (the kernel does not stream before this is done)
+        const uint32_t n4 = T.filt_words / 4;
+        const uint4 *src4 = reinterpret_cast<const uint4 *>(T.filt_bits);
+        uint4 *dst4 = reinterpret_cast<uint4 *>(rows32);
+        for (uint32_t i = threadIdx.x; i < n4; i += blockDim.x) dst4[i] = src4[i];
+        for (uint32_t i = n4 * 4 + threadIdx.x; i < T.filt_words; i += blockDim.x) rows32[i] = T.filt_bits[i];
+    }
     constexpr int D2 = K + 2 < 6 ? K + 2 : 6; // depth of the second-level filter
     // tile geometry of this variant (the names hide the namespace-scope defaults)
     constexpr int kAcVec = L2 ? kL2Vec : acgpu::kAcVec;
@@ -339,7 +345,9 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
     unsigned char *tb = smem + (kTileBlock / kWave) * kL2Cap * 4 + wave_in_block * kTbBytes;
     uint16_t *fresh = reinterpret_cast<uint16_t *>(smem + (kTileBlock / kWave) * (kL2Cap * 4 + kTbBytes)) + wave_in_block * kL2Fresh;
     uint32_t *bloom = reinterpret_cast<uint32_t *>(smem + (kTileBlock / kWave) * kL2WaveBytes);
-    if (L2) for (uint32_t i = threadIdx.x; i < kL2Words; i += blockDim.x) bloom[i] = T.l2_bloom[i];
+    if (L2) for (uint32_t i = threadIdx.x; i < kL2Words / 4; i += blockDim.x)
+        reinterpret_cast<uint4 *>(bloom)[i] = reinterpret_cast<const uint4 *>(T.l2_bloom)[i];
+    static_assert(kL2Words % 4 == 0, "Bloom words are copied 16 bytes at a time");
     __syncthreads();
 
     const uint32_t lane = lane_id();
@@ -403,6 +411,16 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                 nxt[d][u] = stream_load(hay + min(tile + d * kAcTileUnits + lane * kAcLaneUnits + u * 8, last_vec));
     }
 
+#ifdef ACGPU_TIMING
+    // instrumented build (tools/build_variant.sh timing -DACGPU_TIMING): where a wave's time goes, in s_memtime ticks
+    unsigned long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // 0 total, 1 wait for the stream, 2 drains, 3 filter + second level, 4 passes, 5 drain calls
+    const unsigned long long tm_start = clock64();
+#define TM_BEGIN const unsigned long long tm_t0 = clock64()
+#define TM_END(i) tm[i] += clock64() - tm_t0
+#else
+#define TM_BEGIN
+#define TM_END(i)
+#endif
     // One loop, ONE verification site: every pass first drains the candidate queue as far as its state requires
     // (completely at a region seam / before the tail / at the end; down to < 256 otherwise), then does one unit of
     // streaming work.  Keeping the (large) verification code in a single place keeps the kernel small.
@@ -410,6 +428,9 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
         const bool seam = vec_todo ? (!mid && tile >= boundary) : true; // wave-uniform
         const uint32_t keep = SPLIT ? ~0u : (seam ? 1u : (uint32_t)(kVerifyBatches * kWave));
         if (vec_todo && !mid) {
+#ifdef ACGPU_TIMING
+            { TM_BEGIN; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TM_END(1); tm[4]++; }
+#endif
             // take over the prefetched group FIRST: this wait also covers the record stores of the previous pass's
             // verification (gfx950 counts stores in vmcnt), which have had a whole tile group of time to finish
 #pragma unroll
@@ -417,7 +438,14 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
 #pragma unroll
                 for (int u = 0; u < kAcVec; ++u) grp[d][u] = nxt[d][u];
         }
-        if (!SPLIT && c.cand_n >= keep && c.cand_n != 0) drain<K, RANGE, HASHK>(c, keep);
+        if (!SPLIT && c.cand_n >= keep && c.cand_n != 0) {
+            TM_BEGIN;
+            drain<K, RANGE, HASHK>(c, keep);
+            TM_END(2);
+#ifdef ACGPU_TIMING
+            tm[5]++;
+#endif
+        }
 
         if (vec_todo) {
             if (!mid) {
@@ -441,6 +469,9 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                     for (int u = 0; u < kAcVec; ++u)
                         nxt[d][u] = stream_load(hay + min(tile + (kAcTiles + d) * kAcTileUnits + lane * kAcLaneUnits + u * 8, last_vec));
             }
+#ifdef ACGPU_TIMING
+            const unsigned long long tm_f0 = clock64();
+#endif
             // positions a lane may report: inside the region, in the vector part of the buffer, with K units to their
             // left in the buffer.  Only groups at the edges of a region need the per-lane mask.
             const uint32_t lo = max(rb, (uint32_t)(K - 1));
@@ -677,6 +708,9 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                     lane0 = 0;
                 }
             }
+#ifdef ACGPU_TIMING
+            tm[3] += clock64() - tm_f0;
+#endif
             mid = resume;
             if (!resume) {
                 d0 = 0;
@@ -720,6 +754,11 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
         if (lane == 0) L.d_region_cands[region] = make_uint2(slice_base + region_first, c.cand_n - region_first);
         return;
     }
+#ifdef ACGPU_TIMING
+    tm[0] = clock64() - tm_start;
+    if (lane == 0 && L.d_timing)
+        for (int i = 0; i < 8; ++i) L.d_timing[(size_t)wave_global * 8 + i] = tm[i];
+#endif
     if (lane == 0) L.d_region_counts[region] = c.rank_base;
     // hand back the unused tail of the last reservation as holes the permute pass skips
     for (uint32_t i = lane; i < c.res_left; i += kWave)
