@@ -368,8 +368,16 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
             HIP_TRY(hipStreamSynchronize(stream));
             std::vector<unsigned long long> h((size_t)L.grid * 16 * 8);
             HIP_TRY(hipMemcpy(h.data(), timing.p, h.size() * 8, hipMemcpyDeviceToHost));
-            double sum[8] = {0}, mx0 = 0; size_t nw = 0;
-            for (size_t w = 0; w < h.size() / 8; ++w) { if (!h[w * 8]) continue; nw++; for (int i = 0; i < 8; ++i) sum[i] += (double)h[w * 8 + i]; mx0 = std::max(mx0, (double)h[w * 8]); }
+            double sum[8] = {0}, mx0 = 0, vt[4] = {0, 0, 0, 0}; size_t nw = 0;
+            for (size_t w = 0; w < h.size() / 8; ++w) {
+                if (!h[w * 8]) continue;
+                nw++;
+                for (int i = 0; i < 6; ++i) sum[i] += (double)h[w * 8 + i];
+                vt[0] += (double)(h[w * 8 + 6] & 0xffffffffu); vt[1] += (double)(h[w * 8 + 6] >> 32);
+                vt[2] += (double)(h[w * 8 + 7] & 0xffffffffu); vt[3] += (double)(h[w * 8 + 7] >> 32);
+                mx0 = std::max(mx0, (double)h[w * 8]);
+            }
+            if (nw) fprintf(stderr, "[timing] verification: windows %.0f | K-gram nodes %.0f | walks %.0f | emission %.0f\n", vt[0] / nw, vt[1] / nw, vt[2] / nw, vt[3] / nw);
             if (nw) fprintf(stderr, "[timing] waves %zu  total avg %.0f max %.0f | stream wait %.0f | drain %.0f (%.1f calls) | filter+L2 %.0f | passes %.1f  (s_memtime ticks, 100 MHz)\n",
                             nw, sum[0] / nw, mx0, sum[1] / nw, sum[2] / nw, sum[5] / nw, sum[3] / nw, sum[4] / nw);
         }

@@ -54,7 +54,7 @@ ACGPU_HD inline uint32_t ww_bloom_bit2(uint32_t h, uint32_t mask) { return ((h >
 // read per candidate); a key of length L in [K, D] sets / tests a two-bit pattern of that word, rotated by an amount
 // that depends on L and on the L-K classes in front of the K-gram.  Full-rate 24-bit multiplies only.  Identical on
 // host and device.
-constexpr uint32_t kL2Words = 6144; // 24 KiB of LDS
+constexpr uint32_t kL2Words = 5760; // 22.5 KiB of LDS (what is left next to the rows, the queues and the tile copies)
 ACGPU_HD inline uint32_t l2_mul24(uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); } // v_mul_u32_u24
 ACGPU_HD inline uint32_t l2_gram(const uint32_t *c, uint32_t K) { // the K-gram, one byte per class, text[e-1] highest
     uint32_t g = 0;

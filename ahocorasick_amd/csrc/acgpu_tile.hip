@@ -51,12 +51,12 @@ bool tile_split_supported(const DevTables &t) { return t.filt_k >= 1 && t.filt_w
 // queue of SURVIVORS (kL2Cap), a copy of the current tile as packed classes behind an 8-unit halo (kTbBytes) and the list
 // of the tile's first-level candidates (kL2Fresh tile-relative positions); the Bloom words follow
 constexpr int kFilterWordsL2 = 19712;  // 78848 bytes: 27 classes, K = 4
-constexpr int kL2Cap = 320;
+constexpr int kL2Cap = 256;            // a drain leaves fewer than 128; a tile adds at most 128 through the second level
 constexpr int kL2Fresh = 128;
 constexpr int kL2Vec = 4;              // the L2 form takes 32 units per lane: every per-tile cost is shared by 2048 positions
 constexpr int kL2TileUnits = kWave * 8 * kL2Vec;
 constexpr int kTbBytes = 16 + kL2TileUnits; // one BYTE per class: [8 spare][8 classes before the tile][the tile]
-constexpr size_t kL2WaveBytes = kL2Cap * 4 + kTbBytes + kL2Fresh * 2;
+constexpr size_t kL2WaveBytes = kL2Cap * 4 + kL2Cap * 2 + kTbBytes + kL2Fresh * 2; // queue (info + pos16), tile copy, list
 
 // dynamic LDS only: the candidate queues
 size_t tile_lds_bytes(const DevTables &t, int block_threads) {
@@ -114,7 +114,8 @@ __device__ __forceinline__ uint32_t walk_step(const DevTables &T, uint32_t ref, 
 // wave calls this.  Records carry the reversed-trie NODE id; the permute pass translates it to the keyword id.
 // HASHK: bucketed tile classes (dictionaries with more than 63 distinct units): the K units themselves, folded and packed
 // in text order, are looked up in kg_keys/kg_vals, and every step of the walk goes through the unit-keyed hashed edges.
-template <int K, bool RANGE, bool HASHK = false>
+// QI: queue entries carry the K-gram index and the left neighbour's class (TileCtx::pos16): no text window is read for them.
+template <int K, bool RANGE, bool HASHK = false, bool QI = false>
 __device__ __forceinline__ void verify_multi(TileCtx &c, uint32_t head, uint32_t n_cand) {
     constexpr int NB = kVerifyBatches;
     const DevTables &T = *c.Tp;
@@ -122,19 +123,40 @@ __device__ __forceinline__ void verify_multi(TileCtx &c, uint32_t head, uint32_t
     const uint16_t *hay = L.d_hay;
     const uint32_t lane = lane_id();
     bool act[NB];
-    uint32_t e[NB], ref[NB], ref0[NB], child0[NB], left_unit[NB], d[NB], m[NB], one_len[NB], one_node[NB];
+    uint32_t e[NB], ref[NB], ref0[NB], child0[NB], left_unit[NB], d[NB], m[NB], one_len[NB], one_node[NB], info[NB], lcls[NB];
     Units8 win[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const uint32_t q = b * kWave + lane;
         act[b] = q < n_cand;
-        e[b] = act[b] ? c.cand[head + q] + 1 : 8; // exclusive end
+        if (QI) {
+            e[b] = act[b] ? c.pos_base + (uint32_t)c.pos16[head + q] + 1 : 8;
+            info[b] = act[b] ? c.cand[head + q] : 0u;
+        } else {
+            e[b] = act[b] ? c.cand[head + q] + 1 : 8; // exclusive end
+            info[b] = 0;
+        }
         m[b] = 0; one_len[b] = 0; one_node[b] = 0; d[b] = K; left_unit[b] = 0;
     }
+    bool need_win = true; // wave-uniform: some candidate comes without its K-gram index
+    if (QI) {
+        bool unknown = false;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) unknown |= act[b] && !(info[b] & kQiKnown);
+        need_win = __any(unknown);
+    }
+#ifdef ACGPU_TIMING
+    unsigned long long vt0 = clock64();
+#define VT_MARK(i) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const unsigned long long t_ = clock64(); c.vt[i] += t_ - vt0; vt0 = t_; }
+#else
+#define VT_MARK(i)
+#endif
     // text windows: units e-8 .. e-1 in one unaligned 16-byte load (zeros before the buffer start)
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-        if (e[b] >= 8) {
+        if (!need_win) {
+            win[b] = Units8{{0, 0, 0, 0}};
+        } else if (e[b] >= 8) {
             if (L.debug & 8u) win[b] = Units8{{e[b], e[b] * 3u, e[b] * 5u, e[b] * 7u}}; // ablation: no window load
             else win[b] = *reinterpret_cast<const Units8 *>(hay + e[b] - 8);
         } else {
@@ -145,6 +167,7 @@ __device__ __forceinline__ void verify_multi(TileCtx &c, uint32_t head, uint32_t
             }
         }
     }
+    VT_MARK(0)
     // K-gram index (last unit least significant) -> flagged ref of the depth-K node of the reversed trie
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -152,6 +175,13 @@ __device__ __forceinline__ void verify_multi(TileCtx &c, uint32_t head, uint32_t
 #pragma unroll
         for (int j = 8 - K; j < 8; ++j) idx = __umul24(idx, T.filt_n) + tile_class_t<RANGE>(T, (win[b].d[j >> 1] >> (16 * (j & 1))) & 0xffffu);
         if (K < 8) left_unit[b] = (win[b].d[(7 - K) >> 1] >> (16 * ((7 - K) & 1))) & 0xffffu;
+        lcls[b] = 0;
+        if (QI && (info[b] & kQiKnown)) {
+            idx = info[b] & kQiIdxMask;
+            lcls[b] = (info[b] >> kQiLeftShift) & 31u;
+        } else if (K < 8 && need_win) {
+            lcls[b] = tile_class_t<RANGE>(T, left_unit[b]);
+        }
         uint2 ent = make_uint2(idx & 1u, 0u); // 16: ablation, no K-gram node load
         if (HASHK) {
             ent = make_uint2(0u, 0u);
@@ -181,6 +211,7 @@ __device__ __forceinline__ void verify_multi(TileCtx &c, uint32_t head, uint32_t
         ref0[b] = ent.x;
         child0[b] = ent.y; // the depth-K node's only child, travelling with it
     }
+    VT_MARK(1)
     // leftward walks in lock step; every terminal node met is a keyword ending at e (increasing length)
     for (;;) {
         bool go[NB];
@@ -200,17 +231,29 @@ __device__ __forceinline__ void verify_multi(TileCtx &c, uint32_t head, uint32_t
         for (int b = 0; b < NB; ++b) {
             uint32_t next = 0;
             if (go[b]) {
-                const uint32_t unit = (d[b] == K && K < 8) ? left_unit[b] : (uint32_t)hay[e[b] - 1 - d[b]];
+                const bool first = d[b] == K && K < 8; // the unit in front of the K-gram: known from the window / the queue
+                uint32_t unit = 0, cls;
+                if (first && QI && (info[b] & kQiKnown)) {
+                    cls = lcls[b];
+                    if (!T.rdense) unit = (uint32_t)hay[e[b] - 1 - d[b]]; // (hashed edges are keyed by the unit)
+                } else if (first) {
+                    unit = left_unit[b];
+                    cls = lcls[b];
+                } else {
+                    unit = (uint32_t)hay[e[b] - 1 - d[b]];
+                    cls = tile_class_t<RANGE>(T, unit);
+                }
                 const uint32_t hint = (ref[b] >> kRefHintShift) & kRefHintMask;
                 if (!HASHK && d[b] == K && hint != 0) // first step from a one-child node: no memory access at all
-                    next = (hint - 1 == tile_class_t<RANGE>(T, unit)) ? child0[b] : 0u;
-                else
-                    next = walk_step<RANGE>(T, ref[b], unit);
+                    next = (hint - 1 == cls) ? child0[b] : 0u;
+                else if (hint != 0 && hint - 1 != cls) next = 0u; // (walk_step, with the class already in hand)
+                else next = rchild(T, ref[b] & kRefIdMask, unit, cls);
             }
             ref[b] = next;
             ++d[b];
         }
     }
+    VT_MARK(2)
     // record slots and ranks in text order: batch 0's lanes, then batch 1's, ...
     uint32_t prefix[NB], total = 0;
 #pragma unroll
@@ -250,30 +293,33 @@ __device__ __forceinline__ void verify_multi(TileCtx &c, uint32_t head, uint32_t
         }
     }
     c.rank_base += total;
+    VT_MARK(3)
 }
 
 // drain the candidate queue down to fewer than `keep_below` entries
-template <int K, bool RANGE, bool HASHK>
+template <int K, bool RANGE, bool HASHK, bool QI = false>
 __device__ __forceinline__ void drain(TileCtx &c, uint32_t keep_below) {
     uint32_t head = 0;
     while (c.cand_n > head && c.cand_n - head >= keep_below) {
         const uint32_t nb = min(c.cand_n - head, (uint32_t)(kVerifyBatches * kWave));
-        if (!(c.Lp->debug & 1u)) verify_multi<K, RANGE, HASHK>(c, head, nb);
+        if (!(c.Lp->debug & 1u)) verify_multi<K, RANGE, HASHK, QI>(c, head, nb);
         head += nb;
     }
     if (head) { // move the leftovers (fewer than kVerifyBatches*64) to the front
         const uint32_t left = c.cand_n - head;
-        uint32_t tmp[kVerifyBatches];
+        uint32_t tmp[kVerifyBatches], tmp16[kVerifyBatches];
 #pragma unroll
         for (int b = 0; b < kVerifyBatches; ++b) {
             const uint32_t q = b * kWave + lane_id();
             tmp[b] = q < left ? c.cand[head + q] : 0u;
+            tmp16[b] = (QI && q < left) ? (uint32_t)c.pos16[head + q] : 0u;
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int b = 0; b < kVerifyBatches; ++b) {
             const uint32_t q = b * kWave + lane_id();
             if (q < left) c.cand[q] = tmp[b];
+            if (QI && q < left) c.pos16[q] = (uint16_t)tmp16[b];
         }
         __builtin_amdgcn_wave_barrier();
         c.cand_n = left;
@@ -341,9 +387,11 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
     constexpr int kAcCandCap = kAcTileUnits + kVerifyBatches * kWave;
     constexpr uint32_t kQueueCap = L2 ? kL2Cap : kAcCandCap;
     const uint32_t wave_in_block = threadIdx.x / kWave;
-    // L2: [queues][tile buffers][fresh lists][Bloom words]
-    unsigned char *tb = smem + (kTileBlock / kWave) * kL2Cap * 4 + wave_in_block * kTbBytes;
-    uint16_t *fresh = reinterpret_cast<uint16_t *>(smem + (kTileBlock / kWave) * (kL2Cap * 4 + kTbBytes)) + wave_in_block * kL2Fresh;
+    // L2: [queues: info][queues: pos16][tile buffers][fresh lists][Bloom words]
+    constexpr int kWavesPerBlock = kTileBlock / kWave;
+    uint16_t *pos16_all = reinterpret_cast<uint16_t *>(smem + kWavesPerBlock * kL2Cap * 4);
+    unsigned char *tb = smem + kWavesPerBlock * kL2Cap * 6 + wave_in_block * kTbBytes;
+    uint16_t *fresh = reinterpret_cast<uint16_t *>(smem + kWavesPerBlock * (kL2Cap * 6 + kTbBytes)) + wave_in_block * kL2Fresh;
     uint32_t *bloom = reinterpret_cast<uint32_t *>(smem + (kTileBlock / kWave) * kL2WaveBytes);
     if (L2) for (uint32_t i = threadIdx.x; i < kL2Words / 4; i += blockDim.x)
         reinterpret_cast<uint4 *>(bloom)[i] = reinterpret_cast<const uint4 *>(T.l2_bloom)[i];
@@ -353,6 +401,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
     const uint32_t lane = lane_id();
     const uint32_t wave_global = blockIdx.x * (kTileBlock / kWave) + wave_in_block;
     TileCtx c{&T, &L, SPLIT ? L.d_cands + (size_t)wave_global * L.cands_per_wave : cand_all + wave_in_block * kQueueCap, 0, 0, 0u, 0};
+    if (L2) c.pos16 = pos16_all + wave_in_block * kL2Cap;
     uint32_t lane0 = 0; // L2: lanes below it have been enqueued already (a dense tile taken in pieces); wave-uniform
     const uint32_t slice_base = SPLIT ? wave_global * L.cands_per_wave : 0u; // (< 2^32: the host sizes the slices)
     uint32_t region_first = 0; // SPLIT: index (inside the slice) of the current region's first candidate
@@ -385,6 +434,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
     uint32_t boundary = base8 + (region + 1) * R; // first tile of the next region
     uint32_t rb = span_begin;
     uint32_t re = min(span_end, boundary);
+    c.pos_base = boundary - R; // L2: queue positions are relative to the start of the current region
     uint32_t tile = base8 + first_region * R;
 
     bool vec_todo = tile < hi;          // tile groups left in the vector part of the span
@@ -440,7 +490,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
         }
         if (!SPLIT && c.cand_n >= keep && c.cand_n != 0) {
             TM_BEGIN;
-            drain<K, RANGE, HASHK>(c, keep);
+            drain<K, RANGE, HASHK, L2>(c, keep);
             TM_END(2);
 #ifdef ACGPU_TIMING
             tm[5]++;
@@ -459,6 +509,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                     c.rank_base = 0;
                     ++region;
                     rb = boundary;
+                    c.pos_base = boundary;
                     boundary += R;
                     re = min(span_end, boundary);
                 }
@@ -671,7 +722,14 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                         }
                         pass = (pass || (L.debug & 4096u)) && act; // 4096: ablation, the second level passes everything
                         const uint64_t bal = __ballot(pass);
-                        if (pass) c.cand[c.cand_n + (uint32_t)__popcll(bal & lanemask_lt())] = cur + p;
+                        if (pass) { // the entry: position in the region, K-gram index (oldest unit most significant), left class
+                            const uint32_t at = c.cand_n + (uint32_t)__popcll(bal & lanemask_lt());
+                            uint32_t idx = 0;
+#pragma unroll
+                            for (int j = K - 1; j >= 0; --j) idx = __umul24(idx, n) + cls[j];
+                            c.pos16[at] = (uint16_t)(cur + p - c.pos_base);
+                            c.cand[at] = kQiKnown | (cls[K] << kQiLeftShift) | idx;
+                        }
                         c.cand_n += (uint32_t)__popcll(bal);
                     }
                     __builtin_amdgcn_wave_barrier();
@@ -691,7 +749,8 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                     uint32_t slot = c.cand_n + incl - cnt, m = lane < nl ? mask : 0u;
                     while (__any(m != 0)) {
                         if (m != 0) {
-                            c.cand[slot++] = v + (uint32_t)__builtin_ctz(m);
+                            c.pos16[slot] = (uint16_t)(v + (uint32_t)__builtin_ctz(m) - c.pos_base);
+                            c.cand[slot++] = 0u; // (no K-gram index: the verification reads the text window)
                             m &= m - 1;
                         }
                     }
@@ -731,6 +790,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                 }
                 c.rank_base = 0;
                 ++region;
+                c.pos_base = boundary;
             }
             if (SPLIT && c.cand_n + kWave > L.cands_per_wave) {
                 if (lane == 0) atomicOr(L.d_overflow, 1u);
@@ -745,7 +805,18 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                 const uint32_t word = rows32[hrow * (ROWB / 4) + (last >> 5)];
                 mask = (word >> (last & 31)) & 1u;
             }
-            enqueue(c, mask, pos); // one position per lane: lane order is text order
+            if (L2) { // (queue entries without a K-gram index: the verification reads their text window)
+                const uint64_t bal = __ballot(mask != 0);
+                if (mask != 0) {
+                    const uint32_t at = c.cand_n + (uint32_t)__popcll(bal & lanemask_lt());
+                    c.pos16[at] = (uint16_t)(pos - c.pos_base);
+                    c.cand[at] = 0u;
+                }
+                c.cand_n += (uint32_t)__popcll(bal);
+                __builtin_amdgcn_wave_barrier();
+            } else {
+                enqueue(c, mask, pos); // one position per lane: lane order is text order
+            }
             continue;
         }
         break;
@@ -757,7 +828,11 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
 #ifdef ACGPU_TIMING
     tm[0] = clock64() - tm_start;
     if (lane == 0 && L.d_timing)
+    {
         for (int i = 0; i < 8; ++i) L.d_timing[(size_t)wave_global * 8 + i] = tm[i];
+        L.d_timing[(size_t)wave_global * 8 + 6] = c.vt[0] | (c.vt[1] << 32);
+        L.d_timing[(size_t)wave_global * 8 + 7] = c.vt[2] | (c.vt[3] << 32);
+    }
 #endif
     if (lane == 0) L.d_region_counts[region] = c.rank_base;
     // hand back the unused tail of the last reservation as holes the permute pass skips
@@ -851,8 +926,10 @@ static hipError_t launch_tile_pk(const DevTables &t, const TileLaunch &l, hipStr
 
 // the PK form with the second-level filter (l.debug & 2048 keeps the one-level form: A/B)
 static bool tile_l2_usable(const DevTables &t, const TileLaunch &l) {
-    return tile_pk_usable(t, l) && t.l2_bloom != nullptr && t.l2_depth != 0 && t.filt_k <= 5 &&
-           t.filt_words <= (uint32_t)kFilterWordsL2 && !(l.debug & 2048u);
+    uint64_t grams = 1; // queue entries hold the K-gram index in 20 bits and the position in its region in 16
+    for (uint32_t i = 0; i < t.filt_k; ++i) grams *= t.filt_n;
+    return tile_pk_usable(t, l) && t.l2_bloom != nullptr && t.l2_depth != 0 && t.filt_k <= 5 && grams <= (1u << 20) &&
+           l.region_units <= 65536u && t.filt_words <= (uint32_t)kFilterWordsL2 && !(l.debug & 2048u);
 }
 
 template <int K, bool RANGE>

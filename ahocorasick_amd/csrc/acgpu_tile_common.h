@@ -30,6 +30,15 @@ struct TileCtx {
     uint32_t res_cur;   // wave-uniform: next free reserved scratch slot (scratch capacity < 2^32)
     uint32_t res_left;          // wave-uniform: reserved slots left
     uint32_t slot_limit = 0;    // wave-uniform: end of this workgroup's scratch slice (set by the first reservation)
+    // L2 form of the AhoCorasick kernel: a queue entry is a position RELATIVE to pos_base (the start of the current region:
+    // the queue is drained at every region seam) in pos16[], and in cand[] what the second-level stage already knew about
+    // the candidate: kQiKnown | class of the unit in front of the K-gram << 20 | K-gram index -- with it the verification
+    // goes straight to the K-gram node (0: not known, the verification reads the text window first)
+    uint16_t *pos16 = nullptr;
+    uint32_t pos_base = 0;
+#ifdef ACGPU_TIMING
+    unsigned long long vt[4] = {0, 0, 0, 0}; // verification phases: windows, K-gram nodes, walks, emission
+#endif
 };
 
 __device__ __forceinline__ void store_rec(const TileLaunch &L, uint32_t slot, uint32_t start, uint32_t end, uint32_t id,
@@ -47,6 +56,8 @@ __device__ __forceinline__ void store_rec(const TileLaunch &L, uint32_t slot, ui
 #endif
     }
 }
+
+constexpr uint32_t kQiKnown = 0x80000000u, kQiIdxMask = 0xfffffu, kQiLeftShift = 20;
 
 // wave64 inclusive prefix sum with DPP row shifts and row broadcasts (6 dependent v_add_u32_dpp)
 __device__ __forceinline__ uint32_t wave_inclusive_scan_dpp(uint32_t x) {
