@@ -377,6 +377,25 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
                 vt[2] += (double)(h[w * 8 + 7] & 0xffffffffu); vt[3] += (double)(h[w * 8 + 7] >> 32);
                 mx0 = std::max(mx0, (double)h[w * 8]);
             }
+            { // spread of the waves' durations: per XCD (workgroup modulo 8) and per workgroup
+                double xs[8] = {0}, xm[8] = {0}; size_t xn[8] = {0}; double bmin = 1e30, bmax = 0, wmin = 1e30;
+                for (size_t b = 0; b < (size_t)L.grid; ++b) {
+                    double bs = 0; size_t bn = 0;
+                    for (size_t w = b * 16; w < b * 16 + 16; ++w) if (h[w * 8]) { bs += (double)h[w * 8]; bn++; xm[b % 8] = std::max(xm[b % 8], (double)h[w * 8]); wmin = std::min(wmin, (double)h[w * 8]); }
+                    if (!bn) continue;
+                    xs[b % 8] += bs; xn[b % 8] += bn;
+                    bmin = std::min(bmin, bs / bn); bmax = std::max(bmax, bs / bn);
+                }
+                fprintf(stderr, "[timing] wave min %.0f; workgroup averages %.0f .. %.0f; per XCD avg/max:", wmin, bmin, bmax);
+                for (int x = 0; x < 8; ++x) if (xn[x]) fprintf(stderr, " %.0f/%.0f", xs[x] / xn[x], xm[x]);
+                fprintf(stderr, "\n[timing] by wave slot in the workgroup:");
+                for (size_t sl = 0; sl < 16; ++sl) {
+                    double a = 0; size_t n2 = 0;
+                    for (size_t b = 0; b < (size_t)L.grid; ++b) if (h[(b * 16 + sl) * 8]) { a += (double)h[(b * 16 + sl) * 8]; n2++; }
+                    fprintf(stderr, " %.0f", n2 ? a / n2 : 0.0);
+                }
+                fprintf(stderr, "\n");
+            }
             if (nw) fprintf(stderr, "[timing] verification: windows %.0f | K-gram nodes %.0f | walks %.0f | emission %.0f\n", vt[0] / nw, vt[1] / nw, vt[2] / nw, vt[3] / nw);
             if (nw) fprintf(stderr, "[timing] waves %zu  total avg %.0f max %.0f | stream wait %.0f | drain %.0f (%.1f calls) | filter+L2 %.0f | passes %.1f  (s_memtime ticks, 100 MHz)\n",
                             nw, sum[0] / nw, mx0, sum[1] / nw, sum[2] / nw, sum[5] / nw, sum[3] / nw, sum[4] / nw);

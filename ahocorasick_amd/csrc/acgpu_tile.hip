@@ -440,6 +440,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
     bool vec_todo = tile < hi;          // tile groups left in the vector part of the span
     bool tail_todo = span_end > nfull;  // the units behind the last full vector of the buffer (fewer than 8)
     uint32_t d0 = 0;                    // tile of the current group to resume at (after a mid-group drain)
+    uint32_t prio_turn = 0;             // passes so far (issue priority rotation)
     bool mid = false;                   // the current group is being resumed (its registers are live, its loads are out)
     uint32_t carry[4] = {0, 0, 0, 0};
     uint4 nxt[kAcTiles][kAcVec], grp[kAcTiles][kAcVec];
@@ -478,6 +479,20 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
         const bool seam = vec_todo ? (!mid && tile >= boundary) : true; // wave-uniform
         const uint32_t keep = SPLIT ? ~0u : (seam ? 1u : (uint32_t)(kVerifyBatches * kWave));
         if (vec_todo && !mid) {
+#ifndef ACGPU_NO_SETPRIO
+            // The issue arbiter favours the oldest wave of a SIMD: with equal spans the four waves of a SIMD (slots s, s+4,
+            // s+8, s+12 of the workgroup) finish 513 k, 531 k, 557 k and 603 k ticks after the start, and the kernel ends
+            // with the youngest.  Every wave therefore rotates its own issue priority from tile to tile (s_setprio), so
+            // that each holds every rank equally often: 535 / 553 / 559 / 580 k, kernel -1.5 % (no-verify build -4.6 %).
+            // (A feedback form -- priority = number of SIMD siblings ahead, progress published in LDS -- evened the slots
+            // out completely and made every one of them 29 % slower.)
+            switch ((wave_in_block / 4u + prio_turn++) & 3u) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+            }
+#endif
 #ifdef ACGPU_TIMING
             { TM_BEGIN; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TM_END(1); tm[4]++; }
 #endif
