@@ -449,7 +449,18 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
             nxt[d] = *reinterpret_cast<const uint4 *>(hay + min(tile + d * kTileUnits + lane * 8, last_vec));
     }
 
+    uint32_t prio_turn = 0;
     for (;;) {
+#ifndef ACGPU_NO_SETPRIO
+        // the waves of a SIMD take turns at every issue priority (see k_ac_tile: the arbiter's oldest-first order lets the
+        // youngest waves finish last)
+        switch ((threadIdx.x / (4u * kWave) + prio_turn++) & 3u) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+        }
+#endif
         const bool seam = vec_todo ? (d0 == 0 && tile >= boundary) : true;
         const uint32_t keep = seam ? 1u : (uint32_t)(kWwBatches * kWave);
         if (c.cand_n >= keep && c.cand_n != 0) ww_drain<FOLD>(c, wbits, F, keep);
