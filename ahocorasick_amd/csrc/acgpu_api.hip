@@ -77,6 +77,10 @@ struct DeviceState {
     DevBuf cands, region_cands;                          // ALL, split form: candidate positions, {first, count} per region
     DevBuf wwl_rs, wwl_mend, wwl_mid, wwl_sel;          // WWLONGEST: walk starts and what each would report
     unsigned long long *h_counter = nullptr; // pinned
+    // match_all: two sets of slot counters alternate; the permute pass of a call zeroes the set the next call uses
+    int cset = 0;
+    bool cclean[2] = {false, false};
+    void *counter_seen = nullptr; // (a re-allocated counter buffer is not clean)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     Ticket tickets[4];
     ~DeviceState() {
@@ -269,14 +273,26 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         return ACGPU_OK;
     }
     int rc;
-    const size_t counter_bytes = (size_t)kMaxSlices * kCounterStride * 8;
-    if ((rc = d.counter.ensure(counter_bytes))) return rc;
+    const size_t counter_bytes = (size_t)kMaxSlices * kCounterStride * 8; // one set; layout: [set 0][set 1][overflow word]
+    if ((rc = d.counter.ensure(2 * counter_bytes + 64))) return rc;
+    if (d.counter.p != d.counter_seen) {
+        d.counter_seen = d.counter.p;
+        d.cclean[0] = d.cclean[1] = false;
+        HIP_TRY(hipMemsetAsync((char *)d.counter.p + 2 * counter_bytes, 0, 64, stream));
+    }
+    const int cs = d.cset;
+    unsigned long long *counters = (unsigned long long *)((char *)d.counter.p + (size_t)cs * counter_bytes);
+    unsigned long long *counters_next = (unsigned long long *)((char *)d.counter.p + (size_t)(1 - cs) * counter_bytes);
+    uint32_t *overflow_word = (uint32_t *)((char *)d.counter.p + 2 * counter_bytes);
     // the tile kernel reserves scratch slots 256 at a time per wave: head-room for the unused tails; a quarter more than
     // the caller's capacity so that the scratch slices (one per workgroup) tolerate unevenly spread matches
     uint64_t scratch_cap = std::min<uint64_t>(
         std::max<uint64_t>(cap, 1) + cap / 4 + (uint64_t)d.n_cu * (tile_block_threads() / 64) * tile_reserve_slots(), 0xffffffe0ull);
     if ((rc = d.scratch.ensure(scratch_cap * sizeof(ScratchRec)))) return rc;
-    HIP_TRY(hipMemsetAsync(d.counter.p, 0, counter_bytes, stream));
+    if (!d.cclean[cs]) HIP_TRY(hipMemsetAsync(counters, 0, counter_bytes, stream)); // (normally zeroed by the previous call's permute pass)
+    d.cclean[cs] = false;
+    d.cclean[1 - cs] = true;
+    d.cset = 1 - cs;
     uint32_t n_slices = 1;
     uint64_t slice_slots = scratch_cap;
     const char *kname = "";
@@ -306,7 +322,7 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         L.cap = scratch_cap;
         L.lds_bytes = tile_lds_bytes(d.T, L.block);
         L.debug = (uint32_t)tunables().tile_debug;
-        L.d_overflow = (uint32_t *)d.counter.p + 8;
+        L.d_overflow = overflow_word;
         // one scratch slice and slot counter per workgroup (the redo after an overflow takes one slice)
         if (!fused_only && L.grid > 1 && !(L.debug & 16384u)) { // 16384: A/B, one counter
             n_slices = (uint32_t)std::min<int>(L.grid, kMaxSlices);
@@ -318,7 +334,7 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         if ((rc = d.offsets.ensure((size_t)L.n_regions * 8))) return rc;
         if ((rc = d.scan_tmp.ensure(((size_t)L.n_regions / 2048 + 2) * 8))) return rc;
         L.d_scratch = (ScratchRec *)d.scratch.p;
-        L.d_counter = (unsigned long long *)d.counter.p;
+        L.d_counter = counters;
         L.d_region_counts = (uint32_t *)d.chunk_counts.p;
         // (every region's count is written by the wave that owns the region: no memset)
         split = !fused_only && use_split_form(d.T);
@@ -426,7 +442,7 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         if ((rc = d.offsets.ensure((size_t)L.n_chunks * 8))) return rc;
         if ((rc = d.scan_tmp.ensure(((size_t)L.n_chunks / 2048 + 2) * 8))) return rc;
         L.d_scratch = (ScratchRec *)d.scratch.p;
-        L.d_counter = (unsigned long long *)d.counter.p;
+        L.d_counter = counters;
         L.d_chunk_counts = (uint32_t *)d.chunk_counts.p;
         if (timed) HIP_TRY(hipEventRecord(ev[0], stream));
         HIP_TRY(launch_ac_scan(d.T, L, stream, &kname));
@@ -437,17 +453,17 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
     }
     HIP_TRY(launch_exclusive_scan((const uint32_t *)d.chunk_counts.p, n_chunks, (uint64_t *)d.offsets.p,
                                   (uint64_t *)d.scan_tmp.p, stream));
-    HIP_TRY(launch_permute((const ScratchRec *)d.scratch.p, (const unsigned long long *)d.counter.p, n_slices, slice_slots,
+    // the permute pass reports {record count, overflow word} into the pinned host slot of this call, clears the word and
+    // zeroes the other set of slot counters for the next call: no copy or memset operations on the stream
+    unsigned long long *h_slot = tk ? tk->h_count : d.h_counter, *d_slot = nullptr;
+    HIP_TRY(hipHostGetDevicePointer((void **)&d_slot, h_slot, 0));
+    const PermuteTail tail{d_slot, (const uint64_t *)d.scan_tmp.p + scan_tiles_for(n_chunks), overflow_word, counters_next};
+    HIP_TRY(launch_permute((const ScratchRec *)d.scratch.p, counters, n_slices, slice_slots,
                            (const uint64_t *)d.offsets.p, perm_base, chunk_units,
-                           /*by_start=*/0, record_kind, d_out, cap, id_map, stream));
-    const bool flagged = split || n_slices > 1; // the overflow word has to be looked at
+                           /*by_start=*/0, record_kind, d_out, cap, id_map, stream, &tail));
     if (timed) HIP_TRY(hipEventRecord(ev[2], stream));
     // exact record count = grand total of the per-chunk counts (the slot counter also counts reservation holes)
     if (tk) {
-        HIP_TRY(hipMemcpyAsync(tk->h_count, (const uint64_t *)d.scan_tmp.p + scan_tiles_for(n_chunks), 8,
-                               hipMemcpyDeviceToHost, stream));
-        tk->h_count[1] = 0;
-        if (flagged) HIP_TRY(hipMemcpyAsync(tk->h_count + 1, (const uint32_t *)d.counter.p + 8, 4, hipMemcpyDeviceToHost, stream));
         tk->shard = *sh;
         tk->record_kind = record_kind;
         tk->d_out = d_out;
@@ -457,12 +473,8 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         std::snprintf(tk->kname, sizeof(tk->kname), "%s", kname);
         return ACGPU_OK;
     }
-    HIP_TRY(hipMemcpyAsync(d.h_counter, (const uint64_t *)d.scan_tmp.p + scan_tiles_for(n_chunks), 8, hipMemcpyDeviceToHost,
-                           stream));
-    d.h_counter[1] = 0;
-    if (flagged) HIP_TRY(hipMemcpyAsync(d.h_counter + 1, (const uint32_t *)d.counter.p + 8, 4, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
-    if (flagged && (uint32_t)d.h_counter[1] != 0) // a candidate slice / scratch slice overflowed: fused kernel, one scratch slice
+    if ((uint32_t)d.h_counter[1] != 0) // a candidate slice / scratch slice overflowed: fused kernel, one scratch slice
         return match_all(a, d, sh, record_kind, d_out, cap, n_out, stream, prof, nullptr, true);
     *n_out = *d.h_counter;
     if (prof) {
@@ -524,6 +536,7 @@ int match_longest_sparse(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, in
     HIP_TRY(launch_shortest_emit((const int32_t *)d.short_recs.p, M, (const uint32_t *)d.short_mark.p,
                                  (const uint64_t *)d.offsets.p, d_total, record_kind, d_out, cap, (int64_t)entry,
                                  (unsigned long long *)d.counter.p, stream));
+    d.cclean[0] = false; // (the exit position went where match_all's first set of slot counters lives)
     if (prof) HIP_TRY(hipEventRecord(d.ev[1], stream));
     HIP_TRY(hipMemcpyAsync(d.h_counter, d_total, 8, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipMemcpyAsync(d.h_counter + 1, d.counter.p, 8, hipMemcpyDeviceToHost, stream));
@@ -622,6 +635,7 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
     Cn.d_exit = (unsigned long long *)d.counter.p;
 
     HIP_TRY(hipMemsetAsync(d.counter.p, 0, 64, stream));
+    d.cclean[0] = false; // (match_all's first set of slot counters lives here)
     if (prof) HIP_TRY(hipEventRecord(d.ev[0], stream));
     const char *kname = "";
     HIP_TRY(launch_longest_scan(d.T, S, stream, &kname));
@@ -664,6 +678,7 @@ int match_wholeword(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int rec
     const size_t counter_bytes = (size_t)kMaxSlices * kCounterStride * 8;
     if ((rc = d.counter.ensure(counter_bytes))) return rc;
     HIP_TRY(hipMemsetAsync(d.counter.p, 0, counter_bytes, stream));
+    d.cclean[0] = false; // (match_all's first set of slot counters lives here)
     if (!t.fold_consistent) {
         // the reference's mixed folded/raw lookups make token boundaries history dependent: whole text, one lane
         if (!sh->text_begin || !sh->text_end || sh->own_begin != 0 || sh->own_end != sh->n_units) return ACGPU_E_UNSUPPORTED;
@@ -790,6 +805,7 @@ int match_shortest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int reco
     HIP_TRY(launch_shortest_emit((const int32_t *)d.short_recs.p, M, (const uint32_t *)d.short_mark.p,
                                  (const uint64_t *)d.offsets.p, d_total, record_kind, d_out, cap, entry,
                                  (unsigned long long *)d.counter.p, stream));
+    d.cclean[0] = false; // (the exit position went where match_all's first set of slot counters lives)
     if (prof) HIP_TRY(hipEventRecord(d.ev[1], stream));
     HIP_TRY(hipMemcpyAsync(d.h_counter, d_total, 8, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipMemcpyAsync(d.h_counter + 1, d.counter.p, 8, hipMemcpyDeviceToHost, stream));

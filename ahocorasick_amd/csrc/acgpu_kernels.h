@@ -82,11 +82,23 @@ hipError_t launch_exclusive_scan(const uint32_t *d_counts, uint32_t n, uint64_t 
 constexpr uint32_t kCounterStride = 16; // in counters (128 bytes): one cache line per slice counter
 constexpr int kMaxSlices = 512;
 
+// What the permute pass -- the last kernel of a call -- does on the side, so that a call needs no copy and no memset
+// operations of its own on the stream (each costs a launch gap): it reports {record count, overflow word} straight into
+// pinned host memory, clears the overflow word, and zeroes the slot counters the NEXT call will use (the two sets of slot
+// counters alternate).
+struct PermuteTail {
+    unsigned long long *result;       // device-visible pinned host memory: [0] = *total, [1] = *flag
+    const uint64_t *total;
+    uint32_t *flag;                   // read, reported, cleared
+    unsigned long long *zero_counters; // kMaxSlices counters, kCounterStride apart, or nullptr
+};
+
 // scratch (unordered) -> final records in reference order
 // (slots whose rank is ~0u are holes left by slot reservations and are skipped)
 hipError_t launch_permute(const ScratchRec *d_scratch, const unsigned long long *d_counter, uint32_t n_slices, uint64_t slice_slots,
                           const uint64_t *d_offsets, uint32_t own_begin, uint32_t chunk_units, int by_start,
-                          int record_kind, void *d_out, uint64_t out_cap, const uint32_t *d_id_map, hipStream_t stream);
+                          int record_kind, void *d_out, uint64_t out_cap, const uint32_t *d_id_map, hipStream_t stream,
+                          const PermuteTail *tail = nullptr);
 uint32_t scan_tiles_for(uint32_t n); // number of prefix-sum tiles; the grand total is d_tmp[scan_tiles_for(n)]
 uint32_t tile_reserve_slots();
 uint32_t tile_group_units(); // regions must hold whole tile groups

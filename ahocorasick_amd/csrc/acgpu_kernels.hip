@@ -331,7 +331,17 @@ template <int REC>
 __global__ __launch_bounds__(256) void k_permute(const ScratchRec *scratch, const unsigned long long *counter,
                                                 uint64_t slice_slots, const uint64_t *offsets, uint32_t own_begin,
                                                 uint32_t chunk_units, int by_start, void *out, uint64_t cap,
-                                                const uint32_t *id_map) {
+                                                const uint32_t *id_map, PermuteTail tail) {
+    if (blockIdx.x == 0 && blockIdx.y == 0) { // (see PermuteTail)
+        if (tail.zero_counters)
+            for (uint32_t i = threadIdx.x; i < (uint32_t)kMaxSlices; i += blockDim.x) tail.zero_counters[(size_t)i * kCounterStride] = 0;
+        if (tail.result && threadIdx.x == 0) {
+            tail.result[0] = *tail.total;
+            tail.result[1] = tail.flag ? *tail.flag : 0u;
+            if (tail.flag) *tail.flag = 0;
+            __threadfence_system();
+        }
+    }
     // blockIdx.y = slice of the scratch (its own counter, slice_slots slots)
     unsigned long long m = counter[(size_t)blockIdx.y * kCounterStride];
     if (m > slice_slots) m = slice_slots; // overflow: the host redoes the call / reports ACGPU_E_OVERFLOW
@@ -359,15 +369,17 @@ __global__ __launch_bounds__(256) void k_permute(const ScratchRec *scratch, cons
 
 hipError_t launch_permute(const ScratchRec *d_scratch, const unsigned long long *d_counter, uint32_t n_slices, uint64_t slice_slots,
                           const uint64_t *d_offsets, uint32_t own_begin, uint32_t chunk_units, int by_start,
-                          int record_kind, void *d_out, uint64_t out_cap, const uint32_t *d_id_map, hipStream_t stream) {
+                          int record_kind, void *d_out, uint64_t out_cap, const uint32_t *d_id_map, hipStream_t stream,
+                          const PermuteTail *tail) {
     if (n_slices < 1) n_slices = 1;
+    const PermuteTail tl = tail ? *tail : PermuteTail{nullptr, nullptr, nullptr, nullptr};
     const dim3 grid(std::max<uint32_t>(2048u / n_slices, 8u), n_slices);
     if (record_kind == ACGPU_REC_SET)
         hipLaunchKernelGGL(k_permute<ACGPU_REC_SET>, grid, dim3(256), 0, stream, d_scratch, d_counter, slice_slots,
-                           d_offsets, own_begin, chunk_units, by_start, d_out, out_cap, d_id_map);
+                           d_offsets, own_begin, chunk_units, by_start, d_out, out_cap, d_id_map, tl);
     else
         hipLaunchKernelGGL(k_permute<ACGPU_REC_MAP>, grid, dim3(256), 0, stream, d_scratch, d_counter, slice_slots,
-                           d_offsets, own_begin, chunk_units, by_start, d_out, out_cap, d_id_map);
+                           d_offsets, own_begin, chunk_units, by_start, d_out, out_cap, d_id_map, tl);
     return hipGetLastError();
 }
 
