@@ -367,13 +367,19 @@ __global__ __launch_bounds__(256) void k_permute(const ScratchRec *scratch, cons
     }
 }
 
+#ifndef ACGPU_PERMUTE_BLOCKS
+#define ACGPU_PERMUTE_BLOCKS 2048
+#endif
+constexpr uint32_t kPermuteBlocks = ACGPU_PERMUTE_BLOCKS;
+
 hipError_t launch_permute(const ScratchRec *d_scratch, const unsigned long long *d_counter, uint32_t n_slices, uint64_t slice_slots,
                           const uint64_t *d_offsets, uint32_t own_begin, uint32_t chunk_units, int by_start,
                           int record_kind, void *d_out, uint64_t out_cap, const uint32_t *d_id_map, hipStream_t stream,
                           const PermuteTail *tail) {
     if (n_slices < 1) n_slices = 1;
     const PermuteTail tl = tail ? *tail : PermuteTail{nullptr, nullptr, nullptr, nullptr};
-    const dim3 grid(std::max<uint32_t>(2048u / n_slices, 8u), n_slices);
+    // (8192 or 32768 workgroups instead of 2048 were not faster: the pass is bound by its scattered 12-byte stores)
+    const dim3 grid(std::max<uint32_t>(kPermuteBlocks / n_slices, 8u), n_slices);
     if (record_kind == ACGPU_REC_SET)
         hipLaunchKernelGGL(k_permute<ACGPU_REC_SET>, grid, dim3(256), 0, stream, d_scratch, d_counter, slice_slots,
                            d_offsets, own_begin, chunk_units, by_start, d_out, out_cap, d_id_map, tl);
