@@ -77,16 +77,10 @@ struct DeviceState {
     DevBuf cands, region_cands;                          // ALL, split form: candidate positions, {first, count} per region
     DevBuf wwl_rs, wwl_mend, wwl_mid, wwl_sel;          // WWLONGEST: walk starts and what each would report
     unsigned long long *h_counter = nullptr; // pinned
-    // match_all keeps TWO sets of per-call buffers (slot counters, scratch, region counts, offsets, prefix-sum scratch) and
-    // alternates between them, so that the ordering pass of an asynchronous call (prefix sums + permute, on the internal
-    // side stream) runs while the scan kernel of the next call is already running on the caller's stream.  set_done[s]:
-    // the last ordering pass that used set s has finished; tile_done[s]: the scan kernel that feeds it has.
+    // match_all: two sets of slot counters alternate; the permute pass of a call zeroes the set the next call uses
     int cset = 0;
     bool cclean[2] = {false, false};
     void *counter_seen = nullptr; // (a re-allocated counter buffer is not clean)
-    DevBuf chunk_counts2, offsets2, scan_tmp2, scratch2;
-    hipStream_t side = nullptr;
-    hipEvent_t set_done[2] = {nullptr, nullptr}, tile_done[2] = {nullptr, nullptr};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     Ticket tickets[4];
     ~DeviceState() {
@@ -96,10 +90,6 @@ struct DeviceState {
         short_recs.release(); short_nxt.release(); short_tmp.release(); short_mark.release();
         wwl_rs.release(); wwl_mend.release(); wwl_mid.release(); wwl_sel.release(); blockmax.release(); cands.release(); region_cands.release();
         if (h_counter) (void)hipHostFree(h_counter);
-        chunk_counts2.release(); offsets2.release(); scan_tmp2.release(); scratch2.release();
-        for (auto &e : set_done) if (e) (void)hipEventDestroy(e);
-        for (auto &e : tile_done) if (e) (void)hipEventDestroy(e);
-        if (side) (void)hipStreamDestroy(side);
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         for (auto &tk : tickets) {
             for (auto &e : tk.ev) if (e) (void)hipEventDestroy(e);
@@ -216,9 +206,6 @@ int ensure_device(acgpu_automaton *a, DeviceState **out) {
     T.lds_entries = lds_states_for(t) * t.n_cls;
     HIP_TRY(hipHostMalloc((void **)&d->h_counter, 64, hipHostMallocDefault));
     for (auto &e : d->ev) HIP_TRY(hipEventCreate(&e));
-    for (auto &e : d->set_done) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    for (auto &e : d->tile_done) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    HIP_TRY(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
     for (auto &tk : d->tickets) {
         for (auto &e : tk.ev) HIP_TRY(hipEventCreate(&e));
         HIP_TRY(hipEventCreateWithFlags(&tk.done, hipEventDisableTiming));
@@ -295,18 +282,16 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
     }
     const int cs = d.cset;
     unsigned long long *counters = (unsigned long long *)((char *)d.counter.p + (size_t)cs * counter_bytes);
-    uint32_t *overflow_word = (uint32_t *)((char *)d.counter.p + 2 * counter_bytes) + 8 * cs; // one word per set
-    DevBuf &b_counts = cs ? d.chunk_counts2 : d.chunk_counts, &b_offsets = cs ? d.offsets2 : d.offsets;
-    DevBuf &b_scan_tmp = cs ? d.scan_tmp2 : d.scan_tmp, &b_scratch = cs ? d.scratch2 : d.scratch;
-    // the ordering pass goes to the side stream for asynchronous calls (the caller collects the result with _end)
-    hipStream_t fin = tk ? d.side : stream;
-    HIP_TRY(hipStreamWaitEvent(stream, d.set_done[cs], 0)); // this set's previous ordering pass
+    unsigned long long *counters_next = (unsigned long long *)((char *)d.counter.p + (size_t)(1 - cs) * counter_bytes);
+    uint32_t *overflow_word = (uint32_t *)((char *)d.counter.p + 2 * counter_bytes);
     // the tile kernel reserves scratch slots 256 at a time per wave: head-room for the unused tails; a quarter more than
     // the caller's capacity so that the scratch slices (one per workgroup) tolerate unevenly spread matches
     uint64_t scratch_cap = std::min<uint64_t>(
         std::max<uint64_t>(cap, 1) + cap / 4 + (uint64_t)d.n_cu * (tile_block_threads() / 64) * tile_reserve_slots(), 0xffffffe0ull);
-    if ((rc = b_scratch.ensure(scratch_cap * sizeof(ScratchRec)))) return rc;
-    if (!d.cclean[cs]) HIP_TRY(hipMemsetAsync(counters, 0, counter_bytes, stream)); // (normally zeroed behind the set's last ordering pass)
+    if ((rc = d.scratch.ensure(scratch_cap * sizeof(ScratchRec)))) return rc;
+    if (!d.cclean[cs]) HIP_TRY(hipMemsetAsync(counters, 0, counter_bytes, stream)); // (normally zeroed by the previous call's permute pass)
+    d.cclean[cs] = false;
+    d.cclean[1 - cs] = true;
     d.cset = 1 - cs;
     uint32_t n_slices = 1;
     uint64_t slice_slots = scratch_cap;
@@ -345,12 +330,12 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         }
         L.n_slices = n_slices;
         L.slice_slots = (uint32_t)slice_slots;
-        if ((rc = b_counts.ensure((size_t)L.n_regions * 4))) return rc;
-        if ((rc = b_offsets.ensure((size_t)L.n_regions * 8))) return rc;
-        if ((rc = b_scan_tmp.ensure(((size_t)L.n_regions / 2048 + 2) * 8))) return rc;
-        L.d_scratch = (ScratchRec *)b_scratch.p;
+        if ((rc = d.chunk_counts.ensure((size_t)L.n_regions * 4))) return rc;
+        if ((rc = d.offsets.ensure((size_t)L.n_regions * 8))) return rc;
+        if ((rc = d.scan_tmp.ensure(((size_t)L.n_regions / 2048 + 2) * 8))) return rc;
+        L.d_scratch = (ScratchRec *)d.scratch.p;
         L.d_counter = counters;
-        L.d_region_counts = (uint32_t *)b_counts.p;
+        L.d_region_counts = (uint32_t *)d.chunk_counts.p;
         // (every region's count is written by the wave that owns the region: no memset)
         split = !fused_only && use_split_form(d.T);
         if (split) {
@@ -372,10 +357,10 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
                 const uint64_t need = std::min<uint64_t>(std::max<uint64_t>(cap, 1) + (uint64_t)L.verify_grid * 4 * tile_reserve_slots(),
                                                          0xffffffe0ull);
                 if (need > L.cap) {
-                    if ((rc = b_scratch.ensure(need * sizeof(ScratchRec)))) return rc;
+                    if ((rc = d.scratch.ensure(need * sizeof(ScratchRec)))) return rc;
                     L.cap = scratch_cap = need;
                     L.slice_slots = (uint32_t)(slice_slots = scratch_cap);
-                    L.d_scratch = (ScratchRec *)b_scratch.p;
+                    L.d_scratch = (ScratchRec *)d.scratch.p;
                 }
             }
         }
@@ -453,12 +438,12 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         L.own_end = (uint32_t)sh->own_end;
         L.cap = scratch_cap; // every slot below min(counter, scratch_cap) must be written: the permute pass reads them all
         L.lds_bytes = scan_queue_bytes(L.block) + (size_t)d.T.lds_entries * t.entry_bytes;
-        if ((rc = b_counts.ensure((size_t)L.n_chunks * 4))) return rc;
-        if ((rc = b_offsets.ensure((size_t)L.n_chunks * 8))) return rc;
-        if ((rc = b_scan_tmp.ensure(((size_t)L.n_chunks / 2048 + 2) * 8))) return rc;
-        L.d_scratch = (ScratchRec *)b_scratch.p;
+        if ((rc = d.chunk_counts.ensure((size_t)L.n_chunks * 4))) return rc;
+        if ((rc = d.offsets.ensure((size_t)L.n_chunks * 8))) return rc;
+        if ((rc = d.scan_tmp.ensure(((size_t)L.n_chunks / 2048 + 2) * 8))) return rc;
+        L.d_scratch = (ScratchRec *)d.scratch.p;
         L.d_counter = counters;
-        L.d_chunk_counts = (uint32_t *)b_counts.p;
+        L.d_chunk_counts = (uint32_t *)d.chunk_counts.p;
         if (timed) HIP_TRY(hipEventRecord(ev[0], stream));
         HIP_TRY(launch_ac_scan(d.T, L, stream, &kname));
         if (timed) HIP_TRY(hipEventRecord(ev[1], stream));
@@ -466,39 +451,28 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         chunk_units = L.chunk_units;
         scanned = own_len + (uint64_t)L.n_chunks * halo;
     }
-    if (fin != stream) { // the ordering pass waits for the scan kernel(s), nothing on the caller's stream waits for it
-        // (a profiled call has just recorded ev[1] at this very point: one event record less on the caller's stream)
-        hipEvent_t after_scan = timed ? ev[1] : d.tile_done[cs];
-        if (!timed) HIP_TRY(hipEventRecord(after_scan, stream));
-        HIP_TRY(hipStreamWaitEvent(fin, after_scan, 0));
-    }
-    HIP_TRY(launch_exclusive_scan((const uint32_t *)b_counts.p, n_chunks, (uint64_t *)b_offsets.p,
-                                  (uint64_t *)b_scan_tmp.p, fin));
+    HIP_TRY(launch_exclusive_scan((const uint32_t *)d.chunk_counts.p, n_chunks, (uint64_t *)d.offsets.p,
+                                  (uint64_t *)d.scan_tmp.p, stream));
     // the permute pass reports {record count, overflow word} into the pinned host slot of this call, clears the word and
     // zeroes the other set of slot counters for the next call: no copy or memset operations on the stream
     unsigned long long *h_slot = tk ? tk->h_count : d.h_counter, *d_slot = nullptr;
     HIP_TRY(hipHostGetDevicePointer((void **)&d_slot, h_slot, 0));
-    const PermuteTail tail{d_slot, (const uint64_t *)b_scan_tmp.p + scan_tiles_for(n_chunks), overflow_word, nullptr};
-    HIP_TRY(launch_permute((const ScratchRec *)b_scratch.p, counters, n_slices, slice_slots,
-                           (const uint64_t *)b_offsets.p, perm_base, chunk_units,
-                           /*by_start=*/0, record_kind, d_out, cap, id_map, fin, &tail));
-    // the set's slot counters are zeroed behind its ordering pass (off the caller's stream for asynchronous calls)
-    HIP_TRY(hipMemsetAsync(counters, 0, counter_bytes, fin));
-    d.cclean[cs] = true;
-    if (timed) HIP_TRY(hipEventRecord(ev[2], fin));
+    const PermuteTail tail{d_slot, (const uint64_t *)d.scan_tmp.p + scan_tiles_for(n_chunks), overflow_word, counters_next};
+    HIP_TRY(launch_permute((const ScratchRec *)d.scratch.p, counters, n_slices, slice_slots,
+                           (const uint64_t *)d.offsets.p, perm_base, chunk_units,
+                           /*by_start=*/0, record_kind, d_out, cap, id_map, stream, &tail));
+    if (timed) HIP_TRY(hipEventRecord(ev[2], stream));
     // exact record count = grand total of the per-chunk counts (the slot counter also counts reservation holes)
     if (tk) {
         tk->shard = *sh;
         tk->record_kind = record_kind;
         tk->d_out = d_out;
         tk->stream = stream;
-        HIP_TRY(hipEventRecord(tk->done, fin));
-        HIP_TRY(hipEventRecord(d.set_done[cs], fin));
+        HIP_TRY(hipEventRecord(tk->done, stream));
         tk->scanned = scanned;
         std::snprintf(tk->kname, sizeof(tk->kname), "%s", kname);
         return ACGPU_OK;
     }
-    HIP_TRY(hipEventRecord(d.set_done[cs], stream));
     HIP_TRY(hipStreamSynchronize(stream));
     if ((uint32_t)d.h_counter[1] != 0) // a candidate slice / scratch slice overflowed: fused kernel, one scratch slice
         return match_all(a, d, sh, record_kind, d_out, cap, n_out, stream, prof, nullptr, true);
@@ -1200,7 +1174,6 @@ int acgpu_match_device_end(const acgpu_automaton *ca, acgpu_ticket *ticket, uint
     Ticket *tk = reinterpret_cast<Ticket *>(ticket);
     if (!tk->busy) return ACGPU_E_INVALID;
     HIP_TRY(hipEventSynchronize(tk->done)); // outside the lock: other calls may be enqueued meanwhile
-    HIP_TRY(hipStreamWaitEvent(tk->stream, tk->done, 0)); // (the records were written on the side stream)
     std::lock_guard<std::mutex> lock(a->mu);
     if ((uint32_t)tk->h_count[1] != 0) { // the split form's candidate slices were too small: redo with the fused kernel
         DeviceState *d = reinterpret_cast<DeviceState *>(tk->owner);
