@@ -13,8 +13,12 @@
 //            alphabets; L2-resident), collecting every keyword that ends at e -- exactly the keywords on the
 //            reference's output chain of the state reached at e.
 //
-// Work distribution: a wave owns a contiguous span of REGIONS of the haystack and streams it as 1024-unit tiles, lane l
-// holding 16 consecutive units of a tile (two 16-byte loads per lane), 8 KiB per wave in flight.
+//   second level (the L2 form, small range-class dictionaries): between the two, still in LDS, a Bloom filter over
+//            the last K+2 units, probed from an LDS copy of the tile's classes, so that almost only true matches reach
+//            the verification -- and they arrive with their K-gram index, so that no text window is read for them.
+//
+// Work distribution: a wave owns a contiguous span of REGIONS of the haystack and streams it as 1024-unit tiles (L2 form:
+// 2048-unit), lane l holding 16 (32) consecutive units of a tile, the next tile's loads in flight while one is filtered.
 // Because a wave meets its candidates in text order, a record's rank inside its region is a running wave-uniform
 // count plus a wave prefix sum; the finalize pass (prefix sum over regions + permutation) then yields the
 // reference's emission order (end ascending, longest first) without any sort.  Records go straight to HBM into
