@@ -113,9 +113,13 @@ def main():
     t0 = time.time()
     counts = [0, 0, 0, 0, 0]
     it = 0
+    t_said = t0
     while time.time() - t0 < budget:
         counts[one_case(rng, it)] += 1
         it += 1
+        if time.time() - t_said > 30:  # a long soak keeps talking (a silent run is taken to be hung)
+            t_said = time.time()
+            print("  ... %d cases after %.0f s" % (it, t_said - t0), flush=True)
     print("fuzz ok: %d cases (AC %d, Longest %d, WholeWord %d, Shortest %d, WholeWordLongest %d) in %.0f s, seed %d" % (
         it, *counts, time.time() - t0, seed))
 
