@@ -304,7 +304,10 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         TileLaunch L{};
         L.block = tile_block_threads();
         const int waves_per_block = L.block / 64;
-        uint64_t R = tunables().region_units > 0 ? (uint64_t)tunables().region_units : 16384;
+        // regions of 16384 units, or 32768 when that still leaves every wave two of them (fewer forced drains: -1.1 % at
+        // config 2 in interleaved A/B; 65536 was no better)
+        uint64_t R = tunables().region_units > 0 ? (uint64_t)tunables().region_units
+                     : own_len >= 2ull * 32768 * d.n_cu * waves_per_block ? 32768 : 16384;
         { const uint64_t g = tile_group_units(); R = std::max<uint64_t>(g, (R + g - 1) / g * g); }
         L.region_units = (uint32_t)R;
         const uint64_t base8 = sh->own_begin & ~7ull; // regions are laid out from the 16-byte aligned start
