@@ -66,8 +66,10 @@ ACGPU_HD inline uint32_t l2_hash(uint32_t gram) { return l2_mul24(gram ^ (gram >
 ACGPU_HD inline uint32_t l2_word(uint32_t h) { return (((h >> 11) & 0x1fffu) * kL2Words) >> 13; }
 ACGPU_HD inline uint32_t l2_pattern(uint32_t h) {
     const uint32_t x = l2_mul24(h >> 8, 0xC2B2AFu);
-#ifdef ACGPU_L2_TWO_BITS
+#if defined(ACGPU_L2_TWO_BITS)
     return (1u << (x >> 27)) | (1u << ((x >> 22) & 31u));
+#elif defined(ACGPU_L2_FOUR_BITS)
+    return (1u << (x >> 27)) | (1u << ((x >> 22) & 31u)) | (1u << ((x >> 17) & 31u)) | (1u << ((x >> 12) & 31u));
 #else
     return (1u << (x >> 27)) | (1u << ((x >> 22) & 31u)) | (1u << ((x >> 17) & 31u)); // three bits: fewer false survivors
 #endif
