@@ -2,14 +2,14 @@
 """Randomised GPU-vs-oracle soak test (development tool; the pytest suite holds the fixed regression cases).
 
 Draws random dictionaries / haystacks / tunables / shard splits for all three matcher families and compares the
-device records with oracle/ac_oracle.c bit for bit.  Usage: python tools/fuzz_gpu.py [seconds] [seed]"""
+device records with oracle/ac_oracle.c bit for bit.  Usage: python tests/fuzz_gpu.py [seconds] [seed]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root
 
 import torch  # noqa: E402
 
