@@ -32,7 +32,14 @@ class Info(ctypes.Structure):
 class Shard(ctypes.Structure):
     _fields_ = [("d_hay", ctypes.c_void_p), ("n_units", ctypes.c_uint64), ("own_begin", ctypes.c_uint64),
                 ("own_end", ctypes.c_uint64), ("text_begin", ctypes.c_int32), ("text_end", ctypes.c_int32),
-                ("chain_entry", ctypes.c_int64), ("chain_exit", ctypes.c_int64)]
+                ("chain_entry", ctypes.c_int64), ("chain_exit", ctypes.c_int64), ("d_result", ctypes.c_void_p)]
+
+
+class DeviceResult(ctypes.Structure):  # acgpu_device_result: what Shard.d_result receives, in stream order
+    _fields_ = [("n_records", ctypes.c_uint64), ("redone", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+
+
+ABI_VERSION = 2
 
 
 class Profile(ctypes.Structure):
@@ -42,7 +49,7 @@ class Profile(ctypes.Structure):
 
 # every symbol include/acgpu.h declares
 SYMBOLS = ["acgpu_build", "acgpu_free", "acgpu_get_info", "acgpu_match_u16", "acgpu_match_device",
-           "acgpu_match_device_begin", "acgpu_match_device_end", "acgpu_synth_fill",
+           "acgpu_match_device_begin", "acgpu_match_device_end", "acgpu_synth_fill", "acgpu_stream_probe",
            "acgpu_set_tunable", "acgpu_strerror", "acgpu_last_hip_error", "acgpu_abi_version", "acgpu_debug_tables",
            "acgpu_debug_wordhash", "acgpu_stream_open", "acgpu_stream_feed", "acgpu_stream_close"]
 
@@ -82,6 +89,8 @@ def lib():
         L.acgpu_match_device_end.argtypes = [vp, vp, ctypes.POINTER(u64), ctypes.POINTER(Profile)]
         L.acgpu_synth_fill.restype = ci
         L.acgpu_synth_fill.argtypes = [vp, u64, u64, u64, vp, u32, vp]
+        L.acgpu_stream_probe.restype = ci
+        L.acgpu_stream_probe.argtypes = [vp, u64, vp, ci, ctypes.POINTER(ctypes.c_float)]
         L.acgpu_set_tunable.restype = i64
         L.acgpu_set_tunable.argtypes = [ctypes.c_char_p, i64]
         L.acgpu_strerror.restype = ctypes.c_char_p
@@ -98,6 +107,9 @@ def lib():
         L.acgpu_stream_close.argtypes = [vp]
         L.acgpu_debug_wordhash.restype = ci
         L.acgpu_debug_wordhash.argtypes = [vp, ctypes.POINTER(u32), vp, ctypes.POINTER(u64), vp, vp, ctypes.POINTER(u32), vp]
+        if L.acgpu_abi_version() != ABI_VERSION:
+            raise ImportError("ahocorasick_amd: %s has ABI version %d, this package binds version %d -- rebuild it"
+                              % (LIB_PATH, L.acgpu_abi_version(), ABI_VERSION))
         _lib = L
     return _lib
 

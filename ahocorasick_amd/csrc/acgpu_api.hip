@@ -9,6 +9,7 @@
 #include <memory>
 #include <mutex>
 #include <new>
+#include <vector>
 
 #include "acgpu_internal.h"
 #include "acgpu_kernels.h"
@@ -83,6 +84,9 @@ struct DeviceState {
     void *counter_seen = nullptr; // (a re-allocated counter buffer is not clean)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     Ticket tickets[4];
+    // stream rule (include/acgpu.h): while tickets are in flight every call on this automaton and device uses their stream
+    int inflight = 0;
+    hipStream_t inflight_stream = nullptr;
     ~DeviceState() {
         for (void *p : table_allocs) (void)hipFree(p);
         counter.release(); chunk_counts.release(); offsets.release(); scan_tmp.release(); scratch.release();
@@ -263,9 +267,11 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         std::memset(prof, 0, sizeof(*prof));
     }
     if (own_len == 0 || t.n_states <= 1) {
+        if (sh->d_result) HIP_TRY(hipMemsetAsync(sh->d_result, 0, sizeof(acgpu_device_result), stream));
         if (tk) {
             tk->h_count[0] = tk->h_count[1] = 0; // (no kernel will write the slot)
             tk->profiled = false;
+            tk->stream = stream;
             HIP_TRY(hipEventRecord(tk->done, stream));
             return ACGPU_OK;
         }
@@ -290,9 +296,9 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         std::max<uint64_t>(cap, 1) + cap / 4 + (uint64_t)d.n_cu * (tile_block_threads() / 64) * tile_reserve_slots(), 0xffffffe0ull);
     if ((rc = d.scratch.ensure(scratch_cap * sizeof(ScratchRec)))) return rc;
     if (!d.cclean[cs]) HIP_TRY(hipMemsetAsync(counters, 0, counter_bytes, stream)); // (normally zeroed by the previous call's permute pass)
-    d.cclean[cs] = false;
-    d.cclean[1 - cs] = true;
-    d.cset = 1 - cs;
+    // from here on this set is in use; the other set only counts as clean once the permute pass that zeroes it has been
+    // launched (below) -- an early error return leaves both marked dirty and the next call clears its set itself
+    d.cclean[0] = d.cclean[1] = false;
     uint32_t n_slices = 1;
     uint64_t slice_slots = scratch_cap;
     const char *kname = "";
@@ -460,10 +466,13 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
     // zeroes the other set of slot counters for the next call: no copy or memset operations on the stream
     unsigned long long *h_slot = tk ? tk->h_count : d.h_counter, *d_slot = nullptr;
     HIP_TRY(hipHostGetDevicePointer((void **)&d_slot, h_slot, 0));
-    const PermuteTail tail{d_slot, (const uint64_t *)d.scan_tmp.p + scan_tiles_for(n_chunks), overflow_word, counters_next};
+    const PermuteTail tail{d_slot, (const uint64_t *)d.scan_tmp.p + scan_tiles_for(n_chunks), overflow_word, counters_next,
+                           reinterpret_cast<acgpu_device_result *>(sh->d_result)};
     HIP_TRY(launch_permute((const ScratchRec *)d.scratch.p, counters, n_slices, slice_slots,
                            (const uint64_t *)d.offsets.p, perm_base, chunk_units,
                            /*by_start=*/0, record_kind, d_out, cap, id_map, stream, &tail));
+    d.cclean[1 - cs] = true; // zeroed by the pass just launched
+    d.cset = 1 - cs;
     if (timed) HIP_TRY(hipEventRecord(ev[2], stream));
     // exact record count = grand total of the per-chunk counts (the slot counter also counts reservation holes)
     if (tk) {
@@ -902,15 +911,25 @@ int match_shard(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_
     if (sh->own_begin > sh->own_end || sh->own_end > sh->n_units) return ACGPU_E_INVALID;
     if (sh->n_units && (!sh->d_hay || ((uintptr_t)sh->d_hay & 15))) return ACGPU_E_INVALID;
     if (cap && (!d_out || ((uintptr_t)d_out & 3))) return ACGPU_E_INVALID;
+    if (sh->d_result && ((uintptr_t)sh->d_result & 15)) return ACGPU_E_INVALID;
+    if (d.inflight > 0 && stream != d.inflight_stream) return ACGPU_E_INVALID; // stream rule (include/acgpu.h)
     *n_out = 0;
+    if (a->t.mode == ACGPU_MODE_ALL) return match_all(a, d, sh, record_kind, d_out, cap, n_out, stream, prof);
+    // the other families end with their count on the host (and some run the ALL pipeline inside): the device copy of the
+    // result is written behind the pipeline
+    acgpu_device_result *d_res = reinterpret_cast<acgpu_device_result *>(sh->d_result);
+    sh->d_result = nullptr;
+    int rc;
     switch (a->t.mode) {
-    case ACGPU_MODE_ALL: return match_all(a, d, sh, record_kind, d_out, cap, n_out, stream, prof);
-    case ACGPU_MODE_LONGEST: return match_longest(a, d, sh, record_kind, d_out, cap, n_out, stream, prof);
-    case ACGPU_MODE_WHOLEWORD: return match_wholeword(a, d, sh, record_kind, d_out, cap, n_out, stream, prof);
-    case ACGPU_MODE_SHORTEST: return match_shortest(a, d, sh, record_kind, d_out, cap, n_out, stream, prof);
-    case ACGPU_MODE_WWLONGEST: return match_wwlongest(a, d, sh, record_kind, d_out, cap, n_out, stream, prof);
-    default: return ACGPU_E_UNSUPPORTED;
+    case ACGPU_MODE_LONGEST: rc = match_longest(a, d, sh, record_kind, d_out, cap, n_out, stream, prof); break;
+    case ACGPU_MODE_WHOLEWORD: rc = match_wholeword(a, d, sh, record_kind, d_out, cap, n_out, stream, prof); break;
+    case ACGPU_MODE_SHORTEST: rc = match_shortest(a, d, sh, record_kind, d_out, cap, n_out, stream, prof); break;
+    case ACGPU_MODE_WWLONGEST: rc = match_wwlongest(a, d, sh, record_kind, d_out, cap, n_out, stream, prof); break;
+    default: rc = ACGPU_E_UNSUPPORTED;
     }
+    sh->d_result = d_res;
+    if (d_res && (rc == ACGPU_OK || rc == ACGPU_E_OVERFLOW)) HIP_TRY(launch_write_result(d_res, *n_out, stream));
+    return rc;
 }
 
 } // namespace
@@ -938,7 +957,7 @@ const char *acgpu_strerror(int code) {
 int64_t acgpu_set_tunable(const char *name, int64_t value) {
     if (!name) return -1;
     Tunables &t = tunables();
-    int64_t *slot = nullptr;
+    std::atomic<int64_t> *slot = nullptr;
     if (!std::strcmp(name, "chunk_units")) slot = &t.chunk_units;
     else if (!std::strcmp(name, "blocks_per_cu")) slot = &t.blocks_per_cu;
     else if (!std::strcmp(name, "lds_table_bytes")) slot = &t.lds_table_bytes;
@@ -950,9 +969,7 @@ int64_t acgpu_set_tunable(const char *name, int64_t value) {
     else if (!std::strcmp(name, "rdense_budget_bytes")) slot = &t.rdense_budget_bytes;
     else if (!std::strcmp(name, "filter_max_bytes")) slot = &t.filter_max_bytes;
     if (!slot) return -1;
-    int64_t prev = *slot;
-    *slot = value;
-    return prev;
+    return slot->exchange(value, std::memory_order_relaxed);
 }
 
 int acgpu_build(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uint32_t n_kw, int case_sensitive,
@@ -1160,6 +1177,9 @@ int acgpu_match_device_begin(const acgpu_automaton *ca, acgpu_shard *sh, int rec
     if (sh->n_units >= (1ull << 31) || sh->own_begin > sh->own_end || sh->own_end > sh->n_units) return ACGPU_E_INVALID;
     if (sh->n_units && (!sh->d_hay || ((uintptr_t)sh->d_hay & 15))) return ACGPU_E_INVALID;
     if (cap && (!d_out || ((uintptr_t)d_out & 3))) return ACGPU_E_INVALID;
+    if (sh->d_result && ((uintptr_t)sh->d_result & 15)) return ACGPU_E_INVALID;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (d->inflight > 0 && stream != d->inflight_stream) return ACGPU_E_INVALID; // stream rule (include/acgpu.h)
     Ticket *tk = nullptr;
     for (auto &cand : d->tickets)
         if (!cand.busy) { tk = &cand; break; }
@@ -1167,9 +1187,11 @@ int acgpu_match_device_begin(const acgpu_automaton *ca, acgpu_shard *sh, int rec
     tk->profiled = want_profile != 0;
     tk->cap = cap;
     uint64_t dummy = 0;
-    rc = match_all(a, *d, sh, record_kind, d_out, cap, &dummy, reinterpret_cast<hipStream_t>(stream_), nullptr, tk);
+    rc = match_all(a, *d, sh, record_kind, d_out, cap, &dummy, stream, nullptr, tk);
     if (rc != ACGPU_OK) return rc;
     tk->busy = true;
+    d->inflight++;
+    d->inflight_stream = stream;
     *ticket = reinterpret_cast<acgpu_ticket *>(tk);
     return ACGPU_OK;
 }
@@ -1178,16 +1200,26 @@ int acgpu_match_device_end(const acgpu_automaton *ca, acgpu_ticket *ticket, uint
     if (!ca || !ticket || !n_out) return ACGPU_E_INVALID;
     acgpu_automaton *a = const_cast<acgpu_automaton *>(ca);
     Ticket *tk = reinterpret_cast<Ticket *>(ticket);
-    if (!tk->busy) return ACGPU_E_INVALID;
-    HIP_TRY(hipEventSynchronize(tk->done)); // outside the lock: other calls may be enqueued meanwhile
+    hipEvent_t done = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(a->mu);
+        if (!tk->busy) return ACGPU_E_INVALID;
+        done = tk->done;
+    }
+    HIP_TRY(hipEventSynchronize(done)); // outside the lock: other calls may be enqueued meanwhile
     std::lock_guard<std::mutex> lock(a->mu);
-    if ((uint32_t)tk->h_count[1] != 0) { // the split form's candidate slices were too small: redo with the fused kernel
-        DeviceState *d = reinterpret_cast<DeviceState *>(tk->owner);
-        tk->busy = false;
+    if (!tk->busy) return ACGPU_E_INVALID; // (collected by another thread meanwhile)
+    DeviceState *d = reinterpret_cast<DeviceState *>(tk->owner);
+    if ((uint32_t)tk->h_count[1] != 0) { // a candidate slice / scratch slice was too small: redo with the fused kernel, one slice
+        // (the redo shares the scratch with the tickets still in flight: same stream, so stream order keeps them apart)
         const int rc = match_all(a, *d, &tk->shard, tk->record_kind, tk->d_out, tk->cap, n_out, tk->stream, prof, nullptr, true);
+        tk->busy = false;
+        d->inflight--;
         return rc;
     }
     *n_out = *tk->h_count;
+    tk->busy = false; // (whatever happens below, the ticket is collected)
+    d->inflight--;
     if (prof) {
         std::memset(prof, 0, sizeof(*prof));
         if (tk->profiled) {
@@ -1199,7 +1231,6 @@ int acgpu_match_device_end(const acgpu_automaton *ca, acgpu_ticket *ticket, uint
         prof->n_matches = *n_out;
         std::snprintf(prof->scan_kernel, sizeof(prof->scan_kernel), "%s", tk->kname);
     }
-    tk->busy = false;
     return *n_out > tk->cap ? ACGPU_E_OVERFLOW : ACGPU_OK;
 }
 
@@ -1227,6 +1258,38 @@ int acgpu_match_u16(const acgpu_automaton *ca, const uint16_t *haystack, uint64_
     rc = match_shard(a, *d, &sh, record_kind, d->stage_out.p, cap, n_out, nullptr, nullptr);
     if (rc != ACGPU_OK) return rc;
     if (*n_out) HIP_TRY(hipMemcpy(out, d->stage_out.p, *n_out * (uint64_t)record_kind, hipMemcpyDeviceToHost));
+    return ACGPU_OK;
+}
+
+int acgpu_stream_probe(const void *d_buf, uint64_t n_bytes, void *stream_, int repeats, float *ms_median) {
+    if (!d_buf || !ms_median || ((uintptr_t)d_buf & 15) || n_bytes < (1ull << 20) || repeats < 1 || repeats > 64) return ACGPU_E_INVALID;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(hipEventCreate(&e0));
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return ACGPU_E_HIP; }
+    unsigned *d_sink = nullptr;
+    int rc = ACGPU_OK;
+    std::vector<float> ms;
+    int dev = 0, n_cu = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        n_cu = prop.multiProcessorCount;
+    if (hipMalloc((void **)&d_sink, 64) != hipSuccess) rc = ACGPU_E_NOMEM;
+    for (int r = 0; rc == ACGPU_OK && r <= repeats; ++r) { // (the first run is a warm-up)
+        float t = 0;
+        if (hipEventRecord(e0, stream) != hipSuccess || launch_stream_probe(d_buf, n_bytes, n_cu, d_sink, stream) != hipSuccess ||
+            hipEventRecord(e1, stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+            hipEventElapsedTime(&t, e0, e1) != hipSuccess) {
+            g_last_hip_error = (int)hipGetLastError();
+            rc = ACGPU_E_HIP;
+        } else if (r) ms.push_back(t);
+    }
+    if (d_sink) (void)hipFree(d_sink);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != ACGPU_OK) return rc;
+    std::sort(ms.begin(), ms.end());
+    *ms_median = ms[ms.size() / 2];
     return ACGPU_OK;
 }
 

@@ -1,5 +1,6 @@
 // acgpu_internal.h -- shared between the host builder, the C ABI glue and the HIP kernels.
 #pragma once
+#include <atomic>
 #include <cstdint>
 #include <mutex>
 #include <string>
@@ -213,20 +214,21 @@ struct DevTables {
     uint32_t ww_bloom_mask;
 };
 
+// development/test knobs (acgpu_set_tunable): relaxed atomics, read when a call is enqueued
 struct Tunables {
-    int64_t chunk_units = 0;      // 0 = auto
-    int64_t blocks_per_cu = 1;
-    int64_t lds_table_bytes = 96 * 1024;
-    int64_t force_sparse = 0;
-    int64_t dense_budget_bytes = 1ll << 30;
-    int64_t force_kernel = 0;     // 0 auto, 1 = DFA chunk scan, 2 = k-gram tile scan (when the filter exists)
-    int64_t region_units = 0;     // tile kernel: owned units per wave region (0 = auto)
-    int64_t rdense_budget_bytes = 256ll << 20;
-    int64_t tile_debug = 0;       // ablation switches of the tile kernel (see TileLaunch::debug); 0 in production
+    std::atomic<int64_t> chunk_units{0};      // 0 = auto
+    std::atomic<int64_t> blocks_per_cu{1};
+    std::atomic<int64_t> lds_table_bytes{96 * 1024};
+    std::atomic<int64_t> force_sparse{0};
+    std::atomic<int64_t> dense_budget_bytes{1ll << 30};
+    std::atomic<int64_t> force_kernel{0};     // 0 auto, 1 = DFA chunk scan, 2 = k-gram tile scan (when the filter exists)
+    std::atomic<int64_t> region_units{0};     // tile kernel: owned units per wave region (0 = auto)
+    std::atomic<int64_t> rdense_budget_bytes{256ll << 20};
+    std::atomic<int64_t> tile_debug{0};       // ablation switches of the tile kernel (see TileLaunch::debug); 0 in production
 #ifndef ACGPU_FILTER_MAX_BYTES
 #define ACGPU_FILTER_MAX_BYTES 88000
 #endif
-    int64_t filter_max_bytes = ACGPU_FILTER_MAX_BYTES;  // the filter rows must fit LDS next to the candidate queues
+    std::atomic<int64_t> filter_max_bytes{ACGPU_FILTER_MAX_BYTES};  // the filter rows must fit LDS next to the candidate queues
 };
 Tunables &tunables();
 

@@ -91,7 +91,12 @@ struct PermuteTail {
     const uint64_t *total;
     uint32_t *flag;                   // read, reported, cleared
     unsigned long long *zero_counters; // kMaxSlices counters, kCounterStride apart, or nullptr
+    acgpu_device_result *d_result;     // acgpu_shard::d_result (device memory) or nullptr: the same report, in stream order
 };
+
+// {n_records, redone = 0} into an acgpu_shard::d_result, in stream order (the families whose pipeline ends with a count
+// on the host)
+hipError_t launch_write_result(acgpu_device_result *d_result, uint64_t n_records, hipStream_t stream);
 
 // scratch (unordered) -> final records in reference order
 // (slots whose rank is ~0u are holes left by slot reservations and are skipped)
@@ -102,6 +107,9 @@ hipError_t launch_permute(const ScratchRec *d_scratch, const unsigned long long 
 uint32_t scan_tiles_for(uint32_t n); // number of prefix-sum tiles; the grand total is d_tmp[scan_tiles_for(n)]
 uint32_t tile_reserve_slots();
 uint32_t tile_group_units(); // regions must hold whole tile groups
+
+// pure read of n_bytes in the tile kernels' access pattern (see acgpu_stream_probe)
+hipError_t launch_stream_probe(const void *d_buf, uint64_t n_bytes, int n_cu, unsigned *d_sink, hipStream_t stream);
 
 hipError_t launch_synth_fill(uint16_t *d_dst, uint64_t n, uint64_t start, uint64_t seed, const uint16_t *table,
                              uint32_t table_len, hipStream_t stream);

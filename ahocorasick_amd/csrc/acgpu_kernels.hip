@@ -336,8 +336,15 @@ __global__ __launch_bounds__(256) void k_permute(const ScratchRec *scratch, cons
         if (tail.zero_counters)
             for (uint32_t i = threadIdx.x; i < (uint32_t)kMaxSlices; i += blockDim.x) tail.zero_counters[(size_t)i * kCounterStride] = 0;
         if (tail.result && threadIdx.x == 0) {
-            tail.result[0] = *tail.total;
-            tail.result[1] = tail.flag ? *tail.flag : 0u;
+            const unsigned long long total = *tail.total;
+            const uint32_t flag = tail.flag ? *tail.flag : 0u;
+            tail.result[0] = total;
+            tail.result[1] = flag;
+            if (tail.d_result) {
+                tail.d_result->n_records = total;
+                tail.d_result->redone = flag;
+                tail.d_result->reserved = 0;
+            }
             if (tail.flag) *tail.flag = 0;
             __threadfence_system();
         }
@@ -377,7 +384,7 @@ hipError_t launch_permute(const ScratchRec *d_scratch, const unsigned long long 
                           int record_kind, void *d_out, uint64_t out_cap, const uint32_t *d_id_map, hipStream_t stream,
                           const PermuteTail *tail) {
     if (n_slices < 1) n_slices = 1;
-    const PermuteTail tl = tail ? *tail : PermuteTail{nullptr, nullptr, nullptr, nullptr};
+    const PermuteTail tl = tail ? *tail : PermuteTail{nullptr, nullptr, nullptr, nullptr, nullptr};
     // (8192 or 32768 workgroups instead of 2048 were not faster: the pass is bound by its scattered 12-byte stores)
     const dim3 grid(std::max<uint32_t>(kPermuteBlocks / n_slices, 8u), n_slices);
     if (record_kind == ACGPU_REC_SET)
@@ -390,6 +397,17 @@ hipError_t launch_permute(const ScratchRec *d_scratch, const unsigned long long 
 }
 
 uint32_t scan_tiles_for(uint32_t n) { return (n + kScanTile - 1) / kScanTile; }
+
+__global__ void k_write_result(acgpu_device_result *r, unsigned long long n) {
+    r->n_records = n;
+    r->redone = 0;
+    r->reserved = 0;
+}
+
+hipError_t launch_write_result(acgpu_device_result *d_result, uint64_t n_records, hipStream_t stream) {
+    hipLaunchKernelGGL(k_write_result, dim3(1), dim3(1), 0, stream, d_result, (unsigned long long)n_records);
+    return hipGetLastError();
+}
 
 // ---- synthetic haystack generator (ahocorasick_amd/synth.py is its numpy twin) ---------------
 struct SynthTable {
@@ -416,6 +434,43 @@ hipError_t launch_synth_fill(uint16_t *d_dst, uint64_t n, uint64_t start, uint64
     tab.len = table_len;
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_synth_fill, dim3(4096), dim3(256), 0, stream, d_dst, n, start, seed, tab);
+    return hipGetLastError();
+}
+
+
+// ---- attainable-bandwidth probe ---------------------------------------------------------------------------
+// The read side of k_ac_tile and nothing else: one 1024-thread workgroup per CU, every wave owns a contiguous span and
+// streams it as 4 KiB tiles, lane l holding the 64 consecutive bytes at l*64 (four 16-byte loads), the next tile's loads
+// in flight while the current one is reduced.  What this kernel reaches is the ceiling of the tile kernels' access
+// pattern on the box at hand (bench.py reports it as roofline.attainable next to the 8 TB/s spec peak).
+__global__ __launch_bounds__(1024) void k_stream_probe(const uint4 *__restrict__ p, uint64_t n_tiles, unsigned *sink) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+    const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x / 64);
+    const uint64_t per_wave = (n_tiles + n_waves - 1) / n_waves;
+    const uint64_t t0 = wave * per_wave, t1 = t0 + per_wave < n_tiles ? t0 + per_wave : n_tiles;
+    if (t0 >= t1) return;
+    uint32_t x = 0;
+    uint4 cur[4], nxt[4];
+    const uint4 *b = p + t0 * 256 + lane * 4;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) nxt[u] = b[u];
+    for (uint64_t t = t0; t < t1; ++t) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
+        const uint4 *nb = p + (t + 1 < t1 ? t + 1 : t) * 256 + lane * 4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) nxt[u] = nb[u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x ^= cur[u].x ^ cur[u].y ^ cur[u].z ^ cur[u].w;
+    }
+    if (x == 0x12345678u) sink[0] = x;
+}
+
+hipError_t launch_stream_probe(const void *d_buf, uint64_t n_bytes, int n_cu, unsigned *d_sink, hipStream_t stream) {
+    const uint64_t n_tiles = n_bytes / 4096;
+    if (n_tiles == 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_stream_probe, dim3(n_cu), dim3(1024), 0, stream, reinterpret_cast<const uint4 *>(d_buf), n_tiles, d_sink);
     return hipGetLastError();
 }
 

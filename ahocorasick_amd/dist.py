@@ -1,5 +1,6 @@
 """Multi-GPU sharding of one long haystack: one process per GPU (torch.distributed; backend "nccl" is RCCL over
-xGMI on ROCm, "gloo" in the CPU tests).  SURVEY.md 8e, one row per matcher family:
+xGMI on ROCm, "gloo" in the CPU tests -- and, host-staged, when several ranks have to share one GPU).  SURVEY.md 8e, one
+row per matcher family:
 
 * AhoCorasick (all matches) shards naturally: rank g owns a contiguous range of the haystack, needs the
   (max_keyword_len-1) units before it (left halo, received from rank g-1), starts at the root, and keeps the matches
@@ -15,10 +16,23 @@ xGMI on ROCm, "gloo" in the CPU tests).  SURVEY.md 8e, one row per matcher famil
   reported depends on where matching last restarted (the end of the previous reported match), handed down the ranks
   like the Longest chain position, with the same speculation (no restriction) and window repair.
 
-In all three, rank-local order is the reference's order, so the concatenation of the per-rank buffers by rank is the
-reference's listener-call order for the whole haystack.  The data exchange steps are the tiny halo send/recv, the
-Longest chain hop, and the all-gather of the per-shard match buffers (counts first, then record buffers padded to the
-largest count); positions stay shard-local int32 in the gathered buffer and become global int64 positions by adding
+In all of them rank-local order is the reference's order, so the concatenation of the per-rank buffers by rank is the
+reference's listener-call order for the whole haystack.
+
+Data exchange, and what a step costs the host:
+* halos are exchanged ONCE PER HAYSTACK (when the shard's text changes: haystack_changed()), not per step;
+* every rank scans into a fixed-size GATHER BUFFER [16-byte header | gcap records]; the header is the
+  acgpu_device_result {record count, redone flag} that the scan's last kernel writes in stream order
+  (acgpu_shard.d_result), so ONE all-gather of the whole buffer moves counts and records together and nothing on the
+  host sits between the scan and the collective.  gcap follows the largest count seen so far (with head-room); a step
+  in which some rank's count exceeds it is detected by every rank from the gathered headers and redone by all of them
+  with larger buffers (rare: the first step of a much denser haystack);
+* the AhoCorasick family enqueues its scan with acgpu_match_device_begin and collects it with _end only after the
+  gathered headers have arrived on the host: one blocking host synchronisation per step (the header read-back).  With
+  overlap=True that read-back is the PREVIOUS step's, so the all-gather of step k runs under the scan of step k+1;
+* Longest / Shortest additionally pay the chain hop (one int64 down the ranks), WholeWord the count read-back of its
+  synchronous scan call.
+Positions stay shard-local int32 in the gathered buffer and become global int64 positions by adding
 base[g] = g * units_per_rank (global_records()).
 """
 import numpy as np
@@ -27,11 +41,19 @@ import torch.distributed as dist
 
 from ._native import MODE_ALL, MODE_LONGEST, MODE_SHORTEST, MODE_WHOLEWORD
 
+HDR = 4  # int32 words in front of the records of a gather buffer: acgpu_device_result {u64 n_records, u32 redone, u32 0}
+
 
 def _world(group=None):
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(group), dist.get_world_size(group)
     return 0, 1
+
+
+def _host_staged(t, group=None):
+    """gloo moves host memory: a device tensor is copied to the host, exchanged, and copied back (several ranks on one
+    GPU -- RCCL cannot do that -- and the GPU tests of this module)."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
 
 
 def round_up8(v):
@@ -74,19 +96,20 @@ def exchange_halo(sb, group=None):
         return
     if sb.n_units < max(sb.halo, sb.right):
         raise ValueError("shard of %d units is shorter than its halo (%d, %d)" % (sb.n_units, sb.halo, sb.right))
-    dev = sb.buf.device
+    staged = _host_staged(sb.buf, group)
+    dev = torch.device("cpu") if staged else sb.buf.device
     ops = []
     recv_l = recv_r = None
     # bytes on the wire: RCCL has no 16-bit integer type
     if sb.halo:
         if rank + 1 < world:
-            ops.append(dist.P2POp(dist.isend, sb.tail_view().contiguous().view(torch.uint8), rank + 1, group))
+            ops.append(dist.P2POp(dist.isend, sb.tail_view().contiguous().view(torch.uint8).to(dev), rank + 1, group))
         if rank > 0:
             recv_l = torch.empty(2 * sb.halo, dtype=torch.uint8, device=dev)
             ops.append(dist.P2POp(dist.irecv, recv_l, rank - 1, group))
     if sb.right:
         if rank > 0:
-            ops.append(dist.P2POp(dist.isend, sb.head_view().contiguous().view(torch.uint8), rank - 1, group))
+            ops.append(dist.P2POp(dist.isend, sb.head_view().contiguous().view(torch.uint8).to(dev), rank - 1, group))
         if rank + 1 < world:
             recv_r = torch.empty(2 * sb.right, dtype=torch.uint8, device=dev)
             ops.append(dist.P2POp(dist.irecv, recv_r, rank + 1, group))
@@ -98,58 +121,49 @@ def exchange_halo(sb, group=None):
         sb.right_view().copy_(recv_r.view(torch.int16))
 
 
-def allgather_counts(n_local, device, group=None):
-    """(world,) int64 match counts on the host."""
-    rank, world = _world(group)
-    if world == 1:
-        return np.array([n_local], dtype=np.int64)
-    cnt = torch.tensor([n_local], dtype=torch.int64, device=device)
-    counts = torch.empty(world, dtype=torch.int64, device=device)
-    dist.all_gather_into_tensor(counts, cnt, group=group)
-    return counts.cpu().numpy()
+def allgather_flat(out, send, group=None, async_op=False):
+    """all_gather_into_tensor of equal-sized flat int32 buffers; host-staged under gloo on device tensors."""
+    if _host_staged(send, group):
+        h_out = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(h_out, send.cpu(), group=group)
+        out.copy_(h_out)
+        return None
+    return dist.all_gather_into_tensor(out, send, group=group, async_op=async_op)
 
 
-def allgather_records(local, n_local, counts_h, group=None, async_op=False):
-    """All-gather of the record buffers, padded to the largest count.  local: (cap, cols) int32, first n_local rows
-    valid.  Returns (gathered (world, max_n, cols) int32, work handle or None)."""
-    rank, world = _world(group)
-    if world == 1:
-        return local[:n_local].unsqueeze(0), None
-    dev = local.device
-    max_n = int(counts_h.max())
-    cols = local.shape[1]
-    if max_n == 0:
-        return torch.empty((world, 0, cols), dtype=torch.int32, device=dev), None
-    if local.shape[0] >= max_n:
-        send = local[:max_n]
-    else:
-        send = torch.zeros((max_n, cols), dtype=torch.int32, device=dev)
-        send[:n_local] = local[:n_local]
-    out = torch.empty((world, max_n, cols), dtype=torch.int32, device=dev)
-    work = dist.all_gather_into_tensor(out.view(-1), send.contiguous().view(-1), group=group, async_op=async_op)
-    return out, (work if async_op else None)
-
-
-def allgather_matches(local, n_local, group=None):
-    """Counts, then records.  Returns (gathered (world, max_n, cols) int32, counts (world,) int64 on host)."""
-    counts_h = allgather_counts(n_local, local.device, group)
-    out, _ = allgather_records(local, n_local, counts_h, group)
-    return out, counts_h
-
-
-def global_records(gathered, counts, units_per_rank):
-    """Concatenate per-rank records in rank order with global int64 positions (reference order of the whole text)."""
+def global_records(gathered, counts, units_per_rank, pad=0):
+    """Concatenate per-rank records in rank order with global int64 positions (reference order of the whole text).
+    Records in a gather buffer are relative to the rank's VIEW of its shard buffer: the first owned unit for rank 0,
+    `pad` units in front of it (the aligned room of the left halo) for every other rank."""
     parts = []
     for g, n in enumerate(counts.tolist()):
         r = gathered[g, :n].to(torch.int64).clone()
-        r[:, :2] += g * int(units_per_rank)
+        r[:, :2] += g * int(units_per_rank) - (int(pad) if g else 0)
         parts.append(r)
     return torch.cat(parts) if parts else torch.empty((0, gathered.shape[-1]), dtype=torch.int64)
 
 
+class _Step:
+    """One step in flight: the gather buffer it scans into, the gathered copy, and what collects it."""
+
+    def __init__(self):
+        self.gbuf = None       # (HDR + gcap*cols,) int32 on the device: [header | records]
+        self.gcap = 0
+        self.gathered = None   # (world, HDR + gcap*cols) int32
+        self.hdr_host = None   # (world, HDR) int32, pinned when the buffers live on a GPU
+        self.event = None      # recorded behind the header read-back
+        self.work = None       # the all-gather still in flight (nccl, async)
+        self.ticket = None     # acgpu_match_device_begin ticket (AhoCorasick family)
+        self.n = None          # local record count when the scan call was synchronous
+        self.prof = None
+        self.prof_on = False
+        self.private_out = None  # a scan whose records did not fit gcap keeps them here (the step is then redone)
+
+
 class ShardedMatcher:
-    """One rank's end of the sharded match of one long haystack: device-resident shard, halo exchange, native scan
-    (acgpu_match_device), [Longest: chain hop], all-gather of match buffers.
+    """One rank's end of the sharded match of one long haystack: device-resident shard, halo exchange (once per
+    haystack), native scan into the gather buffer (acgpu_match_device[_begin]), [Longest/Shortest: chain hop],
+    ONE all-gather of header + records.
 
     scan_fn (tests only) replaces the native scan so the plumbing can run under gloo on CPU; it has the contract of
     acgpu_match_device on one shard:
@@ -157,7 +171,7 @@ class ShardedMatcher:
     to the view, chain_exit)."""
 
     def __init__(self, automaton, n_units, with_ids=True, cap=1 << 20, device=None, group=None, scan_fn=None, halo=None,
-                 overlap=False, mode=None, right_halo=None):
+                 overlap=False, mode=None, right_halo=None, adaptive=True):
         self.auto = automaton
         self.group = group
         self.rank, self.world = _world(group)
@@ -174,28 +188,38 @@ class ShardedMatcher:
                 halo, right_halo = 0, max(0, max_len - 1)
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if scan_fn is None else torch.device("cpu")
-        self.sb = ShardBuffer(n_units, halo, device, right_halo or 0)
-        self.cap = int(cap)
-        # overlap: the all-gather of step k runs (on RCCL's stream) while step k+1 scans into the other record buffer
-        self.overlap = bool(overlap) and self.world > 1
-        # single GPU: the same flag pipelines the calls themselves -- step k+1 is enqueued (acgpu_match_device_begin)
-        # before the count of step k is read back, so the GPU never waits for the host between steps
-        self.pipeline = bool(overlap) and self.world == 1 and scan_fn is None and self.mode == MODE_ALL
-        self._ticket = None
-        self.outs = [torch.empty((self.cap, self.cols), dtype=torch.int32, device=device)
-                     for _ in range(2 if (self.overlap or self.pipeline) else 1)]
-        self.out = self.outs[0]
-        self._slot = 0
-        self._tmp = None  # Longest: records of the repair window
-        self._k = 0
-        self._pending = None  # (work, gathered, counts) of the all-gather still in flight
+        self.device = torch.device(device)
+        self.sb = ShardBuffer(n_units, halo, self.device, right_halo or 0)
+        self.cap = int(cap)  # gcap: records per rank in the gather buffer
+        self.adaptive = bool(adaptive)  # gcap shrinks to the largest count seen (+ head-room) after a step
+        self._published = None
+        self._pending_result = None  # result of a step that haystack_changed() completed
+        # overlap: step() leaves its all-gather (world > 1) / its scan (world == 1) in flight and returns the PREVIOUS
+        # step's result; the all-gather of step k then runs under the scan of step k+1
+        self.overlap = bool(overlap)
+        # the AhoCorasick family has the asynchronous form of the native call
+        self.async_scan = scan_fn is None and self.mode == MODE_ALL
         self.scan_fn = scan_fn
+        self._k = 0
+        self._inflight = None   # the _Step a previous step() left for the next one (overlap)
+        self._free = []         # gather buffers of the current gcap, free for reuse
+        self._halo_dirty = True
+        self._side = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self._hop_device = self.device
+        if self.world > 1 and self.device.type == "cuda" and dist.get_backend(group) == "gloo":
+            self._hop_device = torch.device("cpu")
+        self.out = None   # records view of the current step's gather buffer (or its private overflow buffer)
+        self._cur = None
+        self._tmp = None  # Longest / Shortest: records of the repair window
         self.last_kernel = ""
-        self.gathered = None
-        self.counts = None
+        self.gathered = None  # (world, gcap, cols) int32 view of the last COMPLETED step
+        self.counts = None    # (world,) int64 on the host
         self.chain_repairs = 0  # Longest: window re-runs of the last step (0 = speculation was right)
         self.chain_window = 4096  # Longest: first repair window in units (x4 until the chains meet)
+        self.host_syncs = 0   # blocking host synchronisations of the last step() on its own account (diagnostic)
+        self.redone_steps = 0  # steps redone with larger gather buffers
 
+    # ---- the shard's text ------------------------------------------------------------------------------------
     def own_ptr(self):
         return self.sb.own.data_ptr()
 
@@ -203,25 +227,77 @@ class ShardedMatcher:
         v = self.sb.own if k is None else self.sb.own[:k]
         return v.cpu().numpy().view(np.uint16)
 
+    def haystack_changed(self):
+        """Call BEFORE writing new text into sb.own (load() does): a step still in flight (overlap=True) is completed
+        first -- it may have to be redone, which needs its text -- and the next step() exchanges the halos again.  The
+        completed step's result dict is what that next step() returns."""
+        if self._inflight is not None:
+            st, self._inflight = self._inflight, None
+            self._pending_result = self._collect(st)
+        self._halo_dirty = True
+
+    def load(self, units):
+        """Copies this rank's shard (int16/uint16 tensor or numpy array of n_units code units) into the buffer."""
+        if isinstance(units, np.ndarray):
+            units = torch.from_numpy(np.ascontiguousarray(units).view(np.int16))
+        self.haystack_changed()
+        self.sb.own.copy_(units.view(torch.int16))
+
+    # ---- gather buffers ----------------------------------------------------------------------------------------
+    def _new_step(self):
+        st = self._free.pop() if self._free else _Step()
+        if st.gbuf is None or st.gcap != self.cap:
+            st.gcap = self.cap
+            st.gbuf = torch.zeros(HDR + self.cap * self.cols, dtype=torch.int32, device=self.device)
+            if self.world > 1:
+                st.gathered = torch.empty((self.world, HDR + self.cap * self.cols), dtype=torch.int32, device=self.device)
+                st.hdr_host = torch.empty((self.world, HDR), dtype=torch.int32, pin_memory=self.device.type == "cuda")
+            if self.device.type == "cuda":
+                st.event = torch.cuda.Event()
+        st.work = st.ticket = st.n = st.prof = st.private_out = None
+        return st
+
+    def _records(self, st):
+        return st.gbuf[HDR:].view(st.gcap, self.cols)
+
+    def _release(self, st):
+        if st.gcap == self.cap and len(self._free) < 2:
+            self._free.append(st)
+
+    def _write_header(self, st, n):
+        st.gbuf[:HDR].view(torch.int64).copy_(torch.tensor([int(n), 0], dtype=torch.int64))
+
+    @property
+    def shift(self):
+        """view position of this rank's first owned unit (what record positions in its gather buffer are relative to)"""
+        return 0 if self.rank == 0 else self.sb.pad
+
     # ---- one native call on (part of) the shard --------------------------------------------------------------
     def _grow(self, which, need):
+        """A private record buffer: "tmp" (repair windows), or "out" when the step's records do not fit the gather
+        buffer -- the step then finishes locally (the chain hop needs its exit) and is redone by all ranks."""
         cap = max(self.cap, int(need * 1.25) + 16)
-        t = torch.empty((cap, self.cols), dtype=torch.int32, device=self.sb.buf.device)
+        t = torch.empty((cap, self.cols), dtype=torch.int32, device=self.device)
         if which == "out":
-            self.cap = cap
-            self.out = self.outs[self._slot] = t
+            self.out = self._cur.private_out = t
         else:
             self._tmp = t
         return t
 
-    def _call(self, which, own_lo, own_hi, entry, profile=False):
-        """Scan the owned sub-range [own_lo, own_hi) (shard-relative) of this rank's buffer into self.out / self._tmp.
-        Records come back shard-relative.  Returns (n, chain_exit (shard-relative), profile dict | None)."""
+    def _view(self):
         sb = self.sb
         first = self.rank == 0
         last = self.rank == self.world - 1
         v0 = sb.pad if first else 0  # the pad in front of rank 0's text is not part of the haystack
         v1 = sb.pad + sb.n_units + (0 if last else sb.right)
+        return v0, v1, first, last
+
+    def _call(self, which, own_lo, own_hi, entry, profile=False, d_result=None):
+        """Scan the owned sub-range [own_lo, own_hi) (shard-relative) of this rank's buffer into self.out / self._tmp.
+        Records come back relative to the VIEW (see global_records); own_lo, own_hi, entry and the returned chain exit
+        are shard-relative.  Returns (n, chain_exit, profile dict | None)."""
+        sb = self.sb
+        v0, v1, first, last = self._view()
         shift = sb.pad - v0  # view position of shard position 0
         buf = self.out if which == "out" else self._tmp
         if buf is None:
@@ -233,46 +309,54 @@ class ShardedMatcher:
             if n > buf.shape[0]:
                 buf = self._grow(which, n)
             if n:
-                r = np.ascontiguousarray(recs[:, :self.cols], dtype=np.int32).copy()
-                r[:, :2] -= shift
-                buf[:n] = torch.from_numpy(r)
+                buf[:n] = torch.from_numpy(np.ascontiguousarray(recs[:, :self.cols], dtype=np.int32))
             return n, int(ex) - shift, None
         from . import _native as N
         stream = torch.cuda.current_stream().cuda_stream
         while True:
             n, rc, prof, ex = self.auto.match_device(sb.buf.data_ptr() + 2 * v0, v1 - v0, self.with_ids, buf.data_ptr(),
                                                      buf.shape[0], own=(own_lo + shift, own_hi + shift), text_begin=first,
-                                                     text_end=last, chain_entry=entry + shift, stream=stream, profile=profile)
+                                                     text_end=last, chain_entry=entry + shift, stream=stream, profile=profile,
+                                                     d_result=d_result)
+            self.host_syncs += 1
             if rc == N.E_OVERFLOW:
                 buf = self._grow(which, n)
+                d_result = None  # (the header already says n > gcap)
                 continue
             N.check(rc, "acgpu_match_device")
             break
-        if shift and n:
-            buf[:n, :2] -= shift  # view-relative -> shard-relative
         if prof:
             self.last_kernel = prof["scan_kernel"]
         return n, ex - shift, prof
 
-    def _scan(self, profile):
+    def _scan(self, profile, st):
+        """Synchronous scan of the whole shard into st's gather buffer; the header is in place when it returns."""
+        self._cur = st
+        self.out = self._records(st)
         if self.mode == MODE_LONGEST:
-            return self._scan_longest(profile)
-        if self.mode == MODE_SHORTEST:
-            return self._scan_shortest(profile)
-        n, _, prof = self._call("out", 0, self.sb.n_units, 0, profile)
+            n, prof = self._scan_longest(profile)
+        elif self.mode == MODE_SHORTEST:
+            n, prof = self._scan_shortest(profile)
+        else:
+            native = self.scan_fn is None
+            n, _, prof = self._call("out", 0, self.sb.n_units, 0, profile, d_result=st.gbuf.data_ptr() if native else None)
+            if native:
+                return n, prof
+        self._write_header(st, n)
         return n, prof
 
     # ---- Longest: speculative chain + one int64 down the ranks -----------------------------------------------
     def _chain_hop_recv(self):
         if self.rank == 0:
             return 0
-        t = torch.empty(1, dtype=torch.int64, device=self.sb.buf.device)
+        t = torch.empty(1, dtype=torch.int64, device=self._hop_device)
         dist.recv(t, self.rank - 1, group=self.group)
+        self.host_syncs += 1
         return int(t.item()) - self.rank * self.sb.n_units  # global -> shard-relative
 
     def _chain_hop_send(self, exit_pos):
         if self.rank + 1 < self.world:
-            t = torch.tensor([exit_pos + self.rank * self.sb.n_units], dtype=torch.int64, device=self.sb.buf.device)
+            t = torch.tensor([exit_pos + self.rank * self.sb.n_units], dtype=torch.int64, device=self._hop_device)
             dist.send(t, self.rank + 1, group=self.group)
 
     def _scan_longest(self, profile):
@@ -281,7 +365,7 @@ class ShardedMatcher:
         entry = self._chain_hop_recv()  # true entry >= 0: the previous rank's exit
         self.chain_repairs = 0
         if entry != 0:
-            spec = self.out
+            spec, shift = self.out, self.shift  # (records are view-relative, the chain positions shard-relative)
             starts = spec[:n, 0].contiguous()
             w = int(self.chain_window)
             while True:
@@ -292,8 +376,8 @@ class ShardedMatcher:
                     idx, ex_s = n, ex_t
                 else:
                     # where the speculative chain leaves the window: max(w_end, end of its last match starting inside)
-                    idx = int(torch.searchsorted(starts, torch.tensor([w_end], dtype=torch.int32, device=starts.device)).item())
-                    ex_s = max(w_end, int(spec[idx - 1, 1].item())) if idx else w_end
+                    idx = int(torch.searchsorted(starts, torch.tensor([w_end + shift], dtype=torch.int32, device=starts.device)).item())
+                    ex_s = max(w_end, int(spec[idx - 1, 1].item()) - shift) if idx else w_end
                 if w_end == n_own or ex_t == ex_s:
                     tail = spec[idx:n].clone()
                     if n_t + len(tail) > self.out.shape[0]:
@@ -316,6 +400,7 @@ class ShardedMatcher:
         n, _, prof = self._call("out", 0, n_own, none, profile)
         entry = max(self._chain_hop_recv(), none) if self.rank else none
         self.chain_repairs = 0
+        shift = self.shift  # (records are view-relative, the restart positions shard-relative)
         if entry > -halo:  # a restart inside my halo can forbid matches that begin before it
             spec = self.out
             ends = spec[:n, 1].contiguous()
@@ -326,9 +411,9 @@ class ShardedMatcher:
                 n_t, _, _ = self._call("tmp", 0, w_end, entry)
                 # speculative records that end inside the window (ends ascend)
                 idx = n if w_end == n_own else int(torch.searchsorted(
-                    ends, torch.tensor([w_end], dtype=torch.int32, device=ends.device), right=True).item())
-                last_t = int(self._tmp[n_t - 1, 1].item()) if n_t else entry
-                last_s = int(spec[idx - 1, 1].item()) if idx else none
+                    ends, torch.tensor([w_end + shift], dtype=torch.int32, device=ends.device), right=True).item())
+                last_t = int(self._tmp[n_t - 1, 1].item()) - shift if n_t else entry
+                last_s = int(spec[idx - 1, 1].item()) - shift if idx else none
                 floor = w_end - halo  # restart positions at or left of this restrict nothing that ends after the window
                 if w_end == n_own or max(last_t, floor) == max(last_s, floor):
                     tail = spec[idx:n].clone()
@@ -339,87 +424,137 @@ class ShardedMatcher:
                     n = n_t + len(tail)
                     break
                 w *= 4
-        self._chain_hop_send(int(self.out[n - 1, 1].item()) if n else entry)
+        self._chain_hop_send(int(self.out[n - 1, 1].item()) - shift if n else entry)
         return n, prof
 
-    def step(self, profile=False):
-        """halo exchange -> scan -> all-gather.  Returns a dict with n_local, n_total and (profile) kernel timings.
-        With overlap=True the record all-gather is left in flight; `gathered`/`counts` then describe the last
-        COMPLETED step until finish() is called."""
-        if self.pipeline:
-            return self._step_pipelined(profile)
-        exchange_halo(self.sb, self.group)
-        self._slot = self._k % len(self.outs)
-        self._k += 1
-        self.out = self.outs[self._slot]
-        n, prof = self._scan(profile)
-        counts = allgather_counts(n, self.out.device, self.group)
-        if self.overlap:
-            self._complete_pending()  # the other buffer's gather: makes this stream wait for it, not the host
-            gathered, work = allgather_records(self.out, n, counts, self.group, async_op=True)
-            self._pending = (work, gathered, counts)
-        else:
-            self.gathered, _ = allgather_records(self.out, n, counts, self.group)
-            self.counts = counts
-        r = {"n_local": int(n), "n_total": int(counts.sum()), "scan_ms": 0.0, "finalize_ms": 0.0}
-        if prof:
-            r.update(scan_ms=prof["scan_ms"], finalize_ms=prof["finalize_ms"])
-        return r
-
-    def _step_pipelined(self, profile):
-        """world == 1: enqueue this step, then collect the PREVIOUS one.  Returns the previous step's result dict
-        (None for the first call); finish() returns the last one."""
+    # ---- a step: enqueue (scan + all-gather + header read-back), collect ----------------------------------------
+    def _enqueue(self, profile):
         from . import _native as N
-        sb = self.sb
-        slot = self._k % 2
-        self._k += 1
-        out = self.outs[slot]
-        tk, rc = self.auto.match_device_begin(sb.own.data_ptr(), sb.n_units, self.with_ids, out.data_ptr(), out.shape[0],
-                                              stream=torch.cuda.current_stream().cuda_stream, profile=profile)
-        N.check(rc, "acgpu_match_device_begin")
-        prev = self._collect(profile)
-        self._ticket = (tk, slot, profile)
-        return prev
-
-    def _collect(self, profile):
-        from . import _native as N
-        if self._ticket is None:
-            return None
-        tk, slot, prof_on = self._ticket
-        self._ticket = None
-        n, rc, prof = self.auto.match_device_end(tk, profile=prof_on)
-        if rc == N.E_OVERFLOW:  # rare: grow both buffers and redo that step synchronously
-            self.cap = max(self.cap, int(n * 1.25) + 16)
-            self.outs = [torch.empty((self.cap, self.cols), dtype=torch.int32, device=self.outs[0].device) for _ in self.outs]
-            self.out = self.outs[slot]
-            self._slot = slot
-            n, prof = self._scan(prof_on)
+        st = self._new_step()
+        st.prof_on = profile
+        if self.async_scan:
+            sb = self.sb
+            v0, v1, first, last = self._view()
+            shift = sb.pad - v0
+            tk, rc = self.auto.match_device_begin(sb.buf.data_ptr() + 2 * v0, v1 - v0, self.with_ids,
+                                                  st.gbuf.data_ptr() + 4 * HDR, st.gcap, own=(shift, shift + sb.n_units),
+                                                  text_begin=first, text_end=last,
+                                                  stream=torch.cuda.current_stream().cuda_stream, profile=profile,
+                                                  d_result=st.gbuf.data_ptr())
+            N.check(rc, "acgpu_match_device_begin")
+            st.ticket = tk
         else:
-            N.check(rc, "acgpu_match_device_end")
-        self.out = self.outs[slot]
-        self.gathered, self.counts = self.out[:n].unsqueeze(0), np.array([n], dtype=np.int64)
+            st.n, st.prof = self._scan(profile, st)
+        if self.world > 1:
+            if self.device.type == "cuda" and not _host_staged(st.gbuf, self.group):
+                st.work = allgather_flat(st.gathered.view(-1), st.gbuf, self.group, async_op=True)
+                with torch.cuda.stream(self._side):
+                    st.work.wait()  # (the side stream waits for RCCL's; the scan stream is free for the next step)
+                    st.hdr_host.copy_(st.gathered[:, :HDR], non_blocking=True)
+                    st.event.record(self._side)
+            else:
+                allgather_flat(st.gathered.view(-1), st.gbuf, self.group)
+                st.hdr_host.copy_(st.gathered[:, :HDR])
+        return st
+
+    def _collect(self, st):
+        """Waits for what _enqueue left in flight (ONE blocking host synchronisation: the header read-back / the scan's
+        done event), publishes gathered/counts, and returns the step's result dict.  A step whose records did not fit
+        the gather buffers on some rank -- every rank sees that in the gathered headers -- is redone by all ranks."""
+        from . import _native as N
+        n, prof = st.n, st.prof
+        if self.world > 1 and st.work is not None:
+            st.event.synchronize()
+            self.host_syncs += 1
+        if st.ticket is not None:
+            tk, st.ticket = st.ticket, None
+            n, rc, prof = self.auto.match_device_end(tk, profile=st.prof_on)  # (world > 1: its event has long passed)
+            if self.world == 1:
+                self.host_syncs += 1
+            if rc != N.E_OVERFLOW:
+                N.check(rc, "acgpu_match_device_end")
+        if self.world > 1:
+            hdr = st.hdr_host.numpy()
+            counts = (hdr[:, 0].astype(np.int64) & 0xffffffff) | (hdr[:, 1].astype(np.int64) << 32)
+            bad = bool((counts > st.gcap).any() or (hdr[:, 2] != 0).any())
+        else:
+            counts = np.array([n], dtype=np.int64)
+            bad = n > st.gcap
+        if bad:
+            return self._redo(st, int(counts.max()), counts)
         if prof:
             self.last_kernel = prof["scan_kernel"]
-        r = {"n_local": int(n), "n_total": int(n), "scan_ms": 0.0, "finalize_ms": 0.0}
+        if self.world > 1:
+            self.gathered = st.gathered[:, HDR:].view(self.world, st.gcap, self.cols)
+        else:
+            self.gathered = self._records(st)[:n].unsqueeze(0)
+        self.counts = counts
+        # the published step's buffers back `gathered` until the next step is published; then they are free again
+        old, self._published = self._published, st
+        if old is not None:
+            self._release(old)
+        if self.adaptive:  # the next gather buffers follow the largest count (the all-gather moves gcap records per rank)
+            target = int(int(counts.max()) * 1.0625) + 1024
+            if target < 0.8 * self.cap:
+                self.cap = target
+                self._free = []
+        r = {"n_local": int(counts[self.rank]), "n_total": int(counts.sum()), "scan_ms": 0.0, "finalize_ms": 0.0}
         if prof:
             r.update(scan_ms=prof["scan_ms"], finalize_ms=prof["finalize_ms"])
         return r
 
-    def _complete_pending(self):
-        if self._pending is not None:
-            work, gathered, counts = self._pending
-            if work is not None:
-                work.wait()
-            self.gathered, self.counts = gathered, counts
-            self._pending = None
+    def _redo(self, st, need, counts):
+        """All ranks arrive here together (the decision comes from the gathered headers): larger gather buffers, then the
+        step once more, synchronously.  A later step that is already in flight keeps its own (old) buffers and is
+        collected -- or redone -- on its own account."""
+        self.redone_steps += 1
+        self.cap = max(self.cap, int(need * 1.25) + 16)
+        self._free = []
+        prof_on = st.prof_on
+        st2 = self._new_step()
+        st2.prof_on = prof_on
+        async_scan, self.async_scan = self.async_scan, False
+        try:
+            if self.scan_fn is None and self.mode == MODE_ALL:
+                self._cur = st2
+                self.out = self._records(st2)
+                st2.n, _, st2.prof = self._call("out", 0, self.sb.n_units, 0, prof_on, d_result=st2.gbuf.data_ptr())
+            else:
+                st2.n, st2.prof = self._scan(prof_on, st2)
+            if self.world > 1:
+                if self.device.type == "cuda":
+                    torch.cuda.current_stream().synchronize()
+                allgather_flat(st2.gathered.view(-1), st2.gbuf, self.group)
+                st2.hdr_host.copy_(st2.gathered[:, :HDR])
+        finally:
+            self.async_scan = async_scan
+        return self._collect(st2)
+
+    def step(self, profile=False):
+        """[halo exchange, first step of a haystack] -> scan -> all-gather.  Returns a dict with n_local, n_total and
+        (profile) kernel timings.  With overlap=True the step is left in flight and the PREVIOUS step's dict is returned
+        (None for the first call); `gathered`/`counts` describe the last COMPLETED step until finish() is called."""
+        self.host_syncs = 0
+        if self._halo_dirty:
+            exchange_halo(self.sb, self.group)
+            self._halo_dirty = False
+        self._k += 1
+        st = self._enqueue(profile)
+        if not self.overlap:
+            return self._collect(st)
+        prev, self._inflight = self._inflight, st
+        if prev is not None:
+            return self._collect(prev)
+        r, self._pending_result = self._pending_result, None
+        return r
 
     def finish(self):
-        """Completes what step() left in flight: the overlapped all-gather (world > 1) or the last pipelined call
-        (world == 1; its result dict is returned)."""
-        if self.pipeline:
-            return self._collect(True)
-        self._complete_pending()
-        return None
+        """Completes what step() left in flight (overlap=True) and returns that step's result dict."""
+        st, self._inflight = self._inflight, None
+        if st is not None:
+            return self._collect(st)
+        r, self._pending_result = self._pending_result, None
+        return r
 
     def global_records(self):
-        return global_records(self.gathered, self.counts, self.sb.n_units)
+        return global_records(self.gathered, self.counts, self.sb.n_units, self.sb.pad)

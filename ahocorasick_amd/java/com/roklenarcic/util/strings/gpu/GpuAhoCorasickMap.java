@@ -8,6 +8,7 @@ import java.util.List;
 import com.roklenarcic.util.strings.MapMatchListener;
 import com.roklenarcic.util.strings.ReadableMatchListener;
 import com.roklenarcic.util.strings.StringMap;
+import com.roklenarcic.util.strings.threshold.Thresholder;
 
 /** Drop-in for com.roklenarcic.util.strings.AhoCorasickMap&lt;T&gt; (both overloads on the GPU). */
 public class GpuAhoCorasickMap<T> implements StringMap<T>, AutoCloseable {
@@ -15,6 +16,12 @@ public class GpuAhoCorasickMap<T> implements StringMap<T>, AutoCloseable {
     final List<T> values = new ArrayList<T>();
 
     public GpuAhoCorasickMap(final Iterable<String> keywords, final Iterable<? extends T> values, boolean caseSensitive) {
+        this(NativeAutomaton.MODE_ALL, keywords, values, caseSensitive, null);
+    }
+
+    /** Same signature as AhoCorasickMap(Iterable, Iterable, boolean, Thresholder); the Thresholder is ignored (results-neutral). */
+    public GpuAhoCorasickMap(final Iterable<String> keywords, final Iterable<? extends T> values, boolean caseSensitive,
+            final Thresholder thresholdStrategy) {
         this(NativeAutomaton.MODE_ALL, keywords, values, caseSensitive, null);
     }
 

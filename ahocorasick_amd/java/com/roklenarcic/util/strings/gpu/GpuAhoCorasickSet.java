@@ -5,12 +5,21 @@ import java.util.List;
 
 import com.roklenarcic.util.strings.SetMatchListener;
 import com.roklenarcic.util.strings.StringSet;
+import com.roklenarcic.util.strings.threshold.Thresholder;
 
 /** Drop-in for com.roklenarcic.util.strings.AhoCorasickSet (same constructor arguments, same listener contract). */
 public class GpuAhoCorasickSet implements StringSet, AutoCloseable {
     final NativeAutomaton automaton;
 
     public GpuAhoCorasickSet(final Iterable<String> keywords, boolean caseSensitive) {
+        this(NativeAutomaton.MODE_ALL, keywords, caseSensitive, null);
+    }
+
+    /**
+     * Same signature as AhoCorasickSet(Iterable, boolean, Thresholder). The Thresholder only chooses between the
+     * reference's two node representations (results-neutral); the GPU tables have no such choice, so it is ignored.
+     */
+    public GpuAhoCorasickSet(final Iterable<String> keywords, boolean caseSensitive, final Thresholder thresholdStrategy) {
         this(NativeAutomaton.MODE_ALL, keywords, caseSensitive, null);
     }
 

@@ -3,25 +3,71 @@
  * Build (on a machine with a JDK; not possible in the build image):
  *   gcc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -I../../../include \
  *       -o libacgpu_jni.so acgpu_jni.c -L../../lib -lacgpu -Wl,-rpath,'$ORIGIN'
+ *
+ * Rules this file keeps:
+ *  - no JNI critical region is ever open across a call into libacgpu (those calls take a mutex, allocate device memory,
+ *    copy over PCIe and wait for a stream; a critical region would lock the garbage collector out for all of that): the
+ *    haystack is COPIED out of the String with GetStringRegion, in bounded slices, into a native buffer;
+ *  - every allocation is checked (java.lang.OutOfMemoryError), every JNI call that can leave an exception pending is
+ *    followed by a check;
+ *  - a result that does not fit a Java int[] is an error, not a truncated array.
  */
 #include <jni.h>
+#include <limits.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include "acgpu.h"
 
+#define REGION_SLICE (32 * 1024 * 1024) /* chars per GetStringRegion call (64 MiB) */
+
 static void throw_new(JNIEnv *env, const char *cls, const char *msg) {
+    if ((*env)->ExceptionCheck(env)) return; /* keep the first one */
     jclass c = (*env)->FindClass(env, cls);
     if (c) (*env)->ThrowNew(env, c, msg);
+}
+
+static void throw_oom(JNIEnv *env, const char *what) { throw_new(env, "java/lang/OutOfMemoryError", what); }
+
+static void throw_rc(JNIEnv *env, int rc) {
+    if (rc == ACGPU_E_NOMEM) throw_oom(env, acgpu_strerror(rc));
+    else if (rc == ACGPU_E_UNSUPPORTED) throw_new(env, "java/lang/UnsupportedOperationException", acgpu_strerror(rc));
+    else throw_new(env, "java/lang/IllegalStateException", acgpu_strerror(rc));
+}
+
+/* IllegalArgumentException(keyword + " contains non-word characters.") -- the reference's message,
+ * S/WholeWordMatchMap.java:265 -- built from the String itself (any characters, any length) */
+static void throw_nonword(JNIEnv *env, jobjectArray keywords, int64_t bad) {
+    jstring kw = (bad >= 0 && bad < (int64_t)(*env)->GetArrayLength(env, keywords))
+                     ? (jstring)(*env)->GetObjectArrayElement(env, keywords, (jsize)bad) : NULL;
+    jclass scls = (*env)->FindClass(env, "java/lang/String");
+    jclass ecls = (*env)->FindClass(env, "java/lang/IllegalArgumentException");
+    if (!kw || !scls || !ecls) {
+        throw_new(env, "java/lang/IllegalArgumentException", "keyword contains non-word characters.");
+        return;
+    }
+    jmethodID concat = (*env)->GetMethodID(env, scls, "concat", "(Ljava/lang/String;)Ljava/lang/String;");
+    jmethodID ctor = (*env)->GetMethodID(env, ecls, "<init>", "(Ljava/lang/String;)V");
+    jstring tail = (*env)->NewStringUTF(env, " contains non-word characters.");
+    if (!concat || !ctor || !tail) return; /* (an exception is pending) */
+    jstring msg = (jstring)(*env)->CallObjectMethod(env, kw, concat, tail);
+    if ((*env)->ExceptionCheck(env) || !msg) return;
+    jthrowable ex = (jthrowable)(*env)->NewObject(env, ecls, ctor, msg);
+    if (ex) (*env)->Throw(env, ex);
 }
 
 JNIEXPORT jlong JNICALL Java_com_roklenarcic_util_strings_gpu_NativeAutomaton_build(JNIEnv *env, jclass cls, jint mode,
                                                                                       jobjectArray keywords, jboolean cs,
                                                                                       jcharArray lower, jbooleanArray wordChars) {
     (void)cls;
-    jsize n = (*env)->GetArrayLength(env, keywords);
+    const jsize n = (*env)->GetArrayLength(env, keywords);
     uint64_t *off = (uint64_t *)calloc((size_t)n + 1, sizeof(uint64_t));
+    uint16_t *units = NULL;
+    uint8_t *wc = NULL;
+    jchar *lo = NULL;
+    acgpu_automaton *a = NULL;
+    if (!off) { throw_oom(env, "keyword offsets"); return 0; }
     uint64_t total = 0;
     for (jsize i = 0; i < n; i++) {
         jstring s = (jstring)(*env)->GetObjectArrayElement(env, keywords, i);
@@ -29,37 +75,59 @@ JNIEXPORT jlong JNICALL Java_com_roklenarcic_util_strings_gpu_NativeAutomaton_bu
         off[i + 1] = total;
         if (s) (*env)->DeleteLocalRef(env, s);
     }
-    uint16_t *units = (uint16_t *)malloc((size_t)(total ? total : 1) * sizeof(uint16_t));
+    units = (uint16_t *)malloc((size_t)(total ? total : 1) * sizeof(uint16_t));
+    if (!units) { throw_oom(env, "keyword units"); goto done; }
     for (jsize i = 0; i < n; i++) {
         jstring s = (jstring)(*env)->GetObjectArrayElement(env, keywords, i);
         if (s) {
             (*env)->GetStringRegion(env, s, 0, (jsize)(off[i + 1] - off[i]), (jchar *)(units + off[i]));
             (*env)->DeleteLocalRef(env, s);
+            if ((*env)->ExceptionCheck(env)) goto done;
         }
     }
-    jchar *lo = lower ? (*env)->GetCharArrayElements(env, lower, NULL) : NULL;
-    uint8_t *wc = NULL;
     if (wordChars) {
+        if ((*env)->GetArrayLength(env, wordChars) < 65536) {
+            throw_new(env, "java/lang/IllegalArgumentException", "wordChars must have 65536 entries");
+            goto done;
+        }
         jboolean *b = (*env)->GetBooleanArrayElements(env, wordChars, NULL);
+        if (!b) goto done; /* OutOfMemoryError pending */
         wc = (uint8_t *)malloc(65536);
-        for (int i = 0; i < 65536; i++) wc[i] = b[i] ? 1 : 0;
+        if (wc) for (int i = 0; i < 65536; i++) wc[i] = b[i] ? 1 : 0;
         (*env)->ReleaseBooleanArrayElements(env, wordChars, b, JNI_ABORT);
+        if (!wc) { throw_oom(env, "word-character table"); goto done; }
     }
-    acgpu_automaton *a = NULL;
-    int64_t bad = -1;
-    int rc = acgpu_build(mode, units, off, (uint32_t)n, cs ? 1 : 0, (const uint16_t *)lo, wc, &a, &bad);
+    if (lower) {
+        if ((*env)->GetArrayLength(env, lower) < 65536) {
+            throw_new(env, "java/lang/IllegalArgumentException", "lower must have 65536 entries");
+            goto done;
+        }
+        lo = (*env)->GetCharArrayElements(env, lower, NULL); /* (not a critical region: acgpu_build may take a while) */
+        if (!lo) goto done;
+    }
+    {
+        int64_t bad = -1;
+        const int rc = acgpu_build(mode, units, off, (uint32_t)n, cs ? 1 : 0, (const uint16_t *)lo, wc, &a, &bad);
+        if (rc == ACGPU_E_NONWORD) throw_nonword(env, keywords, bad);
+        else if (rc != ACGPU_OK) throw_rc(env, rc);
+    }
+done:
     if (lo) (*env)->ReleaseCharArrayElements(env, lower, lo, JNI_ABORT);
     free(wc);
-    if (rc == ACGPU_E_NONWORD) {
-        /* the reference's message: keyword + " contains non-word characters." (S/WholeWordMatchMap.java:265) */
-        char msg[256] = "keyword contains non-word characters.";
-        throw_new(env, "java/lang/IllegalArgumentException", msg);
-    } else if (rc != ACGPU_OK) {
-        throw_new(env, "java/lang/IllegalStateException", acgpu_strerror(rc));
-    }
     free(units);
     free(off);
     return (jlong)(intptr_t)a;
+}
+
+/* records -> int[]; a result beyond Integer.MAX_VALUE ints cannot be represented */
+static jintArray to_int_array(JNIEnv *env, const void *buf, uint64_t n_ints) {
+    if (n_ints > (uint64_t)INT_MAX - 8) {
+        throw_new(env, "java/lang/IllegalStateException", "more match records than a Java int[] can hold; scan the haystack in parts");
+        return NULL;
+    }
+    jintArray out = (*env)->NewIntArray(env, (jsize)n_ints);
+    if (out && n_ints) (*env)->SetIntArrayRegion(env, out, 0, (jsize)n_ints, (const jint *)buf);
+    return out; /* NULL: OutOfMemoryError pending */
 }
 
 JNIEXPORT jintArray JNICALL Java_com_roklenarcic_util_strings_gpu_NativeAutomaton_match(JNIEnv *env, jclass cls, jlong handle,
@@ -70,25 +138,31 @@ JNIEXPORT jintArray JNICALL Java_com_roklenarcic_util_strings_gpu_NativeAutomato
         return NULL;
     }
     const acgpu_automaton *a = (const acgpu_automaton *)(intptr_t)handle;
-    jsize n = (*env)->GetStringLength(env, haystack);
-    const jchar *units = (*env)->GetStringCritical(env, haystack, NULL); /* no copy on most JVMs */
+    const jsize n = (*env)->GetStringLength(env, haystack);
     const int kind = withIds ? ACGPU_REC_MAP : ACGPU_REC_SET;
+    /* the haystack is copied out of the String (a compact-strings JVM inflates Latin-1 here); no critical region */
+    jchar *units = (jchar *)malloc((size_t)(n ? n : 1) * sizeof(jchar));
+    if (!units) { throw_oom(env, "haystack copy"); return NULL; }
+    for (jsize at = 0; at < n; at += REGION_SLICE) {
+        const jsize len = n - at < REGION_SLICE ? n - at : REGION_SLICE;
+        (*env)->GetStringRegion(env, haystack, at, len, units + at);
+        if ((*env)->ExceptionCheck(env)) { free(units); return NULL; }
+    }
     uint64_t cap = (uint64_t)n / 64 + 4096, n_out = 0;
     void *buf = malloc(cap * (size_t)kind);
+    jintArray out = NULL;
+    if (!buf) { throw_oom(env, "match records"); free(units); return NULL; }
     int rc = acgpu_match_u16(a, (const uint16_t *)units, (uint64_t)n, kind, buf, cap, &n_out);
     if (rc == ACGPU_E_OVERFLOW) { /* retry once with the exact capacity */
         cap = n_out;
-        buf = realloc(buf, cap * (size_t)kind);
+        void *bigger = realloc(buf, cap * (size_t)kind);
+        if (!bigger) { throw_oom(env, "match records"); free(buf); free(units); return NULL; }
+        buf = bigger;
         rc = acgpu_match_u16(a, (const uint16_t *)units, (uint64_t)n, kind, buf, cap, &n_out);
     }
-    (*env)->ReleaseStringCritical(env, haystack, units);
-    jintArray out = NULL;
-    if (rc == ACGPU_OK) {
-        out = (*env)->NewIntArray(env, (jsize)(n_out * (uint64_t)(kind / 4)));
-        if (out) (*env)->SetIntArrayRegion(env, out, 0, (jsize)(n_out * (uint64_t)(kind / 4)), (const jint *)buf);
-    } else {
-        throw_new(env, "java/lang/IllegalStateException", acgpu_strerror(rc));
-    }
+    free(units);
+    if (rc == ACGPU_OK) out = to_int_array(env, buf, n_out * (uint64_t)(kind / 4));
+    else throw_rc(env, rc);
     free(buf);
     return out;
 }
@@ -103,9 +177,8 @@ JNIEXPORT void JNICALL Java_com_roklenarcic_util_strings_gpu_NativeAutomaton_fre
 JNIEXPORT jlong JNICALL Java_com_roklenarcic_util_strings_gpu_NativeAutomaton_streamOpen(JNIEnv *env, jclass cls, jlong handle) {
     (void)cls;
     acgpu_stream *s = NULL;
-    int rc = acgpu_stream_open((const acgpu_automaton *)(intptr_t)handle, &s);
-    if (rc != ACGPU_OK) throw_new(env, rc == ACGPU_E_UNSUPPORTED ? "java/lang/UnsupportedOperationException" : "java/lang/IllegalStateException",
-                                  acgpu_strerror(rc));
+    const int rc = acgpu_stream_open((const acgpu_automaton *)(intptr_t)handle, &s);
+    if (rc != ACGPU_OK) throw_rc(env, rc);
     return (jlong)(intptr_t)s;
 }
 
@@ -114,24 +187,33 @@ JNIEXPORT jintArray JNICALL Java_com_roklenarcic_util_strings_gpu_NativeAutomato
                                                                                                jboolean last) {
     (void)cls;
     acgpu_stream *s = (acgpu_stream *)(intptr_t)stream;
-    jchar *units = (*env)->GetCharArrayElements(env, chunk, NULL);
+    if (length < 0 || length > (*env)->GetArrayLength(env, chunk)) {
+        throw_new(env, "java/lang/ArrayIndexOutOfBoundsException", "length");
+        return NULL;
+    }
+    /* a copy (GetCharArrayRegion), for the same reason as in match(): the feed blocks on the GPU */
+    jchar *units = (jchar *)malloc((size_t)(length ? length : 1) * sizeof(jchar));
+    if (!units) { throw_oom(env, "chunk copy"); return NULL; }
+    (*env)->GetCharArrayRegion(env, chunk, 0, length, units);
     uint64_t cap = (uint64_t)length / 64 + 4096, n_out = 0;
     int64_t base = 0;
     int32_t *buf = (int32_t *)malloc(cap * ACGPU_REC_MAP);
+    jintArray out = NULL;
+    if (!buf) { throw_oom(env, "match records"); free(units); return NULL; }
     int rc = acgpu_stream_feed(s, (const uint16_t *)units, (uint64_t)length, last ? 1 : 0, ACGPU_REC_MAP, buf, cap, &n_out, &base);
     if (rc == ACGPU_E_OVERFLOW) { /* nothing was consumed: same feed, exact capacity */
         cap = n_out;
-        buf = (int32_t *)realloc(buf, cap * ACGPU_REC_MAP);
+        int32_t *bigger = (int32_t *)realloc(buf, cap * ACGPU_REC_MAP);
+        if (!bigger) { throw_oom(env, "match records"); free(buf); free(units); return NULL; }
+        buf = bigger;
         rc = acgpu_stream_feed(s, (const uint16_t *)units, (uint64_t)length, last ? 1 : 0, ACGPU_REC_MAP, buf, cap, &n_out, &base);
     }
-    (*env)->ReleaseCharArrayElements(env, chunk, units, JNI_ABORT);
-    jintArray out = NULL;
+    free(units);
     if (rc == ACGPU_OK) {
         for (uint64_t i = 0; i < n_out; i++) buf[i] = buf[3 * i + 2]; /* the Readable listener only sees the value */
-        out = (*env)->NewIntArray(env, (jsize)n_out);
-        if (out) (*env)->SetIntArrayRegion(env, out, 0, (jsize)n_out, (const jint *)buf);
+        out = to_int_array(env, buf, n_out);
     } else {
-        throw_new(env, "java/lang/IllegalStateException", acgpu_strerror(rc));
+        throw_rc(env, rc);
     }
     free(buf);
     return out;

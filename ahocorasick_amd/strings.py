@@ -113,9 +113,10 @@ class Automaton:
             return out[:n_out.value]
 
     def match_device(self, d_hay_ptr, n_units, with_ids, d_out_ptr, cap, own=None, text_begin=True, text_end=True,
-                     chain_entry=None, stream=0, profile=False):
+                     chain_entry=None, stream=0, profile=False, d_result=None):
         """acgpu_match_device on raw device pointers.  Returns (n_out, rc, profile_dict|None, chain_exit)."""
         sh = N.Shard()
+        sh.d_result = d_result
         sh.d_hay = d_hay_ptr
         sh.n_units = n_units
         sh.own_begin, sh.own_end = (0, n_units) if own is None else own
@@ -136,9 +137,10 @@ class Automaton:
 
 
     def match_device_begin(self, d_hay_ptr, n_units, with_ids, d_out_ptr, cap, own=None, text_begin=True, text_end=True,
-                           stream=0, profile=False):
+                           stream=0, profile=False, d_result=None):
         """acgpu_match_device_begin (AhoCorasick family): enqueue without waiting.  Returns (ticket, rc)."""
         sh = N.Shard()
+        sh.d_result = d_result
         sh.d_hay = d_hay_ptr
         sh.n_units = n_units
         sh.own_begin, sh.own_end = (0, n_units) if own is None else own

@@ -7,14 +7,21 @@ A "step" is one pass of the hot path over one batch of synthetic input that is a
   N=1 : BASELINE.json config 2 -- AhoCorasickMap, 10k keywords (len 4..12, a-z), 1 GiB (2^29 UTF-16 units)
         haystack, records (start, end, keyword_id) delivered in reference order on the device.
   N>1 : config 3 -- AhoCorasickSet, same dictionary, 2^29 units PER GPU (weak scaling, shard g = stream 2003+g),
-        each rank scans its shard with a (max_keyword_len-1) left halo received from rank g-1, then the per-shard
-        match buffers are all-gathered over RCCL/xGMI (counts first, then padded record buffers).
+        each rank scans its shard with a (max_keyword_len-1) left halo received from rank g-1 (once: the haystack does not
+        change between steps), then the per-shard match buffers are all-gathered over RCCL/xGMI (one all-gather of
+        [count header | records] per step, left in flight under the next step's scan).
+  --config C3 --gpus 1 : one rank's share of config 3 (Set records, R = 8) without the collective.
   --config C4 | C5 : the sibling matchers (LongestMatchSet / WholeWordMatchMap case-insensitive) at BASELINE's sizes,
         same sharding driver; not the headline line.
-Prints ONE JSON line (rank 0).
+  --backend gloo : the N>1 path with host-staged collectives (several ranks on one GPU; what tests/test_dist_gpu.py runs).
+Prints ONE JSON line (rank 0).  Outside the timed region the line is checked and annotated: the records of the last
+step are compared with the CPU oracle on a prefix of the haystack ("verified"), the CPU restatement is timed on that
+prefix ("cpu_baseline": pinned to one core, median of 5 runs after a warm-up), the tile kernels' access pattern is timed
+as a pure read ("roofline.attainable"), and the host-buffer entry point acgpu_match_u16 is timed ("end_to_end").
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
 import sys
@@ -34,8 +41,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--units-log2", type=int, default=29, help="haystack units per GPU (default 2^29 = 1 GiB)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-log2", type=int, default=28)
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip everything that runs the CPU oracle")
+    ap.add_argument("--cpu-sample-log2", type=int, default=27)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="N>1: nccl = RCCL over xGMI, one rank per GPU; gloo = host-staged collectives, ranks may share a GPU")
     ap.add_argument("--config", default=None, choices=["C2", "C3", "C4", "C5"],
                     help="BASELINE config (default: C2 at N=1, C3 at N>1 -- the configs the metric is quoted on; "
                          "C4 = LongestMatchSet, C5 = WholeWordMatchMap case-insensitive are the sibling matchers)")
@@ -54,10 +63,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU matching path)"
-    torch.cuda.set_device(local_rank)
+    n_dev = torch.cuda.device_count()
+    torch.cuda.set_device(local_rank % n_dev if args.backend == "gloo" else local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     multi = world > 1
     cfg_name = args.config or ("C3" if multi else "C2")
@@ -79,12 +92,12 @@ def main():
         auto = Automaton(N.MODE_ALL, kws, True)
     build_s = time.time() - t0
     info = auto.info()
-    halo = info["max_keyword_len"] - 1
 
     # synthetic shard, generated in place on the device
     seed = cfg["hay_seed"] + (rank if multi else 0)
-    # N>1: the all-gather of step k overlaps the scan of step k+1 (double-buffered record buffers); every gather is
-    # complete before the timed region ends (matcher.finish() + synchronize)
+    # overlap: step k+1 is enqueued before step k is collected -- N>1: the all-gather of step k runs under the scan of step
+    # k+1; N=1: the GPU never waits for the host between steps.  Every step is complete before the timed region ends
+    # (matcher.finish() + synchronize)
     cap = {"C4": n_units // 2, "C5": n_units // 8}.get(cfg_name, max(1 << 16, n_units // 128))
     matcher = ShardedMatcher(auto, n_units, with_ids=with_ids, cap=cap, overlap=True)
     if cfg_name == "C5":
@@ -107,8 +120,7 @@ def main():
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
-    # N=1 pipelines the calls (step k+1 is enqueued before the count of step k is read back): step() then returns the
-    # PREVIOUS step's result and finish() the last one; all K steps are complete before the clock stops
+    # step() returns the PREVIOUS step's result and finish() the last one; all K steps are complete before the clock stops
     results = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -125,7 +137,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if multi:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.backend == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -161,7 +173,9 @@ def main():
             "table": ("dense u%d" % (8 * info["entry_bytes"])) if info["dense"] else "hashed",
             "lds_states": info["lds_states"], "units_per_gpu": n_units, "matches_per_gpu": n_matches_local,
             "matches_total": n_matches_total, "record_bytes": rec_bytes, "build_s": round(build_s, 3),
-            "parallelism": "shard%d+halo(%d,%d)+allgather" % (world, matcher.sb.halo, matcher.sb.right) if multi else "single",
+            "parallelism": ("shard%d+halo(%d,%d)+allgather/%s" % (world, matcher.sb.halo, matcher.sb.right, args.backend))
+            if multi else "single",
+            "gather_records_per_rank": matcher.cap if multi else None,
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -171,19 +185,47 @@ def main():
         },
     }
 
+    # attainable ceiling: a pure read of this shard in the tile kernels' access pattern, timed in this run
+    ms = ctypes.c_float(0)
+    if N.lib().acgpu_stream_probe(matcher.own_ptr(), n_units * 2, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), 7,
+                                  ctypes.byref(ms)) == N.OK and ms.value > 0:
+        att = n_units * 2 / (ms.value * 1e-3) / 1e9
+        out["roofline"]["attainable"] = round(att, 1)
+        out["roofline"]["attainable_ms"] = round(ms.value, 4)
+        out["roofline"]["frac_of_attainable"] = round(achieved / att, 4)
+        out["roofline"]["attainable_what"] = "k_stream_probe: pure read of the shard, one wave span per wave, 64 B per lane and tile"
+
     # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (counters cannot be read from inside
     # this process); the committed measurement is attached when it is for this kernel and this size
     try:
         with open(os.path.join(ROOT, "profiles", "latest_traffic.json")) as f:
             tr = json.load(f)
-        if tr["kernel"] == matcher.last_kernel and tr["units_per_gpu"] == n_units:
-            out["roofline"]["traffic"] = tr["traffic_bytes"]
-            out["roofline"]["traffic_source"] = tr["source"]
+        for ent in (tr if isinstance(tr, list) else [tr]):
+            if ent["kernel"] == matcher.last_kernel and ent["units_per_gpu"] == n_units:
+                out["roofline"]["traffic"] = ent["traffic_bytes"]
+                out["roofline"]["traffic_source"] = ent["source"]
     except (OSError, KeyError, ValueError):
         pass
 
+    # ---- what the timed steps produced, checked against the CPU oracle on a prefix of the shard ------------------------
+    verified = None
+    if not args.no_cpu_baseline:
+        sample = min(n_units, 1 << (args.cpu_sample_log2 if not multi else min(args.cpu_sample_log2, 22)))
+        verified, digest, n_checked = verify(cfg_name, kws, matcher, sample)
+        if multi:
+            t = torch.tensor([1 if verified else 0], dtype=torch.int64, device="cpu" if args.backend == "gloo" else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            verified = bool(t.item())
+        out["verified"] = verified
+        out["verified_what"] = ("records of the last timed step == oracle records on the first 2^%d units of %s shard "
+                                "(%d records compared on rank 0)" % (int(np.log2(sample)), "every rank's" if multi else "the",
+                                                                     n_checked))
+        out["records_sha256"] = digest
+        assert verified, "bench.py: the GPU records differ from the oracle on the sample prefix -- the line above is void"
+
     if rank == 0 and not multi and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg_name, kws, matcher, min(n_units, 1 << args.cpu_sample_log2))
+        out["end_to_end"] = end_to_end(auto, matcher, with_ids, min(n_units, 1 << 28))
     if rank == 0:
         print(json.dumps(out))
     if multi:
@@ -191,26 +233,101 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(cfg_name, kws, matcher, sample_units):
-    """The reference-shaped CPU restatement (oracle/ac_oracle.c, kind "port"), single thread like the reference,
-    no-op listener (R/README.md:144), on a bounded prefix of the same haystack."""
+def _oracle(cfg_name, kws):
     from oracle.oracle import FAM_AC, FAM_LONGEST, FAM_WHOLEWORD, Oracle
     if cfg_name == "C4":
-        o = Oracle(FAM_LONGEST, kws)
-    elif cfg_name == "C5":
+        return Oracle(FAM_LONGEST, kws)
+    if cfg_name == "C5":
         from ahocorasick_amd.unicode_tables import default_word_chars, java_lower_table
-        o = Oracle(FAM_WHOLEWORD, kws, case_sensitive=False, lower=java_lower_table(), word_chars=default_word_chars())
-    else:
-        o = Oracle(FAM_AC, kws)
+        return Oracle(FAM_WHOLEWORD, kws, case_sensitive=False, lower=java_lower_table(), word_chars=default_word_chars())
+    return Oracle(FAM_AC, kws)
+
+
+def verify(cfg_name, kws, matcher, sample_units):
+    """Outside the timed region: the records the last step left in this rank's buffer against the CPU oracle on the first
+    `sample_units` units of this rank's view (halo included for rank > 0).  Returns (ok, sha256 of ALL local records, number
+    of records compared)."""
+    o = _oracle(cfg_name, kws)
+    max_len = max(len(k) for k in kws)
+    n = int(matcher.counts[matcher.rank])
+    recs = matcher.gathered[matcher.rank, :n].cpu().numpy()
+    digest = hashlib.sha256(np.ascontiguousarray(recs).tobytes()).hexdigest()
+    if cfg_name == "C4" and matcher.rank > 0:
+        return True, digest, 0  # (a later shard's chain entry comes from the rank before it: rank 0 carries the check)
+    sb = matcher.sb
+    shift = matcher.shift
+    v0 = sb.pad - shift  # view start in the buffer
+    lo = shift - sb.halo if matcher.rank else 0  # first text unit of the view that is real text (the halo)
+    hay = sb.buf[v0 + lo:v0 + shift + sample_units].cpu().numpy().view(np.uint16)
+    want = o.match(hay, cap=max(1 << 16, hay.size // (2 if cfg_name == "C4" else 8)))[:, :recs.shape[1]].copy()
+    want[:, :2] += lo
+    end = shift + sample_units
+    if cfg_name in ("C2", "C3"):  # a record belongs to the prefix iff it ENDS there and its last unit is owned
+        want = want[want[:, 1] - 1 >= shift]
+        got = recs[recs[:, 1] <= end]
+    else:  # position order; what the cut at the end of the prefix can change lies in its last max_len + 1 units
+        want = want[(want[:, 0] >= shift) & (want[:, 1] < end - max_len - 1)]
+        got = recs[recs[:, 1] < end - max_len - 1]
+    ok = got.shape == want.shape and bool((got == want).all()) and len(want) > 0
+    return ok, digest, len(want)
+
+
+def cpu_baseline(cfg_name, kws, matcher, sample_units):
+    """The reference-shaped CPU restatement (oracle/ac_oracle.c, kind "port"), single thread like the reference, pinned
+    to one core, no-op listener (R/README.md:144), on a bounded prefix of the same haystack: 1 warm-up + 5 timed runs,
+    median."""
+    o = _oracle(cfg_name, kws)
     hay = matcher.own_units_host(sample_units)
-    o.count(hay[:1 << 20])  # warm-up
-    t0 = time.perf_counter()
-    n = o.count(hay)
-    dt = time.perf_counter() - t0
+    core, old = None, None
+    try:
+        old = os.sched_getaffinity(0)
+        core = max(old)  # (the launcher's own threads tend to sit on the low cores)
+        os.sched_setaffinity(0, {core})
+    except (AttributeError, OSError):
+        core = None
+    try:
+        o.count(hay)  # warm-up: the whole sample once (page faults, caches, branch predictors)
+        times = []
+        n = 0
+        for _ in range(5):
+            t0 = time.perf_counter()
+            n = o.count(hay)
+            times.append(time.perf_counter() - t0)
+    finally:
+        if old is not None and core is not None:
+            os.sched_setaffinity(0, old)
+    dt = float(np.median(times))
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     return {"value": round(hay.size * 2 / dt / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": "port",
-            "sample": "first 2^%d units of the same haystack, %d matches, %.1f s, no-op listener" % (
-                int(np.log2(hay.size)), n, dt),
-            "host_cpus": os.cpu_count()}
+            "sample": "first 2^%d units of the same haystack, %d matches, no-op listener; 1 warm-up + 5 runs, median %.2f s "
+                      "(min %.2f, max %.2f)" % (int(np.log2(hay.size)), n, dt, min(times), max(times)),
+            "pinned_core": core, "host_cpu": model, "host_cpus": os.cpu_count()}
+
+
+def end_to_end(auto, matcher, with_ids, sample_units):
+    """acgpu_match_u16 -- what the JNI facade calls: pageable host haystack -> H2D copy -> scan -> D2H of the records.
+    PCIe-inclusive; reported beside `value`, never as it."""
+    hay = matcher.own_units_host(sample_units)
+    cap = max(1 << 16, sample_units // 64)
+    auto.match_host(hay[:1 << 20], with_ids, cap=cap)  # warm-up: staging buffers
+    auto.match_host(hay, with_ids, cap=cap)
+    times = []
+    n = 0
+    for _ in range(3):
+        t0 = time.perf_counter()
+        n = len(auto.match_host(hay, with_ids, cap=cap))
+        times.append(time.perf_counter() - t0)
+    dt = float(np.median(times))
+    return {"value": round(hay.size * 2 / dt / 1e6, 1), "unit": "MB/s", "what": "acgpu_match_u16 on 2^%d units in pageable host "
+            "memory: H2D + scan + D2H of %d records, median of 3" % (int(np.log2(hay.size)), n), "ms": round(dt * 1e3, 2)}
 
 
 if __name__ == "__main__":

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ACGPU_ABI_VERSION 1
+#define ACGPU_ABI_VERSION 2
 
 /* error codes */
 #define ACGPU_OK 0
@@ -156,7 +156,19 @@ typedef struct acgpu_shard {
     int64_t chain_entry;   /* LONGEST in : first greedy-chain position >= own_begin (own_begin on the first shard);
                               SHORTEST in: position of the last restart (0 on the first shard)      */
     int64_t chain_exit;    /* LONGEST out: first greedy-chain position >= own_end; SHORTEST out: see above */
+    void *d_result;        /* optional device pointer (16-byte aligned) to an acgpu_device_result that the call's last
+                              kernel (or a copy enqueued behind it) fills in STREAM ORDER: a multi-GPU driver points it
+                              into the buffer it all-gathers, so the record count travels with the records and no host
+                              round trip sits between the scan and the collective.  NULL: not wanted.            */
 } acgpu_shard;
+
+/* what acgpu_shard.d_result receives */
+typedef struct acgpu_device_result {
+    uint64_t n_records; /* records the call produced (may exceed cap: then d_out is incomplete)                     */
+    uint32_t redone;    /* non-zero: the library has to redo this call (acgpu_match_device_end does) -- the records
+                           behind this header are not valid yet; a driver that gathered them gathers again          */
+    uint32_t reserved;
+} acgpu_device_result;
 
 /* optional per-call timing of the device work, measured with HIP events on `stream` */
 typedef struct acgpu_profile {
@@ -180,9 +192,14 @@ int acgpu_match_device(const acgpu_automaton *a, acgpu_shard *shard, int record_
 /*
  * Asynchronous form (ACGPU_MODE_ALL): _begin enqueues the whole pipeline on `stream` and returns without waiting;
  * _end waits for that call only (an event, not the stream) and returns its count / timings.  Up to 4 calls may be in
- * flight per automaton and device; they must all use the SAME stream (they share the automaton's scratch pool, stream
- * order keeps them apart).  Lets a host keep the GPU busy across calls: the next scan is queued while the previous
- * count travels back.  want_profile != 0 records the HIP events that _end turns into acgpu_profile.
+ * flight per automaton and device.  Lets a host keep the GPU busy across calls: the next scan is queued while the
+ * previous count travels back.  want_profile != 0 records the HIP events that _end turns into acgpu_profile.
+ *
+ * STREAM RULE.  All calls on one automaton and device share that automaton's scratch pool; stream order is what keeps
+ * them apart.  While tickets are in flight, EVERY call on that automaton and device -- another _begin, a synchronous
+ * acgpu_match_device, acgpu_match_u16 or acgpu_stream_feed (both use the NULL stream) -- must use the stream of the
+ * tickets; a call on a different stream is refused with ACGPU_E_INVALID instead of racing on the scratch.  With no
+ * ticket in flight any stream may be used (a synchronous call has left the scratch idle when it returns).
  */
 typedef struct acgpu_ticket acgpu_ticket;
 int acgpu_match_device_begin(const acgpu_automaton *a, acgpu_shard *shard, int record_kind, void *d_out, uint64_t cap,
@@ -221,7 +238,18 @@ void acgpu_stream_close(acgpu_stream *s);
 int acgpu_synth_fill(uint16_t *d_dst, uint64_t n_units, uint64_t start_index, uint64_t seed, const uint16_t *table,
                      uint32_t table_len, void *stream);
 
-/* tuning knobs (process-wide; mainly for tests and benchmarks).  name: "chunk_units",
+/*
+ * Measurement helper ("also report vs. a measured streaming-read kernel on the same box"): a pure read
+ * of n_bytes (>= 1 MiB, 16-byte aligned device pointer) in the access pattern of the tile kernels -- every wave a
+ * contiguous span, 64 bytes per lane and tile, the next tile's loads in flight.  Runs `repeats` timed launches after a
+ * warm-up (HIP events on `stream`, synchronous) and returns the median in *ms_median: the attainable ceiling bench.py
+ * reports next to the 8 TB/s spec peak.
+ */
+int acgpu_stream_probe(const void *d_buf, uint64_t n_bytes, void *stream, int repeats, float *ms_median);
+
+/* tuning knobs: DEVELOPMENT AND TEST HOOK, not part of the product surface a JVM binds.  Process-wide, read when a call
+ * is enqueued; set them only while no match call is running (each knob is a relaxed atomic, so a concurrent reader sees
+ * the old or the new value, never a torn one, but a call may then mix settings).  name: "chunk_units",
  * "blocks_per_cu", "lds_table_bytes", "force_sparse", "dense_budget_bytes", "force_kernel" (0 auto, 1 DFA chunk
  * scan, 2 K-gram tile scan), "region_units", "filter_max_bytes".  Returns the previous value, -1 for an unknown name. */
 int64_t acgpu_set_tunable(const char *name, int64_t value);

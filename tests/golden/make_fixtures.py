@@ -39,6 +39,13 @@ SCENARIOS = [
     ("readmeOverlap", "R/README.md:88-90", "aaaa", ["a", "aa", "aaa", "aaaa"]),
     ("readmeLongest", "R/README.md:94-96", "a1b2c3d4", ["b", "b2", "2c3d4"]),
     ("readmeWholeWord", "R/README.md:106-109", "late evening", ["la", "late", "eve", "evening"]),
+    # README "ShortestMatchSet/Map": with 2, b2, 2c3d4 only b2 matches; with b, 2, b2 both b and 2 match
+    ("readmeShortest1", "R/README.md:100", "a1b2c3d4", ["2", "b2", "2c3d4"]),
+    ("readmeShortest2", "R/README.md:100", "a1b2c3d4", ["b", "2", "b2"]),
+    # README "WholeWordLongestMatchSet/Map": `as if` -> as if; `ax if` -> if; `as of` -> as
+    ("readmeWwlAsIf", "R/README.md:122-124", "as if", ["as if", "as", "if"]),
+    ("readmeWwlAxIf", "R/README.md:122-124", "ax if", ["as if", "as", "if"]),
+    ("readmeWwlAsOf", "R/README.md:122-124", "as of", ["as if", "as", "if"]),
     ("emptyHaystack", "T/SetTest.java:61-65", "", ["ab", "abc", "zz"]),
     ("nwcRejection", "T/WholeWordMatchTest.java:49-52", "A B", ["A B"]),
 ]

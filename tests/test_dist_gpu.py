@@ -1,0 +1,58 @@
+"""The sharded driver (ahocorasick_amd/dist.py) with the NATIVE scan in real, separate processes: 2 and 3 fresh child
+processes on cuda:0, gloo with host-staged collectives (RCCL cannot put two ranks on one device).  Same ShardedMatcher
+code as an N-GPU job -- halo exchange, acgpu_match_device[_begin/_end] on an acgpu_shard, chain hop with speculation and
+window repair, one all-gather of header + records -- compared with the oracle on the WHOLE text in every rank."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "dist_gpu_worker.py")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(family, world, overlap, cap, tmp_path, n=50000):
+    port = str(_free_port())
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, WORKER, family, str(world), str(r), port, str(n), str(tmp_path), str(int(overlap)),
+                               str(cap)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(world)]  # fresh children: nothing that touched the GPU is re-executed
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out.decode(errors="replace"))
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, outs[r][-3000:])
+    oks = [(tmp_path / ("ok%d" % r)).read_text().split() for r in range(world)]
+    return [(int(o[1]), int(o[2]), int(o[3])) for o in oks]
+
+
+@pytest.mark.parametrize("family,world,overlap,cap", [
+    ("ac", 2, False, 1 << 16), ("ac", 3, True, 1 << 16), ("ac", 2, True, 64),   # cap 64: the redo path (gather buffers grow)
+    ("wholeword", 2, False, 1 << 16), ("wholeword", 3, True, 64),
+    ("longest", 2, False, 1 << 16), ("longest", 3, True, 64),
+    ("shortest", 2, True, 1 << 16)])
+def test_sharded_matcher_native_scan_in_separate_processes(family, world, overlap, cap, tmp_path):
+    res = _run(family, world, overlap, cap, tmp_path)
+    assert all(r[2] > 0 for r in res)  # there were matches to get right
+    if family in ("longest", "shortest"):
+        assert sum(r[0] for r in res) > 0  # a shard boundary fell inside a match: the window repair ran on the device
+    if cap == 64:
+        assert all(r[1] > 0 for r in res)  # every rank went through the collective redo

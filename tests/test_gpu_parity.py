@@ -11,7 +11,7 @@ from ahocorasick_amd import _native as N
 from ahocorasick_amd import synth
 from ahocorasick_amd.strings import Automaton, utf16
 from oracle.oracle import FAM_AC, FAM_LONGEST, FAM_WHOLEWORD, Oracle
-from tests.helpers import LOWER, WORD, fixture_inputs, rand_case
+from tests.helpers import oracle_parallel, LOWER, WORD, fixture_inputs, rand_case
 
 pytestmark = pytest.mark.gpu
 
@@ -232,7 +232,7 @@ def test_device_entry_and_shard_split_invariance(ac_kernel):
 
 # ---- BASELINE.json config 2 at FULL size: size-independent properties -------------------------------------------
 
-def test_config_c2_full_size_properties():
+def test_config_c2_full_size_every_record():
     import torch
     c = synth.CONFIGS["C2"]
     kws = synth.config_keywords("C2")
@@ -257,10 +257,14 @@ def test_config_c2_full_size_properties():
         s, e, k = got[i].tolist()
         seg = synth.haystack(c["hay_seed"], e - s, start=s)
         assert (seg == kws[k]).all()
-    # (3) the prefix of the result equals the oracle on the first 2^22 units (bit-exact, incl. order)
-    pre = 1 << 22
-    want = Oracle(FAM_AC, kws).match(synth.haystack(c["hay_seed"], pre))
-    assert (got[:len(want)] == want).all() and got[len(want), 1] > pre
+    # (3) EVERY record equals the oracle's on the whole 2^29-unit text, bit for bit and in order (the single-threaded
+    #     oracle run on chunks in host threads and stitched: tests/helpers.py oracle_parallel; T/SetTest.java:145-192
+    #     compares the count on the whole input)
+    hay = d_hay.cpu().numpy().view(np.uint16)
+    assert (hay[:1 << 16] == synth.haystack(c["hay_seed"], 1 << 16)).all()  # (the device generator is the numpy one)
+    want = oracle_parallel(Oracle(FAM_AC, kws), hay, "ac", a.info()["max_keyword_len"], cap_per_unit=0.02)
+    assert got.shape == want.shape and (got == want).all()
+    del hay
     # (4) the independent kernels (fused K-gram tile scan / its split form / DFA chunk scan), other region and chunk
     #     sizes, and no LDS residency all give the identical record stream
     assert prof["scan_kernel"].startswith("k_ac_tile")
@@ -510,7 +514,7 @@ def test_wholeword_shards_own_their_word_starts():
 
 # ---- BASELINE.json configs 4 and 5 at FULL size: size-independent properties -----------------------------------------
 
-def test_config_c4_full_size_properties():
+def test_config_c4_full_size_every_record():
     """LongestMatchSet, 50k prefix-closed keywords (max length 1000), 2^29 units with P(a)=0.75."""
     import torch
     c = synth.CONFIGS["C4"]
@@ -532,10 +536,13 @@ def test_config_c4_full_size_properties():
     assert bool((got[1:, 0] >= got[:-1, 1]).all()) and bool((got[:, 1] > got[:, 0]).all())
     # (2) greedy chain: every unit between two matches starts no keyword -- here every 'a' starts one, so gaps are 'b's
     #     that start no keyword; and every match is maximal among the a-run family: checked against the oracle prefix
-    pre = 1 << 21
-    want = Oracle(FAM_LONGEST, kws).match(synth.haystack(c["hay_seed"], pre, table=synth.ALPHA_AB_75))[:, :2]
-    k = len(want) - 1  # the last oracle match may be cut by the end of the prefix
-    assert (got[:k].cpu().numpy() == want[:k]).all()
+    #     EVERY record against the oracle on the whole 2^29-unit text (leftmost-longest is a chain: one oracle run, one
+    #     thread, like the reference)
+    hay = d_hay.cpu().numpy().view(np.uint16)
+    want = Oracle(FAM_LONGEST, kws).match(hay, cap=n // 4)[:, :2]
+    g = got.cpu().numpy()
+    assert g.shape == want.shape and (g == want).all()
+    del hay, want, g
     # (3) shard invariance at full size: two shards chained through chain_exit give the same stream (checksums)
     half = n // 2 + 12345
     d2 = torch.empty((cap, 2), dtype=torch.int32, device="cuda")
@@ -547,7 +554,7 @@ def test_config_c4_full_size_properties():
     assert bool((first == got[:n1]).all()) and bool((d2[:n2] == got[n1:]).all())
 
 
-def test_config_c5_full_size_properties():
+def test_config_c5_full_size_every_record():
     """WholeWordMatchMap, 100k mixed-script words, case-insensitive, 2^28 units (one GPU's share of config 5).
     The haystack is a host-generated 2^22-unit block of the config-5 token stream repeated 64 times."""
     import torch
@@ -558,13 +565,14 @@ def test_config_c5_full_size_properties():
     a = Automaton(N.MODE_WHOLEWORD, words, False, word_chars=WORD)
     d_hay = torch.from_numpy(block.view(np.int16)).cuda().repeat(reps)
     n = d_hay.numel()
-    want = Oracle(FAM_WHOLEWORD, words, case_sensitive=False, lower=LOWER, word_chars=WORD).match(block)
-    cap = (len(want) + 8) * reps
+    orc = Oracle(FAM_WHOLEWORD, words, case_sensitive=False, lower=LOWER, word_chars=WORD)
+    cap = (len(orc.match(block)) + 8) * reps
     got, prof = _dev_match(a, d_hay, n, True, cap, profile=True)
     print("C5 full size: %d matches, scan %.3f ms" % (len(got), prof["scan_ms"]))
-    # (1) the first block equals the oracle bit for bit (except a word cut by the block seam)
-    k = len(want) - 2
-    assert (got[:k] == want[:k]).all()
+    # (1) EVERY record equals the oracle's on the whole 2^28-unit text (chunks in host threads, stitched by word start)
+    want = oracle_parallel(orc, np.tile(block, reps), "wholeword", a.info()["max_keyword_len"], cap_per_unit=0.1)
+    assert got.shape == want.shape and (got == want).all()
+    del want
     # (2) position order; every record is delimited by non-word characters (T/WholeWordMatchTest.java:60-70)
     assert (np.diff(got[:, 0].astype(np.int64)) > 0).all()
     hay = np.tile(block, reps)
@@ -579,6 +587,50 @@ def test_config_c5_full_size_properties():
     last = inner[inner[:, 0] >= (reps - 1) * per].copy()
     last[:, :2] -= (reps - 1) * per
     assert first.shape == last.shape and (first == last).all()
+
+
+def test_config_c3_one_shard_full_size():
+    """BASELINE config 3, shard g = 3 of 8: AhoCorasickSet (8-byte records), 2^29 units of stream 2003+3 behind the
+    (max_keyword_len-1)-unit left halo a rank receives from rank g-1 (here: the tail of stream 2003+2), text_begin = 0,
+    text_end = 0.  Order, membership, cross-kernel agreement and EVERY record against the oracle."""
+    import torch
+    c = synth.CONFIGS["C3"]
+    kws = synth.config_keywords("C3")
+    g, n = 3, c["n_units"]
+    a = Automaton(N.MODE_ALL, kws, True)
+    halo = a.info()["max_keyword_len"] - 1
+    pad = (halo + 7) // 8 * 8
+    buf = torch.zeros(pad + n, dtype=torch.int16, device="cuda")
+    tab = np.ascontiguousarray(synth.ALPHA_LOWER)
+    N.check(N.lib().acgpu_synth_fill(buf.data_ptr() + 2 * pad, n, 0, c["hay_seed"] + g, tab.ctypes.data_as(ctypes.c_void_p),
+                                     len(tab), None), "synth")
+    prev_tail = synth.haystack(c["hay_seed"] + g - 1, halo, start=n - halo)  # what rank g-1 sends
+    buf[pad - halo:pad] = torch.from_numpy(prev_tail.view(np.int16)).cuda()
+    cap = 4_000_000
+    got, prof = _dev_match(a, buf, pad + n, False, cap, own=(pad, pad + n), text_begin=False, text_end=False, profile=True)
+    m = len(got)
+    assert got.shape[1] == 2 and 1_200_000 < m < 1_550_000 and prof["scan_kernel"].startswith("k_ac_tile")
+    end, start = got[:, 1].astype(np.int64), got[:, 0].astype(np.int64)
+    assert (np.diff(end * (1 << 32) + start) > 0).all()          # reference order
+    assert end.min() > pad and end.max() <= pad + n              # owned: the LAST unit lies in the owned range
+    assert (start < pad).any()                                    # (some match begins inside the halo: it is needed)
+    # every record against the oracle: the view [halo | shard] scanned from its first unit, records that end in the shard
+    view = buf[pad - halo:].cpu().numpy().view(np.uint16)
+    want = oracle_parallel(Oracle(FAM_AC, kws), view, "ac", halo + 1, cap_per_unit=0.02)[:, :2]
+    want = want[want[:, 1] - 1 >= halo]
+    want[:, :2] += pad - halo
+    assert got.shape == want.shape and (got == want).all()
+    # membership: every record is an occurrence of a keyword (the Set listener contract, T/SetTest.java:156-165)
+    kwset = {k.tobytes() for k in kws}
+    for i in np.random.default_rng(1).integers(0, m, 5000).tolist():
+        s0, e0 = got[i].tolist()
+        assert view[s0 - (pad - halo):e0 - (pad - halo)].tobytes() in kwset
+    # the DFA chunk scan and the split tile kernels deliver the identical stream
+    for knobs in ({"force_kernel": 1}, {"force_kernel": 3}):
+        for k, v in knobs.items():
+            N.set_tunable(k, v)
+        got2, _ = _dev_match(a, buf, pad + n, False, cap, own=(pad, pad + n), text_begin=False, text_end=False)
+        assert got2.shape == got.shape and (got2 == got).all(), knobs
 
 
 def test_maximum_size_haystack_just_under_2_31_units():
@@ -638,7 +690,8 @@ def test_async_begin_end_matches_synchronous_call():
 
 def _emulated_ranks(auto, whole, world, chain_window=4096):
     """What `world` ranks of ShardedMatcher.step() compute, minus the collectives: halos filled from the whole text,
-    the Longest chain hop handed over in Python.  Returns the concatenation with global positions + repair count."""
+    the Longest chain hop handed over in Python.  Returns the concatenation with global positions + repair count.
+    (tests/test_dist_gpu.py runs the same thing in real separate processes.)"""
     import torch
     from ahocorasick_amd.dist import ShardedMatcher
     n = whole.size // world
@@ -657,9 +710,9 @@ def _emulated_ranks(auto, whole, world, chain_window=4096):
             sb.right_view().copy_(d_whole[(g + 1) * n:(g + 1) * n + sb.right])
         m._chain_hop_recv = lambda g=g: box[0] - g * n if g else 0
         m._chain_hop_send = lambda ex, g=g: box.__setitem__(0, ex + g * n)
-        cnt, _ = m._scan(False)
+        cnt, _ = m._scan(False, m._new_step())
         r = m.out[:cnt].cpu().numpy().astype(np.int64)
-        r[:, :2] += g * n
+        r[:, :2] += g * n - m.shift  # (records are relative to the rank's view of its buffer)
         parts.append(r)
         repairs += m.chain_repairs
     return np.concatenate(parts), repairs
@@ -1127,3 +1180,89 @@ def test_case_insensitive_folded_range_classes(min_len):
         args = prof["scan_kernel"].split("<")[1].rstrip(">").split(", ")
         assert args[1] == "false" and len(args) >= 6 and args[5] == "true", prof["scan_kernel"]  # folded range + packed filter
         assert len(want) >= 40 and got.shape == want.shape and (got == want).all()
+
+
+# ---- the pipelined single-GPU driver (bench.py's N=1 path), device-side result header, stream rule ------------------
+
+def test_pipelined_steps_survive_overflow_with_a_changing_haystack():
+    """ShardedMatcher(overlap=True), world 1 (bench.py's N=1 driver): step k+1 is enqueued before step k is collected.
+    A tiny record capacity makes steps overflow; phase 1 changes the haystack between steps (load() completes the step
+    in flight first -- a redo needs its text), phase 2 keeps it and lets step k overflow while step k+1 is in flight in
+    its own, equally small buffer.  Every step's published records must be the oracle's for ITS haystack."""
+    from ahocorasick_amd.dist import ShardedMatcher
+    kws = synth.random_keywords(11, 300, 2, 9)
+    a = Automaton(N.MODE_ALL, kws, True)
+    orc = Oracle(FAM_AC, kws)
+    n = 200000
+    hays = [synth.haystack(300 + i, n, table=synth.ALPHA_LOWER[:6 + 5 * (i % 3)]) for i in range(6)]  # very different densities
+    wants = [orc.match(h) for h in hays]
+    assert len({len(w) for w in wants}) > 3
+    m = ShardedMatcher(a, n, with_ids=True, cap=8, overlap=True)
+    results = []
+    for h in hays:
+        m.load(h)
+        r = m.step()
+        if r is not None:  # the PREVIOUS step's result: gathered/counts describe it now
+            results.append((r, m.global_records().cpu().numpy()))
+    results.append((m.finish(), m.global_records().cpu().numpy()))
+    assert len(results) == len(hays) and m.redone_steps >= 1
+    for (r, got), want in zip(results, wants):
+        assert r["n_total"] == len(want) and got.shape == want.shape and (got == want).all()
+    # phase 2: one haystack, pipelined for real; the first two steps both start with 8 record slots
+    m = ShardedMatcher(a, n, with_ids=True, cap=8, overlap=True, adaptive=False)
+    m.load(hays[1])
+    outs = [m.step() for _ in range(4)] + [m.finish()]
+    assert outs[0] is None and all(o["n_total"] == len(wants[1]) for o in outs[1:])
+    assert m.redone_steps == 2 and (m.global_records().cpu().numpy() == wants[1]).all()
+
+
+def test_device_result_header_and_stream_rule():
+    import torch
+    kws = synth.random_keywords(11, 300, 2, 9)
+    hay = synth.haystack(91, 150000)
+    d_hay = torch.from_numpy(hay.view(np.int16)).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    for mode, fam in ((N.MODE_ALL, FAM_AC), (N.MODE_LONGEST, 1), (N.MODE_SHORTEST, 3)):
+        a = Automaton(mode, kws, True)
+        want = Oracle(fam, kws).match(hay)
+        buf = torch.zeros(4 + 3 * (len(want) + 8), dtype=torch.int32, device="cuda")
+        n, rc, _, _ = a.match_device(d_hay.data_ptr(), hay.size, True, buf.data_ptr() + 16, len(want) + 8, stream=st,
+                                     d_result=buf.data_ptr())
+        torch.cuda.synchronize()
+        hdr = buf[:4].cpu().numpy()
+        assert rc == N.OK and n == len(want) and hdr.tolist() == [len(want), 0, 0, 0], (mode, hdr)
+        assert (buf[4:4 + 3 * n].view(n, 3).cpu().numpy() == want).all()
+        # too small a capacity: the header still carries the exact count
+        n2, rc2, _, _ = a.match_device(d_hay.data_ptr(), hay.size, True, buf.data_ptr() + 16, 5, stream=st, d_result=buf.data_ptr())
+        torch.cuda.synchronize()
+        assert rc2 == N.E_OVERFLOW and n2 == len(want) and buf[:2].cpu().numpy().tolist() == [len(want), 0]
+        assert a.match_device(d_hay.data_ptr(), hay.size, True, buf.data_ptr() + 16, 5, stream=st, d_result=buf.data_ptr() + 4)[1] == N.E_INVALID
+    # asynchronous form: the header arrives in stream order; a call on ANOTHER stream while the ticket is in flight is refused
+    a = Automaton(N.MODE_ALL, kws, True)
+    want = Oracle(FAM_AC, kws).match(hay)
+    buf = torch.zeros(4 + 3 * (len(want) + 8), dtype=torch.int32, device="cuda")
+    tk, rc = a.match_device_begin(d_hay.data_ptr(), hay.size, True, buf.data_ptr() + 16, len(want) + 8, stream=st, d_result=buf.data_ptr())
+    assert rc == N.OK
+    other = torch.cuda.Stream()
+    out2 = torch.empty((len(want) + 8, 3), dtype=torch.int32, device="cuda")
+    assert a.match_device(d_hay.data_ptr(), hay.size, True, out2.data_ptr(), len(want) + 8, stream=other.cuda_stream)[1] == N.E_INVALID
+    assert a.match_device_begin(d_hay.data_ptr(), hay.size, True, out2.data_ptr(), len(want) + 8, stream=other.cuda_stream)[1] == N.E_INVALID
+    n3, rc3, _, _ = a.match_device(d_hay.data_ptr(), hay.size, True, out2.data_ptr(), len(want) + 8, stream=st)  # same stream: fine
+    assert rc3 == N.OK and n3 == len(want)
+    n, rc, _ = a.match_device_end(tk)
+    assert rc == N.OK and n == len(want) and buf[:4].cpu().numpy().tolist() == [len(want), 0, 0, 0]
+    assert (buf[4:4 + 3 * n].view(n, 3).cpu().numpy() == want).all() and (out2[:n3].cpu().numpy() == want).all()
+    # with nothing in flight any stream may be used again
+    assert a.match_device(d_hay.data_ptr(), hay.size, True, out2.data_ptr(), len(want) + 8, stream=other.cuda_stream)[1] == N.OK
+    other.synchronize()
+    assert a.match_device_end(tk)[1] == N.E_INVALID  # a ticket is collected once
+
+
+def test_stream_probe_reports_a_plausible_read_bandwidth():
+    import torch
+    d = torch.zeros(1 << 27, dtype=torch.int16, device="cuda")  # 256 MiB
+    ms = ctypes.c_float(0)
+    N.check(N.lib().acgpu_stream_probe(d.data_ptr(), d.numel() * 2, None, 5, ctypes.byref(ms)), "probe")
+    gbps = d.numel() * 2 / (ms.value * 1e-3) / 1e9
+    assert 500 < gbps < 8000, gbps  # below the 8 TB/s spec peak, far above anything a host path reaches
+    assert N.lib().acgpu_stream_probe(d.data_ptr() + 2, 1 << 21, None, 5, ctypes.byref(ms)) == N.E_INVALID

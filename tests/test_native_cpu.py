@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(N.LIB_PATH)
     for s in declared:
         assert hasattr(L, s), s
-    assert N.lib().acgpu_abi_version() == 1
+    assert N.lib().acgpu_abi_version() == N.ABI_VERSION == int(re.search(r"#define ACGPU_ABI_VERSION (\d+)", hdr).group(1))
 
 
 def _tables(a):

@@ -38,6 +38,24 @@ def test_appendix_b_hand_pins():
     assert len(Oracle(FAM_AC, ["a" * k for k in range(1, 101)]).match("a" * 100)) == 5050
 
 
+def test_readme_worked_examples_hand_pins():
+    # what R/README.md states in prose, typed by hand (the generated fixtures hold the same cases)
+    from oracle.oracle import FAM_SHORTEST, FAM_WWLONGEST
+    # "ShortestMatchSet/Map": a1b2c3d4 with 2, b2, 2c3d4 -> only b2; with b, 2, b2 -> both b and 2
+    assert _as_list(Oracle(FAM_SHORTEST, ["2", "b2", "2c3d4"]).match("a1b2c3d4")[:, :2]) == [[2, 4]]
+    assert _as_list(Oracle(FAM_SHORTEST, ["b", "2", "b2"]).match("a1b2c3d4")[:, :2]) == [[2, 3], [3, 4]]
+    # "LongestMatchSet/Map": b, b2, 2c3d4 -> only b2
+    assert _as_list(Oracle(FAM_LONGEST, ["b", "b2", "2c3d4"]).match("a1b2c3d4")[:, :2]) == [[2, 4]]
+    # "WholeWordLongestMatchSet/Map": as if -> as if; ax if -> if; as of -> as
+    wwl = Oracle(FAM_WWLONGEST, ["as if", "as", "if"], word_chars=WORD)
+    assert _as_list(wwl.match("as if")[:, :2]) == [[0, 5]]
+    assert _as_list(wwl.match("ax if")[:, :2]) == [[3, 5]]
+    assert _as_list(wwl.match("as of")[:, :2]) == [[0, 2]]
+    # "AhoCorasickSet/Map": aaaa with a, aa, aaa, aaaa -> a x4, aa x3, aaa x2, aaaa x1
+    r = Oracle(FAM_AC, ["a", "aa", "aaa", "aaaa"]).match("aaaa")
+    assert sorted(np.bincount(r[:, 2], minlength=4).tolist(), reverse=True) == [4, 3, 2, 1]
+
+
 def test_match_queue_sequences():
     # T/MatchQueueTest.java:10-20  testMatchQueue
     q = MatchQueue()
