@@ -73,15 +73,21 @@ struct __attribute__((packed, aligned(2))) Units8 { // 8 UTF-16 units at any uni
     uint32_t d[4];
 };
 
-// the haystack stream: read once
-__device__ __forceinline__ uint4 stream_load(const uint16_t *p) {
+// the haystack stream: read once.  `unit` < 2^31, so the byte offset fits 32 bits: uniform base + 32-bit lane offset
+// (global_load ... s[base:base+1]) instead of a 64-bit address per lane.  A vector travels as two 64-bit halves so that
+// taking over a prefetched group is 8 v_mov_b64 per tile, not 16 v_mov_b32.
+struct Vec16 {
+    unsigned long long lo, hi;
+};
+__device__ __forceinline__ Vec16 stream_load(const uint16_t *hay, uint32_t unit) {
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(hay) + (size_t)(unit * 2u);
+    typedef unsigned long long v2ul __attribute__((ext_vector_type(2)));
 #ifdef ACGPU_STREAM_NT
-    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-    const v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p));
-    return make_uint4(v.x, v.y, v.z, v.w);
+    const v2ul v = __builtin_nontemporal_load(reinterpret_cast<const v2ul *>(p));
 #else
-    return *reinterpret_cast<const uint4 *>(p);
+    const v2ul v = *reinterpret_cast<const v2ul *>(p);
 #endif
+    return Vec16{v.x, v.y};
 }
 
 __device__ __forceinline__ uint32_t tile_class(const DevTables &T, uint32_t unit) {
@@ -390,7 +396,9 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
     static_assert(kAcTiles >= 1 && kAcLaneUnits <= 32, "tile geometry");
     constexpr int kAcCandCap = kAcTileUnits + kVerifyBatches * kWave;
     constexpr uint32_t kQueueCap = L2 ? kL2Cap : kAcCandCap;
-    const uint32_t wave_in_block = threadIdx.x / kWave;
+    // (readfirstlane: the wave index and everything derived from it -- spans, tile positions, queue counts -- is then
+    // scalar for the compiler too: bookkeeping on the SALU, scalar branches instead of exec masking; -1.6 % at config 2)
+    const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     // L2: [queues: info][queues: pos16][tile buffers][fresh lists][Bloom words]
     constexpr int kWavesPerBlock = kTileBlock / kWave;
     uint16_t *pos16_all = reinterpret_cast<uint16_t *>(smem + kWavesPerBlock * kL2Cap * 4);
@@ -447,11 +455,11 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
     uint32_t prio_turn = 0;             // passes so far (issue priority rotation)
     bool mid = false;                   // the current group is being resumed (its registers are live, its loads are out)
     uint32_t carry[4] = {0, 0, 0, 0};
-    uint4 nxt[kAcTiles][kAcVec], grp[kAcTiles][kAcVec];
+    Vec16 nxt[kAcTiles][kAcVec], grp[kAcTiles][kAcVec];
 #pragma unroll
     for (int d = 0; d < kAcTiles; ++d)
 #pragma unroll
-        for (int u = 0; u < kAcVec; ++u) nxt[d][u] = grp[d][u] = make_uint4(0, 0, 0, 0);
+        for (int u = 0; u < kAcVec; ++u) nxt[d][u] = grp[d][u] = Vec16{0ull, 0ull};
     if (vec_todo) {
         if (K > 1 && tile >= 8) {
             const uint4 p = *reinterpret_cast<const uint4 *>(hay + tile - 8);
@@ -463,7 +471,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
         for (int d = 0; d < kAcTiles; ++d)
 #pragma unroll
             for (int u = 0; u < kAcVec; ++u)
-                nxt[d][u] = stream_load(hay + min(tile + d * kAcTileUnits + lane * kAcLaneUnits + u * 8, last_vec));
+                nxt[d][u] = stream_load(hay, min(tile + d * kAcTileUnits + lane * kAcLaneUnits + u * 8, last_vec));
     }
 
 #ifdef ACGPU_TIMING
@@ -537,7 +545,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                 for (int d = 0; d < kAcTiles; ++d)
 #pragma unroll
                     for (int u = 0; u < kAcVec; ++u)
-                        nxt[d][u] = stream_load(hay + min(tile + (kAcTiles + d) * kAcTileUnits + lane * kAcLaneUnits + u * 8, last_vec));
+                        nxt[d][u] = stream_load(hay, min(tile + (kAcTiles + d) * kAcTileUnits + lane * kAcLaneUnits + u * 8, last_vec));
             }
 #ifdef ACGPU_TIMING
             const unsigned long long tm_f0 = clock64();
@@ -570,8 +578,8 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                 uint32_t ww[4 * kAcVec];
 #pragma unroll
                 for (int u = 0; u < kAcVec; ++u) {
-                    ww[4 * u + 0] = grp[d][u].x; ww[4 * u + 1] = grp[d][u].y;
-                    ww[4 * u + 2] = grp[d][u].z; ww[4 * u + 3] = grp[d][u].w;
+                    ww[4 * u + 0] = (uint32_t)grp[d][u].lo; ww[4 * u + 1] = (uint32_t)(grp[d][u].lo >> 32);
+                    ww[4 * u + 2] = (uint32_t)grp[d][u].hi; ww[4 * u + 3] = (uint32_t)(grp[d][u].hi >> 32);
                 }
                 // the previous lane's last dwords give the K-1 units before v; lane 0 takes the previous tile's lane 63
                 uint32_t pp[4] = {0, 0, 0, 0};
@@ -659,7 +667,8 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     mask = kAcLaneUnits == 32 ? acc : acc >> ((32 - kAcLaneUnits) & 31);
-                    if (edge) {
+                    if (edge) { // wave-uniform, rare (the empty asm keeps this a branch: if-converted it is 16 VALU in every tile)
+                        asm volatile("" ::: "memory");
                         const uint32_t first = lo > v ? min(lo - v, (uint32_t)kAcLaneUnits) : 0u;
                         const uint32_t last = top > v ? min(top - v, (uint32_t)kAcLaneUnits) : 0u;
                         mask &= (uint32_t)((1ull << last) - 1ull) & ~(uint32_t)((1ull << first) - 1ull);
@@ -730,7 +739,8 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                         const uint32_t p = act ? (uint32_t)fresh[k] : 0u;
                         const Win8 w = *reinterpret_cast<const Win8 *>(tb8 + (int)p - 7);
                         const uint32_t cls[6] = {w.hi >> 24, (w.hi >> 16) & 0xffu, (w.hi >> 8) & 0xffu, w.hi & 0xffu, w.lo >> 24, (w.lo >> 16) & 0xffu};
-                        const uint32_t h = l2_hash(l2_gram(cls, K));
+                        // l2_gram(cls, K): one byte per class, text[e-1] highest -- for K = 4 that is the window's high word as it stands
+                        const uint32_t h = l2_hash(K == 4 ? w.hi : l2_gram(cls, K));
                         const uint32_t word = bloom[l2_word(h)];
                         const uint32_t pat = l2_pattern(h);
                         bool pass = false;
@@ -743,9 +753,9 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                         const uint64_t bal = __ballot(pass);
                         if (pass) { // the entry: position in the region, K-gram index (oldest unit most significant), left class
                             const uint32_t at = c.cand_n + (uint32_t)__popcll(bal & lanemask_lt());
-                            uint32_t idx = 0;
+                            uint32_t idx = cls[K - 1]; // (v_mad_u32_u24: the compiler's own choice here is the quarter-rate 64-bit mad)
 #pragma unroll
-                            for (int j = K - 1; j >= 0; --j) idx = __umul24(idx, n) + cls[j];
+                            for (int j = K - 2; j >= 0; --j) asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(idx) : "v"(idx), "s"(n), "v"(cls[j]));
                             c.pos16[at] = (uint16_t)(cur + p - c.pos_base);
                             c.cand[at] = kQiKnown | (cls[K] << kQiLeftShift) | idx;
                         }

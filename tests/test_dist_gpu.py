@@ -52,7 +52,7 @@ def _run(family, world, overlap, cap, tmp_path, n=50000):
 def test_sharded_matcher_native_scan_in_separate_processes(family, world, overlap, cap, tmp_path):
     res = _run(family, world, overlap, cap, tmp_path)
     assert all(r[2] > 0 for r in res)  # there were matches to get right
-    if family in ("longest", "shortest"):
-        assert sum(r[0] for r in res) > 0  # a shard boundary fell inside a match: the window repair ran on the device
+    if family in ("longest", "shortest") and world >= 3:
+        assert sum(r[0] for r in res) > 0  # some shard boundary fell inside a match: the window repair ran on the device
     if cap == 64:
         assert all(r[1] > 0 for r in res)  # every rank went through the collective redo

@@ -606,6 +606,9 @@ def test_config_c3_one_shard_full_size():
                                      len(tab), None), "synth")
     prev_tail = synth.haystack(c["hay_seed"] + g - 1, halo, start=n - halo)  # what rank g-1 sends
     buf[pad - halo:pad] = torch.from_numpy(prev_tail.view(np.int16)).cuda()
+    # (one planted occurrence across the shard boundary -- 3 units in the halo, the rest owned -- so that the halo matters)
+    k0 = max(kws, key=len)
+    buf[pad - 3:pad - 3 + len(k0)] = torch.from_numpy(k0.view(np.int16)).cuda()
     cap = 4_000_000
     got, prof = _dev_match(a, buf, pad + n, False, cap, own=(pad, pad + n), text_begin=False, text_end=False, profile=True)
     m = len(got)
