@@ -75,6 +75,7 @@ struct DeviceState {
     DevBuf stage_hay, stage_out; // acgpu_match_u16 staging
     DevBuf short_recs, short_nxt, short_tmp, short_mark; // SHORTEST: all-matches list + selection scratch
     DevBuf blockmax;                                     // LONGEST: farthest landing per 64 positions
+    DevBuf chainbits;                                    // LONGEST: one bit per position, set where the chain reports a match
     DevBuf cands, region_cands;                          // ALL, split form: candidate positions, {first, count} per region
     DevBuf wwl_rs, wwl_mend, wwl_mid, wwl_sel;          // WWLONGEST: walk starts and what each would report
     unsigned long long *h_counter = nullptr; // pinned
@@ -92,7 +93,7 @@ struct DeviceState {
         counter.release(); chunk_counts.release(); offsets.release(); scan_tmp.release(); scratch.release();
         chain.release(); lenbuf.release(); statebuf.release(); stage_hay.release(); stage_out.release();
         short_recs.release(); short_nxt.release(); short_tmp.release(); short_mark.release();
-        wwl_rs.release(); wwl_mend.release(); wwl_mid.release(); wwl_sel.release(); blockmax.release(); cands.release(); region_cands.release();
+        wwl_rs.release(); wwl_mend.release(); wwl_mid.release(); wwl_sel.release(); blockmax.release(); chainbits.release(); cands.release(); region_cands.release();
         if (h_counter) (void)hipHostFree(h_counter);
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         for (auto &tk : tickets) {
@@ -609,6 +610,15 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
     if (S.pairs) lds_rows = (uint32_t)std::min<uint64_t>(t.n_states, (72 * 1024) / ((uint64_t)t.n_cls * 4) - 2);
     S.lds_rows = lds_rows;
     S.lds_bytes = std::max<size_t>((size_t)(lds_rows + (S.pairs ? 2 : 0)) * t.n_cls * 4, 16);
+    // the work-list form of the range-class walk (tunable force_kernel=4 keeps the lock-step form): 16-bit lengths, LDS rows
+    // below 64 KiB (the row offset is the low word of an entry), two workgroups per CU
+    if (S.pairs && S.len_bytes == 2 && t.max_len < 64000 && tunables().force_kernel != 4) {
+        S.pairs = 2;
+        S.lds_rows = lds_rows = std::min<uint32_t>(t.n_states, longest_list_max_rows(t.n_cls, record_kind == ACGPU_REC_MAP));
+        S.lds_bytes = longest_list_lds_bytes(record_kind == ACGPU_REC_MAP);
+        // two workgroups per CU (Set records: 60 KiB of rows + 17 KiB of lists each; Map: 52 + 26)
+        S.grid = (int)std::min<uint64_t>(2ull * d.n_cu, (own_len + 16 * 1024 - 1) / (16 * 1024));
+    }
     int rc;
     if ((rc = d.lenbuf.ensure((size_t)sh->n_units * S.len_bytes + 64))) return rc;
     S.d_len = d.lenbuf.p;
@@ -654,10 +664,20 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
     if (prof) HIP_TRY(hipEventRecord(d.ev[1], stream));
     if ((rc = d.chain.ensure((size_t)Cn.n_tiles * 4 + 64))) return rc;
     uint32_t *d_sync = (uint32_t *)d.chain.p;
+    // the count pass marks the chain's matches in a bitmap, from which the records are written position-parallel
+    // (tunable tile_debug bit 65536 keeps the second serial pass over the chain)
+    Cn.d_bits = nullptr;
+    if (!(tunables().tile_debug & 65536)) {
+        const size_t bit_bytes = ((size_t)sh->n_units / 128 + 2) * 16; // whole groups of four words (16-byte stores)
+        if ((rc = d.chainbits.ensure(bit_bytes))) return rc;
+        Cn.d_bits = (uint32_t *)d.chainbits.p;
+        HIP_TRY(hipMemsetAsync(d.chainbits.p, 0, bit_bytes, stream));
+    }
     HIP_TRY(launch_longest_sync(Cn, d_sync, stream));
     HIP_TRY(launch_longest_chain(Cn, d_sync, /*write_pass=*/false, stream));
     HIP_TRY(launch_exclusive_scan(Cn.d_counts, Cn.n_tiles, (uint64_t *)d.offsets.p, (uint64_t *)d.scan_tmp.p, stream));
-    HIP_TRY(launch_longest_chain(Cn, d_sync, /*write_pass=*/true, stream));
+    if (Cn.d_bits) HIP_TRY(launch_longest_emit(Cn, d_sync, stream));
+    else HIP_TRY(launch_longest_chain(Cn, d_sync, /*write_pass=*/true, stream));
     if (prof) HIP_TRY(hipEventRecord(d.ev[2], stream));
     HIP_TRY(hipMemcpyAsync(d.h_counter, (const uint64_t *)d.scan_tmp.p + scan_tiles_for(Cn.n_tiles), 8, hipMemcpyDeviceToHost,
                            stream));

@@ -130,11 +130,14 @@ struct LongestScanLaunch {
     uint32_t *d_blockmax;           // per 64 owned positions: max(p + max(L[p],1)) -- lets the chain kernels skip
     int len_bytes;                  // 2 or 4
     uint32_t lds_rows;              // trie rows staged in LDS
-    int pairs;                      // 1: the lean range-class walk (k_longest_walk_range)
+    int pairs;                      // 1: the lean range-class walk (k_longest_walk_range), 2: its work-list form
+                                    // (k_longest_walk_list: one workgroup per CU, grid-stride over 1024-position chunks)
     int grid, block;
     size_t lds_bytes;
 };
 hipError_t launch_longest_scan(const DevTables &t, const LongestScanLaunch &l, hipStream_t stream, const char **kernel_name);
+size_t longest_list_lds_bytes(bool state);       // dynamic LDS of k_longest_walk_list (work lists)
+uint32_t longest_list_max_rows(uint32_t n_cls, bool state); // trie rows its static LDS holds
 
 struct LongestChainLaunch {
     const void *d_len;
@@ -153,9 +156,13 @@ struct LongestChainLaunch {
     uint64_t cap;
     int record_kind;
     unsigned long long *d_exit; // first chain position >= own_end
+    uint32_t *d_bits;           // one bit per buffer position: set by the count pass where a match is reported (zeroed by the
+                                // caller), read by k_longest_emit; nullptr: the serial write pass is used instead
 };
 hipError_t launch_longest_sync(const LongestChainLaunch &l, uint32_t *d_sync, hipStream_t stream);
 hipError_t launch_longest_chain(const LongestChainLaunch &l, const uint32_t *d_sync, bool write_pass, hipStream_t stream);
+// the records from the bitmap of the count pass (d_bits), one wave per chain segment
+hipError_t launch_longest_emit(const LongestChainLaunch &l, const uint32_t *d_sync, hipStream_t stream);
 } // namespace acgpu
 
 namespace acgpu {

@@ -223,6 +223,271 @@ __global__ __launch_bounds__(kLScanBlock) void k_longest_walk_range(DevTables T,
     }
 }
 
+// ---- the work-list form of the range-class walk ------------------------------------------------------------------------
+// k_longest_walk_range keeps a wave in lock step until its LONGEST walk ends: at config 4 a wave runs ~24 trie steps for
+// walks that average ~9 (SQ counters: 2.8 G VALU wave-instructions), i.e. 60 % of its lanes are dead weight.  Here a wave
+// owns a chunk of 1024 consecutive positions and walks in rounds of 8 steps:
+//   first round : 64 consecutive positions per lane group, all lanes alive at the start (text loads and len[] stores
+//                 coalesced), two independent walks per lane (p and p+64) to cover the LDS latency of the dependent reads;
+//   survivors   : walks still alive after a round are appended, compacted, to the wave's work list in LDS
+//                 {row offset, longest keyword so far, position, depth}; whenever the list holds 64 entries a full batch
+//                 takes its next round, and the list is run dry at the end of the chunk -- lanes are only idle in the few
+//                 last batches of a chunk.
+// A step is 3.5 VALU instructions instead of 7: the columns of two units come out of three packed 16-bit operations
+// (v_pk_sub_u16, v_pk_min_u16, v_pk_lshlrev_b16), the LDS rows sit below 64 KiB so that the row offset is the low WORD of
+// an entry (the address is one v_add_u32 with SDWA word selects, no masking), and "this node ends a keyword" (bit 31 of the
+// entry) is shifted into a history word by one v_alignbit_b32 -- the longest keyword of a round is read off that word once
+// per round.  The farthest landing of every 64 positions (d_blockmax) is collected in LDS: the first round's finished lanes
+// by a wave reduction, later finishers by ds_max_u32.
+// wave64 maximum in lane 63 with DPP row shifts and row broadcasts (VALU only: __shfl_xor is a ds_bpermute each, and the
+// LDS is this kernel's busiest unit)
+__device__ __forceinline__ uint32_t wave_max_dpp(uint32_t x) {
+    // (written as v_max_u32_dpp: the compiler's own choice is a v_mov_b32_dpp and a v_max_u32 per step; lanes without a
+    // source keep their value: bound_ctrl off, the old value is the destination itself)
+    asm("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(x));
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+
+constexpr int kWlChunk = 1024;  // positions per wave and chunk
+constexpr int kWlCap = 128;     // work-list entries per wave (a round is run as soon as there are 64)
+
+__device__ __forceinline__ uint32_t wl_pk_col4(uint32_t units2, uint32_t base2, uint32_t span2) {
+    uint32_t t, u, r;
+    asm("v_pk_sub_u16 %0, %1, %2" : "=v"(t) : "v"(units2), "s"(base2));
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(u) : "v"(t), "s"(span2));
+    // (the shift count is packed too: an inline constant would only reach the low half)
+    asm("v_pk_lshlrev_b16 %0, %1, %2" : "=v"(r) : "s"(0x00020002u), "v"(u));
+    return r;
+}
+
+// one round: 8 trie steps from row offset `e` (low word) through the 8 units in w[]; returns the last entry read.
+// tm collects the keyword-end flags (bit 7-j = step j); hist[j] = entry after step j (STATE: which node the longest keyword is)
+template <bool STATE, bool CHECK>
+__device__ __forceinline__ uint32_t wl_round(const unsigned char *rows8, const uint32_t (&w)[4], uint32_t nvalid, uint32_t base2,
+                                             uint32_t span2, uint32_t span4, uint32_t e, uint32_t &tm, uint32_t (&hist)[8]) {
+    tm = 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        uint32_t cc = wl_pk_col4(w[d], base2, span2);
+        if (CHECK) { // units past the end of the buffer: no transition
+            if ((uint32_t)(2 * d) >= nvalid) cc = (cc & 0xffff0000u) | span4;
+            if ((uint32_t)(2 * d + 1) >= nvalid) cc = (cc & 0xffffu) | (span4 << 16);
+        }
+        // address = row offset (low word of the entry) + column offset (low / high word of cc): one SDWA add each
+        uint32_t a0, a1;
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_0" : "=v"(a0) : "v"(e), "v"(cc));
+        e = *reinterpret_cast<const uint32_t *>(rows8 + a0);
+        tm = __builtin_amdgcn_alignbit(tm, e, 31);
+        if (STATE) hist[2 * d] = e;
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "=v"(a1) : "v"(e), "v"(cc));
+        e = *reinterpret_cast<const uint32_t *>(rows8 + a1);
+        tm = __builtin_amdgcn_alignbit(tm, e, 31);
+        if (STATE) hist[2 * d + 1] = e;
+    }
+    return e;
+}
+
+// trie rows in STATIC LDS at offset 0 (a row offset is the ds_read address as it stands): 60 KiB, or 52 KiB next to the
+// larger work lists of the Map flavour, so that two workgroups share a CU either way
+constexpr int kWlRowWordsSet = 15360, kWlRowWordsMap = 13312;
+
+template <typename LenT, bool STATE>
+__global__ __launch_bounds__(kLScanBlock) void k_longest_walk_list(DevTables T, LongestScanLaunch L) {
+    __shared__ __attribute__((aligned(16))) uint32_t rows[STATE ? kWlRowWordsMap : kWlRowWordsSet];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[]; // the work lists
+    const uint32_t *glob = reinterpret_cast<const uint32_t *>(T.dfa);
+    const uint32_t n = T.n_cls, span = T.cls_span, base = T.cls_base; // n == span + 1
+    const uint32_t row_bytes = n * 4u;
+    const uint32_t real_bytes = L.lds_rows * row_bytes, dead_off = real_bytes, deep_off = real_bytes + row_bytes;
+    for (uint32_t i = threadIdx.x; i < (L.lds_rows + 2) * n; i += blockDim.x) { // (as k_longest_walk_range stages them)
+        const uint32_t r = i / n, col = i - r * n;
+        uint32_t e;
+        if (r >= L.lds_rows) {
+            e = r == L.lds_rows ? dead_off : deep_off;
+        } else {
+            const uint32_t g = col < span ? glob[r * n + col + 1] : 0u;
+            if (!g) e = dead_off;
+            else if ((g & 0x7fffffffu) >= L.lds_rows) e = deep_off;
+            else e = (g & 0x80000000u) | ((g & 0x7fffffffu) * row_bytes);
+        }
+        rows[i] = e;
+    }
+    constexpr int kWaves = kLScanBlock / kWave;
+    constexpr int kEntryWords = STATE ? 3 : 2;
+    const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const uint32_t lane = lane_id();
+    // behind the rows: per wave the work list (kEntryWords arrays of kWlCap words) and 16 block maxima
+    uint32_t *wl = reinterpret_cast<uint32_t *>(smem) + wave_in_block * (kEntryWords * kWlCap + kWlChunk / 64);
+    uint32_t *wl0 = wl, *wl1 = wl + kWlCap, *wl2 = wl + 2 * kWlCap; // {row offset | best << 16}, {position in chunk | depth << 16}, [best node's entry]
+    uint32_t *bm = wl + kEntryWords * kWlCap;
+    __syncthreads();
+    LenT *out_len = reinterpret_cast<LenT *>(L.d_len);
+    const uint16_t *hay = L.d_hay;
+    const unsigned char *rows8 = reinterpret_cast<const unsigned char *>(rows);
+    const uint32_t nu = L.n_units;
+    const uint32_t base2 = base * 0x10001u, span2 = span * 0x10001u, span4 = span * 4u;
+    const uint32_t n_waves = gridDim.x * kWaves;
+    const uint32_t wave_global = blockIdx.x * kWaves + wave_in_block;
+    const uint64_t own_len = (uint64_t)L.own_end - L.own_begin;
+    const uint32_t n_chunks = (uint32_t)((own_len + kWlChunk - 1) / kWlChunk);
+
+    // a finished walk: len[] (and the node), its landing into the block maximum; a walk that ran into the DEEP row is redone
+    // through the table in global memory first (rare: nodes beyond the LDS rows)
+    auto finish = [&](uint32_t p, uint32_t prel, uint32_t off16, uint32_t best, uint32_t best_e, bool by_atomic) {
+        uint32_t best_node = STATE ? (best_e & 0xffffu) / row_bytes : 0u;
+        if (off16 == deep_off) {
+            uint32_t node = 0, j = p;
+            best = 0;
+            best_node = 0;
+            while (j < nu) {
+                const uint32_t dlt = hay[j] - base;
+                const uint32_t g = glob[node * n + (dlt < span ? dlt + 1u : 0u)];
+                if (!g) break;
+                node = g & 0x7fffffffu;
+                ++j;
+                if (g >> 31) {
+                    best = j - p;
+                    best_node = node;
+                }
+            }
+        }
+        out_len[p] = (LenT)best;
+        if (STATE) L.d_state[p] = best_node;
+        const uint32_t reach = p + (best ? best : 1u);
+        if (by_atomic) atomicMax(&bm[prel >> 6], reach);
+        return reach;
+    };
+    // the longest keyword of a round: the LAST flagged step (lowest set bit of the history), depth0 steps done before it
+    auto round_best = [&](uint32_t tm, uint32_t depth0, const uint32_t (&hist)[8], uint32_t &best, uint32_t &best_e) {
+        const uint32_t t8 = tm & 0xffu;
+        if (t8) {
+            const uint32_t b = (uint32_t)__builtin_ctz(t8); // step 7 - b
+            best = depth0 + 8u - b;
+            if (STATE) {
+                uint32_t x0 = (b & 4u) ? hist[3] : hist[7], x1 = (b & 4u) ? hist[2] : hist[6];
+                uint32_t x2 = (b & 4u) ? hist[1] : hist[5], x3 = (b & 4u) ? hist[0] : hist[4];
+                x0 = (b & 2u) ? x2 : x0;
+                x1 = (b & 2u) ? x3 : x1;
+                best_e = (b & 1u) ? x1 : x0;
+            }
+        }
+    };
+    auto load8 = [&](uint32_t i, uint32_t (&w)[4], uint32_t &nvalid, bool check) {
+        nvalid = 8;
+        if (!check) {
+            const Units8 u = *reinterpret_cast<const Units8 *>(hay + i);
+            w[0] = u.d[0]; w[1] = u.d[1]; w[2] = u.d[2]; w[3] = u.d[3];
+            return;
+        }
+        nvalid = min(nu - min(i, nu), 8u);
+        w[0] = w[1] = w[2] = w[3] = 0;
+        if (nvalid == 8) {
+            const Units8 u = *reinterpret_cast<const Units8 *>(hay + i);
+            w[0] = u.d[0]; w[1] = u.d[1]; w[2] = u.d[2]; w[3] = u.d[3];
+        } else {
+            for (uint32_t j = 0; j < nvalid; ++j) w[j >> 1] |= (uint32_t)hay[i + j] << (16 * (j & 1));
+        }
+    };
+    uint32_t wl_n = 0; // wave-uniform: entries in the work list
+    // survivors of a round -> work list (compacted by ballot); alive lanes only
+    auto append = [&](bool alive, uint32_t e, uint32_t best, uint32_t best_e, uint32_t prel, uint32_t depth) {
+        const uint64_t bal = __ballot(alive);
+        if (alive) {
+            const uint32_t at = wl_n + (uint32_t)__popcll(bal & lanemask_lt());
+            wl0[at] = (e & 0xffffu) | (best << 16);
+            wl1[at] = prel | (depth << 16);
+            if (STATE) wl2[at] = best_e;
+        }
+        wl_n += (uint32_t)__popcll(bal);
+    };
+    // one more round for the top min(wl_n, 64) entries of the list
+    auto list_round = [&](uint32_t chunk0, bool check) {
+        const uint32_t nb = min(wl_n, (uint32_t)kWave);
+        const uint32_t first = wl_n - nb;
+        const bool act = lane < nb;
+        uint32_t e = dead_off, best = 0, best_e = 0, prel = 0, depth = 0;
+        if (act) {
+            const uint32_t a = wl0[first + lane], b = wl1[first + lane];
+            e = a & 0xffffu; best = a >> 16;
+            prel = b & 0xffffu; depth = b >> 16;
+            if (STATE) best_e = wl2[first + lane];
+        }
+        __builtin_amdgcn_wave_barrier();
+        wl_n = first;
+        const uint32_t p = chunk0 + prel;
+        uint32_t w[4], nvalid, tm, hist[8];
+        load8(act ? p + depth : chunk0, w, nvalid, check);
+        if (check) e = wl_round<STATE, true>(rows8, w, nvalid, base2, span2, span4, e, tm, hist);
+        else e = wl_round<STATE, false>(rows8, w, nvalid, base2, span2, span4, e, tm, hist);
+        round_best(tm, depth, hist, best, best_e);
+        const uint32_t off16 = e & 0xffffu;
+        const bool alive = act && off16 < real_bytes && depth < 65000u; // (no keyword is that long: see the launch condition)
+        if (act && !alive) (void)finish(p, prel, off16, best, best_e, true);
+        append(alive, e, best, best_e, prel, depth + 8u);
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    for (uint32_t ck = wave_global; ck < n_chunks; ck += n_waves) {
+        const uint32_t chunk0 = L.own_begin + ck * kWlChunk;
+        const uint32_t chunk_end = (uint32_t)min((uint64_t)L.own_end, (uint64_t)chunk0 + kWlChunk);
+        // every 16-byte text load of this chunk stays inside the buffer (walks are at most max_len deep)
+        const bool check = (uint64_t)chunk_end + T.max_len + 8u > (uint64_t)nu;
+        if (lane < kWlChunk / 64) bm[lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t s0 = chunk0; s0 < chunk_end; s0 += 2 * kWave) { // first round: positions s0+lane and s0+64+lane
+            uint32_t pp[2] = {s0 + lane, s0 + kWave + lane};
+            uint32_t ee[2], tmm[2], hh[2][8], ww[2][4], nv[2];
+            bool in[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                in[h] = pp[h] < chunk_end;
+                load8(in[h] ? pp[h] : chunk0, ww[h], nv[h], check);
+            }
+            // (the two walks are written out side by side: their dependent LDS reads interleave)
+            if (check) {
+                ee[0] = wl_round<STATE, true>(rows8, ww[0], nv[0], base2, span2, span4, 0u, tmm[0], hh[0]);
+                ee[1] = wl_round<STATE, true>(rows8, ww[1], nv[1], base2, span2, span4, 0u, tmm[1], hh[1]);
+            } else {
+                ee[0] = wl_round<STATE, false>(rows8, ww[0], nv[0], base2, span2, span4, 0u, tmm[0], hh[0]);
+                ee[1] = wl_round<STATE, false>(rows8, ww[1], nv[1], base2, span2, span4, 0u, tmm[1], hh[1]);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                uint32_t best = 0, best_e = 0;
+                round_best(tmm[h], 0u, hh[h], best, best_e);
+                const uint32_t off16 = ee[h] & 0xffffu;
+                const bool alive = in[h] && off16 < real_bytes;
+                const uint32_t prel = pp[h] - chunk0;
+                uint32_t reach = 0;
+                if (in[h] && !alive) reach = finish(pp[h], prel, off16, best, best_e, false);
+                reach = wave_max_dpp(reach); // (no survivor has touched this block's maximum yet: a plain store)
+                if (lane == 0 && s0 + h * kWave < chunk_end) bm[(s0 + h * kWave - chunk0) >> 6] = reach;
+                append(alive, ee[h], best, best_e, prel, 8u);
+                __builtin_amdgcn_wave_barrier();
+                while (wl_n >= (uint32_t)kWave) list_round(chunk0, check); // fewer than 64 entries are left: the next append fits
+            }
+        }
+        while (wl_n) list_round(chunk0, check);
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t nblk = (chunk_end - chunk0 + 63u) >> 6;
+        if (lane < nblk) L.d_blockmax[((chunk0 - L.own_begin) >> 6) + lane] = bm[lane];
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// dynamic LDS of k_longest_walk_list (the work lists); its trie rows are static: at most longest_list_max_rows(n_cls) rows
+size_t longest_list_lds_bytes(bool state) { return (size_t)(kLScanBlock / kWave) * ((state ? 3 : 2) * kWlCap + kWlChunk / 64) * 4; }
+uint32_t longest_list_max_rows(uint32_t n_cls, bool state) {
+    return n_cls ? (uint32_t)(state ? kWlRowWordsMap : kWlRowWordsSet) / n_cls - 2u : 0u;
+}
+
 hipError_t launch_longest_scan(const DevTables &t, const LongestScanLaunch &l, hipStream_t stream, const char **kernel_name) {
 #define ACGPU_LAUNCH(KERNEL, NAME)                                                                                      \
     do {                                                                                                                \
@@ -232,7 +497,10 @@ hipError_t launch_longest_scan(const DevTables &t, const LongestScanLaunch &l, h
         hipLaunchKernelGGL(KERNEL, dim3(l.grid), dim3(l.block), l.lds_bytes, stream, t, l);                             \
         if (kernel_name) *kernel_name = NAME;                                                                           \
     } while (0)
-    if (l.pairs) { // (field name kept: the lean range-class form)
+    if (l.pairs == 2) { // the work-list form (16-bit lengths, LDS rows below 64 KiB)
+        if (l.d_state) ACGPU_LAUNCH((k_longest_walk_list<uint16_t, true>), "k_longest_walk_list<unsigned short, true>");
+        else ACGPU_LAUNCH((k_longest_walk_list<uint16_t, false>), "k_longest_walk_list<unsigned short, false>");
+    } else if (l.pairs) { // (field name kept: the lean range-class form)
         if (l.d_state) {
             if (l.len_bytes == 2) ACGPU_LAUNCH((k_longest_walk_range<uint16_t, true>), "k_longest_walk_range<unsigned short, true>");
             else ACGPU_LAUNCH((k_longest_walk_range<uint32_t, true>), "k_longest_walk_range<unsigned int, true>");
@@ -327,7 +595,11 @@ __global__ __launch_bounds__(256) void k_longest_sync(LongestChainLaunch L, uint
 // stores by the same lane), so that the L2 sees full sectors instead of one 8-byte store per line and instruction.
 constexpr int kChainBlock = 256;
 
-template <typename LenT, bool WRITE>
+// BITS (count pass): the lane also marks every position at which it reports a match in the bitmap L.d_bits -- with it
+// the records are written by k_longest_emit, in parallel over all positions, instead of a second serial pass over the
+// chain (WRITE).  A segment's first and last bitmap word may be shared with its neighbours (atomicOr); the words between
+// are its own (plain stores into the zeroed bitmap).
+template <typename LenT, bool WRITE, bool BITS = false>
 __global__ __launch_bounds__(kChainBlock) void k_longest_chain(LongestChainLaunch L, const uint32_t *S) {
     __shared__ int2 ring_se[WRITE ? 8 : 1][kChainBlock]; // [slot][lane]: conflict-free for a lane's own slots
     __shared__ int ring_id[WRITE ? 4 : 1][kChainBlock];
@@ -390,9 +662,39 @@ __global__ __launch_bounds__(kChainBlock) void k_longest_chain(LongestChainLaunc
         x0 = (k & 2u) ? x1 : x0;
         return (k & 1u) ? (x0 >> 16) : (x0 & 0xffffu);
     };
+    // BITS: the aligned group of four bitmap words (128 positions) being filled.  Stores sit in the lane's in-order vmcnt
+    // stream in front of its next window load (gfx950 counts stores there), so they are few and wide: one 16-byte store per
+    // group; only the first and the last group of a segment can be shared with a neighbour (atomicOr per word).
+    uint32_t bg = ~0u;
+    unsigned long long blo = 0, bhi = 0;
+    bool bfirst = true;
+    auto flush_bits = [&](bool shared) {
+        if (!(blo | bhi)) return;
+        uint32_t *dst = L.d_bits + (size_t)bg * 4u;
+        if (shared) {
+            if ((uint32_t)blo) atomicOr(dst, (uint32_t)blo);
+            if ((uint32_t)(blo >> 32)) atomicOr(dst + 1, (uint32_t)(blo >> 32));
+            if ((uint32_t)bhi) atomicOr(dst + 2, (uint32_t)bhi);
+            if ((uint32_t)(bhi >> 32)) atomicOr(dst + 3, (uint32_t)(bhi >> 32));
+        } else {
+            *reinterpret_cast<uint4 *>(dst) = make_uint4((uint32_t)blo, (uint32_t)(blo >> 32), (uint32_t)bhi, (uint32_t)(bhi >> 32));
+        }
+    };
     while (pos < target && pos < L.own_end) {
         const uint32_t l = len_at(pos);
         if (l > 0) {
+            if (BITS) {
+                const uint32_t g = pos >> 7;
+                if (g != bg) {
+                    flush_bits(bfirst);
+                    bfirst = bg == ~0u; // (still nothing flushed: the next flush is the segment's first)
+                    bg = g;
+                    blo = bhi = 0;
+                }
+                const unsigned long long bit = 1ull << (pos & 63u);
+                if (pos & 64u) bhi |= bit;
+                else blo |= bit;
+            }
             if (WRITE) {
                 const uint32_t k = (uint32_t)dst & gmask;
                 ring_se[k][lane] = make_int2((int)pos, (int)(pos + l));
@@ -451,9 +753,84 @@ __global__ __launch_bounds__(kChainBlock) void k_longest_chain(LongestChainLaunc
         const uint32_t k = (uint32_t)dst & gmask;
         if (k > gfirst) flush_scalar(dst - k, gfirst, k);
     }
+    if (BITS) flush_bits(true);
     if (!WRITE) {
         L.d_counts[t] = count;
         if (pos >= L.own_end) *L.d_exit = pos; // exactly one lane's segment crosses the end of the owned range
+    }
+}
+
+// The records of segment t -- the matches of the chain between the synchronisation points S[t] and the next one -- from
+// the bitmap the count pass left: one wave per segment, 64 bitmap words per step (lane i: word i), a wave prefix sum of
+// the popcounts gives every record its place behind d_offsets[t]; the records are staged in LDS in order and leave as
+// coalesced stores.  Position parallel: this pass runs at memory speed where the serial write pass waited for the chain.
+constexpr int kEmitBlock = 256;
+constexpr int kEmitCap = 1024; // records staged per wave and step (a denser step goes out in several rounds)
+
+template <typename LenT, int REC>
+__global__ __launch_bounds__(kEmitBlock) void k_longest_emit(LongestChainLaunch L, const uint32_t *S) {
+    __shared__ int2 st_se[kEmitBlock / kWave][kEmitCap];
+    __shared__ int st_id[REC == ACGPU_REC_MAP ? kEmitBlock / kWave : 1][REC == ACGPU_REC_MAP ? kEmitCap : 1];
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const uint32_t t = blockIdx.x * (kEmitBlock / kWave) + wave;
+    if (t >= L.n_tiles) return;
+    const uint32_t lane = lane_id();
+    const uint32_t start = __builtin_amdgcn_readfirstlane(S[t]);
+    if (start == ~0u || start >= L.own_end) return;
+    uint32_t target = L.own_end; // the next synchronisation point on the chain (the segment ends before it)
+    for (uint32_t t2 = t + 1; t2 < L.n_tiles; ++t2) {
+        const uint32_t v = __builtin_amdgcn_readfirstlane(S[t2]);
+        if (v != ~0u) {
+            target = min(v, L.own_end);
+            break;
+        }
+    }
+    const LenT *len = reinterpret_cast<const LenT *>(L.d_len);
+    uint64_t base = L.d_offsets[t];
+    const uint32_t w_first = start >> 5, w_last = (target - 1u) >> 5;
+    int2 *se = st_se[wave];
+    for (uint32_t w0 = w_first; w0 <= w_last; w0 += kWave) {
+        const uint32_t wi = w0 + lane;
+        uint32_t bits = wi <= w_last ? L.d_bits[wi] : 0u;
+        // positions of this segment only: [start, target)
+        if (wi == w_first) bits &= ~0u << (start & 31u);
+        if (wi == w_last && (target & 31u)) bits &= ~(~0u << (target & 31u));
+        const uint32_t cnt = __popc(bits);
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+            if ((int)lane >= d) incl += o;
+        }
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
+        const uint32_t first = incl - cnt;
+        for (uint32_t done = 0; done < total; done += kEmitCap) { // (one round unless the chain is dense)
+            uint32_t b = bits, k = first;
+            while (b) {
+                const uint32_t p = wi * 32u + (uint32_t)__builtin_ctz(b);
+                b &= b - 1u;
+                if (k >= done && k < done + kEmitCap) {
+                    se[k - done] = make_int2((int)p, (int)(p + (uint32_t)len[p]));
+                    if (REC == ACGPU_REC_MAP) st_id[wave][k - done] = (int)L.d_out_id[L.d_state[p]];
+                }
+                ++k;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t m = min(total - done, (uint32_t)kEmitCap);
+            for (uint32_t j = lane; j < m; j += kWave) {
+                const uint64_t dst = base + done + j;
+                if (dst >= L.cap) break;
+                const int2 r = se[j];
+                if (REC == ACGPU_REC_SET) {
+                    reinterpret_cast<int2 *>(L.d_out)[dst] = r;
+                } else {
+                    int32_t *o = reinterpret_cast<int32_t *>(L.d_out) + dst * 3;
+                    o[0] = r.x; o[1] = r.y; o[2] = st_id[wave][j];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        base += total;
     }
 }
 
@@ -470,10 +847,26 @@ hipError_t launch_longest_chain(const LongestChainLaunch &l, const uint32_t *d_s
     const dim3 grid((l.n_tiles + kChainBlock - 1) / kChainBlock), block(kChainBlock);
     if (l.len_bytes == 2) {
         if (write_pass) hipLaunchKernelGGL((k_longest_chain<uint16_t, true>), grid, block, 0, stream, l, d_sync);
+        else if (l.d_bits) hipLaunchKernelGGL((k_longest_chain<uint16_t, false, true>), grid, block, 0, stream, l, d_sync);
         else hipLaunchKernelGGL((k_longest_chain<uint16_t, false>), grid, block, 0, stream, l, d_sync);
     } else {
         if (write_pass) hipLaunchKernelGGL((k_longest_chain<uint32_t, true>), grid, block, 0, stream, l, d_sync);
+        else if (l.d_bits) hipLaunchKernelGGL((k_longest_chain<uint32_t, false, true>), grid, block, 0, stream, l, d_sync);
         else hipLaunchKernelGGL((k_longest_chain<uint32_t, false>), grid, block, 0, stream, l, d_sync);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_longest_emit(const LongestChainLaunch &l, const uint32_t *d_sync, hipStream_t stream) {
+    if (l.n_tiles == 0) return hipSuccess;
+    const dim3 grid((l.n_tiles + kEmitBlock / kWave - 1) / (kEmitBlock / kWave)), block(kEmitBlock);
+    const bool set_kind = l.record_kind == ACGPU_REC_SET;
+    if (l.len_bytes == 2) {
+        if (set_kind) hipLaunchKernelGGL((k_longest_emit<uint16_t, ACGPU_REC_SET>), grid, block, 0, stream, l, d_sync);
+        else hipLaunchKernelGGL((k_longest_emit<uint16_t, ACGPU_REC_MAP>), grid, block, 0, stream, l, d_sync);
+    } else {
+        if (set_kind) hipLaunchKernelGGL((k_longest_emit<uint32_t, ACGPU_REC_SET>), grid, block, 0, stream, l, d_sync);
+        else hipLaunchKernelGGL((k_longest_emit<uint32_t, ACGPU_REC_MAP>), grid, block, 0, stream, l, d_sync);
     }
     return hipGetLastError();
 }
