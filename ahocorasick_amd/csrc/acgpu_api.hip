@@ -664,19 +664,26 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
     if (prof) HIP_TRY(hipEventRecord(d.ev[1], stream));
     if ((rc = d.chain.ensure((size_t)Cn.n_tiles * 4 + 64))) return rc;
     uint32_t *d_sync = (uint32_t *)d.chain.p;
-    // the count pass marks the chain's matches in a bitmap, from which the records are written position-parallel
-    // (tunable tile_debug bit 65536 keeps the second serial pass over the chain)
+    // Chain: synchronisation points, a count pass that also marks the chain's matches in a bitmap, prefix sum, and the
+    // records written position-parallel from the bitmap (k_longest_emit).  16-bit lengths take the count pass that reads the
+    // lengths through LDS in chunks (k_longest_chain_lds).  Tunable tile_debug, for A/B: bit 65536 = the serial write pass
+    // instead of bitmap + emit, bit 131072 = the count/write passes that read the lengths from global memory.
     Cn.d_bits = nullptr;
-    if (!(tunables().tile_debug & 65536)) {
+    Cn.len_units = (uint32_t)sh->n_units;
+    const bool serial_write = (tunables().tile_debug & 65536) != 0;
+    const bool chain_lds = Cn.len_bytes == 2 && !(tunables().tile_debug & 131072);
+    if (!serial_write) {
         const size_t bit_bytes = ((size_t)sh->n_units / 128 + 2) * 16; // whole groups of four words (16-byte stores)
         if ((rc = d.chainbits.ensure(bit_bytes))) return rc;
         Cn.d_bits = (uint32_t *)d.chainbits.p;
         HIP_TRY(hipMemsetAsync(d.chainbits.p, 0, bit_bytes, stream));
     }
     HIP_TRY(launch_longest_sync(Cn, d_sync, stream));
-    HIP_TRY(launch_longest_chain(Cn, d_sync, /*write_pass=*/false, stream));
+    if (chain_lds) HIP_TRY(launch_longest_chain_lds(Cn, d_sync, /*write_pass=*/false, stream));
+    else HIP_TRY(launch_longest_chain(Cn, d_sync, /*write_pass=*/false, stream));
     HIP_TRY(launch_exclusive_scan(Cn.d_counts, Cn.n_tiles, (uint64_t *)d.offsets.p, (uint64_t *)d.scan_tmp.p, stream));
-    if (Cn.d_bits) HIP_TRY(launch_longest_emit(Cn, d_sync, stream));
+    if (!serial_write) HIP_TRY(launch_longest_emit(Cn, d_sync, stream));
+    else if (chain_lds) HIP_TRY(launch_longest_chain_lds(Cn, d_sync, /*write_pass=*/true, stream));
     else HIP_TRY(launch_longest_chain(Cn, d_sync, /*write_pass=*/true, stream));
     if (prof) HIP_TRY(hipEventRecord(d.ev[2], stream));
     HIP_TRY(hipMemcpyAsync(d.h_counter, (const uint64_t *)d.scan_tmp.p + scan_tiles_for(Cn.n_tiles), 8, hipMemcpyDeviceToHost,

@@ -156,11 +156,14 @@ struct LongestChainLaunch {
     uint64_t cap;
     int record_kind;
     unsigned long long *d_exit; // first chain position >= own_end
+    uint32_t len_units;         // entries of d_len that hold lengths (the chain passes through LDS read whole chunks)
     uint32_t *d_bits;           // one bit per buffer position: set by the count pass where a match is reported (zeroed by the
                                 // caller), read by k_longest_emit; nullptr: the serial write pass is used instead
 };
 hipError_t launch_longest_sync(const LongestChainLaunch &l, uint32_t *d_sync, hipStream_t stream);
 hipError_t launch_longest_chain(const LongestChainLaunch &l, const uint32_t *d_sync, bool write_pass, hipStream_t stream);
+// count / write pass with the lengths staged through LDS in chunks (16-bit lengths)
+hipError_t launch_longest_chain_lds(const LongestChainLaunch &l, const uint32_t *d_sync, bool write_pass, hipStream_t stream);
 // the records from the bitmap of the count pass (d_bits), one wave per chain segment
 hipError_t launch_longest_emit(const LongestChainLaunch &l, const uint32_t *d_sync, hipStream_t stream);
 } // namespace acgpu

@@ -296,11 +296,68 @@ __device__ __forceinline__ uint32_t wl_round(const unsigned char *rows8, const u
 
 // trie rows in STATIC LDS at offset 0 (a row offset is the ds_read address as it stands): 60 KiB, or 52 KiB next to the
 // larger work lists of the Map flavour, so that two workgroups share a CU either way
-constexpr int kWlRowWordsSet = 15360, kWlRowWordsMap = 13312;
+constexpr int kWlRowWordsSet = 13056, kWlRowWordsMap = 13312; // (Set: 51 KiB of rows + 9 KiB of root table)
+
+// The first round through a ROOT TABLE (Set flavour, small alphabets): every walk starts at the root, so the node reached
+// by the first RK units is a function of those units alone -- n^RK entries {row offset reached | longest keyword among the
+// RK steps << 16}, built in LDS by the kernel itself from the staged rows.  One LDS read replaces RK dependent ones (the
+// LDS is the busiest unit of this kernel); the remaining 8 - RK units of the round are ordinary steps.  The index is the
+// columns in radix n, most of it in packed arithmetic: even and odd columns run through the same two v_pk_mad_u16.
+constexpr int kWlRootWords = 2304; // n = 3 (two letters + "other"): RK = 7 (2187 entries); n <= 5 (DNA): RK = 4
+
+__device__ __forceinline__ uint32_t wl_mad_u16(uint32_t a, uint32_t b, uint32_t c, bool a_hi) {
+    uint32_t r;
+    if (a_hi) asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    else asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[0,0,0,0]" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
+}
+
+// returns the entry after 8 units; best = longest keyword of the round (0: none)
+template <int RK>
+__device__ __forceinline__ uint32_t wl_round_root(const unsigned char *rows8, const uint32_t *rt, const uint32_t (&w)[4], uint32_t base2,
+                                                  uint32_t span2, uint32_t n, uint32_t &best) {
+    static_assert(RK == 4 || RK == 7, "root table depth");
+    uint32_t P[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        uint32_t t;
+        asm("v_pk_sub_u16 %0, %1, %2" : "=v"(t) : "v"(w[d]), "s"(base2));
+        asm("v_pk_min_u16 %0, %1, %2" : "=v"(P[d]) : "v"(t), "s"(span2));
+    }
+    const uint32_t nn2 = n * n * 0x10001u;
+    uint32_t idx;
+    if (RK == 7) {
+        uint32_t E;
+        asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(E) : "v"(P[0]), "s"(nn2), "v"(P[1]));
+        asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(E) : "v"(E), "s"(nn2), "v"(P[2])); // lo: c0 n^4 + c2 n^2 + c4, hi: c1 n^4 + c3 n^2 + c5
+        idx = wl_mad_u16(E, n, P[3] & 0xffffu, true);                                  // hi n + c6
+        idx = wl_mad_u16(E, n * n, idx, false);                                        // + lo n^2
+    } else {
+        uint32_t E;
+        asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(E) : "v"(P[0]), "s"(nn2), "v"(P[1])); // lo: c0 n^2 + c2, hi: c1 n^2 + c3
+        idx = wl_mad_u16(E, n, E >> 16, false);                                        // lo n + hi
+    }
+    uint32_t e = rt[idx];
+    best = (e >> 16) & 0xfu;
+    uint32_t tm = 0;
+#pragma unroll
+    for (int j = RK; j < 8; ++j) { // the ordinary steps of the round
+        uint32_t cc, a;
+        asm("v_pk_lshlrev_b16 %0, %1, %2" : "=v"(cc) : "s"(0x00020002u), "v"(P[j >> 1]));
+        if (j & 1) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "=v"(a) : "v"(e), "v"(cc));
+        else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_0" : "=v"(a) : "v"(e), "v"(cc));
+        e = *reinterpret_cast<const uint32_t *>(rows8 + a);
+        tm = __builtin_amdgcn_alignbit(tm, e, 31);
+    }
+    if (tm) best = 8u - (uint32_t)__builtin_ctz(tm); // bit b = step 7 - b
+    return e;
+}
 
 template <typename LenT, bool STATE>
 __global__ __launch_bounds__(kLScanBlock) void k_longest_walk_list(DevTables T, LongestScanLaunch L) {
+    constexpr bool ROOT = !STATE;
     __shared__ __attribute__((aligned(16))) uint32_t rows[STATE ? kWlRowWordsMap : kWlRowWordsSet];
+    __shared__ uint32_t rt[ROOT ? kWlRootWords : 1];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[]; // the work lists
     const uint32_t *glob = reinterpret_cast<const uint32_t *>(T.dfa);
     const uint32_t n = T.n_cls, span = T.cls_span, base = T.cls_base; // n == span + 1
@@ -328,6 +385,25 @@ __global__ __launch_bounds__(kLScanBlock) void k_longest_walk_list(DevTables T, 
     uint32_t *wl0 = wl, *wl1 = wl + kWlCap, *wl2 = wl + 2 * kWlCap; // {row offset | best << 16}, {position in chunk | depth << 16}, [best node's entry]
     uint32_t *bm = wl + kEntryWords * kWlCap;
     __syncthreads();
+    // root table depth: 7 units for n <= 3, 4 for n <= 5, none for wider alphabets (n^2 entries would save one read in 8)
+    const uint32_t rk = !ROOT ? 0u : n <= 3 ? 7u : n <= 5 ? 4u : 0u;
+    if (ROOT && rk) {
+        uint32_t total = 1;
+        for (uint32_t j = 0; j < rk; ++j) total *= n;
+        for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) {
+            uint32_t div = total, rem = i, off = 0, best = 0;
+            for (uint32_t j = 0; j < rk; ++j) { // digit j (most significant first) = column of unit j
+                div /= n;
+                const uint32_t col = rem / div;
+                rem -= col * div;
+                const uint32_t e = rows[(off >> 2) + col];
+                off = e & 0xffffu;
+                if (e >> 31) best = j + 1;
+            }
+            rt[i] = off | (best << 16);
+        }
+        __syncthreads();
+    }
     LenT *out_len = reinterpret_cast<LenT *>(L.d_len);
     const uint16_t *hay = L.d_hay;
     const unsigned char *rows8 = reinterpret_cast<const unsigned char *>(rows);
@@ -451,9 +527,19 @@ __global__ __launch_bounds__(kLScanBlock) void k_longest_walk_list(DevTables T, 
                 load8(in[h] ? pp[h] : chunk0, ww[h], nv[h], check);
             }
             // (the two walks are written out side by side: their dependent LDS reads interleave)
+            uint32_t rbest[2] = {0, 0};
+            bool rooted = false; // wave-uniform
             if (check) {
                 ee[0] = wl_round<STATE, true>(rows8, ww[0], nv[0], base2, span2, span4, 0u, tmm[0], hh[0]);
                 ee[1] = wl_round<STATE, true>(rows8, ww[1], nv[1], base2, span2, span4, 0u, tmm[1], hh[1]);
+            } else if (ROOT && rk == 7) {
+                rooted = true;
+                ee[0] = wl_round_root<7>(rows8, rt, ww[0], base2, span2, n, rbest[0]);
+                ee[1] = wl_round_root<7>(rows8, rt, ww[1], base2, span2, n, rbest[1]);
+            } else if (ROOT && rk == 4) {
+                rooted = true;
+                ee[0] = wl_round_root<4>(rows8, rt, ww[0], base2, span2, n, rbest[0]);
+                ee[1] = wl_round_root<4>(rows8, rt, ww[1], base2, span2, n, rbest[1]);
             } else {
                 ee[0] = wl_round<STATE, false>(rows8, ww[0], nv[0], base2, span2, span4, 0u, tmm[0], hh[0]);
                 ee[1] = wl_round<STATE, false>(rows8, ww[1], nv[1], base2, span2, span4, 0u, tmm[1], hh[1]);
@@ -461,7 +547,8 @@ __global__ __launch_bounds__(kLScanBlock) void k_longest_walk_list(DevTables T, 
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 uint32_t best = 0, best_e = 0;
-                round_best(tmm[h], 0u, hh[h], best, best_e);
+                if (rooted) best = rbest[h];
+                else round_best(tmm[h], 0u, hh[h], best, best_e);
                 const uint32_t off16 = ee[h] & 0xffffu;
                 const bool alive = in[h] && off16 < real_bytes;
                 const uint32_t prel = pp[h] - chunk0;
@@ -487,6 +574,7 @@ size_t longest_list_lds_bytes(bool state) { return (size_t)(kLScanBlock / kWave)
 uint32_t longest_list_max_rows(uint32_t n_cls, bool state) {
     return n_cls ? (uint32_t)(state ? kWlRowWordsMap : kWlRowWordsSet) / n_cls - 2u : 0u;
 }
+static_assert(2187 <= kWlRootWords && 625 <= kWlRootWords, "root table: 3^7 and 5^4 entries");
 
 hipError_t launch_longest_scan(const DevTables &t, const LongestScanLaunch &l, hipStream_t stream, const char **kernel_name) {
 #define ACGPU_LAUNCH(KERNEL, NAME)                                                                                      \
@@ -832,6 +920,175 @@ __global__ __launch_bounds__(kEmitBlock) void k_longest_emit(LongestChainLaunch 
         }
         base += total;
     }
+}
+
+// ---- chain passes through LDS --------------------------------------------------------------------------------------------
+// k_longest_chain waits for global memory once per 16 positions of its (serial) chain: ~250 dependent round trips per lane,
+// 0.46 ms per pass at config 4 with every wave of the grid resident.  Here a lane still follows its own segment, but the
+// lengths come through LDS in chunks of 256 positions: a lane requests its whole chunk at once (32 independent 16-byte
+// loads: one memory latency per 256 positions instead of one per 16) and then walks it with LDS reads.  The walk is cheap
+// enough to run twice -- count, (prefix sum), write -- without the bitmap and the separate emit pass.
+constexpr int kC2Chunk = 256; // positions per lane and chunk: 32 pieces of 8 lengths; piece j of all lanes is one LDS-DMA
+                              // instruction (global_load_lds_dwordx4: lane i's 16 bytes land at piece base + 16 i)
+
+// BITS (count pass): the matches are also marked in the bitmap L.d_bits for k_longest_emit -- collected per chunk in LDS
+// (chunks start on a bitmap word) and merged into the zeroed bitmap with one atomicOr per non-zero word; these stores are
+// issued when a chunk is done and complete under the next chunk's load.
+template <bool WRITE, bool BITS = false>
+__global__ __launch_bounds__(kWave) void k_longest_chain_lds(LongestChainLaunch L, const uint32_t *S) {
+    __shared__ __attribute__((aligned(16))) unsigned char buf[kC2Chunk / 8 * kWave * 16]; // [piece][lane][8 lengths]
+    __shared__ uint32_t lbits[BITS ? kC2Chunk / 32 : 1][kWave];
+    __shared__ int2 ring_se[WRITE ? 8 : 1][kWave];
+    __shared__ int ring_id[WRITE ? 4 : 1][kWave];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t t = blockIdx.x * kWave + lane;
+    const uint16_t *len = reinterpret_cast<const uint16_t *>(L.d_len);
+    uint32_t start = t < L.n_tiles ? S[t] : ~0u;
+    bool active = start != ~0u && start < L.own_end;
+    if (t < L.n_tiles && !active && !WRITE) {
+        L.d_counts[t] = 0;
+        if (t == 0) *L.d_exit = L.entry; // entry at/after the end of the owned range
+    }
+    uint32_t target = ~0u; // the next synchronisation point on the chain
+    if (active)
+        for (uint32_t t2 = t + 1; t2 < L.n_tiles; ++t2) {
+            const uint32_t v = S[t2];
+            if (v != ~0u) {
+                target = v;
+                break;
+            }
+        }
+    const uint32_t limit = min(target, L.own_end);
+    const bool set_kind = L.record_kind == ACGPU_REC_SET;
+    const uint32_t gmask = set_kind ? 7u : 3u; // records per aligned group - 1
+    uint32_t pos = active ? start : 0u, count = 0;
+    uint64_t dst = (WRITE && active) ? L.d_offsets[t] : 0;
+    uint32_t gfirst = (uint32_t)dst & gmask;
+    auto flush_scalar = [&](uint64_t gbase, uint32_t from, uint32_t to) {
+        for (uint32_t k = from; k < to; ++k) {
+            const uint64_t d = gbase + k;
+            if (d >= L.cap) break;
+            const int2 se = ring_se[k][lane];
+            if (set_kind) {
+                reinterpret_cast<int2 *>(L.d_out)[d] = se;
+            } else {
+                int32_t *o = reinterpret_cast<int32_t *>(L.d_out) + d * 3;
+                o[0] = se.x; o[1] = se.y; o[2] = ring_id[k][lane];
+            }
+        }
+    };
+    const unsigned char *mine = buf + lane * 16;
+    // length x of the lane's chunk: piece x >> 3, entry x & 7
+    auto at = [&](uint32_t x) -> const unsigned char * { return mine + (x >> 3) * (kWave * 16) + (x & 7u) * 2u; };
+    // a chunk starts on a 16-byte boundary of len[]; pieces past its end are read from the last whole piece instead (never
+    // consulted: the walk stops at limit <= the end of the owned range; the allocation of len[] has 64 bytes of slack)
+    const uint32_t last_piece = L.len_units & ~7u;
+    while (__any(active)) {
+        const uint32_t cb = pos & (BITS ? ~31u : ~7u);
+        if (BITS) {
+#pragma unroll
+            for (int w = 0; w < kC2Chunk / 32; ++w) lbits[w][lane] = 0;
+        }
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < kC2Chunk / 8; ++j) // 32 loads straight into LDS, all in flight together
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(len + min(cb + j * 8, last_piece)),
+                                                 (__attribute__((address_space(3))) void *)(buf + j * (kWave * 16)), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (active) {
+            const uint32_t cend = cb + kC2Chunk;
+            while (pos < limit && pos < cend) {
+                const uint32_t l = *reinterpret_cast<const uint16_t *>(at(pos - cb));
+                if (l > 0) {
+                    if (BITS) lbits[(pos - cb) >> 5][lane] |= 1u << (pos & 31u);
+                    if (WRITE) {
+                        const uint32_t k = (uint32_t)dst & gmask;
+                        ring_se[k][lane] = make_int2((int)pos, (int)(pos + l));
+                        if (!set_kind) ring_id[k][lane] = (int)L.d_out_id[L.d_state[pos]];
+                        if (k == gmask) { // the group is full up to its last slot
+                            const uint64_t gbase = dst - gmask;
+                            if (gfirst == 0 && dst < L.cap) {
+                                if (set_kind) {
+                                    uint4 *o = reinterpret_cast<uint4 *>(reinterpret_cast<int2 *>(L.d_out) + gbase);
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) {
+                                        const int2 r0 = ring_se[2 * q][lane], r1 = ring_se[2 * q + 1][lane];
+                                        o[q] = make_uint4((uint32_t)r0.x, (uint32_t)r0.y, (uint32_t)r1.x, (uint32_t)r1.y);
+                                    }
+                                } else {
+                                    uint4 *o = reinterpret_cast<uint4 *>(reinterpret_cast<int32_t *>(L.d_out) + gbase * 3);
+                                    const int2 r0 = ring_se[0][lane], r1 = ring_se[1][lane], r2 = ring_se[2][lane], r3 = ring_se[3][lane];
+                                    o[0] = make_uint4((uint32_t)r0.x, (uint32_t)r0.y, (uint32_t)ring_id[0][lane], (uint32_t)r1.x);
+                                    o[1] = make_uint4((uint32_t)r1.y, (uint32_t)ring_id[1][lane], (uint32_t)r2.x, (uint32_t)r2.y);
+                                    o[2] = make_uint4((uint32_t)ring_id[2][lane], (uint32_t)r3.x, (uint32_t)r3.y, (uint32_t)ring_id[3][lane]);
+                                }
+                            } else {
+                                flush_scalar(gbase, gfirst, gmask + 1);
+                            }
+                            gfirst = 0;
+                        }
+                    }
+                    ++dst;
+                    ++count;
+                    pos += l;
+                } else {
+                    // no keyword starts here; from a piece boundary on, whole pieces of eight such positions are skipped at a stroke
+                    ++pos;
+                    const uint32_t stop = min(limit, cend);
+                    while ((pos & 7u) == 0 && pos + 8 <= stop) {
+                        const uint4 z = *reinterpret_cast<const uint4 *>(at(pos - cb));
+                        if (z.x | z.y | z.z | z.w) break;
+                        pos += 8;
+                    }
+                }
+            }
+            if (BITS) { // words wholly inside the segment are this lane's own (plain stores); the two at its ends may be shared
+                uint32_t bw[kC2Chunk / 32];
+#pragma unroll
+                for (int w = 0; w < kC2Chunk / 32; ++w) bw[w] = lbits[w][lane];
+                uint32_t *dstw = L.d_bits + (cb >> 5);
+                if (cb >= start && cb + kC2Chunk <= limit) {
+                    uint4 *d4 = reinterpret_cast<uint4 *>(dstw); // (cb is a multiple of 32 positions, not of 128: 4-byte aligned only)
+                    if ((cb & 127u) == 0) {
+                        d4[0] = make_uint4(bw[0], bw[1], bw[2], bw[3]);
+                        d4[1] = make_uint4(bw[4], bw[5], bw[6], bw[7]);
+                    } else {
+#pragma unroll
+                        for (int w = 0; w < kC2Chunk / 32; ++w) dstw[w] = bw[w];
+                    }
+                } else {
+#pragma unroll
+                    for (int w = 0; w < kC2Chunk / 32; ++w) {
+                        const uint32_t wp = cb + 32u * w;
+                        if (wp >= start && wp + 32u <= limit) dstw[w] = bw[w];
+                        else if (bw[w]) atomicOr(&dstw[w], bw[w]);
+                    }
+                }
+            }
+            if (pos >= limit) active = false;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (t < L.n_tiles && start != ~0u && start < L.own_end) {
+        if (WRITE) {
+            const uint32_t k = (uint32_t)dst & gmask;
+            if (k > gfirst) flush_scalar(dst - k, gfirst, k);
+        } else {
+            L.d_counts[t] = count;
+            if (pos >= L.own_end) *L.d_exit = pos; // exactly one lane's segment crosses the end of the owned range
+        }
+    }
+}
+
+hipError_t launch_longest_chain_lds(const LongestChainLaunch &l, const uint32_t *d_sync, bool write_pass, hipStream_t stream) {
+    if (l.n_tiles == 0) return hipSuccess;
+    const dim3 grid((l.n_tiles + kWave - 1) / kWave), block(kWave);
+    if (write_pass) hipLaunchKernelGGL((k_longest_chain_lds<true>), grid, block, 0, stream, l, d_sync);
+    else if (l.d_bits) hipLaunchKernelGGL((k_longest_chain_lds<false, true>), grid, block, 0, stream, l, d_sync);
+    else hipLaunchKernelGGL((k_longest_chain_lds<false>), grid, block, 0, stream, l, d_sync);
+    return hipGetLastError();
 }
 
 hipError_t launch_longest_sync(const LongestChainLaunch &l, uint32_t *d_sync, hipStream_t stream) {
