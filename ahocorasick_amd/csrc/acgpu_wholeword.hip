@@ -54,7 +54,7 @@ static size_t ww_bloom_bytes(const DevTables &t) { return ((size_t)t.ww_bloom_ma
 
 size_t ww_lds_bytes(int block_threads, const DevTables &t) {
     const uint32_t fold_pages = ww_fold_pages_in_lds(t);
-    return 8192 + ww_bloom_bytes(t) + (fold_pages ? 256 + (size_t)t.fold_direct_n * 2 + (size_t)fold_pages * 512 : 0) +
+    return 8192 + ww_bloom_bytes(t) + (fold_pages ? 256 + (size_t)fold_pages * 512 : 0) +
            (size_t)(block_threads / kWave) * kWwCandCap * sizeof(uint32_t);
 }
 
@@ -66,9 +66,7 @@ struct FoldLds {
     const uint32_t *bloom;  // Bloom filter over the keyword hashes (not part of folding; travels with the LDS tables)
     uint32_t bloom_mask;
     const uint8_t *pgidx;   // 256 page numbers
-    const uint16_t *pages;  // pages of 256 deltas
-    const uint16_t *direct; // lower[u] for u < direct_n: the bicameral scripts of the low pages in ONE read
-    uint32_t direct_n;
+    const uint16_t *pages;  // pages of 256 deltas (page 0: all zero)
 };
 
 // FOLD: 0 = case sensitive, 1 = paged delta table in LDS, 2 = the 65536-entry table in global memory
@@ -76,9 +74,12 @@ template <int FOLD>
 __device__ __forceinline__ uint32_t ww_fold(const DevTables &T, const FoldLds &F, uint32_t u) {
     if (FOLD == 0) return u;
     if (FOLD == 1) {
-        if (u < F.direct_n) return F.direct[u];
+        // branch free: page 0 (nothing on the page folds) is stored as 256 zero deltas, so every unit takes the same two
+        // dependent LDS reads and the eight units of a chunk have theirs in flight together.  (A direct table for the low,
+        // cased pages saved one read for those units but made the fold a divergent branch with a wait per unit:
+        // 20 instructions and up to two LDS round trips per unit, one unit after the other.)
         const uint32_t pg = F.pgidx[u >> 8];
-        return pg ? (u + F.pages[pg * 256u + (u & 255u)]) & 0xffffu : u; // page 0: nothing on the page folds
+        return (u + F.pages[pg * 256u + (u & 255u)]) & 0xffffu;
     }
     return T.lower[u];
 }
@@ -95,12 +96,16 @@ __device__ __forceinline__ WwUnits8 ww_window(const uint16_t *hay, uint32_t p, u
 
 // One 8-unit chunk of a run: word bits, run length inside the chunk (0..8; `valid` = units that exist in the buffer),
 // folded units packed two per word and zeroed beyond the run.
+// `look` (wave-uniform, 1..8): only the first `look` units are examined -- a run that is still going after them is longer
+// than every keyword anyway (the second chunk of a run needs max_len + 1 - 8 units, not 8)
 template <int FOLD>
 __device__ __forceinline__ uint32_t ww_chunk(const DevTables &T, const FoldLds &F, const uint32_t *wbits, const WwUnits8 &w,
-                                             uint32_t valid, uint32_t out[4]) {
+                                             uint32_t valid, uint32_t out[4], uint32_t look = 8) {
     uint32_t wm = 0, f[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
+        f[j] = 0;
+        if ((uint32_t)j >= look) continue; // (scalar branch)
         const uint32_t u = (w.d[j >> 1] >> (16 * (j & 1))) & 0xffffu;
         wm |= word_bit(wbits, u) << j;
         f[j] = ww_fold<FOLD>(T, F, u);
@@ -137,19 +142,31 @@ __device__ __forceinline__ void ww_verify_hash(TileCtx &c, const uint32_t *wbits
 #pragma unroll
         for (int k = 0; k < 8; ++k) fw[b][k] = 0;
     }
-    // units 0..15 of every run: the folded units are kept (packed) for the exact comparison
+    // units 0..15 of every run: the folded units are kept (packed) for the exact comparison.  Both 16-byte windows of every
+    // run start are requested up front: one memory round trip per call instead of one per chunk (a third of the runs go on
+    // into the second window, so the wave would wait for it anyway).
+    WwUnits8 win2[2][NB];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            win2[k][b] = WwUnits8{{0, 0, 0, 0}};
+            if (act[b] && s[b] + 8 * k < n) win2[k][b] = ww_window(hay, s[b] + 8 * k, n);
+        }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         WwUnits8 win[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            win[b] = WwUnits8{{0, 0, 0, 0}};
-            if (run[b] && s[b] + 8 * k < n) win[b] = ww_window(hay, s[b] + 8 * k, n);
+            win[b] = win2[k][b];
+            if (!run[b]) win[b] = WwUnits8{{0, 0, 0, 0}};
         }
+        // units 8..: a run of more than max_len units matches nothing, so only max_len + 1 - 8 of them matter
+        const uint32_t look = k == 0 ? 8u : min(8u, T.max_len > 7u ? T.max_len - 7u : 1u);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const uint32_t valid = run[b] ? min(n - min(s[b] + 8 * k, n), 8u) : 0u;
-            const uint32_t rl = ww_chunk<FOLD>(T, F, wbits, win[b], valid, &fw[b][4 * k]);
+            const uint32_t rl = ww_chunk<FOLD>(T, F, wbits, win[b], valid, &fw[b][4 * k], look);
             r[b] += rl;
             run[b] = rl == 8;
         }
@@ -390,7 +407,7 @@ template <int FOLD>
 __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) void k_ww_tile(DevTables T, TileLaunch L) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *wbits = reinterpret_cast<uint32_t *>(smem); // 65536 word-character bits
-    const uint32_t fold_bytes = FOLD == 1 ? 256u + T.fold_direct_n * 2u + T.fold_n_pages * 512u : 0u;
+    const uint32_t fold_bytes = FOLD == 1 ? 256u + T.fold_n_pages * 512u : 0u;
     const uint32_t bloom_bytes = (T.ww_bloom_mask + 1u) / 8u;
     uint32_t *bloom = reinterpret_cast<uint32_t *>(smem + 8192);
     unsigned char *fold_base = smem + 8192 + bloom_bytes;
@@ -401,18 +418,16 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
         for (uint32_t k = 0; k < 32; ++k) bits |= (uint32_t)(T.wflags[w * 32 + k] & 1u) << k;
         wbits[w] = bits;
     }
-    uint16_t *direct = reinterpret_cast<uint16_t *>(fold_base + 256);
-    uint16_t *pages = direct + (FOLD == 1 ? T.fold_direct_n : 0u);
-    FoldLds F{bloom, T.ww_bloom_mask, fold_base, pages, direct, FOLD == 1 ? T.fold_direct_n : 0u};
+    uint16_t *pages = reinterpret_cast<uint16_t *>(fold_base + 256);
+    FoldLds F{bloom, T.ww_bloom_mask, fold_base, pages};
     if (FOLD == 1) {
         for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) fold_base[i] = T.fold_pgidx[i];
-        for (uint32_t i = threadIdx.x; i < T.fold_direct_n; i += blockDim.x) direct[i] = T.lower[i];
         for (uint32_t i = threadIdx.x; i < T.fold_n_pages * 256u; i += blockDim.x) pages[i] = T.fold_pages[i];
     }
     __syncthreads();
 
     const uint32_t lane = lane_id();
-    const uint32_t wave_in_block = threadIdx.x / kWave;
+    const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave); // (scalar bookkeeping: see k_ac_tile)
     const uint32_t wave_global = blockIdx.x * (kTileBlock / kWave) + wave_in_block;
     TileCtx c{&T, &L, cand_all + wave_in_block * kWwCandCap, 0, 0, 0u, 0};
 
@@ -454,7 +469,7 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
 #ifndef ACGPU_NO_SETPRIO
         // the waves of a SIMD take turns at every issue priority (see k_ac_tile: the arbiter's oldest-first order lets the
         // youngest waves finish last)
-        switch ((threadIdx.x / (4u * kWave) + prio_turn++) & 3u) {
+        switch ((wave_in_block / 4u + prio_turn++) & 3u) {
         case 0: __builtin_amdgcn_s_setprio(0); break;
         case 1: __builtin_amdgcn_s_setprio(1); break;
         case 2: __builtin_amdgcn_s_setprio(2); break;
