@@ -306,7 +306,8 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
     uint64_t scanned = 0;
     uint32_t n_chunks = 0, chunk_units = 0, perm_base = (uint32_t)sh->own_begin;
     const uint32_t *id_map = nullptr;
-    bool split = false;
+    bool split = false, fused_finalize = false;
+    uint32_t regions_per_wg = 0;
     if (use_tile_kernel(t)) {
         TileLaunch L{};
         L.block = tile_block_threads();
@@ -340,6 +341,7 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         }
         L.n_slices = n_slices;
         L.slice_slots = (uint32_t)slice_slots;
+        L.wg_sums = 0;
         if ((rc = d.chunk_counts.ensure((size_t)L.n_regions * 4))) return rc;
         if ((rc = d.offsets.ensure((size_t)L.n_regions * 8))) return rc;
         if ((rc = d.scan_tmp.ensure(((size_t)L.n_regions / 2048 + 2) * 8))) return rc;
@@ -374,6 +376,13 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
                 }
             }
         }
+        // one finalize launch instead of three (prefix-sum kernels + permute) when a scratch slice is a workgroup: the scan
+        // kernel leaves every workgroup's record count next to its slot counter and the permute pass (k_permute_wg) derives
+        // its offsets from those and the region counts of its own workgroup.  (tunable tile_debug bit 262144: the old way)
+        fused_finalize = !split && n_slices == (uint32_t)L.grid && L.grid <= kMaxSlices &&
+                         (uint64_t)waves_per_block * L.regions_per_wave <= kPermuteWgRegions && !(L.debug & 262144u);
+        L.wg_sums = fused_finalize ? 1u : 0u;
+        regions_per_wg = (uint32_t)waves_per_block * L.regions_per_wave;
 #ifdef ACGPU_TIMING
         static DevBuf timing;
         if ((rc = timing.ensure((size_t)L.grid * 16 * 8 * 8))) return rc;
@@ -461,17 +470,22 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         chunk_units = L.chunk_units;
         scanned = own_len + (uint64_t)L.n_chunks * halo;
     }
-    HIP_TRY(launch_exclusive_scan((const uint32_t *)d.chunk_counts.p, n_chunks, (uint64_t *)d.offsets.p,
-                                  (uint64_t *)d.scan_tmp.p, stream));
+    if (!fused_finalize)
+        HIP_TRY(launch_exclusive_scan((const uint32_t *)d.chunk_counts.p, n_chunks, (uint64_t *)d.offsets.p,
+                                      (uint64_t *)d.scan_tmp.p, stream));
     // the permute pass reports {record count, overflow word} into the pinned host slot of this call, clears the word and
     // zeroes the other set of slot counters for the next call: no copy or memset operations on the stream
     unsigned long long *h_slot = tk ? tk->h_count : d.h_counter, *d_slot = nullptr;
     HIP_TRY(hipHostGetDevicePointer((void **)&d_slot, h_slot, 0));
     const PermuteTail tail{d_slot, (const uint64_t *)d.scan_tmp.p + scan_tiles_for(n_chunks), overflow_word, counters_next,
                            reinterpret_cast<acgpu_device_result *>(sh->d_result)};
-    HIP_TRY(launch_permute((const ScratchRec *)d.scratch.p, counters, n_slices, slice_slots,
-                           (const uint64_t *)d.offsets.p, perm_base, chunk_units,
-                           /*by_start=*/0, record_kind, d_out, cap, id_map, stream, &tail));
+    if (fused_finalize)
+        HIP_TRY(launch_permute_wg((const ScratchRec *)d.scratch.p, counters, n_slices, slice_slots, (const uint32_t *)d.chunk_counts.p,
+                                  n_chunks, regions_per_wg, perm_base, chunk_units, record_kind, d_out, cap, id_map, stream, &tail));
+    else
+        HIP_TRY(launch_permute((const ScratchRec *)d.scratch.p, counters, n_slices, slice_slots,
+                               (const uint64_t *)d.offsets.p, perm_base, chunk_units,
+                               /*by_start=*/0, record_kind, d_out, cap, id_map, stream, &tail));
     d.cclean[1 - cs] = true; // zeroed by the pass just launched
     d.cset = 1 - cs;
     if (timed) HIP_TRY(hipEventRecord(ev[2], stream));

@@ -47,6 +47,8 @@ struct TileLaunch {
     // and thousands of atomics on ONE address are served at under 100 per microsecond.  A slice that fills up sets bit 1
     // of *d_overflow; the host then redoes the call with one slice.  n_slices = 1: the whole scratch, one counter.
     uint32_t n_slices, slice_slots;
+    uint32_t wg_sums; // 1: every workgroup also adds its record count to d_counter[blockIdx.x * kCounterStride + 1] (the fused
+                      // permute pass needs n_slices == grid: slice == workgroup)
     uint32_t *d_region_counts;
     int grid, block;
     size_t lds_bytes;
@@ -105,6 +107,16 @@ hipError_t launch_permute(const ScratchRec *d_scratch, const unsigned long long 
                           int record_kind, void *d_out, uint64_t out_cap, const uint32_t *d_id_map, hipStream_t stream,
                           const PermuteTail *tail = nullptr);
 uint32_t scan_tiles_for(uint32_t n); // number of prefix-sum tiles; the grand total is d_tmp[scan_tiles_for(n)]
+
+// Fused finalize of the tile kernel (one launch instead of prefix-sum kernels + permute): slice y of the scratch holds the
+// records of workgroup y, whose regions are [y * regions_per_wg, ...); the block derives its offsets from the workgroup sums
+// the scan kernel left next to the slot counters (d_counter[w * kCounterStride + 1]) and the region counts of its own
+// workgroup.  Needs n_slices == number of workgroups and regions_per_wg <= kPermuteWgRegions.
+constexpr uint32_t kPermuteWgRegions = 1024;
+hipError_t launch_permute_wg(const ScratchRec *d_scratch, const unsigned long long *d_counter, uint32_t n_wg, uint64_t slice_slots,
+                             const uint32_t *d_region_counts, uint32_t n_regions, uint32_t regions_per_wg, uint32_t own_begin,
+                             uint32_t chunk_units, int record_kind, void *d_out, uint64_t out_cap, const uint32_t *d_id_map,
+                             hipStream_t stream, const PermuteTail *tail);
 uint32_t tile_reserve_slots();
 uint32_t tile_group_units(); // regions must hold whole tile groups
 

@@ -334,7 +334,10 @@ __global__ __launch_bounds__(256) void k_permute(const ScratchRec *scratch, cons
                                                 const uint32_t *id_map, PermuteTail tail) {
     if (blockIdx.x == 0 && blockIdx.y == 0) { // (see PermuteTail)
         if (tail.zero_counters)
-            for (uint32_t i = threadIdx.x; i < (uint32_t)kMaxSlices; i += blockDim.x) tail.zero_counters[(size_t)i * kCounterStride] = 0;
+            for (uint32_t i = threadIdx.x; i < (uint32_t)kMaxSlices; i += blockDim.x) {
+                tail.zero_counters[(size_t)i * kCounterStride] = 0;
+                tail.zero_counters[(size_t)i * kCounterStride + 1] = 0; // (the workgroup sums of the fused finalize)
+            }
         if (tail.result && threadIdx.x == 0) {
             const unsigned long long total = *tail.total;
             const uint32_t flag = tail.flag ? *tail.flag : 0u;
@@ -393,6 +396,127 @@ hipError_t launch_permute(const ScratchRec *d_scratch, const unsigned long long 
     else
         hipLaunchKernelGGL(k_permute<ACGPU_REC_MAP>, grid, dim3(256), 0, stream, d_scratch, d_counter, slice_slots,
                            d_offsets, own_begin, chunk_units, by_start, d_out, out_cap, d_id_map, tl);
+    return hipGetLastError();
+}
+
+// ---- fused finalize of the tile kernel: offsets + permutation in one launch -------------------------------------------------
+template <int REC>
+__global__ __launch_bounds__(256) void k_permute_wg(const ScratchRec *scratch, const unsigned long long *counter, uint32_t n_wg,
+                                                   uint64_t slice_slots, const uint32_t *region_counts, uint32_t n_regions,
+                                                   uint32_t regions_per_wg, uint32_t own_begin, uint32_t chunk_units, void *out,
+                                                   uint64_t cap, const uint32_t *id_map, PermuteTail tail) {
+    __shared__ uint64_t red[256];
+    __shared__ uint32_t local[kPermuteWgRegions]; // exclusive offsets of this workgroup's regions
+    __shared__ uint64_t base_s;
+    const uint32_t wg = blockIdx.y;
+    // base = records of the workgroups before this one; block (0,0) also needs the grand total
+    const bool first = blockIdx.x == 0 && blockIdx.y == 0;
+    uint64_t below = 0, all = 0;
+    for (uint32_t w = threadIdx.x; w < n_wg; w += blockDim.x) {
+        const uint64_t v = counter[(size_t)w * kCounterStride + 1];
+        if (w < wg) below += v;
+        all += v;
+    }
+    red[threadIdx.x] = below;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) base_s = red[0];
+    __syncthreads();
+    uint64_t total = 0;
+    if (first) { // (only this block pays for the second reduction)
+        red[threadIdx.x] = all;
+        __syncthreads();
+        for (int d = 128; d >= 1; d >>= 1) {
+            if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
+            __syncthreads();
+        }
+        total = red[0];
+        __syncthreads();
+    }
+    // exclusive prefix sum of the workgroup's region counts (at most kPermuteWgRegions: 4 per thread)
+    const uint32_t r0 = wg * regions_per_wg;
+    {
+        uint32_t c[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = threadIdx.x * 4 + k;
+            c[k] = (i < regions_per_wg && r0 + i < n_regions) ? region_counts[r0 + i] : 0u;
+            sum += c[k];
+        }
+        red[threadIdx.x] = sum;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) { // inclusive scan over the 256 partial sums
+            const uint64_t v = (int)threadIdx.x >= d ? red[threadIdx.x - d] : 0;
+            __syncthreads();
+            red[threadIdx.x] += v;
+            __syncthreads();
+        }
+        uint32_t ex = (uint32_t)(red[threadIdx.x] - sum);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = threadIdx.x * 4 + k;
+            if (i < kPermuteWgRegions) local[i] = ex;
+            ex += c[k];
+        }
+        __syncthreads();
+    }
+    if (first) { // (see PermuteTail)
+        if (tail.zero_counters)
+            for (uint32_t i = threadIdx.x; i < (uint32_t)kMaxSlices; i += blockDim.x) {
+                tail.zero_counters[(size_t)i * kCounterStride] = 0;
+                tail.zero_counters[(size_t)i * kCounterStride + 1] = 0;
+            }
+        if (tail.result && threadIdx.x == 0) {
+            const uint32_t flag = tail.flag ? *tail.flag : 0u;
+            tail.result[0] = total;
+            tail.result[1] = flag;
+            if (tail.d_result) {
+                tail.d_result->n_records = total;
+                tail.d_result->redone = flag;
+                tail.d_result->reserved = 0;
+            }
+            if (tail.flag) *tail.flag = 0;
+            __threadfence_system();
+        }
+    }
+    const uint64_t base = base_s;
+    unsigned long long m = counter[(size_t)wg * kCounterStride];
+    if (m > slice_slots) m = slice_slots; // overflow: the host redoes the call / reports ACGPU_E_OVERFLOW
+    scratch += (size_t)wg * slice_slots;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint4 raw = *reinterpret_cast<const uint4 *>(&scratch[i]);
+        const int32_t start = (int32_t)raw.x, end = (int32_t)raw.y, id = (int32_t)raw.z;
+        const uint32_t rank = raw.w;
+        if (rank == ~0u) continue; // hole left by a slot reservation
+        const uint32_t chunk = ((uint32_t)(end - 1) - own_begin) / chunk_units; // the region owning the match's last unit
+        const uint64_t dst = base + local[chunk - r0] + rank;
+        if (dst >= cap) continue;
+        if (REC == ACGPU_REC_SET) {
+            reinterpret_cast<int2 *>(out)[dst] = make_int2(start, end);
+        } else {
+            int32_t *o = reinterpret_cast<int32_t *>(out) + dst * 3;
+            o[0] = start;
+            o[1] = end;
+            o[2] = id_map ? (int32_t)id_map[id] : id;
+        }
+    }
+}
+
+hipError_t launch_permute_wg(const ScratchRec *d_scratch, const unsigned long long *d_counter, uint32_t n_wg, uint64_t slice_slots,
+                             const uint32_t *d_region_counts, uint32_t n_regions, uint32_t regions_per_wg, uint32_t own_begin,
+                             uint32_t chunk_units, int record_kind, void *d_out, uint64_t out_cap, const uint32_t *d_id_map,
+                             hipStream_t stream, const PermuteTail *tail) {
+    const PermuteTail tl = tail ? *tail : PermuteTail{nullptr, nullptr, nullptr, nullptr, nullptr};
+    const dim3 grid(std::max<uint32_t>(kPermuteBlocks / std::max<uint32_t>(n_wg, 1u), 8u), n_wg);
+    if (record_kind == ACGPU_REC_SET)
+        hipLaunchKernelGGL(k_permute_wg<ACGPU_REC_SET>, grid, dim3(256), 0, stream, d_scratch, d_counter, n_wg, slice_slots,
+                           d_region_counts, n_regions, regions_per_wg, own_begin, chunk_units, d_out, out_cap, d_id_map, tl);
+    else
+        hipLaunchKernelGGL(k_permute_wg<ACGPU_REC_MAP>, grid, dim3(256), 0, stream, d_scratch, d_counter, n_wg, slice_slots,
+                           d_region_counts, n_regions, regions_per_wg, own_begin, chunk_units, d_out, out_cap, d_id_map, tl);
     return hipGetLastError();
 }
 

@@ -442,6 +442,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
     const uint32_t last_vec = nfull >= 8 ? nfull - 8 : 0;
     const uint16_t *hay = L.d_hay;
 
+    uint32_t wave_total = 0; // wave-uniform: records of the regions this wave has finished
     uint32_t region = first_region;
     uint32_t boundary = base8 + (region + 1) * R; // first tile of the next region
     uint32_t rb = span_begin;
@@ -533,6 +534,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                     } else if (lane == 0) {
                         L.d_region_counts[region] = c.rank_base;
                     }
+                    wave_total += c.rank_base;
                     c.rank_base = 0;
                     ++region;
                     rb = boundary;
@@ -817,6 +819,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                 } else if (lane == 0) {
                     L.d_region_counts[region] = c.rank_base;
                 }
+                wave_total += c.rank_base;
                 c.rank_base = 0;
                 ++region;
                 c.pos_base = boundary;
@@ -864,6 +867,10 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
     }
 #endif
     if (lane == 0) L.d_region_counts[region] = c.rank_base;
+    // the workgroup's record count, next to its slot counter: the fused permute pass (k_permute_wg) turns the per-workgroup
+    // sums and the region counts into offsets itself, so no prefix-sum kernels run between the scan and the permutation
+    wave_total += c.rank_base;
+    if (lane == 0 && L.wg_sums && wave_total) atomicAdd(L.d_counter + (size_t)blockIdx.x * kCounterStride + 1, (unsigned long long)wave_total);
     // hand back the unused tail of the last reservation as holes the permute pass skips
     for (uint32_t i = lane; i < c.res_left; i += kWave)
         if (c.res_cur + i < c.slot_limit) store_rec(L, c.res_cur + i, 0, 0, 0, ~0u);
