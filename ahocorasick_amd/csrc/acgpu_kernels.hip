@@ -400,69 +400,63 @@ hipError_t launch_permute(const ScratchRec *d_scratch, const unsigned long long 
 }
 
 // ---- fused finalize of the tile kernel: offsets + permutation in one launch -------------------------------------------------
+// wave64 inclusive prefix sum (DPP row shifts + row broadcasts), as in the tile kernels
+__device__ __forceinline__ uint32_t pw_wave_scan(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
+    return x;
+}
+
 template <int REC>
 __global__ __launch_bounds__(256) void k_permute_wg(const ScratchRec *scratch, const unsigned long long *counter, uint32_t n_wg,
                                                    uint64_t slice_slots, const uint32_t *region_counts, uint32_t n_regions,
                                                    uint32_t regions_per_wg, uint32_t own_begin, uint32_t chunk_units, void *out,
                                                    uint64_t cap, const uint32_t *id_map, PermuteTail tail) {
-    __shared__ uint64_t red[256];
     __shared__ uint32_t local[kPermuteWgRegions]; // exclusive offsets of this workgroup's regions
-    __shared__ uint64_t base_s;
+    __shared__ uint32_t part[3][4];               // per wave: records below this workgroup, all records, region counts
     const uint32_t wg = blockIdx.y;
-    // base = records of the workgroups before this one; block (0,0) also needs the grand total
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const bool first = blockIdx.x == 0 && blockIdx.y == 0;
-    uint64_t below = 0, all = 0;
+    // (record counts fit 32 bits: the scratch holds fewer than 2^32 records)
+    uint32_t below = 0, all = 0;
     for (uint32_t w = threadIdx.x; w < n_wg; w += blockDim.x) {
-        const uint64_t v = counter[(size_t)w * kCounterStride + 1];
+        const uint32_t v = (uint32_t)counter[(size_t)w * kCounterStride + 1];
         if (w < wg) below += v;
         all += v;
     }
-    red[threadIdx.x] = below;
-    __syncthreads();
-    for (int d = 128; d >= 1; d >>= 1) {
-        if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) base_s = red[0];
-    __syncthreads();
-    uint64_t total = 0;
-    if (first) { // (only this block pays for the second reduction)
-        red[threadIdx.x] = all;
-        __syncthreads();
-        for (int d = 128; d >= 1; d >>= 1) {
-            if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
-            __syncthreads();
-        }
-        total = red[0];
-        __syncthreads();
-    }
-    // exclusive prefix sum of the workgroup's region counts (at most kPermuteWgRegions: 4 per thread)
+    // the workgroup's region counts: 4 consecutive ones per thread, wave prefix sums, the waves' totals through LDS
     const uint32_t r0 = wg * regions_per_wg;
-    {
-        uint32_t c[4], sum = 0;
+    uint32_t c[4], sum = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t i = threadIdx.x * 4 + k;
-            c[k] = (i < regions_per_wg && r0 + i < n_regions) ? region_counts[r0 + i] : 0u;
-            sum += c[k];
-        }
-        red[threadIdx.x] = sum;
-        __syncthreads();
-        for (int d = 1; d < 256; d <<= 1) { // inclusive scan over the 256 partial sums
-            const uint64_t v = (int)threadIdx.x >= d ? red[threadIdx.x - d] : 0;
-            __syncthreads();
-            red[threadIdx.x] += v;
-            __syncthreads();
-        }
-        uint32_t ex = (uint32_t)(red[threadIdx.x] - sum);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t i = threadIdx.x * 4 + k;
-            if (i < kPermuteWgRegions) local[i] = ex;
-            ex += c[k];
-        }
-        __syncthreads();
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t i = threadIdx.x * 4 + k;
+        c[k] = (i < regions_per_wg && r0 + i < n_regions) ? region_counts[r0 + i] : 0u;
+        sum += c[k];
     }
+    const uint32_t incl = pw_wave_scan(sum);
+    below = pw_wave_scan(below);
+    all = pw_wave_scan(all);
+    if (lane == 63) {
+        part[0][wave] = below;
+        part[1][wave] = all;
+        part[2][wave] = incl;
+    }
+    __syncthreads();
+    const uint32_t base32 = part[0][0] + part[0][1] + part[0][2] + part[0][3];
+    const uint32_t total = part[1][0] + part[1][1] + part[1][2] + part[1][3];
+    uint32_t ex = incl - sum;
+    for (uint32_t w = 0; w < wave; ++w) ex += part[2][w];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t i = threadIdx.x * 4 + k;
+        if (i < kPermuteWgRegions) local[i] = ex;
+        ex += c[k];
+    }
+    __syncthreads();
     if (first) { // (see PermuteTail)
         if (tail.zero_counters)
             for (uint32_t i = threadIdx.x; i < (uint32_t)kMaxSlices; i += blockDim.x) {
@@ -482,7 +476,7 @@ __global__ __launch_bounds__(256) void k_permute_wg(const ScratchRec *scratch, c
             __threadfence_system();
         }
     }
-    const uint64_t base = base_s;
+    const uint64_t base = base32;
     unsigned long long m = counter[(size_t)wg * kCounterStride];
     if (m > slice_slots) m = slice_slots; // overflow: the host redoes the call / reports ACGPU_E_OVERFLOW
     scratch += (size_t)wg * slice_slots;
