@@ -77,7 +77,7 @@ struct DeviceState {
     DevBuf blockmax;                                     // LONGEST: farthest landing per 64 positions
     DevBuf chainbits;                                    // LONGEST: one bit per position, set where the chain reports a match
     DevBuf cands, region_cands;                          // ALL, split form: candidate positions, {first, count} per region
-    DevBuf wwl_rs, wwl_mend, wwl_mid, wwl_sel;          // WWLONGEST: walk starts and what each would report
+    DevBuf wwl_rs, wwl_mend, wwl_mid, wwl_sel, wwl_stop, wwl_nxt0; // WWLONGEST: walk starts, what each would report, where it stops
     unsigned long long *h_counter = nullptr; // pinned
     // match_all: two sets of slot counters alternate; the permute pass of a call zeroes the set the next call uses
     int cset = 0;
@@ -93,7 +93,7 @@ struct DeviceState {
         counter.release(); chunk_counts.release(); offsets.release(); scan_tmp.release(); scratch.release();
         chain.release(); lenbuf.release(); statebuf.release(); stage_hay.release(); stage_out.release();
         short_recs.release(); short_nxt.release(); short_tmp.release(); short_mark.release();
-        wwl_rs.release(); wwl_mend.release(); wwl_mid.release(); wwl_sel.release(); blockmax.release(); chainbits.release(); cands.release(); region_cands.release();
+        wwl_rs.release(); wwl_mend.release(); wwl_mid.release(); wwl_sel.release(); wwl_stop.release(); wwl_nxt0.release(); blockmax.release(); chainbits.release(); cands.release(); region_cands.release();
         if (h_counter) (void)hipHostFree(h_counter);
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         for (auto &tk : tickets) {
@@ -878,43 +878,82 @@ int match_shortest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int reco
     return *n_out > cap ? ACGPU_E_OVERFLOW : ACGPU_OK;
 }
 
-// WWLONGEST-mode pipeline: the whole haystack is one shard.
+// WWLONGEST-mode pipeline on one shard.  A walk belongs to the shard that owns its first unit; the scan visits the first walk
+// start at or after chain_entry and leaves chain_exit = the position behind the stop of its last visited walk.
 int match_wwlongest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_kind, void *d_out, uint64_t cap,
                     uint64_t *n_out, hipStream_t stream, acgpu_profile *prof) {
     const HostTables &t = a->t;
     if (prof) std::memset(prof, 0, sizeof(*prof));
-    if (!t.fold_consistent) return ACGPU_E_UNSUPPORTED;
-    if (!sh->text_begin || !sh->text_end || sh->own_begin != 0 || sh->own_end != sh->n_units) return ACGPU_E_UNSUPPORTED;
     *n_out = 0;
     const uint32_t n = (uint32_t)sh->n_units;
-    if (n == 0 || t.n_states <= 1) return ACGPU_OK;
+    const uint64_t entry = (uint64_t)std::max<int64_t>(sh->chain_entry, (int64_t)sh->own_begin);
+    sh->chain_exit = (int64_t)entry;
     int rc;
+    if (!t.fold_consistent) {
+        // the reference's mixed folded/raw lookups make token boundaries history dependent: whole text, one lane
+        if (!sh->text_begin || !sh->text_end || sh->own_begin != 0 || sh->own_end != sh->n_units) return ACGPU_E_UNSUPPORTED;
+        if (n == 0 || t.n_states <= 1) return ACGPU_OK;
+        if ((rc = d.counter.ensure(64))) return rc;
+        d.cclean[0] = false; // (match_all's first set of slot counters lives here)
+        if (prof) HIP_TRY(hipEventRecord(d.ev[0], stream));
+        HIP_TRY(launch_wwl_sequential(d.T, sh->d_hay, n, d_out, cap, record_kind, (unsigned long long *)d.counter.p, stream));
+        if (prof) HIP_TRY(hipEventRecord(d.ev[1], stream));
+        HIP_TRY(hipMemcpyAsync(d.h_counter, d.counter.p, 8, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        *n_out = *d.h_counter;
+        sh->chain_exit = (int64_t)n;
+        if (prof) {
+            HIP_TRY(hipEventElapsedTime(&prof->scan_ms, d.ev[0], d.ev[1]));
+            prof->total_ms = prof->scan_ms;
+            prof->scan_units = n;
+            prof->n_matches = *n_out;
+            std::snprintf(prof->scan_kernel, sizeof(prof->scan_kernel), "k_wwl_sequential");
+        }
+        return *n_out > cap ? ACGPU_E_OVERFLOW : ACGPU_OK;
+    }
+    if (!sh->text_begin && sh->own_begin < 1) return ACGPU_E_INVALID;                              // left context: 1 unit
+    if (!sh->text_end && sh->n_units - sh->own_end < (uint64_t)t.max_len + 1) return ACGPU_E_INVALID; // right halo
+    if (n == 0 || t.n_states <= 1 || sh->own_end == sh->own_begin || entry >= sh->own_end) return ACGPU_OK;
     const uint32_t n_tiles = wwl_tiles(n);
     if ((rc = d.chunk_counts.ensure((size_t)n_tiles * 4))) return rc;
     if ((rc = d.offsets.ensure((size_t)n_tiles * 8))) return rc;
     if ((rc = d.scan_tmp.ensure(((size_t)n_tiles / 2048 + 2) * 8))) return rc;
+    if ((rc = d.counter.ensure(64))) return rc;
+    d.cclean[0] = false; // (match_all's first set of slot counters lives here)
     if (prof) HIP_TRY(hipEventRecord(d.ev[0], stream));
-    HIP_TRY(launch_wwl_starts(d.T, sh->d_hay, n, d.n_cu, false, (uint32_t *)d.chunk_counts.p, nullptr, nullptr, stream));
+    HIP_TRY(launch_wwl_starts(d.T, sh->d_hay, n, d.n_cu, false, (uint32_t *)d.chunk_counts.p, nullptr, nullptr, sh->text_begin, stream));
     HIP_TRY(launch_exclusive_scan((const uint32_t *)d.chunk_counts.p, n_tiles, (uint64_t *)d.offsets.p, (uint64_t *)d.scan_tmp.p,
                                   stream));
     HIP_TRY(hipMemcpyAsync(d.h_counter, (const uint64_t *)d.scan_tmp.p + scan_tiles_for(n_tiles), 8, hipMemcpyDeviceToHost,
                            stream));
     HIP_TRY(hipStreamSynchronize(stream));
-    const uint32_t M = (uint32_t)*d.h_counter; // walk starts (>= 1: position 0)
+    const uint32_t M = (uint32_t)*d.h_counter; // walk starts of the buffer (halos included)
+    if (M == 0) return ACGPU_OK;
     if ((rc = d.wwl_rs.ensure(((size_t)M + 1) * 4))) return rc;
     if ((rc = d.wwl_mend.ensure(((size_t)M + 1) * 4))) return rc;
     if ((rc = d.wwl_mid.ensure(((size_t)M + 1) * 4))) return rc;
     if ((rc = d.wwl_sel.ensure(((size_t)M + 1) * 4))) return rc;
+    if ((rc = d.wwl_stop.ensure(((size_t)M + 1) * 4))) return rc;
     if ((rc = d.short_nxt.ensure(((size_t)M + 1) * 4))) return rc;
     if ((rc = d.short_tmp.ensure(((size_t)M + 1) * 4))) return rc;
     if ((rc = d.short_mark.ensure(((size_t)M + 1) * 4))) return rc;
+    { // the exit position, preset to the entry (no visited walk start: nothing changes hands)
+        d.h_counter[2] = entry;
+        HIP_TRY(hipMemcpyAsync(d.counter.p, d.h_counter + 2, 8, hipMemcpyHostToDevice, stream));
+    }
     HIP_TRY(launch_wwl_starts(d.T, sh->d_hay, n, d.n_cu, true, nullptr, (const uint64_t *)d.offsets.p, (uint32_t *)d.wwl_rs.p,
-                              stream));
+                              sh->text_begin, stream));
     HIP_TRY(launch_wwl_walk(d.T, sh->d_hay, n, (const uint32_t *)d.wwl_rs.p, M, (uint32_t *)d.short_nxt.p,
-                            (uint32_t *)d.short_mark.p, (int32_t *)d.wwl_mend.p, (int32_t *)d.wwl_mid.p, stream));
+                            (uint32_t *)d.short_mark.p, (int32_t *)d.wwl_mend.p, (int32_t *)d.wwl_mid.p, (uint32_t *)d.wwl_stop.p,
+                            (uint32_t)entry, stream));
     if (prof) HIP_TRY(hipEventRecord(d.ev[1], stream));
+    // (the pointer doubling squares the jump table: the walk kernel's NXT is copied first, the select pass needs it)
+    if ((rc = d.wwl_nxt0.ensure(((size_t)M + 1) * 4))) return rc;
+    HIP_TRY(hipMemcpyAsync(d.wwl_nxt0.p, d.short_nxt.p, ((size_t)M + 1) * 4, hipMemcpyDeviceToDevice, stream));
     HIP_TRY(launch_chain_mark((uint32_t *)d.short_nxt.p, (uint32_t *)d.short_tmp.p, (uint32_t *)d.short_mark.p, M, stream));
-    HIP_TRY(launch_wwl_select((const uint32_t *)d.short_mark.p, (const int32_t *)d.wwl_mend.p, (uint32_t *)d.wwl_sel.p, M, stream));
+    HIP_TRY(launch_wwl_select((const uint32_t *)d.short_mark.p, (const int32_t *)d.wwl_mend.p, (const uint32_t *)d.wwl_rs.p,
+                              (const uint32_t *)d.wwl_nxt0.p, (const uint32_t *)d.wwl_stop.p, (uint32_t *)d.wwl_sel.p, M,
+                              (uint32_t)sh->own_begin, (uint32_t)sh->own_end, (unsigned long long *)d.counter.p, stream));
     if ((rc = d.offsets.ensure((size_t)M * 8))) return rc; // (the tile offsets are no longer needed)
     if ((rc = d.scan_tmp.ensure(((size_t)M / 2048 + 2) * 8))) return rc;
     HIP_TRY(launch_exclusive_scan((const uint32_t *)d.wwl_sel.p, M, (uint64_t *)d.offsets.p, (uint64_t *)d.scan_tmp.p, stream));
@@ -922,8 +961,10 @@ int match_wwlongest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int rec
                             (const int32_t *)d.wwl_mid.p, (const uint64_t *)d.offsets.p, M, record_kind, d_out, cap, stream));
     if (prof) HIP_TRY(hipEventRecord(d.ev[2], stream));
     HIP_TRY(hipMemcpyAsync(d.h_counter, (const uint64_t *)d.scan_tmp.p + scan_tiles_for(M), 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(d.h_counter + 1, d.counter.p, 8, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     *n_out = *d.h_counter;
+    sh->chain_exit = (int64_t)d.h_counter[1];
     if (prof) {
         HIP_TRY(hipEventElapsedTime(&prof->scan_ms, d.ev[0], d.ev[1]));
         HIP_TRY(hipEventElapsedTime(&prof->finalize_ms, d.ev[1], d.ev[2]));
@@ -1102,8 +1143,9 @@ struct acgpu_stream {
 int acgpu_stream_open(const acgpu_automaton *a, acgpu_stream **out) {
     if (!a || !out) return ACGPU_E_INVALID;
     *out = nullptr;
-    if (a->t.mode == ACGPU_MODE_WHOLEWORD && !a->t.fold_consistent) return ACGPU_E_UNSUPPORTED;
-    if (a->t.mode == ACGPU_MODE_WWLONGEST) return ACGPU_E_UNSUPPORTED; // the scan position depends on every earlier walk
+    // (word-character tables that are not fold-consistent: the reference's Readable loops fold in their skip loops where its
+    // String loops do not, S/WholeWordMatchMap.java:328, S/WholeWordLongestMatchMap.java:404 -- no chunked form here)
+    if ((a->t.mode == ACGPU_MODE_WHOLEWORD || a->t.mode == ACGPU_MODE_WWLONGEST) && !a->t.fold_consistent) return ACGPU_E_UNSUPPORTED;
     acgpu_stream *s = new (std::nothrow) acgpu_stream();
     if (!s) return ACGPU_E_NOMEM;
     s->a = const_cast<acgpu_automaton *>(a);
@@ -1128,8 +1170,8 @@ int acgpu_stream_feed(acgpu_stream *s, const uint16_t *units, uint64_t n_units, 
     if (t.mode == ACGPU_MODE_ALL || t.mode == ACGPU_MODE_SHORTEST) {
         const uint64_t halo = t.max_len > 0 ? t.max_len - 1 : 0;
         keep_from = total > halo ? total - halo : 0;
-    } else if (t.mode == ACGPU_MODE_WHOLEWORD) {
-        const uint64_t hold = (uint64_t)t.max_len + 1; // a word that starts here may still grow
+    } else if (t.mode == ACGPU_MODE_WHOLEWORD || t.mode == ACGPU_MODE_WWLONGEST) {
+        const uint64_t hold = (uint64_t)t.max_len + 1; // a word / walk that starts here may still grow
         if (!final) own_end = std::max<uint64_t>(own_begin, total > hold ? total - hold : 0);
         keep_from = own_end > 0 ? own_end - 1 : 0; // one unit of left context
     } else {
@@ -1165,7 +1207,7 @@ int acgpu_stream_feed(acgpu_stream *s, const uint16_t *units, uint64_t n_units, 
         rc = match_shard(a, *d, &sh, record_kind, d->stage_out.p, cap, n_out, nullptr, nullptr);
         if (rc != ACGPU_OK) return rc; // ACGPU_E_OVERFLOW: nothing consumed, *n_out = capacity to retry with
         if (*n_out) HIP_TRY(hipMemcpy(out, d->stage_out.p, *n_out * (uint64_t)record_kind, hipMemcpyDeviceToHost));
-        if (t.mode == ACGPU_MODE_LONGEST) chain_exit = s->carry_pos + (uint64_t)sh.chain_exit;
+        if (t.mode == ACGPU_MODE_LONGEST || t.mode == ACGPU_MODE_WWLONGEST) chain_exit = s->carry_pos + (uint64_t)sh.chain_exit;
         // SHORTEST: the last restart; an exit equal to the relative entry means "no match in this feed"
         if (t.mode == ACGPU_MODE_SHORTEST && *n_out) chain_exit = s->carry_pos + (uint64_t)sh.chain_exit;
     }

@@ -195,10 +195,15 @@ hipError_t launch_shortest_emit(const int32_t *d_recs, uint32_t M, const uint32_
 // WholeWordLongest (acgpu_wwlongest.hip)
 uint32_t wwl_tiles(uint32_t n_units);
 hipError_t launch_wwl_starts(const DevTables &t, const uint16_t *d_hay, uint32_t n, int n_cu, bool fill, uint32_t *d_counts,
-                             const uint64_t *d_offsets, uint32_t *d_rs, hipStream_t stream);
+                             const uint64_t *d_offsets, uint32_t *d_rs, int text_begin, hipStream_t stream);
 hipError_t launch_wwl_walk(const DevTables &t, const uint16_t *d_hay, uint32_t n, const uint32_t *d_rs, uint32_t M,
-                           uint32_t *d_nxt, uint32_t *d_mark, int32_t *d_mend, int32_t *d_mid, hipStream_t stream);
-hipError_t launch_wwl_select(const uint32_t *d_mark, const int32_t *d_mend, uint32_t *d_sel, uint32_t M, hipStream_t stream);
+                           uint32_t *d_nxt, uint32_t *d_mark, int32_t *d_mend, int32_t *d_mid, uint32_t *d_stop, uint32_t entry,
+                           hipStream_t stream);
+hipError_t launch_wwl_select(const uint32_t *d_mark, const int32_t *d_mend, const uint32_t *d_rs, const uint32_t *d_nxt,
+                             const uint32_t *d_stop, uint32_t *d_sel, uint32_t M, uint32_t own_begin, uint32_t own_end,
+                             unsigned long long *d_exit, hipStream_t stream);
+hipError_t launch_wwl_sequential(const DevTables &t, const uint16_t *d_hay, uint32_t len, void *d_out, uint64_t cap,
+                                 int record_kind, unsigned long long *d_counter, hipStream_t stream);
 hipError_t launch_wwl_emit(const uint32_t *d_rs, const uint32_t *d_sel, const int32_t *d_mend, const int32_t *d_mid,
                            const uint64_t *d_offsets, uint32_t M, int record_kind, void *d_out, uint64_t cap, hipStream_t stream);
 

@@ -13,8 +13,12 @@
 //   chain        : the walk starts the scan really visits are 0, NXT[0], NXT[NXT[0]], ...: marked by pointer doubling
 //                  (launch_chain_mark, shared with acgpu_shortest.hip); the marked starts that report something are
 //                  prefix-summed and scattered in order.
-// Fold-consistent word-character tables only (every case-sensitive use and the default table); the whole haystack is
-// one shard.
+// Shards: a walk belongs to the shard that owns its first unit (left context 1 unit, right halo max_keyword_len + 1
+// units); which walk starts the scan visits depends on where the previous shard's last walk stopped, handed on as
+// chain_entry / chain_exit (the scan visits the first walk start at or after that position) -- the same hop as the Longest
+// chain.  Word-character tables that are not fold-consistent (custom tables in case-insensitive mode: the reference
+// mixes folded and raw lookups, S/WholeWordLongestMatchSet.java:127-157) take k_wwl_sequential, a literal single-lane
+// restatement of the reference loop over the whole haystack.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -36,7 +40,7 @@ __device__ __forceinline__ uint32_t wbit(const uint32_t *wbits, uint32_t unit) {
 // FILL == false: counts[tile] = walk starts in the tile.  FILL == true: RS[offsets[tile] + rank] = position.
 template <bool FILL>
 __global__ __launch_bounds__(kStartsBlock) void k_wwl_starts(DevTables T, const uint16_t *hay, uint32_t n, uint32_t n_tiles,
-                                                            uint32_t *counts, const uint64_t *offsets, uint32_t *rs) {
+                                                            uint32_t *counts, const uint64_t *offsets, uint32_t *rs, int text_begin) {
     __shared__ uint32_t wbits[2048];
     __shared__ uint32_t wave_tot[kStartsBlock / kWave];
     for (uint32_t w = threadIdx.x; w < 2048; w += blockDim.x) {
@@ -59,7 +63,7 @@ __global__ __launch_bounds__(kStartsBlock) void k_wwl_starts(DevTables T, const 
         }
         const uint32_t prev = (v > 0 && v <= n) ? wbit(wbits, hay[v - 1]) : 0u;
         uint32_t sm = wm & ~((wm << 1) | prev) & 0xffu;
-        if (v == 0 && n > 0) sm |= 1u; // the scan starts at position 0 whatever stands there
+        if (v == 0 && n > 0 && text_begin) sm |= 1u; // the scan starts at position 0 of the TEXT whatever stands there
         const uint32_t cnt = __popc(sm);
         const uint32_t incl = wave_inclusive_scan(cnt);
         if (lane == kWave - 1) wave_tot[wave] = incl;
@@ -84,7 +88,8 @@ __global__ __launch_bounds__(kStartsBlock) void k_wwl_starts(DevTables T, const 
 }
 
 __global__ __launch_bounds__(256) void k_wwl_walk(DevTables T, const uint16_t *hay, uint32_t n, const uint32_t *rs, uint32_t M,
-                                                  uint32_t *nxt, uint32_t *mark, int32_t *mend, int32_t *mid) {
+                                                  uint32_t *nxt, uint32_t *mark, int32_t *mend, int32_t *mid, uint32_t *stop,
+                                                  uint32_t entry) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k > M) return;
     if (k == M) {
@@ -92,8 +97,9 @@ __global__ __launch_bounds__(256) void k_wwl_walk(DevTables T, const uint16_t *h
         mark[M] = 0;
         return;
     }
-    mark[k] = k == 0 ? 1u : 0u; // the scan starts at the first walk start
     const uint32_t ws = rs[k];
+    // the scan of this shard starts at the first walk start at or after the entry position
+    mark[k] = (ws >= entry && (k == 0 || rs[k - 1] < entry)) ? 1u : 0u;
     uint32_t node = 0, i = ws, stop_unit = 0;
     while (i < n) {
         const uint32_t u = hay[i];
@@ -118,6 +124,7 @@ __global__ __launch_bounds__(256) void k_wwl_walk(DevTables T, const uint16_t *h
     }
     mend[k] = end;
     mid[k] = id;
+    stop[k] = i;
     // the scan resumes at the first walk start after the stop position
     uint32_t lo = k + 1, hi = M;
     while (lo < hi) {
@@ -128,9 +135,69 @@ __global__ __launch_bounds__(256) void k_wwl_walk(DevTables T, const uint16_t *h
     nxt[k] = lo;
 }
 
-__global__ __launch_bounds__(256) void k_wwl_select(const uint32_t *mark, const int32_t *mend, uint32_t *sel, uint32_t M) {
+// visited walk starts that report something and lie in the owned range; the LAST visited start of the owned range leaves
+// the position behind its stop as the shard's chain exit (d_exit is preset to the entry: no visited start, no change)
+__global__ __launch_bounds__(256) void k_wwl_select(const uint32_t *mark, const int32_t *mend, const uint32_t *rs, const uint32_t *nxt,
+                                                    const uint32_t *stop, uint32_t *sel, uint32_t M, uint32_t own_begin,
+                                                    uint32_t own_end, unsigned long long *d_exit) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < M) sel[k] = (mark[k] && mend[k] != 0) ? 1u : 0u;
+    if (k >= M) return;
+    const bool mine = mark[k] && rs[k] >= own_begin && rs[k] < own_end;
+    sel[k] = (mine && mend[k] != 0) ? 1u : 0u;
+    if (mine) {
+        const uint32_t nk = nxt[k];
+        if (nk >= M || rs[nk] >= own_end) *d_exit = (unsigned long long)stop[k] + 1ull;
+    }
+}
+
+// Literal restatement of S/WholeWordLongestMatchSet.java:47-178 by ONE lane (word-character tables that are not
+// fold-consistent; the whole haystack is one shard).  wflags bit 0 = wordChars[raw unit], bit 1 = wordChars[folded unit].
+__global__ void k_wwl_sequential(DevTables T, const uint16_t *hay, uint32_t len, void *out, uint64_t cap, int record_kind,
+                                 unsigned long long *counter) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    unsigned long long n = 0;
+    auto emit = [&](uint32_t start, uint32_t end, uint32_t id) {
+        if (n < cap) {
+            if (record_kind == ACGPU_REC_SET) {
+                reinterpret_cast<int2 *>(out)[n] = make_int2((int)start, (int)end);
+            } else {
+                int32_t *o = reinterpret_cast<int32_t *>(out) + n * 3;
+                o[0] = (int)start; o[1] = (int)end; o[2] = (int)id;
+            }
+        }
+        ++n;
+    };
+    // matchLength != 0 <=> the node is a keyword (its depth); failMatchLength/Offset/value = out_len/out_link/out_id
+    auto report = [&](uint32_t node, uint32_t idx, bool own_match_allowed) {
+        if (own_match_allowed && node != 0 && T.term_id[node] != ~0u) emit(idx - T.depth[node], idx, T.term_id[node]);
+        else if (T.out_len[node] != 0) {
+            const uint32_t fe = idx - T.out_link[node];
+            emit(fe - T.out_len[node], fe, T.out_id[node]);
+        }
+    };
+    uint32_t node = 0, idx = 0;
+    while (idx < len) {
+        const uint32_t raw = hay[idx];
+        const uint32_t c = T.cs ? raw : (uint32_t)T.lower[raw];
+        const uint32_t next = hashed_goto(T.hkeys, T.hvals, T.hmask, node, c);
+        if (next == ~0u) {
+            if (!(T.wflags[raw] & 2u)) { // !wordChars[c], c = folded unit (:73 / :128)
+                report(node, idx, true);
+            } else {
+                report(node, idx, false); // only the fail match (:86-93)
+                while (++idx < len && (T.wflags[hay[idx]] & 1u)) { // raw units (:95 / :150)
+                }
+            }
+            while (++idx < len && !(T.wflags[hay[idx]] & 1u)) {
+            }
+            node = 0;
+        } else {
+            ++idx;
+            node = next;
+        }
+    }
+    report(node, idx, true);
+    *counter = n;
 }
 
 template <int REC>
@@ -154,24 +221,34 @@ __global__ __launch_bounds__(256) void k_wwl_emit(const uint32_t *rs, const uint
 uint32_t wwl_tiles(uint32_t n_units) { return (n_units + kStartsTile - 1) / kStartsTile; }
 
 hipError_t launch_wwl_starts(const DevTables &t, const uint16_t *d_hay, uint32_t n, int n_cu, bool fill, uint32_t *d_counts,
-                             const uint64_t *d_offsets, uint32_t *d_rs, hipStream_t stream) {
+                             const uint64_t *d_offsets, uint32_t *d_rs, int text_begin, hipStream_t stream) {
     const uint32_t n_tiles = wwl_tiles(n);
     if (n_tiles == 0) return hipSuccess;
     const dim3 block(kStartsBlock), grid(std::min<uint32_t>(n_tiles, (uint32_t)n_cu * 8));
-    if (fill) hipLaunchKernelGGL(k_wwl_starts<true>, grid, block, 0, stream, t, d_hay, n, n_tiles, d_counts, d_offsets, d_rs);
-    else hipLaunchKernelGGL(k_wwl_starts<false>, grid, block, 0, stream, t, d_hay, n, n_tiles, d_counts, d_offsets, d_rs);
+    if (fill) hipLaunchKernelGGL(k_wwl_starts<true>, grid, block, 0, stream, t, d_hay, n, n_tiles, d_counts, d_offsets, d_rs, text_begin);
+    else hipLaunchKernelGGL(k_wwl_starts<false>, grid, block, 0, stream, t, d_hay, n, n_tiles, d_counts, d_offsets, d_rs, text_begin);
     return hipGetLastError();
 }
 
 hipError_t launch_wwl_walk(const DevTables &t, const uint16_t *d_hay, uint32_t n, const uint32_t *d_rs, uint32_t M,
-                           uint32_t *d_nxt, uint32_t *d_mark, int32_t *d_mend, int32_t *d_mid, hipStream_t stream) {
+                           uint32_t *d_nxt, uint32_t *d_mark, int32_t *d_mend, int32_t *d_mid, uint32_t *d_stop, uint32_t entry,
+                           hipStream_t stream) {
     hipLaunchKernelGGL(k_wwl_walk, dim3((M + 1 + 255) / 256), dim3(256), 0, stream, t, d_hay, n, d_rs, M, d_nxt, d_mark, d_mend,
-                       d_mid);
+                       d_mid, d_stop, entry);
     return hipGetLastError();
 }
 
-hipError_t launch_wwl_select(const uint32_t *d_mark, const int32_t *d_mend, uint32_t *d_sel, uint32_t M, hipStream_t stream) {
-    hipLaunchKernelGGL(k_wwl_select, dim3((M + 255) / 256), dim3(256), 0, stream, d_mark, d_mend, d_sel, M);
+hipError_t launch_wwl_select(const uint32_t *d_mark, const int32_t *d_mend, const uint32_t *d_rs, const uint32_t *d_nxt,
+                             const uint32_t *d_stop, uint32_t *d_sel, uint32_t M, uint32_t own_begin, uint32_t own_end,
+                             unsigned long long *d_exit, hipStream_t stream) {
+    hipLaunchKernelGGL(k_wwl_select, dim3((M + 255) / 256), dim3(256), 0, stream, d_mark, d_mend, d_rs, d_nxt, d_stop, d_sel, M,
+                       own_begin, own_end, d_exit);
+    return hipGetLastError();
+}
+
+hipError_t launch_wwl_sequential(const DevTables &t, const uint16_t *d_hay, uint32_t len, void *d_out, uint64_t cap,
+                                 int record_kind, unsigned long long *d_counter, hipStream_t stream) {
+    hipLaunchKernelGGL(k_wwl_sequential, dim3(1), dim3(64), 0, stream, t, d_hay, len, d_out, cap, record_kind, d_counter);
     return hipGetLastError();
 }
 

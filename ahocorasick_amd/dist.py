@@ -15,6 +15,9 @@ row per matcher family:
 * Shortest: a match belongs to the rank that owns its LAST unit (left halo as AhoCorasick); which occurrences are
   reported depends on where matching last restarted (the end of the previous reported match), handed down the ranks
   like the Longest chain position, with the same speculation (no restriction) and window repair.
+* WholeWordLongest: a walk belongs to the rank that owns its FIRST unit (halos as WholeWord); which word starts the scan
+  visits depends on where the previous rank's last walk stopped -- the same hop; a rank whose true entry lies inside its
+  shard (the previous rank's last walk ran over the boundary) scans once more from there.
 
 In all of them rank-local order is the reference's order, so the concatenation of the per-rank buffers by rank is the
 reference's listener-call order for the whole haystack.
@@ -39,7 +42,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from ._native import MODE_ALL, MODE_LONGEST, MODE_SHORTEST, MODE_WHOLEWORD
+from ._native import MODE_ALL, MODE_LONGEST, MODE_SHORTEST, MODE_WHOLEWORD, MODE_WWLONGEST
 
 HDR = 4  # int32 words in front of the records of a gather buffer: acgpu_device_result {u64 n_records, u32 redone, u32 0}
 
@@ -182,7 +185,7 @@ class ShardedMatcher:
             max_len = automaton.info()["max_keyword_len"]
             if self.mode in (MODE_ALL, MODE_SHORTEST):
                 halo, right_halo = max(0, max_len - 1), 0
-            elif self.mode == MODE_WHOLEWORD:
+            elif self.mode in (MODE_WHOLEWORD, MODE_WWLONGEST):
                 halo, right_halo = 1, max_len + 1
             else:
                 halo, right_halo = 0, max(0, max_len - 1)
@@ -337,6 +340,8 @@ class ShardedMatcher:
             n, prof = self._scan_longest(profile)
         elif self.mode == MODE_SHORTEST:
             n, prof = self._scan_shortest(profile)
+        elif self.mode == MODE_WWLONGEST:
+            n, prof = self._scan_wwlongest(profile)
         else:
             native = self.scan_fn is None
             n, _, prof = self._call("out", 0, self.sb.n_units, 0, profile, d_result=st.gbuf.data_ptr() if native else None)
@@ -390,6 +395,20 @@ class ShardedMatcher:
                     break
                 w *= 4
         self._chain_hop_send(ex)
+        return n, prof
+
+    def _scan_wwlongest(self, profile):
+        """WholeWordLongest: speculation = the scan enters at my first unit; the true entry is the position behind the stop
+        of the previous rank's last walk.  Walks are short (at most max_keyword_len units), so an entry inside my shard
+        lies within my first few units: the shard is scanned once more from there."""
+        n_own = self.sb.n_units
+        n, ex, prof = self._call("out", 0, n_own, 0, profile)
+        entry = self._chain_hop_recv()
+        self.chain_repairs = 0
+        if entry > 0:
+            self.chain_repairs = 1
+            n, ex, prof = self._call("out", 0, n_own, entry, profile)
+        self._chain_hop_send(max(ex, entry))
         return n, prof
 
     def _scan_shortest(self, profile):

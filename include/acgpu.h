@@ -51,10 +51,11 @@ extern "C" {
 #define ACGPU_MODE_WHOLEWORD 2 /* WholeWordMatchSet / WholeWordMatchMap S/WholeWordMatchSet.java:47-132, S/WholeWordMatchMap.java:155-240 */
 #define ACGPU_MODE_SHORTEST 3  /* ShortestMatchSet / ShortestMatchMap   S/ShortestMatchSet.java:193-262, S/ShortestMatchMap.java:294-372;
                                   keyword_id = FIRST duplicate (S/ShortestMatchMap.java:47-49) */
-#define ACGPU_MODE_WWLONGEST 4 /* WholeWordLongestMatchSet / Map        S/WholeWordLongestMatchSet.java:47-178, S/WholeWordLongestMatchMap.java:180-305;
-                                  keywords are trimmed but may contain non-word characters; the whole haystack must be ONE
-                                  shard (own range = buffer, text_begin = text_end = 1), no streaming form, fold-consistent
-                                  word-character tables only -- ACGPU_E_UNSUPPORTED otherwise */
+#define ACGPU_MODE_WWLONGEST 4 /* WholeWordLongestMatchSet / Map        S/WholeWordLongestMatchSet.java:47-178, S/WholeWordLongestMatchMap.java:54-305;
+                                  keywords are trimmed but may contain non-word characters.  Word-character tables that are
+                                  not fold-consistent (acgpu_info) are served by a sequential kernel over the whole haystack
+                                  as ONE shard (own range = buffer, text_begin = text_end = 1; ACGPU_E_UNSUPPORTED for
+                                  other shards and for streams) */
 
 /* output record layouts */
 #define ACGPU_REC_SET 8  /* acgpu_set_match: what SetMatchListener.match(haystack, start, end) receives */
@@ -142,7 +143,9 @@ int acgpu_match_u16(const acgpu_automaton *a, const uint16_t *haystack, uint64_t
  * halo >= max_keyword_len-1 units needed); WHOLEWORD -> to the shard that owns the first unit of
  * the word (left halo 1 unit, right halo up to the end of the word or max_keyword_len+1 units);
  * LONGEST -> to the shard that owns its first unit, given the greedy chain's entry position
- * (right halo >= max_keyword_len-1 units); SHORTEST -> to the shard that owns its LAST unit (left halo as ALL), given
+ * (right halo >= max_keyword_len-1 units); WWLONGEST -> to the shard that owns its first unit (left halo 1 unit, right
+ * halo max_keyword_len+1 units), given the position from which the scan looks for its next word start (chain_entry;
+ * chain_exit: the position behind the stop of the last walk this shard's scan made); SHORTEST -> to the shard that owns its LAST unit (left halo as ALL), given
  * the position at which matching last restarted (chain_entry: no match may start before it; chain_exit: the end of
  * the last match reported, or chain_entry if there was none).
  */
@@ -154,8 +157,9 @@ typedef struct acgpu_shard {
     int32_t text_begin;    /* 1: buffer unit 0 is the first unit of the whole haystack           */
     int32_t text_end;      /* 1: buffer unit n_units-1 is the last unit of the whole haystack    */
     int64_t chain_entry;   /* LONGEST in : first greedy-chain position >= own_begin (own_begin on the first shard);
+                              WWLONGEST in: the scan visits the first word start at or after this position;
                               SHORTEST in: position of the last restart (0 on the first shard)      */
-    int64_t chain_exit;    /* LONGEST out: first greedy-chain position >= own_end; SHORTEST out: see above */
+    int64_t chain_exit;    /* LONGEST out: first greedy-chain position >= own_end; WWLONGEST / SHORTEST out: see above */
     void *d_result;        /* optional device pointer (16-byte aligned) to an acgpu_device_result that the call's last
                               kernel (or a copy enqueued behind it) fills in STREAM ORDER: a multi-GPU driver points it
                               into the buffer it all-gathers, so the record count travels with the records and no host
@@ -217,12 +221,13 @@ int acgpu_match_device_end(const acgpu_automaton *a, acgpu_ticket *ticket, uint6
  *           haystack, after which only close is valid.  Internally the stream keeps the few units a later chunk can
  *           still change the answer for (ALL: max_keyword_len-1 units of left context; WHOLEWORD: one unit of context
  *           plus the last max_keyword_len+1 units, whose words are decided by the next feed; LONGEST: the last
- *           max_keyword_len-1 units plus the position at which the greedy chain continues).
+ *           max_keyword_len-1 units plus the position at which the greedy chain continues; WWLONGEST: as WHOLEWORD plus
+ *           the position from which the scan looks for its next word start).
  *  out    : cap records of record_kind; start/end are int32 relative to *base (the global position, in units since
  *           the first feed, that record coordinate 0 stands for).  On ACGPU_E_OVERFLOW nothing was consumed: *n_out
  *           is the capacity to call the SAME feed again with.
  *  carried units + n_units must stay below 2^31.
- *  ACGPU_E_UNSUPPORTED: WHOLEWORD with a word-character table that is not fold-consistent (acgpu_info).
+ *  ACGPU_E_UNSUPPORTED: WHOLEWORD / WWLONGEST with a word-character table that is not fold-consistent (acgpu_info).
  */
 typedef struct acgpu_stream acgpu_stream;
 int acgpu_stream_open(const acgpu_automaton *a, acgpu_stream **out);

@@ -907,6 +907,50 @@ static void match_wholeword_readable(const oracle *o, const uint16_t *hay, int32
     if (currentNode->matchLength != 0) l(ctx, -1, -1, currentNode->value);
 }
 
+/* WholeWordLongestMatchMap.match(Readable, ReadableMatchListener<T>): S/WholeWordLongestMatchMap.java:54-181, with scroll()
+ * :401-415 (the same shape as WholeWordMatchMap's: folded word-character lookups in case-insensitive mode). */
+static void match_wwlongest_readable(const oracle *o, const uint16_t *hay, int32_t len, int32_t bufsize, match_listener l,
+                                     void *ctx) {
+    const Node *root = o->root;
+    const Node *currentNode = root;
+    CharBuf b = {hay, len, 0, bufsize, 0, 0, 0};
+    int done = 0;
+    while (!done && cb_read(&b) != -1) {
+        while (b.pos < b.lim) {
+            uint16_t c = b.hay[b.base + b.pos++];
+            if (!o->caseSensitive) c = o->lower[c];
+            const Node *nextNode = get_transition(currentNode, c);
+            if (nextNode == NULL) {
+                if (!o->wordChars[c]) {
+                    if (currentNode->matchLength != 0) {
+                        if (!l(ctx, -1, -1, currentNode->value)) return;
+                    } else if (currentNode->failMatchLength != 0) {
+                        if (!l(ctx, -1, -1, currentNode->failValue)) return;
+                    }
+                } else {
+                    if (currentNode->failMatchLength != 0) {
+                        if (!l(ctx, -1, -1, currentNode->failValue)) return;
+                    }
+                    if (ww_scroll(o, &b, 1)) {
+                        currentNode = root;
+                        done = 1;
+                        break;
+                    }
+                }
+                currentNode = root;
+                if (ww_scroll(o, &b, 0)) {
+                    done = 1;
+                    break;
+                }
+            } else {
+                currentNode = nextNode;
+            }
+        }
+    }
+    if (currentNode->matchLength != 0) l(ctx, -1, -1, currentNode->value);
+    else if (currentNode->failMatchLength != 0) l(ctx, -1, -1, currentNode->failValue);
+}
+
 /* values only, in listener-call order; bufsize = charBufferSize */
 int64_t oracle_match_readable(const oracle *o, const uint16_t *hay, int32_t len, int32_t bufsize, int32_t *out, int64_t cap,
                               int64_t stop_after);
@@ -1022,6 +1066,7 @@ int64_t oracle_match_readable(const oracle *o, const uint16_t *hay, int32_t len,
                               int64_t stop_after) {
     Collect c = {out, cap, 0, stop_after};
     if (o->family == FAM_WHOLEWORD) match_wholeword_readable(o, hay, len, bufsize > 0 ? bufsize : 1024, collect_listener, &c);
+    else if (o->family == FAM_WWLONGEST) match_wwlongest_readable(o, hay, len, bufsize > 0 ? bufsize : 1024, collect_listener, &c);
     else match_dispatch(o, hay, len, collect_listener, &c);
     return c.n;
 }

@@ -28,6 +28,16 @@ def case(family, n_total, variant=0):
         whole = synth.haystack(41 + variant, n_total, table=table)
         return (Automaton(N.MODE_WHOLEWORD, kws, False, word_chars=default_word_chars()),
                 Oracle(FAM_WHOLEWORD, kws, case_sensitive=False, lower=java_lower_table(), word_chars=default_word_chars()), whole)
+    if family == "wwlongest":
+        from oracle.oracle import FAM_WWLONGEST
+        table = np.array([ord(c) for c in "abcE -,"] + [0x00E9, 0x00C9], dtype=np.uint16)
+        rng = np.random.default_rng(35)
+        words = synth.random_keywords(35, 120, 1, 5, table=table[:4])
+        sp = np.array([32], dtype=np.uint16)
+        kws = list(words[:60]) + [np.concatenate([words[int(i)], sp, words[int(j)]]) for i, j in rng.integers(0, 120, (80, 2))]
+        whole = synth.haystack(45 + variant, n_total, table=table)
+        return (Automaton(N.MODE_WWLONGEST, kws, False, word_chars=default_word_chars()),
+                Oracle(FAM_WWLONGEST, kws, case_sensitive=False, lower=java_lower_table(), word_chars=default_word_chars()), whole)
     if family == "longest":
         kws = synth.random_keywords(32, 300, 2, 40, table=synth.ALPHA_LOWER[:2])
         whole = synth.haystack(42 + variant, n_total, table=synth.ALPHA_LOWER[:2])

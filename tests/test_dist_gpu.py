@@ -48,7 +48,7 @@ def _run(family, world, overlap, cap, tmp_path, n=50000):
     ("ac", 2, False, 1 << 16), ("ac", 3, True, 1 << 16), ("ac", 2, True, 64),   # cap 64: the redo path (gather buffers grow)
     ("wholeword", 2, False, 1 << 16), ("wholeword", 3, True, 64),
     ("longest", 2, False, 1 << 16), ("longest", 3, True, 64),
-    ("shortest", 2, True, 1 << 16)])
+    ("shortest", 2, True, 1 << 16), ("wwlongest", 3, False, 1 << 16), ("wwlongest", 2, True, 64)])
 def test_sharded_matcher_native_scan_in_separate_processes(family, world, overlap, cap, tmp_path):
     res = _run(family, world, overlap, cap, tmp_path)
     assert all(r[2] > 0 for r in res)  # there were matches to get right

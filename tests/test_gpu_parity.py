@@ -936,7 +936,7 @@ def test_fuzz_wwlongest_vs_oracle(seed):
 
 
 def test_wwlongest_listener_examples_and_limits():
-    from ahocorasick_amd import Stream, WholeWordLongestMatchMap, WholeWordLongestMatchSet
+    from ahocorasick_amd import WholeWordLongestMatchMap, WholeWordLongestMatchSet
     m = WholeWordLongestMatchMap(["as", "if", "as if"], [1, 2, 3], True)
     seen = []
     m.match("as if, as in; ax if", lambda h, s, e, v: seen.append((s, e, v)) or True)
@@ -953,14 +953,106 @@ def test_wwlongest_listener_examples_and_limits():
     want = Oracle(FAM_WWLONGEST, kws, case_sensitive=False, lower=LOWER, word_chars=WORD).match(block)
     got = Automaton(N.MODE_WWLONGEST, kws, False, word_chars=WORD).match_host(block, True)
     assert len(want) > 1000 and got.shape == want.shape and (got == want).all()
-    # shards and streams are refused, not mis-scanned
+
+
+def _wwl_case(seed, n, cs=False):
+    """multi-word keywords over a token stream with punctuation: walks run across words and over shard boundaries"""
+    table = np.array([ord(c) for c in "abcE -,"] + [0x00E9, 0x00C9], dtype=np.uint16)
+    rng = np.random.default_rng(seed)
+    words = synth.random_keywords(seed, 120, 1, 5, table=table[:4])
+    sp = np.array([32], dtype=np.uint16)
+    kws = list(words[:60]) + [np.concatenate([words[int(i)], sp, words[int(j)]]) for i, j in rng.integers(0, 120, (80, 2))] + \
+          [np.concatenate([words[int(i)], sp, words[int(j)], np.array([44, 32], np.uint16), words[int(k)]])
+           for i, j, k in rng.integers(0, 120, (30, 3))]
+    hay = synth.haystack(seed + 1000, n, table=table)
+    return kws, hay
+
+
+def test_wwlongest_shards_chain_through_entry_and_exit():
+    """acgpu_shard for WWLONGEST: a walk belongs to the shard that owns its first unit; chain_exit of one shard is the
+    chain_entry of the next.  Shards of one buffer, and a shard handed only its slice + halos."""
     import torch
-    a = Automaton(N.MODE_WWLONGEST, ["as if"], True, word_chars=WORD)
-    d = torch.zeros(64, dtype=torch.int16, device="cuda")
-    o = torch.zeros((8, 3), dtype=torch.int32, device="cuda")
-    assert a.match_device(d.data_ptr(), 64, True, o.data_ptr(), 8, own=(8, 64))[1] == N.E_UNSUPPORTED
-    with pytest.raises(N.AcgpuError):
-        Stream(a)
+    from oracle.oracle import FAM_WWLONGEST
+    for seed in range(3):
+        kws, hay = _wwl_case(500 + seed, 120000)
+        a = Automaton(N.MODE_WWLONGEST, kws, False, word_chars=WORD)
+        want = Oracle(FAM_WWLONGEST, kws, case_sensitive=False, lower=LOWER, word_chars=WORD).match(hay)
+        assert len(want) > 2000
+        d_hay = torch.from_numpy(hay.view(np.int16)).cuda()
+        cap = len(want) + 16
+        got, _ = _dev_match(a, d_hay, hay.size, True, cap)
+        assert got.shape == want.shape and (got == want).all()
+        cuts = [0, 39989, 40000, 40003, 90001, hay.size]  # (some shards are only a few units long)
+        parts, entry = [], 0
+        d_out = torch.empty((cap, 3), dtype=torch.int32, device="cuda")
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            n_out, rc, _, ex = a.match_device(d_hay.data_ptr(), hay.size, True, d_out.data_ptr(), cap, own=(lo, hi), chain_entry=entry)
+            assert rc == N.OK and ex >= entry
+            parts.append(d_out[:n_out].cpu().numpy())
+            entry = ex
+        assert (np.concatenate(parts) == want).all()
+        # a rank's view: 1 unit of left context, max_keyword_len + 1 units of right halo, positions buffer-relative
+        ml = a.info()["max_keyword_len"]
+        lo, hi = cuts[1], cuts[4]
+        base = (lo - 1) // 8 * 8
+        sub = d_hay[base:hi + ml + 1].clone()
+        entry = 0
+        for l2, h2 in zip(cuts[:1], cuts[1:2]):  # the entry the previous shards leave
+            _, _, _, entry = a.match_device(d_hay.data_ptr(), hay.size, True, d_out.data_ptr(), cap, own=(l2, h2), chain_entry=0)
+        n_out, rc, _, ex = a.match_device(sub.data_ptr(), sub.numel(), True, d_out.data_ptr(), cap, own=(lo - base, hi - base),
+                                          text_begin=False, text_end=False, chain_entry=entry - base)
+        assert rc == N.OK
+        p = d_out[:n_out].cpu().numpy()
+        p[:, :2] += base
+        assert (p == np.concatenate(parts[1:4])).all()
+        # too short a right halo is refused
+        assert a.match_device(sub.data_ptr(), sub.numel() - 2, True, d_out.data_ptr(), cap, own=(lo - base, hi - base),
+                              text_begin=False, text_end=False, chain_entry=entry - base)[1] == N.E_INVALID
+
+
+def test_wwlongest_fold_inconsistent_tables_take_the_sequential_kernel():
+    """Custom word characters in case-insensitive mode where wordChars[c] != wordChars[lower(c)]: the reference's String loop
+    tests the folded unit where a walk stops and raw units in its skip loops (S/WholeWordLongestMatchSet.java:127,150,155)."""
+    from ahocorasick_amd import Stream, WholeWordLongestMatchMap
+    from oracle.oracle import FAM_WWLONGEST
+    from ahocorasick_amd.unicode_tables import word_chars_from_list
+    wc = word_chars_from_list("abcdxyABCD")  # X, Y are not word characters although x, y are
+    rng = np.random.default_rng(9)
+    alpha = np.array([ord(c) for c in "abxyABXY ,"], dtype=np.uint16)
+    for it in range(30):
+        kws = [alpha[rng.integers(0, 4, int(rng.integers(1, 5)))] for _ in range(12)]
+        kws += [np.concatenate([kws[0], np.array([32], np.uint16), kws[1]])]
+        hay = alpha[rng.integers(0, len(alpha), int(rng.integers(1, 3000)))]
+        m = WholeWordLongestMatchMap(kws, list(range(len(kws))), False, word_characters="abcdxyABCD")
+        assert m.automaton.info()["fold_consistent"] == 0
+        want = Oracle(FAM_WWLONGEST, kws, case_sensitive=False, lower=LOWER, word_chars=wc).match(hay)
+        got = m.find_all(hay)
+        assert got.shape == want.shape and (got == want).all(), it
+    with pytest.raises(N.AcgpuError):  # no chunked form: the Readable loop folds where the String loop does not
+        Stream(m.automaton)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_wwlongest_stream_feeds_equal_whole_text(seed):
+    """WholeWordLongestMatchMap.match(Readable, ...) (S/WholeWordLongestMatchMap.java:54-181): the feeds' records are the
+    String overload's; the values are what the oracle's literal Readable loop reports."""
+    from oracle.oracle import FAM_WWLONGEST
+    kws, hay = _wwl_case(700 + seed, 50000)
+    auto = Automaton(N.MODE_WWLONGEST, kws, False, word_chars=WORD)
+    orc = Oracle(FAM_WWLONGEST, kws, case_sensitive=False, lower=LOWER, word_chars=WORD)
+    want = orc.match(hay)
+    assert orc.match_readable(hay, 7).tolist() == want[:, 2].tolist()
+    rng = np.random.default_rng(seed)
+    for cuts in ([], [25000], sorted(rng.integers(0, hay.size, 12).tolist()), [1, 2, 3, 3, 4, 10, 11, 40, 5000, 5001, 49999],
+                 list(range(100, 400, 7))):
+        got = _stream_all(auto, hay, cuts)
+        assert got.shape == want.shape and (got == want.astype(np.int64)).all(), cuts[:5]
+    from ahocorasick_amd import WholeWordLongestMatchMap
+    m = WholeWordLongestMatchMap(kws, list(range(len(kws))), False)
+    seen = []
+    text = "".join(chr(c) for c in hay[:5000].tolist())
+    m.match(iter([text[:777], text[777:3000], "", text[3000:]]), lambda v: seen.append(v) or True)
+    assert seen == orc.match(hay[:5000])[:, 2].tolist()
 
 
 def test_split_form_falls_back_when_the_candidate_slices_overflow():

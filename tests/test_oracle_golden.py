@@ -178,6 +178,30 @@ def test_readable_wholeword_scroll_and_refills_fuzz():
     assert o.match_readable("ab b ab", 2, stop_after=2).tolist() == [0, 1]
 
 
+def test_readable_wwlongest_reports_the_string_loops_values():
+    """S/WholeWordLongestMatchMap.java:54-181 (Readable) against :180-305 (String): the fixtures and fuzzed inputs, buffer
+    refills at every unit, fold-consistent tables."""
+    import json, os
+    from oracle.oracle import FAM_WWLONGEST
+    from tests.helpers import LOWER, WORD, rand_case
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for fx in json.load(open(os.path.join(root, "tests", "golden", "reference_fixtures.json"))):
+        if "WWL" not in fx or "keywords_gen" in fx:
+            continue
+        o = Oracle(FAM_WWLONGEST, fx["WWL_keywords"], word_chars=WORD)
+        for bufsize in (1, 3, 4096):
+            assert o.match_readable(fx["haystack"], bufsize).tolist() == [r[2] for r in fx["WWL"]], (fx["name"], bufsize)
+    rng = np.random.default_rng(23)
+    alpha = [ord(c) for c in "abAB -_.9"] + [0x00E9, 0x00C9, 0x3002]
+    for it in range(150):
+        hay, kws = rand_case(rng, alpha, int(rng.integers(1, 30)), 7, int(rng.integers(0, 200)))
+        for cs in (True, False):
+            o = Oracle(FAM_WWLONGEST, kws, case_sensitive=cs, lower=LOWER, word_chars=WORD)
+            want = o.match(hay)[:, 2].tolist()
+            for bufsize in (1, 2, 5, 64):
+                assert o.match_readable(hay, bufsize).tolist() == want, (it, cs, bufsize)
+
+
 # ---- ShortestMatchSet / ShortestMatchMap (S/ShortestMatchSet.java) ------------------------------------------------------
 
 def test_shortest_fixtures_and_reference_test_counts(fixtures):
