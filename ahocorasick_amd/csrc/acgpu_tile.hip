@@ -167,7 +167,7 @@ __device__ __forceinline__ void verify_multi(TileCtx &c, uint32_t head, uint32_t
         if (!need_win) {
             win[b] = Units8{{0, 0, 0, 0}};
         } else if (e[b] >= 8) {
-            if (L.debug & 8u) win[b] = Units8{{e[b], e[b] * 3u, e[b] * 5u, e[b] * 7u}}; // ablation: no window load
+            if (ACGPU_DBG(L, 8u)) win[b] = Units8{{e[b], e[b] * 3u, e[b] * 5u, e[b] * 7u}}; // ablation: no window load
             else win[b] = *reinterpret_cast<const Units8 *>(hay + e[b] - 8);
         } else {
             win[b] = Units8{{0, 0, 0, 0}}; // within 8 units of the buffer start (rare): unit by unit
@@ -213,7 +213,7 @@ __device__ __forceinline__ void verify_multi(TileCtx &c, uint32_t head, uint32_t
                     slot = (slot + 1) & T.kg_mask;
                 }
             }
-        } else if (!(L.debug & 16u)) {
+        } else if (!ACGPU_DBG(L, 16u)) {
             ent = act[b] ? reinterpret_cast<const uint2 *>(T.kgram_node)[idx] : make_uint2(0u, 0u);
         }
         if (!act[b]) ent = make_uint2(0u, 0u);
@@ -236,7 +236,7 @@ __device__ __forceinline__ void verify_multi(TileCtx &c, uint32_t head, uint32_t
             go[b] = (ref[b] & kRefHasChildren) && e[b] > d[b]; // not a leaf, and the buffer does not start here
             any_go |= go[b];
         }
-        if (!__any(any_go) || (L.debug & 64u)) break; // 64: ablation, no walk beyond the K-gram node
+        if (!__any(any_go) || ACGPU_DBG(L, 64u)) break; // 64: ablation, no walk beyond the K-gram node
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             uint32_t next = 0;
@@ -272,7 +272,7 @@ __device__ __forceinline__ void verify_multi(TileCtx &c, uint32_t head, uint32_t
         prefix[b] = total + incl - m[b];
         total += __builtin_amdgcn_readlane(incl, kWave - 1);
     }
-    if (total == 0 || (L.debug & 32u)) return; // 32: ablation, no record emission
+    if (total == 0 || ACGPU_DBG(L, 32u)) return; // 32: ablation, no record emission
     const SlotRange sr = reserve_slots(c, total);
     auto slot_of = [&](uint32_t k) -> uint32_t { return sr.slot(k); };
     bool multi = false;
@@ -312,7 +312,7 @@ __device__ __forceinline__ void drain(TileCtx &c, uint32_t keep_below) {
     uint32_t head = 0;
     while (c.cand_n > head && c.cand_n - head >= keep_below) {
         const uint32_t nb = min(c.cand_n - head, (uint32_t)(kVerifyBatches * kWave));
-        if (!(c.Lp->debug & 1u)) verify_multi<K, RANGE, HASHK, QI>(c, head, nb);
+        if (!ACGPU_DBG(*c.Lp, 1u)) verify_multi<K, RANGE, HASHK, QI>(c, head, nb);
         head += nb;
     }
     if (head) { // move the leftovers (fewer than kVerifyBatches*64) to the front
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                     carry[q] = __builtin_amdgcn_readlane(mine, 63);
                 }
                 uint32_t mask = 0;
-                if (L.debug & 4u) { // ablation: stream only
+                if (ACGPU_DBG(L, 4u)) { // ablation: stream only
                     uint32_t x = 0;
 #pragma unroll
                     for (int q = 0; q < 4 * kAcVec; ++q) x ^= ww[q];
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                         mask &= ((1u << last) - 1u) & ~((1u << first) - 1u);
                     }
                 }
-                if (L.debug & 512u) mask &= 0x0101u << (lane & 7u); // ablation: one candidate in eight survives (timing only)
+                if (ACGPU_DBG(L, 512u)) mask &= 0x0101u << (lane & 7u); // ablation: one candidate in eight survives (timing only)
                 if (!L2) {
                     enqueue(c, mask, v);
                     continue;
@@ -751,7 +751,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                             const uint32_t bits = __builtin_amdgcn_alignbit(pat, pat, l2_rot(cls, len, K));
                             pass |= (word & bits) == bits;
                         }
-                        pass = (pass || (L.debug & 4096u)) && act; // 4096: ablation, the second level passes everything
+                        pass = (pass || ACGPU_DBG(L, 4096u)) && act; // 4096: ablation, the second level passes everything
                         const uint64_t bal = __ballot(pass);
                         if (pass) { // the entry: position in the region, K-gram index (oldest unit most significant), left class
                             const uint32_t at = c.cand_n + (uint32_t)__popcll(bal & lanemask_lt());
@@ -830,7 +830,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
             }
             const uint32_t pos = t0 + lane;
             uint32_t mask = 0;
-            if (pos < span_end && pos + 1 >= (uint32_t)K && !(L.debug & 4u)) {
+            if (pos < span_end && pos + 1 >= (uint32_t)K && !ACGPU_DBG(L, 4u)) {
                 uint32_t hrow = 0;
                 for (int j = K - 1; j >= 1; --j) hrow = hrow * n + tile_class_t<RANGE>(T, hay[pos - j]);
                 const uint32_t last = tile_class_t<RANGE>(T, hay[pos]);

@@ -21,6 +21,15 @@ constexpr int kCandCap = 1024;                 // candidate queue entries per wa
 constexpr int kPrefetch = ACGPU_PREFETCH;                   // tiles per group; one group of loads is in flight per wave
 constexpr uint32_t kReserve = 256;             // scratch slots a wave reserves per atomic
 
+// The ablation switches of TileLaunch::debug exist only in builds with -DACGPU_ABLATION (tools/build_variant.sh abl
+// -DACGPU_ABLATION; tools/kbench.py and tools/collect_profiles.sh select that library for their ablation variants): in
+// the product build every test is a constant 0 and costs neither an SGPR nor a branch in the hot loops.
+#ifdef ACGPU_ABLATION
+#define ACGPU_DBG(L, bits) ((L).debug & (bits))
+#else
+#define ACGPU_DBG(L, bits) 0u
+#endif
+
 struct TileCtx {
     const DevTables *Tp;
     const TileLaunch *Lp;
@@ -43,7 +52,7 @@ struct TileCtx {
 
 __device__ __forceinline__ void store_rec(const TileLaunch &L, uint32_t slot, uint32_t start, uint32_t end, uint32_t id,
                                           uint32_t rank) {
-    if ((uint64_t)slot < L.cap && !(L.debug & 128u)) { // 128: ablation, records are not stored
+    if ((uint64_t)slot < L.cap && !ACGPU_DBG(L, 128u)) { // 128: ablation, records are not stored
         // non-temporal: the records are read once, by the permute pass, and must not push the just-streamed text (which
         // the verification gathers from) out of the L2; about 1 % at config 2, same-box A/B against -DACGPU_REC_PLAIN
 #ifndef ACGPU_REC_PLAIN

@@ -220,8 +220,8 @@ __device__ __forceinline__ void ww_verify_hash(TileCtx &c, const uint32_t *wbits
     for (int b = 0; b < NB; ++b) {
         id[b] = ~0u;
         h[b] = ww_hash_final(h[b]);
-        probing[b] = act[b] && r[b] != 0 && r[b] <= T.max_len && !(L.debug & 2u); // 2: ablation, no table lookup
-        if (!(L.debug & 4u)) { // 4: ablation, no Bloom filter in front of the table
+        probing[b] = act[b] && r[b] != 0 && r[b] <= T.max_len && !ACGPU_DBG(L, 2u); // 2: ablation, no table lookup
+        if (!ACGPU_DBG(L, 4u)) { // 4: ablation, no Bloom filter in front of the table
             const uint32_t b1 = ww_bloom_bit1(h[b], F.bloom_mask), b2 = ww_bloom_bit2(h[b], F.bloom_mask);
             probing[b] = probing[b] && ((F.bloom[b1 >> 5] >> (b1 & 31)) & (F.bloom[b2 >> 5] >> (b2 & 31)) & 1u);
         }
@@ -380,7 +380,7 @@ __device__ __forceinline__ void ww_drain(TileCtx &c, const uint32_t *wbits, cons
     while (c.cand_n > head && c.cand_n - head >= keep_below) {
         const uint32_t nb = min(c.cand_n - head, (uint32_t)(kWwBatches * kWave));
         if (c.Lp->debug & 256u) ww_verify(c, wbits, head, nb);
-        else if (!(c.Lp->debug & 1u)) ww_verify_hash<FOLD>(c, wbits, F, head, nb); // 1: ablation, run starts are dropped
+        else if (!ACGPU_DBG(*c.Lp, 1u)) ww_verify_hash<FOLD>(c, wbits, F, head, nb); // 1: ablation, run starts are dropped
         head += nb;
     }
     if (head) {

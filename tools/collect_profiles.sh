@@ -13,13 +13,18 @@ python3 bench.py --config C5 --steps 5 --warmup 1 > "$OUT/bench_c5.json" 2> "$OU
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c2" -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/stats_c2.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c4" -- python3 bench.py --config C4 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/stats_c4.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c5" -- python3 bench.py --config C5 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/stats_c5.log" 2>&1
-# HBM traffic counters: separate passes, counters only (no other trace domains)
+# HBM traffic counters: separate passes, counters only (no other trace domains).  The no-verify / stream-only variants are
+# ablation switches, which only the -DACGPU_ABLATION build has (tools/build_variant.sh abl -DACGPU_ABLATION, built before the
+# gpurun call: ahocorasick_amd/lib_abl/ travels with the snapshot); its full build is the product kernel plus the switches.
+export ACGPU_LIB=ahocorasick_amd/lib_abl/libacgpu.so
+[ -f "$ACGPU_LIB" ] || { echo "missing $ACGPU_LIB: run tools/build_variant.sh abl -DACGPU_ABLATION first"; unset ACGPU_LIB; }
 V='{"tile":{"force_kernel":2},"noverify":{"force_kernel":2,"tile_debug":1},"stream":{"force_kernel":2,"tile_debug":5}}'
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 tools/kbench.py --rounds 1 --variants "$V" > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 tools/kbench.py --rounds 1 --variants "$V" > "$OUT/pmc_write.log" 2>&1
 python3 tools/pmc_traffic.py "$OUT" "$OUT/pmc_traffic.json"
 # SQ instruction / busy counters of the same three builds
 bash tools/pmc_sq.sh "${1:-final}/pmc_sq" "$V" > "$OUT/pmc_sq.txt" 2>&1
+unset ACGPU_LIB
 # config 3's share on one GPU (Set records, R = 8), and the sibling kernels' counters (SQ + HBM traffic)
 python3 bench.py --config C3 --steps 20 --warmup 3 > "$OUT/bench_c3_1gpu.json" 2> "$OUT/bench_c3_1gpu.err"
 bash tools/pmc_sq.sh "${1:-final}/pmc_sq_c4" '{"c4":{}}' "--config C4 --set" k_longest > "$OUT/pmc_sq_c4.txt" 2>&1

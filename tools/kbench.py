@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Kernel A/B harness (development tool): times the ALL-mode scan of BASELINE config 2 under several tunable
-settings in ONE process, interleaved rounds, and prints median/min kernel ms per variant."""
+settings in ONE process, interleaved rounds, and prints median/min kernel ms per variant.  The ablation variants
+(tile_debug bits 1, 2, 4, 8 ... 4096) need the -DACGPU_ABLATION build: tools/build_variant.sh abl -DACGPU_ABLATION, then
+ACGPU_LIB=ahocorasick_amd/lib_abl/libacgpu.so python tools/kbench.py ..."""
 import argparse
 import ctypes
 import json
