@@ -296,61 +296,57 @@ __device__ __forceinline__ uint32_t wl_round(const unsigned char *rows8, const u
 
 // trie rows in STATIC LDS at offset 0 (a row offset is the ds_read address as it stands): 60 KiB, or 52 KiB next to the
 // larger work lists of the Map flavour, so that two workgroups share a CU either way
-constexpr int kWlRowWordsSet = 13056, kWlRowWordsMap = 13312; // (Set: 51 KiB of rows + 9 KiB of root table)
+constexpr int kWlRowWordsSet = 8768, kWlRowWordsMap = 13312; // (Set: 34.25 KiB of rows + 25.75 KiB of root table)
 
 // The first round through a ROOT TABLE (Set flavour, small alphabets): every walk starts at the root, so the node reached
 // by the first RK units is a function of those units alone -- n^RK entries {row offset reached | longest keyword among the
 // RK steps << 16}, built in LDS by the kernel itself from the staged rows.  One LDS read replaces RK dependent ones (the
 // LDS is the busiest unit of this kernel); the remaining 8 - RK units of the round are ordinary steps.  The index is the
 // columns in radix n, most of it in packed arithmetic: even and odd columns run through the same two v_pk_mad_u16.
-constexpr int kWlRootWords = 2304; // n = 3 (two letters + "other"): RK = 7 (2187 entries); n <= 5 (DNA): RK = 4
+constexpr int kWlRootWords = 6592; // n = 3 (two letters + "other"): RK = 8 (6561 entries); n <= 5 (DNA): RK = 4
+// entry of the root table: row offset reached | longest keyword among the RK steps << 16 | flags
+constexpr uint32_t kRtAlive = 0x80000000u, kRtDeep = 0x40000000u;
 
-__device__ __forceinline__ uint32_t wl_mad_u16(uint32_t a, uint32_t b, uint32_t c, bool a_hi) {
+__device__ __forceinline__ uint32_t wl_pk_mad(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t r;
-    if (a_hi) asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(r) : "v"(a), "s"(b), "v"(c));
-    else asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[0,0,0,0]" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
     return r;
 }
 
-// returns the entry after 8 units; best = longest keyword of the round (0: none)
+// Byte offsets into the root table for the 8 consecutive positions a lane owns, two per register (low half: even
+// position): w[] = the 16 units from the lane's first position on.  The index of a position is its next RK columns in
+// radix n, first unit most significant; with Q_k = {c[2k] n + c[2k+1], c[2k+1] n + c[2k+2]} (one v_alignbit_b32 and one
+// v_pk_mad_u16 per column pair) the index pairs are two (RK = 4: one) more packed Horner steps: 3 instructions per
+// position instead of a dozen, and every column is computed once instead of once per position that looks at it.
 template <int RK>
-__device__ __forceinline__ uint32_t wl_round_root(const unsigned char *rows8, const uint32_t *rt, const uint32_t (&w)[4], uint32_t base2,
-                                                  uint32_t span2, uint32_t n, uint32_t &best) {
-    static_assert(RK == 4 || RK == 7, "root table depth");
-    uint32_t P[4];
+__device__ __forceinline__ void wl_block_index(const uint32_t (&w)[8], uint32_t base2, uint32_t span2, uint32_t n, uint32_t (&A)[4]) {
+    static_assert(RK == 4 || RK == 8, "root table depth");
+    uint32_t P[8];
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
+    for (int d = 0; d < 8; ++d) {
         uint32_t t;
         asm("v_pk_sub_u16 %0, %1, %2" : "=v"(t) : "v"(w[d]), "s"(base2));
         asm("v_pk_min_u16 %0, %1, %2" : "=v"(P[d]) : "v"(t), "s"(span2));
     }
-    const uint32_t nn2 = n * n * 0x10001u;
-    uint32_t idx;
-    if (RK == 7) {
-        uint32_t E;
-        asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(E) : "v"(P[0]), "s"(nn2), "v"(P[1]));
-        asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(E) : "v"(E), "s"(nn2), "v"(P[2])); // lo: c0 n^4 + c2 n^2 + c4, hi: c1 n^4 + c3 n^2 + c5
-        idx = wl_mad_u16(E, n, P[3] & 0xffffu, true);                                  // hi n + c6
-        idx = wl_mad_u16(E, n * n, idx, false);                                        // + lo n^2
-    } else {
-        uint32_t E;
-        asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(E) : "v"(P[0]), "s"(nn2), "v"(P[1])); // lo: c0 n^2 + c2, hi: c1 n^2 + c3
-        idx = wl_mad_u16(E, n, E >> 16, false);                                        // lo n + hi
-    }
-    uint32_t e = rt[idx];
-    best = (e >> 16) & 0xfu;
-    uint32_t tm = 0;
+    const uint32_t n2 = n * 0x10001u, nn2 = n * n * 0x10001u;
+    constexpr int NQ = RK == 8 ? 7 : 5;
+    uint32_t Q[NQ];
 #pragma unroll
-    for (int j = RK; j < 8; ++j) { // the ordinary steps of the round
-        uint32_t cc, a;
-        asm("v_pk_lshlrev_b16 %0, %1, %2" : "=v"(cc) : "s"(0x00020002u), "v"(P[j >> 1]));
-        if (j & 1) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "=v"(a) : "v"(e), "v"(cc));
-        else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_0" : "=v"(a) : "v"(e), "v"(cc));
-        e = *reinterpret_cast<const uint32_t *>(rows8 + a);
-        tm = __builtin_amdgcn_alignbit(tm, e, 31);
+    for (int k = 0; k < NQ; ++k) Q[k] = wl_pk_mad(P[k], n2, __builtin_amdgcn_alignbit(P[k + 1], P[k], 16));
+    uint32_t I[4];
+    if (RK == 8) {
+        const uint32_t n4 = n * n * n * n * 0x10001u;
+        uint32_t T[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) T[k] = wl_pk_mad(Q[k], nn2, Q[k + 1]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) I[k] = wl_pk_mad(T[k], n4, T[k + 2]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) I[k] = wl_pk_mad(Q[k], nn2, Q[k + 1]);
     }
-    if (tm) best = 8u - (uint32_t)__builtin_ctz(tm); // bit b = step 7 - b
-    return e;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) asm("v_pk_lshlrev_b16 %0, %1, %2" : "=v"(A[k]) : "s"(0x00020002u), "v"(I[k]));
 }
 
 template <typename LenT, bool STATE>
@@ -385,9 +381,12 @@ __global__ __launch_bounds__(kLScanBlock) void k_longest_walk_list(DevTables T, 
     uint32_t *wl0 = wl, *wl1 = wl + kWlCap, *wl2 = wl + 2 * kWlCap; // {row offset | best << 16}, {position in chunk | depth << 16}, [best node's entry]
     uint32_t *bm = wl + kEntryWords * kWlCap;
     __syncthreads();
-    // root table depth: 7 units for n <= 3, 4 for n <= 5, none for wider alphabets (n^2 entries would save one read in 8)
-    const uint32_t rk = !ROOT ? 0u : n <= 3 ? 7u : n <= 5 ? 4u : 0u;
+    // root table depth: 8 units for n <= 3, 4 for n <= 5, none for wider alphabets
+    __shared__ uint32_t rt_deep; // some RK-unit path leaves the LDS rows: no block form
+    const uint32_t rk = (!ROOT || sizeof(LenT) != 2) ? 0u : n <= 3 ? 8u : n <= 5 ? 4u : 0u;
     if (ROOT && rk) {
+        if (threadIdx.x == 0) rt_deep = 0;
+        __syncthreads();
         uint32_t total = 1;
         for (uint32_t j = 0; j < rk; ++j) total *= n;
         for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) {
@@ -400,10 +399,12 @@ __global__ __launch_bounds__(kLScanBlock) void k_longest_walk_list(DevTables T, 
                 off = e & 0xffffu;
                 if (e >> 31) best = j + 1;
             }
-            rt[i] = off | (best << 16);
+            if (off == deep_off) rt_deep = 1;
+            rt[i] = off | (best << 16) | (off < real_bytes ? kRtAlive : 0u);
         }
         __syncthreads();
     }
+    const bool block_form = ROOT && rk && !rt_deep; // block-uniform
     LenT *out_len = reinterpret_cast<LenT *>(L.d_len);
     const uint16_t *hay = L.d_hay;
     const unsigned char *rows8 = reinterpret_cast<const unsigned char *>(rows);
@@ -515,50 +516,82 @@ __global__ __launch_bounds__(kLScanBlock) void k_longest_walk_list(DevTables T, 
         const uint32_t chunk_end = (uint32_t)min((uint64_t)L.own_end, (uint64_t)chunk0 + kWlChunk);
         // every 16-byte text load of this chunk stays inside the buffer (walks are at most max_len deep)
         const bool check = (uint64_t)chunk_end + T.max_len + 8u > (uint64_t)nu;
-        if (lane < kWlChunk / 64) bm[lane] = 0;
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t s0 = chunk0; s0 < chunk_end; s0 += 2 * kWave) { // first round: positions s0+lane and s0+64+lane
-            uint32_t pp[2] = {s0 + lane, s0 + kWave + lane};
-            uint32_t ee[2], tmm[2], hh[2][8], ww[2][4], nv[2];
-            bool in[2];
+        if (ROOT && block_form && !check && chunk_end - chunk0 == (uint32_t)kWlChunk) {
+            // First round, block form: a lane owns 8 consecutive positions.  Their root-table indices come out of packed
+            // arithmetic over the 16 units behind the lane's first position (wl_block_index), one LDS read per position
+            // gives {node after RK units, longest keyword so far, alive}; the 8 lengths leave as ONE 16-byte store (walks
+            // that go on overwrite theirs when they finish), and the block maxima start from the bound p + RK.
+            if (lane < kWlChunk / 64) bm[lane] = chunk0 + lane * 64u + 63u + rk;
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t s0 = chunk0; s0 < chunk_end; s0 += 8 * kWave) {
+                const uint32_t pb = s0 + lane * 8u;
+                const Units8 u0 = *reinterpret_cast<const Units8 *>(hay + pb);
+                const Units8 u1 = *reinterpret_cast<const Units8 *>(hay + pb + 8);
+                const uint32_t w16[8] = {u0.d[0], u0.d[1], u0.d[2], u0.d[3], u1.d[0], u1.d[1], u1.d[2], u1.d[3]};
+                uint32_t A[4];
+                if (rk == 8) wl_block_index<8>(w16, base2, span2, n, A);
+                else wl_block_index<4>(w16, base2, span2, n, A);
+                const unsigned char *rt8 = reinterpret_cast<const unsigned char *>(rt);
+                uint32_t e[8];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                in[h] = pp[h] < chunk_end;
-                load8(in[h] ? pp[h] : chunk0, ww[h], nv[h], check);
-            }
-            // (the two walks are written out side by side: their dependent LDS reads interleave)
-            uint32_t rbest[2] = {0, 0};
-            bool rooted = false; // wave-uniform
-            if (check) {
-                ee[0] = wl_round<STATE, true>(rows8, ww[0], nv[0], base2, span2, span4, 0u, tmm[0], hh[0]);
-                ee[1] = wl_round<STATE, true>(rows8, ww[1], nv[1], base2, span2, span4, 0u, tmm[1], hh[1]);
-            } else if (ROOT && rk == 7) {
-                rooted = true;
-                ee[0] = wl_round_root<7>(rows8, rt, ww[0], base2, span2, n, rbest[0]);
-                ee[1] = wl_round_root<7>(rows8, rt, ww[1], base2, span2, n, rbest[1]);
-            } else if (ROOT && rk == 4) {
-                rooted = true;
-                ee[0] = wl_round_root<4>(rows8, rt, ww[0], base2, span2, n, rbest[0]);
-                ee[1] = wl_round_root<4>(rows8, rt, ww[1], base2, span2, n, rbest[1]);
-            } else {
-                ee[0] = wl_round<STATE, false>(rows8, ww[0], nv[0], base2, span2, span4, 0u, tmm[0], hh[0]);
-                ee[1] = wl_round<STATE, false>(rows8, ww[1], nv[1], base2, span2, span4, 0u, tmm[1], hh[1]);
-            }
+                for (int k = 0; k < 4; ++k) {
+                    e[2 * k] = *reinterpret_cast<const uint32_t *>(rt8 + (A[k] & 0xffffu));
+                    e[2 * k + 1] = *reinterpret_cast<const uint32_t *>(rt8 + (A[k] >> 16));
+                }
+                Units8 lens; // byte 2 of an entry = longest keyword among the RK steps
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                uint32_t best = 0, best_e = 0;
-                if (rooted) best = rbest[h];
-                else round_best(tmm[h], 0u, hh[h], best, best_e);
-                const uint32_t off16 = ee[h] & 0xffffu;
-                const bool alive = in[h] && off16 < real_bytes;
-                const uint32_t prel = pp[h] - chunk0;
-                uint32_t reach = 0;
-                if (in[h] && !alive) reach = finish(pp[h], prel, off16, best, best_e, false);
-                reach = wave_max_dpp(reach); // (no survivor has touched this block's maximum yet: a plain store)
-                if (lane == 0 && s0 + h * kWave < chunk_end) bm[(s0 + h * kWave - chunk0) >> 6] = reach;
-                append(alive, ee[h], best, best_e, prel, 8u);
-                __builtin_amdgcn_wave_barrier();
-                while (wl_n >= (uint32_t)kWave) list_round(chunk0, check); // fewer than 64 entries are left: the next append fits
+                for (int k = 0; k < 4; ++k) lens.d[k] = __builtin_amdgcn_perm(e[2 * k + 1], e[2 * k], 0x0c060c02u);
+                *reinterpret_cast<Units8 *>(out_len + pb) = lens;
+                const uint32_t prel0 = (pb - chunk0) | (rk << 16);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const bool alive = (int32_t)e[i] < 0;
+                    const uint64_t bal = __ballot(alive);
+                    if (alive) {
+                        const uint32_t at = wl_n + (uint32_t)__popcll(bal & lanemask_lt());
+                        wl0[at] = e[i] & 0x00ffffffu;
+                        wl1[at] = prel0 + (uint32_t)i;
+                    }
+                    wl_n += (uint32_t)__popcll(bal);
+                    __builtin_amdgcn_wave_barrier();
+                    while (wl_n >= (uint32_t)kWave) list_round(chunk0, false);
+                }
+            }
+        } else {
+            if (lane < kWlChunk / 64) bm[lane] = 0;
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t s0 = chunk0; s0 < chunk_end; s0 += 2 * kWave) { // first round: positions s0+lane and s0+64+lane
+                uint32_t pp[2] = {s0 + lane, s0 + kWave + lane};
+                uint32_t ee[2], tmm[2], hh[2][8], ww[2][4], nv[2];
+                bool in[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    in[h] = pp[h] < chunk_end;
+                    load8(in[h] ? pp[h] : chunk0, ww[h], nv[h], check);
+                }
+                // (the two walks are written out side by side: their dependent LDS reads interleave)
+                if (check) {
+                    ee[0] = wl_round<STATE, true>(rows8, ww[0], nv[0], base2, span2, span4, 0u, tmm[0], hh[0]);
+                    ee[1] = wl_round<STATE, true>(rows8, ww[1], nv[1], base2, span2, span4, 0u, tmm[1], hh[1]);
+                } else {
+                    ee[0] = wl_round<STATE, false>(rows8, ww[0], nv[0], base2, span2, span4, 0u, tmm[0], hh[0]);
+                    ee[1] = wl_round<STATE, false>(rows8, ww[1], nv[1], base2, span2, span4, 0u, tmm[1], hh[1]);
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    uint32_t best = 0, best_e = 0;
+                    round_best(tmm[h], 0u, hh[h], best, best_e);
+                    const uint32_t off16 = ee[h] & 0xffffu;
+                    const bool alive = in[h] && off16 < real_bytes;
+                    const uint32_t prel = pp[h] - chunk0;
+                    uint32_t reach = 0;
+                    if (in[h] && !alive) reach = finish(pp[h], prel, off16, best, best_e, false);
+                    reach = wave_max_dpp(reach); // (no survivor has touched this block's maximum yet: a plain store)
+                    if (lane == 0 && s0 + h * kWave < chunk_end) bm[(s0 + h * kWave - chunk0) >> 6] = reach;
+                    append(alive, ee[h], best, best_e, prel, 8u);
+                    __builtin_amdgcn_wave_barrier();
+                    while (wl_n >= (uint32_t)kWave) list_round(chunk0, check); // fewer than 64 entries are left: the next append fits
+                }
             }
         }
         while (wl_n) list_round(chunk0, check);
@@ -574,7 +607,7 @@ size_t longest_list_lds_bytes(bool state) { return (size_t)(kLScanBlock / kWave)
 uint32_t longest_list_max_rows(uint32_t n_cls, bool state) {
     return n_cls ? (uint32_t)(state ? kWlRowWordsMap : kWlRowWordsSet) / n_cls - 2u : 0u;
 }
-static_assert(2187 <= kWlRootWords && 625 <= kWlRootWords, "root table: 3^7 and 5^4 entries");
+static_assert(6561 <= kWlRootWords && 625 <= kWlRootWords, "root table: 3^8 and 5^4 entries");
 
 hipError_t launch_longest_scan(const DevTables &t, const LongestScanLaunch &l, hipStream_t stream, const char **kernel_name) {
 #define ACGPU_LAUNCH(KERNEL, NAME)                                                                                      \
