@@ -34,10 +34,10 @@ DEFAULTS = {"chunk_units": 0, "lds_table_bytes": 96 * 1024, "force_sparse": 0, "
             "rdense_budget_bytes": 256 << 20}
 
 
-def dev_match(a, d_hay, n, cap, **kw):
+def dev_match(a, d_hay, n, cap, with_ids=True, **kw):
     while True:
-        d_out = torch.empty((max(cap, 1), 3), dtype=torch.int32, device="cuda")
-        n_out, rc, _, ex = a.match_device(d_hay.data_ptr(), n, True, d_out.data_ptr(), cap, **kw)
+        d_out = torch.empty((max(cap, 1), 3 if with_ids else 2), dtype=torch.int32, device="cuda")
+        n_out, rc, _, ex = a.match_device(d_hay.data_ptr(), n, with_ids, d_out.data_ptr(), cap, **kw)
         if rc == N.E_OVERFLOW:
             cap = n_out
             continue
@@ -58,6 +58,13 @@ def one_case(rng, it):
         kw_alpha = alpha
     kws = [np.array(rng.choice(kw_alpha, int(rng.integers(min_len, max_len + 1))), dtype=np.uint16) for _ in range(n_kw)]
     n = int(rng.choice([0, 1, 7, 63, 1000, 4097, 70001, 300007]))
+    if fam == 1 and len(alpha) <= 3 and rng.integers(0, 2):
+        # config 4's shape: all prefixes of a few long words (deep walks: root table, work lists, DEEP rows)
+        kws = []
+        for _ in range(int(rng.integers(1, 6))):
+            w = np.array(rng.choice(alpha, int(rng.integers(5, 400))), dtype=np.uint16)
+            kws += [w[:k].copy() for k in range(1, len(w) + 1)]
+        n_kw, min_len, max_len = len(kws), 1, max(len(k) for k in kws)
     hay = np.array(rng.choice(alpha, n), dtype=np.uint16) if n else np.zeros(0, np.uint16)
     if n > 100 and rng.integers(0, 2):  # plant keywords so that deep matches occur
         for _ in range(int(rng.integers(1, 50))):
@@ -84,10 +91,13 @@ def one_case(rng, it):
     wc = WORD if fam in (2, 4) else None
     a = Automaton(mode, kws, cs, word_chars=wc)
     want = Oracle(ofam, kws, case_sensitive=cs, lower=LOWER, word_chars=wc).match(hay)
-    got = a.match_host(hay, True, cap=64)
-    desc = (it, fam, cs, n_kw, min_len, max_len, n, len(alpha), knobs, a.info()["filter_k"], a.info()["tile_kernel"])
+    with_ids = bool(rng.integers(0, 3))  # one case in three runs the Set flavour (8-byte records)
+    if not with_ids:
+        want = np.ascontiguousarray(want[:, :2])
+    got = a.match_host(hay, with_ids, cap=64)
+    desc = (it, fam, cs, with_ids, n_kw, min_len, max_len, n, len(alpha), knobs, a.info()["filter_k"], a.info()["tile_kernel"])
     assert got.shape == want.shape and (got == want).all(), ("host path", desc)
-    if n >= 1000 and fam != 4:
+    if n >= 1000:
         # shards of the device-resident buffer
         d_hay = torch.from_numpy(hay.view(np.int16)).cuda()
         cuts = sorted(set([0, n] + [int(x) for x in rng.integers(1, n, 2)]))
@@ -96,12 +106,12 @@ def one_case(rng, it):
             kw = dict(own=(lo, hi))
             if fam == 1:
                 kw["chain_entry"] = max(entry, lo)
-            if fam == 3:
+            if fam in (3, 4):
                 kw["chain_entry"] = entry
-            p, ex = dev_match(a, d_hay, n, 64, **kw)
+            p, ex = dev_match(a, d_hay, n, 64, with_ids, **kw)
             entry = ex
             parts.append(p)
-        cat = np.concatenate(parts) if parts else np.zeros((0, 3), np.int32)
+        cat = np.concatenate(parts) if parts else np.zeros((0, want.shape[1]), np.int32)
         assert cat.shape == want.shape and (cat == want).all(), ("shards", cuts, desc)
     return fam
 
