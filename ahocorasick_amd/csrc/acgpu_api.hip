@@ -683,14 +683,18 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
     // lengths through LDS in chunks (k_longest_chain_lds).  Tunable tile_debug, for A/B: bit 65536 = the serial write pass
     // instead of bitmap + emit, bit 131072 = the count/write passes that read the lengths from global memory.
     Cn.d_bits = nullptr;
+    Cn.d_ebits = nullptr;
     Cn.len_units = (uint32_t)sh->n_units;
     const bool serial_write = (tunables().tile_debug & 65536) != 0;
     const bool chain_lds = Cn.len_bytes == 2 && !(tunables().tile_debug & 131072);
     if (!serial_write) {
         const size_t bit_bytes = ((size_t)sh->n_units / 128 + 2) * 16; // whole groups of four words (16-byte stores)
-        if ((rc = d.chainbits.ensure(bit_bytes))) return rc;
+        // (a second bitmap of match ends for the emit pass; tile_debug bit 524288: without it, the emit pass looks lengths up)
+        const bool end_bits = chain_lds && !(tunables().tile_debug & 524288);
+        if ((rc = d.chainbits.ensure(bit_bytes * (end_bits ? 2 : 1)))) return rc;
         Cn.d_bits = (uint32_t *)d.chainbits.p;
-        HIP_TRY(hipMemsetAsync(d.chainbits.p, 0, bit_bytes, stream));
+        if (end_bits) Cn.d_ebits = Cn.d_bits + bit_bytes / 4;
+        HIP_TRY(hipMemsetAsync(d.chainbits.p, 0, bit_bytes * (end_bits ? 2 : 1), stream));
     }
     HIP_TRY(launch_longest_sync(Cn, d_sync, stream));
     if (chain_lds) HIP_TRY(launch_longest_chain_lds(Cn, d_sync, /*write_pass=*/false, stream));

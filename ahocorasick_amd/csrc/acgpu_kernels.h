@@ -171,6 +171,9 @@ struct LongestChainLaunch {
     uint32_t len_units;         // entries of d_len that hold lengths (the chain passes through LDS read whole chunks)
     uint32_t *d_bits;           // one bit per buffer position: set by the count pass where a match is reported (zeroed by the
                                 // caller), read by k_longest_emit; nullptr: the serial write pass is used instead
+    uint32_t *d_ebits;          // optional second bitmap (zeroed by the caller): bit end-1 of every reported match.  Matches do
+                                // not overlap, so the k-th set bit of d_bits and the k-th of d_ebits are one record and the
+                                // emit pass needs no length lookups (16-bit lengths through k_longest_chain_lds only)
 };
 hipError_t launch_longest_sync(const LongestChainLaunch &l, uint32_t *d_sync, hipStream_t stream);
 hipError_t launch_longest_chain(const LongestChainLaunch &l, const uint32_t *d_sync, bool write_pass, hipStream_t stream);

@@ -686,10 +686,34 @@ __global__ __launch_bounds__(256) void k_longest_sync(LongestChainLaunch L, uint
         const uint32_t b = (q - L.own_begin) >> 6;
         const uint32_t bend = min(tb, L.own_begin + ((b + 1) << 6));
         if (L.d_blockmax[b] >= tb) {
-            for (; q < bend && ok; ++q) {
-                const uint32_t l = (uint32_t)len[q];
-                const uint32_t land = q + (l > 0 ? l : 1u);
-                if (land >= tb) insert(land);
+            if (sizeof(LenT) == 2 && bend >= L.own_begin + 64u) {
+                // the 64 lengths below bend in eight independent 16-byte loads (one memory latency for the block, not 64);
+                // which positions land at or beyond the tile start is decided in registers, only those are inserted
+                const uint32_t b0 = bend - 64u;
+                Units8 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const Units8 *>(reinterpret_cast<const uint16_t *>(len) + b0 + 8 * j);
+                uint64_t hit = 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const uint32_t pos = b0 + 8u * j + i;
+                        const uint32_t l = (v[j].d[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+                        if (pos >= q && pos + (l > 0 ? l : 1u) >= tb) hit |= 1ull << (8 * j + i);
+                    }
+                while (hit && ok) {
+                    const uint32_t pos = b0 + (uint32_t)__builtin_ctzll(hit);
+                    hit &= hit - 1;
+                    const uint32_t l = (uint32_t)len[pos];
+                    insert(pos + (l > 0 ? l : 1u));
+                }
+            } else {
+                for (; q < bend && ok; ++q) {
+                    const uint32_t l = (uint32_t)len[q];
+                    const uint32_t land = q + (l > 0 ? l : 1u);
+                    if (land >= tb) insert(land);
+                }
             }
         }
         q = bend;
@@ -955,14 +979,102 @@ __global__ __launch_bounds__(kEmitBlock) void k_longest_emit(LongestChainLaunch 
     }
 }
 
+// The same with the second bitmap (L.d_ebits: bit end-1 of every match): matches do not overlap, so inside a segment the
+// k-th start and the k-th end are one record and no length is looked up (the lookups were, in effect, a second read of
+// the whole len[] array).  A step covers 1024 positions: lanes 0-31 take the words of the starts, lanes 32-63 the words of
+// the ends; at most one match is open across a step boundary (its start is carried in slot 0).  The last segment of the
+// owned range looks for its last end up to max_len positions beyond the range.
+template <int REC>
+__global__ __launch_bounds__(kEmitBlock, 8) void k_longest_emit_ends(LongestChainLaunch L, const uint32_t *S) {
+    // staged positions are relative to the step's first position (16 bits: 4 KB per wave, so that 32 waves share a CU and
+    // hide each other's start-up loads); the start carried over a step boundary lives in a scalar register
+    constexpr int kCap = 1024 + 8;
+    __shared__ uint16_t st_x[kEmitBlock / kWave][kCap], st_y[kEmitBlock / kWave][kCap];
+    __shared__ int st_id[REC == ACGPU_REC_MAP ? kEmitBlock / kWave : 1][REC == ACGPU_REC_MAP ? kCap : 1];
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const uint32_t t = blockIdx.x * (kEmitBlock / kWave) + wave;
+    if (t >= L.n_tiles) return;
+    const uint32_t lane = lane_id();
+    // (the three start-up loads are independent: one memory latency, not three)
+    const uint32_t s_here = S[t], s_next = t + 1 < L.n_tiles ? S[t + 1] : ~0u;
+    uint64_t base = L.d_offsets[t];
+    const uint32_t start = __builtin_amdgcn_readfirstlane(s_here);
+    if (start == ~0u || start >= L.own_end) return;
+    uint32_t target = L.own_end; // the next synchronisation point on the chain (the segment ends before it)
+    {
+        uint32_t v = __builtin_amdgcn_readfirstlane(s_next);
+        for (uint32_t t2 = t + 2; v == ~0u && t2 < L.n_tiles; ++t2) v = __builtin_amdgcn_readfirstlane(S[t2]);
+        if (v != ~0u) target = min(v, L.own_end);
+    }
+    const uint32_t e_end = target >= L.own_end ? (uint32_t)min((uint64_t)L.len_units, (uint64_t)L.own_end + L.max_len) : target;
+    const uint32_t half = lane >> 5; // 0: starts, 1: ends
+    const uint32_t *bitmap = half ? L.d_ebits : L.d_bits;
+    const uint32_t my_end = half ? e_end : target; // this half looks at positions [start, my_end)
+    const uint32_t w_first = start >> 5, w_last_all = (e_end - 1u) >> 5, w_last = (my_end - 1u) >> 5;
+    uint16_t *sx = st_x[wave], *sy = st_y[wave];
+    uint16_t *mine = half ? sy : sx; // (one store for both halves: no divergent branch in the loop)
+    uint32_t carry = 0, carry_start = 0, carry_id = 0; // wave-uniform: a start whose end has not been seen yet
+    auto load_bits = [&](uint32_t w0) {
+        const uint32_t wi = w0 + (lane & 31u);
+        uint32_t bits = wi <= w_last ? bitmap[wi] : 0u;
+        if (wi == w_first) bits &= ~0u << (start & 31u);
+        if (wi == w_last && (my_end & 31u)) bits &= ~(~0u << (my_end & 31u));
+        return bits;
+    };
+    uint32_t next_bits = load_bits(w_first);
+    for (uint32_t w0 = w_first; w0 <= w_last_all; w0 += 32) {
+        const uint32_t step_base = w0 * 32u;
+        const uint32_t bits = next_bits;
+        if (w0 + 32 <= w_last_all) next_bits = load_bits(w0 + 32); // (in flight under this step's staging and stores)
+        const uint32_t cnt = __popc(bits);
+        const uint32_t incl = wave_inclusive_scan<uint32_t>(cnt);
+        const uint32_t total_m = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31);
+        const uint32_t total_e = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1) - total_m;
+        uint32_t k = incl - cnt + (half ? 0u - total_m : carry);
+        uint32_t b = bits;
+        const uint32_t r0 = (lane & 31u) * 32u + half; // starts: p, ends: p + 1 (relative to the step)
+        while (b) {
+            const uint32_t r = r0 + (uint32_t)__builtin_ctz(b);
+            b &= b - 1u;
+            if (k < (uint32_t)kCap) { // (always, with consistent bitmaps)
+                mine[k] = (uint16_t)r;
+                if (REC == ACGPU_REC_MAP && !half) st_id[wave][k] = (int)L.d_out_id[L.d_state[step_base + r]];
+            }
+            ++k;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t m = min(total_e, carry + total_m); // records complete after this step
+        for (uint32_t j = lane; j < m; j += kWave) {
+            const uint64_t dst = base + j;
+            if (dst >= L.cap) break;
+            const bool carried = carry && j == 0;
+            const int x = (int)(carried ? carry_start : step_base + sx[j]), y = (int)(step_base + sy[j]);
+            if (REC == ACGPU_REC_SET) {
+                reinterpret_cast<int2 *>(L.d_out)[dst] = make_int2(x, y);
+            } else {
+                int32_t *o = reinterpret_cast<int32_t *>(L.d_out) + dst * 3;
+                o[0] = x; o[1] = y; o[2] = carried ? (int)carry_id : st_id[wave][j];
+            }
+        }
+        const uint32_t open = carry + total_m - m; // 0 or 1
+        if (open && !(carry && m == 0)) {           // the open start is this step's last one (slot m)
+            carry_start = __builtin_amdgcn_readfirstlane(step_base + sx[m]);
+            if (REC == ACGPU_REC_MAP) carry_id = __builtin_amdgcn_readfirstlane((uint32_t)st_id[wave][m]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        carry = open ? 1u : 0u;
+        base += m;
+    }
+}
+
 // ---- chain passes through LDS --------------------------------------------------------------------------------------------
 // k_longest_chain waits for global memory once per 16 positions of its (serial) chain: ~250 dependent round trips per lane,
 // 0.46 ms per pass at config 4 with every wave of the grid resident.  Here a lane still follows its own segment, but the
 // lengths come through LDS in chunks of 256 positions: a lane requests its whole chunk at once (32 independent 16-byte
 // loads: one memory latency per 256 positions instead of one per 16) and then walks it with LDS reads.  The walk is cheap
 // enough to run twice -- count, (prefix sum), write -- without the bitmap and the separate emit pass.
-constexpr int kC2Chunk = 256; // positions per lane and chunk: 32 pieces of 8 lengths; piece j of all lanes is one LDS-DMA
-                              // instruction (global_load_lds_dwordx4: lane i's 16 bytes land at piece base + 16 i)
+constexpr int kC2Chunk = 256; // positions per lane and chunk: 32 pieces of 8 lengths = 512 bytes, loaded by one half wave
+                              // of one LDS-DMA instruction (global_load_lds_dwordx4: lane i's 16 bytes land at base + 16 i)
 
 // BITS (count pass): the matches are also marked in the bitmap L.d_bits for k_longest_emit -- collected per chunk in LDS
 // (chunks start on a bitmap word) and merged into the zeroed bitmap with one atomicOr per non-zero word; these stores are
@@ -971,6 +1083,7 @@ template <bool WRITE, bool BITS = false>
 __global__ __launch_bounds__(kWave) void k_longest_chain_lds(LongestChainLaunch L, const uint32_t *S) {
     __shared__ __attribute__((aligned(16))) unsigned char buf[kC2Chunk / 8 * kWave * 16]; // [piece][lane][8 lengths]
     __shared__ uint32_t lbits[BITS ? kC2Chunk / 32 : 1][kWave];
+    __shared__ uint32_t lebits[BITS ? kC2Chunk / 32 + 1 : 1][kWave]; // the ends (bit end-1), when L.d_ebits is there (+ a dummy word)
     __shared__ int2 ring_se[WRITE ? 8 : 1][kWave];
     __shared__ int ring_id[WRITE ? 4 : 1][kWave];
     const uint32_t lane = threadIdx.x;
@@ -1010,23 +1123,46 @@ __global__ __launch_bounds__(kWave) void k_longest_chain_lds(LongestChainLaunch 
             }
         }
     };
-    const unsigned char *mine = buf + lane * 16;
-    // length x of the lane's chunk: piece x >> 3, entry x & 7
-    auto at = [&](uint32_t x) -> const unsigned char * { return mine + (x >> 3) * (kWave * 16) + (x & 7u) * 2u; };
+    // LDS layout: a lane's chunk is contiguous (kC2Chunk * 2 bytes at lane * kC2Chunk * 2), its 16-byte pieces permuted by
+    // piece ^ lane -- the lanes walk their chunks at about the same pace, and without the permutation they would all sit in
+    // the same banks.  Length x of the lane's chunk: piece x >> 3, entry x & 7.
+    constexpr uint32_t kPieces = kC2Chunk / 8, kChunkBytes = kC2Chunk * 2;
+    static_assert(kPieces == 32, "one half wave loads one lane's chunk: 32 pieces of 16 bytes");
+    const unsigned char *mine = buf + lane * kChunkBytes;
+    auto at = [&](uint32_t x) -> const unsigned char * { return mine + (((x >> 3) ^ lane) & (kPieces - 1u)) * 16u + (x & 7u) * 2u; };
     // a chunk starts on a 16-byte boundary of len[]; pieces past its end are read from the last whole piece instead (never
     // consulted: the walk stops at limit <= the end of the owned range; the allocation of len[] has 64 bytes of slack)
     const uint32_t last_piece = L.len_units & ~7u;
+    const bool ebits = BITS && L.d_ebits != nullptr;
+    uint32_t pend = ~0u; // an end beyond the chunk in which its match started: it lies in the first word of the lane's next chunk
     while (__any(active)) {
         const uint32_t cb = pos & (BITS ? ~31u : ~7u);
         if (BITS) {
 #pragma unroll
             for (int w = 0; w < kC2Chunk / 32; ++w) lbits[w][lane] = 0;
-        }
-        if (active) {
+            if (ebits) {
 #pragma unroll
-            for (int j = 0; j < kC2Chunk / 8; ++j) // 32 loads straight into LDS, all in flight together
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(len + min(cb + j * 8, last_piece)),
+                for (int w = 0; w < kC2Chunk / 32; ++w) lebits[w][lane] = 0;
+            }
+        }
+        if (ebits && active && pend != ~0u) { // (an end beyond its chunk lies in the first word of the lane's next chunk)
+            lebits[0][lane] = 1u << (pend & 31u);
+            pend = ~0u;
+        }
+        {
+            // 32 loads straight into LDS, all in flight together.  Load j brings the whole chunks of lanes 2j and 2j+1: one
+            // half wave each, 32 consecutive pieces = 512 contiguous bytes per half (every cache line is requested once and
+            // used whole; a lane asking for its own 16 bytes per load requested each line four times, from 64 places per
+            // instruction: 0.56 ms for the loads alone at config 4)
+            const uint32_t my_piece = lane & (kPieces - 1u), half = lane >> 5;
+#pragma unroll
+            for (int j = 0; j < kWave / 2; ++j) {
+                const uint32_t cb0 = (uint32_t)__builtin_amdgcn_readlane((int)cb, 2 * j), cb1 = (uint32_t)__builtin_amdgcn_readlane((int)cb, 2 * j + 1);
+                const uint32_t owner = 2u * j + half;
+                const uint32_t src = (half ? cb1 : cb0) + ((my_piece ^ owner) & (kPieces - 1u)) * 8u;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(len + min(src, last_piece)),
                                                  (__attribute__((address_space(3))) void *)(buf + j * (kWave * 16)), 16, 0, 0);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
@@ -1035,7 +1171,15 @@ __global__ __launch_bounds__(kWave) void k_longest_chain_lds(LongestChainLaunch 
             while (pos < limit && pos < cend) {
                 const uint32_t l = *reinterpret_cast<const uint16_t *>(at(pos - cb));
                 if (l > 0) {
-                    if (BITS) lbits[(pos - cb) >> 5][lane] |= 1u << (pos & 31u);
+                    // (branch free: LDS ors without return; only the LAST match of a chunk can end beyond it -- its bit goes
+                    // to a dummy word and the position into `pend`)
+                    if (BITS) atomicOr(&lbits[(pos - cb) >> 5][lane], 1u << (pos & 31u));
+                    if (ebits) {
+                        const uint32_t e = pos + l - 1u;
+                        const bool in = e < cend;
+                        atomicOr(&lebits[in ? (e - cb) >> 5 : (uint32_t)(kC2Chunk / 32)][lane], 1u << (e & 31u));
+                        pend = in ? pend : e;
+                    }
                     if (WRITE) {
                         const uint32_t k = (uint32_t)dst & gmask;
                         ring_se[k][lane] = make_int2((int)pos, (int)(pos + l));
@@ -1078,27 +1222,35 @@ __global__ __launch_bounds__(kWave) void k_longest_chain_lds(LongestChainLaunch 
                 }
             }
             if (BITS) { // words wholly inside the segment are this lane's own (plain stores); the two at its ends may be shared
-                uint32_t bw[kC2Chunk / 32];
+                if (ebits && pend != ~0u && ((pend + 1u) & 31u) == 0) { // a word between this lane's chunks: nobody stores it
+                    atomicOr(&L.d_ebits[pend >> 5], 0x80000000u);
+                    pend = ~0u;
+                }
+                auto store_bits = [&](const uint32_t (*lb)[kWave], uint32_t *bitmap) {
+                    uint32_t bw[kC2Chunk / 32];
 #pragma unroll
-                for (int w = 0; w < kC2Chunk / 32; ++w) bw[w] = lbits[w][lane];
-                uint32_t *dstw = L.d_bits + (cb >> 5);
-                if (cb >= start && cb + kC2Chunk <= limit) {
-                    uint4 *d4 = reinterpret_cast<uint4 *>(dstw); // (cb is a multiple of 32 positions, not of 128: 4-byte aligned only)
-                    if ((cb & 127u) == 0) {
-                        d4[0] = make_uint4(bw[0], bw[1], bw[2], bw[3]);
-                        d4[1] = make_uint4(bw[4], bw[5], bw[6], bw[7]);
+                    for (int w = 0; w < kC2Chunk / 32; ++w) bw[w] = lb[w][lane];
+                    uint32_t *dstw = bitmap + (cb >> 5);
+                    if (cb >= start && cb + kC2Chunk <= limit) {
+                        uint4 *d4 = reinterpret_cast<uint4 *>(dstw); // (cb is a multiple of 32 positions, not of 128: 4-byte aligned only)
+                        if (kC2Chunk >= 128 && (cb & 127u) == 0) {
+#pragma unroll
+                            for (int g = 0; g < kC2Chunk / 128; ++g) d4[g] = make_uint4(bw[4 * g], bw[4 * g + 1], bw[4 * g + 2], bw[4 * g + 3]);
+                        } else {
+#pragma unroll
+                            for (int w = 0; w < kC2Chunk / 32; ++w) dstw[w] = bw[w];
+                        }
                     } else {
 #pragma unroll
-                        for (int w = 0; w < kC2Chunk / 32; ++w) dstw[w] = bw[w];
+                        for (int w = 0; w < kC2Chunk / 32; ++w) {
+                            const uint32_t wp = cb + 32u * w;
+                            if (wp >= start && wp + 32u <= limit) dstw[w] = bw[w];
+                            else if (bw[w]) atomicOr(&dstw[w], bw[w]);
+                        }
                     }
-                } else {
-#pragma unroll
-                    for (int w = 0; w < kC2Chunk / 32; ++w) {
-                        const uint32_t wp = cb + 32u * w;
-                        if (wp >= start && wp + 32u <= limit) dstw[w] = bw[w];
-                        else if (bw[w]) atomicOr(&dstw[w], bw[w]);
-                    }
-                }
+                };
+                store_bits(lbits, L.d_bits);
+                if (ebits) store_bits(lebits, L.d_ebits);
             }
             if (pos >= limit) active = false;
         }
@@ -1111,6 +1263,7 @@ __global__ __launch_bounds__(kWave) void k_longest_chain_lds(LongestChainLaunch 
         } else {
             L.d_counts[t] = count;
             if (pos >= L.own_end) *L.d_exit = pos; // exactly one lane's segment crosses the end of the owned range
+            if (ebits && pend != ~0u) atomicOr(&L.d_ebits[pend >> 5], 1u << (pend & 31u)); // (the segment ended before that chunk)
         }
     }
 }
@@ -1151,7 +1304,10 @@ hipError_t launch_longest_emit(const LongestChainLaunch &l, const uint32_t *d_sy
     if (l.n_tiles == 0) return hipSuccess;
     const dim3 grid((l.n_tiles + kEmitBlock / kWave - 1) / (kEmitBlock / kWave)), block(kEmitBlock);
     const bool set_kind = l.record_kind == ACGPU_REC_SET;
-    if (l.len_bytes == 2) {
+    if (l.d_ebits) {
+        if (set_kind) hipLaunchKernelGGL((k_longest_emit_ends<ACGPU_REC_SET>), grid, block, 0, stream, l, d_sync);
+        else hipLaunchKernelGGL((k_longest_emit_ends<ACGPU_REC_MAP>), grid, block, 0, stream, l, d_sync);
+    } else if (l.len_bytes == 2) {
         if (set_kind) hipLaunchKernelGGL((k_longest_emit<uint16_t, ACGPU_REC_SET>), grid, block, 0, stream, l, d_sync);
         else hipLaunchKernelGGL((k_longest_emit<uint16_t, ACGPU_REC_MAP>), grid, block, 0, stream, l, d_sync);
     } else {
