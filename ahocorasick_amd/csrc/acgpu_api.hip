@@ -262,8 +262,12 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
     hipEvent_t *ev = tk ? tk->ev : d.ev;
     const bool timed = tk ? tk->profiled : prof != nullptr;
     const uint64_t own_len = sh->own_end - sh->own_begin;
-    const uint32_t halo = t.max_len > 0 ? t.max_len - 1 : 0;
+    // WHOLEWORD (fold-consistent tables) is the same pipeline around another scan kernel: run starts instead of K-gram
+    // candidates, ranks by match start, halos of 1 unit on the left and max_len + 1 on the right
+    const bool ww = t.mode == ACGPU_MODE_WHOLEWORD;
+    const uint32_t halo = ww ? 1u : (t.max_len > 0 ? t.max_len - 1 : 0);
     if (!sh->text_begin && sh->own_begin < halo) return ACGPU_E_INVALID; // left halo too short
+    if (ww && !sh->text_end && sh->n_units - sh->own_end < (uint64_t)t.max_len + 1) return ACGPU_E_INVALID; // right halo
     if (prof) {
         std::memset(prof, 0, sizeof(*prof));
     }
@@ -294,7 +298,9 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
     // the tile kernel reserves scratch slots 256 at a time per wave: head-room for the unused tails; a quarter more than
     // the caller's capacity so that the scratch slices (one per workgroup) tolerate unevenly spread matches
     uint64_t scratch_cap = std::min<uint64_t>(
-        std::max<uint64_t>(cap, 1) + cap / 4 + (uint64_t)d.n_cu * (tile_block_threads() / 64) * tile_reserve_slots(), 0xffffffe0ull);
+        std::max<uint64_t>(cap, 1) + cap / 4 +
+            (uint64_t)d.n_cu * (ww ? ww_blocks_per_cu() : 1) * (tile_block_threads() / 64) * tile_reserve_slots(),
+        0xffffffe0ull);
     if ((rc = d.scratch.ensure(scratch_cap * sizeof(ScratchRec)))) return rc;
     if (!d.cclean[cs]) HIP_TRY(hipMemsetAsync(counters, 0, counter_bytes, stream)); // (normally zeroed by the previous call's permute pass)
     // from here on this set is in use; the other set only counts as clean once the permute pass that zeroes it has been
@@ -308,7 +314,54 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
     const uint32_t *id_map = nullptr;
     bool split = false, fused_finalize = false;
     uint32_t regions_per_wg = 0;
-    if (use_tile_kernel(t)) {
+    int by_start = 0;
+    if (ww) {
+        TileLaunch L{};
+        L.block = tile_block_threads();
+        const int waves_per_block = L.block / 64;
+        // regions as large as still gives every wave one (fewer forced drains: 65536 against 16384 units -2 % at config 5's share)
+        const uint64_t ww_waves = (uint64_t)d.n_cu * ww_blocks_per_cu() * waves_per_block;
+        uint64_t R = tunables().region_units > 0 ? (uint64_t)tunables().region_units
+                     : own_len >= 65536 * ww_waves ? 65536 : own_len >= 32768 * ww_waves ? 32768 : 16384;
+        { const uint64_t g = tile_group_units(); R = std::max<uint64_t>(g, (R + g - 1) / g * g); }
+        L.region_units = (uint32_t)R;
+        const uint64_t base8 = sh->own_begin & ~7ull;
+        L.n_regions = (uint32_t)((sh->own_end - base8 + R - 1) / R);
+        L.regions_per_wave = (uint32_t)((L.n_regions + ww_waves - 1) / ww_waves);
+        const uint64_t waves_used = ((uint64_t)L.n_regions + L.regions_per_wave - 1) / L.regions_per_wave;
+        L.grid = (int)((waves_used + waves_per_block - 1) / waves_per_block);
+        perm_base = (uint32_t)base8;
+        by_start = 1;
+        L.d_hay = sh->d_hay;
+        L.n_units = (uint32_t)sh->n_units;
+        L.own_begin = (uint32_t)sh->own_begin;
+        L.own_end = (uint32_t)sh->own_end;
+        L.cap = scratch_cap;
+        L.lds_bytes = ww_lds_bytes(L.block, d.T);
+        L.debug = (uint32_t)tunables().tile_debug | (tunables().force_kernel == 1 ? 256u : 0u); // 256: trie-walk verification
+        L.d_overflow = overflow_word;
+        // one scratch slice and slot counter per workgroup (config 5 emits 15 M records per shard: 60 k reservations that one
+        // counter would serve at under 100 per microsecond); a slice that fills up -> redo with one slice
+        if (!fused_only && L.grid > 1 && !(L.debug & 16384u)) {
+            n_slices = (uint32_t)std::min<int>(L.grid, kMaxSlices);
+            slice_slots = scratch_cap / n_slices;
+        }
+        L.n_slices = n_slices;
+        L.slice_slots = (uint32_t)slice_slots;
+        if ((rc = d.chunk_counts.ensure((size_t)L.n_regions * 4))) return rc;
+        if ((rc = d.offsets.ensure((size_t)L.n_regions * 8))) return rc;
+        if ((rc = d.scan_tmp.ensure(((size_t)L.n_regions / 2048 + 2) * 8))) return rc;
+        L.d_scratch = (ScratchRec *)d.scratch.p;
+        L.d_counter = counters;
+        L.d_region_counts = (uint32_t *)d.chunk_counts.p;
+        HIP_TRY(hipMemsetAsync(d.chunk_counts.p, 0, (size_t)L.n_regions * 4, stream));
+        if (timed) HIP_TRY(hipEventRecord(ev[0], stream));
+        HIP_TRY(launch_ww_tile(d.T, L, stream, &kname));
+        if (timed) HIP_TRY(hipEventRecord(ev[1], stream));
+        n_chunks = L.n_regions;
+        chunk_units = L.region_units;
+        scanned = own_len;
+    } else if (use_tile_kernel(t)) {
         TileLaunch L{};
         L.block = tile_block_threads();
         const int waves_per_block = L.block / 64;
@@ -484,8 +537,8 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
                                   n_chunks, regions_per_wg, perm_base, chunk_units, record_kind, d_out, cap, id_map, stream, &tail));
     else
         HIP_TRY(launch_permute((const ScratchRec *)d.scratch.p, counters, n_slices, slice_slots,
-                               (const uint64_t *)d.offsets.p, perm_base, chunk_units,
-                               /*by_start=*/0, record_kind, d_out, cap, id_map, stream, &tail));
+                               (const uint64_t *)d.offsets.p, perm_base, chunk_units, by_start, record_kind, d_out, cap, id_map,
+                               stream, &tail));
     d.cclean[1 - cs] = true; // zeroed by the pass just launched
     d.cset = 1 - cs;
     if (timed) HIP_TRY(hipEventRecord(ev[2], stream));
@@ -721,10 +774,10 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
     return *n_out > cap ? ACGPU_E_OVERFLOW : ACGPU_OK;
 }
 
-// WHOLEWORD-mode pipeline on one shard.
-int match_wholeword(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_kind, void *d_out, uint64_t cap,
-                    uint64_t *n_out, hipStream_t stream, acgpu_profile *prof, bool one_slice = false) {
-    const HostTables &t = a->t;
+// WHOLEWORD with a word-character table that is not fold-consistent: the reference's mixed folded/raw lookups make
+// token boundaries history dependent -- whole text, one lane (k_ww_sequential).  (Fold-consistent tables: match_all.)
+int match_wholeword_sequential(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_kind, void *d_out, uint64_t cap,
+                               uint64_t *n_out, hipStream_t stream, acgpu_profile *prof) {
     const uint64_t own_len = sh->own_end - sh->own_begin;
     if (prof) std::memset(prof, 0, sizeof(*prof));
     if (own_len == 0) {
@@ -732,95 +785,23 @@ int match_wholeword(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int rec
         return ACGPU_OK;
     }
     int rc;
-    const size_t counter_bytes = (size_t)kMaxSlices * kCounterStride * 8;
-    if ((rc = d.counter.ensure(counter_bytes))) return rc;
-    HIP_TRY(hipMemsetAsync(d.counter.p, 0, counter_bytes, stream));
+    if ((rc = d.counter.ensure(64))) return rc;
+    HIP_TRY(hipMemsetAsync(d.counter.p, 0, 64, stream));
     d.cclean[0] = false; // (match_all's first set of slot counters lives here)
-    if (!t.fold_consistent) {
-        // the reference's mixed folded/raw lookups make token boundaries history dependent: whole text, one lane
-        if (!sh->text_begin || !sh->text_end || sh->own_begin != 0 || sh->own_end != sh->n_units) return ACGPU_E_UNSUPPORTED;
-        if (prof) HIP_TRY(hipEventRecord(d.ev[0], stream));
-        HIP_TRY(launch_ww_sequential(d.T, sh->d_hay, (uint32_t)sh->n_units, d_out, cap, record_kind,
-                                     (unsigned long long *)d.counter.p, stream));
-        if (prof) HIP_TRY(hipEventRecord(d.ev[1], stream));
-        HIP_TRY(hipMemcpyAsync(d.h_counter, d.counter.p, 8, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        *n_out = *d.h_counter;
-        if (prof) {
-            HIP_TRY(hipEventElapsedTime(&prof->scan_ms, d.ev[0], d.ev[1]));
-            prof->total_ms = prof->scan_ms;
-            prof->scan_units = own_len;
-            prof->n_matches = *n_out;
-            std::snprintf(prof->scan_kernel, sizeof(prof->scan_kernel), "k_ww_sequential");
-        }
-        return *n_out > cap ? ACGPU_E_OVERFLOW : ACGPU_OK;
-    }
-    if (!sh->text_begin && sh->own_begin < 1) return ACGPU_E_INVALID;                              // left context: 1 unit
-    if (!sh->text_end && sh->n_units - sh->own_end < (uint64_t)t.max_len + 1) return ACGPU_E_INVALID; // right halo
-    // (a quarter more than the caller's capacity: the scratch is cut into one slice per workgroup, see TileLaunch::n_slices)
-    const uint64_t scratch_cap = std::min<uint64_t>(
-        std::max<uint64_t>(cap, 1) + cap / 4 + (uint64_t)d.n_cu * ww_blocks_per_cu() * (tile_block_threads() / 64) * tile_reserve_slots(),
-        0xffffffe0ull);
-    if ((rc = d.scratch.ensure(scratch_cap * sizeof(ScratchRec)))) return rc;
-    TileLaunch L{};
-    L.block = tile_block_threads();
-    const int waves_per_block = L.block / 64;
-    // regions as large as still gives every wave one (fewer forced drains: 65536 against 16384 units -2 % at config 5's share)
-    const uint64_t ww_waves = (uint64_t)d.n_cu * ww_blocks_per_cu() * waves_per_block;
-    uint64_t R = tunables().region_units > 0 ? (uint64_t)tunables().region_units
-                 : own_len >= 65536 * ww_waves ? 65536 : own_len >= 32768 * ww_waves ? 32768 : 16384;
-    { const uint64_t g = tile_group_units(); R = std::max<uint64_t>(g, (R + g - 1) / g * g); }
-    L.region_units = (uint32_t)R;
-    const uint64_t base8 = sh->own_begin & ~7ull;
-    L.n_regions = (uint32_t)((sh->own_end - base8 + R - 1) / R);
-    const uint64_t waves_max = (uint64_t)d.n_cu * ww_blocks_per_cu() * waves_per_block;
-    L.regions_per_wave = (uint32_t)((L.n_regions + waves_max - 1) / waves_max);
-    const uint64_t waves_used = ((uint64_t)L.n_regions + L.regions_per_wave - 1) / L.regions_per_wave;
-    L.grid = (int)((waves_used + waves_per_block - 1) / waves_per_block);
-    L.d_hay = sh->d_hay;
-    L.n_units = (uint32_t)sh->n_units;
-    L.own_begin = (uint32_t)sh->own_begin;
-    L.own_end = (uint32_t)sh->own_end;
-    L.cap = scratch_cap;
-    L.lds_bytes = ww_lds_bytes(L.block, d.T);
-    L.debug = (uint32_t)tunables().tile_debug | (tunables().force_kernel == 1 ? 256u : 0u); // 256: trie-walk verification
-    if ((rc = d.chunk_counts.ensure((size_t)L.n_regions * 4))) return rc;
-    if ((rc = d.offsets.ensure((size_t)L.n_regions * 8))) return rc;
-    if ((rc = d.scan_tmp.ensure(((size_t)L.n_regions / 2048 + 2) * 8))) return rc;
-    L.d_scratch = (ScratchRec *)d.scratch.p;
-    L.d_counter = (unsigned long long *)d.counter.p;
-    L.d_overflow = (uint32_t *)d.counter.p + 8;
-    // one scratch slice and slot counter per workgroup (config 5 emits 15 M records per shard: 60 k reservations that one
-    // counter would serve at under 100 per microsecond); a slice that fills up -> redo with one slice
-    L.n_slices = (one_slice || L.grid < 2 || (L.debug & 16384u)) ? 1u : (uint32_t)std::min<int>(L.grid, kMaxSlices);
-    L.slice_slots = (uint32_t)(scratch_cap / L.n_slices);
-    L.d_region_counts = (uint32_t *)d.chunk_counts.p;
-    HIP_TRY(hipMemsetAsync(d.chunk_counts.p, 0, (size_t)L.n_regions * 4, stream));
+    if (!sh->text_begin || !sh->text_end || sh->own_begin != 0 || sh->own_end != sh->n_units) return ACGPU_E_UNSUPPORTED;
     if (prof) HIP_TRY(hipEventRecord(d.ev[0], stream));
-    const char *kname = "";
-    HIP_TRY(launch_ww_tile(d.T, L, stream, &kname));
+    HIP_TRY(launch_ww_sequential(d.T, sh->d_hay, (uint32_t)sh->n_units, d_out, cap, record_kind,
+                                 (unsigned long long *)d.counter.p, stream));
     if (prof) HIP_TRY(hipEventRecord(d.ev[1], stream));
-    HIP_TRY(launch_exclusive_scan((const uint32_t *)d.chunk_counts.p, L.n_regions, (uint64_t *)d.offsets.p,
-                                  (uint64_t *)d.scan_tmp.p, stream));
-    HIP_TRY(launch_permute((const ScratchRec *)d.scratch.p, (const unsigned long long *)d.counter.p, L.n_slices, L.slice_slots,
-                           (const uint64_t *)d.offsets.p, (uint32_t)base8, L.region_units, /*by_start=*/1, record_kind,
-                           d_out, cap, nullptr, stream));
-    if (prof) HIP_TRY(hipEventRecord(d.ev[2], stream));
-    HIP_TRY(hipMemcpyAsync(d.h_counter, (const uint64_t *)d.scan_tmp.p + scan_tiles_for(L.n_regions), 8,
-                           hipMemcpyDeviceToHost, stream));
-    d.h_counter[1] = 0;
-    if (L.n_slices > 1) HIP_TRY(hipMemcpyAsync(d.h_counter + 1, (const uint32_t *)d.counter.p + 8, 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(d.h_counter, d.counter.p, 8, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
-    if (L.n_slices > 1 && (uint32_t)d.h_counter[1] != 0) // a scratch slice filled up: once more with one slice
-        return match_wholeword(a, d, sh, record_kind, d_out, cap, n_out, stream, prof, true);
     *n_out = *d.h_counter;
     if (prof) {
         HIP_TRY(hipEventElapsedTime(&prof->scan_ms, d.ev[0], d.ev[1]));
-        HIP_TRY(hipEventElapsedTime(&prof->finalize_ms, d.ev[1], d.ev[2]));
-        HIP_TRY(hipEventElapsedTime(&prof->total_ms, d.ev[0], d.ev[2]));
+        prof->total_ms = prof->scan_ms;
         prof->scan_units = own_len;
         prof->n_matches = *n_out;
-        std::snprintf(prof->scan_kernel, sizeof(prof->scan_kernel), "%s", kname);
+        std::snprintf(prof->scan_kernel, sizeof(prof->scan_kernel), "k_ww_sequential");
     }
     return *n_out > cap ? ACGPU_E_OVERFLOW : ACGPU_OK;
 }
@@ -1000,7 +981,8 @@ int match_shard(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_
     if (sh->d_result && ((uintptr_t)sh->d_result & 15)) return ACGPU_E_INVALID;
     if (d.inflight > 0 && stream != d.inflight_stream) return ACGPU_E_INVALID; // stream rule (include/acgpu.h)
     *n_out = 0;
-    if (a->t.mode == ACGPU_MODE_ALL) return match_all(a, d, sh, record_kind, d_out, cap, n_out, stream, prof);
+    if (a->t.mode == ACGPU_MODE_ALL || (a->t.mode == ACGPU_MODE_WHOLEWORD && a->t.fold_consistent))
+        return match_all(a, d, sh, record_kind, d_out, cap, n_out, stream, prof);
     // the other families end with their count on the host (and some run the ALL pipeline inside): the device copy of the
     // result is written behind the pipeline
     acgpu_device_result *d_res = reinterpret_cast<acgpu_device_result *>(sh->d_result);
@@ -1008,7 +990,7 @@ int match_shard(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_
     int rc;
     switch (a->t.mode) {
     case ACGPU_MODE_LONGEST: rc = match_longest(a, d, sh, record_kind, d_out, cap, n_out, stream, prof); break;
-    case ACGPU_MODE_WHOLEWORD: rc = match_wholeword(a, d, sh, record_kind, d_out, cap, n_out, stream, prof); break;
+    case ACGPU_MODE_WHOLEWORD: rc = match_wholeword_sequential(a, d, sh, record_kind, d_out, cap, n_out, stream, prof); break;
     case ACGPU_MODE_SHORTEST: rc = match_shortest(a, d, sh, record_kind, d_out, cap, n_out, stream, prof); break;
     case ACGPU_MODE_WWLONGEST: rc = match_wwlongest(a, d, sh, record_kind, d_out, cap, n_out, stream, prof); break;
     default: rc = ACGPU_E_UNSUPPORTED;
@@ -1255,7 +1237,8 @@ int acgpu_match_device_begin(const acgpu_automaton *ca, acgpu_shard *sh, int rec
     if (!ca || !sh || !ticket) return ACGPU_E_INVALID;
     *ticket = nullptr;
     acgpu_automaton *a = const_cast<acgpu_automaton *>(ca);
-    if (a->t.mode != ACGPU_MODE_ALL) return ACGPU_E_UNSUPPORTED; // the other families use the synchronous call
+    // (AhoCorasick and WholeWord with fold-consistent tables: one scan + ordering pass; the other families end on the host)
+    if (a->t.mode != ACGPU_MODE_ALL && !(a->t.mode == ACGPU_MODE_WHOLEWORD && a->t.fold_consistent)) return ACGPU_E_UNSUPPORTED;
     std::lock_guard<std::mutex> lock(a->mu);
     DeviceState *d = nullptr;
     int rc = device_for_call(a, &d);

@@ -30,11 +30,11 @@ Data exchange, and what a step costs the host:
   host sits between the scan and the collective.  gcap follows the largest count seen so far (with head-room); a step
   in which some rank's count exceeds it is detected by every rank from the gathered headers and redone by all of them
   with larger buffers (rare: the first step of a much denser haystack);
-* the AhoCorasick family enqueues its scan with acgpu_match_device_begin and collects it with _end only after the
+* AhoCorasick and WholeWord enqueue their scan with acgpu_match_device_begin and collect it with _end only after the
   gathered headers have arrived on the host: one blocking host synchronisation per step (the header read-back).  With
   overlap=True that read-back is the PREVIOUS step's, so the all-gather of step k runs under the scan of step k+1;
-* Longest / Shortest additionally pay the chain hop (one int64 down the ranks), WholeWord the count read-back of its
-  synchronous scan call.
+* Longest / Shortest / WholeWordLongest additionally pay the chain hop (one int64 down the ranks) and the count
+  read-back of their synchronous scan calls.
 Positions stay shard-local int32 in the gathered buffer and become global int64 positions by adding
 base[g] = g * units_per_rank (global_records()).
 """
@@ -200,8 +200,9 @@ class ShardedMatcher:
         # overlap: step() leaves its all-gather (world > 1) / its scan (world == 1) in flight and returns the PREVIOUS
         # step's result; the all-gather of step k then runs under the scan of step k+1
         self.overlap = bool(overlap)
-        # the AhoCorasick family has the asynchronous form of the native call
-        self.async_scan = scan_fn is None and self.mode == MODE_ALL
+        # AhoCorasick and WholeWord (fold-consistent word-character tables) have the asynchronous form of the native call
+        self.async_scan = scan_fn is None and (self.mode == MODE_ALL or (
+            self.mode == MODE_WHOLEWORD and bool(automaton.info()["fold_consistent"])))
         self.scan_fn = scan_fn
         self._k = 0
         self._inflight = None   # the _Step a previous step() left for the next one (overlap)

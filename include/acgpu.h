@@ -194,7 +194,8 @@ int acgpu_match_device(const acgpu_automaton *a, acgpu_shard *shard, int record_
                        uint64_t *n_out, void *stream, acgpu_profile *prof);
 
 /*
- * Asynchronous form (ACGPU_MODE_ALL): _begin enqueues the whole pipeline on `stream` and returns without waiting;
+ * Asynchronous form (ACGPU_MODE_ALL, and ACGPU_MODE_WHOLEWORD with a fold-consistent word-character table; the other
+ * families end on the host: ACGPU_E_UNSUPPORTED): _begin enqueues the whole pipeline on `stream` and returns without waiting;
  * _end waits for that call only (an event, not the stream) and returns its count / timings.  Up to 4 calls may be in
  * flight per automaton and device.  Lets a host keep the GPU busy across calls: the next scan is queued while the
  * previous count travels back.  want_profile != 0 records the HIP events that _end turns into acgpu_profile.

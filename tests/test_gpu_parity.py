@@ -1247,6 +1247,72 @@ def test_wholeword_scratch_slice_overflow_is_redone_with_one_slice():
     assert got.shape == want.shape and (got == want).all()
 
 
+def test_wholeword_async_begin_end_pipelined_overflow_and_slice_redo():
+    """acgpu_match_device_begin/_end for WHOLEWORD (fold-consistent tables): three calls in flight on one stream equal the
+    synchronous results; too small a capacity is reported by _end with the exact count; a scratch slice that fills up is
+    redone inside _end; a fold-inconsistent table has no asynchronous form."""
+    import torch
+    from oracle.oracle import FAM_WHOLEWORD
+    words = synth.mixed_script_words(1005, 3000)
+    a = Automaton(N.MODE_WHOLEWORD, words, False, lower=LOWER, word_chars=WORD)
+    hays = [synth.mixed_script_haystack(2100 + i, 150000 + 999 * i, words, swapcase_tbl=synth.swapcase_table()) for i in range(3)]
+    d_hays = [torch.from_numpy(h.view(np.int16)).cuda() for h in hays]
+    wants = [Oracle(FAM_WHOLEWORD, words, case_sensitive=False, lower=LOWER, word_chars=WORD).match(h) for h in hays]
+    cap = max(len(w) for w in wants) + 8
+    outs = [torch.empty((cap, 3), dtype=torch.int32, device="cuda") for _ in hays]
+    st = torch.cuda.current_stream().cuda_stream
+    tickets = []
+    for d, o, h in zip(d_hays, outs, hays):
+        tk, rc = a.match_device_begin(d.data_ptr(), h.size, True, o.data_ptr(), cap, stream=st, profile=True)
+        assert rc == N.OK
+        tickets.append(tk)
+    for tk, o, w in zip(tickets, outs, wants):
+        n, rc, prof = a.match_device_end(tk, profile=True)
+        assert rc == N.OK and n == len(w) and len(w) > 3000 and prof["scan_kernel"].startswith("k_ww_tile")
+        assert (o[:n].cpu().numpy() == w).all()
+    tk, rc = a.match_device_begin(d_hays[0].data_ptr(), hays[0].size, True, outs[0].data_ptr(), 5, stream=st)
+    n, rc, _ = a.match_device_end(tk)
+    assert rc == N.E_OVERFLOW and n == len(wants[0])
+    # the device-side result header, and a shard with halos through the asynchronous form
+    buf = torch.zeros(4 + 3 * cap, dtype=torch.int32, device="cuda")
+    ml = a.info()["max_keyword_len"]
+    lo, hi = 40000, 90001
+    base = (lo - 1) // 8 * 8
+    sub = d_hays[1][base:hi + ml + 1].clone()
+    tk, rc = a.match_device_begin(sub.data_ptr(), sub.numel(), True, buf.data_ptr() + 16, cap, own=(lo - base, hi - base),
+                                  text_begin=False, text_end=False, stream=st, d_result=buf.data_ptr())
+    assert rc == N.OK
+    n, rc, _ = a.match_device_end(tk)
+    w = wants[1]
+    w = w[(w[:, 0] >= lo) & (w[:, 0] < hi)].copy()
+    w[:, :2] -= base
+    host = buf.cpu().numpy()
+    assert rc == N.OK and n == len(w) and int(host[0]) == n and int(host[2]) == 0
+    assert (host[4:4 + 3 * n].reshape(n, 3) == w).all()
+    # all words in the first workgroup's share, exact capacity: the slice overflow is redone with one slice inside _end
+    small = ["ab", "abc", "b", "cab"]
+    a2 = Automaton(N.MODE_WHOLEWORD, small, True, word_chars=WORD)
+    n2 = 1 << 22
+    rng = np.random.default_rng(3)
+    hay = np.full(n2, ord(" "), dtype=np.uint16)
+    head = np.array([ord(c) for c in " ".join(small[i] for i in rng.integers(0, len(small), 1 << 16))], dtype=np.uint16)
+    hay[: head.size] = head
+    want = Oracle(FAM_WHOLEWORD, small, word_chars=WORD).match(hay)
+    d_hay = torch.from_numpy(hay.view(np.int16)).cuda()
+    out = torch.empty((len(want), 3), dtype=torch.int32, device="cuda")
+    tk, rc = a2.match_device_begin(d_hay.data_ptr(), n2, True, out.data_ptr(), len(want), stream=st)
+    assert rc == N.OK
+    m, rc, _ = a2.match_device_end(tk)
+    assert rc == N.OK and m == len(want) and (out[:m].cpu().numpy() == want).all()
+    # fold-inconsistent custom table: sequential kernel, synchronous call only
+    wc = np.zeros(65536, np.uint8)
+    for ch in "ABx":
+        wc[ord(ch)] = 1
+    a3 = Automaton(N.MODE_WHOLEWORD, ["A", "AB", "x"], False, lower=LOWER, word_chars=wc)
+    assert a3.info()["fold_consistent"] == 0
+    assert a3.match_device_begin(d_hay.data_ptr(), 4096, True, out.data_ptr(), 16, stream=st)[1] == N.E_UNSUPPORTED
+
+
 @pytest.mark.parametrize("min_len", [2, 4, 6])
 def test_case_insensitive_folded_range_classes(min_len):
     """Case-insensitive dictionaries over a short range of letters take the packed filter with FOLDED range classes: the
