@@ -7,8 +7,8 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 python3 bench.py --steps 20 --warmup 3 > "$OUT/bench_c2.json" 2> "$OUT/bench_c2.err"
-python3 bench.py --config C4 --steps 5 --warmup 1 > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err"
-python3 bench.py --config C5 --steps 5 --warmup 1 > "$OUT/bench_c5.json" 2> "$OUT/bench_c5.err"
+python3 bench.py --config C4 --steps 10 --warmup 2 > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err"
+python3 bench.py --config C5 --steps 20 --warmup 3 > "$OUT/bench_c5.json" 2> "$OUT/bench_c5.err"
 # per-kernel time: the program itself after "--"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c2" -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/stats_c2.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c4" -- python3 bench.py --config C4 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/stats_c4.log" 2>&1
