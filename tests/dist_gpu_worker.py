@@ -5,7 +5,8 @@ collectives through host memory; everything else -- ShardedMatcher, acgpu_match_
 (owned range, halos, chain entry/exit), the gather-buffer header written by the scan's last kernel -- is the code an
 N-GPU job runs.  Test infrastructure: compares with the CPU oracle on the whole text.
 
-usage: dist_gpu_worker.py FAMILY WORLD RANK PORT N_PER_RANK OUTDIR OVERLAP CAP"""
+usage: dist_gpu_worker.py FAMILY WORLD RANK PORT N_PER_RANK OUTDIR OVERLAP CAP [BACKEND]
+(BACKEND nccl: one rank per GPU over RCCL -- only where the box has that many GPUs)"""
 import os
 import sys
 
@@ -53,13 +54,18 @@ def case(family, n_total, variant=0):
 
 def main():
     family, world, rank, port, n, outdir, overlap, cap = sys.argv[1:9]
+    backend = sys.argv[9] if len(sys.argv) > 9 else "gloo"
     world, rank, n, overlap, cap = int(world), int(rank), int(n), int(overlap), int(cap)
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = port
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from ahocorasick_amd.dist import ShardedMatcher
         auto, orc, whole = case(family, n * world)

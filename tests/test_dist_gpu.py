@@ -23,11 +23,11 @@ def _free_port():
     return p
 
 
-def _run(family, world, overlap, cap, tmp_path, n=50000):
+def _run(family, world, overlap, cap, tmp_path, n=50000, backend="gloo"):
     port = str(_free_port())
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, WORKER, family, str(world), str(r), port, str(n), str(tmp_path), str(int(overlap)),
-                               str(cap)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+                               str(cap), backend], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
              for r in range(world)]  # fresh children: nothing that touched the GPU is re-executed
     outs = []
     for p in procs:
@@ -56,3 +56,23 @@ def test_sharded_matcher_native_scan_in_separate_processes(family, world, overla
         assert sum(r[0] for r in res) > 0  # some shard boundary fell inside a match: the window repair ran on the device
     if cap == 64:
         assert all(r[1] > 0 for r in res)  # every rank went through the collective redo
+
+
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count()  # (counting devices does not initialise the GPU in this process)
+
+
+@pytest.mark.parametrize("family,world,overlap,cap", [
+    ("ac", 2, True, 1 << 16), ("ac", 2, True, 64), ("wholeword", 2, True, 1 << 16), ("longest", 2, False, 64),
+    ("shortest", 2, True, 1 << 16), ("wwlongest", 2, False, 1 << 16)])
+def test_sharded_matcher_over_rccl_one_rank_per_gpu(family, world, overlap, cap, tmp_path):
+    """The same workers with backend "nccl" (RCCL): device-to-device halo exchange (batch_isend_irecv of byte views), the
+    asynchronous all-gather of header + records left in flight under the next scan, the chain hop on device tensors.
+    Needs one GPU per rank: skipped on a one-GPU box."""
+    if _n_gpus() < world:
+        pytest.skip("needs %d GPUs" % world)
+    res = _run(family, world, overlap, cap, tmp_path, backend="nccl")
+    assert all(r[2] > 0 for r in res)
+    if cap == 64:
+        assert all(r[1] > 0 for r in res)
