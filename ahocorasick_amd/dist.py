@@ -156,7 +156,7 @@ class _Step:
         self.hdr_host = None   # (world, HDR) int32, pinned when the buffers live on a GPU
         self.event = None      # recorded behind the header read-back
         self.work = None       # the all-gather still in flight (nccl, async)
-        self.ticket = None     # acgpu_match_device_begin ticket (AhoCorasick family)
+        self.ticket = None     # acgpu_match_device_begin ticket (AhoCorasick, WholeWord)
         self.n = None          # local record count when the scan call was synchronous
         self.prof = None
         self.prof_on = False

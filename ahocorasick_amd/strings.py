@@ -138,7 +138,7 @@ class Automaton:
 
     def match_device_begin(self, d_hay_ptr, n_units, with_ids, d_out_ptr, cap, own=None, text_begin=True, text_end=True,
                            stream=0, profile=False, d_result=None):
-        """acgpu_match_device_begin (AhoCorasick family): enqueue without waiting.  Returns (ticket, rc)."""
+        """acgpu_match_device_begin (AhoCorasick; WholeWord with fold-consistent tables): enqueue without waiting.  Returns (ticket, rc)."""
         sh = N.Shard()
         sh.d_result = d_result
         sh.d_hay = d_hay_ptr
