@@ -355,9 +355,30 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         L.d_counter = counters;
         L.d_region_counts = (uint32_t *)d.chunk_counts.p;
         HIP_TRY(hipMemsetAsync(d.chunk_counts.p, 0, (size_t)L.n_regions * 4, stream));
+#ifdef ACGPU_TIMING
+        static DevBuf ww_timing;
+        if ((rc = ww_timing.ensure((size_t)L.grid * 16 * 8 * 8))) return rc;
+        HIP_TRY(hipMemsetAsync(ww_timing.p, 0, (size_t)L.grid * 16 * 8 * 8, stream));
+        L.d_timing = (unsigned long long *)ww_timing.p;
+#endif
         if (timed) HIP_TRY(hipEventRecord(ev[0], stream));
         HIP_TRY(launch_ww_tile(d.T, L, stream, &kname));
         if (timed) HIP_TRY(hipEventRecord(ev[1], stream));
+#ifdef ACGPU_TIMING
+        if (!tk) { // where a wave's time goes (s_memtime ticks, 100 MHz), averaged over the waves
+            HIP_TRY(hipStreamSynchronize(stream));
+            std::vector<unsigned long long> h((size_t)L.grid * 16 * 8);
+            HIP_TRY(hipMemcpy(h.data(), ww_timing.p, h.size() * 8, hipMemcpyDeviceToHost));
+            double sum[8] = {0}; size_t nw = 0;
+            for (size_t w = 0; w < h.size() / 8; ++w) {
+                if (!h[w * 8]) continue;
+                nw++;
+                for (int i = 0; i < 8; ++i) sum[i] += (double)h[w * 8 + i];
+            }
+            if (nw) fprintf(stderr, "[ww timing] waves %zu total %.0f | windows %.0f | chunk1 %.0f | chunk2 %.0f | hash+bloom %.0f | probes %.0f | emission %.0f | calls %.1f\n",
+                            nw, sum[0] / nw, sum[1] / nw, sum[2] / nw, sum[3] / nw, sum[4] / nw, sum[5] / nw, sum[6] / nw, sum[7] / nw);
+        }
+#endif
         n_chunks = L.n_regions;
         chunk_units = L.region_units;
         scanned = own_len;

@@ -305,7 +305,7 @@ constexpr int kWlRowWordsSet = 8768, kWlRowWordsMap = 13312; // (Set: 34.25 KiB 
 // columns in radix n, most of it in packed arithmetic: even and odd columns run through the same two v_pk_mad_u16.
 constexpr int kWlRootWords = 6592; // n = 3 (two letters + "other"): RK = 8 (6561 entries); n <= 5 (DNA): RK = 4
 // entry of the root table: row offset reached | longest keyword among the RK steps << 16 | flags
-constexpr uint32_t kRtAlive = 0x80000000u, kRtDeep = 0x40000000u;
+constexpr uint32_t kRtAlive = 0x80000000u;
 
 __device__ __forceinline__ uint32_t wl_pk_mad(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t r;

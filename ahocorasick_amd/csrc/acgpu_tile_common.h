@@ -46,7 +46,8 @@ struct TileCtx {
     uint16_t *pos16 = nullptr;
     uint32_t pos_base = 0;
 #ifdef ACGPU_TIMING
-    unsigned long long vt[4] = {0, 0, 0, 0}; // verification phases: windows, K-gram nodes, walks, emission
+    unsigned long long vt[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // verification phases (k_ac_tile: windows, K-gram nodes, walks, emission;
+                                                          // k_ww_tile: windows, chunk 1, chunk 2, hash + Bloom, probes, emission, calls)
 #endif
 };
 

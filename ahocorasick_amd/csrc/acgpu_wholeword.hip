@@ -29,8 +29,29 @@ __device__ __forceinline__ uint32_t word_bit(const uint32_t *wbits, uint32_t uni
     return __builtin_amdgcn_ubfe(wbits[unit >> 5], unit, 1);
 }
 
+// word-character bit of unit j (0..7) of a packed 8-unit window, or-ed into bit j of wm.  Spelled out because it runs for
+// every unit of the haystack and of every run: word address = (unit >> 5) * 4 straight from the packed register (two
+// instructions), the bit offset is the packed register itself for the low unit (v_bfe_u32 looks at five bits of it), and
+// the bit lands in the mask by one v_lshl_or_b32.
+template <int J>
+__device__ __forceinline__ uint32_t word_bit_into(const uint32_t *wbits, uint32_t packed, uint32_t wm) {
+    const uint32_t off = ((J & 1) ? packed >> 19 : packed >> 3) & 0x1ffcu;
+    const uint32_t word = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(wbits) + off);
+    uint32_t bit, r;
+    asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(bit) : "v"(word), "v"((J & 1) ? packed >> 16 : packed));
+    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(bit), "n"(J), "v"(wm));
+    return r;
+}
+
+// (the first N units only, N a compile-time constant: no branches between the lookups, all of them in flight together)
+template <int N, int J = 0>
+__device__ __forceinline__ uint32_t word_bits8(const uint32_t *wbits, const uint32_t (&d)[4], uint32_t wm = 0) {
+    if constexpr (J < N) return word_bits8<N, J + 1>(wbits, d, word_bit_into<J>(wbits, d[J >> 1], wm));
+    else return wm;
+}
+
 #ifndef ACGPU_WW_NB
-#define ACGPU_WW_NB 2
+#define ACGPU_WW_NB 3
 #endif
 constexpr int kWwBatches = ACGPU_WW_NB;   // run starts verified per lane and call (independent lookup chains in flight)
 #ifndef ACGPU_WW_PREFETCH
@@ -52,10 +73,13 @@ uint32_t ww_fold_pages_in_lds(const DevTables &t) { return (!t.cs && t.fold_n_pa
 
 static size_t ww_bloom_bytes(const DevTables &t) { return ((size_t)t.ww_bloom_mask + 1) / 8; }
 
+// dynamic LDS of k_ww_tile: [Bloom words | candidate queues]; the word-character bits (8 KB), the page index (256 B) and
+// the pages of the fold table (32 KB) are STATIC LDS, at addresses the compiler knows: a lookup is then address arithmetic on the unit alone
+// (with everything behind a dynamic base the compiler added the base -- a literal 0 -- to every one of them)
 size_t ww_lds_bytes(int block_threads, const DevTables &t) {
     const uint32_t fold_pages = ww_fold_pages_in_lds(t);
-    return 8192 + ww_bloom_bytes(t) + (fold_pages ? 256 + (size_t)fold_pages * 512 : 0) +
-           (size_t)(block_threads / kWave) * kWwCandCap * sizeof(uint32_t);
+    (void)fold_pages; // (the pages are static LDS as well: kFoldPagesMax of them)
+    return ww_bloom_bytes(t) + (size_t)(block_threads / kWave) * kWwCandCap * sizeof(uint32_t);
 }
 
 struct __attribute__((packed, aligned(2))) WwUnits8 { // 8 UTF-16 units at any unit address (one global_load_dwordx4)
@@ -96,21 +120,22 @@ __device__ __forceinline__ WwUnits8 ww_window(const uint16_t *hay, uint32_t p, u
 
 // One 8-unit chunk of a run: word bits, run length inside the chunk (0..8; `valid` = units that exist in the buffer),
 // folded units packed two per word and zeroed beyond the run.
-// `look` (wave-uniform, 1..8): only the first `look` units are examined -- a run that is still going after them is longer
-// than every keyword anyway (the second chunk of a run needs max_len + 1 - 8 units, not 8)
-template <int FOLD>
+// `look` (wave-uniform, 1..8): only the first `look` units count -- a run that is still going after them is longer
+// than every keyword anyway (the second chunk of a run needs max_len + 1 - 8 units, not 8).  N >= look units are looked up,
+// N a compile-time constant: with a run-time bound every unit sat behind its own scalar branch, and its two dependent LDS
+// reads were waited for one unit after the other (instrumented build: the 5-unit second chunk took 3.4x the 8-unit first).
+template <int FOLD, int N = 8>
 __device__ __forceinline__ uint32_t ww_chunk(const DevTables &T, const FoldLds &F, const uint32_t *wbits, const WwUnits8 &w,
                                              uint32_t valid, uint32_t out[4], uint32_t look = 8) {
-    uint32_t wm = 0, f[8];
+    uint32_t wm = word_bits8<N>(wbits, w.d), f[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         f[j] = 0;
-        if ((uint32_t)j >= look) continue; // (scalar branch)
+        if (j >= N) continue;
         const uint32_t u = (w.d[j >> 1] >> (16 * (j & 1))) & 0xffffu;
-        wm |= word_bit(wbits, u) << j;
         f[j] = ww_fold<FOLD>(T, F, u);
     }
-    wm &= (1u << valid) - 1u;
+    wm &= (1u << min(valid, look)) - 1u;
     const uint32_t rl = (uint32_t)__builtin_ctz(~wm | 0x100u);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -132,6 +157,13 @@ __device__ __forceinline__ void ww_verify_hash(TileCtx &c, const uint32_t *wbits
     const uint32_t n = L.n_units;
     uint32_t s[NB], r[NB], h[NB], fw[NB][8];
     bool act[NB], run[NB]; // run: every unit so far was a word character
+#ifdef ACGPU_TIMING
+    unsigned long long vt0 = clock64();
+    c.vt[6] += 1;
+#define WT_MARK(i) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = clock64(); c.vt[i] += t_ - vt0; vt0 = t_; }
+#else
+#define WT_MARK(i)
+#endif
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const uint32_t q = b * kWave + lane;
@@ -153,6 +185,7 @@ __device__ __forceinline__ void ww_verify_hash(TileCtx &c, const uint32_t *wbits
             win2[k][b] = WwUnits8{{0, 0, 0, 0}};
             if (act[b] && s[b] + 8 * k < n) win2[k][b] = ww_window(hay, s[b] + 8 * k, n);
         }
+    WT_MARK(0)
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         WwUnits8 win[NB];
@@ -163,16 +196,19 @@ __device__ __forceinline__ void ww_verify_hash(TileCtx &c, const uint32_t *wbits
         }
         // units 8..: a run of more than max_len units matches nothing, so only max_len + 1 - 8 of them matter
         const uint32_t look = k == 0 ? 8u : min(8u, T.max_len > 7u ? T.max_len - 7u : 1u);
+        const bool short_look = look <= 4; // (wave-uniform)
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const uint32_t valid = run[b] ? min(n - min(s[b] + 8 * k, n), 8u) : 0u;
-            const uint32_t rl = ww_chunk<FOLD>(T, F, wbits, win[b], valid, &fw[b][4 * k], look);
+            const uint32_t rl = (k == 1 && short_look) ? ww_chunk<FOLD, 4>(T, F, wbits, win[b], valid, &fw[b][4 * k], look)
+                                                       : ww_chunk<FOLD, 8>(T, F, wbits, win[b], valid, &fw[b][4 * k], look);
             r[b] += rl;
             run[b] = rl == 8;
         }
         bool any_run = false;
 #pragma unroll
         for (int b = 0; b < NB; ++b) any_run |= run[b];
+        if (k == 0) { WT_MARK(1) } else { WT_MARK(2) }
         if (!__any(any_run)) break;
     }
 #pragma unroll
@@ -228,6 +264,7 @@ __device__ __forceinline__ void ww_verify_hash(TileCtx &c, const uint32_t *wbits
         grp[b] = ww_hash_home(h[b], T.ww_mask);
         t0[b] = 0; // entries of the group below t0 were already tried
     }
+    WT_MARK(3)
     for (;;) {
         bool any_p = false;
 #pragma unroll
@@ -295,6 +332,7 @@ __device__ __forceinline__ void ww_verify_hash(TileCtx &c, const uint32_t *wbits
             }
         }
     }
+    WT_MARK(4)
     uint32_t m[NB], prefix[NB], total = 0;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -309,6 +347,7 @@ __device__ __forceinline__ void ww_verify_hash(TileCtx &c, const uint32_t *wbits
     for (int b = 0; b < NB; ++b)
         if (m[b]) store_rec(L, sr.slot(prefix[b]), s[b], s[b] + r[b], id[b], c.rank_base + prefix[b]);
     c.rank_base += total;
+    WT_MARK(5)
 }
 
 // Verification of up to kWwBatches*64 run starts, kWwBatches per lane, advanced in lock step.
@@ -405,20 +444,19 @@ __device__ __forceinline__ void ww_drain(TileCtx &c, const uint32_t *wbits, cons
 // Same span/region/tile-group structure as k_ac_tile (acgpu_tile.hip); only the filter and the verification differ.
 template <int FOLD>
 __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) void k_ww_tile(DevTables T, TileLaunch L) {
+    __shared__ uint32_t wbits[2048];       // 65536 word-character bits
+    __shared__ unsigned char fold_base[FOLD == 1 ? 256 : 4];             // page index of the fold table
+    __shared__ uint16_t pages[FOLD == 1 ? kFoldPagesMax * 256 : 2];      // its pages of 256 deltas
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *wbits = reinterpret_cast<uint32_t *>(smem); // 65536 word-character bits
-    const uint32_t fold_bytes = FOLD == 1 ? 256u + T.fold_n_pages * 512u : 0u;
     const uint32_t bloom_bytes = (T.ww_bloom_mask + 1u) / 8u;
-    uint32_t *bloom = reinterpret_cast<uint32_t *>(smem + 8192);
-    unsigned char *fold_base = smem + 8192 + bloom_bytes;
-    uint32_t *cand_all = reinterpret_cast<uint32_t *>(fold_base + fold_bytes);
+    uint32_t *bloom = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *cand_all = reinterpret_cast<uint32_t *>(smem + bloom_bytes);
     for (uint32_t w = threadIdx.x; w < bloom_bytes / 4; w += blockDim.x) bloom[w] = T.ww_bloom[w];
     for (uint32_t w = threadIdx.x; w < 2048; w += blockDim.x) { // pack the raw-unit flag (bit 0 of wflags) into bits
         uint32_t bits = 0;
         for (uint32_t k = 0; k < 32; ++k) bits |= (uint32_t)(T.wflags[w * 32 + k] & 1u) << k;
         wbits[w] = bits;
     }
-    uint16_t *pages = reinterpret_cast<uint16_t *>(fold_base + 256);
     FoldLds F{bloom, T.ww_bloom_mask, fold_base, pages};
     if (FOLD == 1) {
         for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) fold_base[i] = T.fold_pgidx[i];
@@ -433,6 +471,9 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
 
     const uint32_t first_region = wave_global * L.regions_per_wave;
     if (first_region >= L.n_regions) return;
+#ifdef ACGPU_TIMING
+    const unsigned long long tm_start = clock64();
+#endif
     const uint32_t last_region = min(first_region + L.regions_per_wave, L.n_regions);
     const uint32_t base8 = L.own_begin & ~7u;
     const uint32_t R = L.region_units;
@@ -513,9 +554,7 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
                 const uint4 w = grp[d];
                 const uint32_t v = cur + lane * 8;
                 const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-                uint32_t wm = 0; // word-character bits of the lane's 8 units
-#pragma unroll
-                for (int j = 0; j < 8; ++j) wm |= word_bit(wbits, (ww[j >> 1] >> (16 * (j & 1))) & 0xffffu) << j;
+                const uint32_t wm = word_bits8<8>(wbits, ww); // word-character bits of the lane's 8 units
                 const uint32_t prev = from_prev_lane(wm >> 7, carry); // bit of the unit left of v
                 carry = __builtin_amdgcn_readlane(wm, 63) >> 7;
                 uint32_t mask = wm & ~((wm << 1) | (prev & 1u)) & 0xffu; // run starts
@@ -554,6 +593,12 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
         break;
     }
     if (lane == 0) L.d_region_counts[region] = c.rank_base;
+#ifdef ACGPU_TIMING
+    if (lane == 0 && L.d_timing) {
+        L.d_timing[(size_t)wave_global * 8 + 0] = clock64() - tm_start;
+        for (int i = 0; i < 7; ++i) L.d_timing[(size_t)wave_global * 8 + 1 + i] = c.vt[i];
+    }
+#endif
     for (uint32_t i = lane; i < c.res_left; i += kWave)
         if (c.res_cur + i < c.slot_limit) store_rec(L, c.res_cur + i, 0, 0, 0, ~0u); // (not into the next slice)
 }
