@@ -196,12 +196,12 @@ int ensure_device(acgpu_automaton *a, DeviceState **out) {
     if ((rc = upload(*d, t.kg_keys, &T.kg_keys))) return rc;
     if ((rc = upload(*d, t.kg_vals, &T.kg_vals))) return rc;
     T.kg_mask = t.kg_mask; T.hashk = t.hashk;
-    if ((rc = upload(*d, t.ww_slots, &T.ww_slots))) return rc;
+    if ((rc = upload(*d, t.ww_fat, &T.ww_fat))) return rc;
     if ((rc = upload(*d, t.ww_recs, &T.ww_recs))) return rc;
     if ((rc = upload(*d, t.fold_pgidx, &T.fold_pgidx))) return rc;
     if ((rc = upload(*d, t.fold_pages, &T.fold_pages))) return rc;
     if ((rc = upload(*d, t.ww_bloom, &T.ww_bloom))) return rc;
-    T.ww_mask = t.ww_mask; T.fold_n_pages = t.fold_n_pages; T.fold_direct_n = t.fold_direct_n; T.ww_bloom_mask = t.ww_bloom_mask;
+    T.ww_fat_mask = t.ww_fat_mask; T.ww_seed = t.ww_seed; T.fold_n_pages = t.fold_n_pages; T.fold_direct_n = t.fold_direct_n; T.ww_bloom_mask = t.ww_bloom_mask;
     T.rhmask = t.rhmask; T.filt_k = t.filt_k; T.filt_n = t.filt_n; T.filt_other = t.filt_other;
     T.filt_words = (uint32_t)t.filt_bits.size(); T.filt_row_bytes = t.filt_row_bytes;
     T.hmask = t.hmask;

@@ -44,6 +44,17 @@ ACGPU_HD inline uint32_t ww_hash_final(uint32_t h) {
     return h;
 }
 ACGPU_HD inline uint32_t ww_hash_home(uint32_t h, uint32_t mask) { return h & mask & ~3u; }
+ACGPU_HD inline uint32_t ww_tag(uint32_t h, uint32_t length) { return (h & 0xffffff00u) | (length < 255u ? length : 255u); }
+constexpr uint32_t kWwInlineUnits = 12;
+// second hash of a keyword (rotate-xor over the same packed words: linear over GF(2), where ww_hash_step is linear modulo
+// 2^32 -- dictionaries over dense alphabets do hold triples of keywords with one ww_hash, hardly with both)
+ACGPU_HD inline uint32_t ww_hash2_step(uint32_t g, uint32_t packed_units) { return ((g << 5) | (g >> 27)) ^ packed_units; }
+ACGPU_HD inline uint32_t ww_slot1(uint32_t h, uint32_t mask) { return h & mask; }
+ACGPU_HD inline uint32_t ww_slot2(uint32_t h, uint32_t g, uint32_t mask) {
+    const uint32_t x = g ^ (h >> 16) ^ (g >> 13);
+    const uint32_t s = ((x * 0x2C1B3C6Du) >> 11) & mask;
+    return s != (h & mask) ? s : s ^ 1u;
+}
 // two bit positions of the Bloom filter in front of the table (the filter sits in LDS)
 ACGPU_HD inline uint32_t ww_bloom_bit1(uint32_t h, uint32_t mask) { return (h >> 7) & mask; }
 ACGPU_HD inline uint32_t ww_bloom_bit2(uint32_t h, uint32_t mask) { return ((h >> 19) | (h << 13)) & mask; }
@@ -163,6 +174,15 @@ struct HostTables {
     std::vector<uint32_t> ww_slots; // 2 u32 per slot
     uint32_t ww_mask = 0;
     std::vector<uint32_t> ww_recs;
+    uint32_t ww_fat_mask = 0;
+    uint32_t ww_seed = kWwHashSeed; // start value of the keyword hash (another one if the two-choice table cannot be built)
+    // What the kernel probes: a two-choice (cuckoo) table with the keyword INLINE, 32 bytes per slot -- {tag, id | record
+    // offset, folded units 0..11 packed 2 per u32}; tag = hash with its low byte replaced by min(length, 255) (0 = free
+    // slot), so a tag match fixes the length.  A keyword sits in slot ww_slot1(hash) or ww_slot2(hash, hash2): a lookup gathers
+    // both at once and a word of up to 12 units is decided by ONE round of memory accesses, for every lane alike (linear
+    // probing made a wave wait for its unluckiest lane's probe sequence).  Longer keywords: the record, whose offset
+    // takes the id's place, is compared as well.
+    std::vector<uint32_t> ww_fat;   // 8 u32 per slot
     // fold table as pages of 256 deltas (lower[u] - u mod 2^16), identical pages shared: fits LDS for real tables
     std::vector<uint8_t> fold_pgidx;   // 256
     std::vector<uint16_t> fold_pages;  // fold_n_pages * 256
@@ -204,7 +224,8 @@ struct DevTables {
     const uint32_t *kg_vals;
     uint32_t kg_mask;
     // WholeWord word hash
-    const uint32_t *ww_slots; // uint2 per slot
+    const uint32_t *ww_fat;   // 8 u32 per slot (see HostTables::ww_fat)
+    uint32_t ww_fat_mask, ww_seed;
     const uint32_t *ww_recs;  // 16-byte aligned records
     uint32_t ww_mask;
     const uint8_t *fold_pgidx;

@@ -196,12 +196,12 @@ __device__ __forceinline__ void ww_verify_hash(TileCtx &c, const uint32_t *wbits
         }
         // units 8..: a run of more than max_len units matches nothing, so only max_len + 1 - 8 of them matter
         const uint32_t look = k == 0 ? 8u : min(8u, T.max_len > 7u ? T.max_len - 7u : 1u);
-        const bool short_look = look <= 4; // (wave-uniform)
+        // (no branch inside this loop: the batches' LDS lookups interleave, and a branch per batch -- a shorter variant of the
+        // second chunk was one -- puts every batch's two dependent LDS round trips end to end)
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const uint32_t valid = run[b] ? min(n - min(s[b] + 8 * k, n), 8u) : 0u;
-            const uint32_t rl = (k == 1 && short_look) ? ww_chunk<FOLD, 4>(T, F, wbits, win[b], valid, &fw[b][4 * k], look)
-                                                       : ww_chunk<FOLD, 8>(T, F, wbits, win[b], valid, &fw[b][4 * k], look);
+            const uint32_t rl = ww_chunk<FOLD, 8>(T, F, wbits, win[b], valid, &fw[b][4 * k], look);
             r[b] += rl;
             run[b] = rl == 8;
         }
@@ -211,11 +211,15 @@ __device__ __forceinline__ void ww_verify_hash(TileCtx &c, const uint32_t *wbits
         if (k == 0) { WT_MARK(1) } else { WT_MARK(2) }
         if (!__any(any_run)) break;
     }
+    uint32_t g[NB]; // the second hash (names the keyword's other slot in the table)
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-        h[b] = kWwHashSeed;
+        h[b] = g[b] = T.ww_seed;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) h[b] = ww_hash_step(h[b], fw[b][i]);
+        for (int i = 0; i < 8; ++i) {
+            h[b] = ww_hash_step(h[b], fw[b][i]);
+            g[b] = ww_hash2_step(g[b], fw[b][i]);
+        }
     }
     // longer runs: hash only (the comparison re-reads the text beyond unit 16)
     for (uint32_t k = 2;; ++k) {
@@ -241,17 +245,22 @@ __device__ __forceinline__ void ww_verify_hash(TileCtx &c, const uint32_t *wbits
             const uint32_t rl = ww_chunk<FOLD>(T, F, wbits, ww_window(hay, p, n), min(n - p, 8u), out);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (rl > 2u * i) h[b] = ww_hash_step(h[b], out[i]);
+                if (rl > 2u * i) {
+                    h[b] = ww_hash_step(h[b], out[i]);
+                    g[b] = ww_hash2_step(g[b], out[i]);
+                }
             r[b] += rl;
             run[b] = rl == 8;
         }
     }
-    // table lookup: one aligned group of 4 slots per probe, in lock step; a hash hit is compared with the keyword
-    // record unit for unit
-    const uint4 *slots4 = reinterpret_cast<const uint4 *>(T.ww_slots);
+    // table lookup: a keyword sits in one of TWO 32-byte slots -- {tag, id, its first 12 folded units} -- that the hash names;
+    // both are gathered at once, so a word of up to 12 units is decided by one round of memory accesses, the same for
+    // every lane (the tag carries the length); longer keywords also compare their record, whose offset takes the id's place
+    const uint4 *fat = reinterpret_cast<const uint4 *>(T.ww_fat);
     const uint4 *recs = reinterpret_cast<const uint4 *>(T.ww_recs);
-    uint32_t id[NB], grp[NB], t0[NB];
+    uint32_t id[NB];
     bool probing[NB];
+    uint4 ea0[NB], ea1[NB], eb0[NB], eb1[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         id[b] = ~0u;
@@ -261,74 +270,53 @@ __device__ __forceinline__ void ww_verify_hash(TileCtx &c, const uint32_t *wbits
             const uint32_t b1 = ww_bloom_bit1(h[b], F.bloom_mask), b2 = ww_bloom_bit2(h[b], F.bloom_mask);
             probing[b] = probing[b] && ((F.bloom[b1 >> 5] >> (b1 & 31)) & (F.bloom[b2 >> 5] >> (b2 & 31)) & 1u);
         }
-        grp[b] = ww_hash_home(h[b], T.ww_mask);
-        t0[b] = 0; // entries of the group below t0 were already tried
+        ea0[b] = ea1[b] = eb0[b] = eb1[b] = make_uint4(0u, 0u, 0u, 0u);
+        if (probing[b]) {
+            const uint32_t s1 = ww_slot1(h[b], T.ww_fat_mask), s2 = ww_slot2(h[b], g[b], T.ww_fat_mask);
+            ea0[b] = fat[2 * s1];
+            ea1[b] = fat[2 * s1 + 1];
+            eb0[b] = fat[2 * s2];
+            eb1[b] = fat[2 * s2 + 1];
+        }
     }
     WT_MARK(3)
-    for (;;) {
-        bool any_p = false;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) any_p |= probing[b];
-        if (!__any(any_p)) break;
-        uint4 e0[NB], e1[NB];
+    for (int b = 0; b < NB; ++b) {
+        const uint32_t tag = ww_tag(h[b], r[b]);
+        const bool in_a = ea0[b].x == tag && ea0[b].z == fw[b][0] && ea0[b].w == fw[b][1] && ea1[b].x == fw[b][2] &&
+                          ea1[b].y == fw[b][3] && ea1[b].z == fw[b][4] && ea1[b].w == fw[b][5];
+        const bool in_b = eb0[b].x == tag && eb0[b].z == fw[b][0] && eb0[b].w == fw[b][1] && eb1[b].x == fw[b][2] &&
+                          eb1[b].y == fw[b][3] && eb1[b].z == fw[b][4] && eb1[b].w == fw[b][5];
+        if (probing[b] && (in_a || in_b)) id[b] = in_a ? ea0[b].y : eb0[b].y;
+    }
+    {
+        // keywords of more than 12 units (rare): tag and first 12 units agree, the rest from the record.  Two keywords
+        // can share tag and 12 units; then both slots say yes and both records are looked at.
+        bool any_long = false;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            e0[b] = e1[b] = make_uint4(0u, kWwEmpty, 0u, kWwEmpty);
-            if (probing[b]) {
-                e0[b] = slots4[grp[b] >> 1];
-                e1[b] = slots4[(grp[b] >> 1) + 1];
-            }
-        }
-        uint32_t sel[NB], tsel[NB];
-        bool stop[NB];
+        for (int b = 0; b < NB; ++b) any_long |= id[b] != ~0u && r[b] > kWwInlineUnits;
+        if (__any(any_long)) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const uint32_t hh[4] = {e0[b].x, e0[b].z, e1[b].x, e1[b].z}, oo[4] = {e0[b].y, e0[b].w, e1[b].y, e1[b].w};
-            sel[b] = kWwEmpty;
-            tsel[b] = 0;
-            stop[b] = false; // a free slot ends the probe sequence
+            for (int b = 0; b < NB; ++b) {
+                if (id[b] == ~0u || r[b] <= kWwInlineUnits) continue;
+                const uint32_t tag = ww_tag(h[b], r[b]);
+                uint32_t found = ~0u;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if (oo[t] == kWwEmpty) stop[b] = true;
-                else if (!stop[b] && (uint32_t)t >= t0[b] && hh[t] == h[b] && sel[b] == kWwEmpty) {
-                    sel[b] = oo[t];
-                    tsel[b] = t;
+                for (int which = 0; which < 2; ++which) {
+                    const uint4 &e0 = which ? eb0[b] : ea0[b], &e1 = which ? eb1[b] : ea1[b];
+                    const bool head = e0.x == tag && e0.z == fw[b][0] && e0.w == fw[b][1] && e1.x == fw[b][2] &&
+                                      e1.y == fw[b][3] && e1.z == fw[b][4] && e1.w == fw[b][5];
+                    if (!head || found != ~0u) continue;
+                    const uint4 *rec = recs + e0.y;
+                    const uint4 a = rec[0], q = rec[2];
+                    bool same = a.y == r[b] && q.x == fw[b][6] && q.y == fw[b][7];
+                    if (same && r[b] > 16) {
+                        const uint16_t *ru = reinterpret_cast<const uint16_t *>(rec) + 4; // the record's units
+                        for (uint32_t i = 16; i < r[b] && same; ++i) same = ww_fold<FOLD>(T, F, hay[s[b] + i]) == ru[i];
+                    }
+                    if (same) found = a.x;
                 }
-            }
-        }
-        uint4 a[NB], q1[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            a[b] = q1[b] = make_uint4(0, 0, 0, 0);
-            if (probing[b] && sel[b] != kWwEmpty) {
-                a[b] = recs[sel[b]];      // {id, length, units 0-1, units 2-3}
-                q1[b] = recs[sel[b] + 1]; // units 4-11 (or the next record / padding: both loads leave together)
-            }
-        }
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            if (!probing[b]) continue;
-            if (sel[b] == kWwEmpty) {
-                if (stop[b]) probing[b] = false; // not a keyword
-                else { grp[b] = (grp[b] + 4) & T.ww_mask; t0[b] = 0; }
-                continue;
-            }
-            bool same = a[b].y == r[b] && a[b].z == fw[b][0] && a[b].w == fw[b][1];
-            if (same && r[b] > 4) same = q1[b].x == fw[b][2] && q1[b].y == fw[b][3] && q1[b].z == fw[b][4] && q1[b].w == fw[b][5];
-            if (same && r[b] > 12) {
-                const uint4 *rec = recs + sel[b];
-                const uint4 q = rec[2];
-                same = q.x == fw[b][6] && q.y == fw[b][7];
-                if (same && r[b] > 16) {
-                    const uint16_t *ru = reinterpret_cast<const uint16_t *>(rec) + 4; // the record's units
-                    for (uint32_t i = 16; i < r[b] && same; ++i) same = ww_fold<FOLD>(T, F, hay[s[b] + i]) == ru[i];
-                }
-            }
-            if (same) {
-                id[b] = a[b].x;
-                probing[b] = false;
-            } else {
-                t0[b] = tsel[b] + 1; // a different word with the same 32-bit hash: keep looking in this group
+                id[b] = found;
             }
         }
     }
