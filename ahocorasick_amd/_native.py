@@ -106,7 +106,8 @@ def lib():
         L.acgpu_stream_close.restype = None
         L.acgpu_stream_close.argtypes = [vp]
         L.acgpu_debug_wordhash.restype = ci
-        L.acgpu_debug_wordhash.argtypes = [vp, ctypes.POINTER(u32), vp, ctypes.POINTER(u64), vp, vp, ctypes.POINTER(u32), vp]
+        L.acgpu_debug_wordhash.argtypes = [vp, ctypes.POINTER(u32), vp, ctypes.POINTER(u64), vp, vp, ctypes.POINTER(u32), vp,
+                                           ctypes.POINTER(u32)]
         if L.acgpu_abi_version() != ABI_VERSION:
             raise ImportError("ahocorasick_amd: %s has ABI version %d, this package binds version %d -- rebuild it"
                               % (LIB_PATH, L.acgpu_abi_version(), ABI_VERSION))

@@ -1228,17 +1228,18 @@ int acgpu_stream_feed(acgpu_stream *s, const uint16_t *units, uint64_t n_units, 
 }
 
 int acgpu_debug_wordhash(const acgpu_automaton *a, uint32_t *n_slots, uint32_t *slots, uint64_t *n_rec_words, uint32_t *recs,
-                         uint8_t *fold_pgidx, uint32_t *n_pages, uint16_t *fold_pages) {
+                         uint8_t *fold_pgidx, uint32_t *n_pages, uint16_t *fold_pages, uint32_t *seed) {
     if (!a) return ACGPU_E_INVALID;
     const HostTables &t = a->t;
     if (t.mode != ACGPU_MODE_WHOLEWORD) return ACGPU_E_UNSUPPORTED;
-    if (n_slots) *n_slots = (uint32_t)(t.ww_slots.size() / 2);
-    if (slots) std::memcpy(slots, t.ww_slots.data(), t.ww_slots.size() * sizeof(uint32_t));
+    if (n_slots) *n_slots = (uint32_t)(t.ww_fat.size() / 8);
+    if (slots) std::memcpy(slots, t.ww_fat.data(), t.ww_fat.size() * sizeof(uint32_t));
     if (n_rec_words) *n_rec_words = t.ww_recs.size();
     if (recs) std::memcpy(recs, t.ww_recs.data(), t.ww_recs.size() * sizeof(uint32_t));
     if (fold_pgidx) std::memcpy(fold_pgidx, t.fold_pgidx.data(), 256);
     if (n_pages) *n_pages = t.fold_n_pages;
     if (fold_pages) std::memcpy(fold_pages, t.fold_pages.data(), t.fold_pages.size() * sizeof(uint16_t));
+    if (seed) *seed = t.ww_seed;
     return ACGPU_OK;
 }
 

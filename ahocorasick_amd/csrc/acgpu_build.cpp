@@ -240,23 +240,9 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
 
     // ---- 5b. WholeWord: hash table of whole folded keywords + paged fold table ----
     if (mode == ACGPU_MODE_WHOLEWORD) {
-      // (a dictionary in which three keywords share one 32-bit hash cannot be placed in the two-choice table: the next seed)
-      for (uint32_t attempt = 0;; attempt++) {
-        if (attempt == 8) return ACGPU_E_UNSUPPORTED;
-        t.ww_seed = kWwHashSeed + attempt * 0x9E3779B9u;
-        t.ww_recs.clear();
-        bool placed = false;
-        std::vector<uint32_t> hash2; // per slot of the linear-probing table
-        uint64_t cap = 16;
-        while (cap < 2 * (uint64_t)n_terminal + 2) cap <<= 1;
-        t.ww_slots.assign(2 * cap, kWwEmpty);
-        hash2.assign(cap, 0u);
-        t.ww_mask = (uint32_t)(cap - 1);
-        // Bloom filter: ~16 bits per keyword, at least 1 Kbit, at most 512 Kbit (64 KB of LDS)
-        uint64_t bits = 1024;
-        while (bits < 16 * (uint64_t)n_terminal && bits < (512u << 10)) bits <<= 1;
-        t.ww_bloom.assign(bits / 32, 0u);
-        t.ww_bloom_mask = (uint32_t)(bits - 1);
+        // records {keyword id, length, folded units}, 16-byte aligned (what keywords of more than 12 units are compared with)
+        struct WwKey { uint32_t h, g, off16; };
+        std::vector<WwKey> keys;
         std::vector<uint16_t> word;
         for (uint32_t s = 1; s < N; s++) {
             if (nodes[s].kw == ~0u) continue;
@@ -271,62 +257,72 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
             rec[0] = nodes[s].kw;
             rec[1] = len;
             for (uint32_t i = 0; i < len; i++) rec[2 + (i >> 1)] |= (uint32_t)word[i] << (16 * (i & 1));
-            uint32_t h = t.ww_seed;
-            const uint32_t packed = (len + 1) / 2;
-            uint32_t g = t.ww_seed;
-            for (uint32_t i = 0; i < std::max(8u, packed); i++) {
-                h = ww_hash_step(h, i < packed ? rec[2 + i] : 0u);
-                g = ww_hash2_step(g, i < packed ? rec[2 + i] : 0u);
+            keys.push_back(WwKey{0u, 0u, (uint32_t)off16});
+        }
+        t.ww_recs.resize(t.ww_recs.size() + 8, 0u); // the compare may read one 16-byte group past a short record
+        // Bloom filter: ~16 bits per keyword, at least 1 Kbit, at most 512 Kbit (64 KB of LDS)
+        uint64_t bits = 1024;
+        while (bits < 16 * (uint64_t)keys.size() && bits < (512u << 10)) bits <<= 1;
+        t.ww_bloom_mask = (uint32_t)(bits - 1);
+        uint64_t cap = 16;
+        while (cap < 2 * (uint64_t)keys.size() + 2) cap <<= 1;
+        // The two-choice table the kernel probes (HostTables::ww_fat): cuckoo insertion (load factor below 1/2: a random
+        // walk of evictions finds room), the table doubled if a keyword cannot be placed.  Three keywords that agree in both
+        // hashes can never be placed: the hashes are then taken from the next seed.
+        bool placed = false;
+        for (uint32_t attempt = 0; attempt < 8 && !placed; attempt++) {
+            t.ww_seed = kWwHashSeed + attempt * 0x9E3779B9u;
+            for (WwKey &k : keys) {
+                const uint32_t *rec = &t.ww_recs[(size_t)k.off16 * 4];
+                const uint32_t packed = (rec[1] + 1) / 2;
+                uint32_t h = t.ww_seed, g = t.ww_seed;
+                for (uint32_t i = 0; i < std::max(8u, packed); i++) {
+                    h = ww_hash_step(h, i < packed ? rec[2 + i] : 0u);
+                    g = ww_hash2_step(g, i < packed ? rec[2 + i] : 0u);
+                }
+                k.h = ww_hash_final(h);
+                k.g = g;
             }
-            h = ww_hash_final(h);
-            uint32_t slot = ww_hash_home(h, t.ww_mask);
-            while (t.ww_slots[2 * slot + 1] != kWwEmpty) slot = (slot + 1) & t.ww_mask;
-            t.ww_slots[2 * slot] = h;
-            t.ww_slots[2 * slot + 1] = (uint32_t)off16;
-            hash2[slot] = g;
-            const uint32_t b1 = ww_bloom_bit1(h, t.ww_bloom_mask), b2 = ww_bloom_bit2(h, t.ww_bloom_mask);
+            for (uint64_t fcap = cap; fcap <= 8 * cap && fcap <= (1ull << 30) && !placed; fcap <<= 1) {
+                const uint32_t fmask = (uint32_t)(fcap - 1);
+                std::vector<uint32_t> owner(fcap, kWwEmpty); // slot -> index of the keyword that sits there
+                bool ok = true;
+                uint64_t rng = 0x9E3779B97F4A7C15ull;
+                for (uint32_t ki = 0; ki < keys.size() && ok; ki++) {
+                    uint32_t cur = ki;
+                    for (int kick = 0;; kick++) {
+                        const uint32_t s1 = ww_slot1(keys[cur].h, fmask), s2 = ww_slot2(keys[cur].h, keys[cur].g, fmask);
+                        if (owner[s1] == kWwEmpty) { owner[s1] = cur; break; }
+                        if (owner[s2] == kWwEmpty) { owner[s2] = cur; break; }
+                        if (kick >= 2048) { ok = false; break; }
+                        // both taken: evict one occupant (pseudo-random choice) and place IT again
+                        rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+                        std::swap(cur, owner[(rng >> 40) & 1 ? s1 : s2]);
+                    }
+                }
+                if (!ok) continue;
+                t.ww_fat.assign((size_t)fcap * 8, 0u);
+                t.ww_fat_mask = fmask;
+                for (uint64_t slot = 0; slot < fcap; slot++) {
+                    if (owner[slot] == kWwEmpty) continue;
+                    const WwKey &k = keys[owner[slot]];
+                    const uint32_t *rec = &t.ww_recs[(size_t)k.off16 * 4];
+                    uint32_t *fat = &t.ww_fat[slot * 8];
+                    const uint32_t len = rec[1];
+                    fat[0] = ww_tag(k.h, len);
+                    fat[1] = len <= kWwInlineUnits ? rec[0] : k.off16;
+                    for (uint32_t i = 0; i < kWwInlineUnits / 2; i++) fat[2 + i] = i < (len + 1) / 2 ? rec[2 + i] : 0u;
+                }
+                placed = true;
+            }
+        }
+        if (!placed) return ACGPU_E_UNSUPPORTED;
+        t.ww_bloom.assign(bits / 32, 0u);
+        for (const WwKey &k : keys) {
+            const uint32_t b1 = ww_bloom_bit1(k.h, t.ww_bloom_mask), b2 = ww_bloom_bit2(k.h, t.ww_bloom_mask);
             t.ww_bloom[b1 >> 5] |= 1u << (b1 & 31);
             t.ww_bloom[b2 >> 5] |= 1u << (b2 & 31);
         }
-        t.ww_recs.resize(t.ww_recs.size() + 8, 0u); // the compare may read one 16-byte group past a short record
-        // the two-choice table the kernel probes (HostTables::ww_fat): cuckoo insertion, the table doubled if a keyword
-        // cannot be placed (load factor below 1/2: practically never)
-        for (uint64_t fcap = cap; fcap <= 8 * cap && fcap <= (1ull << 30); fcap <<= 1) {
-            const uint32_t fmask = (uint32_t)(fcap - 1);
-            std::vector<uint32_t> owner(fcap, kWwEmpty); // slot -> linear-probing slot of the keyword that sits there
-            bool ok = true;
-            uint64_t rng = 0x9E3779B97F4A7C15ull;
-            for (uint64_t ls = 0; ls < cap && ok; ls++) {
-                if (t.ww_slots[2 * ls + 1] == kWwEmpty) continue;
-                uint32_t cur = (uint32_t)ls; // (keywords are named by their slot in the linear-probing table)
-                for (int kick = 0;; kick++) {
-                    const uint32_t h = t.ww_slots[2 * cur], s1 = ww_slot1(h, fmask), s2 = ww_slot2(h, hash2[cur], fmask);
-                    if (owner[s1] == kWwEmpty) { owner[s1] = cur; break; }
-                    if (owner[s2] == kWwEmpty) { owner[s2] = cur; break; }
-                    if (kick >= 2048) { ok = false; break; }
-                    // both taken: evict one occupant (pseudo-random choice) and place IT again
-                    rng = rng * 6364136223846793005ull + 1442695040888963407ull;
-                    std::swap(cur, owner[(rng >> 40) & 1 ? s1 : s2]);
-                }
-            }
-            if (!ok) continue;
-            t.ww_fat.assign((size_t)fcap * 8, 0u);
-            t.ww_fat_mask = fmask;
-            for (uint64_t slot = 0; slot < fcap; slot++) {
-                if (owner[slot] == kWwEmpty) continue;
-                const uint32_t ls = owner[slot], off16 = t.ww_slots[2 * ls + 1];
-                const uint32_t *rec = &t.ww_recs[(size_t)off16 * 4];
-                uint32_t *fat = &t.ww_fat[slot * 8];
-                const uint32_t len = rec[1];
-                fat[0] = ww_tag(t.ww_slots[2 * ls], len);
-                fat[1] = len <= kWwInlineUnits ? rec[0] : off16;
-                for (uint32_t i = 0; i < kWwInlineUnits / 2; i++) fat[2 + i] = i < (len + 1) / 2 ? rec[2 + i] : 0u;
-            }
-            placed = true;
-            break;
-        }
-        if (placed) break;
-      }
         t.fold_pgidx.assign(256, 0);
         t.fold_pages.assign(256, 0); // page 0 = identity (no unit of the page folds): the kernel skips its lookup
         t.fold_n_pages = 1;

@@ -43,7 +43,6 @@ ACGPU_HD inline uint32_t ww_hash_final(uint32_t h) {
     h ^= h >> 16;
     return h;
 }
-ACGPU_HD inline uint32_t ww_hash_home(uint32_t h, uint32_t mask) { return h & mask & ~3u; }
 ACGPU_HD inline uint32_t ww_tag(uint32_t h, uint32_t length) { return (h & 0xffffff00u) | (length < 255u ? length : 255u); }
 constexpr uint32_t kWwInlineUnits = 12;
 // second hash of a keyword (rotate-xor over the same packed words: linear over GF(2), where ww_hash_step is linear modulo
@@ -166,16 +165,10 @@ struct HostTables {
     std::vector<uint32_t> kg_vals;
     uint32_t kg_mask = 0;
     // ---- WholeWord: hash table of whole (folded) keywords + paged fold table ----
-    // A maximal run of word characters matches iff its folded text IS a keyword, so the run is hashed once and looked
-    // up: ww_slots = open-addressing table of {hash, record offset in 16-byte units} (kWwEmpty = free), linear probing
-    // from the first slot of the aligned group of 4 the hash points into (the kernel reads a whole group per probe);
-    // ww_recs = records {u32 keyword id, u32 length, folded units packed 2 per u32, zero padded}, each 16-byte aligned,
-    // against which a hash hit is compared unit for unit (exact).
-    std::vector<uint32_t> ww_slots; // 2 u32 per slot
-    uint32_t ww_mask = 0;
+    // A maximal run of word characters matches iff its folded text IS a keyword, so the run is hashed once and looked up.
+    // ww_recs = records {u32 keyword id, u32 length, folded units packed 2 per u32, zero padded}, each 16-byte aligned
+    // (what a keyword of more than 12 units is compared with, unit for unit).
     std::vector<uint32_t> ww_recs;
-    uint32_t ww_fat_mask = 0;
-    uint32_t ww_seed = kWwHashSeed; // start value of the keyword hash (another one if the two-choice table cannot be built)
     // What the kernel probes: a two-choice (cuckoo) table with the keyword INLINE, 32 bytes per slot -- {tag, id | record
     // offset, folded units 0..11 packed 2 per u32}; tag = hash with its low byte replaced by min(length, 255) (0 = free
     // slot), so a tag match fixes the length.  A keyword sits in slot ww_slot1(hash) or ww_slot2(hash, hash2): a lookup gathers
@@ -183,6 +176,8 @@ struct HostTables {
     // probing made a wave wait for its unluckiest lane's probe sequence).  Longer keywords: the record, whose offset
     // takes the id's place, is compared as well.
     std::vector<uint32_t> ww_fat;   // 8 u32 per slot
+    uint32_t ww_fat_mask = 0;
+    uint32_t ww_seed = kWwHashSeed; // start value of both hashes (another one if the two-choice table cannot be built)
     // fold table as pages of 256 deltas (lower[u] - u mod 2^16), identical pages shared: fits LDS for real tables
     std::vector<uint8_t> fold_pgidx;   // 256
     std::vector<uint16_t> fold_pages;  // fold_n_pages * 256
@@ -227,7 +222,6 @@ struct DevTables {
     const uint32_t *ww_fat;   // 8 u32 per slot (see HostTables::ww_fat)
     uint32_t ww_fat_mask, ww_seed;
     const uint32_t *ww_recs;  // 16-byte aligned records
-    uint32_t ww_mask;
     const uint8_t *fold_pgidx;
     const uint16_t *fold_pages;
     uint32_t fold_n_pages, fold_direct_n;

@@ -270,15 +270,20 @@ uint32_t acgpu_abi_version(void);
 int acgpu_debug_tables(const acgpu_automaton *a, uint16_t *cls_lut /*65536*/, uint32_t *dfa, uint32_t *out_len,
                        uint32_t *out_link, uint32_t *out_id, uint32_t *depth, uint32_t *first_out_state);
 
-/* Test hook (ACGPU_MODE_WHOLEWORD): the whole-keyword hash table the device kernel probes.  Sizes are always written;
- * arrays are copied when the pointer is non-NULL.  slots: 2 uint32 per slot {hash of the folded keyword, record offset
- * in 16-byte units; 0xffffffff = free}, linear probing from slot (hash & (n_slots-1) & ~3).  recs: uint32 words, record
- * = {keyword id, length, folded units packed two per word, zero padded to 16 bytes}.  hash: h = 0x811C9DC5; for each of
- * the max(8, ceil(length/2)) packed words (zero beyond the keyword) h = h*33 + word; then the murmur3 32-bit finaliser.
+/* Test hook (ACGPU_MODE_WHOLEWORD): the whole-keyword hash table the device kernel probes.  Sizes and the seed are always
+ * written; arrays are copied when the pointer is non-NULL.
+ * Hashes of a folded keyword over its max(8, ceil(length/2)) packed words w (two units per word, zero beyond the keyword):
+ *   h = seed; h = h*33 + w            ... then the murmur3 32-bit finaliser        (hash)
+ *   g = seed; g = rotl(g, 5) ^ w                                                    (second hash)
+ * slots: a two-choice table of n_slots (a power of two) slots of 8 uint32: {tag, id, units 0..11 packed two per word};
+ * tag = (h & 0xffffff00) | min(length, 255), 0 = free slot; a keyword sits in slot (h & (n_slots-1)) or in slot
+ * s2 = (((g ^ (h >> 16) ^ (g >> 13)) * 0x2C1B3C6D) >> 11) & (n_slots-1)  (s2 ^ 1 if that equals the first).  Keywords of
+ * more than 12 units hold their record's offset (in 16-byte units) in place of the id.
+ * recs: uint32 words, record = {keyword id, length, folded units packed two per word, zero padded to 16 bytes}.
  * fold_pgidx[256] / fold_pages[n_pages*256]: lower[u] = (u + fold_pages[fold_pgidx[u>>8]*256 + (u&255)]) & 0xffff;
  * page 0 is all zero. */
 int acgpu_debug_wordhash(const acgpu_automaton *a, uint32_t *n_slots, uint32_t *slots, uint64_t *n_rec_words, uint32_t *recs,
-                         uint8_t *fold_pgidx, uint32_t *n_pages, uint16_t *fold_pages);
+                         uint8_t *fold_pgidx, uint32_t *n_pages, uint16_t *fold_pages, uint32_t *seed);
 
 #ifdef __cplusplus
 }

@@ -150,22 +150,24 @@ def test_longest_and_wholeword_automata_build_on_cpu():
 # ---- WholeWord: the whole-keyword hash table + paged fold table (what k_ww_tile probes) ----------------------------
 
 def _wordhash_tables(a):
-    n_slots, n_pages, n_words = ctypes.c_uint32(0), ctypes.c_uint32(0), ctypes.c_uint64(0)
+    n_slots, n_pages, n_words, seed = ctypes.c_uint32(0), ctypes.c_uint32(0), ctypes.c_uint64(0), ctypes.c_uint32(0)
     f = N.lib().acgpu_debug_wordhash
-    N.check(f(a.handle, ctypes.byref(n_slots), None, ctypes.byref(n_words), None, None, ctypes.byref(n_pages), None), "sizes")
-    slots = np.zeros(2 * n_slots.value, np.uint32)
+    N.check(f(a.handle, ctypes.byref(n_slots), None, ctypes.byref(n_words), None, None, ctypes.byref(n_pages), None,
+              ctypes.byref(seed)), "sizes")
+    slots = np.zeros(8 * n_slots.value, np.uint32)
     recs = np.zeros(n_words.value, np.uint32)
     pgidx = np.zeros(256, np.uint8)
     pages = np.zeros(max(n_pages.value, 1) * 256, np.uint16)
     vp = lambda x: x.ctypes.data_as(ctypes.c_void_p)
-    N.check(f(a.handle, None, vp(slots), None, vp(recs), vp(pgidx), None, vp(pages)), "tables")
-    return slots.reshape(-1, 2), recs, pgidx, pages
+    N.check(f(a.handle, None, vp(slots), None, vp(recs), vp(pgidx), None, vp(pages), None), "tables")
+    return slots.reshape(-1, 8), recs, pgidx, pages, seed.value
 
 
 def _simulate_wholeword(a, hay, word, cs):
-    """Test-only restatement of the kernel's verification: maximal word runs, folded through the paged table, FNV-1a
-    hashed (h*33 + packed units, murmur finaliser), probed linearly from the aligned group of 4, compared with the keyword record unit for unit."""
-    slots, recs, pgidx, pages = _wordhash_tables(a)
+    """Test-only restatement of the kernel's verification: maximal word runs, folded through the paged table, hashed twice
+    over the packed units (h*33 + w with the murmur finaliser; rotl(g,5) ^ w), looked up in the two slots the hashes name --
+    tag (hash | length), the first 12 units inline, longer keywords through their record."""
+    slots, recs, pgidx, pages, seed = _wordhash_tables(a)
     mask = len(slots) - 1
     fold = (lambda u: u) if cs else (lambda u: (u + int(pages[int(pgidx[u >> 8]) * 256 + (u & 255)])) & 0xffff)
     out, i, n = [], 0, len(hay)
@@ -180,31 +182,40 @@ def _simulate_wholeword(a, hay, word, cs):
         f = [fold(u) for u in h_list[i:j]]
         packed = [f[k] | ((f[k + 1] if k + 1 < len(f) else 0) << 16) for k in range(0, len(f), 2)]
         packed += [0] * (8 - len(packed))
-        h = 0x811C9DC5
+        h = g = seed
         for d in packed:
             h = (h * 33 + d) & 0xffffffff
+            g = (((g << 5) | (g >> 27)) & 0xffffffff) ^ d
         h ^= h >> 16
         h = (h * 0x85EBCA6B) & 0xffffffff
         h ^= h >> 13
         h = (h * 0xC2B2AE35) & 0xffffffff
         h ^= h >> 16
-        s = h & mask & ~3
-        while slots[s, 1] != 0xffffffff:
-            if slots[s, 0] == h:
-                off = int(slots[s, 1]) * 4
-                ln = int(recs[off + 1])
-                units = [(int(recs[off + 2 + (k >> 1)]) >> (16 * (k & 1))) & 0xffff for k in range(ln)]
-                if units == f:
-                    out.append([i, j, int(recs[off])])
-                    break
-            s = (s + 1) & mask
+        tag = (h & 0xffffff00) | min(len(f), 255)
+        s1 = h & mask
+        s2 = ((((g ^ (h >> 16) ^ (g >> 13)) * 0x2C1B3C6D) & 0xffffffff) >> 11) & mask
+        if s2 == s1:
+            s2 ^= 1
+        for s in (s1, s2):
+            e = [int(x) for x in slots[s]]
+            if e[0] != tag or e[2:8] != (packed + [0] * 6)[:6]:
+                continue
+            if len(f) <= 12:
+                out.append([i, j, e[1]])
+                break
+            off = e[1] * 4
+            ln = int(recs[off + 1])
+            units = [(int(recs[off + 2 + (k >> 1)]) >> (16 * (k & 1))) & 0xffff for k in range(ln)]
+            if units == f:
+                out.append([i, j, int(recs[off])])
+                break
         i = j
     return out
 
 
 def test_wordhash_fold_pages_equal_the_fold_table():
     a = Automaton(N.MODE_WHOLEWORD, ["a"], False, word_chars=WORD)
-    _, _, pgidx, pages = _wordhash_tables(a)
+    _, _, pgidx, pages, _ = _wordhash_tables(a)
     u = np.arange(65536)
     got = (u + pages[pgidx[u >> 8].astype(np.int64) * 256 + (u & 255)]) & 0xffff
     assert (got == LOWER).all()
@@ -228,6 +239,29 @@ def test_wordhash_tables_reproduce_oracle(fixtures):
             a = Automaton(N.MODE_WHOLEWORD, kws, cs, word_chars=WORD)
             want = Oracle(FAM_WHOLEWORD, kws, case_sensitive=cs, lower=LOWER, word_chars=WORD).match(hay).tolist()
             assert _simulate_wholeword(a, hay, WORD, cs) == want, (it, cs)
+
+
+def test_wordhash_two_choice_table_holds_config5_dictionary():
+    """Config 5's 100 k mixed-script words: the primary hash has triples of keywords with one 32-bit value (h*33 + w is linear
+    modulo 2^32 and the alphabets are dense), which a two-choice table can only place because the second slot comes from the
+    second hash.  Every keyword must be found where the kernel will look, non-keywords must not."""
+    from ahocorasick_amd import synth
+    from oracle.oracle import FAM_WHOLEWORD
+    words = synth.mixed_script_words(1005, 100000)
+    a = Automaton(N.MODE_WHOLEWORD, words, False, word_chars=WORD)
+    slots, _, _, _, seed = _wordhash_tables(a)
+    used = int((slots[:, 0] != 0).sum())
+    assert used == a.info()["n_keywords"] and len(slots) >= 2 * used and seed == 0x811C9DC5
+    rng = np.random.default_rng(8)
+    pick = rng.choice(len(words), 3000, replace=False)
+    sep = np.array([32], np.uint16)
+    toks = []
+    for i in pick:
+        toks += [np.asarray(words[int(i)], dtype=np.uint16), sep, np.asarray(words[int(i)], dtype=np.uint16)[::-1].copy(), sep]
+    hay = np.concatenate(toks)
+    got = _simulate_wholeword(a, hay, WORD, False)
+    want = Oracle(FAM_WHOLEWORD, words, case_sensitive=False, lower=LOWER, word_chars=WORD).match(hay).tolist()
+    assert len(want) >= 3000 and got == want
 
 
 def test_stream_argument_checks_without_a_device():
