@@ -270,7 +270,8 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
         // walk of evictions finds room), the table doubled if a keyword cannot be placed.  Three keywords that agree in both
         // hashes can never be placed: the hashes are then taken from the next seed.
         bool placed = false;
-        for (uint32_t attempt = 0; attempt < 8 && !placed; attempt++) {
+        const uint32_t first_attempt = (uint32_t)std::min<int64_t>(std::max<int64_t>(tunables().ww_first_seed, 0), 7);
+        for (uint32_t attempt = first_attempt; attempt < 8 && !placed; attempt++) {
             t.ww_seed = kWwHashSeed + attempt * 0x9E3779B9u;
             for (WwKey &k : keys) {
                 const uint32_t *rec = &t.ww_recs[(size_t)k.off16 * 4];

@@ -244,6 +244,7 @@ struct Tunables {
 #define ACGPU_FILTER_MAX_BYTES 88000
 #endif
     std::atomic<int64_t> filter_max_bytes{ACGPU_FILTER_MAX_BYTES};  // the filter rows must fit LDS next to the candidate queues
+    std::atomic<int64_t> ww_first_seed{0};    // WHOLEWORD builder: first hash seed tried (tests: the fallback seeds end to end)
 };
 Tunables &tunables();
 

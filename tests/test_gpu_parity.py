@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 def _reset_tunables():
     yield
     for k, v in [("chunk_units", 0), ("blocks_per_cu", 1), ("lds_table_bytes", 96 * 1024), ("force_sparse", 0),
-                 ("force_kernel", 0), ("region_units", 0)]:
+                 ("force_kernel", 0), ("region_units", 0), ("ww_first_seed", 0), ("tile_debug", 0)]:
         N.set_tunable(k, v)
 
 
@@ -1311,6 +1311,24 @@ def test_wholeword_async_begin_end_pipelined_overflow_and_slice_redo():
     a3 = Automaton(N.MODE_WHOLEWORD, ["A", "AB", "x"], False, lower=LOWER, word_chars=wc)
     assert a3.info()["fold_consistent"] == 0
     assert a3.match_device_begin(d_hay.data_ptr(), 4096, True, out.data_ptr(), 16, stream=st)[1] == N.E_UNSUPPORTED
+
+
+def test_wholeword_fallback_hash_seeds_end_to_end():
+    """The builder takes another hash seed when the two-choice table cannot hold a dictionary (three keywords agreeing in
+    both hashes).  That never happens by chance, so the test hook "ww_first_seed" starts the builder at a later seed: the
+    kernel must hash with the seed the tables were built with (acgpu debug hook: seed != default), results unchanged."""
+    from oracle.oracle import FAM_WHOLEWORD
+    words = synth.mixed_script_words(1005, 4000)
+    hay = synth.mixed_script_haystack(2051, 200000, words, swapcase_tbl=synth.swapcase_table())
+    want = Oracle(FAM_WHOLEWORD, words, case_sensitive=False, lower=LOWER, word_chars=WORD).match(hay)
+    for first in (0, 3, 7):
+        N.set_tunable("ww_first_seed", first)
+        a = Automaton(N.MODE_WHOLEWORD, words, False, lower=LOWER, word_chars=WORD)
+        seed = ctypes.c_uint32(0)
+        N.check(N.lib().acgpu_debug_wordhash(a.handle, None, None, None, None, None, None, None, ctypes.byref(seed)), "seed")
+        assert (seed.value == 0x811C9DC5) == (first == 0)
+        got = a.match_host(hay, True)
+        assert len(want) > 5000 and got.shape == want.shape and (got == want).all()
 
 
 @pytest.mark.parametrize("min_len", [2, 4, 6])

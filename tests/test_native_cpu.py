@@ -264,6 +264,23 @@ def test_wordhash_two_choice_table_holds_config5_dictionary():
     assert len(want) >= 3000 and got == want
 
 
+def test_wordhash_fallback_seed_tables_reproduce_oracle():
+    """Tables built from a later hash seed (test hook ww_first_seed; the builder goes there by itself when a dictionary
+    cannot be placed) still find exactly the oracle's matches."""
+    from ahocorasick_amd import synth
+    from oracle.oracle import FAM_WHOLEWORD
+    words = synth.mixed_script_words(1005, 1500)
+    hay = synth.mixed_script_haystack(2052, 20000, words, swapcase_tbl=synth.swapcase_table())
+    want = Oracle(FAM_WHOLEWORD, words, case_sensitive=False, lower=LOWER, word_chars=WORD).match(hay).tolist()
+    try:
+        N.set_tunable("ww_first_seed", 5)
+        a = Automaton(N.MODE_WHOLEWORD, words, False, word_chars=WORD)
+    finally:
+        N.set_tunable("ww_first_seed", 0)
+    assert _wordhash_tables(a)[4] != 0x811C9DC5
+    assert len(want) > 500 and _simulate_wholeword(a, hay, WORD, False) == want
+
+
 def test_stream_argument_checks_without_a_device():
     a = Automaton(N.MODE_ALL, ["ab"], True)
     L = N.lib()
