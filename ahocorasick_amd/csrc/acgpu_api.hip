@@ -157,6 +157,7 @@ int ensure_device(acgpu_automaton *a, DeviceState **out) {
     if ((rc = upload(*d, t.cls_lut, &T.cls_lut))) return rc;
     if ((rc = upload(*d, t.lower, &T.lower))) return rc;
     if ((rc = upload(*d, t.wflags, &T.wflags))) return rc;
+    if ((rc = upload(*d, t.wbits, &T.wbits))) return rc;
     if ((rc = upload(*d, t.out_len, &T.out_len))) return rc;
     if ((rc = upload(*d, t.out_link, &T.out_link))) return rc;
     if ((rc = upload(*d, t.out_id, &T.out_id))) return rc;

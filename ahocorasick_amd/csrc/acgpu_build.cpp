@@ -62,6 +62,8 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
             t.wflags[c] = (uint8_t)(raw | (fold << 1));
             if (raw != fold) t.fold_consistent = false;
         }
+        t.wbits.assign(2048, 0u);
+        for (uint32_t c = 0; c < 65536; c++) t.wbits[c >> 5] |= (uint32_t)(t.wflags[c] & 1u) << (c & 31);
     }
 
     // ---- 1. trie insertion (keyword order matters: the LAST duplicate's index wins) ----

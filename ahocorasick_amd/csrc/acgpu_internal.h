@@ -108,6 +108,7 @@ struct HostTables {
                                    // using > 65535 distinct units is always built sparse and needs no classes)
     std::vector<uint16_t> lower;   // 65536 fold table (identity when case sensitive)
     std::vector<uint8_t> wflags;   // WHOLEWORD: bit0 = word[raw], bit1 = word[lower[raw]]
+    std::vector<uint32_t> wbits;   // bit0 of wflags packed 32 units per word (2048 words: what the kernels keep in LDS)
     bool fold_consistent = true;
     // per state
     std::vector<uint32_t> depth, fail, out_len, out_link, out_id, term_id; // term_id: own keyword id or ~0u
@@ -195,6 +196,7 @@ struct DevTables {
     const uint16_t *cls_lut;
     const uint16_t *lower;
     const uint8_t *wflags;
+    const uint32_t *wbits;
     const void *dfa; // uint16_t or uint32_t entries
     const uint32_t *out_len, *out_link, *out_id, *fail, *depth, *term_id;
     const uint64_t *hkeys;

@@ -432,23 +432,25 @@ __device__ __forceinline__ void ww_drain(TileCtx &c, const uint32_t *wbits, cons
 // Same span/region/tile-group structure as k_ac_tile (acgpu_tile.hip); only the filter and the verification differ.
 template <int FOLD>
 __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) void k_ww_tile(DevTables T, TileLaunch L) {
-    __shared__ uint32_t wbits[2048];       // 65536 word-character bits
-    __shared__ unsigned char fold_base[FOLD == 1 ? 256 : 4];             // page index of the fold table
-    __shared__ uint16_t pages[FOLD == 1 ? kFoldPagesMax * 256 : 2];      // its pages of 256 deltas
+    __shared__ __attribute__((aligned(16))) uint32_t wbits[2048];       // 65536 word-character bits
+    __shared__ __attribute__((aligned(16))) unsigned char fold_base[FOLD == 1 ? 256 : 16];        // page index of the fold table
+    __shared__ __attribute__((aligned(16))) uint16_t pages[FOLD == 1 ? kFoldPagesMax * 256 : 8]; // its pages of 256 deltas
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t bloom_bytes = (T.ww_bloom_mask + 1u) / 8u;
     uint32_t *bloom = reinterpret_cast<uint32_t *>(smem);
     uint32_t *cand_all = reinterpret_cast<uint32_t *>(smem + bloom_bytes);
-    for (uint32_t w = threadIdx.x; w < bloom_bytes / 4; w += blockDim.x) bloom[w] = T.ww_bloom[w];
-    for (uint32_t w = threadIdx.x; w < 2048; w += blockDim.x) { // pack the raw-unit flag (bit 0 of wflags) into bits
-        uint32_t bits = 0;
-        for (uint32_t k = 0; k < 32; ++k) bits |= (uint32_t)(T.wflags[w * 32 + k] & 1u) << k;
-        wbits[w] = bits;
-    }
+    // the LDS tables, 16 bytes per load (every workgroup copies them while nothing else runs: the packed word bits come
+    // ready-made from the builder -- packing them here took 64 byte loads per thread)
+    for (uint32_t w = threadIdx.x; w < bloom_bytes / 16; w += blockDim.x)
+        reinterpret_cast<uint4 *>(bloom)[w] = reinterpret_cast<const uint4 *>(T.ww_bloom)[w];
+    for (uint32_t w = threadIdx.x; w < 2048 / 4; w += blockDim.x)
+        reinterpret_cast<uint4 *>(wbits)[w] = reinterpret_cast<const uint4 *>(T.wbits)[w];
     FoldLds F{bloom, T.ww_bloom_mask, fold_base, pages};
     if (FOLD == 1) {
-        for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) fold_base[i] = T.fold_pgidx[i];
-        for (uint32_t i = threadIdx.x; i < T.fold_n_pages * 256u; i += blockDim.x) pages[i] = T.fold_pages[i];
+        for (uint32_t i = threadIdx.x; i < 256 / 16; i += blockDim.x)
+            reinterpret_cast<uint4 *>(fold_base)[i] = reinterpret_cast<const uint4 *>(T.fold_pgidx)[i];
+        for (uint32_t i = threadIdx.x; i < T.fold_n_pages * 32u; i += blockDim.x) // (a page = 512 bytes)
+            reinterpret_cast<uint4 *>(pages)[i] = reinterpret_cast<const uint4 *>(T.fold_pages)[i];
     }
     __syncthreads();
 

@@ -43,11 +43,7 @@ __global__ __launch_bounds__(kStartsBlock) void k_wwl_starts(DevTables T, const 
                                                             uint32_t *counts, const uint64_t *offsets, uint32_t *rs, int text_begin) {
     __shared__ uint32_t wbits[2048];
     __shared__ uint32_t wave_tot[kStartsBlock / kWave];
-    for (uint32_t w = threadIdx.x; w < 2048; w += blockDim.x) {
-        uint32_t bits = 0;
-        for (uint32_t k = 0; k < 32; ++k) bits |= (uint32_t)(T.wflags[w * 32 + k] & 1u) << k;
-        wbits[w] = bits;
-    }
+    for (uint32_t w = threadIdx.x; w < 2048; w += blockDim.x) wbits[w] = T.wbits[w];
     __syncthreads();
     const uint32_t lane = lane_id(), wave = threadIdx.x / kWave;
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
