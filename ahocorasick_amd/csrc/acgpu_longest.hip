@@ -15,6 +15,8 @@
 //                    sum), write.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+
 #include "acgpu_device.h"
 #include "acgpu_kernels.h"
 
@@ -1073,14 +1075,26 @@ __global__ __launch_bounds__(kEmitBlock, 8) void k_longest_emit_ends(LongestChai
 // lengths come through LDS in chunks of 256 positions: a lane requests its whole chunk at once (32 independent 16-byte
 // loads: one memory latency per 256 positions instead of one per 16) and then walks it with LDS reads.  The walk is cheap
 // enough to run twice -- count, (prefix sum), write -- without the bitmap and the separate emit pass.
-constexpr int kC2Chunk = 256; // positions per lane and chunk: 32 pieces of 8 lengths = 512 bytes, loaded by one half wave
+#ifndef ACGPU_C2CHUNK
+#define ACGPU_C2CHUNK 256
+#endif
+constexpr int kC2Chunk = ACGPU_C2CHUNK; // positions per lane and chunk: 32 pieces of 8 lengths = 512 bytes, loaded by one half wave
                               // of one LDS-DMA instruction (global_load_lds_dwordx4: lane i's 16 bytes land at base + 16 i)
 
 // BITS (count pass): the matches are also marked in the bitmap L.d_bits for k_longest_emit -- collected per chunk in LDS
 // (chunks start on a bitmap word) and merged into the zeroed bitmap with one atomicOr per non-zero word; these stores are
 // issued when a chunk is done and complete under the next chunk's load.
+#ifndef ACGPU_C2WAVES
+#define ACGPU_C2WAVES 1
+#endif
+#ifdef ACGPU_TIMING
+__device__ unsigned long long g_c2_timing[8]; // total, zero+issue, load wait, walk, bit stores, chunks (per-wave sums)
+#define C2_MARK(i) { const unsigned long long t_ = clock64(); c2t[i] += t_ - c2t0; c2t0 = t_; }
+#else
+#define C2_MARK(i)
+#endif
 template <bool WRITE, bool BITS = false>
-__global__ __launch_bounds__(kWave) void k_longest_chain_lds(LongestChainLaunch L, const uint32_t *S) {
+__global__ __launch_bounds__(kWave, ACGPU_C2WAVES) void k_longest_chain_lds(LongestChainLaunch L, const uint32_t *S) {
     __shared__ __attribute__((aligned(16))) unsigned char buf[kC2Chunk / 8 * kWave * 16]; // [piece][lane][8 lengths]
     __shared__ uint32_t lbits[BITS ? kC2Chunk / 32 : 1][kWave];
     __shared__ uint32_t lebits[BITS ? kC2Chunk / 32 + 1 : 1][kWave]; // the ends (bit end-1), when L.d_ebits is there (+ a dummy word)
@@ -1127,13 +1141,20 @@ __global__ __launch_bounds__(kWave) void k_longest_chain_lds(LongestChainLaunch 
     // piece ^ lane -- the lanes walk their chunks at about the same pace, and without the permutation they would all sit in
     // the same banks.  Length x of the lane's chunk: piece x >> 3, entry x & 7.
     constexpr uint32_t kPieces = kC2Chunk / 8, kChunkBytes = kC2Chunk * 2;
-    static_assert(kPieces == 32, "one half wave loads one lane's chunk: 32 pieces of 16 bytes");
+    static_assert(kPieces == 32 || kPieces == 16 || kPieces == 8, "a half (quarter, eighth) wave loads one lane's chunk: 32 (16, 8) pieces of 16 bytes");
+    constexpr uint32_t kOwnersPerLoad = kWave / kPieces; // lanes whose chunks one load instruction brings
     const unsigned char *mine = buf + lane * kChunkBytes;
-    auto at = [&](uint32_t x) -> const unsigned char * { return mine + (((x >> 3) ^ lane) & (kPieces - 1u)) * 16u + (x & 7u) * 2u; };
+    // (slot = piece ^ lane, i.e. byte offset ((x ^ lane's piece bits) * 2): two instructions from x to the address)
+    const uint32_t swz = (lane & (kPieces - 1u)) << 3;
+    auto at = [&](uint32_t x) -> const unsigned char * { return mine + ((x ^ swz) << 1); };
     // a chunk starts on a 16-byte boundary of len[]; pieces past its end are read from the last whole piece instead (never
     // consulted: the walk stops at limit <= the end of the owned range; the allocation of len[] has 64 bytes of slack)
     const uint32_t last_piece = L.len_units & ~7u;
     const bool ebits = BITS && L.d_ebits != nullptr;
+#ifdef ACGPU_TIMING
+    unsigned long long c2t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c2t0 = clock64();
+    const unsigned long long c2start = c2t0;
+#endif
     uint32_t pend = ~0u; // an end beyond the chunk in which its match started: it lies in the first word of the lane's next chunk
     while (__any(active)) {
         const uint32_t cb = pos & (BITS ? ~31u : ~7u);
@@ -1154,33 +1175,44 @@ __global__ __launch_bounds__(kWave) void k_longest_chain_lds(LongestChainLaunch 
             // half wave each, 32 consecutive pieces = 512 contiguous bytes per half (every cache line is requested once and
             // used whole; a lane asking for its own 16 bytes per load requested each line four times, from 64 places per
             // instruction: 0.56 ms for the loads alone at config 4)
-            const uint32_t my_piece = lane & (kPieces - 1u), half = lane >> 5;
+            const uint32_t my_piece = lane & (kPieces - 1u), sub = lane / kPieces;
 #pragma unroll
-            for (int j = 0; j < kWave / 2; ++j) {
-                const uint32_t cb0 = (uint32_t)__builtin_amdgcn_readlane((int)cb, 2 * j), cb1 = (uint32_t)__builtin_amdgcn_readlane((int)cb, 2 * j + 1);
-                const uint32_t owner = 2u * j + half;
-                const uint32_t src = (half ? cb1 : cb0) + ((my_piece ^ owner) & (kPieces - 1u)) * 8u;
+            for (int j = 0; j < (int)kPieces; ++j) {
+                uint32_t cbo = (uint32_t)__builtin_amdgcn_readlane((int)cb, kOwnersPerLoad * j);
+#pragma unroll
+                for (int o = 1; o < (int)kOwnersPerLoad; ++o) {
+                    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cb, kOwnersPerLoad * j + o);
+                    cbo = sub == (uint32_t)o ? c : cbo;
+                }
+                const uint32_t owner = kOwnersPerLoad * j + sub;
+                const uint32_t src = cbo + ((my_piece ^ owner) & (kPieces - 1u)) * 8u;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(len + min(src, last_piece)),
                                                  (__attribute__((address_space(3))) void *)(buf + j * (kWave * 16)), 16, 0, 0);
             }
         }
+        C2_MARK(1)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        C2_MARK(2)
         __builtin_amdgcn_wave_barrier();
         if (active) {
-            const uint32_t cend = cb + kC2Chunk;
-            while (pos < limit && pos < cend) {
-                const uint32_t l = *reinterpret_cast<const uint16_t *>(at(pos - cb));
+            // The chain inside the chunk, on the chunk-relative position `rel` (the loop-carried chain is rel -> address (two
+            // instructions) -> length (one LDS read) -> rel + length).  BITS: chunks start on a bitmap word, so bit numbers are
+            // rel's low five bits; the ors go to LDS without return; only the LAST match of a chunk can end beyond it -- its
+            // bit goes to a dummy word and its position into `pend`.
+            const uint32_t rel_end = limit > cb ? min(limit - cb, (uint32_t)kC2Chunk) : 0u;
+            uint32_t rel = pos - cb, pend_rel = ~0u;
+            while (rel < rel_end) {
+                const uint32_t l = *reinterpret_cast<const uint16_t *>(at(rel));
                 if (l > 0) {
-                    // (branch free: LDS ors without return; only the LAST match of a chunk can end beyond it -- its bit goes
-                    // to a dummy word and the position into `pend`)
-                    if (BITS) atomicOr(&lbits[(pos - cb) >> 5][lane], 1u << (pos & 31u));
+                    if (BITS) atomicOr(&lbits[rel >> 5][lane], 1u << (rel & 31u));
                     if (ebits) {
-                        const uint32_t e = pos + l - 1u;
-                        const bool in = e < cend;
-                        atomicOr(&lebits[in ? (e - cb) >> 5 : (uint32_t)(kC2Chunk / 32)][lane], 1u << (e & 31u));
-                        pend = in ? pend : e;
+                        const uint32_t er = rel + l - 1u;
+                        const bool in = er < (uint32_t)kC2Chunk;
+                        atomicOr(&lebits[in ? er >> 5 : (uint32_t)(kC2Chunk / 32)][lane], 1u << (er & 31u));
+                        pend_rel = in ? pend_rel : er;
                     }
                     if (WRITE) {
+                        pos = cb + rel;
                         const uint32_t k = (uint32_t)dst & gmask;
                         ring_se[k][lane] = make_int2((int)pos, (int)(pos + l));
                         if (!set_kind) ring_id[k][lane] = (int)L.d_out_id[L.d_state[pos]];
@@ -1209,18 +1241,20 @@ __global__ __launch_bounds__(kWave) void k_longest_chain_lds(LongestChainLaunch 
                     }
                     ++dst;
                     ++count;
-                    pos += l;
+                    rel += l;
                 } else {
                     // no keyword starts here; from a piece boundary on, whole pieces of eight such positions are skipped at a stroke
-                    ++pos;
-                    const uint32_t stop = min(limit, cend);
-                    while ((pos & 7u) == 0 && pos + 8 <= stop) {
-                        const uint4 z = *reinterpret_cast<const uint4 *>(at(pos - cb));
+                    ++rel;
+                    while ((rel & 7u) == 0 && rel + 8 <= rel_end) {
+                        const uint4 z = *reinterpret_cast<const uint4 *>(at(rel));
                         if (z.x | z.y | z.z | z.w) break;
-                        pos += 8;
+                        rel += 8;
                     }
                 }
             }
+            pos = cb + rel;
+            if (ebits && pend_rel != ~0u) pend = cb + pend_rel;
+            C2_MARK(3)
             if (BITS) { // words wholly inside the segment are this lane's own (plain stores); the two at its ends may be shared
                 if (ebits && pend != ~0u && ((pend + 1u) & 31u) == 0) { // a word between this lane's chunks: nobody stores it
                     atomicOr(&L.d_ebits[pend >> 5], 0x80000000u);
@@ -1255,7 +1289,18 @@ __global__ __launch_bounds__(kWave) void k_longest_chain_lds(LongestChainLaunch 
             if (pos >= limit) active = false;
         }
         __builtin_amdgcn_wave_barrier();
+        C2_MARK(4)
+#ifdef ACGPU_TIMING
+        c2t[5] += 1;
+#endif
     }
+#ifdef ACGPU_TIMING
+    if (lane == 0) {
+        atomicAdd(&g_c2_timing[0], clock64() - c2start);
+        for (int i = 1; i < 6; ++i) atomicAdd(&g_c2_timing[i], c2t[i]);
+        atomicAdd(&g_c2_timing[6], 1ull);
+    }
+#endif
     if (t < L.n_tiles && start != ~0u && start < L.own_end) {
         if (WRITE) {
             const uint32_t k = (uint32_t)dst & gmask;
@@ -1274,6 +1319,17 @@ hipError_t launch_longest_chain_lds(const LongestChainLaunch &l, const uint32_t 
     if (write_pass) hipLaunchKernelGGL((k_longest_chain_lds<true>), grid, block, 0, stream, l, d_sync);
     else if (l.d_bits) hipLaunchKernelGGL((k_longest_chain_lds<false, true>), grid, block, 0, stream, l, d_sync);
     else hipLaunchKernelGGL((k_longest_chain_lds<false>), grid, block, 0, stream, l, d_sync);
+#ifdef ACGPU_TIMING
+    if (!write_pass) {
+        (void)hipStreamSynchronize(stream);
+        unsigned long long h[8] = {0};
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_c2_timing), sizeof(h));
+        if (h[6]) fprintf(stderr, "[c2 timing] waves %llu: total %.0f | zero+issue %.0f | load wait %.0f | walk %.0f | bit stores %.0f | chunks %.1f (cycles per wave)\n",
+                          h[6], (double)h[0] / h[6], (double)h[1] / h[6], (double)h[2] / h[6], (double)h[3] / h[6], (double)h[4] / h[6], (double)h[5] / h[6]);
+        unsigned long long z[8] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_c2_timing), z, sizeof(z));
+    }
+#endif
     return hipGetLastError();
 }
 
