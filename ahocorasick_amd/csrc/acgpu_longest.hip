@@ -351,6 +351,13 @@ __device__ __forceinline__ void wl_block_index(const uint32_t (&w)[8], uint32_t 
     for (int k = 0; k < 4; ++k) asm("v_pk_lshlrev_b16 %0, %1, %2" : "=v"(A[k]) : "s"(0x00020002u), "v"(I[k]));
 }
 
+#ifdef ACGPU_TIMING
+__device__ unsigned long long g_wl_rounds;
+__device__ unsigned long long g_wl_timing[8]; // total, text wait, index + root lookups + store, appends + their rounds, tail rounds, waves
+#define WL_MARK(i) { const unsigned long long t_ = clock64(); wlt[i] += t_ - wlt0; wlt0 = t_; }
+#else
+#define WL_MARK(i)
+#endif
 template <typename LenT, bool STATE>
 __global__ __launch_bounds__(kLScanBlock) void k_longest_walk_list(DevTables T, LongestScanLaunch L) {
     constexpr bool ROOT = !STATE;
@@ -417,6 +424,10 @@ __global__ __launch_bounds__(kLScanBlock) void k_longest_walk_list(DevTables T, 
     const uint64_t own_len = (uint64_t)L.own_end - L.own_begin;
     const uint32_t n_chunks = (uint32_t)((own_len + kWlChunk - 1) / kWlChunk);
 
+#ifdef ACGPU_TIMING
+    unsigned long long wlt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wlt0 = clock64();
+    const unsigned long long wl_start = wlt0;
+#endif
     // a finished walk: len[] (and the node), its landing into the block maximum; a walk that ran into the DEEP row is redone
     // through the table in global memory first (rare: nodes beyond the LDS rows)
     auto finish = [&](uint32_t p, uint32_t prel, uint32_t off16, uint32_t best, uint32_t best_e, bool by_atomic) {
@@ -502,10 +513,22 @@ __global__ __launch_bounds__(kLScanBlock) void k_longest_walk_list(DevTables T, 
         wl_n = first;
         const uint32_t p = chunk0 + prel;
         uint32_t w[4], nvalid, tm, hist[8];
+#ifdef ACGPU_TIMING
+        const unsigned long long lr0 = clock64();
+#endif
         load8(act ? p + depth : chunk0, w, nvalid, check);
+#ifdef ACGPU_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long lr1 = clock64();
+#endif
         if (check) e = wl_round<STATE, true>(rows8, w, nvalid, base2, span2, span4, e, tm, hist);
         else e = wl_round<STATE, false>(rows8, w, nvalid, base2, span2, span4, e, tm, hist);
         round_best(tm, depth, hist, best, best_e);
+#ifdef ACGPU_TIMING
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long lr2 = clock64();
+        wlt[5] += lr1 - lr0; wlt[6] += lr2 - lr1; wlt[7] += 1;
+#endif
         const uint32_t off16 = e & 0xffffu;
         const bool alive = act && off16 < real_bytes && depth < 65000u; // (no keyword is that long: see the launch condition)
         if (act && !alive) (void)finish(p, prel, off16, best, best_e, true);
@@ -527,8 +550,13 @@ __global__ __launch_bounds__(kLScanBlock) void k_longest_walk_list(DevTables T, 
             __builtin_amdgcn_wave_barrier();
             for (uint32_t s0 = chunk0; s0 < chunk_end; s0 += 8 * kWave) {
                 const uint32_t pb = s0 + lane * 8u;
+                WL_MARK(3)
                 const Units8 u0 = *reinterpret_cast<const Units8 *>(hay + pb);
                 const Units8 u1 = *reinterpret_cast<const Units8 *>(hay + pb + 8);
+#ifdef ACGPU_TIMING
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                WL_MARK(1)
                 const uint32_t w16[8] = {u0.d[0], u0.d[1], u0.d[2], u0.d[3], u1.d[0], u1.d[1], u1.d[2], u1.d[3]};
                 uint32_t A[4];
                 if (rk == 8) wl_block_index<8>(w16, base2, span2, n, A);
@@ -544,6 +572,10 @@ __global__ __launch_bounds__(kLScanBlock) void k_longest_walk_list(DevTables T, 
 #pragma unroll
                 for (int k = 0; k < 4; ++k) lens.d[k] = __builtin_amdgcn_perm(e[2 * k + 1], e[2 * k], 0x0c060c02u);
                 *reinterpret_cast<Units8 *>(out_len + pb) = lens;
+#ifdef ACGPU_TIMING
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+                WL_MARK(2)
                 const uint32_t prel0 = (pb - chunk0) | (rk << 16);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -596,12 +628,24 @@ __global__ __launch_bounds__(kLScanBlock) void k_longest_walk_list(DevTables T, 
                 }
             }
         }
+        WL_MARK(3)
         while (wl_n) list_round(chunk0, check);
         __builtin_amdgcn_wave_barrier();
         const uint32_t nblk = (chunk_end - chunk0 + 63u) >> 6;
         if (lane < nblk) L.d_blockmax[((chunk0 - L.own_begin) >> 6) + lane] = bm[lane];
         __builtin_amdgcn_wave_barrier();
+        WL_MARK(4)
     }
+#ifdef ACGPU_TIMING
+    if (lane == 0) {
+        atomicAdd(&g_wl_timing[0], clock64() - wl_start);
+        for (int i = 1; i < 5; ++i) atomicAdd(&g_wl_timing[i], wlt[i]);
+        atomicAdd(&g_wl_timing[5], 1ull);
+        atomicAdd(&g_wl_timing[6], wlt[5]);
+        atomicAdd(&g_wl_timing[7], wlt[6]);
+        atomicAdd(&g_wl_rounds, wlt[7]);
+    }
+#endif
 }
 
 // dynamic LDS of k_longest_walk_list (the work lists); its trie rows are static: at most longest_list_max_rows(n_cls) rows
@@ -639,6 +683,21 @@ hipError_t launch_longest_scan(const DevTables &t, const LongestScanLaunch &l, h
         else ACGPU_LAUNCH((k_longest_walk<uint32_t, false>), "k_longest_walk<unsigned int, false>");
     }
 #undef ACGPU_LAUNCH
+#ifdef ACGPU_TIMING
+    {
+        (void)hipStreamSynchronize(stream);
+        unsigned long long h[8] = {0};
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wl_timing), sizeof(h));
+        unsigned long long nr = 0;
+        (void)hipMemcpyFromSymbol(&nr, HIP_SYMBOL(g_wl_rounds), sizeof(nr));
+        if (h[5]) fprintf(stderr, "[walk timing] waves %llu: total %.0f | text wait %.0f | index+lookups+store %.0f | appends+rounds %.0f | tail rounds %.0f | list rounds %.1f: text %.0f, steps %.0f (cycles per wave)\n",
+                          h[5], (double)h[0] / h[5], (double)h[1] / h[5], (double)h[2] / h[5], (double)h[3] / h[5], (double)h[4] / h[5],
+                          (double)nr / h[5], (double)h[6] / h[5], (double)h[7] / h[5]);
+        unsigned long long z[8] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wl_rounds), z, sizeof(nr));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wl_timing), z, sizeof(z));
+    }
+#endif
     return hipGetLastError();
 }
 
