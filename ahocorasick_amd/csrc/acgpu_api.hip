@@ -954,12 +954,57 @@ int match_wwlongest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int rec
                             (uint32_t *)d.short_mark.p, (int32_t *)d.wwl_mend.p, (int32_t *)d.wwl_mid.p, (uint32_t *)d.wwl_stop.p,
                             (uint32_t)entry, stream));
     if (prof) HIP_TRY(hipEventRecord(d.ev[1], stream));
-    // (the pointer doubling squares the jump table: the walk kernel's NXT is copied first, the select pass needs it)
-    if ((rc = d.wwl_nxt0.ensure(((size_t)M + 1) * 4))) return rc;
-    HIP_TRY(hipMemcpyAsync(d.wwl_nxt0.p, d.short_nxt.p, ((size_t)M + 1) * 4, hipMemcpyDeviceToDevice, stream));
-    HIP_TRY(launch_chain_mark((uint32_t *)d.short_nxt.p, (uint32_t *)d.short_tmp.p, (uint32_t *)d.short_mark.p, M, stream));
+    // Which starts does the scan visit?  The chain k0, NXT[k0], ... over the start indices.  A walk runs over at most
+    // max_len/2 + 2 later starts, so the jumps are short and the chain is marked in ONE pass by the Longest chain kernels
+    // (tiles of indices with synchronisation points; acgpu_wwlongest.hip: k_wwl_jumps) -- pointer doubling took
+    // ceil(log2 M) rounds over all M starts (2.5 ms of 8.4 on config 5's text).  Tunable tile_debug bit 2097152 or very long
+    // keywords: the doubling.
+    const uint64_t max_jump = (uint64_t)t.max_len / 2 + 2;
+    const uint32_t *nxt_for_select = (const uint32_t *)d.short_nxt.p;
+    if (max_jump < 60000 && !(tunables().tile_debug & 2097152)) {
+        const uint32_t tile_units = M >= (1u << 22) ? 4096u : 1024u;
+        if ((rc = d.lenbuf.ensure((size_t)M * 2 + 128))) return rc;
+        if ((rc = d.blockmax.ensure(((size_t)M / 64 + 2) * 4))) return rc;
+        const size_t bit_bytes = ((size_t)M / 128 + 2) * 16;
+        if ((rc = d.chainbits.ensure(bit_bytes))) return rc;
+        HIP_TRY(hipMemsetAsync(d.chainbits.p, 0, bit_bytes, stream));
+        HIP_TRY(hipMemsetAsync((char *)d.counter.p + 16, 0xff, 8, stream)); // the chain head's index (none: all ones)
+        HIP_TRY(launch_wwl_jumps((const uint32_t *)d.short_nxt.p, (const uint32_t *)d.short_mark.p, M, (uint16_t *)d.lenbuf.p,
+                                 (uint32_t *)d.blockmax.p, (unsigned long long *)d.counter.p + 2, stream));
+        HIP_TRY(hipMemcpyAsync(d.h_counter + 3, (const char *)d.counter.p + 16, 8, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        const uint64_t head = d.h_counter[3];
+        if (head < M) {
+            LongestChainLaunch Cn{};
+            Cn.d_len = d.lenbuf.p;
+            Cn.len_bytes = 2;
+            Cn.own_begin = 0;
+            Cn.own_end = M;
+            Cn.d_blockmax = (const uint32_t *)d.blockmax.p;
+            Cn.entry = (uint32_t)head;
+            Cn.tile_units = tile_units;
+            Cn.n_tiles = (uint32_t)(((uint64_t)M - head + tile_units - 1) / tile_units);
+            Cn.max_len = (uint32_t)max_jump;
+            if ((rc = d.wwl_sel.ensure(std::max<size_t>(((size_t)M + 1) * 4, (size_t)Cn.n_tiles * 4)))) return rc;
+            Cn.d_counts = (uint32_t *)d.wwl_sel.p; // (per-tile counts nobody reads: the select pass overwrites them)
+            Cn.d_exit = (unsigned long long *)d.counter.p + 3;
+            Cn.len_units = M;
+            Cn.d_bits = (uint32_t *)d.chainbits.p;
+            Cn.record_kind = ACGPU_REC_SET;
+            if ((rc = d.chain.ensure((size_t)Cn.n_tiles * 4 + 64))) return rc;
+            HIP_TRY(launch_longest_sync(Cn, (uint32_t *)d.chain.p, stream));
+            HIP_TRY(launch_longest_chain_lds(Cn, (const uint32_t *)d.chain.p, /*write_pass=*/false, stream));
+        }
+        HIP_TRY(launch_wwl_bits_to_mark((const uint32_t *)d.chainbits.p, M, (uint32_t *)d.short_mark.p, stream));
+    } else {
+        // (the pointer doubling squares the jump table: the walk kernel's NXT is copied first, the select pass needs it)
+        if ((rc = d.wwl_nxt0.ensure(((size_t)M + 1) * 4))) return rc;
+        HIP_TRY(hipMemcpyAsync(d.wwl_nxt0.p, d.short_nxt.p, ((size_t)M + 1) * 4, hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(launch_chain_mark((uint32_t *)d.short_nxt.p, (uint32_t *)d.short_tmp.p, (uint32_t *)d.short_mark.p, M, stream));
+        nxt_for_select = (const uint32_t *)d.wwl_nxt0.p;
+    }
     HIP_TRY(launch_wwl_select((const uint32_t *)d.short_mark.p, (const int32_t *)d.wwl_mend.p, (const uint32_t *)d.wwl_rs.p,
-                              (const uint32_t *)d.wwl_nxt0.p, (const uint32_t *)d.wwl_stop.p, (uint32_t *)d.wwl_sel.p, M,
+                              nxt_for_select, (const uint32_t *)d.wwl_stop.p, (uint32_t *)d.wwl_sel.p, M,
                               (uint32_t)sh->own_begin, (uint32_t)sh->own_end, (unsigned long long *)d.counter.p, stream));
     if ((rc = d.offsets.ensure((size_t)M * 8))) return rc; // (the tile offsets are no longer needed)
     if ((rc = d.scan_tmp.ensure(((size_t)M / 2048 + 2) * 8))) return rc;

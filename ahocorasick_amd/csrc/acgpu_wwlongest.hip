@@ -146,6 +146,33 @@ __global__ __launch_bounds__(256) void k_wwl_select(const uint32_t *mark, const 
     }
 }
 
+// ---- chain marking in one pass (instead of pointer doubling) ---------------------------------------------------------------
+// The visited walk starts are the chain k0, NXT[k0], NXT[NXT[k0]], ... over the start INDICES: the same problem as the
+// greedy chain of LongestMatchSet with "length" NXT[k] - k (>= 1, bounded by the starts a walk can run over), so the
+// Longest chain kernels mark it: synchronisation points per tile of indices, one lane per tile following its segment and
+// setting a bit per visited index (acgpu_longest.hip).  These two kernels translate to and from that form.
+// jumps: len16[k] = NXT[k] - k, the farthest landing per 64 indices, and the chain head k0 (the one start the walk kernel marked)
+__global__ __launch_bounds__(256) void k_wwl_jumps(const uint32_t *nxt, const uint32_t *mark, uint32_t M, uint16_t *len16,
+                                                   uint32_t *blockmax, unsigned long long *d_head) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t land = 0;
+    if (k < M) {
+        land = nxt[k];
+        len16[k] = (uint16_t)(land - k);
+        if (mark[k]) *d_head = k;
+    }
+    // (64 consecutive indices are one wave)
+    uint32_t m = land;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
+    if ((threadIdx.x & 63u) == 0 && k < M) blockmax[k >> 6] = m;
+}
+
+__global__ __launch_bounds__(256) void k_wwl_bits_to_mark(const uint32_t *bits, uint32_t M, uint32_t *mark) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < M) mark[k] = (bits[k >> 5] >> (k & 31u)) & 1u;
+}
+
 // Literal restatement of S/WholeWordLongestMatchSet.java:47-178 by ONE lane (word-character tables that are not
 // fold-consistent; the whole haystack is one shard).  wflags bit 0 = wordChars[raw unit], bit 1 = wordChars[folded unit].
 __global__ void k_wwl_sequential(DevTables T, const uint16_t *hay, uint32_t len, void *out, uint64_t cap, int record_kind,
@@ -213,6 +240,18 @@ __global__ __launch_bounds__(256) void k_wwl_emit(const uint32_t *rs, const uint
 }
 
 } // namespace
+
+hipError_t launch_wwl_jumps(const uint32_t *d_nxt, const uint32_t *d_mark, uint32_t M, uint16_t *d_len16, uint32_t *d_blockmax,
+                            unsigned long long *d_head, hipStream_t stream) {
+    hipLaunchKernelGGL(k_wwl_jumps, dim3((M + 255) / 256), dim3(256), 0, stream, d_nxt, d_mark, M, d_len16, d_blockmax, d_head);
+    return hipGetLastError();
+}
+
+hipError_t launch_wwl_bits_to_mark(const uint32_t *d_bits, uint32_t M, uint32_t *d_mark, hipStream_t stream) {
+    hipLaunchKernelGGL(k_wwl_bits_to_mark, dim3((M + 255) / 256), dim3(256), 0, stream, d_bits, M, d_mark);
+    return hipGetLastError();
+}
+
 
 uint32_t wwl_tiles(uint32_t n_units) { return (n_units + kStartsTile - 1) / kStartsTile; }
 
