@@ -121,12 +121,23 @@ __global__ __launch_bounds__(256) void k_wwl_walk(DevTables T, const uint16_t *h
     mend[k] = end;
     mid[k] = id;
     stop[k] = i;
-    // the scan resumes at the first walk start after the stop position
-    uint32_t lo = k + 1, hi = M;
-    while (lo < hi) {
-        const uint32_t mid_k = lo + ((hi - lo) >> 1);
-        if (rs[mid_k] <= i) lo = mid_k + 1;
-        else hi = mid_k;
+    // the scan resumes at the first walk start after the stop position: almost always the very next start, otherwise a few
+    // starts on (a walk runs over few words) -- a galloping search from k + 1, not a binary search over all M starts
+    // (25 dependent loads per walk on config 5's text)
+    uint32_t lo = k + 1;
+    if (lo < M && rs[lo] <= i) {
+        uint32_t step = 1;
+        while (lo + step < M && rs[lo + step] <= i) {
+            lo += step;
+            step <<= 1;
+        }
+        uint32_t hi = min(M, lo + step); // rs[lo] <= i, and rs[hi] > i or hi == M
+        ++lo;
+        while (lo < hi) {
+            const uint32_t mid_k = lo + ((hi - lo) >> 1);
+            if (rs[mid_k] <= i) lo = mid_k + 1;
+            else hi = mid_k;
+        }
     }
     nxt[k] = lo;
 }
