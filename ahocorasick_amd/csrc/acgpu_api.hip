@@ -952,7 +952,7 @@ int match_wwlongest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int rec
                               sh->text_begin, stream));
     HIP_TRY(launch_wwl_walk(d.T, sh->d_hay, n, (const uint32_t *)d.wwl_rs.p, M, (uint32_t *)d.short_nxt.p,
                             (uint32_t *)d.short_mark.p, (int32_t *)d.wwl_mend.p, (int32_t *)d.wwl_mid.p, (uint32_t *)d.wwl_stop.p,
-                            (uint32_t)entry, stream));
+                            (uint32_t)entry, d.n_cu, stream));
     if (prof) HIP_TRY(hipEventRecord(d.ev[1], stream));
     // Which starts does the scan visit?  The chain k0, NXT[k0], ... over the start indices.  A walk runs over at most
     // max_len/2 + 2 later starts, so the jumps are short and the chain is marked in ONE pass by the Longest chain kernels
@@ -962,7 +962,8 @@ int match_wwlongest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int rec
     const uint64_t max_jump = (uint64_t)t.max_len / 2 + 2;
     const uint32_t *nxt_for_select = (const uint32_t *)d.short_nxt.p;
     if (max_jump < 60000 && !(tunables().tile_debug & 2097152)) {
-        const uint32_t tile_units = M >= (1u << 22) ? 4096u : 1024u;
+        // (jumps are ~1, so a lane makes one step per index: short tiles, i.e. many lanes; tunable region_units for A/B)
+        const uint32_t tile_units = tunables().region_units > 0 ? (uint32_t)tunables().region_units : 512u;
         if ((rc = d.lenbuf.ensure((size_t)M * 2 + 128))) return rc;
         if ((rc = d.blockmax.ensure(((size_t)M / 64 + 2) * 4))) return rc;
         const size_t bit_bytes = ((size_t)M / 128 + 2) * 16;

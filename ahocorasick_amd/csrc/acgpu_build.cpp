@@ -326,6 +326,9 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
             t.ww_bloom[b1 >> 5] |= 1u << (b1 & 31);
             t.ww_bloom[b2 >> 5] |= 1u << (b2 & 31);
         }
+    }
+    // the fold table as shared pages of 256 deltas (what the word kernels keep in LDS)
+    if (mode == ACGPU_MODE_WHOLEWORD || mode == ACGPU_MODE_WWLONGEST) {
         t.fold_pgidx.assign(256, 0);
         t.fold_pages.assign(256, 0); // page 0 = identity (no unit of the page folds): the kernel skips its lookup
         t.fold_n_pages = 1;

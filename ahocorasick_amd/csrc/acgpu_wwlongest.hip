@@ -83,63 +83,110 @@ __global__ __launch_bounds__(kStartsBlock) void k_wwl_starts(DevTables T, const 
     }
 }
 
+// One lane per walk start.  Every step of a walk is a chain of dependent memory accesses, so the kernel is as fast as that
+// chain is short: the text comes 8 units per 16-byte load, the fold table sits in LDS as shared pages (as in k_ww_tile;
+// persistent workgroups, so it is staged once per workgroup), and a probe of the hashed trie edges requests key and value
+// together -- one memory round trip per unit where the first version made four (unit, fold table, key, value).
+constexpr uint32_t kWwlFoldPagesMax = 64;
+struct __attribute__((packed, aligned(2))) WwlUnits8 {
+    uint32_t d[4];
+};
+
+template <bool PAGED>
 __global__ __launch_bounds__(256) void k_wwl_walk(DevTables T, const uint16_t *hay, uint32_t n, const uint32_t *rs, uint32_t M,
                                                   uint32_t *nxt, uint32_t *mark, int32_t *mend, int32_t *mid, uint32_t *stop,
                                                   uint32_t entry) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k > M) return;
-    if (k == M) {
-        nxt[M] = M;
-        mark[M] = 0;
-        return;
+    __shared__ __attribute__((aligned(16))) unsigned char pgidx[PAGED ? 256 : 16];
+    __shared__ __attribute__((aligned(16))) uint16_t pages[PAGED ? kWwlFoldPagesMax * 256 : 8];
+    if (PAGED) {
+        for (uint32_t i = threadIdx.x; i < 256 / 16; i += blockDim.x)
+            reinterpret_cast<uint4 *>(pgidx)[i] = reinterpret_cast<const uint4 *>(T.fold_pgidx)[i];
+        for (uint32_t i = threadIdx.x; i < T.fold_n_pages * 32u; i += blockDim.x)
+            reinterpret_cast<uint4 *>(pages)[i] = reinterpret_cast<const uint4 *>(T.fold_pages)[i];
+        __syncthreads();
     }
-    const uint32_t ws = rs[k];
-    // the scan of this shard starts at the first walk start at or after the entry position
-    mark[k] = (ws >= entry && (k == 0 || rs[k - 1] < entry)) ? 1u : 0u;
-    uint32_t node = 0, i = ws, stop_unit = 0;
-    while (i < n) {
-        const uint32_t u = hay[i];
-        const uint32_t child = hashed_goto(T.hkeys, T.hvals, T.hmask, node, T.cs ? u : (uint32_t)T.lower[u]);
-        if (child == ~0u) {
-            stop_unit = u;
-            break;
+    auto fold = [&](uint32_t u) -> uint32_t {
+        if (T.cs) return u;
+        if (PAGED) return (u + pages[(uint32_t)pgidx[u >> 8] * 256u + (u & 255u)]) & 0xffffu;
+        return (uint32_t)T.lower[u];
+    };
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k <= M; k += gridDim.x * blockDim.x) {
+        if (k == M) {
+            nxt[M] = M;
+            mark[M] = 0;
+            continue;
         }
-        node = child;
-        ++i;
-    }
-    // what the reference reports where the walk stops
-    int32_t end = 0, id = -1;
-    const bool at_end = i >= n;
-    const bool stop_is_word = !at_end && (T.wflags[stop_unit] & 1u);
-    if (!stop_is_word && node != 0 && T.term_id[node] != ~0u) {
-        end = (int32_t)i; // the whole path is a keyword and ends at a word boundary
-        id = (int32_t)T.term_id[node];
-    } else if (T.out_len[node] != 0) { // the carried fail match: ends out_link[node] units before the stop
-        end = (int32_t)(i - T.out_link[node]);
-        id = (int32_t)T.out_id[node];
-    }
-    mend[k] = end;
-    mid[k] = id;
-    stop[k] = i;
-    // the scan resumes at the first walk start after the stop position: almost always the very next start, otherwise a few
-    // starts on (a walk runs over few words) -- a galloping search from k + 1, not a binary search over all M starts
-    // (25 dependent loads per walk on config 5's text)
-    uint32_t lo = k + 1;
-    if (lo < M && rs[lo] <= i) {
-        uint32_t step = 1;
-        while (lo + step < M && rs[lo + step] <= i) {
-            lo += step;
-            step <<= 1;
+        const uint32_t ws = rs[k];
+        // the scan of this shard starts at the first walk start at or after the entry position
+        mark[k] = (ws >= entry && (k == 0 || rs[k - 1] < entry)) ? 1u : 0u;
+        uint32_t node = 0, i = ws, stop_unit = 0;
+        bool walking = true;
+        while (walking && i < n) {
+            // 8 units per load (unit by unit at the end of the buffer)
+            WwlUnits8 w{{0u, 0u, 0u, 0u}};
+            const uint32_t have = min(n - i, 8u);
+            if (have == 8) {
+                w = *reinterpret_cast<const WwlUnits8 *>(hay + i);
+            } else {
+                for (uint32_t j = 0; j < have; ++j) w.d[j >> 1] |= (uint32_t)hay[i + j] << (16 * (j & 1));
+            }
+            for (uint32_t j = 0; j < have; ++j) {
+                const uint32_t u = (w.d[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+                // hashed goto edge (node, folded unit) -> child: key and value of a slot are requested together
+                const uint64_t key = edge_key(node, fold(u));
+                uint32_t slot = edge_hash(key) & T.hmask, child = ~0u;
+                for (;;) {
+                    const uint64_t kk = T.hkeys[slot];
+                    const uint32_t vv = T.hvals[slot];
+                    if (kk == key) {
+                        child = vv;
+                        break;
+                    }
+                    if (kk == kEmptyKey) break;
+                    slot = (slot + 1) & T.hmask;
+                }
+                if (child == ~0u) {
+                    stop_unit = u;
+                    walking = false;
+                    break;
+                }
+                node = child;
+                ++i;
+            }
         }
-        uint32_t hi = min(M, lo + step); // rs[lo] <= i, and rs[hi] > i or hi == M
-        ++lo;
-        while (lo < hi) {
-            const uint32_t mid_k = lo + ((hi - lo) >> 1);
-            if (rs[mid_k] <= i) lo = mid_k + 1;
-            else hi = mid_k;
+        // what the reference reports where the walk stops
+        int32_t end = 0, id = -1;
+        const bool at_end = i >= n;
+        const bool stop_is_word = !at_end && (T.wflags[stop_unit] & 1u);
+        if (!stop_is_word && node != 0 && T.term_id[node] != ~0u) {
+            end = (int32_t)i; // the whole path is a keyword and ends at a word boundary
+            id = (int32_t)T.term_id[node];
+        } else if (T.out_len[node] != 0) { // the carried fail match: ends out_link[node] units before the stop
+            end = (int32_t)(i - T.out_link[node]);
+            id = (int32_t)T.out_id[node];
         }
+        mend[k] = end;
+        mid[k] = id;
+        stop[k] = i;
+        // the scan resumes at the first walk start after the stop position: almost always the very next start, otherwise a
+        // few starts on (a walk runs over few words) -- a galloping search from k + 1, not a binary search over all M starts
+        uint32_t lo = k + 1;
+        if (lo < M && rs[lo] <= i) {
+            uint32_t step = 1;
+            while (lo + step < M && rs[lo + step] <= i) {
+                lo += step;
+                step <<= 1;
+            }
+            uint32_t hi = min(M, lo + step); // rs[lo] <= i, and rs[hi] > i or hi == M
+            ++lo;
+            while (lo < hi) {
+                const uint32_t mid_k = lo + ((hi - lo) >> 1);
+                if (rs[mid_k] <= i) lo = mid_k + 1;
+                else hi = mid_k;
+            }
+        }
+        nxt[k] = lo;
     }
-    nxt[k] = lo;
 }
 
 // visited walk starts that report something and lie in the owned range; the LAST visited start of the owned range leaves
@@ -278,9 +325,12 @@ hipError_t launch_wwl_starts(const DevTables &t, const uint16_t *d_hay, uint32_t
 
 hipError_t launch_wwl_walk(const DevTables &t, const uint16_t *d_hay, uint32_t n, const uint32_t *d_rs, uint32_t M,
                            uint32_t *d_nxt, uint32_t *d_mark, int32_t *d_mend, int32_t *d_mid, uint32_t *d_stop, uint32_t entry,
-                           hipStream_t stream) {
-    hipLaunchKernelGGL(k_wwl_walk, dim3((M + 1 + 255) / 256), dim3(256), 0, stream, t, d_hay, n, d_rs, M, d_nxt, d_mark, d_mend,
-                       d_mid, d_stop, entry);
+                           int n_cu, hipStream_t stream) {
+    // persistent workgroups (the fold pages are staged once each): 8 per CU, fewer when there is less to do
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)std::max(n_cu, 1) * 8, ((uint64_t)M + 1 + 255) / 256);
+    const bool paged = !t.cs && t.fold_n_pages >= 1 && t.fold_n_pages <= kWwlFoldPagesMax;
+    if (paged) hipLaunchKernelGGL(k_wwl_walk<true>, dim3(grid), dim3(256), 0, stream, t, d_hay, n, d_rs, M, d_nxt, d_mark, d_mend, d_mid, d_stop, entry);
+    else hipLaunchKernelGGL(k_wwl_walk<false>, dim3(grid), dim3(256), 0, stream, t, d_hay, n, d_rs, M, d_nxt, d_mark, d_mend, d_mid, d_stop, entry);
     return hipGetLastError();
 }
 
