@@ -241,13 +241,35 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
     }
 
     // ---- 5b. WholeWord: hash table of whole folded keywords + paged fold table ----
-    if (mode == ACGPU_MODE_WHOLEWORD) {
-        // records {keyword id, length, folded units}, 16-byte aligned (what keywords of more than 12 units are compared with)
+    // WHOLEWORD: the table holds the keywords (payload: keyword id).  WWLONGEST: it holds the trie nodes a walk can stand on
+    // when its first word ends -- paths of word characters only that are a keyword or go on with a non-word unit (payload:
+    // node number, bit 31 = "goes on"); any other first word reports nothing and the walk is over (acgpu_wwlongest.hip).
+    if (mode == ACGPU_MODE_WHOLEWORD || mode == ACGPU_MODE_WWLONGEST) {
+        // records {payload, length, folded units}, 16-byte aligned (what keywords of more than 12 units are compared with)
         struct WwKey { uint32_t h, g, off16; };
         std::vector<WwKey> keys;
         std::vector<uint16_t> word;
+        std::vector<uint8_t> allword, goes_on;
+        if (mode == ACGPU_MODE_WWLONGEST) {
+            allword.assign(N, 0);
+            goes_on.assign(N, 0);
+            allword[0] = 1;
+            for (uint32_t s : bfs) // (parents before children)
+                for (uint32_t ci = child_begin[s]; ci < child_begin[s + 1]; ci++) {
+                    const uint32_t c = child_ids[ci];
+                    const bool wc = wordchar_tbl[nodes[c].unit] != 0;
+                    allword[c] = allword[s] && wc;
+                    if (!wc) goes_on[s] = 1;
+                }
+        }
         for (uint32_t s = 1; s < N; s++) {
-            if (nodes[s].kw == ~0u) continue;
+            uint32_t payload = nodes[s].kw;
+            if (mode == ACGPU_MODE_WWLONGEST) {
+                if (!allword[s] || nodes[s].depth > kWwInlineUnits || (nodes[s].kw == ~0u && !goes_on[s])) continue;
+                payload = newid[s] | (goes_on[s] ? 0x80000000u : 0u);
+            } else if (nodes[s].kw == ~0u) {
+                continue;
+            }
             const uint32_t len = nodes[s].depth;
             word.resize(len);
             for (uint32_t n = s, i = len; n != 0; n = nodes[n].parent) word[--i] = nodes[n].unit;
@@ -256,7 +278,7 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
             const size_t words = 2 + (len + 1) / 2;
             t.ww_recs.resize(t.ww_recs.size() + (words + 3) / 4 * 4, 0u);
             uint32_t *rec = &t.ww_recs[off16 * 4];
-            rec[0] = nodes[s].kw;
+            rec[0] = payload;
             rec[1] = len;
             for (uint32_t i = 0; i < len; i++) rec[2 + (i >> 1)] |= (uint32_t)word[i] << (16 * (i & 1));
             keys.push_back(WwKey{0u, 0u, (uint32_t)off16});

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(kStartsBlock) void k_wwl_starts(DevTables T, const 
 // chain is short: the text comes 8 units per 16-byte load, the fold table sits in LDS as shared pages (as in k_ww_tile;
 // persistent workgroups, so it is staged once per workgroup), and a probe of the hashed trie edges requests key and value
 // together -- one memory round trip per unit where the first version made four (unit, fold table, key, value).
-constexpr uint32_t kWwlFoldPagesMax = 64;
+constexpr uint32_t kWwlFoldPagesMax = 24; // 12 KB of LDS per workgroup (Unicode 13 simple lower-casing needs 18 pages)
 struct __attribute__((packed, aligned(2))) WwlUnits8 {
     uint32_t d[4];
 };
@@ -98,6 +98,10 @@ __global__ __launch_bounds__(256) void k_wwl_walk(DevTables T, const uint16_t *h
                                                   uint32_t entry) {
     __shared__ __attribute__((aligned(16))) unsigned char pgidx[PAGED ? 256 : 16];
     __shared__ __attribute__((aligned(16))) uint16_t pages[PAGED ? kWwlFoldPagesMax * 256 : 8];
+    __shared__ __attribute__((aligned(16))) uint32_t wbits[2048]; // 65536 word-character bits
+    for (uint32_t i = threadIdx.x; i < 2048 / 4; i += blockDim.x)
+        reinterpret_cast<uint4 *>(wbits)[i] = reinterpret_cast<const uint4 *>(T.wbits)[i];
+    if (!PAGED) __syncthreads();
     if (PAGED) {
         for (uint32_t i = threadIdx.x; i < 256 / 16; i += blockDim.x)
             reinterpret_cast<uint4 *>(pgidx)[i] = reinterpret_cast<const uint4 *>(T.fold_pgidx)[i];
@@ -121,6 +125,52 @@ __global__ __launch_bounds__(256) void k_wwl_walk(DevTables T, const uint16_t *h
         mark[k] = (ws >= entry && (k == 0 || rs[k - 1] < entry)) ? 1u : 0u;
         uint32_t node = 0, i = ws, stop_unit = 0;
         bool walking = true;
+        // The first word of the walk, looked up WHOLE (the builder's table of the trie nodes a walk can stand on when its
+        // first word ends: word-character paths that are a keyword or go on with a non-word unit; the hashing and the
+        // two-choice table of k_ww_tile): one probe instead of one per unit.  A first word that is not in the table
+        // reports nothing -- the walk dies inside it or at its end on a node without a keyword, and no keyword "followed by
+        // a non-word unit" has been passed yet -- and the scan goes on behind it either way.  Runs of more than 12 units
+        // and a walk that starts on a non-word unit (position 0) take the unit-by-unit walk from the start.
+        if (T.ww_fat && ws + 16 <= n) {
+            const WwlUnits8 a = *reinterpret_cast<const WwlUnits8 *>(hay + ws), b = *reinterpret_cast<const WwlUnits8 *>(hay + ws + 8);
+            const uint32_t wd[8] = {a.d[0], a.d[1], a.d[2], a.d[3], b.d[0], b.d[1], b.d[2], b.d[3]};
+            uint32_t wm = 0, f[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t u = (wd[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+                wm |= ((wbits[u >> 5] >> (u & 31u)) & 1u) << j;
+                f[j] = fold(u);
+            }
+            const uint32_t r = (uint32_t)__builtin_ctz(~wm | 0x10000u); // word characters from the start on (0..16)
+            if (r >= 1 && r <= kWwInlineUnits) {
+                uint32_t h = T.ww_seed, g = T.ww_seed, fw[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const uint32_t lo = (uint32_t)(2 * q) < r ? f[2 * q] : 0u, hi = (uint32_t)(2 * q + 1) < r ? f[2 * q + 1] : 0u;
+                    fw[q] = lo | (hi << 16);
+                    h = ww_hash_step(h, fw[q]);
+                    g = ww_hash2_step(g, fw[q]);
+                }
+                h = ww_hash_final(h);
+                const uint32_t tag = ww_tag(h, r);
+                const uint4 *fat = reinterpret_cast<const uint4 *>(T.ww_fat);
+                const uint32_t s1 = ww_slot1(h, T.ww_fat_mask), s2 = ww_slot2(h, g, T.ww_fat_mask);
+                const uint4 ea0 = fat[2 * s1], ea1 = fat[2 * s1 + 1], eb0 = fat[2 * s2], eb1 = fat[2 * s2 + 1];
+                const bool in_a = ea0.x == tag && ea0.z == fw[0] && ea0.w == fw[1] && ea1.x == fw[2] && ea1.y == fw[3] &&
+                                  ea1.z == fw[4] && ea1.w == fw[5];
+                const bool in_b = eb0.x == tag && eb0.z == fw[0] && eb0.w == fw[1] && eb1.x == fw[2] && eb1.y == fw[3] &&
+                                  eb1.z == fw[4] && eb1.w == fw[5];
+                i = ws + r; // (the unit behind the run: a non-word unit, inside the buffer)
+                if (in_a || in_b) {
+                    const uint32_t payload = in_a ? ea0.y : eb0.y;
+                    node = payload & 0x7fffffffu;
+                    walking = (payload >> 31) != 0; // the path goes on with a non-word unit: unit by unit from here
+                } else {
+                    walking = false;
+                }
+                if (!walking) stop_unit = hay[i];
+            }
+        }
         while (walking && i < n) {
             // 8 units per load (unit by unit at the end of the buffer)
             WwlUnits8 w{{0u, 0u, 0u, 0u}};
