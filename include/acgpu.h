@@ -145,7 +145,8 @@ int acgpu_match_u16(const acgpu_automaton *a, const uint16_t *haystack, uint64_t
  * LONGEST -> to the shard that owns its first unit, given the greedy chain's entry position
  * (right halo >= max_keyword_len-1 units); WWLONGEST -> to the shard that owns its first unit (left halo 1 unit, right
  * halo max_keyword_len+1 units), given the position from which the scan looks for its next word start (chain_entry;
- * chain_exit: the position behind the stop of the last walk this shard's scan made); SHORTEST -> to the shard that owns its LAST unit (left halo as ALL), given
+ * chain_exit: a position behind the last walk this shard's scan made from which the search for the next word start finds
+ * what the reference's scan finds -- behind the walk's stop, or behind the word in which the walk died); SHORTEST -> to the shard that owns its LAST unit (left halo as ALL), given
  * the position at which matching last restarted (chain_entry: no match may start before it; chain_exit: the end of
  * the last match reported, or chain_entry if there was none).
  */
