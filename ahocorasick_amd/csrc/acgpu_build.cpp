@@ -243,7 +243,7 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
     // ---- 5b. WholeWord: hash table of whole folded keywords + paged fold table ----
     // WHOLEWORD: the table holds the keywords (payload: keyword id).  WWLONGEST: it holds the trie nodes a walk can stand on
     // when its first word ends -- paths of word characters only that are a keyword or go on with a non-word unit (payload:
-    // node number, bit 31 = "goes on"); any other first word reports nothing and the walk is over (acgpu_wwlongest.hip).
+    // bit 31 and the node number if the path goes on, else the keyword id); any other first word reports nothing and the walk is over (acgpu_wwlongest.hip).
     if (mode == ACGPU_MODE_WHOLEWORD || mode == ACGPU_MODE_WWLONGEST) {
         // records {payload, length, folded units}, 16-byte aligned (what keywords of more than 12 units are compared with)
         struct WwKey { uint32_t h, g, off16; };
@@ -266,7 +266,8 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
             uint32_t payload = nodes[s].kw;
             if (mode == ACGPU_MODE_WWLONGEST) {
                 if (!allword[s] || nodes[s].depth > kWwInlineUnits || (nodes[s].kw == ~0u && !goes_on[s])) continue;
-                payload = newid[s] | (goes_on[s] ? 0x80000000u : 0u);
+                // (a node the walk cannot leave needs no number: what it reports is its keyword)
+                payload = goes_on[s] ? (newid[s] | 0x80000000u) : nodes[s].kw;
             } else if (nodes[s].kw == ~0u) {
                 continue;
             }

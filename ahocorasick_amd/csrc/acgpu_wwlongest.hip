@@ -124,7 +124,8 @@ __global__ __launch_bounds__(256) void k_wwl_walk(DevTables T, const uint16_t *h
         // the scan of this shard starts at the first walk start at or after the entry position
         mark[k] = (ws >= entry && (k == 0 || rs[k - 1] < entry)) ? 1u : 0u;
         uint32_t node = 0, i = ws, stop_unit = 0;
-        bool walking = true;
+        bool walking = true, resolved = false; // resolved: the first-word table has settled the walk (nothing else to read)
+        int32_t word_id = -1;
         // The first word of the walk, looked up WHOLE (the builder's table of the trie nodes a walk can stand on when its
         // first word ends: word-character paths that are a keyword or go on with a non-word unit; the hashing and the
         // two-choice table of k_ww_tile): one probe instead of one per unit.  A first word that is not in the table
@@ -161,14 +162,17 @@ __global__ __launch_bounds__(256) void k_wwl_walk(DevTables T, const uint16_t *h
                 const bool in_b = eb0.x == tag && eb0.z == fw[0] && eb0.w == fw[1] && eb1.x == fw[2] && eb1.y == fw[3] &&
                                   eb1.z == fw[4] && eb1.w == fw[5];
                 i = ws + r; // (the unit behind the run: a non-word unit, inside the buffer)
+                walking = false;
                 if (in_a || in_b) {
                     const uint32_t payload = in_a ? ea0.y : eb0.y;
-                    node = payload & 0x7fffffffu;
-                    walking = (payload >> 31) != 0; // the path goes on with a non-word unit: unit by unit from here
-                } else {
-                    walking = false;
+                    if (payload >> 31) { // the path goes on with a non-word unit: unit by unit from its node
+                        node = payload & 0x7fffffffu;
+                        walking = true;
+                    } else { // the walk ends here, on a keyword followed by a non-word unit: the payload is its id
+                        word_id = (int32_t)payload;
+                    }
                 }
-                if (!walking) stop_unit = hay[i];
+                resolved = !walking;
             }
         }
         while (walking && i < n) {
@@ -207,8 +211,13 @@ __global__ __launch_bounds__(256) void k_wwl_walk(DevTables T, const uint16_t *h
         // what the reference reports where the walk stops
         int32_t end = 0, id = -1;
         const bool at_end = i >= n;
-        const bool stop_is_word = !at_end && (T.wflags[stop_unit] & 1u);
-        if (!stop_is_word && node != 0 && T.term_id[node] != ~0u) {
+        const bool stop_is_word = !resolved && !at_end && (T.wflags[stop_unit] & 1u);
+        if (resolved) {
+            if (word_id >= 0) {
+                end = (int32_t)i;
+                id = word_id;
+            }
+        } else if (!stop_is_word && node != 0 && T.term_id[node] != ~0u) {
             end = (int32_t)i; // the whole path is a keyword and ends at a word boundary
             id = (int32_t)T.term_id[node];
         } else if (T.out_len[node] != 0) { // the carried fail match: ends out_link[node] units before the stop
