@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void k_wwl_walk(DevTables T, const uint16_t *h
                                                   uint32_t *nxt, uint32_t *mark, int32_t *mend, int32_t *mid, uint32_t *stop,
                                                   uint32_t entry) {
     __shared__ __attribute__((aligned(16))) unsigned char pgidx[PAGED ? 256 : 16];
-    __shared__ __attribute__((aligned(16))) uint16_t pages[PAGED ? kWwlFoldPagesMax * 256 : 8];
+    extern __shared__ __attribute__((aligned(16))) uint16_t pages[]; // PAGED: fold_n_pages * 256 deltas
     __shared__ __attribute__((aligned(16))) uint32_t wbits[2048]; // 65536 word-character bits
     for (uint32_t i = threadIdx.x; i < 2048 / 4; i += blockDim.x)
         reinterpret_cast<uint4 *>(wbits)[i] = reinterpret_cast<const uint4 *>(T.wbits)[i];
@@ -385,10 +385,11 @@ hipError_t launch_wwl_starts(const DevTables &t, const uint16_t *d_hay, uint32_t
 hipError_t launch_wwl_walk(const DevTables &t, const uint16_t *d_hay, uint32_t n, const uint32_t *d_rs, uint32_t M,
                            uint32_t *d_nxt, uint32_t *d_mark, int32_t *d_mend, int32_t *d_mid, uint32_t *d_stop, uint32_t entry,
                            int n_cu, hipStream_t stream) {
-    // persistent workgroups (the fold pages are staged once each): 8 per CU, fewer when there is less to do
+    // persistent workgroups (the LDS tables are staged once each): 8 per CU -- all the waves a CU holds; the fold pages are
+    // dynamic LDS so that Unicode's 18 pages leave room for all eight -- fewer when there is less to do
     const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)std::max(n_cu, 1) * 8, ((uint64_t)M + 1 + 255) / 256);
     const bool paged = !t.cs && t.fold_n_pages >= 1 && t.fold_n_pages <= kWwlFoldPagesMax;
-    if (paged) hipLaunchKernelGGL(k_wwl_walk<true>, dim3(grid), dim3(256), 0, stream, t, d_hay, n, d_rs, M, d_nxt, d_mark, d_mend, d_mid, d_stop, entry);
+    if (paged) hipLaunchKernelGGL(k_wwl_walk<true>, dim3(grid), dim3(256), (size_t)t.fold_n_pages * 512, stream, t, d_hay, n, d_rs, M, d_nxt, d_mark, d_mend, d_mid, d_stop, entry);
     else hipLaunchKernelGGL(k_wwl_walk<false>, dim3(grid), dim3(256), 0, stream, t, d_hay, n, d_rs, M, d_nxt, d_mark, d_mend, d_mid, d_stop, entry);
     return hipGetLastError();
 }
