@@ -590,6 +590,75 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
     return *n_out > cap ? ACGPU_E_OVERFLOW : ACGPU_OK;
 }
 
+// Marks the chain k0, nxt[k0], nxt[nxt[k0]], ... (nxt[k] in (k, M], nxt[M] = M; d_mark[k0] = 1 on entry, every other mark 0):
+// afterwards d_mark[k] = 1 exactly for the chain's elements.  One pass when the jumps are short: with nxt[k] - k as the
+// "length" this is the greedy chain of LongestMatchSet, and the Longest chain kernels mark it (tiles of indices with
+// synchronisation points, one lane per tile, a bit per visited index; acgpu_longest.hip, acgpu_wwlongest.hip: k_wwl_jumps);
+// pointer doubling -- ceil(log2 M) rounds over all M elements -- otherwise (tiny inputs, jumps beyond 16 bits, tunable
+// tile_debug bit 2097152).  The doubling squares the jump table: *d_nxt_kept is where the successors survive
+// (d_nxt itself, or d_nxt_copy -- M + 1 words, may be null if the caller does not need them).
+// jump_bound: what the caller knows nxt[k] - k cannot exceed (0: unknown -- the largest jump is measured).  The one pass has a
+// fixed cost (a read-back, four small launches) that 21 doubling rounds over a million elements do not reach: it is taken
+// from 4 M elements on.
+int mark_chain(DeviceState &d, uint32_t *d_nxt, uint32_t *d_tmp, uint32_t *d_mark, uint32_t M, hipStream_t stream,
+               uint32_t *d_nxt_copy, const uint32_t **d_nxt_kept, uint32_t jump_bound) {
+    int rc;
+    if (d_nxt_kept) *d_nxt_kept = d_nxt;
+    // (tunable tile_debug: bit 2097152 = always the doubling, bit 4194304 = the one pass from 64 elements on -- tests)
+    const uint32_t one_pass_from = (tunables().tile_debug & 4194304) ? 64u : (1u << 22);
+    bool one_pass = M >= one_pass_from && jump_bound <= 60000 && !(tunables().tile_debug & 2097152);
+    uint64_t head = ~0ull, max_jump = 0;
+    if (one_pass) {
+        if ((rc = d.counter.ensure(64))) return rc;
+        if ((rc = d.lenbuf.ensure((size_t)M * 2 + 128))) return rc;
+        if ((rc = d.blockmax.ensure(((size_t)M / 64 + 2) * 4))) return rc;
+        HIP_TRY(hipMemsetAsync((char *)d.counter.p + 16, 0xff, 8, stream)); // the chain head's index (none: all ones)
+        HIP_TRY(hipMemsetAsync((char *)d.counter.p + 24, 0, 8, stream));    // the largest jump
+        HIP_TRY(launch_wwl_jumps(d_nxt, d_mark, M, (uint16_t *)d.lenbuf.p, (uint32_t *)d.blockmax.p,
+                                 (unsigned long long *)d.counter.p + 2, jump_bound == 0, stream));
+        HIP_TRY(hipMemcpyAsync(d.h_counter + 3, (const char *)d.counter.p + 16, 16, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        head = d.h_counter[3];
+        max_jump = jump_bound ? jump_bound : d.h_counter[4];
+        if (head >= M) return ACGPU_OK; // no head: nothing is marked, nothing to mark
+        if (max_jump > 60000) one_pass = false;
+    }
+    if (!one_pass) {
+        if (d_nxt_copy) {
+            HIP_TRY(hipMemcpyAsync(d_nxt_copy, d_nxt, ((size_t)M + 1) * 4, hipMemcpyDeviceToDevice, stream));
+            if (d_nxt_kept) *d_nxt_kept = d_nxt_copy;
+        }
+        HIP_TRY(launch_chain_mark(d_nxt, d_tmp, d_mark, M, stream));
+        return ACGPU_OK;
+    }
+    // (jumps are ~1, so a lane makes about one step per index: short tiles, i.e. many lanes)
+    const uint32_t tile_units = 512;
+    const size_t bit_bytes = ((size_t)M / 128 + 2) * 16;
+    if ((rc = d.chainbits.ensure(bit_bytes))) return rc;
+    HIP_TRY(hipMemsetAsync(d.chainbits.p, 0, bit_bytes, stream));
+    LongestChainLaunch Cn{};
+    Cn.d_len = d.lenbuf.p;
+    Cn.len_bytes = 2;
+    Cn.own_begin = 0;
+    Cn.own_end = M;
+    Cn.d_blockmax = (const uint32_t *)d.blockmax.p;
+    Cn.entry = (uint32_t)head;
+    Cn.tile_units = tile_units;
+    Cn.n_tiles = (uint32_t)(((uint64_t)M - head + tile_units - 1) / tile_units);
+    Cn.max_len = (uint32_t)std::max<uint64_t>(max_jump, 1);
+    if ((rc = d.chunk_counts.ensure((size_t)Cn.n_tiles * 4))) return rc;
+    Cn.d_counts = (uint32_t *)d.chunk_counts.p; // (per-tile counts nobody reads)
+    Cn.d_exit = (unsigned long long *)d.counter.p + 3;
+    Cn.len_units = M;
+    Cn.d_bits = (uint32_t *)d.chainbits.p;
+    Cn.record_kind = ACGPU_REC_SET;
+    if ((rc = d.chain.ensure((size_t)Cn.n_tiles * 4 + 64))) return rc;
+    HIP_TRY(launch_longest_sync(Cn, (uint32_t *)d.chain.p, stream));
+    HIP_TRY(launch_longest_chain_lds(Cn, (const uint32_t *)d.chain.p, /*write_pass=*/false, stream));
+    HIP_TRY(launch_wwl_bits_to_mark((const uint32_t *)d.chainbits.p, M, d_mark, stream));
+    return ACGPU_OK;
+}
+
 // LONGEST over a dictionary whose suffix filter is selective: matches are sparse, so leftmost-longest is a selection
 // over the all-matches list (the AhoCorasick tile pipeline into an internal buffer + k_long_next + chain marking)
 // instead of a trie walk from every position.  Returns ACGPU_E_UNSUPPORTED when the haystack turns out to be dense in
@@ -633,6 +702,9 @@ int match_longest_sparse(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, in
     if (prof) HIP_TRY(hipEventRecord(d.ev[0], stream));
     HIP_TRY(launch_longest_select((const int32_t *)d.short_recs.p, M, (int64_t)entry, (int64_t)sh->own_end, t.max_len,
                                   (uint32_t *)d.short_nxt.p, (uint32_t *)d.short_tmp.p, (uint32_t *)d.short_mark.p, stream));
+    if ((rc = mark_chain(d, (uint32_t *)d.short_nxt.p, (uint32_t *)d.short_tmp.p, (uint32_t *)d.short_mark.p, M, stream, nullptr,
+                         nullptr, 0)))
+        return rc;
     HIP_TRY(launch_exclusive_scan((const uint32_t *)d.short_mark.p, M, (uint64_t *)d.offsets.p, (uint64_t *)d.scan_tmp.p, stream));
     const uint64_t *d_total = (const uint64_t *)d.scan_tmp.p + scan_tiles_for(M);
     HIP_TRY(launch_shortest_emit((const int32_t *)d.short_recs.p, M, (const uint32_t *)d.short_mark.p,
@@ -863,6 +935,9 @@ int match_shortest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int reco
     if (prof) HIP_TRY(hipEventRecord(d.ev[0], stream));
     HIP_TRY(launch_shortest_select((const int32_t *)d.short_recs.p, M, entry, (uint32_t *)d.short_nxt.p,
                                    (uint32_t *)d.short_tmp.p, (uint32_t *)d.short_mark.p, stream));
+    if ((rc = mark_chain(d, (uint32_t *)d.short_nxt.p, (uint32_t *)d.short_tmp.p, (uint32_t *)d.short_mark.p, M, stream, nullptr,
+                         nullptr, 0)))
+        return rc;
     HIP_TRY(launch_exclusive_scan((const uint32_t *)d.short_mark.p, M, (uint64_t *)d.offsets.p, (uint64_t *)d.scan_tmp.p, stream));
     const uint64_t *d_total = (const uint64_t *)d.scan_tmp.p + scan_tiles_for(M);
     HIP_TRY(launch_shortest_emit((const int32_t *)d.short_recs.p, M, (const uint32_t *)d.short_mark.p,
@@ -954,56 +1029,14 @@ int match_wwlongest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int rec
                             (uint32_t *)d.short_mark.p, (int32_t *)d.wwl_mend.p, (int32_t *)d.wwl_mid.p, (uint32_t *)d.wwl_stop.p,
                             (uint32_t)entry, d.n_cu, stream));
     if (prof) HIP_TRY(hipEventRecord(d.ev[1], stream));
-    // Which starts does the scan visit?  The chain k0, NXT[k0], ... over the start indices.  A walk runs over at most
-    // max_len/2 + 2 later starts, so the jumps are short and the chain is marked in ONE pass by the Longest chain kernels
-    // (tiles of indices with synchronisation points; acgpu_wwlongest.hip: k_wwl_jumps) -- pointer doubling took
-    // ceil(log2 M) rounds over all M starts (2.5 ms of 8.4 on config 5's text).  Tunable tile_debug bit 2097152 or very long
-    // keywords: the doubling.
-    const uint64_t max_jump = (uint64_t)t.max_len / 2 + 2;
-    const uint32_t *nxt_for_select = (const uint32_t *)d.short_nxt.p;
-    if (max_jump < 60000 && !(tunables().tile_debug & 2097152)) {
-        // (jumps are ~1, so a lane makes one step per index: short tiles, i.e. many lanes; tunable region_units for A/B)
-        const uint32_t tile_units = tunables().region_units > 0 ? (uint32_t)tunables().region_units : 512u;
-        if ((rc = d.lenbuf.ensure((size_t)M * 2 + 128))) return rc;
-        if ((rc = d.blockmax.ensure(((size_t)M / 64 + 2) * 4))) return rc;
-        const size_t bit_bytes = ((size_t)M / 128 + 2) * 16;
-        if ((rc = d.chainbits.ensure(bit_bytes))) return rc;
-        HIP_TRY(hipMemsetAsync(d.chainbits.p, 0, bit_bytes, stream));
-        HIP_TRY(hipMemsetAsync((char *)d.counter.p + 16, 0xff, 8, stream)); // the chain head's index (none: all ones)
-        HIP_TRY(launch_wwl_jumps((const uint32_t *)d.short_nxt.p, (const uint32_t *)d.short_mark.p, M, (uint16_t *)d.lenbuf.p,
-                                 (uint32_t *)d.blockmax.p, (unsigned long long *)d.counter.p + 2, stream));
-        HIP_TRY(hipMemcpyAsync(d.h_counter + 3, (const char *)d.counter.p + 16, 8, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        const uint64_t head = d.h_counter[3];
-        if (head < M) {
-            LongestChainLaunch Cn{};
-            Cn.d_len = d.lenbuf.p;
-            Cn.len_bytes = 2;
-            Cn.own_begin = 0;
-            Cn.own_end = M;
-            Cn.d_blockmax = (const uint32_t *)d.blockmax.p;
-            Cn.entry = (uint32_t)head;
-            Cn.tile_units = tile_units;
-            Cn.n_tiles = (uint32_t)(((uint64_t)M - head + tile_units - 1) / tile_units);
-            Cn.max_len = (uint32_t)max_jump;
-            if ((rc = d.wwl_sel.ensure(std::max<size_t>(((size_t)M + 1) * 4, (size_t)Cn.n_tiles * 4)))) return rc;
-            Cn.d_counts = (uint32_t *)d.wwl_sel.p; // (per-tile counts nobody reads: the select pass overwrites them)
-            Cn.d_exit = (unsigned long long *)d.counter.p + 3;
-            Cn.len_units = M;
-            Cn.d_bits = (uint32_t *)d.chainbits.p;
-            Cn.record_kind = ACGPU_REC_SET;
-            if ((rc = d.chain.ensure((size_t)Cn.n_tiles * 4 + 64))) return rc;
-            HIP_TRY(launch_longest_sync(Cn, (uint32_t *)d.chain.p, stream));
-            HIP_TRY(launch_longest_chain_lds(Cn, (const uint32_t *)d.chain.p, /*write_pass=*/false, stream));
-        }
-        HIP_TRY(launch_wwl_bits_to_mark((const uint32_t *)d.chainbits.p, M, (uint32_t *)d.short_mark.p, stream));
-    } else {
-        // (the pointer doubling squares the jump table: the walk kernel's NXT is copied first, the select pass needs it)
-        if ((rc = d.wwl_nxt0.ensure(((size_t)M + 1) * 4))) return rc;
-        HIP_TRY(hipMemcpyAsync(d.wwl_nxt0.p, d.short_nxt.p, ((size_t)M + 1) * 4, hipMemcpyDeviceToDevice, stream));
-        HIP_TRY(launch_chain_mark((uint32_t *)d.short_nxt.p, (uint32_t *)d.short_tmp.p, (uint32_t *)d.short_mark.p, M, stream));
-        nxt_for_select = (const uint32_t *)d.wwl_nxt0.p;
-    }
+    // Which starts does the scan visit?  The chain k0, NXT[k0], ... over the start indices: mark_chain (one pass -- a walk
+    // runs over few later starts; pointer doubling took 2.5 ms of 8.4 on config 5's text).  The select pass needs the
+    // successors afterwards.
+    const uint32_t *nxt_for_select = nullptr;
+    if ((rc = d.wwl_nxt0.ensure(((size_t)M + 1) * 4))) return rc;
+    if ((rc = mark_chain(d, (uint32_t *)d.short_nxt.p, (uint32_t *)d.short_tmp.p, (uint32_t *)d.short_mark.p, M, stream,
+                         (uint32_t *)d.wwl_nxt0.p, &nxt_for_select, t.max_len / 2 + 2)))
+        return rc;
     HIP_TRY(launch_wwl_select((const uint32_t *)d.short_mark.p, (const int32_t *)d.wwl_mend.p, (const uint32_t *)d.wwl_rs.p,
                               nxt_for_select, (const uint32_t *)d.wwl_stop.p, (uint32_t *)d.wwl_sel.p, M,
                               (uint32_t)sh->own_begin, (uint32_t)sh->own_end, (unsigned long long *)d.counter.p, stream));

@@ -207,7 +207,7 @@ hipError_t launch_wwl_select(const uint32_t *d_mark, const int32_t *d_mend, cons
                              unsigned long long *d_exit, hipStream_t stream);
 // chain marking in one pass: index jumps for the Longest chain kernels, and their bitmap back into the mark array
 hipError_t launch_wwl_jumps(const uint32_t *d_nxt, const uint32_t *d_mark, uint32_t M, uint16_t *d_len16, uint32_t *d_blockmax,
-                            unsigned long long *d_head, hipStream_t stream);
+                            unsigned long long *d_head, bool measure_max_jump, hipStream_t stream);
 hipError_t launch_wwl_bits_to_mark(const uint32_t *d_bits, uint32_t M, uint32_t *d_mark, hipStream_t stream);
 hipError_t launch_wwl_sequential(const DevTables &t, const uint16_t *d_hay, uint32_t len, void *d_out, uint64_t cap,
                                  int record_kind, unsigned long long *d_counter, hipStream_t stream);

@@ -137,7 +137,8 @@ __global__ __launch_bounds__(256) void k_short_emit(const int32_t *recs, uint32_
 
 } // namespace
 
-// d_nxt, d_tmp: M+1 uint32 each; d_mark: M+1 uint32.  After the call d_mark[k] = 1 for the selected records.
+// d_nxt, d_tmp: M+1 uint32 each; d_mark: M+1 uint32.  After the call d_nxt holds every record's successor and d_mark[k] = 1
+// for the head of the chain; marking the chain is the caller's next step (acgpu_api.hip: mark_chain).
 hipError_t launch_shortest_select(const int32_t *d_recs, uint32_t M, int64_t entry, uint32_t *d_nxt, uint32_t *d_tmp,
                                   uint32_t *d_mark, hipStream_t stream) {
     if (M == 0) return hipSuccess;
@@ -145,7 +146,8 @@ hipError_t launch_shortest_select(const int32_t *d_recs, uint32_t M, int64_t ent
     const int32_t e32 = (int32_t)std::min<int64_t>(std::max<int64_t>(entry, 0), 0x7fffffff);
     hipLaunchKernelGGL(k_short_clear, grid, block, 0, stream, d_mark, M);
     hipLaunchKernelGGL(k_short_next, grid, block, 0, stream, d_recs, M, e32, d_nxt, d_mark);
-    return launch_chain_mark(d_nxt, d_tmp, d_mark, M, stream);
+    (void)d_tmp; // (the chain is marked by the caller: acgpu_api.hip mark_chain)
+    return hipGetLastError();
 }
 
 // Longest over the all-matches list: see k_long_next.  limit = own_end (matches must start before it).
@@ -156,7 +158,8 @@ hipError_t launch_longest_select(const int32_t *d_recs, uint32_t M, int64_t entr
     hipLaunchKernelGGL(k_short_clear, grid, block, 0, stream, d_mark, M);
     hipLaunchKernelGGL(k_long_next, grid, block, 0, stream, d_recs, M, (int32_t)std::min<int64_t>(entry, 0x7fffffff),
                        (int32_t)std::min<int64_t>(limit, 0x7fffffff), (int32_t)max_len, d_nxt, d_mark);
-    return launch_chain_mark(d_nxt, d_tmp, d_mark, M, stream);
+    (void)d_tmp; // (the chain is marked by the caller: acgpu_api.hip mark_chain)
+    return hipGetLastError();
 }
 
 // Marks every element of the chain that starts at the elements already marked: nxt[k] in (k, M], nxt[M] = M.

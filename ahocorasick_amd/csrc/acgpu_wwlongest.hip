@@ -268,15 +268,26 @@ __global__ __launch_bounds__(256) void k_wwl_select(const uint32_t *mark, const 
 // greedy chain of LongestMatchSet with "length" NXT[k] - k (>= 1, bounded by the starts a walk can run over), so the
 // Longest chain kernels mark it: synchronisation points per tile of indices, one lane per tile following its segment and
 // setting a bit per visited index (acgpu_longest.hip).  These two kernels translate to and from that form.
-// jumps: len16[k] = NXT[k] - k, the farthest landing per 64 indices, and the chain head k0 (the one start the walk kernel marked)
+// jumps: len16[k] = NXT[k] - k, the farthest landing per 64 indices, the chain head k0 (the one element marked so far, d_head[0])
+// and the largest jump (d_head[1])
+template <bool MEASURE>
 __global__ __launch_bounds__(256) void k_wwl_jumps(const uint32_t *nxt, const uint32_t *mark, uint32_t M, uint16_t *len16,
                                                    uint32_t *blockmax, unsigned long long *d_head) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t land = 0;
     if (k < M) {
         land = nxt[k];
-        len16[k] = (uint16_t)(land - k);
-        if (mark[k]) *d_head = k;
+        len16[k] = (uint16_t)min(land - k, 65535u);
+        if (mark[k]) d_head[0] = k;
+    }
+    if (MEASURE) { // the largest jump (d_head[1]): bounds how far back a synchronisation scan has to look
+        uint32_t j = k < M ? land - k : 0u;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) j = max(j, (uint32_t)__shfl_xor((int)j, d));
+        // (one address for every wave: the atomic only when the value read is smaller -- half a million atomics on one
+        // address were 5 ms)
+        if ((threadIdx.x & 63u) == 0 && (unsigned long long)j > *reinterpret_cast<volatile unsigned long long *>(&d_head[1]))
+            atomicMax(&d_head[1], (unsigned long long)j);
     }
     // (64 consecutive indices are one wave)
     uint32_t m = land;
@@ -359,8 +370,11 @@ __global__ __launch_bounds__(256) void k_wwl_emit(const uint32_t *rs, const uint
 } // namespace
 
 hipError_t launch_wwl_jumps(const uint32_t *d_nxt, const uint32_t *d_mark, uint32_t M, uint16_t *d_len16, uint32_t *d_blockmax,
-                            unsigned long long *d_head, hipStream_t stream) {
-    hipLaunchKernelGGL(k_wwl_jumps, dim3((M + 255) / 256), dim3(256), 0, stream, d_nxt, d_mark, M, d_len16, d_blockmax, d_head);
+                            unsigned long long *d_head, bool measure_max_jump, hipStream_t stream) {
+    if (measure_max_jump)
+        hipLaunchKernelGGL(k_wwl_jumps<true>, dim3((M + 255) / 256), dim3(256), 0, stream, d_nxt, d_mark, M, d_len16, d_blockmax, d_head);
+    else
+        hipLaunchKernelGGL(k_wwl_jumps<false>, dim3((M + 255) / 256), dim3(256), 0, stream, d_nxt, d_mark, M, d_len16, d_blockmax, d_head);
     return hipGetLastError();
 }
 

@@ -31,7 +31,7 @@ ALPHABETS = [
     [ord(c) for c in "ab -_.,9"] + [0x00E9, 0x00C9, 0x3002],                                 # separators (WholeWord)
 ]
 DEFAULTS = {"chunk_units": 0, "lds_table_bytes": 96 * 1024, "force_sparse": 0, "force_kernel": 0, "region_units": 0,
-            "rdense_budget_bytes": 256 << 20}
+            "rdense_budget_bytes": 256 << 20, "tile_debug": 0}
 
 
 def dev_match(a, d_hay, n, cap, with_ids=True, **kw):
@@ -84,6 +84,8 @@ def one_case(rng, it):
         knobs["region_units"] = int(rng.choice([4096, 8192]))
     if rng.integers(0, 4) == 0:
         knobs["rdense_budget_bytes"] = 0  # hashed reversed trie
+    if rng.integers(0, 2):
+        knobs["tile_debug"] = 4194304  # chain marking in one pass (Shortest, sparse Longest, WholeWordLongest) on small inputs too
     for k, v in knobs.items():
         N.set_tunable(k, v)
     mode = [N.MODE_ALL, N.MODE_LONGEST, N.MODE_WHOLEWORD, N.MODE_SHORTEST, N.MODE_WWLONGEST][fam]

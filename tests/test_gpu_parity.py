@@ -1313,6 +1313,27 @@ def test_wholeword_async_begin_end_pipelined_overflow_and_slice_redo():
     assert a3.match_device_begin(d_hay.data_ptr(), 4096, True, out.data_ptr(), 16, stream=st)[1] == N.E_UNSUPPORTED
 
 
+def test_chain_marking_in_one_pass_equals_pointer_doubling():
+    """Shortest, the sparse form of Longest and WholeWordLongest select a chain k0, nxt[k0], ... over their candidates.  From
+    4 M candidates on the chain is marked in one pass by the Longest chain kernels, below that by pointer doubling; the test
+    hook (tile_debug bit 4194304) takes the one pass from 64 candidates on, bit 2097152 forces the doubling: same records."""
+    from oracle.oracle import FAM_SHORTEST, FAM_WWLONGEST
+    kws = synth.random_keywords(21, 400, 2, 9, table=synth.ALPHA_LOWER[:6])
+    hay = synth.haystack(77, 400000, table=synth.ALPHA_LOWER[:6])
+    cases = [(N.MODE_SHORTEST, FAM_SHORTEST, kws, hay, {}), (N.MODE_LONGEST, FAM_LONGEST, kws, hay, {})]
+    wkws, whay = _wwl_case(900, 300000)
+    cases.append((N.MODE_WWLONGEST, FAM_WWLONGEST, wkws, whay, dict(case_sensitive=False, lower=LOWER, word_chars=WORD)))
+    for mode, fam, k, h, okw in cases:
+        want = Oracle(fam, k, **okw).match(h)
+        assert len(want) > 1000
+        for bits in (4194304, 2097152, 0):
+            N.set_tunable("tile_debug", bits)
+            a = Automaton(mode, k, okw.get("case_sensitive", True), word_chars=okw.get("word_chars"))
+            got = a.match_host(h, True)
+            assert got.shape == want.shape and (got == want).all(), (mode, bits)
+        N.set_tunable("tile_debug", 0)
+
+
 def test_wholeword_fallback_hash_seeds_end_to_end():
     """The builder takes another hash seed when the two-choice table cannot hold a dictionary (three keywords agreeing in
     both hashes).  That never happens by chance, so the test hook "ww_first_seed" starts the builder at a later seed: the
