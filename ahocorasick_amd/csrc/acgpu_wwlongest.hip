@@ -92,13 +92,20 @@ struct __attribute__((packed, aligned(2))) WwlUnits8 {
     uint32_t d[4];
 };
 
+constexpr int kWwlWalkBlock = 512;
 template <bool PAGED>
-__global__ __launch_bounds__(256) void k_wwl_walk(DevTables T, const uint16_t *hay, uint32_t n, const uint32_t *rs, uint32_t M,
+__global__ __launch_bounds__(kWwlWalkBlock) void k_wwl_walk(DevTables T, const uint16_t *hay, uint32_t n, const uint32_t *rs, uint32_t M,
                                                   uint32_t *nxt, uint32_t *mark, int32_t *mend, int32_t *mid, uint32_t *stop,
                                                   uint32_t entry) {
     __shared__ __attribute__((aligned(16))) unsigned char pgidx[PAGED ? 256 : 16];
-    extern __shared__ __attribute__((aligned(16))) uint16_t pages[]; // PAGED: fold_n_pages * 256 deltas
+    extern __shared__ __attribute__((aligned(16))) uint16_t pages[]; // PAGED: fold_n_pages * 256 deltas; then the Bloom words
     __shared__ __attribute__((aligned(16))) uint32_t wbits[2048]; // 65536 word-character bits
+    // Bloom filter over the hashes of the first-word table (the builder's, as in k_ww_tile): a first word that is certainly
+    // not in the table -- half of a text's words -- does not go to memory for it
+    uint32_t *bloom = reinterpret_cast<uint32_t *>(pages + (PAGED ? T.fold_n_pages * 256u : 0u));
+    const uint32_t bloom_words = T.ww_fat ? (T.ww_bloom_mask + 1u) / 32u : 0u;
+    for (uint32_t i = threadIdx.x; i < bloom_words / 4; i += blockDim.x)
+        reinterpret_cast<uint4 *>(bloom)[i] = reinterpret_cast<const uint4 *>(T.ww_bloom)[i];
     for (uint32_t i = threadIdx.x; i < 2048 / 4; i += blockDim.x)
         reinterpret_cast<uint4 *>(wbits)[i] = reinterpret_cast<const uint4 *>(T.wbits)[i];
     if (!PAGED) __syncthreads();
@@ -156,7 +163,12 @@ __global__ __launch_bounds__(256) void k_wwl_walk(DevTables T, const uint16_t *h
                 const uint32_t tag = ww_tag(h, r);
                 const uint4 *fat = reinterpret_cast<const uint4 *>(T.ww_fat);
                 const uint32_t s1 = ww_slot1(h, T.ww_fat_mask), s2 = ww_slot2(h, g, T.ww_fat_mask);
-                const uint4 ea0 = fat[2 * s1], ea1 = fat[2 * s1 + 1], eb0 = fat[2 * s2], eb1 = fat[2 * s2 + 1];
+                const uint32_t b1 = ww_bloom_bit1(h, T.ww_bloom_mask), b2 = ww_bloom_bit2(h, T.ww_bloom_mask);
+                const bool maybe = ((bloom[b1 >> 5] >> (b1 & 31u)) & (bloom[b2 >> 5] >> (b2 & 31u)) & 1u) != 0;
+                uint4 ea0 = make_uint4(0u, 0u, 0u, 0u), ea1 = ea0, eb0 = ea0, eb1 = ea0;
+                if (maybe) {
+                    ea0 = fat[2 * s1]; ea1 = fat[2 * s1 + 1]; eb0 = fat[2 * s2]; eb1 = fat[2 * s2 + 1];
+                }
                 const bool in_a = ea0.x == tag && ea0.z == fw[0] && ea0.w == fw[1] && ea1.x == fw[2] && ea1.y == fw[3] &&
                                   ea1.z == fw[4] && ea1.w == fw[5];
                 const bool in_b = eb0.x == tag && eb0.z == fw[0] && eb0.w == fw[1] && eb1.x == fw[2] && eb1.y == fw[3] &&
@@ -399,12 +411,13 @@ hipError_t launch_wwl_starts(const DevTables &t, const uint16_t *d_hay, uint32_t
 hipError_t launch_wwl_walk(const DevTables &t, const uint16_t *d_hay, uint32_t n, const uint32_t *d_rs, uint32_t M,
                            uint32_t *d_nxt, uint32_t *d_mark, int32_t *d_mend, int32_t *d_mid, uint32_t *d_stop, uint32_t entry,
                            int n_cu, hipStream_t stream) {
-    // persistent workgroups (the LDS tables are staged once each): 8 per CU -- all the waves a CU holds; the fold pages are
-    // dynamic LDS so that Unicode's 18 pages leave room for all eight -- fewer when there is less to do
-    const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)std::max(n_cu, 1) * 8, ((uint64_t)M + 1 + 255) / 256);
+    // persistent workgroups of 512 lanes (the LDS tables are staged once each): three per CU -- 8 KB of word bits, the fold
+    // pages (Unicode: 9 KB) and up to 32 KB of Bloom words each -- fewer when there is less to do
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)std::max(n_cu, 1) * 3, ((uint64_t)M + kWwlWalkBlock) / kWwlWalkBlock);
     const bool paged = !t.cs && t.fold_n_pages >= 1 && t.fold_n_pages <= kWwlFoldPagesMax;
-    if (paged) hipLaunchKernelGGL(k_wwl_walk<true>, dim3(grid), dim3(256), (size_t)t.fold_n_pages * 512, stream, t, d_hay, n, d_rs, M, d_nxt, d_mark, d_mend, d_mid, d_stop, entry);
-    else hipLaunchKernelGGL(k_wwl_walk<false>, dim3(grid), dim3(256), 0, stream, t, d_hay, n, d_rs, M, d_nxt, d_mark, d_mend, d_mid, d_stop, entry);
+    const size_t lds = (paged ? (size_t)t.fold_n_pages * 512 : 0) + (t.ww_fat ? ((size_t)t.ww_bloom_mask + 1) / 8 : 0);
+    if (paged) hipLaunchKernelGGL(k_wwl_walk<true>, dim3(grid), dim3(kWwlWalkBlock), lds, stream, t, d_hay, n, d_rs, M, d_nxt, d_mark, d_mend, d_mid, d_stop, entry);
+    else hipLaunchKernelGGL(k_wwl_walk<false>, dim3(grid), dim3(kWwlWalkBlock), lds, stream, t, d_hay, n, d_rs, M, d_nxt, d_mark, d_mend, d_mid, d_stop, entry);
     return hipGetLastError();
 }
 
