@@ -50,6 +50,9 @@ def main():
                          "C4 = LongestMatchSet, C5 = WholeWordMatchMap case-insensitive are the sibling matchers)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))  # plain `python bench.py --gpus N`: this process never touches the GPU
+
     import torch
     import torch.distributed as dist
 
@@ -64,6 +67,8 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU matching path)"
     n_dev = torch.cuda.device_count()
+    assert args.backend == "gloo" or local_rank < n_dev, \
+        "--backend nccl (RCCL) needs one GPU per rank: %d GPUs visible, local rank %d (use --backend gloo to share a GPU)" % (n_dev, local_rank)
     torch.cuda.set_device(local_rank % n_dev if args.backend == "gloo" else local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -185,6 +190,14 @@ def main():
         },
     }
 
+    if multi:  # every rank's own dominant-kernel figures (the headline roofline object above is rank 0's)
+        mine = {"rank": rank, "device": torch.cuda.current_device(), "kernel": matcher.last_kernel, "kernel_ms": round(kernel_ms, 4),
+                "algorithmic_bytes": alg_bytes, "achieved": round(achieved, 2), "frac": round(achieved / HBM_PEAK_GBPS, 5),
+                "matches": n_matches_local, "host_syncs_per_step": matcher.host_syncs, "redone_steps": matcher.redone_steps}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        out["roofline"]["per_rank"] = per_rank
+
     # attainable ceiling: a pure read of this shard in the tile kernels' access pattern, timed in this run
     ms = ctypes.c_float(0)
     if N.lib().acgpu_stream_probe(matcher.own_ptr(), n_units * 2, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), 7,
@@ -231,6 +244,22 @@ def main():
     if multi:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher around it: start N fresh ranks under torch.distributed.run (one per GPU,
+    rendezvous on 127.0.0.1), relay what they print -- rank 0's single JSON line -- and return their exit code.  This parent
+    has not imported torch or made any HIP call: nothing that touched the GPU is re-executed, the ranks are children."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def _oracle(cfg_name, kws):

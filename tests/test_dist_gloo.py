@@ -117,3 +117,20 @@ def test_sharded_match_equals_whole_text(world, overlap, family, tmp_path):
     assert all(p.exists() for p in oks)
     if family in ("longest", "shortest"):  # at least one shard boundary falls inside a match, so the repair path ran
         assert sum(int(p.read_text().split()[1]) for p in oks) > 0
+
+
+def test_bench_launcher_starts_ranks_without_touching_the_gpu():
+    """bench.py --gpus 2 as a plain python call: the parent must spawn torch.distributed.run children (here, without a GPU,
+    they fail loudly -- there is no CPU matching path) and hand their exit code on."""
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0",
+                        "--units-log2", "16", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    text = p.stdout.decode(errors="replace")
+    import torch
+    if torch.cuda.device_count() == 0:
+        assert p.returncode != 0 and "bench.py needs a GPU" in text, text[-2000:]
+    else:
+        assert p.returncode == 0, text[-2000:]

@@ -76,3 +76,22 @@ def test_sharded_matcher_over_rccl_one_rank_per_gpu(family, world, overlap, cap,
     assert all(r[2] > 0 for r in res)
     if cap == 64:
         assert all(r[1] > 0 for r in res)
+
+
+def test_bench_self_launches_its_ranks(tmp_path):
+    """`python bench.py --gpus 2` started plainly (no torch.distributed.run around it, the way the driver may start it):
+    the parent spawns the ranks before it touches the GPU and relays rank 0's single JSON line."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1",
+                        "--units-log2", "24", "--cpu-sample-log2", "20"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=600)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak" and out["verified"] is True
+    assert out["config"]["parallelism"].startswith("shard2+halo") and out["config"]["parallelism"].endswith("allgather/gloo")
+    assert [r["rank"] for r in out["roofline"]["per_rank"]] == [0, 1]
+    assert all(r["kernel_ms"] > 0 and r["matches"] > 0 for r in out["roofline"]["per_rank"])
