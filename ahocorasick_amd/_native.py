@@ -26,7 +26,7 @@ class Info(ctypes.Structure):
                 ("min_keyword_len", ctypes.c_uint32), ("max_keyword_len", ctypes.c_uint32), ("dense", ctypes.c_uint32),
                 ("entry_bytes", ctypes.c_uint32), ("table_bytes", ctypes.c_uint64), ("lds_states", ctypes.c_uint32),
                 ("fold_consistent", ctypes.c_uint32), ("filter_k", ctypes.c_uint32), ("filter_bits", ctypes.c_uint32),
-                ("tile_kernel", ctypes.c_uint32), ("filter_density", ctypes.c_float)]
+                ("tile_kernel", ctypes.c_uint32), ("filter_density", ctypes.c_float), ("fold_clean", ctypes.c_uint32)]
 
 
 class Shard(ctypes.Structure):
@@ -39,7 +39,7 @@ class DeviceResult(ctypes.Structure):  # acgpu_device_result: what Shard.d_resul
     _fields_ = [("n_records", ctypes.c_uint64), ("redone", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
 
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class Profile(ctypes.Structure):

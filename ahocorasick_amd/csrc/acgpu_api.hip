@@ -69,6 +69,8 @@ struct DeviceState {
     int device = -1;
     int n_cu = 256;
     DevTables T{};
+    const uint8_t *wflags_f = nullptr; // word-character tables of the loops that fold in every lookup (HostTables::wflags_f)
+    const uint32_t *wbits_f = nullptr;
     std::vector<void *> table_allocs;
     // scratch pool (one in-flight match per automaton and device)
     DevBuf counter, chunk_counts, offsets, scan_tmp, scratch, chain, lenbuf, statebuf;
@@ -158,6 +160,10 @@ int ensure_device(acgpu_automaton *a, DeviceState **out) {
     if ((rc = upload(*d, t.lower, &T.lower))) return rc;
     if ((rc = upload(*d, t.wflags, &T.wflags))) return rc;
     if ((rc = upload(*d, t.wbits, &T.wbits))) return rc;
+    if (!t.fold_consistent) {
+        if ((rc = upload(*d, t.wflags_f, &d->wflags_f))) return rc;
+        if ((rc = upload(*d, t.wbits_f, &d->wbits_f))) return rc;
+    }
     if ((rc = upload(*d, t.out_len, &T.out_len))) return rc;
     if ((rc = upload(*d, t.out_link, &T.out_link))) return rc;
     if ((rc = upload(*d, t.out_id, &T.out_id))) return rc;
@@ -253,10 +259,23 @@ bool filter_is_selective(const HostTables &t) { return t.filt_k != 0 && t.filt_d
 // so the split form is only taken on request)
 bool use_split_form(const DevTables &T) { return tunables().force_kernel == 3 && tile_split_supported(T); }
 
+// The device tables as a scan that folds in EVERY lookup sees them (word-character tables that are not fold-consistent):
+// w'[c] = word[lower[c]] in place of both word-character tables.
+DevTables folded_tables(const DeviceState &d) {
+    DevTables T = d.T;
+    if (d.wflags_f) {
+        T.wflags = d.wflags_f;
+        T.wbits = d.wbits_f;
+    }
+    return T;
+}
+
 // ALL-mode pipeline on one shard.
 // With a ticket the call returns after enqueueing (no host synchronisation); acgpu_match_device_end collects it.
 int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_kind, void *d_out, uint64_t cap,
-              uint64_t *n_out, hipStream_t stream, acgpu_profile *prof, Ticket *tk = nullptr, bool fused_only = false) {
+              uint64_t *n_out, hipStream_t stream, acgpu_profile *prof, Ticket *tk = nullptr, bool fused_only = false,
+              const DevTables *Tov = nullptr) {
+    // (Tov: WHOLEWORD -- the tables of a folding scan, see folded_tables)
     // (fused_only: the redo after an overflow of the split form's candidate slices or of a scratch slice -- the fused
     // kernel, one scratch slice)
     const HostTables &t = a->t;
@@ -338,7 +357,7 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         L.own_begin = (uint32_t)sh->own_begin;
         L.own_end = (uint32_t)sh->own_end;
         L.cap = scratch_cap;
-        L.lds_bytes = ww_lds_bytes(L.block, d.T);
+        L.lds_bytes = ww_lds_bytes(L.block, Tov ? *Tov : d.T);
         L.debug = (uint32_t)tunables().tile_debug | (tunables().force_kernel == 1 ? 256u : 0u); // 256: trie-walk verification
         L.d_overflow = overflow_word;
         // one scratch slice and slot counter per workgroup (config 5 emits 15 M records per shard: 60 k reservations that one
@@ -363,7 +382,7 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         L.d_timing = (unsigned long long *)ww_timing.p;
 #endif
         if (timed) HIP_TRY(hipEventRecord(ev[0], stream));
-        HIP_TRY(launch_ww_tile(d.T, L, stream, &kname));
+        HIP_TRY(launch_ww_tile(Tov ? *Tov : d.T, L, stream, &kname));
         if (timed) HIP_TRY(hipEventRecord(ev[1], stream));
 #ifdef ACGPU_TIMING
         if (!tk) { // where a wave's time goes (s_memtime ticks, 100 MHz), averaged over the waves
@@ -577,7 +596,7 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
     }
     HIP_TRY(hipStreamSynchronize(stream));
     if ((uint32_t)d.h_counter[1] != 0) // a candidate slice / scratch slice overflowed: fused kernel, one scratch slice
-        return match_all(a, d, sh, record_kind, d_out, cap, n_out, stream, prof, nullptr, true);
+        return match_all(a, d, sh, record_kind, d_out, cap, n_out, stream, prof, nullptr, true, Tov);
     *n_out = *d.h_counter;
     if (prof) {
         HIP_TRY(hipEventElapsedTime(&prof->scan_ms, d.ev[0], d.ev[1]));
@@ -960,10 +979,46 @@ int match_shortest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int reco
     return *n_out > cap ? ACGPU_E_OVERFLOW : ACGPU_OK;
 }
 
+// WholeWordLongestMatchSet.match(String) with a word-character table that is not fold-consistent: the reference mixes folded
+// and raw lookups (S/WholeWordLongestMatchSet.java:126 against :151,:156), which makes token boundaries history dependent --
+// whole text, one lane (k_wwl_sequential).
+int match_wwlongest_sequential(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_kind, void *d_out, uint64_t cap,
+                               uint64_t *n_out, hipStream_t stream, acgpu_profile *prof) {
+    const HostTables &t = a->t;
+    if (prof) std::memset(prof, 0, sizeof(*prof));
+    *n_out = 0;
+    const uint32_t n = (uint32_t)sh->n_units;
+    sh->chain_exit = (int64_t)std::max<int64_t>(sh->chain_entry, (int64_t)sh->own_begin);
+    int rc;
+    if (!sh->text_begin || !sh->text_end || sh->own_begin != 0 || sh->own_end != sh->n_units) return ACGPU_E_UNSUPPORTED;
+    if (n == 0 || t.n_states <= 1) return ACGPU_OK;
+    if ((rc = d.counter.ensure(64))) return rc;
+    d.cclean[0] = false; // (match_all's first set of slot counters lives here)
+    if (prof) HIP_TRY(hipEventRecord(d.ev[0], stream));
+    HIP_TRY(launch_wwl_sequential(d.T, sh->d_hay, n, d_out, cap, record_kind, (unsigned long long *)d.counter.p, stream));
+    if (prof) HIP_TRY(hipEventRecord(d.ev[1], stream));
+    HIP_TRY(hipMemcpyAsync(d.h_counter, d.counter.p, 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    *n_out = *d.h_counter;
+    sh->chain_exit = (int64_t)n;
+    if (prof) {
+        HIP_TRY(hipEventElapsedTime(&prof->scan_ms, d.ev[0], d.ev[1]));
+        prof->total_ms = prof->scan_ms;
+        prof->scan_units = n;
+        prof->n_matches = *n_out;
+        std::snprintf(prof->scan_kernel, sizeof(prof->scan_kernel), "k_wwl_sequential");
+    }
+    return *n_out > cap ? ACGPU_E_OVERFLOW : ACGPU_OK;
+}
+
 // WWLONGEST-mode pipeline on one shard.  A walk belongs to the shard that owns its first unit; the scan visits the first walk
 // start at or after chain_entry and leaves chain_exit = the position behind the stop of its last visited walk.
+// T: the device tables the scan sees (d.T, or folded_tables(d) for the loops that fold in every lookup).
+// plain_words: the walk reports only a whole path that is a keyword and ends at a word boundary -- no carried fail match --
+// and does without the first-word table: WholeWordMatchMap's loop (S/WholeWordMatchMap.java:55-153), which is this walk
+// without fail matches, over a WHOLEWORD automaton whose folded keywords hold non-word units (HostTables::fold_clean).
 int match_wwlongest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_kind, void *d_out, uint64_t cap,
-                    uint64_t *n_out, hipStream_t stream, acgpu_profile *prof) {
+                    uint64_t *n_out, hipStream_t stream, acgpu_profile *prof, const DevTables &T, bool plain_words) {
     const HostTables &t = a->t;
     if (prof) std::memset(prof, 0, sizeof(*prof));
     *n_out = 0;
@@ -971,28 +1026,6 @@ int match_wwlongest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int rec
     const uint64_t entry = (uint64_t)std::max<int64_t>(sh->chain_entry, (int64_t)sh->own_begin);
     sh->chain_exit = (int64_t)entry;
     int rc;
-    if (!t.fold_consistent) {
-        // the reference's mixed folded/raw lookups make token boundaries history dependent: whole text, one lane
-        if (!sh->text_begin || !sh->text_end || sh->own_begin != 0 || sh->own_end != sh->n_units) return ACGPU_E_UNSUPPORTED;
-        if (n == 0 || t.n_states <= 1) return ACGPU_OK;
-        if ((rc = d.counter.ensure(64))) return rc;
-        d.cclean[0] = false; // (match_all's first set of slot counters lives here)
-        if (prof) HIP_TRY(hipEventRecord(d.ev[0], stream));
-        HIP_TRY(launch_wwl_sequential(d.T, sh->d_hay, n, d_out, cap, record_kind, (unsigned long long *)d.counter.p, stream));
-        if (prof) HIP_TRY(hipEventRecord(d.ev[1], stream));
-        HIP_TRY(hipMemcpyAsync(d.h_counter, d.counter.p, 8, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        *n_out = *d.h_counter;
-        sh->chain_exit = (int64_t)n;
-        if (prof) {
-            HIP_TRY(hipEventElapsedTime(&prof->scan_ms, d.ev[0], d.ev[1]));
-            prof->total_ms = prof->scan_ms;
-            prof->scan_units = n;
-            prof->n_matches = *n_out;
-            std::snprintf(prof->scan_kernel, sizeof(prof->scan_kernel), "k_wwl_sequential");
-        }
-        return *n_out > cap ? ACGPU_E_OVERFLOW : ACGPU_OK;
-    }
     if (!sh->text_begin && sh->own_begin < 1) return ACGPU_E_INVALID;                              // left context: 1 unit
     if (!sh->text_end && sh->n_units - sh->own_end < (uint64_t)t.max_len + 1) return ACGPU_E_INVALID; // right halo
     if (n == 0 || t.n_states <= 1 || sh->own_end == sh->own_begin || entry >= sh->own_end) return ACGPU_OK;
@@ -1003,7 +1036,7 @@ int match_wwlongest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int rec
     if ((rc = d.counter.ensure(64))) return rc;
     d.cclean[0] = false; // (match_all's first set of slot counters lives here)
     if (prof) HIP_TRY(hipEventRecord(d.ev[0], stream));
-    HIP_TRY(launch_wwl_starts(d.T, sh->d_hay, n, d.n_cu, false, (uint32_t *)d.chunk_counts.p, nullptr, nullptr, sh->text_begin, stream));
+    HIP_TRY(launch_wwl_starts(T, sh->d_hay, n, d.n_cu, false, (uint32_t *)d.chunk_counts.p, nullptr, nullptr, sh->text_begin, stream));
     HIP_TRY(launch_exclusive_scan((const uint32_t *)d.chunk_counts.p, n_tiles, (uint64_t *)d.offsets.p, (uint64_t *)d.scan_tmp.p,
                                   stream));
     HIP_TRY(hipMemcpyAsync(d.h_counter, (const uint64_t *)d.scan_tmp.p + scan_tiles_for(n_tiles), 8, hipMemcpyDeviceToHost,
@@ -1023,9 +1056,9 @@ int match_wwlongest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int rec
         d.h_counter[2] = entry;
         HIP_TRY(hipMemcpyAsync(d.counter.p, d.h_counter + 2, 8, hipMemcpyHostToDevice, stream));
     }
-    HIP_TRY(launch_wwl_starts(d.T, sh->d_hay, n, d.n_cu, true, nullptr, (const uint64_t *)d.offsets.p, (uint32_t *)d.wwl_rs.p,
+    HIP_TRY(launch_wwl_starts(T, sh->d_hay, n, d.n_cu, true, nullptr, (const uint64_t *)d.offsets.p, (uint32_t *)d.wwl_rs.p,
                               sh->text_begin, stream));
-    HIP_TRY(launch_wwl_walk(d.T, sh->d_hay, n, (const uint32_t *)d.wwl_rs.p, M, (uint32_t *)d.short_nxt.p,
+    HIP_TRY(launch_wwl_walk(T, plain_words, sh->d_hay, n, (const uint32_t *)d.wwl_rs.p, M, (uint32_t *)d.short_nxt.p,
                             (uint32_t *)d.short_mark.p, (int32_t *)d.wwl_mend.p, (int32_t *)d.wwl_mid.p, (uint32_t *)d.wwl_stop.p,
                             (uint32_t)entry, d.n_cu, stream));
     if (prof) HIP_TRY(hipEventRecord(d.ev[1], stream));
@@ -1071,9 +1104,11 @@ int device_for_call(acgpu_automaton *a, DeviceState **d) {
     return ensure_device(a, d);
 }
 
-// validates a shard and runs the pipeline of the automaton's family; caller holds a->mu
+// validates a shard and runs the pipeline of the automaton's family; caller holds a->mu.
+// readable: the call stands for match(Readable, ...) (acgpu_stream_feed) -- the word matchers' Readable loops fold in every
+// lookup where their String loops mix folded and raw ones, which only matters for tables that are not fold-consistent.
 int match_shard(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_kind, void *d_out, uint64_t cap,
-                uint64_t *n_out, hipStream_t stream, acgpu_profile *prof) {
+                uint64_t *n_out, hipStream_t stream, acgpu_profile *prof, bool readable = false) {
     if (record_kind != ACGPU_REC_SET && record_kind != ACGPU_REC_MAP) return ACGPU_E_INVALID;
     if (sh->n_units >= (1ull << 31)) return ACGPU_E_INVALID;
     if (sh->own_begin > sh->own_end || sh->own_end > sh->n_units) return ACGPU_E_INVALID;
@@ -1082,18 +1117,39 @@ int match_shard(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_
     if (sh->d_result && ((uintptr_t)sh->d_result & 15)) return ACGPU_E_INVALID;
     if (d.inflight > 0 && stream != d.inflight_stream) return ACGPU_E_INVALID; // stream rule (include/acgpu.h)
     *n_out = 0;
-    if (a->t.mode == ACGPU_MODE_ALL || (a->t.mode == ACGPU_MODE_WHOLEWORD && a->t.fold_consistent))
+    const HostTables &t = a->t;
+    if (t.mode == ACGPU_MODE_ALL || (t.mode == ACGPU_MODE_WHOLEWORD && t.fold_consistent))
         return match_all(a, d, sh, record_kind, d_out, cap, n_out, stream, prof);
+    if (t.mode == ACGPU_MODE_WHOLEWORD && readable && t.fold_clean) { // the Readable loop: an ordinary scan over w' = word o lower
+        const DevTables Tf = folded_tables(d);
+        return match_all(a, d, sh, record_kind, d_out, cap, n_out, stream, prof, nullptr, false, &Tf);
+    }
     // the other families end with their count on the host (and some run the ALL pipeline inside): the device copy of the
     // result is written behind the pipeline
     acgpu_device_result *d_res = reinterpret_cast<acgpu_device_result *>(sh->d_result);
     sh->d_result = nullptr;
     int rc;
-    switch (a->t.mode) {
+    switch (t.mode) {
     case ACGPU_MODE_LONGEST: rc = match_longest(a, d, sh, record_kind, d_out, cap, n_out, stream, prof); break;
-    case ACGPU_MODE_WHOLEWORD: rc = match_wholeword_sequential(a, d, sh, record_kind, d_out, cap, n_out, stream, prof); break;
+    case ACGPU_MODE_WHOLEWORD:
+        if (readable) { // folded keywords with non-word units: the WholeWordLongest walk without fail matches, unit by unit
+            DevTables Tf = folded_tables(d);
+            Tf.ww_fat = nullptr;
+            rc = match_wwlongest(a, d, sh, record_kind, d_out, cap, n_out, stream, prof, Tf, true);
+        } else {
+            rc = match_wholeword_sequential(a, d, sh, record_kind, d_out, cap, n_out, stream, prof);
+        }
+        break;
     case ACGPU_MODE_SHORTEST: rc = match_shortest(a, d, sh, record_kind, d_out, cap, n_out, stream, prof); break;
-    case ACGPU_MODE_WWLONGEST: rc = match_wwlongest(a, d, sh, record_kind, d_out, cap, n_out, stream, prof); break;
+    case ACGPU_MODE_WWLONGEST:
+        // not fold-consistent: the Map class's String loop and both Readable loops fold in every lookup
+        // (S/WholeWordLongestMatchMap.java:252-288, :404) -- position parallel over w'; the Set class's String loop mixes
+        // raw and folded lookups (S/WholeWordLongestMatchSet.java:126,151,156) -- sequential
+        if (t.fold_consistent) rc = match_wwlongest(a, d, sh, record_kind, d_out, cap, n_out, stream, prof, d.T, false);
+        else if (readable || record_kind == ACGPU_REC_MAP)
+            rc = match_wwlongest(a, d, sh, record_kind, d_out, cap, n_out, stream, prof, folded_tables(d), false);
+        else rc = match_wwlongest_sequential(a, d, sh, record_kind, d_out, cap, n_out, stream, prof);
+        break;
     default: rc = ACGPU_E_UNSUPPORTED;
     }
     sh->d_result = d_res;
@@ -1197,6 +1253,7 @@ int acgpu_get_info(const acgpu_automaton *a, acgpu_info *info) {
     info->filter_bits = (uint32_t)(t.filt_bits.size() * 32);
     info->tile_kernel = t.mode == ACGPU_MODE_LONGEST ? (filter_is_selective(t) && tunables().force_kernel != 1) : use_tile_kernel(t);
     info->filter_density = (float)t.filt_density;
+    info->fold_clean = t.fold_clean;
     return ACGPU_OK;
 }
 
@@ -1231,9 +1288,9 @@ struct acgpu_stream {
 int acgpu_stream_open(const acgpu_automaton *a, acgpu_stream **out) {
     if (!a || !out) return ACGPU_E_INVALID;
     *out = nullptr;
-    // (word-character tables that are not fold-consistent: the reference's Readable loops fold in their skip loops where its
-    // String loops do not, S/WholeWordMatchMap.java:328, S/WholeWordLongestMatchMap.java:404 -- no chunked form here)
-    if ((a->t.mode == ACGPU_MODE_WHOLEWORD || a->t.mode == ACGPU_MODE_WWLONGEST) && !a->t.fold_consistent) return ACGPU_E_UNSUPPORTED;
+    // (word-character tables that are not fold-consistent: the reference's Readable loops fold in EVERY lookup,
+    // S/WholeWordMatchMap.java:112,117,328, S/WholeWordLongestMatchMap.java:404 -- ordinary scans over word o lower,
+    // match_shard(..., readable))
     acgpu_stream *s = new (std::nothrow) acgpu_stream();
     if (!s) return ACGPU_E_NOMEM;
     s->a = const_cast<acgpu_automaton *>(a);
@@ -1249,16 +1306,19 @@ int acgpu_stream_feed(acgpu_stream *s, const uint16_t *units, uint64_t n_units, 
     if (record_kind != ACGPU_REC_SET && record_kind != ACGPU_REC_MAP) return ACGPU_E_INVALID;
     acgpu_automaton *a = s->a;
     const HostTables &t = a->t;
+    // what the scan carries between feeds: a WHOLEWORD automaton whose folded keywords hold non-word units is scanned by the
+    // WholeWordLongest walk (match_shard), which hands the position of its next word start on
+    const int mode = (t.mode == ACGPU_MODE_WHOLEWORD && !t.fold_consistent && !t.fold_clean) ? ACGPU_MODE_WWLONGEST : t.mode;
     const uint64_t total = s->carry.size() + n_units;
     if (total >= (1ull << 31)) return ACGPU_E_INVALID;
     *n_out = 0;
     *base = (int64_t)s->carry_pos;
     const uint64_t own_begin = s->own_from - s->carry_pos;
     uint64_t own_end = total, keep_from = 0; // keep_from: first buffer unit the next feed still needs
-    if (t.mode == ACGPU_MODE_ALL || t.mode == ACGPU_MODE_SHORTEST) {
+    if (mode == ACGPU_MODE_ALL || mode == ACGPU_MODE_SHORTEST) {
         const uint64_t halo = t.max_len > 0 ? t.max_len - 1 : 0;
         keep_from = total > halo ? total - halo : 0;
-    } else if (t.mode == ACGPU_MODE_WHOLEWORD || t.mode == ACGPU_MODE_WWLONGEST) {
+    } else if (mode == ACGPU_MODE_WHOLEWORD || mode == ACGPU_MODE_WWLONGEST) {
         const uint64_t hold = (uint64_t)t.max_len + 1; // a word / walk that starts here may still grow
         if (!final) own_end = std::max<uint64_t>(own_begin, total > hold ? total - hold : 0);
         keep_from = own_end > 0 ? own_end - 1 : 0; // one unit of left context
@@ -1274,7 +1334,7 @@ int acgpu_stream_feed(acgpu_stream *s, const uint16_t *units, uint64_t n_units, 
     }
     if (!s->carry.empty()) std::memcpy(s->buf.data(), s->carry.data(), s->carry.size() * 2);
     if (n_units) std::memcpy(s->buf.data() + s->carry.size(), units, n_units * 2);
-    uint64_t chain_exit = t.mode == ACGPU_MODE_SHORTEST ? s->chain_entry : std::max<uint64_t>(s->chain_entry, s->carry_pos + own_end);
+    uint64_t chain_exit = mode == ACGPU_MODE_SHORTEST ? s->chain_entry : std::max<uint64_t>(s->chain_entry, s->carry_pos + own_end);
     if (own_end > own_begin) {
         std::lock_guard<std::mutex> lock(a->mu); // staging buffers are part of the per-device scratch pool
         DeviceState *d = nullptr;
@@ -1291,13 +1351,13 @@ int acgpu_stream_feed(acgpu_stream *s, const uint16_t *units, uint64_t n_units, 
         sh.text_begin = s->carry_pos == 0 ? 1 : 0;
         sh.text_end = final ? 1 : 0;
         sh.chain_entry = (int64_t)(s->chain_entry > s->carry_pos ? s->chain_entry - s->carry_pos : 0);
-        if (t.mode != ACGPU_MODE_SHORTEST) sh.chain_entry = std::max<int64_t>(sh.chain_entry, (int64_t)own_begin);
-        rc = match_shard(a, *d, &sh, record_kind, d->stage_out.p, cap, n_out, nullptr, nullptr);
+        if (mode != ACGPU_MODE_SHORTEST) sh.chain_entry = std::max<int64_t>(sh.chain_entry, (int64_t)own_begin);
+        rc = match_shard(a, *d, &sh, record_kind, d->stage_out.p, cap, n_out, nullptr, nullptr, /*readable=*/true);
         if (rc != ACGPU_OK) return rc; // ACGPU_E_OVERFLOW: nothing consumed, *n_out = capacity to retry with
         if (*n_out) HIP_TRY(hipMemcpy(out, d->stage_out.p, *n_out * (uint64_t)record_kind, hipMemcpyDeviceToHost));
-        if (t.mode == ACGPU_MODE_LONGEST || t.mode == ACGPU_MODE_WWLONGEST) chain_exit = s->carry_pos + (uint64_t)sh.chain_exit;
+        if (mode == ACGPU_MODE_LONGEST || mode == ACGPU_MODE_WWLONGEST) chain_exit = s->carry_pos + (uint64_t)sh.chain_exit;
         // SHORTEST: the last restart; an exit equal to the relative entry means "no match in this feed"
-        if (t.mode == ACGPU_MODE_SHORTEST && *n_out) chain_exit = s->carry_pos + (uint64_t)sh.chain_exit;
+        if (mode == ACGPU_MODE_SHORTEST && *n_out) chain_exit = s->carry_pos + (uint64_t)sh.chain_exit;
     }
     // commit
     s->own_from = s->carry_pos + own_end;

@@ -64,6 +64,15 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
         }
         t.wbits.assign(2048, 0u);
         for (uint32_t c = 0; c < 65536; c++) t.wbits[c >> 5] |= (uint32_t)(t.wflags[c] & 1u) << (c & 31);
+        if (!t.fold_consistent) { // the tables of the loops that fold in every lookup (HostTables::wflags_f)
+            t.wflags_f.resize(65536);
+            t.wbits_f.assign(2048, 0u);
+            for (uint32_t c = 0; c < 65536; c++) {
+                const uint32_t f = (t.wflags[c] >> 1) & 1u;
+                t.wflags_f[c] = (uint8_t)(f | (f << 1));
+                t.wbits_f[c >> 5] |= f << (c & 31);
+            }
+        }
     }
 
     // ---- 1. trie insertion (keyword order matters: the LAST duplicate's index wins) ----
@@ -113,6 +122,10 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
         if (t.min_len == 0 || L < t.min_len) t.min_len = L;
     }
     const uint32_t N = (uint32_t)nodes.size();
+    t.fold_clean = true;
+    if (mode == ACGPU_MODE_WHOLEWORD)
+        for (uint32_t i = 1; i < N; i++)
+            if (!wordchar_tbl[nodes[i].unit]) t.fold_clean = false;
     t.n_states = N;
     t.n_kw = n_terminal;
     t.n_edges = N - 1;

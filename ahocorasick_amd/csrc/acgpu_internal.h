@@ -110,6 +110,15 @@ struct HostTables {
     std::vector<uint8_t> wflags;   // WHOLEWORD: bit0 = word[raw], bit1 = word[lower[raw]]
     std::vector<uint32_t> wbits;   // bit0 of wflags packed 32 units per word (2048 words: what the kernels keep in LDS)
     bool fold_consistent = true;
+    // Word-character tables that are NOT fold-consistent (custom tables, case-insensitive): the reference loops that fold
+    // in EVERY lookup -- match(Readable) of the word matchers (S/WholeWordMatchMap.java:112,117,328,
+    // S/WholeWordLongestMatchMap.java:404) and WholeWordLongestMatchMap.match(String) (:252,258,283,288) -- are ordinary
+    // scans over w'[c] = word[lower[c]]: the same kernels with these tables in place of wflags / wbits.
+    std::vector<uint8_t> wflags_f;  // bit0 = bit1 = word[lower[raw]]
+    std::vector<uint32_t> wbits_f;  // bit0 of wflags_f packed
+    bool fold_clean = true;         // WHOLEWORD: every FOLDED keyword unit is a word character (keywords are validated on
+                                    // their raw units, S/WholeWordMatchMap.java:263-267); if not, a keyword holds units that
+                                    // are no word characters to a folding scan, which then has to walk through them
     // per state
     std::vector<uint32_t> depth, fail, out_len, out_link, out_id, term_id; // term_id: own keyword id or ~0u
     // dense delta (AC semantics, fail transitions resolved): n_states * n_cls entries

@@ -96,7 +96,9 @@ constexpr int kWwlWalkBlock = 512;
 template <bool PAGED>
 __global__ __launch_bounds__(kWwlWalkBlock) void k_wwl_walk(DevTables T, const uint16_t *hay, uint32_t n, const uint32_t *rs, uint32_t M,
                                                   uint32_t *nxt, uint32_t *mark, int32_t *mend, int32_t *mid, uint32_t *stop,
-                                                  uint32_t entry) {
+                                                  uint32_t entry, uint32_t plain_words) {
+    // plain_words: no carried fail matches -- the walk of WholeWordMatchMap's loops (S/WholeWordMatchMap.java:55-153) over a
+    // WHOLEWORD automaton (whose out_len holds the keyword's own length, not a fail match)
     __shared__ __attribute__((aligned(16))) unsigned char pgidx[PAGED ? 256 : 16];
     extern __shared__ __attribute__((aligned(16))) uint16_t pages[]; // PAGED: fold_n_pages * 256 deltas; then the Bloom words
     __shared__ __attribute__((aligned(16))) uint32_t wbits[2048]; // 65536 word-character bits
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(kWwlWalkBlock) void k_wwl_walk(DevTables T, const u
         } else if (!stop_is_word && node != 0 && T.term_id[node] != ~0u) {
             end = (int32_t)i; // the whole path is a keyword and ends at a word boundary
             id = (int32_t)T.term_id[node];
-        } else if (T.out_len[node] != 0) { // the carried fail match: ends out_link[node] units before the stop
+        } else if (!plain_words && T.out_len[node] != 0) { // the carried fail match: ends out_link[node] units before the stop
             end = (int32_t)(i - T.out_link[node]);
             id = (int32_t)T.out_id[node];
         }
@@ -408,7 +410,7 @@ hipError_t launch_wwl_starts(const DevTables &t, const uint16_t *d_hay, uint32_t
     return hipGetLastError();
 }
 
-hipError_t launch_wwl_walk(const DevTables &t, const uint16_t *d_hay, uint32_t n, const uint32_t *d_rs, uint32_t M,
+hipError_t launch_wwl_walk(const DevTables &t, bool plain_words, const uint16_t *d_hay, uint32_t n, const uint32_t *d_rs, uint32_t M,
                            uint32_t *d_nxt, uint32_t *d_mark, int32_t *d_mend, int32_t *d_mid, uint32_t *d_stop, uint32_t entry,
                            int n_cu, hipStream_t stream) {
     // persistent workgroups of 512 lanes (the LDS tables are staged once each): three per CU -- 8 KB of word bits, the fold
@@ -416,8 +418,8 @@ hipError_t launch_wwl_walk(const DevTables &t, const uint16_t *d_hay, uint32_t n
     const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)std::max(n_cu, 1) * 3, ((uint64_t)M + kWwlWalkBlock) / kWwlWalkBlock);
     const bool paged = !t.cs && t.fold_n_pages >= 1 && t.fold_n_pages <= kWwlFoldPagesMax;
     const size_t lds = (paged ? (size_t)t.fold_n_pages * 512 : 0) + (t.ww_fat ? ((size_t)t.ww_bloom_mask + 1) / 8 : 0);
-    if (paged) hipLaunchKernelGGL(k_wwl_walk<true>, dim3(grid), dim3(kWwlWalkBlock), lds, stream, t, d_hay, n, d_rs, M, d_nxt, d_mark, d_mend, d_mid, d_stop, entry);
-    else hipLaunchKernelGGL(k_wwl_walk<false>, dim3(grid), dim3(kWwlWalkBlock), lds, stream, t, d_hay, n, d_rs, M, d_nxt, d_mark, d_mend, d_mid, d_stop, entry);
+    if (paged) hipLaunchKernelGGL(k_wwl_walk<true>, dim3(grid), dim3(kWwlWalkBlock), lds, stream, t, d_hay, n, d_rs, M, d_nxt, d_mark, d_mend, d_mid, d_stop, entry, plain_words ? 1u : 0u);
+    else hipLaunchKernelGGL(k_wwl_walk<false>, dim3(grid), dim3(kWwlWalkBlock), lds, stream, t, d_hay, n, d_rs, M, d_nxt, d_mark, d_mend, d_mid, d_stop, entry, plain_words ? 1u : 0u);
     return hipGetLastError();
 }
 

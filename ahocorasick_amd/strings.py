@@ -15,8 +15,8 @@ tests read like the reference's own tests:
 The matching itself always runs on the GPU through the C ABI (include/acgpu.h); the listener loop runs here, and
 stops at the first listener call that returns False -- which is observationally what the reference does
 (S/AhoCorasickSet.java:223-225).  The Thresholder constructor argument of the reference is accepted and ignored
-(results-neutral node-representation knob).  The streaming match(Readable, ...) overload is out of scope
-(SURVEY.md 8f).
+(results-neutral node-representation knob).  StringMap.match also takes a Readable (an object with read(n), or an
+iterable of chunks) with a value-only ReadableMatchListener, S/StringMap.java:6-8: match_readable over acgpu_stream_*.
 """
 import ctypes
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ACGPU_ABI_VERSION 2
+#define ACGPU_ABI_VERSION 3
 
 /* error codes */
 #define ACGPU_OK 0
@@ -52,10 +52,22 @@ extern "C" {
 #define ACGPU_MODE_SHORTEST 3  /* ShortestMatchSet / ShortestMatchMap   S/ShortestMatchSet.java:193-262, S/ShortestMatchMap.java:294-372;
                                   keyword_id = FIRST duplicate (S/ShortestMatchMap.java:47-49) */
 #define ACGPU_MODE_WWLONGEST 4 /* WholeWordLongestMatchSet / Map        S/WholeWordLongestMatchSet.java:47-178, S/WholeWordLongestMatchMap.java:54-305;
-                                  keywords are trimmed but may contain non-word characters.  Word-character tables that are
-                                  not fold-consistent (acgpu_info) are served by a sequential kernel over the whole haystack
-                                  as ONE shard (own range = buffer, text_begin = text_end = 1; ACGPU_E_UNSUPPORTED for
-                                  other shards and for streams) */
+                                  keywords are trimmed but may contain non-word characters */
+
+/*
+ * Word-character tables that are NOT fold-consistent (acgpu_info.fold_consistent == 0: a custom table, case-insensitive,
+ * with wordChars[c] != wordChars[toLowerCase(c)] for some c).  The reference's loops differ in which lookups fold, and so
+ * do the calls that replace them:
+ *  - WholeWordMatchSet/Map.match(String) (S/WholeWordMatchMap.java:204,209 folded; :221,:226 raw) and
+ *    WholeWordLongestMatchSet.match(String) (S/WholeWordLongestMatchSet.java:126 folded; :151,:156 raw) MIX folded and raw
+ *    lookups, which makes token boundaries history dependent: acgpu_match_u16 / acgpu_match_device serve them with a
+ *    sequential kernel over the whole haystack as ONE shard (own range = buffer, text_begin = text_end = 1;
+ *    ACGPU_E_UNSUPPORTED for other shards).  For WWLONGEST that is the call with ACGPU_REC_SET.
+ *  - WholeWordLongestMatchMap.match(String) (S/WholeWordLongestMatchMap.java:252,258,283,288: every lookup folded) -- the
+ *    WWLONGEST call with ACGPU_REC_MAP -- and every match(Readable) loop (S/WholeWordMatchMap.java:112,117,328,
+ *    S/WholeWordLongestMatchMap.java:404) -- acgpu_stream_feed -- fold in EVERY lookup: ordinary position-parallel scans
+ *    over wordChars o toLowerCase; shards and streams as with a fold-consistent table.
+ */
 
 /* output record layouts */
 #define ACGPU_REC_SET 8  /* acgpu_set_match: what SetMatchListener.match(haystack, start, end) receives */
@@ -110,12 +122,15 @@ typedef struct acgpu_info {
     uint32_t entry_bytes;    /* 2 or 4                                                   */
     uint64_t table_bytes;    /* bytes of the transition structure resident in HBM        */
     uint32_t lds_states;     /* states whose rows are staged in LDS by the scan kernel   */
-    uint32_t fold_consistent;/* WHOLEWORD: wordchar[c] == wordchar[lower[c]] for all c   */
+    uint32_t fold_consistent;/* WHOLEWORD / WWLONGEST: wordchar[c] == wordchar[lower[c]] for all c (see above) */
     uint32_t filter_k;       /* ALL: length of the suffix K-gram filter, 0 = none          */
     uint32_t filter_bits;    /* ALL: size of the K-gram bitmap in bits                      */
     uint32_t tile_kernel;    /* ALL/SHORTEST: 1 if the position-parallel K-gram kernel will be used (whenever the filter
                                 exists); LONGEST: 1 if the filter is selective (all-matches pipeline + selection) */
     float filter_density;    /* ALL: fraction of K-grams (over keyword units) that pass     */
+    uint32_t fold_clean;     /* WHOLEWORD: every FOLDED keyword unit is a word character (always 1 with a fold-consistent
+                                table: keywords are validated on their raw units, S/WholeWordMatchMap.java:263-267); 0: a
+                                folding scan walks the keyword trie through units it does not take for word characters */
 } acgpu_info;
 
 int acgpu_get_info(const acgpu_automaton *a, acgpu_info *info);
@@ -229,7 +244,8 @@ int acgpu_match_device_end(const acgpu_automaton *a, acgpu_ticket *ticket, uint6
  *           the first feed, that record coordinate 0 stands for).  On ACGPU_E_OVERFLOW nothing was consumed: *n_out
  *           is the capacity to call the SAME feed again with.
  *  carried units + n_units must stay below 2^31.
- *  ACGPU_E_UNSUPPORTED: WHOLEWORD / WWLONGEST with a word-character table that is not fold-consistent (acgpu_info).
+ *  Word-character tables that are not fold-consistent: the Readable loops fold in every lookup (see above), and so do
+ *  the feeds.
  */
 typedef struct acgpu_stream acgpu_stream;
 int acgpu_stream_open(const acgpu_automaton *a, acgpu_stream **out);

@@ -69,6 +69,8 @@ struct Node {
 typedef struct oracle {
     int family;
     int caseSensitive;
+    int mapFlavour; /* 1: the *Map class of the family is restated where its loops differ from the *Set class's
+                       (WholeWordLongest, case-insensitive skip loops: oracle_set_map_flavour) */
     Node *root;
     Node *all;
     uint16_t *lower;    /* Character.toLowerCase(char) table (caller supplied) */
@@ -833,7 +835,9 @@ static void match_wholeword(const oracle *o, const uint16_t *hay, int32_t len, m
 }
 
 /* ---- match(Readable, ReadableMatchListener<T>): the haystack arrives through a CharBuffer of charBufferSize units.
- * The listener only receives the value (S/ReadableMatchListener.java:7); start/end are reported as -1 here.
+ * The listener only receives the value (S/ReadableMatchListener.java:7).  TEST ANNOTATION: the two word-matcher loops
+ * restated below also hand the collecting listener the positions the String loops' arithmetic gives at the same place
+ * (idx = global position of the unit just read), so that the positions acgpu_stream_feed returns can be checked too.
  * AhoCorasickMap.match(Readable) (S/AhoCorasickMap.java:208-275) and LongestMatchMap.match(Readable)
  * (S/LongestMatchMap.java:203-286) are the String loops with buf.get() in place of charAt(idx), so they are
  * restated by calling those loops; WholeWordMatchMap.match(Readable) (S/WholeWordMatchMap.java:55-153) has its own
@@ -885,7 +889,8 @@ static void match_wholeword_readable(const oracle *o, const uint16_t *hay, int32
             if (nextNode == NULL) {
                 if (!o->wordChars[c]) {
                     if (currentNode->matchLength != 0) {
-                        if (!l(ctx, -1, -1, currentNode->value)) return;
+                        const int32_t idx = b.base + b.pos - 1; /* position of c (test annotation, see above) */
+                        if (!l(ctx, idx - currentNode->matchLength, idx, currentNode->value)) return;
                     }
                 } else {
                     if (ww_scroll(o, &b, 1)) {
@@ -904,7 +909,7 @@ static void match_wholeword_readable(const oracle *o, const uint16_t *hay, int32
             }
         }
     }
-    if (currentNode->matchLength != 0) l(ctx, -1, -1, currentNode->value);
+    if (currentNode->matchLength != 0) l(ctx, len - currentNode->matchLength, len, currentNode->value);
 }
 
 /* WholeWordLongestMatchMap.match(Readable, ReadableMatchListener<T>): S/WholeWordLongestMatchMap.java:54-181, with scroll()
@@ -922,14 +927,17 @@ static void match_wwlongest_readable(const oracle *o, const uint16_t *hay, int32
             const Node *nextNode = get_transition(currentNode, c);
             if (nextNode == NULL) {
                 if (!o->wordChars[c]) {
+                    const int32_t idx = b.base + b.pos - 1; /* position of c (test annotation) */
                     if (currentNode->matchLength != 0) {
-                        if (!l(ctx, -1, -1, currentNode->value)) return;
+                        if (!l(ctx, idx - currentNode->matchLength, idx, currentNode->value)) return;
                     } else if (currentNode->failMatchLength != 0) {
-                        if (!l(ctx, -1, -1, currentNode->failValue)) return;
+                        const int32_t fe = idx - currentNode->failMatchOffset;
+                        if (!l(ctx, fe - currentNode->failMatchLength, fe, currentNode->failValue)) return;
                     }
                 } else {
                     if (currentNode->failMatchLength != 0) {
-                        if (!l(ctx, -1, -1, currentNode->failValue)) return;
+                        const int32_t fe = b.base + b.pos - 1 - currentNode->failMatchOffset;
+                        if (!l(ctx, fe - currentNode->failMatchLength, fe, currentNode->failValue)) return;
                     }
                     if (ww_scroll(o, &b, 1)) {
                         currentNode = root;
@@ -947,8 +955,11 @@ static void match_wwlongest_readable(const oracle *o, const uint16_t *hay, int32
             }
         }
     }
-    if (currentNode->matchLength != 0) l(ctx, -1, -1, currentNode->value);
-    else if (currentNode->failMatchLength != 0) l(ctx, -1, -1, currentNode->failValue);
+    if (currentNode->matchLength != 0) l(ctx, len - currentNode->matchLength, len, currentNode->value);
+    else if (currentNode->failMatchLength != 0) {
+        const int32_t fe = len - currentNode->failMatchOffset;
+        l(ctx, fe - currentNode->failMatchLength, fe, currentNode->failValue);
+    }
 }
 
 /* values only, in listener-call order; bufsize = charBufferSize */
@@ -984,8 +995,10 @@ static void match_shortest(const oracle *o, const uint16_t *hay, int32_t len, ma
     if (currentNodeMatchLength != 0) l(ctx, idx - currentNodeMatchLength, idx, currentNodeMatchValue);
 }
 
-/* WholeWordLongestMatchSet.match: S/WholeWordLongestMatchSet.java:47-178 (Map: S/WholeWordLongestMatchMap.java:180-305).
- * CI: the transition and the !wordChars[c] test see the folded unit, the two skip loops the raw unit. */
+/* WholeWordLongestMatchSet.match: S/WholeWordLongestMatchSet.java:47-178, and the case-sensitive loop of
+ * WholeWordLongestMatchMap.match(String) S/WholeWordLongestMatchMap.java:194-245 (the same statements).
+ * CI (Set, :120-177): the transition and the !wordChars[c] test see the folded unit (:122,:126), the two skip loops
+ * the RAW unit (:151,:156). */
 static void match_wwlongest(const oracle *o, const uint16_t *hay, int32_t len, match_listener l, void *ctx) {
     const Node *root = o->root;
     const Node *currentNode = root;
@@ -1026,9 +1039,56 @@ static void match_wwlongest(const oracle *o, const uint16_t *hay, int32_t len, m
     }
 }
 
+/* WholeWordLongestMatchMap.match(String), case-insensitive loop: S/WholeWordLongestMatchMap.java:246-304.  Unlike the
+ * Set class it folds in the two skip loops as well (:283, :288: wordChars[Character.toLowerCase(haystack.charAt(idx))]),
+ * so with a word-character table that is not fold-consistent the two classes report different matches. */
+static void match_wwlongest_map_ci(const oracle *o, const uint16_t *hay, int32_t len, match_listener l, void *ctx) {
+    const Node *root = o->root;
+    const Node *currentNode = root;
+    const uint8_t *wordChars = o->wordChars;
+    const uint16_t *lower = o->lower;
+    int32_t idx = 0;
+    while (idx < len) {
+        const uint16_t c = lower[hay[idx]];
+        const Node *nextNode = get_transition(currentNode, c);
+        if (nextNode == NULL) {
+            if (!wordChars[c]) {
+                if (currentNode->matchLength != 0) {
+                    if (!l(ctx, idx - currentNode->matchLength, idx, currentNode->value)) return;
+                } else if (currentNode->failMatchLength != 0) {
+                    const int32_t failMatchEnd = idx - currentNode->failMatchOffset;
+                    if (!l(ctx, failMatchEnd - currentNode->failMatchLength, failMatchEnd, currentNode->failValue)) return;
+                }
+            } else {
+                if (currentNode->failMatchLength != 0) {
+                    const int32_t failMatchEnd = idx - currentNode->failMatchOffset;
+                    if (!l(ctx, failMatchEnd - currentNode->failMatchLength, failMatchEnd, currentNode->failValue)) return;
+                }
+                while (++idx < len && wordChars[lower[hay[idx]]]) {
+                }
+            }
+            while (++idx < len && !wordChars[lower[hay[idx]]]) {
+            }
+            currentNode = root;
+        } else {
+            ++idx;
+            currentNode = nextNode;
+        }
+    }
+    if (currentNode->matchLength != 0) {
+        l(ctx, idx - currentNode->matchLength, idx, currentNode->value);
+    } else if (currentNode->failMatchLength != 0) {
+        const int32_t failMatchEnd = idx - currentNode->failMatchOffset;
+        l(ctx, failMatchEnd - currentNode->failMatchLength, failMatchEnd, currentNode->failValue);
+    }
+}
+
 static void match_dispatch(const oracle *o, const uint16_t *hay, int32_t len, match_listener l, void *ctx) {
     switch (o->family) {
-    case FAM_WWLONGEST: match_wwlongest(o, hay, len, l, ctx); break;
+    case FAM_WWLONGEST:
+        if (o->mapFlavour && !o->caseSensitive) match_wwlongest_map_ci(o, hay, len, l, ctx);
+        else match_wwlongest(o, hay, len, l, ctx);
+        break;
     case FAM_SHORTEST: match_shortest(o, hay, len, l, ctx); break;
     case FAM_AC: match_ac(o, hay, len, l, ctx); break;
     case FAM_LONGEST: match_longest(o, hay, len, l, ctx); break;
@@ -1085,6 +1145,9 @@ int64_t oracle_match_count(const oracle *o, const uint16_t *hay, int32_t len) {
     match_dispatch(o, hay, len, g_noop, &n);
     return n;
 }
+
+/* Which class of a family the String loop restates where Set and Map differ (WholeWordLongest CI): 0 = *Set, 1 = *Map. */
+void oracle_set_map_flavour(oracle *o, int map_flavour) { o->mapFlavour = map_flavour != 0; }
 
 int64_t oracle_num_nodes(const oracle *o, int which) {
     return which == 0 ? o->nNodes : which == 1 ? o->nRange : o->nHash;

@@ -53,6 +53,8 @@ def lib():
         L.oracle_match_readable.argtypes = [vp, vp, i32, i32, vp, i64, i64]
         L.oracle_match_count.restype = i64
         L.oracle_match_count.argtypes = [vp, vp, i32]
+        L.oracle_set_map_flavour.restype = None
+        L.oracle_set_map_flavour.argtypes = [vp, ctypes.c_int]
         L.oracle_num_nodes.restype = i64
         L.oracle_num_nodes.argtypes = [vp, ctypes.c_int]
         L.oracle_queue_new.restype = vp
@@ -93,7 +95,10 @@ def _ptr(a):
 class Oracle:
     """One reference matcher instance (family = FAM_AC / FAM_LONGEST / FAM_WHOLEWORD / FAM_SHORTEST)."""
 
-    def __init__(self, family, keywords, case_sensitive=True, lower=None, word_chars=None, packed=None):
+    def __init__(self, family, keywords, case_sensitive=True, lower=None, word_chars=None, packed=None, map_flavour=False):
+        """map_flavour: restate the *Map class where its String loop differs from the *Set class's -- only
+        WholeWordLongestMatchMap's case-insensitive loop does (S/WholeWordLongestMatchMap.java:283,288 fold in the skip
+        loops, S/WholeWordLongestMatchSet.java:151,156 do not); the match(Readable) loops exist for Maps only."""
         L = lib()
         units, off = packed if packed is not None else pack_keywords(keywords)
         self._keep = (units, off)
@@ -109,6 +114,9 @@ class Oracle:
             raise MemoryError("oracle_build rc=%d" % rc)
         self._h = h
         self.family = family
+        self.map_flavour = bool(map_flavour)
+        if map_flavour:
+            L.oracle_set_map_flavour(h, 1)
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -133,8 +141,10 @@ class Oracle:
                 return out[:cnt].copy()
             cap = int(cnt)
 
-    def match_readable(self, haystack, bufsize=1024, stop_after=-1):
-        """match(Readable, ReadableMatchListener): the keyword indices (values) in listener-call order."""
+    def match_readable(self, haystack, bufsize=1024, stop_after=-1, positions=False):
+        """match(Readable, ReadableMatchListener): the keyword indices (values) in listener-call order.  positions=True:
+        (n,3) records (start, end, value) -- the word matchers' Readable loops annotated with the positions the String loops'
+        arithmetic gives (the other families ARE the String loops)."""
         hay = utf16(haystack)
         n = int(hay.size)
         if n == 0:
@@ -144,7 +154,7 @@ class Oracle:
             out = np.empty((cap, 3), dtype=np.int32)
             cnt = lib().oracle_match_readable(self._h, _ptr(hay), n, bufsize, _ptr(out), cap, stop_after)
             if cnt <= cap:
-                return out[:cnt, 2].copy()
+                return out[:cnt].copy() if positions else out[:cnt, 2].copy()
             cap = int(cnt)
 
     def count(self, haystack_units):

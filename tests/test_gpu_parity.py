@@ -822,14 +822,42 @@ def test_readable_overload_values_and_early_stop():
     assert seen == Oracle(FAM_AC, kws).match_readable(hay).tolist()
 
 
-def test_stream_fold_inconsistent_wholeword_is_refused():
-    from ahocorasick_amd import Stream
-    wc = WORD.copy()
-    wc[ord("a")] = 0  # 'A' is a word character, its lower case is not: the reference's Readable loop is history dependent
-    a = Automaton(N.MODE_WHOLEWORD, ["B"], False, word_chars=wc)
-    with pytest.raises(N.AcgpuError) as e:
-        Stream(a)
-    assert e.value.code == N.E_UNSUPPORTED
+def test_stream_fold_inconsistent_wholeword_folds_in_every_lookup():
+    """WholeWordMatchMap.match(Readable) folds in EVERY word-character lookup (S/WholeWordMatchMap.java:112,117 and scroll()
+    :328), so with a table that is not fold-consistent it is an ordinary scan over w' = wordChars o lower -- unlike the String
+    loop, which mixes raw and folded lookups (:204,:209 vs :221,:226) and keeps the sequential kernel.  Two dictionary shapes:
+    folded keywords made of word characters only (k_ww_tile over w') and folded keywords that hold units which are no word
+    characters to the folding scan (the WholeWordLongest walk without fail matches)."""
+    rng = np.random.default_rng(91)
+    alpha = np.array([ord(c) for c in "abxyABXY ,."], dtype=np.uint16)
+    for wchars, clean in (("ABXYxy", False), ("abxyAB", True)):
+        # "ABXYxy": A, B are word characters, a, b are not -> a keyword "AB" folds to units the folding scan does not take for
+        # word characters.  "abxyAB": X, Y are not word characters but fold to x, y which are -> every folded unit is one.
+        wc = np.zeros(65536, np.uint8)
+        for ch in wchars:
+            wc[ord(ch)] = 1
+        for it in range(12):
+            pool = [ord(c) for c in wchars]
+            kws = [np.array([pool[int(j)] for j in rng.integers(0, len(pool), int(rng.integers(1, 5)))], dtype=np.uint16)
+                   for _ in range(10)]
+            hay = alpha[rng.integers(0, len(alpha), int(rng.integers(1, 4000)))]
+            a = Automaton(N.MODE_WHOLEWORD, kws, False, word_chars=wc)
+            assert a.info()["fold_consistent"] == 0
+            orc = Oracle(FAM_WHOLEWORD, kws, case_sensitive=False, lower=LOWER, word_chars=wc)
+            want = orc.match_readable(hay, 7, positions=True)
+            assert (want == orc.match_readable(hay, 1024, positions=True)).all()
+            for cuts in ([], [hay.size // 2], sorted(rng.integers(0, hay.size, 6).tolist()), list(range(1, min(hay.size, 40), 3))):
+                got = _stream_all(a, hay, cuts)
+                assert got.shape == want.shape and (got == want.astype(np.int64)).all(), (wchars, it, cuts[:4])
+            # the String overload keeps the reference's mixed lookups: a different record list on some inputs
+            want_s = orc.match(hay)
+            got_s = a.match_host(hay, True)
+            assert got_s.shape == want_s.shape and (got_s == want_s).all()
+    w = WholeWordMatchMap(["AB", "x"], [1, 2], False, word_characters=list("ABXYxy"))
+    seen = []
+    w.match(iter(["AB x,", " ab X"]), lambda v: seen.append(v) or True)
+    orc = Oracle(FAM_WHOLEWORD, ["AB", "x"], case_sensitive=False, lower=LOWER, word_chars=w.get_word_chars())
+    assert [v - 1 for v in seen] == orc.match_readable("AB x, ab X").tolist()
 
 
 # ---- ShortestMatchSet / ShortestMatchMap (ACGPU_MODE_SHORTEST) ----------------------------------------------------------
@@ -1010,26 +1038,56 @@ def test_wwlongest_shards_chain_through_entry_and_exit():
                               text_begin=False, text_end=False, chain_entry=entry - base)[1] == N.E_INVALID
 
 
-def test_wwlongest_fold_inconsistent_tables_take_the_sequential_kernel():
-    """Custom word characters in case-insensitive mode where wordChars[c] != wordChars[lower(c)]: the reference's String loop
-    tests the folded unit where a walk stops and raw units in its skip loops (S/WholeWordLongestMatchSet.java:127,150,155)."""
-    from ahocorasick_amd import Stream, WholeWordLongestMatchMap
+def test_wwlongest_fold_inconsistent_tables_set_and_map_flavours():
+    """Custom word characters in case-insensitive mode where wordChars[c] != wordChars[lower(c)].  WholeWordLongestMatchSet's
+    String loop tests the folded unit where a walk stops and RAW units in its skip loops (S/WholeWordLongestMatchSet.java:126,
+    151,156): sequential kernel.  WholeWordLongestMatchMap's String loop folds there too (S/WholeWordLongestMatchMap.java:283,
+    288), and so does its Readable loop (:404): position-parallel scans over w' = wordChars o lower -- whole text, shards and
+    streams.  The two classes report different matches on the same input."""
+    import torch
+    from ahocorasick_amd import WholeWordLongestMatchMap, WholeWordLongestMatchSet
     from oracle.oracle import FAM_WWLONGEST
     from ahocorasick_amd.unicode_tables import word_chars_from_list
     wc = word_chars_from_list("abcdxyABCD")  # X, Y are not word characters although x, y are
     rng = np.random.default_rng(9)
     alpha = np.array([ord(c) for c in "abxyABXY ,"], dtype=np.uint16)
+    differ = 0
     for it in range(30):
         kws = [alpha[rng.integers(0, 4, int(rng.integers(1, 5)))] for _ in range(12)]
         kws += [np.concatenate([kws[0], np.array([32], np.uint16), kws[1]])]
         hay = alpha[rng.integers(0, len(alpha), int(rng.integers(1, 3000)))]
-        m = WholeWordLongestMatchMap(kws, list(range(len(kws))), False, word_characters="abcdxyABCD")
-        assert m.automaton.info()["fold_consistent"] == 0
-        want = Oracle(FAM_WWLONGEST, kws, case_sensitive=False, lower=LOWER, word_chars=wc).match(hay)
-        got = m.find_all(hay)
-        assert got.shape == want.shape and (got == want).all(), it
-    with pytest.raises(N.AcgpuError):  # no chunked form: the Readable loop folds where the String loop does not
-        Stream(m.automaton)
+        ms = WholeWordLongestMatchSet(kws, False, word_characters="abcdxyABCD")
+        mm = WholeWordLongestMatchMap(kws, list(range(len(kws))), False, word_characters="abcdxyABCD")
+        assert mm.automaton.info()["fold_consistent"] == 0
+        o_set = Oracle(FAM_WWLONGEST, kws, case_sensitive=False, lower=LOWER, word_chars=wc)
+        o_map = Oracle(FAM_WWLONGEST, kws, case_sensitive=False, lower=LOWER, word_chars=wc, map_flavour=True)
+        want_s, want_m = o_set.match(hay), o_map.match(hay)
+        got_s, got_m = ms.find_all(hay), mm.find_all(hay)
+        assert got_s.shape == want_s[:, :2].shape and (got_s == want_s[:, :2]).all(), it
+        assert got_m.shape == want_m.shape and (got_m == want_m).all(), it
+        differ += int(want_s.shape != want_m.shape or not (want_s == want_m).all())
+        # Map flavour: shards of one buffer chain through entry / exit
+        a = mm.automaton
+        d_hay = torch.from_numpy(np.concatenate([hay, np.zeros(8, np.uint16)]).view(np.int16)).cuda()
+        cap = len(want_m) + 16
+        d_out = torch.empty((cap, 3), dtype=torch.int32, device="cuda")
+        cuts = sorted(set([0, hay.size] + rng.integers(0, hay.size + 1, 3).tolist()))
+        parts, entry = [], 0
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            n_out, rc, _, ex = a.match_device(d_hay.data_ptr(), hay.size, True, d_out.data_ptr(), cap, own=(lo, hi), chain_entry=entry)
+            assert rc == N.OK
+            parts.append(d_out[:n_out].cpu().numpy())
+            entry = ex
+        assert (np.concatenate(parts) == want_m).all(), (it, cuts)
+        # a shard of the Set flavour is refused (its loop is history dependent), the whole text is not
+        if hay.size > 16:
+            assert a.match_device(d_hay.data_ptr(), hay.size, False, d_out.data_ptr(), cap, own=(0, 8))[1] == N.E_UNSUPPORTED
+        # streams: the Readable loop folds everywhere -- the Map flavour's records
+        assert (o_map.match_readable(hay, 5, positions=True) == want_m).all()
+        for cuts in ([], sorted(rng.integers(0, hay.size, 5).tolist())):
+            got = _stream_all(a, hay, cuts)
+            assert got.shape == want_m.shape and (got == want_m.astype(np.int64)).all(), (it, cuts)
+    assert differ >= 3  # the inputs do tell the two classes apart
 
 
 @pytest.mark.parametrize("seed", range(3))

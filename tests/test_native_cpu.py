@@ -141,10 +141,14 @@ def test_longest_and_wholeword_automata_build_on_cpu():
     assert a["n_states"] == 3001 and a["dense"] == 1 and a["entry_bytes"] == 4  # the forward trie, not a reversed automaton
     words = synth.mixed_script_words(1005, 2000)
     w = Automaton(N.MODE_WHOLEWORD, words, False, word_chars=WORD).info()
-    assert w["n_keywords"] <= 2000 and w["fold_consistent"] == 1
+    assert w["n_keywords"] <= 2000 and w["fold_consistent"] == 1 and w["fold_clean"] == 1
     wc = np.zeros(65536, np.uint8)
     wc[ord("A")] = 1
-    assert Automaton(N.MODE_WHOLEWORD, ["A"], False, word_chars=wc).info()["fold_consistent"] == 0
+    i = Automaton(N.MODE_WHOLEWORD, ["A"], False, word_chars=wc).info()  # 'A' is a word character, its folded form 'a' is not
+    assert i["fold_consistent"] == 0 and i["fold_clean"] == 0
+    wc[ord("a")], wc[ord("B")] = 1, 1  # now only 'b' is missing: the keyword "A" folds to word characters
+    i = Automaton(N.MODE_WHOLEWORD, ["A"], False, word_chars=wc).info()
+    assert i["fold_consistent"] == 0 and i["fold_clean"] == 1
 
 
 # ---- WholeWord: the whole-keyword hash table + paged fold table (what k_ww_tile probes) ----------------------------
