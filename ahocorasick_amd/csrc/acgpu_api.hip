@@ -77,6 +77,7 @@ struct DeviceState {
     DevBuf stage_hay, stage_out; // acgpu_match_u16 staging
     DevBuf short_recs, short_nxt, short_tmp, short_mark; // SHORTEST: all-matches list + selection scratch
     DevBuf blockmax;                                     // LONGEST: farthest landing per 64 positions
+    DevBuf lenbig, todo;                                 // LONGEST: escaped lengths; root-table form: flagged chunks
     DevBuf chainbits;                                    // LONGEST: one bit per position, set where the chain reports a match
     DevBuf cands, region_cands;                          // ALL, split form: candidate positions, {first, count} per region
     DevBuf wwl_rs, wwl_mend, wwl_mid, wwl_sel, wwl_stop, wwl_nxt0; // WWLONGEST: walk starts, what each would report, where it stops
@@ -95,7 +96,7 @@ struct DeviceState {
         counter.release(); chunk_counts.release(); offsets.release(); scan_tmp.release(); scratch.release();
         chain.release(); lenbuf.release(); statebuf.release(); stage_hay.release(); stage_out.release();
         short_recs.release(); short_nxt.release(); short_tmp.release(); short_mark.release();
-        wwl_rs.release(); wwl_mend.release(); wwl_mid.release(); wwl_sel.release(); wwl_stop.release(); wwl_nxt0.release(); blockmax.release(); chainbits.release(); cands.release(); region_cands.release();
+        wwl_rs.release(); wwl_mend.release(); wwl_mid.release(); wwl_sel.release(); wwl_stop.release(); wwl_nxt0.release(); blockmax.release(); lenbig.release(); todo.release(); chainbits.release(); cands.release(); region_cands.release();
         if (h_counter) (void)hipHostFree(h_counter);
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         for (auto &tk : tickets) {
@@ -186,6 +187,8 @@ int ensure_device(acgpu_automaton *a, DeviceState **out) {
             T.dfa = p;
         }
     }
+    T.root_tab = nullptr; T.root_b = t.root_b; T.root_rk = t.root_rk;
+    if (t.root_b && (rc = upload(*d, t.root_tab, &T.root_tab))) return rc;
     if ((rc = upload(*d, t.filt_bits, &T.filt_bits))) return rc;
     if ((rc = upload(*d, t.kgram_node, &T.kgram_node))) return rc;
     T.fold_range = t.fold_range; T.fr_base = t.fr_base; T.fr_span = t.fr_span; T.fr_base2 = t.fr_base2; T.fr_himask = t.fr_himask;
@@ -800,6 +803,13 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
         S.grid = (int)std::min<uint64_t>(2ull * d.n_cu, (own_len + 16 * 1024 - 1) / (16 * 1024));
     }
     int rc;
+    // the work-list form stores ONE byte per length, 255 = "255 or more: see the 16-bit side array" (tunable tile_debug bit
+    // 8388608: 16-bit lengths, for A/B) -- half the bytes written by the walk and read back by the chain passes
+    if (S.pairs == 2 && !(tunables().tile_debug & 8388608)) {
+        S.len_bytes = 1;
+        if ((rc = d.lenbig.ensure((size_t)sh->n_units * 2 + 64))) return rc;
+        S.d_len_big = (uint16_t *)d.lenbig.p;
+    }
     if ((rc = d.lenbuf.ensure((size_t)sh->n_units * S.len_bytes + 64))) return rc;
     S.d_len = d.lenbuf.p;
     if ((rc = d.blockmax.ensure((own_len / 64 + 2) * 4))) return rc;
@@ -808,6 +818,19 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
     if (record_kind == ACGPU_REC_MAP) {
         if ((rc = d.statebuf.ensure((size_t)sh->n_units * 4 + 64))) return rc;
         S.d_state = (uint32_t *)d.statebuf.p;
+    }
+    // Set records over a small alphabet: k_longest_block (first round through the root table, the live walks through its own
+    // work list), then the general kernel for the chunks it flagged (tunable tile_debug bit 16777216: the general kernel for
+    // everything).  A wave's span must fit the 16-bit lane positions of its queue.
+    const uint64_t blk_waves = (uint64_t)S.grid * (S.block / 64), blk_chunks = (own_len + 1023) / 1024;
+    const uint64_t blk_span = (blk_chunks + blk_waves - 1) / std::max<uint64_t>(blk_waves, 1);
+    const bool root_form = S.pairs == 2 && S.len_bytes == 1 && record_kind == ACGPU_REC_SET && d.T.root_b != 0 &&
+                           !(tunables().tile_debug & 16777216) && blk_span * 1024 <= (1u << 19) && sh->n_units >= 4096 &&
+                           (sh->own_begin & 7) == 0;
+    if (root_form) {
+        S.span_chunks = (uint32_t)blk_span;
+        if ((rc = d.todo.ensure(blk_chunks + 64))) return rc;
+        S.d_todo_w = (uint8_t *)d.todo.p;
     }
     LongestChainLaunch Cn{};
     // positions per chain lane: the synchronisation scan skips 64-position blocks that cannot reach the tile, so tiles
@@ -821,6 +844,7 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
     if ((rc = d.offsets.ensure((size_t)Cn.n_tiles * 8))) return rc;
     if ((rc = d.scan_tmp.ensure(((size_t)Cn.n_tiles / 2048 + 2) * 8))) return rc;
     Cn.d_len = d.lenbuf.p;
+    Cn.d_len_big = S.d_len_big;
     Cn.d_state = S.d_state;
     Cn.d_out_id = d.T.term_id; // state[] holds the trie node of the longest keyword starting at a position
     Cn.len_bytes = S.len_bytes;
@@ -840,7 +864,16 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
     d.cclean[0] = false; // (match_all's first set of slot counters lives here)
     if (prof) HIP_TRY(hipEventRecord(d.ev[0], stream));
     const char *kname = "";
-    HIP_TRY(launch_longest_scan(d.T, S, stream, &kname));
+    if (root_form) {
+        LongestScanLaunch Sb = S;
+        Sb.debug = (uint32_t)(tunables().tile_debug >> 32);
+        Sb.lds_rows = std::min<uint32_t>(t.n_states, longest_block_max_rows(t.n_cls));
+        HIP_TRY(launch_longest_block(d.T, Sb, stream, &kname));
+        S.d_todo = S.d_todo_w;
+        HIP_TRY(launch_longest_scan(d.T, S, stream, nullptr));
+    } else {
+        HIP_TRY(launch_longest_scan(d.T, S, stream, &kname));
+    }
     if (prof) HIP_TRY(hipEventRecord(d.ev[1], stream));
     if ((rc = d.chain.ensure((size_t)Cn.n_tiles * 4 + 64))) return rc;
     uint32_t *d_sync = (uint32_t *)d.chain.p;
@@ -852,7 +885,7 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
     Cn.d_ebits = nullptr;
     Cn.len_units = (uint32_t)sh->n_units;
     const bool serial_write = (tunables().tile_debug & 65536) != 0;
-    const bool chain_lds = Cn.len_bytes == 2 && !(tunables().tile_debug & 131072);
+    const bool chain_lds = Cn.len_bytes <= 2 && !(tunables().tile_debug & 131072);
     if (!serial_write) {
         const size_t bit_bytes = ((size_t)sh->n_units / 128 + 2) * 16; // whole groups of four words (16-byte stores)
         // (a second bitmap of match ends for the emit pass; tile_debug bit 524288: without it, the emit pass looks lengths up)

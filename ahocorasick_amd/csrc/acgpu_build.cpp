@@ -447,6 +447,35 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
         }
     }
 
+    // ---- 6b. LONGEST: root table of the walk's first round (small alphabets) ----
+    // Every walk starts at the root, so what the first RK units of a walk do is a function of those units alone: one byte
+    // per RK-gram {bit 7: the walk is still alive after RK units | low bits: longest keyword among the RK steps}, indexed by
+    // a BIT FIELD of unit codes (unit - cls_base, B bits each: B = 1 for alphabets of up to two letters, RK = 14; B = 2
+    // for up to four, RK = 7: 16384 entries either way), de-interleaved: the units at even offsets of the window in the
+    // low field, those at odd offsets above it -- the order in which k_longest_block's packed arithmetic produces them
+    // (acgpu_longest.hip).
+    t.root_b = 0;
+    t.root_rk = 0;
+    if (mode == ACGPU_MODE_LONGEST && t.dense && t.range_cls && t.n_cls == t.cls_span + 1 && t.cls_span <= 4) {
+        const uint32_t B = t.cls_span <= 2 ? 1u : 2u, RK = 14u / B, HE = (RK + 1) / 2;
+        const uint32_t total = 1u << (B * RK), cmask = (1u << B) - 1u;
+        t.root_tab.resize(total);
+        for (uint32_t i = 0; i < total; i++) {
+            uint32_t node = 0, best = 0;
+            bool alive = true;
+            for (uint32_t j = 0; j < RK && alive; j++) {
+                const uint32_t code = (i >> (B * ((j & 1u) ? HE + (j >> 1) : (j >> 1)))) & cmask;
+                const uint32_t e = code < t.cls_span ? t.dfa[(uint64_t)node * t.n_cls + code + 1] : 0u;
+                if (!e) { alive = false; break; }
+                node = e & 0x7fffffffu;
+                if (e >> 31) best = j + 1;
+            }
+            t.root_tab[i] = (uint8_t)(best | (alive ? 0x80u : 0u));
+        }
+        t.root_b = B;
+        t.root_rk = RK;
+    }
+
     // ---- 7. suffix K-gram filter + reversed trie (ALL mode) ----
     // Filter layout: one ROW per (K-1)-gram of tile classes (the K-1 units before the last one), one BIT per class of
     // the last unit; rows are 4 bytes (n <= 32 classes) or 8 bytes (n <= 64).  A position survives iff its K-gram is

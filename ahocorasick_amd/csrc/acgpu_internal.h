@@ -125,6 +125,9 @@ struct HostTables {
     bool dense = false;
     uint32_t entry_bytes = 4;
     std::vector<uint32_t> dfa;
+    // LONGEST, small alphabets: root table of the walk's first round (acgpu_build.cpp 6b); root_b = 0: none
+    std::vector<uint8_t> root_tab;
+    uint32_t root_b = 0, root_rk = 0;
     // hashed goto edges keyed by (state, folded unit): open addressing, linear probing
     std::vector<uint64_t> hkeys;
     std::vector<uint32_t> hvals;
@@ -238,6 +241,8 @@ struct DevTables {
     uint32_t fold_n_pages, fold_direct_n;
     const uint32_t *ww_bloom;
     uint32_t ww_bloom_mask;
+    const uint8_t *root_tab; // LONGEST: see HostTables::root_tab
+    uint32_t root_b, root_rk;
 };
 
 // development/test knobs (acgpu_set_tunable): relaxed atomics, read when a call is enqueued

@@ -146,13 +146,23 @@ struct LongestScanLaunch {
                                     // (k_longest_walk_list: one workgroup per CU, grid-stride over 1024-position chunks)
     int grid, block;
     size_t lds_bytes;
+    uint16_t *d_len_big;            // len_bytes == 1: the lengths of 255 units and more (escape 255 in d_len), sparse
+    // root-table form (k_longest_block, then k_longest_walk_list over the flagged chunks)
+    const uint8_t *d_todo;          // k_longest_walk_list: only the chunks (1024 positions) flagged here; nullptr = all
+    uint8_t *d_todo_w;              // k_longest_block: one flag per chunk
+    uint32_t span_chunks;           // k_longest_block: chunks per wave (contiguous)
+    uint32_t debug;                 // ACGPU_ABLATION builds: timing experiments (results are wrong)
 };
+hipError_t launch_longest_block(const DevTables &t, const LongestScanLaunch &l, hipStream_t stream, const char **kernel_name);
+size_t longest_block_lds_bytes();
+uint32_t longest_block_max_rows(uint32_t n_cls);
 hipError_t launch_longest_scan(const DevTables &t, const LongestScanLaunch &l, hipStream_t stream, const char **kernel_name);
 size_t longest_list_lds_bytes(bool state);       // dynamic LDS of k_longest_walk_list (work lists)
 uint32_t longest_list_max_rows(uint32_t n_cls, bool state); // trie rows its static LDS holds
 
 struct LongestChainLaunch {
     const void *d_len;
+    const uint16_t *d_len_big; // len_bytes == 1: see LongestScanLaunch
     const uint32_t *d_state; // or nullptr (Set records)
     const uint32_t *d_out_id;
     int len_bytes;

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <type_traits>
 
 #include "acgpu_device.h"
 #include "acgpu_kernels.h"
@@ -298,57 +299,283 @@ __device__ __forceinline__ uint32_t wl_round(const unsigned char *rows8, const u
 
 // trie rows in STATIC LDS at offset 0 (a row offset is the ds_read address as it stands): 60 KiB, or 52 KiB next to the
 // larger work lists of the Map flavour, so that two workgroups share a CU either way
-constexpr int kWlRowWordsSet = 8768, kWlRowWordsMap = 13312; // (Set: 34.25 KiB of rows + 25.75 KiB of root table)
+constexpr int kWlRowWordsSet = 13312, kWlRowWordsMap = 13312; // 52 KiB of rows
 
-// The first round through a ROOT TABLE (Set flavour, small alphabets): every walk starts at the root, so the node reached
-// by the first RK units is a function of those units alone -- n^RK entries {row offset reached | longest keyword among the
-// RK steps << 16}, built in LDS by the kernel itself from the staged rows.  One LDS read replaces RK dependent ones (the
-// LDS is the busiest unit of this kernel); the remaining 8 - RK units of the round are ordinary steps.  The index is the
-// columns in radix n, most of it in packed arithmetic: even and odd columns run through the same two v_pk_mad_u16.
-constexpr int kWlRootWords = 6592; // n = 3 (two letters + "other"): RK = 8 (6561 entries); n <= 5 (DNA): RK = 4
-// entry of the root table: row offset reached | longest keyword among the RK steps << 16 | flags
-constexpr uint32_t kRtAlive = 0x80000000u;
+// One byte per length with an escape: 255 = "255 or more, the value is in d_len_big[p]" (a full-size 16-bit array that is only
+// written -- and read -- for such positions: config 4's keywords go up to 1000 units, its walks die below 40).
+constexpr uint32_t kLenEscape = 255u;
+template <typename LenT>
+__device__ __forceinline__ void store_len(const LongestScanLaunch &L, uint32_t p, uint32_t best) {
+    if (sizeof(LenT) == 1) {
+        reinterpret_cast<uint8_t *>(L.d_len)[p] = (uint8_t)min(best, kLenEscape);
+        if (best >= kLenEscape) L.d_len_big[p] = (uint16_t)best;
+    } else {
+        reinterpret_cast<LenT *>(L.d_len)[p] = (LenT)best;
+    }
+}
 
-__device__ __forceinline__ uint32_t wl_pk_mad(uint32_t a, uint32_t b, uint32_t c) {
+// ---- the first round through a ROOT TABLE: k_longest_block (Set records, small alphabets) ----------------------------------
+// Every walk starts at the root, so what its first RK units do is a function of those units alone: the host builder's root
+// table (acgpu_build.cpp 6b), one byte per RK-gram {bit 7: the walk is still alive | longest keyword among the RK steps},
+// copied to LDS (16 KiB).  The index is a BIT FIELD: a unit's code (unit - base) takes B bits (B = 1: alphabets of up to two
+// letters, RK = 14; B = 2: up to four letters, RK = 7), so the table has 2^14 entries instead of (letters + 1)^RK -- config
+// 4: 1.9 % of the walks are alive after 14 units where 25 % survive 8.
+//  * A wave owns a contiguous span of 1024-position chunks and streams it in steps of 512 positions; a lane owns 8
+//    consecutive positions and loads ONLY their 16 bytes.  It packs the codes of its 8 units into one register -- even units
+//    in the low half, odd units in the high half (one v_pk_sub_u16 and one v_lshl_or_b32 per two units) -- and takes the
+//    packed codes of the units behind them from the next lanes (v_mov_b32_dpp wave_shl:1; the last lanes from the NEXT step's
+//    first lanes: the stream runs two steps ahead, which also keeps a wave's loads in flight across its steps).
+//  * The index of a position is two bit-field extracts -- the units at even offsets of its window from one half, those at odd
+//    offsets from the other; the table is laid out for that de-interleaved index, and the index IS the LDS byte address.  One
+//    LDS read per position, the 8 lengths leave as ONE store, the block maxima are preset to a bound.
+//  * A lane some of whose 8 walks are still alive queues {first position, which of the 8} in LDS; when 64 lanes have queued
+//    up they are expanded into the wave's work list and the listed walks run, from the root, in rounds of 16 steps through
+//    the LDS rows (both 16-byte pieces of a walk's text requested together) -- every round but the wave's last few with all
+//    64 lanes, the text still in the cache, and the one-byte stores of the final lengths into lines this wave has just written.
+//    (Inside k_longest_walk_list the survivors of a 1024-position chunk, ~29, were drained chunk by chunk: a third of the
+//    lanes busy, every round a memory latency the wave spent alone.  As two kernels -- survivor slices in global memory, a
+//    kernel for the listed walks -- the byte stores went to lines long evicted: 0.12 ms of partial writes at config 4.)
+//  * A chunk the kernel cannot do -- a unit outside the alphabet, the end of the buffer -- is FLAGGED (d_todo) and left to the
+//    general kernel (k_longest_walk_list over the flagged chunks only).
+constexpr uint32_t kBlockMaxSlack = 40; // block maxima are preset to last position + this: only a longer match needs the atomic
+constexpr int kBlkRowWords = 7168;      // 28 KiB of trie rows next to the root table and the queues: two workgroups per CU
+constexpr int kBlkQueueWords = 64 + 128 + 3 * kWlCap; // per wave: 128 u16 lane positions, 128 alive masks, the work list
+
+__device__ __forceinline__ uint32_t dpp_wave_shl1(uint32_t x) { // lane i <- lane i + 1 (lane 63: 0)
     uint32_t r;
-    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1" : "=v"(r) : "v"(x));
     return r;
 }
 
-// Byte offsets into the root table for the 8 consecutive positions a lane owns, two per register (low half: even
-// position): w[] = the 16 units from the lane's first position on.  The index of a position is its next RK columns in
-// radix n, first unit most significant; with Q_k = {c[2k] n + c[2k+1], c[2k+1] n + c[2k+2]} (one v_alignbit_b32 and one
-// v_pk_mad_u16 per column pair) the index pairs are two (RK = 4: one) more packed Horner steps: 3 instructions per
-// position instead of a dozen, and every column is computed once instead of once per position that looks at it.
-template <int RK>
-__device__ __forceinline__ void wl_block_index(const uint32_t (&w)[8], uint32_t base2, uint32_t span2, uint32_t n, uint32_t (&A)[4]) {
-    static_assert(RK == 4 || RK == 8, "root table depth");
-    uint32_t P[8];
-#pragma unroll
-    for (int d = 0; d < 8; ++d) {
-        uint32_t t;
-        asm("v_pk_sub_u16 %0, %1, %2" : "=v"(t) : "v"(w[d]), "s"(base2));
-        asm("v_pk_min_u16 %0, %1, %2" : "=v"(P[d]) : "v"(t), "s"(span2));
+template <uint32_t B>
+__global__ __launch_bounds__(kLScanBlock, 8) void k_longest_block(DevTables T, LongestScanLaunch L) {
+    constexpr uint32_t RK = 14u / B, HE = (RK + 1) / 2, HO = RK / 2;
+    constexpr uint32_t kEntries = 1u << 14;
+    static_assert(B * RK == 14, "the root table has 2^14 entries");
+    __shared__ __attribute__((aligned(16))) uint8_t rt[kEntries];
+    __shared__ __attribute__((aligned(16))) uint32_t rows[kBlkRowWords];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[]; // per wave: kBlkQueueWords words
+    const uint32_t *glob = reinterpret_cast<const uint32_t *>(T.dfa);
+    const uint32_t n = T.n_cls, span = T.cls_span, base = T.cls_base; // n == span + 1
+    const uint32_t row_bytes = n * 4u;
+    const uint32_t real_bytes = L.lds_rows * row_bytes, dead_off = real_bytes, deep_off = real_bytes + row_bytes;
+    for (uint32_t i = threadIdx.x; i < kEntries / 16; i += blockDim.x)
+        reinterpret_cast<uint4 *>(rt)[i] = reinterpret_cast<const uint4 *>(T.root_tab)[i];
+    for (uint32_t i = threadIdx.x; i < (L.lds_rows + 2) * n; i += blockDim.x) { // (as k_longest_walk_list stages them)
+        const uint32_t r = i / n, col = i - r * n;
+        uint32_t e;
+        if (r >= L.lds_rows) {
+            e = r == L.lds_rows ? dead_off : deep_off;
+        } else {
+            const uint32_t g = col < span ? glob[r * n + col + 1] : 0u;
+            if (!g) e = dead_off;
+            else if ((g & 0x7fffffffu) >= L.lds_rows) e = deep_off;
+            else e = (g & 0x80000000u) | ((g & 0x7fffffffu) * row_bytes);
+        }
+        rows[i] = e;
     }
-    const uint32_t n2 = n * 0x10001u, nn2 = n * n * 0x10001u;
-    constexpr int NQ = RK == 8 ? 7 : 5;
-    uint32_t Q[NQ];
+    __syncthreads();
+    constexpr int kWaves = kLScanBlock / kWave;
+    const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const uint32_t lane = lane_id();
+    const uint32_t wave_global = blockIdx.x * kWaves + wave_in_block;
+    uint32_t *wq = reinterpret_cast<uint32_t *>(smem) + wave_in_block * kBlkQueueWords;
+    uint16_t *pbq = reinterpret_cast<uint16_t *>(wq); // queued lanes: (first position - span start) / 8
+    uint32_t *mq = wq + 64;                           //               which of the 8 walks are alive
+    uint32_t *wl0 = wq + 192, *wl1 = wl0 + kWlCap, *wl2 = wl0 + 2 * kWlCap; // work list: {row offset | best << 16}, position, depth
+    const uint16_t *hay = L.d_hay;
+    uint8_t *out_len = reinterpret_cast<uint8_t *>(L.d_len);
+    const unsigned char *rows8 = reinterpret_cast<const unsigned char *>(rows);
+    const uint32_t nu = L.n_units;
+    const uint32_t base2 = base * 0x10001u, span2 = span * 0x10001u, span4 = span * 4u;
+    const uint64_t own_len = (uint64_t)L.own_end - L.own_begin;
+    const uint32_t n_chunks = (uint32_t)((own_len + kWlChunk - 1) / kWlChunk);
+    const uint32_t c0 = (uint32_t)min((uint64_t)n_chunks, (uint64_t)wave_global * L.span_chunks);
+    const uint32_t c1 = (uint32_t)min((uint64_t)n_chunks, (uint64_t)c0 + L.span_chunks);
+    if (c0 >= c1) return;
+    const uint32_t sp0 = L.own_begin + c0 * kWlChunk; // first position of the span
+    uint32_t eq_n = 0, wl_n = 0;                      // wave-uniform: queued lanes, listed walks
+
+    auto append = [&](bool alive, uint32_t off16, uint32_t best, uint32_t p, uint32_t depth) {
+        const uint64_t bal = __ballot(alive);
+        if (bal) {
+            if (alive) {
+                const uint32_t at = wl_n + (uint32_t)__popcll(bal & lanemask_lt());
+                wl0[at] = off16 | (best << 16);
+                wl1[at] = p;
+                wl2[at] = depth;
+            }
+            wl_n += (uint32_t)__popcll(bal);
+        }
+    };
+    // one more round of 16 steps for the top min(wl_n, 64) walks of the list (a listed walk is known to go on for RK units);
+    // the DEAD row loops to itself, so the steps behind the end of a walk change nothing
+    auto list_round = [&]() {
+        const uint32_t nb = min(wl_n, (uint32_t)kWave);
+        const uint32_t first = wl_n - nb;
+        const bool act = lane < nb;
+        uint32_t e = dead_off, best = 0, p = sp0, depth = 0;
+        if (act) {
+            const uint32_t a = wl0[first + lane];
+            e = a & 0xffffu; best = a >> 16;
+            p = wl1[first + lane];
+            depth = wl2[first + lane];
+        }
+        __builtin_amdgcn_wave_barrier();
+        wl_n = first;
+        // (no bounds check: the chunk of a listed walk ends max_len + 24 units before the buffer does)
+        uint32_t w0[4], w1[4], tm0, tm1, hist[8];
+        {
+            const uint16_t *src = hay + (act ? p + depth : sp0);
+            const Units8 u = *reinterpret_cast<const Units8 *>(src), v = *reinterpret_cast<const Units8 *>(src + 8);
+            w0[0] = u.d[0]; w0[1] = u.d[1]; w0[2] = u.d[2]; w0[3] = u.d[3];
+            w1[0] = v.d[0]; w1[1] = v.d[1]; w1[2] = v.d[2]; w1[3] = v.d[3];
+        }
+        e = wl_round<false, false>(rows8, w0, 8u, base2, span2, span4, e, tm0, hist);
+        e = wl_round<false, false>(rows8, w1, 8u, base2, span2, span4, e, tm1, hist);
+        if (tm1 & 0xffu) best = depth + 16u - (uint32_t)__builtin_ctz(tm1 & 0xffu); // the last flagged step of the round
+        else if (tm0 & 0xffu) best = depth + 8u - (uint32_t)__builtin_ctz(tm0 & 0xffu);
+        const uint32_t off16 = e & 0xffffu;
+        const bool alive = act && off16 < real_bytes && depth < 65000u;
+        if (act && !alive) {
+            if (off16 == deep_off) { // rare: redo the walk through the table in global memory
+                uint32_t node = 0, j = p;
+                best = 0;
+                while (j < nu) {
+                    const uint32_t dlt = hay[j] - base;
+                    const uint32_t g = glob[node * n + (dlt < span ? dlt + 1u : 0u)];
+                    if (!g) break;
+                    node = g & 0x7fffffffu;
+                    ++j;
+                    if (g >> 31) best = j - p;
+                }
+            }
+#ifdef ACGPU_ABLATION
+            if (!(L.debug & 1u))
+#endif
+            store_len<uint8_t>(L, p, best);
+            // (the block maximum was preset to its last position + kBlockMaxSlack: only a longer match raises it)
+            const uint32_t blk = (p - L.own_begin) >> 6;
+            if (p + best > L.own_begin + (blk << 6) + 63u + kBlockMaxSlack) atomicMax(&L.d_blockmax[blk], p + best);
+        }
+        append(alive, off16, best, p, depth + 16u);
+        __builtin_amdgcn_wave_barrier();
+    };
+    // the top min(eq_n, 64) queued lanes -> their live walks into the work list (from the root), rounds as the list fills
+    auto expand = [&]() {
+        const uint32_t nb = min(eq_n, (uint32_t)kWave);
+        const uint32_t first = eq_n - nb;
+        uint32_t pb = 0, m = 0;
+        if (lane < nb) {
+            pb = sp0 + (uint32_t)pbq[first + lane] * 8u;
+            m = mq[first + lane];
+        }
+        __builtin_amdgcn_wave_barrier();
+        eq_n = first;
+#ifdef ACGPU_ABLATION
+        if (L.debug & 16u) m = 0; // queued lanes are dropped: no walks
+#endif
+        for (int i = 0; i < 8; ++i) { // alive bits: 7, 15, 23, 31 (positions 0-3) and 3, 11, 19, 27 (positions 4-7)
+            append((m >> (i < 4 ? 8 * i + 7 : 8 * (i - 4) + 3)) & 1u, 0u, 0u, pb + (uint32_t)i, 0u);
+            __builtin_amdgcn_wave_barrier();
+            while (wl_n >= (uint32_t)kWave) list_round(); // fewer than 64 walks are left: the next 64 fit
+        }
+    };
+
+    // ---- the stream: steps of 512 positions; own-unit codes of step s+1 and the text of step s+2 are ahead of step s ----
+    const uint32_t n_steps = (c1 - c0) * 2u;
+    const uint32_t last_load = (nu - 8u) & ~7u; // (the launch makes sure the buffer holds more than a chunk)
+    auto load_own = [&](uint32_t st, uint32_t (&w)[4]) {
+        const uint32_t pb = min(sp0 + st * 512u + lane * 8u, last_load); // (steps behind the span / the buffer: values nobody uses)
+        const uint4 u = *reinterpret_cast<const uint4 *>(hay + pb);      // (16-byte aligned: the span starts on a chunk of the aligned own range)
+        w[0] = u.x; w[1] = u.y; w[2] = u.z; w[3] = u.w;
+    };
+    // a lane's 8 units as packed codes: even units in bits 0.., odd units in bits 16..; O: the raw differences or-ed (units
+    // outside the alphabet leave bits above a code's)
+    auto pack_own = [&](const uint32_t (&w)[4], uint32_t &E, uint32_t &O) {
+        uint32_t t1, t2, t3;
+        asm("v_pk_sub_u16 %0, %1, %2" : "=v"(E) : "v"(w[0]), "s"(base2));
+        asm("v_pk_sub_u16 %0, %1, %2" : "=v"(t1) : "v"(w[1]), "s"(base2));
+        asm("v_pk_sub_u16 %0, %1, %2" : "=v"(t2) : "v"(w[2]), "s"(base2));
+        asm("v_pk_sub_u16 %0, %1, %2" : "=v"(t3) : "v"(w[3]), "s"(base2));
+        O = E | t1 | t2 | t3;
+        E = (t1 << B) | E;
+        E = (t2 << (2 * B)) | E;
+        E = (t3 << (3 * B)) | E;
+    };
+    constexpr uint32_t kCodeMask = ((1u << B) - 1u) * 0x10001u;
+    uint32_t wa[4], wb[4], Ecur, Ocur, Enext, Onext;
+    load_own(0, wa);
+    load_own(1, wb);
+    pack_own(wa, Ecur, Ocur);
+    load_own(2, wa);
+    bool chunk_bad = false;
+    for (uint32_t st = 0; st < n_steps; ++st) {
+        // (wa: text of step st + 2, in flight; wb: text of step st + 1)
+        pack_own(wb, Enext, Onext);
 #pragma unroll
-    for (int k = 0; k < NQ; ++k) Q[k] = wl_pk_mad(P[k], n2, __builtin_amdgcn_alignbit(P[k + 1], P[k], 16));
-    uint32_t I[4];
-    if (RK == 8) {
-        const uint32_t n4 = n * n * n * n * 0x10001u;
-        uint32_t T[6];
+        for (int k = 0; k < 4; ++k) wb[k] = wa[k];
+        load_own(st + 3, wa);
+        const uint32_t s0 = sp0 + st * 512u, pb = s0 + lane * 8u;
+        // the codes of the units behind the lane's own: the next lanes' (the last lanes: the next step's first lanes')
+        uint32_t E1 = dpp_wave_shl1(Ecur);
+        E1 = lane == 63 ? (uint32_t)__builtin_amdgcn_readlane((int)Enext, 0) : E1;
+        uint32_t E = (E1 << (4 * B)) | Ecur;
+        uint32_t Oall = Ocur | (lane < 2 ? Onext : 0u);
+        if (B == 1) {
+            uint32_t E2 = dpp_wave_shl1(E1);
+            E2 = lane == 63 ? (uint32_t)__builtin_amdgcn_readlane((int)Enext, 1) : E2;
+            E = (E2 << 8) | E;
+        }
+        const uint32_t chunk_end = (uint32_t)min((uint64_t)L.own_end, (uint64_t)(s0 - ((st & 1u) ? 512u : 0u)) + kWlChunk);
+        // not this kernel's: a unit outside the alphabet (also among the units of the next step that this step's last windows
+        // cover), a chunk near the end of the buffer (every text load of its walks stays inside the buffer: walks are at most
+        // max_len deep, a round reads 16 units from a walk's current depth), a last, partial chunk
+        const bool bad = __any((Oall & ~kCodeMask) != 0u) || (uint64_t)chunk_end + max(T.max_len, 16u) + 24u > (uint64_t)nu ||
+                         (uint64_t)(s0 - ((st & 1u) ? 512u : 0u)) + kWlChunk > (uint64_t)L.own_end;
+        chunk_bad = ((st & 1u) ? chunk_bad : false) || bad;
+        if (!bad) {
+            uint32_t e[8];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) T[k] = wl_pk_mad(Q[k], nn2, Q[k + 1]);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) I[k] = wl_pk_mad(T[k], n4, T[k + 2]);
-    } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) I[k] = wl_pk_mad(Q[k], nn2, Q[k + 1]);
+            for (uint32_t i = 0; i < 8; ++i) {
+                const uint32_t k = i >> 1;
+                const uint32_t idx = (i & 1u) ? (__builtin_amdgcn_ubfe(E, 16 + B * k, B * HE) | (__builtin_amdgcn_ubfe(E, B * (k + 1), B * HO) << (B * HE)))
+                                              : (__builtin_amdgcn_ubfe(E, B * k, B * HE) | (__builtin_amdgcn_ubfe(E, 16 + B * k, B * HO) << (B * HE)));
+                e[i] = rt[idx];
+            }
+            const uint32_t p0 = e[0] | (e[1] << 8) | (e[2] << 16) | (e[3] << 24), p1 = e[4] | (e[5] << 8) | (e[6] << 16) | (e[7] << 24);
+            // (a length of the first round is at most RK: no escape)
+#ifdef ACGPU_ABLATION
+            if (!(L.debug & 8u))
+#endif
+            *reinterpret_cast<uint2 *>(out_len + pb) = make_uint2(p0 & 0x0f0f0f0fu, p1 & 0x0f0f0f0fu);
+            uint32_t m = (p0 & 0x80808080u) | ((p1 & 0x80808080u) >> 4);
+#ifdef ACGPU_ABLATION
+            if (L.debug & 4u) m = 0; // no live walks
+#endif
+            const uint64_t bal = __ballot(m != 0u);
+            if (bal) {
+                if (m != 0u) {
+                    const uint32_t at = eq_n + (uint32_t)__popcll(bal & lanemask_lt());
+                    pbq[at] = (uint16_t)((pb - sp0) >> 3);
+                    mq[at] = m;
+                }
+                eq_n += (uint32_t)__popcll(bal);
+                __builtin_amdgcn_wave_barrier();
+                if (eq_n >= (uint32_t)kWave) expand(); // fewer than 64 lanes are left: the next step's fit
+            }
+        }
+        if (st & 1u) { // the chunk is complete
+            const uint32_t ck = c0 + (st >> 1);
+            const uint32_t cb = sp0 + (st >> 1) * kWlChunk;
+            if (lane == 0) L.d_todo_w[ck] = chunk_bad ? 1 : 0;
+            if (!chunk_bad && lane < kWlChunk / 64) L.d_blockmax[((cb - L.own_begin) >> 6) + lane] = cb + lane * 64u + 63u + kBlockMaxSlack;
+        }
+        Ecur = Enext;
+        Ocur = Onext;
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) asm("v_pk_lshlrev_b16 %0, %1, %2" : "=v"(A[k]) : "s"(0x00020002u), "v"(I[k]));
+    while (eq_n) expand();
+    while (wl_n) list_round();
 }
 
 #ifdef ACGPU_TIMING
@@ -359,15 +586,22 @@ __device__ unsigned long long g_wl_timing[8]; // total, text wait, index + root 
 #define WL_MARK(i)
 #endif
 template <typename LenT, bool STATE>
-__global__ __launch_bounds__(kLScanBlock) void k_longest_walk_list(DevTables T, LongestScanLaunch L) {
-    constexpr bool ROOT = !STATE;
+__global__ __launch_bounds__(kLScanBlock, 8) void k_longest_walk_list(DevTables T, LongestScanLaunch L) { // (8 waves per SIMD: two workgroups per CU)
     __shared__ __attribute__((aligned(16))) uint32_t rows[STATE ? kWlRowWordsMap : kWlRowWordsSet];
-    __shared__ uint32_t rt[ROOT ? kWlRootWords : 1];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[]; // the work lists
     const uint32_t *glob = reinterpret_cast<const uint32_t *>(T.dfa);
     const uint32_t n = T.n_cls, span = T.cls_span, base = T.cls_base; // n == span + 1
     const uint32_t row_bytes = n * 4u;
     const uint32_t real_bytes = L.lds_rows * row_bytes, dead_off = real_bytes, deep_off = real_bytes + row_bytes;
+    if (L.d_todo != nullptr) { // only the chunks k_longest_block left: a workgroup none of whose chunks is flagged leaves at once
+        const uint64_t nw = (uint64_t)gridDim.x * (kLScanBlock / kWave);
+        const uint64_t nck = ((uint64_t)L.own_end - L.own_begin + kWlChunk - 1) / kWlChunk;
+        bool has = false;
+        for (uint64_t ck = (uint64_t)blockIdx.x * (kLScanBlock / kWave) + (threadIdx.x >> 6) + (uint64_t)(threadIdx.x & 63u) * nw; ck < nck;
+             ck += 64ull * nw)
+            has |= L.d_todo[ck] != 0;
+        if (!__syncthreads_or(has)) return;
+    }
     for (uint32_t i = threadIdx.x; i < (L.lds_rows + 2) * n; i += blockDim.x) { // (as k_longest_walk_range stages them)
         const uint32_t r = i / n, col = i - r * n;
         uint32_t e;
@@ -390,31 +624,6 @@ __global__ __launch_bounds__(kLScanBlock) void k_longest_walk_list(DevTables T, 
     uint32_t *wl0 = wl, *wl1 = wl + kWlCap, *wl2 = wl + 2 * kWlCap; // {row offset | best << 16}, {position in chunk | depth << 16}, [best node's entry]
     uint32_t *bm = wl + kEntryWords * kWlCap;
     __syncthreads();
-    // root table depth: 8 units for n <= 3, 4 for n <= 5, none for wider alphabets
-    __shared__ uint32_t rt_deep; // some RK-unit path leaves the LDS rows: no block form
-    const uint32_t rk = (!ROOT || sizeof(LenT) != 2) ? 0u : n <= 3 ? 8u : n <= 5 ? 4u : 0u;
-    if (ROOT && rk) {
-        if (threadIdx.x == 0) rt_deep = 0;
-        __syncthreads();
-        uint32_t total = 1;
-        for (uint32_t j = 0; j < rk; ++j) total *= n;
-        for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) {
-            uint32_t div = total, rem = i, off = 0, best = 0;
-            for (uint32_t j = 0; j < rk; ++j) { // digit j (most significant first) = column of unit j
-                div /= n;
-                const uint32_t col = rem / div;
-                rem -= col * div;
-                const uint32_t e = rows[(off >> 2) + col];
-                off = e & 0xffffu;
-                if (e >> 31) best = j + 1;
-            }
-            if (off == deep_off) rt_deep = 1;
-            rt[i] = off | (best << 16) | (off < real_bytes ? kRtAlive : 0u);
-        }
-        __syncthreads();
-    }
-    const bool block_form = ROOT && rk && !rt_deep; // block-uniform
-    LenT *out_len = reinterpret_cast<LenT *>(L.d_len);
     const uint16_t *hay = L.d_hay;
     const unsigned char *rows8 = reinterpret_cast<const unsigned char *>(rows);
     const uint32_t nu = L.n_units;
@@ -448,7 +657,7 @@ __global__ __launch_bounds__(kLScanBlock) void k_longest_walk_list(DevTables T, 
                 }
             }
         }
-        out_len[p] = (LenT)best;
+        store_len<LenT>(L, p, best);
         if (STATE) L.d_state[p] = best_node;
         const uint32_t reach = p + (best ? best : 1u);
         if (by_atomic) atomicMax(&bm[prel >> 6], reach);
@@ -536,98 +745,58 @@ __global__ __launch_bounds__(kLScanBlock) void k_longest_walk_list(DevTables T, 
         __builtin_amdgcn_wave_barrier();
     };
 
-    for (uint32_t ck = wave_global; ck < n_chunks; ck += n_waves) {
+    // the general first round of positions [sa, sb) of a chunk: two walks per lane (p and p + 64) through the rows
+    auto first_round = [&](uint32_t chunk0, uint32_t chunk_end, uint32_t sa, uint32_t sb, bool check) {
+        for (uint32_t s0 = sa; s0 < sb; s0 += 2 * kWave) { // positions s0+lane and s0+64+lane
+            uint32_t pp[2] = {s0 + lane, s0 + kWave + lane};
+            uint32_t ee[2], tmm[2], hh[2][8], ww[2][4], nv[2];
+            bool in[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                in[h] = pp[h] < chunk_end;
+                load8(in[h] ? pp[h] : chunk0, ww[h], nv[h], check);
+            }
+            // (the two walks are written out side by side: their dependent LDS reads interleave)
+            if (check) {
+                ee[0] = wl_round<STATE, true>(rows8, ww[0], nv[0], base2, span2, span4, 0u, tmm[0], hh[0]);
+                ee[1] = wl_round<STATE, true>(rows8, ww[1], nv[1], base2, span2, span4, 0u, tmm[1], hh[1]);
+            } else {
+                ee[0] = wl_round<STATE, false>(rows8, ww[0], nv[0], base2, span2, span4, 0u, tmm[0], hh[0]);
+                ee[1] = wl_round<STATE, false>(rows8, ww[1], nv[1], base2, span2, span4, 0u, tmm[1], hh[1]);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                uint32_t best = 0, best_e = 0;
+                round_best(tmm[h], 0u, hh[h], best, best_e);
+                const uint32_t off16 = ee[h] & 0xffffu;
+                const bool alive = in[h] && off16 < real_bytes;
+                const uint32_t prel = pp[h] - chunk0;
+                uint32_t reach = 0;
+                if (in[h] && !alive) reach = finish(pp[h], prel, off16, best, best_e, false);
+                reach = wave_max_dpp(reach); // (no survivor has touched this block's maximum yet: a plain store)
+                if (lane == 0 && s0 + h * kWave < chunk_end) bm[(s0 + h * kWave - chunk0) >> 6] = reach;
+                append(alive, ee[h], best, best_e, prel, 8u);
+                __builtin_amdgcn_wave_barrier();
+                while (wl_n >= (uint32_t)kWave) list_round(chunk0, check); // fewer than 64 entries are left: the next append fits
+            }
+        }
+    };
+    // chunks wave_global, wave_global + n_waves, ...; with L.d_todo only the flagged ones (what k_longest_block left): the flags
+    // of 64 of the wave's chunks are fetched at once
+    for (uint64_t it0 = 0; (uint64_t)wave_global + it0 * n_waves < n_chunks; it0 += kWave) {
+        const uint64_t ck_lane = (uint64_t)wave_global + (it0 + lane) * n_waves;
+        const bool flagged = ck_lane < n_chunks && (L.d_todo == nullptr || L.d_todo[ck_lane] != 0);
+        uint64_t todo_mask = __ballot(flagged);
+      while (todo_mask) {
+        const uint32_t ck = (uint32_t)((uint64_t)wave_global + (it0 + (uint32_t)__builtin_ctzll(todo_mask)) * n_waves);
+        todo_mask &= todo_mask - 1;
         const uint32_t chunk0 = L.own_begin + ck * kWlChunk;
         const uint32_t chunk_end = (uint32_t)min((uint64_t)L.own_end, (uint64_t)chunk0 + kWlChunk);
         // every 16-byte text load of this chunk stays inside the buffer (walks are at most max_len deep)
         const bool check = (uint64_t)chunk_end + T.max_len + 8u > (uint64_t)nu;
-        if (ROOT && block_form && !check && chunk_end - chunk0 == (uint32_t)kWlChunk) {
-            // First round, block form: a lane owns 8 consecutive positions.  Their root-table indices come out of packed
-            // arithmetic over the 16 units behind the lane's first position (wl_block_index), one LDS read per position
-            // gives {node after RK units, longest keyword so far, alive}; the 8 lengths leave as ONE 16-byte store (walks
-            // that go on overwrite theirs when they finish), and the block maxima start from the bound p + RK.
-            if (lane < kWlChunk / 64) bm[lane] = chunk0 + lane * 64u + 63u + rk;
-            __builtin_amdgcn_wave_barrier();
-            for (uint32_t s0 = chunk0; s0 < chunk_end; s0 += 8 * kWave) {
-                const uint32_t pb = s0 + lane * 8u;
-                WL_MARK(3)
-                const Units8 u0 = *reinterpret_cast<const Units8 *>(hay + pb);
-                const Units8 u1 = *reinterpret_cast<const Units8 *>(hay + pb + 8);
-#ifdef ACGPU_TIMING
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-                WL_MARK(1)
-                const uint32_t w16[8] = {u0.d[0], u0.d[1], u0.d[2], u0.d[3], u1.d[0], u1.d[1], u1.d[2], u1.d[3]};
-                uint32_t A[4];
-                if (rk == 8) wl_block_index<8>(w16, base2, span2, n, A);
-                else wl_block_index<4>(w16, base2, span2, n, A);
-                const unsigned char *rt8 = reinterpret_cast<const unsigned char *>(rt);
-                uint32_t e[8];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    e[2 * k] = *reinterpret_cast<const uint32_t *>(rt8 + (A[k] & 0xffffu));
-                    e[2 * k + 1] = *reinterpret_cast<const uint32_t *>(rt8 + (A[k] >> 16));
-                }
-                Units8 lens; // byte 2 of an entry = longest keyword among the RK steps
-#pragma unroll
-                for (int k = 0; k < 4; ++k) lens.d[k] = __builtin_amdgcn_perm(e[2 * k + 1], e[2 * k], 0x0c060c02u);
-                *reinterpret_cast<Units8 *>(out_len + pb) = lens;
-#ifdef ACGPU_TIMING
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-                WL_MARK(2)
-                const uint32_t prel0 = (pb - chunk0) | (rk << 16);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const bool alive = (int32_t)e[i] < 0;
-                    const uint64_t bal = __ballot(alive);
-                    if (alive) {
-                        const uint32_t at = wl_n + (uint32_t)__popcll(bal & lanemask_lt());
-                        wl0[at] = e[i] & 0x00ffffffu;
-                        wl1[at] = prel0 + (uint32_t)i;
-                    }
-                    wl_n += (uint32_t)__popcll(bal);
-                    __builtin_amdgcn_wave_barrier();
-                    while (wl_n >= (uint32_t)kWave) list_round(chunk0, false);
-                }
-            }
-        } else {
-            if (lane < kWlChunk / 64) bm[lane] = 0;
-            __builtin_amdgcn_wave_barrier();
-            for (uint32_t s0 = chunk0; s0 < chunk_end; s0 += 2 * kWave) { // first round: positions s0+lane and s0+64+lane
-                uint32_t pp[2] = {s0 + lane, s0 + kWave + lane};
-                uint32_t ee[2], tmm[2], hh[2][8], ww[2][4], nv[2];
-                bool in[2];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    in[h] = pp[h] < chunk_end;
-                    load8(in[h] ? pp[h] : chunk0, ww[h], nv[h], check);
-                }
-                // (the two walks are written out side by side: their dependent LDS reads interleave)
-                if (check) {
-                    ee[0] = wl_round<STATE, true>(rows8, ww[0], nv[0], base2, span2, span4, 0u, tmm[0], hh[0]);
-                    ee[1] = wl_round<STATE, true>(rows8, ww[1], nv[1], base2, span2, span4, 0u, tmm[1], hh[1]);
-                } else {
-                    ee[0] = wl_round<STATE, false>(rows8, ww[0], nv[0], base2, span2, span4, 0u, tmm[0], hh[0]);
-                    ee[1] = wl_round<STATE, false>(rows8, ww[1], nv[1], base2, span2, span4, 0u, tmm[1], hh[1]);
-                }
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    uint32_t best = 0, best_e = 0;
-                    round_best(tmm[h], 0u, hh[h], best, best_e);
-                    const uint32_t off16 = ee[h] & 0xffffu;
-                    const bool alive = in[h] && off16 < real_bytes;
-                    const uint32_t prel = pp[h] - chunk0;
-                    uint32_t reach = 0;
-                    if (in[h] && !alive) reach = finish(pp[h], prel, off16, best, best_e, false);
-                    reach = wave_max_dpp(reach); // (no survivor has touched this block's maximum yet: a plain store)
-                    if (lane == 0 && s0 + h * kWave < chunk_end) bm[(s0 + h * kWave - chunk0) >> 6] = reach;
-                    append(alive, ee[h], best, best_e, prel, 8u);
-                    __builtin_amdgcn_wave_barrier();
-                    while (wl_n >= (uint32_t)kWave) list_round(chunk0, check); // fewer than 64 entries are left: the next append fits
-                }
-            }
-        }
+        if (lane < kWlChunk / 64) bm[lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+        first_round(chunk0, chunk_end, chunk0, chunk_end, check);
         WL_MARK(3)
         while (wl_n) list_round(chunk0, check);
         __builtin_amdgcn_wave_barrier();
@@ -635,6 +804,7 @@ __global__ __launch_bounds__(kLScanBlock) void k_longest_walk_list(DevTables T, 
         if (lane < nblk) L.d_blockmax[((chunk0 - L.own_begin) >> 6) + lane] = bm[lane];
         __builtin_amdgcn_wave_barrier();
         WL_MARK(4)
+      }
     }
 #ifdef ACGPU_TIMING
     if (lane == 0) {
@@ -653,7 +823,28 @@ size_t longest_list_lds_bytes(bool state) { return (size_t)(kLScanBlock / kWave)
 uint32_t longest_list_max_rows(uint32_t n_cls, bool state) {
     return n_cls ? (uint32_t)(state ? kWlRowWordsMap : kWlRowWordsSet) / n_cls - 2u : 0u;
 }
-static_assert(6561 <= kWlRootWords && 625 <= kWlRootWords, "root table: 3^8 and 5^4 entries");
+
+size_t longest_block_lds_bytes() { return (size_t)(kLScanBlock / kWave) * kBlkQueueWords * 4; }
+uint32_t longest_block_max_rows(uint32_t n_cls) { return n_cls ? (uint32_t)kBlkRowWords / n_cls - 2u : 0u; }
+
+// k_longest_block (one-byte lengths; l.d_todo_w, l.span_chunks, l.lds_rows <= longest_block_max_rows set); the chunks flagged in
+// d_todo_w are left for launch_longest_scan with l.d_todo
+hipError_t launch_longest_block(const DevTables &t, const LongestScanLaunch &l, hipStream_t stream, const char **kernel_name) {
+    const size_t lds = longest_block_lds_bytes();
+    hipError_t e;
+    if (t.root_b == 1) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_longest_block<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_longest_block<1>), dim3(l.grid), dim3(l.block), lds, stream, t, l);
+        if (kernel_name) *kernel_name = "k_longest_block<1u>";
+    } else {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_longest_block<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_longest_block<2>), dim3(l.grid), dim3(l.block), lds, stream, t, l);
+        if (kernel_name) *kernel_name = "k_longest_block<2u>";
+    }
+    return hipGetLastError();
+}
 
 hipError_t launch_longest_scan(const DevTables &t, const LongestScanLaunch &l, hipStream_t stream, const char **kernel_name) {
 #define ACGPU_LAUNCH(KERNEL, NAME)                                                                                      \
@@ -664,8 +855,11 @@ hipError_t launch_longest_scan(const DevTables &t, const LongestScanLaunch &l, h
         hipLaunchKernelGGL(KERNEL, dim3(l.grid), dim3(l.block), l.lds_bytes, stream, t, l);                             \
         if (kernel_name) *kernel_name = NAME;                                                                           \
     } while (0)
-    if (l.pairs == 2) { // the work-list form (16-bit lengths, LDS rows below 64 KiB)
-        if (l.d_state) ACGPU_LAUNCH((k_longest_walk_list<uint16_t, true>), "k_longest_walk_list<unsigned short, true>");
+    if (l.pairs == 2) { // the work-list form (8- or 16-bit lengths, LDS rows below 64 KiB)
+        if (l.len_bytes == 1) {
+            if (l.d_state) ACGPU_LAUNCH((k_longest_walk_list<uint8_t, true>), "k_longest_walk_list<unsigned char, true>");
+            else ACGPU_LAUNCH((k_longest_walk_list<uint8_t, false>), "k_longest_walk_list<unsigned char, false>");
+        } else if (l.d_state) ACGPU_LAUNCH((k_longest_walk_list<uint16_t, true>), "k_longest_walk_list<unsigned short, true>");
         else ACGPU_LAUNCH((k_longest_walk_list<uint16_t, false>), "k_longest_walk_list<unsigned short, false>");
     } else if (l.pairs) { // (field name kept: the lean range-class form)
         if (l.d_state) {
@@ -700,6 +894,16 @@ hipError_t launch_longest_scan(const DevTables &t, const LongestScanLaunch &l, h
 #endif
     return hipGetLastError();
 }
+
+// a length as the chain kernels read it: one-byte lengths carry the escape kLenEscape (the value is in d_len_big)
+template <typename LenT>
+__device__ __forceinline__ uint32_t len_full(const LongestChainLaunch &L, uint32_t pos, uint32_t l) {
+    if (sizeof(LenT) == 1 && l == kLenEscape) return (uint32_t)L.d_len_big[pos];
+    return l;
+}
+struct __attribute__((packed, aligned(1))) Bytes16 { // 16 one-byte lengths at any address
+    uint32_t d[4];
+};
 
 // ---- chain -------------------------------------------------------------------------------------------------
 // Synchronisation point of tile t (t >= 1): follow, in lock step by position, the greedy chains of EVERY position at
@@ -747,31 +951,46 @@ __global__ __launch_bounds__(256) void k_longest_sync(LongestChainLaunch L, uint
         const uint32_t b = (q - L.own_begin) >> 6;
         const uint32_t bend = min(tb, L.own_begin + ((b + 1) << 6));
         if (L.d_blockmax[b] >= tb) {
-            if (sizeof(LenT) == 2 && bend >= L.own_begin + 64u) {
-                // the 64 lengths below bend in eight independent 16-byte loads (one memory latency for the block, not 64);
-                // which positions land at or beyond the tile start is decided in registers, only those are inserted
+            if (sizeof(LenT) <= 2 && bend >= L.own_begin + 64u) {
+                // the 64 lengths below bend in eight (one-byte lengths: four) independent 16-byte loads (one memory latency
+                // for the block, not 64); which positions land at or beyond the tile start is decided in registers, only
+                // those are inserted
                 const uint32_t b0 = bend - 64u;
-                Units8 v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const Units8 *>(reinterpret_cast<const uint16_t *>(len) + b0 + 8 * j);
                 uint64_t hit = 0;
+                if (sizeof(LenT) == 2) {
+                    Units8 v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
+                    for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const Units8 *>(reinterpret_cast<const uint16_t *>(len) + b0 + 8 * j);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const uint32_t pos = b0 + 8u * j + i;
-                        const uint32_t l = (v[j].d[i >> 1] >> (16 * (i & 1))) & 0xffffu;
-                        if (pos >= q && pos + (l > 0 ? l : 1u) >= tb) hit |= 1ull << (8 * j + i);
-                    }
+                    for (int j = 0; j < 8; ++j)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const uint32_t pos = b0 + 8u * j + i;
+                            const uint32_t l = (v[j].d[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+                            if (pos >= q && pos + (l > 0 ? l : 1u) >= tb) hit |= 1ull << (8 * j + i);
+                        }
+                } else {
+                    Bytes16 v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const Bytes16 *>(reinterpret_cast<const uint8_t *>(len) + b0 + 16 * j);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const uint32_t pos = b0 + 16u * j + i;
+                            const uint32_t l = (v[j].d[i >> 2] >> (8 * (i & 3))) & 0xffu; // (an escaped length lands at pos + 255 or beyond)
+                            if (pos >= q && (l == kLenEscape || pos + (l > 0 ? l : 1u) >= tb)) hit |= 1ull << (16 * j + i);
+                        }
+                }
                 while (hit && ok) {
                     const uint32_t pos = b0 + (uint32_t)__builtin_ctzll(hit);
                     hit &= hit - 1;
-                    const uint32_t l = (uint32_t)len[pos];
-                    insert(pos + (l > 0 ? l : 1u));
+                    const uint32_t l = len_full<LenT>(L, pos, (uint32_t)len[pos]);
+                    if (pos + (l > 0 ? l : 1u) >= tb) insert(pos + (l > 0 ? l : 1u));
                 }
             } else {
                 for (; q < bend && ok; ++q) {
-                    const uint32_t l = (uint32_t)len[q];
+                    const uint32_t l = len_full<LenT>(L, q, (uint32_t)len[q]);
                     const uint32_t land = q + (l > 0 ? l : 1u);
                     if (land >= tb) insert(land);
                 }
@@ -789,7 +1008,7 @@ __global__ __launch_bounds__(256) void k_longest_sync(LongestChainLaunch L, uint
             break;
         }
         set[mi] = set[--cnt];
-        const uint32_t l = (uint32_t)len[p];
+        const uint32_t l = len_full<LenT>(L, p, (uint32_t)len[p]);
         insert(p + (l > 0 ? l : 1u));
     }
     S[t] = (ok && cnt == 1 && set[0] < te) ? set[0] : ~0u;
@@ -852,7 +1071,7 @@ __global__ __launch_bounds__(kChainBlock) void k_longest_chain(LongestChainLaunc
     uint32_t win[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t wbase = ~0u - 64u; // no window yet
     auto len_at = [&](uint32_t q) -> uint32_t {
-        if (sizeof(LenT) != 2) return (uint32_t)len[q];
+        if (sizeof(LenT) != 2) return len_full<LenT>(L, q, (uint32_t)len[q]);
         if (q - wbase >= 16u) { // (also true for q < wbase: the chain only moves forwards)
             const uint16_t *src = reinterpret_cast<const uint16_t *>(len) + q;
             const Units8 a = *reinterpret_cast<const Units8 *>(src), b = *reinterpret_cast<const Units8 *>(src + 8);
@@ -1016,7 +1235,7 @@ __global__ __launch_bounds__(kEmitBlock) void k_longest_emit(LongestChainLaunch 
                 const uint32_t p = wi * 32u + (uint32_t)__builtin_ctz(b);
                 b &= b - 1u;
                 if (k >= done && k < done + kEmitCap) {
-                    se[k - done] = make_int2((int)p, (int)(p + (uint32_t)len[p]));
+                    se[k - done] = make_int2((int)p, (int)(p + len_full<LenT>(L, p, (uint32_t)len[p])));
                     if (REC == ACGPU_REC_MAP) st_id[wave][k - done] = (int)L.d_out_id[L.d_state[p]];
                 }
                 ++k;
@@ -1134,11 +1353,9 @@ __global__ __launch_bounds__(kEmitBlock, 8) void k_longest_emit_ends(LongestChai
 // lengths come through LDS in chunks of 256 positions: a lane requests its whole chunk at once (32 independent 16-byte
 // loads: one memory latency per 256 positions instead of one per 16) and then walks it with LDS reads.  The walk is cheap
 // enough to run twice -- count, (prefix sum), write -- without the bitmap and the separate emit pass.
-#ifndef ACGPU_C2CHUNK
-#define ACGPU_C2CHUNK 256
-#endif
-constexpr int kC2Chunk = ACGPU_C2CHUNK; // positions per lane and chunk: 32 pieces of 8 lengths = 512 bytes, loaded by one half wave
-                              // of one LDS-DMA instruction (global_load_lds_dwordx4: lane i's 16 bytes land at base + 16 i)
+constexpr int kC2Pieces = 32; // 16-byte pieces per lane and chunk: 512 bytes, loaded by one half wave of one LDS-DMA instruction
+                              // (global_load_lds_dwordx4: lane i's 16 bytes land at base + 16 i) -- 256 positions of 16-bit
+                              // lengths, 512 positions of one-byte lengths
 
 // BITS (count pass): the matches are also marked in the bitmap L.d_bits for k_longest_emit -- collected per chunk in LDS
 // (chunks start on a bitmap word) and merged into the zeroed bitmap with one atomicOr per non-zero word; these stores are
@@ -1152,16 +1369,19 @@ __device__ unsigned long long g_c2_timing[8]; // total, zero+issue, load wait, w
 #else
 #define C2_MARK(i)
 #endif
-template <bool WRITE, bool BITS = false>
+template <typename LenT, bool WRITE, bool BITS = false>
 __global__ __launch_bounds__(kWave, ACGPU_C2WAVES) void k_longest_chain_lds(LongestChainLaunch L, const uint32_t *S) {
-    __shared__ __attribute__((aligned(16))) unsigned char buf[kC2Chunk / 8 * kWave * 16]; // [piece][lane][8 lengths]
+    constexpr uint32_t kPP = 16 / sizeof(LenT);            // lengths per piece: 8 or 16
+    constexpr uint32_t kPPLog = sizeof(LenT) == 2 ? 3 : 4;
+    constexpr int kC2Chunk = kC2Pieces * (int)kPP;         // positions per lane and chunk
+    __shared__ __attribute__((aligned(16))) unsigned char buf[kC2Pieces * kWave * 16]; // [piece][lane][16 bytes of lengths]
     __shared__ uint32_t lbits[BITS ? kC2Chunk / 32 : 1][kWave];
     __shared__ uint32_t lebits[BITS ? kC2Chunk / 32 + 1 : 1][kWave]; // the ends (bit end-1), when L.d_ebits is there (+ a dummy word)
     __shared__ int2 ring_se[WRITE ? 8 : 1][kWave];
     __shared__ int ring_id[WRITE ? 4 : 1][kWave];
     const uint32_t lane = threadIdx.x;
     const uint32_t t = blockIdx.x * kWave + lane;
-    const uint16_t *len = reinterpret_cast<const uint16_t *>(L.d_len);
+    const LenT *len = reinterpret_cast<const LenT *>(L.d_len);
     uint32_t start = t < L.n_tiles ? S[t] : ~0u;
     bool active = start != ~0u && start < L.own_end;
     if (t < L.n_tiles && !active && !WRITE) {
@@ -1199,16 +1419,16 @@ __global__ __launch_bounds__(kWave, ACGPU_C2WAVES) void k_longest_chain_lds(Long
     // LDS layout: a lane's chunk is contiguous (kC2Chunk * 2 bytes at lane * kC2Chunk * 2), its 16-byte pieces permuted by
     // piece ^ lane -- the lanes walk their chunks at about the same pace, and without the permutation they would all sit in
     // the same banks.  Length x of the lane's chunk: piece x >> 3, entry x & 7.
-    constexpr uint32_t kPieces = kC2Chunk / 8, kChunkBytes = kC2Chunk * 2;
+    constexpr uint32_t kPieces = kC2Pieces, kChunkBytes = kC2Pieces * 16;
     static_assert(kPieces == 32 || kPieces == 16 || kPieces == 8, "a half (quarter, eighth) wave loads one lane's chunk: 32 (16, 8) pieces of 16 bytes");
     constexpr uint32_t kOwnersPerLoad = kWave / kPieces; // lanes whose chunks one load instruction brings
     const unsigned char *mine = buf + lane * kChunkBytes;
-    // (slot = piece ^ lane, i.e. byte offset ((x ^ lane's piece bits) * 2): two instructions from x to the address)
-    const uint32_t swz = (lane & (kPieces - 1u)) << 3;
-    auto at = [&](uint32_t x) -> const unsigned char * { return mine + ((x ^ swz) << 1); };
+    // (slot = piece ^ lane, i.e. byte offset ((x ^ lane's piece bits) * sizeof(LenT)): two instructions from x to the address)
+    const uint32_t swz = (lane & (kPieces - 1u)) << kPPLog;
+    auto at = [&](uint32_t x) -> const unsigned char * { return mine + ((x ^ swz) * (uint32_t)sizeof(LenT)); };
     // a chunk starts on a 16-byte boundary of len[]; pieces past its end are read from the last whole piece instead (never
     // consulted: the walk stops at limit <= the end of the owned range; the allocation of len[] has 64 bytes of slack)
-    const uint32_t last_piece = L.len_units & ~7u;
+    const uint32_t last_piece = L.len_units & ~(kPP - 1u);
     const bool ebits = BITS && L.d_ebits != nullptr;
 #ifdef ACGPU_TIMING
     unsigned long long c2t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c2t0 = clock64();
@@ -1216,7 +1436,7 @@ __global__ __launch_bounds__(kWave, ACGPU_C2WAVES) void k_longest_chain_lds(Long
 #endif
     uint32_t pend = ~0u; // an end beyond the chunk in which its match started: it lies in the first word of the lane's next chunk
     while (__any(active)) {
-        const uint32_t cb = pos & (BITS ? ~31u : ~7u);
+        const uint32_t cb = pos & (BITS ? ~31u : ~(kPP - 1u));
         if (BITS) {
 #pragma unroll
             for (int w = 0; w < kC2Chunk / 32; ++w) lbits[w][lane] = 0;
@@ -1244,7 +1464,7 @@ __global__ __launch_bounds__(kWave, ACGPU_C2WAVES) void k_longest_chain_lds(Long
                     cbo = sub == (uint32_t)o ? c : cbo;
                 }
                 const uint32_t owner = kOwnersPerLoad * j + sub;
-                const uint32_t src = cbo + ((my_piece ^ owner) & (kPieces - 1u)) * 8u;
+                const uint32_t src = cbo + ((my_piece ^ owner) & (kPieces - 1u)) * kPP;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(len + min(src, last_piece)),
                                                  (__attribute__((address_space(3))) void *)(buf + j * (kWave * 16)), 16, 0, 0);
             }
@@ -1261,7 +1481,8 @@ __global__ __launch_bounds__(kWave, ACGPU_C2WAVES) void k_longest_chain_lds(Long
             const uint32_t rel_end = limit > cb ? min(limit - cb, (uint32_t)kC2Chunk) : 0u;
             uint32_t rel = pos - cb, pend_rel = ~0u;
             while (rel < rel_end) {
-                const uint32_t l = *reinterpret_cast<const uint16_t *>(at(rel));
+                uint32_t l = *reinterpret_cast<const LenT *>(at(rel));
+                if (sizeof(LenT) == 1 && l == kLenEscape) l = (uint32_t)L.d_len_big[cb + rel]; // (rare: 255 units and more)
                 if (l > 0) {
                     if (BITS) atomicOr(&lbits[rel >> 5][lane], 1u << (rel & 31u));
                     if (ebits) {
@@ -1270,7 +1491,7 @@ __global__ __launch_bounds__(kWave, ACGPU_C2WAVES) void k_longest_chain_lds(Long
                         atomicOr(&lebits[in ? er >> 5 : (uint32_t)(kC2Chunk / 32)][lane], 1u << (er & 31u));
                         pend_rel = in ? pend_rel : er;
                     }
-                    if (WRITE) {
+                    if constexpr (WRITE) {
                         pos = cb + rel;
                         const uint32_t k = (uint32_t)dst & gmask;
                         ring_se[k][lane] = make_int2((int)pos, (int)(pos + l));
@@ -1304,10 +1525,10 @@ __global__ __launch_bounds__(kWave, ACGPU_C2WAVES) void k_longest_chain_lds(Long
                 } else {
                     // no keyword starts here; from a piece boundary on, whole pieces of eight such positions are skipped at a stroke
                     ++rel;
-                    while ((rel & 7u) == 0 && rel + 8 <= rel_end) {
+                    while ((rel & (kPP - 1u)) == 0 && rel + kPP <= rel_end) {
                         const uint4 z = *reinterpret_cast<const uint4 *>(at(rel));
                         if (z.x | z.y | z.z | z.w) break;
-                        rel += 8;
+                        rel += kPP;
                     }
                 }
             }
@@ -1375,9 +1596,15 @@ __global__ __launch_bounds__(kWave, ACGPU_C2WAVES) void k_longest_chain_lds(Long
 hipError_t launch_longest_chain_lds(const LongestChainLaunch &l, const uint32_t *d_sync, bool write_pass, hipStream_t stream) {
     if (l.n_tiles == 0) return hipSuccess;
     const dim3 grid((l.n_tiles + kWave - 1) / kWave), block(kWave);
-    if (write_pass) hipLaunchKernelGGL((k_longest_chain_lds<true>), grid, block, 0, stream, l, d_sync);
-    else if (l.d_bits) hipLaunchKernelGGL((k_longest_chain_lds<false, true>), grid, block, 0, stream, l, d_sync);
-    else hipLaunchKernelGGL((k_longest_chain_lds<false>), grid, block, 0, stream, l, d_sync);
+    if (l.len_bytes == 1) {
+        if (write_pass) hipLaunchKernelGGL((k_longest_chain_lds<uint8_t, true>), grid, block, 0, stream, l, d_sync);
+        else if (l.d_bits) hipLaunchKernelGGL((k_longest_chain_lds<uint8_t, false, true>), grid, block, 0, stream, l, d_sync);
+        else hipLaunchKernelGGL((k_longest_chain_lds<uint8_t, false>), grid, block, 0, stream, l, d_sync);
+    } else {
+        if (write_pass) hipLaunchKernelGGL((k_longest_chain_lds<uint16_t, true>), grid, block, 0, stream, l, d_sync);
+        else if (l.d_bits) hipLaunchKernelGGL((k_longest_chain_lds<uint16_t, false, true>), grid, block, 0, stream, l, d_sync);
+        else hipLaunchKernelGGL((k_longest_chain_lds<uint16_t, false>), grid, block, 0, stream, l, d_sync);
+    }
 #ifdef ACGPU_TIMING
     if (!write_pass) {
         (void)hipStreamSynchronize(stream);
@@ -1395,7 +1622,8 @@ hipError_t launch_longest_chain_lds(const LongestChainLaunch &l, const uint32_t 
 hipError_t launch_longest_sync(const LongestChainLaunch &l, uint32_t *d_sync, hipStream_t stream) {
     if (l.n_tiles == 0) return hipSuccess;
     const dim3 grid((l.n_tiles + 255) / 256), block(256);
-    if (l.len_bytes == 2) hipLaunchKernelGGL((k_longest_sync<uint16_t>), grid, block, 0, stream, l, d_sync);
+    if (l.len_bytes == 1) hipLaunchKernelGGL((k_longest_sync<uint8_t>), grid, block, 0, stream, l, d_sync);
+    else if (l.len_bytes == 2) hipLaunchKernelGGL((k_longest_sync<uint16_t>), grid, block, 0, stream, l, d_sync);
     else hipLaunchKernelGGL((k_longest_sync<uint32_t>), grid, block, 0, stream, l, d_sync);
     return hipGetLastError();
 }
@@ -1403,7 +1631,11 @@ hipError_t launch_longest_sync(const LongestChainLaunch &l, uint32_t *d_sync, hi
 hipError_t launch_longest_chain(const LongestChainLaunch &l, const uint32_t *d_sync, bool write_pass, hipStream_t stream) {
     if (l.n_tiles == 0) return hipSuccess;
     const dim3 grid((l.n_tiles + kChainBlock - 1) / kChainBlock), block(kChainBlock);
-    if (l.len_bytes == 2) {
+    if (l.len_bytes == 1) {
+        if (write_pass) hipLaunchKernelGGL((k_longest_chain<uint8_t, true>), grid, block, 0, stream, l, d_sync);
+        else if (l.d_bits) hipLaunchKernelGGL((k_longest_chain<uint8_t, false, true>), grid, block, 0, stream, l, d_sync);
+        else hipLaunchKernelGGL((k_longest_chain<uint8_t, false>), grid, block, 0, stream, l, d_sync);
+    } else if (l.len_bytes == 2) {
         if (write_pass) hipLaunchKernelGGL((k_longest_chain<uint16_t, true>), grid, block, 0, stream, l, d_sync);
         else if (l.d_bits) hipLaunchKernelGGL((k_longest_chain<uint16_t, false, true>), grid, block, 0, stream, l, d_sync);
         else hipLaunchKernelGGL((k_longest_chain<uint16_t, false>), grid, block, 0, stream, l, d_sync);
@@ -1422,6 +1654,9 @@ hipError_t launch_longest_emit(const LongestChainLaunch &l, const uint32_t *d_sy
     if (l.d_ebits) {
         if (set_kind) hipLaunchKernelGGL((k_longest_emit_ends<ACGPU_REC_SET>), grid, block, 0, stream, l, d_sync);
         else hipLaunchKernelGGL((k_longest_emit_ends<ACGPU_REC_MAP>), grid, block, 0, stream, l, d_sync);
+    } else if (l.len_bytes == 1) {
+        if (set_kind) hipLaunchKernelGGL((k_longest_emit<uint8_t, ACGPU_REC_SET>), grid, block, 0, stream, l, d_sync);
+        else hipLaunchKernelGGL((k_longest_emit<uint8_t, ACGPU_REC_MAP>), grid, block, 0, stream, l, d_sync);
     } else if (l.len_bytes == 2) {
         if (set_kind) hipLaunchKernelGGL((k_longest_emit<uint16_t, ACGPU_REC_SET>), grid, block, 0, stream, l, d_sync);
         else hipLaunchKernelGGL((k_longest_emit<uint16_t, ACGPU_REC_MAP>), grid, block, 0, stream, l, d_sync);

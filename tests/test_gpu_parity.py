@@ -339,6 +339,34 @@ def test_longest_prefix_closed_dictionary_like_config_c4():
     assert (got2 == want2).all()
 
 
+@pytest.mark.parametrize("letters,others", [("ab", ""), ("ab", " ,"), ("a", "b"), ("acgt", ""), ("acgt", "n"), ("abc", "xyz")])
+def test_longest_walk_root_table_bit_fields_and_units_outside_the_alphabet(letters, others):
+    """k_longest_walk_list's first round (Set records): the bit-field root table -- one bit per unit for alphabets of up to two
+    letters (13 units deep), two bits for up to four (6 deep) -- and its fall-back to the general first round for a
+    512-position step that holds a unit outside the alphabet; keywords longer than the table is deep go on through the work
+    list, some beyond 255 units."""
+    rng = np.random.default_rng(len(letters) * 100 + len(others))
+    la = np.array([ord(c) for c in letters], dtype=np.uint16)
+    n = 300000
+    hay = la[rng.integers(0, len(la), n)]
+    if others:  # a few stretches with other units, the rest clean (both paths run)
+        oa = np.array([ord(c) for c in others], dtype=np.uint16)
+        for at in rng.integers(0, n - 2000, 12).tolist():
+            k = int(rng.integers(1, 900))
+            idx = at + rng.integers(0, 2000, k)
+            hay[idx] = oa[rng.integers(0, len(oa), k)]
+    base = [hay[o:o + ln].copy() for o, ln in zip(rng.integers(0, n - 700, 40).tolist(), rng.integers(1, 600, 40).tolist())]
+    kws = [b[:k] for b in base for k in sorted(set(rng.integers(1, len(b) + 1, 6).tolist()))]  # prefixes: long shared paths
+    kws += [la[rng.integers(0, len(la), int(rng.integers(1, 16)))] for _ in range(200)]
+    want = Oracle(FAM_LONGEST, kws).match(hay)
+    m = LongestMatchSet(kws, True)
+    got = m.find_all(hay)
+    assert got.shape == want[:, :2].shape and (got == want[:, :2]).all()
+    assert int((want[:, 1] - want[:, 0]).max()) > 255 or len(letters) == 1
+    gm = LongestMatchMap(kws, _ids(len(kws)), True).find_all(hay)  # (the Map flavour walks without the root table)
+    assert gm.shape == want.shape and (gm == want).all()
+
+
 def test_longest_shards_with_chain_entry_and_exit():
     import torch
     kws = synth.random_keywords(21, 400, 1, 7, table=synth.ALPHA_LOWER[:5])
