@@ -55,6 +55,14 @@ struct Ticket {
     hipEvent_t done = nullptr;
     unsigned long long *h_count = nullptr; // pinned, 64 bytes
     bool busy = false, profiled = false;
+    // how _end collects it: 0 = the AhoCorasick / WholeWord pipeline (count and overflow word in h_count), 1 = a chain pipeline
+    // that was enqueued (LONGEST walk: count in h_count[0], chain exit in h_count[2]), 2 = the call ran synchronously inside
+    // _begin (the other families): everything is in the fields below
+    int kind = 0;
+    int sync_rc = 0;
+    uint64_t sync_n = 0;
+    acgpu_profile sync_prof{};
+    acgpu_shard *user_shard = nullptr; // receives chain_exit in _end
     uint64_t cap = 0, scanned = 0;
     char kname[64] = {0};
     void *owner = nullptr; // the DeviceState it belongs to
@@ -752,9 +760,12 @@ int match_longest_sparse(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, in
 }
 
 // LONGEST-mode pipeline on one shard: reverse scan -> chain count -> prefix sum -> chain write.
+// With a ticket (the walk pipeline only: want_async_longest) the call returns after enqueueing; acgpu_match_device_end collects it.
 int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_kind, void *d_out, uint64_t cap,
-                  uint64_t *n_out, hipStream_t stream, acgpu_profile *prof) {
+                  uint64_t *n_out, hipStream_t stream, acgpu_profile *prof, Ticket *tk = nullptr) {
     const HostTables &t = a->t;
+    hipEvent_t *ev = tk ? tk->ev : d.ev;
+    const bool timed = tk ? tk->profiled : prof != nullptr;
     const uint32_t halo = t.max_len > 0 ? t.max_len - 1 : 0;
     if (!sh->text_end && sh->n_units - sh->own_end < halo) return ACGPU_E_INVALID; // right halo too short
     if (sh->chain_entry < (int64_t)sh->own_begin) return ACGPU_E_INVALID;
@@ -764,10 +775,18 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
     if (entry >= sh->own_end || t.n_states <= 1) {
         *n_out = 0;
         if (entry < sh->own_end) sh->chain_exit = (int64_t)sh->own_end;
+        if (tk) { // (no kernel will write the slot)
+            tk->h_count[0] = tk->h_count[1] = 0;
+            tk->h_count[2] = (unsigned long long)sh->chain_exit;
+            tk->profiled = false;
+            tk->stream = stream;
+            if (sh->d_result) HIP_TRY(hipMemsetAsync(sh->d_result, 0, sizeof(acgpu_device_result), stream));
+            HIP_TRY(hipEventRecord(tk->done, stream));
+        }
         return ACGPU_OK;
     }
     const uint64_t own_len = sh->own_end - sh->own_begin;
-    if (filter_is_selective(t) && tunables().force_kernel != 1) { // selective suffix filter: selection over all matches
+    if (!tk && filter_is_selective(t) && tunables().force_kernel != 1) { // selective suffix filter: selection over all matches
         const int src = match_longest_sparse(a, d, sh, record_kind, d_out, cap, n_out, stream, prof, entry);
         if (src != ACGPU_E_UNSUPPORTED) return src;
         sh->chain_exit = (int64_t)std::max<uint64_t>(entry, sh->own_end); // dense in matches after all: the walk
@@ -862,7 +881,7 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
 
     HIP_TRY(hipMemsetAsync(d.counter.p, 0, 64, stream));
     d.cclean[0] = false; // (match_all's first set of slot counters lives here)
-    if (prof) HIP_TRY(hipEventRecord(d.ev[0], stream));
+    if (timed) HIP_TRY(hipEventRecord(ev[0], stream));
     const char *kname = "";
     if (root_form) {
         LongestScanLaunch Sb = S;
@@ -874,7 +893,7 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
     } else {
         HIP_TRY(launch_longest_scan(d.T, S, stream, &kname));
     }
-    if (prof) HIP_TRY(hipEventRecord(d.ev[1], stream));
+    if (timed) HIP_TRY(hipEventRecord(ev[1], stream));
     if ((rc = d.chain.ensure((size_t)Cn.n_tiles * 4 + 64))) return rc;
     uint32_t *d_sync = (uint32_t *)d.chain.p;
     // Chain: synchronisation points, a count pass that also marks the chain's matches in a bitmap, prefix sum, and the
@@ -902,13 +921,22 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
     if (!serial_write) HIP_TRY(launch_longest_emit(Cn, d_sync, stream));
     else if (chain_lds) HIP_TRY(launch_longest_chain_lds(Cn, d_sync, /*write_pass=*/true, stream));
     else HIP_TRY(launch_longest_chain(Cn, d_sync, /*write_pass=*/true, stream));
-    if (prof) HIP_TRY(hipEventRecord(d.ev[2], stream));
-    HIP_TRY(hipMemcpyAsync(d.h_counter, (const uint64_t *)d.scan_tmp.p + scan_tiles_for(Cn.n_tiles), 8, hipMemcpyDeviceToHost,
-                           stream));
-    HIP_TRY(hipMemcpyAsync(d.h_counter + 1, d.counter.p, 8, hipMemcpyDeviceToHost, stream));
+    if (timed) HIP_TRY(hipEventRecord(ev[2], stream));
+    // {count, 0, exit} into the call's pinned host slot (and the device result) by the pipeline's last kernel
+    unsigned long long *h_slot = tk ? tk->h_count : d.h_counter, *d_slot = nullptr;
+    HIP_TRY(hipHostGetDevicePointer((void **)&d_slot, h_slot, 0));
+    HIP_TRY(launch_publish_result((const unsigned long long *)d.scan_tmp.p + scan_tiles_for(Cn.n_tiles), (const unsigned long long *)d.counter.p,
+                                  d_slot, tk ? reinterpret_cast<acgpu_device_result *>(sh->d_result) : nullptr, stream));
+    if (tk) {
+        tk->stream = stream;
+        HIP_TRY(hipEventRecord(tk->done, stream));
+        tk->scanned = own_len;
+        std::snprintf(tk->kname, sizeof(tk->kname), "%s", kname);
+        return ACGPU_OK;
+    }
     HIP_TRY(hipStreamSynchronize(stream));
     *n_out = d.h_counter[0];
-    sh->chain_exit = (int64_t)d.h_counter[1];
+    sh->chain_exit = (int64_t)d.h_counter[2];
     if (prof) {
         HIP_TRY(hipEventElapsedTime(&prof->scan_ms, d.ev[0], d.ev[1]));
         HIP_TRY(hipEventElapsedTime(&prof->finalize_ms, d.ev[1], d.ev[2]));
@@ -1433,8 +1461,7 @@ int acgpu_match_device_begin(const acgpu_automaton *ca, acgpu_shard *sh, int rec
     if (!ca || !sh || !ticket) return ACGPU_E_INVALID;
     *ticket = nullptr;
     acgpu_automaton *a = const_cast<acgpu_automaton *>(ca);
-    // (AhoCorasick and WholeWord with fold-consistent tables: one scan + ordering pass; the other families end on the host)
-    if (a->t.mode != ACGPU_MODE_ALL && !(a->t.mode == ACGPU_MODE_WHOLEWORD && a->t.fold_consistent)) return ACGPU_E_UNSUPPORTED;
+    const HostTables &t = a->t;
     std::lock_guard<std::mutex> lock(a->mu);
     DeviceState *d = nullptr;
     int rc = device_for_call(a, &d);
@@ -1452,8 +1479,29 @@ int acgpu_match_device_begin(const acgpu_automaton *ca, acgpu_shard *sh, int rec
     if (!tk) return ACGPU_E_INVALID; // too many calls in flight: collect one first
     tk->profiled = want_profile != 0;
     tk->cap = cap;
+    tk->user_shard = sh;
+    tk->kname[0] = 0;
     uint64_t dummy = 0;
-    rc = match_all(a, *d, sh, record_kind, d_out, cap, &dummy, stream, nullptr, tk);
+    // enqueued without waiting: the AhoCorasick / WholeWord pipeline (one scan + ordering pass) and the LongestMatch walk
+    // pipeline (lengths, synchronisation points, chain count, prefix sum, emit: nothing of it needs the host).  The other
+    // families -- and LongestMatch over a dictionary with a selective suffix filter, whose sparse form falls back to the walk
+    // after looking at the match count -- run their call inside _begin: the ticket is complete when _begin returns.
+    if (t.mode == ACGPU_MODE_ALL || (t.mode == ACGPU_MODE_WHOLEWORD && t.fold_consistent)) {
+        tk->kind = 0;
+        rc = match_all(a, *d, sh, record_kind, d_out, cap, &dummy, stream, nullptr, tk);
+    } else if (t.mode == ACGPU_MODE_LONGEST && !(filter_is_selective(t) && tunables().force_kernel != 1)) {
+        tk->kind = 1;
+        rc = match_longest(a, *d, sh, record_kind, d_out, cap, &dummy, stream, nullptr, tk);
+    } else {
+        tk->kind = 2;
+        tk->sync_n = 0;
+        std::memset(&tk->sync_prof, 0, sizeof(tk->sync_prof));
+        tk->sync_rc = match_shard(a, *d, sh, record_kind, d_out, cap, &tk->sync_n, stream, want_profile ? &tk->sync_prof : nullptr);
+        if (tk->sync_rc != ACGPU_OK && tk->sync_rc != ACGPU_E_OVERFLOW) return tk->sync_rc;
+        tk->busy = true; // (complete: nothing in flight on the device, the stream rule does not apply to it)
+        *ticket = reinterpret_cast<acgpu_ticket *>(tk);
+        return ACGPU_OK;
+    }
     if (rc != ACGPU_OK) return rc;
     tk->busy = true;
     d->inflight++;
@@ -1470,13 +1518,19 @@ int acgpu_match_device_end(const acgpu_automaton *ca, acgpu_ticket *ticket, uint
     {
         std::lock_guard<std::mutex> lock(a->mu);
         if (!tk->busy) return ACGPU_E_INVALID;
+        if (tk->kind == 2) { // ran inside _begin
+            tk->busy = false;
+            *n_out = tk->sync_n;
+            if (prof) *prof = tk->sync_prof;
+            return tk->sync_rc;
+        }
         done = tk->done;
     }
     HIP_TRY(hipEventSynchronize(done)); // outside the lock: other calls may be enqueued meanwhile
     std::lock_guard<std::mutex> lock(a->mu);
     if (!tk->busy) return ACGPU_E_INVALID; // (collected by another thread meanwhile)
     DeviceState *d = reinterpret_cast<DeviceState *>(tk->owner);
-    if ((uint32_t)tk->h_count[1] != 0) { // a candidate slice / scratch slice was too small: redo with the fused kernel, one slice
+    if (tk->kind == 0 && (uint32_t)tk->h_count[1] != 0) { // a candidate slice / scratch slice was too small: redo with the fused kernel, one slice
         // (the redo shares the scratch with the tickets still in flight: same stream, so stream order keeps them apart)
         const int rc = match_all(a, *d, &tk->shard, tk->record_kind, tk->d_out, tk->cap, n_out, tk->stream, prof, nullptr, true);
         tk->busy = false;
@@ -1484,6 +1538,7 @@ int acgpu_match_device_end(const acgpu_automaton *ca, acgpu_ticket *ticket, uint
         return rc;
     }
     *n_out = *tk->h_count;
+    if (tk->kind == 1 && tk->user_shard) tk->user_shard->chain_exit = (int64_t)tk->h_count[2];
     tk->busy = false; // (whatever happens below, the ticket is collected)
     d->inflight--;
     if (prof) {

@@ -99,6 +99,8 @@ struct PermuteTail {
 // {n_records, redone = 0} into an acgpu_shard::d_result, in stream order (the families whose pipeline ends with a count
 // on the host)
 hipError_t launch_write_result(acgpu_device_result *d_result, uint64_t n_records, hipStream_t stream);
+hipError_t launch_publish_result(const unsigned long long *d_total, const unsigned long long *d_exit, unsigned long long *h_slot_dev,
+                                 acgpu_device_result *d_result, hipStream_t stream);
 
 // scratch (unordered) -> final records in reference order
 // (slots whose rank is ~0u are holes left by slot reservations and are skipped)

@@ -522,6 +522,27 @@ __global__ void k_write_result(acgpu_device_result *r, unsigned long long n) {
     r->reserved = 0;
 }
 
+// the end of a chain pipeline (LONGEST): record count and chain exit from device memory into the call's pinned host slot
+// {count, 0, exit} and, if wanted, the device result -- in stream order, no copy operations
+__global__ void k_publish_result(const unsigned long long *d_total, const unsigned long long *d_exit, unsigned long long *h_slot,
+                                 acgpu_device_result *r) {
+    const unsigned long long n = *d_total;
+    h_slot[1] = 0;
+    h_slot[2] = *d_exit;
+    h_slot[0] = n;
+    if (r) {
+        r->n_records = n;
+        r->redone = 0;
+        r->reserved = 0;
+    }
+}
+
+hipError_t launch_publish_result(const unsigned long long *d_total, const unsigned long long *d_exit, unsigned long long *h_slot_dev,
+                                 acgpu_device_result *d_result, hipStream_t stream) {
+    hipLaunchKernelGGL(k_publish_result, dim3(1), dim3(1), 0, stream, d_total, d_exit, h_slot_dev, d_result);
+    return hipGetLastError();
+}
+
 hipError_t launch_write_result(acgpu_device_result *d_result, uint64_t n_records, hipStream_t stream) {
     hipLaunchKernelGGL(k_write_result, dim3(1), dim3(1), 0, stream, d_result, (unsigned long long)n_records);
     return hipGetLastError();

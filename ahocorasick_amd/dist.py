@@ -200,9 +200,11 @@ class ShardedMatcher:
         # overlap: step() leaves its all-gather (world > 1) / its scan (world == 1) in flight and returns the PREVIOUS
         # step's result; the all-gather of step k then runs under the scan of step k+1
         self.overlap = bool(overlap)
-        # AhoCorasick and WholeWord (fold-consistent word-character tables) have the asynchronous form of the native call
+        # AhoCorasick and WholeWord (fold-consistent word-character tables) have the asynchronous form of the native call; so
+        # does LongestMatch where the chain entry is known when the scan is enqueued (one rank: it is the first unit)
         self.async_scan = scan_fn is None and (self.mode == MODE_ALL or (
-            self.mode == MODE_WHOLEWORD and bool(automaton.info()["fold_consistent"])))
+            self.mode == MODE_WHOLEWORD and bool(automaton.info()["fold_consistent"])) or (
+            self.mode == MODE_LONGEST and self.world == 1))
         self.scan_fn = scan_fn
         self._k = 0
         self._inflight = None   # the _Step a previous step() left for the next one (overlap)

@@ -137,8 +137,10 @@ class Automaton:
 
 
     def match_device_begin(self, d_hay_ptr, n_units, with_ids, d_out_ptr, cap, own=None, text_begin=True, text_end=True,
-                           stream=0, profile=False, d_result=None):
-        """acgpu_match_device_begin (AhoCorasick; WholeWord with fold-consistent tables): enqueue without waiting.  Returns (ticket, rc)."""
+                           stream=0, profile=False, d_result=None, chain_entry=None):
+        """acgpu_match_device_begin: enqueue without waiting (AhoCorasick, WholeWord with fold-consistent tables, the LongestMatch
+        walk pipeline; the other families run inside the call).  Returns (ticket, rc); the ticket keeps the acgpu_shard alive
+        (the library writes chain_exit into it when the ticket is collected)."""
         sh = N.Shard()
         sh.d_result = d_result
         sh.d_hay = d_hay_ptr
@@ -146,22 +148,36 @@ class Automaton:
         sh.own_begin, sh.own_end = (0, n_units) if own is None else own
         sh.text_begin = 1 if text_begin else 0
         sh.text_end = 1 if text_end else 0
-        sh.chain_entry = sh.own_begin
+        sh.chain_entry = sh.own_begin if chain_entry is None else chain_entry
+        sh.chain_exit = -1
         tk = ctypes.c_void_p()
         rc = N.lib().acgpu_match_device_begin(self._h, ctypes.byref(sh), N.REC_MAP if with_ids else N.REC_SET, d_out_ptr, cap,
                                               ctypes.c_void_p(stream), 1 if profile else 0, ctypes.byref(tk))
-        return tk, rc
+        return Ticket(tk, sh), rc
 
     def match_device_end(self, ticket, profile=False):
-        """acgpu_match_device_end: waits for that call only.  Returns (n_out, rc, profile_dict|None)."""
+        """acgpu_match_device_end: waits for that call only.  Returns (n_out, rc, profile_dict|None); ticket.chain_exit holds
+        the shard's chain exit afterwards."""
         prof = N.Profile() if profile else None
         n_out = ctypes.c_uint64(0)
-        rc = N.lib().acgpu_match_device_end(self._h, ticket, ctypes.byref(n_out), ctypes.byref(prof) if profile else None)
+        rc = N.lib().acgpu_match_device_end(self._h, ticket.handle, ctypes.byref(n_out), ctypes.byref(prof) if profile else None)
         pd = None
         if profile:
             pd = dict(scan_ms=prof.scan_ms, finalize_ms=prof.finalize_ms, total_ms=prof.total_ms,
                       scan_units=prof.scan_units, n_matches=prof.n_matches, scan_kernel=prof.scan_kernel.decode())
         return int(n_out.value), rc, pd
+
+
+class Ticket:
+    """One acgpu_match_device_begin call in flight: the native ticket and the acgpu_shard it was begun with."""
+
+    def __init__(self, handle, shard):
+        self.handle = handle
+        self.shard = shard
+
+    @property
+    def chain_exit(self):
+        return int(self.shard.chain_exit)
 
 
 class Stream:

@@ -150,6 +150,12 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     mb_per_s = total_units * 2 / (elapsed / args.steps) / 1e6
     kernel_ms = float(np.mean(scan_ms))
+    kernel_what = matcher.last_kernel
+    if cfg_name == "C4":
+        # LongestMatch: the walk kernel writes no record -- the records come out of the chain passes behind it -- so the
+        # algorithmic bytes (text in, records out) are divided by the SUM of the family's kernels (HIP events around all of them)
+        kernel_ms = float(np.mean(scan_ms)) + float(np.mean(fin_ms))
+        kernel_what = matcher.last_kernel + " + k_longest_sync + k_longest_chain_lds + k_scan_* + k_longest_emit_ends (whole pipeline)"
     alg_bytes = 2 * n_units + rec_bytes * n_matches_local  # per launch of the dominant kernel (one rank's shard)
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
 
@@ -185,13 +191,14 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
-            "kernel": matcher.last_kernel, "kernel_ms": round(kernel_ms, 4), "finalize_ms": round(float(np.mean(fin_ms)), 4),
+            "kernel": kernel_what, "kernel_ms": round(kernel_ms, 4), "scan_ms": round(float(np.mean(scan_ms)), 4),
+            "finalize_ms": round(float(np.mean(fin_ms)), 4),
             "algorithmic_bytes": alg_bytes,
         },
     }
 
     if multi:  # every rank's own dominant-kernel figures (the headline roofline object above is rank 0's)
-        mine = {"rank": rank, "device": torch.cuda.current_device(), "kernel": matcher.last_kernel, "kernel_ms": round(kernel_ms, 4),
+        mine = {"rank": rank, "device": torch.cuda.current_device(), "kernel": kernel_what, "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes": alg_bytes, "achieved": round(achieved, 2), "frac": round(achieved / HBM_PEAK_GBPS, 5),
                 "matches": n_matches_local, "host_syncs_per_step": matcher.host_syncs, "redone_steps": matcher.redone_steps}
         per_rank = [None] * world

@@ -210,11 +210,15 @@ int acgpu_match_device(const acgpu_automaton *a, acgpu_shard *shard, int record_
                        uint64_t *n_out, void *stream, acgpu_profile *prof);
 
 /*
- * Asynchronous form (ACGPU_MODE_ALL, and ACGPU_MODE_WHOLEWORD with a fold-consistent word-character table; the other
- * families end on the host: ACGPU_E_UNSUPPORTED): _begin enqueues the whole pipeline on `stream` and returns without waiting;
- * _end waits for that call only (an event, not the stream) and returns its count / timings.  Up to 4 calls may be in
- * flight per automaton and device.  Lets a host keep the GPU busy across calls: the next scan is queued while the
- * previous count travels back.  want_profile != 0 records the HIP events that _end turns into acgpu_profile.
+ * Asynchronous form: _begin enqueues the whole pipeline on `stream` and returns without waiting; _end waits for that call only
+ * (an event, not the stream) and returns its count / timings.  Up to 4 calls may be in flight per automaton and device.
+ * Lets a host keep the GPU busy across calls: the next scan is queued while the previous count travels back.
+ * want_profile != 0 records the HIP events that _end turns into acgpu_profile.
+ *  - Enqueued without any host round trip: ACGPU_MODE_ALL, ACGPU_MODE_WHOLEWORD (fold-consistent tables) and
+ *    ACGPU_MODE_LONGEST through its walk pipeline (shard->chain_entry is read at _begin; chain_exit is written to the
+ *    SAME acgpu_shard object when _end returns, so it must outlive the ticket).
+ *  - The other families (and LONGEST over a dictionary with a selective suffix filter, whose sparse form decides on the
+ *    host) run inside _begin: the ticket is complete when _begin returns and _end only hands the result over.
  *
  * STREAM RULE.  All calls on one automaton and device share that automaton's scratch pool; stream order is what keeps
  * them apart.  While tickets are in flight, EVERY call on that automaton and device -- another _begin, a synchronous

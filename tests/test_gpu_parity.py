@@ -709,12 +709,84 @@ def test_async_begin_end_matches_synchronous_call():
         n, rc, prof = a.match_device_end(tk, profile=True)
         assert rc == N.OK and n == len(w) and prof["scan_ms"] > 0
         assert (o[:n].cpu().numpy() == w).all()
-    # overflow is reported by _end with the exact count; LONGEST has no async form
+    # overflow is reported by _end with the exact count
     tk, rc = a.match_device_begin(d_hays[0].data_ptr(), hays[0].size, True, outs[0].data_ptr(), 5, stream=st)
     n, rc, _ = a.match_device_end(tk)
     assert rc == N.E_OVERFLOW and n == len(wants[0])
-    lo = Automaton(N.MODE_LONGEST, kws, True)
-    assert lo.match_device_begin(d_hays[0].data_ptr(), hays[0].size, True, outs[0].data_ptr(), cap)[1] == N.E_UNSUPPORTED
+
+
+def test_async_begin_end_for_the_chain_families():
+    """acgpu_match_device_begin/_end beyond AhoCorasick: the LongestMatch walk pipeline is enqueued without a host round trip
+    (count and chain exit arrive through the ticket: three calls in flight, shards chained through entry / exit, Set and Map
+    records, overflow); the other families -- and LongestMatch over a selective dictionary -- run inside _begin."""
+    import torch
+    from ahocorasick_amd.strings import Automaton as A
+    from oracle.oracle import FAM_SHORTEST, FAM_WWLONGEST
+    st = torch.cuda.current_stream().cuda_stream
+    kws = synth.random_keywords(32, 300, 2, 40, table=synth.ALPHA_LOWER[:2])
+    lo = A(N.MODE_LONGEST, kws, True)
+    assert lo.info()["tile_kernel"] == 0  # the walk pipeline
+    orc = Oracle(FAM_LONGEST, kws)
+    hays = [synth.haystack(140 + i, 300000 + 1111 * i, table=synth.ALPHA_LOWER[:2]) for i in range(3)]
+    d_hays = [torch.from_numpy(h.view(np.int16)).cuda() for h in hays]
+    wants = [orc.match(h) for h in hays]
+    cap = max(len(w) for w in wants) + 8
+    for with_ids in (False, True):
+        cols = 3 if with_ids else 2
+        outs = [torch.empty((cap, cols), dtype=torch.int32, device="cuda") for _ in hays]
+        tickets = []
+        for d, o, h in zip(d_hays, outs, hays):
+            tk, rc = lo.match_device_begin(d.data_ptr(), h.size, with_ids, o.data_ptr(), cap, stream=st, profile=True)
+            assert rc == N.OK
+            tickets.append(tk)
+        for tk, o, w, h in zip(tickets, outs, wants, hays):
+            n, rc, prof = lo.match_device_end(tk, profile=True)
+            assert rc == N.OK and n == len(w) and prof["scan_ms"] > 0 and prof["scan_kernel"].startswith("k_longest")
+            assert (o[:n].cpu().numpy() == w[:, :cols]).all()
+            assert tk.chain_exit >= h.size
+    # shards of one buffer: every ticket's chain exit is the next shard's entry
+    h, d, w = hays[0], d_hays[0], wants[0]
+    out = torch.empty((cap, 3), dtype=torch.int32, device="cuda")
+    parts, entry = [], 0
+    for lo_, hi_ in ((0, 100003), (100003, 100010), (100010, h.size)):
+        tk, rc = lo.match_device_begin(d.data_ptr(), h.size, True, out.data_ptr(), cap, own=(lo_, hi_), stream=st, chain_entry=max(entry, lo_))
+        assert rc == N.OK
+        n, rc, _ = lo.match_device_end(tk)
+        assert rc == N.OK
+        parts.append(out[:n].cpu().numpy())
+        entry = tk.chain_exit
+        assert entry >= hi_
+    assert (np.concatenate(parts) == w).all()
+    tk, rc = lo.match_device_begin(d.data_ptr(), h.size, True, out.data_ptr(), 5, stream=st)
+    n, rc, _ = lo.match_device_end(tk)
+    assert rc == N.E_OVERFLOW and n == len(w)
+    # a device result in stream order (what a multi-GPU driver gathers)
+    buf = torch.zeros(4 + cap * 2, dtype=torch.int32, device="cuda")
+    tk, rc = lo.match_device_begin(d.data_ptr(), h.size, False, buf.data_ptr() + 16, cap, stream=st, d_result=buf.data_ptr())
+    assert rc == N.OK
+    torch.cuda.current_stream().synchronize()
+    assert int(buf[:2].cpu().numpy().view(np.int64)[0]) == len(w)
+    assert lo.match_device_end(tk)[0] == len(w)
+    # families whose call runs inside _begin: same records as the synchronous call
+    kw2 = synth.random_keywords(34, 300, 2, 30, table=synth.ALPHA_LOWER[:3])
+    hay2 = synth.haystack(144, 100000, table=synth.ALPHA_LOWER[:3])
+    d2 = torch.from_numpy(hay2.view(np.int16)).cuda()
+    sh = A(N.MODE_SHORTEST, kw2, True)
+    want2 = Oracle(FAM_SHORTEST, kw2).match(hay2)
+    out2 = torch.empty((len(want2) + 8, 3), dtype=torch.int32, device="cuda")
+    tk, rc = sh.match_device_begin(d2.data_ptr(), hay2.size, True, out2.data_ptr(), len(want2) + 8, stream=st, profile=True)
+    assert rc == N.OK
+    n, rc, prof = sh.match_device_end(tk, profile=True)
+    assert rc == N.OK and n == len(want2) and (out2[:n].cpu().numpy() == want2).all() and prof["scan_ms"] > 0
+    sel = A(N.MODE_LONGEST, synth.random_keywords(11, 300, 4, 9), True)  # selective suffix filter: the sparse form, inside _begin
+    assert sel.info()["tile_kernel"] == 1
+    hay3 = synth.haystack(145, 200000)
+    want3 = Oracle(FAM_LONGEST, synth.random_keywords(11, 300, 4, 9)).match(hay3)
+    d3 = torch.from_numpy(hay3.view(np.int16)).cuda()
+    out3 = torch.empty((len(want3) + 8, 3), dtype=torch.int32, device="cuda")
+    tk, rc = sel.match_device_begin(d3.data_ptr(), hay3.size, True, out3.data_ptr(), len(want3) + 8, stream=st)
+    n, rc, _ = sel.match_device_end(tk)
+    assert rc == N.OK and n == len(want3) and (out3[:n].cpu().numpy() == want3).all()
 
 
 # ---- ShardedMatcher (ahocorasick_amd/dist.py) through the native scan: the ranks of one job emulated in one process ----
@@ -1396,7 +1468,8 @@ def test_wholeword_async_begin_end_pipelined_overflow_and_slice_redo():
         wc[ord(ch)] = 1
     a3 = Automaton(N.MODE_WHOLEWORD, ["A", "AB", "x"], False, lower=LOWER, word_chars=wc)
     assert a3.info()["fold_consistent"] == 0
-    assert a3.match_device_begin(d_hay.data_ptr(), 4096, True, out.data_ptr(), 16, stream=st)[1] == N.E_UNSUPPORTED
+    tk, rc = a3.match_device_begin(d_hay.data_ptr(), 4096, True, out.data_ptr(), 16, stream=st)  # (runs inside _begin)
+    assert rc == N.OK and a3.match_device_end(tk)[1] in (N.OK, N.E_OVERFLOW)
 
 
 def test_chain_marking_in_one_pass_equals_pointer_doubling():
