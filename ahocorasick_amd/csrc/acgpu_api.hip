@@ -3,12 +3,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <map>
 #include <memory>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "acgpu_internal.h"
@@ -83,6 +85,12 @@ struct DeviceState {
     // scratch pool (one in-flight match per automaton and device)
     DevBuf counter, chunk_counts, offsets, scan_tmp, scratch, chain, lenbuf, statebuf;
     DevBuf stage_hay, stage_out; // acgpu_match_u16 staging
+    // pipelined host entry: pinned staging ring (one slot per chunk in flight), its copy stream, one event per chunk
+    static constexpr int kPinSlots = 8;
+    void *pin[kPinSlots] = {nullptr};
+    size_t pin_bytes = 0;
+    hipStream_t copy_stream = nullptr;
+    std::vector<hipEvent_t> chunk_ev;
     DevBuf short_recs, short_nxt, short_tmp, short_mark; // SHORTEST: all-matches list + selection scratch
     DevBuf blockmax;                                     // LONGEST: farthest landing per 64 positions
     DevBuf lenbig, todo;                                 // LONGEST: escaped lengths; root-table form: flagged chunks
@@ -106,6 +114,9 @@ struct DeviceState {
         short_recs.release(); short_nxt.release(); short_tmp.release(); short_mark.release();
         wwl_rs.release(); wwl_mend.release(); wwl_mid.release(); wwl_sel.release(); wwl_stop.release(); wwl_nxt0.release(); blockmax.release(); lenbig.release(); todo.release(); chainbits.release(); cands.release(); region_cands.release();
         if (h_counter) (void)hipHostFree(h_counter);
+        for (auto &q : pin) if (q) (void)hipHostFree(q);
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
+        for (auto &e : chunk_ev) if (e) (void)hipEventDestroy(e);
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         for (auto &tk : tickets) {
             for (auto &e : tk.ev) if (e) (void)hipEventDestroy(e);
@@ -1555,6 +1566,138 @@ int acgpu_match_device_end(const acgpu_automaton *ca, acgpu_ticket *ticket, uint
     return *n_out > tk->cap ? ACGPU_E_OVERFLOW : ACGPU_OK;
 }
 
+namespace {
+
+// acgpu_match_u16 on a long haystack, pipelined: the text goes to the device in chunks -- worker threads copy the caller's
+// (pageable) memory into a ring of pinned staging buffers and enqueue the DMA on a copy stream -- while the chunks that have
+// arrived are scanned as shards of the device buffer (own range = the chunk, halos = its neighbours already / also there;
+// the chain families hand their entry on from shard to shard).  The scans are a fraction of the transfer time, so the call
+// runs at the rate of the slower of the host copy and the link instead of copy + scan + copy back in sequence.
+constexpr uint64_t kHostChunkUnits = 1ull << 24; // 32 MiB per chunk
+
+int match_u16_pipelined(acgpu_automaton *a, DeviceState &d, const uint16_t *haystack, uint64_t n_units, int record_kind, void *out,
+                        uint64_t cap, uint64_t *n_out) {
+    const HostTables &t = a->t;
+    const uint64_t C = kHostChunkUnits;
+    const uint32_t n_chunks = (uint32_t)((n_units + C - 1) / C);
+    int rc;
+    if ((rc = d.stage_hay.ensure(n_units * 2 + 16))) return rc;
+    if ((rc = d.stage_out.ensure(cap * (uint64_t)record_kind + 16))) return rc;
+    if (!d.copy_stream) HIP_TRY(hipStreamCreateWithFlags(&d.copy_stream, hipStreamNonBlocking));
+    if (d.pin_bytes < C * 2) {
+        for (auto &q : d.pin) {
+            if (q) (void)hipHostFree(q);
+            q = nullptr;
+        }
+        d.pin_bytes = 0;
+        for (auto &q : d.pin) HIP_TRY(hipHostMalloc(&q, C * 2, hipHostMallocDefault));
+        d.pin_bytes = C * 2;
+    }
+    while (d.chunk_ev.size() < n_chunks) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        d.chunk_ev.push_back(e);
+    }
+    // producers: chunk k -> pinned slot k % kPinSlots (free once chunk k - kPinSlots has been copied to the device) -> DMA
+    const int n_workers = (int)std::min<uint32_t>({(uint32_t)DeviceState::kPinSlots - 2, n_chunks, std::max(2u, std::thread::hardware_concurrency() / 2)});
+    std::atomic<uint32_t> next_chunk{0};
+    std::atomic<int> worker_rc{ACGPU_OK};
+    std::vector<std::atomic<int>> ready(n_chunks); // 1: the chunk's DMA and event are enqueued
+    for (auto &r : ready) r.store(0, std::memory_order_relaxed);
+    const int dev = d.device;
+    auto worker = [&]() {
+        if (hipSetDevice(dev) != hipSuccess) {
+            worker_rc.store(ACGPU_E_HIP);
+            return;
+        }
+        for (;;) {
+            const uint32_t k = next_chunk.fetch_add(1);
+            if (k >= n_chunks || worker_rc.load() != ACGPU_OK) return;
+            const uint64_t lo = (uint64_t)k * C, len = std::min<uint64_t>(C, n_units - lo);
+            const int slot = (int)(k % DeviceState::kPinSlots);
+            if (k >= (uint32_t)DeviceState::kPinSlots) { // the slot's previous chunk must have left it
+                while (!ready[k - DeviceState::kPinSlots].load(std::memory_order_acquire)) {
+                    if (worker_rc.load() != ACGPU_OK) return;
+                    std::this_thread::yield();
+                }
+                if (hipEventSynchronize(d.chunk_ev[k - DeviceState::kPinSlots]) != hipSuccess) {
+                    worker_rc.store(ACGPU_E_HIP);
+                    return;
+                }
+            }
+            std::memcpy(d.pin[slot], haystack + lo, len * 2);
+            if (hipMemcpyAsync((char *)d.stage_hay.p + lo * 2, d.pin[slot], len * 2, hipMemcpyHostToDevice, d.copy_stream) != hipSuccess ||
+                hipEventRecord(d.chunk_ev[k], d.copy_stream) != hipSuccess) {
+                worker_rc.store(ACGPU_E_HIP);
+                return;
+            }
+            ready[k].store(1, std::memory_order_release);
+        }
+    };
+    std::vector<std::thread> pool;
+    try {
+        for (int i = 0; i < n_workers; ++i) pool.emplace_back(worker);
+    } catch (...) {
+        worker_rc.store(ACGPU_E_NOMEM);
+    }
+    auto join_all = [&]() {
+        for (auto &th : pool) if (th.joinable()) th.join();
+    };
+    // consumer: shard k once the chunks its halos reach into have arrived
+    const uint64_t left = (t.mode == ACGPU_MODE_WHOLEWORD || t.mode == ACGPU_MODE_WWLONGEST) ? 1 : (t.mode == ACGPU_MODE_LONGEST ? 0 : (t.max_len ? t.max_len - 1 : 0));
+    const uint64_t right = (t.mode == ACGPU_MODE_WHOLEWORD || t.mode == ACGPU_MODE_WWLONGEST) ? (uint64_t)t.max_len + 1
+                           : (t.mode == ACGPU_MODE_LONGEST ? (t.max_len ? t.max_len - 1 : 0) : 0);
+    (void)left; // (the chunks before a shard have always arrived)
+    uint64_t total = 0;
+    int64_t chain = 0;
+    uint32_t waited = 0; // chunks whose arrival the compute stream already waits for
+    int result = ACGPU_OK;
+    for (uint32_t k = 0; k < n_chunks && result == ACGPU_OK; ++k) {
+        const uint64_t lo = (uint64_t)k * C, hi = std::min<uint64_t>(n_units, lo + C);
+        const uint32_t need = (uint32_t)std::min<uint64_t>(n_chunks, (std::min<uint64_t>(n_units, hi + right) + C - 1) / C); // chunks [0, need)
+        for (; waited < need && result == ACGPU_OK; ++waited) {
+            while (!ready[waited].load(std::memory_order_acquire)) {
+                if (worker_rc.load() != ACGPU_OK) { result = worker_rc.load(); break; }
+                std::this_thread::yield();
+            }
+            if (result == ACGPU_OK && hipStreamWaitEvent(nullptr, d.chunk_ev[waited], 0) != hipSuccess) result = ACGPU_E_HIP;
+        }
+        if (result != ACGPU_OK) break;
+        acgpu_shard sh{};
+        sh.d_hay = (const uint16_t *)d.stage_hay.p;
+        sh.n_units = std::min<uint64_t>(n_units, (uint64_t)need * C); // what has arrived
+        sh.own_begin = lo;
+        sh.own_end = hi;
+        sh.text_begin = 1;
+        sh.text_end = sh.n_units == n_units ? 1 : 0;
+        sh.chain_entry = t.mode == ACGPU_MODE_SHORTEST ? chain : std::max<int64_t>(chain, (int64_t)lo);
+        uint64_t n_k = 0;
+        const uint64_t room = total < cap ? cap - total : 0;
+        rc = match_shard(a, d, &sh, record_kind, (char *)d.stage_out.p + std::min(total, cap) * (uint64_t)record_kind, room, &n_k, nullptr, nullptr);
+        if (rc != ACGPU_OK && rc != ACGPU_E_OVERFLOW) {
+            result = rc;
+            break;
+        }
+        total += n_k; // (beyond cap: the remaining shards only count)
+        if (t.mode == ACGPU_MODE_SHORTEST) chain = n_k ? sh.chain_exit : chain;
+        else chain = sh.chain_exit;
+    }
+    if (result != ACGPU_OK) worker_rc.store(result); // (stops the producers)
+    join_all();
+    if (result == ACGPU_OK && worker_rc.load() != ACGPU_OK) result = worker_rc.load();
+    (void)hipStreamSynchronize(d.copy_stream); // nothing of this call stays in flight
+    if (result != ACGPU_OK) {
+        if (result == ACGPU_E_HIP) g_last_hip_error = (int)hipGetLastError();
+        return result;
+    }
+    *n_out = total;
+    if (total > cap) return ACGPU_E_OVERFLOW;
+    if (total) HIP_TRY(hipMemcpy(out, d.stage_out.p, total * (uint64_t)record_kind, hipMemcpyDeviceToHost));
+    return ACGPU_OK;
+}
+
+} // namespace
+
 int acgpu_match_u16(const acgpu_automaton *ca, const uint16_t *haystack, uint64_t n_units, int record_kind, void *out,
                     uint64_t cap, uint64_t *n_out) {
     if (!ca || !n_out || (n_units && !haystack) || (cap && !out)) return ACGPU_E_INVALID;
@@ -1565,6 +1708,14 @@ int acgpu_match_u16(const acgpu_automaton *ca, const uint16_t *haystack, uint64_
     DeviceState *d = nullptr;
     int rc = device_for_call(a, &d);
     if (rc) return rc;
+    // long haystacks of the families whose shards chain: the pipelined form (the loops that only exist as a sequential kernel
+    // over the whole text -- WholeWord / WholeWordLongestSet with a fold-inconsistent table -- take the plain one)
+    const HostTables &t = a->t;
+    const bool sequential_only = (t.mode == ACGPU_MODE_WHOLEWORD && !t.fold_consistent) ||
+                                 (t.mode == ACGPU_MODE_WWLONGEST && !t.fold_consistent && record_kind == ACGPU_REC_SET);
+    if (n_units >= 2 * kHostChunkUnits && !sequential_only && d->inflight == 0 && !(tunables().tile_debug & 33554432) &&
+        (uint64_t)t.max_len + 2 < kHostChunkUnits)
+        return match_u16_pipelined(a, *d, haystack, n_units, record_kind, out, cap, n_out);
     if ((rc = d->stage_hay.ensure(n_units * 2 + 16))) return rc;
     if ((rc = d->stage_out.ensure(cap * (uint64_t)record_kind + 16))) return rc;
     if (n_units) HIP_TRY(hipMemcpy(d->stage_hay.p, haystack, n_units * 2, hipMemcpyHostToDevice));

@@ -789,6 +789,50 @@ def test_async_begin_end_for_the_chain_families():
     assert rc == N.OK and n == len(want3) and (out3[:n].cpu().numpy() == want3).all()
 
 
+@pytest.mark.parametrize("family", ["ac", "wholeword", "longest", "shortest", "wwlongest"])
+def test_host_entry_pipelined_over_chunks_equals_the_oracle(family):
+    """acgpu_match_u16 -- what StringSet/StringMap.match(String, ...) binds -- on a haystack of several 2^24-unit chunks: the
+    text travels through the pinned staging ring while the chunks that have arrived are scanned as shards (halos, chain entry
+    handed from shard to shard); records and the overflow protocol as for the plain call."""
+    from oracle.oracle import FAM_SHORTEST, FAM_WWLONGEST
+    n = (1 << 25) + (1 << 24) + 12345  # four chunks, the last one short
+    if family == "ac":
+        kws = synth.random_keywords(33, 2000, 3, 11, table=synth.ALPHA_LOWER[:12])
+        hay = synth.haystack(401, n, table=synth.ALPHA_LOWER[:12])
+        hay[(1 << 24) - 5:(1 << 24) + 6] = np.concatenate([kws[0], kws[1], kws[2]])[:11]  # matches across a chunk boundary
+        auto, orc = Automaton(N.MODE_ALL, kws, True), Oracle(FAM_AC, kws)
+        want = oracle_parallel(orc, hay, "ac", max(len(k) for k in kws), cap_per_unit=0.05)
+    elif family == "wholeword":
+        table = np.array([ord(c) for c in "abcdE -,"] + [0x00E9, 0x00C9], dtype=np.uint16)
+        kws = synth.random_keywords(31, 300, 1, 6, table=table[:5])
+        hay = synth.haystack(402, n, table=table)
+        auto = Automaton(N.MODE_WHOLEWORD, kws, False, word_chars=WORD)
+        orc = Oracle(FAM_WHOLEWORD, kws, case_sensitive=False, lower=LOWER, word_chars=WORD)
+        want = oracle_parallel(orc, hay, "wholeword", max(len(k) for k in kws), cap_per_unit=0.2)
+    elif family == "longest":
+        kws = synth.random_keywords(32, 300, 2, 40, table=synth.ALPHA_LOWER[:2])
+        hay = synth.haystack(403, n, table=synth.ALPHA_LOWER[:2])
+        auto, orc = Automaton(N.MODE_LONGEST, kws, True), Oracle(FAM_LONGEST, kws)
+        want = orc.match(hay, cap=n // 2)
+    elif family == "shortest":
+        kws = synth.random_keywords(34, 300, 2, 30, table=synth.ALPHA_LOWER[:3])
+        hay = synth.haystack(404, n, table=synth.ALPHA_LOWER[:3])
+        auto, orc = Automaton(N.MODE_SHORTEST, kws, True), Oracle(FAM_SHORTEST, kws)
+        want = orc.match(hay, cap=n // 2)
+    else:
+        kws, hay = _wwl_case(405, n)
+        auto = Automaton(N.MODE_WWLONGEST, kws, False, word_chars=WORD)
+        want = Oracle(FAM_WWLONGEST, kws, case_sensitive=False, lower=LOWER, word_chars=WORD).match(hay, cap=n // 4)
+    assert len(want) > 1000
+    got = auto.match_host(hay, True, cap=len(want) + 16)
+    assert got.shape == want.shape and (got == want).all()
+    got2 = auto.match_host(hay, False, cap=1000)  # too small: the call reports the capacity to retry with, and the retry delivers
+    assert got2.shape == (len(want), 2) and (got2 == want[:, :2]).all()
+    N.set_tunable("tile_debug", 33554432)  # the plain form: one copy, one scan
+    got3 = auto.match_host(hay, True, cap=len(want) + 16)
+    assert (got3 == want).all()
+
+
 # ---- ShardedMatcher (ahocorasick_amd/dist.py) through the native scan: the ranks of one job emulated in one process ----
 
 def _emulated_ranks(auto, whole, world, chain_window=4096):
