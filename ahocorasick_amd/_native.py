@@ -48,7 +48,7 @@ class Profile(ctypes.Structure):
 
 
 # every symbol include/acgpu.h declares
-SYMBOLS = ["acgpu_build", "acgpu_free", "acgpu_get_info", "acgpu_match_u16", "acgpu_match_device",
+SYMBOLS = ["acgpu_build", "acgpu_free", "acgpu_get_info", "acgpu_match_u16", "acgpu_match_batch_u16", "acgpu_match_device",
            "acgpu_match_device_begin", "acgpu_match_device_end", "acgpu_synth_fill", "acgpu_stream_probe",
            "acgpu_set_tunable", "acgpu_strerror", "acgpu_last_hip_error", "acgpu_abi_version", "acgpu_debug_tables",
            "acgpu_debug_wordhash", "acgpu_stream_open", "acgpu_stream_feed", "acgpu_stream_close"]
@@ -80,6 +80,8 @@ def lib():
         L.acgpu_get_info.argtypes = [vp, ctypes.POINTER(Info)]
         L.acgpu_match_u16.restype = ci
         L.acgpu_match_u16.argtypes = [vp, vp, u64, ci, vp, u64, ctypes.POINTER(u64)]
+        L.acgpu_match_batch_u16.restype = ci
+        L.acgpu_match_batch_u16.argtypes = [vp, vp, vp, u32, ci, vp, u64, ctypes.POINTER(u64)]
         L.acgpu_match_device.restype = ci
         L.acgpu_match_device.argtypes = [vp, ctypes.POINTER(Shard), ci, vp, u64, ctypes.POINTER(u64), vp,
                                          ctypes.POINTER(Profile)]

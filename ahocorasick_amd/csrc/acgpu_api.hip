@@ -85,6 +85,10 @@ struct DeviceState {
     // scratch pool (one in-flight match per automaton and device)
     DevBuf counter, chunk_counts, offsets, scan_tmp, scratch, chain, lenbuf, statebuf;
     DevBuf stage_hay, stage_out; // acgpu_match_u16 staging
+    // batch entry: pinned concatenation + offsets, device offsets, tagged records
+    void *batch_pin = nullptr;
+    size_t batch_pin_bytes = 0;
+    DevBuf batch_off, batch_out;
     // pipelined host entry: pinned staging ring (one slot per chunk in flight), its copy stream, one event per chunk
     static constexpr int kPinSlots = 8;
     void *pin[kPinSlots] = {nullptr};
@@ -115,6 +119,8 @@ struct DeviceState {
         wwl_rs.release(); wwl_mend.release(); wwl_mid.release(); wwl_sel.release(); wwl_stop.release(); wwl_nxt0.release(); blockmax.release(); lenbig.release(); todo.release(); chainbits.release(); cands.release(); region_cands.release();
         if (h_counter) (void)hipHostFree(h_counter);
         for (auto &q : pin) if (q) (void)hipHostFree(q);
+        if (batch_pin) (void)hipHostFree(batch_pin);
+        batch_off.release(); batch_out.release();
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
         for (auto &e : chunk_ev) if (e) (void)hipEventDestroy(e);
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
@@ -1730,6 +1736,100 @@ int acgpu_match_u16(const acgpu_automaton *ca, const uint16_t *haystack, uint64_
     rc = match_shard(a, *d, &sh, record_kind, d->stage_out.p, cap, n_out, nullptr, nullptr);
     if (rc != ACGPU_OK) return rc;
     if (*n_out) HIP_TRY(hipMemcpy(out, d->stage_out.p, *n_out * (uint64_t)record_kind, hipMemcpyDeviceToHost));
+    return ACGPU_OK;
+}
+
+int acgpu_match_batch_u16(const acgpu_automaton *ca, const uint16_t *units, const uint64_t *offsets, uint32_t n_haystacks,
+                          int record_kind, void *out, uint64_t cap, uint64_t *n_out) {
+    if (!ca || !n_out || !offsets || (cap && !out)) return ACGPU_E_INVALID;
+    if (record_kind != ACGPU_REC_SET && record_kind != ACGPU_REC_MAP) return ACGPU_E_INVALID;
+    *n_out = 0;
+    if (n_haystacks == 0) return ACGPU_OK;
+    for (uint32_t i = 0; i < n_haystacks; i++)
+        if (offsets[i] > offsets[i + 1]) return ACGPU_E_INVALID;
+    const uint64_t total = offsets[n_haystacks] - offsets[0];
+    if (total && !units) return ACGPU_E_INVALID;
+    const uint64_t cat = total + n_haystacks; // one separator behind every haystack
+    if (cat >= (1ull << 31)) return ACGPU_E_INVALID;
+    acgpu_automaton *a = const_cast<acgpu_automaton *>(ca);
+    const HostTables &t = a->t;
+    const size_t out_rec = (size_t)record_kind + 4;
+    // no unit can stand between two haystacks (every one of the 65536 is in use), or a loop that only exists as a sequential
+    // kernel over one whole text: one call per haystack
+    const bool sequential_only = (t.mode == ACGPU_MODE_WHOLEWORD && !t.fold_consistent) ||
+                                 (t.mode == ACGPU_MODE_WWLONGEST && !t.fold_consistent && record_kind == ACGPU_REC_SET);
+    if (t.sep_unit < 0 || sequential_only) {
+        std::vector<int32_t> tmp;
+        uint64_t n = 0;
+        for (uint32_t i = 0; i < n_haystacks; i++) {
+            const uint64_t len = offsets[i + 1] - offsets[i];
+            uint64_t got = 0, room = cap > n ? cap - n : 0;
+            try {
+                tmp.resize(std::max<size_t>(room * (record_kind / 4), 4));
+            } catch (...) {
+                return ACGPU_E_NOMEM;
+            }
+            const int rc = acgpu_match_u16(ca, units + offsets[i], len, record_kind, tmp.data(), room, &got);
+            if (rc != ACGPU_OK && rc != ACGPU_E_OVERFLOW) return rc;
+            if (rc == ACGPU_OK) {
+                const int W = record_kind / 4;
+                for (uint64_t r = 0; r < got; r++) {
+                    int32_t *o = (int32_t *)((char *)out + (n + r) * out_rec);
+                    o[0] = (int32_t)i;
+                    for (int w = 0; w < W; w++) o[1 + w] = tmp[r * W + w];
+                }
+            }
+            n += got;
+        }
+        *n_out = n;
+        return n > cap ? ACGPU_E_OVERFLOW : ACGPU_OK;
+    }
+    std::lock_guard<std::mutex> lock(a->mu); // staging buffers are part of the per-device scratch pool
+    DeviceState *d = nullptr;
+    int rc = device_for_call(a, &d);
+    if (rc) return rc;
+    if (d->inflight > 0) return ACGPU_E_INVALID; // (the NULL stream: see the stream rule)
+    const size_t off_bytes = ((size_t)n_haystacks + 1) * 4, pin_need = cat * 2 + 64 + off_bytes;
+    if (d->batch_pin_bytes < pin_need) {
+        if (d->batch_pin) (void)hipHostFree(d->batch_pin);
+        d->batch_pin = nullptr;
+        d->batch_pin_bytes = 0;
+        HIP_TRY(hipHostMalloc(&d->batch_pin, pin_need + pin_need / 4, hipHostMallocDefault));
+        d->batch_pin_bytes = pin_need + pin_need / 4;
+    }
+    uint16_t *h_cat = (uint16_t *)d->batch_pin;
+    uint32_t *h_off = (uint32_t *)((char *)d->batch_pin + ((cat * 2 + 63) & ~(size_t)63));
+    {
+        uint64_t at = 0;
+        for (uint32_t i = 0; i < n_haystacks; i++) {
+            const uint64_t len = offsets[i + 1] - offsets[i];
+            h_off[i] = (uint32_t)at;
+            if (len) std::memcpy(h_cat + at, units + offsets[i], len * 2);
+            at += len;
+            h_cat[at++] = (uint16_t)t.sep_unit;
+        }
+        h_off[n_haystacks] = (uint32_t)at;
+    }
+    if ((rc = d->stage_hay.ensure(cat * 2 + 16))) return rc;
+    if ((rc = d->stage_out.ensure(cap * (uint64_t)record_kind + 16))) return rc;
+    if ((rc = d->batch_off.ensure(off_bytes + 16))) return rc;
+    if ((rc = d->batch_out.ensure(cap * out_rec + 16))) return rc;
+    HIP_TRY(hipMemcpyAsync(d->stage_hay.p, h_cat, cat * 2, hipMemcpyHostToDevice, nullptr));
+    HIP_TRY(hipMemcpyAsync(d->batch_off.p, h_off, off_bytes, hipMemcpyHostToDevice, nullptr));
+    acgpu_shard sh{};
+    sh.d_hay = (const uint16_t *)d->stage_hay.p;
+    sh.n_units = cat;
+    sh.own_begin = 0;
+    sh.own_end = cat;
+    sh.text_begin = 1;
+    sh.text_end = 1;
+    sh.chain_entry = 0;
+    rc = match_shard(a, *d, &sh, record_kind, d->stage_out.p, cap, n_out, nullptr, nullptr);
+    if (rc != ACGPU_OK) return rc; // ACGPU_E_OVERFLOW: *n_out is the capacity to retry with
+    if (*n_out) {
+        HIP_TRY(launch_batch_tag(d->stage_out.p, *n_out, record_kind, (const uint32_t *)d->batch_off.p, n_haystacks, d->batch_out.p, nullptr));
+        HIP_TRY(hipMemcpy(out, d->batch_out.p, *n_out * out_rec, hipMemcpyDeviceToHost));
+    }
     return ACGPU_OK;
 }
 

@@ -129,6 +129,20 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
     t.n_states = N;
     t.n_kw = n_terminal;
     t.n_edges = N - 1;
+    // a unit that can stand between two haystacks of a batch (acgpu_match_batch_u16): its folded form occurs in no keyword and
+    // -- word matchers -- neither it nor its folded form is a word character, so no match, word or walk reaches across it
+    {
+        std::vector<uint8_t> in_kw(65536, 0);
+        for (uint32_t i = 1; i < N; i++) in_kw[nodes[i].unit] = 1;
+        t.sep_unit = -1;
+        for (int32_t u = 0xffff; u >= 0; --u) { // (from the top: U+FFFF is a noncharacter)
+            const uint16_t f = t.lower[u];
+            if (in_kw[f] || in_kw[u]) continue;
+            if (word_mode && (wordchar_tbl[u] || wordchar_tbl[f])) continue;
+            t.sep_unit = u;
+            break;
+        }
+    }
 
     // ---- 2. children lists (CSR by insertion id), sorted by unit for a deterministic BFS ----
     std::vector<uint32_t> child_begin(N + 1, 0);

@@ -100,6 +100,7 @@ struct HostTables {
     bool cs = true;
     uint32_t n_states = 1, n_cls = 1, n_kw = 0, min_len = 0, max_len = 0;
     uint32_t first_out = 1;
+    int32_t sep_unit = -1; // a unit no match, word or walk reaches across (batches of haystacks); -1: every unit is in use
     // character classes: class 0 = unit occurs in no keyword.  range_cls (case-sensitive only):
     // class = unit - cls_base + 1 for unit in [cls_base, cls_base + cls_span), computed arithmetically.
     bool range_cls = false;

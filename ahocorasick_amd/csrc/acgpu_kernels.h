@@ -99,6 +99,8 @@ struct PermuteTail {
 // {n_records, redone = 0} into an acgpu_shard::d_result, in stream order (the families whose pipeline ends with a count
 // on the host)
 hipError_t launch_write_result(acgpu_device_result *d_result, uint64_t n_records, hipStream_t stream);
+hipError_t launch_batch_tag(const void *d_recs, uint64_t n, int record_kind, const uint32_t *d_cat_off, uint32_t n_hay, void *d_out,
+                            hipStream_t stream);
 hipError_t launch_publish_result(const unsigned long long *d_total, const unsigned long long *d_exit, unsigned long long *h_slot_dev,
                                  acgpu_device_result *d_result, hipStream_t stream);
 

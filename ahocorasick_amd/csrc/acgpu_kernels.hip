@@ -543,6 +543,39 @@ hipError_t launch_publish_result(const unsigned long long *d_total, const unsign
     return hipGetLastError();
 }
 
+// acgpu_match_batch_u16: records of the scan over the concatenation -> records tagged with their haystack.  cat_off[i] = first
+// unit of haystack i in the concatenation (one separator unit behind every haystack), cat_off[n_hay] = its length.
+template <int REC>
+__global__ __launch_bounds__(256) void k_batch_tag(const int32_t *recs, uint64_t n, const uint32_t *cat_off, uint32_t n_hay, int32_t *out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    constexpr int W = REC / 4;
+    const int32_t start = recs[i * W], end = recs[i * W + 1];
+    uint32_t lo = 0, hi = n_hay; // the last haystack that begins at or before start
+    while (hi - lo > 1) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (cat_off[mid] <= (uint32_t)start) lo = mid;
+        else hi = mid;
+    }
+    const int32_t base = (int32_t)cat_off[lo];
+    int32_t *o = out + i * (W + 1);
+    o[0] = (int32_t)lo;
+    o[1] = start - base;
+    o[2] = end - base;
+    if (W == 3) o[3] = recs[i * W + 2];
+}
+
+hipError_t launch_batch_tag(const void *d_recs, uint64_t n, int record_kind, const uint32_t *d_cat_off, uint32_t n_hay, void *d_out,
+                            hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (record_kind == ACGPU_REC_SET)
+        hipLaunchKernelGGL(k_batch_tag<ACGPU_REC_SET>, grid, block, 0, stream, (const int32_t *)d_recs, n, d_cat_off, n_hay, (int32_t *)d_out);
+    else
+        hipLaunchKernelGGL(k_batch_tag<ACGPU_REC_MAP>, grid, block, 0, stream, (const int32_t *)d_recs, n, d_cat_off, n_hay, (int32_t *)d_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_write_result(acgpu_device_result *d_result, uint64_t n_records, hipStream_t stream) {
     hipLaunchKernelGGL(k_write_result, dim3(1), dim3(1), 0, stream, d_result, (unsigned long long)n_records);
     return hipGetLastError();

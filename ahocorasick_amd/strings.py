@@ -112,6 +112,24 @@ class Automaton:
             N.check(rc, "acgpu_match_u16")
             return out[:n_out.value]
 
+    def match_batch(self, haystacks, with_ids, cap=None):
+        """acgpu_match_batch_u16: many short haystacks (str or uint16 arrays) in one call -> (n, 3|4) int32 array of
+        (haystack index, start, end[, keyword index]) records, haystack by haystack in reference call order."""
+        units, off = _pack(haystacks)
+        kind = N.REC_MAP if with_ids else N.REC_SET
+        cols = kind // 4 + 1
+        if cap is None:
+            cap = max(4096, int(off[-1]) // 16)
+        while True:
+            out = np.empty((cap, cols), dtype=np.int32)
+            n_out = ctypes.c_uint64(0)
+            rc = N.lib().acgpu_match_batch_u16(self._h, _vp(units), _vp(off), len(off) - 1, kind, _vp(out), cap, ctypes.byref(n_out))
+            if rc == N.E_OVERFLOW:
+                cap = int(n_out.value)
+                continue
+            N.check(rc, "acgpu_match_batch_u16")
+            return out[:n_out.value]
+
     def match_device(self, d_hay_ptr, n_units, with_ids, d_out_ptr, cap, own=None, text_begin=True, text_end=True,
                      chain_entry=None, stream=0, profile=False, d_result=None):
         """acgpu_match_device on raw device pointers.  Returns (n_out, rc, profile_dict|None, chain_exit)."""
@@ -280,6 +298,15 @@ class StringSet:
         """Convenience (not in the reference): the (n,2) int32 array of (start, end) records."""
         return self._auto.match_host(utf16(haystack), with_ids=False)
 
+    def match_batch(self, haystacks, listener):
+        """Not in the reference: match(haystack, listener) for every haystack of a list in ONE device call (short inputs: a
+        call has tens of microseconds of fixed cost).  A listener call that returns False ends THAT haystack's matches."""
+        fn = _listener_fn(listener)
+        skip = -1
+        for h, s, e in self._auto.match_batch(haystacks, with_ids=False).tolist():
+            if h != skip and not fn(haystacks[h], s, e):
+                skip = h
+
     @property
     def automaton(self):
         return self._auto
@@ -330,6 +357,16 @@ class StringMap:
     def find_all(self, haystack):
         """Convenience (not in the reference): the (n,3) int32 array of (start, end, keyword_index) records."""
         return self._auto.match_host(utf16(haystack), with_ids=True)
+
+    def match_batch(self, haystacks, listener):
+        """Not in the reference: match(haystack, listener) for every haystack of a list in ONE device call (see
+        StringSet.match_batch)."""
+        fn = _listener_fn(listener)
+        vals = self._values
+        skip = -1
+        for h, s, e, k in self._auto.match_batch(haystacks, with_ids=True).tolist():
+            if h != skip and not fn(haystacks[h], s, e, vals[k]):
+                skip = h
 
     @property
     def automaton(self):

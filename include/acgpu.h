@@ -152,6 +152,27 @@ int acgpu_match_u16(const acgpu_automaton *a, const uint16_t *haystack, uint64_t
                     uint64_t cap, uint64_t *n_out);
 
 /*
+ * Many short haystacks in ONE call (the reference publishes one workload: a paragraph against a 235 k-word dictionary at
+ * 3.6 us per match() call, R/README.md:130-148; a call here has tens of microseconds of fixed cost, so short inputs are
+ * batched): haystack i is units[offsets[i] .. offsets[i+1]).  The haystacks are scanned as one text with a separator unit
+ * between them that no keyword contains (word matchers: and that is no word character), so every haystack's matches are
+ * exactly what match(String) reports for it alone -- any family.  Records carry the haystack index in front:
+ *   ACGPU_REC_SET -> acgpu_batch_set_match {haystack, start, end}, ACGPU_REC_MAP -> acgpu_batch_map_match {haystack, start,
+ *   end, keyword_id}; positions are relative to their haystack; order: haystack ascending, inside a haystack the
+ *   reference's listener-call order.  The facade calls the listener per record and, if it returns false, skips the rest of
+ *   THAT haystack's records.
+ * offsets[n_haystacks] - offsets[0] + n_haystacks must stay below 2^31.  On ACGPU_E_OVERFLOW *n_out is the capacity to retry with.
+ */
+typedef struct acgpu_batch_set_match {
+    int32_t haystack, start, end;
+} acgpu_batch_set_match;
+typedef struct acgpu_batch_map_match {
+    int32_t haystack, start, end, keyword_id;
+} acgpu_batch_map_match;
+int acgpu_match_batch_u16(const acgpu_automaton *a, const uint16_t *units, const uint64_t *offsets, uint32_t n_haystacks,
+                          int record_kind, void *out, uint64_t cap, uint64_t *n_out);
+
+/*
  * Device-resident form of the same call, and the unit of multi-GPU sharding.
  * The buffer holds an owned range plus halos; positions in the records are relative to the
  * buffer start.  Ownership: ALL -> a match belongs to the shard that owns its LAST unit (left

@@ -833,6 +833,66 @@ def test_host_entry_pipelined_over_chunks_equals_the_oracle(family):
     assert (got3 == want).all()
 
 
+@pytest.mark.parametrize("family", ["ac", "ac_ci", "wholeword", "longest", "shortest", "wwlongest"])
+def test_batch_of_short_haystacks_equals_one_call_per_haystack(family):
+    """acgpu_match_batch_u16: many short haystacks in one device call (separator units between them) report, haystack by
+    haystack, exactly what the reference's match(String) reports for each of them alone -- empty haystacks, haystacks that end
+    in the middle of a keyword / a word, keywords that would match across a boundary."""
+    from oracle.oracle import FAM_SHORTEST, FAM_WWLONGEST
+    rng = np.random.default_rng(77)
+    if family in ("ac", "ac_ci"):
+        cs = family == "ac"
+        table = synth.ALPHA_LOWER[:6] if cs else np.array([ord(c) for c in "abcABC"] + [0x00E9, 0x00C9], dtype=np.uint16)
+        kws = synth.random_keywords(51, 400, 1, 9, table=table)
+        auto = Automaton(N.MODE_ALL, kws, cs)
+        orc = Oracle(FAM_AC, kws, case_sensitive=cs, lower=LOWER)
+    elif family == "wholeword":
+        table = np.array([ord(c) for c in "abcdE -,"] + [0x00E9, 0x00C9], dtype=np.uint16)
+        kws = synth.random_keywords(52, 300, 1, 6, table=table[:5])
+        auto = Automaton(N.MODE_WHOLEWORD, kws, False, word_chars=WORD)
+        orc = Oracle(FAM_WHOLEWORD, kws, case_sensitive=False, lower=LOWER, word_chars=WORD)
+    elif family == "longest":
+        table = synth.ALPHA_LOWER[:2]
+        kws = synth.random_keywords(53, 300, 1, 30, table=table)
+        auto, orc = Automaton(N.MODE_LONGEST, kws, True), Oracle(FAM_LONGEST, kws)
+    elif family == "shortest":
+        table = synth.ALPHA_LOWER[:3]
+        kws = synth.random_keywords(54, 300, 2, 20, table=table)
+        auto, orc = Automaton(N.MODE_SHORTEST, kws, True), Oracle(FAM_SHORTEST, kws)
+    else:
+        table = np.array([ord(c) for c in "abcE -,"] + [0x00E9, 0x00C9], dtype=np.uint16)
+        kws, _ = _wwl_case(55, 10)
+        auto = Automaton(N.MODE_WWLONGEST, kws, False, word_chars=WORD)
+        orc = Oracle(FAM_WWLONGEST, kws, case_sensitive=False, lower=LOWER, word_chars=WORD)
+    hays = [table[rng.integers(0, len(table), int(ln))] for ln in rng.integers(0, 300, 400)]
+    hays[3] = np.zeros(0, np.uint16)
+    hays[4] = np.zeros(0, np.uint16)
+    hays[10] = np.asarray(kws[0])[: max(1, len(kws[0]) - 1)]  # ends inside a keyword; the next one begins with its tail
+    hays[11] = np.asarray(kws[0])[max(1, len(kws[0]) - 1):]
+    want = []
+    for i, h in enumerate(hays):
+        r = orc.match(h)
+        want.append(np.concatenate([np.full((len(r), 1), i, np.int32), r], axis=1))
+    want = np.concatenate(want)
+    assert len(want) > 500
+    got = auto.match_batch(hays, True, cap=len(want) + 8)
+    assert got.shape == want.shape and (got == want).all()
+    got2 = auto.match_batch(hays, False, cap=16)  # overflow: the call reports the capacity to retry with
+    assert got2.shape == (len(want), 3) and (got2 == want[:, :3]).all()
+    assert auto.match_batch([], True).shape == (0, 4) and auto.match_batch([hays[3]], True).shape == (0, 4)
+
+
+def test_batch_facade_listener_and_a_dictionary_without_a_free_unit():
+    m = AhoCorasickMap(["he", "she", "hers"], ["HE", "SHE", "HERS"], True)
+    seen = []
+    m.match_batch(["ushers", "", "she he"], lambda h, s, e, v: seen.append((h, s, e, v)) or not (h == "she he" and v == "SHE"))
+    assert seen == [("ushers", 1, 4, "SHE"), ("ushers", 2, 4, "HE"), ("ushers", 2, 6, "HERS"), ("she he", 0, 3, "SHE")]
+    # every one of the 65536 units is a keyword: no separator exists, the batch falls back to one call per haystack
+    every = AhoCorasickSet([np.array([i], dtype=np.uint16) for i in range(65536)], True)
+    got = every.automaton.match_batch([np.array([5, 6], np.uint16), np.array([7], np.uint16)], False).tolist()
+    assert got == [[0, 0, 1], [0, 1, 2], [1, 0, 1]]
+
+
 # ---- ShardedMatcher (ahocorasick_amd/dist.py) through the native scan: the ranks of one job emulated in one process ----
 
 def _emulated_ranks(auto, whole, world, chain_window=4096):
