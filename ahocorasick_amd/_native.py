@@ -49,7 +49,7 @@ class Profile(ctypes.Structure):
 
 # every symbol include/acgpu.h declares
 SYMBOLS = ["acgpu_build", "acgpu_free", "acgpu_get_info", "acgpu_match_u16", "acgpu_match_batch_u16", "acgpu_match_device",
-           "acgpu_match_device_begin", "acgpu_match_device_end", "acgpu_synth_fill", "acgpu_stream_probe",
+           "acgpu_match_device_begin", "acgpu_match_device_end", "acgpu_match_device_abandon", "acgpu_synth_fill", "acgpu_stream_probe",
            "acgpu_set_tunable", "acgpu_strerror", "acgpu_last_hip_error", "acgpu_abi_version", "acgpu_debug_tables",
            "acgpu_debug_wordhash", "acgpu_stream_open", "acgpu_stream_feed", "acgpu_stream_close"]
 
@@ -89,6 +89,8 @@ def lib():
         L.acgpu_match_device_begin.argtypes = [vp, ctypes.POINTER(Shard), ci, vp, u64, vp, ci, ctypes.POINTER(vp)]
         L.acgpu_match_device_end.restype = ci
         L.acgpu_match_device_end.argtypes = [vp, vp, ctypes.POINTER(u64), ctypes.POINTER(Profile)]
+        L.acgpu_match_device_abandon.restype = ci
+        L.acgpu_match_device_abandon.argtypes = [vp, vp]
         L.acgpu_synth_fill.restype = ci
         L.acgpu_synth_fill.argtypes = [vp, u64, u64, u64, vp, u32, vp]
         L.acgpu_stream_probe.restype = ci

@@ -1527,6 +1527,28 @@ int acgpu_match_device_begin(const acgpu_automaton *ca, acgpu_shard *sh, int rec
     return ACGPU_OK;
 }
 
+int acgpu_match_device_abandon(const acgpu_automaton *ca, acgpu_ticket *ticket) {
+    if (!ca || !ticket) return ACGPU_E_INVALID;
+    acgpu_automaton *a = const_cast<acgpu_automaton *>(ca);
+    Ticket *tk = reinterpret_cast<Ticket *>(ticket);
+    hipEvent_t done = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(a->mu);
+        if (!tk->busy) return ACGPU_E_INVALID;
+        if (tk->kind == 2) {
+            tk->busy = false;
+            return ACGPU_OK;
+        }
+        done = tk->done;
+    }
+    HIP_TRY(hipEventSynchronize(done)); // (its kernels still write the caller's buffers until then)
+    std::lock_guard<std::mutex> lock(a->mu);
+    if (!tk->busy) return ACGPU_E_INVALID;
+    tk->busy = false;
+    reinterpret_cast<DeviceState *>(tk->owner)->inflight--;
+    return ACGPU_OK;
+}
+
 int acgpu_match_device_end(const acgpu_automaton *ca, acgpu_ticket *ticket, uint64_t *n_out, acgpu_profile *prof) {
     if (!ca || !ticket || !n_out) return ACGPU_E_INVALID;
     acgpu_automaton *a = const_cast<acgpu_automaton *>(ca);

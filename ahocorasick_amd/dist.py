@@ -9,9 +9,10 @@ row per matcher family:
   character?), right halo max_keyword_len+1 units from rank g+1 (enough to see that a run is longer than any keyword).
 * Longest: the lengths L[pos] need a right halo of max_keyword_len-1 units and are independent per shard; the greedy
   chain pos -> pos + max(L[pos],1) needs each shard's entry position = the previous shard's exit.  Every rank first
-  runs its chain speculatively from its own first unit (all ranks in parallel); then ONE int64 travels down the ranks
-  (send/recv, world-1 hops) and a rank whose true entry differs re-runs a short window until the true chain leaves the
-  window where the speculative one did -- from there on both are the same chain.
+  runs its chain speculatively from its own first unit (all ranks in parallel); then the ranks ALL-GATHER their exits
+  (one int64 each, all ranks at once -- not a hop down the ranks), a rank whose true entry differs re-runs a short window
+  until the true chain leaves the window where the speculative one did -- from there on both are the same chain -- and
+  the gather is repeated until it returns what the previous one did (two gathers unless a repair changed an exit).
 * Shortest: a match belongs to the rank that owns its LAST unit (left halo as AhoCorasick); which occurrences are
   reported depends on where matching last restarted (the end of the previous reported match), handed down the ranks
   like the Longest chain position, with the same speculation (no restriction) and window repair.
@@ -33,8 +34,8 @@ Data exchange, and what a step costs the host:
 * AhoCorasick and WholeWord enqueue their scan with acgpu_match_device_begin and collect it with _end only after the
   gathered headers have arrived on the host: one blocking host synchronisation per step (the header read-back).  With
   overlap=True that read-back is the PREVIOUS step's, so the all-gather of step k runs under the scan of step k+1;
-* Longest / Shortest / WholeWordLongest additionally pay the chain hop (one int64 down the ranks) and the count
-  read-back of their synchronous scan calls.
+* Longest / Shortest / WholeWordLongest additionally pay the all-gathers of the chain exits (two per step as a rule,
+  whatever the number of ranks) and the count read-back of their synchronous scan calls.
 Positions stay shard-local int32 in the gathered buffer and become global int64 positions by adding
 base[g] = g * units_per_rank (global_records()).
 """
@@ -221,6 +222,7 @@ class ShardedMatcher:
         self.gathered = None  # (world, gcap, cols) int32 view of the last COMPLETED step
         self.counts = None    # (world,) int64 on the host
         self.chain_repairs = 0  # Longest: window re-runs of the last step (0 = speculation was right)
+        self.chain_entry_applied = None  # chain families: the entry the last step's records assume
         self.chain_window = 4096  # Longest: first repair window in units (x4 until the chains meet)
         self.host_syncs = 0   # blocking host synchronisations of the last step() on its own account (diagnostic)
         self.redone_steps = 0  # steps redone with larger gather buffers
@@ -353,28 +355,65 @@ class ShardedMatcher:
         self._write_header(st, n)
         return n, prof
 
-    # ---- Longest: speculative chain + one int64 down the ranks -----------------------------------------------
-    def _chain_hop_recv(self):
-        if self.rank == 0:
-            return 0
-        t = torch.empty(1, dtype=torch.int64, device=self._hop_device)
-        dist.recv(t, self.rank - 1, group=self.group)
-        self.host_syncs += 1
-        return int(t.item()) - self.rank * self.sb.n_units  # global -> shard-relative
+    # ---- the chain families: speculation on every rank + all-gathers of the chain exits until they settle ------------------
+    # Longest / Shortest / WholeWordLongest: what a rank reports depends on one number from the rank before it (where the
+    # greedy chain enters / where matching last restarted / from where the scan looks for its next word start).  Round 1's
+    # driver sent that number DOWN the ranks: world-1 serial hops, each behind the sender's scan and repair.  Here every rank
+    # scans speculatively at once ("nothing comes in"), then the ranks all-gather their exits -- one small collective, all
+    # ranks in parallel -- take the exit of the rank before them as their entry, repair the head of their shard if that
+    # entry differs from the assumption, and gather again: the loop ends when a gather returns what the previous one did.
+    # A repair almost never changes a rank's exit (the chains merge within a few keyword lengths), so a step costs two
+    # gathers however many ranks there are; the worst case -- every exit depends on the entry -- is the old serial hop.
+    _NONE = -(1 << 62)  # "nothing comes in" in global coordinates
 
-    def _chain_hop_send(self, exit_pos):
-        if self.rank + 1 < self.world:
-            t = torch.tensor([exit_pos + self.rank * self.sb.n_units], dtype=torch.int64, device=self._hop_device)
-            dist.send(t, self.rank + 1, group=self.group)
+    def _gather_exits(self, ex_global):
+        """All ranks' exits (global positions), identical on every rank."""
+        t = torch.tensor([int(ex_global)], dtype=torch.int64, device=self._hop_device)
+        out = torch.empty(self.world, dtype=torch.int64, device=self._hop_device)
+        dist.all_gather_into_tensor(out, t, group=self.group)
+        self.host_syncs += 1
+        return out.cpu().tolist()
+
+    def _scan_chain(self, profile, spec, repair, to_global, from_global):
+        """spec() -> (n, exit) under the assumption that nothing comes in; repair(entry) -> (n, exit) for a true entry (always
+        from the speculative records, which spec() left in self.out / keeps in self._spec); to_global / from_global map a
+        rank's exit to and from the number that travels."""
+        n, ex, prof = spec(profile)
+        self.chain_repairs = 0
+        if self.world == 1:
+            return n, prof
+        applied = None   # the entry my current records assume (None: the speculation)
+        prev = None
+        self._spec_dirty = False
+        while True:
+            exits = self._gather_exits(to_global(ex, n, applied))
+            if exits == prev:
+                break
+            prev = exits
+            entry = from_global(exits[self.rank - 1]) if self.rank else None
+            if entry != applied:
+                if self._spec_dirty:  # a second repair starts from the speculation again
+                    n, ex, _ = spec(False)
+                    self._spec_dirty = False
+                if entry is not None:
+                    n, ex = repair(entry, n, ex)
+                applied = entry
+        self.chain_entry_applied = applied  # (shard-relative; None on rank 0: diagnostic, bench.py's self-check)
+        return n, prof
 
     def _scan_longest(self, profile):
         n_own = self.sb.n_units
-        n, ex, prof = self._call("out", 0, n_own, 0, profile)  # speculation: the chain enters at my first unit
-        entry = self._chain_hop_recv()  # true entry >= 0: the previous rank's exit
-        self.chain_repairs = 0
-        if entry != 0:
-            spec, shift = self.out, self.shift  # (records are view-relative, the chain positions shard-relative)
-            starts = spec[:n, 0].contiguous()
+        base = self.rank * n_own
+
+        def spec(prof_on):
+            n, ex, prof = self._call("out", 0, n_own, 0, prof_on)  # the chain enters at my first unit
+            return n, ex, prof
+
+        def repair(entry, n, ex):
+            if entry == 0:
+                return n, ex
+            spec_recs, shift = self.out, self.shift  # (records are view-relative, the chain positions shard-relative)
+            starts = spec_recs[:n, 0].contiguous()
             w = int(self.chain_window)
             while True:
                 w_end = min(w, n_own)
@@ -385,47 +424,58 @@ class ShardedMatcher:
                 else:
                     # where the speculative chain leaves the window: max(w_end, end of its last match starting inside)
                     idx = int(torch.searchsorted(starts, torch.tensor([w_end + shift], dtype=torch.int32, device=starts.device)).item())
-                    ex_s = max(w_end, int(spec[idx - 1, 1].item()) - shift) if idx else w_end
+                    ex_s = max(w_end, int(spec_recs[idx - 1, 1].item()) - shift) if idx else w_end
                 if w_end == n_own or ex_t == ex_s:
-                    tail = spec[idx:n].clone()
+                    tail = spec_recs[idx:n].clone()
                     if n_t + len(tail) > self.out.shape[0]:
                         self._grow("out", n_t + len(tail))
                     self.out[:n_t] = self._tmp[:n_t]
                     self.out[n_t:n_t + len(tail)] = tail
-                    n = n_t + len(tail)
-                    if w_end == n_own:
-                        ex = ex_t
-                    break
+                    self._spec_dirty = True
+                    return n_t + len(tail), (ex_t if w_end == n_own else ex)
                 w *= 4
-        self._chain_hop_send(ex)
-        return n, prof
+
+        return self._scan_chain(profile, spec, repair, lambda ex, n, applied: ex + base,
+                                lambda g: max(g - base, 0))
 
     def _scan_wwlongest(self, profile):
-        """WholeWordLongest: speculation = the scan enters at my first unit; the true entry is the position behind the stop
-        of the previous rank's last walk.  Walks are short (at most max_keyword_len units), so an entry inside my shard
-        lies within my first few units: the shard is scanned once more from there."""
+        """WholeWordLongest: speculation = the scan enters at my first unit; the true entry is the position behind the stop of
+        the previous rank's last walk.  Walks are short (at most max_keyword_len units), so an entry inside my shard lies
+        within my first few units: the shard is scanned once more from there."""
         n_own = self.sb.n_units
-        n, ex, prof = self._call("out", 0, n_own, 0, profile)
-        entry = self._chain_hop_recv()
-        self.chain_repairs = 0
-        if entry > 0:
-            self.chain_repairs = 1
-            n, ex, prof = self._call("out", 0, n_own, entry, profile)
-        self._chain_hop_send(max(ex, entry))
-        return n, prof
+        base = self.rank * n_own
+
+        def spec(prof_on):
+            return self._call("out", 0, n_own, 0, prof_on)
+
+        def repair(entry, n, ex):
+            if entry <= 0:
+                return n, ex
+            self.chain_repairs += 1
+            self._spec_dirty = True
+            n2, ex2, _ = self._call("out", 0, n_own, entry)
+            return n2, max(ex2, entry)
+
+        return self._scan_chain(profile, spec, repair, lambda ex, n, applied: ex + base,
+                                lambda g: max(g - base, 0))
 
     def _scan_shortest(self, profile):
-        """Shortest: records are owned by their END; the chain state is the position of the last restart (the end of
-        the last reported match, or what came in if this shard reported nothing).  Speculation: no restriction."""
+        """Shortest: records are owned by their END; the chain state is the position of the last restart (the end of the last
+        reported match, or what came in if this shard reported nothing).  Speculation: no restriction."""
         n_own, halo = self.sb.n_units, self.sb.halo
+        base = self.rank * n_own
         none = -(self.sb.pad + 1)  # a restart position left of everything this rank can see restricts nothing
-        n, _, prof = self._call("out", 0, n_own, none, profile)
-        entry = max(self._chain_hop_recv(), none) if self.rank else none
-        self.chain_repairs = 0
         shift = self.shift  # (records are view-relative, the restart positions shard-relative)
-        if entry > -halo:  # a restart inside my halo can forbid matches that begin before it
-            spec = self.out
-            ends = spec[:n, 1].contiguous()
+
+        def spec(prof_on):
+            n, _, prof = self._call("out", 0, n_own, none, prof_on)
+            return n, None, prof
+
+        def repair(entry, n, ex):
+            if entry <= -halo:  # a restart left of my halo forbids nothing
+                return n, ex
+            spec_recs = self.out
+            ends = spec_recs[:n, 1].contiguous()
             w = int(self.chain_window)
             while True:
                 w_end = min(w, n_own)
@@ -435,19 +485,25 @@ class ShardedMatcher:
                 idx = n if w_end == n_own else int(torch.searchsorted(
                     ends, torch.tensor([w_end + shift], dtype=torch.int32, device=ends.device), right=True).item())
                 last_t = int(self._tmp[n_t - 1, 1].item()) - shift if n_t else entry
-                last_s = int(spec[idx - 1, 1].item()) - shift if idx else none
+                last_s = int(spec_recs[idx - 1, 1].item()) - shift if idx else none
                 floor = w_end - halo  # restart positions at or left of this restrict nothing that ends after the window
                 if w_end == n_own or max(last_t, floor) == max(last_s, floor):
-                    tail = spec[idx:n].clone()
+                    tail = spec_recs[idx:n].clone()
                     if n_t + len(tail) > self.out.shape[0]:
                         self._grow("out", n_t + len(tail))
                     self.out[:n_t] = self._tmp[:n_t]
                     self.out[n_t:n_t + len(tail)] = tail
-                    n = n_t + len(tail)
-                    break
+                    self._spec_dirty = True
+                    return n_t + len(tail), None
                 w *= 4
-        self._chain_hop_send(int(self.out[n - 1, 1].item()) - shift if n else entry)
-        return n, prof
+
+        def to_global(ex, n, applied):  # the end of my last reported match, or what came in
+            if n:
+                return int(self.out[n - 1, 1].item()) - shift + base
+            return self._NONE if applied is None else applied + base
+
+        return self._scan_chain(profile, spec, repair, to_global,
+                                lambda g: none if g == self._NONE else max(g - base, none))
 
     # ---- a step: enqueue (scan + all-gather + header read-back), collect ----------------------------------------
     def _enqueue(self, profile):
@@ -488,18 +544,23 @@ class ShardedMatcher:
         if self.world > 1 and st.work is not None:
             st.event.synchronize()
             self.host_syncs += 1
-        if st.ticket is not None:
-            tk, st.ticket = st.ticket, None
-            n, rc, prof = self.auto.match_device_end(tk, profile=st.prof_on)  # (world > 1: its event has long passed)
-            if self.world == 1:
-                self.host_syncs += 1
-            if rc != N.E_OVERFLOW:
-                N.check(rc, "acgpu_match_device_end")
         if self.world > 1:
             hdr = st.hdr_host.numpy()
             counts = (hdr[:, 0].astype(np.int64) & 0xffffffff) | (hdr[:, 1].astype(np.int64) << 32)
             bad = bool((counts > st.gcap).any() or (hdr[:, 2] != 0).any())
-        else:
+        if st.ticket is not None:
+            tk, st.ticket = st.ticket, None
+            if self.world > 1 and bad:
+                # every rank redoes this step anyway (_redo): the ticket is given up, not collected -- collecting it would
+                # make the ranks whose own scan has to be redone scan twice, and leave the others waiting for them
+                N.check(self.auto.match_device_abandon(tk), "acgpu_match_device_abandon")
+            else:
+                n, rc, prof = self.auto.match_device_end(tk, profile=st.prof_on)  # (world > 1: its event has long passed)
+                if self.world == 1:
+                    self.host_syncs += 1
+                if rc != N.E_OVERFLOW:
+                    N.check(rc, "acgpu_match_device_end")
+        if self.world == 1:
             counts = np.array([n], dtype=np.int64)
             bad = n > st.gcap
         if bad:

@@ -186,6 +186,11 @@ class Automaton:
         return int(n_out.value), rc, pd
 
 
+    def match_device_abandon(self, ticket):
+        """acgpu_match_device_abandon: give the ticket up (waits for its kernels, never redoes the call)."""
+        return N.lib().acgpu_match_device_abandon(self._h, ticket.handle)
+
+
 class Ticket:
     """One acgpu_match_device_begin call in flight: the native ticket and the acgpu_shard it was begun with."""
 

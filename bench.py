@@ -289,12 +289,14 @@ def verify(cfg_name, kws, matcher, sample_units):
     n = int(matcher.counts[matcher.rank])
     recs = matcher.gathered[matcher.rank, :n].cpu().numpy()
     digest = hashlib.sha256(np.ascontiguousarray(recs).tobytes()).hexdigest()
-    if cfg_name == "C4" and matcher.rank > 0:
-        return True, digest, 0  # (a later shard's chain entry comes from the rank before it: rank 0 carries the check)
     sb = matcher.sb
     shift = matcher.shift
     v0 = sb.pad - shift  # view start in the buffer
     lo = shift - sb.halo if matcher.rank else 0  # first text unit of the view that is real text (the halo)
+    if cfg_name == "C4" and matcher.rank > 0:
+        # a later shard's greedy chain enters where the rank before it left: the oracle runs from that position (a chain
+        # started there IS the rest of the whole text's chain)
+        lo = shift + int(matcher.chain_entry_applied or 0)
     hay = sb.buf[v0 + lo:v0 + shift + sample_units].cpu().numpy().view(np.uint16)
     want = o.match(hay, cap=max(1 << 16, hay.size // (2 if cfg_name == "C4" else 8)))[:, :recs.shape[1]].copy()
     want[:, :2] += lo

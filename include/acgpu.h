@@ -251,6 +251,10 @@ typedef struct acgpu_ticket acgpu_ticket;
 int acgpu_match_device_begin(const acgpu_automaton *a, acgpu_shard *shard, int record_kind, void *d_out, uint64_t cap,
                              void *stream, int want_profile, acgpu_ticket **ticket);
 int acgpu_match_device_end(const acgpu_automaton *a, acgpu_ticket *ticket, uint64_t *n_out, acgpu_profile *prof);
+/* Gives a ticket up without collecting it: waits until its kernels have finished (they write the caller's buffers until
+ * then), never redoes the call.  For a driver that already knows -- from the device result it gathered -- that the step has
+ * to be done again with larger buffers. */
+int acgpu_match_device_abandon(const acgpu_automaton *a, acgpu_ticket *ticket);
 
 /*
  * Replaces StringMap.match(Readable, ReadableMatchListener<T>) (S/StringMap.java:6; S/AhoCorasickMap.java:208-275,

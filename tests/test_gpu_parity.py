@@ -897,13 +897,13 @@ def test_batch_facade_listener_and_a_dictionary_without_a_free_unit():
 
 def _emulated_ranks(auto, whole, world, chain_window=4096):
     """What `world` ranks of ShardedMatcher.step() compute, minus the collectives: halos filled from the whole text,
-    the Longest chain hop handed over in Python.  Returns the concatenation with global positions + repair count.
+    the chain families' all-gather of exits emulated rank by rank.  Returns the concatenation with global positions + repair count.
     (tests/test_dist_gpu.py runs the same thing in real separate processes.)"""
     import torch
     from ahocorasick_amd.dist import ShardedMatcher
     n = whole.size // world
     d_whole = torch.from_numpy(whole.view(np.int16)).cuda()
-    box = [0]
+    box = [0] * world  # the exits (global) of the ranks done so far
     parts, repairs = [], 0
     for g in range(world):
         m = ShardedMatcher(auto, n, with_ids=True, cap=64)
@@ -915,8 +915,7 @@ def _emulated_ranks(auto, whole, world, chain_window=4096):
             sb.halo_view().copy_(d_whole[g * n - sb.halo:g * n])
         if g + 1 < world and sb.right:
             sb.right_view().copy_(d_whole[(g + 1) * n:(g + 1) * n + sb.right])
-        m._chain_hop_recv = lambda g=g: box[0] - g * n if g else 0
-        m._chain_hop_send = lambda ex, g=g: box.__setitem__(0, ex + g * n)
+        m._gather_exits = lambda ex, g=g: (box.__setitem__(g, int(ex)), list(box))[1]  # (ranks before g: their final exits)
         cnt, _ = m._scan(False, m._new_step())
         r = m.out[:cnt].cpu().numpy().astype(np.int64)
         r[:, :2] += g * n - m.shift  # (records are relative to the rank's view of its buffer)
