@@ -49,7 +49,7 @@ class Profile(ctypes.Structure):
 
 # every symbol include/acgpu.h declares
 SYMBOLS = ["acgpu_build", "acgpu_free", "acgpu_get_info", "acgpu_match_u16", "acgpu_match_batch_u16", "acgpu_match_device",
-           "acgpu_match_device_begin", "acgpu_match_device_end", "acgpu_match_device_abandon", "acgpu_synth_fill", "acgpu_stream_probe",
+           "acgpu_match_device_begin", "acgpu_match_device_end", "acgpu_match_device_abandon", "acgpu_synth_fill", "acgpu_synth_tokens", "acgpu_stream_probe",
            "acgpu_set_tunable", "acgpu_strerror", "acgpu_last_hip_error", "acgpu_abi_version", "acgpu_debug_tables",
            "acgpu_debug_wordhash", "acgpu_stream_open", "acgpu_stream_feed", "acgpu_stream_close"]
 
@@ -93,6 +93,8 @@ def lib():
         L.acgpu_match_device_abandon.argtypes = [vp, vp]
         L.acgpu_synth_fill.restype = ci
         L.acgpu_synth_fill.argtypes = [vp, u64, u64, u64, vp, u32, vp]
+        L.acgpu_synth_tokens.restype = ci
+        L.acgpu_synth_tokens.argtypes = [vp, u64, u64, vp, vp, u32, vp, vp]
         L.acgpu_stream_probe.restype = ci
         L.acgpu_stream_probe.argtypes = [vp, u64, vp, ci, ctypes.POINTER(ctypes.c_float)]
         L.acgpu_set_tunable.restype = i64

@@ -1894,4 +1894,68 @@ int acgpu_synth_fill(uint16_t *d_dst, uint64_t n_units, uint64_t start_index, ui
     return ACGPU_OK;
 }
 
+int acgpu_synth_tokens(uint16_t *d_dst, uint64_t n_units, uint64_t seed, const uint16_t *kw_units, const uint64_t *kw_off,
+                       uint32_t n_kw, const uint16_t *swapcase_tbl, void *stream_) {
+    if ((n_units && !d_dst) || (n_kw && (!kw_units || !kw_off))) return ACGPU_E_INVALID;
+    if (n_units == 0) return ACGPU_OK;
+    if (n_units / 3 + 2 >= (1ull << 32)) return ACGPU_E_INVALID;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    // the benchmark's scripts and separators (ahocorasick_amd/synth.py: _SCRIPTS, _SEPARATORS)
+    static const uint16_t ranges[][2] = {{0x41, 0x5A}, {0x61, 0x7A}, {0xC0, 0xD6}, {0xD8, 0xF6}, {0xF8, 0xFF}, // latin
+                                         {0x0391, 0x03A1}, {0x03A3, 0x03A9}, {0x03B1, 0x03C9},                // greek
+                                         {0x0410, 0x044F},                                                    // cyrillic
+                                         {0x4E00, 0x9FA5},                                                    // cjk
+                                         {0xAC00, 0xD7A3},                                                    // hangul
+                                         {0x0621, 0x063A}, {0x0641, 0x064A}};                                 // arabic
+    static const int script_first[7] = {0, 5, 8, 9, 10, 11, 13};
+    static const uint16_t seps[6] = {0x20, ',', '.', 0x0A, 0x3002, 0x2014};
+    std::vector<uint16_t> scripts;
+    uint32_t script_off[7];
+    std::vector<uint32_t> off32;
+    try {
+        for (int sc = 0; sc < 6; ++sc) {
+            script_off[sc] = (uint32_t)scripts.size();
+            for (int r = script_first[sc]; r < script_first[sc + 1]; ++r)
+                for (uint32_t u = ranges[r][0]; u <= ranges[r][1]; ++u) scripts.push_back((uint16_t)u);
+        }
+        script_off[6] = (uint32_t)scripts.size();
+        off32.resize((size_t)n_kw + 1);
+        for (uint32_t i = 0; i <= n_kw; ++i) {
+            const uint64_t o = n_kw ? kw_off[i] - kw_off[0] : 0;
+            if (o >= (1ull << 32)) return ACGPU_E_INVALID;
+            off32[i] = (uint32_t)o;
+        }
+    } catch (...) {
+        return ACGPU_E_NOMEM;
+    }
+    const uint32_t n_tokens = (uint32_t)(n_units / 3 + 2); // a token is at least 3 units long: these cover the haystack
+    const size_t kw_bytes = n_kw ? (size_t)off32[n_kw] * 2 : 0;
+    DevBuf b_kw, b_off, b_sw, b_sc, b_len, b_start, b_tmp;
+    auto release = [&]() { b_kw.release(); b_off.release(); b_sw.release(); b_sc.release(); b_len.release(); b_start.release(); b_tmp.release(); };
+    int rc = ACGPU_OK;
+    if ((rc = b_kw.ensure(kw_bytes + 16)) || (rc = b_off.ensure(off32.size() * 4 + 16)) || (rc = b_sc.ensure(scripts.size() * 2 + 16)) ||
+        (rc = b_len.ensure((size_t)n_tokens * 4 + 16)) || (rc = b_start.ensure((size_t)n_tokens * 8 + 16)) ||
+        (rc = b_tmp.ensure(((size_t)n_tokens / 2048 + 2) * 8 + 16)) || (swapcase_tbl && (rc = b_sw.ensure(65536 * 2)))) {
+        release();
+        return rc;
+    }
+    hipError_t e = hipSuccess;
+    if (kw_bytes) e = hipMemcpy(b_kw.p, kw_units + kw_off[0], kw_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(b_off.p, off32.data(), off32.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(b_sc.p, scripts.data(), scripts.size() * 2, hipMemcpyHostToDevice);
+    if (e == hipSuccess && swapcase_tbl) e = hipMemcpy(b_sw.p, swapcase_tbl, 65536 * 2, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = launch_token_stream(d_dst, n_units, seed, (const uint16_t *)b_kw.p, (const uint32_t *)b_off.p, n_kw,
+                                swapcase_tbl ? (const uint16_t *)b_sw.p : nullptr, (const uint16_t *)b_sc.p, script_off, seps, n_tokens,
+                                (uint32_t *)b_len.p, (uint64_t *)b_start.p, (uint64_t *)b_tmp.p, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream); // (the scratch is released below)
+    release();
+    if (e != hipSuccess) {
+        g_last_hip_error = (int)e;
+        (void)hipGetLastError();
+        return e == hipErrorOutOfMemory ? ACGPU_E_NOMEM : ACGPU_E_HIP;
+    }
+    return ACGPU_OK;
+}
+
 } // extern "C"

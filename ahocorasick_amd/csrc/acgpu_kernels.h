@@ -99,6 +99,10 @@ struct PermuteTail {
 // {n_records, redone = 0} into an acgpu_shard::d_result, in stream order (the families whose pipeline ends with a count
 // on the host)
 hipError_t launch_write_result(acgpu_device_result *d_result, uint64_t n_records, hipStream_t stream);
+hipError_t launch_token_stream(uint16_t *d_dst, uint64_t n_units, uint64_t seed, const uint16_t *d_kw_units, const uint32_t *d_kw_off,
+                               uint32_t n_kw, const uint16_t *d_swapcase, const uint16_t *d_script_units, const uint32_t *script_off,
+                               const uint16_t *seps, uint32_t n_tokens, uint32_t *d_len, uint64_t *d_start, uint64_t *d_tmp,
+                               hipStream_t stream);
 hipError_t launch_batch_tag(const void *d_recs, uint64_t n, int record_kind, const uint32_t *d_cat_off, uint32_t n_hay, void *d_out,
                             hipStream_t stream);
 hipError_t launch_publish_result(const unsigned long long *d_total, const unsigned long long *d_exit, unsigned long long *h_slot_dev,

@@ -610,6 +610,89 @@ hipError_t launch_synth_fill(uint16_t *d_dst, uint64_t n, uint64_t start, uint64
 }
 
 
+// ---- token-stream generator (config 5's haystack; ahocorasick_amd/synth.py: token_stream_haystack is its numpy twin) --------
+// Token t owns the draws 32 t .. 32 t + 31 of the SplitMix64 stream, so a token is a function of (seed, t) alone: draw 0: a
+// dictionary word (0) or a random word; dictionary word: draw 1 its index, draws 2.. a case flip per unit (the first 24);
+// random word: draw 1 the script, draw 2 the length 2..12, draws 3.. the units; draw 28: 1..3 separators, draws 29.. which.
+// The haystack is the tokens one after the other, cut at n_units: lengths, a prefix sum, a fill.
+struct TokenTables {
+    const uint16_t *kw_units;
+    const uint32_t *kw_off; // n_kw + 1
+    uint32_t n_kw;
+    const uint16_t *swapcase; // 65536 entries or nullptr
+    const uint16_t *script_units; // the six script tables one after the other
+    uint32_t script_off[7];
+    uint16_t seps[6];
+};
+__device__ __forceinline__ uint64_t synth_draw(uint64_t seed, uint64_t idx) {
+    uint64_t x = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
+    uint64_t z = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ uint32_t synth_bounded(uint64_t z, uint32_t k) { return (uint32_t)(((z >> 32) * (uint64_t)k) >> 32); }
+
+__global__ __launch_bounds__(256) void k_token_lengths(TokenTables T, uint64_t seed, uint32_t n_tokens, uint32_t *len) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tokens) return;
+    const uint64_t d0 = (uint64_t)t * 32;
+    uint32_t wl;
+    if (synth_bounded(synth_draw(seed, d0), 2) == 0 && T.n_kw) {
+        const uint32_t wi = synth_bounded(synth_draw(seed, d0 + 1), T.n_kw);
+        wl = T.kw_off[wi + 1] - T.kw_off[wi];
+    } else {
+        wl = 2 + synth_bounded(synth_draw(seed, d0 + 2), 11);
+    }
+    len[t] = wl + 1 + synth_bounded(synth_draw(seed, d0 + 28), 3);
+}
+
+__global__ __launch_bounds__(256) void k_token_fill(TokenTables T, uint64_t seed, uint32_t n_tokens, const uint64_t *start, uint16_t *dst,
+                                                    uint64_t n_units) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tokens) return;
+    uint64_t at = start[t];
+    if (at >= n_units) return;
+    const uint64_t d0 = (uint64_t)t * 32;
+    auto put = [&](uint32_t u) {
+        if (at < n_units) dst[at] = (uint16_t)u;
+        ++at;
+    };
+    if (synth_bounded(synth_draw(seed, d0), 2) == 0 && T.n_kw) {
+        const uint32_t wi = synth_bounded(synth_draw(seed, d0 + 1), T.n_kw);
+        const uint32_t a = T.kw_off[wi], wl = T.kw_off[wi + 1] - a;
+        for (uint32_t i = 0; i < wl; ++i) {
+            uint32_t u = T.kw_units[a + i];
+            if (T.swapcase && i < 24 && synth_bounded(synth_draw(seed, d0 + 2 + i), 2)) u = T.swapcase[u];
+            put(u);
+        }
+    } else {
+        const uint32_t sc = synth_bounded(synth_draw(seed, d0 + 1), 6);
+        const uint32_t wl = 2 + synth_bounded(synth_draw(seed, d0 + 2), 11);
+        const uint32_t a = T.script_off[sc], tl = T.script_off[sc + 1] - a;
+        for (uint32_t i = 0; i < wl; ++i) put(T.script_units[a + synth_bounded(synth_draw(seed, d0 + 3 + i), tl)]);
+    }
+    const uint32_t ns = 1 + synth_bounded(synth_draw(seed, d0 + 28), 3);
+    for (uint32_t i = 0; i < ns; ++i) put(T.seps[synth_bounded(synth_draw(seed, d0 + 29 + i), 6)]);
+}
+
+hipError_t launch_token_stream(uint16_t *d_dst, uint64_t n_units, uint64_t seed, const uint16_t *d_kw_units, const uint32_t *d_kw_off,
+                               uint32_t n_kw, const uint16_t *d_swapcase, const uint16_t *d_script_units, const uint32_t *script_off,
+                               const uint16_t *seps, uint32_t n_tokens, uint32_t *d_len, uint64_t *d_start, uint64_t *d_tmp,
+                               hipStream_t stream) {
+    TokenTables T;
+    T.kw_units = d_kw_units; T.kw_off = d_kw_off; T.n_kw = n_kw; T.swapcase = d_swapcase; T.script_units = d_script_units;
+    for (int i = 0; i < 7; ++i) T.script_off[i] = script_off[i];
+    for (int i = 0; i < 6; ++i) T.seps[i] = seps[i];
+    const dim3 grid((n_tokens + 255) / 256), block(256);
+    hipLaunchKernelGGL(k_token_lengths, grid, block, 0, stream, T, seed, n_tokens, d_len);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = launch_exclusive_scan(d_len, n_tokens, d_start, d_tmp, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_token_fill, grid, block, 0, stream, T, seed, n_tokens, d_start, d_dst, n_units);
+    return hipGetLastError();
+}
+
 // ---- attainable-bandwidth probe ---------------------------------------------------------------------------
 // The read side of k_ac_tile and nothing else: one 1024-thread workgroup per CU, every wave owns a contiguous span and
 // streams it as 4 KiB tiles, lane l holding the 64 consecutive bytes at l*64 (four 16-byte loads), the next tile's loads

@@ -177,6 +177,75 @@ def mixed_script_haystack(seed, n_units, words, swapcase_tbl=None):
     return out[:n_units].copy()
 
 
+def token_stream_haystack(seed, n_units, words, swapcase_tbl=None, chunk_tokens=1 << 20):
+    """C5 haystack, token-indexed (numpy twin of acgpu_synth_tokens): token t owns draws 32 t .. 32 t + 31 of stream `seed` --
+    draw 0: dictionary word (0) or random word; dictionary word: draw 1 its index, draws 2.. a case flip per unit (the first
+    24); random word: draw 1 the script, draw 2 the length 2..12, draws 3.. its units; draw 28: 1..3 separators, draws 29..
+    which -- so the text is a function of (seed, dictionary) alone and every token can be generated independently.  The
+    haystack is the tokens one after the other, cut at n_units."""
+    tabs = _script_tables()
+    nw = len(words)
+    wl = np.array([len(w) for w in words], dtype=np.int64)
+    woff = np.concatenate([[0], np.cumsum(wl)])
+    wcat = np.concatenate([np.asarray(w, dtype=np.uint16) for w in words]) if nw else np.zeros(0, np.uint16)
+    soff = np.concatenate([[0], np.cumsum([len(t) for t in tabs])])
+    scat = np.concatenate(tabs)
+    out = np.empty(n_units + (int(wl.max()) if nw else 0) + 16, dtype=np.uint16)  # (room for the token that crosses the end)
+    pos, t0 = 0, 0
+    while pos < n_units:
+        t = np.arange(t0, t0 + chunk_tokens, dtype=np.uint64)
+        d0 = t * np.uint64(32)
+
+        def draw(j, k):
+            return bounded(splitmix64_at(seed, d0 + np.uint64(j)), k).astype(np.int64)
+        is_dict = (draw(0, 2) == 0) & (nw > 0)
+        d1_dict = draw(1, max(nw, 1))
+        d1_scr = draw(1, 6)
+        length = np.where(is_dict, wl[d1_dict] if nw else 0, 2 + draw(2, 11))
+        nsep = 1 + draw(28, 3)
+        tok_len = length + nsep
+        starts = pos + np.concatenate([[0], np.cumsum(tok_len)[:-1]])
+        keep = starts < n_units
+        for i in range(int(length.max())):  # unit i of every token's word
+            m = keep & (i < length)
+            md, mr = m & is_dict, m & ~is_dict
+            if md.any():
+                u = wcat[woff[d1_dict[md]] + i]
+                if swapcase_tbl is not None and i < 24:
+                    fl = draw(2 + i, 2)[md].astype(bool)
+                    u = np.where(fl, swapcase_tbl[u], u)
+                out[starts[md] + i] = u
+            if mr.any():
+                sc = d1_scr[mr]
+                tl = (soff[sc + 1] - soff[sc])
+                z = splitmix64_at(seed, d0[mr] + np.uint64(3 + i))
+                out[starts[mr] + i] = scat[soff[sc] + (((z >> np.uint64(32)) * tl.astype(np.uint64)) >> np.uint64(32)).astype(np.int64)]
+        for i in range(3):
+            m = keep & (i < nsep)
+            out[starts[m] + length[m] + i] = _SEPARATORS[draw(29 + i, 6)[m]]
+        n_keep = int(keep.sum())
+        pos = int(starts[n_keep - 1] + tok_len[n_keep - 1]) if n_keep else pos
+        if n_keep < chunk_tokens:
+            break
+        t0 += chunk_tokens
+    return out[:n_units].copy()
+
+
+def token_stream_on_device(d_ptr, n_units, seed, words, swapcase_tbl=None, stream=0):
+    """acgpu_synth_tokens: token_stream_haystack(seed, n_units, words, swapcase_tbl) written to the device buffer at d_ptr."""
+    import ctypes
+    from . import _native as N
+    parts = [np.asarray(w, dtype=np.uint16) for w in words]
+    off = np.zeros(len(parts) + 1, dtype=np.uint64)
+    if parts:
+        off[1:] = np.cumsum([len(p) for p in parts], dtype=np.uint64)
+    units = np.ascontiguousarray(np.concatenate(parts) if parts else np.zeros(1, np.uint16), dtype=np.uint16)
+    sw = None if swapcase_tbl is None else np.ascontiguousarray(swapcase_tbl, dtype=np.uint16)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p) if a is not None else None  # noqa: E731
+    N.check(N.lib().acgpu_synth_tokens(ctypes.c_void_p(d_ptr), int(n_units), int(seed), vp(units), vp(off), len(parts), vp(sw),
+                                       ctypes.c_void_p(stream)), "acgpu_synth_tokens")
+
+
 def swapcase_table():
     """Per-unit case flip used by mixed_script_haystack (upper<->lower where a single-unit mapping exists)."""
     t = np.arange(65536, dtype=np.uint16)

@@ -107,10 +107,9 @@ def main():
     matcher = ShardedMatcher(auto, n_units, with_ids=with_ids, cap=cap, overlap=True)
     matcher.cfg_name = cfg_name
     if cfg_name == "C5":
-        # the token stream is generated on the host: one 2^22-unit block of it, repeated (tests do the same)
-        blk = min(n_units, 1 << 22)
-        block = synth.mixed_script_haystack(seed, blk, kws, swapcase_tbl=synth.swapcase_table())
-        matcher.sb.own.copy_(torch.from_numpy(block.view(np.int16)).cuda().repeat(n_units // blk))
+        # the token stream of SURVEY 8d (seed 2005 + rank), aperiodic, generated in place on the device
+        synth.token_stream_on_device(matcher.own_ptr(), n_units, seed, kws, synth.swapcase_table(),
+                                     stream=torch.cuda.current_stream().cuda_stream)
     else:
         tab = np.ascontiguousarray(synth.ALPHA_AB_75 if cfg_name == "C4" else synth.ALPHA_LOWER)
         N.check(N.lib().acgpu_synth_fill(matcher.own_ptr(), n_units, 0, seed, tab.ctypes.data_as(ctypes.c_void_p), len(tab),

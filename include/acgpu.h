@@ -291,6 +291,16 @@ int acgpu_synth_fill(uint16_t *d_dst, uint64_t n_units, uint64_t start_index, ui
                      uint32_t table_len, void *stream);
 
 /*
+ * Config 5's haystack (tokens -- a dictionary word with random per-unit case flips, or a random single-script
+ * word -- separated by 1-3 separator units), generated in place on the device.  Token t owns draws 32 t .. 32 t + 31 of the
+ * SplitMix64 stream `seed`, so the text is a function of (seed, dictionary) alone (ahocorasick_amd/synth.py:
+ * token_stream_haystack is the numpy twin).  kw_units / kw_off / swapcase_tbl (65536 entries, may be NULL: no case flips) are
+ * HOST pointers; d_dst is a device pointer.  Synchronises `stream`.
+ */
+int acgpu_synth_tokens(uint16_t *d_dst, uint64_t n_units, uint64_t seed, const uint16_t *kw_units, const uint64_t *kw_off,
+                       uint32_t n_kw, const uint16_t *swapcase_tbl, void *stream);
+
+/*
  * Measurement helper ("also report vs. a measured streaming-read kernel on the same box"): a pure read
  * of n_bytes (>= 1 MiB, 16-byte aligned device pointer) in the access pattern of the tile kernels -- every wave a
  * contiguous span, 64 bytes per lane and tile, the next tile's loads in flight.  Runs `repeats` timed launches after a

@@ -41,9 +41,8 @@ def main():
             sp = np.array([32], dtype=np.uint16)
             kws = list(kws) + [np.concatenate([kws[i], sp, kws[i + 1]]) for i in range(0, 20000, 2)]
         a = Automaton(N.MODE_WWLONGEST if wwl else N.MODE_WHOLEWORD, kws, False, word_chars=default_word_chars())
-        blk = min(n, 1 << 22)
-        block = synth.mixed_script_haystack(synth.CONFIGS["C5"]["hay_seed"], blk, kws, swapcase_tbl=synth.swapcase_table())
-        d_hay = torch.from_numpy(block.view(np.int16)).cuda().repeat(n // blk)
+        d_hay = torch.empty(n, dtype=torch.int16, device="cuda")
+        synth.token_stream_on_device(d_hay.data_ptr(), n, synth.CONFIGS["C5"]["hay_seed"], synth.config_keywords("C5"), synth.swapcase_table())
         cap = n // 8
         dflt = {"wwl": {}} if wwl else {"ww": {}, "ww_noverify": {"tile_debug": 1}, "ww_nolookup": {"tile_debug": 2}, "ww_nobloom": {"tile_debug": 4}}
     else:
