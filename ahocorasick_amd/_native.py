@@ -121,6 +121,21 @@ def lib():
     return _lib
 
 
+def source_hash():
+    """SHA-256 (first 16 hex digits) over the kernel and builder sources: what measured evidence (profiles/latest_traffic.json)
+    is keyed by, so that a counter figure is never attached to a kernel that has been edited since."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")) +
+                   glob.glob(os.path.join(_HERE, "csrc", "*.cpp")) + [os.path.join(os.path.dirname(_HERE), "include", "acgpu.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def check(rc, where):
     if rc != OK:
         raise AcgpuError(rc, where)

@@ -656,6 +656,10 @@ int mark_chain(DeviceState &d, uint32_t *d_nxt, uint32_t *d_tmp, uint32_t *d_mar
     bool one_pass = M >= one_pass_from && jump_bound <= 60000 && !(tunables().tile_debug & 2097152);
     uint64_t head = ~0ull, max_jump = 0;
     if (one_pass) {
+        // counter words used here: [2] chain head, [3] largest jump (bytes 16..32).  They lie inside match_all's first slot
+        // counter line (word 0 = slot counter, word 1 = workgroup sum, the rest of the 128-byte line is padding), which every
+        // caller marks dirty (cclean[0] = false) so that the next AhoCorasick call clears it
+        static_assert(kCounterStride >= 4, "mark_chain keeps its head and largest jump in words 2 and 3 of the first counter line");
         if ((rc = d.counter.ensure(64))) return rc;
         if ((rc = d.lenbuf.ensure((size_t)M * 2 + 128))) return rc;
         if ((rc = d.blockmax.ensure(((size_t)M / 64 + 2) * 4))) return rc;
@@ -1259,6 +1263,13 @@ const char *acgpu_strerror(int code) {
 
 int64_t acgpu_set_tunable(const char *name, int64_t value) {
     if (!name) return -1;
+    if (!std::strcmp(name, "ablation_build")) { // (read only) 1: built with -DACGPU_ABLATION, the ablation bits of tile_debug work
+#ifdef ACGPU_ABLATION
+        return 1;
+#else
+        return 0;
+#endif
+    }
     Tunables &t = tunables();
     std::atomic<int64_t> *slot = nullptr;
     if (!std::strcmp(name, "chunk_units")) slot = &t.chunk_units;

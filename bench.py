@@ -216,14 +216,22 @@ def main():
         out["roofline"]["attainable_what"] = "k_stream_probe: pure read of the shard, one wave span per wave, 64 B per lane and tile"
 
     # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (counters cannot be read from inside
-    # this process); the committed measurement is attached when it is for this kernel and this size
+    # this process); the committed measurement is attached when it is for THIS configuration, this size and these kernel
+    # sources (keyed by a hash of csrc/: a figure measured before a kernel edit is not carried over)
     try:
         with open(os.path.join(ROOT, "profiles", "latest_traffic.json")) as f:
             tr = json.load(f)
+        src = N.source_hash()
         for ent in (tr if isinstance(tr, list) else [tr]):
-            if ent["kernel"] == matcher.last_kernel and ent["units_per_gpu"] == n_units:
-                out["roofline"]["traffic"] = ent["traffic_bytes"]
-                out["roofline"]["traffic_source"] = ent["source"]
+            if ent.get("config") == cfg_name and ent["units_per_gpu"] == n_units:
+                if ent.get("csrc_sha256") == src:
+                    out["roofline"]["traffic"] = ent["traffic_bytes"]
+                    out["roofline"]["traffic_source"] = ent["source"]
+                    if "traffic_bytes_range" in ent:
+                        out["roofline"]["traffic_range"] = ent["traffic_bytes_range"]
+                else:
+                    out["roofline"]["traffic_note"] = ("profiles/latest_traffic.json holds a figure for other kernel sources (%s, now %s): "
+                                                       "not attached" % (ent.get("csrc_sha256"), src))
     except (OSError, KeyError, ValueError):
         pass
 

@@ -14,7 +14,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+_LIB_PATH = os.environ.get("ORACLE_LIB") or os.path.join(_HERE, "_build", "liboracle.so")  # ORACLE_LIB: the sanitizer build
 
 FAM_AC, FAM_LONGEST, FAM_WHOLEWORD, FAM_SHORTEST, FAM_WWLONGEST = 0, 1, 2, 3, 4
 E_ILLEGAL_ARGUMENT = -2
@@ -38,7 +38,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
+        if not os.path.exists(_LIB_PATH) and not os.environ.get("ORACLE_LIB"):
             build_lib()
         L = ctypes.CDLL(_LIB_PATH)
         vp, i32, i64, u32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32

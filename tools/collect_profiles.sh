@@ -17,7 +17,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c5" -- pytho
 # ablation switches, which only the -DACGPU_ABLATION build has (tools/build_variant.sh abl -DACGPU_ABLATION, built before the
 # gpurun call: ahocorasick_amd/lib_abl/ travels with the snapshot); its full build is the product kernel plus the switches.
 export ACGPU_LIB=ahocorasick_amd/lib_abl/libacgpu.so
-[ -f "$ACGPU_LIB" ] || { echo "missing $ACGPU_LIB: run tools/build_variant.sh abl -DACGPU_ABLATION first"; unset ACGPU_LIB; }
+[ -f "$ACGPU_LIB" ] || { echo "missing $ACGPU_LIB: run tools/build_variant.sh abl -DACGPU_ABLATION first (the no-verify / stream-only variants would silently measure the product kernel)"; exit 3; }
 V='{"tile":{"force_kernel":2},"noverify":{"force_kernel":2,"tile_debug":1},"stream":{"force_kernel":2,"tile_debug":5}}'
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 tools/kbench.py --rounds 1 --variants "$V" > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 tools/kbench.py --rounds 1 --variants "$V" > "$OUT/pmc_write.log" 2>&1
@@ -29,10 +29,10 @@ unset ACGPU_LIB
 python3 bench.py --config C3 --steps 20 --warmup 3 > "$OUT/bench_c3_1gpu.json" 2> "$OUT/bench_c3_1gpu.err"
 bash tools/pmc_sq.sh "${1:-final}/pmc_sq_c4" '{"c4":{}}' "--config C4 --set" k_longest > "$OUT/pmc_sq_c4.txt" 2>&1
 bash tools/pmc_sq.sh "${1:-final}/pmc_sq_c5" '{"c5":{}}' "--config C5" k_ww_tile > "$OUT/pmc_sq_c5.txt" 2>&1
-for c in C4 C5; do
+for c in C2 C4 C5; do
   extra=""; [ $c = C4 ] && extra="--set"
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_$c" -- python3 tools/kbench.py --rounds 1 --config $c $extra --variants '{"k":{}}' > "$OUT/pmc_fetch_$c.log" 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_$c" -- python3 tools/kbench.py --rounds 1 --config $c $extra --variants '{"k":{}}' > "$OUT/pmc_write_$c.log" 2>&1
 done
-python3 tools/pmc_traffic_all.py "$OUT" > "$OUT/pmc_traffic_c4_c5.json" 2> "$OUT/pmc_traffic_c4_c5.err"
+python3 tools/pmc_traffic_all.py "$OUT" --latest "$OUT/latest_traffic.json" --tag "profiles/${2:-rNN}/${1:-final}_pmc_traffic_all.json" > "$OUT/pmc_traffic_all.json" 2> "$OUT/pmc_traffic_all.err"
 cat "$OUT/bench_c2.json"

@@ -70,6 +70,9 @@ def main():
                 N.set_tunable(k, v)
             nout, rc, prof, _ = a.match_device(d_hay.data_ptr(), n, not args.set, d_out.data_ptr(), cap,
                                                stream=torch.cuda.current_stream().cuda_stream, profile=True)
+            if (knobs.get("tile_debug", 0) & 0xfff or knobs.get("tile_debug", 0) >> 32) and N.set_tunable("ablation_build", 0) != 1:
+                raise SystemExit("kbench: the ablation bits of tile_debug need the -DACGPU_ABLATION build "
+                                 "(tools/build_variant.sh abl -DACGPU_ABLATION; ACGPU_LIB=ahocorasick_amd/lib_abl/libacgpu.so)")
             if r > 0:
                 res[name].append(prof["scan_ms"])
             info[name] = (nout, rc, prof["scan_kernel"], prof["finalize_ms"])

@@ -1,17 +1,25 @@
 #!/usr/bin/env python3
-"""HBM traffic of the config-4 / config-5 kernels from the counter passes of tools/collect_profiles.sh (rocprofv3 --pmc
-FETCH_SIZE and --pmc WRITE_SIZE, separate passes over tools/kbench.py --config C4|C5): per kernel, the counters of the last
-dispatch of each kernel, in bytes.   usage: pmc_traffic_all.py <dir with pmc_fetch_C4/ ... pmc_write_C5/>
+"""HBM traffic of the configurations' kernels from the counter passes of tools/collect_profiles.sh (rocprofv3 --pmc FETCH_SIZE
+and --pmc WRITE_SIZE, separate passes over tools/kbench.py --config C2|C4|C5): per kernel, the counters of the last dispatch of
+each kernel, in bytes, and per configuration the sum over the family's kernels.
+usage: pmc_traffic_all.py <dir with pmc_fetch_C4/ ... pmc_write_C5/> [--latest profiles/latest_traffic.json --tag profiles/r03/x.json]
 
-gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports half of the bytes of a wide coalesced streaming read
-(16 B per lane).  The dominant reads of these kernels are such streams (k_longest_walk_list: 16-byte text windows per lane;
-k_ww_tile: the haystack stream; k_longest_emit / chain: 16-byte pieces of len[]), so `traffic_bytes` = 2 x FETCH_SIZE +
-WRITE_SIZE, an upper estimate where a kernel also gathers (gathers are counted in full)."""
+gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports half of the bytes of a wide coalesced streaming read (16 B per
+lane).  That factor is applied PER KERNEL, and only to kernels whose reads are such streams (STREAMING below: the text stream
+of the scan kernels, 16-byte pieces of len[] through LDS-DMA, whole bitmap words); a kernel that gathers (synchronisation
+points, table probes, ordering passes that read scattered slots) is taken as reported, and a kernel that does both gets a
+RANGE [as reported, doubled] -- its figure is an estimate and is tagged so."""
 import collections
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+STREAMING = ("k_longest_block", "k_longest_chain_lds", "k_longest_emit_ends", "k_scan_", "k_stream_probe")  # reads: 16 B/lane streams only
+MIXED = ("k_ww_tile", "k_ac_tile", "k_longest_walk_list", "k_permute")                                       # a stream plus gathers
 
 
 def last_per_kernel(path, counter):
@@ -31,18 +39,39 @@ def last_per_kernel(path, counter):
 
 def main():
     d = sys.argv[1]
-    out = {}
-    for cfg, units in (("C4", 1 << 29), ("C5", 1 << 28)):
+    from ahocorasick_amd import _native as N
+    src = N.source_hash()
+    out = {"csrc_sha256": src}
+    latest = []
+    for cfg, units in (("C2", 1 << 29), ("C4", 1 << 29), ("C5", 1 << 28)):
         fetch = last_per_kernel("%s/pmc_fetch_%s" % (d, cfg), "FETCH_SIZE")
         write = last_per_kernel("%s/pmc_write_%s" % (d, cfg), "WRITE_SIZE")
+        if not fetch:
+            continue
         ks = {}
+        lo = hi = 0.0
         for k in fetch:
-            if k.startswith("k_synth"):
+            if k.startswith("k_synth") or k.startswith("k_token"):
                 continue
             f, w = fetch[k] * 1024, write.get(k, 0.0) * 1024
-            ks[k] = {"FETCH_SIZE_bytes_as_reported": f, "WRITE_SIZE_bytes": w, "traffic_bytes": 2 * f + w}
-        out[cfg] = {"units": units, "kernels": ks}
+            if k.startswith(STREAMING):
+                kind, a, b = "stream (FETCH_SIZE x2)", 2 * f + w, 2 * f + w
+            elif k.startswith(MIXED):
+                kind, a, b = "stream + gathers (range: FETCH_SIZE as reported .. x2)", f + w, 2 * f + w
+            else:
+                kind, a, b = "gathers (as reported)", f + w, f + w
+            ks[k] = {"FETCH_SIZE_bytes_as_reported": f, "WRITE_SIZE_bytes": w, "reads": kind, "traffic_bytes_range": [a, b]}
+            lo += a
+            hi += b
+        out[cfg] = {"units": units, "kernels": ks, "pipeline_traffic_bytes_range": [lo, hi]}
+        latest.append({"config": cfg, "units_per_gpu": units, "csrc_sha256": src, "traffic_bytes": hi, "traffic_bytes_range": [lo, hi],
+                       "source": "%s: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tools/kbench.py, summed over the "
+                                 "configuration's kernels; FETCH_SIZE x2 (gfx950 half-count of wide streaming reads, MI355X_MICROARCH.md) per "
+                                 "kernel where its reads are streams, as reported where they are gathers; `traffic` is the upper end of "
+                                 "`traffic_range`" % (sys.argv[sys.argv.index("--tag") + 1] if "--tag" in sys.argv else d)})
     print(json.dumps(out, indent=1))
+    if "--latest" in sys.argv:
+        json.dump(latest, open(sys.argv[sys.argv.index("--latest") + 1], "w"), indent=1)
 
 
 if __name__ == "__main__":
