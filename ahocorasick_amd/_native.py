@@ -96,7 +96,7 @@ def lib():
         L.acgpu_synth_tokens.restype = ci
         L.acgpu_synth_tokens.argtypes = [vp, u64, u64, vp, vp, u32, vp, vp]
         L.acgpu_stream_probe.restype = ci
-        L.acgpu_stream_probe.argtypes = [vp, u64, vp, ci, ctypes.POINTER(ctypes.c_float)]
+        L.acgpu_stream_probe.argtypes = [vp, u64, vp, ci, ci, ctypes.POINTER(ctypes.c_float)]
         L.acgpu_set_tunable.restype = i64
         L.acgpu_set_tunable.argtypes = [ctypes.c_char_p, i64]
         L.acgpu_strerror.restype = ctypes.c_char_p

@@ -1866,7 +1866,8 @@ int acgpu_match_batch_u16(const acgpu_automaton *ca, const uint16_t *units, cons
     return ACGPU_OK;
 }
 
-int acgpu_stream_probe(const void *d_buf, uint64_t n_bytes, void *stream_, int repeats, float *ms_median) {
+int acgpu_stream_probe(const void *d_buf, uint64_t n_bytes, void *stream_, int repeats, int pattern, float *ms_median) {
+    if (pattern != 0 && pattern != 1) return ACGPU_E_INVALID;
     if (!d_buf || !ms_median || ((uintptr_t)d_buf & 15) || n_bytes < (1ull << 20) || repeats < 1 || repeats > 64) return ACGPU_E_INVALID;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1882,7 +1883,7 @@ int acgpu_stream_probe(const void *d_buf, uint64_t n_bytes, void *stream_, int r
     if (hipMalloc((void **)&d_sink, 64) != hipSuccess) rc = ACGPU_E_NOMEM;
     for (int r = 0; rc == ACGPU_OK && r <= repeats; ++r) { // (the first run is a warm-up)
         float t = 0;
-        if (hipEventRecord(e0, stream) != hipSuccess || launch_stream_probe(d_buf, n_bytes, n_cu, d_sink, stream) != hipSuccess ||
+        if (hipEventRecord(e0, stream) != hipSuccess || launch_stream_probe(d_buf, n_bytes, n_cu, d_sink, pattern, stream) != hipSuccess ||
             hipEventRecord(e1, stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
             hipEventElapsedTime(&t, e0, e1) != hipSuccess) {
             g_last_hip_error = (int)hipGetLastError();

@@ -129,7 +129,7 @@ uint32_t tile_reserve_slots();
 uint32_t tile_group_units(); // regions must hold whole tile groups
 
 // pure read of n_bytes in the tile kernels' access pattern (see acgpu_stream_probe)
-hipError_t launch_stream_probe(const void *d_buf, uint64_t n_bytes, int n_cu, unsigned *d_sink, hipStream_t stream);
+hipError_t launch_stream_probe(const void *d_buf, uint64_t n_bytes, int n_cu, unsigned *d_sink, int pattern, hipStream_t stream);
 
 hipError_t launch_synth_fill(uint16_t *d_dst, uint64_t n, uint64_t start, uint64_t seed, const uint16_t *table,
                              uint32_t table_len, hipStream_t stream);

@@ -722,7 +722,36 @@ __global__ __launch_bounds__(1024) void k_stream_probe(const uint4 *__restrict__
     if (x == 0x12345678u) sink[0] = x;
 }
 
-hipError_t launch_stream_probe(const void *d_buf, uint64_t n_bytes, int n_cu, unsigned *d_sink, hipStream_t stream) {
+// The fastest pure read found on this chip (tools/micro/stream_patterns.hip, pattern B2): groups of four 2 KiB tiles dealt
+// round robin to the waves of 2048 small workgroups, 32 bytes per lane and tile, four tiles in flight -- 6.2-6.3 TB/s where the
+// tile kernels' own pattern (k_stream_probe: one contiguous span per wave, 64 bytes per lane) reads at 5.4.  The ceiling
+// bench.py reports as roofline.attainable.
+__global__ __launch_bounds__(256) void k_stream_probe_best(const uint4 *__restrict__ p, uint64_t n_groups, unsigned *sink) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+    const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x / 64);
+    uint32_t x = 0;
+    for (uint64_t g = wave; g < n_groups; g += n_waves) {
+        uint4 buf[4][2];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const uint4 *b = p + (g * 4 + d) * 128;
+            buf[d][0] = b[lane * 2];
+            buf[d][1] = b[lane * 2 + 1];
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) x ^= buf[d][0].x ^ buf[d][0].y ^ buf[d][0].z ^ buf[d][0].w ^ buf[d][1].x ^ buf[d][1].y ^ buf[d][1].z ^ buf[d][1].w;
+    }
+    if (x == 0x12345678u) sink[0] = x;
+}
+
+hipError_t launch_stream_probe(const void *d_buf, uint64_t n_bytes, int n_cu, unsigned *d_sink, int pattern, hipStream_t stream) {
+    if (pattern == 1) {
+        const uint64_t n_groups = n_bytes / 8192;
+        if (n_groups == 0) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(k_stream_probe_best, dim3(n_cu * 8), dim3(256), 0, stream, reinterpret_cast<const uint4 *>(d_buf), n_groups, d_sink);
+        return hipGetLastError();
+    }
     const uint64_t n_tiles = n_bytes / 4096;
     if (n_tiles == 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_stream_probe, dim3(n_cu), dim3(1024), 0, stream, reinterpret_cast<const uint4 *>(d_buf), n_tiles, d_sink);

@@ -205,15 +205,20 @@ def main():
         dist.all_gather_object(per_rank, mine)
         out["roofline"]["per_rank"] = per_rank
 
-    # attainable ceiling: a pure read of this shard in the tile kernels' access pattern, timed in this run
+    # attainable ceiling: the fastest pure read of this shard found on the chip (pattern 1), timed in this run; and what the
+    # tile kernels' own access pattern reads at (pattern 0: their stream alone)
     ms = ctypes.c_float(0)
-    if N.lib().acgpu_stream_probe(matcher.own_ptr(), n_units * 2, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), 7,
-                                  ctypes.byref(ms)) == N.OK and ms.value > 0:
+    cur = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if N.lib().acgpu_stream_probe(matcher.own_ptr(), n_units * 2, cur, 7, 1, ctypes.byref(ms)) == N.OK and ms.value > 0:
         att = n_units * 2 / (ms.value * 1e-3) / 1e9
         out["roofline"]["attainable"] = round(att, 1)
         out["roofline"]["attainable_ms"] = round(ms.value, 4)
         out["roofline"]["frac_of_attainable"] = round(achieved / att, 4)
-        out["roofline"]["attainable_what"] = "k_stream_probe: pure read of the shard, one wave span per wave, 64 B per lane and tile"
+        out["roofline"]["attainable_what"] = ("k_stream_probe_best: the fastest pure read of the shard found on this chip (2 KiB tiles dealt "
+                                              "round robin to 2048 workgroups of 256 lanes, 32 B per lane, four tiles in flight)")
+    if N.lib().acgpu_stream_probe(matcher.own_ptr(), n_units * 2, cur, 7, 0, ctypes.byref(ms)) == N.OK and ms.value > 0:
+        out["roofline"]["kernel_pattern_read_gbps"] = round(n_units * 2 / (ms.value * 1e-3) / 1e9, 1)
+        out["roofline"]["kernel_pattern_what"] = "k_stream_probe: the tile kernels' own pattern as a pure read (one span per wave, 64 B per lane and tile)"
 
     # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (counters cannot be read from inside
     # this process); the committed measurement is attached when it is for THIS configuration, this size and these kernel

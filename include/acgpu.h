@@ -302,12 +302,14 @@ int acgpu_synth_tokens(uint16_t *d_dst, uint64_t n_units, uint64_t seed, const u
 
 /*
  * Measurement helper ("also report vs. a measured streaming-read kernel on the same box"): a pure read
- * of n_bytes (>= 1 MiB, 16-byte aligned device pointer) in the access pattern of the tile kernels -- every wave a
- * contiguous span, 64 bytes per lane and tile, the next tile's loads in flight.  Runs `repeats` timed launches after a
- * warm-up (HIP events on `stream`, synchronous) and returns the median in *ms_median: the attainable ceiling bench.py
- * reports next to the 8 TB/s spec peak.
+ * of n_bytes (>= 1 MiB, 16-byte aligned device pointer), `repeats` timed launches after a warm-up (HIP events on `stream`,
+ * synchronous), the median in *ms_median.
+ *  pattern 1: the fastest pure read found on this chip (groups of 2 KiB tiles dealt round robin to small workgroups, 32 bytes
+ *             per lane): the attainable ceiling bench.py reports next to the 8 TB/s spec peak;
+ *  pattern 0: the access pattern of the tile kernels themselves -- every wave a contiguous span, 64 bytes per lane and tile,
+ *             the next tile's loads in flight -- i.e. what their stream alone costs.
  */
-int acgpu_stream_probe(const void *d_buf, uint64_t n_bytes, void *stream, int repeats, float *ms_median);
+int acgpu_stream_probe(const void *d_buf, uint64_t n_bytes, void *stream, int repeats, int pattern, float *ms_median);
 
 /* tuning knobs: DEVELOPMENT AND TEST HOOK, not part of the product surface a JVM binds.  Process-wide, read when a call
  * is enqueued; set them only while no match call is running (each knob is a relaxed atomic, so a concurrent reader sees

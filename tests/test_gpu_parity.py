@@ -1738,7 +1738,9 @@ def test_stream_probe_reports_a_plausible_read_bandwidth():
     import torch
     d = torch.zeros(1 << 27, dtype=torch.int16, device="cuda")  # 256 MiB
     ms = ctypes.c_float(0)
-    N.check(N.lib().acgpu_stream_probe(d.data_ptr(), d.numel() * 2, None, 5, ctypes.byref(ms)), "probe")
-    gbps = d.numel() * 2 / (ms.value * 1e-3) / 1e9
-    assert 500 < gbps < 8000, gbps  # below the 8 TB/s spec peak, far above anything a host path reaches
-    assert N.lib().acgpu_stream_probe(d.data_ptr() + 2, 1 << 21, None, 5, ctypes.byref(ms)) == N.E_INVALID
+    for pattern in (0, 1):  # the tile kernels' own pattern, the fastest pure read
+        N.check(N.lib().acgpu_stream_probe(d.data_ptr(), d.numel() * 2, None, 5, pattern, ctypes.byref(ms)), "probe")
+        gbps = d.numel() * 2 / (ms.value * 1e-3) / 1e9
+        assert 500 < gbps < 8000, gbps  # below the 8 TB/s spec peak, far above anything a host path reaches
+    assert N.lib().acgpu_stream_probe(d.data_ptr(), 1 << 21, None, 5, 2, ctypes.byref(ms)) == N.E_INVALID
+    assert N.lib().acgpu_stream_probe(d.data_ptr() + 2, 1 << 21, None, 5, 0, ctypes.byref(ms)) == N.E_INVALID
