@@ -46,6 +46,20 @@ public class GpuAhoCorasickMap<T> implements StringMap<T>, AutoCloseable {
         }
     }
 
+    /**
+     * Not in the reference: {@link #match(String, MapMatchListener)} for every haystack of an array in ONE device call (see
+     * GpuAhoCorasickSet.matchBatch). A listener call that returns false ends THAT haystack's matches.
+     */
+    public void matchBatch(final String[] haystacks, final MapMatchListener<T> listener) {
+        final int[] r = automaton.matchBatch(haystacks, true);
+        int skip = -1;
+        for (int i = 0; i < r.length; i += 4) {
+            if (r[i] != skip && !listener.match(haystacks[r[i]], r[i + 1], r[i + 2], values.get(r[i + 3]))) {
+                skip = r[i];
+            }
+        }
+    }
+
     /** Chunked scan through acgpu_stream_*: the listener receives only the value; false stops scan and reading. */
     public void match(final Readable haystack, final ReadableMatchListener<T> listener) throws IOException {
         final java.nio.CharBuffer buf = java.nio.CharBuffer.allocate(1 << 22);

@@ -38,6 +38,20 @@ public class GpuAhoCorasickSet implements StringSet, AutoCloseable {
         }
     }
 
+    /**
+     * Not in the reference: {@link #match(String, SetMatchListener)} for every haystack of an array in ONE device call (short
+     * inputs: a call has tens of microseconds of fixed cost). A listener call that returns false ends THAT haystack's matches.
+     */
+    public void matchBatch(final String[] haystacks, final SetMatchListener listener) {
+        final int[] r = automaton.matchBatch(haystacks, false);
+        int skip = -1;
+        for (int i = 0; i < r.length; i += 3) {
+            if (r[i] != skip && !listener.match(haystacks[r[i]], r[i + 1], r[i + 2])) {
+                skip = r[i];
+            }
+        }
+    }
+
     public void close() {
         automaton.close();
     }

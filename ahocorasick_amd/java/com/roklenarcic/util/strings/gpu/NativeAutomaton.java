@@ -28,6 +28,15 @@ final class NativeAutomaton implements AutoCloseable {
         return match(handle, haystack, withIds);
     }
 
+    /**
+     * acgpu_match_batch_u16: many short haystacks in ONE device call (a call has tens of microseconds of fixed cost).
+     * Returns (haystackIndex,start,end[,keywordIndex]) tuples, flattened, haystack by haystack, inside a haystack in the
+     * reference's listener-call order; positions are relative to their haystack.
+     */
+    int[] matchBatch(String[] haystacks, boolean withIds) {
+        return matchBatch(handle, haystacks, withIds);
+    }
+
     /** acgpu_stream_*: the haystack arrives in chunks; returns a stream handle for {@link #feed}. */
     long openStream() {
         return streamOpen(handle);
@@ -54,6 +63,8 @@ final class NativeAutomaton implements AutoCloseable {
     private static native long build(int mode, String[] keywords, boolean caseSensitive, char[] lower, boolean[] wordChars);
 
     private static native int[] match(long handle, String haystack, boolean withIds);
+
+    private static native int[] matchBatch(long handle, String[] haystacks, boolean withIds);
 
     private static native void free(long handle);
 

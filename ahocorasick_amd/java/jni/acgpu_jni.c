@@ -167,6 +167,60 @@ JNIEXPORT jintArray JNICALL Java_com_roklenarcic_util_strings_gpu_NativeAutomato
     return out;
 }
 
+/* many short haystacks in one device call: acgpu_match_batch_u16 */
+JNIEXPORT jintArray JNICALL Java_com_roklenarcic_util_strings_gpu_NativeAutomaton_matchBatch(JNIEnv *env, jclass cls, jlong handle,
+                                                                                               jobjectArray haystacks, jboolean withIds) {
+    (void)cls;
+    if (!haystacks) {
+        throw_new(env, "java/lang/NullPointerException", "haystacks");
+        return NULL;
+    }
+    const acgpu_automaton *a = (const acgpu_automaton *)(intptr_t)handle;
+    const jsize n = (*env)->GetArrayLength(env, haystacks);
+    const int kind = withIds ? ACGPU_REC_MAP : ACGPU_REC_SET;
+    uint64_t *off = (uint64_t *)calloc((size_t)n + 1, sizeof(uint64_t));
+    jchar *units = NULL;
+    void *buf = NULL;
+    jintArray out = NULL;
+    if (!off) { throw_oom(env, "haystack offsets"); return NULL; }
+    uint64_t total = 0;
+    for (jsize i = 0; i < n; i++) {
+        jstring s = (jstring)(*env)->GetObjectArrayElement(env, haystacks, i);
+        if (!s) { throw_new(env, "java/lang/NullPointerException", "haystack"); goto done; } /* reference: haystack.length() on null */
+        total += (uint64_t)(*env)->GetStringLength(env, s);
+        off[i + 1] = total;
+        (*env)->DeleteLocalRef(env, s);
+    }
+    units = (jchar *)malloc((size_t)(total ? total : 1) * sizeof(jchar));
+    if (!units) { throw_oom(env, "haystack copies"); goto done; }
+    for (jsize i = 0; i < n; i++) {
+        jstring s = (jstring)(*env)->GetObjectArrayElement(env, haystacks, i);
+        (*env)->GetStringRegion(env, s, 0, (jsize)(off[i + 1] - off[i]), units + off[i]);
+        (*env)->DeleteLocalRef(env, s);
+        if ((*env)->ExceptionCheck(env)) goto done;
+    }
+    {
+        uint64_t cap = total / 16 + 4096, n_out = 0;
+        buf = malloc(cap * (size_t)(kind + 4));
+        if (!buf) { throw_oom(env, "match records"); goto done; }
+        int rc = acgpu_match_batch_u16(a, (const uint16_t *)units, off, (uint32_t)n, kind, buf, cap, &n_out);
+        if (rc == ACGPU_E_OVERFLOW) { /* retry once with the exact capacity */
+            cap = n_out;
+            void *bigger = realloc(buf, cap * (size_t)(kind + 4));
+            if (!bigger) { throw_oom(env, "match records"); goto done; }
+            buf = bigger;
+            rc = acgpu_match_batch_u16(a, (const uint16_t *)units, off, (uint32_t)n, kind, buf, cap, &n_out);
+        }
+        if (rc == ACGPU_OK) out = to_int_array(env, buf, n_out * (uint64_t)(kind / 4 + 1));
+        else throw_rc(env, rc);
+    }
+done:
+    free(buf);
+    free(units);
+    free(off);
+    return out;
+}
+
 JNIEXPORT void JNICALL Java_com_roklenarcic_util_strings_gpu_NativeAutomaton_free(JNIEnv *env, jclass cls, jlong handle) {
     (void)env;
     (void)cls;

@@ -34,5 +34,5 @@ for c in C2 C4 C5; do
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_$c" -- python3 tools/kbench.py --rounds 1 --config $c $extra --variants '{"k":{}}' > "$OUT/pmc_fetch_$c.log" 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_$c" -- python3 tools/kbench.py --rounds 1 --config $c $extra --variants '{"k":{}}' > "$OUT/pmc_write_$c.log" 2>&1
 done
-python3 tools/pmc_traffic_all.py "$OUT" --latest "$OUT/latest_traffic.json" --tag "profiles/${2:-rNN}/${1:-final}_pmc_traffic_all.json" > "$OUT/pmc_traffic_all.json" 2> "$OUT/pmc_traffic_all.err"
+python3 tools/pmc_traffic_all.py "$OUT" --c2-calibrated "$OUT/pmc_traffic.json" --latest "$OUT/latest_traffic.json" --tag "profiles/${2:-rNN}/${1:-final}_pmc_traffic_all.json" > "$OUT/pmc_traffic_all.json" 2> "$OUT/pmc_traffic_all.err"
 cat "$OUT/bench_c2.json"

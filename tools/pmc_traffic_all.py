@@ -18,8 +18,11 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-STREAMING = ("k_longest_block", "k_longest_chain_lds", "k_longest_emit_ends", "k_scan_", "k_stream_probe")  # reads: 16 B/lane streams only
-MIXED = ("k_ww_tile", "k_ac_tile", "k_longest_walk_list", "k_permute")                                       # a stream plus gathers
+STREAMING = ("k_longest_chain_lds", "k_longest_emit_ends", "k_scan_", "k_stream_probe")        # reads: 16 B/lane streams only
+MIXED = ("k_ww_tile", "k_ac_tile", "k_longest_block", "k_longest_walk_list", "k_permute")       # a stream plus gathers
+
+
+GENERATORS = ("k_synth", "k_token")  # the benchmark's input generators (and everything dispatched before them: their prefix sums)
 
 
 def last_per_kernel(path, counter):
@@ -31,9 +34,12 @@ def last_per_kernel(path, counter):
             if r["Counter_Name"] != counter or "acgpu::" not in r["Kernel_Name"]:
                 continue
             rows[int(r["Dispatch_Id"])] += float(r["Counter_Value"])
-            names[int(r["Dispatch_Id"])] = r["Kernel_Name"].split("(")[0].replace("void acgpu::", "")
+            names[int(r["Dispatch_Id"])] = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("acgpu::", "")
+        gen = [d for d in names if names[d].startswith(GENERATORS)]
+        first = max(gen) + 1 if gen else 0
         for d in sorted(rows):
-            per[names[d]] = rows[d]  # the last dispatch of every kernel wins
+            if d >= first:
+                per[names[d]] = rows[d]  # the last dispatch of every kernel wins
     return per
 
 
@@ -51,8 +57,6 @@ def main():
         ks = {}
         lo = hi = 0.0
         for k in fetch:
-            if k.startswith("k_synth") or k.startswith("k_token"):
-                continue
             f, w = fetch[k] * 1024, write.get(k, 0.0) * 1024
             if k.startswith(STREAMING):
                 kind, a, b = "stream (FETCH_SIZE x2)", 2 * f + w, 2 * f + w
@@ -69,6 +73,17 @@ def main():
                                  "configuration's kernels; FETCH_SIZE x2 (gfx950 half-count of wide streaming reads, MI355X_MICROARCH.md) per "
                                  "kernel where its reads are streams, as reported where they are gathers; `traffic` is the upper end of "
                                  "`traffic_range`" % (sys.argv[sys.argv.index("--tag") + 1] if "--tag" in sys.argv else d)})
+    if "--c2-calibrated" in sys.argv:
+        # config 2's tile kernel has a better figure: tools/pmc_traffic.py calibrates the half-count on the kernel's own
+        # stream-only build and applies it to the stream alone (gathers as reported)
+        cal = json.load(open(sys.argv[sys.argv.index("--c2-calibrated") + 1]))
+        for ent in latest:
+            if ent["config"] == "C2" and "C2" in out:
+                perm = sum(v["traffic_bytes_range"][1] for k, v in out["C2"]["kernels"].items() if not k.startswith("k_ac_tile"))
+                ent["traffic_bytes"] = cal["traffic_bytes_corrected"]
+                ent["traffic_bytes_all_kernels"] = cal["traffic_bytes_corrected"] + perm
+                ent["source"] += "; config 2: `traffic` is the tile kernel's, from the calibrated passes of tools/pmc_traffic.py (" + cal["calibration"] + ")"
+        out["C2"]["tile_kernel_calibrated"] = cal
     print(json.dumps(out, indent=1))
     if "--latest" in sys.argv:
         json.dump(latest, open(sys.argv[sys.argv.index("--latest") + 1], "w"), indent=1)
