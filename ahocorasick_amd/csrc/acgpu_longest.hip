@@ -1353,7 +1353,12 @@ __global__ __launch_bounds__(kEmitBlock, 8) void k_longest_emit_ends(LongestChai
 // lengths come through LDS in chunks of 256 positions: a lane requests its whole chunk at once (32 independent 16-byte
 // loads: one memory latency per 256 positions instead of one per 16) and then walks it with LDS reads.  The walk is cheap
 // enough to run twice -- count, (prefix sum), write -- without the bitmap and the separate emit pass.
-constexpr int kC2Pieces = 32; // 16-byte pieces per lane and chunk: 512 bytes, loaded by one half wave of one LDS-DMA instruction
+// (measured at config 4 with one-byte lengths, whole chain pipeline: 32 pieces / 1 wave per SIMD / 4096-position tiles 0.795 ms;
+// 16 pieces / 2 waves per SIMD: 0.75 at 4096-position tiles, 0.65 at 6144, 0.67 at 8192; 8 pieces / 4 waves: 0.70 / 0.68 / 0.73)
+#ifndef ACGPU_C2PIECES
+#define ACGPU_C2PIECES 16
+#endif
+constexpr int kC2Pieces = ACGPU_C2PIECES; // 16-byte pieces per lane and chunk: 512 bytes, loaded by one half wave of one LDS-DMA instruction
                               // (global_load_lds_dwordx4: lane i's 16 bytes land at base + 16 i) -- 256 positions of 16-bit
                               // lengths, 512 positions of one-byte lengths
 
@@ -1361,7 +1366,7 @@ constexpr int kC2Pieces = 32; // 16-byte pieces per lane and chunk: 512 bytes, l
 // (chunks start on a bitmap word) and merged into the zeroed bitmap with one atomicOr per non-zero word; these stores are
 // issued when a chunk is done and complete under the next chunk's load.
 #ifndef ACGPU_C2WAVES
-#define ACGPU_C2WAVES 1
+#define ACGPU_C2WAVES 2
 #endif
 #ifdef ACGPU_TIMING
 __device__ unsigned long long g_c2_timing[8]; // total, zero+issue, load wait, walk, bit stores, chunks (per-wave sums)
