@@ -96,6 +96,7 @@ struct DeviceState {
     hipStream_t copy_stream = nullptr;
     std::vector<hipEvent_t> chunk_ev;
     DevBuf short_recs, short_nxt, short_tmp, short_mark; // SHORTEST: all-matches list + selection scratch
+    DevBuf ww_recs;                                      // WHOLEWORD: region-local record slots (TileLaunch::d_region_recs)
     DevBuf blockmax;                                     // LONGEST: farthest landing per 64 positions
     DevBuf lenbig, todo;                                 // LONGEST: escaped lengths; root-table form: flagged chunks
     DevBuf chainbits;                                    // LONGEST: one bit per position, set where the chain reports a match
@@ -116,7 +117,7 @@ struct DeviceState {
         counter.release(); chunk_counts.release(); offsets.release(); scan_tmp.release(); scratch.release();
         chain.release(); lenbuf.release(); statebuf.release(); stage_hay.release(); stage_out.release();
         short_recs.release(); short_nxt.release(); short_tmp.release(); short_mark.release();
-        wwl_rs.release(); wwl_mend.release(); wwl_mid.release(); wwl_sel.release(); wwl_stop.release(); wwl_nxt0.release(); blockmax.release(); lenbig.release(); todo.release(); chainbits.release(); cands.release(); region_cands.release();
+        wwl_rs.release(); wwl_mend.release(); wwl_mid.release(); wwl_sel.release(); wwl_stop.release(); wwl_nxt0.release(); ww_recs.release(); blockmax.release(); lenbig.release(); todo.release(); chainbits.release(); cands.release(); region_cands.release();
         if (h_counter) (void)hipHostFree(h_counter);
         for (auto &q : pin) if (q) (void)hipHostFree(q);
         if (batch_pin) (void)hipHostFree(batch_pin);
@@ -360,8 +361,8 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
     uint64_t scanned = 0;
     uint32_t n_chunks = 0, chunk_units = 0, perm_base = (uint32_t)sh->own_begin;
     const uint32_t *id_map = nullptr;
-    bool split = false, fused_finalize = false;
-    uint32_t regions_per_wg = 0;
+    bool split = false, fused_finalize = false, ww_direct = false;
+    uint32_t regions_per_wg = 0, ww_region_cap = 0;
     int by_start = 0;
     if (ww) {
         TileLaunch L{};
@@ -402,6 +403,16 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         L.d_scratch = (ScratchRec *)d.scratch.p;
         L.d_counter = counters;
         L.d_region_counts = (uint32_t *)d.chunk_counts.p;
+        // region-local record slots (a region of R units holds at most R/2 + 1 words): no slot reservations in the scan, and a
+        // coalesced copy instead of the permutation (tunable tile_debug bit 134217728: the scratch slices + k_permute, for A/B)
+        L.d_region_recs = nullptr;
+        L.region_cap = (uint32_t)(R / 2 + 1);
+        const uint64_t ww_rec_bytes = (uint64_t)L.n_regions * L.region_cap * 12;
+        if (!(tunables().tile_debug & 134217728) && ww_rec_bytes <= (24ull << 30)) {
+            if ((rc = d.ww_recs.ensure(ww_rec_bytes + 64))) return rc;
+            L.d_region_recs = (int32_t *)d.ww_recs.p;
+            ww_direct = true;
+        }
         HIP_TRY(hipMemsetAsync(d.chunk_counts.p, 0, (size_t)L.n_regions * 4, stream));
 #ifdef ACGPU_TIMING
         static DevBuf ww_timing;
@@ -430,6 +441,7 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         n_chunks = L.n_regions;
         chunk_units = L.region_units;
         scanned = own_len;
+        ww_region_cap = L.region_cap;
     } else if (use_tile_kernel(t)) {
         TileLaunch L{};
         L.block = tile_block_threads();
@@ -601,7 +613,10 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
     HIP_TRY(hipHostGetDevicePointer((void **)&d_slot, h_slot, 0));
     const PermuteTail tail{d_slot, (const uint64_t *)d.scan_tmp.p + scan_tiles_for(n_chunks), overflow_word, counters_next,
                            reinterpret_cast<acgpu_device_result *>(sh->d_result)};
-    if (fused_finalize)
+    if (ww_direct)
+        HIP_TRY(launch_ww_compact((const int32_t *)d.ww_recs.p, ww_region_cap, (const uint32_t *)d.chunk_counts.p, (const uint64_t *)d.offsets.p,
+                                  n_chunks, record_kind, d_out, cap, stream, &tail));
+    else if (fused_finalize)
         HIP_TRY(launch_permute_wg((const ScratchRec *)d.scratch.p, counters, n_slices, slice_slots, (const uint32_t *)d.chunk_counts.p,
                                   n_chunks, regions_per_wg, perm_base, chunk_units, record_kind, d_out, cap, id_map, stream, &tail));
     else

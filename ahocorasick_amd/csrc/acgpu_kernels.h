@@ -61,6 +61,12 @@ struct TileLaunch {
     uint2 *d_region_cands;
     uint32_t *d_overflow;
     int verify_grid;
+    // WholeWord, region-local records: a word belongs to the region of its first unit and a region of R units holds at most
+    // R/2 + 1 words, so every region owns region_cap 12-byte slots {start, end, id} of d_region_recs and a record goes
+    // straight to slot region * region_cap + rank -- no slot reservations, no (region, rank) tags; k_ww_compact then copies
+    // every region's records, whole and coalesced, to its final place (offsets = prefix sum of the region counts)
+    int32_t *d_region_recs; // nullptr: the scratch slices + k_permute
+    uint32_t region_cap;
     unsigned long long *d_timing; // -DACGPU_TIMING builds only: 8 cycle counters per wave (tools/build_variant.sh timing)
     uint32_t debug; // ablation switches (tunable "tile_debug"): 1 = drop candidates unverified, 4 = no filter arithmetic
                     // at all (stream + reduce only), 8 = verification without the text-window load, 16 = without the
@@ -110,6 +116,8 @@ hipError_t launch_publish_result(const unsigned long long *d_total, const unsign
 
 // scratch (unordered) -> final records in reference order
 // (slots whose rank is ~0u are holes left by slot reservations and are skipped)
+hipError_t launch_ww_compact(const int32_t *d_region_recs, uint32_t region_cap, const uint32_t *d_region_counts, const uint64_t *d_offsets,
+                             uint32_t n_regions, int record_kind, void *d_out, uint64_t out_cap, hipStream_t stream, const PermuteTail *tail);
 hipError_t launch_permute(const ScratchRec *d_scratch, const unsigned long long *d_counter, uint32_t n_slices, uint64_t slice_slots,
                           const uint64_t *d_offsets, uint32_t own_begin, uint32_t chunk_units, int by_start,
                           int record_kind, void *d_out, uint64_t out_cap, const uint32_t *d_id_map, hipStream_t stream,

@@ -377,6 +377,60 @@ __global__ __launch_bounds__(256) void k_permute(const ScratchRec *scratch, cons
     }
 }
 
+// WholeWord, region-local records (TileLaunch::d_region_recs): region r's records lie, in order, in its own slots; this pass
+// copies them -- whole regions, coalesced dwords -- to out[offsets[r] ...].  One workgroup per region (grid-stride).
+template <int REC>
+__global__ __launch_bounds__(256) void k_ww_compact(const int32_t *recs, uint32_t region_cap, const uint32_t *counts, const uint64_t *offsets,
+                                                   uint32_t n_regions, int32_t *out, uint64_t cap, PermuteTail tail) {
+    if (blockIdx.x == 0) { // (see PermuteTail)
+        if (tail.zero_counters)
+            for (uint32_t i = threadIdx.x; i < (uint32_t)kMaxSlices; i += blockDim.x) {
+                tail.zero_counters[(size_t)i * kCounterStride] = 0;
+                tail.zero_counters[(size_t)i * kCounterStride + 1] = 0;
+            }
+        if (tail.result && threadIdx.x == 0) {
+            const unsigned long long total = *tail.total;
+            const uint32_t flag = tail.flag ? *tail.flag : 0u;
+            tail.result[0] = total;
+            tail.result[1] = flag;
+            if (tail.d_result) {
+                tail.d_result->n_records = total;
+                tail.d_result->redone = flag;
+                tail.d_result->reserved = 0;
+            }
+            if (tail.flag) *tail.flag = 0;
+            __threadfence_system();
+        }
+    }
+    constexpr uint32_t W = REC / 4; // dwords per output record
+    for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {
+        const uint64_t off = offsets[r];
+        if (off >= cap) continue;
+        const uint64_t n = min((uint64_t)counts[r], cap - off);
+        const int32_t *src = recs + (size_t)r * region_cap * 3;
+        // a record per lane and step: one 12-byte load, one 12- or 8-byte store
+        typedef int32_t v3i __attribute__((ext_vector_type(3)));
+        for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) {
+            const v3i rec = *reinterpret_cast<const v3i *>(src + i * 3);
+            if (W == 3) *reinterpret_cast<v3i *>(out + (off + i) * 3) = rec;
+            else reinterpret_cast<int2 *>(out)[off + i] = make_int2(rec.x, rec.y);
+        }
+    }
+}
+
+hipError_t launch_ww_compact(const int32_t *d_region_recs, uint32_t region_cap, const uint32_t *d_region_counts, const uint64_t *d_offsets,
+                             uint32_t n_regions, int record_kind, void *d_out, uint64_t out_cap, hipStream_t stream, const PermuteTail *tail) {
+    const PermuteTail tl = tail ? *tail : PermuteTail{nullptr, nullptr, nullptr, nullptr, nullptr};
+    const dim3 grid(std::max<uint32_t>(std::min<uint32_t>(n_regions, 8192u), 1u)), block(256);
+    if (record_kind == ACGPU_REC_SET)
+        hipLaunchKernelGGL(k_ww_compact<ACGPU_REC_SET>, grid, block, 0, stream, d_region_recs, region_cap, d_region_counts, d_offsets,
+                           n_regions, (int32_t *)d_out, out_cap, tl);
+    else
+        hipLaunchKernelGGL(k_ww_compact<ACGPU_REC_MAP>, grid, block, 0, stream, d_region_recs, region_cap, d_region_counts, d_offsets,
+                           n_regions, (int32_t *)d_out, out_cap, tl);
+    return hipGetLastError();
+}
+
 #ifndef ACGPU_PERMUTE_BLOCKS
 #define ACGPU_PERMUTE_BLOCKS 2048
 #endif

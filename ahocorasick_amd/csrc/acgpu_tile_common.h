@@ -45,6 +45,7 @@ struct TileCtx {
     // goes straight to the K-gram node (0: not known, the verification reads the text window first)
     uint16_t *pos16 = nullptr;
     uint32_t pos_base = 0;
+    uint32_t region = 0; // WholeWord, region-local records: the region the queued run starts belong to (wave-uniform)
 #ifdef ACGPU_TIMING
     unsigned long long vt[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // verification phases (k_ac_tile: windows, K-gram nodes, walks, emission;
                                                           // k_ww_tile: windows, chunk 1, chunk 2, hash + Bloom, probes, emission, calls)

@@ -330,10 +330,21 @@ __device__ __forceinline__ void ww_verify_hash(TileCtx &c, const uint32_t *wbits
         total += __builtin_amdgcn_readlane(incl, kWave - 1);
     }
     if (total == 0) return;
-    const SlotRange sr = reserve_slots(c, total);
+    if (L.d_region_recs) { // region-local records: the slot is the rank (see TileLaunch::d_region_recs)
+        int32_t *base = L.d_region_recs + ((size_t)c.region * L.region_cap + c.rank_base) * 3;
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
-        if (m[b]) store_rec(L, sr.slot(prefix[b]), s[b], s[b] + r[b], id[b], c.rank_base + prefix[b]);
+        for (int b = 0; b < NB; ++b)
+            if (m[b]) {
+                typedef int32_t v3i __attribute__((ext_vector_type(3)));
+                const v3i rec = {(int32_t)s[b], (int32_t)(s[b] + r[b]), (int32_t)id[b]};
+                __builtin_nontemporal_store(rec, reinterpret_cast<v3i *>(base + (size_t)prefix[b] * 3));
+            }
+    } else {
+        const SlotRange sr = reserve_slots(c, total);
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+            if (m[b]) store_rec(L, sr.slot(prefix[b]), s[b], s[b] + r[b], id[b], c.rank_base + prefix[b]);
+    }
     c.rank_base += total;
     WT_MARK(5)
 }
@@ -394,10 +405,20 @@ __device__ __forceinline__ void ww_verify(TileCtx &c, const uint32_t *wbits, uin
         total += __builtin_amdgcn_readlane(incl, kWave - 1);
     }
     if (total == 0) return;
-    const SlotRange sr = reserve_slots(c, total);
+    if (L.d_region_recs) {
+        int32_t *base = L.d_region_recs + ((size_t)c.region * L.region_cap + c.rank_base) * 3;
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
-        if (m[b]) store_rec(L, sr.slot(prefix[b]), s[b], i[b], id[b], c.rank_base + prefix[b]);
+        for (int b = 0; b < NB; ++b)
+            if (m[b]) {
+                int32_t *o = base + (size_t)prefix[b] * 3;
+                o[0] = (int32_t)s[b]; o[1] = (int32_t)i[b]; o[2] = (int32_t)id[b];
+            }
+    } else {
+        const SlotRange sr = reserve_slots(c, total);
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+            if (m[b]) store_rec(L, sr.slot(prefix[b]), s[b], i[b], id[b], c.rank_base + prefix[b]);
+    }
     c.rank_base += total;
 }
 
@@ -476,6 +497,7 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
     const uint16_t *hay = L.d_hay;
 
     uint32_t region = first_region;
+    c.region = region;
     uint32_t boundary = base8 + (region + 1) * R;
     uint32_t rb = span_begin;
     uint32_t re = min(span_end, boundary);
@@ -517,6 +539,7 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
                     if (lane == 0) L.d_region_counts[region] = c.rank_base;
                     c.rank_base = 0;
                     ++region;
+                    c.region = region;
                     rb = boundary;
                     boundary += R;
                     re = min(span_end, boundary);
@@ -569,6 +592,7 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
                 if (lane == 0) L.d_region_counts[region] = c.rank_base;
                 c.rank_base = 0;
                 ++region;
+                c.region = region;
             }
             const uint32_t pos = t0 + lane;
             uint32_t mask = 0;
