@@ -81,6 +81,7 @@ struct DeviceState {
     DevTables T{};
     const uint8_t *wflags_f = nullptr; // word-character tables of the loops that fold in every lookup (HostTables::wflags_f)
     const uint32_t *wbits_f = nullptr;
+    int start_behind = -1; // set for the duration of a batch call: the separator unit (k_wwl_starts: a haystack's first unit is a walk start)
     std::vector<void *> table_allocs;
     // scratch pool (one in-flight match per automaton and device)
     DevBuf counter, chunk_counts, offsets, scan_tmp, scratch, chain, lenbuf, statebuf;
@@ -1134,7 +1135,7 @@ int match_wwlongest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int rec
     if ((rc = d.counter.ensure(64))) return rc;
     d.cclean[0] = false; // (match_all's first set of slot counters lives here)
     if (prof) HIP_TRY(hipEventRecord(d.ev[0], stream));
-    HIP_TRY(launch_wwl_starts(T, sh->d_hay, n, d.n_cu, false, (uint32_t *)d.chunk_counts.p, nullptr, nullptr, sh->text_begin, stream));
+    HIP_TRY(launch_wwl_starts(T, sh->d_hay, n, d.n_cu, false, (uint32_t *)d.chunk_counts.p, nullptr, nullptr, sh->text_begin, d.start_behind, stream));
     HIP_TRY(launch_exclusive_scan((const uint32_t *)d.chunk_counts.p, n_tiles, (uint64_t *)d.offsets.p, (uint64_t *)d.scan_tmp.p,
                                   stream));
     HIP_TRY(hipMemcpyAsync(d.h_counter, (const uint64_t *)d.scan_tmp.p + scan_tiles_for(n_tiles), 8, hipMemcpyDeviceToHost,
@@ -1155,7 +1156,7 @@ int match_wwlongest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int rec
         HIP_TRY(hipMemcpyAsync(d.counter.p, d.h_counter + 2, 8, hipMemcpyHostToDevice, stream));
     }
     HIP_TRY(launch_wwl_starts(T, sh->d_hay, n, d.n_cu, true, nullptr, (const uint64_t *)d.offsets.p, (uint32_t *)d.wwl_rs.p,
-                              sh->text_begin, stream));
+                              sh->text_begin, d.start_behind, stream));
     HIP_TRY(launch_wwl_walk(T, plain_words, sh->d_hay, n, (const uint32_t *)d.wwl_rs.p, M, (uint32_t *)d.short_nxt.p,
                             (uint32_t *)d.short_mark.p, (int32_t *)d.wwl_mend.p, (int32_t *)d.wwl_mid.p, (uint32_t *)d.wwl_stop.p,
                             (uint32_t)entry, d.n_cu, stream));
@@ -1803,11 +1804,12 @@ int acgpu_match_batch_u16(const acgpu_automaton *ca, const uint16_t *units, cons
     acgpu_automaton *a = const_cast<acgpu_automaton *>(ca);
     const HostTables &t = a->t;
     const size_t out_rec = (size_t)record_kind + 4;
-    // no unit can stand between two haystacks (every one of the 65536 is in use), or a loop that only exists as a sequential
-    // kernel over one whole text: one call per haystack
-    const bool sequential_only = (t.mode == ACGPU_MODE_WHOLEWORD && !t.fold_consistent) ||
-                                 (t.mode == ACGPU_MODE_WWLONGEST && !t.fold_consistent && record_kind == ACGPU_REC_SET);
-    if (t.sep_unit < 0 || sequential_only) {
+    // no unit can stand between two haystacks (every one of the 65536 is in use), or a word matcher over a table that is not
+    // fold-consistent: one call per haystack.  (Such a table makes some loops sequential kernels over one whole text; and in
+    // the folding scans a keyword's FOLDED first unit need not be a word character, so a walk that begins at position 0 of a
+    // text -- where the scan starts whatever stands there -- is not a walk that begins behind a separator.)
+    const bool per_haystack = (t.mode == ACGPU_MODE_WHOLEWORD || t.mode == ACGPU_MODE_WWLONGEST) && !t.fold_consistent;
+    if (t.sep_unit < 0 || per_haystack) {
         std::vector<int32_t> tmp;
         uint64_t n = 0;
         for (uint32_t i = 0; i < n_haystacks; i++) {
@@ -1873,7 +1875,9 @@ int acgpu_match_batch_u16(const acgpu_automaton *ca, const uint16_t *units, cons
     sh.text_begin = 1;
     sh.text_end = 1;
     sh.chain_entry = 0;
+    d->start_behind = t.sep_unit; // (WholeWordLongest: every haystack's first unit is a walk start, as position 0 of a text is)
     rc = match_shard(a, *d, &sh, record_kind, d->stage_out.p, cap, n_out, nullptr, nullptr);
+    d->start_behind = -1;
     if (rc != ACGPU_OK) return rc; // ACGPU_E_OVERFLOW: *n_out is the capacity to retry with
     if (*n_out) {
         HIP_TRY(launch_batch_tag(d->stage_out.p, *n_out, record_kind, (const uint32_t *)d->batch_off.p, n_haystacks, d->batch_out.p, nullptr));

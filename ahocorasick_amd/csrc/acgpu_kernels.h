@@ -224,7 +224,8 @@ hipError_t launch_shortest_emit(const int32_t *d_recs, uint32_t M, const uint32_
 // WholeWordLongest (acgpu_wwlongest.hip)
 uint32_t wwl_tiles(uint32_t n_units);
 hipError_t launch_wwl_starts(const DevTables &t, const uint16_t *d_hay, uint32_t n, int n_cu, bool fill, uint32_t *d_counts,
-                             const uint64_t *d_offsets, uint32_t *d_rs, int text_begin, hipStream_t stream);
+                             const uint64_t *d_offsets, uint32_t *d_rs, int text_begin, int start_behind,
+                             hipStream_t stream);
 hipError_t launch_wwl_walk(const DevTables &t, bool plain_words, const uint16_t *d_hay, uint32_t n, const uint32_t *d_rs, uint32_t M,
                            uint32_t *d_nxt, uint32_t *d_mark, int32_t *d_mend, int32_t *d_mid, uint32_t *d_stop, uint32_t entry, int n_cu,
                            hipStream_t stream);

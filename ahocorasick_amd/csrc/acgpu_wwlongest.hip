@@ -40,7 +40,11 @@ __device__ __forceinline__ uint32_t wbit(const uint32_t *wbits, uint32_t unit) {
 // FILL == false: counts[tile] = walk starts in the tile.  FILL == true: RS[offsets[tile] + rank] = position.
 template <bool FILL>
 __global__ __launch_bounds__(kStartsBlock) void k_wwl_starts(DevTables T, const uint16_t *hay, uint32_t n, uint32_t n_tiles,
-                                                            uint32_t *counts, const uint64_t *offsets, uint32_t *rs, int text_begin) {
+                                                            uint32_t *counts, const uint64_t *offsets, uint32_t *rs, int text_begin,
+                                                            int start_behind) {
+    // start_behind >= 0 (acgpu_match_batch_u16: the separator unit): the unit behind every such unit is a walk start too --
+    // the first unit of a haystack, where the reference's scan starts whatever stands there (a keyword without word
+    // characters is kept as it is, R/WordCharacters.java:41-62, so the root can have a transition on a non-word unit)
     __shared__ uint32_t wbits[2048];
     __shared__ uint32_t wave_tot[kStartsBlock / kWave];
     for (uint32_t w = threadIdx.x; w < 2048; w += blockDim.x) wbits[w] = T.wbits[w];
@@ -48,17 +52,30 @@ __global__ __launch_bounds__(kStartsBlock) void k_wwl_starts(DevTables T, const 
     const uint32_t lane = lane_id(), wave = threadIdx.x / kWave;
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint32_t v = tile * kStartsTile + threadIdx.x * 8;
-        uint32_t wm = 0;
+        uint32_t wm = 0, bm = 0; // bm: bit j + 1 = unit v + j is start_behind
         if (v + 8 <= n) {
             const uint4 q = *reinterpret_cast<const uint4 *>(hay + v);
             const uint32_t ww[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) wm |= wbit(wbits, (ww[j >> 1] >> (16 * (j & 1))) & 0xffffu) << j;
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t u = (ww[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+                wm |= wbit(wbits, u) << j;
+                bm |= ((int)u == start_behind ? 2u : 0u) << j;
+            }
         } else {
-            for (uint32_t j = 0; j < 8 && v + j < n; ++j) wm |= wbit(wbits, hay[v + j]) << j;
+            for (uint32_t j = 0; j < 8 && v + j < n; ++j) {
+                wm |= wbit(wbits, hay[v + j]) << j;
+                bm |= ((int)hay[v + j] == start_behind ? 2u : 0u) << j;
+            }
         }
-        const uint32_t prev = (v > 0 && v <= n) ? wbit(wbits, hay[v - 1]) : 0u;
+        const uint32_t pu = (v > 0 && v <= n) ? (uint32_t)hay[v - 1] : 0x10000u;
+        const uint32_t prev = pu < 0x10000u ? wbit(wbits, pu) : 0u;
         uint32_t sm = wm & ~((wm << 1) | prev) & 0xffu;
+        if (start_behind >= 0) {
+            bm |= (int)pu == start_behind ? 1u : 0u;
+            const uint32_t in = v < n ? min(n - v, 8u) : 0u;
+            sm |= bm & ((1u << in) - 1u);
+        }
         if (v == 0 && n > 0 && text_begin) sm |= 1u; // the scan starts at position 0 of the TEXT whatever stands there
         const uint32_t cnt = __popc(sm);
         const uint32_t incl = wave_inclusive_scan(cnt);
@@ -401,12 +418,13 @@ hipError_t launch_wwl_bits_to_mark(const uint32_t *d_bits, uint32_t M, uint32_t 
 uint32_t wwl_tiles(uint32_t n_units) { return (n_units + kStartsTile - 1) / kStartsTile; }
 
 hipError_t launch_wwl_starts(const DevTables &t, const uint16_t *d_hay, uint32_t n, int n_cu, bool fill, uint32_t *d_counts,
-                             const uint64_t *d_offsets, uint32_t *d_rs, int text_begin, hipStream_t stream) {
+                             const uint64_t *d_offsets, uint32_t *d_rs, int text_begin, int start_behind,
+                             hipStream_t stream) {
     const uint32_t n_tiles = wwl_tiles(n);
     if (n_tiles == 0) return hipSuccess;
     const dim3 block(kStartsBlock), grid(std::min<uint32_t>(n_tiles, (uint32_t)n_cu * 8));
-    if (fill) hipLaunchKernelGGL(k_wwl_starts<true>, grid, block, 0, stream, t, d_hay, n, n_tiles, d_counts, d_offsets, d_rs, text_begin);
-    else hipLaunchKernelGGL(k_wwl_starts<false>, grid, block, 0, stream, t, d_hay, n, n_tiles, d_counts, d_offsets, d_rs, text_begin);
+    if (fill) hipLaunchKernelGGL(k_wwl_starts<true>, grid, block, 0, stream, t, d_hay, n, n_tiles, d_counts, d_offsets, d_rs, text_begin, start_behind);
+    else hipLaunchKernelGGL(k_wwl_starts<false>, grid, block, 0, stream, t, d_hay, n, n_tiles, d_counts, d_offsets, d_rs, text_begin, start_behind);
     return hipGetLastError();
 }
 

@@ -161,6 +161,10 @@ int acgpu_match_u16(const acgpu_automaton *a, const uint16_t *haystack, uint64_t
  *   end, keyword_id}; positions are relative to their haystack; order: haystack ascending, inside a haystack the
  *   reference's listener-call order.  The facade calls the listener per record and, if it returns false, skips the rest of
  *   THAT haystack's records.
+ * WholeWordLongest: the reference's scan starts a walk at position 0 whatever stands there (and a keyword without word
+ * characters gives the root a transition on a non-word unit), so the unit behind every separator is a walk start too.
+ * One call per haystack inside the library instead, same results: a dictionary that uses all 65536 units, and the word
+ * matchers over a table that is not fold-consistent (acgpu_info.fold_consistent == 0).
  * offsets[n_haystacks] - offsets[0] + n_haystacks must stay below 2^31.  On ACGPU_E_OVERFLOW *n_out is the capacity to retry with.
  */
 typedef struct acgpu_batch_set_match {

@@ -91,15 +91,47 @@ def one_case(rng, it):
     mode = [N.MODE_ALL, N.MODE_LONGEST, N.MODE_WHOLEWORD, N.MODE_SHORTEST, N.MODE_WWLONGEST][fam]
     ofam = [FAM_AC, FAM_LONGEST, FAM_WHOLEWORD, FAM_SHORTEST, FAM_WWLONGEST][fam]
     wc = WORD if fam in (2, 4) else None
-    a = Automaton(mode, kws, cs, word_chars=wc)
-    want = Oracle(ofam, kws, case_sensitive=cs, lower=LOWER, word_chars=wc).match(hay)
     with_ids = bool(rng.integers(0, 3))  # one case in three runs the Set flavour (8-byte records)
+    if fam in (2, 4) and rng.integers(0, 4) == 0:
+        # a word-character table that is not fold-consistent: some lower-case letters of the alphabet stop being word
+        # characters while their capitals stay (the reference's loops then differ in which lookups fold)
+        wc = WORD.copy()
+        for c in alpha:
+            if LOWER[c] != c and rng.integers(0, 2):
+                wc[LOWER[c]] = 0
+        if fam == 2:  # WholeWord keywords are validated on their raw units
+            ok = [c for c in alpha if wc[c]] or [ord("A")]
+            kws = [np.array(rng.choice(ok, max(1, len(k))), dtype=np.uint16) for k in kws]
+            wc[ord("A")] = 1
+    a = Automaton(mode, kws, cs, word_chars=wc)
+    orc = Oracle(ofam, kws, case_sensitive=cs, lower=LOWER, word_chars=wc, map_flavour=(fam == 4 and with_ids))
+    want = orc.match(hay)
+    if fam in (2, 4) and n and rng.integers(0, 3) == 0:
+        # match(Readable): the feeds' records are the Readable loop's (which folds in every lookup), under a random chunking
+        from ahocorasick_amd.strings import Stream
+        want_r = orc.match_readable(hay, int(rng.choice([1, 5, 1024])), positions=True)
+        st = Stream(a, with_ids=True)
+        cuts = sorted(set([0, n] + [int(x) for x in rng.integers(0, n + 1, int(rng.integers(0, 5)))]))
+        parts = [st.feed(hay[lo:hi], final=(hi == n), cap=8) for lo, hi in zip(cuts[:-1], cuts[1:])]
+        st.close()
+        got_r = np.concatenate(parts) if parts else np.zeros((0, 3), np.int64)
+        assert got_r.shape == want_r.shape and (got_r == want_r.astype(np.int64)).all(), ("stream", it, fam, cs, cuts)
+    if n and rng.integers(0, 4) == 0:
+        # the batch entry: the haystack cut into pieces, every piece its own haystack
+        cuts = sorted(set([0, n] + [int(x) for x in rng.integers(0, n + 1, int(rng.integers(1, 9)))]))
+        pieces = [hay[lo:hi] for lo, hi in zip(cuts[:-1], cuts[1:])] + [np.zeros(0, np.uint16)]
+        orc_b = orc if fam != 4 else Oracle(ofam, kws, case_sensitive=cs, lower=LOWER, word_chars=wc, map_flavour=True)  # (Map records)
+        want_b = np.concatenate([np.concatenate([np.full((len(r), 1), i, np.int32), r], axis=1) for i, r in
+                                 enumerate(orc_b.match(h) for h in pieces)])
+        got_b = a.match_batch(pieces, True, cap=16)
+        assert got_b.shape == want_b.shape and (got_b == want_b).all(), ("batch", it, fam, cs, cuts)
     if not with_ids:
         want = np.ascontiguousarray(want[:, :2])
     got = a.match_host(hay, with_ids, cap=64)
     desc = (it, fam, cs, with_ids, n_kw, min_len, max_len, n, len(alpha), knobs, a.info()["filter_k"], a.info()["tile_kernel"])
     assert got.shape == want.shape and (got == want).all(), ("host path", desc)
-    if n >= 1000:
+    fold_seq = wc is not None and not cs and a.info()["fold_consistent"] == 0 and (fam == 2 or not with_ids)
+    if n >= 1000 and not fold_seq:  # (the loops that mix raw and folded lookups exist for the whole text only)
         # shards of the device-resident buffer
         d_hay = torch.from_numpy(hay.view(np.int16)).cuda()
         cuts = sorted(set([0, n] + [int(x) for x in rng.integers(1, n, 2)]))

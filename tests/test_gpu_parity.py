@@ -896,6 +896,27 @@ def test_batch_of_short_haystacks_equals_one_call_per_haystack(family):
     assert auto.match_batch([], True).shape == (0, 4) and auto.match_batch([hays[3]], True).shape == (0, 4)
 
 
+def test_batch_wwlongest_keyword_without_word_characters_starts_a_walk_at_every_haystack():
+    """A keyword without word characters is kept untrimmed (R/WordCharacters.java:41-62), so the root has a transition on a
+    non-word unit; the reference's scan starts at position 0 whatever stands there, so in ' éa,' the walk that begins on the
+    space swallows it and the word behind it is skipped to its end -- 'éa' is NOT reported, while '.éa,' reports it.  In a batch
+    every haystack's first unit has to be such a walk start (found by the GPU fuzz, seed 2026)."""
+    from oracle.oracle import FAM_WWLONGEST
+    kws = [np.array([ord(c) for c in k], dtype=np.uint16) for k in (" ", "Éa", "b", ", ", "b a")]
+    auto = Automaton(N.MODE_WWLONGEST, kws, False, word_chars=WORD)
+    orc = Oracle(FAM_WWLONGEST, kws, case_sensitive=False, lower=LOWER, word_chars=WORD)
+    texts = ["b.", " éa, b", ".éa, b", "", " ", "  b a", ", b", "éa", " b"] * 40
+    hays = [np.array([ord(c) for c in s], dtype=np.uint16) for s in texts]
+    want = []
+    for i, h in enumerate(hays):
+        r = orc.match(h)
+        want.append(np.concatenate([np.full((len(r), 1), i, np.int32), r.reshape(-1, 3)], axis=1))
+    want = np.concatenate(want)
+    assert [1, 1, 3, 1] not in want.tolist() and [2, 1, 3, 1] in want.tolist()
+    got = auto.match_batch(hays, True, cap=len(want) + 8)
+    assert got.shape == want.shape and (got == want).all()
+
+
 def test_batch_facade_listener_and_a_dictionary_without_a_free_unit():
     m = AhoCorasickMap(["he", "she", "hers"], ["HE", "SHE", "HERS"], True)
     seen = []
