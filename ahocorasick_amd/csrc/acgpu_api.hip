@@ -1300,6 +1300,7 @@ int64_t acgpu_set_tunable(const char *name, int64_t value) {
     else if (!std::strcmp(name, "ww_first_seed")) slot = &t.ww_first_seed;
     else if (!std::strcmp(name, "rdense_budget_bytes")) slot = &t.rdense_budget_bytes;
     else if (!std::strcmp(name, "filter_max_bytes")) slot = &t.filter_max_bytes;
+    else if (!std::strcmp(name, "no_merged_ranges")) slot = &t.no_merged_ranges;
     if (!slot) return -1;
     return slot->exchange(value, std::memory_order_relaxed);
 }

@@ -518,6 +518,40 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
         }
         // folded range classes (see HostTables::fold_range)
         t.fold_range = false;
+        // Two merged ranges (case-sensitive dictionaries with 33 .. 64 classes whose units lie in two stretches of at most 31
+        // code points each -- keywords in mixed case): unit u of either stretch gets the class u - (start of its stretch), so
+        // the filter is the packed two-range arithmetic of the folded range classes with 4-byte rows and the second level
+        // (a superset test: 'T' and 't' share a class), and the verification is the bucketed form's -- the K units
+        // themselves looked up, the walk through the unit-keyed hashed edges.
+        bool merged = false;
+        uint32_t mg_lo = 0, mg_hi = 0, mg_span = 0;
+        if (t.cs && !t.hashk && t.n_cls > 32 && t.min_len >= 2 && !tunables().force_sparse && !tunables().no_merged_ranges) {
+            std::vector<uint32_t> used;
+            {
+                std::vector<uint8_t> seen(65536, 0);
+                for (uint32_t i = 1; i < N; i++) seen[nodes[i].unit] = 1;
+                for (uint32_t u = 0; u < 65536; u++) if (seen[u]) used.push_back(u);
+            }
+            // the cut between two used units that gives the shortest pair of disjoint stretches
+            for (size_t cut = 1; cut < used.size(); cut++) {
+                const uint32_t lo = used.front(), hi = used[cut];
+                const uint32_t span = std::max(used[cut - 1] - lo + 1, used.back() - hi + 1);
+                if (span <= 31 && lo + span <= hi && hi + span < 65536 && (!merged || span < mg_span)) {
+                    merged = true;
+                    mg_lo = lo; mg_hi = hi; mg_span = span;
+                }
+            }
+            if (merged) {
+                t.hashk = true; // (K-gram and edges by the units themselves)
+                t.fold_range = true;
+                t.fr_base = mg_hi; t.fr_span = mg_span; t.fr_base2 = mg_lo; t.fr_himask = 0;
+                t.tile_lut.assign(65536, (uint16_t)mg_span);
+                for (uint32_t i = 0; i < mg_span; i++) {
+                    t.tile_lut[mg_lo + i] = (uint16_t)i;
+                    t.tile_lut[mg_hi + i] = (uint16_t)i;
+                }
+            }
+        }
         if (!t.cs && !t.hashk && !t.range_cls && !tunables().force_sparse) {
             uint32_t minu = 65535, maxu = 0;
             for (uint32_t i = 1; i < N; i++) {
@@ -564,11 +598,12 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
                 }
             }
         }
-        const uint32_t n = t.hashk ? 64 : t.fold_range ? t.fr_span + 1 : t.n_cls;
+        const uint32_t n = t.fold_range ? t.fr_span + 1 : t.hashk ? 64 : t.n_cls;
         t.filt_n = n;
-        t.filt_other = t.hashk ? 0 : t.fold_range ? t.fr_span : t.range_cls ? t.cls_span : 0;
+        t.filt_other = t.fold_range ? t.fr_span : t.hashk ? 0 : t.range_cls ? t.cls_span : 0;
         t.filt_row_bytes = n <= 32 ? 4 : 8;
         auto tcls = [&](uint16_t folded_unit) -> uint32_t {
+            if (merged) return (uint32_t)folded_unit - (folded_unit >= mg_hi ? mg_hi : mg_lo);
             if (t.hashk) return bucket_of[folded_unit];
             if (t.fold_range) return (uint32_t)folded_unit - t.fr_base; // only called on keyword units: inside the range
             if (t.range_cls) return (uint32_t)folded_unit - t.cls_base;
@@ -576,7 +611,7 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
         };
         uint32_t K = 1;
         uint64_t rows = 1; // n^(K-1)
-        while (K < t.min_len && K < (t.hashk ? 3u : 8u) && rows * n * t.filt_row_bytes <= (uint64_t)tunables().filter_max_bytes &&
+        while (K < t.min_len && K < (merged ? 4u : t.hashk ? 3u : 8u) && rows * n * t.filt_row_bytes <= (uint64_t)tunables().filter_max_bytes &&
                rows * n * n <= (1ull << 24)) {
             rows *= n;
             K++;
@@ -664,8 +699,8 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
                     *word |= bit;
                     if (t.hashk) {
                         uint64_t key = 0;
-                        // walking up from i meets text[e-K] first: text order, leftmost unit in the lowest 16 bits (K <= 3,
-                        // so a key never equals the all-ones empty marker)
+                        // walking up from i meets text[e-K] first: text order, leftmost unit in the lowest 16 bits (K <= 3, or
+                        // K = 4 over units below 0xffff: a key never equals the all-ones empty marker)
                         for (uint32_t p = i, sh = 0; p != 0; p = rn[p].parent, sh += 16) key |= (uint64_t)rn[p].unit << sh;
                         kg.emplace_back(key, ref(i));
                     } else {
@@ -677,7 +712,7 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
                 // node of a depth in [K, D), is a key
                 t.l2_depth = 0;
                 t.l2_bloom.clear();
-                if (!t.hashk && (t.range_cls || t.fold_range) && n <= 32 && K >= 2 && K <= 5) {
+                if ((!t.hashk || merged) && (t.range_cls || t.fold_range) && n <= 32 && K >= 2 && K <= 5) {
                     const uint32_t D = std::min<uint32_t>(K + 2, 6);
                     t.l2_bloom.assign(kL2Words, 0);
                     for (uint32_t i = 1; i < RN; i++) {

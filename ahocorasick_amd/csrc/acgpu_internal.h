@@ -167,6 +167,9 @@ struct HostTables {
     // it folds to its opposite number) and a few exceptions (U+0130 -> i, U+212A -> k ...), all of which have a bit of
     // fr_himask set -- so the packed filter computes classes from the two ranges and takes the class table (tile_lut)
     // for a tile only when some unit of it has such a bit.
+    // fold_range together with hashk: two MERGED ranges of a case-sensitive dictionary (acgpu_build.cpp 7; keywords in mixed
+    // case): the same filter arithmetic (fr_base / fr_base2 the two stretches, fr_himask = 0, exact for every unit), the
+    // verification by the units themselves as for bucketed classes.
     bool fold_range = false;
     uint32_t fr_base = 0, fr_span = 0, fr_base2 = 0, fr_himask = 0;
     // second-level (Bloom) filter of the tile kernel: see l2_gram; l2_depth = D, 0 = not built
@@ -261,6 +264,7 @@ struct Tunables {
 #define ACGPU_FILTER_MAX_BYTES 88000
 #endif
     std::atomic<int64_t> filter_max_bytes{ACGPU_FILTER_MAX_BYTES};  // the filter rows must fit LDS next to the candidate queues
+    std::atomic<int64_t> no_merged_ranges{0}; // builder: 1 = mixed-case dictionaries keep the 8-byte-row scalar filter (A/B)
     std::atomic<int64_t> ww_first_seed{0};    // WHOLEWORD builder: first hash seed tried (tests: the fallback seeds end to end)
 };
 Tunables &tunables();

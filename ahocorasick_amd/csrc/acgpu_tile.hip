@@ -49,7 +49,9 @@ uint32_t tile_group_units() { return kPrefetch * kTileUnits; }
 #endif
 constexpr int kFilterWordsMax = ACGPU_FILTER_WORDS; // 88064 bytes of static LDS for the filter rows (tunable filter_max_bytes <= 88000)
 constexpr int kFilterWordsSplit = 20224; // the filter-only kernel: 79 KiB, so that two workgroups fit one CU's 160 KiB
-bool tile_split_supported(const DevTables &t) { return t.filt_k >= 1 && t.filt_words <= (uint32_t)kFilterWordsSplit; }
+bool tile_split_supported(const DevTables &t) {
+    return t.filt_k >= 1 && t.filt_words <= (uint32_t)kFilterWordsSplit && !(t.hashk && t.fold_range); // (merged ranges: fused only)
+}
 
 // L2 form (second-level filter in LDS, see l2_gram in acgpu_internal.h): smaller static array for the rows, and per wave a
 // queue of SURVIVORS (kL2Cap), a copy of the current tile as packed classes behind an 8-unit halo (kTbBytes) and the list
@@ -90,14 +92,12 @@ __device__ __forceinline__ Vec16 stream_load(const uint16_t *hay, uint32_t unit)
     return Vec16{v.x, v.y};
 }
 
-__device__ __forceinline__ uint32_t tile_class(const DevTables &T, uint32_t unit) {
-    if (T.range_cls) return min(unit - T.cls_base, T.cls_span); // outside [base, base+span) -> span ("other")
-    return T.tile_lut[unit];
-}
-
+// RANGE: min(unit - base, span), outside [base, base+span) -> span ("other").  Two merged ranges (hashk with fold_range): the
+// smaller of the two range classes, exact for every unit.  Otherwise the class table.
 template <bool RANGE>
 __device__ __forceinline__ uint32_t tile_class_t(const DevTables &T, uint32_t unit) {
     if (RANGE) return min(unit - T.cls_base, T.cls_span);
+    if (T.hashk && T.fold_range) return min(min(unit - T.fr_base, unit - T.fr_base2), T.fr_span);
     return T.tile_lut[unit];
 }
 
@@ -759,7 +759,8 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
 #pragma unroll
                             for (int j = K - 2; j >= 0; --j) asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(idx) : "v"(idx), "s"(n), "v"(cls[j]));
                             c.pos16[at] = (uint16_t)(cur + p - c.pos_base);
-                            c.cand[at] = kQiKnown | (cls[K] << kQiLeftShift) | idx;
+                            // (HASHK: a class K-gram does not name a K-gram of units -- the verification reads the window)
+                            c.cand[at] = HASHK ? 0u : kQiKnown | (cls[K] << kQiLeftShift) | idx;
                         }
                         c.cand_n += (uint32_t)__popcll(bal);
                     }
@@ -943,12 +944,23 @@ static hipError_t launch_tile_hashk(const DevTables &t, const TileLaunch &l, hip
 
 // the packed 16-bit filter: range classes, 4-byte rows, row index below 2^16 (l.debug & 1024 keeps the scalar filter: A/B)
 static bool tile_pk_usable(const DevTables &t, const TileLaunch &l) {
-    if (!(t.range_cls || t.fold_range) || t.filt_row_bytes != 4 || t.filt_k < 2 || t.hashk || (l.debug & 1024u)) return false;
+    if (!(t.range_cls || t.fold_range) || t.filt_row_bytes != 4 || t.filt_k < 2 || (t.hashk && !t.fold_range) || (l.debug & 1024u)) return false;
     uint64_t rows = 1;
     for (uint32_t i = 0; i + 1 < t.filt_k; ++i) rows *= t.filt_n;
     if (rows > 65536) return false;
-    if (t.range_cls) return t.cls_base + t.cls_span <= 65536;
-    return t.fr_base + t.fr_span <= 65536 && t.fr_base2 + t.fr_span <= 65536;
+    if (t.fold_range) return t.fr_base + t.fr_span <= 65536 && t.fr_base2 + t.fr_span <= 65536;
+    return t.cls_base + t.cls_span <= 65536;
+}
+
+// two merged ranges (DevTables::hashk with fold_range): the packed two-range filter, the verification by units; K <= 4
+template <int K, bool L2>
+static hipError_t launch_tile_merged(const DevTables &t, const TileLaunch &l, hipStream_t stream) {
+    const size_t lds = L2 ? tile_l2_lds_bytes(l.block) : l.lds_bytes;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ac_tile<K, false, false, false, true, true, L2>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_ac_tile<K, false, false, false, true, true, L2>), dim3(l.grid), dim3(l.block), lds, stream, t, l);
+    return hipGetLastError();
 }
 
 template <int K, bool RANGE>
@@ -991,6 +1003,17 @@ hipError_t launch_ac_tile(const DevTables &t, const TileLaunch &l, hipStream_t s
     std::snprintf(name, sizeof(name), "k_ac_tile<%u, %s, %s, false>", t.filt_k, t.range_cls ? "true" : "false",
                   t.filt_row_bytes == 8 ? "true" : "false");
     if (kernel_name) *kernel_name = name;
+    if (t.hashk && t.fold_range) {
+        if (!tile_pk_usable(t, l)) return hipErrorInvalidValue; // (the builder chooses this form only where it is)
+        const bool l2 = tile_l2_usable(t, l);
+        std::snprintf(name, sizeof(name), "k_ac_tile<%u, false, false, false, true, true, %s>", t.filt_k, l2 ? "true" : "false");
+        switch (t.filt_k) {
+        case 2: return l2 ? launch_tile_merged<2, true>(t, l, stream) : launch_tile_merged<2, false>(t, l, stream);
+        case 3: return l2 ? launch_tile_merged<3, true>(t, l, stream) : launch_tile_merged<3, false>(t, l, stream);
+        case 4: return l2 ? launch_tile_merged<4, true>(t, l, stream) : launch_tile_merged<4, false>(t, l, stream);
+        default: return hipErrorInvalidValue;
+        }
+    }
     if (t.hashk) {
         std::snprintf(name, sizeof(name), "k_ac_tile<%u, false, true, false, true>", t.filt_k);
         switch (t.filt_k) {

@@ -1679,6 +1679,52 @@ def test_case_insensitive_folded_range_classes(min_len):
         assert len(want) >= 40 and got.shape == want.shape and (got == want).all()
 
 
+@pytest.mark.parametrize("min_len", [2, 3, 4, 6])
+def test_case_sensitive_mixed_case_dictionary_merged_ranges(min_len):
+    """Case-sensitive dictionaries whose units lie in two stretches of at most 31 code points (keywords in mixed case: A-Z and
+    a-z, 33..64 classes) take the packed two-range filter with MERGED classes ('T' and 't' share one) and verify by the units
+    themselves: a haystack full of case variants of the keywords -- which pass both filter levels -- must report exactly the
+    exact-case occurrences, like the 8-byte-row scalar form (tunable no_merged_ranges) and the oracle."""
+    import torch
+    rng = np.random.default_rng(900 + min_len)
+    low = list(range(ord("b"), ord("z") + 1))       # the two stretches are not aligned letter for letter: B..X and b..z
+    up = list(range(ord("B"), ord("X") + 1))
+    hay, kws = rand_case(rng, low[:12], 300, min_len + 7, 400001, min_len=min_len)
+    kws = [np.where((rng.integers(0, 2, k.size) == 1) & (k - 32 <= up[-1]), k - 32, k).astype(np.uint16) for k in kws]
+    kws.append(np.array([ord(c) for c in "zzXBb"[:max(min_len, 2)] + "zX"], dtype=np.uint16))  # both ends of both stretches
+    hay_alpha = np.asarray(low[:12] + up[:12] + [ord("z"), ord("X"), ord(" "), 0x00E9, 0x4E2D, ord("A"), ord("a"), ord("Y"), 0xFFFF], dtype=np.uint16)
+    hay = hay_alpha[rng.integers(0, len(hay_alpha), hay.size)]
+    pos = 0
+    for i, k in enumerate(kws * 3):  # plant keywords: exact, and with the case of one unit flipped (passes the filters, must fail)
+        u = k.copy()
+        if i % 2:
+            j = int(rng.integers(0, u.size))
+            u[j] = u[j] ^ 32
+        if pos + u.size < hay.size:
+            hay[pos:pos + u.size] = u
+        pos += u.size + 37
+    want = Oracle(FAM_AC, kws, case_sensitive=True).match(hay)
+    d_hay = torch.from_numpy(hay.view(np.int16)).cuda()
+    m = AhoCorasickMap(kws, _ids(len(kws)), True)
+    assert m.automaton.info()["n_classes"] > 32
+    got, prof = _dev_match(m.automaton, d_hay, hay.size, True, len(want) + 8, profile=True)
+    args = prof["scan_kernel"].split("<")[1].rstrip(">").split(", ")
+    assert args[1] == "false" and args[4] == "true" and args[5] == "true", prof["scan_kernel"]  # merged classes, by units, packed
+    assert len(want) >= 300 and got.shape == want.shape and (got == want).all()
+    # a tail of fewer than 8 units, and shards
+    for n in (hay.size - 3, 4099):
+        w2 = Oracle(FAM_AC, kws, case_sensitive=True).match(hay[:n])
+        g2, _ = _dev_match(m.automaton, d_hay, n, True, len(w2) + 8, profile=True)
+        assert g2.shape == w2.shape and (g2 == w2).all()
+    N.lib().acgpu_set_tunable(b"no_merged_ranges", 1)
+    try:
+        m8 = AhoCorasickMap(kws, _ids(len(kws)), True)
+        got8, prof8 = _dev_match(m8.automaton, d_hay, hay.size, True, len(want) + 8, profile=True)
+    finally:
+        N.lib().acgpu_set_tunable(b"no_merged_ranges", 0)
+    assert prof8["scan_kernel"] != prof["scan_kernel"] and (got8 == want).all()
+
+
 # ---- the pipelined single-GPU driver (bench.py's N=1 path), device-side result header, stream rule ------------------
 
 def test_pipelined_steps_survive_overflow_with_a_changing_haystack():

@@ -22,16 +22,22 @@ def upper_some(k):
     m = rng.integers(0, 2, k.size).astype(bool)
     k[m] -= 32
     return k
+mixed = [upper_some(k) for k in kws]
 shapes = {
     "C2 case-sensitive (range classes)": (kws, True),
     "C2 case-insensitive (LUT classes)": (kws, False),
-    "C2 mixed-case keywords, case-sensitive (52 classes, wide rows)": ([upper_some(k) for k in kws], True),
+    "C2 mixed-case keywords, case-sensitive (merged ranges)": (mixed, True),
+    "C2 mixed-case keywords, case-sensitive (52 classes, wide rows)": (mixed, True, {"no_merged_ranges": 1}),
     "1000 keywords len 3-8 (K=3)": (synth.random_keywords(7, 1000, 3, 8), True),
     "100 keywords len 2-6 (K=2)": (synth.random_keywords(8, 100, 2, 6), True),
     "30k keywords len 4-12": (synth.random_keywords(9, 30000, 4, 12), True),
 }
-for name, (k, cs) in shapes.items():
+for name, spec in shapes.items():
+    k, cs = spec[0], spec[1]
+    knobs = spec[2] if len(spec) > 2 else {}
+    for kn, v in knobs.items(): N.lib().acgpu_set_tunable(kn.encode(), v)
     a = Automaton(N.MODE_ALL, k, cs)
+    for kn in knobs: N.lib().acgpu_set_tunable(kn.encode(), 0)
     ts = []
     for r in range(6):
         nout, rc, prof, _ = a.match_device(d_hay.data_ptr(), n, True, d_out.data_ptr(), cap, stream=torch.cuda.current_stream().cuda_stream, profile=True)
