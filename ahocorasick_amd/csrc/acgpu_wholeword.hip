@@ -617,6 +617,342 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
         if (c.res_cur + i < c.slot_limit) store_rec(L, c.res_cur + i, 0, 0, 0, ~0u); // (not into the next slice)
 }
 
+// ---- k_ww_pp: the position-parallel form (keywords of at most 16 units, fold table in LDS or none) ----------------------
+// k_ww_tile verifies a run start by reading the run back from memory: two text windows, then word bits, fold and hash of 16
+// units per run, then the table round trip -- a chain of dependent stages, 70 % of a wave's time.  Here every unit is folded
+// ONCE, at stream time, by the lane that holds it: the folded units of the current and the next tile and their
+// word-character bits sit in a small per-wave LDS ring, a run start reads its 16 folded units and its run length from there
+// (two LDS reads, no text window), and the table probes of one batch of run starts are in flight while the next tile is
+// folded and hashed -- they are compared, in text order, just before the next batch's probes go out.
+//   per wave: ring   = 2 tile slots of 512 folded units + a copy of slot 0's first 32 units behind slot 1 (a run of the
+//                      tile in slot 1 goes on in slot 0)
+//             bits   = the same for the word-character bits, one byte per lane and tile
+//             list   = the run starts of the tile being verified, tile relative, in text order
+constexpr int kPpRingUnits = 2 * kTileUnits + 32;
+constexpr int kPpBitBytes = 2 * (kTileUnits / 8) + 8;
+constexpr int kPpListCap = kTileUnits / 2; // a run start needs a unit that is no word character before it
+constexpr int kPpWaveBytes = (kPpRingUnits * 2 + kPpBitBytes + kPpListCap * 2 + 15) & ~15;
+constexpr uint32_t kPpMaxLen = 16; // longer keywords: k_ww_tile
+
+static size_t ww_pp_lds_bytes(int block_threads, const DevTables &t) {
+    return ww_bloom_bytes(t) + (size_t)(block_threads / kWave) * kPpWaveBytes;
+}
+
+// ww_hash_step (h * 33 + w) in two full-rate operations (the compiler's own choice is the quarter-rate 64-bit multiply-add)
+__device__ __forceinline__ uint32_t pp_hash_step(uint32_t h, uint32_t w) {
+    uint32_t t;
+    asm("v_lshl_add_u32 %0, %1, 5, %1" : "=v"(t) : "v"(h));
+    return t + w;
+}
+
+// One batch of run starts, hashed and ready to probe: everything but the probed slots (registers; PpBatch travels from the
+// pass that computes it to the next pass, which issues its probes, and compares them at its end -- the LOADED registers
+// never cross the loop's back edge, where a register copy would wait for the loads right behind their issue)
+struct PpFlight {
+    uint32_t n = 0; // wave-uniform: entries of the batch, 0 = nothing to do
+    bool probing = false;
+    uint32_t s = 0, r = 0, tag = 0, s1 = 0, s2 = 0, fw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+struct PpProbe {
+    uint4 ea0, ea1, eb0, eb1;
+};
+
+// the four probe loads of a batch, unconditional (a lane that does not probe reads slot 0: one cached line): the number of
+// memory operations of a pass is then the same on every path, and the compiler's waits can count
+__device__ __forceinline__ PpProbe pp_issue(const DevTables &T, const PpFlight &fl) {
+    const uint4 *fat = reinterpret_cast<const uint4 *>(T.ww_fat);
+    PpProbe pr;
+#ifdef PP_COND_LOADS
+    pr.ea0 = pr.ea1 = pr.eb0 = pr.eb1 = make_uint4(0u, 0u, 0u, 0u);
+    if (fl.probing)
+#endif
+    {
+        pr.ea0 = fat[2 * fl.s1];
+        pr.ea1 = fat[2 * fl.s1 + 1];
+        pr.eb0 = fat[2 * fl.s2];
+        pr.eb1 = fat[2 * fl.s2 + 1];
+    }
+    return pr;
+}
+
+// compare the probed slots with the runs of the batch and emit its records (text order: lane order)
+__device__ __forceinline__ void pp_consume(TileCtx &c, const PpFlight &fl, const PpProbe &pr) {
+    if (fl.n == 0) return; // wave-uniform
+    const DevTables &T = *c.Tp;
+    const TileLaunch &L = *c.Lp;
+    const uint4 a0 = pr.ea0, a1 = pr.ea1, b0 = pr.eb0, b1 = pr.eb1;
+    const uint32_t ida = a0.y, idb = b0.y;
+    const bool in_a = a0.x == fl.tag && a0.z == fl.fw[0] && a0.w == fl.fw[1] && a1.x == fl.fw[2] && a1.y == fl.fw[3] &&
+                      a1.z == fl.fw[4] && a1.w == fl.fw[5];
+    const bool in_b = b0.x == fl.tag && b0.z == fl.fw[0] && b0.w == fl.fw[1] && b1.x == fl.fw[2] && b1.y == fl.fw[3] &&
+                      b1.z == fl.fw[4] && b1.w == fl.fw[5];
+    uint32_t id = ~0u;
+    if (fl.probing && (in_a || in_b)) id = in_a ? ida : idb;
+    if (__any(id != ~0u && fl.r > kWwInlineUnits)) { // keywords of 13..16 units: units 12..15 from the record (see k_ww_tile)
+        if (id != ~0u && fl.r > kWwInlineUnits) {
+            const uint4 *recs = reinterpret_cast<const uint4 *>(T.ww_recs);
+            uint32_t found = ~0u;
+            if (in_a) {
+                const uint4 *rec = recs + ida;
+                const uint4 a = rec[0], q = rec[2];
+                if (a.y == fl.r && q.x == fl.fw[6] && q.y == fl.fw[7]) found = a.x;
+            }
+            if (in_b && found == ~0u) {
+                const uint4 *rec = recs + idb;
+                const uint4 a = rec[0], q = rec[2];
+                if (a.y == fl.r && q.x == fl.fw[6] && q.y == fl.fw[7]) found = a.x;
+            }
+            id = found;
+        }
+    }
+    const uint32_t m = id != ~0u ? 1u : 0u;
+    const uint32_t incl = wave_inclusive_scan_dpp(m);
+    const uint32_t total = __builtin_amdgcn_readlane(incl, kWave - 1);
+    if (total == 0) return;
+    const uint32_t prefix = incl - m;
+    if (L.d_region_recs) {
+        int32_t *base = L.d_region_recs + ((size_t)c.region * L.region_cap + c.rank_base) * 3;
+        if (m) {
+            typedef int32_t v3i __attribute__((ext_vector_type(3)));
+            const v3i rec = {(int32_t)fl.s, (int32_t)(fl.s + fl.r), (int32_t)id};
+            __builtin_nontemporal_store(rec, reinterpret_cast<v3i *>(base + (size_t)prefix * 3));
+        }
+    } else {
+        const SlotRange sr = reserve_slots(c, total);
+        if (m) store_rec(L, sr.slot(prefix), fl.s, fl.s + fl.r, id, c.rank_base + prefix);
+    }
+    c.rank_base += total;
+}
+
+template <int FOLD>
+__global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) void k_ww_pp(DevTables T, TileLaunch L) {
+    static_assert(FOLD == 0 || FOLD == 1, "the fold table sits in LDS");
+    __shared__ __attribute__((aligned(16))) uint32_t wbits[2048];
+    __shared__ __attribute__((aligned(16))) unsigned char fold_base[FOLD == 1 ? 256 : 16];
+    __shared__ __attribute__((aligned(16))) uint16_t pages[FOLD == 1 ? kFoldPagesMax * 256 : 8];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t bloom_bytes = (T.ww_bloom_mask + 1u) / 8u;
+    uint32_t *bloom = reinterpret_cast<uint32_t *>(smem);
+    for (uint32_t w = threadIdx.x; w < bloom_bytes / 16; w += blockDim.x)
+        reinterpret_cast<uint4 *>(bloom)[w] = reinterpret_cast<const uint4 *>(T.ww_bloom)[w];
+    for (uint32_t w = threadIdx.x; w < 2048 / 4; w += blockDim.x)
+        reinterpret_cast<uint4 *>(wbits)[w] = reinterpret_cast<const uint4 *>(T.wbits)[w];
+    FoldLds F{bloom, T.ww_bloom_mask, fold_base, pages};
+    if (FOLD == 1) {
+        for (uint32_t i = threadIdx.x; i < 256 / 16; i += blockDim.x)
+            reinterpret_cast<uint4 *>(fold_base)[i] = reinterpret_cast<const uint4 *>(T.fold_pgidx)[i];
+        for (uint32_t i = threadIdx.x; i < T.fold_n_pages * 32u; i += blockDim.x)
+            reinterpret_cast<uint4 *>(pages)[i] = reinterpret_cast<const uint4 *>(T.fold_pages)[i];
+    }
+    __syncthreads();
+
+    const uint32_t lane = lane_id();
+    const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const uint32_t wave_global = blockIdx.x * (kTileBlock / kWave) + wave_in_block;
+    unsigned char *mine = smem + bloom_bytes + wave_in_block * kPpWaveBytes;
+    uint16_t *ring = reinterpret_cast<uint16_t *>(mine);
+    unsigned char *bits = mine + kPpRingUnits * 2;
+    uint16_t *list = reinterpret_cast<uint16_t *>(mine + kPpRingUnits * 2 + kPpBitBytes);
+    TileCtx c{&T, &L, nullptr, 0, 0, 0u, 0};
+
+    const uint32_t first_region = wave_global * L.regions_per_wave;
+    if (first_region >= L.n_regions) return;
+    const uint32_t last_region = min(first_region + L.regions_per_wave, L.n_regions);
+    const uint32_t base8 = L.own_begin & ~7u;
+    const uint32_t R = L.region_units;
+    const uint32_t span_begin = max(L.own_begin, base8 + first_region * R);
+    uint32_t span_end = base8 + last_region * R;
+    if (span_end > L.own_end || last_region == L.n_regions) span_end = L.own_end;
+    const uint32_t n = L.n_units;
+    const uint16_t *hay = L.d_hay;
+    const uint32_t tile0 = base8 + first_region * R;
+
+    uint32_t region = first_region;
+    c.region = region;
+    uint32_t boundary = tile0 + R;
+    uint32_t carry = tile0 >= 1 && tile0 - 1 < n ? word_bit(wbits, hay[tile0 - 1]) : 0u; // bit of the unit before the tile
+
+    // the lane's 8 units of the tile at `cur` (zeros beyond the buffer)
+    auto load_tile = [&](uint32_t cur) -> uint4 {
+        const uint32_t v = cur + lane * 8;
+        if (cur + kTileUnits <= n) return *reinterpret_cast<const uint4 *>(hay + v); // wave-uniform: the whole tile exists
+        uint4 w = make_uint4(0u, 0u, 0u, 0u);
+        if (v + 8 <= n) {
+            w = *reinterpret_cast<const uint4 *>(hay + v);
+        } else if (v < n) { // the last, partial vector of the buffer: unit by unit
+            unsigned long long lo = 0, hi = 0;
+            for (uint32_t j = 0; j < 8 && v + j < n; ++j) {
+                const unsigned long long u = (unsigned long long)hay[v + j] << (16 * (j & 3u));
+                if (j < 4) lo |= u;
+                else hi |= u;
+            }
+            w = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+        }
+        return w;
+    };
+    // Stage a tile: word bits and folded units of the lane's 8 units into the ring slot of tile j; returns the lane's run starts
+    auto stage = [&](uint32_t j, const uint4 w) -> uint32_t {
+        const uint32_t cur = tile0 + j * kTileUnits, v = cur + lane * 8, slot = j & 1u;
+        const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#ifdef PP_WBITS_C
+        uint32_t wm = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wm |= word_bit(wbits, (ww[k >> 1] >> (16 * (k & 1))) & 0xffffu) << k;
+#else
+        uint32_t wm = word_bits8<8>(wbits, ww);
+#endif
+        if (cur + kTileUnits > n) wm &= (1u << (v < n ? min(n - v, 8u) : 0u)) - 1u; // (wave-uniform) nothing beyond the buffer is a word
+        const uint32_t prev = from_prev_lane(wm >> 7, carry);
+        carry = __builtin_amdgcn_readlane(wm, 63) >> 7;
+        uint32_t sm = wm & ~((wm << 1) | (prev & 1u)) & 0xffu;
+        if (cur < span_begin || cur + kTileUnits > span_end) { // wave-uniform: a tile at the edges of the span
+            const uint32_t first = span_begin > v ? min(span_begin - v, 8u) : 0u;
+            const uint32_t last = span_end > v ? min(span_end - v, 8u) : 0u;
+            sm &= ((1u << last) - 1u) & ~((1u << first) - 1u);
+        }
+        uint32_t f[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] = ww_fold<FOLD>(T, F, (ww[k >> 1] >> (16 * (k & 1))) & 0xffffu);
+        const uint4 fd = make_uint4(f[0] | (f[1] << 16), f[2] | (f[3] << 16), f[4] | (f[5] << 16), f[6] | (f[7] << 16));
+        *reinterpret_cast<uint4 *>(ring + slot * kTileUnits + lane * 8) = fd;
+        bits[slot * (kTileUnits / 8) + lane] = (unsigned char)wm;
+        if (slot == 0 && lane < 8) { // the copy behind slot 1
+            if (lane < 4) *reinterpret_cast<uint4 *>(ring + 2 * kTileUnits + lane * 8) = fd;
+            bits[2 * (kTileUnits / 8) + lane] = (unsigned char)wm;
+        }
+        return sm;
+    };
+
+    // the run starts of a staged tile (its lanes' start masks), tile relative and in text order, into the list; returns their number
+    auto build_list = [&](uint32_t sm) -> uint32_t {
+        const uint32_t k = __popc(sm);
+        const uint32_t incl = wave_inclusive_scan_dpp(k);
+        uint32_t at = incl - k, m = sm;
+        while (__any(m != 0)) {
+            if (m != 0) {
+                list[at++] = (uint16_t)(lane * 8 + (uint32_t)__builtin_ctz(m));
+                m &= m - 1;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t cnt = __builtin_amdgcn_readlane(incl, kWave - 1);
+        return ACGPU_DBG(L, 1u) ? 0u : cnt; // 1: ablation, run starts are dropped
+    };
+    // One batch of the listed run starts of tile j (entries b0 .. b0+63): run length and folded units from the ring, both
+    // hashes, Bloom test, slots.  Tile j + 1 has been staged.
+    auto batch = [&](uint32_t j, uint32_t cnt, uint32_t b0) -> PpFlight {
+        const uint32_t slot = j & 1u, q = b0 + lane;
+        const bool act = q < cnt;
+        const uint32_t p = act ? (uint32_t)list[q] : 0u;
+        // run length: the word-character bits from p on (24 of them are enough: keywords have at most 16 units)
+        struct __attribute__((packed, aligned(1), may_alias)) Bits4 { uint32_t v; };
+        const uint32_t wb = reinterpret_cast<const Bits4 *>(bits + slot * (kTileUnits / 8) + (p >> 3))->v >> (p & 7u);
+        const uint32_t r = (uint32_t)__builtin_ctz(~wb | (1u << (kPpMaxLen + 1)));
+        struct __attribute__((packed, aligned(2), may_alias)) Run16 { uint32_t d[8]; };
+        const Run16 run = *reinterpret_cast<const Run16 *>(ring + slot * kTileUnits + p);
+        PpFlight fl;
+        uint32_t h = T.ww_seed, g = T.ww_seed;
+        const uint32_t r2 = r | (r << 16);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            // units 2i and 2i+1 of the run, zero from unit r on: (index - r) >> 15 (arithmetic) is 0xffff below r, per half
+            // (the shift count as a register: an inline constant would reach the low half only)
+#ifdef PP_ZERO_ASM
+            uint32_t keep;
+            asm("v_pk_sub_i16 %0, %1, %2" : "=v"(keep) : "s"((uint32_t)((2 * i) | ((2 * i + 1) << 16))), "v"(r2));
+            asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(keep) : "s"(0x000f000fu), "v"(keep));
+            fl.fw[i] = run.d[i] & keep;
+#else
+            const int m = (int)r - 2 * i;
+            fl.fw[i] = m >= 2 ? run.d[i] : (m == 1 ? (run.d[i] & 0xffffu) : 0u);
+            (void)r2;
+#endif
+#ifndef PP_HASH_ASM
+            h = ww_hash_step(h, fl.fw[i]);
+#else
+            h = pp_hash_step(h, fl.fw[i]);
+#endif
+            g = ww_hash2_step(g, fl.fw[i]);
+        }
+        h = ww_hash_final(h);
+        bool probing = act && r <= T.max_len && !ACGPU_DBG(L, 2u); // 2: ablation, no table lookup
+        if (!ACGPU_DBG(L, 4u)) { // 4: ablation, no Bloom filter in front of the table
+            const uint32_t b1 = ww_bloom_bit1(h, F.bloom_mask), b2 = ww_bloom_bit2(h, F.bloom_mask);
+            probing = probing && ((F.bloom[b1 >> 5] >> (b1 & 31)) & (F.bloom[b2 >> 5] >> (b2 & 31)) & 1u);
+        }
+#ifdef PP_COND_LOADS
+        fl.s1 = ww_slot1(h, T.ww_fat_mask);
+        fl.s2 = ww_slot2(h, g, T.ww_fat_mask);
+#else
+        fl.s1 = probing ? ww_slot1(h, T.ww_fat_mask) : 0u;
+        fl.s2 = probing ? ww_slot2(h, g, T.ww_fat_mask) : 0u;
+#endif
+        fl.n = cnt > b0 ? min(cnt - b0, (uint32_t)kWave) : 0u;
+        fl.probing = probing;
+        fl.s = tile0 + j * kTileUnits + p;
+        fl.r = r;
+        fl.tag = ww_tag(h, r);
+        return fl;
+    };
+
+    // more than 64 run starts in a tile are rare: all but the tile's last batch are probed and compared at once
+    auto early_batches = [&](uint32_t j, uint32_t cnt, uint32_t b_last) {
+        for (uint32_t b0 = 0; b0 < b_last; b0 += kWave) {
+            const PpFlight now = batch(j, cnt, b0);
+            pp_consume(c, now, pp_issue(T, now));
+        }
+    };
+    // Pass j: the probes of tile j's last batch go out first; then tile j+2 is staged, tile j+1's run starts are listed and its
+    // last batch is hashed -- LDS and VALU work, under which the probes arrive -- and then tile j's batch is compared and
+    // emitted.  The stream runs one tile ahead of the staging in ONE set of registers (the load goes out right after the
+    // registers are staged and has a whole pass to arrive; rotating register sets would copy registers whose loads are in
+    // flight, and such a copy waits for everything issued before it).
+    PpFlight fl;
+    uint32_t sm_next;
+    {
+        const uint32_t sm0 = stage(0, load_tile(tile0));
+        sm_next = stage(1, load_tile(tile0 + kTileUnits));
+        const uint32_t cnt = build_list(sm0);
+        const uint32_t b_last = cnt ? ((cnt - 1) & ~(uint32_t)(kWave - 1)) : 0u;
+        early_batches(0, cnt, b_last);
+        fl = batch(0, cnt, b_last);
+    }
+    uint4 nx = load_tile(tile0 + 2 * kTileUnits);
+    uint32_t prio_turn = 0;
+    for (uint32_t j = 0;; ++j) {
+        const uint32_t cur = tile0 + j * kTileUnits; // tile j: `fl` is its last batch
+        if (cur >= span_end) break; // wave-uniform
+#ifndef ACGPU_NO_SETPRIO
+        switch ((wave_in_block / 4u + prio_turn++) & 3u) { // (see k_ac_tile: the waves of a SIMD take turns at every issue priority)
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+        }
+#endif
+        const PpProbe pr = pp_issue(T, fl);
+        const uint32_t sm2 = stage(j + 2, nx);
+        nx = load_tile(cur + 3 * kTileUnits);
+        const uint32_t cnt = build_list(sm_next); // tile j + 1 (none beyond the span: its start mask is empty)
+        const uint32_t b_last = cnt ? ((cnt - 1) & ~(uint32_t)(kWave - 1)) : 0u;
+        const PpFlight nf = batch(j + 1, cnt, b_last);
+        pp_consume(c, fl, pr);
+        if (cur + kTileUnits >= boundary && cur + kTileUnits < span_end) { // tile j + 1 opens the next region
+            if (lane == 0) L.d_region_counts[region] = c.rank_base;
+            c.rank_base = 0;
+            ++region;
+            c.region = region;
+            boundary += R;
+        }
+        early_batches(j + 1, cnt, b_last);
+        fl = nf;
+        sm_next = sm2;
+    }
+    if (lane == 0) L.d_region_counts[region] = c.rank_base;
+    for (uint32_t i = lane; i < c.res_left; i += kWave)
+        if (c.res_cur + i < c.slot_limit) store_rec(L, c.res_cur + i, 0, 0, 0, ~0u); // (not into the next slice)
+}
+
 // Literal restatement of S/WholeWordMatchMap.java:155-240 by ONE lane, for word-character tables that are not
 // fold-consistent.  The whole haystack is one shard.  Records come out in order; count in *counter.
 __global__ void k_ww_sequential(DevTables T, const uint16_t *hay, uint32_t len, void *out, uint64_t cap, int record_kind,
@@ -658,8 +994,26 @@ __global__ void k_ww_sequential(DevTables T, const uint16_t *hay, uint32_t len, 
     *counter = n;
 }
 
+// the position-parallel form serves keywords of at most 16 units whose fold table (if any) fits LDS, when its LDS fits next
+// to the Bloom filter (tile_debug bit 268435456 keeps k_ww_tile: A/B; bit 256, the trie-walk verification, exists only there)
+static bool ww_pp_usable(const DevTables &t, const TileLaunch &l) {
+    const int fold = t.cs ? 0 : (ww_fold_pages_in_lds(t) ? 1 : 2);
+    return fold != 2 && t.max_len <= kPpMaxLen && !(l.debug & (256u | 268435456u)) &&
+           ww_pp_lds_bytes(l.block, t) + 8192 + 256 + kFoldPagesMax * 512 <= 160 * 1024;
+}
+
 hipError_t launch_ww_tile(const DevTables &t, const TileLaunch &l, hipStream_t stream, const char **kernel_name) {
     const int fold = t.cs ? 0 : (ww_fold_pages_in_lds(t) ? 1 : 2);
+    if (ww_pp_usable(t, l)) {
+        const size_t lds = ww_pp_lds_bytes(l.block, t);
+        const void *fn = fold == 0 ? reinterpret_cast<const void *>(&k_ww_pp<0>) : reinterpret_cast<const void *>(&k_ww_pp<1>);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        if (fold == 0) hipLaunchKernelGGL(k_ww_pp<0>, dim3(l.grid), dim3(l.block), lds, stream, t, l);
+        else hipLaunchKernelGGL(k_ww_pp<1>, dim3(l.grid), dim3(l.block), lds, stream, t, l);
+        if (kernel_name) *kernel_name = fold == 0 ? "k_ww_pp<0>" : "k_ww_pp<1>";
+        return hipGetLastError();
+    }
     const void *fn = fold == 0 ? reinterpret_cast<const void *>(&k_ww_tile<0>)
                    : fold == 1 ? reinterpret_cast<const void *>(&k_ww_tile<1>) : reinterpret_cast<const void *>(&k_ww_tile<2>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds_bytes);

@@ -1564,7 +1564,7 @@ def test_wholeword_async_begin_end_pipelined_overflow_and_slice_redo():
         tickets.append(tk)
     for tk, o, w in zip(tickets, outs, wants):
         n, rc, prof = a.match_device_end(tk, profile=True)
-        assert rc == N.OK and n == len(w) and len(w) > 3000 and prof["scan_kernel"].startswith("k_ww_tile")
+        assert rc == N.OK and n == len(w) and len(w) > 3000 and prof["scan_kernel"].startswith("k_ww_")
         assert (o[:n].cpu().numpy() == w).all()
     tk, rc = a.match_device_begin(d_hays[0].data_ptr(), hays[0].size, True, outs[0].data_ptr(), 5, stream=st)
     n, rc, _ = a.match_device_end(tk)

@@ -28,7 +28,7 @@ unset ACGPU_LIB
 # config 3's share on one GPU (Set records, R = 8), and the sibling kernels' counters (SQ + HBM traffic)
 python3 bench.py --config C3 --steps 20 --warmup 3 > "$OUT/bench_c3_1gpu.json" 2> "$OUT/bench_c3_1gpu.err"
 bash tools/pmc_sq.sh "${1:-final}/pmc_sq_c4" '{"c4":{}}' "--config C4 --set" k_longest > "$OUT/pmc_sq_c4.txt" 2>&1
-bash tools/pmc_sq.sh "${1:-final}/pmc_sq_c5" '{"c5":{}}' "--config C5" k_ww_tile > "$OUT/pmc_sq_c5.txt" 2>&1
+bash tools/pmc_sq.sh "${1:-final}/pmc_sq_c5" '{"c5":{}}' "--config C5" k_ww_ > "$OUT/pmc_sq_c5.txt" 2>&1
 for c in C2 C4 C5; do
   extra=""; [ $c = C4 ] && extra="--set"
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_$c" -- python3 tools/kbench.py --rounds 1 --config $c $extra --variants '{"k":{}}' > "$OUT/pmc_fetch_$c.log" 2>&1

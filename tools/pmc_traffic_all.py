@@ -19,7 +19,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 STREAMING = ("k_longest_chain_lds", "k_longest_emit_ends", "k_scan_", "k_stream_probe")        # reads: 16 B/lane streams only
-MIXED = ("k_ww_tile", "k_ac_tile", "k_longest_block", "k_longest_walk_list", "k_permute")       # a stream plus gathers
+MIXED = ("k_ww_tile", "k_ww_pp", "k_ac_tile", "k_longest_block", "k_longest_walk_list", "k_permute")       # a stream plus gathers
 
 
 GENERATORS = ("k_synth", "k_token")  # the benchmark's input generators (and everything dispatched before them: their prefix sums)
