@@ -352,6 +352,16 @@ __device__ __forceinline__ uint32_t roll_row(uint32_t hs, uint32_t n, uint32_t c
 //   classes  : min(unit - base, span) for both halves            v_pk_sub_u16 + v_pk_min_u16   (2 ops per 2 units)
 //   row index: Horner over the (K-1)-gram, both positions at once  v_pk_mad_u16                 (K-2 ops per 2 positions)
 // (usable when the row index n^(K-1) fits 16 bits; every intermediate is exact modulo 2^16)
+#ifdef ACGPU_PK_C
+typedef unsigned short pk_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk_u16x2 pk_v(uint32_t x) { return __builtin_bit_cast(pk_u16x2, x); }
+__device__ __forceinline__ uint32_t pk_u(pk_u16x2 x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ uint32_t pk_class(uint32_t units2, uint32_t base2, uint32_t span2) {
+    return pk_u(__builtin_elementwise_min(pk_v(units2) - pk_v(base2), pk_v(span2)));
+}
+__device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t n2, uint32_t c) { return pk_u(pk_v(a) * pk_v(n2) + pk_v(c)); }
+__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) { return pk_u(__builtin_elementwise_min(pk_v(a), pk_v(b))); }
+#else
 __device__ __forceinline__ uint32_t pk_class(uint32_t units2, uint32_t base2, uint32_t span2) {
     uint32_t t, r;
     asm("v_pk_sub_u16 %0, %1, %2" : "=v"(t) : "v"(units2), "s"(base2));
@@ -363,6 +373,12 @@ __device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t n2, uint32_t c) 
     asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(n2), "v"(c));
     return r;
 }
+__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+#endif
 
 // A wave owns a contiguous SPAN of regions.  Region boundaries sit at base8 + r * region_units (base8 = own_begin
 // rounded down to 8 units, region_units a multiple of the 2048-unit tile group), so a tile group never straddles two
@@ -619,9 +635,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                         if (RANGE) return pk_class(units2, base2, span2);
                         if (by_table) return (uint32_t)T.tile_lut[units2 & 0xffffu] | ((uint32_t)T.tile_lut[units2 >> 16] << 16);
                         const uint32_t c1 = pk_class(units2, base2, span2), c2 = pk_class(units2, baseB2, span2);
-                        uint32_t r;
-                        asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(c1), "v"(c2));
-                        return r;
+                        return pk_min(c1, c2);
                     };
                     uint32_t CC[ND], MM[ND], B8[ND / 2];
 #pragma unroll
@@ -757,7 +771,11 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                             const uint32_t at = c.cand_n + (uint32_t)__popcll(bal & lanemask_lt());
                             uint32_t idx = cls[K - 1]; // (v_mad_u32_u24: the compiler's own choice here is the quarter-rate 64-bit mad)
 #pragma unroll
+#ifdef ACGPU_PK_C
+                            for (int j = K - 2; j >= 0; --j) idx = __umul24(idx, n) + cls[j];
+#else
                             for (int j = K - 2; j >= 0; --j) asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(idx) : "v"(idx), "s"(n), "v"(cls[j]));
+#endif
                             c.pos16[at] = (uint16_t)(cur + p - c.pos_base);
                             // (HASHK: a class K-gram does not name a K-gram of units -- the verification reads the window)
                             c.cand[at] = HASHK ? 0u : kQiKnown | (cls[K] << kQiLeftShift) | idx;

@@ -485,15 +485,17 @@ def test_wholeword_mixed_script_like_config_c5():
         assert (WholeWordMatchSet(words, False).find_all(hay) == want[:, :2]).all()
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", range(6))
 def test_wholeword_long_words_and_hash_table_paths(seed):
     """Words longer than the 16 units the kernel keeps in registers, many words sharing long prefixes, buffer ends
-    inside a word, case folding on every unit."""
+    inside a word, case folding on every unit.  Seeds 4 and 5: no keyword beyond 16 units -- the position-parallel kernel
+    (k_ww_pp), whose keywords of 13..16 units compare their record, with runs of up to 17+ units in the text."""
     rng = np.random.default_rng(100 + seed)
     alpha = np.array([ord(c) for c in "abAB"] + [0x00E9, 0x00C9, 0x0391, 0x03B1], dtype=np.uint16)
     kws = []
+    lens = [1, 2, 5, 8, 9, 12, 13, 16, 17, 24, 33, 100] if seed < 4 else [1, 2, 5, 8, 9, 11, 12, 13, 14, 15, 16]
     for _ in range(300):
-        ln = int(rng.choice([1, 2, 5, 8, 9, 12, 13, 16, 17, 24, 33, 100]))
+        ln = int(rng.choice(lens))
         kws.append(alpha[rng.integers(0, len(alpha), ln)])
     parts = []
     for _ in range(3000):
@@ -508,8 +510,12 @@ def test_wholeword_long_words_and_hash_table_paths(seed):
     hay = np.concatenate(parts[:-1])  # ends inside a word
     for cs in (True, False):
         want = Oracle(FAM_WHOLEWORD, kws, case_sensitive=cs, lower=LOWER, word_chars=WORD).match(hay)
-        got = WholeWordMatchMap(kws, _ids(len(kws)), cs).find_all(hay)
+        m = WholeWordMatchMap(kws, _ids(len(kws)), cs)
+        got = m.find_all(hay)
         assert got.shape == want.shape and (got == want).all()
+        import torch
+        _, prof = _dev_match(m.automaton, torch.from_numpy(hay.view(np.int16)).cuda(), hay.size, True, len(want) + 8, profile=True)
+        assert prof["scan_kernel"].startswith("k_ww_tile" if seed < 4 else "k_ww_pp"), prof["scan_kernel"]
         N.set_tunable("force_kernel", 1)  # the trie-walk verification agrees
         got2 = WholeWordMatchMap(kws, _ids(len(kws)), cs).find_all(hay)
         N.set_tunable("force_kernel", 0)
