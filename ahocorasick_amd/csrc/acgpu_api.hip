@@ -219,6 +219,7 @@ int ensure_device(acgpu_automaton *a, DeviceState **out) {
     if ((rc = upload(*d, t.filt_bits, &T.filt_bits))) return rc;
     if ((rc = upload(*d, t.kgram_node, &T.kgram_node))) return rc;
     T.fold_range = t.fold_range; T.fr_base = t.fr_base; T.fr_span = t.fr_span; T.fr_base2 = t.fr_base2; T.fr_himask = t.fr_himask;
+    T.fr_base3 = t.fr_base3; T.fr_base4 = t.fr_base4; T.fr_nr = t.fr_nr;
     T.l2_bloom = nullptr; T.l2_depth = 0;
     if (t.l2_depth) {
         if ((rc = upload(*d, t.l2_bloom, &T.l2_bloom))) return rc;

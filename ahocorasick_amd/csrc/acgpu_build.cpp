@@ -501,57 +501,8 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
     t.tile_lut = t.cls_lut;
     if ((mode == ACGPU_MODE_ALL || mode == ACGPU_MODE_SHORTEST || mode == ACGPU_MODE_LONGEST) && t.n_cls > 1 && t.min_len >= 1) {
         // tile classes: range mode -> min(unit - base, span) (other = span); LUT mode -> tile_lut (other = 0)
-        std::vector<uint32_t> bucket_of; // hashk: folded unit -> bucket 1..63
-        if (t.n_cls > 64) {
-            // more than 63 distinct units: 63 buckets, filled round robin in order of decreasing frequency so that the
-            // buckets (and with them the class K-grams) are used evenly
-            t.hashk = true;
-            std::vector<uint32_t> freq(65536, 0);
-            for (uint32_t i = 1; i < N; i++) freq[nodes[i].unit]++;
-            std::vector<uint32_t> order;
-            for (uint32_t u = 0; u < 65536; u++) if (freq[u]) order.push_back(u);
-            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return freq[a] > freq[b]; });
-            bucket_of.assign(65536, 0);
-            for (size_t i = 0; i < order.size(); i++) bucket_of[order[i]] = 1 + (uint32_t)(i % 63);
-            t.tile_lut.assign(65536, 0);
-            for (uint32_t raw = 0; raw < 65536; raw++) t.tile_lut[raw] = (uint16_t)bucket_of[t.lower[raw]];
-        }
         // folded range classes (see HostTables::fold_range)
         t.fold_range = false;
-        // Two merged ranges (case-sensitive dictionaries with 33 .. 64 classes whose units lie in two stretches of at most 31
-        // code points each -- keywords in mixed case): unit u of either stretch gets the class u - (start of its stretch), so
-        // the filter is the packed two-range arithmetic of the folded range classes with 4-byte rows and the second level
-        // (a superset test: 'T' and 't' share a class), and the verification is the bucketed form's -- the K units
-        // themselves looked up, the walk through the unit-keyed hashed edges.
-        bool merged = false;
-        uint32_t mg_lo = 0, mg_hi = 0, mg_span = 0;
-        if (t.cs && !t.hashk && t.n_cls > 32 && t.min_len >= 2 && !tunables().force_sparse && !tunables().no_merged_ranges) {
-            std::vector<uint32_t> used;
-            {
-                std::vector<uint8_t> seen(65536, 0);
-                for (uint32_t i = 1; i < N; i++) seen[nodes[i].unit] = 1;
-                for (uint32_t u = 0; u < 65536; u++) if (seen[u]) used.push_back(u);
-            }
-            // the cut between two used units that gives the shortest pair of disjoint stretches
-            for (size_t cut = 1; cut < used.size(); cut++) {
-                const uint32_t lo = used.front(), hi = used[cut];
-                const uint32_t span = std::max(used[cut - 1] - lo + 1, used.back() - hi + 1);
-                if (span <= 31 && lo + span <= hi && hi + span < 65536 && (!merged || span < mg_span)) {
-                    merged = true;
-                    mg_lo = lo; mg_hi = hi; mg_span = span;
-                }
-            }
-            if (merged) {
-                t.hashk = true; // (K-gram and edges by the units themselves)
-                t.fold_range = true;
-                t.fr_base = mg_hi; t.fr_span = mg_span; t.fr_base2 = mg_lo; t.fr_himask = 0;
-                t.tile_lut.assign(65536, (uint16_t)mg_span);
-                for (uint32_t i = 0; i < mg_span; i++) {
-                    t.tile_lut[mg_lo + i] = (uint16_t)i;
-                    t.tile_lut[mg_hi + i] = (uint16_t)i;
-                }
-            }
-        }
         if (!t.cs && !t.hashk && !t.range_cls && !tunables().force_sparse) {
             uint32_t minu = 65535, maxu = 0;
             for (uint32_t i = 1; i < N; i++) {
@@ -598,12 +549,107 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
                 }
             }
         }
+        // Merged stretches (round 3).  The (folded) keyword units are cut greedily into stretches of at most 31 code points; with at
+        // most four ranges of raw units -- the stretches themselves and, case-insensitive, their partner ranges of the other case --
+        // unit u of a range gets the class u - (start of its range): classes computed by packed arithmetic (the smallest of the
+        // range classes), 4-byte rows, K up to 4 and the second level, for dictionaries that used to take the class table, 8-byte
+        // rows and K = 3 (keywords in mixed case: A-Z / a-z; phrases: space and digits / letters; both).  Units of different
+        // stretches share classes, so the filter is a superset test and the verification is the bucketed form's: the K units
+        // themselves looked up, the walk through the unit-keyed hashed edges.  Exactness is needed for the raw units that fold to
+        // a keyword unit only (any other unit may get any class: a false positive the verification drops), and it is CHECKED here
+        // for all 65536 raw units; raw units beyond the low zone that holds the ranges (U+0130 -> i, U+212A -> k) go through the
+        // class table, as for the folded range classes.
+        bool merged = false;
+        std::vector<uint32_t> mg_starts; // first unit of every stretch (ascending)
+        uint32_t mg_span = 0;
+        auto mg_class = [&](uint32_t f) -> uint32_t { // class of a folded keyword unit: its offset in its stretch
+            size_t i = std::upper_bound(mg_starts.begin(), mg_starts.end(), f) - mg_starts.begin();
+            return f - mg_starts[i - 1];
+        };
+        if (!t.hashk && !t.fold_range && (t.range_cls ? t.n_cls > 32 : true) && t.min_len >= 2 && !tunables().force_sparse &&
+            !tunables().no_merged_ranges) {
+            std::vector<uint8_t> is_kw(65536, 0);
+            for (uint32_t i = 1; i < N; i++) is_kw[nodes[i].unit] = 1;
+            for (uint32_t u = 0; u < 65536; u++) {
+                if (!is_kw[u]) continue;
+                if (mg_starts.empty() || u - mg_starts.back() > 30) mg_starts.push_back(u);
+                mg_span = std::max(mg_span, u - mg_starts.back() + 1);
+            }
+            std::vector<uint32_t> bases(mg_starts);
+            merged = !bases.empty() && bases.size() <= 4;
+            if (merged && !t.cs) { // partner ranges: the base that gives a raw unit the class of the unit it folds to, by votes
+                std::vector<uint32_t> votes(65536, 0);
+                for (uint32_t r = 0; r < 65536; r++) {
+                    const uint32_t f = t.lower[r];
+                    if (f == r || !is_kw[f]) continue;
+                    const uint32_t c = mg_class(f);
+                    if (r >= c) votes[r - c]++;
+                }
+                while (bases.size() < 4) {
+                    uint32_t best = 0, at = 0;
+                    for (uint32_t b = 0; b < 65536; b++)
+                        if (votes[b] > best && std::find(bases.begin(), bases.end(), b) == bases.end()) { best = votes[b]; at = b; }
+                    if (best < 4) break; // (single units that fold into a stretch from far away are left to the class table)
+                    bases.push_back(at);
+                }
+            }
+            uint32_t himask = 0;
+            if (merged) {
+                uint32_t top = 0, bits = 0;
+                for (uint32_t b : bases) top = std::max(top, b + mg_span - 1);
+                merged = top < 65535;
+                while (bits < 16 && (1u << bits) <= top) bits++;
+                himask = (0xffffu << bits) & 0xffffu;
+                if (t.cs) himask = 0; // (nothing folds: the arithmetic is the class function for every unit)
+            }
+            if (merged) {
+                while (bases.size() < 4) bases.push_back(bases[0]);
+                t.tile_lut.assign(65536, (uint16_t)mg_span);
+                for (uint32_t r = 0; r < 65536 && merged; r++) {
+                    const uint32_t f = t.lower[r];
+                    if (r & himask) {
+                        if (is_kw[f]) t.tile_lut[r] = (uint16_t)mg_class(f);
+                        continue;
+                    }
+                    uint32_t a = mg_span;
+                    for (uint32_t b : bases) a = std::min(a, (r - b) & 0xffffu);
+                    if (is_kw[f] && a != mg_class(f)) merged = false; // the ranges overlap where it matters
+                    t.tile_lut[r] = (uint16_t)a;
+                }
+            }
+            if (merged) {
+                uint32_t nr = 4;
+                while (nr > 1 && bases[nr - 1] == bases[0]) nr--;
+                t.hashk = true; // (K-gram and edges by the units themselves)
+                t.fold_range = true;
+                t.fr_base = bases[0]; t.fr_base2 = bases[1]; t.fr_base3 = bases[2]; t.fr_base4 = bases[3];
+                t.fr_nr = nr;
+                t.fr_span = mg_span; t.fr_himask = himask;
+            } else {
+                t.tile_lut = t.cls_lut;
+            }
+        }
+        std::vector<uint32_t> bucket_of; // hashk: folded unit -> bucket 1..63
+        if (!merged && t.n_cls > 64) {
+            // more than 63 distinct units: 63 buckets, filled round robin in order of decreasing frequency so that the
+            // buckets (and with them the class K-grams) are used evenly
+            t.hashk = true;
+            std::vector<uint32_t> freq(65536, 0);
+            for (uint32_t i = 1; i < N; i++) freq[nodes[i].unit]++;
+            std::vector<uint32_t> order;
+            for (uint32_t u = 0; u < 65536; u++) if (freq[u]) order.push_back(u);
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return freq[a] > freq[b]; });
+            bucket_of.assign(65536, 0);
+            for (size_t i = 0; i < order.size(); i++) bucket_of[order[i]] = 1 + (uint32_t)(i % 63);
+            t.tile_lut.assign(65536, 0);
+            for (uint32_t raw = 0; raw < 65536; raw++) t.tile_lut[raw] = (uint16_t)bucket_of[t.lower[raw]];
+        }
         const uint32_t n = t.fold_range ? t.fr_span + 1 : t.hashk ? 64 : t.n_cls;
         t.filt_n = n;
         t.filt_other = t.fold_range ? t.fr_span : t.hashk ? 0 : t.range_cls ? t.cls_span : 0;
         t.filt_row_bytes = n <= 32 ? 4 : 8;
         auto tcls = [&](uint16_t folded_unit) -> uint32_t {
-            if (merged) return (uint32_t)folded_unit - (folded_unit >= mg_hi ? mg_hi : mg_lo);
+            if (merged) return mg_class(folded_unit);
             if (t.hashk) return bucket_of[folded_unit];
             if (t.fold_range) return (uint32_t)folded_unit - t.fr_base; // only called on keyword units: inside the range
             if (t.range_cls) return (uint32_t)folded_unit - t.cls_base;

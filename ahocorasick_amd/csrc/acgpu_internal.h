@@ -167,11 +167,12 @@ struct HostTables {
     // it folds to its opposite number) and a few exceptions (U+0130 -> i, U+212A -> k ...), all of which have a bit of
     // fr_himask set -- so the packed filter computes classes from the two ranges and takes the class table (tile_lut)
     // for a tile only when some unit of it has such a bit.
-    // fold_range together with hashk: two MERGED ranges of a case-sensitive dictionary (acgpu_build.cpp 7; keywords in mixed
-    // case): the same filter arithmetic (fr_base / fr_base2 the two stretches, fr_himask = 0, exact for every unit), the
-    // verification by the units themselves as for bucketed classes.
+    // fold_range together with hashk: MERGED stretches (acgpu_build.cpp 7; keywords in mixed case, phrases with spaces and
+    // digits, case-sensitive or not): the same filter arithmetic over up to four ranges (fr_base .. fr_base4, fr_nr of them in
+    // use), units of different stretches sharing classes, the verification by the units themselves as for bucketed classes.
     bool fold_range = false;
     uint32_t fr_base = 0, fr_span = 0, fr_base2 = 0, fr_himask = 0;
+    uint32_t fr_base3 = 0, fr_base4 = 0, fr_nr = 2; // merged stretches: up to four ranges (unused ones repeat fr_base)
     // second-level (Bloom) filter of the tile kernel: see l2_gram; l2_depth = D, 0 = not built
     uint32_t l2_depth = 0;
     std::vector<uint32_t> l2_bloom; // kL2Words
@@ -232,6 +233,7 @@ struct DevTables {
     const uint32_t *l2_bloom;  // second-level filter (kL2Words words) or nullptr
     uint32_t l2_depth;
     uint32_t fold_range, fr_base, fr_span, fr_base2, fr_himask; // see HostTables::fold_range
+    uint32_t fr_base3, fr_base4, fr_nr;
     const uint16_t *tile_lut;  // tile classes of the LUT mode (cls_lut, or the bucket table)
     const uint64_t *kg_keys;
     const uint32_t *kg_vals;

@@ -92,12 +92,15 @@ __device__ __forceinline__ Vec16 stream_load(const uint16_t *hay, uint32_t unit)
     return Vec16{v.x, v.y};
 }
 
-// RANGE: min(unit - base, span), outside [base, base+span) -> span ("other").  Two merged ranges (hashk with fold_range): the
-// smaller of the two range classes, exact for every unit.  Otherwise the class table.
+// RANGE: min(unit - base, span), outside [base, base+span) -> span ("other").  Merged stretches (hashk with fold_range): the
+// smallest of up to four range classes.  Otherwise the class table.
 template <bool RANGE>
 __device__ __forceinline__ uint32_t tile_class_t(const DevTables &T, uint32_t unit) {
     if (RANGE) return min(unit - T.cls_base, T.cls_span);
-    if (T.hashk && T.fold_range) return min(min(unit - T.fr_base, unit - T.fr_base2), T.fr_span);
+    if (T.hashk && T.fold_range) { // merged stretches: the smallest of the range classes; units beyond the low zone by the table
+        if (unit & T.fr_himask) return T.tile_lut[unit];
+        return min(min(min(unit - T.fr_base, unit - T.fr_base2), min(unit - T.fr_base3, unit - T.fr_base4)), T.fr_span);
+    }
     return T.tile_lut[unit];
 }
 
@@ -388,7 +391,8 @@ __device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) {
 // SPLIT: the filter-only form.  Nothing is verified here: the candidates of the wave's span go, in text order, to the
 // wave's slice of L.d_cands (the "queue" is that slice and is never drained), with a {first index, count} pair per
 // region for k_ac_verify.  No LDS besides the filter rows.
-template <int K, bool RANGE, bool WIDE, bool SPLIT, bool HASHK = false, bool PK = false, bool L2 = false>
+// NR4: merged stretches with three or four ranges (DevTables::fr_nr > 2; with PK only)
+template <int K, bool RANGE, bool WIDE, bool SPLIT, bool HASHK = false, bool PK = false, bool L2 = false, bool NR4 = false>
 __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch L) {
     // the filter rows are STATIC LDS (offset 0, so a scaled row index is the ds_read address with nothing to add);
     // the candidate queues are the dynamic part behind it
@@ -622,6 +626,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                     // fr_himask (the few other units that fold into the range all do) takes the class table instead
                     const uint32_t base2 = (RANGE ? T.cls_base : T.fr_base) * 0x10001u, span2 = (RANGE ? T.cls_span : T.fr_span) * 0x10001u;
                     const uint32_t baseB2 = T.fr_base2 * 0x10001u, n2 = n * 0x10001u;
+                    const uint32_t baseC2 = T.fr_base3 * 0x10001u, baseD2 = T.fr_base4 * 0x10001u;
                     bool by_table = false;
                     if (!RANGE && T.fr_himask != 0) {
                         uint32_t any_bits = 0;
@@ -635,7 +640,9 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                         if (RANGE) return pk_class(units2, base2, span2);
                         if (by_table) return (uint32_t)T.tile_lut[units2 & 0xffffu] | ((uint32_t)T.tile_lut[units2 >> 16] << 16);
                         const uint32_t c1 = pk_class(units2, base2, span2), c2 = pk_class(units2, baseB2, span2);
-                        return pk_min(c1, c2);
+                        if (!NR4) return pk_min(c1, c2);
+                        const uint32_t c3 = pk_class(units2, baseC2, span2), c4 = pk_class(units2, baseD2, span2);
+                        return pk_min(pk_min(c1, c2), pk_min(c3, c4));
                     };
                     uint32_t CC[ND], MM[ND], B8[ND / 2];
 #pragma unroll
@@ -966,19 +973,25 @@ static bool tile_pk_usable(const DevTables &t, const TileLaunch &l) {
     uint64_t rows = 1;
     for (uint32_t i = 0; i + 1 < t.filt_k; ++i) rows *= t.filt_n;
     if (rows > 65536) return false;
-    if (t.fold_range) return t.fr_base + t.fr_span <= 65536 && t.fr_base2 + t.fr_span <= 65536;
+    if (t.fold_range) return t.fr_base + t.fr_span <= 65536 && t.fr_base2 + t.fr_span <= 65536 &&
+                             (t.fr_nr <= 2 || (t.fr_base3 + t.fr_span <= 65536 && t.fr_base4 + t.fr_span <= 65536));
     return t.cls_base + t.cls_span <= 65536;
 }
 
 // two merged ranges (DevTables::hashk with fold_range): the packed two-range filter, the verification by units; K <= 4
-template <int K, bool L2>
+template <int K, bool L2, bool NR4>
 static hipError_t launch_tile_merged(const DevTables &t, const TileLaunch &l, hipStream_t stream) {
     const size_t lds = L2 ? tile_l2_lds_bytes(l.block) : l.lds_bytes;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ac_tile<K, false, false, false, true, true, L2>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ac_tile<K, false, false, false, true, true, L2, NR4>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_ac_tile<K, false, false, false, true, true, L2>), dim3(l.grid), dim3(l.block), lds, stream, t, l);
+    hipLaunchKernelGGL((k_ac_tile<K, false, false, false, true, true, L2, NR4>), dim3(l.grid), dim3(l.block), lds, stream, t, l);
     return hipGetLastError();
+}
+template <int K>
+static hipError_t launch_tile_merged_k(const DevTables &t, const TileLaunch &l, bool l2, hipStream_t stream) {
+    if (t.fr_nr > 2) return l2 ? launch_tile_merged<K, true, true>(t, l, stream) : launch_tile_merged<K, false, true>(t, l, stream);
+    return l2 ? launch_tile_merged<K, true, false>(t, l, stream) : launch_tile_merged<K, false, false>(t, l, stream);
 }
 
 template <int K, bool RANGE>
@@ -1024,11 +1037,12 @@ hipError_t launch_ac_tile(const DevTables &t, const TileLaunch &l, hipStream_t s
     if (t.hashk && t.fold_range) {
         if (!tile_pk_usable(t, l)) return hipErrorInvalidValue; // (the builder chooses this form only where it is)
         const bool l2 = tile_l2_usable(t, l);
-        std::snprintf(name, sizeof(name), "k_ac_tile<%u, false, false, false, true, true, %s>", t.filt_k, l2 ? "true" : "false");
+        std::snprintf(name, sizeof(name), "k_ac_tile<%u, false, false, false, true, true, %s, %s>", t.filt_k, l2 ? "true" : "false",
+                      t.fr_nr > 2 ? "true" : "false");
         switch (t.filt_k) {
-        case 2: return l2 ? launch_tile_merged<2, true>(t, l, stream) : launch_tile_merged<2, false>(t, l, stream);
-        case 3: return l2 ? launch_tile_merged<3, true>(t, l, stream) : launch_tile_merged<3, false>(t, l, stream);
-        case 4: return l2 ? launch_tile_merged<4, true>(t, l, stream) : launch_tile_merged<4, false>(t, l, stream);
+        case 2: return launch_tile_merged_k<2>(t, l, l2, stream);
+        case 3: return launch_tile_merged_k<3>(t, l, l2, stream);
+        case 4: return launch_tile_merged_k<4>(t, l, l2, stream);
         default: return hipErrorInvalidValue;
         }
     }

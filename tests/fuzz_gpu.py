@@ -29,6 +29,7 @@ ALPHABETS = [
     [ord(c) for c in "abcABC"] + [0x00E9, 0x00C9, 0x0130, 0x4E2D],                           # LUT classes
     list(range(0x4E00, 0x4E00 + 300)),                                                       # > 64 classes: DFA only
     [ord(c) for c in "ab -_.,9"] + [0x00E9, 0x00C9, 0x3002],                                 # separators (WholeWord)
+    [ord(c) for c in "abcdefikABCDEFIK 0129-"] + [0x0130, 0x212A],                           # phrases: merged stretches, fold exceptions
 ]
 DEFAULTS = {"chunk_units": 0, "lds_table_bytes": 96 * 1024, "force_sparse": 0, "force_kernel": 0, "region_units": 0,
             "rdense_budget_bytes": 256 << 20, "tile_debug": 0}

@@ -1731,6 +1731,63 @@ def test_case_sensitive_mixed_case_dictionary_merged_ranges(min_len):
     assert prof8["scan_kernel"] != prof["scan_kernel"] and (got8 == want).all()
 
 
+@pytest.mark.parametrize("shape", ["cs_phrases", "ci_phrases", "cs_mixed_phrases", "ci_mixed_phrases", "ci_greek_latin"])
+def test_merged_stretches_phrases_and_case_insensitive(shape):
+    """Dictionaries whose (folded) units fall into up to four ranges of at most 31 code points -- phrases with spaces, digits and
+    hyphens, in lower or mixed case, case-sensitive or not; two scripts -- take the packed filter with merged classes (three or
+    four ranges: the NR4 form) and verify by units.  The haystack holds case variants, the fold exceptions U+0130 / U+212A (beyond
+    the low zone: class table), units between and around the ranges, and planted keywords."""
+    import torch
+    rng = np.random.default_rng(hash(shape) % 1000)
+    cs = shape.startswith("cs")
+    letters = list(range(ord("a"), ord("z") + 1))
+    extra = [32, 45, 48, 49, 50, 57]
+    if shape == "ci_greek_latin":
+        # (Latin without i and k: U+0130 and U+212A fold to them from INSIDE / beyond a low zone that reaches up to the Greek
+        # range, and a fold exception inside the low zone is something the arithmetic cannot express: such a dictionary keeps
+        # the class-table form)
+        # (and Greek without theta, to which U+03F4 folds from inside the low zone)
+        letters = [ord(c) for c in "abcdefghjlmn"] + [c for c in range(0x03B1, 0x03B1 + 13) if c != 0x03B8]
+        extra = []
+    kws = []
+    for _ in range(400):
+        ln = int(rng.integers(3, 11))
+        k = np.array(rng.choice(letters, ln), dtype=np.uint16)
+        if extra and ln >= 5:
+            k[int(rng.integers(1, ln - 1))] = int(rng.choice(extra))
+        if "mixed" in shape or shape == "ci_greek_latin":
+            m = (rng.integers(0, 2, ln) == 1) & np.isin(k, letters)
+            k = np.where(m, k - 32, k).astype(np.uint16)
+        kws.append(k)
+    alpha = np.array(letters[:14] + [c - 32 for c in letters[:14]] + extra + [58, 64, 91, 96, 123, 0x0130, 0x212A, 0x00E9, 0x4E2D, 0xFFFF, 0],
+                     dtype=np.uint16)
+    hay = alpha[rng.integers(0, len(alpha), 300001)]
+    pos = 0
+    for i, k in enumerate(kws * 3):
+        u = k.copy()
+        if i % 3 == 1:  # flip the case of one letter: a match only when case-insensitive
+            j = int(rng.integers(0, u.size))
+            if u[j] in letters or (u[j] + 32) in letters:
+                u[j] = u[j] ^ 32
+        elif i % 3 == 2 and not cs:  # through the fold exceptions
+            u[(u | 32) == ord("i")] = 0x0130
+            u[(u | 32) == ord("k")] = 0x212A
+        if pos + u.size < hay.size:
+            hay[pos:pos + u.size] = u
+        pos += u.size + 29
+    want = Oracle(FAM_AC, kws, case_sensitive=cs, lower=LOWER).match(hay)
+    d_hay = torch.from_numpy(hay.view(np.int16)).cuda()
+    m = AhoCorasickMap(kws, _ids(len(kws)), cs)
+    got, prof = _dev_match(m.automaton, d_hay, hay.size, True, len(want) + 8, profile=True)
+    args = prof["scan_kernel"].split("<")[1].rstrip(">").split(", ")
+    assert args[4] == "true" and args[5] == "true", prof["scan_kernel"]  # verification by units, packed filter
+    assert (args[7] == "true") == (shape != "cs_phrases"), prof["scan_kernel"]  # three or four ranges but for lower case + space/digits
+    assert len(want) >= 400 and got.shape == want.shape and (got == want).all()
+    w2 = Oracle(FAM_AC, kws, case_sensitive=cs, lower=LOWER).match(hay[:70003])
+    g2, _ = _dev_match(m.automaton, d_hay, 70003, True, len(w2) + 8, profile=True)
+    assert g2.shape == w2.shape and (g2 == w2).all()
+
+
 # ---- the pipelined single-GPU driver (bench.py's N=1 path), device-side result header, stream rule ------------------
 
 def test_pipelined_steps_survive_overflow_with_a_changing_haystack():

@@ -23,11 +23,27 @@ def upper_some(k):
     k[m] -= 32
     return k
 mixed = [upper_some(k) for k in kws]
+def phrase(k):
+    k = np.array(k, dtype=np.uint16).copy()
+    if k.size >= 6:
+        k[int(rng.integers(2, k.size - 2))] = int(rng.choice([32, 45, 48, 49, 50, 57]))
+    return k
+phrases = [phrase(k) for k in kws]
+def upper_letters(k):
+    k = k.copy()
+    m = rng.integers(0, 2, k.size).astype(bool) & (k >= 97) & (k <= 122)
+    k[m] -= 32
+    return k
 shapes = {
     "C2 case-sensitive (range classes)": (kws, True),
     "C2 case-insensitive (LUT classes)": (kws, False),
     "C2 mixed-case keywords, case-sensitive (merged ranges)": (mixed, True),
     "C2 mixed-case keywords, case-sensitive (52 classes, wide rows)": (mixed, True, {"no_merged_ranges": 1}),
+    "C2 keywords as phrases (space / digit / hyphen inside), case-sensitive": (phrases, True),
+    "C2 keywords as phrases, case-insensitive": (phrases, False),
+    "C2 mixed-case phrases, case-sensitive": ([upper_letters(k) for k in phrases], True),
+    "C2 mixed-case phrases, case-insensitive": ([upper_letters(k) for k in phrases], False),
+    "C2 keywords as phrases, case-insensitive, class table form": (phrases, False, {"no_merged_ranges": 1}),
     "1000 keywords len 3-8 (K=3)": (synth.random_keywords(7, 1000, 3, 8), True),
     "100 keywords len 2-6 (K=2)": (synth.random_keywords(8, 100, 2, 6), True),
     "30k keywords len 4-12": (synth.random_keywords(9, 30000, 4, 12), True),
