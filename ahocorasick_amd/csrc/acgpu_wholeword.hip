@@ -632,26 +632,20 @@ constexpr int kPpRingUnits = 2 * kTileUnits + 32;
 constexpr int kPpBitBytes = 2 * (kTileUnits / 8) + 8;
 constexpr int kPpListCap = kTileUnits / 2; // a run start needs a unit that is no word character before it
 constexpr int kPpWaveBytes = (kPpRingUnits * 2 + kPpBitBytes + kPpListCap * 2 + 15) & ~15;
-constexpr uint32_t kPpMaxLen = 16; // longer keywords: k_ww_tile
+constexpr uint32_t kPpMaxLen = 32; // longer keywords: k_ww_tile (up to 16 units: the LONG = false form, one 32-byte ring read per run)
 
 static size_t ww_pp_lds_bytes(int block_threads, const DevTables &t) {
     return ww_bloom_bytes(t) + (size_t)(block_threads / kWave) * kPpWaveBytes;
 }
 
-// ww_hash_step (h * 33 + w) in two full-rate operations (the compiler's own choice is the quarter-rate 64-bit multiply-add)
-__device__ __forceinline__ uint32_t pp_hash_step(uint32_t h, uint32_t w) {
-    uint32_t t;
-    asm("v_lshl_add_u32 %0, %1, 5, %1" : "=v"(t) : "v"(h));
-    return t + w;
-}
-
 // One batch of run starts, hashed and ready to probe: everything but the probed slots (registers; PpBatch travels from the
 // pass that computes it to the next pass, which issues its probes, and compares them at its end -- the LOADED registers
 // never cross the loop's back edge, where a register copy would wait for the loads right behind their issue)
+template <int NW> // folded units kept per run, two per word: 8 (keywords of up to 16 units) or 16 (up to 32)
 struct PpFlight {
     uint32_t n = 0; // wave-uniform: entries of the batch, 0 = nothing to do
     bool probing = false;
-    uint32_t s = 0, r = 0, tag = 0, s1 = 0, s2 = 0, fw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t s = 0, r = 0, tag = 0, s1 = 0, s2 = 0, fw[NW] = {};
 };
 struct PpProbe {
     uint4 ea0, ea1, eb0, eb1;
@@ -659,24 +653,37 @@ struct PpProbe {
 
 // the four probe loads of a batch, unconditional (a lane that does not probe reads slot 0: one cached line): the number of
 // memory operations of a pass is then the same on every path, and the compiler's waits can count
-__device__ __forceinline__ PpProbe pp_issue(const DevTables &T, const PpFlight &fl) {
+template <int NW>
+__device__ __forceinline__ PpProbe pp_issue(const DevTables &T, const PpFlight<NW> &fl) {
     const uint4 *fat = reinterpret_cast<const uint4 *>(T.ww_fat);
     PpProbe pr;
-#ifdef PP_COND_LOADS
-    pr.ea0 = pr.ea1 = pr.eb0 = pr.eb1 = make_uint4(0u, 0u, 0u, 0u);
-    if (fl.probing)
-#endif
-    {
-        pr.ea0 = fat[2 * fl.s1];
-        pr.ea1 = fat[2 * fl.s1 + 1];
-        pr.eb0 = fat[2 * fl.s2];
-        pr.eb1 = fat[2 * fl.s2 + 1];
-    }
+    pr.ea0 = fat[2 * fl.s1];
+    pr.ea1 = fat[2 * fl.s1 + 1];
+    pr.eb0 = fat[2 * fl.s2];
+    pr.eb1 = fat[2 * fl.s2 + 1];
     return pr;
 }
 
+// units 16.. of a run against its keyword's record (record words: payload, length, then the folded units two per word; rec4[2]
+// = words 6..9 of them is in q).  Only words the keyword has are looked at: the groups behind a record belong to the next one.
+template <int NW>
+__device__ __forceinline__ bool pp_tail_same(const PpFlight<NW> &fl, const uint4 *rec, const uint4 &q) {
+    if (NW <= 8 || fl.r <= 16) return true;
+    bool same = q.z == fl.fw[8] && (fl.r <= 18 || q.w == fl.fw[9]);
+    if (fl.r > 20) {
+        const uint4 t = rec[3];
+        same = same && t.x == fl.fw[10] && (fl.r <= 22 || t.y == fl.fw[11]) && (fl.r <= 24 || t.z == fl.fw[12]) && (fl.r <= 26 || t.w == fl.fw[13]);
+    }
+    if (fl.r > 28) {
+        const uint4 t = rec[4];
+        same = same && t.x == fl.fw[14] && (fl.r <= 30 || t.y == fl.fw[15]);
+    }
+    return same;
+}
+
 // compare the probed slots with the runs of the batch and emit its records (text order: lane order)
-__device__ __forceinline__ void pp_consume(TileCtx &c, const PpFlight &fl, const PpProbe &pr) {
+template <int NW>
+__device__ __forceinline__ void pp_consume(TileCtx &c, const PpFlight<NW> &fl, const PpProbe &pr) {
     if (fl.n == 0) return; // wave-uniform
     const DevTables &T = *c.Tp;
     const TileLaunch &L = *c.Lp;
@@ -688,19 +695,19 @@ __device__ __forceinline__ void pp_consume(TileCtx &c, const PpFlight &fl, const
                       b1.z == fl.fw[4] && b1.w == fl.fw[5];
     uint32_t id = ~0u;
     if (fl.probing && (in_a || in_b)) id = in_a ? ida : idb;
-    if (__any(id != ~0u && fl.r > kWwInlineUnits)) { // keywords of 13..16 units: units 12..15 from the record (see k_ww_tile)
+    if (__any(id != ~0u && fl.r > kWwInlineUnits)) { // keywords of more than 12 units: the rest from the record (see k_ww_tile)
         if (id != ~0u && fl.r > kWwInlineUnits) {
             const uint4 *recs = reinterpret_cast<const uint4 *>(T.ww_recs);
             uint32_t found = ~0u;
             if (in_a) {
                 const uint4 *rec = recs + ida;
                 const uint4 a = rec[0], q = rec[2];
-                if (a.y == fl.r && q.x == fl.fw[6] && q.y == fl.fw[7]) found = a.x;
+                if (a.y == fl.r && q.x == fl.fw[6] && q.y == fl.fw[7] && pp_tail_same<NW>(fl, rec, q)) found = a.x;
             }
             if (in_b && found == ~0u) {
                 const uint4 *rec = recs + idb;
                 const uint4 a = rec[0], q = rec[2];
-                if (a.y == fl.r && q.x == fl.fw[6] && q.y == fl.fw[7]) found = a.x;
+                if (a.y == fl.r && q.x == fl.fw[6] && q.y == fl.fw[7] && pp_tail_same<NW>(fl, rec, q)) found = a.x;
             }
             id = found;
         }
@@ -724,9 +731,12 @@ __device__ __forceinline__ void pp_consume(TileCtx &c, const PpFlight &fl, const
     c.rank_base += total;
 }
 
-template <int FOLD>
+template <int FOLD, bool LONG>
 __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) void k_ww_pp(DevTables T, TileLaunch L) {
     static_assert(FOLD == 0 || FOLD == 1, "the fold table sits in LDS");
+    constexpr int NW = LONG ? 16 : 8;           // words of folded units per run
+    constexpr uint32_t kRunCap = 2 * NW + 1;    // run lengths are counted up to here: longer than every keyword
+    typedef PpFlight<NW> Flight;
     __shared__ __attribute__((aligned(16))) uint32_t wbits[2048];
     __shared__ __attribute__((aligned(16))) unsigned char fold_base[FOLD == 1 ? 256 : 16];
     __shared__ __attribute__((aligned(16))) uint16_t pages[FOLD == 1 ? kFoldPagesMax * 256 : 8];
@@ -794,13 +804,7 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
     auto stage = [&](uint32_t j, const uint4 w) -> uint32_t {
         const uint32_t cur = tile0 + j * kTileUnits, v = cur + lane * 8, slot = j & 1u;
         const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-#ifdef PP_WBITS_C
-        uint32_t wm = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) wm |= word_bit(wbits, (ww[k >> 1] >> (16 * (k & 1))) & 0xffffu) << k;
-#else
         uint32_t wm = word_bits8<8>(wbits, ww);
-#endif
         if (cur + kTileUnits > n) wm &= (1u << (v < n ? min(n - v, 8u) : 0u)) - 1u; // (wave-uniform) nothing beyond the buffer is a word
         const uint32_t prev = from_prev_lane(wm >> 7, carry);
         carry = __builtin_amdgcn_readlane(wm, 63) >> 7;
@@ -840,39 +844,51 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
     };
     // One batch of the listed run starts of tile j (entries b0 .. b0+63): run length and folded units from the ring, both
     // hashes, Bloom test, slots.  Tile j + 1 has been staged.
-    auto batch = [&](uint32_t j, uint32_t cnt, uint32_t b0) -> PpFlight {
+    auto batch = [&](uint32_t j, uint32_t cnt, uint32_t b0) -> Flight {
         const uint32_t slot = j & 1u, q = b0 + lane;
         const bool act = q < cnt;
         const uint32_t p = act ? (uint32_t)list[q] : 0u;
-        // run length: the word-character bits from p on (24 of them are enough: keywords have at most 16 units)
-        struct __attribute__((packed, aligned(1), may_alias)) Bits4 { uint32_t v; };
-        const uint32_t wb = reinterpret_cast<const Bits4 *>(bits + slot * (kTileUnits / 8) + (p >> 3))->v >> (p & 7u);
-        const uint32_t r = (uint32_t)__builtin_ctz(~wb | (1u << (kPpMaxLen + 1)));
+        // run length: the word-character bits from p on (17 or 33 of them decide: keywords have at most 16 / 32 units)
+        uint32_t r;
+        if (LONG) {
+            struct __attribute__((packed, aligned(1), may_alias)) Bits8 { unsigned long long v; };
+            const unsigned long long wb = reinterpret_cast<const Bits8 *>(bits + slot * (kTileUnits / 8) + (p >> 3))->v >> (p & 7u);
+            r = (uint32_t)__builtin_ctzll(~wb | (1ull << kRunCap));
+        } else {
+            struct __attribute__((packed, aligned(1), may_alias)) Bits4 { uint32_t v; };
+            const uint32_t wb = reinterpret_cast<const Bits4 *>(bits + slot * (kTileUnits / 8) + (p >> 3))->v >> (p & 7u);
+            r = (uint32_t)__builtin_ctz(~wb | (1u << kRunCap));
+        }
         struct __attribute__((packed, aligned(2), may_alias)) Run16 { uint32_t d[8]; };
         const Run16 run = *reinterpret_cast<const Run16 *>(ring + slot * kTileUnits + p);
-        PpFlight fl;
+        Flight fl;
         uint32_t h = T.ww_seed, g = T.ww_seed;
-        const uint32_t r2 = r | (r << 16);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            // units 2i and 2i+1 of the run, zero from unit r on: (index - r) >> 15 (arithmetic) is 0xffff below r, per half
-            // (the shift count as a register: an inline constant would reach the low half only)
-#ifdef PP_ZERO_ASM
-            uint32_t keep;
-            asm("v_pk_sub_i16 %0, %1, %2" : "=v"(keep) : "s"((uint32_t)((2 * i) | ((2 * i + 1) << 16))), "v"(r2));
-            asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(keep) : "s"(0x000f000fu), "v"(keep));
-            fl.fw[i] = run.d[i] & keep;
-#else
+            // units 2i and 2i+1 of the run, zero from unit r on.  (Plain C on purpose: a packed-arithmetic version of this in
+            // inline assembly, and a two-instruction h*33+w, made the kernel slower -- see DESIGN.md 4.4.)
             const int m = (int)r - 2 * i;
             fl.fw[i] = m >= 2 ? run.d[i] : (m == 1 ? (run.d[i] & 0xffffu) : 0u);
-            (void)r2;
-#endif
-#ifndef PP_HASH_ASM
-            h = ww_hash_step(h, fl.fw[i]);
-#else
-            h = pp_hash_step(h, fl.fw[i]);
-#endif
+            h = ww_hash_step(h, fl.fw[i]); // (the first 16 units are hashed as 8 words whatever the length)
             g = ww_hash2_step(g, fl.fw[i]);
+        }
+        if (LONG) {
+            // units 16..31: only when some run of the batch goes that far (wave-uniform; rare in a text of words) -- further
+            // words are hashed only as far as the run goes (k_ww_tile's chunk loop and the builder do the same)
+#pragma unroll
+            for (int i = 8; i < NW; ++i) fl.fw[i] = 0u;
+            if (__any(act && r > 16u)) {
+                const Run16 more = *reinterpret_cast<const Run16 *>(ring + slot * kTileUnits + p + 16);
+#pragma unroll
+                for (int i = 8; i < NW; ++i) {
+                    const int m = (int)r - 2 * i;
+                    fl.fw[i] = m >= 2 ? more.d[i - 8] : (m == 1 ? (more.d[i - 8] & 0xffffu) : 0u);
+                    if (m > 0) {
+                        h = ww_hash_step(h, fl.fw[i]);
+                        g = ww_hash2_step(g, fl.fw[i]);
+                    }
+                }
+            }
         }
         h = ww_hash_final(h);
         bool probing = act && r <= T.max_len && !ACGPU_DBG(L, 2u); // 2: ablation, no table lookup
@@ -880,13 +896,8 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
             const uint32_t b1 = ww_bloom_bit1(h, F.bloom_mask), b2 = ww_bloom_bit2(h, F.bloom_mask);
             probing = probing && ((F.bloom[b1 >> 5] >> (b1 & 31)) & (F.bloom[b2 >> 5] >> (b2 & 31)) & 1u);
         }
-#ifdef PP_COND_LOADS
-        fl.s1 = ww_slot1(h, T.ww_fat_mask);
-        fl.s2 = ww_slot2(h, g, T.ww_fat_mask);
-#else
         fl.s1 = probing ? ww_slot1(h, T.ww_fat_mask) : 0u;
         fl.s2 = probing ? ww_slot2(h, g, T.ww_fat_mask) : 0u;
-#endif
         fl.n = cnt > b0 ? min(cnt - b0, (uint32_t)kWave) : 0u;
         fl.probing = probing;
         fl.s = tile0 + j * kTileUnits + p;
@@ -898,7 +909,7 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
     // more than 64 run starts in a tile are rare: all but the tile's last batch are probed and compared at once
     auto early_batches = [&](uint32_t j, uint32_t cnt, uint32_t b_last) {
         for (uint32_t b0 = 0; b0 < b_last; b0 += kWave) {
-            const PpFlight now = batch(j, cnt, b0);
+            const Flight now = batch(j, cnt, b0);
             pp_consume(c, now, pp_issue(T, now));
         }
     };
@@ -907,7 +918,7 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
     // emitted.  The stream runs one tile ahead of the staging in ONE set of registers (the load goes out right after the
     // registers are staged and has a whole pass to arrive; rotating register sets would copy registers whose loads are in
     // flight, and such a copy waits for everything issued before it).
-    PpFlight fl;
+    Flight fl;
     uint32_t sm_next;
     {
         const uint32_t sm0 = stage(0, load_tile(tile0));
@@ -935,7 +946,7 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
         nx = load_tile(cur + 3 * kTileUnits);
         const uint32_t cnt = build_list(sm_next); // tile j + 1 (none beyond the span: its start mask is empty)
         const uint32_t b_last = cnt ? ((cnt - 1) & ~(uint32_t)(kWave - 1)) : 0u;
-        const PpFlight nf = batch(j + 1, cnt, b_last);
+        const Flight nf = batch(j + 1, cnt, b_last);
         pp_consume(c, fl, pr);
         if (cur + kTileUnits >= boundary && cur + kTileUnits < span_end) { // tile j + 1 opens the next region
             if (lane == 0) L.d_region_counts[region] = c.rank_base;
@@ -1006,12 +1017,16 @@ hipError_t launch_ww_tile(const DevTables &t, const TileLaunch &l, hipStream_t s
     const int fold = t.cs ? 0 : (ww_fold_pages_in_lds(t) ? 1 : 2);
     if (ww_pp_usable(t, l)) {
         const size_t lds = ww_pp_lds_bytes(l.block, t);
-        const void *fn = fold == 0 ? reinterpret_cast<const void *>(&k_ww_pp<0>) : reinterpret_cast<const void *>(&k_ww_pp<1>);
+        const bool lng = t.max_len > 16;
+        const void *fn = fold == 0 ? (lng ? reinterpret_cast<const void *>(&k_ww_pp<0, true>) : reinterpret_cast<const void *>(&k_ww_pp<0, false>))
+                                   : (lng ? reinterpret_cast<const void *>(&k_ww_pp<1, true>) : reinterpret_cast<const void *>(&k_ww_pp<1, false>));
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        if (fold == 0) hipLaunchKernelGGL(k_ww_pp<0>, dim3(l.grid), dim3(l.block), lds, stream, t, l);
-        else hipLaunchKernelGGL(k_ww_pp<1>, dim3(l.grid), dim3(l.block), lds, stream, t, l);
-        if (kernel_name) *kernel_name = fold == 0 ? "k_ww_pp<0>" : "k_ww_pp<1>";
+        if (fold == 0 && lng) hipLaunchKernelGGL((k_ww_pp<0, true>), dim3(l.grid), dim3(l.block), lds, stream, t, l);
+        else if (fold == 0) hipLaunchKernelGGL((k_ww_pp<0, false>), dim3(l.grid), dim3(l.block), lds, stream, t, l);
+        else if (lng) hipLaunchKernelGGL((k_ww_pp<1, true>), dim3(l.grid), dim3(l.block), lds, stream, t, l);
+        else hipLaunchKernelGGL((k_ww_pp<1, false>), dim3(l.grid), dim3(l.block), lds, stream, t, l);
+        if (kernel_name) *kernel_name = fold == 0 ? (lng ? "k_ww_pp<0, true>" : "k_ww_pp<0, false>") : (lng ? "k_ww_pp<1, true>" : "k_ww_pp<1, false>");
         return hipGetLastError();
     }
     const void *fn = fold == 0 ? reinterpret_cast<const void *>(&k_ww_tile<0>)

@@ -54,7 +54,7 @@ def one_case(rng, it):
     min_len = int(rng.integers(1, 6))
     max_len = min_len + int(rng.integers(0, 9))
     if fam == 2 and rng.integers(0, 4) == 0:
-        max_len = min_len + int(rng.integers(9, 24))  # keywords beyond 16 units: k_ww_tile instead of k_ww_pp
+        max_len = min_len + int(rng.integers(9, 40))  # keywords beyond 16 units: k_ww_pp's 32-unit form, beyond 32: k_ww_tile
     if fam == 2:
         kw_alpha = [c for c in alpha if WORD[c]] or [ord("a")]
     else:

@@ -485,15 +485,17 @@ def test_wholeword_mixed_script_like_config_c5():
         assert (WholeWordMatchSet(words, False).find_all(hay) == want[:, :2]).all()
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(8))
 def test_wholeword_long_words_and_hash_table_paths(seed):
     """Words longer than the 16 units the kernel keeps in registers, many words sharing long prefixes, buffer ends
     inside a word, case folding on every unit.  Seeds 4 and 5: no keyword beyond 16 units -- the position-parallel kernel
-    (k_ww_pp), whose keywords of 13..16 units compare their record, with runs of up to 17+ units in the text."""
+    (k_ww_pp), whose keywords of 13..16 units compare their record, with runs of up to 17+ units in the text; seeds 6 and 7: up
+    to 32 units, its LONG form (two ring reads per run, the tail compared with the record word by word)."""
     rng = np.random.default_rng(100 + seed)
     alpha = np.array([ord(c) for c in "abAB"] + [0x00E9, 0x00C9, 0x0391, 0x03B1], dtype=np.uint16)
     kws = []
-    lens = [1, 2, 5, 8, 9, 12, 13, 16, 17, 24, 33, 100] if seed < 4 else [1, 2, 5, 8, 9, 11, 12, 13, 14, 15, 16]
+    lens = ([1, 2, 5, 8, 9, 12, 13, 16, 17, 24, 33, 100] if seed < 4 else [1, 2, 5, 8, 9, 11, 12, 13, 14, 15, 16] if seed < 6 else
+            [1, 2, 8, 12, 13, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32])  # 6, 7: k_ww_pp's 32-unit form
     for _ in range(300):
         ln = int(rng.choice(lens))
         kws.append(alpha[rng.integers(0, len(alpha), ln)])
@@ -515,7 +517,8 @@ def test_wholeword_long_words_and_hash_table_paths(seed):
         assert got.shape == want.shape and (got == want).all()
         import torch
         _, prof = _dev_match(m.automaton, torch.from_numpy(hay.view(np.int16)).cuda(), hay.size, True, len(want) + 8, profile=True)
-        assert prof["scan_kernel"].startswith("k_ww_tile" if seed < 4 else "k_ww_pp"), prof["scan_kernel"]
+        kn = prof["scan_kernel"]
+        assert kn.startswith("k_ww_tile") if seed < 4 else (kn.startswith("k_ww_pp") and kn.endswith("false>" if seed < 6 else "true>")), kn
         N.set_tunable("force_kernel", 1)  # the trie-walk verification agrees
         got2 = WholeWordMatchMap(kws, _ids(len(kws)), cs).find_all(hay)
         N.set_tunable("force_kernel", 0)

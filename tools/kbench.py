@@ -40,6 +40,8 @@ def main():
         if wwl:
             sp = np.array([32], dtype=np.uint16)
             kws = list(kws) + [np.concatenate([kws[i], sp, kws[i + 1]]) for i in range(0, 20000, 2)]
+        if os.environ.get("KBENCH_EXTRA_KW"):  # one more keyword of that many units (24: the 32-unit form of k_ww_pp; 40: k_ww_tile)
+            kws = list(kws) + [np.full(int(os.environ["KBENCH_EXTRA_KW"]), ord("q"), dtype=np.uint16)]
         a = Automaton(N.MODE_WWLONGEST if wwl else N.MODE_WHOLEWORD, kws, False, word_chars=default_word_chars())
         d_hay = torch.empty(n, dtype=torch.int16, device="cuda")
         synth.token_stream_on_device(d_hay.data_ptr(), n, synth.CONFIGS["C5"]["hay_seed"], synth.config_keywords("C5"), synth.swapcase_table())
