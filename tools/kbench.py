@@ -33,6 +33,9 @@ def main():
     shortest = args.config == "C2S"  # config 2's dictionary and haystack through ShortestMatchMap
     if shortest:
         args.config = "C2"
+    for kv in filter(None, os.environ.get("KBENCH_BUILD_TUNABLES", "").split(",")):  # builder knobs (e.g. no_tails=1) for A/B of table forms
+        k, v = kv.split("=")
+        N.set_tunable(k, int(v))
     kws = synth.config_keywords(args.config)
     if args.config == "C5":
         from ahocorasick_amd.unicode_tables import default_word_chars
