@@ -227,6 +227,8 @@ int ensure_device(acgpu_automaton *a, DeviceState **out) {
     }
     if ((rc = upload(*d, t.rterm, &T.rterm))) return rc;
     if ((rc = upload(*d, t.rtab, &T.rtab))) return rc;
+    T.kshort = nullptr;
+    if (t.has_short && (rc = upload(*d, t.kshort, &T.kshort))) return rc;
     T.rdense = t.rdense;
     if ((rc = upload(*d, t.rhkeys, &T.rhkeys))) return rc;
     if ((rc = upload(*d, t.rhvals, &T.rhvals))) return rc;
@@ -1302,6 +1304,7 @@ int64_t acgpu_set_tunable(const char *name, int64_t value) {
     else if (!std::strcmp(name, "rdense_budget_bytes")) slot = &t.rdense_budget_bytes;
     else if (!std::strcmp(name, "filter_max_bytes")) slot = &t.filter_max_bytes;
     else if (!std::strcmp(name, "no_merged_ranges")) slot = &t.no_merged_ranges;
+    else if (!std::strcmp(name, "no_short_keywords")) slot = &t.no_short_keywords;
     if (!slot) return -1;
     return slot->exchange(value, std::memory_order_relaxed);
 }

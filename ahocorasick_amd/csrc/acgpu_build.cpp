@@ -655,13 +655,24 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
             if (t.range_cls) return (uint32_t)folded_unit - t.cls_base;
             return cls_of[folded_unit];
         };
+        // Short keywords (round 3).  K used to be at most the SHORTEST keyword, so one two-letter entry took a 10 k-word dictionary
+        // from K = 4 to K = 2 and its scan from 0.26 to 6 ms.  Now keywords of fewer than K units (K <= 4 then: lengths 1..3) sit
+        // beside the K-gram filter: a short keyword sets the filter bit of EVERY K-gram that ends with it (its missing left
+        // context as a wild card), so a position passes where a long keyword's K-suffix or a whole short keyword ends; the
+        // second level lets such a position through by testing the row with "other" as the leading class (only wild cards set
+        // it); and the verification takes the short keywords that end at a candidate from a table indexed by the last K-1
+        // classes (kshort).  Not with bucketed / merged classes, whose verification goes by units.
+        const bool shorts_ok = !t.hashk && !tunables().no_short_keywords && !tunables().force_sparse;
+        const uint32_t k_cap = (shorts_ok && t.min_len < 4) ? std::min<uint32_t>(t.max_len, 4u) : t.min_len;
         uint32_t K = 1;
         uint64_t rows = 1; // n^(K-1)
-        while (K < t.min_len && K < (merged ? 4u : t.hashk ? 3u : 8u) && rows * n * t.filt_row_bytes <= (uint64_t)tunables().filter_max_bytes &&
+        while (K < k_cap && K < (merged ? 4u : t.hashk ? 3u : 8u) && rows * n * t.filt_row_bytes <= (uint64_t)tunables().filter_max_bytes &&
                rows * n * n <= (1ull << 24)) {
             rows *= n;
             K++;
         }
+        t.has_short = K > t.min_len;
+        t.kshort.clear();
         {
             // reversed trie: walking a terminal node's parent chain in the forward trie spells the reversed keyword
             struct RNode { uint32_t parent; uint16_t unit; uint32_t depth; uint32_t kw; uint32_t n_child; uint32_t only_child; };
@@ -752,6 +763,35 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
                     } else {
                         t.kgram_node[(hi * n + last) * 2] = ref(i);
                         t.kgram_node[(hi * n + last) * 2 + 1] = rn[i].n_child == 1 ? ref(rn[i].only_child) : 0u;
+                    }
+                }
+                if (t.has_short) {
+                    // kshort[g], g = index of the last K-1 classes (oldest most significant): {node + 1 of the keyword that is the
+                    // last unit, the last two, the last three, 0}; and the wild-card bits of the filter
+                    t.kshort.assign(rows * 4, 0u);
+                    std::vector<uint32_t> sc; // a short keyword's classes in text order
+                    for (uint32_t i = 1; i < RN; i++) {
+                        const uint32_t Ls = rn[i].depth;
+                        if (Ls >= K || rn[i].kw == ~0u) continue;
+                        sc.assign(Ls, 0u);
+                        for (uint32_t p = i, j = 0; p != 0; p = rn[p].parent, j++) sc[j] = tcls(rn[p].unit); // walking up: text order
+                        uint64_t body = 0, tail = 0; // the keyword without its last class / whole, as digits
+                        for (uint32_t j = 0; j + 1 < Ls; j++) body = body * n + sc[j];
+                        for (uint32_t j = 0; j < Ls; j++) tail = tail * n + sc[j];
+                        uint64_t pw_body = 1, pw_tail = 1, free_rows = 1, free_grams = 1;
+                        for (uint32_t j = 0; j + 1 < Ls; j++) pw_body *= n;
+                        for (uint32_t j = 0; j < Ls; j++) pw_tail *= n;
+                        for (uint32_t j = 0; j < K - Ls; j++) free_rows *= n;      // rows: K-1 classes, the last Ls-1 fixed
+                        for (uint32_t j = 0; j + 1 < K - Ls; j++) free_grams *= n; // kshort: K-1 classes, the last Ls fixed
+                        const uint32_t last = sc[Ls - 1];
+                        for (uint64_t f = 0; f < free_rows; f++) {
+                            const uint64_t hi = f * pw_body + body;
+                            uint32_t *word = t.filt_row_bytes == 4 ? &t.filt_bits[hi] : &t.filt_bits[hi * 2 + (last >> 5)];
+                            const uint32_t bit = 1u << (last & 31);
+                            if (!(*word & bit)) n_set++;
+                            *word |= bit;
+                        }
+                        for (uint64_t f = 0; f < free_grams; f++) t.kshort[(f * pw_tail + tail) * 4 + (Ls - 1)] = i + 1;
                     }
                 }
                 // second-level filter (range classes below 32, K <= 5): every reverse node of depth D, and every terminal

@@ -151,6 +151,8 @@ struct HostTables {
     std::vector<uint32_t> kgram_node;  // filt_n^K pairs {flagged ref of the depth-K node (0 = none), flagged ref of its
                                        // only child (0 = none or several)}: the common one-step walk needs no second load
     std::vector<uint32_t> rterm;       // per reverse node: keyword id (valid when the terminal flag is set)
+    bool has_short = false;            // keywords of fewer than filt_k units exist (acgpu_build.cpp 7, "Short keywords")
+    std::vector<uint32_t> kshort;      // filt_n^(filt_k-1) entries of 4 words: node + 1 of the keyword of 1, 2, 3 units that ends here
     bool rdense = false;
     std::vector<uint32_t> rtab;        // dense: n_rstates * filt_n flagged child refs indexed by tile class (0 = none)
     std::vector<uint64_t> rhkeys;      // hashed: (node, folded unit) -> flagged child ref
@@ -224,7 +226,7 @@ struct DevTables {
     int32_t range_cls, cs, dense, entry_bytes;
     uint32_t lds_entries; // leading dfa entries staged in LDS by the scan kernel
     // k-gram filter / reversed trie
-    const uint32_t *filt_bits, *kgram_node, *rterm, *rtab;
+    const uint32_t *filt_bits, *kgram_node, *rterm, *rtab, *kshort; // kshort: nullptr = no keyword is shorter than filt_k
     const uint64_t *rhkeys;
     const uint32_t *rhvals;
     uint32_t rhmask, filt_k, filt_n, filt_other, filt_words, filt_row_bytes;
@@ -266,6 +268,7 @@ struct Tunables {
 #define ACGPU_FILTER_MAX_BYTES 88000
 #endif
     std::atomic<int64_t> filter_max_bytes{ACGPU_FILTER_MAX_BYTES};  // the filter rows must fit LDS next to the candidate queues
+    std::atomic<int64_t> no_short_keywords{0}; // builder: 1 = the filter's K stays at most the shortest keyword (A/B)
     std::atomic<int64_t> no_merged_ranges{0}; // builder: 1 = mixed-case dictionaries keep the 8-byte-row scalar filter (A/B)
     std::atomic<int64_t> ww_first_seed{0};    // WHOLEWORD builder: first hash seed tried (tests: the fallback seeds end to end)
 };

@@ -151,6 +151,7 @@ __device__ __forceinline__ void verify_multi(TileCtx &c, uint32_t head, uint32_t
         }
         m[b] = 0; one_len[b] = 0; one_node[b] = 0; d[b] = K; left_unit[b] = 0;
     }
+    uint32_t kidx[NB]; // the K-gram index (short keywords are looked up by its last K-1 classes)
     bool need_win = true; // wave-uniform: some candidate comes without its K-gram index
     if (QI) {
         bool unknown = false;
@@ -195,6 +196,7 @@ __device__ __forceinline__ void verify_multi(TileCtx &c, uint32_t head, uint32_t
         } else if (K < 8 && need_win) {
             lcls[b] = tile_class_t<RANGE>(T, left_unit[b]);
         }
+        kidx[b] = idx;
         uint2 ent = make_uint2(idx & 1u, 0u); // 16: ablation, no K-gram node load
         if (HASHK) {
             ent = make_uint2(0u, 0u);
@@ -267,12 +269,42 @@ __device__ __forceinline__ void verify_multi(TileCtx &c, uint32_t head, uint32_t
         }
     }
     VT_MARK(2)
+    // keywords of fewer than K units that end at a candidate (DevTables::kshort; the second-level stage marks the candidates
+    // they can end at, an entry without that knowledge is looked up): node + 1 per length 1..3, in the order of the lengths
+    uint32_t ms[NB];
+    uint4 sh[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        ms[b] = 0;
+        sh[b] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    if (!HASHK && T.kshort != nullptr) { // wave-uniform
+        uint32_t grams = 1;
+#pragma unroll
+        for (int j = 0; j < K - 1; ++j) grams *= T.filt_n;
+        bool want[NB], any_want = false;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            want[b] = act[b] && (!(QI && (info[b] & kQiKnown)) || (info[b] & kQiShort));
+            any_want |= want[b];
+        }
+        if (__any(any_want)) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                if (want[b]) sh[b] = reinterpret_cast<const uint4 *>(T.kshort)[kidx[b] % grams];
+                if (e[b] < 1u) sh[b].x = 0; // (a keyword does not begin before the buffer does)
+                if (e[b] < 2u) sh[b].y = 0;
+                if (e[b] < 3u) sh[b].z = 0;
+                ms[b] = (sh[b].x != 0) + (sh[b].y != 0) + (sh[b].z != 0);
+            }
+        }
+    }
     // record slots and ranks in text order: batch 0's lanes, then batch 1's, ...
     uint32_t prefix[NB], total = 0;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-        const uint32_t incl = wave_inclusive_scan_dpp(m[b]);
-        prefix[b] = total + incl - m[b];
+        const uint32_t incl = wave_inclusive_scan_dpp(m[b] + ms[b]);
+        prefix[b] = total + incl - (m[b] + ms[b]);
         total += __builtin_amdgcn_readlane(incl, kWave - 1);
     }
     if (total == 0 || ACGPU_DBG(L, 32u)) return; // 32: ablation, no record emission
@@ -303,6 +335,20 @@ __device__ __forceinline__ void verify_multi(TileCtx &c, uint32_t head, uint32_t
                     ++dd;
                 }
             }
+        }
+    }
+    // the short keywords come last (longest first): of them, too, the longer before the shorter
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        if (ms[b] == 0) continue;
+        const uint32_t ids[3] = {sh[b].x, sh[b].y, sh[b].z};
+        uint32_t r = 0;
+#pragma unroll
+        for (uint32_t len = 1; len <= 3; ++len) {
+            if (ids[len - 1] == 0) continue;
+            const uint32_t k = prefix[b] + m[b] + (ms[b] - 1 - r);
+            store_rec(L, slot_of(k), e[b] - len, e[b], ids[len - 1] - 1, c.rank_base + k);
+            ++r;
         }
     }
     c.rank_base += total;
@@ -574,7 +620,9 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
 #endif
             // positions a lane may report: inside the region, in the vector part of the buffer, with K units to their
             // left in the buffer.  Only groups at the edges of a region need the per-lane mask.
-            const uint32_t lo = max(rb, (uint32_t)(K - 1));
+            // (with short keywords every position counts: the units before the buffer are zeros in the carry, and the wild
+            // cards of the short keywords cover whatever class those get)
+            const uint32_t lo = T.kshort != nullptr ? rb : max(rb, (uint32_t)(K - 1));
             const uint32_t top = min(re, hi);
             const bool edge = tile < lo || tile + kAcTiles * kAcTileUnits > top; // wave-uniform
             bool resume = false;
@@ -772,7 +820,15 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                             const uint32_t bits = __builtin_amdgcn_alignbit(pat, pat, l2_rot(cls, len, K));
                             pass |= (word & bits) == bits;
                         }
-                        pass = (pass || ACGPU_DBG(L, 4096u)) && act; // 4096: ablation, the second level passes everything
+                        // a keyword of fewer than K units: only their wild cards set a bit in a row whose leading class is "other"
+                        uint32_t shortbit = 0;
+                        if (T.kshort != nullptr) { // wave-uniform
+                            uint32_t hrow = T.filt_other;
+#pragma unroll
+                            for (int j = K - 2; j >= 1; --j) hrow = hrow * n + cls[j];
+                            shortbit = (rows32[hrow] >> cls[0]) & 1u;
+                        }
+                        pass = (pass || shortbit || ACGPU_DBG(L, 4096u)) && act; // 4096: ablation, the second level passes everything
                         const uint64_t bal = __ballot(pass);
                         if (pass) { // the entry: position in the region, K-gram index (oldest unit most significant), left class
                             const uint32_t at = c.cand_n + (uint32_t)__popcll(bal & lanemask_lt());
@@ -785,7 +841,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
 #endif
                             c.pos16[at] = (uint16_t)(cur + p - c.pos_base);
                             // (HASHK: a class K-gram does not name a K-gram of units -- the verification reads the window)
-                            c.cand[at] = HASHK ? 0u : kQiKnown | (cls[K] << kQiLeftShift) | idx;
+                            c.cand[at] = HASHK ? 0u : kQiKnown | (shortbit ? kQiShort : 0u) | (cls[K] << kQiLeftShift) | idx;
                         }
                         c.cand_n += (uint32_t)__popcll(bal);
                     }
@@ -856,9 +912,9 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
             }
             const uint32_t pos = t0 + lane;
             uint32_t mask = 0;
-            if (pos < span_end && pos + 1 >= (uint32_t)K && !ACGPU_DBG(L, 4u)) {
+            if (pos < span_end && (pos + 1 >= (uint32_t)K || T.kshort != nullptr) && !ACGPU_DBG(L, 4u)) {
                 uint32_t hrow = 0;
-                for (int j = K - 1; j >= 1; --j) hrow = hrow * n + tile_class_t<RANGE>(T, hay[pos - j]);
+                for (int j = K - 1; j >= 1; --j) hrow = hrow * n + (pos >= (uint32_t)j ? tile_class_t<RANGE>(T, hay[pos - j]) : T.filt_other);
                 const uint32_t last = tile_class_t<RANGE>(T, hay[pos]);
                 const uint32_t word = rows32[hrow * (ROWB / 4) + (last >> 5)];
                 mask = (word >> (last & 31)) & 1u;

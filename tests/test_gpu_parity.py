@@ -108,18 +108,25 @@ def test_chunking_lds_and_sparse_variants_agree(chunk_units, lds_bytes, sparse):
 
 @pytest.mark.parametrize("region_units,min_len", [(512, 1), (512, 2), (1024, 3), (512, 4), (4096, 6), (0, 8)])
 def test_tile_kernel_regions_and_filter_lengths(region_units, min_len):
-    # the K-gram filter length follows the shortest keyword (K <= min_len); small regions stress the region seams
+    # the K-gram filter length: at most the shortest keyword when that has 4 units or more (or with the builder knob
+    # no_short_keywords), else up to 4 with the shorter keywords beside the filter; small regions stress the region seams
     N.set_tunable("force_kernel", 2)
     N.set_tunable("region_units", region_units)
     rng = np.random.default_rng(1000 + min_len)
     for alpha in ([ord(c) for c in "ab"], list(range(ord("a"), ord("h") + 1)), [ord(c) for c in "abAB"] + [0x00E9, 0x00C9]):
         hay, kws = rand_case(rng, alpha, 30, min_len + 5, 30011, min_len=min_len)
         for cs in (True, False):
-            m = AhoCorasickMap(kws, _ids(len(kws)), cs)
-            info = m.automaton.info()
-            assert info["filter_k"] >= 1 and info["filter_k"] <= min(info["min_keyword_len"], 8) and info["tile_kernel"] == 1
             want = Oracle(FAM_AC, kws, case_sensitive=cs, lower=LOWER).match(hay).tolist()
-            assert m.find_all(hay).tolist() == want
+            for no_short in (0, 1):
+                N.set_tunable("no_short_keywords", no_short)
+                try:
+                    m = AhoCorasickMap(kws, _ids(len(kws)), cs)
+                finally:
+                    N.set_tunable("no_short_keywords", 0)
+                info = m.automaton.info()
+                k_max = info["min_keyword_len"] if (no_short or info["min_keyword_len"] >= 4) else min(4, info["max_keyword_len"])
+                assert 1 <= info["filter_k"] <= min(k_max, 8) and info["tile_kernel"] == 1
+                assert m.find_all(hay).tolist() == want
 
 
 def test_kernel_selection_defaults():
@@ -1789,6 +1796,73 @@ def test_merged_stretches_phrases_and_case_insensitive(shape):
     w2 = Oracle(FAM_AC, kws, case_sensitive=cs, lower=LOWER).match(hay[:70003])
     g2, _ = _dev_match(m.automaton, d_hay, 70003, True, len(w2) + 8, profile=True)
     assert g2.shape == w2.shape and (g2 == w2).all()
+
+
+@pytest.mark.parametrize("shape", ["range", "ci", "lut_wide", "only_short", "k3"])
+def test_short_keywords_beside_the_k_gram_filter(shape):
+    """Keywords of fewer than K units no longer pull the filter's K down to their length: they set wild-card bits, pass the
+    second level through the 'other'-led row and are reported from the table of the last K-1 classes -- after the longer
+    keywords that end at the same position (longest first), at the very start of the text, in shards and with several short
+    and long keywords ending together."""
+    import torch
+    rng = np.random.default_rng(hash(shape) % 997)
+    cs = shape != "ci"
+    if shape == "lut_wide":  # more than 32 classes that are no range: the scalar filter with 8-byte rows
+        alpha = [ord(c) for c in "abcdefghijklmnopqrstuvwxyzABCDEFGHIJ 0123"]
+    else:
+        alpha = list(range(ord("a"), ord("a") + (8 if shape != "k3" else 26)))
+    kws = [np.array(rng.choice(alpha, int(rng.integers(4, 10))), dtype=np.uint16) for _ in range(300 if shape != "only_short" else 0)]
+    shorts = [[alpha[0]], [alpha[1], alpha[0]], [alpha[0], alpha[1]], [alpha[2], alpha[0], alpha[1]], [alpha[3]] * 3, [alpha[3]] * 2,
+              [alpha[4], alpha[5]]]
+    if shape == "k3":
+        shorts = [s for s in shorts if len(s) > 1] + [[alpha[9], alpha[7]]]
+        kws = [k[:3 + int(rng.integers(0, 6))] for k in kws]  # longest keywords: K stays 4; some of 3
+    kws += [np.array(s, dtype=np.uint16) for s in shorts]
+    if kws and shape != "only_short":
+        kws.append(np.concatenate([kws[0], np.array(shorts[3], dtype=np.uint16)]))  # a long keyword that ends with a short one
+    if shape == "ci":
+        kws = [np.where(rng.integers(0, 2, k.size) == 1, k - 32, k).astype(np.uint16) for k in kws]
+    hay_alpha = np.array(alpha[:10] + ([c - 32 for c in alpha[:6]] if shape == "ci" else []) + [ord("!")], dtype=np.uint16)
+    hay = hay_alpha[rng.integers(0, len(hay_alpha), 200003)]
+    hay[:3] = np.array(shorts[3], dtype=np.uint16)  # short keywords at the very start of the text
+    for i, k in enumerate(kws * 2):
+        p0 = 50 + i * 41
+        if p0 + k.size < hay.size:
+            hay[p0:p0 + k.size] = k
+    orc = Oracle(FAM_AC, kws, case_sensitive=cs, lower=LOWER)
+    want = orc.match(hay)
+    d_hay = torch.from_numpy(hay.view(np.int16)).cuda()
+    m = AhoCorasickMap(kws, _ids(len(kws)), cs)
+    info = m.automaton.info()
+    assert info["filter_k"] > info["min_keyword_len"] and info["filter_k"] == (3 if shape == "lut_wide" else min(4, info["max_keyword_len"])), info
+    got, prof = _dev_match(m.automaton, d_hay, hay.size, True, len(want) + 8, profile=True)
+    assert len(want) > 1000 and got.shape == want.shape and (got == want).all(), prof["scan_kernel"]
+    assert 0 in got[:8, 0].tolist() and got[0, 1] <= 2  # matches at the very start of the text
+    for n in (1, 2, 3, 5, hay.size - 5):  # texts shorter than K; a tail of fewer than 8 units
+        w2 = orc.match(hay[:n])
+        g2, _ = _dev_match(m.automaton, d_hay, n, True, len(w2) + 8, profile=True)
+        assert g2.shape == w2.shape and (g2 == w2).all(), n
+    for knobs in ({"force_kernel": 3}, {"tile_debug": 2048}, {"tile_debug": 1024}):  # split form, no second level, scalar filter
+        for k, v in knobs.items():
+            N.set_tunable(k, v)
+        try:
+            g3, p3 = _dev_match(m.automaton, d_hay, hay.size, True, len(want) + 8, profile=True)
+        finally:
+            for k in knobs:
+                N.set_tunable(k, 0)
+        assert g3.shape == want.shape and (g3 == want).all(), (knobs, p3["scan_kernel"])
+    # shards: a rank owns the matches whose last unit it owns
+    cuts = [0, 66671, 66673, hay.size]
+    parts = [_dev_match(m.automaton, d_hay, hay.size, True, len(want) + 8, own=(cuts[r], cuts[r + 1]))[0] for r in range(3)]
+    assert (np.concatenate(parts) == want).all()
+    N.set_tunable("no_short_keywords", 1)
+    try:
+        m0 = AhoCorasickMap(kws, _ids(len(kws)), cs)
+        assert m0.automaton.info()["filter_k"] == info["min_keyword_len"]
+        g0, _ = _dev_match(m0.automaton, d_hay, hay.size, True, len(want) + 8, profile=True)
+    finally:
+        N.set_tunable("no_short_keywords", 0)
+    assert (g0 == want).all()
 
 
 # ---- the pipelined single-GPU driver (bench.py's N=1 path), device-side result header, stream rule ------------------

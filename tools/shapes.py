@@ -44,6 +44,9 @@ shapes = {
     "C2 mixed-case phrases, case-sensitive": ([upper_letters(k) for k in phrases], True),
     "C2 mixed-case phrases, case-insensitive": ([upper_letters(k) for k in phrases], False),
     "C2 keywords as phrases, case-insensitive, class table form": (phrases, False, {"no_merged_ranges": 1}),
+    "C2 + one keyword of 3 units": (list(kws) + [np.array([113, 120, 122], dtype=np.uint16)], True),
+    "C2 + one keyword of 2 units": (list(kws) + [np.array([113, 120], dtype=np.uint16)], True),
+    "C2 + one keyword of 1 unit": (list(kws) + [np.array([113], dtype=np.uint16)], True),
     "1000 keywords len 3-8 (K=3)": (synth.random_keywords(7, 1000, 3, 8), True),
     "100 keywords len 2-6 (K=2)": (synth.random_keywords(8, 100, 2, 6), True),
     "30k keywords len 4-12": (synth.random_keywords(9, 30000, 4, 12), True),
