@@ -227,8 +227,12 @@ int ensure_device(acgpu_automaton *a, DeviceState **out) {
     }
     if ((rc = upload(*d, t.rterm, &T.rterm))) return rc;
     if ((rc = upload(*d, t.rtab, &T.rtab))) return rc;
-    T.kshort = nullptr;
-    if (t.has_short && (rc = upload(*d, t.kshort, &T.kshort))) return rc;
+    T.kshort = nullptr; T.ks_keys = nullptr; T.ks_vals = nullptr; T.ks_mask = t.ks_mask; T.has_short = t.has_short ? 1u : 0u;
+    if (t.has_short && !t.kshort.empty() && (rc = upload(*d, t.kshort, &T.kshort))) return rc;
+    if (t.has_short && !t.ks_keys.empty()) {
+        if ((rc = upload(*d, t.ks_keys, &T.ks_keys))) return rc;
+        if ((rc = upload(*d, t.ks_vals, &T.ks_vals))) return rc;
+    }
     T.rdense = t.rdense;
     if ((rc = upload(*d, t.rhkeys, &T.rhkeys))) return rc;
     if ((rc = upload(*d, t.rhvals, &T.rhvals))) return rc;

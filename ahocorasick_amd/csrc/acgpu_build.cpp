@@ -559,6 +559,8 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
         // a keyword unit only (any other unit may get any class: a false positive the verification drops), and it is CHECKED here
         // for all 65536 raw units; raw units beyond the low zone that holds the ranges (U+0130 -> i, U+212A -> k) go through the
         // class table, as for the folded range classes.
+        // (keywords shorter than the filter's K sit beside it, see "Short keywords" below: then the LONGEST keyword bounds K)
+        const bool shorts_ok = !tunables().no_short_keywords && !tunables().force_sparse;
         bool merged = false;
         std::vector<uint32_t> mg_starts; // first unit of every stretch (ascending)
         uint32_t mg_span = 0;
@@ -566,7 +568,7 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
             size_t i = std::upper_bound(mg_starts.begin(), mg_starts.end(), f) - mg_starts.begin();
             return f - mg_starts[i - 1];
         };
-        if (!t.hashk && !t.fold_range && (t.range_cls ? t.n_cls > 32 : true) && t.min_len >= 2 && !tunables().force_sparse &&
+        if (!t.hashk && !t.fold_range && (t.range_cls ? t.n_cls > 32 : true) && (shorts_ok ? t.max_len : t.min_len) >= 2 && !tunables().force_sparse &&
             !tunables().no_merged_ranges) {
             std::vector<uint8_t> is_kw(65536, 0);
             for (uint32_t i = 1; i < N; i++) is_kw[nodes[i].unit] = 1;
@@ -661,8 +663,8 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
         // context as a wild card), so a position passes where a long keyword's K-suffix or a whole short keyword ends; the
         // second level lets such a position through by testing the row with "other" as the leading class (only wild cards set
         // it); and the verification takes the short keywords that end at a candidate from a table indexed by the last K-1
-        // classes (kshort).  Not with bucketed / merged classes, whose verification goes by units.
-        const bool shorts_ok = !t.hashk && !tunables().no_short_keywords && !tunables().force_sparse;
+        // classes (kshort) -- bucketed / merged classes, whose verification goes by units: from a hash table keyed by the length
+        // and the units themselves (ks_keys / ks_vals).
         const uint32_t k_cap = (shorts_ok && t.min_len < 4) ? std::min<uint32_t>(t.max_len, 4u) : t.min_len;
         uint32_t K = 1;
         uint64_t rows = 1; // n^(K-1)
@@ -673,6 +675,8 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
         }
         t.has_short = K > t.min_len;
         t.kshort.clear();
+        t.ks_keys.clear();
+        t.ks_vals.clear();
         {
             // reversed trie: walking a terminal node's parent chain in the forward trie spells the reversed keyword
             struct RNode { uint32_t parent; uint16_t unit; uint32_t depth; uint32_t kw; uint32_t n_child; uint32_t only_child; };
@@ -768,7 +772,8 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
                 if (t.has_short) {
                     // kshort[g], g = index of the last K-1 classes (oldest most significant): {node + 1 of the keyword that is the
                     // last unit, the last two, the last three, 0}; and the wild-card bits of the filter
-                    t.kshort.assign(rows * 4, 0u);
+                    if (!t.hashk) t.kshort.assign(rows * 4, 0u);
+                    std::vector<std::pair<uint64_t, uint32_t>> ks; // hashk: (length << 48 | folded units, leftmost lowest) -> node + 1
                     std::vector<uint32_t> sc; // a short keyword's classes in text order
                     for (uint32_t i = 1; i < RN; i++) {
                         const uint32_t Ls = rn[i].depth;
@@ -791,7 +796,26 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
                             if (!(*word & bit)) n_set++;
                             *word |= bit;
                         }
-                        for (uint64_t f = 0; f < free_grams; f++) t.kshort[(f * pw_tail + tail) * 4 + (Ls - 1)] = i + 1;
+                        if (!t.hashk) {
+                            for (uint64_t f = 0; f < free_grams; f++) t.kshort[(f * pw_tail + tail) * 4 + (Ls - 1)] = i + 1;
+                        } else {
+                            uint64_t key = (uint64_t)Ls << 48;
+                            for (uint32_t p = i, shift = 0; p != 0; p = rn[p].parent, shift += 16) key |= (uint64_t)rn[p].unit << shift;
+                            ks.emplace_back(key, i + 1);
+                        }
+                    }
+                    if (t.hashk) {
+                        uint64_t cap = 16;
+                        while (cap < 2 * (uint64_t)ks.size() + 2) cap <<= 1;
+                        t.ks_keys.assign(cap, kEmptyKey);
+                        t.ks_vals.assign(cap, 0);
+                        t.ks_mask = (uint32_t)(cap - 1);
+                        for (auto &kv : ks) {
+                            uint32_t slot = edge_hash(kv.first) & t.ks_mask;
+                            while (t.ks_keys[slot] != kEmptyKey) slot = (slot + 1) & t.ks_mask;
+                            t.ks_keys[slot] = kv.first;
+                            t.ks_vals[slot] = kv.second;
+                        }
                     }
                 }
                 // second-level filter (range classes below 32, K <= 5): every reverse node of depth D, and every terminal

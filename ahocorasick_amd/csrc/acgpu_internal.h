@@ -153,6 +153,9 @@ struct HostTables {
     std::vector<uint32_t> rterm;       // per reverse node: keyword id (valid when the terminal flag is set)
     bool has_short = false;            // keywords of fewer than filt_k units exist (acgpu_build.cpp 7, "Short keywords")
     std::vector<uint32_t> kshort;      // filt_n^(filt_k-1) entries of 4 words: node + 1 of the keyword of 1, 2, 3 units that ends here
+    std::vector<uint64_t> ks_keys;     // bucketed / merged classes: the same by units -- (length << 48 | folded units) -> node + 1
+    std::vector<uint32_t> ks_vals;
+    uint32_t ks_mask = 0;
     bool rdense = false;
     std::vector<uint32_t> rtab;        // dense: n_rstates * filt_n flagged child refs indexed by tile class (0 = none)
     std::vector<uint64_t> rhkeys;      // hashed: (node, folded unit) -> flagged child ref
@@ -226,7 +229,10 @@ struct DevTables {
     int32_t range_cls, cs, dense, entry_bytes;
     uint32_t lds_entries; // leading dfa entries staged in LDS by the scan kernel
     // k-gram filter / reversed trie
-    const uint32_t *filt_bits, *kgram_node, *rterm, *rtab, *kshort; // kshort: nullptr = no keyword is shorter than filt_k
+    const uint32_t *filt_bits, *kgram_node, *rterm, *rtab, *kshort; // kshort: nullptr = no keyword is shorter than filt_k (or hashk)
+    const uint64_t *ks_keys;                                        // hashk: short keywords by units (nullptr: none)
+    const uint32_t *ks_vals;
+    uint32_t ks_mask, has_short;
     const uint64_t *rhkeys;
     const uint32_t *rhvals;
     uint32_t rhmask, filt_k, filt_n, filt_other, filt_words, filt_row_bytes;

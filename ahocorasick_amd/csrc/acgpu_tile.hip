@@ -285,7 +285,7 @@ __device__ __forceinline__ void verify_multi(TileCtx &c, uint32_t head, uint32_t
         bool want[NB], any_want = false;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            want[b] = act[b] && (!(QI && (info[b] & kQiKnown)) || (info[b] & kQiShort));
+            want[b] = act[b] && (!(QI && (info[b] & kQiChecked)) || (info[b] & kQiShort));
             any_want |= want[b];
         }
         if (__any(any_want)) {
@@ -296,6 +296,44 @@ __device__ __forceinline__ void verify_multi(TileCtx &c, uint32_t head, uint32_t
                 if (e[b] < 2u) sh[b].y = 0;
                 if (e[b] < 3u) sh[b].z = 0;
                 ms[b] = (sh[b].x != 0) + (sh[b].y != 0) + (sh[b].z != 0);
+            }
+        }
+    }
+    if (HASHK && T.ks_keys != nullptr) { // bucketed / merged classes: the short keywords by their units (the window is loaded)
+        bool want[NB], any_want = false;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            want[b] = act[b] && (!(QI && (info[b] & kQiChecked)) || (info[b] & kQiShort));
+            any_want |= want[b];
+        }
+        if (__any(any_want)) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                uint32_t found[3] = {0u, 0u, 0u};
+                if (want[b]) {
+#pragma unroll
+                    for (uint32_t len = 1; len <= 3; ++len) {
+                        if (len >= (uint32_t)K || e[b] < len) continue;
+                        uint64_t key = (uint64_t)len << 48;
+                        for (uint32_t t = 0; t < len; ++t) {
+                            const uint32_t j = 8 - len + t; // unit e - len + t of the window
+                            const uint32_t u = (win[b].d[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+                            key |= (uint64_t)(T.cs ? u : (uint32_t)T.lower[u]) << (16 * t);
+                        }
+                        uint32_t slot = edge_hash(key) & T.ks_mask;
+                        for (;;) {
+                            const uint64_t kk = T.ks_keys[slot];
+                            if (kk == key) {
+                                found[len - 1] = T.ks_vals[slot];
+                                break;
+                            }
+                            if (kk == kEmptyKey) break;
+                            slot = (slot + 1) & T.ks_mask;
+                        }
+                    }
+                }
+                sh[b] = make_uint4(found[0], found[1], found[2], 0u);
+                ms[b] = (found[0] != 0) + (found[1] != 0) + (found[2] != 0);
             }
         }
     }
@@ -622,7 +660,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
             // left in the buffer.  Only groups at the edges of a region need the per-lane mask.
             // (with short keywords every position counts: the units before the buffer are zeros in the carry, and the wild
             // cards of the short keywords cover whatever class those get)
-            const uint32_t lo = T.kshort != nullptr ? rb : max(rb, (uint32_t)(K - 1));
+            const uint32_t lo = T.has_short ? rb : max(rb, (uint32_t)(K - 1));
             const uint32_t top = min(re, hi);
             const bool edge = tile < lo || tile + kAcTiles * kAcTileUnits > top; // wave-uniform
             bool resume = false;
@@ -822,7 +860,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                         }
                         // a keyword of fewer than K units: only their wild cards set a bit in a row whose leading class is "other"
                         uint32_t shortbit = 0;
-                        if (T.kshort != nullptr) { // wave-uniform
+                        if (T.has_short) { // wave-uniform
                             uint32_t hrow = T.filt_other;
 #pragma unroll
                             for (int j = K - 2; j >= 1; --j) hrow = hrow * n + cls[j];
@@ -841,7 +879,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
 #endif
                             c.pos16[at] = (uint16_t)(cur + p - c.pos_base);
                             // (HASHK: a class K-gram does not name a K-gram of units -- the verification reads the window)
-                            c.cand[at] = HASHK ? 0u : kQiKnown | (shortbit ? kQiShort : 0u) | (cls[K] << kQiLeftShift) | idx;
+                            c.cand[at] = HASHK ? (kQiChecked | (shortbit ? kQiShort : 0u)) : kQiKnown | kQiChecked | (shortbit ? kQiShort : 0u) | (cls[K] << kQiLeftShift) | idx;
                         }
                         c.cand_n += (uint32_t)__popcll(bal);
                     }
@@ -912,7 +950,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
             }
             const uint32_t pos = t0 + lane;
             uint32_t mask = 0;
-            if (pos < span_end && (pos + 1 >= (uint32_t)K || T.kshort != nullptr) && !ACGPU_DBG(L, 4u)) {
+            if (pos < span_end && (pos + 1 >= (uint32_t)K || T.has_short) && !ACGPU_DBG(L, 4u)) {
                 uint32_t hrow = 0;
                 for (int j = K - 1; j >= 1; --j) hrow = hrow * n + (pos >= (uint32_t)j ? tile_class_t<RANGE>(T, hay[pos - j]) : T.filt_other);
                 const uint32_t last = tile_class_t<RANGE>(T, hay[pos]);

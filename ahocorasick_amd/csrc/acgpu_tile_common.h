@@ -69,7 +69,8 @@ __device__ __forceinline__ void store_rec(const TileLaunch &L, uint32_t slot, ui
 }
 
 constexpr uint32_t kQiKnown = 0x80000000u, kQiIdxMask = 0xfffffu, kQiLeftShift = 20;
-constexpr uint32_t kQiShort = 0x40000000u; // a keyword of fewer than K units may end here (DevTables::kshort)
+constexpr uint32_t kQiShort = 0x40000000u; // a keyword of fewer than K units may end here (DevTables::kshort / ks_keys)
+constexpr uint32_t kQiChecked = 0x20000000u; // the second level has looked: no kQiShort = no short keyword (entries without it: unknown)
 
 // wave64 inclusive prefix sum with DPP row shifts and row broadcasts (6 dependent v_add_u32_dpp)
 __device__ __forceinline__ uint32_t wave_inclusive_scan_dpp(uint32_t x) {

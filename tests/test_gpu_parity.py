@@ -1798,7 +1798,7 @@ def test_merged_stretches_phrases_and_case_insensitive(shape):
     assert g2.shape == w2.shape and (g2 == w2).all()
 
 
-@pytest.mark.parametrize("shape", ["range", "ci", "lut_wide", "only_short", "k3"])
+@pytest.mark.parametrize("shape", ["range", "ci", "lut_wide", "only_short", "k3", "merged_cs", "merged_ci", "buckets"])
 def test_short_keywords_beside_the_k_gram_filter(shape):
     """Keywords of fewer than K units no longer pull the filter's K down to their length: they set wild-card bits, pass the
     second level through the 'other'-led row and are reported from the table of the last K-1 classes -- after the longer
@@ -1806,9 +1806,14 @@ def test_short_keywords_beside_the_k_gram_filter(shape):
     and long keywords ending together."""
     import torch
     rng = np.random.default_rng(hash(shape) % 997)
-    cs = shape != "ci"
+    cs = shape not in ("ci", "merged_ci")
     if shape == "lut_wide":  # more than 32 classes that are no range: the scalar filter with 8-byte rows
         alpha = [ord(c) for c in "abcdefghijklmnopqrstuvwxyzABCDEFGHIJ 0123"]
+        N.set_tunable("no_merged_ranges", 1)
+    elif shape in ("merged_cs", "merged_ci"):  # mixed case / phrases: merged stretches, verification by units (ks_keys)
+        alpha = [ord(c) for c in "abcdefghABCDEFGH 019"]
+    elif shape == "buckets":  # more than 63 distinct units: bucketed classes, K <= 3
+        alpha = list(range(0x4E00, 0x4E00 + 300, 3))  # (100 units over 300 code points: more than four stretches of 31)
     else:
         alpha = list(range(ord("a"), ord("a") + (8 if shape != "k3" else 26)))
     kws = [np.array(rng.choice(alpha, int(rng.integers(4, 10))), dtype=np.uint16) for _ in range(300 if shape != "only_short" else 0)]
@@ -1822,6 +1827,8 @@ def test_short_keywords_beside_the_k_gram_filter(shape):
         kws.append(np.concatenate([kws[0], np.array(shorts[3], dtype=np.uint16)]))  # a long keyword that ends with a short one
     if shape == "ci":
         kws = [np.where(rng.integers(0, 2, k.size) == 1, k - 32, k).astype(np.uint16) for k in kws]
+    if shape == "buckets":
+        kws = [k for k in kws if k.size != 3 or rng.integers(0, 2)]
     hay_alpha = np.array(alpha[:10] + ([c - 32 for c in alpha[:6]] if shape == "ci" else []) + [ord("!")], dtype=np.uint16)
     hay = hay_alpha[rng.integers(0, len(hay_alpha), 200003)]
     hay[:3] = np.array(shorts[3], dtype=np.uint16)  # short keywords at the very start of the text
@@ -1832,17 +1839,24 @@ def test_short_keywords_beside_the_k_gram_filter(shape):
     orc = Oracle(FAM_AC, kws, case_sensitive=cs, lower=LOWER)
     want = orc.match(hay)
     d_hay = torch.from_numpy(hay.view(np.int16)).cuda()
-    m = AhoCorasickMap(kws, _ids(len(kws)), cs)
+    try:
+        m = AhoCorasickMap(kws, _ids(len(kws)), cs)
+    finally:
+        N.set_tunable("no_merged_ranges", 0)
     info = m.automaton.info()
-    assert info["filter_k"] > info["min_keyword_len"] and info["filter_k"] == (3 if shape == "lut_wide" else min(4, info["max_keyword_len"])), info
+    assert info["filter_k"] > info["min_keyword_len"] and info["filter_k"] == (3 if shape in ("lut_wide", "buckets") else min(4, info["max_keyword_len"])), info
     got, prof = _dev_match(m.automaton, d_hay, hay.size, True, len(want) + 8, profile=True)
     assert len(want) > 1000 and got.shape == want.shape and (got == want).all(), prof["scan_kernel"]
-    assert 0 in got[:8, 0].tolist() and got[0, 1] <= 2  # matches at the very start of the text
+    assert got[0, 1] <= 3 and (shape == "buckets" or 0 in got[:8, 0].tolist())  # matches at the very start of the text
+    if shape in ("merged_cs", "merged_ci", "buckets"):
+        assert prof["scan_kernel"].split(", ")[4].startswith("true"), prof["scan_kernel"]  # verification by units
     for n in (1, 2, 3, 5, hay.size - 5):  # texts shorter than K; a tail of fewer than 8 units
         w2 = orc.match(hay[:n])
         g2, _ = _dev_match(m.automaton, d_hay, n, True, len(w2) + 8, profile=True)
         assert g2.shape == w2.shape and (g2 == w2).all(), n
     for knobs in ({"force_kernel": 3}, {"tile_debug": 2048}, {"tile_debug": 1024}):  # split form, no second level, scalar filter
+        if shape.startswith("merged") and knobs.get("tile_debug") == 1024:
+            continue  # (merged classes exist in the packed filter only)
         for k, v in knobs.items():
             N.set_tunable(k, v)
         try:

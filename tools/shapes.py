@@ -47,6 +47,8 @@ shapes = {
     "C2 + one keyword of 3 units": (list(kws) + [np.array([113, 120, 122], dtype=np.uint16)], True),
     "C2 + one keyword of 2 units": (list(kws) + [np.array([113, 120], dtype=np.uint16)], True),
     "C2 + one keyword of 1 unit": (list(kws) + [np.array([113], dtype=np.uint16)], True),
+    "C2 mixed-case + one keyword of 2 units": (mixed + [np.array([81, 120], dtype=np.uint16)], True),
+    "C2 phrases case-insensitive + one keyword of 2 units": (phrases + [np.array([81, 120], dtype=np.uint16)], False),
     "1000 keywords len 3-8 (K=3)": (synth.random_keywords(7, 1000, 3, 8), True),
     "100 keywords len 2-6 (K=2)": (synth.random_keywords(8, 100, 2, 6), True),
     "30k keywords len 4-12": (synth.random_keywords(9, 30000, 4, 12), True),
