@@ -128,7 +128,8 @@ __device__ __forceinline__ uint32_t walk_step(const DevTables &T, uint32_t ref, 
 // HASHK: bucketed tile classes (dictionaries with more than 63 distinct units): the K units themselves, folded and packed
 // in text order, are looked up in kg_keys/kg_vals, and every step of the walk goes through the unit-keyed hashed edges.
 // QI: queue entries carry the K-gram index and the left neighbour's class (TileCtx::pos16): no text window is read for them.
-template <int K, bool RANGE, bool HASHK = false, bool QI = false>
+// SHORTS = false: the dictionary has no keyword shorter than K (compiled out: the config-2 form is register- and SGPR-tight)
+template <int K, bool RANGE, bool HASHK = false, bool QI = false, bool SHORTS = true>
 __device__ __forceinline__ void verify_multi(TileCtx &c, uint32_t head, uint32_t n_cand) {
     constexpr int NB = kVerifyBatches;
     const DevTables &T = *c.Tp;
@@ -278,7 +279,7 @@ __device__ __forceinline__ void verify_multi(TileCtx &c, uint32_t head, uint32_t
         ms[b] = 0;
         sh[b] = make_uint4(0u, 0u, 0u, 0u);
     }
-    if (!HASHK && T.kshort != nullptr) { // wave-uniform
+    if (SHORTS && !HASHK && T.kshort != nullptr) { // wave-uniform
         uint32_t grams = 1;
 #pragma unroll
         for (int j = 0; j < K - 1; ++j) grams *= T.filt_n;
@@ -299,7 +300,7 @@ __device__ __forceinline__ void verify_multi(TileCtx &c, uint32_t head, uint32_t
             }
         }
     }
-    if (HASHK && T.ks_keys != nullptr) { // bucketed / merged classes: the short keywords by their units (the window is loaded)
+    if (SHORTS && HASHK && T.ks_keys != nullptr) { // bucketed / merged classes: the short keywords by their units (the window is loaded)
         bool want[NB], any_want = false;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
@@ -394,12 +395,12 @@ __device__ __forceinline__ void verify_multi(TileCtx &c, uint32_t head, uint32_t
 }
 
 // drain the candidate queue down to fewer than `keep_below` entries
-template <int K, bool RANGE, bool HASHK, bool QI = false>
+template <int K, bool RANGE, bool HASHK, bool QI = false, bool SHORTS = true>
 __device__ __forceinline__ void drain(TileCtx &c, uint32_t keep_below) {
     uint32_t head = 0;
     while (c.cand_n > head && c.cand_n - head >= keep_below) {
         const uint32_t nb = min(c.cand_n - head, (uint32_t)(kVerifyBatches * kWave));
-        if (!ACGPU_DBG(*c.Lp, 1u)) verify_multi<K, RANGE, HASHK, QI>(c, head, nb);
+        if (!ACGPU_DBG(*c.Lp, 1u)) verify_multi<K, RANGE, HASHK, QI, SHORTS>(c, head, nb);
         head += nb;
     }
     if (head) { // move the leftovers (fewer than kVerifyBatches*64) to the front
@@ -476,8 +477,9 @@ __device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) {
 // wave's slice of L.d_cands (the "queue" is that slice and is never drained), with a {first index, count} pair per
 // region for k_ac_verify.  No LDS besides the filter rows.
 // NR4: merged stretches with three or four ranges (DevTables::fr_nr > 2; with PK only)
-template <int K, bool RANGE, bool WIDE, bool SPLIT, bool HASHK = false, bool PK = false, bool L2 = false, bool NR4 = false>
+template <int K, bool RANGE, bool WIDE, bool SPLIT, bool HASHK = false, bool PK = false, bool L2 = false, bool NR4 = false, bool SHORTS = true>
 __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch L) {
+    const bool has_short = SHORTS && T.has_short != 0; // (SHORTS = false: the launcher knows there is none)
     // the filter rows are STATIC LDS (offset 0, so a scaled row index is the ds_read address with nothing to add);
     // the candidate queues are the dynamic part behind it
     __shared__ __attribute__((aligned(16))) uint32_t rows32[SPLIT ? kFilterWordsSplit : (L2 ? kFilterWordsL2 : kFilterWordsMax)];
@@ -622,7 +624,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
         }
         if (!SPLIT && c.cand_n >= keep && c.cand_n != 0) {
             TM_BEGIN;
-            drain<K, RANGE, HASHK, L2>(c, keep);
+            drain<K, RANGE, HASHK, L2, SHORTS>(c, keep);
             TM_END(2);
 #ifdef ACGPU_TIMING
             tm[5]++;
@@ -660,7 +662,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
             // left in the buffer.  Only groups at the edges of a region need the per-lane mask.
             // (with short keywords every position counts: the units before the buffer are zeros in the carry, and the wild
             // cards of the short keywords cover whatever class those get)
-            const uint32_t lo = T.has_short ? rb : max(rb, (uint32_t)(K - 1));
+            const uint32_t lo = has_short ? rb : max(rb, (uint32_t)(K - 1));
             const uint32_t top = min(re, hi);
             const bool edge = tile < lo || tile + kAcTiles * kAcTileUnits > top; // wave-uniform
             bool resume = false;
@@ -860,7 +862,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                         }
                         // a keyword of fewer than K units: only their wild cards set a bit in a row whose leading class is "other"
                         uint32_t shortbit = 0;
-                        if (T.has_short) { // wave-uniform
+                        if (has_short) { // wave-uniform
                             uint32_t hrow = T.filt_other;
 #pragma unroll
                             for (int j = K - 2; j >= 1; --j) hrow = hrow * n + cls[j];
@@ -950,7 +952,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
             }
             const uint32_t pos = t0 + lane;
             uint32_t mask = 0;
-            if (pos < span_end && (pos + 1 >= (uint32_t)K || T.has_short) && !ACGPU_DBG(L, 4u)) {
+            if (pos < span_end && (pos + 1 >= (uint32_t)K || has_short) && !ACGPU_DBG(L, 4u)) {
                 uint32_t hrow = 0;
                 for (int j = K - 1; j >= 1; --j) hrow = hrow * n + (pos >= (uint32_t)j ? tile_class_t<RANGE>(T, hay[pos - j]) : T.filt_other);
                 const uint32_t last = tile_class_t<RANGE>(T, hay[pos]);
@@ -1105,14 +1107,20 @@ static bool tile_l2_usable(const DevTables &t, const TileLaunch &l) {
            l.region_units <= 65536u && t.filt_words <= (uint32_t)kFilterWordsL2 && !(l.debug & 2048u);
 }
 
-template <int K, bool RANGE>
-static hipError_t launch_tile_l2(const DevTables &t, const TileLaunch &l, hipStream_t stream) {
+template <int K, bool RANGE, bool SHORTS>
+static hipError_t launch_tile_l2s(const DevTables &t, const TileLaunch &l, hipStream_t stream) {
     const size_t lds = tile_l2_lds_bytes(l.block);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ac_tile<K, RANGE, false, false, false, true, true>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ac_tile<K, RANGE, false, false, false, true, true, false, SHORTS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_ac_tile<K, RANGE, false, false, false, true, true>), dim3(l.grid), dim3(l.block), lds, stream, t, l);
+    hipLaunchKernelGGL((k_ac_tile<K, RANGE, false, false, false, true, true, false, SHORTS>), dim3(l.grid), dim3(l.block), lds, stream, t, l);
     return hipGetLastError();
+}
+template <int K, bool RANGE>
+static hipError_t launch_tile_l2(const DevTables &t, const TileLaunch &l, hipStream_t stream) {
+    // (short keywords imply K <= 4: the K = 5 form needs no SHORTS instantiation)
+    if (K <= 4 && t.has_short) return launch_tile_l2s<K, RANGE, (K <= 4)>(t, l, stream);
+    return launch_tile_l2s<K, RANGE, false>(t, l, stream);
 }
 
 template <int K>

@@ -52,6 +52,8 @@ shapes = {
     "1000 keywords len 3-8 (K=3)": (synth.random_keywords(7, 1000, 3, 8), True),
     "100 keywords len 2-6 (K=2)": (synth.random_keywords(8, 100, 2, 6), True),
     "30k keywords len 4-12": (synth.random_keywords(9, 30000, 4, 12), True),
+    "100k keywords len 4-12": (synth.random_keywords(10, 100000, 4, 12), True),
+    "235k keywords len 2-14": (synth.random_keywords(11, 235000, 2, 14), True),
 }
 for name, spec in shapes.items():
     k, cs = spec[0], spec[1]
