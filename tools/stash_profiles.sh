@@ -6,9 +6,9 @@ tag=$1; round=$2; pre=$3
 src=gpurun_out/$tag; dst=profiles/$round
 mkdir -p $dst
 for c in c2 c3_1gpu c4 c5; do [ -f $src/bench_$c.json ] && cp $src/bench_$c.json $dst/${pre}_bench_$c.json; done
-for c in c2 c4 c5; do f=$(find $src/stats_$c -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $dst/${pre}_kernel_stats_$c.csv; done
+for c in c2 c4 c5; do f=$(find $src/stats_$c -name "*kernel_stats.csv" -printf '%T@ %p\n' | sort -rn | head -1 | cut -d' ' -f2-); [ -n "$f" ] && cp $f $dst/${pre}_kernel_stats_$c.csv; done
 for d in pmc_fetch pmc_write pmc_fetch_C2 pmc_write_C2 pmc_fetch_C4 pmc_write_C4 pmc_fetch_C5 pmc_write_C5; do
-  f=$(find $src/$d -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp $f $dst/${pre}_${d}_counter_collection.csv
+  f=$(find $src/$d -name "*counter_collection.csv" -printf '%T@ %p\n' | sort -rn | head -1 | cut -d' ' -f2-); [ -n "$f" ] && cp $f $dst/${pre}_${d}_counter_collection.csv
 done
 cp $src/pmc_traffic.json $dst/${pre}_pmc_traffic.json
 cp $src/pmc_traffic_all.json $dst/${pre}_pmc_traffic_all.json
