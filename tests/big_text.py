@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Development tool: position arithmetic at the size limit.  A haystack of just under 2^31 units (the ABI's limit) is scanned whole
+"""Position arithmetic at the size limit (under tests/ because it checks against the oracle; also runnable on its own).  A haystack of just under 2^31 units (the ABI's limit) is scanned whole
 and as four shards by the same automaton (records must concatenate to the same list), and the last 2^20 units are compared with
 the oracle.  AhoCorasick (config 2's dictionary), WholeWord (config 5's dictionary on letters + spaces), Longest (config 4)."""
 import ctypes, os, sys, hashlib

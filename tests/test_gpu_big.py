@@ -1,11 +1,11 @@
-"""Position arithmetic at the ABI's size limit (just under 2^31 units): tools/big_text.py -- whole text == four shards, the
+"""Position arithmetic at the ABI's size limit (just under 2^31 units): tests/big_text.py -- whole text == four shards, the
 tail == the oracle, for AhoCorasick, WholeWord and Longest."""
 import os
 import sys
 
 import pytest
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
