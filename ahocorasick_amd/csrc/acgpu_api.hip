@@ -369,7 +369,7 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
     uint64_t scanned = 0;
     uint32_t n_chunks = 0, chunk_units = 0, perm_base = (uint32_t)sh->own_begin;
     const uint32_t *id_map = nullptr;
-    bool split = false, fused_finalize = false, ww_direct = false;
+    bool split = false, fused_finalize = false, ww_direct = false, ext_timed = false;
     uint32_t regions_per_wg = 0, ww_region_cap = 0;
     int by_start = 0;
     if (ww) {
@@ -428,9 +428,12 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         HIP_TRY(hipMemsetAsync(ww_timing.p, 0, (size_t)L.grid * 16 * 8 * 8, stream));
         L.d_timing = (unsigned long long *)ww_timing.p;
 #endif
-        if (timed) HIP_TRY(hipEventRecord(ev[0], stream));
+        if (timed) { // (the kernel's own dispatch timestamps: no marker packets around it)
+            L.ev_start = ev[0];
+            L.ev_stop = ev[1];
+            ext_timed = true;
+        }
         HIP_TRY(launch_ww_tile(Tov ? *Tov : d.T, L, stream, &kname));
-        if (timed) HIP_TRY(hipEventRecord(ev[1], stream));
 #ifdef ACGPU_TIMING
         if (!tk) { // where a wave's time goes (s_memtime ticks, 100 MHz), averaged over the waves
             HIP_TRY(hipStreamSynchronize(stream));
@@ -531,14 +534,18 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         HIP_TRY(hipMemsetAsync(timing.p, 0, (size_t)L.grid * 16 * 8 * 8, stream));
         L.d_timing = (unsigned long long *)timing.p;
 #endif
-        if (timed) HIP_TRY(hipEventRecord(ev[0], stream));
         if (split) {
+            if (timed) HIP_TRY(hipEventRecord(ev[0], stream));
             HIP_TRY(launch_ac_filter(d.T, L, stream, &kname));
             if (timed) HIP_TRY(hipEventRecord(ev[1], stream)); // the verification is accounted with the ordering
             HIP_TRY(launch_ac_verify(d.T, L, stream));
         } else {
+            if (timed) { // (the kernel's own dispatch timestamps: no marker packets around it)
+                L.ev_start = ev[0];
+                L.ev_stop = ev[1];
+                ext_timed = true;
+            }
             HIP_TRY(launch_ac_tile(d.T, L, stream, &kname));
-            if (timed) HIP_TRY(hipEventRecord(ev[1], stream));
         }
 #ifdef ACGPU_TIMING
         if (!tk && !split) {
@@ -621,19 +628,22 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
     HIP_TRY(hipHostGetDevicePointer((void **)&d_slot, h_slot, 0));
     const PermuteTail tail{d_slot, (const uint64_t *)d.scan_tmp.p + scan_tiles_for(n_chunks), overflow_word, counters_next,
                            reinterpret_cast<acgpu_device_result *>(sh->d_result)};
+    // (profiled: the last kernel of the finalize delivers its own end timestamp where it is ONE kernel that ends the call)
+    const bool ext_stop = timed && ext_timed && (ww_direct || fused_finalize);
     if (ww_direct)
         HIP_TRY(launch_ww_compact((const int32_t *)d.ww_recs.p, ww_region_cap, (const uint32_t *)d.chunk_counts.p, (const uint64_t *)d.offsets.p,
-                                  n_chunks, record_kind, d_out, cap, stream, &tail));
+                                  n_chunks, record_kind, d_out, cap, stream, &tail, ext_stop ? ev[2] : nullptr));
     else if (fused_finalize)
         HIP_TRY(launch_permute_wg((const ScratchRec *)d.scratch.p, counters, n_slices, slice_slots, (const uint32_t *)d.chunk_counts.p,
-                                  n_chunks, regions_per_wg, perm_base, chunk_units, record_kind, d_out, cap, id_map, stream, &tail));
+                                  n_chunks, regions_per_wg, perm_base, chunk_units, record_kind, d_out, cap, id_map, stream, &tail,
+                                  ext_stop ? ev[2] : nullptr));
     else
         HIP_TRY(launch_permute((const ScratchRec *)d.scratch.p, counters, n_slices, slice_slots,
                                (const uint64_t *)d.offsets.p, perm_base, chunk_units, by_start, record_kind, d_out, cap, id_map,
                                stream, &tail));
     d.cclean[1 - cs] = true; // zeroed by the pass just launched
     d.cset = 1 - cs;
-    if (timed) HIP_TRY(hipEventRecord(ev[2], stream));
+    if (timed && !ext_stop) HIP_TRY(hipEventRecord(ev[2], stream));
     // exact record count = grand total of the per-chunk counts (the slot counter also counts reservation holes)
     if (tk) {
         tk->shard = *sh;

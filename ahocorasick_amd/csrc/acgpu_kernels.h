@@ -1,5 +1,6 @@
 // acgpu_kernels.h -- launch wrappers of the gfx950 kernels (implemented in acgpu_kernels.hip).
 #pragma once
+#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
 #include "acgpu_internal.h"
@@ -33,6 +34,15 @@ hipError_t launch_ac_scan(const DevTables &t, const ScanLaunch &l, hipStream_t s
 
 // Position-parallel AC-all scan (suffix K-gram filter in LDS + reversed-trie verification).  Ordering unit
 // ("chunk" for the permute pass) = one wave region of region_units owned units.
+// launch with the dispatch's own start / stop timestamps delivered to two events (either may be nullptr; both: a plain launch)
+#define ACGPU_LAUNCH_EV(kernel, grid, block, lds, stream, ev0, ev1, ...)                                        \
+    do {                                                                                                        \
+        if ((ev0) != nullptr || (ev1) != nullptr)                                                               \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, (ev0), (ev1), 0, __VA_ARGS__);              \
+        else                                                                                                    \
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                  \
+    } while (0)
+
 struct TileLaunch {
     const uint16_t *d_hay;
     uint32_t n_units, own_begin, own_end;
@@ -65,6 +75,9 @@ struct TileLaunch {
     // R/2 + 1 words, so every region owns region_cap 12-byte slots {start, end, id} of d_region_recs and a record goes
     // straight to slot region * region_cap + rank -- no slot reservations, no (region, rank) tags; k_ww_compact then copies
     // every region's records, whole and coalesced, to its final place (offsets = prefix sum of the region counts)
+    // Profiled calls: the scan kernel's own dispatch timestamps instead of two hipEventRecord markers around it (host side only;
+    // nullptr = a plain launch).  A marker is a packet of its own with a barrier: three of them cost 13-20 us per step at config 2.
+    hipEvent_t ev_start, ev_stop;
     int32_t *d_region_recs; // nullptr: the scratch slices + k_permute
     uint32_t region_cap;
     unsigned long long *d_timing; // -DACGPU_TIMING builds only: 8 cycle counters per wave (tools/build_variant.sh timing)
@@ -117,7 +130,8 @@ hipError_t launch_publish_result(const unsigned long long *d_total, const unsign
 // scratch (unordered) -> final records in reference order
 // (slots whose rank is ~0u are holes left by slot reservations and are skipped)
 hipError_t launch_ww_compact(const int32_t *d_region_recs, uint32_t region_cap, const uint32_t *d_region_counts, const uint64_t *d_offsets,
-                             uint32_t n_regions, int record_kind, void *d_out, uint64_t out_cap, hipStream_t stream, const PermuteTail *tail);
+                             uint32_t n_regions, int record_kind, void *d_out, uint64_t out_cap, hipStream_t stream, const PermuteTail *tail,
+                             hipEvent_t ev_stop = nullptr);
 hipError_t launch_permute(const ScratchRec *d_scratch, const unsigned long long *d_counter, uint32_t n_slices, uint64_t slice_slots,
                           const uint64_t *d_offsets, uint32_t own_begin, uint32_t chunk_units, int by_start,
                           int record_kind, void *d_out, uint64_t out_cap, const uint32_t *d_id_map, hipStream_t stream,
@@ -132,7 +146,8 @@ constexpr uint32_t kPermuteWgRegions = 1024;
 hipError_t launch_permute_wg(const ScratchRec *d_scratch, const unsigned long long *d_counter, uint32_t n_wg, uint64_t slice_slots,
                              const uint32_t *d_region_counts, uint32_t n_regions, uint32_t regions_per_wg, uint32_t own_begin,
                              uint32_t chunk_units, int record_kind, void *d_out, uint64_t out_cap, const uint32_t *d_id_map,
-                             hipStream_t stream, const PermuteTail *tail);
+                             hipStream_t stream, const PermuteTail *tail,
+                             hipEvent_t ev_stop = nullptr);
 uint32_t tile_reserve_slots();
 uint32_t tile_group_units(); // regions must hold whole tile groups
 

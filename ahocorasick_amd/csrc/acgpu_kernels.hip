@@ -419,15 +419,17 @@ __global__ __launch_bounds__(256) void k_ww_compact(const int32_t *recs, uint32_
 }
 
 hipError_t launch_ww_compact(const int32_t *d_region_recs, uint32_t region_cap, const uint32_t *d_region_counts, const uint64_t *d_offsets,
-                             uint32_t n_regions, int record_kind, void *d_out, uint64_t out_cap, hipStream_t stream, const PermuteTail *tail) {
+                             uint32_t n_regions, int record_kind, void *d_out, uint64_t out_cap, hipStream_t stream, const PermuteTail *tail,
+                             hipEvent_t ev_stop) {
     const PermuteTail tl = tail ? *tail : PermuteTail{nullptr, nullptr, nullptr, nullptr, nullptr};
     const dim3 grid(std::max<uint32_t>(std::min<uint32_t>(n_regions, 8192u), 1u)), block(256);
+    const hipEvent_t ev_none = nullptr;
     if (record_kind == ACGPU_REC_SET)
-        hipLaunchKernelGGL(k_ww_compact<ACGPU_REC_SET>, grid, block, 0, stream, d_region_recs, region_cap, d_region_counts, d_offsets,
-                           n_regions, (int32_t *)d_out, out_cap, tl);
+        ACGPU_LAUNCH_EV(k_ww_compact<ACGPU_REC_SET>, grid, block, 0, stream, ev_none, ev_stop, d_region_recs, region_cap, d_region_counts, d_offsets,
+                        n_regions, (int32_t *)d_out, out_cap, tl);
     else
-        hipLaunchKernelGGL(k_ww_compact<ACGPU_REC_MAP>, grid, block, 0, stream, d_region_recs, region_cap, d_region_counts, d_offsets,
-                           n_regions, (int32_t *)d_out, out_cap, tl);
+        ACGPU_LAUNCH_EV(k_ww_compact<ACGPU_REC_MAP>, grid, block, 0, stream, ev_none, ev_stop, d_region_recs, region_cap, d_region_counts, d_offsets,
+                        n_regions, (int32_t *)d_out, out_cap, tl);
     return hipGetLastError();
 }
 
@@ -556,15 +558,16 @@ __global__ __launch_bounds__(256) void k_permute_wg(const ScratchRec *scratch, c
 hipError_t launch_permute_wg(const ScratchRec *d_scratch, const unsigned long long *d_counter, uint32_t n_wg, uint64_t slice_slots,
                              const uint32_t *d_region_counts, uint32_t n_regions, uint32_t regions_per_wg, uint32_t own_begin,
                              uint32_t chunk_units, int record_kind, void *d_out, uint64_t out_cap, const uint32_t *d_id_map,
-                             hipStream_t stream, const PermuteTail *tail) {
+                             hipStream_t stream, const PermuteTail *tail, hipEvent_t ev_stop) {
     const PermuteTail tl = tail ? *tail : PermuteTail{nullptr, nullptr, nullptr, nullptr, nullptr};
     const dim3 grid(std::max<uint32_t>(kPermuteBlocks / std::max<uint32_t>(n_wg, 1u), 8u), n_wg);
+    const hipEvent_t ev_none = nullptr;
     if (record_kind == ACGPU_REC_SET)
-        hipLaunchKernelGGL(k_permute_wg<ACGPU_REC_SET>, grid, dim3(256), 0, stream, d_scratch, d_counter, n_wg, slice_slots,
-                           d_region_counts, n_regions, regions_per_wg, own_begin, chunk_units, d_out, out_cap, d_id_map, tl);
+        ACGPU_LAUNCH_EV(k_permute_wg<ACGPU_REC_SET>, grid, dim3(256), 0, stream, ev_none, ev_stop, d_scratch, d_counter, n_wg, slice_slots,
+                        d_region_counts, n_regions, regions_per_wg, own_begin, chunk_units, d_out, out_cap, d_id_map, tl);
     else
-        hipLaunchKernelGGL(k_permute_wg<ACGPU_REC_MAP>, grid, dim3(256), 0, stream, d_scratch, d_counter, n_wg, slice_slots,
-                           d_region_counts, n_regions, regions_per_wg, own_begin, chunk_units, d_out, out_cap, d_id_map, tl);
+        ACGPU_LAUNCH_EV(k_permute_wg<ACGPU_REC_MAP>, grid, dim3(256), 0, stream, ev_none, ev_stop, d_scratch, d_counter, n_wg, slice_slots,
+                        d_region_counts, n_regions, regions_per_wg, own_begin, chunk_units, d_out, out_cap, d_id_map, tl);
     return hipGetLastError();
 }
 

@@ -1025,13 +1025,13 @@ static hipError_t launch_tile_variant(const DevTables &t, const TileLaunch &l, h
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ac_tile<K, RANGE, WIDE, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_ac_tile<K, RANGE, WIDE, false>), dim3(l.grid), dim3(l.block), l.lds_bytes, stream, t, l);
+    ACGPU_LAUNCH_EV((k_ac_tile<K, RANGE, WIDE, false>), dim3(l.grid), dim3(l.block), l.lds_bytes, stream, l.ev_start, l.ev_stop, t, l);
     return hipGetLastError();
 }
 
 template <int K, bool RANGE, bool WIDE>
 static hipError_t launch_filter_variant(const DevTables &t, const TileLaunch &l, hipStream_t stream) {
-    hipLaunchKernelGGL((k_ac_tile<K, RANGE, WIDE, true>), dim3(l.grid), dim3(l.block), 0, stream, t, l);
+    ACGPU_LAUNCH_EV((k_ac_tile<K, RANGE, WIDE, true>), dim3(l.grid), dim3(l.block), 0, stream, l.ev_start, l.ev_stop, t, l);
     return hipGetLastError();
 }
 
@@ -1056,9 +1056,9 @@ static hipError_t launch_tile_hashk(const DevTables &t, const TileLaunch &l, hip
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ac_tile<K, false, true, false, true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds_bytes);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_ac_tile<K, false, true, false, true>), dim3(l.grid), dim3(l.block), l.lds_bytes, stream, t, l);
+        ACGPU_LAUNCH_EV((k_ac_tile<K, false, true, false, true>), dim3(l.grid), dim3(l.block), l.lds_bytes, stream, l.ev_start, l.ev_stop, t, l);
     } else {
-        hipLaunchKernelGGL((k_ac_tile<K, false, true, true, true>), dim3(l.grid), dim3(l.block), 0, stream, t, l);
+        ACGPU_LAUNCH_EV((k_ac_tile<K, false, true, true, true>), dim3(l.grid), dim3(l.block), 0, stream, l.ev_start, l.ev_stop, t, l);
     }
     return hipGetLastError();
 }
@@ -1081,7 +1081,7 @@ static hipError_t launch_tile_merged(const DevTables &t, const TileLaunch &l, hi
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ac_tile<K, false, false, false, true, true, L2, NR4>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_ac_tile<K, false, false, false, true, true, L2, NR4>), dim3(l.grid), dim3(l.block), lds, stream, t, l);
+    ACGPU_LAUNCH_EV((k_ac_tile<K, false, false, false, true, true, L2, NR4>), dim3(l.grid), dim3(l.block), lds, stream, l.ev_start, l.ev_stop, t, l);
     return hipGetLastError();
 }
 template <int K>
@@ -1095,7 +1095,7 @@ static hipError_t launch_tile_pk(const DevTables &t, const TileLaunch &l, hipStr
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ac_tile<K, RANGE, false, false, false, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_ac_tile<K, RANGE, false, false, false, true>), dim3(l.grid), dim3(l.block), l.lds_bytes, stream, t, l);
+    ACGPU_LAUNCH_EV((k_ac_tile<K, RANGE, false, false, false, true>), dim3(l.grid), dim3(l.block), l.lds_bytes, stream, l.ev_start, l.ev_stop, t, l);
     return hipGetLastError();
 }
 
@@ -1113,7 +1113,7 @@ static hipError_t launch_tile_l2s(const DevTables &t, const TileLaunch &l, hipSt
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ac_tile<K, RANGE, false, false, false, true, true, false, SHORTS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_ac_tile<K, RANGE, false, false, false, true, true, false, SHORTS>), dim3(l.grid), dim3(l.block), lds, stream, t, l);
+    ACGPU_LAUNCH_EV((k_ac_tile<K, RANGE, false, false, false, true, true, false, SHORTS>), dim3(l.grid), dim3(l.block), lds, stream, l.ev_start, l.ev_stop, t, l);
     return hipGetLastError();
 }
 template <int K, bool RANGE>

@@ -1022,10 +1022,10 @@ hipError_t launch_ww_tile(const DevTables &t, const TileLaunch &l, hipStream_t s
                                    : (lng ? reinterpret_cast<const void *>(&k_ww_pp<1, true>) : reinterpret_cast<const void *>(&k_ww_pp<1, false>));
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        if (fold == 0 && lng) hipLaunchKernelGGL((k_ww_pp<0, true>), dim3(l.grid), dim3(l.block), lds, stream, t, l);
-        else if (fold == 0) hipLaunchKernelGGL((k_ww_pp<0, false>), dim3(l.grid), dim3(l.block), lds, stream, t, l);
-        else if (lng) hipLaunchKernelGGL((k_ww_pp<1, true>), dim3(l.grid), dim3(l.block), lds, stream, t, l);
-        else hipLaunchKernelGGL((k_ww_pp<1, false>), dim3(l.grid), dim3(l.block), lds, stream, t, l);
+        if (fold == 0 && lng) ACGPU_LAUNCH_EV((k_ww_pp<0, true>), dim3(l.grid), dim3(l.block), lds, stream, l.ev_start, l.ev_stop, t, l);
+        else if (fold == 0) ACGPU_LAUNCH_EV((k_ww_pp<0, false>), dim3(l.grid), dim3(l.block), lds, stream, l.ev_start, l.ev_stop, t, l);
+        else if (lng) ACGPU_LAUNCH_EV((k_ww_pp<1, true>), dim3(l.grid), dim3(l.block), lds, stream, l.ev_start, l.ev_stop, t, l);
+        else ACGPU_LAUNCH_EV((k_ww_pp<1, false>), dim3(l.grid), dim3(l.block), lds, stream, l.ev_start, l.ev_stop, t, l);
         if (kernel_name) *kernel_name = fold == 0 ? (lng ? "k_ww_pp<0, true>" : "k_ww_pp<0, false>") : (lng ? "k_ww_pp<1, true>" : "k_ww_pp<1, false>");
         return hipGetLastError();
     }
@@ -1033,9 +1033,9 @@ hipError_t launch_ww_tile(const DevTables &t, const TileLaunch &l, hipStream_t s
                    : fold == 1 ? reinterpret_cast<const void *>(&k_ww_tile<1>) : reinterpret_cast<const void *>(&k_ww_tile<2>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds_bytes);
     if (e != hipSuccess) return e;
-    if (fold == 0) hipLaunchKernelGGL(k_ww_tile<0>, dim3(l.grid), dim3(l.block), l.lds_bytes, stream, t, l);
-    else if (fold == 1) hipLaunchKernelGGL(k_ww_tile<1>, dim3(l.grid), dim3(l.block), l.lds_bytes, stream, t, l);
-    else hipLaunchKernelGGL(k_ww_tile<2>, dim3(l.grid), dim3(l.block), l.lds_bytes, stream, t, l);
+    if (fold == 0) ACGPU_LAUNCH_EV(k_ww_tile<0>, dim3(l.grid), dim3(l.block), l.lds_bytes, stream, l.ev_start, l.ev_stop, t, l);
+    else if (fold == 1) ACGPU_LAUNCH_EV(k_ww_tile<1>, dim3(l.grid), dim3(l.block), l.lds_bytes, stream, l.ev_start, l.ev_stop, t, l);
+    else ACGPU_LAUNCH_EV(k_ww_tile<2>, dim3(l.grid), dim3(l.block), l.lds_bytes, stream, l.ev_start, l.ev_stop, t, l);
     if (kernel_name) *kernel_name = fold == 0 ? "k_ww_tile<0>" : fold == 1 ? "k_ww_tile<1>" : "k_ww_tile<2>";
     return hipGetLastError();
 }
