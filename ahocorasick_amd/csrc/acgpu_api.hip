@@ -57,6 +57,7 @@ struct Ticket {
     hipEvent_t done = nullptr;
     unsigned long long *h_count = nullptr; // pinned, 64 bytes
     bool busy = false, profiled = false;
+    bool done_is_ev2 = false; // the completion to wait for is ev[2] (the finalize kernel's own end), not `done`
     // how _end collects it: 0 = the AhoCorasick / WholeWord pipeline (count and overflow word in h_count), 1 = a chain pipeline
     // that was enqueued (LONGEST walk: count in h_count[0], chain exit in h_count[2]), 2 = the call ran synchronously inside
     // _begin (the other families): everything is in the fields below
@@ -650,7 +651,9 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         tk->record_kind = record_kind;
         tk->d_out = d_out;
         tk->stream = stream;
-        HIP_TRY(hipEventRecord(tk->done, stream));
+        // (the call's last kernel delivered its end to ev[2]: that IS the call's completion -- one marker packet less per step)
+        tk->done_is_ev2 = ext_stop;
+        if (!ext_stop) HIP_TRY(hipEventRecord(tk->done, stream));
         tk->scanned = scanned;
         std::snprintf(tk->kname, sizeof(tk->kname), "%s", kname);
         return ACGPU_OK;
@@ -1542,6 +1545,7 @@ int acgpu_match_device_begin(const acgpu_automaton *ca, acgpu_shard *sh, int rec
         if (!cand.busy) { tk = &cand; break; }
     if (!tk) return ACGPU_E_INVALID; // too many calls in flight: collect one first
     tk->profiled = want_profile != 0;
+    tk->done_is_ev2 = false;
     tk->cap = cap;
     tk->user_shard = sh;
     tk->kname[0] = 0;
@@ -1586,7 +1590,7 @@ int acgpu_match_device_abandon(const acgpu_automaton *ca, acgpu_ticket *ticket) 
             tk->busy = false;
             return ACGPU_OK;
         }
-        done = tk->done;
+        done = tk->done_is_ev2 ? tk->ev[2] : tk->done;
     }
     HIP_TRY(hipEventSynchronize(done)); // (its kernels still write the caller's buffers until then)
     std::lock_guard<std::mutex> lock(a->mu);
@@ -1610,7 +1614,7 @@ int acgpu_match_device_end(const acgpu_automaton *ca, acgpu_ticket *ticket, uint
             if (prof) *prof = tk->sync_prof;
             return tk->sync_rc;
         }
-        done = tk->done;
+        done = tk->done_is_ev2 ? tk->ev[2] : tk->done;
     }
     HIP_TRY(hipEventSynchronize(done)); // outside the lock: other calls may be enqueued meanwhile
     std::lock_guard<std::mutex> lock(a->mu);
