@@ -58,6 +58,7 @@ bool tile_split_supported(const DevTables &t) {
 // of the tile's first-level candidates (kL2Fresh tile-relative positions); the Bloom words follow
 constexpr int kFilterWordsL2 = 19712;  // 78848 bytes: 27 classes, K = 4
 constexpr int kL2Cap = 256;            // a drain leaves fewer than 128; a tile adds at most 128 through the second level
+static_assert(kVerifyBatches * kWave + 128 <= kL2Cap, "the queue holds what a drain leaves plus a tile's survivors (-DACGPU_NB=4 hangs)");
 constexpr int kL2Fresh = 128;
 constexpr int kL2Vec = 4;              // the L2 form takes 32 units per lane: every per-tile cost is shared by 2048 positions
 constexpr int kL2TileUnits = kWave * 8 * kL2Vec;
