@@ -630,7 +630,8 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
     const PermuteTail tail{d_slot, (const uint64_t *)d.scan_tmp.p + scan_tiles_for(n_chunks), overflow_word, counters_next,
                            reinterpret_cast<acgpu_device_result *>(sh->d_result)};
     // (profiled: the last kernel of the finalize delivers its own end timestamp where it is ONE kernel that ends the call)
-    const bool ext_stop = timed && ext_timed && (ww_direct || fused_finalize);
+    // (a ticket's completion is that timestamp too, profiled or not: no marker packet behind the call)
+    const bool ext_stop = ((timed && ext_timed) || (tk != nullptr && !split)) && (ww_direct || fused_finalize);
     if (ww_direct)
         HIP_TRY(launch_ww_compact((const int32_t *)d.ww_recs.p, ww_region_cap, (const uint32_t *)d.chunk_counts.p, (const uint64_t *)d.offsets.p,
                                   n_chunks, record_kind, d_out, cap, stream, &tail, ext_stop ? ev[2] : nullptr));
