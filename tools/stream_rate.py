@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Development tool: rate of the chunked entry (acgpu_stream_feed = match(Readable, ...)): config 2's haystack fed in 4 Mi-unit
+chunks, as the Java facade does, for the AhoCorasick and the WholeWord family."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ahocorasick_amd import _native as N, synth
+from ahocorasick_amd.strings import Automaton, Stream
+from ahocorasick_amd.unicode_tables import default_word_chars
+
+n, chunk = 1 << 27, 1 << 22
+for name, mode, kws, cs, hay in (
+        ("AhoCorasick C2", N.MODE_ALL, synth.config_keywords("C2"), True, synth.haystack(2002, n)),
+        ("WholeWord C5 words", N.MODE_WHOLEWORD, synth.config_keywords("C5"), False,
+         np.asarray(list(synth.ALPHA_LOWER[:8]) + [32, 32], dtype=np.uint16)[np.random.default_rng(5).integers(0, 10, n)])):
+    a = Automaton(mode, kws, cs, word_chars=default_word_chars() if mode == N.MODE_WHOLEWORD else None)
+    for rep in range(2):
+        s = Stream(a, with_ids=True)
+        t0 = time.perf_counter()
+        total = 0
+        for o in range(0, n, chunk):
+            total += len(s.feed(hay[o:o + chunk], final=o + chunk >= n, cap=chunk // 8))
+        dt = time.perf_counter() - t0
+        s.close()
+    print("%-20s %d units in %d-unit chunks: %.1f ms, %.1f GB/s of UTF-16, %d records" % (name, n, chunk, dt * 1e3, 2.0 * n / dt / 1e9, total), flush=True)
