@@ -107,13 +107,22 @@ __global__ __launch_bounds__(256) void k_short_clear(uint32_t *mark, uint32_t M)
     if (k < M) mark[k] = 0;
 }
 
+// One launch = kRoundLog doubling rounds: with the jump table G = nxt^(8^t), a marked element marks G(x), G^2(x), ..., G^7(x) and the
+// table becomes G^8 -- if everything at chain distance < 8^t from the head was marked, everything < 8^(t+1) is afterwards.  (The
+// rounds are launch-bound: 21 launches of a few microseconds each for 1.3 M records; 7 now.)
+constexpr int kRoundLog = 3;
 __global__ __launch_bounds__(256) void k_short_round(const uint32_t *jump_in, uint32_t *jump_out, uint32_t *mark, uint32_t M) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k > M) return;
-    const uint32_t j = jump_in[k];
-    // a record marked earlier in this same round is on the chain too, so is its 2^t-th successor: the race is benign
-    if (k < M && mark[k] && j < M) mark[j] = 1u;
-    jump_out[k] = jump_in[j];
+    // a record marked earlier in this same launch is on the chain too, so are its successors: the race is benign
+    const bool on_chain = k < M && mark[k];
+    uint32_t p = k;
+#pragma unroll
+    for (int i = 1; i < (1 << kRoundLog); ++i) {
+        p = jump_in[p]; // (jump_in[M] = M: a chain that has left the list stays there)
+        if (on_chain && p < M) mark[p] = 1u;
+    }
+    jump_out[k] = jump_in[p];
 }
 
 template <int REC>
@@ -167,7 +176,7 @@ hipError_t launch_longest_select(const int32_t *d_recs, uint32_t M, int64_t entr
 hipError_t launch_chain_mark(uint32_t *d_nxt, uint32_t *d_tmp, uint32_t *d_mark, uint32_t M, hipStream_t stream) {
     const dim3 block(256), grid((M + 1 + 255) / 256);
     uint32_t *in = d_nxt, *out = d_tmp;
-    for (uint64_t reach = 1; reach <= M; reach <<= 1) { // after the round with 2^t-step jumps, 2^(t+1) chain elements are marked
+    for (uint64_t reach = 1; reach <= M; reach <<= kRoundLog) { // after the launch with 8^t-step jumps, 8^(t+1) chain elements are marked
         hipLaunchKernelGGL(k_short_round, grid, block, 0, stream, in, out, d_mark, M);
         std::swap(in, out);
     }
