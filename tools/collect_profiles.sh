@@ -1,6 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): the bench lines and rocprofv3 evidence that profiles/<round>/ keeps.
-# usage: bash tools/collect_profiles.sh <out-dir under gpurun_out/>
+# usage: bash tools/collect_profiles.sh <out-dir under gpurun_out/> <round dir under profiles/> [<file prefix in it>]
+# (the last two only name, inside latest_traffic.json, the file tools/stash_profiles.sh will copy the traffic summary to)
 set -u
 OUT=gpurun_out/${1:-final}
 mkdir -p "$OUT"
@@ -34,5 +35,5 @@ for c in C2 C4 C5; do
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_$c" -- python3 tools/kbench.py --rounds 1 --config $c $extra --variants '{"k":{}}' > "$OUT/pmc_fetch_$c.log" 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_$c" -- python3 tools/kbench.py --rounds 1 --config $c $extra --variants '{"k":{}}' > "$OUT/pmc_write_$c.log" 2>&1
 done
-python3 tools/pmc_traffic_all.py "$OUT" --c2-calibrated "$OUT/pmc_traffic.json" --latest "$OUT/latest_traffic.json" --tag "profiles/${2:-rNN}/${1:-final}_pmc_traffic_all.json" > "$OUT/pmc_traffic_all.json" 2> "$OUT/pmc_traffic_all.err"
+python3 tools/pmc_traffic_all.py "$OUT" --c2-calibrated "$OUT/pmc_traffic.json" --latest "$OUT/latest_traffic.json" --tag "profiles/${2:-rNN}/${3:-${1:-final}}_pmc_traffic_all.json" > "$OUT/pmc_traffic_all.json" 2> "$OUT/pmc_traffic_all.err"
 cat "$OUT/bench_c2.json"
