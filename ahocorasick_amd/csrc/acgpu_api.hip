@@ -1193,11 +1193,11 @@ int match_wwlongest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int rec
     HIP_TRY(launch_wwl_select((const uint32_t *)d.short_mark.p, (const int32_t *)d.wwl_mend.p, (const uint32_t *)d.wwl_rs.p,
                               nxt_for_select, (const uint32_t *)d.wwl_stop.p, (uint32_t *)d.wwl_sel.p, M,
                               (uint32_t)sh->own_begin, (uint32_t)sh->own_end, (unsigned long long *)d.counter.p, stream));
-    if ((rc = d.offsets.ensure((size_t)M * 8))) return rc; // (the tile offsets are no longer needed)
+    if (scan_tile_elems() != 2048) return ACGPU_E_INVALID; // (k_wwl_emit ranks one prefix-sum tile per workgroup)
     if ((rc = d.scan_tmp.ensure(((size_t)M / 2048 + 2) * 8))) return rc;
-    HIP_TRY(launch_exclusive_scan((const uint32_t *)d.wwl_sel.p, M, (uint64_t *)d.offsets.p, (uint64_t *)d.scan_tmp.p, stream));
+    HIP_TRY(launch_scan_tile_offsets((const uint32_t *)d.wwl_sel.p, M, (uint64_t *)d.scan_tmp.p, stream));
     HIP_TRY(launch_wwl_emit((const uint32_t *)d.wwl_rs.p, (const uint32_t *)d.wwl_sel.p, (const int32_t *)d.wwl_mend.p,
-                            (const int32_t *)d.wwl_mid.p, (const uint64_t *)d.offsets.p, M, record_kind, d_out, cap, stream));
+                            (const int32_t *)d.wwl_mid.p, (const uint64_t *)d.scan_tmp.p, M, record_kind, d_out, cap, stream));
     if (prof) HIP_TRY(hipEventRecord(d.ev[2], stream));
     HIP_TRY(hipMemcpyAsync(d.h_counter, (const uint64_t *)d.scan_tmp.p + scan_tiles_for(M), 8, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipMemcpyAsync(d.h_counter + 1, d.counter.p, 8, hipMemcpyDeviceToHost, stream));

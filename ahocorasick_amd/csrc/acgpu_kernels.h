@@ -137,6 +137,8 @@ hipError_t launch_permute(const ScratchRec *d_scratch, const unsigned long long 
                           int record_kind, void *d_out, uint64_t out_cap, const uint32_t *d_id_map, hipStream_t stream,
                           const PermuteTail *tail = nullptr);
 uint32_t scan_tiles_for(uint32_t n); // number of prefix-sum tiles; the grand total is d_tmp[scan_tiles_for(n)]
+hipError_t launch_scan_tile_offsets(const uint32_t *d_counts, uint32_t n, uint64_t *d_tmp, hipStream_t stream); // tile level only
+uint32_t scan_tile_elems();          // elements per prefix-sum tile
 
 // Fused finalize of the tile kernel (one launch instead of prefix-sum kernels + permute): slice y of the scratch holds the
 // records of workgroup y, whose regions are [y * regions_per_wg, ...); the block derives its offsets from the workgroup sums
@@ -253,6 +255,7 @@ hipError_t launch_wwl_jumps(const uint32_t *d_nxt, const uint32_t *d_mark, uint3
 hipError_t launch_wwl_bits_to_mark(const uint32_t *d_bits, uint32_t M, uint32_t *d_mark, hipStream_t stream);
 hipError_t launch_wwl_sequential(const DevTables &t, const uint16_t *d_hay, uint32_t len, void *d_out, uint64_t cap,
                                  int record_kind, unsigned long long *d_counter, hipStream_t stream);
+// (d_tile_offsets: launch_scan_tile_offsets over d_sel)
 hipError_t launch_wwl_emit(const uint32_t *d_rs, const uint32_t *d_sel, const int32_t *d_mend, const int32_t *d_mid,
                            const uint64_t *d_offsets, uint32_t M, int record_kind, void *d_out, uint64_t cap, hipStream_t stream);
 

@@ -326,6 +326,17 @@ hipError_t launch_exclusive_scan(const uint32_t *d_counts, uint32_t n, uint64_t 
     return hipGetLastError();
 }
 
+// the tile level of the prefix sum alone: d_tmp[t] = number of flagged elements in front of tile t (kScanTile elements per tile),
+// d_tmp[scan_tiles_for(n)] = their total -- for a consumer that ranks inside a tile itself (k_wwl_emit) and needs no offset per element
+hipError_t launch_scan_tile_offsets(const uint32_t *d_counts, uint32_t n, uint64_t *d_tmp, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const uint32_t n_tiles = (n + kScanTile - 1) / kScanTile;
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(n_tiles), dim3(256), 0, stream, d_counts, n, d_tmp);
+    hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(256), 0, stream, d_tmp, n_tiles);
+    return hipGetLastError();
+}
+uint32_t scan_tile_elems() { return kScanTile; }
+
 // ---- permutation to reference order ----------------------------------------------------------------------
 template <int REC>
 __global__ __launch_bounds__(256) void k_permute(const ScratchRec *scratch, const unsigned long long *counter,

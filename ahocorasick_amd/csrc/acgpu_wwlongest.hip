@@ -382,19 +382,52 @@ __global__ void k_wwl_sequential(DevTables T, const uint16_t *hay, uint32_t len,
     *counter = n;
 }
 
+// One workgroup per prefix-sum tile (2048 walk starts, 8 passes of 256): the selected starts are ranked inside the tile
+// here -- ballots, the waves' totals through LDS -- on top of the tile's offset, so no 8-byte offset per start is written
+// and read back (k_scan_apply: 0.24 ms for config 5's 30 M starts).
 template <int REC>
 __global__ __launch_bounds__(256) void k_wwl_emit(const uint32_t *rs, const uint32_t *sel, const int32_t *mend,
-                                                  const int32_t *mid, const uint64_t *offsets, uint32_t M, void *out,
+                                                  const int32_t *mid, const uint64_t *tile_offsets, uint32_t M, void *out,
                                                   uint64_t cap) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= M || !sel[k]) return;
-    const uint64_t dst = offsets[k];
-    if (dst >= cap) return;
-    if (REC == ACGPU_REC_SET) {
-        reinterpret_cast<int2 *>(out)[dst] = make_int2((int)rs[k], mend[k]);
-    } else {
-        int32_t *o = reinterpret_cast<int32_t *>(out) + dst * 3;
-        o[0] = (int)rs[k]; o[1] = mend[k]; o[2] = mid[k];
+    // element j * 256 + thread of the tile in pass j: every access coalesced; the rank of a selected start = the tile's offset +
+    // the selected ones of the passes before + those of this pass in the waves and lanes before (ballots)
+    __shared__ uint32_t tot[8][4];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t base = blockIdx.x * 2048u;
+    uint32_t pre[8];
+    bool f[8];
+#pragma unroll
+    for (uint32_t j = 0; j < 8; ++j) {
+        const uint32_t k = base + j * 256u + threadIdx.x;
+        f[j] = k < M && sel[k] != 0;
+        const uint64_t bal = __ballot(f[j]);
+        pre[j] = (uint32_t)__popcll(bal & lanemask_lt());
+        if (lane == 0) tot[j][wave] = (uint32_t)__popcll(bal);
+    }
+    __syncthreads();
+    uint64_t running = tile_offsets[blockIdx.x];
+#pragma unroll
+    for (uint32_t j = 0; j < 8; ++j) {
+        uint32_t before = 0, all = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 4; ++w) {
+            const uint32_t t = tot[j][w];
+            before += w < wave ? t : 0u;
+            all += t;
+        }
+        if (f[j]) {
+            const uint32_t k = base + j * 256u + threadIdx.x;
+            const uint64_t dst = running + before + pre[j];
+            if (dst < cap) {
+                if (REC == ACGPU_REC_SET) {
+                    reinterpret_cast<int2 *>(out)[dst] = make_int2((int)rs[k], mend[k]);
+                } else {
+                    int32_t *o = reinterpret_cast<int32_t *>(out) + dst * 3;
+                    o[0] = (int)rs[k]; o[1] = mend[k]; o[2] = mid[k];
+                }
+            }
+        }
+        running += all;
     }
 }
 
@@ -457,7 +490,7 @@ hipError_t launch_wwl_sequential(const DevTables &t, const uint16_t *d_hay, uint
 
 hipError_t launch_wwl_emit(const uint32_t *d_rs, const uint32_t *d_sel, const int32_t *d_mend, const int32_t *d_mid,
                            const uint64_t *d_offsets, uint32_t M, int record_kind, void *d_out, uint64_t cap, hipStream_t stream) {
-    const dim3 grid((M + 255) / 256), block(256);
+    const dim3 grid((M + 2047) / 2048), block(256); // (one workgroup per prefix-sum tile: scan_tile_elems() == 2048)
     if (record_kind == ACGPU_REC_SET)
         hipLaunchKernelGGL(k_wwl_emit<ACGPU_REC_SET>, grid, block, 0, stream, d_rs, d_sel, d_mend, d_mid, d_offsets, M, d_out, cap);
     else
