@@ -320,7 +320,9 @@ int acgpu_stream_probe(const void *d_buf, uint64_t n_bytes, void *stream, int re
  * the old or the new value, never a torn one, but a call may then mix settings).  name: "chunk_units",
  * "blocks_per_cu", "lds_table_bytes", "force_sparse", "dense_budget_bytes", "force_kernel" (0 auto, 1 DFA chunk
  * scan, 2 K-gram tile scan), "region_units", "filter_max_bytes", "ww_first_seed" (WHOLEWORD builder: index of the first
- * hash seed tried).  Returns the previous value, -1 for an unknown name. */
+ * hash seed tried), and the builder's A/B switches "no_merged_ranges" (dictionaries over several ranges keep the class-table
+ * filter), "no_short_keywords" (the filter's K stays at most the shortest keyword).  Returns the previous value, -1 for an
+ * unknown name. */
 int64_t acgpu_set_tunable(const char *name, int64_t value);
 
 const char *acgpu_strerror(int code);
