@@ -9,6 +9,12 @@ LIB_PATH = os.environ.get("ACGPU_LIB") or os.path.join(_HERE, "lib", "libacgpu.s
 OK, E_INVALID, E_NONWORD, E_NOMEM, E_OVERFLOW, E_HIP, E_NODEVICE, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7
 MODE_ALL, MODE_LONGEST, MODE_WHOLEWORD, MODE_SHORTEST, MODE_WWLONGEST = 0, 1, 2, 3, 4
 REC_SET, REC_MAP = 8, 12
+TRANSPORT_AUTO, TRANSPORT_RCCL, TRANSPORT_PEER = 0, 1, 2
+
+
+def gather_slot_bytes(gcap, record_kind):
+    """acgpu_gather_slot_bytes (include/acgpu.h): [16-byte acgpu_device_result | gcap records], padded to 16 bytes."""
+    return (16 + int(gcap) * int(record_kind) + 15) & ~15
 
 
 class AcgpuError(RuntimeError):
@@ -39,7 +45,7 @@ class DeviceResult(ctypes.Structure):  # acgpu_device_result: what Shard.d_resul
     _fields_ = [("n_records", ctypes.c_uint64), ("redone", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
 
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class Profile(ctypes.Structure):
@@ -51,7 +57,9 @@ class Profile(ctypes.Structure):
 SYMBOLS = ["acgpu_build", "acgpu_free", "acgpu_get_info", "acgpu_match_u16", "acgpu_match_batch_u16", "acgpu_match_device",
            "acgpu_match_device_begin", "acgpu_match_device_end", "acgpu_match_device_abandon", "acgpu_synth_fill", "acgpu_synth_tokens", "acgpu_stream_probe",
            "acgpu_set_tunable", "acgpu_strerror", "acgpu_last_hip_error", "acgpu_abi_version", "acgpu_debug_tables",
-           "acgpu_debug_wordhash", "acgpu_stream_open", "acgpu_stream_feed", "acgpu_stream_close"]
+           "acgpu_debug_wordhash", "acgpu_stream_open", "acgpu_stream_feed", "acgpu_stream_close",
+           "acgpu_match_u16_multi", "acgpu_comm_open", "acgpu_comm_close", "acgpu_comm_transport", "acgpu_comm_stream",
+           "acgpu_match_device_allgather", "acgpu_last_rccl_error"]
 
 _lib = None
 
@@ -114,6 +122,20 @@ def lib():
         L.acgpu_debug_wordhash.restype = ci
         L.acgpu_debug_wordhash.argtypes = [vp, ctypes.POINTER(u32), vp, ctypes.POINTER(u64), vp, vp, ctypes.POINTER(u32), vp,
                                            ctypes.POINTER(u32)]
+        L.acgpu_match_u16_multi.restype = ci
+        L.acgpu_match_u16_multi.argtypes = [vp, vp, u64, ctypes.POINTER(ci), ci, ci, vp, u64, ctypes.POINTER(u64)]
+        L.acgpu_comm_open.restype = ci
+        L.acgpu_comm_open.argtypes = [ctypes.POINTER(ci), ci, ci, ctypes.POINTER(vp)]
+        L.acgpu_comm_close.restype = None
+        L.acgpu_comm_close.argtypes = [vp]
+        L.acgpu_comm_transport.restype = ci
+        L.acgpu_comm_transport.argtypes = [vp]
+        L.acgpu_comm_stream.restype = vp
+        L.acgpu_comm_stream.argtypes = [vp, ci]
+        L.acgpu_match_device_allgather.restype = ci
+        L.acgpu_match_device_allgather.argtypes = [vp, vp, ctypes.POINTER(Shard), ci, ctypes.POINTER(vp), u64, ctypes.POINTER(u64),
+                                                   ctypes.POINTER(Profile)]
+        L.acgpu_last_rccl_error.restype = ci
         if L.acgpu_abi_version() != ABI_VERSION:
             raise ImportError("ahocorasick_amd: %s has ABI version %d, this package binds version %d -- rebuild it"
                               % (LIB_PATH, L.acgpu_abi_version(), ABI_VERSION))

@@ -13,127 +13,17 @@
 #include <thread>
 #include <vector>
 
+#include "acgpu_host.h"
 #include "acgpu_internal.h"
 #include "acgpu_kernels.h"
 
 using namespace acgpu;
 
-namespace {
-
+namespace acgpu {
 thread_local int g_last_hip_error = 0;
+}
 
-#define HIP_TRY(expr)                                  \
-    do {                                               \
-        hipError_t _e = (expr);                        \
-        if (_e != hipSuccess) {                        \
-            g_last_hip_error = (int)_e;                \
-            (void)hipGetLastError();                   \
-            return _e == hipErrorOutOfMemory ? ACGPU_E_NOMEM : (_e == hipErrorNoDevice ? ACGPU_E_NODEVICE : ACGPU_E_HIP); \
-        }                                              \
-    } while (0)
-
-// grow-only device buffer
-struct DevBuf {
-    void *p = nullptr;
-    size_t bytes = 0;
-    int ensure(size_t need) {
-        if (need <= bytes) return ACGPU_OK;
-        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
-        size_t want = need + need / 4 + 256;
-        HIP_TRY(hipMalloc(&p, want));
-        bytes = want;
-        return ACGPU_OK;
-    }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        bytes = 0;
-    }
-};
-
-// One asynchronous call in flight (acgpu_match_device_begin/_end): its own events and pinned count slot.
-struct Ticket {
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t done = nullptr;
-    unsigned long long *h_count = nullptr; // pinned, 64 bytes
-    bool busy = false, profiled = false;
-    bool done_is_ev2 = false; // the completion to wait for is ev[2] (the finalize kernel's own end), not `done`
-    // how _end collects it: 0 = the AhoCorasick / WholeWord pipeline (count and overflow word in h_count), 1 = a chain pipeline
-    // that was enqueued (LONGEST walk: count in h_count[0], chain exit in h_count[2]), 2 = the call ran synchronously inside
-    // _begin (the other families): everything is in the fields below
-    int kind = 0;
-    int sync_rc = 0;
-    uint64_t sync_n = 0;
-    acgpu_profile sync_prof{};
-    acgpu_shard *user_shard = nullptr; // receives chain_exit in _end
-    uint64_t cap = 0, scanned = 0;
-    char kname[64] = {0};
-    void *owner = nullptr; // the DeviceState it belongs to
-    // what _end needs to redo the call when the split form's candidate slices were too small
-    acgpu_shard shard{};
-    int record_kind = 0;
-    void *d_out = nullptr;
-    hipStream_t stream = nullptr;
-};
-
-struct DeviceState {
-    int device = -1;
-    int n_cu = 256;
-    DevTables T{};
-    const uint8_t *wflags_f = nullptr; // word-character tables of the loops that fold in every lookup (HostTables::wflags_f)
-    const uint32_t *wbits_f = nullptr;
-    int start_behind = -1; // set for the duration of a batch call: the separator unit (k_wwl_starts: a haystack's first unit is a walk start)
-    std::vector<void *> table_allocs;
-    // scratch pool (one in-flight match per automaton and device)
-    DevBuf counter, chunk_counts, offsets, scan_tmp, scratch, chain, lenbuf, statebuf;
-    DevBuf stage_hay, stage_out; // acgpu_match_u16 staging
-    // batch entry: pinned concatenation + offsets, device offsets, tagged records
-    void *batch_pin = nullptr;
-    size_t batch_pin_bytes = 0;
-    DevBuf batch_off, batch_out;
-    // pipelined host entry: pinned staging ring (one slot per chunk in flight), its copy stream, one event per chunk
-    static constexpr int kPinSlots = 8;
-    void *pin[kPinSlots] = {nullptr};
-    size_t pin_bytes = 0;
-    hipStream_t copy_stream = nullptr;
-    std::vector<hipEvent_t> chunk_ev;
-    DevBuf short_recs, short_nxt, short_tmp, short_mark; // SHORTEST: all-matches list + selection scratch
-    DevBuf ww_recs;                                      // WHOLEWORD: region-local record slots (TileLaunch::d_region_recs)
-    DevBuf blockmax;                                     // LONGEST: farthest landing per 64 positions
-    DevBuf lenbig, todo;                                 // LONGEST: escaped lengths; root-table form: flagged chunks
-    DevBuf chainbits;                                    // LONGEST: one bit per position, set where the chain reports a match
-    DevBuf cands, region_cands;                          // ALL, split form: candidate positions, {first, count} per region
-    DevBuf wwl_rs, wwl_mend, wwl_mid, wwl_sel, wwl_stop, wwl_nxt0; // WWLONGEST: walk starts, what each would report, where it stops
-    unsigned long long *h_counter = nullptr; // pinned
-    // match_all: two sets of slot counters alternate; the permute pass of a call zeroes the set the next call uses
-    int cset = 0;
-    bool cclean[2] = {false, false};
-    void *counter_seen = nullptr; // (a re-allocated counter buffer is not clean)
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    Ticket tickets[4];
-    // stream rule (include/acgpu.h): while tickets are in flight every call on this automaton and device uses their stream
-    int inflight = 0;
-    hipStream_t inflight_stream = nullptr;
-    ~DeviceState() {
-        for (void *p : table_allocs) (void)hipFree(p);
-        counter.release(); chunk_counts.release(); offsets.release(); scan_tmp.release(); scratch.release();
-        chain.release(); lenbuf.release(); statebuf.release(); stage_hay.release(); stage_out.release();
-        short_recs.release(); short_nxt.release(); short_tmp.release(); short_mark.release();
-        wwl_rs.release(); wwl_mend.release(); wwl_mid.release(); wwl_sel.release(); wwl_stop.release(); wwl_nxt0.release(); ww_recs.release(); blockmax.release(); lenbig.release(); todo.release(); chainbits.release(); cands.release(); region_cands.release();
-        if (h_counter) (void)hipHostFree(h_counter);
-        for (auto &q : pin) if (q) (void)hipHostFree(q);
-        if (batch_pin) (void)hipHostFree(batch_pin);
-        batch_off.release(); batch_out.release();
-        if (copy_stream) (void)hipStreamDestroy(copy_stream);
-        for (auto &e : chunk_ev) if (e) (void)hipEventDestroy(e);
-        for (auto &e : ev) if (e) (void)hipEventDestroy(e);
-        for (auto &tk : tickets) {
-            for (auto &e : tk.ev) if (e) (void)hipEventDestroy(e);
-            if (tk.done) (void)hipEventDestroy(tk.done);
-            if (tk.h_count) (void)hipHostFree(tk.h_count);
-        }
-    }
-};
+namespace {
 
 template <typename T>
 int upload(DeviceState &d, const std::vector<T> &v, const T **out) {
@@ -148,12 +38,6 @@ int upload(DeviceState &d, const std::vector<T> &v, const T **out) {
 
 } // namespace
 
-struct acgpu_automaton {
-    HostTables t;
-    std::mutex mu;
-    std::map<int, std::unique_ptr<DeviceState>> dev;
-};
-
 namespace {
 
 uint32_t lds_states_for(const HostTables &t) {
@@ -166,19 +50,20 @@ uint32_t lds_states_for(const HostTables &t) {
     return (uint32_t)std::min<uint64_t>(s, t.n_states);
 }
 
-int ensure_device(acgpu_automaton *a, DeviceState **out) {
+// caller holds a->mu
+int ensure_device(acgpu_automaton *a, DeviceState **out, int lane) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    auto it = a->dev.find(dev);
+    auto it = a->dev.find({dev, lane});
     if (it != a->dev.end()) {
-        // the LDS residency tunable may have changed between calls
-        it->second->T.lds_entries = lds_states_for(a->t) * a->t.n_cls;
         *out = it->second.get();
         return ACGPU_OK;
     }
     std::unique_ptr<DeviceState> d(new (std::nothrow) DeviceState());
     if (!d) return ACGPU_E_NOMEM;
     d->device = dev;
+    d->lane = lane;
+    if (lane > 0) HIP_TRY(hipStreamCreateWithFlags(&d->call_stream, hipStreamNonBlocking));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, dev));
     d->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -263,7 +148,7 @@ int ensure_device(acgpu_automaton *a, DeviceState **out) {
         tk.owner = d.get();
     }
     *out = d.get();
-    a->dev[dev] = std::move(d);
+    a->dev[{dev, lane}] = std::move(d);
     return ACGPU_OK;
 }
 
@@ -418,9 +303,15 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         L.region_cap = (uint32_t)(R / 2 + 1);
         const uint64_t ww_rec_bytes = (uint64_t)L.n_regions * L.region_cap * 12;
         if (!(tunables().tile_debug & 134217728) && ww_rec_bytes <= (24ull << 30)) {
-            if ((rc = d.ww_recs.ensure(ww_rec_bytes + 64))) return rc;
-            L.d_region_recs = (int32_t *)d.ww_recs.p;
-            ww_direct = true;
+            // (about 6 bytes per haystack unit: on a device that cannot spare them the call falls back to the scratch slices +
+            // k_permute instead of failing; tunable tile_debug bit 2^40: the allocation "fails", for the test of that path)
+            rc = (tunables().tile_debug & (1ll << 40)) ? ACGPU_E_NOMEM : d.ww_recs.ensure(ww_rec_bytes + 64);
+            if (rc == ACGPU_OK) {
+                L.d_region_recs = (int32_t *)d.ww_recs.p;
+                ww_direct = true;
+            } else if (rc != ACGPU_E_NOMEM) {
+                return rc;
+            }
         }
         HIP_TRY(hipMemsetAsync(d.chunk_counts.p, 0, (size_t)L.n_regions * 4, stream));
 #ifdef ACGPU_TIMING
@@ -1215,20 +1106,26 @@ int match_wwlongest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int rec
     return *n_out > cap ? ACGPU_E_OVERFLOW : ACGPU_OK;
 }
 
-int device_for_call(acgpu_automaton *a, DeviceState **d) {
+} // namespace
+
+namespace acgpu {
+
+int device_for_call(acgpu_automaton *a, DeviceState **d, int lane) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
         (void)hipGetLastError();
         return ACGPU_E_NODEVICE;
     }
-    return ensure_device(a, d);
+    std::lock_guard<std::mutex> lock(a->mu); // (the map; a new pool uploads its tables under it)
+    return ensure_device(a, d, lane);
 }
 
-// validates a shard and runs the pipeline of the automaton's family; caller holds a->mu.
+// validates a shard and runs the pipeline of the automaton's family; caller holds d.mu.
 // readable: the call stands for match(Readable, ...) (acgpu_stream_feed) -- the word matchers' Readable loops fold in every
 // lookup where their String loops mix folded and raw ones, which only matters for tables that are not fold-consistent.
 int match_shard(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_kind, void *d_out, uint64_t cap,
-                uint64_t *n_out, hipStream_t stream, acgpu_profile *prof, bool readable = false) {
+                uint64_t *n_out, hipStream_t stream, acgpu_profile *prof, bool readable) {
+    d.T.lds_entries = lds_states_for(a->t) * a->t.n_cls; // (the LDS residency tunable may have changed between calls)
     if (record_kind != ACGPU_REC_SET && record_kind != ACGPU_REC_MAP) return ACGPU_E_INVALID;
     if (sh->n_units >= (1ull << 31)) return ACGPU_E_INVALID;
     if (sh->own_begin > sh->own_end || sh->own_end > sh->n_units) return ACGPU_E_INVALID;
@@ -1277,7 +1174,59 @@ int match_shard(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_
     return rc;
 }
 
-} // namespace
+// acgpu_match_device_begin on a given scratch pool (the caller holds dd.mu and has made dd's device current)
+int begin_shard(acgpu_automaton *a, DeviceState &dd, acgpu_shard *sh, int record_kind, void *d_out, uint64_t cap, hipStream_t stream,
+                int want_profile, acgpu_ticket **ticket) {
+    *ticket = nullptr;
+    const HostTables &t = a->t;
+    DeviceState *d = &dd;
+    int rc;
+    if (record_kind != ACGPU_REC_SET && record_kind != ACGPU_REC_MAP) return ACGPU_E_INVALID;
+    if (sh->n_units >= (1ull << 31) || sh->own_begin > sh->own_end || sh->own_end > sh->n_units) return ACGPU_E_INVALID;
+    if (sh->n_units && (!sh->d_hay || ((uintptr_t)sh->d_hay & 15))) return ACGPU_E_INVALID;
+    if (cap && (!d_out || ((uintptr_t)d_out & 3))) return ACGPU_E_INVALID;
+    if (sh->d_result && ((uintptr_t)sh->d_result & 15)) return ACGPU_E_INVALID;
+    if (d->inflight > 0 && stream != d->inflight_stream) return ACGPU_E_INVALID; // stream rule (include/acgpu.h)
+    Ticket *tk = nullptr;
+    for (auto &cand : d->tickets)
+        if (!cand.busy) { tk = &cand; break; }
+    if (!tk) return ACGPU_E_INVALID; // too many calls in flight: collect one first
+    tk->profiled = want_profile != 0;
+    tk->done_is_ev2 = false;
+    tk->cap = cap;
+    tk->user_shard = sh;
+    tk->kname[0] = 0;
+    uint64_t dummy = 0;
+    // enqueued without waiting: the AhoCorasick / WholeWord pipeline (one scan + ordering pass) and the LongestMatch walk
+    // pipeline (lengths, synchronisation points, chain count, prefix sum, emit: nothing of it needs the host).  The other
+    // families -- and LongestMatch over a dictionary with a selective suffix filter, whose sparse form falls back to the walk
+    // after looking at the match count -- run their call inside _begin: the ticket is complete when _begin returns.
+    if (t.mode == ACGPU_MODE_ALL || (t.mode == ACGPU_MODE_WHOLEWORD && t.fold_consistent)) {
+        tk->kind = 0;
+        rc = match_all(a, *d, sh, record_kind, d_out, cap, &dummy, stream, nullptr, tk);
+    } else if (t.mode == ACGPU_MODE_LONGEST && !(filter_is_selective(t) && tunables().force_kernel != 1)) {
+        tk->kind = 1;
+        rc = match_longest(a, *d, sh, record_kind, d_out, cap, &dummy, stream, nullptr, tk);
+    } else {
+        tk->kind = 2;
+        tk->sync_n = 0;
+        std::memset(&tk->sync_prof, 0, sizeof(tk->sync_prof));
+        tk->sync_rc = match_shard(a, *d, sh, record_kind, d_out, cap, &tk->sync_n, stream, want_profile ? &tk->sync_prof : nullptr);
+        if (tk->sync_rc != ACGPU_OK && tk->sync_rc != ACGPU_E_OVERFLOW) return tk->sync_rc;
+        tk->busy = true; // (complete: nothing in flight on the device, the stream rule does not apply to it)
+        *ticket = reinterpret_cast<acgpu_ticket *>(tk);
+        return ACGPU_OK;
+    }
+    if (rc != ACGPU_OK) return rc;
+    tk->busy = true;
+    d->inflight++;
+    d->inflight_stream = stream;
+    *ticket = reinterpret_cast<acgpu_ticket *>(tk);
+    return ACGPU_OK;
+}
+
+
+} // namespace acgpu
 
 extern "C" {
 
@@ -1354,7 +1303,7 @@ void acgpu_free(acgpu_automaton *a) {
     int cur = -1;
     bool have = hipGetDevice(&cur) == hipSuccess;
     for (auto &kv : a->dev) {
-        if (have) (void)hipSetDevice(kv.first);
+        if (have) (void)hipSetDevice(kv.first.first);
         kv.second.reset();
     }
     if (have) (void)hipSetDevice(cur);
@@ -1465,10 +1414,10 @@ int acgpu_stream_feed(acgpu_stream *s, const uint16_t *units, uint64_t n_units, 
     if (n_units) std::memcpy(s->buf.data() + s->carry.size(), units, n_units * 2);
     uint64_t chain_exit = mode == ACGPU_MODE_SHORTEST ? s->chain_entry : std::max<uint64_t>(s->chain_entry, s->carry_pos + own_end);
     if (own_end > own_begin) {
-        std::lock_guard<std::mutex> lock(a->mu); // staging buffers are part of the per-device scratch pool
         DeviceState *d = nullptr;
         int rc = device_for_call(a, &d);
         if (rc) return rc;
+        std::lock_guard<std::mutex> lock(d->mu); // staging buffers are part of the per-device scratch pool
         if ((rc = d->stage_hay.ensure(total * 2 + 16))) return rc;
         if ((rc = d->stage_out.ensure(cap * (uint64_t)record_kind + 16))) return rc;
         HIP_TRY(hipMemcpy(d->stage_hay.p, s->buf.data(), total * 2, hipMemcpyHostToDevice));
@@ -1517,10 +1466,10 @@ int acgpu_match_device(const acgpu_automaton *ca, acgpu_shard *sh, int record_ki
                        uint64_t *n_out, void *stream_, acgpu_profile *prof) {
     if (!ca || !sh || !n_out) return ACGPU_E_INVALID;
     acgpu_automaton *a = const_cast<acgpu_automaton *>(ca);
-    std::lock_guard<std::mutex> lock(a->mu);
     DeviceState *d = nullptr;
     int rc = device_for_call(a, &d);
     if (rc) return rc;
+    std::lock_guard<std::mutex> lock(d->mu);
     return match_shard(a, *d, sh, record_kind, d_out, cap, n_out, reinterpret_cast<hipStream_t>(stream_), prof);
 }
 
@@ -1529,63 +1478,20 @@ int acgpu_match_device_begin(const acgpu_automaton *ca, acgpu_shard *sh, int rec
     if (!ca || !sh || !ticket) return ACGPU_E_INVALID;
     *ticket = nullptr;
     acgpu_automaton *a = const_cast<acgpu_automaton *>(ca);
-    const HostTables &t = a->t;
-    std::lock_guard<std::mutex> lock(a->mu);
     DeviceState *d = nullptr;
     int rc = device_for_call(a, &d);
     if (rc) return rc;
-    if (record_kind != ACGPU_REC_SET && record_kind != ACGPU_REC_MAP) return ACGPU_E_INVALID;
-    if (sh->n_units >= (1ull << 31) || sh->own_begin > sh->own_end || sh->own_end > sh->n_units) return ACGPU_E_INVALID;
-    if (sh->n_units && (!sh->d_hay || ((uintptr_t)sh->d_hay & 15))) return ACGPU_E_INVALID;
-    if (cap && (!d_out || ((uintptr_t)d_out & 3))) return ACGPU_E_INVALID;
-    if (sh->d_result && ((uintptr_t)sh->d_result & 15)) return ACGPU_E_INVALID;
-    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-    if (d->inflight > 0 && stream != d->inflight_stream) return ACGPU_E_INVALID; // stream rule (include/acgpu.h)
-    Ticket *tk = nullptr;
-    for (auto &cand : d->tickets)
-        if (!cand.busy) { tk = &cand; break; }
-    if (!tk) return ACGPU_E_INVALID; // too many calls in flight: collect one first
-    tk->profiled = want_profile != 0;
-    tk->done_is_ev2 = false;
-    tk->cap = cap;
-    tk->user_shard = sh;
-    tk->kname[0] = 0;
-    uint64_t dummy = 0;
-    // enqueued without waiting: the AhoCorasick / WholeWord pipeline (one scan + ordering pass) and the LongestMatch walk
-    // pipeline (lengths, synchronisation points, chain count, prefix sum, emit: nothing of it needs the host).  The other
-    // families -- and LongestMatch over a dictionary with a selective suffix filter, whose sparse form falls back to the walk
-    // after looking at the match count -- run their call inside _begin: the ticket is complete when _begin returns.
-    if (t.mode == ACGPU_MODE_ALL || (t.mode == ACGPU_MODE_WHOLEWORD && t.fold_consistent)) {
-        tk->kind = 0;
-        rc = match_all(a, *d, sh, record_kind, d_out, cap, &dummy, stream, nullptr, tk);
-    } else if (t.mode == ACGPU_MODE_LONGEST && !(filter_is_selective(t) && tunables().force_kernel != 1)) {
-        tk->kind = 1;
-        rc = match_longest(a, *d, sh, record_kind, d_out, cap, &dummy, stream, nullptr, tk);
-    } else {
-        tk->kind = 2;
-        tk->sync_n = 0;
-        std::memset(&tk->sync_prof, 0, sizeof(tk->sync_prof));
-        tk->sync_rc = match_shard(a, *d, sh, record_kind, d_out, cap, &tk->sync_n, stream, want_profile ? &tk->sync_prof : nullptr);
-        if (tk->sync_rc != ACGPU_OK && tk->sync_rc != ACGPU_E_OVERFLOW) return tk->sync_rc;
-        tk->busy = true; // (complete: nothing in flight on the device, the stream rule does not apply to it)
-        *ticket = reinterpret_cast<acgpu_ticket *>(tk);
-        return ACGPU_OK;
-    }
-    if (rc != ACGPU_OK) return rc;
-    tk->busy = true;
-    d->inflight++;
-    d->inflight_stream = stream;
-    *ticket = reinterpret_cast<acgpu_ticket *>(tk);
-    return ACGPU_OK;
+    std::lock_guard<std::mutex> lock(d->mu);
+    return begin_shard(a, *d, sh, record_kind, d_out, cap, reinterpret_cast<hipStream_t>(stream_), want_profile, ticket);
 }
 
 int acgpu_match_device_abandon(const acgpu_automaton *ca, acgpu_ticket *ticket) {
     if (!ca || !ticket) return ACGPU_E_INVALID;
-    acgpu_automaton *a = const_cast<acgpu_automaton *>(ca);
     Ticket *tk = reinterpret_cast<Ticket *>(ticket);
+    DeviceState *own = reinterpret_cast<DeviceState *>(tk->owner); // (set when the pool was created)
     hipEvent_t done = nullptr;
     {
-        std::lock_guard<std::mutex> lock(a->mu);
+        std::lock_guard<std::mutex> lock(own->mu);
         if (!tk->busy) return ACGPU_E_INVALID;
         if (tk->kind == 2) {
             tk->busy = false;
@@ -1594,7 +1500,7 @@ int acgpu_match_device_abandon(const acgpu_automaton *ca, acgpu_ticket *ticket) 
         done = tk->done_is_ev2 ? tk->ev[2] : tk->done;
     }
     HIP_TRY(hipEventSynchronize(done)); // (its kernels still write the caller's buffers until then)
-    std::lock_guard<std::mutex> lock(a->mu);
+    std::lock_guard<std::mutex> lock(own->mu);
     if (!tk->busy) return ACGPU_E_INVALID;
     tk->busy = false;
     reinterpret_cast<DeviceState *>(tk->owner)->inflight--;
@@ -1602,12 +1508,22 @@ int acgpu_match_device_abandon(const acgpu_automaton *ca, acgpu_ticket *ticket) 
 }
 
 int acgpu_match_device_end(const acgpu_automaton *ca, acgpu_ticket *ticket, uint64_t *n_out, acgpu_profile *prof) {
+    return end_ticket(ca, ticket, n_out, prof, nullptr);
+}
+
+} // extern "C"
+
+namespace acgpu {
+
+int end_ticket(const acgpu_automaton *ca, acgpu_ticket *ticket, uint64_t *n_out, acgpu_profile *prof, bool *redone) {
+    if (redone) *redone = false;
     if (!ca || !ticket || !n_out) return ACGPU_E_INVALID;
     acgpu_automaton *a = const_cast<acgpu_automaton *>(ca);
     Ticket *tk = reinterpret_cast<Ticket *>(ticket);
+    DeviceState *own = reinterpret_cast<DeviceState *>(tk->owner); // (set when the pool was created)
     hipEvent_t done = nullptr;
     {
-        std::lock_guard<std::mutex> lock(a->mu);
+        std::lock_guard<std::mutex> lock(own->mu);
         if (!tk->busy) return ACGPU_E_INVALID;
         if (tk->kind == 2) { // ran inside _begin
             tk->busy = false;
@@ -1618,7 +1534,7 @@ int acgpu_match_device_end(const acgpu_automaton *ca, acgpu_ticket *ticket, uint
         done = tk->done_is_ev2 ? tk->ev[2] : tk->done;
     }
     HIP_TRY(hipEventSynchronize(done)); // outside the lock: other calls may be enqueued meanwhile
-    std::lock_guard<std::mutex> lock(a->mu);
+    std::lock_guard<std::mutex> lock(own->mu);
     if (!tk->busy) return ACGPU_E_INVALID; // (collected by another thread meanwhile)
     DeviceState *d = reinterpret_cast<DeviceState *>(tk->owner);
     if (tk->kind == 0 && (uint32_t)tk->h_count[1] != 0) { // a candidate slice / scratch slice was too small: redo with the fused kernel, one slice
@@ -1626,6 +1542,7 @@ int acgpu_match_device_end(const acgpu_automaton *ca, acgpu_ticket *ticket, uint
         const int rc = match_all(a, *d, &tk->shard, tk->record_kind, tk->d_out, tk->cap, n_out, tk->stream, prof, nullptr, true);
         tk->busy = false;
         d->inflight--;
+        if (redone) *redone = true;
         return rc;
     }
     *n_out = *tk->h_count;
@@ -1646,22 +1563,35 @@ int acgpu_match_device_end(const acgpu_automaton *ca, acgpu_ticket *ticket, uint
     return *n_out > tk->cap ? ACGPU_E_OVERFLOW : ACGPU_OK;
 }
 
-namespace {
+} // namespace acgpu
+
+extern "C" {
+
+} // extern "C"
+
+namespace acgpu {
 
 // acgpu_match_u16 on a long haystack, pipelined: the text goes to the device in chunks -- worker threads copy the caller's
 // (pageable) memory into a ring of pinned staging buffers and enqueue the DMA on a copy stream -- while the chunks that have
 // arrived are scanned as shards of the device buffer (own range = the chunk, halos = its neighbours already / also there;
 // the chain families hand their entry on from shard to shard).  The scans are a fraction of the transfer time, so the call
 // runs at the rate of the slower of the host copy and the link instead of copy + scan + copy back in sequence.
+// The general form serves one device's share of a multi-device call as well: the device buffer holds the units [lo, hi) of
+// the text (the share plus its halos), of which [own_lo, own_hi) is owned; positions in the records and in *chain are
+// relative to the buffer.
 constexpr uint64_t kHostChunkUnits = 1ull << 24; // 32 MiB per chunk
 
-int match_u16_pipelined(acgpu_automaton *a, DeviceState &d, const uint16_t *haystack, uint64_t n_units, int record_kind, void *out,
-                        uint64_t cap, uint64_t *n_out) {
+int scan_host_range(acgpu_automaton *a, DeviceState &d, const uint16_t *haystack, uint64_t n_units, uint64_t lo, uint64_t hi,
+                    uint64_t own_lo, uint64_t own_hi, int record_kind, uint64_t cap, uint64_t *n_out, int64_t *chain_io) {
     const HostTables &t = a->t;
     const uint64_t C = kHostChunkUnits;
-    const uint32_t n_chunks = (uint32_t)((n_units + C - 1) / C);
+    const uint64_t nb = hi - lo; // units in the device buffer
+    const uint32_t n_chunks = (uint32_t)((nb + C - 1) / C);
+    const uint64_t ob = own_lo - lo, oe = own_hi - lo; // the owned range in the buffer
+    hipStream_t stream = d.call_stream;
+    *n_out = 0;
     int rc;
-    if ((rc = d.stage_hay.ensure(n_units * 2 + 16))) return rc;
+    if ((rc = d.stage_hay.ensure(nb * 2 + 16))) return rc;
     if ((rc = d.stage_out.ensure(cap * (uint64_t)record_kind + 16))) return rc;
     if (!d.copy_stream) HIP_TRY(hipStreamCreateWithFlags(&d.copy_stream, hipStreamNonBlocking));
     if (d.pin_bytes < C * 2) {
@@ -1693,7 +1623,7 @@ int match_u16_pipelined(acgpu_automaton *a, DeviceState &d, const uint16_t *hays
         for (;;) {
             const uint32_t k = next_chunk.fetch_add(1);
             if (k >= n_chunks || worker_rc.load() != ACGPU_OK) return;
-            const uint64_t lo = (uint64_t)k * C, len = std::min<uint64_t>(C, n_units - lo);
+            const uint64_t b0 = (uint64_t)k * C, len = std::min<uint64_t>(C, nb - b0);
             const int slot = (int)(k % DeviceState::kPinSlots);
             if (k >= (uint32_t)DeviceState::kPinSlots) { // the slot's previous chunk must have left it
                 while (!ready[k - DeviceState::kPinSlots].load(std::memory_order_acquire)) {
@@ -1705,8 +1635,8 @@ int match_u16_pipelined(acgpu_automaton *a, DeviceState &d, const uint16_t *hays
                     return;
                 }
             }
-            std::memcpy(d.pin[slot], haystack + lo, len * 2);
-            if (hipMemcpyAsync((char *)d.stage_hay.p + lo * 2, d.pin[slot], len * 2, hipMemcpyHostToDevice, d.copy_stream) != hipSuccess ||
+            std::memcpy(d.pin[slot], haystack + lo + b0, len * 2);
+            if (hipMemcpyAsync((char *)d.stage_hay.p + b0 * 2, d.pin[slot], len * 2, hipMemcpyHostToDevice, d.copy_stream) != hipSuccess ||
                 hipEventRecord(d.chunk_ev[k], d.copy_stream) != hipSuccess) {
                 worker_rc.store(ACGPU_E_HIP);
                 return;
@@ -1723,37 +1653,36 @@ int match_u16_pipelined(acgpu_automaton *a, DeviceState &d, const uint16_t *hays
     auto join_all = [&]() {
         for (auto &th : pool) if (th.joinable()) th.join();
     };
-    // consumer: shard k once the chunks its halos reach into have arrived
-    const uint64_t left = (t.mode == ACGPU_MODE_WHOLEWORD || t.mode == ACGPU_MODE_WWLONGEST) ? 1 : (t.mode == ACGPU_MODE_LONGEST ? 0 : (t.max_len ? t.max_len - 1 : 0));
+    // consumer: shard k once the chunks its right halo reaches into have arrived (the chunks before a shard always have)
     const uint64_t right = (t.mode == ACGPU_MODE_WHOLEWORD || t.mode == ACGPU_MODE_WWLONGEST) ? (uint64_t)t.max_len + 1
                            : (t.mode == ACGPU_MODE_LONGEST ? (t.max_len ? t.max_len - 1 : 0) : 0);
-    (void)left; // (the chunks before a shard have always arrived)
     uint64_t total = 0;
-    int64_t chain = 0;
+    int64_t chain = chain_io ? *chain_io : 0;
     uint32_t waited = 0; // chunks whose arrival the compute stream already waits for
     int result = ACGPU_OK;
     for (uint32_t k = 0; k < n_chunks && result == ACGPU_OK; ++k) {
-        const uint64_t lo = (uint64_t)k * C, hi = std::min<uint64_t>(n_units, lo + C);
-        const uint32_t need = (uint32_t)std::min<uint64_t>(n_chunks, (std::min<uint64_t>(n_units, hi + right) + C - 1) / C); // chunks [0, need)
+        const uint64_t c0 = std::max<uint64_t>((uint64_t)k * C, ob), c1 = std::min<uint64_t>({nb, (uint64_t)(k + 1) * C, oe});
+        if (c0 >= c1) continue; // a chunk of halo units only
+        const uint32_t need = (uint32_t)std::min<uint64_t>(n_chunks, (std::min<uint64_t>(nb, c1 + right) + C - 1) / C); // chunks [0, need)
         for (; waited < need && result == ACGPU_OK; ++waited) {
             while (!ready[waited].load(std::memory_order_acquire)) {
                 if (worker_rc.load() != ACGPU_OK) { result = worker_rc.load(); break; }
                 std::this_thread::yield();
             }
-            if (result == ACGPU_OK && hipStreamWaitEvent(nullptr, d.chunk_ev[waited], 0) != hipSuccess) result = ACGPU_E_HIP;
+            if (result == ACGPU_OK && hipStreamWaitEvent(stream, d.chunk_ev[waited], 0) != hipSuccess) result = ACGPU_E_HIP;
         }
         if (result != ACGPU_OK) break;
         acgpu_shard sh{};
         sh.d_hay = (const uint16_t *)d.stage_hay.p;
-        sh.n_units = std::min<uint64_t>(n_units, (uint64_t)need * C); // what has arrived
-        sh.own_begin = lo;
-        sh.own_end = hi;
-        sh.text_begin = 1;
-        sh.text_end = sh.n_units == n_units ? 1 : 0;
-        sh.chain_entry = t.mode == ACGPU_MODE_SHORTEST ? chain : std::max<int64_t>(chain, (int64_t)lo);
+        sh.n_units = std::min<uint64_t>(nb, (uint64_t)need * C); // what has arrived
+        sh.own_begin = c0;
+        sh.own_end = c1;
+        sh.text_begin = lo == 0 ? 1 : 0;
+        sh.text_end = (sh.n_units == nb && hi == n_units) ? 1 : 0;
+        sh.chain_entry = t.mode == ACGPU_MODE_SHORTEST ? chain : std::max<int64_t>(chain, (int64_t)c0);
         uint64_t n_k = 0;
         const uint64_t room = total < cap ? cap - total : 0;
-        rc = match_shard(a, d, &sh, record_kind, (char *)d.stage_out.p + std::min(total, cap) * (uint64_t)record_kind, room, &n_k, nullptr, nullptr);
+        rc = match_shard(a, d, &sh, record_kind, (char *)d.stage_out.p + std::min(total, cap) * (uint64_t)record_kind, room, &n_k, stream, nullptr);
         if (rc != ACGPU_OK && rc != ACGPU_E_OVERFLOW) {
             result = rc;
             break;
@@ -1771,12 +1700,29 @@ int match_u16_pipelined(acgpu_automaton *a, DeviceState &d, const uint16_t *hays
         return result;
     }
     *n_out = total;
-    if (total > cap) return ACGPU_E_OVERFLOW;
-    if (total) HIP_TRY(hipMemcpy(out, d.stage_out.p, total * (uint64_t)record_kind, hipMemcpyDeviceToHost));
+    if (chain_io) *chain_io = chain;
+    return total > cap ? ACGPU_E_OVERFLOW : ACGPU_OK;
+}
+
+} // namespace acgpu
+
+namespace {
+
+int match_u16_pipelined(acgpu_automaton *a, DeviceState &d, const uint16_t *haystack, uint64_t n_units, int record_kind, void *out,
+                        uint64_t cap, uint64_t *n_out) {
+    int64_t chain = 0;
+    const int rc = scan_host_range(a, d, haystack, n_units, 0, n_units, 0, n_units, record_kind, cap, n_out, &chain);
+    if (rc != ACGPU_OK) return rc;
+    if (*n_out) {
+        HIP_TRY(hipMemcpyAsync(out, d.stage_out.p, *n_out * (uint64_t)record_kind, hipMemcpyDeviceToHost, d.call_stream));
+        HIP_TRY(hipStreamSynchronize(d.call_stream));
+    }
     return ACGPU_OK;
 }
 
 } // namespace
+
+extern "C" {
 
 int acgpu_match_u16(const acgpu_automaton *ca, const uint16_t *haystack, uint64_t n_units, int record_kind, void *out,
                     uint64_t cap, uint64_t *n_out) {
@@ -1784,10 +1730,10 @@ int acgpu_match_u16(const acgpu_automaton *ca, const uint16_t *haystack, uint64_
     if (record_kind != ACGPU_REC_SET && record_kind != ACGPU_REC_MAP) return ACGPU_E_INVALID;
     if (n_units >= (1ull << 31)) return ACGPU_E_INVALID;
     acgpu_automaton *a = const_cast<acgpu_automaton *>(ca);
-    std::lock_guard<std::mutex> lock(a->mu); // staging buffers are part of the per-device scratch pool
     DeviceState *d = nullptr;
     int rc = device_for_call(a, &d);
     if (rc) return rc;
+    std::lock_guard<std::mutex> lock(d->mu); // staging buffers are part of the per-device scratch pool
     // long haystacks of the families whose shards chain: the pipelined form (the loops that only exist as a sequential kernel
     // over the whole text -- WholeWord / WholeWordLongestSet with a fold-inconsistent table -- take the plain one)
     const HostTables &t = a->t;
@@ -1859,10 +1805,10 @@ int acgpu_match_batch_u16(const acgpu_automaton *ca, const uint16_t *units, cons
         *n_out = n;
         return n > cap ? ACGPU_E_OVERFLOW : ACGPU_OK;
     }
-    std::lock_guard<std::mutex> lock(a->mu); // staging buffers are part of the per-device scratch pool
     DeviceState *d = nullptr;
     int rc = device_for_call(a, &d);
     if (rc) return rc;
+    std::lock_guard<std::mutex> lock(d->mu); // staging buffers are part of the per-device scratch pool
     if (d->inflight > 0) return ACGPU_E_INVALID; // (the NULL stream: see the stream rule)
     const size_t off_bytes = ((size_t)n_haystacks + 1) * 4, pin_need = cat * 2 + 64 + off_bytes;
     if (d->batch_pin_bytes < pin_need) {
@@ -1954,7 +1900,12 @@ int acgpu_synth_tokens(uint16_t *d_dst, uint64_t n_units, uint64_t seed, const u
                        uint32_t n_kw, const uint16_t *swapcase_tbl, void *stream_) {
     if ((n_units && !d_dst) || (n_kw && (!kw_units || !kw_off))) return ACGPU_E_INVALID;
     if (n_units == 0) return ACGPU_OK;
-    if (n_units / 3 + 2 >= (1ull << 32)) return ACGPU_E_INVALID;
+    // a token is a word -- of the dictionary, or a random one of 2..12 units -- plus 1..3 separators: its shortest form bounds
+    // the number of tokens that cover the haystack (a dictionary with a 1-unit or empty word makes 2- and 1-unit tokens)
+    uint64_t min_word = 2;
+    for (uint32_t i = 0; i < n_kw; ++i) min_word = std::min<uint64_t>(min_word, kw_off[i + 1] - kw_off[i]);
+    const uint64_t n_tokens64 = n_units / (min_word + 1) + 2;
+    if (n_tokens64 >= (1ull << 32)) return ACGPU_E_INVALID;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     // the benchmark's scripts and separators (ahocorasick_amd/synth.py: _SCRIPTS, _SEPARATORS)
     static const uint16_t ranges[][2] = {{0x41, 0x5A}, {0x61, 0x7A}, {0xC0, 0xD6}, {0xD8, 0xF6}, {0xF8, 0xFF}, // latin
@@ -1984,7 +1935,7 @@ int acgpu_synth_tokens(uint16_t *d_dst, uint64_t n_units, uint64_t seed, const u
     } catch (...) {
         return ACGPU_E_NOMEM;
     }
-    const uint32_t n_tokens = (uint32_t)(n_units / 3 + 2); // a token is at least 3 units long: these cover the haystack
+    const uint32_t n_tokens = (uint32_t)n_tokens64; // these cover the haystack
     const size_t kw_bytes = n_kw ? (size_t)off32[n_kw] * 2 : 0;
     DevBuf b_kw, b_off, b_sw, b_sc, b_len, b_start, b_tmp;
     auto release = [&]() { b_kw.release(); b_off.release(); b_sw.release(); b_sc.release(); b_len.release(); b_start.release(); b_tmp.release(); };

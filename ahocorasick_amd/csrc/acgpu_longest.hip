@@ -517,6 +517,13 @@ __global__ __launch_bounds__(kLScanBlock, 8) void k_longest_block(DevTables T, L
         for (int k = 0; k < 4; ++k) wb[k] = wa[k];
         load_own(st + 3, wa);
         const uint32_t s0 = sp0 + st * 512u, pb = s0 + lane * 8u;
+        // A chunk begins: its 16 block maxima are preset BEFORE any of its walks is queued -- a walk of this chunk can run to its
+        // end inside expand() / list_round() during this very step (64 lanes queued, the list at 64 or more: dense live walks),
+        // and a plain store at the END of the chunk would overwrite what its atomicMax had raised.  The store is issued ahead of
+        // every text load of those rounds, and a round consumes its load (s_waitcnt vmcnt(0): stores pending) before the atomic.
+        // A chunk that turns out to be flagged gets all 16 maxima from the general kernel, which runs behind this one.
+        if (!(st & 1u) && lane < kWlChunk / 64 && (uint64_t)s0 + lane * 64u < (uint64_t)L.own_end)
+            L.d_blockmax[((s0 - L.own_begin) >> 6) + lane] = s0 + lane * 64u + 63u + kBlockMaxSlack;
         // the codes of the units behind the lane's own: the next lanes' (the last lanes: the next step's first lanes')
         uint32_t E1 = dpp_wave_shl1(Ecur);
         E1 = lane == 63 ? (uint32_t)__builtin_amdgcn_readlane((int)Enext, 0) : E1;
@@ -567,9 +574,7 @@ __global__ __launch_bounds__(kLScanBlock, 8) void k_longest_block(DevTables T, L
         }
         if (st & 1u) { // the chunk is complete
             const uint32_t ck = c0 + (st >> 1);
-            const uint32_t cb = sp0 + (st >> 1) * kWlChunk;
             if (lane == 0) L.d_todo_w[ck] = chunk_bad ? 1 : 0;
-            if (!chunk_bad && lane < kWlChunk / 64) L.d_blockmax[((cb - L.own_begin) >> 6) + lane] = cb + lane * 64u + 63u + kBlockMaxSlack;
         }
         Ecur = Enext;
         Ocur = Onext;

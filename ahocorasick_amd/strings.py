@@ -19,6 +19,7 @@ stops at the first listener call that returns False -- which is observationally 
 iterable of chunks) with a value-only ReadableMatchListener, S/StringMap.java:6-8: match_readable over acgpu_stream_*.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -50,6 +51,13 @@ def _pack(keywords):
 
 def _vp(a):
     return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def configured_devices():
+    """The device list of match(String, ...): the environment variable ACGPU_DEVICES ("0,1,2,3"), this mirror's counterpart of
+    the Java facade's system property -Dacgpu.devices=....  None: the current device alone."""
+    v = os.environ.get("ACGPU_DEVICES", "").strip()
+    return [int(x) for x in v.split(",") if x.strip() != ""] if v else None
 
 
 class Automaton:
@@ -93,8 +101,9 @@ class Automaton:
         N.check(N.lib().acgpu_get_info(self._h, ctypes.byref(i)), "acgpu_get_info")
         return {f: getattr(i, f) for f, _ in N.Info._fields_}
 
-    def match_host(self, hay_units, with_ids, cap=None):
-        """acgpu_match_u16: haystack in host memory -> (n, 2|3) int32 array in reference call order."""
+    def match_host(self, hay_units, with_ids, cap=None, devices=None):
+        """acgpu_match_u16 -- or, with a device list (argument, or ACGPU_DEVICES), acgpu_match_u16_multi: haystack in host
+        memory -> (n, 2|3) int32 array in reference call order."""
         hay = np.ascontiguousarray(hay_units, dtype=np.uint16)
         n = int(hay.size)
         kind = N.REC_MAP if with_ids else N.REC_SET
@@ -102,14 +111,20 @@ class Automaton:
         if cap is None:
             cap = max(4096, n // 64)
         buf_in = hay if n else np.zeros(1, np.uint16)
+        if devices is None:
+            devices = configured_devices()
+        devs = (ctypes.c_int * len(devices))(*devices) if devices else None
         while True:
             out = np.empty((cap, cols), dtype=np.int32)
             n_out = ctypes.c_uint64(0)
-            rc = N.lib().acgpu_match_u16(self._h, _vp(buf_in), n, kind, _vp(out), cap, ctypes.byref(n_out))
+            if devs is not None:
+                rc = N.lib().acgpu_match_u16_multi(self._h, _vp(buf_in), n, devs, len(devices), kind, _vp(out), cap, ctypes.byref(n_out))
+            else:
+                rc = N.lib().acgpu_match_u16(self._h, _vp(buf_in), n, kind, _vp(out), cap, ctypes.byref(n_out))
             if rc == N.E_OVERFLOW:
                 cap = int(n_out.value)
                 continue
-            N.check(rc, "acgpu_match_u16")
+            N.check(rc, "acgpu_match_u16_multi" if devs is not None else "acgpu_match_u16")
             return out[:n_out.value]
 
     def match_batch(self, haystacks, with_ids, cap=None):
@@ -189,6 +204,59 @@ class Automaton:
     def match_device_abandon(self, ticket):
         """acgpu_match_device_abandon: give the ticket up (waits for its kernels, never redoes the call)."""
         return N.lib().acgpu_match_device_abandon(self._h, ticket.handle)
+
+
+class Comm:
+    """acgpu_comm: the devices of a single-process multi-GPU job, one stream per device, and the transport of the gather
+    (RCCL ncclCommInitAll / peer copies).  match_device_allgather: every device scans its shard into its slot of its gather
+    buffer, one all-gather leaves every device with every shard's records."""
+
+    def __init__(self, devices, transport=N.TRANSPORT_AUTO):
+        self.devices = list(devices)
+        arr = (ctypes.c_int * len(self.devices))(*self.devices)
+        h = ctypes.c_void_p()
+        N.check(N.lib().acgpu_comm_open(arr, len(self.devices), transport, ctypes.byref(h)), "acgpu_comm_open")
+        self._h = h
+
+    @property
+    def transport(self):
+        return N.lib().acgpu_comm_transport(self._h)
+
+    def stream(self, i):
+        return N.lib().acgpu_comm_stream(self._h, i) or 0
+
+    def match_device_allgather(self, automaton, shards, with_ids, gather_ptrs, gcap, profile=False):
+        """shards: list of dicts(d_hay, n_units, own=(b, e), text_begin, text_end[, chain_entry]) -- shard i on devices[i];
+        gather_ptrs: device pointers, buffer i on devices[i].  Returns (rc, counts list, chain exits list, profiles | None)."""
+        k = len(self.devices)
+        arr = (N.Shard * k)()
+        for i, sd in enumerate(shards):
+            sh = arr[i]
+            sh.d_hay = sd["d_hay"]
+            sh.n_units = sd["n_units"]
+            sh.own_begin, sh.own_end = sd.get("own", (0, sd["n_units"]))
+            sh.text_begin = 1 if sd.get("text_begin", i == 0) else 0
+            sh.text_end = 1 if sd.get("text_end", i == k - 1) else 0
+            sh.chain_entry = sd.get("chain_entry", sh.own_begin)
+            sh.chain_exit = -1
+            sh.d_result = None
+        ptrs = (ctypes.c_void_p * k)(*gather_ptrs)
+        counts = (ctypes.c_uint64 * k)()
+        profs = (N.Profile * k)() if profile else None
+        rc = N.lib().acgpu_match_device_allgather(automaton.handle, self._h, arr, N.REC_MAP if with_ids else N.REC_SET, ptrs, gcap,
+                                                  counts, profs)
+        pd = None
+        if profile:
+            pd = [dict(scan_ms=p.scan_ms, finalize_ms=p.finalize_ms, total_ms=p.total_ms, scan_units=p.scan_units,
+                       n_matches=p.n_matches, scan_kernel=p.scan_kernel.decode()) for p in profs]
+        return rc, [int(c) for c in counts], [int(arr[i].chain_exit) for i in range(k)], pd
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            N.lib().acgpu_comm_close(h)
+
+    __del__ = close
 
 
 class Ticket:

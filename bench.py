@@ -48,8 +48,16 @@ def main():
     ap.add_argument("--config", default=None, choices=["C2", "C3", "C4", "C5"],
                     help="BASELINE config (default: C2 at N=1, C3 at N>1 -- the configs the metric is quoted on; "
                          "C4 = LongestMatchSet, C5 = WholeWordMatchMap case-insensitive are the sibling matchers)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="ONE host process drives all N GPUs through the C ABI (acgpu_comm_open + acgpu_match_device_allgather: "
+                         "single-process RCCL ncclCommInitAll / peer copies) instead of one torch.distributed rank per GPU -- the "
+                         "shape a JVM calls (INTEGRATION.md)")
+    ap.add_argument("--devices", default=None, help="--single-process: comma-separated device list (default 0..N-1; a device may "
+                                                    "be named twice on a box with fewer GPUs: peer-copy transport)")
     args = ap.parse_args()
 
+    if args.single_process:
+        return main_single_process(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))  # plain `python bench.py --gpus N`: this process never touches the GPU
 
@@ -264,6 +272,151 @@ def main():
     if multi:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main_single_process(args):
+    """`--single-process`: the multi-GPU job of config 3 (or C2/C4/C5 with --config) behind the C ABI -- one process, one
+    acgpu_comm over the device list, every step one acgpu_match_device_allgather call: each device scans its resident shard
+    into its slot of its gather buffer, one all-gather (single-process RCCL, or peer copies) leaves every device with every
+    shard's records.  Same JSON line as the one-rank-per-GPU job."""
+    import torch
+
+    from ahocorasick_amd import _native as N
+    from ahocorasick_amd import synth
+    from ahocorasick_amd.strings import Automaton, Comm
+
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU matching path)"
+    devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(args.gpus))
+    assert len(devices) == args.gpus, "--devices must name --gpus devices"
+    k = len(devices)
+    cfg_name = args.config or ("C3" if k > 1 else "C2")
+    if cfg_name == "C5" and args.units_log2 == 29:
+        args.units_log2 = 28
+    n_units = 1 << args.units_log2
+    with_ids = cfg_name in ("C2", "C5")
+    rec_bytes = 12 if with_ids else 8
+    cols = rec_bytes // 4
+    cfg = synth.CONFIGS[cfg_name]
+    kws = synth.config_keywords(cfg_name)
+    t0 = time.time()
+    if cfg_name == "C4":
+        auto = Automaton(N.MODE_LONGEST, kws, True)
+    elif cfg_name == "C5":
+        from ahocorasick_amd.unicode_tables import default_word_chars
+        auto = Automaton(N.MODE_WHOLEWORD, kws, False, word_chars=default_word_chars())
+    else:
+        auto = Automaton(N.MODE_ALL, kws, True)
+    build_s = time.time() - t0
+    info = auto.info()
+    m = info["max_keyword_len"]
+    left, right = {"C4": (0, m - 1), "C5": (1, m + 1)}.get(cfg_name, (m - 1, 0))
+    pad = (left + 7) // 8 * 8
+    comm = Comm(devices, N.TRANSPORT_AUTO)
+    # shard g: [pad | 2^units_log2 own units (stream hay_seed + g) | right halo], resident on devices[g]
+    bufs, shards = [], []
+    for g, dev in enumerate(devices):
+        torch.cuda.set_device(dev)
+        first, last = g == 0, g == k - 1
+        buf = torch.zeros(pad + n_units + (0 if last else right), dtype=torch.int16, device="cuda:%d" % dev)
+        own = buf[pad:pad + n_units]
+        if cfg_name == "C5":
+            synth.token_stream_on_device(own.data_ptr(), n_units, cfg["hay_seed"] + g, kws, synth.swapcase_table(),
+                                         stream=torch.cuda.current_stream().cuda_stream)
+        else:
+            tab = np.ascontiguousarray(synth.ALPHA_AB_75 if cfg_name == "C4" else synth.ALPHA_LOWER)
+            N.check(N.lib().acgpu_synth_fill(own.data_ptr(), n_units, 0, cfg["hay_seed"] + g, tab.ctypes.data_as(ctypes.c_void_p), len(tab),
+                                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "synth_fill")
+        torch.cuda.synchronize(dev)
+        bufs.append(buf)
+    for g in range(k):  # halos, once per haystack: device-to-device copies
+        if g > 0 and left:
+            bufs[g][pad - left:pad].copy_(bufs[g - 1][pad + n_units - left:pad + n_units])
+        if g + 1 < k and right:
+            bufs[g][pad + n_units:].copy_(bufs[g + 1][pad:pad + right])
+    for g, dev in enumerate(devices):
+        torch.cuda.synchronize(dev)
+        v0 = pad if g == 0 else 0  # (the pad in front of the first shard is not text)
+        shards.append(dict(d_hay=bufs[g].data_ptr() + 2 * v0, n_units=bufs[g].numel() - v0, own=(pad - v0, pad - v0 + n_units),
+                           text_begin=g == 0, text_end=g == k - 1))
+    gcap = {"C4": n_units // 2, "C5": n_units // 8}.get(cfg_name, max(1 << 16, n_units // 128))
+    gbufs = None
+
+    def alloc():
+        slot = N.gather_slot_bytes(gcap, rec_bytes)
+        return [torch.zeros(k * slot // 4, dtype=torch.int32, device="cuda:%d" % d) for d in devices]
+
+    def step(profile=False):
+        nonlocal gcap, gbufs
+        while True:
+            if gbufs is None:
+                gbufs = alloc()
+                for d in devices:
+                    torch.cuda.synchronize(d)
+            rc, counts, _, prof = comm.match_device_allgather(auto, shards, with_ids, [g.data_ptr() for g in gbufs], gcap, profile=profile)
+            if rc == N.E_OVERFLOW:
+                gcap, gbufs = int(max(counts) * 1.0625) + 1024, None
+                continue
+            N.check(rc, "acgpu_match_device_allgather")
+            return counts, prof
+
+    counts, _ = step()
+    if max(counts) * 1.0625 + 1024 < 0.8 * gcap:  # the gather moves gcap records per device: follow the counts
+        gcap, gbufs = int(max(counts) * 1.0625) + 1024, None
+    for _ in range(args.warmup):
+        step()
+    t0 = time.perf_counter()
+    profs = []
+    for _ in range(args.steps):
+        counts, prof = step(profile=True)
+        profs.append(prof)
+    for d in devices:
+        torch.cuda.synchronize(d)
+    elapsed = time.perf_counter() - t0
+    ms_per_step = elapsed / args.steps * 1e3
+    per_dev = []
+    for g in range(k):
+        sc = float(np.mean([p[g]["scan_ms"] for p in profs]))
+        fin = float(np.mean([p[g]["finalize_ms"] for p in profs]))
+        kms = sc + fin if cfg_name == "C4" else sc
+        ab = 2 * n_units + rec_bytes * counts[g]
+        per_dev.append({"share": g, "device": devices[g], "kernel": profs[-1][g]["scan_kernel"], "kernel_ms": round(kms, 4),
+                        "scan_ms": round(sc, 4), "finalize_ms": round(fin, 4), "algorithmic_bytes": ab,
+                        "achieved": round(ab / (kms * 1e-3) / 1e9, 2), "frac": round(ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+                        "matches": counts[g]})
+    out = {
+        "metric": "haystack MB/s (UTF-16 bytes scanned per second, records delivered in reference order)",
+        "value": round(n_units * k * 2 / (elapsed / args.steps) / 1e6, 1), "unit": "MB/s", "n_gpus": k, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u16", "data": "synthetic", "matches_per_s": round(sum(counts) / (elapsed / args.steps), 1),
+        "config": {
+            "workload": "BASELINE config %s through ONE host process: %d x 2^%d UTF-16 units, acgpu_match_device_allgather" % (cfg_name[1], k, args.units_log2),
+            "keywords": len(kws), "states": info["n_states"], "classes": info["n_classes"], "units_per_gpu": n_units,
+            "matches_per_gpu": counts[0], "matches_total": sum(counts), "record_bytes": rec_bytes, "build_s": round(build_s, 3),
+            "parallelism": "single-process shard%d+halo(%d,%d)+allgather/%s" % (k, left, right, "rccl" if comm.transport == N.TRANSPORT_RCCL else "peer-copies"),
+            "devices": devices, "gather_records_per_device": gcap,
+        },
+        "roofline": dict(per_dev[0], bound="hbm", peak=HBM_PEAK_GBPS, unit="GB/s", traffic=None, per_device=per_dev),
+    }
+    if not args.no_cpu_baseline:  # share 0's slot of the LAST device's gather buffer against the oracle on a prefix of share 0
+        sample = min(n_units, 1 << min(args.cpu_sample_log2, 24))
+        o = _oracle(cfg_name, kws)
+        hay = bufs[0][pad:pad + sample].cpu().numpy().view(np.uint16)
+        want = o.match(hay, cap=max(1 << 16, sample // (2 if cfg_name == "C4" else 8)))[:, :cols]
+        slot_words = N.gather_slot_bytes(gcap, rec_bytes) // 4
+        recs = gbufs[-1][4:4 + counts[0] * cols].cpu().numpy().reshape(-1, cols)
+        if cfg_name in ("C2", "C3"):
+            got = recs[recs[:, 1] <= sample]
+        else:
+            want = want[want[:, 1] < sample - m - 1]
+            got = recs[recs[:, 1] < sample - m - 1]
+        hdr = [int(gbufs[-1][j * slot_words:j * slot_words + 2].cpu().numpy().view(np.int64)[0]) for j in range(k)]
+        out["verified"] = bool(got.shape == want.shape and (got == want).all() and len(want) > 0 and hdr == counts)
+        out["verified_what"] = ("share 0's records as gathered on the last device == oracle records on the first 2^%d units (%d "
+                                "records), and every gathered header holds its share's count" % (int(np.log2(sample)), len(want)))
+        assert out["verified"], "bench.py --single-process: the gathered records differ from the oracle"
+    comm.close()
+    print(json.dumps(out))
+    return 0
 
 
 def launch_ranks(n):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ACGPU_ABI_VERSION 3
+#define ACGPU_ABI_VERSION 4
 
 /* error codes */
 #define ACGPU_OK 0
@@ -239,6 +239,7 @@ int acgpu_match_device(const acgpu_automaton *a, acgpu_shard *shard, int record_
  * (an event, not the stream) and returns its count / timings.  Up to 4 calls may be in flight per automaton and device.
  * Lets a host keep the GPU busy across calls: the next scan is queued while the previous count travels back.
  * want_profile != 0 records the HIP events that _end turns into acgpu_profile.
+ * The acgpu_shard passed to _begin must stay alive until _end (or _abandon) has returned: _end writes chain_exit into it.
  *  - Enqueued without any host round trip: ACGPU_MODE_ALL, ACGPU_MODE_WHOLEWORD (fold-consistent tables) and
  *    ACGPU_MODE_LONGEST through its walk pipeline (shard->chain_entry is read at _begin; chain_exit is written to the
  *    SAME acgpu_shard object when _end returns, so it must outlive the ticket).
@@ -259,6 +260,70 @@ int acgpu_match_device_end(const acgpu_automaton *a, acgpu_ticket *ticket, uint6
  * then), never redoes the call.  For a driver that already knows -- from the device result it gathered -- that the step has
  * to be done again with larger buffers. */
 int acgpu_match_device_abandon(const acgpu_automaton *a, acgpu_ticket *ticket);
+
+/*
+ * ---- several devices, ONE host process -------------------------------------------------------------------------------------
+ * BASELINE north_star: "long haystacks shard naturally across the 8 GPUs of one node with an RCCL all-gather over xGMI of
+ * per-shard match buffers plus a (longest-pattern - 1) halo".  The reference's call is one call in one process
+ * (S/StringSet.java:3-5, S/StringMap.java:5-9: match(String haystack, listener)); so is this one.
+ *
+ * acgpu_match_u16_multi: acgpu_match_u16 with the haystack cut into n_devices contiguous shares, share i on HIP device
+ * devices[i] -- each with its own pinned staging ring, copy stream, scan stream and copy of the automaton's tables, each fed
+ * and scanned by its own host thread, all at once.  A share carries the halo its family needs (ALL / SHORTEST: max_len-1
+ * units on the left; WHOLEWORD / WWLONGEST: 1 unit on the left, max_len+1 on the right; LONGEST: max_len-1 on the right).
+ * The chain families (LONGEST, SHORTEST, WWLONGEST) scan every share speculatively and repair the head of a share whose
+ * true entry -- the previous share's exit -- differs (two short window scans, as a rule).  Records arrive in `out` in the
+ * reference's listener-call order for the WHOLE haystack with global positions: exactly what acgpu_match_u16 returns.
+ *  devices   : n_devices HIP device ordinals.  A device may be named more than once (further shares on the same device get
+ *              their own scratch pool and stream): how a one-GPU box tests the split.
+ *  Haystacks too short to cut (under 1024 units per share) and the loops that only exist as one sequential scan (word
+ *  matchers over a table that is not fold-consistent) run on devices[0] alone.
+ * The calling thread's current device is restored.  Errors and ACGPU_E_OVERFLOW as acgpu_match_u16.
+ */
+int acgpu_match_u16_multi(const acgpu_automaton *a, const uint16_t *haystack, uint64_t n_units, const int *devices, int n_devices,
+                          int record_kind, void *out, uint64_t cap, uint64_t *n_out);
+
+/*
+ * Device-resident form with the gather the north_star names: every device scans ITS shard (already in its memory, halos in
+ * place: acgpu_shard as for acgpu_match_device) into its own slot of a gather buffer, and one all-gather leaves every
+ * device with every shard's records -- config 3 of BASELINE.json.
+ *
+ * acgpu_comm: the devices of a job, one stream per device, and the transport of the gather:
+ *   ACGPU_TRANSPORT_RCCL : single-process RCCL (ncclCommInitAll over the device list, one ncclAllGather per device inside
+ *                          ncclGroupStart/End, in place).  librccl.so.1 is bound at run time (dlopen): libacgpu.so does not
+ *                          link it, and ACGPU_E_UNSUPPORTED is returned where it is missing.  Needs distinct devices.
+ *   ACGPU_TRANSPORT_PEER : hipMemcpyPeerAsync of every slot to every other device over the direct xGMI links (also what a
+ *                          device list that names a device twice gets).
+ *   ACGPU_TRANSPORT_AUTO : RCCL when the devices are distinct and the library loads, else peer copies.
+ *
+ * Gather buffer of device i: n_devices slots of acgpu_gather_slot_bytes(gcap, record_kind) bytes; slot j =
+ * [acgpu_device_result (16 bytes) | gcap records] of shard j, positions relative to shard j's buffer.  d_gather[i] is a
+ * device pointer on devices[i], 16-byte aligned.
+ *  shards  : n_devices shards, shard i resident on devices[i].  Chain families: shards[0].chain_entry is the chain's entry
+ *            into the whole text; every shards[i].chain_exit is set to the true scan's exit from shard i.
+ *  counts  : receives the n_devices record counts (also in the gathered headers).
+ *  profs   : NULL, or n_devices acgpu_profile (HIP-event timings of each device's scan).
+ * Returns ACGPU_E_OVERFLOW when some count exceeds gcap: counts[] are exact, the buffers hold nothing useful, nothing was
+ * gathered; call again with gcap >= the largest count.
+ * AhoCorasick and WholeWord (fold-consistent tables) are enqueued on every device without a host round trip (scan, header
+ * and gather in stream order; one host wait at the end); the other families run their shards on one host thread per
+ * device, then the repairs, then the gather.
+ */
+#define ACGPU_TRANSPORT_AUTO 0
+#define ACGPU_TRANSPORT_RCCL 1
+#define ACGPU_TRANSPORT_PEER 2
+typedef struct acgpu_comm acgpu_comm;
+int acgpu_comm_open(const int *devices, int n_devices, int transport, acgpu_comm **out);
+void acgpu_comm_close(acgpu_comm *c);
+int acgpu_comm_transport(const acgpu_comm *c);       /* the transport in use: ACGPU_TRANSPORT_RCCL or _PEER              */
+void *acgpu_comm_stream(const acgpu_comm *c, int i); /* hipStream_t of device i: work a caller enqueues there (filling the
+                                                        shard, reading the gathered records) is ordered with the call's   */
+static inline uint64_t acgpu_gather_slot_bytes(uint64_t gcap, int record_kind) {
+    return (16 + gcap * (uint64_t)record_kind + 15) & ~(uint64_t)15;
+}
+int acgpu_match_device_allgather(const acgpu_automaton *a, acgpu_comm *c, acgpu_shard *shards, int record_kind,
+                                 void *const *d_gather, uint64_t gcap, uint64_t *counts, acgpu_profile *profs);
+int acgpu_last_rccl_error(void); /* ncclResult_t of the last RCCL failure on this thread */
 
 /*
  * Replaces StringMap.match(Readable, ReadableMatchListener<T>) (S/StringMap.java:6; S/AhoCorasickMap.java:208-275,

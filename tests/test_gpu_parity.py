@@ -346,6 +346,37 @@ def test_longest_prefix_closed_dictionary_like_config_c4():
     assert (got2 == want2).all()
 
 
+@pytest.mark.parametrize("seed", [1, 2])
+def test_longest_block_maxima_of_walks_that_finish_before_their_chunk_does(seed):
+    """k_longest_block over text that keeps its work list full (long runs of 'a' under a^1..a^100: every walk is still alive
+    behind the root table), so that walks run to their end while their 1024-position chunk is still being streamed -- the
+    chunk's block maxima must already be preset then, or the maximum a long match has raised is overwritten and
+    k_longest_sync skips the block.  Planted copies of a 100-unit word W whose inner positions only match single units
+    make such a miss visible: the real chain jumps over W, a synchronisation point inside it reports its units one by one."""
+    rng = np.random.default_rng(4200 + seed)
+    a, b = ord("a"), ord("b")
+    W = np.array([b, a, b, b] + [a if x else b for x in rng.integers(0, 2, 96).tolist()], dtype=np.uint16)
+    kws = [np.full(k, a, np.uint16) for k in range(1, 101)] + [utf16("ab"), utf16("b")] + [W[:k] for k in (2, 3, 4, 100)]
+    parts, n = [], 0
+    while n < 600000:
+        r = int(rng.integers(0, 10))
+        if r < 3:
+            parts.append(W)
+        elif r < 8:  # runs of 'a' that outlive the root table's 14 units
+            parts.append(np.concatenate([np.full(int(rng.integers(15, 130)), a, np.uint16), np.array([b], np.uint16)]))
+        else:
+            parts.append(np.where(rng.integers(0, 4, int(rng.integers(1, 40))) > 0, a, b).astype(np.uint16))
+        n += len(parts[-1])
+    hay = np.concatenate(parts)
+    want = Oracle(FAM_LONGEST, kws).match(hay)
+    m = LongestMatchSet(kws, True)
+    for region in (0, 1024, 4096):  # chain tiles: the default and two fixed sizes (synchronisation points fall elsewhere)
+        N.set_tunable("region_units", region)
+        got = m.find_all(hay)
+        assert got.shape == want[:, :2].shape and (got == want[:, :2]).all(), region
+    assert int((want[:, 1] - want[:, 0]).max()) == 100
+
+
 @pytest.mark.parametrize("letters,others", [("ab", ""), ("ab", " ,"), ("a", "b"), ("acgt", ""), ("acgt", "n"), ("abc", "xyz")])
 def test_longest_walk_root_table_bit_fields_and_units_outside_the_alphabet(letters, others):
     """k_longest_walk_list's first round (Set records): the bit-field root table -- one bit per unit for alphabets of up to two
@@ -490,6 +521,11 @@ def test_wholeword_mixed_script_like_config_c5():
     for region in (2048, 0):
         N.set_tunable("region_units", region)
         assert (WholeWordMatchSet(words, False).find_all(hay) == want[:, :2]).all()
+    # a device that cannot spare the region-local record slots (6 bytes per unit): the scratch slices + k_permute, not an error
+    for bits in (1 << 40, 134217728):  # the allocation "fails" / the slices on request
+        N.set_tunable("tile_debug", bits)
+        got2 = WholeWordMatchMap(words, _ids(len(words)), False).find_all(hay)
+        assert got2.shape == want.shape and (got2 == want).all(), bits
 
 
 @pytest.mark.parametrize("seed", range(8))
@@ -615,6 +651,12 @@ def test_token_stream_generator_matches_numpy_twin():
     d = torch.empty(50000, dtype=torch.int16, device="cuda")
     synth.token_stream_on_device(d.data_ptr(), 50000, 11, long_words, sw)
     assert (d.cpu().numpy().view(np.uint16) == synth.token_stream_haystack(11, 50000, long_words, sw)).all()
+    # words of ONE unit make 2-unit tokens: the device must size its token count from the shortest token, not from 3 units
+    short_words = [np.array([0x61], np.uint16), np.array([0x4E00], np.uint16), np.array([0x62, 0x63], np.uint16)]
+    d = torch.empty(30000, dtype=torch.int16, device="cuda")
+    d.fill_(-1)
+    synth.token_stream_on_device(d.data_ptr(), 30000, 12, short_words, sw)
+    assert (d.cpu().numpy().view(np.uint16) == synth.token_stream_haystack(12, 30000, short_words, sw)).all()
 
 
 def test_config_c5_full_size_every_record():
