@@ -59,7 +59,7 @@ SYMBOLS = ["acgpu_build", "acgpu_free", "acgpu_get_info", "acgpu_match_u16", "ac
            "acgpu_set_tunable", "acgpu_strerror", "acgpu_last_hip_error", "acgpu_abi_version", "acgpu_debug_tables",
            "acgpu_debug_wordhash", "acgpu_stream_open", "acgpu_stream_feed", "acgpu_stream_close",
            "acgpu_match_u16_multi", "acgpu_comm_open", "acgpu_comm_close", "acgpu_comm_transport", "acgpu_comm_stream",
-           "acgpu_match_device_allgather", "acgpu_last_rccl_error"]
+           "acgpu_match_device_allgather", "acgpu_last_rccl_error", "acgpu_gather_slot_bytes"]
 
 _lib = None
 
@@ -136,6 +136,8 @@ def lib():
         L.acgpu_match_device_allgather.argtypes = [vp, vp, ctypes.POINTER(Shard), ci, ctypes.POINTER(vp), u64, ctypes.POINTER(u64),
                                                    ctypes.POINTER(Profile)]
         L.acgpu_last_rccl_error.restype = ci
+        L.acgpu_gather_slot_bytes.restype = u64
+        L.acgpu_gather_slot_bytes.argtypes = [u64, ci]
         if L.acgpu_abi_version() != ABI_VERSION:
             raise ImportError("ahocorasick_amd: %s has ABI version %d, this package binds version %d -- rebuild it"
                               % (LIB_PATH, L.acgpu_abi_version(), ABI_VERSION))

@@ -356,6 +356,8 @@ extern "C" {
 
 int acgpu_last_rccl_error(void) { return g_last_rccl_error; }
 
+uint64_t acgpu_gather_slot_bytes(uint64_t gcap, int record_kind) { return (16 + gcap * (uint64_t)record_kind + 15) & ~(uint64_t)15; }
+
 int acgpu_match_u16_multi(const acgpu_automaton *ca, const uint16_t *haystack, uint64_t n_units, const int *devices, int n_devices,
                           int record_kind, void *out, uint64_t cap, uint64_t *n_out) {
     if (!ca || !n_out || (n_units && !haystack) || (cap && !out)) return ACGPU_E_INVALID;

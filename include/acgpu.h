@@ -297,12 +297,12 @@ int acgpu_match_u16_multi(const acgpu_automaton *a, const uint16_t *haystack, ui
  *   ACGPU_TRANSPORT_AUTO : RCCL when the devices are distinct and the library loads, else peer copies.
  *
  * Gather buffer of device i: n_devices slots of acgpu_gather_slot_bytes(gcap, record_kind) bytes; slot j =
- * [acgpu_device_result (16 bytes) | gcap records] of shard j, positions relative to shard j's buffer.  d_gather[i] is a
+ * [the 16 bytes of an acgpu_device_result | gcap records] of shard j, positions relative to shard j's buffer.  d_gather[i] is a
  * device pointer on devices[i], 16-byte aligned.
  *  shards  : n_devices shards, shard i resident on devices[i].  Chain families: shards[0].chain_entry is the chain's entry
  *            into the whole text; every shards[i].chain_exit is set to the true scan's exit from shard i.
  *  counts  : receives the n_devices record counts (also in the gathered headers).
- *  profs   : NULL, or n_devices acgpu_profile (HIP-event timings of each device's scan).
+ *  profs   : NULL, or n_devices acgpu_profile structs: HIP-event timings of each device's scan.
  * Returns ACGPU_E_OVERFLOW when some count exceeds gcap: counts[] are exact, the buffers hold nothing useful, nothing was
  * gathered; call again with gcap >= the largest count.
  * AhoCorasick and WholeWord (fold-consistent tables) are enqueued on every device without a host round trip (scan, header
@@ -318,9 +318,7 @@ void acgpu_comm_close(acgpu_comm *c);
 int acgpu_comm_transport(const acgpu_comm *c);       /* the transport in use: ACGPU_TRANSPORT_RCCL or _PEER              */
 void *acgpu_comm_stream(const acgpu_comm *c, int i); /* hipStream_t of device i: work a caller enqueues there (filling the
                                                         shard, reading the gathered records) is ordered with the call's   */
-static inline uint64_t acgpu_gather_slot_bytes(uint64_t gcap, int record_kind) {
-    return (16 + gcap * (uint64_t)record_kind + 15) & ~(uint64_t)15;
-}
+uint64_t acgpu_gather_slot_bytes(uint64_t gcap, int record_kind); /* (16 + gcap * record_kind), rounded up to 16 */
 int acgpu_match_device_allgather(const acgpu_automaton *a, acgpu_comm *c, acgpu_shard *shards, int record_kind,
                                  void *const *d_gather, uint64_t gcap, uint64_t *counts, acgpu_profile *profs);
 int acgpu_last_rccl_error(void); /* ncclResult_t of the last RCCL failure on this thread */
