@@ -66,7 +66,7 @@ int ensure_device(acgpu_automaton *a, DeviceState **out, int lane) {
     if (lane > 0) HIP_TRY(hipStreamCreateWithFlags(&d->call_stream, hipStreamNonBlocking));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, dev));
-    d->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    d->n_cu = d->n_cu_phys = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const HostTables &t = a->t;
     DevTables &T = d->T;
     int rc;
@@ -1110,6 +1110,15 @@ int match_wwlongest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int rec
 
 namespace acgpu {
 
+// what the tunables decide per call: the LDS residency of the DFA rows, and the CUs the scan kernels size their grids for --
+// "reserve_cus" leaves that many CUs without a scan workgroup (the scans hold a whole CU's LDS per workgroup, so a grid of
+// n_cu - k workgroups keeps k CUs free: room for the workgroups of a collective that runs under the scan)
+void refresh_call_state(acgpu_automaton *a, DeviceState &d) {
+    d.T.lds_entries = lds_states_for(a->t) * a->t.n_cls;
+    const int64_t k = std::max<int64_t>(0, tunables().reserve_cus);
+    d.n_cu = (int)std::max<int64_t>(8, (int64_t)d.n_cu_phys - k);
+}
+
 int device_for_call(acgpu_automaton *a, DeviceState **d, int lane) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
@@ -1125,7 +1134,7 @@ int device_for_call(acgpu_automaton *a, DeviceState **d, int lane) {
 // lookup where their String loops mix folded and raw ones, which only matters for tables that are not fold-consistent.
 int match_shard(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_kind, void *d_out, uint64_t cap,
                 uint64_t *n_out, hipStream_t stream, acgpu_profile *prof, bool readable) {
-    d.T.lds_entries = lds_states_for(a->t) * a->t.n_cls; // (the LDS residency tunable may have changed between calls)
+    refresh_call_state(a, d);
     if (record_kind != ACGPU_REC_SET && record_kind != ACGPU_REC_MAP) return ACGPU_E_INVALID;
     if (sh->n_units >= (1ull << 31)) return ACGPU_E_INVALID;
     if (sh->own_begin > sh->own_end || sh->own_end > sh->n_units) return ACGPU_E_INVALID;
@@ -1180,6 +1189,7 @@ int begin_shard(acgpu_automaton *a, DeviceState &dd, acgpu_shard *sh, int record
     *ticket = nullptr;
     const HostTables &t = a->t;
     DeviceState *d = &dd;
+    refresh_call_state(a, dd);
     int rc;
     if (record_kind != ACGPU_REC_SET && record_kind != ACGPU_REC_MAP) return ACGPU_E_INVALID;
     if (sh->n_units >= (1ull << 31) || sh->own_begin > sh->own_end || sh->own_end > sh->n_units) return ACGPU_E_INVALID;
@@ -1272,6 +1282,7 @@ int64_t acgpu_set_tunable(const char *name, int64_t value) {
     else if (!std::strcmp(name, "filter_max_bytes")) slot = &t.filter_max_bytes;
     else if (!std::strcmp(name, "no_merged_ranges")) slot = &t.no_merged_ranges;
     else if (!std::strcmp(name, "no_short_keywords")) slot = &t.no_short_keywords;
+    else if (!std::strcmp(name, "reserve_cus")) slot = &t.reserve_cus;
     if (!slot) return -1;
     return slot->exchange(value, std::memory_order_relaxed);
 }

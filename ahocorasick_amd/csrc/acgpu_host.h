@@ -75,7 +75,8 @@ struct DeviceState {
     int device = -1;
     int lane = 0;    // 0: what the single-device entries use; > 0: further shards of a multi-device call on the SAME device
     hipStream_t call_stream = nullptr; // the stream the host-haystack entries work on: the NULL stream for lane 0, its own otherwise
-    int n_cu = 256;
+    int n_cu = 256;      // CUs the scan kernels size their grids for: n_cu_phys minus the tunable reserve_cus
+    int n_cu_phys = 256; // multiProcessorCount of the device
     DevTables T{};
     const uint8_t *wflags_f = nullptr; // word-character tables of the loops that fold in every lookup (HostTables::wflags_f)
     const uint32_t *wbits_f = nullptr;

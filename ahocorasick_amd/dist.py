@@ -175,10 +175,14 @@ class ShardedMatcher:
     to the view, chain_exit)."""
 
     def __init__(self, automaton, n_units, with_ids=True, cap=1 << 20, device=None, group=None, scan_fn=None, halo=None,
-                 overlap=False, mode=None, right_halo=None, adaptive=True):
+                 overlap=False, mode=None, right_halo=None, adaptive=True, force_collectives=False):
         self.auto = automaton
         self.group = group
         self.rank, self.world = _world(group)
+        # a world of ONE normally bypasses every collective; force_collectives keeps them (the gather buffers, the all-gather
+        # left in flight under the next scan, the header read-back, the chain families' gathers of exits) -- how a one-GPU box
+        # drives the whole multi-rank step over a real RCCL communicator
+        self.collective = self.world > 1 or bool(force_collectives)
         self.with_ids = with_ids
         self.cols = 3 if with_ids else 2
         self.mode = automaton.mode if automaton is not None else (MODE_ALL if mode is None else mode)
@@ -205,7 +209,7 @@ class ShardedMatcher:
         # does LongestMatch where the chain entry is known when the scan is enqueued (one rank: it is the first unit)
         self.async_scan = scan_fn is None and (self.mode == MODE_ALL or (
             self.mode == MODE_WHOLEWORD and bool(automaton.info()["fold_consistent"])) or (
-            self.mode == MODE_LONGEST and self.world == 1))
+            self.mode == MODE_LONGEST and not self.collective))
         self.scan_fn = scan_fn
         self._k = 0
         self._inflight = None   # the _Step a previous step() left for the next one (overlap)
@@ -257,7 +261,7 @@ class ShardedMatcher:
         if st.gbuf is None or st.gcap != self.cap:
             st.gcap = self.cap
             st.gbuf = torch.zeros(HDR + self.cap * self.cols, dtype=torch.int32, device=self.device)
-            if self.world > 1:
+            if self.collective:
                 st.gathered = torch.empty((self.world, HDR + self.cap * self.cols), dtype=torch.int32, device=self.device)
                 st.hdr_host = torch.empty((self.world, HDR), dtype=torch.int32, pin_memory=self.device.type == "cuda")
             if self.device.type == "cuda":
@@ -380,7 +384,7 @@ class ShardedMatcher:
         rank's exit to and from the number that travels."""
         n, ex, prof = spec(profile)
         self.chain_repairs = 0
-        if self.world == 1:
+        if not self.collective:
             return n, prof
         applied = None   # the entry my current records assume (None: the speculation)
         prev = None
@@ -523,7 +527,7 @@ class ShardedMatcher:
             st.ticket = tk
         else:
             st.n, st.prof = self._scan(profile, st)
-        if self.world > 1:
+        if self.collective:
             if self.device.type == "cuda" and not _host_staged(st.gbuf, self.group):
                 st.work = allgather_flat(st.gathered.view(-1), st.gbuf, self.group, async_op=True)
                 with torch.cuda.stream(self._side):
@@ -541,33 +545,33 @@ class ShardedMatcher:
         the gather buffers on some rank -- every rank sees that in the gathered headers -- is redone by all ranks."""
         from . import _native as N
         n, prof = st.n, st.prof
-        if self.world > 1 and st.work is not None:
+        if self.collective and st.work is not None:
             st.event.synchronize()
             self.host_syncs += 1
-        if self.world > 1:
+        if self.collective:
             hdr = st.hdr_host.numpy()
             counts = (hdr[:, 0].astype(np.int64) & 0xffffffff) | (hdr[:, 1].astype(np.int64) << 32)
             bad = bool((counts > st.gcap).any() or (hdr[:, 2] != 0).any())
         if st.ticket is not None:
             tk, st.ticket = st.ticket, None
-            if self.world > 1 and bad:
+            if self.collective and bad:
                 # every rank redoes this step anyway (_redo): the ticket is given up, not collected -- collecting it would
                 # make the ranks whose own scan has to be redone scan twice, and leave the others waiting for them
                 N.check(self.auto.match_device_abandon(tk), "acgpu_match_device_abandon")
             else:
                 n, rc, prof = self.auto.match_device_end(tk, profile=st.prof_on)  # (world > 1: its event has long passed)
-                if self.world == 1:
+                if not self.collective:
                     self.host_syncs += 1
                 if rc != N.E_OVERFLOW:
                     N.check(rc, "acgpu_match_device_end")
-        if self.world == 1:
+        if not self.collective:
             counts = np.array([n], dtype=np.int64)
             bad = n > st.gcap
         if bad:
             return self._redo(st, int(counts.max()), counts)
         if prof:
             self.last_kernel = prof["scan_kernel"]
-        if self.world > 1:
+        if self.collective:
             self.gathered = st.gathered[:, HDR:].view(self.world, st.gcap, self.cols)
         else:
             self.gathered = self._records(st)[:n].unsqueeze(0)
@@ -604,7 +608,7 @@ class ShardedMatcher:
                 st2.n, _, st2.prof = self._call("out", 0, self.sb.n_units, 0, prof_on, d_result=st2.gbuf.data_ptr())
             else:
                 st2.n, st2.prof = self._scan(prof_on, st2)
-            if self.world > 1:
+            if self.collective:
                 if self.device.type == "cuda":
                     torch.cuda.current_stream().synchronize()
                 allgather_flat(st2.gathered.view(-1), st2.gbuf, self.group)

@@ -11,6 +11,20 @@ final class NativeAutomaton implements AutoCloseable {
         System.loadLibrary("acgpu_jni");
     }
 
+    /**
+     * The devices a match(String, ...) call is spread over: system property {@code acgpu.devices}, a comma-separated list of HIP
+     * device ordinals ("0,1,2,3,4,5,6,7" on an 8-GPU node); unset = the current device alone. Read once per JVM.
+     */
+    private static final int[] DEVICES = parseDevices(System.getProperty("acgpu.devices"));
+
+    static int[] parseDevices(String prop) {
+        if (prop == null || prop.trim().isEmpty()) return null;
+        String[] parts = prop.split(",");
+        int[] d = new int[parts.length];
+        for (int i = 0; i < parts.length; i++) d[i] = Integer.parseInt(parts[i].trim());
+        return d;
+    }
+
     private long handle;
 
     NativeAutomaton(int mode, String[] keywords, boolean caseSensitive, boolean[] wordChars) {
@@ -25,7 +39,7 @@ final class NativeAutomaton implements AutoCloseable {
 
     /** (start,end) pairs or (start,end,keywordIndex) triples, flattened, in the reference's listener-call order. */
     int[] match(String haystack, boolean withIds) {
-        return match(handle, haystack, withIds);
+        return match(handle, haystack, withIds, DEVICES);
     }
 
     /**
@@ -62,7 +76,8 @@ final class NativeAutomaton implements AutoCloseable {
     /** throws IllegalArgumentException("<keyword> contains non-word characters.") on ACGPU_E_NONWORD */
     private static native long build(int mode, String[] keywords, boolean caseSensitive, char[] lower, boolean[] wordChars);
 
-    private static native int[] match(long handle, String haystack, boolean withIds);
+    /** devices == null: acgpu_match_u16 on the current device; else acgpu_match_u16_multi over the list (one call, one process) */
+    private static native int[] match(long handle, String haystack, boolean withIds, int[] devices);
 
     private static native int[] matchBatch(long handle, String[] haystacks, boolean withIds);
 

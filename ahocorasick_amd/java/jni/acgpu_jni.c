@@ -130,9 +130,21 @@ static jintArray to_int_array(JNIEnv *env, const void *buf, uint64_t n_ints) {
     return out; /* NULL: OutOfMemoryError pending */
 }
 
+/* devices: null = the current HIP device alone (acgpu_match_u16); else the device list of -Dacgpu.devices -- the haystack is
+ * cut into one contiguous share per entry and all of them are scanned at once (acgpu_match_u16_multi, ONE call, one process:
+ * the shape of S/StringSet.java:3-5). */
 JNIEXPORT jintArray JNICALL Java_com_roklenarcic_util_strings_gpu_NativeAutomaton_match(JNIEnv *env, jclass cls, jlong handle,
-                                                                                          jstring haystack, jboolean withIds) {
+                                                                                          jstring haystack, jboolean withIds,
+                                                                                          jintArray devices) {
     (void)cls;
+    jint devs[64];
+    jsize n_devs = 0;
+    if (devices) {
+        n_devs = (*env)->GetArrayLength(env, devices);
+        if (n_devs < 1 || n_devs > 64) { throw_new(env, "java/lang/IllegalArgumentException", "acgpu.devices: 1..64 device ordinals"); return NULL; }
+        (*env)->GetIntArrayRegion(env, devices, 0, n_devs, devs);
+        if ((*env)->ExceptionCheck(env)) return NULL;
+    }
     if (!haystack) {
         throw_new(env, "java/lang/NullPointerException", "haystack"); /* reference: haystack.length() on null */
         return NULL;
@@ -152,13 +164,15 @@ JNIEXPORT jintArray JNICALL Java_com_roklenarcic_util_strings_gpu_NativeAutomato
     void *buf = malloc(cap * (size_t)kind);
     jintArray out = NULL;
     if (!buf) { throw_oom(env, "match records"); free(units); return NULL; }
-    int rc = acgpu_match_u16(a, (const uint16_t *)units, (uint64_t)n, kind, buf, cap, &n_out);
+    int rc = n_devs ? acgpu_match_u16_multi(a, (const uint16_t *)units, (uint64_t)n, (const int *)devs, (int)n_devs, kind, buf, cap, &n_out)
+                    : acgpu_match_u16(a, (const uint16_t *)units, (uint64_t)n, kind, buf, cap, &n_out);
     if (rc == ACGPU_E_OVERFLOW) { /* retry once with the exact capacity */
         cap = n_out;
         void *bigger = realloc(buf, cap * (size_t)kind);
         if (!bigger) { throw_oom(env, "match records"); free(buf); free(units); return NULL; }
         buf = bigger;
-        rc = acgpu_match_u16(a, (const uint16_t *)units, (uint64_t)n, kind, buf, cap, &n_out);
+        rc = n_devs ? acgpu_match_u16_multi(a, (const uint16_t *)units, (uint64_t)n, (const int *)devs, (int)n_devs, kind, buf, cap, &n_out)
+                    : acgpu_match_u16(a, (const uint16_t *)units, (uint64_t)n, kind, buf, cap, &n_out);
     }
     free(units);
     if (rc == ACGPU_OK) out = to_int_array(env, buf, n_out * (uint64_t)(kind / 4));

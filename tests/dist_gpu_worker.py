@@ -5,8 +5,9 @@ collectives through host memory; everything else -- ShardedMatcher, acgpu_match_
 (owned range, halos, chain entry/exit), the gather-buffer header written by the scan's last kernel -- is the code an
 N-GPU job runs.  Test infrastructure: compares with the CPU oracle on the whole text.
 
-usage: dist_gpu_worker.py FAMILY WORLD RANK PORT N_PER_RANK OUTDIR OVERLAP CAP [BACKEND]
-(BACKEND nccl: one rank per GPU over RCCL -- only where the box has that many GPUs)"""
+usage: dist_gpu_worker.py FAMILY WORLD RANK PORT N_PER_RANK OUTDIR OVERLAP CAP [BACKEND [FORCE]]
+(BACKEND nccl: one rank per GPU over RCCL -- only where the box has that many GPUs; FORCE 1: ShardedMatcher keeps its
+collectives in a world of one -- a one-GPU box then drives the whole multi-rank step over a real RCCL communicator)"""
 import os
 import sys
 
@@ -55,6 +56,7 @@ def case(family, n_total, variant=0):
 def main():
     family, world, rank, port, n, outdir, overlap, cap = sys.argv[1:9]
     backend = sys.argv[9] if len(sys.argv) > 9 else "gloo"
+    force = len(sys.argv) > 10 and sys.argv[10] == "1"
     world, rank, n, overlap, cap = int(world), int(rank), int(n), int(overlap), int(cap)
     import torch
     import torch.distributed as dist
@@ -69,8 +71,17 @@ def main():
     try:
         from ahocorasick_amd.dist import ShardedMatcher
         auto, orc, whole = case(family, n * world)
-        m = ShardedMatcher(auto, n, with_ids=True, cap=cap, overlap=bool(overlap))
+        m = ShardedMatcher(auto, n, with_ids=True, cap=cap, overlap=bool(overlap), force_collectives=force)
         assert m.scan_fn is None and m.device.type == "cuda"
+        if force and backend == "nccl":
+            # the halo exchange's transport, which a world of one never needs: byte views through batch_isend_irecv on RCCL
+            # (rank 0 sends its tail to itself)
+            src = torch.arange(4096, dtype=torch.int16, device="cuda")
+            dst = torch.zeros(2 * 4096, dtype=torch.uint8, device="cuda")
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, src.view(torch.uint8), rank), dist.P2POp(dist.irecv, dst, rank)]):
+                w.wait()
+            torch.cuda.synchronize()
+            assert (dst.view(torch.int16) == src).all()
         m.chain_window = 32
         m.load(whole[rank * n:(rank + 1) * n])
         repairs = 0
@@ -92,7 +103,7 @@ def main():
         got2 = m.global_records().cpu().numpy()
         assert got2.shape == want2.shape and (got2 == want2).all(), (family, rank, "second haystack")
         with open(os.path.join(outdir, "ok%d" % rank), "w") as f:
-            f.write("ok %d %d %d" % (repairs, redone, len(want)))
+            f.write("ok %d %d %d %d" % (repairs, redone, len(want), m.host_syncs))
     finally:
         dist.destroy_process_group()
 

@@ -23,11 +23,11 @@ def _free_port():
     return p
 
 
-def _run(family, world, overlap, cap, tmp_path, n=50000, backend="gloo"):
+def _run(family, world, overlap, cap, tmp_path, n=50000, backend="gloo", force=False):
     port = str(_free_port())
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, WORKER, family, str(world), str(r), port, str(n), str(tmp_path), str(int(overlap)),
-                               str(cap), backend], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+                               str(cap), backend, "1" if force else "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
              for r in range(world)]  # fresh children: nothing that touched the GPU is re-executed
     outs = []
     for p in procs:
@@ -76,6 +76,20 @@ def test_sharded_matcher_over_rccl_one_rank_per_gpu(family, world, overlap, cap,
     assert all(r[2] > 0 for r in res)
     if cap == 64:
         assert all(r[1] > 0 for r in res)
+
+
+@pytest.mark.parametrize("family,overlap,cap", [("ac", True, 1 << 16), ("ac", True, 64), ("wholeword", True, 1 << 16),
+                                                 ("longest", False, 1 << 16), ("shortest", False, 1 << 16), ("wwlongest", False, 64)])
+def test_sharded_matcher_over_rccl_world_of_one_keeps_its_collectives(family, overlap, cap, tmp_path):
+    """RCCL on the one-GPU box: a process group of ONE rank with backend "nccl", and a ShardedMatcher told to keep every
+    collective it would run among N ranks (force_collectives) -- the gather buffers [header | records], the asynchronous
+    all_gather_into_tensor left in flight under the next scan, the header read-back on the side stream, the chain families'
+    all-gathers of exits, the collective redo with larger buffers (cap 64), and a batch_isend_irecv of byte views (the halo
+    exchange's transport).  Everything an 8-GPU job executes on RCCL has then executed on RCCL once."""
+    res = _run(family, 1, overlap, cap, tmp_path, n=150000, backend="nccl", force=True)
+    assert res[0][2] > 0
+    if cap == 64:
+        assert res[0][1] > 0  # the collective redo ran
 
 
 def test_bench_self_launches_its_ranks(tmp_path):
