@@ -154,6 +154,27 @@ int ensure_device(acgpu_automaton *a, DeviceState **out, int lane) {
 
 uint32_t round_up8(uint64_t v) { return (uint32_t)((v + 7) & ~7ull); }
 
+// Region size of the tile kernels for a long shard: every wave scans r regions of R units one after the other, so the scan
+// lasts as long as r * R units of one wave -- with a fixed R the step from "r regions fill the waves exactly" to one region
+// more costs a whole region per wave (2^29 units in 32768-unit regions on 4096 waves: r = 4; one unit more, or four CUs
+// fewer (tunable reserve_cus): r = 5, a quarter slower).  Chosen here: whole tile groups, between r_lo and r_hi regions per
+// wave, the smallest r * R that covers the shard; among equals the R nearest `prefer`.
+uint64_t balanced_region_units(uint64_t len, uint64_t waves, uint64_t g, uint64_t r_min, uint64_t r_hi, uint64_t prefer) {
+    uint64_t best_R = 0, best_cost = ~0ull, best_dist = ~0ull;
+    for (uint64_t r = 1; r <= r_hi; ++r) {
+        const uint64_t m = (len + waves * r * g - 1) / (waves * r * g);
+        const uint64_t R = std::max<uint64_t>(m, 1) * g;
+        if (R < r_min || R > 65536) continue;
+        const uint64_t cost = r * R, dist = R > prefer ? R - prefer : prefer - R;
+        if (cost < best_cost || (cost == best_cost && dist < best_dist)) {
+            best_cost = cost;
+            best_dist = dist;
+            best_R = R;
+        }
+    }
+    return best_R;
+}
+
 // Which ALL-mode kernel serves this dictionary: the position-parallel K-gram tile kernel when the suffix filter
 // exists and is selective, otherwise the general DFA chunk scan (any alphabet, any keyword lengths).
 // force_kernel: 0 = automatic, 1 = DFA chunk scan, 2 = fused tile kernel, 3 = split tile kernels (filter + verification)
@@ -266,6 +287,10 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         const uint64_t ww_waves = (uint64_t)d.n_cu * ww_blocks_per_cu() * waves_per_block;
         uint64_t R = tunables().region_units > 0 ? (uint64_t)tunables().region_units
                      : own_len >= 65536 * ww_waves ? 65536 : own_len >= 32768 * ww_waves ? 32768 : 16384;
+        if (tunables().region_units <= 0 && own_len >= 32768 * ww_waves) { // long shards: regions that fill the waves evenly
+            const uint64_t Rb = balanced_region_units(sh->own_end - (sh->own_begin & ~7ull), ww_waves, tile_group_units(), 16384, 16, 65536);
+            if (Rb) R = Rb;
+        }
         { const uint64_t g = tile_group_units(); R = std::max<uint64_t>(g, (R + g - 1) / g * g); }
         L.region_units = (uint32_t)R;
         const uint64_t base8 = sh->own_begin & ~7ull;
@@ -353,6 +378,11 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         // config 2 in interleaved A/B; 65536 was no better)
         uint64_t R = tunables().region_units > 0 ? (uint64_t)tunables().region_units
                      : own_len >= 2ull * 32768 * d.n_cu * waves_per_block ? 32768 : 16384;
+        if (tunables().region_units <= 0 && own_len >= 2ull * 16384 * d.n_cu * waves_per_block) { // long shards: regions that fill the waves evenly
+            const uint64_t Rb = balanced_region_units(sh->own_end - (sh->own_begin & ~7ull), (uint64_t)d.n_cu * waves_per_block, tile_group_units(),
+                                                      12288, 16, 32768);
+            if (Rb) R = Rb;
+        }
         { const uint64_t g = tile_group_units(); R = std::max<uint64_t>(g, (R + g - 1) / g * g); }
         L.region_units = (uint32_t)R;
         const uint64_t base8 = sh->own_begin & ~7ull; // regions are laid out from the 16-byte aligned start
