@@ -16,6 +16,7 @@
 #include "acgpu_host.h"
 #include "acgpu_internal.h"
 #include "acgpu_kernels.h"
+#include "acgpu_small.h"
 
 using namespace acgpu;
 
@@ -1763,6 +1764,61 @@ int match_u16_pipelined(acgpu_automaton *a, DeviceState &d, const uint16_t *hays
 
 } // namespace
 
+namespace {
+
+// acgpu_match_u16 on a short haystack: ONE launch of one workgroup (acgpu_small.hip) that reads the haystack from, and writes
+// the records to, host-mapped pinned memory; the host waits on a flag in that memory.  *handled = false: the kernel could not
+// hold the call (too many occurrences) -- the general path takes it.
+int match_small(acgpu_automaton *a, DeviceState &d, const uint16_t *haystack, uint64_t n_units, int record_kind, void *out,
+                uint64_t cap, uint64_t *n_out, bool *handled) {
+    *handled = false;
+    constexpr size_t kHayBytes = (size_t)kSmallMaxUnits * 2 + 64, kOutBytes = (size_t)kSmallMaxRecs * ACGPU_REC_MAP + 64;
+    if (!d.small_pin) {
+        // fine-grained (coherent) host memory: the device's writes are visible to the host while the kernel is still running
+        HIP_TRY(hipHostMalloc(&d.small_pin, 64 + kHayBytes + kOutBytes, hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_TRY(hipHostGetDevicePointer(&d.small_pin_dev, d.small_pin, 0));
+        HIP_TRY(hipStreamCreateWithFlags(&d.small_stream, hipStreamNonBlocking));
+    }
+    volatile unsigned long long *status = reinterpret_cast<volatile unsigned long long *>(d.small_pin);
+    char *h_hay = (char *)d.small_pin + 64, *h_out = h_hay + kHayBytes;
+    char *dev = (char *)d.small_pin_dev;
+    std::memcpy(h_hay, haystack, n_units * 2);
+    std::memset(h_hay + n_units * 2, 0, 8); // (the kernel reads whole 8-byte groups)
+    status[0] = 0;
+    status[1] = 0;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    SmallCall c{};
+    c.hay = reinterpret_cast<const uint16_t *>(dev + 64);
+    c.n_units = (uint32_t)n_units;
+    c.record_kind = record_kind;
+    c.out = dev + 64 + kHayBytes;
+    c.cap = (uint32_t)std::min<uint64_t>(cap, kSmallMaxRecs);
+    c.status = reinterpret_cast<unsigned long long *>(dev);
+    HIP_TRY(launch_small(d.T, a->t.mode, c, d.small_stream));
+    // the flag; every so often the stream itself, so that a launch that failed behind the call cannot hang the host
+    for (uint64_t spins = 1;; ++spins) {
+        if (status[0] != 0) break;
+        if ((spins & 0xfffffu) == 0) {
+            const hipError_t q = hipStreamQuery(d.small_stream);
+            if (q != hipErrorNotReady && status[0] == 0) {
+                if (q == hipSuccess) continue; // (finished: the flag is on its way)
+                g_last_hip_error = (int)q;
+                (void)hipGetLastError();
+                return ACGPU_E_HIP;
+            }
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    if (status[0] != 1) return ACGPU_OK; // not handled
+    *handled = true;
+    *n_out = status[1];
+    if (*n_out > cap) return ACGPU_E_OVERFLOW;
+    if (*n_out) std::memcpy(out, h_out, *n_out * (uint64_t)record_kind);
+    return ACGPU_OK;
+}
+
+} // namespace
+
 extern "C" {
 
 int acgpu_match_u16(const acgpu_automaton *ca, const uint16_t *haystack, uint64_t n_units, int record_kind, void *out,
@@ -1778,6 +1834,12 @@ int acgpu_match_u16(const acgpu_automaton *ca, const uint16_t *haystack, uint64_
     // long haystacks of the families whose shards chain: the pipelined form (the loops that only exist as a sequential kernel
     // over the whole text -- WholeWord / WholeWordLongestSet with a fold-inconsistent table -- take the plain one)
     const HostTables &t = a->t;
+    // short haystacks: one launch, no copies (tunable tile_debug bit 2^41: the general path, for A/B and the tests)
+    if (n_units > 0 && n_units <= kSmallMaxUnits && d->inflight == 0 && small_call_supported(t) && !(tunables().tile_debug & (1ll << 41))) {
+        bool handled = false;
+        rc = match_small(a, *d, haystack, n_units, record_kind, out, cap, n_out, &handled);
+        if (rc != ACGPU_OK || handled) return rc;
+    }
     const bool sequential_only = (t.mode == ACGPU_MODE_WHOLEWORD && !t.fold_consistent) ||
                                  (t.mode == ACGPU_MODE_WWLONGEST && !t.fold_consistent && record_kind == ACGPU_REC_SET);
     if (n_units >= 2 * kHostChunkUnits && !sequential_only && d->inflight == 0 && !(tunables().tile_debug & 33554432) &&

@@ -85,6 +85,9 @@ struct DeviceState {
     // scratch pool (one in-flight match per automaton and device)
     DevBuf counter, chunk_counts, offsets, scan_tmp, scratch, chain, lenbuf, statebuf;
     DevBuf stage_hay, stage_out; // acgpu_match_u16 staging
+    // the one-launch form for short haystacks (acgpu_small.hip): host-mapped pinned block [status | haystack | records], its stream
+    void *small_pin = nullptr, *small_pin_dev = nullptr;
+    hipStream_t small_stream = nullptr;
     DevBuf multi_win, multi_tail; // multi-device calls, chain families: records of a repair window, the kept tail of the speculation
     // batch entry: pinned concatenation + offsets, device offsets, tagged records
     void *batch_pin = nullptr;
@@ -119,6 +122,8 @@ struct DeviceState {
         chain.release(); lenbuf.release(); statebuf.release(); stage_hay.release(); stage_out.release();
         multi_win.release(); multi_tail.release();
         if (call_stream) (void)hipStreamDestroy(call_stream);
+        if (small_stream) (void)hipStreamDestroy(small_stream);
+        if (small_pin) (void)hipHostFree(small_pin);
         short_recs.release(); short_nxt.release(); short_tmp.release(); short_mark.release();
         wwl_rs.release(); wwl_mend.release(); wwl_mid.release(); wwl_sel.release(); wwl_stop.release(); wwl_nxt0.release(); ww_recs.release(); blockmax.release(); lenbig.release(); todo.release(); chainbits.release(); cands.release(); region_cands.release();
         if (h_counter) (void)hipHostFree(h_counter);

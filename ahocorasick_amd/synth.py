@@ -283,3 +283,93 @@ def config_keywords(name):
     if name == "C5":
         return mixed_script_words(c["dict_seed"], c["n_kw"], c["min_len"], c["max_len"])
     raise KeyError(name)
+
+
+# ---- the reference's own published workload (R/README.md:126-152) --------------------------------------------------------------
+# "Dictionary: OS X dictionary at /usr/share/dict/words, 235886 english words.  Input string: a paragraph of english text" -- the
+# file does not exist in this image, so the dictionary is an English-SHAPED stand-in of the same size: words drawn letter by letter
+# from the English letter frequencies, lengths 1..24 distributed like a word list's (mode 9), one word in twelve capitalised (the
+# list's proper nouns), the 52 single letters and the words of the paragraph itself included (a real word list holds them too).
+README_PARAGRAPH = (  # the paragraph of T/SetTest.java:50-54, typed in as data
+    "Values specified as nondelimited strings are interpreted according their length. For a string 8 or 14 characters long, the year "
+    "is assumed to be given by the first 4 characters. Otherwise, the year is assumed to be given by the first 2 characters. The string "
+    "is interpreted from left to right to find year, month, day, hour, minute, and second values, for as many parts as are present in "
+    "the string. This means you should not use strings that have fewer than 6 characters.")
+README_WORDS = 235886
+_LETTER_WEIGHTS = [("e", 127), ("t", 91), ("a", 82), ("o", 75), ("i", 70), ("n", 67), ("s", 63), ("h", 61), ("r", 60), ("d", 43), ("l", 40),
+                   ("c", 28), ("u", 28), ("m", 24), ("w", 24), ("f", 22), ("g", 20), ("y", 20), ("p", 19), ("b", 15), ("v", 10), ("k", 8),
+                   ("j", 2), ("x", 2), ("q", 1), ("z", 1)]
+_LENGTH_WEIGHTS = [0, 0, 2, 10, 40, 90, 150, 210, 260, 280, 270, 230, 180, 130, 90, 60, 35, 20, 12, 7, 4, 2, 1, 1, 1]  # index = length
+
+
+def readme_dictionary(seed=1006, n=README_WORDS):
+    """n distinct words as uint16 arrays, deterministic (SplitMix64 stream `seed`)."""
+    import re
+    letters = np.concatenate([np.full(w, ord(c), np.uint16) for c, w in _LETTER_WEIGHTS])
+    lens = np.concatenate([np.full(w, L, np.int64) for L, w in enumerate(_LENGTH_WEIGHTS)])
+    seen = set()
+    out = []
+
+    def add(b):
+        if b not in seen:
+            seen.add(b)
+            out.append(np.frombuffer(b, dtype=np.uint8).astype(np.uint16))
+
+    for c in range(26):  # the single letters of the word list
+        add(bytes([ord("a") + c]))
+        add(bytes([ord("A") + c]))
+    for w in re.findall(r"[A-Za-z]+", README_PARAGRAPH):
+        add(w.encode())
+        add(w.lower().encode())
+    st = Stream(seed)
+    while len(out) < n:
+        m = 4096
+        ls = lens[st.draws(m, len(lens))]
+        caps = st.draws(m, 12) == 0
+        us = letters[st.draws(int(ls.sum()), len(letters))]
+        at = 0
+        for L, cap in zip(ls.tolist(), caps.tolist()):
+            w = us[at:at + L].astype(np.uint8)
+            at += L
+            if cap:
+                w = w.copy()
+                w[0] -= 32
+            add(w.tobytes())
+            if len(out) >= n:
+                break
+    return out[:n]
+
+
+def readme_text(seed, n_units, words):
+    """English-shaped text of n_units units: dictionary words (rank-skewed: low indices far more often) and, one token in five, a
+    random letter string, separated by a space -- one in ten by ', ' or '. '.  Vectorised; deterministic."""
+    wl = np.array([len(w) for w in words], dtype=np.int64)
+    woff = np.concatenate([[0], np.cumsum(wl)])
+    wcat = np.concatenate(words)
+    letters = np.concatenate([np.full(w, ord(c), np.uint16) for c, w in _LETTER_WEIGHTS])
+    n_tok = n_units // 4 + 16  # (tokens are at least 2 units long: more than enough)
+    st = Stream(seed)
+    u = st.draws(n_tok, 1 << 30).astype(np.float64) / float(1 << 30)
+    idx = np.minimum((len(words) * u ** 3).astype(np.int64), len(words) - 1)  # cubic skew towards the head of the list
+    rnd = st.draws(n_tok, 5) == 0
+    rlen = 2 + st.draws(n_tok, 9)
+    length = np.where(rnd, rlen, wl[idx])
+    sepk = st.draws(n_tok, 20)
+    nsep = np.where(sepk < 2, 2, 1)
+    tok = length + nsep
+    start = np.concatenate([[0], np.cumsum(tok)[:-1]])
+    keep = int(np.searchsorted(start, n_units))
+    length, nsep, tok, start, idx, rnd, sepk = (a[:keep] for a in (length, nsep, tok, start, idx, rnd, sepk))
+    total = int(tok.sum())
+    tid = np.repeat(np.arange(keep, dtype=np.int64), tok)
+    pos = np.arange(total, dtype=np.int64) - np.repeat(start, tok)
+    in_word = pos < length[tid]
+    src = np.where(rnd[tid], 0, woff[idx[tid]]) + np.minimum(pos, np.maximum(length[tid] - 1, 0))
+    out = np.where(in_word, wcat[np.minimum(src, len(wcat) - 1)], 32).astype(np.uint16)
+    rmask = in_word & rnd[tid]
+    out[rmask] = letters[st.draws(int(rmask.sum()), len(letters))]
+    first_sep = (~in_word) & (pos == length[tid]) & (nsep[tid] == 2)
+    out[first_sep] = np.where(sepk[tid[first_sep]] == 0, ord("."), ord(","))
+    if total < n_units:
+        out = np.concatenate([out, np.full(n_units - total, 32, np.uint16)])
+    return np.ascontiguousarray(out[:n_units])

@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--cpu-sample-log2", type=int, default=27)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="N>1: nccl = RCCL over xGMI, one rank per GPU; gloo = host-staged collectives, ranks may share a GPU")
-    ap.add_argument("--config", default=None, choices=["C2", "C3", "C4", "C5"],
+    ap.add_argument("--config", default=None, choices=["C2", "C3", "C4", "C5", "README"],
                     help="BASELINE config (default: C2 at N=1, C3 at N>1 -- the configs the metric is quoted on; "
                          "C4 = LongestMatchSet, C5 = WholeWordMatchMap case-insensitive are the sibling matchers)")
     ap.add_argument("--single-process", action="store_true",
@@ -56,6 +56,8 @@ def main():
                                                     "be named twice on a box with fewer GPUs: peer-copy transport)")
     args = ap.parse_args()
 
+    if args.config == "README":
+        return main_readme(args)
     if args.single_process:
         return main_single_process(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -272,6 +274,125 @@ def main():
     if multi:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main_readme(args):
+    """`--config README`: the reference's OWN published workload (R/README.md:126-152) -- a 235 886-word dictionary (an
+    English-shaped stand-in of that size: /usr/share/dict/words does not exist here), one paragraph of English text
+    (T/SetTest.java:50-54) per match() call, for AhoCorasickSet / WholeWordMatchSet / LongestMatchSet -- three ways:
+    (i) microseconds per single acgpu_match_u16 call (what StringSet.match(String, listener) costs through the C ABI),
+    (ii) microseconds per haystack through the batch entry (10 000 paragraphs in one call), (iii) milliseconds per GiB on a
+    device-resident text of such words; beside the reference's published 3.6 / 2.9 / 7.1 us per call (hardware unstated)."""
+    import torch
+
+    from ahocorasick_amd import _native as N
+    from ahocorasick_amd import synth
+    from ahocorasick_amd.strings import Automaton, utf16
+    from ahocorasick_amd.unicode_tables import default_word_chars
+    from oracle.oracle import FAM_AC, FAM_LONGEST, FAM_WHOLEWORD, Oracle
+
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU matching path)"
+    words = synth.readme_dictionary()
+    para = utf16(synth.README_PARAGRAPH)
+    n_units = 1 << args.units_log2
+    block = synth.readme_text(2006, min(n_units, 1 << 25), words)
+    d_hay = torch.from_numpy(block.view(np.int16)).cuda().repeat(max(1, n_units // block.size))
+    fams = [("AhoCorasickSet", N.MODE_ALL, FAM_AC, {}, 3.6), ("WholeWordMatchSet", N.MODE_WHOLEWORD, FAM_WHOLEWORD, {"word_chars": default_word_chars()}, 2.9),
+            ("LongestMatchSet", N.MODE_LONGEST, FAM_LONGEST, {}, 7.1)]
+    res = {}
+    L = N.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    for name, mode, fam, kw, ref_us in fams:
+        t0 = time.time()
+        auto = Automaton(mode, words, True, **kw)
+        build_s = time.time() - t0
+        info = auto.info()
+        r = {"build_s": round(build_s, 2), "states": info["n_states"], "classes": info["n_classes"], "reference_us_per_call": ref_us}
+        # (i) one call: preallocated buffers, the bare ctypes call in a loop
+        cap = 4096
+        out = np.empty((cap, 2), dtype=np.int32)
+        n_out = ctypes.c_uint64(0)
+        hp, op = para.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p)
+        for _ in range(50):
+            N.check(L.acgpu_match_u16(auto.handle, hp, para.size, N.REC_SET, op, cap, ctypes.byref(n_out)), "acgpu_match_u16")
+        got = out[:n_out.value].copy()
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            for _ in range(400):
+                L.acgpu_match_u16(auto.handle, hp, para.size, N.REC_SET, op, cap, ctypes.byref(n_out))
+            ts.append((time.perf_counter() - t0) / 400)
+        r["us_per_call"] = round(float(np.median(ts)) * 1e6, 2)
+        N.set_tunable("tile_debug", 1 << 41)  # the general path, for comparison
+        for _ in range(5):
+            L.acgpu_match_u16(auto.handle, hp, para.size, N.REC_SET, op, cap, ctypes.byref(n_out))
+        t0 = time.perf_counter()
+        for _ in range(100):
+            L.acgpu_match_u16(auto.handle, hp, para.size, N.REC_SET, op, cap, ctypes.byref(n_out))
+        r["us_per_call_general_path"] = round((time.perf_counter() - t0) / 100 * 1e6, 2)
+        N.set_tunable("tile_debug", 0)
+        r["matches_per_call"] = int(len(got))
+        if not args.no_cpu_baseline:
+            orc = Oracle(fam, words, **({"word_chars": default_word_chars()} if fam == FAM_WHOLEWORD else {}))
+            want = orc.match(para)[:, :2]
+            assert got.shape == want.shape and (got == want).all(), "bench.py --config README: %s differs from the oracle on the paragraph" % name
+            orc.count(para)
+            t0 = time.perf_counter()
+            for _ in range(2000):
+                orc.count(para)
+            r["cpu_port_us_per_call"] = round((time.perf_counter() - t0) / 2000 * 1e6, 2)
+        # (ii) 10 000 paragraphs through the batch entry
+        hs = [para] * 10000
+        auto.match_batch(hs[:100], False)
+        t0 = time.perf_counter()
+        b = auto.match_batch(hs, False, cap=len(got) * 10000 + 16)
+        r["us_per_haystack_batched"] = round((time.perf_counter() - t0) / 10000 * 1e6, 3)
+        assert len(b) == len(got) * 10000
+        # (iii) a device-resident text of dictionary words
+        # (the word list holds the 52 single letters: AhoCorasickSet reports every letter of the text, as the reference does)
+        capd = int(n_units * 1.75) if mode == N.MODE_ALL else n_units // 2
+        d_out = torch.empty((capd, 2), dtype=torch.int32, device="cuda")
+        ms, nm, kern = [], 0, ""
+        for i in range(args.warmup + args.steps):
+            nm, rc, prof, _ = auto.match_device(d_hay.data_ptr(), n_units, False, d_out.data_ptr(), capd, stream=stream, profile=True)
+            if rc == N.E_OVERFLOW:
+                capd = nm + 16
+                d_out = torch.empty((capd, 2), dtype=torch.int32, device="cuda")
+                nm, rc, prof, _ = auto.match_device(d_hay.data_ptr(), n_units, False, d_out.data_ptr(), capd, stream=stream, profile=True)
+            N.check(rc, "acgpu_match_device")
+            if i >= args.warmup:
+                ms.append(prof["scan_ms"] + prof["finalize_ms"])
+                kern = prof["scan_kernel"]
+        gib = n_units * 2 / float(1 << 30)
+        ab = 2 * n_units + 8 * nm
+        r.update(ms_per_gib=round(float(np.median(ms)) / gib, 4), kernel=kern, matches_per_gib=int(nm / gib),
+                 roofline_frac=round(ab / (float(np.median(ms)) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4))
+        if not args.no_cpu_baseline:  # the device records of a prefix against the oracle
+            k = min(n_units, 1 << 22)
+            want = orc.match(block[:k], cap=4 * k)[:, :2]
+            recs = d_out[:min(nm, 4 * k)].cpu().numpy()
+            if mode == N.MODE_ALL:
+                ok = (recs[recs[:, 1] <= k] == want).all()
+            else:
+                lim = k - info["max_keyword_len"] - 2
+                ok = (recs[recs[:, 1] < lim] == want[want[:, 1] < lim]).all()
+            assert ok, "bench.py --config README: %s differs from the oracle on the text" % name
+            r["verified"] = True
+        res[name] = r
+        del auto
+    a = res["AhoCorasickSet"]
+    out = {"metric": "haystack MB/s (UTF-16 bytes scanned per second, records delivered in reference order)",
+           "value": round(float(1 << 30) / (a["ms_per_gib"] * 1e-3) / 1e6, 1), "unit": "MB/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": a["ms_per_gib"] * n_units * 2 / float(1 << 30), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+           "config": {"workload": "the reference's published workload (R/README.md:126-152): 235886-word dictionary (English-shaped stand-in), "
+                                  "the paragraph of T/SetTest.java:50-54 per call (%d units), and 2^%d units of such words" % (para.size, args.units_log2),
+                      "keywords": len(words)},
+           "roofline": {"bound": "hbm", "achieved": round(a["roofline_frac"] * HBM_PEAK_GBPS, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": a["roofline_frac"], "traffic": None, "kernel": a["kernel"]},
+           "readme": res}
+    print(json.dumps(out))
+    return 0
 
 
 def main_single_process(args):

@@ -2007,3 +2007,53 @@ def test_stream_probe_reports_a_plausible_read_bandwidth():
         assert 500 < gbps < 8000, gbps  # below the 8 TB/s spec peak, far above anything a host path reaches
     assert N.lib().acgpu_stream_probe(d.data_ptr(), 1 << 21, None, 5, 2, ctypes.byref(ms)) == N.E_INVALID
     assert N.lib().acgpu_stream_probe(d.data_ptr() + 2, 1 << 21, None, 5, 0, ctypes.byref(ms)) == N.E_INVALID
+
+
+# ---- the one-launch form of acgpu_match_u16 for short haystacks (csrc/acgpu_small.hip) ---------------------------------------
+
+@pytest.mark.parametrize("family", ["ac", "ac_ci", "shortest", "longest", "wholeword", "wholeword_ci"])
+def test_short_haystacks_one_launch_equals_oracle_and_general_path(family):
+    """A haystack of up to 4096 units is matched by ONE launch of one workgroup that reads it from, and writes the records to,
+    host-mapped pinned memory (no copies, no second launch): every family it serves against the oracle and against the general
+    path (tunable tile_debug bit 2^41), Set and Map records, lengths 1 .. 4096, the capacity protocol, and the hand-over to
+    the general path when the occurrences do not fit its LDS lists."""
+    from oracle.oracle import FAM_SHORTEST
+    rng = np.random.default_rng({"ac": 1, "ac_ci": 2, "shortest": 3, "longest": 4, "wholeword": 5, "wholeword_ci": 6}[family])
+    alpha = np.array([ord(c) for c in "abcAB d,"] + [0x00E9, 0x00C9], dtype=np.uint16)
+    for trial in range(12):
+        n_kw = int(rng.integers(1, 400))
+        letters = alpha[:5] if family.startswith("wholeword") else alpha[:int(rng.integers(2, 6))]
+        kws = [letters[rng.integers(0, len(letters), int(rng.integers(1, 9)))] for _ in range(n_kw)]
+        cs = not family.endswith("_ci")
+        if family.startswith("ac"):
+            auto, orc = Automaton(N.MODE_ALL, kws, cs), Oracle(FAM_AC, kws, case_sensitive=cs, lower=None if cs else LOWER)
+        elif family == "shortest":
+            auto, orc = Automaton(N.MODE_SHORTEST, kws, True), Oracle(FAM_SHORTEST, kws)
+        elif family == "longest":
+            auto, orc = Automaton(N.MODE_LONGEST, kws, True), Oracle(FAM_LONGEST, kws)
+        else:
+            auto = Automaton(N.MODE_WHOLEWORD, kws, cs, word_chars=WORD)
+            orc = Oracle(FAM_WHOLEWORD, kws, case_sensitive=cs, lower=None if cs else LOWER, word_chars=WORD)
+        for n in (1, 2, 7, 64, 333, 1024, 1025, 4095, 4096):
+            hay = alpha[rng.integers(0, len(alpha), n)]
+            want = orc.match(hay)
+            for ids in (True, False):
+                w = want if ids else want[:, :2]
+                N.set_tunable("tile_debug", 0)
+                got = auto.match_host(hay, ids, cap=max(len(w), 1))
+                assert got.shape == w.shape and (got == w).all(), (family, trial, n, ids)
+                N.set_tunable("tile_debug", 1 << 41)
+                gen = auto.match_host(hay, ids, cap=max(len(w), 1))
+                assert gen.shape == w.shape and (gen == w).all(), (family, trial, n, ids, "general path")
+            N.set_tunable("tile_debug", 0)
+            if len(want) > 1:  # capacity too small: ACGPU_E_OVERFLOW with the count, the retry delivers
+                got = auto.match_host(hay, True, cap=len(want) - 1)
+                assert got.shape == want.shape and (got == want).all()
+    # more occurrences than the kernel's lists hold: a^1 .. a^8 on 4096 a's -> the general path takes the call
+    if family == "ac":
+        kws = [np.full(k, ord("a"), np.uint16) for k in range(1, 9)]
+        hay = np.full(4096, ord("a"), np.uint16)
+        want = Oracle(FAM_AC, kws).match(hay)
+        assert len(want) > 30000
+        got = Automaton(N.MODE_ALL, kws, True).match_host(hay, True)
+        assert got.shape == want.shape and (got == want).all()
