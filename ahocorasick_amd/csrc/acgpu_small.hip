@@ -184,9 +184,10 @@ __global__ __launch_bounds__(kSmallBlock) void k_small(DevTables T, SmallCall C)
     if (MODE == ACGPU_MODE_WHOLEWORD) { // the run must end where the walk stopped, on the terminal the walk last saw
 #pragma unroll
         for (int k = 0; k < kWalks; ++k) {
+            // (branch free: every lane reads the flag behind its walk -- position n and beyond hold zeros)
             const uint32_t p = t + k * kSmallBlock;
-            const bool whole = best[k] != 0 && best[k] == pos[k] - p && !wordf[pos[k]];
-            if (!whole) best[k] = 0;
+            const uint32_t behind = wordf[min(pos[k], kSmallMaxUnits)];
+            best[k] = (best[k] == pos[k] - p && behind == 0u) ? best[k] : 0u;
         }
     }
     __syncthreads();
