@@ -59,7 +59,8 @@ SYMBOLS = ["acgpu_build", "acgpu_free", "acgpu_get_info", "acgpu_match_u16", "ac
            "acgpu_set_tunable", "acgpu_strerror", "acgpu_last_hip_error", "acgpu_abi_version", "acgpu_debug_tables",
            "acgpu_debug_wordhash", "acgpu_stream_open", "acgpu_stream_feed", "acgpu_stream_close",
            "acgpu_match_u16_multi", "acgpu_comm_open", "acgpu_comm_close", "acgpu_comm_transport", "acgpu_comm_stream",
-           "acgpu_match_device_allgather", "acgpu_last_rccl_error", "acgpu_gather_slot_bytes"]
+           "acgpu_match_device_allgather", "acgpu_last_rccl_error", "acgpu_gather_slot_bytes",
+           "acgpu_stream_set_pipelined", "acgpu_stream_reserve"]
 
 _lib = None
 
@@ -119,6 +120,10 @@ def lib():
         L.acgpu_stream_feed.argtypes = [vp, vp, u64, ci, ci, vp, u64, ctypes.POINTER(u64), ctypes.POINTER(i64)]
         L.acgpu_stream_close.restype = None
         L.acgpu_stream_close.argtypes = [vp]
+        L.acgpu_stream_set_pipelined.restype = ci
+        L.acgpu_stream_set_pipelined.argtypes = [vp, ci]
+        L.acgpu_stream_reserve.restype = ci
+        L.acgpu_stream_reserve.argtypes = [vp, u64, ctypes.POINTER(vp)]
         L.acgpu_debug_wordhash.restype = ci
         L.acgpu_debug_wordhash.argtypes = [vp, ctypes.POINTER(u32), vp, ctypes.POINTER(u64), vp, vp, ctypes.POINTER(u32), vp,
                                            ctypes.POINTER(u32)]

@@ -191,8 +191,10 @@ bool use_tile_kernel(const HostTables &t) {
     // bucketed classes (more than 63 distinct units): every candidate costs a hash probe of its K units, which pays while
     // the bucket filter still rejects something -- 3000 CJK units, 0.5 GiB: 20 k keywords of 3-8 units (density 0.08)
     // 0.9 against 4.9 ms for the DFA scan, 100 k (0.33) 2.1 against 5.6 ms, but 20 k keywords of 2-8 units (K = 2,
-    // density 1.0) 3.5 against 1.45 ms
-    return !t.hashk || t.filt_density <= 0.5;
+    // density 1.0) 3.5 against 1.45 ms.  With K = 4 the tile kernel wins even where the filter passes everything: the
+    // 235 886-word list of the reference's README (52 letters in two ranges, the single letters among the keywords: every
+    // position ends a keyword) 23.5 against 62.9 ms per 2^28 units, both bound by 412 M records (tools/scratch: round 4)
+    return !t.hashk || t.filt_density <= 0.5 || t.filt_k >= 4;
 }
 
 // LONGEST takes the all-matches pipeline only when matches are expected to be sparse
@@ -1391,100 +1393,6 @@ int acgpu_debug_tables(const acgpu_automaton *a, uint16_t *cls_lut, uint32_t *df
     if (out_id) std::memcpy(out_id, t.out_id.data(), t.n_states * sizeof(uint32_t));
     if (depth) std::memcpy(depth, t.depth.data(), t.n_states * sizeof(uint32_t));
     if (first_out_state) *first_out_state = t.first_out;
-    return ACGPU_OK;
-}
-
-// ---- streaming form: match(Readable, ...) ----------------------------------------------------------------------------
-struct acgpu_stream {
-    acgpu_automaton *a = nullptr;
-    std::vector<uint16_t> carry; // units a later chunk can still change the answer for (context + held back)
-    uint64_t carry_pos = 0;      // global position of carry[0]
-    uint64_t own_from = 0;       // global position of the first unit no earlier feed has owned
-    uint64_t chain_entry = 0;    // LONGEST: global position at which the greedy chain continues
-    bool finished = false;
-    std::vector<uint16_t> buf;
-};
-
-int acgpu_stream_open(const acgpu_automaton *a, acgpu_stream **out) {
-    if (!a || !out) return ACGPU_E_INVALID;
-    *out = nullptr;
-    // (word-character tables that are not fold-consistent: the reference's Readable loops fold in EVERY lookup,
-    // S/WholeWordMatchMap.java:112,117,328, S/WholeWordLongestMatchMap.java:404 -- ordinary scans over word o lower,
-    // match_shard(..., readable))
-    acgpu_stream *s = new (std::nothrow) acgpu_stream();
-    if (!s) return ACGPU_E_NOMEM;
-    s->a = const_cast<acgpu_automaton *>(a);
-    *out = s;
-    return ACGPU_OK;
-}
-
-void acgpu_stream_close(acgpu_stream *s) { delete s; }
-
-int acgpu_stream_feed(acgpu_stream *s, const uint16_t *units, uint64_t n_units, int final, int record_kind, void *out,
-                      uint64_t cap, uint64_t *n_out, int64_t *base) {
-    if (!s || !n_out || !base || (n_units && !units) || (cap && !out) || s->finished) return ACGPU_E_INVALID;
-    if (record_kind != ACGPU_REC_SET && record_kind != ACGPU_REC_MAP) return ACGPU_E_INVALID;
-    acgpu_automaton *a = s->a;
-    const HostTables &t = a->t;
-    // what the scan carries between feeds: a WHOLEWORD automaton whose folded keywords hold non-word units is scanned by the
-    // WholeWordLongest walk (match_shard), which hands the position of its next word start on
-    const int mode = (t.mode == ACGPU_MODE_WHOLEWORD && !t.fold_consistent && !t.fold_clean) ? ACGPU_MODE_WWLONGEST : t.mode;
-    const uint64_t total = s->carry.size() + n_units;
-    if (total >= (1ull << 31)) return ACGPU_E_INVALID;
-    *n_out = 0;
-    *base = (int64_t)s->carry_pos;
-    const uint64_t own_begin = s->own_from - s->carry_pos;
-    uint64_t own_end = total, keep_from = 0; // keep_from: first buffer unit the next feed still needs
-    if (mode == ACGPU_MODE_ALL || mode == ACGPU_MODE_SHORTEST) {
-        const uint64_t halo = t.max_len > 0 ? t.max_len - 1 : 0;
-        keep_from = total > halo ? total - halo : 0;
-    } else if (mode == ACGPU_MODE_WHOLEWORD || mode == ACGPU_MODE_WWLONGEST) {
-        const uint64_t hold = (uint64_t)t.max_len + 1; // a word / walk that starts here may still grow
-        if (!final) own_end = std::max<uint64_t>(own_begin, total > hold ? total - hold : 0);
-        keep_from = own_end > 0 ? own_end - 1 : 0; // one unit of left context
-    } else {
-        const uint64_t halo = t.max_len > 0 ? t.max_len - 1 : 0;
-        if (!final) own_end = std::max<uint64_t>(own_begin, total > halo ? total - halo : 0);
-        keep_from = own_end;
-    }
-    try {
-        s->buf.resize(total);
-    } catch (...) {
-        return ACGPU_E_NOMEM;
-    }
-    if (!s->carry.empty()) std::memcpy(s->buf.data(), s->carry.data(), s->carry.size() * 2);
-    if (n_units) std::memcpy(s->buf.data() + s->carry.size(), units, n_units * 2);
-    uint64_t chain_exit = mode == ACGPU_MODE_SHORTEST ? s->chain_entry : std::max<uint64_t>(s->chain_entry, s->carry_pos + own_end);
-    if (own_end > own_begin) {
-        DeviceState *d = nullptr;
-        int rc = device_for_call(a, &d);
-        if (rc) return rc;
-        std::lock_guard<std::mutex> lock(d->mu); // staging buffers are part of the per-device scratch pool
-        if ((rc = d->stage_hay.ensure(total * 2 + 16))) return rc;
-        if ((rc = d->stage_out.ensure(cap * (uint64_t)record_kind + 16))) return rc;
-        HIP_TRY(hipMemcpy(d->stage_hay.p, s->buf.data(), total * 2, hipMemcpyHostToDevice));
-        acgpu_shard sh{};
-        sh.d_hay = (const uint16_t *)d->stage_hay.p;
-        sh.n_units = total;
-        sh.own_begin = own_begin;
-        sh.own_end = own_end;
-        sh.text_begin = s->carry_pos == 0 ? 1 : 0;
-        sh.text_end = final ? 1 : 0;
-        sh.chain_entry = (int64_t)(s->chain_entry > s->carry_pos ? s->chain_entry - s->carry_pos : 0);
-        if (mode != ACGPU_MODE_SHORTEST) sh.chain_entry = std::max<int64_t>(sh.chain_entry, (int64_t)own_begin);
-        rc = match_shard(a, *d, &sh, record_kind, d->stage_out.p, cap, n_out, nullptr, nullptr, /*readable=*/true);
-        if (rc != ACGPU_OK) return rc; // ACGPU_E_OVERFLOW: nothing consumed, *n_out = capacity to retry with
-        if (*n_out) HIP_TRY(hipMemcpy(out, d->stage_out.p, *n_out * (uint64_t)record_kind, hipMemcpyDeviceToHost));
-        if (mode == ACGPU_MODE_LONGEST || mode == ACGPU_MODE_WWLONGEST) chain_exit = s->carry_pos + (uint64_t)sh.chain_exit;
-        // SHORTEST: the last restart; an exit equal to the relative entry means "no match in this feed"
-        if (mode == ACGPU_MODE_SHORTEST && *n_out) chain_exit = s->carry_pos + (uint64_t)sh.chain_exit;
-    }
-    // commit
-    s->own_from = s->carry_pos + own_end;
-    s->chain_entry = chain_exit;
-    s->carry.assign(s->buf.begin() + (ptrdiff_t)keep_from, s->buf.end());
-    s->carry_pos += keep_from;
-    s->finished = final != 0;
     return ACGPU_OK;
 }
 

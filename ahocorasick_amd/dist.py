@@ -426,9 +426,12 @@ class ShardedMatcher:
                 if w_end == n_own:  # the window is the whole shard: nothing of the speculation is kept
                     idx, ex_s = n, ex_t
                 else:
-                    # where the speculative chain leaves the window: max(w_end, end of its last match starting inside)
-                    idx = int(torch.searchsorted(starts, torch.tensor([w_end + shift], dtype=torch.int32, device=starts.device)).item())
-                    ex_s = max(w_end, int(spec_recs[idx - 1, 1].item()) - shift) if idx else w_end
+                    # where the speculative chain leaves the window: max(w_end, end of its last match starting inside) -- index
+                    # and end computed on the device, ONE read-back
+                    idx_t = torch.searchsorted(starts, torch.tensor([w_end + shift], dtype=torch.int32, device=starts.device))
+                    end_t = spec_recs[(idx_t - 1).clamp(min=0), 1]
+                    idx, last_end = torch.stack([idx_t.view(()).to(torch.int64), end_t.view(()).to(torch.int64)]).cpu().tolist()
+                    ex_s = max(w_end, last_end - shift) if idx else w_end
                 if w_end == n_own or ex_t == ex_s:
                     tail = spec_recs[idx:n].clone()
                     if n_t + len(tail) > self.out.shape[0]:
@@ -485,11 +488,16 @@ class ShardedMatcher:
                 w_end = min(w, n_own)
                 self.chain_repairs += 1
                 n_t, _, _ = self._call("tmp", 0, w_end, entry)
-                # speculative records that end inside the window (ends ascend)
-                idx = n if w_end == n_own else int(torch.searchsorted(
-                    ends, torch.tensor([w_end + shift], dtype=torch.int32, device=ends.device), right=True).item())
-                last_t = int(self._tmp[n_t - 1, 1].item()) - shift if n_t else entry
-                last_s = int(spec_recs[idx - 1, 1].item()) - shift if idx else none
+                # speculative records that end inside the window (ends ascend); index and both last ends in ONE read-back
+                if w_end == n_own:
+                    idx_t = torch.tensor([n], dtype=torch.int64, device=ends.device)
+                else:
+                    idx_t = torch.searchsorted(ends, torch.tensor([w_end + shift], dtype=torch.int32, device=ends.device), right=True)
+                ls_t = spec_recs[(idx_t - 1).clamp(min=0), 1] if n else torch.zeros(1, dtype=torch.int32, device=ends.device)
+                lt_t = self._tmp[max(n_t - 1, 0):max(n_t - 1, 0) + 1, 1]
+                idx, ls, lt = torch.stack([idx_t.view(()).to(torch.int64), ls_t.view(()).to(torch.int64), lt_t.view(()).to(torch.int64)]).cpu().tolist()
+                last_t = lt - shift if n_t else entry
+                last_s = ls - shift if idx else none
                 floor = w_end - halo  # restart positions at or left of this restrict nothing that ends after the window
                 if w_end == n_own or max(last_t, floor) == max(last_s, floor):
                     tail = spec_recs[idx:n].clone()

@@ -275,15 +275,25 @@ class Stream:
     """acgpu_stream: the haystack arrives in chunks (match(Readable, ...)); feed() returns the records that have become
     decidable as an (n, 2|3) int64 array with GLOBAL positions (units since the first feed)."""
 
-    def __init__(self, automaton, with_ids=True):
+    def __init__(self, automaton, with_ids=True, pipelined=False):
+        """pipelined: acgpu_stream_set_pipelined -- a feed returns the records of the PREVIOUS feed's chunk (the final feed both),
+        host copy, transfer and scan of neighbouring chunks overlap."""
         self._auto = automaton  # keeps the handle alive
         self._kind = N.REC_MAP if with_ids else N.REC_SET
         h = ctypes.c_void_p()
         N.check(N.lib().acgpu_stream_open(automaton.handle, ctypes.byref(h)), "acgpu_stream_open")
         self._h = h
+        if pipelined:
+            N.check(N.lib().acgpu_stream_set_pipelined(h, 1), "acgpu_stream_set_pipelined")
+
+    def reserve(self, n_units):
+        """acgpu_stream_reserve: a uint16 numpy view of the staging memory the next chunk may be written into; feed that view."""
+        p = ctypes.c_void_p()
+        N.check(N.lib().acgpu_stream_reserve(self._h, int(n_units), ctypes.byref(p)), "acgpu_stream_reserve")
+        return np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint16)), shape=(int(n_units),))
 
     def feed(self, units, final=False, cap=None):
-        u = np.ascontiguousarray(units, dtype=np.uint16)
+        u = np.ascontiguousarray(units, dtype=np.uint16)  # (a view of the reserved staging memory stays where it is)
         n = int(u.size)
         cols = self._kind // 4
         if cap is None:

@@ -348,6 +348,23 @@ int acgpu_stream_open(const acgpu_automaton *a, acgpu_stream **out);
 int acgpu_stream_feed(acgpu_stream *s, const uint16_t *units, uint64_t n_units, int final, int record_kind, void *out,
                       uint64_t cap, uint64_t *n_out, int64_t *base);
 void acgpu_stream_close(acgpu_stream *s);
+/*
+ * The pipelined form of the feeds (call before the first feed; on != 0).  A feed then copies its chunk into pinned staging
+ * memory with several host threads -- every piece goes on its way to the device as soon as it has been copied -- while the
+ * calling thread scans the PREVIOUS chunk and returns ITS records: host copy, transfer and scan of neighbouring chunks
+ * overlap.  Differences to the default form, all of them about WHEN records arrive, none about which:
+ *  - a feed returns the records the previous feed's chunk made decidable (the first feed returns none); the feed with
+ *    final != 0 returns the previous chunk's and its own; *base is the position record coordinate 0 stands for, as before;
+ *  - ACGPU_E_OVERFLOW: the chunk HAS been consumed; call the same feed again with the capacity in *n_out and it hands the
+ *    records over (its units are not looked at again);
+ *  - carried units + n_units must stay below 2^30; all feeds of a stream come from threads whose current HIP device is the
+ *    one the first feed ran on.
+ * acgpu_stream_reserve (pipelined streams): the address at which the next chunk of up to n_units units may be WRITTEN by the
+ * caller -- the staging memory itself; a feed whose `units` is that address copies nothing (a JNI glue reads the Java char[]
+ * straight into it).
+ */
+int acgpu_stream_set_pipelined(acgpu_stream *s, int on);
+int acgpu_stream_reserve(acgpu_stream *s, uint64_t n_units, uint16_t **buf);
 
 /*
  * Synthetic haystack generator of the benchmark: unit i of the stream is

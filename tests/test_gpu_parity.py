@@ -1051,14 +1051,29 @@ def test_sharded_matcher_native_scan_equals_whole_text(family):
 # ---- match(Readable, ReadableMatchListener): acgpu_stream_* ------------------------------------------------------------
 
 def _stream_all(auto, hay, cuts, with_ids=True):
+    """The records of all feeds, concatenated -- from the synchronous form; the pipelined form (a feed returns the previous
+    chunk's records, copy / transfer / scan overlap) and the pipelined form fed through acgpu_stream_reserve (the chunk written
+    straight into the staging memory) must deliver the very same list."""
     from ahocorasick_amd import Stream
-    st = Stream(auto, with_ids=with_ids)
-    parts = []
     edges = [0] + list(cuts) + [hay.size]
-    for i, (lo, hi) in enumerate(zip(edges[:-1], edges[1:])):
-        parts.append(st.feed(hay[lo:hi], final=(i == len(edges) - 2), cap=8))  # cap=8: the overflow/retry protocol
-    st.close()
-    return np.concatenate(parts)
+    results = []
+    for form in ("sync", "pipelined", "reserved"):
+        st = Stream(auto, with_ids=with_ids, pipelined=form != "sync")
+        parts = []
+        for i, (lo, hi) in enumerate(zip(edges[:-1], edges[1:])):
+            chunk = hay[lo:hi]
+            if form == "reserved" and hi > lo:
+                view = st.reserve(hi - lo)
+                view[:] = chunk
+                chunk = view
+            parts.append(st.feed(chunk, final=(i == len(edges) - 2), cap=8))  # cap=8: the overflow/retry protocol
+        st.close()
+        results.append(np.concatenate(parts))
+        if form == "pipelined" and len(edges) > 2:
+            assert len(parts[0]) == 0  # the first feed has no previous chunk to report
+    assert results[1].shape == results[0].shape and (results[1] == results[0]).all(), "pipelined feeds differ"
+    assert results[2].shape == results[0].shape and (results[2] == results[0]).all(), "reserved feeds differ"
+    return results[0]
 
 
 @pytest.mark.parametrize("family", ["ac", "longest", "wholeword"])

@@ -14,12 +14,18 @@ for name, mode, kws, cs, hay in (
         ("WholeWord C5 words", N.MODE_WHOLEWORD, synth.config_keywords("C5"), False,
          np.asarray(list(synth.ALPHA_LOWER[:8]) + [32, 32], dtype=np.uint16)[np.random.default_rng(5).integers(0, 10, n)])):
     a = Automaton(mode, kws, cs, word_chars=default_word_chars() if mode == N.MODE_WHOLEWORD else None)
-    for rep in range(2):
-        s = Stream(a, with_ids=True)
-        t0 = time.perf_counter()
-        total = 0
-        for o in range(0, n, chunk):
-            total += len(s.feed(hay[o:o + chunk], final=o + chunk >= n, cap=chunk // 8))
-        dt = time.perf_counter() - t0
-        s.close()
-    print("%-20s %d units in %d-unit chunks: %.1f ms, %.1f GB/s of UTF-16, %d records" % (name, n, chunk, dt * 1e3, 2.0 * n / dt / 1e9, total), flush=True)
+    for form in ("synchronous", "pipelined", "pipelined, chunks written into the reserved staging memory"):
+        for rep in range(2):
+            s = Stream(a, with_ids=True, pipelined=form != "synchronous")
+            t0 = time.perf_counter()
+            total = 0
+            for o in range(0, n, chunk):
+                c = hay[o:o + chunk]
+                if form.endswith("memory"):  # (the producer's own write: a Reader would fill this buffer itself)
+                    v = s.reserve(c.size)
+                    np.copyto(v, c)
+                    c = v
+                total += len(s.feed(c, final=o + chunk >= n, cap=chunk // 8))
+            dt = time.perf_counter() - t0
+            s.close()
+        print("%-20s %-62s %d units in %d-unit chunks: %.1f ms, %.1f GB/s of UTF-16, %d records" % (name, form, n, chunk, dt * 1e3, 2.0 * n / dt / 1e9, total), flush=True)
