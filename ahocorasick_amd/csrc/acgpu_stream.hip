@@ -13,7 +13,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstring>
 #include <functional>
 #include <new>
@@ -171,7 +173,11 @@ struct acgpu_stream {
     int cur = 0; // the slot the NEXT feed fills
     hipStream_t copy_stream = nullptr;
     CopyPool *pool = nullptr;
-    DevBuf out_dev;                  // records of one scan
+    // records of one scan: a device buffer, and pinned host memory they are copied back to (a hipMemcpy straight into the
+    // caller's pageable memory cost more than the scan of a chunk; kernels writing records into host-mapped memory: 50x more)
+    DevBuf out_dev;
+    void *out_pin = nullptr;
+    size_t out_pin_bytes = 0;
     std::vector<char> undelivered;   // records a feed could not hand over (capacity too small): the same feed, called again, gets them
     uint64_t undelivered_n = 0;
     int64_t undelivered_base = 0;
@@ -192,6 +198,7 @@ struct acgpu_stream {
                 sl.dev.release();
             }
             out_dev.release();
+            if (out_pin) (void)hipHostFree(out_pin);
             if (have) (void)hipSetDevice(cur_dev);
         }
     }
@@ -213,8 +220,15 @@ int scan_slot(acgpu_stream *s, Slot &sl, int record_kind, void *out, uint64_t ca
         int rc = device_for_call(a, &d);
         if (rc) return rc;
         std::lock_guard<std::mutex> lock(d->mu);
+        const bool trace = (tunables().tile_debug & (1ll << 42)) != 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        auto since = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); };
+        if (trace) {
+            HIP_TRY(hipEventSynchronize(sl.arrived));
+            fprintf(stderr, "[scan] chunk arrived after %.0f us", since());
+        }
         HIP_TRY(hipStreamWaitEvent(nullptr, sl.arrived, 0));
-        uint64_t n = 0, scap = std::max<uint64_t>(s->out_dev.bytes / (uint64_t)record_kind, 4096);
+        uint64_t n = 0, scap = std::max<uint64_t>(s->out_dev.bytes / (uint64_t)record_kind, 1 << 16);
         acgpu_shard sh{};
         for (;;) { // (the scan keeps ALL its records: the caller's capacity only decides what this feed can hand over)
             if ((rc = s->out_dev.ensure(scap * (uint64_t)record_kind + 16))) return rc;
@@ -235,6 +249,7 @@ int scan_slot(acgpu_stream *s, Slot &sl, int record_kind, void *out, uint64_t ca
             if (rc) return rc;
             break;
         }
+        if (trace) fprintf(stderr, ", scanned after %.0f us (%llu records)\n", since(), (unsigned long long)n);
         if (mode == ACGPU_MODE_LONGEST || mode == ACGPU_MODE_WWLONGEST) chain_exit = sl.carry_pos + (uint64_t)sh.chain_exit;
         if (mode == ACGPU_MODE_SHORTEST && n) chain_exit = sl.carry_pos + (uint64_t)sh.chain_exit;
         if (n) {
@@ -253,13 +268,24 @@ int scan_slot(acgpu_stream *s, Slot &sl, int record_kind, void *out, uint64_t ca
                 if (n_done && n_done <= cap) std::memcpy(s->undelivered.data(), out, n_done * (size_t)record_kind);
                 dst = s->undelivered.data() + n_done * (size_t)record_kind;
             }
-            HIP_TRY(hipMemcpy(dst, s->out_dev.p, bytes, hipMemcpyDeviceToHost));
-            if (delta) {
+            if (s->out_pin_bytes < bytes) {
+                if (s->out_pin) (void)hipHostFree(s->out_pin);
+                s->out_pin = nullptr;
+                s->out_pin_bytes = 0;
+                HIP_TRY(hipHostMalloc(&s->out_pin, bytes + bytes / 4 + 4096, hipHostMallocDefault));
+                s->out_pin_bytes = bytes + bytes / 4 + 4096;
+            }
+            HIP_TRY(hipMemcpy(s->out_pin, s->out_dev.p, bytes, hipMemcpyDeviceToHost)); // (pinned: one DMA, no bounce buffer)
+            if (!delta) {
+                std::memcpy(dst, s->out_pin, bytes);
+            } else {
+                const int32_t *src = reinterpret_cast<const int32_t *>(s->out_pin);
                 int32_t *r = reinterpret_cast<int32_t *>(dst);
                 const int cols = record_kind / 4;
                 for (uint64_t i = 0; i < n; ++i) {
-                    r[i * cols] += (int32_t)delta;
-                    r[i * cols + 1] += (int32_t)delta;
+                    r[i * cols] = src[i * cols] + (int32_t)delta;
+                    r[i * cols + 1] = src[i * cols + 1] + (int32_t)delta;
+                    if (cols == 3) r[i * cols + 2] = src[i * cols + 2];
                 }
             }
             *n_out = n_done + n;
@@ -334,14 +360,21 @@ int feed_pipelined(acgpu_stream *s, const uint16_t *units, uint64_t n_units, int
         if (!in_place) std::memcpy(h + n_carry + o, units + o, len * 2);
         send(n_carry + o, len);
     };
+    const bool trace = (tunables().tile_debug & (1ll << 42)) != 0; // development: where a feed's time goes (stderr)
+    const auto t_start = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_start).count(); };
     if (n_carry) send(0, n_carry);
     if (n_pieces) s->pool->start(n_pieces, job);
+    const double t_started = since();
     // meanwhile: the previous chunk's scan, whose records this feed returns
     *base = prev.pending ? (int64_t)prev.carry_pos : (int64_t)s->carry_pos;
     int scan_rc = ACGPU_OK;
     uint64_t n_done = 0;
     if (prev.pending) scan_rc = scan_slot(s, prev, record_kind, out, cap, 0, *base, &n_done);
+    const double t_scanned = since();
     if (n_pieces) s->pool->wait();
+    if (trace) fprintf(stderr, "[feed] %llu units: copies started %.0f us, previous chunk scanned %.0f us, copies done %.0f us\n",
+                       (unsigned long long)n_units, t_started, t_scanned, since());
     if (scan_rc == ACGPU_OK && copy_rc.load() != ACGPU_OK) scan_rc = copy_rc.load();
     if (scan_rc != ACGPU_OK) {
         (void)hipStreamSynchronize(s->copy_stream);

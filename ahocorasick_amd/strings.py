@@ -300,7 +300,9 @@ class Stream:
             cap = max(4096, n // 64)
         src = u if n else np.zeros(1, np.uint16)
         while True:
-            out = np.empty((cap, cols), dtype=np.int32)
+            out = getattr(self, "_out", None)  # (one record buffer per stream: a fresh one per feed costs more than the feed)
+            if out is None or out.shape != (cap, cols):
+                out = self._out = np.empty((cap, cols), dtype=np.int32)
             n_out, base = ctypes.c_uint64(0), ctypes.c_int64(0)
             rc = N.lib().acgpu_stream_feed(self._h, _vp(src), n, 1 if final else 0, self._kind, _vp(out), cap,
                                            ctypes.byref(n_out), ctypes.byref(base))

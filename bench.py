@@ -269,6 +269,7 @@ def main():
     if rank == 0 and not multi and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg_name, kws, matcher, min(n_units, 1 << args.cpu_sample_log2))
         out["end_to_end"] = end_to_end(auto, matcher, with_ids, n_units, out.get("records_sha256"))
+        out["end_to_end_stream"], out["single_call"] = end_to_end_stream(auto, matcher, with_ids, n_units)
     if rank == 0:
         print(json.dumps(out))
     if multi:
@@ -659,6 +660,48 @@ def end_to_end(auto, matcher, with_ids, sample_units, device_digest=None):
         r["same_records_as_device_run"] = digest == device_digest
         assert digest == device_digest, "bench.py: acgpu_match_u16 delivered other records than the device-resident run"
     return r
+
+
+def end_to_end_stream(auto, matcher, with_ids, sample_units):
+    """acgpu_stream_feed -- match(Readable, ...) -- on a prefix of the shard in 4 Mi-unit chunks, pipelined form (a feed returns
+    the previous chunk's records; host copy, transfer and scan overlap), and the fixed cost of ONE acgpu_match_u16 call on a
+    paragraph-sized haystack (472 units: the reference's published workload is one such call, R/README.md:126-152)."""
+    from ahocorasick_amd import _native as N
+    from ahocorasick_amd.strings import Stream
+    n = min(sample_units, 1 << 27)
+    hay = matcher.own_units_host(n)
+    chunk = 1 << 22
+    best = None
+    for pipelined in (False, True):
+        for _ in range(2):
+            st = Stream(auto, with_ids=with_ids, pipelined=pipelined)
+            t0 = time.perf_counter()
+            total = 0
+            for o in range(0, n, chunk):
+                total += len(st.feed(hay[o:o + chunk], final=o + chunk >= n, cap=chunk // 8))
+            dt = time.perf_counter() - t0
+            st.close()
+        if pipelined:
+            best = {"value": round(2.0 * n / dt / 1e6, 1), "unit": "MB/s", "what": "acgpu_stream_feed, pipelined form, 2^%d units in 2^22-unit "
+                    "chunks from pageable host memory, %d records" % (int(np.log2(n)), total), "synchronous_form_mbps": sync_rate}
+        else:
+            sync_rate = round(2.0 * n / dt / 1e6, 1)
+    para = np.ascontiguousarray(hay[:472])
+    out = np.empty((4096, 3), dtype=np.int32)
+    n_out = ctypes.c_uint64(0)
+    L = N.lib()
+    args = (auto.handle, para.ctypes.data_as(ctypes.c_void_p), para.size, N.REC_MAP if with_ids else N.REC_SET, out.ctypes.data_as(ctypes.c_void_p), 4096,
+            ctypes.byref(n_out))
+    for _ in range(50):
+        L.acgpu_match_u16(*args)
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        for _ in range(200):
+            L.acgpu_match_u16(*args)
+        ts.append((time.perf_counter() - t0) / 200)
+    return best, {"value": round(float(np.median(ts)) * 1e6, 2), "unit": "us", "what": "one acgpu_match_u16 call on a 472-unit haystack (one launch, "
+                  "host-mapped buffers; the bare ctypes call in a loop, median of 5 x 200)"}
 
 
 if __name__ == "__main__":
