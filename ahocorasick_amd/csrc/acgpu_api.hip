@@ -425,7 +425,7 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
             L.slice_slots = (uint32_t)(slice_slots = scratch_cap);
             // a wave's slice holds one candidate per 8 units of its span (the filter passes ~2 % on selective
             // dictionaries); a haystack that needs more is redone with the fused kernel
-            const uint64_t per_wave = (uint64_t)L.regions_per_wave * R / 8 + 2 * 1024;
+            const uint64_t per_wave = (uint64_t)L.regions_per_wave * R / (uint64_t)std::max<int64_t>(1, tunables().split_cand_div) + 2 * 1024;
             if (per_wave * waves_used >= (1ull << 32)) split = false;
             else {
                 L.cands_per_wave = (uint32_t)per_wave;
@@ -1316,6 +1316,7 @@ int64_t acgpu_set_tunable(const char *name, int64_t value) {
     else if (!std::strcmp(name, "no_merged_ranges")) slot = &t.no_merged_ranges;
     else if (!std::strcmp(name, "no_short_keywords")) slot = &t.no_short_keywords;
     else if (!std::strcmp(name, "reserve_cus")) slot = &t.reserve_cus;
+    else if (!std::strcmp(name, "split_cand_div")) slot = &t.split_cand_div;
     if (!slot) return -1;
     return slot->exchange(value, std::memory_order_relaxed);
 }

@@ -277,6 +277,7 @@ struct Tunables {
     std::atomic<int64_t> no_short_keywords{0}; // builder: 1 = the filter's K stays at most the shortest keyword (A/B)
     std::atomic<int64_t> no_merged_ranges{0}; // builder: 1 = mixed-case dictionaries keep the 8-byte-row scalar filter (A/B)
     std::atomic<int64_t> ww_first_seed{0};    // WHOLEWORD builder: first hash seed tried (tests: the fallback seeds end to end)
+    std::atomic<int64_t> split_cand_div{8};   // split form: a wave's candidate slice holds one candidate per this many units of its span
     std::atomic<int64_t> reserve_cus{0};      // CUs left without a scan workgroup (room for a collective's kernels under the scan)
 };
 Tunables &tunables();

@@ -1000,7 +1000,7 @@ def _emulated_ranks(auto, whole, world, chain_window=4096):
     parts, repairs = [], 0
     for g in range(world):
         m = ShardedMatcher(auto, n, with_ids=True, cap=64)
-        m.rank, m.world = g, world
+        m.rank, m.world, m.collective = g, world, True
         m.chain_window = chain_window
         sb = m.sb
         sb.own.copy_(d_whole[g * n:(g + 1) * n])
