@@ -36,4 +36,12 @@ for c in C2 C4 C5; do
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_$c" -- python3 tools/kbench.py --rounds 1 --config $c $extra --variants '{"k":{}}' > "$OUT/pmc_write_$c.log" 2>&1
 done
 python3 tools/pmc_traffic_all.py "$OUT" --c2-calibrated "$OUT/pmc_traffic.json" --latest "$OUT/latest_traffic.json" --tag "profiles/${2:-rNN}/${3:-${1:-final}}_pmc_traffic_all.json" > "$OUT/pmc_traffic_all.json" 2> "$OUT/pmc_traffic_all.err"
+# round 4: the multi-device entries through ONE host process (a one-GPU box: RCCL over a world of one; peer copies over the
+# device named twice), the reference's own published workload, the CU reserve, the chunked entry
+python3 bench.py --gpus 1 --single-process --config C3 --steps 20 --warmup 3 > "$OUT/bench_c3_single_process_rccl.json" 2> "$OUT/bench_c3_sp.err"
+python3 bench.py --gpus 2 --devices 0,0 --single-process --units-log2 28 --steps 10 --warmup 2 > "$OUT/bench_c3_single_process_peer2.json" 2>> "$OUT/bench_c3_sp.err"
+python3 bench.py --config README --steps 5 --warmup 1 > "$OUT/bench_readme.json" 2> "$OUT/bench_readme.err"
+python3 tools/kbench.py --rounds 9 --variants '{"reserve_cus=0":{},"reserve_cus=4":{"reserve_cus":4},"reserve_cus=8":{"reserve_cus":8},"reserve_cus=16":{"reserve_cus":16},"reserve_cus=32":{"reserve_cus":32}}' > "$OUT/reserve_cus.txt" 2>&1
+python3 tools/stream_rate.py > "$OUT/stream_rate.txt" 2>&1
+python3 tools/latency.py > "$OUT/latency.txt" 2>&1
 cat "$OUT/bench_c2.json"
