@@ -28,6 +28,13 @@ using namespace acgpu;
 
 namespace {
 
+// records device -> host-mapped pinned memory, coalesced 16-byte pieces (a hipMemcpy of the same 100 KB queues behind the
+// chunk transfers that are in flight and takes as long as the scan)
+__global__ void k_copy_out(const uint4 *src, uint4 *dst, uint64_t n16) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+}
+
 // what one feed scans, from lengths alone: the buffer is [carry | chunk] = `total` units, of which [own_begin, own_end) become
 // decidable now, and the units from keep_from on are carried to the next feed
 struct FeedPlan {
@@ -176,7 +183,7 @@ struct acgpu_stream {
     // records of one scan: a device buffer, and pinned host memory they are copied back to (a hipMemcpy straight into the
     // caller's pageable memory cost more than the scan of a chunk; kernels writing records into host-mapped memory: 50x more)
     DevBuf out_dev;
-    void *out_pin = nullptr;
+    void *out_pin = nullptr, *out_pin_dev = nullptr;
     size_t out_pin_bytes = 0;
     std::vector<char> undelivered;   // records a feed could not hand over (capacity too small): the same feed, called again, gets them
     uint64_t undelivered_n = 0;
@@ -272,10 +279,17 @@ int scan_slot(acgpu_stream *s, Slot &sl, int record_kind, void *out, uint64_t ca
                 if (s->out_pin) (void)hipHostFree(s->out_pin);
                 s->out_pin = nullptr;
                 s->out_pin_bytes = 0;
-                HIP_TRY(hipHostMalloc(&s->out_pin, bytes + bytes / 4 + 4096, hipHostMallocDefault));
+                HIP_TRY(hipHostMalloc(&s->out_pin, bytes + bytes / 4 + 4096, hipHostMallocMapped));
+                HIP_TRY(hipHostGetDevicePointer(&s->out_pin_dev, s->out_pin, 0));
                 s->out_pin_bytes = bytes + bytes / 4 + 4096;
             }
-            HIP_TRY(hipMemcpy(s->out_pin, s->out_dev.p, bytes, hipMemcpyDeviceToHost)); // (pinned: one DMA, no bounce buffer)
+            {
+                const uint64_t n16 = (bytes + 15) / 16;
+                hipLaunchKernelGGL(k_copy_out, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, nullptr, (const uint4 *)s->out_dev.p,
+                                   (uint4 *)s->out_pin_dev, n16);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipStreamSynchronize(nullptr));
+            }
             if (!delta) {
                 std::memcpy(dst, s->out_pin, bytes);
             } else {
@@ -314,7 +328,11 @@ int feed_pipelined(acgpu_stream *s, const uint16_t *units, uint64_t n_units, int
     }
     if (!s->started) {
         HIP_TRY(hipGetDevice(&s->device));
-        HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+        {   // the transfers at the LOWEST priority: where they run as copy kernels they must not hold the scan's CUs
+            int lo = 0, hi = 0;
+            HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            HIP_TRY(hipStreamCreateWithPriority(&s->copy_stream, hipStreamNonBlocking, lo));
+        }
         for (auto &sl : s->slot) HIP_TRY(hipEventCreateWithFlags(&sl.arrived, hipEventDisableTiming));
         const int workers = (int)std::min<unsigned>(5, std::max(1u, std::thread::hardware_concurrency() / 2));
         s->pool = new (std::nothrow) CopyPool(workers);
@@ -339,31 +357,21 @@ int feed_pipelined(acgpu_stream *s, const uint16_t *units, uint64_t n_units, int
     if ((rc = sl.dev.ensure(p.total * 2 + 64))) return rc;
     uint16_t *h = reinterpret_cast<uint16_t *>(sl.pin);
     if (n_carry) std::memcpy(h, s->carry.data(), n_carry * 2);
-    // the chunk: pieces of 1 MiB (units == our own staging memory: acgpu_stream_reserve -- nothing to copy), every piece sent
-    // on its way by the thread that copied it
+    // the chunk: pieces of 1 MiB copied by the pool's threads (units == our own staging memory: acgpu_stream_reserve --
+    // nothing to copy).  The threads only copy; the ONE transfer of the whole buffer is enqueued by the calling thread behind
+    // the previous chunk's scan (transfers enqueued from several threads while the scan's launches go out from this one made
+    // every launch wait for the runtime: the scan took 310 us instead of 75)
     const bool in_place = units == h + n_carry;
     const uint64_t piece = 1ull << 19; // units
-    const int n_pieces = (int)((n_units + piece - 1) / piece);
+    const int n_pieces = in_place ? 0 : (int)((n_units + piece - 1) / piece);
     std::atomic<int> copy_rc{ACGPU_OK};
-    const int dev = s->device;
-    auto send = [&](uint64_t off_units, uint64_t len_units) {
-        if (hipMemcpyAsync((char *)sl.dev.p + off_units * 2, (const char *)sl.pin + off_units * 2, len_units * 2, hipMemcpyHostToDevice,
-                           s->copy_stream) != hipSuccess)
-            copy_rc.store(ACGPU_E_HIP);
-    };
     std::function<void(int)> job = [&](int i) {
-        if (hipSetDevice(dev) != hipSuccess) {
-            copy_rc.store(ACGPU_E_HIP);
-            return;
-        }
         const uint64_t o = (uint64_t)i * piece, len = std::min<uint64_t>(piece, n_units - o);
-        if (!in_place) std::memcpy(h + n_carry + o, units + o, len * 2);
-        send(n_carry + o, len);
+        std::memcpy(h + n_carry + o, units + o, len * 2);
     };
     const bool trace = (tunables().tile_debug & (1ll << 42)) != 0; // development: where a feed's time goes (stderr)
     const auto t_start = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_start).count(); };
-    if (n_carry) send(0, n_carry);
     if (n_pieces) s->pool->start(n_pieces, job);
     const double t_started = since();
     // meanwhile: the previous chunk's scan, whose records this feed returns
@@ -381,6 +389,7 @@ int feed_pipelined(acgpu_stream *s, const uint16_t *units, uint64_t n_units, int
         s->finished = true; // (a stream that failed half way cannot go on)
         return scan_rc;
     }
+    if (p.total) HIP_TRY(hipMemcpyAsync(sl.dev.p, sl.pin, p.total * 2, hipMemcpyHostToDevice, s->copy_stream));
     HIP_TRY(hipEventRecord(sl.arrived, s->copy_stream));
     // commit this chunk
     sl.plan = p;

@@ -32,6 +32,23 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+import contextlib
+
+
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """RCCL prints a version banner on STDOUT when its first communicator comes up; the contract is ONE JSON line there."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
@@ -82,10 +99,12 @@ def main():
     torch.cuda.set_device(local_rank % n_dev if args.backend == "gloo" else local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo")
+        with stdout_to_stderr():
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                dist.barrier()  # (the communicator, and its banner, come up here at the latest)
+            else:
+                dist.init_process_group("gloo")
 
     multi = world > 1
     cfg_name = args.config or ("C3" if multi else "C2")
@@ -433,7 +452,8 @@ def main_single_process(args):
     m = info["max_keyword_len"]
     left, right = {"C4": (0, m - 1), "C5": (1, m + 1)}.get(cfg_name, (m - 1, 0))
     pad = (left + 7) // 8 * 8
-    comm = Comm(devices, N.TRANSPORT_AUTO)
+    with stdout_to_stderr():
+        comm = Comm(devices, N.TRANSPORT_AUTO)
     # shard g: [pad | 2^units_log2 own units (stream hay_seed + g) | right halo], resident on devices[g]
     bufs, shards = [], []
     for g, dev in enumerate(devices):
