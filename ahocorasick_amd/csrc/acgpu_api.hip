@@ -1743,8 +1743,10 @@ int acgpu_match_u16(const acgpu_automaton *ca, const uint16_t *haystack, uint64_
     // long haystacks of the families whose shards chain: the pipelined form (the loops that only exist as a sequential kernel
     // over the whole text -- WholeWord / WholeWordLongestSet with a fold-inconsistent table -- take the plain one)
     const HostTables &t = a->t;
-    // short haystacks: one launch, no copies (tunable tile_debug bit 2^41: the general path, for A/B and the tests)
-    if (n_units > 0 && n_units <= kSmallMaxUnits && d->inflight == 0 && small_call_supported(t) && !(tunables().tile_debug & (1ll << 41))) {
+    // short haystacks: one launch, no copies (tunable tile_debug bit 2^41, or a kernel form forced by "force_kernel": the
+    // general path -- for A/B, and for the tests that run the scan kernels on the short edge-case inputs)
+    if (n_units > 0 && n_units <= kSmallMaxUnits && d->inflight == 0 && small_call_supported(t) && !(tunables().tile_debug & (1ll << 41)) &&
+        tunables().force_kernel == 0) {
         bool handled = false;
         rc = match_small(a, *d, haystack, n_units, record_kind, out, cap, n_out, &handled);
         if (rc != ACGPU_OK || handled) return rc;

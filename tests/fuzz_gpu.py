@@ -89,6 +89,8 @@ def one_case(rng, it):
         knobs["rdense_budget_bytes"] = 0  # hashed reversed trie
     if rng.integers(0, 2):
         knobs["tile_debug"] = 4194304  # chain marking in one pass (Shortest, sparse Longest, WholeWordLongest) on small inputs too
+    if rng.integers(0, 2):
+        knobs["tile_debug"] |= 1 << 41  # short haystacks through the general path instead of the one-launch form
     for k, v in knobs.items():
         N.set_tunable(k, v)
     mode = [N.MODE_ALL, N.MODE_LONGEST, N.MODE_WHOLEWORD, N.MODE_SHORTEST, N.MODE_WWLONGEST][fam]
@@ -133,6 +135,21 @@ def one_case(rng, it):
     got = a.match_host(hay, with_ids, cap=64)
     desc = (it, fam, cs, with_ids, n_kw, min_len, max_len, n, len(alpha), knobs, a.info()["filter_k"], a.info()["tile_kernel"])
     assert got.shape == want.shape and (got == want).all(), ("host path", desc)
+    if n >= 2048 and rng.integers(0, 3) == 0:
+        # the multi-device entry: the one GPU named several times (shares, halos, speculative scans, window repairs)
+        devs = [0] * int(rng.integers(2, 6))
+        got_m = a.match_host(hay, with_ids, cap=64, devices=devs)
+        assert got_m.shape == want.shape and (got_m == want).all(), ("multi-device", len(devs), desc)
+    if n and rng.integers(0, 3) == 0 and (wc is None or a.info()["fold_consistent"]):
+        # pipelined feeds (a feed returns the previous chunk's records): the String overload's records, under a random chunking
+        from ahocorasick_amd.strings import Stream
+        want_s = want if with_ids else orc.match(hay)
+        st = Stream(a, with_ids=True, pipelined=True)
+        cuts = sorted(set([0, n] + [int(x) for x in rng.integers(0, n + 1, int(rng.integers(0, 6)))]))
+        parts = [st.feed(hay[lo:hi], final=(hi == n), cap=8) for lo, hi in zip(cuts[:-1], cuts[1:])]
+        st.close()
+        got_s = np.concatenate(parts) if parts else np.zeros((0, 3), np.int64)
+        assert got_s.shape == want_s.shape and (got_s == want_s.astype(np.int64)).all(), ("pipelined stream", cuts, desc)
     fold_seq = wc is not None and not cs and a.info()["fold_consistent"] == 0 and (fam == 2 or not with_ids)
     if n >= 1000 and not fold_seq:  # (the loops that mix raw and folded lookups exist for the whole text only)
         # shards of the device-resident buffer

@@ -33,6 +33,16 @@ def ac_kernel(request):
     return request.param
 
 
+@pytest.fixture(params=["one_launch", "general_path"])
+def host_path(request):
+    """Tests on short haystacks run twice: through the one-launch form acgpu_match_u16 takes for up to 4096 units
+    (csrc/acgpu_small.hip) and through the general path (copy in, scan kernels of the family, copy out) that every longer
+    haystack takes -- the short inputs are where the edge cases live, both paths must see them."""
+    if request.param == "general_path":
+        N.set_tunable("tile_debug", 1 << 41)
+    return request.param
+
+
 def _ids(n):
     return list(range(n))
 
@@ -48,7 +58,7 @@ def test_fixtures_ahocorasick(fixtures, ac_kernel):
         assert s.find_all(hay).tolist() == [r[:2] for r in fx["AC"]], fx["name"]
 
 
-def test_listener_contract_and_early_stop():
+def test_listener_contract_and_early_stop(host_path):
     # SetTest-style counting listener + membership assertion (T/SetTest.java:156-165), and early stop (R/README.md:70)
     kws = ["a", "aa", "aaa", "aaaa"]
     hay = "aaaa"
@@ -285,7 +295,7 @@ def test_config_c2_full_size_every_record():
 
 # ---- LongestMatchSet / LongestMatchMap ------------------------------------------------------------------------------
 
-def test_fixtures_longest(fixtures):
+def test_fixtures_longest(fixtures, host_path):
     for fx in fixtures:
         hay, kws = fixture_inputs(fx)
         assert LongestMatchMap(kws, _ids(len(kws)), True).find_all(hay).tolist() == fx["L"], fx["name"]
@@ -293,7 +303,7 @@ def test_fixtures_longest(fixtures):
 
 
 @pytest.mark.parametrize("seed", range(6))
-def test_fuzz_longest_vs_oracle(seed):
+def test_fuzz_longest_vs_oracle(seed, host_path):
     rng = np.random.default_rng(500 + seed)
     alpha = [ord(c) for c in "ab"] if seed % 2 == 0 else [ord(c) for c in "abcAB"] + [0x00E9, 0x00C9]
     for it in range(12):
@@ -316,7 +326,7 @@ def test_longest_variants(chunk_units, lds_bytes, sparse):
         assert LongestMatchMap(kws, _ids(len(kws)), True).find_all(hay).tolist() == want
 
 
-def test_longest_listener_and_early_stop():
+def test_longest_listener_and_early_stop(host_path):
     kws = ["a", "aa", "aaa", "aaaa"]
     hay = " aaaaaaa aaababababaabaa "
     s = LongestMatchSet(kws, True)
@@ -428,7 +438,7 @@ def test_longest_shards_with_chain_entry_and_exit():
 
 # ---- WholeWordMatchSet / WholeWordMatchMap ---------------------------------------------------------------------------
 
-def test_fixtures_wholeword(fixtures):
+def test_fixtures_wholeword(fixtures, host_path):
     for fx in fixtures:
         hay, kws = fixture_inputs(fx)
         if fx["WW"] == "IllegalArgumentException":
@@ -442,7 +452,7 @@ def test_fixtures_wholeword(fixtures):
         assert WholeWordMatchSet(kws, True).find_all(hay).tolist() == [r[:2] for r in fx["WW"]], fx["name"]
 
 
-def test_wholeword_boundaries_like_reference_assertions():
+def test_wholeword_boundaries_like_reference_assertions(host_path):
     # T/WholeWordMatchTest.java:60-70: every reported needle is delimited by non-word characters or the string ends
     kws = ["The", "quick", "red", "fox", "jumps", "over", "the", "lazy", "brown", "dog", "re", "ox"]
     hay = "The quick red fox, jumps over the lazy brown dog. redfox ox-re re_d dog"
@@ -462,7 +472,7 @@ def test_wholeword_boundaries_like_reference_assertions():
 
 
 @pytest.mark.parametrize("seed", range(6))
-def test_fuzz_wholeword_vs_oracle(seed):
+def test_fuzz_wholeword_vs_oracle(seed, host_path):
     rng = np.random.default_rng(900 + seed)
     alpha = [ord(c) for c in "abB -_.9"] + [0x00E9, 0x00C9, 0x4E2D, 0x3002, 0x0130]
     word_alpha = [c for c in alpha if WORD[c]]
