@@ -107,9 +107,10 @@ int ensure_device(acgpu_automaton *a, DeviceState **out, int lane) {
     if ((rc = upload(*d, t.kgram_node, &T.kgram_node))) return rc;
     T.fold_range = t.fold_range; T.fr_base = t.fr_base; T.fr_span = t.fr_span; T.fr_base2 = t.fr_base2; T.fr_himask = t.fr_himask;
     T.fr_base3 = t.fr_base3; T.fr_base4 = t.fr_base4; T.fr_nr = t.fr_nr;
-    T.l2_bloom = nullptr; T.l2_depth = 0;
+    T.l2_bloom = nullptr; T.l2_big = nullptr; T.l2_depth = 0;
     if (t.l2_depth) {
         if ((rc = upload(*d, t.l2_bloom, &T.l2_bloom))) return rc;
+        if (!t.l2_big.empty() && (rc = upload(*d, t.l2_big, &T.l2_big))) return rc;
         T.l2_depth = t.l2_depth;
     }
     if ((rc = upload(*d, t.rterm, &T.rterm))) return rc;
@@ -1316,6 +1317,7 @@ int64_t acgpu_set_tunable(const char *name, int64_t value) {
     else if (!std::strcmp(name, "no_merged_ranges")) slot = &t.no_merged_ranges;
     else if (!std::strcmp(name, "no_short_keywords")) slot = &t.no_short_keywords;
     else if (!std::strcmp(name, "reserve_cus")) slot = &t.reserve_cus;
+    else if (!std::strcmp(name, "no_big_l2")) slot = &t.no_big_l2;
     else if (!std::strcmp(name, "split_cand_div")) slot = &t.split_cand_div;
     if (!slot) return -1;
     return slot->exchange(value, std::memory_order_relaxed);

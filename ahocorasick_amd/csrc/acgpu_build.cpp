@@ -822,6 +822,7 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
                 // node of a depth in [K, D), is a key
                 t.l2_depth = 0;
                 t.l2_bloom.clear();
+                t.l2_big.clear();
                 if ((!t.hashk || merged) && (t.range_cls || t.fold_range) && n <= 32 && K >= 2 && K <= 5) {
                     const uint32_t D = std::min<uint32_t>(K + 2, 6);
                     t.l2_bloom.assign(kL2Words, 0);
@@ -837,6 +838,18 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
                     for (uint32_t w : t.l2_bloom) set += (uint64_t)__builtin_popcount(w);
                     t.l2_density = (double)set / (32.0 * kL2Words);
                     t.l2_depth = D;
+                    // a saturated filter rejects nothing (100 k keywords set 60 % of its bits): the same keys in 2 MB
+                    if (t.l2_density > 0.25 && K == 4 && !tunables().no_big_l2) {
+                        t.l2_big.assign(kL2BigWords, 0);
+                        for (uint32_t i = 1; i < RN; i++) {
+                            const uint32_t L = rn[i].depth;
+                            if (L < K || L > D || (L < D && rn[i].kw == ~0u)) continue;
+                            uint32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                            for (uint32_t p = i; p != 0; p = rn[p].parent) c[rn[p].depth - 1] = tcls(rn[p].unit);
+                            const uint32_t h = l2_hash(l2_gram(c, K));
+                            t.l2_big[l2_word_big(h)] |= l2_rotr(l2_pattern(h), l2_rot(c, L, K));
+                        }
+                    }
                 }
                 if (t.hashk) {
                     uint64_t cap = 16;

@@ -75,6 +75,9 @@ ACGPU_HD inline uint32_t l2_gram(const uint32_t *c, uint32_t K) { // the K-gram,
 }
 ACGPU_HD inline uint32_t l2_hash(uint32_t gram) { return l2_mul24(gram ^ (gram >> 13), 0x9E3779u); }
 ACGPU_HD inline uint32_t l2_word(uint32_t h) { return (((h >> 11) & 0x1fffu) * kL2Words) >> 13; }
+// the LARGE form of the same filter (dictionaries that saturate 22.5 KB): 2 MB in global memory, resident in the L2 cache
+constexpr uint32_t kL2BigWords = 1u << 19;
+ACGPU_HD inline uint32_t l2_word_big(uint32_t h) { return (l2_mul24(h ^ (h >> 11), 0x85EBCBu) >> 4) & (kL2BigWords - 1u); }
 ACGPU_HD inline uint32_t l2_pattern(uint32_t h) {
     const uint32_t x = l2_mul24(h >> 8, 0xC2B2AFu);
 #if defined(ACGPU_L2_TWO_BITS)
@@ -182,6 +185,7 @@ struct HostTables {
     uint32_t l2_depth = 0;
     std::vector<uint32_t> l2_bloom; // kL2Words
     double l2_density = 0;          // fraction of set bits
+    std::vector<uint32_t> l2_big;   // kL2BigWords: the same keys in the large form; empty unless the small one is saturated
     bool hashk = false;
     std::vector<uint16_t> tile_lut;    // 65536: raw unit -> tile class (== cls_lut when the classes are injective)
     std::vector<uint64_t> kg_keys;
@@ -239,6 +243,7 @@ struct DevTables {
     int32_t rdense;
     int32_t hashk;             // 1: bucketed tile classes, K-gram looked up by its units (see HostTables)
     const uint32_t *l2_bloom;  // second-level filter (kL2Words words) or nullptr
+    const uint32_t *l2_big;    // its large form in global memory (kL2BigWords words) or nullptr
     uint32_t l2_depth;
     uint32_t fold_range, fr_base, fr_span, fr_base2, fr_himask; // see HostTables::fold_range
     uint32_t fr_base3, fr_base4, fr_nr;
@@ -278,6 +283,7 @@ struct Tunables {
     std::atomic<int64_t> no_merged_ranges{0}; // builder: 1 = mixed-case dictionaries keep the 8-byte-row scalar filter (A/B)
     std::atomic<int64_t> ww_first_seed{0};    // WHOLEWORD builder: first hash seed tried (tests: the fallback seeds end to end)
     std::atomic<int64_t> split_cand_div{8};   // split form: a wave's candidate slice holds one candidate per this many units of its span
+    std::atomic<int64_t> no_big_l2{0};        // builder: 1 = large dictionaries keep the (saturated) second level in LDS (A/B)
     std::atomic<int64_t> reserve_cus{0};      // CUs left without a scan workgroup (room for a collective's kernels under the scan)
 };
 Tunables &tunables();

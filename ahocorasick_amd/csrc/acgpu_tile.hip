@@ -60,6 +60,8 @@ constexpr int kFilterWordsL2 = 19712;  // 78848 bytes: 27 classes, K = 4
 constexpr int kL2Cap = 256;            // a drain leaves fewer than 128; a tile adds at most 128 through the second level
 static_assert(kVerifyBatches * kWave + 128 <= kL2Cap, "the queue holds what a drain leaves plus a tile's survivors (-DACGPU_NB=4 hangs)");
 constexpr int kL2Fresh = 128;
+constexpr int kBigFresh = 704;          // BIG: candidates of one tile a wave lists (the LDS of the Bloom words: 1440 bytes per wave)
+static_assert(kBigFresh * 2 * (kTileBlock / kWave) <= kL2Words * 4, "the lists of the large second level live where the Bloom words did");
 constexpr int kL2Vec = 4;              // the L2 form takes 32 units per lane: every per-tile cost is shared by 2048 positions
 constexpr int kL2TileUnits = kWave * 8 * kL2Vec;
 constexpr int kTbBytes = 16 + kL2TileUnits; // one BYTE per class: [8 spare][8 classes before the tile][the tile]
@@ -478,8 +480,14 @@ __device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) {
 // wave's slice of L.d_cands (the "queue" is that slice and is never drained), with a {first index, count} pair per
 // region for k_ac_verify.  No LDS besides the filter rows.
 // NR4: merged stretches with three or four ranges (DevTables::fr_nr > 2; with PK only)
-template <int K, bool RANGE, bool WIDE, bool SPLIT, bool HASHK = false, bool PK = false, bool L2 = false, bool NR4 = false, bool SHORTS = true>
+// BIG (with L2): large dictionaries -- the second level is the SAME Bloom structure at 2 MB in global memory (DevTables::l2_big,
+// resident in the L2 cache) instead of 22.5 KB in LDS, which 100 k keywords saturate; the LDS that held the Bloom words holds a
+// list of up to kBigFresh first-level candidates per wave and tile, tested four batches at a time (their cached reads in flight
+// together); only the survivors -- about one candidate in fifty instead of nearly all -- reach the gather-bound verification
+template <int K, bool RANGE, bool WIDE, bool SPLIT, bool HASHK = false, bool PK = false, bool L2 = false, bool NR4 = false, bool SHORTS = true,
+          bool BIG = false>
 __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch L) {
+    static_assert(!BIG || L2, "the large second level is a form of the L2 kernel");
     const bool has_short = SHORTS && T.has_short != 0; // (SHORTS = false: the launcher knows there is none)
     // the filter rows are STATIC LDS (offset 0, so a scaled row index is the ds_read address with nothing to add);
     // the candidate queues are the dynamic part behind it
@@ -512,8 +520,9 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
     unsigned char *tb = smem + kWavesPerBlock * kL2Cap * 6 + wave_in_block * kTbBytes;
     uint16_t *fresh = reinterpret_cast<uint16_t *>(smem + kWavesPerBlock * (kL2Cap * 6 + kTbBytes)) + wave_in_block * kL2Fresh;
     uint32_t *bloom = reinterpret_cast<uint32_t *>(smem + (kTileBlock / kWave) * kL2WaveBytes);
-    if (L2) for (uint32_t i = threadIdx.x; i < kL2Words / 4; i += blockDim.x)
+    if (L2 && !BIG) for (uint32_t i = threadIdx.x; i < kL2Words / 4; i += blockDim.x)
         reinterpret_cast<uint4 *>(bloom)[i] = reinterpret_cast<const uint4 *>(T.l2_bloom)[i];
+    uint16_t *bigl = reinterpret_cast<uint16_t *>(bloom) + wave_in_block * kBigFresh; // BIG: the tile's candidates, text order
     static_assert(kL2Words % 4 == 0, "Bloom words are copied 16 bytes at a time");
     __syncthreads();
 
@@ -834,7 +843,92 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                     lane0 = 0;
                     continue;
                 }
-                if (total <= (uint32_t)kL2Fresh && c.cand_n + total <= (uint32_t)kL2Cap) {
+                struct __attribute__((packed, aligned(1), may_alias)) Win8b { uint32_t lo, hi; }; // classes of units p-7 .. p
+                if (BIG && total <= (uint32_t)kBigFresh) {
+                    { // the tile's candidates, tile relative, text order
+                        uint32_t slot = incl - cnt, m = mask;
+                        while (__any(m != 0)) {
+                            if (m != 0) {
+                                bigl[slot++] = (uint16_t)(lane * kAcLaneUnits + (uint32_t)__builtin_ctz(m));
+                                m &= m - 1;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    const unsigned char *tb8 = tb + 16;
+                    const uint32_t *bigtab = T.l2_big;
+                    uint32_t survivors = 0;
+                    for (uint32_t b = 0; b < total; b += 4u * kWave) { // four batches: their (cached) reads are in flight together
+                        uint32_t word[4], hh[4], pp[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const uint32_t k = b + (uint32_t)q * kWave + lane;
+                            pp[q] = k < total ? (uint32_t)bigl[k] : 0u;
+                            const Win8b w = *reinterpret_cast<const Win8b *>(tb8 + (int)pp[q] - 7);
+                            const uint32_t cl[4] = {w.hi >> 24, (w.hi >> 16) & 0xffu, (w.hi >> 8) & 0xffu, w.hi & 0xffu};
+                            hh[q] = l2_hash(K == 4 ? w.hi : l2_gram(cl, K));
+                            word[q] = bigtab[l2_word_big(hh[q])]; // (a lane beyond the list reads the word of position 0: cached)
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const uint32_t k = b + (uint32_t)q * kWave + lane;
+                            const bool act = k < total;
+                            const Win8b w = *reinterpret_cast<const Win8b *>(tb8 + (int)pp[q] - 7);
+                            const uint32_t cls[6] = {w.hi >> 24, (w.hi >> 16) & 0xffu, (w.hi >> 8) & 0xffu, w.hi & 0xffu, w.lo >> 24, (w.lo >> 16) & 0xffu};
+                            const uint32_t pat = l2_pattern(hh[q]);
+                            bool pass = false;
+#pragma unroll
+                            for (int len = K; len <= D2; ++len) {
+                                const uint32_t bits = __builtin_amdgcn_alignbit(pat, pat, l2_rot(cls, len, K));
+                                pass |= (word[q] & bits) == bits;
+                            }
+                            if (has_short) { // a keyword of fewer than K units ends here (see below)
+                                uint32_t hrow = T.filt_other;
+#pragma unroll
+                                for (int j = K - 2; j >= 1; --j) hrow = hrow * n + cls[j];
+                                pass = pass || ((rows32[hrow] >> cls[0]) & 1u);
+                            }
+                            pass = pass && act;
+                            if (act) bigl[k] = (uint16_t)(pp[q] | (pass ? 0x8000u : 0u));
+                            survivors += (uint32_t)__popcll(__ballot(pass));
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (survivors <= 128u && c.cand_n + survivors <= (uint32_t)kL2Cap) {
+                        for (uint32_t b = 0; b < total; b += kWave) {
+                            const uint32_t k = b + lane;
+                            const uint32_t e = k < total ? (uint32_t)bigl[k] : 0u;
+                            const bool pass = (e & 0x8000u) != 0;
+                            const uint32_t p = e & 0x7fffu;
+                            const uint64_t bal = __ballot(pass);
+                            if (bal == 0) continue; // wave-uniform
+                            if (pass) {
+                                const Win8b w = *reinterpret_cast<const Win8b *>(tb8 + (int)p - 7);
+                                const uint32_t cls[6] = {w.hi >> 24, (w.hi >> 16) & 0xffu, (w.hi >> 8) & 0xffu, w.hi & 0xffu, w.lo >> 24, (w.lo >> 16) & 0xffu};
+                                uint32_t shortbit = 0;
+                                if (has_short) {
+                                    uint32_t hrow = T.filt_other;
+#pragma unroll
+                                    for (int j = K - 2; j >= 1; --j) hrow = hrow * n + cls[j];
+                                    shortbit = (rows32[hrow] >> cls[0]) & 1u;
+                                }
+                                const uint32_t at = c.cand_n + (uint32_t)__popcll(bal & lanemask_lt());
+                                uint32_t idx = cls[K - 1];
+#pragma unroll
+                                for (int j = K - 2; j >= 0; --j) idx = __umul24(idx, n) + cls[j];
+                                c.pos16[at] = (uint16_t)(cur + p - c.pos_base);
+                                c.cand[at] = HASHK ? (kQiChecked | (shortbit ? kQiShort : 0u)) : kQiKnown | kQiChecked | (shortbit ? kQiShort : 0u) | (cls[K] << kQiLeftShift) | idx;
+                            }
+                            c.cand_n += (uint32_t)__popcll(bal);
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        lane0 = 0;
+                        continue;
+                    }
+                    // (the survivors do not fit the queue: a drain first and the tile once more, or -- more than 128 true
+                    // candidates in one tile -- the unfiltered way below)
+                }
+                if (!BIG && total <= (uint32_t)kL2Fresh && c.cand_n + total <= (uint32_t)kL2Cap) {
                     uint32_t slot = incl - cnt, m = mask;
                     while (__any(m != 0)) { // tile-relative positions, text order
                         if (m != 0) {
@@ -1076,6 +1170,19 @@ static bool tile_pk_usable(const DevTables &t, const TileLaunch &l) {
 }
 
 // two merged ranges (DevTables::hashk with fold_range): the packed two-range filter, the verification by units; K <= 4
+// the large second level (K = 4, DevTables::l2_big): tile_debug bit 2^30 keeps the LDS form for A/B
+static bool tile_big_usable(const DevTables &t, const TileLaunch &l) { return t.l2_big != nullptr && t.filt_k == 4 && !(l.debug & (1u << 30)); }
+
+template <bool NR4>
+static hipError_t launch_tile_merged_big(const DevTables &t, const TileLaunch &l, hipStream_t stream) {
+    const size_t lds = tile_l2_lds_bytes(l.block);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ac_tile<4, false, false, false, true, true, true, NR4, true, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    ACGPU_LAUNCH_EV((k_ac_tile<4, false, false, false, true, true, true, NR4, true, true>), dim3(l.grid), dim3(l.block), lds, stream, l.ev_start, l.ev_stop, t, l);
+    return hipGetLastError();
+}
+
 template <int K, bool L2, bool NR4>
 static hipError_t launch_tile_merged(const DevTables &t, const TileLaunch &l, hipStream_t stream) {
     const size_t lds = L2 ? tile_l2_lds_bytes(l.block) : l.lds_bytes;
@@ -1087,6 +1194,7 @@ static hipError_t launch_tile_merged(const DevTables &t, const TileLaunch &l, hi
 }
 template <int K>
 static hipError_t launch_tile_merged_k(const DevTables &t, const TileLaunch &l, bool l2, hipStream_t stream) {
+    if (K == 4 && l2 && tile_big_usable(t, l)) return t.fr_nr > 2 ? launch_tile_merged_big<true>(t, l, stream) : launch_tile_merged_big<false>(t, l, stream);
     if (t.fr_nr > 2) return l2 ? launch_tile_merged<K, true, true>(t, l, stream) : launch_tile_merged<K, false, true>(t, l, stream);
     return l2 ? launch_tile_merged<K, true, false>(t, l, stream) : launch_tile_merged<K, false, false>(t, l, stream);
 }
@@ -1117,8 +1225,18 @@ static hipError_t launch_tile_l2s(const DevTables &t, const TileLaunch &l, hipSt
     ACGPU_LAUNCH_EV((k_ac_tile<K, RANGE, false, false, false, true, true, false, SHORTS>), dim3(l.grid), dim3(l.block), lds, stream, l.ev_start, l.ev_stop, t, l);
     return hipGetLastError();
 }
+template <bool RANGE, bool SHORTS>
+static hipError_t launch_tile_l2_big(const DevTables &t, const TileLaunch &l, hipStream_t stream) {
+    const size_t lds = tile_l2_lds_bytes(l.block);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ac_tile<4, RANGE, false, false, false, true, true, false, SHORTS, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    ACGPU_LAUNCH_EV((k_ac_tile<4, RANGE, false, false, false, true, true, false, SHORTS, true>), dim3(l.grid), dim3(l.block), lds, stream, l.ev_start, l.ev_stop, t, l);
+    return hipGetLastError();
+}
 template <int K, bool RANGE>
 static hipError_t launch_tile_l2(const DevTables &t, const TileLaunch &l, hipStream_t stream) {
+    if (K == 4 && tile_big_usable(t, l)) return t.has_short ? launch_tile_l2_big<RANGE, true>(t, l, stream) : launch_tile_l2_big<RANGE, false>(t, l, stream);
     // (short keywords imply K <= 4: the K = 5 form needs no SHORTS instantiation)
     if (K <= 4 && t.has_short) return launch_tile_l2s<K, RANGE, (K <= 4)>(t, l, stream);
     return launch_tile_l2s<K, RANGE, false>(t, l, stream);
@@ -1142,6 +1260,8 @@ hipError_t launch_ac_tile(const DevTables &t, const TileLaunch &l, hipStream_t s
         const bool l2 = tile_l2_usable(t, l);
         std::snprintf(name, sizeof(name), "k_ac_tile<%u, false, false, false, true, true, %s, %s>", t.filt_k, l2 ? "true" : "false",
                       t.fr_nr > 2 ? "true" : "false");
+        if (l2 && tile_big_usable(t, l))
+            std::snprintf(name, sizeof(name), "k_ac_tile<4, false, false, false, true, true, true, %s, true, true>", t.fr_nr > 2 ? "true" : "false");
         switch (t.filt_k) {
         case 2: return launch_tile_merged_k<2>(t, l, l2, stream);
         case 3: return launch_tile_merged_k<3>(t, l, l2, stream);
@@ -1161,6 +1281,8 @@ hipError_t launch_ac_tile(const DevTables &t, const TileLaunch &l, hipStream_t s
     const char *rg = t.range_cls ? "true" : "false";
     if (tile_l2_usable(t, l)) {
         std::snprintf(name, sizeof(name), "k_ac_tile<%u, %s, false, false, false, true, true>", t.filt_k, rg);
+        if (tile_big_usable(t, l))
+            std::snprintf(name, sizeof(name), "k_ac_tile<4, %s, false, false, false, true, true, false, %s, true>", rg, t.has_short ? "true" : "false");
         switch (t.filt_k) {
         case 2: return t.range_cls ? launch_tile_l2<2, true>(t, l, stream) : launch_tile_l2<2, false>(t, l, stream);
         case 3: return t.range_cls ? launch_tile_l2<3, true>(t, l, stream) : launch_tile_l2<3, false>(t, l, stream);

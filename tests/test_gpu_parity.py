@@ -2082,3 +2082,55 @@ def test_short_haystacks_one_launch_equals_oracle_and_general_path(family):
         assert len(want) > 30000
         got = Automaton(N.MODE_ALL, kws, True).match_host(hay, True)
         assert got.shape == want.shape and (got == want).all()
+
+
+@pytest.mark.parametrize("shape", ["lower", "lower_with_short", "case_insensitive", "mixed_case"])
+def test_large_dictionaries_second_level_in_global_memory(shape):
+    """Dictionaries that saturate the 22.5 KB second-level filter in LDS (60 k keywords and more) take the same Bloom structure
+    at 2 MB in global memory (k_ac_tile<..., BIG>): a wave lists a tile's first-level candidates (up to 704) and tests them four
+    batches at a time; tiles with more candidates, and tiles whose survivors do not fit the queue, take the older ways.  Against
+    the oracle, with planted keywords, and against the LDS form (builder tunable no_big_l2)."""
+    import torch
+    rng = np.random.default_rng({"lower": 1, "lower_with_short": 2, "case_insensitive": 3, "mixed_case": 4}[shape])
+    kws = synth.random_keywords(70, 70000, 4, 12)
+    cs = True
+    if shape == "lower_with_short":
+        kws = list(kws) + [utf16("qz"), utf16("xjq"), utf16("k")]
+    if shape == "case_insensitive":
+        cs = False
+    if shape == "mixed_case":
+        kws = [np.where(rng.integers(0, 3, len(k)) == 0, k - 32, k).astype(np.uint16) for k in kws]
+    n = (1 << 22) + 12345
+    hay = synth.haystack(71, n)
+    if shape in ("case_insensitive", "mixed_case"):
+        hay = np.where(rng.integers(0, 3, n) == 0, hay - 32, hay).astype(np.uint16)
+    for _ in range(3000):  # whole keywords in the text: true candidates for the verification; some stretches dense in them
+        k = kws[int(rng.integers(0, len(kws)))]
+        p = int(rng.integers(0, n - 16))
+        hay[p:p + len(k)] = k
+    at = 100000
+    for i in range(400):  # a tile with more than 128 true candidates: the survivors do not fit the queue
+        k = kws[i]
+        hay[at:at + len(k)] = k
+        at += len(k)
+    orc = Oracle(FAM_AC, kws, case_sensitive=cs, lower=None if cs else LOWER)
+    want = oracle_parallel(orc, hay, "ac", 12, cap_per_unit=0.3)
+    a = Automaton(N.MODE_ALL, kws, cs)
+    d_hay = torch.from_numpy(hay.view(np.int16)).cuda()
+    got, prof = _dev_match(a, d_hay, n, True, len(want) + 16, profile=True)
+    assert prof["scan_kernel"].endswith("true>") and prof["scan_kernel"].count("true") >= 4, prof["scan_kernel"]  # (the BIG form)
+    assert got.shape == want.shape and (got == want).all()
+    got_s, _ = _dev_match(a, d_hay, n, False, len(want) + 16, own=(4096, n - 77), text_begin=True, text_end=True)  # a shard, Set records
+    w2 = want[(want[:, 1] - 1 >= 4096) & (want[:, 1] - 1 < n - 77)][:, :2]
+    assert got_s.shape == w2.shape and (got_s == w2).all()
+    N.set_tunable("tile_debug", 1 << 30)  # the LDS form of the second level on the same tables
+    got_l, prof_l = _dev_match(a, d_hay, n, True, len(want) + 16, profile=True)
+    assert prof_l["scan_kernel"] != prof["scan_kernel"] and (got_l == want).all()
+    N.set_tunable("tile_debug", 0)
+    N.set_tunable("no_big_l2", 1)
+    try:
+        b = Automaton(N.MODE_ALL, kws, cs)
+    finally:
+        N.set_tunable("no_big_l2", 0)
+    got_b, prof_b = _dev_match(b, d_hay, n, True, len(want) + 16, profile=True)
+    assert prof_b["scan_kernel"] == prof_l["scan_kernel"] and (got_b == want).all()

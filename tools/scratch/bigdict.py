@@ -13,8 +13,8 @@ cap = n // 16
 d_out = torch.empty((cap, 3), dtype=torch.int32, device="cuda")
 for name, kws in (("30k", synth.random_keywords(9, 30000, 4, 12)), ("100k", synth.random_keywords(10, 100000, 4, 12)), ("300k", synth.random_keywords(12, 300000, 4, 12))):
     a = Automaton(N.MODE_ALL, kws, True)
-    for label, knobs in (("fused", {}), ("split div8", {"force_kernel": 3}), ("split div3", {"force_kernel": 3, "split_cand_div": 3}), ("split div1", {"force_kernel": 3, "split_cand_div": 1}), ("dfa", {"force_kernel": 1})):
-        for k, v in {"force_kernel": 0, "split_cand_div": 8}.items(): N.set_tunable(k, v)
+    for label, knobs in (("big L2 (global)", {}), ("LDS L2", {"tile_debug": 1 << 30})):
+        for k, v in {"force_kernel": 0, "split_cand_div": 8, "tile_debug": 0}.items(): N.set_tunable(k, v)
         for k, v in knobs.items(): N.set_tunable(k, v)
         ts = []
         for r in range(4):
