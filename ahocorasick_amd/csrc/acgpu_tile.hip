@@ -836,9 +836,9 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                 }
                 // ---- second-level filter: only candidates whose last D2 units still look like a keyword are queued ----
                 if (lane < lane0) mask = 0;
-                const uint32_t cnt = __popc(mask);
-                const uint32_t incl = wave_inclusive_scan_dpp(cnt);
-                const uint32_t total = __builtin_amdgcn_readlane(incl, kWave - 1);
+                uint32_t cnt = __popc(mask);
+                uint32_t incl = wave_inclusive_scan_dpp(cnt);
+                uint32_t total = __builtin_amdgcn_readlane(incl, kWave - 1);
                 if (total == 0) {
                     lane0 = 0;
                     continue;
@@ -925,8 +925,21 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                         lane0 = 0;
                         continue;
                     }
-                    // (the survivors do not fit the queue: a drain first and the tile once more, or -- more than 128 true
-                    // candidates in one tile -- the unfiltered way below)
+                    // The survivors do not fit the queue.  What has been learnt is kept: every lane's mask shrinks to its survivors,
+                    // and the ways below -- a drain first and the tile once more, or as many whole lanes as fit -- see only those
+                    // (a tile with more than 128 TRUE candidates used to hand all of its first-level candidates to the verification)
+                    {
+                        uint32_t keep = 0;
+                        for (uint32_t j = 0; j < cnt; ++j) {
+                            const uint32_t e = bigl[incl - cnt + j];
+                            if (e & 0x8000u) keep |= 1u << ((e & 0x7fffu) - lane * kAcLaneUnits);
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        mask = keep;
+                        cnt = __popc(mask);
+                        incl = wave_inclusive_scan_dpp(cnt);
+                        total = __builtin_amdgcn_readlane(incl, kWave - 1);
+                    }
                 }
                 if (!BIG && total <= (uint32_t)kL2Fresh && c.cand_n + total <= (uint32_t)kL2Cap) {
                     uint32_t slot = incl - cnt, m = mask;

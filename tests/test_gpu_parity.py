@@ -2118,7 +2118,7 @@ def test_large_dictionaries_second_level_in_global_memory(shape):
     a = Automaton(N.MODE_ALL, kws, cs)
     d_hay = torch.from_numpy(hay.view(np.int16)).cuda()
     got, prof = _dev_match(a, d_hay, n, True, len(want) + 16, profile=True)
-    assert prof["scan_kernel"].endswith("true>") and prof["scan_kernel"].count("true") >= 4, prof["scan_kernel"]  # (the BIG form)
+    assert prof["scan_kernel"].startswith("k_ac_tile<4, ") and len(prof["scan_kernel"]) == 63, prof["scan_kernel"]  # (the BIG form: ten arguments)
     assert got.shape == want.shape and (got == want).all()
     got_s, _ = _dev_match(a, d_hay, n, False, len(want) + 16, own=(4096, n - 77), text_begin=True, text_end=True)  # a shard, Set records
     w2 = want[(want[:, 1] - 1 >= 4096) & (want[:, 1] - 1 < n - 77)][:, :2]
