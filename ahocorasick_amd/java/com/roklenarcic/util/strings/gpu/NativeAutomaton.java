@@ -25,6 +25,12 @@ final class NativeAutomaton implements AutoCloseable {
         return d;
     }
 
+    /**
+     * match(Readable, ...) through the pipelined feeds (system property {@code acgpu.stream.pipelined}): a feed returns the records of
+     * the PREVIOUS chunk, so the listener hears of a match one chunk later and one more chunk has been read when it says stop.
+     */
+    private static final boolean PIPELINED = Boolean.getBoolean("acgpu.stream.pipelined");
+
     private long handle;
 
     NativeAutomaton(int mode, String[] keywords, boolean caseSensitive, boolean[] wordChars) {
@@ -53,12 +59,12 @@ final class NativeAutomaton implements AutoCloseable {
 
     /** acgpu_stream_*: the haystack arrives in chunks; returns a stream handle for {@link #feed}. */
     long openStream() {
-        return streamOpen(handle);
+        return streamOpen(handle, PIPELINED);
     }
 
     /** keyword indices of the records that became decidable with this chunk, in the reference's listener-call order */
     static int[] feed(long stream, char[] chunk, int length, boolean last) {
-        return streamFeed(stream, chunk, length, last);
+        return streamFeed(stream, chunk, length, last, PIPELINED);
     }
 
     static void closeStream(long stream) {
@@ -83,9 +89,9 @@ final class NativeAutomaton implements AutoCloseable {
 
     private static native void free(long handle);
 
-    private static native long streamOpen(long handle);
+    private static native long streamOpen(long handle, boolean pipelined);
 
-    private static native int[] streamFeed(long stream, char[] chunk, int length, boolean last);
+    private static native int[] streamFeed(long stream, char[] chunk, int length, boolean last, boolean pipelined);
 
     private static native void streamClose(long stream);
 }

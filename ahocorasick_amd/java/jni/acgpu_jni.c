@@ -242,41 +242,57 @@ JNIEXPORT void JNICALL Java_com_roklenarcic_util_strings_gpu_NativeAutomaton_fre
 }
 
 /* ---- match(Readable, ReadableMatchListener<T>): acgpu_stream_* ---- */
-JNIEXPORT jlong JNICALL Java_com_roklenarcic_util_strings_gpu_NativeAutomaton_streamOpen(JNIEnv *env, jclass cls, jlong handle) {
+/* pipelined (-Dacgpu.stream.pipelined=true): acgpu_stream_set_pipelined -- a feed returns the PREVIOUS chunk's records, the last
+ * one both; the chunk is read out of the Java array straight into the library's pinned staging memory (acgpu_stream_reserve) */
+JNIEXPORT jlong JNICALL Java_com_roklenarcic_util_strings_gpu_NativeAutomaton_streamOpen(JNIEnv *env, jclass cls, jlong handle,
+                                                                                           jboolean pipelined) {
     (void)cls;
     acgpu_stream *s = NULL;
-    const int rc = acgpu_stream_open((const acgpu_automaton *)(intptr_t)handle, &s);
+    int rc = acgpu_stream_open((const acgpu_automaton *)(intptr_t)handle, &s);
+    if (rc == ACGPU_OK && pipelined) {
+        rc = acgpu_stream_set_pipelined(s, 1);
+        if (rc != ACGPU_OK) { acgpu_stream_close(s); s = NULL; }
+    }
     if (rc != ACGPU_OK) throw_rc(env, rc);
     return (jlong)(intptr_t)s;
 }
 
 JNIEXPORT jintArray JNICALL Java_com_roklenarcic_util_strings_gpu_NativeAutomaton_streamFeed(JNIEnv *env, jclass cls, jlong stream,
                                                                                                jcharArray chunk, jint length,
-                                                                                               jboolean last) {
+                                                                                               jboolean last, jboolean pipelined) {
     (void)cls;
     acgpu_stream *s = (acgpu_stream *)(intptr_t)stream;
     if (length < 0 || length > (*env)->GetArrayLength(env, chunk)) {
         throw_new(env, "java/lang/ArrayIndexOutOfBoundsException", "length");
         return NULL;
     }
-    /* a copy (GetCharArrayRegion), for the same reason as in match(): the feed blocks on the GPU */
-    jchar *units = (jchar *)malloc((size_t)(length ? length : 1) * sizeof(jchar));
-    if (!units) { throw_oom(env, "chunk copy"); return NULL; }
+    /* a copy (GetCharArrayRegion), for the same reason as in match(): the feed blocks on the GPU.  Pipelined streams: the copy
+     * goes straight into the stream's pinned staging memory, and the feed copies nothing */
+    jchar *units = NULL, *owned = NULL;
+    if (pipelined && length > 0) {
+        uint16_t *staging = NULL;
+        const int rrc = acgpu_stream_reserve(s, (uint64_t)length, &staging);
+        if (rrc != ACGPU_OK) { throw_rc(env, rrc); return NULL; }
+        units = (jchar *)staging;
+    } else {
+        units = owned = (jchar *)malloc((size_t)(length ? length : 1) * sizeof(jchar));
+        if (!units) { throw_oom(env, "chunk copy"); return NULL; }
+    }
     (*env)->GetCharArrayRegion(env, chunk, 0, length, units);
     uint64_t cap = (uint64_t)length / 64 + 4096, n_out = 0;
     int64_t base = 0;
     int32_t *buf = (int32_t *)malloc(cap * ACGPU_REC_MAP);
     jintArray out = NULL;
-    if (!buf) { throw_oom(env, "match records"); free(units); return NULL; }
+    if (!buf) { throw_oom(env, "match records"); free(owned); return NULL; }
     int rc = acgpu_stream_feed(s, (const uint16_t *)units, (uint64_t)length, last ? 1 : 0, ACGPU_REC_MAP, buf, cap, &n_out, &base);
     if (rc == ACGPU_E_OVERFLOW) { /* nothing was consumed: same feed, exact capacity */
         cap = n_out;
         int32_t *bigger = (int32_t *)realloc(buf, cap * ACGPU_REC_MAP);
-        if (!bigger) { throw_oom(env, "match records"); free(buf); free(units); return NULL; }
+        if (!bigger) { throw_oom(env, "match records"); free(buf); free(owned); return NULL; }
         buf = bigger;
         rc = acgpu_stream_feed(s, (const uint16_t *)units, (uint64_t)length, last ? 1 : 0, ACGPU_REC_MAP, buf, cap, &n_out, &base);
     }
-    free(units);
+    free(owned);
     if (rc == ACGPU_OK) {
         for (uint64_t i = 0; i < n_out; i++) buf[i] = buf[3 * i + 2]; /* the Readable listener only sees the value */
         out = to_int_array(env, buf, n_out);
