@@ -194,7 +194,7 @@ bool use_tile_kernel(const HostTables &t) {
     // 0.9 against 4.9 ms for the DFA scan, 100 k (0.33) 2.1 against 5.6 ms, but 20 k keywords of 2-8 units (K = 2,
     // density 1.0) 3.5 against 1.45 ms.  With K = 4 the tile kernel wins even where the filter passes everything: the
     // 235 886-word list of the reference's README (52 letters in two ranges, the single letters among the keywords: every
-    // position ends a keyword) 23.5 against 62.9 ms per 2^28 units, both bound by 412 M records (tools/scratch: round 4)
+    // position ends a keyword) 23.5 against 62.9 ms per 2^28 units, both bound by 412 M records (tools/readme_shapes.py, round 4)
     return !t.hashk || t.filt_density <= 0.5 || t.filt_k >= 4;
 }
 

@@ -17,6 +17,9 @@
 
 namespace acgpu {
 
+#ifndef ACGPU_SCAN_MINBLOCKS
+#define ACGPU_SCAN_MINBLOCKS 1
+#endif
 constexpr int kScanBlock = 1024;                 // 16 waves: one workgroup per CU shares one LDS copy of the hot rows
 constexpr int kQueueCap = 128;                   // records per wave queue
 constexpr int kQueueFlush = kQueueCap - kWave;   // flush when fewer than 64 free slots remain
@@ -172,7 +175,7 @@ __device__ __forceinline__ void ac_scan_body(const DevTables &T, const ScanLaunc
 }
 
 template <typename E>
-__global__ __launch_bounds__(kScanBlock) void k_ac_scan_dense(DevTables T, ScanLaunch L) {
+__global__ __launch_bounds__(kScanBlock, ACGPU_SCAN_MINBLOCKS) void k_ac_scan_dense(DevTables T, ScanLaunch L) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ScratchRec *queues = reinterpret_cast<ScratchRec *>(smem);
     E *tab = reinterpret_cast<E *>(smem + (size_t)(kScanBlock / kWave) * kQueueCap * sizeof(ScratchRec));

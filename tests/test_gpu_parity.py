@@ -2134,3 +2134,38 @@ def test_large_dictionaries_second_level_in_global_memory(shape):
         N.set_tunable("no_big_l2", 0)
     got_b, prof_b = _dev_match(b, d_hay, n, True, len(want) + 16, profile=True)
     assert prof_b["scan_kernel"] == prof_l["scan_kernel"] and (got_b == want).all()
+
+
+def test_balanced_regions_and_reserved_cus_on_long_shards():
+    """Long shards: the region size is chosen so that (regions per wave) x (region units) covers the shard with the least
+    slack, also when some CUs are kept free for a collective's kernels (tunable reserve_cus) -- odd shard lengths, a shard that
+    starts off a 16-byte boundary, both tile kernels, against the oracle."""
+    import torch
+    n = (1 << 27) + 54321
+    kws = synth.config_keywords("C2")
+    hay = synth.haystack(2002, n)
+    want = oracle_parallel(Oracle(FAM_AC, kws), hay, "ac", 12, cap_per_unit=0.02)
+    a = Automaton(N.MODE_ALL, kws, True)
+    d_hay = torch.from_numpy(hay.view(np.int16)).cuda()
+    for reserve, own in ((0, None), (24, None), (8, (1003, n - 77))):
+        N.set_tunable("reserve_cus", reserve)
+        try:
+            kw = {} if own is None else dict(own=own)
+            got, prof = _dev_match(a, d_hay, n, True, len(want) + 16, profile=True, **kw)
+        finally:
+            N.set_tunable("reserve_cus", 0)
+        w = want if own is None else want[(want[:, 1] - 1 >= own[0]) & (want[:, 1] - 1 < own[1])]
+        assert got.shape == w.shape and (got == w).all(), (reserve, own)
+    words = synth.mixed_script_words(1005, 20000)
+    d2 = torch.empty(n, dtype=torch.int16, device="cuda")
+    synth.token_stream_on_device(d2.data_ptr(), n, 2005, words, synth.swapcase_table())  # (config 5's token stream, generated in place)
+    hay2 = d2.cpu().numpy().view(np.uint16)
+    want2 = oracle_parallel(Oracle(FAM_WHOLEWORD, words, case_sensitive=False, lower=LOWER, word_chars=WORD), hay2, "wholeword", 12, cap_per_unit=0.2)
+    ww = Automaton(N.MODE_WHOLEWORD, words, False, word_chars=WORD)
+    for reserve in (0, 24):
+        N.set_tunable("reserve_cus", reserve)
+        try:
+            got2, _ = _dev_match(ww, d2, n, True, len(want2) + 16)
+        finally:
+            N.set_tunable("reserve_cus", 0)
+        assert got2.shape == want2.shape and (got2 == want2).all(), reserve

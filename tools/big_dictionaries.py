@@ -1,6 +1,8 @@
+"""Development tool: AhoCorasick scan time of config 2's haystack under 30 k / 100 k / 300 k random keywords, with the second level
+in global memory (the BIG form of k_ac_tile) and with the saturated one in LDS (tile_debug bit 2^30) -- DESIGN.md 7."""
 import ctypes, os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ahocorasick_amd import _native as N, synth
 from ahocorasick_amd.strings import Automaton
