@@ -804,7 +804,7 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
     auto stage = [&](uint32_t j, const uint4 w) -> uint32_t {
         const uint32_t cur = tile0 + j * kTileUnits, v = cur + lane * 8, slot = j & 1u;
         const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-        uint32_t wm = word_bits8<8>(wbits, ww);
+        uint32_t wm = ACGPU_DBG(L, 8u) ? ((ww[0] ^ ww[2]) & 0xbfu) | 1u : word_bits8<8>(wbits, ww); // 8: ablation, no word-bit lookups (timing only)
         if (cur + kTileUnits > n) wm &= (1u << (v < n ? min(n - v, 8u) : 0u)) - 1u; // (wave-uniform) nothing beyond the buffer is a word
         const uint32_t prev = from_prev_lane(wm >> 7, carry);
         carry = __builtin_amdgcn_readlane(wm, 63) >> 7;

@@ -107,6 +107,12 @@ def main():
                 dist.init_process_group("gloo")
 
     multi = world > 1
+    reserve = 0
+    if multi and args.backend == "nccl":
+        # the all-gather of step k runs under the scan of step k+1, and a scan workgroup holds a whole CU's LDS: a few CUs are
+        # kept free for RCCL's kernels (measured cost of the reserve on one GPU: profiles/r04/*_reserve_cus.txt)
+        reserve = int(os.environ.get("ACGPU_RESERVE_CUS", "8"))
+        N.set_tunable("reserve_cus", reserve)
     cfg_name = args.config or ("C3" if multi else "C2")
     if cfg_name == "C5" and args.units_log2 == 29:
         args.units_log2 = 28  # config 5 is 2^31 units over 8 GPUs
@@ -215,7 +221,7 @@ def main():
             "matches_total": n_matches_total, "record_bytes": rec_bytes, "build_s": round(build_s, 3),
             "parallelism": ("shard%d+halo(%d,%d)+allgather/%s" % (world, matcher.sb.halo, matcher.sb.right, args.backend))
             if multi else "single",
-            "gather_records_per_rank": matcher.cap if multi else None,
+            "gather_records_per_rank": matcher.cap if multi else None, "reserve_cus": reserve,
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
