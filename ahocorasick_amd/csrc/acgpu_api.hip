@@ -1353,6 +1353,10 @@ void acgpu_free(acgpu_automaton *a) {
         if (have) (void)hipSetDevice(kv.first.first);
         kv.second.reset();
     }
+    for (auto &b : a->stream_cache) {
+        if (have) (void)hipSetDevice(b.device);
+        b.release();
+    }
     if (have) (void)hipSetDevice(cur);
     delete a;
 }

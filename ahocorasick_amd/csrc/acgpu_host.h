@@ -144,9 +144,37 @@ struct DeviceState {
 
 } // namespace acgpu
 
+namespace acgpu {
+// what a pipelined stream (acgpu_stream.hip) works in: two chunks in pinned host memory and on the device, one scan's records on
+// the device and in host-mapped pinned memory.  Pinning 30 MB takes longer than streaming 100 MB, and a stream is single-use:
+// a closed stream leaves its buffers to the automaton, the next one on the same device takes them over.
+struct StreamBufs {
+    int device = -1;
+    void *pin[2] = {nullptr, nullptr};
+    size_t pin_bytes[2] = {0, 0};
+    DevBuf dev[2];
+    DevBuf out_dev;
+    void *out_pin = nullptr, *out_pin_dev = nullptr;
+    size_t out_pin_bytes = 0;
+    void release() { // (the caller has made `device` current)
+        for (int i = 0; i < 2; ++i) {
+            if (pin[i]) (void)hipHostFree(pin[i]);
+            pin[i] = nullptr;
+            pin_bytes[i] = 0;
+            dev[i].release();
+        }
+        out_dev.release();
+        if (out_pin) (void)hipHostFree(out_pin);
+        out_pin = out_pin_dev = nullptr;
+        out_pin_bytes = 0;
+    }
+};
+} // namespace acgpu
+
 struct acgpu_automaton {
     acgpu::HostTables t;
-    std::mutex mu;                                                               // guards `dev`
+    std::vector<acgpu::StreamBufs> stream_cache;                                 // guarded by mu
+    std::mutex mu;                                                               // guards `dev` and `stream_cache`
     std::map<std::pair<int, int>, std::unique_ptr<acgpu::DeviceState>> dev;      // (HIP device, lane) -> scratch pool + tables
 };
 

@@ -153,9 +153,6 @@ class CopyPool {
 
 // one chunk on its way: its units in pinned host memory and (soon) in device memory, and what its scan will be
 struct Slot {
-    void *pin = nullptr;
-    size_t pin_bytes = 0;
-    DevBuf dev;
     hipEvent_t arrived = nullptr;
     bool pending = false; // transferred (or on its way), not yet scanned
     FeedPlan plan{};
@@ -180,11 +177,10 @@ struct acgpu_stream {
     int cur = 0; // the slot the NEXT feed fills
     hipStream_t copy_stream = nullptr;
     CopyPool *pool = nullptr;
-    // records of one scan: a device buffer, and pinned host memory they are copied back to (a hipMemcpy straight into the
-    // caller's pageable memory cost more than the scan of a chunk; kernels writing records into host-mapped memory: 50x more)
-    DevBuf out_dev;
-    void *out_pin = nullptr, *out_pin_dev = nullptr;
-    size_t out_pin_bytes = 0;
+    // the chunks' staging memory, and the records of one scan: a device buffer, and pinned host memory they are copied back to (a
+    // hipMemcpy straight into the caller's pageable memory cost more than the scan of a chunk; kernels writing records into
+    // host-mapped memory: 50x more).  Taken from / left to the automaton's cache (StreamBufs, acgpu_host.h).
+    StreamBufs b;
     std::vector<char> undelivered;   // records a feed could not hand over (capacity too small): the same feed, called again, gets them
     uint64_t undelivered_n = 0;
     int64_t undelivered_base = 0;
@@ -199,13 +195,17 @@ struct acgpu_stream {
                 (void)hipStreamSynchronize(copy_stream);
                 (void)hipStreamDestroy(copy_stream);
             }
-            for (auto &sl : slot) {
-                if (sl.pin) (void)hipHostFree(sl.pin);
+            for (auto &sl : slot)
                 if (sl.arrived) (void)hipEventDestroy(sl.arrived);
-                sl.dev.release();
+            if (b.device >= 0 && a) { // (the buffers outlive the stream: the next one on this device takes them over)
+                std::lock_guard<std::mutex> l(a->mu);
+                try {
+                    a->stream_cache.push_back(std::move(b));
+                    b = StreamBufs();
+                } catch (...) {
+                }
             }
-            out_dev.release();
-            if (out_pin) (void)hipHostFree(out_pin);
+            if (b.device >= 0) b.release();
             if (have) (void)hipSetDevice(cur_dev);
         }
     }
@@ -220,6 +220,7 @@ int scan_slot(acgpu_stream *s, Slot &sl, int record_kind, void *out, uint64_t ca
     const HostTables &t = a->t;
     const int mode = scan_mode(t);
     const FeedPlan &p = sl.plan;
+    const int si = (int)(&sl - s->slot);
     *n_out = n_done;
     uint64_t chain_exit = mode == ACGPU_MODE_SHORTEST ? s->chain_entry : std::max<uint64_t>(s->chain_entry, sl.carry_pos + p.own_end);
     if (p.own_end > p.own_begin) {
@@ -235,12 +236,12 @@ int scan_slot(acgpu_stream *s, Slot &sl, int record_kind, void *out, uint64_t ca
             fprintf(stderr, "[scan] chunk arrived after %.0f us", since());
         }
         HIP_TRY(hipStreamWaitEvent(nullptr, sl.arrived, 0));
-        uint64_t n = 0, scap = std::max<uint64_t>(s->out_dev.bytes / (uint64_t)record_kind, 1 << 16);
+        uint64_t n = 0, scap = std::max<uint64_t>(s->b.out_dev.bytes / (uint64_t)record_kind, 1 << 16);
         acgpu_shard sh{};
         for (;;) { // (the scan keeps ALL its records: the caller's capacity only decides what this feed can hand over)
-            if ((rc = s->out_dev.ensure(scap * (uint64_t)record_kind + 16))) return rc;
+            if ((rc = s->b.out_dev.ensure(scap * (uint64_t)record_kind + 16))) return rc;
             sh = acgpu_shard{};
-            sh.d_hay = (const uint16_t *)sl.dev.p;
+            sh.d_hay = (const uint16_t *)s->b.dev[si].p;
             sh.n_units = p.total;
             sh.own_begin = p.own_begin;
             sh.own_end = p.own_end;
@@ -248,7 +249,7 @@ int scan_slot(acgpu_stream *s, Slot &sl, int record_kind, void *out, uint64_t ca
             sh.text_end = sl.final ? 1 : 0;
             sh.chain_entry = (int64_t)(s->chain_entry > sl.carry_pos ? s->chain_entry - sl.carry_pos : 0);
             if (mode != ACGPU_MODE_SHORTEST) sh.chain_entry = std::max<int64_t>(sh.chain_entry, (int64_t)p.own_begin);
-            rc = match_shard(a, *d, &sh, record_kind, s->out_dev.p, scap, &n, nullptr, nullptr, /*readable=*/true);
+            rc = match_shard(a, *d, &sh, record_kind, s->b.out_dev.p, scap, &n, nullptr, nullptr, /*readable=*/true);
             if (rc == ACGPU_E_OVERFLOW) {
                 scap = n + n / 8 + 16;
                 continue;
@@ -275,25 +276,25 @@ int scan_slot(acgpu_stream *s, Slot &sl, int record_kind, void *out, uint64_t ca
                 if (n_done && n_done <= cap) std::memcpy(s->undelivered.data(), out, n_done * (size_t)record_kind);
                 dst = s->undelivered.data() + n_done * (size_t)record_kind;
             }
-            if (s->out_pin_bytes < bytes) {
-                if (s->out_pin) (void)hipHostFree(s->out_pin);
-                s->out_pin = nullptr;
-                s->out_pin_bytes = 0;
-                HIP_TRY(hipHostMalloc(&s->out_pin, bytes + bytes / 4 + 4096, hipHostMallocMapped));
-                HIP_TRY(hipHostGetDevicePointer(&s->out_pin_dev, s->out_pin, 0));
-                s->out_pin_bytes = bytes + bytes / 4 + 4096;
+            if (s->b.out_pin_bytes < bytes) {
+                if (s->b.out_pin) (void)hipHostFree(s->b.out_pin);
+                s->b.out_pin = nullptr;
+                s->b.out_pin_bytes = 0;
+                HIP_TRY(hipHostMalloc(&s->b.out_pin, bytes + bytes / 4 + 4096, hipHostMallocMapped));
+                HIP_TRY(hipHostGetDevicePointer(&s->b.out_pin_dev, s->b.out_pin, 0));
+                s->b.out_pin_bytes = bytes + bytes / 4 + 4096;
             }
             {
                 const uint64_t n16 = (bytes + 15) / 16;
-                hipLaunchKernelGGL(k_copy_out, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, nullptr, (const uint4 *)s->out_dev.p,
-                                   (uint4 *)s->out_pin_dev, n16);
+                hipLaunchKernelGGL(k_copy_out, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, nullptr, (const uint4 *)s->b.out_dev.p,
+                                   (uint4 *)s->b.out_pin_dev, n16);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipStreamSynchronize(nullptr));
             }
             if (!delta) {
-                std::memcpy(dst, s->out_pin, bytes);
+                std::memcpy(dst, s->b.out_pin, bytes);
             } else {
-                const int32_t *src = reinterpret_cast<const int32_t *>(s->out_pin);
+                const int32_t *src = reinterpret_cast<const int32_t *>(s->b.out_pin);
                 int32_t *r = reinterpret_cast<int32_t *>(dst);
                 const int cols = record_kind / 4;
                 for (uint64_t i = 0; i < n; ++i) {
@@ -307,6 +308,21 @@ int scan_slot(acgpu_stream *s, Slot &sl, int record_kind, void *out, uint64_t ca
     }
     s->chain_entry = chain_exit;
     sl.pending = false;
+    return ACGPU_OK;
+}
+
+// the stream's buffers: those a closed stream on this device left to the automaton, or none yet (they grow on demand)
+int adopt_bufs(acgpu_stream *s) {
+    if (s->b.device >= 0) return ACGPU_OK;
+    if (s->device < 0) HIP_TRY(hipGetDevice(&s->device));
+    std::lock_guard<std::mutex> l(s->a->mu);
+    for (size_t i = 0; i < s->a->stream_cache.size(); ++i) {
+        if (s->a->stream_cache[i].device != s->device) continue;
+        s->b = std::move(s->a->stream_cache[i]);
+        s->a->stream_cache.erase(s->a->stream_cache.begin() + (ptrdiff_t)i);
+        return ACGPU_OK;
+    }
+    s->b.device = s->device;
     return ACGPU_OK;
 }
 
@@ -327,7 +343,8 @@ int feed_pipelined(acgpu_stream *s, const uint16_t *units, uint64_t n_units, int
         return ACGPU_OK;
     }
     if (!s->started) {
-        HIP_TRY(hipGetDevice(&s->device));
+        if (s->device < 0) HIP_TRY(hipGetDevice(&s->device));
+        { const int arc = adopt_bufs(s); if (arc) return arc; }
         {   // the transfers at the LOWEST priority: where they run as copy kernels they must not hold the scan's CUs
             int lo = 0, hi = 0;
             HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -344,18 +361,19 @@ int feed_pipelined(acgpu_stream *s, const uint16_t *units, uint64_t n_units, int
     if (n_carry + n_units >= (1ull << 30)) return ACGPU_E_INVALID;
     Slot &sl = s->slot[s->cur];
     Slot &prev = s->slot[1 - s->cur];
+    const int si = s->cur;
     const FeedPlan p = plan_feed(t, n_carry, n_units, s->own_from, s->carry_pos, final != 0);
     int rc;
-    if (sl.pin_bytes < p.total * 2 + 64) {
-        if (sl.pin) (void)hipHostFree(sl.pin);
-        sl.pin = nullptr;
-        sl.pin_bytes = 0;
+    if (s->b.pin_bytes[si] < p.total * 2 + 64) {
+        if (s->b.pin[si]) (void)hipHostFree(s->b.pin[si]);
+        s->b.pin[si] = nullptr;
+        s->b.pin_bytes[si] = 0;
         const size_t want = p.total * 2 + p.total / 2 + 4096;
-        HIP_TRY(hipHostMalloc(&sl.pin, want, hipHostMallocNumaUser)); // (pages where the copying threads run, not on the device's node: 3x the copy rate)
-        sl.pin_bytes = want;
+        HIP_TRY(hipHostMalloc(&s->b.pin[si], want, hipHostMallocNumaUser)); // (pages where the copying threads run, not on the device's node: 3x the copy rate)
+        s->b.pin_bytes[si] = want;
     }
-    if ((rc = sl.dev.ensure(p.total * 2 + 64))) return rc;
-    uint16_t *h = reinterpret_cast<uint16_t *>(sl.pin);
+    if ((rc = s->b.dev[si].ensure(p.total * 2 + 64))) return rc;
+    uint16_t *h = reinterpret_cast<uint16_t *>(s->b.pin[si]);
     if (n_carry) std::memcpy(h, s->carry.data(), n_carry * 2);
     // the chunk: pieces of 1 MiB copied by the pool's threads (units == our own staging memory: acgpu_stream_reserve --
     // nothing to copy).  The threads only copy; the ONE transfer of the whole buffer is enqueued by the calling thread behind
@@ -389,7 +407,7 @@ int feed_pipelined(acgpu_stream *s, const uint16_t *units, uint64_t n_units, int
         s->finished = true; // (a stream that failed half way cannot go on)
         return scan_rc;
     }
-    if (p.total) HIP_TRY(hipMemcpyAsync(sl.dev.p, sl.pin, p.total * 2, hipMemcpyHostToDevice, s->copy_stream));
+    if (p.total) HIP_TRY(hipMemcpyAsync(s->b.dev[si].p, s->b.pin[si], p.total * 2, hipMemcpyHostToDevice, s->copy_stream));
     HIP_TRY(hipEventRecord(sl.arrived, s->copy_stream));
     // commit this chunk
     sl.plan = p;
@@ -452,17 +470,17 @@ int acgpu_stream_reserve(acgpu_stream *s, uint64_t n_units, uint16_t **buf) {
     *buf = nullptr;
     const uint64_t n_carry = s->carry.size();
     if (n_carry + n_units >= (1ull << 30)) return ACGPU_E_INVALID;
-    Slot &sl = s->slot[s->cur];
-    if (sl.pin_bytes < (n_carry + n_units) * 2 + 64) {
-        if (s->device < 0) HIP_TRY(hipGetDevice(&s->device));
-        if (sl.pin) (void)hipHostFree(sl.pin);
-        sl.pin = nullptr;
-        sl.pin_bytes = 0;
+    const int si = s->cur;
+    { const int arc = adopt_bufs(s); if (arc) return arc; }
+    if (s->b.pin_bytes[si] < (n_carry + n_units) * 2 + 64) {
+        if (s->b.pin[si]) (void)hipHostFree(s->b.pin[si]);
+        s->b.pin[si] = nullptr;
+        s->b.pin_bytes[si] = 0;
         const size_t want = (n_carry + n_units) * 2 + (n_carry + n_units) / 2 + 4096;
-        HIP_TRY(hipHostMalloc(&sl.pin, want, hipHostMallocNumaUser)); // (pages where the copying threads run, not on the device's node: 3x the copy rate)
-        sl.pin_bytes = want;
+        HIP_TRY(hipHostMalloc(&s->b.pin[si], want, hipHostMallocNumaUser)); // (pages where the copying threads run, not on the device's node: 3x the copy rate)
+        s->b.pin_bytes[si] = want;
     }
-    *buf = reinterpret_cast<uint16_t *>(sl.pin) + n_carry;
+    *buf = reinterpret_cast<uint16_t *>(s->b.pin[si]) + n_carry;
     return ACGPU_OK;
 }
 
