@@ -100,7 +100,7 @@ int set_device(int dev) {
 
 // one synchronous native call on the sub-range [own_begin, w_end) of a share, into a grow-only private buffer
 int scan_window(acgpu_automaton *a, Share &s, uint64_t w_end, int64_t entry, DevBuf &dst, int record_kind, uint64_t *n, int64_t *exit) {
-    uint64_t cap = dst.bytes / (uint64_t)record_kind;
+    uint64_t cap = (dst.bytes > 16 ? dst.bytes - 16 : 0) / (uint64_t)record_kind; // (what it holds already: no growth per call)
     if (cap < 1024) cap = 1024;
     for (;;) {
         int rc = dst.ensure(cap * (uint64_t)record_kind + 16);

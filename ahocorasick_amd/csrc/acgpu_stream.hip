@@ -236,7 +236,8 @@ int scan_slot(acgpu_stream *s, Slot &sl, int record_kind, void *out, uint64_t ca
             fprintf(stderr, "[scan] chunk arrived after %.0f us", since());
         }
         HIP_TRY(hipStreamWaitEvent(nullptr, sl.arrived, 0));
-        uint64_t n = 0, scap = std::max<uint64_t>(s->b.out_dev.bytes / (uint64_t)record_kind, 1 << 16);
+        // (what the buffer holds already -- NOT a record more, or the buffer would grow by a quarter with every feed)
+        uint64_t n = 0, scap = std::max<uint64_t>((s->b.out_dev.bytes > 16 ? s->b.out_dev.bytes - 16 : 0) / (uint64_t)record_kind, 1 << 16);
         acgpu_shard sh{};
         for (;;) { // (the scan keeps ALL its records: the caller's capacity only decides what this feed can hand over)
             if ((rc = s->b.out_dev.ensure(scap * (uint64_t)record_kind + 16))) return rc;
