@@ -156,7 +156,18 @@ struct StreamBufs {
     DevBuf out_dev;
     void *out_pin = nullptr, *out_pin_dev = nullptr;
     size_t out_pin_bytes = 0;
+    hipStream_t copy_stream = nullptr;          // the chunk transfers' stream (creating one per stream object cost milliseconds)
+    hipEvent_t arrived[2] = {nullptr, nullptr}; // chunk i has arrived on the device
     void release() { // (the caller has made `device` current)
+        if (copy_stream) {
+            (void)hipStreamSynchronize(copy_stream);
+            (void)hipStreamDestroy(copy_stream);
+            copy_stream = nullptr;
+        }
+        for (auto &e : arrived) {
+            if (e) (void)hipEventDestroy(e);
+            e = nullptr;
+        }
         for (int i = 0; i < 2; ++i) {
             if (pin[i]) (void)hipHostFree(pin[i]);
             pin[i] = nullptr;

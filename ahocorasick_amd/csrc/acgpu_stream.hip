@@ -153,7 +153,6 @@ class CopyPool {
 
 // one chunk on its way: its units in pinned host memory and (soon) in device memory, and what its scan will be
 struct Slot {
-    hipEvent_t arrived = nullptr;
     bool pending = false; // transferred (or on its way), not yet scanned
     FeedPlan plan{};
     uint64_t carry_pos = 0; // global position of buffer unit 0
@@ -175,7 +174,6 @@ struct acgpu_stream {
     int device = -1;
     Slot slot[2];
     int cur = 0; // the slot the NEXT feed fills
-    hipStream_t copy_stream = nullptr;
     CopyPool *pool = nullptr;
     // the chunks' staging memory, and the records of one scan: a device buffer, and pinned host memory they are copied back to (a
     // hipMemcpy straight into the caller's pageable memory cost more than the scan of a chunk; kernels writing records into
@@ -191,12 +189,7 @@ struct acgpu_stream {
             int cur_dev = -1;
             const bool have = hipGetDevice(&cur_dev) == hipSuccess;
             (void)hipSetDevice(device);
-            if (copy_stream) {
-                (void)hipStreamSynchronize(copy_stream);
-                (void)hipStreamDestroy(copy_stream);
-            }
-            for (auto &sl : slot)
-                if (sl.arrived) (void)hipEventDestroy(sl.arrived);
+            if (b.copy_stream) (void)hipStreamSynchronize(b.copy_stream); // (nothing of this stream stays in flight)
             if (b.device >= 0 && a) { // (the buffers outlive the stream: the next one on this device takes them over)
                 std::lock_guard<std::mutex> l(a->mu);
                 try {
@@ -232,10 +225,10 @@ int scan_slot(acgpu_stream *s, Slot &sl, int record_kind, void *out, uint64_t ca
         const auto t0 = std::chrono::steady_clock::now();
         auto since = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); };
         if (trace) {
-            HIP_TRY(hipEventSynchronize(sl.arrived));
+            HIP_TRY(hipEventSynchronize(s->b.arrived[si]));
             fprintf(stderr, "[scan] chunk arrived after %.0f us", since());
         }
-        HIP_TRY(hipStreamWaitEvent(nullptr, sl.arrived, 0));
+        HIP_TRY(hipStreamWaitEvent(nullptr, s->b.arrived[si], 0));
         // (what the buffer holds already -- NOT a record more, or the buffer would grow by a quarter with every feed)
         uint64_t n = 0, scap = std::max<uint64_t>((s->b.out_dev.bytes > 16 ? s->b.out_dev.bytes - 16 : 0) / (uint64_t)record_kind, 1 << 16);
         acgpu_shard sh{};
@@ -346,12 +339,13 @@ int feed_pipelined(acgpu_stream *s, const uint16_t *units, uint64_t n_units, int
     if (!s->started) {
         if (s->device < 0) HIP_TRY(hipGetDevice(&s->device));
         { const int arc = adopt_bufs(s); if (arc) return arc; }
-        {   // the transfers at the LOWEST priority: where they run as copy kernels they must not hold the scan's CUs
+        if (!s->b.copy_stream) { // the transfers at the LOWEST priority: where they run as copy kernels they must not hold the scan's CUs
             int lo = 0, hi = 0;
             HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            HIP_TRY(hipStreamCreateWithPriority(&s->copy_stream, hipStreamNonBlocking, lo));
+            HIP_TRY(hipStreamCreateWithPriority(&s->b.copy_stream, hipStreamNonBlocking, lo));
         }
-        for (auto &sl : s->slot) HIP_TRY(hipEventCreateWithFlags(&sl.arrived, hipEventDisableTiming));
+        for (auto &e : s->b.arrived)
+            if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         const int workers = (int)std::min<unsigned>(5, std::max(1u, std::thread::hardware_concurrency() / 2));
         s->pool = new (std::nothrow) CopyPool(workers);
         if (!s->pool) return ACGPU_E_NOMEM;
@@ -404,12 +398,12 @@ int feed_pipelined(acgpu_stream *s, const uint16_t *units, uint64_t n_units, int
                        (unsigned long long)n_units, t_started, t_scanned, since());
     if (scan_rc == ACGPU_OK && copy_rc.load() != ACGPU_OK) scan_rc = copy_rc.load();
     if (scan_rc != ACGPU_OK) {
-        (void)hipStreamSynchronize(s->copy_stream);
+        (void)hipStreamSynchronize(s->b.copy_stream);
         s->finished = true; // (a stream that failed half way cannot go on)
         return scan_rc;
     }
-    if (p.total) HIP_TRY(hipMemcpyAsync(s->b.dev[si].p, s->b.pin[si], p.total * 2, hipMemcpyHostToDevice, s->copy_stream));
-    HIP_TRY(hipEventRecord(sl.arrived, s->copy_stream));
+    if (p.total) HIP_TRY(hipMemcpyAsync(s->b.dev[si].p, s->b.pin[si], p.total * 2, hipMemcpyHostToDevice, s->b.copy_stream));
+    HIP_TRY(hipEventRecord(s->b.arrived[si], s->b.copy_stream));
     // commit this chunk
     sl.plan = p;
     sl.carry_pos = s->carry_pos;
