@@ -633,7 +633,16 @@ def cpu_baseline(cfg_name, kws, matcher, sample_units):
     core, old = None, None
     try:
         old = os.sched_getaffinity(0)
-        core = max(old)  # (the launcher's own threads tend to sit on the low cores)
+        # the core this thread is running on (field 39 of /proc/self/stat): pinning it THERE keeps it -- and everything it
+        # allocates afterwards -- on its NUMA node (pinning to the highest core moved the process to the far socket, and the
+        # host-side copies of the measurements behind this one ran at a third of their rate)
+        try:
+            with open("/proc/thread-self/stat") as f:
+                core = int(f.read().rsplit(")", 1)[1].split()[36])
+            if core not in old:
+                core = max(old)
+        except (OSError, ValueError, IndexError):
+            core = max(old)
         os.sched_setaffinity(0, {core})
     except (AttributeError, OSError):
         core = None
