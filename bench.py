@@ -708,17 +708,19 @@ def end_to_end_stream(auto, matcher, with_ids, sample_units):
     chunk = 1 << 22
     best = None
     for pipelined in (False, True):
-        for _ in range(2):
-            st = Stream(auto, with_ids=with_ids, pipelined=pipelined)
+        dts = []
+        for _ in range(4):  # (the first pass allocates the staging buffers; median of the other three: a pass now and then holds a
+            st = Stream(auto, with_ids=with_ids, pipelined=pipelined)  # 20-40 ms stall of the host that is not the library's)
             t0 = time.perf_counter()
             total = 0
             for o in range(0, n, chunk):
                 total += len(st.feed(hay[o:o + chunk], final=o + chunk >= n, cap=chunk // 8))
-            dt = time.perf_counter() - t0
+            dts.append(time.perf_counter() - t0)
             st.close()
+        dt = float(np.median(dts[1:]))
         if pipelined:
             best = {"value": round(2.0 * n / dt / 1e6, 1), "unit": "MB/s", "what": "acgpu_stream_feed, pipelined form, 2^%d units in 2^22-unit "
-                    "chunks from pageable host memory, %d records" % (int(np.log2(n)), total), "synchronous_form_mbps": sync_rate}
+                    "chunks from pageable host memory, %d records; median of 3 passes" % (int(np.log2(n)), total), "synchronous_form_mbps": sync_rate}
         else:
             sync_rate = round(2.0 * n / dt / 1e6, 1)
     para = np.ascontiguousarray(hay[:472])

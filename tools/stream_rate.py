@@ -15,7 +15,8 @@ for name, mode, kws, cs, hay in (
          np.asarray(list(synth.ALPHA_LOWER[:8]) + [32, 32], dtype=np.uint16)[np.random.default_rng(5).integers(0, 10, n)])):
     a = Automaton(mode, kws, cs, word_chars=default_word_chars() if mode == N.MODE_WHOLEWORD else None)
     for form in ("synchronous", "pipelined", "pipelined, chunks written into the reserved staging memory"):
-        for rep in range(2):
+        dts = []
+        for rep in range(4):  # (first pass: the staging buffers are allocated; median of the other three)
             s = Stream(a, with_ids=True, pipelined=form != "synchronous")
             t0 = time.perf_counter()
             total = 0
@@ -26,6 +27,7 @@ for name, mode, kws, cs, hay in (
                     np.copyto(v, c)
                     c = v
                 total += len(s.feed(c, final=o + chunk >= n, cap=chunk // 8))
-            dt = time.perf_counter() - t0
+            dts.append(time.perf_counter() - t0)
             s.close()
+        dt = float(np.median(dts[1:]))
         print("%-20s %-62s %d units in %d-unit chunks: %.1f ms, %.1f GB/s of UTF-16, %d records" % (name, form, n, chunk, dt * 1e3, 2.0 * n / dt / 1e9, total), flush=True)
