@@ -650,6 +650,31 @@ __global__ __launch_bounds__(kLScanBlock, 8) void k_longest_walk_list(DevTables 
             uint32_t node = 0, j = p;
             best = 0;
             best_node = 0;
+            // (large dictionaries: a few hundred of a million rows fit LDS, nearly EVERY walk comes through here.)  The first 16
+            // units of text up front -- two loads in flight together -- so that a step waits for the table alone, not for the
+            // text and then the table
+            if (p + 16u <= nu) {
+                const Units8 u0 = *reinterpret_cast<const Units8 *>(hay + p), u1 = *reinterpret_cast<const Units8 *>(hay + p + 8);
+                const uint32_t w[8] = {u0.d[0], u0.d[1], u0.d[2], u0.d[3], u1.d[0], u1.d[1], u1.d[2], u1.d[3]};
+                bool going = true;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    if (going) {
+                        const uint32_t dlt = ((w[k >> 1] >> (16 * (k & 1))) & 0xffffu) - base;
+                        const uint32_t g = glob[node * n + (dlt < span ? dlt + 1u : 0u)];
+                        if (!g) {
+                            going = false;
+                        } else {
+                            node = g & 0x7fffffffu;
+                            if (g >> 31) {
+                                best = (uint32_t)k + 1u;
+                                best_node = node;
+                            }
+                        }
+                    }
+                }
+                j = going ? p + 16u : nu; // (a walk that has ended skips the loop below)
+            }
             while (j < nu) {
                 const uint32_t dlt = hay[j] - base;
                 const uint32_t g = glob[node * n + (dlt < span ? dlt + 1u : 0u)];
