@@ -518,7 +518,10 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         ScanLaunch L{};
         L.block = scan_block_threads();
         L.grid = d.n_cu * (int)std::max<int64_t>(1, tunables().blocks_per_cu);
-        const uint64_t lanes = (uint64_t)L.grid * L.block;
+        // tile_debug bit 2^43: the one-chain kernel of rounds 1-3 (A/B); bit 2^45 (ablation build): no lookups in global memory
+        L.debug = (uint32_t)((tunables().tile_debug >> 43) & 5);
+        if (sh->n_units < 64) L.debug |= 1u; // (k_ac_dfa takes the buffer's last vector whole: the old kernel reads unit by unit)
+        const uint64_t lanes = (uint64_t)L.grid * L.block * (uint64_t)((L.debug & 1u) ? 1 : std::max(1, scan_chains(d.T)));
         uint64_t C = tunables().chunk_units > 0 ? (uint64_t)tunables().chunk_units
                                                 : std::max<uint64_t>({(own_len + lanes - 1) / lanes, 256, 16ull * halo});
         C = std::max<uint32_t>(8, round_up8(C));
@@ -531,7 +534,7 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         L.own_begin = (uint32_t)sh->own_begin;
         L.own_end = (uint32_t)sh->own_end;
         L.cap = scratch_cap; // every slot below min(counter, scratch_cap) must be written: the permute pass reads them all
-        L.lds_bytes = scan_queue_bytes(L.block) + (size_t)d.T.lds_entries * t.entry_bytes;
+        L.lds_bytes = scan_queue_bytes(L.block) + (size_t)d.T.lds_entries * t.entry_bytes + 16;
         if ((rc = d.chunk_counts.ensure((size_t)L.n_chunks * 4))) return rc;
         if ((rc = d.offsets.ensure((size_t)L.n_chunks * 8))) return rc;
         if ((rc = d.scan_tmp.ensure(((size_t)L.n_chunks / 2048 + 2) * 8))) return rc;

@@ -76,6 +76,7 @@ ACGPU_HD inline uint32_t l2_gram(const uint32_t *c, uint32_t K) { // the K-gram,
 ACGPU_HD inline uint32_t l2_hash(uint32_t gram) { return l2_mul24(gram ^ (gram >> 13), 0x9E3779u); }
 ACGPU_HD inline uint32_t l2_word(uint32_t h) { return (((h >> 11) & 0x1fffu) * kL2Words) >> 13; }
 // the LARGE form of the same filter (dictionaries that saturate 22.5 KB): 2 MB in global memory, resident in the L2 cache
+constexpr uint32_t kDfaLdsBytes = 127 * 1024; // k_ac_dfa: static LDS for the hot rows (next to 32 KB of record queues)
 constexpr uint32_t kL2BigWords = 1u << 19;
 ACGPU_HD inline uint32_t l2_word_big(uint32_t h) { return (l2_mul24(h ^ (h >> 11), 0x85EBCBu) >> 4) & (kL2BigWords - 1u); }
 ACGPU_HD inline uint32_t l2_pattern(uint32_t h) {
@@ -268,7 +269,7 @@ struct DevTables {
 struct Tunables {
     std::atomic<int64_t> chunk_units{0};      // 0 = auto
     std::atomic<int64_t> blocks_per_cu{1};
-    std::atomic<int64_t> lds_table_bytes{96 * 1024};
+    std::atomic<int64_t> lds_table_bytes{127 * 1024};
     std::atomic<int64_t> force_sparse{0};
     std::atomic<int64_t> dense_budget_bytes{1ll << 30};
     std::atomic<int64_t> force_kernel{0};     // 0 auto, 1 = DFA chunk scan, 2 = k-gram tile scan (when the filter exists)

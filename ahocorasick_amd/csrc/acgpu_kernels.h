@@ -27,6 +27,7 @@ struct ScanLaunch {
     uint32_t *d_chunk_counts;      // n_chunks entries
     int grid, block;
     size_t lds_bytes;
+    uint32_t debug; // 1: the one-chain kernel (k_ac_scan_dense) where k_ac_dfa would run
 };
 
 // AC-all scan: dense (state x class table, hot rows in LDS) or sparse (hashed goto + fail links).
@@ -160,6 +161,7 @@ hipError_t launch_synth_fill(uint16_t *d_dst, uint64_t n, uint64_t start, uint64
                              uint32_t table_len, hipStream_t stream);
 
 int scan_block_threads();
+int scan_chains(const DevTables &t); // chunks per lane of the dense chunk scan: the host sizes the chunks for lanes x this
 size_t scan_queue_bytes(int block_threads);
 
 } // namespace acgpu

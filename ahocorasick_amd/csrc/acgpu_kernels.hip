@@ -20,6 +20,9 @@ namespace acgpu {
 #ifndef ACGPU_SCAN_MINBLOCKS
 #define ACGPU_SCAN_MINBLOCKS 1
 #endif
+#ifndef ACGPU_DFA_CHAINS
+#define ACGPU_DFA_CHAINS 2 // chunks per lane in k_ac_dfa
+#endif
 constexpr int kScanBlock = 1024;                 // 16 waves: one workgroup per CU shares one LDS copy of the hot rows
 constexpr int kQueueCap = 128;                   // records per wave queue
 constexpr int kQueueFlush = kQueueCap - kWave;   // flush when fewer than 64 free slots remain
@@ -187,6 +190,155 @@ __global__ __launch_bounds__(kScanBlock, ACGPU_SCAN_MINBLOCKS) void k_ac_scan_de
     ac_scan_body(T, L, step, wq);
 }
 
+// ---- k_ac_dfa: the dense chunk scan as straight-line code, NCH chunks per lane -----------------------------
+// What bounds a chunk scan is the chain state -> table entry -> state: one LDS read or one cached gather per unit, each
+// waiting for the one before.  k_ac_scan_dense ran ONE such chain per lane behind ~30 instructions per unit (class branch,
+// LDS-or-global branch, range tests and a ballot per unit); here
+//  * a lane owns NCH chunks and steps them alternately -- NCH independent chains per lane, their lookups in flight together;
+//  * a step is branch-free: class by subtract / compare / select (range classes; table classes: the 8 class loads of a
+//    vector are issued together, ahead of its steps), index by one 24-bit multiply-add, the LDS read with a clamped index AND
+//    the global read with a masked index (a lane whose row is in LDS reads entry 0: one cached line for the whole wave) both
+//    issued unconditionally, one select;
+//  * outputs are looked for once per 8 units (the maximum of the 8 states against first_out, one ballot); the rare vector
+//    with an output re-examines its 8 saved states, in order, through the same emit_chain / wave queue as before.
+// Records, chunk counts and ordering are k_ac_scan_dense's: chunk = the owned range's chunk_units-slice the match ends in.
+template <typename E, bool RANGE, bool GLOB, int NCH>
+__global__ __launch_bounds__(kScanBlock) void k_ac_dfa(DevTables T, ScanLaunch L) {
+    // (static LDS: addresses are immediates; the host never stages more than kDfaLdsBytes of rows)
+    __shared__ __attribute__((aligned(16))) ScratchRec queues[(kScanBlock / kWave) * kQueueCap];
+    __shared__ __attribute__((aligned(16))) unsigned char tab8[kDfaLdsBytes];
+    E *tab = reinterpret_cast<E *>(tab8);
+    const E *glob = reinterpret_cast<const E *>(T.dfa);
+    for (uint32_t i = threadIdx.x; i < T.lds_entries; i += blockDim.x) tab[i] = glob[i];
+    __syncthreads();
+    WaveQueue wq{queues + (threadIdx.x / kWave) * kQueueCap, 0};
+    const uint32_t row_bytes = T.n_cls * (uint32_t)sizeof(E), fo = T.first_out;
+    const uint32_t lds_bytes = T.lds_entries * (uint32_t)sizeof(E);
+    const uint32_t lds_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_bytes ? lds_bytes - (uint32_t)sizeof(E) : 0u));
+    const uint32_t base = T.cls_base, span = T.cls_span;
+    const uint16_t *lut = T.cls_lut;
+    const uint32_t halo = T.max_len > 0 ? T.max_len - 1 : 0;
+    const uint32_t lanes_total = gridDim.x * blockDim.x, gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t rounds = (uint32_t)(((uint64_t)L.n_chunks + (uint64_t)lanes_total * NCH - 1) / ((uint64_t)lanes_total * NCH));
+    const uint32_t n_line = (L.chunk_units + halo + 63 + 63) / 64; // chunk + halo + alignment slack, in 128-byte lines
+    for (uint32_t round = 0; round < rounds; ++round) {
+        uint32_t chunk[NCH], cb[NCH], ce[NCH], rs[NCH], s[NCH], rank[NCH];
+        bool valid[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const uint64_t ck = ((uint64_t)round * NCH + c) * lanes_total + gtid;
+            valid[c] = ck < L.n_chunks;
+            chunk[c] = (uint32_t)ck;
+            cb[c] = valid[c] ? L.own_begin + chunk[c] * L.chunk_units : L.own_end;
+            ce[c] = cb[c] + L.chunk_units;
+            if (ce[c] > L.own_end || ce[c] < cb[c]) ce[c] = L.own_end;
+            rs[c] = (cb[c] > halo ? cb[c] - halo : 0u) & ~63u; // whole lines (see ac_scan_body)
+            s[c] = 0;
+            rank[c] = 0;
+        }
+        for (uint32_t it = 0; it < n_line; ++it) {
+            uint4 line[NCH][8];
+            bool tail = false; // some line of the wave reaches beyond the buffer (its last chunks only)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) tail = tail || (uint64_t)rs[c] + (uint64_t)it * 64 + 64 > (uint64_t)L.n_units;
+            if (!__any(tail)) {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) line[c][k] = *reinterpret_cast<const uint4 *>(L.d_hay + rs[c] + it * 64 + k * 8);
+            } else { // the vector that holds the buffer's last 8 units, shifted down: units behind the buffer read as zero
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const uint64_t v = (uint64_t)rs[c] + (uint64_t)it * 64 + k * 8;
+                        const uint64_t over = v + 8 > (uint64_t)L.n_units ? v + 8 - L.n_units : 0; // units of the vector behind the buffer
+                        const uint4 w = *reinterpret_cast<const uint4 *>(L.d_hay + (over ? (uint64_t)L.n_units - 8 : v));
+                        uint64_t lo = (uint64_t)w.x | ((uint64_t)w.y << 32), hi = (uint64_t)w.z | ((uint64_t)w.w << 32);
+                        const uint32_t sh = (uint32_t)min(over, (uint64_t)8);
+                        if (sh >= 8) { lo = 0; hi = 0; }
+                        else if (sh >= 4) { lo = hi >> (16 * (sh - 4)); hi = 0; }
+                        else if (sh) { lo = (lo >> (16 * sh)) | (hi << (64 - 16 * sh)); hi >>= 16 * sh; }
+                        line[c][k] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                uint32_t cls[NCH][8], st[NCH][8];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const uint32_t words[4] = {line[c][k].x, line[c][k].y, line[c][k].z, line[c][k].w};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const uint32_t unit = (j & 1) ? words[j >> 1] >> 16 : words[j >> 1] & 0xffffu;
+                        if (RANGE) { // (classes as byte offsets into a row)
+                            const uint32_t d = unit - base;
+                            cls[c][j] = d < span ? (d + 1u) * (uint32_t)sizeof(E) : 0u;
+                        } else {
+                            cls[c][j] = (uint32_t)lut[unit] * (uint32_t)sizeof(E);
+                        }
+                    }
+                }
+                uint32_t mx = 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        const uint32_t off = __umul24(s[c], row_bytes) + cls[c][j]; // byte offset of the entry
+                        uint32_t nx = *reinterpret_cast<const E *>(reinterpret_cast<const unsigned char *>(tab) + min(off, lds_last));
+                        if (GLOB) {
+#ifdef ACGPU_ABLATION // (timing only, bit 4: no lookups in global memory -- such a state goes to the root's entry 0 instead)
+                            const uint32_t g = *reinterpret_cast<const E *>(reinterpret_cast<const unsigned char *>(glob) + (off >= lds_bytes && !(L.debug & 4u) ? off : 0u));
+#else
+                            const uint32_t g = *reinterpret_cast<const E *>(reinterpret_cast<const unsigned char *>(glob) + (off >= lds_bytes ? off : 0u));
+#endif
+                            nx = off >= lds_bytes ? g : nx;
+                        }
+                        s[c] = nx;
+                        st[c][j] = nx;
+                        mx = max(mx, nx);
+                    }
+                }
+                if (__any(mx >= fo)) { // rare: some state of these 8 steps has an output
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        const uint32_t v = rs[c] + it * 64 + k * 8;
+                        uint32_t m8 = 0;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            m8 |= (valid[c] && st[c][j] >= fo && v + j >= cb[c] && v + j < ce[c]) ? 1u << j : 0u;
+                        while (__any(m8 != 0u)) { // every lane its own lowest step first: a chunk's records in position order
+                            const uint32_t j = m8 ? (uint32_t)__builtin_ctz(m8) : 0u;
+                            uint32_t t = st[c][0];
+#pragma unroll
+                            for (int q = 1; q < 8; ++q) t = j == (uint32_t)q ? st[c][q] : t;
+                            emit_chain(T, m8 ? t : 0u, v + j + 1, rank[c], wq, L.d_scratch, L.cap, L.d_counter);
+                            m8 &= m8 - 1u;
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+            if (valid[c]) L.d_chunk_counts[chunk[c]] = rank[c];
+    }
+    queue_flush(wq, L.d_scratch, L.cap, L.d_counter);
+}
+
+int scan_chains(const DevTables &t) { // chunks per lane of the dense chunk scan (the host sizes the chunks for it); 0: k_ac_dfa cannot run
+    return t.dense && t.n_states < (1u << 24) && t.n_cls < (1u << 22) && (uint64_t)t.n_states * t.n_cls < (1ull << 30) ? ACGPU_DFA_CHAINS : 0;
+}
+
+template <typename E, bool RANGE, bool GLOB>
+static hipError_t launch_ac_dfa(const DevTables &t, const ScanLaunch &l, hipStream_t stream) {
+    auto *k = &k_ac_dfa<E, RANGE, GLOB, ACGPU_DFA_CHAINS>;
+    if ((uint64_t)t.lds_entries * sizeof(E) > (uint64_t)kDfaLdsBytes) return hipErrorInvalidValue; // (lds_states_for keeps below it)
+    hipLaunchKernelGGL(k, dim3(l.grid), dim3(l.block), 0, stream, t, l);
+    return hipSuccess;
+}
+
 __global__ __launch_bounds__(kScanBlock) void k_ac_scan_sparse(DevTables T, ScanLaunch L) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ScratchRec *queues = reinterpret_cast<ScratchRec *>(smem);
@@ -197,6 +349,26 @@ __global__ __launch_bounds__(kScanBlock) void k_ac_scan_sparse(DevTables T, Scan
 
 hipError_t launch_ac_scan(const DevTables &t, const ScanLaunch &l, hipStream_t stream, const char **kernel_name) {
     hipError_t e;
+    if (t.dense && scan_chains(t) > 0 && !(l.debug & 1u)) { // (debug bit 1: the one-chain kernel of rounds 1-3, for A/B)
+        const bool glob = (uint64_t)t.lds_entries < (uint64_t)t.n_states * t.n_cls;
+        const bool u16 = t.entry_bytes == 2;
+#define ACGPU_DFA_CASE(E, R, G, NAME)                                                    \
+    if (u16 == (sizeof(E) == 2) && (t.range_cls != 0) == R && glob == G) {               \
+        e = launch_ac_dfa<E, R, G>(t, l, stream);                                          \
+        if (e != hipSuccess) return e;                                                    \
+        if (kernel_name) *kernel_name = NAME;                                             \
+        return hipGetLastError();                                                         \
+    }
+        ACGPU_DFA_CASE(uint16_t, true, true, "k_ac_dfa<unsigned short, true, true>")
+        ACGPU_DFA_CASE(uint16_t, true, false, "k_ac_dfa<unsigned short, true, false>")
+        ACGPU_DFA_CASE(uint16_t, false, true, "k_ac_dfa<unsigned short, false, true>")
+        ACGPU_DFA_CASE(uint16_t, false, false, "k_ac_dfa<unsigned short, false, false>")
+        ACGPU_DFA_CASE(uint32_t, true, true, "k_ac_dfa<unsigned int, true, true>")
+        ACGPU_DFA_CASE(uint32_t, true, false, "k_ac_dfa<unsigned int, true, false>")
+        ACGPU_DFA_CASE(uint32_t, false, true, "k_ac_dfa<unsigned int, false, true>")
+        ACGPU_DFA_CASE(uint32_t, false, false, "k_ac_dfa<unsigned int, false, false>")
+#undef ACGPU_DFA_CASE
+    }
     if (t.dense) {
         if (t.entry_bytes == 2) {
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ac_scan_dense<uint16_t>),

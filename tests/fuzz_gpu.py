@@ -31,7 +31,7 @@ ALPHABETS = [
     [ord(c) for c in "ab -_.,9"] + [0x00E9, 0x00C9, 0x3002],                                 # separators (WholeWord)
     [ord(c) for c in "abcdefikABCDEFIK 0129-"] + [0x0130, 0x212A],                           # phrases: merged stretches, fold exceptions
 ]
-DEFAULTS = {"chunk_units": 0, "lds_table_bytes": 96 * 1024, "force_sparse": 0, "force_kernel": 0, "region_units": 0,
+DEFAULTS = {"chunk_units": 0, "lds_table_bytes": 127 * 1024, "force_sparse": 0, "force_kernel": 0, "region_units": 0,
             "rdense_budget_bytes": 256 << 20, "tile_debug": 0}
 
 
@@ -80,7 +80,7 @@ def one_case(rng, it):
     if rng.integers(0, 3) == 0:
         knobs["chunk_units"] = int(rng.choice([8, 64, 1000]))
     if rng.integers(0, 3) == 0:
-        knobs["lds_table_bytes"] = int(rng.choice([0, 1024, 96 * 1024]))
+        knobs["lds_table_bytes"] = int(rng.choice([0, 1024, 96 * 1024, 127 * 1024]))
     if rng.integers(0, 4) == 0:
         knobs["force_sparse"] = 1
     if rng.integers(0, 3) == 0:

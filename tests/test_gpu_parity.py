@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _reset_tunables():
     yield
-    for k, v in [("chunk_units", 0), ("blocks_per_cu", 1), ("lds_table_bytes", 96 * 1024), ("force_sparse", 0),
+    for k, v in [("chunk_units", 0), ("blocks_per_cu", 1), ("lds_table_bytes", 127 * 1024), ("force_sparse", 0),
                  ("force_kernel", 0), ("region_units", 0), ("ww_first_seed", 0), ("tile_debug", 0)]:
         N.set_tunable(k, v)
 
@@ -114,6 +114,45 @@ def test_chunking_lds_and_sparse_variants_agree(chunk_units, lds_bytes, sparse):
         want = Oracle(FAM_AC, kws).match(hay).tolist()
         got = AhoCorasickMap(kws, _ids(len(kws)), True).find_all(hay).tolist()
         assert got == want
+
+
+def test_dfa_chunk_scan_two_chunks_per_lane_buffer_tails_and_table_forms():
+    # k_ac_dfa (round 4): every lane steps TWO chunks alternately, looks for outputs once per 8 units and takes the buffer's
+    # last vector whole -- so: haystack lengths around multiples of 8 and 64 (the tail vector, shifted), chunks that end at the
+    # buffer's end, fewer chunks than lanes, 16- and 32-bit tables (more than 65536 states), range classes and table classes
+    # (case-insensitive), rows in LDS / partly / not at all; against the oracle and the one-chain kernel of rounds 1-3.
+    N.set_tunable("force_kernel", 1)
+    rng = np.random.default_rng(404)
+    lower26 = list(range(ord("a"), ord("z") + 1))
+    cases = []
+    for alpha, n_kw, max_len in (([ord(c) for c in "ab"], 30, 9), (lower26, 300, 6), ([ord(c) for c in "abcAB"] + [0x00E9, 0x00C9, 0x0130], 40, 5)):
+        for n_units in (64, 65, 71, 72, 127, 1000, 1001, 4097, 20005, 65543):
+            hay, kws = rand_case(rng, alpha, n_kw, max_len, n_units)
+            cases.append((hay, kws))
+    big_kws = [rng.choice(lower26, size=int(rng.integers(4, 10))).astype(np.uint16) for _ in range(22000)]  # > 65536 states: 32-bit entries
+    big_hay = rng.choice(lower26, size=300001).astype(np.uint16)
+    for k in range(0, 300001 - 10, 977):
+        kw = big_kws[k % len(big_kws)]
+        big_hay[k:k + len(kw)] = kw
+    cases.append((big_hay, big_kws))
+    seen = set()
+    for hay, kws in cases:
+        for cs in (True, False):
+            want = Oracle(FAM_AC, kws, case_sensitive=cs, lower=LOWER).match(hay).tolist()
+            m = AhoCorasickMap(kws, _ids(len(kws)), cs)
+            for knobs in ({}, {"lds_table_bytes": 1024}, {"lds_table_bytes": 0, "chunk_units": 64}, {"chunk_units": 8}, {"tile_debug": 1 << 43}):
+                if len(hay) > 100000 and knobs.get("chunk_units") == 8:
+                    continue
+                for k, v in {"lds_table_bytes": 127 * 1024, "chunk_units": 0, "tile_debug": 0, **knobs}.items():
+                    N.set_tunable(k, v)
+                assert m.find_all(hay).tolist() == want, (len(hay), len(kws), cs, knobs)
+            import torch
+            N.set_tunable("tile_debug", 0)
+            d_hay = torch.from_numpy(hay.view(np.int16)).cuda()
+            _, prof = _dev_match(m._auto, d_hay, len(hay), True, len(want) + 16, profile=True)
+            seen.add(prof["scan_kernel"])
+    assert any(k.startswith("k_ac_dfa<unsigned int") for k in seen) and any(k.startswith("k_ac_dfa<unsigned short, true") for k in seen) \
+        and any(k.startswith("k_ac_dfa<unsigned short, false") for k in seen), seen
 
 
 @pytest.mark.parametrize("region_units,min_len", [(512, 1), (512, 2), (1024, 3), (512, 4), (4096, 6), (0, 8)])

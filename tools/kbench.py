@@ -59,11 +59,11 @@ def main():
         cap = n // 2 if args.config == "C4" else n // 128
         dflt = {"longest": {}} if args.config == "C4" else {"shortest": {}} if shortest else {
             "tile": {}, "split": {"force_kernel": 3}, "tile_noverify": {"force_kernel": 2, "tile_debug": 1},
-            "tile_stream": {"force_kernel": 2, "tile_debug": 5}, "dfa": {"force_kernel": 1}}
+            "tile_stream": {"force_kernel": 2, "tile_debug": 5}, "dfa": {"force_kernel": 1}, "dfa_one_chain_r3": {"force_kernel": 1, "tile_debug": 1 << 43, "lds_table_bytes": 96 * 1024}}
     torch.cuda.synchronize()
     d_out = torch.empty((cap, 3), dtype=torch.int32, device="cuda")
     variants = json.loads(args.variants) if args.variants else dflt
-    defaults = {"force_kernel": 0, "tile_debug": 0, "region_units": 0, "chunk_units": 0, "lds_table_bytes": 96 * 1024,
+    defaults = {"force_kernel": 0, "tile_debug": 0, "region_units": 0, "chunk_units": 0, "lds_table_bytes": 127 * 1024,
                 "blocks_per_cu": 1, "reserve_cus": 0}
     res = {k: [] for k in variants}
     info = {}
@@ -75,7 +75,7 @@ def main():
                 N.set_tunable(k, v)
             nout, rc, prof, _ = a.match_device(d_hay.data_ptr(), n, not args.set, d_out.data_ptr(), cap,
                                                stream=torch.cuda.current_stream().cuda_stream, profile=True)
-            if (knobs.get("tile_debug", 0) & 0xfff or knobs.get("tile_debug", 0) >> 32) and N.set_tunable("ablation_build", 0) != 1:
+            if (knobs.get("tile_debug", 0) & 0xfff or (knobs.get("tile_debug", 0) >> 32) & 0x20ff) and N.set_tunable("ablation_build", 0) != 1:
                 raise SystemExit("kbench: the ablation bits of tile_debug need the -DACGPU_ABLATION build "
                                  "(tools/build_variant.sh abl -DACGPU_ABLATION; ACGPU_LIB=ahocorasick_amd/lib_abl/libacgpu.so)")
             if r > 0:
