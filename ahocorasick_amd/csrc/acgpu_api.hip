@@ -125,6 +125,8 @@ int ensure_device(acgpu_automaton *a, DeviceState **out, int lane) {
     if ((rc = upload(*d, t.rhkeys, &T.rhkeys))) return rc;
     if ((rc = upload(*d, t.rhvals, &T.rhvals))) return rc;
     if ((rc = upload(*d, t.tile_lut, &T.tile_lut))) return rc;
+    T.cls_pages = nullptr; T.cls_pages_bytes = (uint32_t)t.cls_pages.size();
+    if (!t.cls_pages.empty() && (rc = upload(*d, t.cls_pages, &T.cls_pages))) return rc;
     if ((rc = upload(*d, t.kg_keys, &T.kg_keys))) return rc;
     if ((rc = upload(*d, t.kg_vals, &T.kg_vals))) return rc;
     T.kg_mask = t.kg_mask; T.hashk = t.hashk;
@@ -189,13 +191,22 @@ bool use_tile_kernel(const HostTables &t) {
     const int64_t f = tunables().force_kernel;
     if (f == 1) return false;
     if (f == 2 || f == 3) return true;
-    // bucketed classes (more than 63 distinct units): every candidate costs a hash probe of its K units, which pays while
-    // the bucket filter still rejects something -- 3000 CJK units, 0.5 GiB: 20 k keywords of 3-8 units (density 0.08)
-    // 0.9 against 4.9 ms for the DFA scan, 100 k (0.33) 2.1 against 5.6 ms, but 20 k keywords of 2-8 units (K = 2,
-    // density 1.0) 3.5 against 1.45 ms.  With K = 4 the tile kernel wins even where the filter passes everything: the
-    // 235 886-word list of the reference's README (52 letters in two ranges, the single letters among the keywords: every
-    // position ends a keyword) 23.5 against 62.9 ms per 2^28 units, both bound by 412 M records (tools/readme_shapes.py, round 4)
-    return !t.hashk || t.filt_density <= 0.5 || t.filt_k >= 4;
+    // The packed forms (range classes, folded or merged ranges) always win: with K = 4 even where the filter passes everything --
+    // the 235 886-word list of the reference's README (52 letters in two ranges, the single letters among the keywords: every
+    // position ends a keyword) 23.5 against 62.9 ms per 2^28 units, both bound by 412 M records (tools/readme_shapes.py).
+    if (t.range_cls || t.fold_range) return true;
+    // The class-table forms (bucketed classes: more than 63 distinct units; or up to 63 classes that no range arithmetic
+    // gives) run the scalar filter -- three LDS reads per unit and, bucketed, a hash probe of its K units per candidate.
+    // Against them (tools/wide_alphabets.py, 2^28 units, round 4): a DFA table that stays in the L2 cache makes k_ac_dfa the
+    // faster kernel as soon as the filter passes more than a tenth of the positions (300 CJK units, 2 k keywords of 2-4
+    // units, a 3.6 MB table, density 0.17: 0.65 against 1.06 ms; config 2's phrases case-insensitive, density 0.24: 0.60
+    // against 1.04 ms; density 0.08: 0.39 ms for the tile kernel), while a table far beyond the cache (3000 CJK units) loses
+    // to the tile kernel whatever the filter passes (20 k keywords of 2-8 units, density 0.54: 2.97 against 5.19 ms; of 1-4
+    // units, 1.03: 10.6 against 25.8 ms, 218 M records; 20 k of 2 units, K = 2: 2.63 against 3.92 ms; only 100 k keywords of
+    // 2-3 units went the other way, 6.8 against 5.35 ms), as does the sparse form (4.7 ms and more).
+    const uint64_t table_bytes = t.dense ? (uint64_t)t.n_states * t.n_cls * (uint64_t)t.entry_bytes : ~0ull;
+    if (table_bytes <= (6ull << 20)) return t.filt_density <= 0.1;
+    return true;
 }
 
 // LONGEST takes the all-matches pipeline only when matches are expected to be sparse
@@ -1321,6 +1332,7 @@ int64_t acgpu_set_tunable(const char *name, int64_t value) {
     else if (!std::strcmp(name, "no_short_keywords")) slot = &t.no_short_keywords;
     else if (!std::strcmp(name, "reserve_cus")) slot = &t.reserve_cus;
     else if (!std::strcmp(name, "no_big_l2")) slot = &t.no_big_l2;
+    else if (!std::strcmp(name, "no_class_pages")) slot = &t.no_class_pages;
     else if (!std::strcmp(name, "split_cand_div")) slot = &t.split_cand_div;
     if (!slot) return -1;
     return slot->exchange(value, std::memory_order_relaxed);

@@ -871,6 +871,33 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
             }
         }
     }
+    // ---- 7b. the class table of the tile kernel's LUT forms as PAGES for LDS ----
+    // tile_lut is 128 KB: a class looked up there is a 2-byte gather from a table eight times a CU's L1 -- a 128-byte line
+    // through the L1 fill path for every unit of the text, which is what bounded the class-table forms.  A
+    // dictionary's units sit in a few 256-unit pages: [256-byte page index][distinct pages, one byte per unit], copied to
+    // LDS behind the filter rows when it fits there (k_ac_tile).
+    t.cls_pages.clear();
+    if (t.filt_k >= 1 && !t.range_cls && !tunables().no_class_pages) {
+        bool bytes_ok = true;
+        for (uint32_t raw = 0; raw < 65536 && bytes_ok; raw++) bytes_ok = t.tile_lut[raw] < 256;
+        if (bytes_ok) {
+            t.cls_pages.assign(256, 0);
+            uint32_t n_pages = 0;
+            for (uint32_t pg = 0; pg < 256; pg++) {
+                uint32_t same = n_pages;
+                for (uint32_t q = 0; q < n_pages && same == n_pages; q++) {
+                    bool eq = true;
+                    for (uint32_t i = 0; i < 256 && eq; i++) eq = t.cls_pages[256 + q * 256 + i] == (uint8_t)t.tile_lut[pg * 256 + i];
+                    if (eq) same = q;
+                }
+                if (same == n_pages) {
+                    for (uint32_t i = 0; i < 256; i++) t.cls_pages.push_back((uint8_t)t.tile_lut[pg * 256 + i]);
+                    n_pages++;
+                }
+                t.cls_pages[pg] = (uint8_t)same;
+            }
+        }
+    }
     return ACGPU_OK;
 }
 

@@ -189,6 +189,7 @@ struct HostTables {
     std::vector<uint32_t> l2_big;   // kL2BigWords: the same keys in the large form; empty unless the small one is saturated
     bool hashk = false;
     std::vector<uint16_t> tile_lut;    // 65536: raw unit -> tile class (== cls_lut when the classes are injective)
+    std::vector<uint8_t> cls_pages;    // the same table as [256-byte page index][distinct 256-byte pages] (acgpu_build.cpp 7b); empty: none
     std::vector<uint64_t> kg_keys;
     std::vector<uint32_t> kg_vals;
     uint32_t kg_mask = 0;
@@ -249,6 +250,8 @@ struct DevTables {
     uint32_t fold_range, fr_base, fr_span, fr_base2, fr_himask; // see HostTables::fold_range
     uint32_t fr_base3, fr_base4, fr_nr;
     const uint16_t *tile_lut;  // tile classes of the LUT mode (cls_lut, or the bucket table)
+    const uint8_t *cls_pages;  // HostTables::cls_pages (nullptr: none), cls_pages_bytes a multiple of 256
+    uint32_t cls_pages_bytes;
     const uint64_t *kg_keys;
     const uint32_t *kg_vals;
     uint32_t kg_mask;
@@ -284,6 +287,7 @@ struct Tunables {
     std::atomic<int64_t> no_merged_ranges{0}; // builder: 1 = mixed-case dictionaries keep the 8-byte-row scalar filter (A/B)
     std::atomic<int64_t> ww_first_seed{0};    // WHOLEWORD builder: first hash seed tried (tests: the fallback seeds end to end)
     std::atomic<int64_t> split_cand_div{8};   // split form: a wave's candidate slice holds one candidate per this many units of its span
+    std::atomic<int64_t> no_class_pages{0};   // builder: 1 = the tile kernel's LUT forms look classes up in global memory (A/B)
     std::atomic<int64_t> no_big_l2{0};        // builder: 1 = large dictionaries keep the (saturated) second level in LDS (A/B)
     std::atomic<int64_t> reserve_cus{0};      // CUs left without a scan workgroup (room for a collective's kernels under the scan)
 };

@@ -502,6 +502,13 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
         for (uint32_t i = threadIdx.x; i < n4; i += blockDim.x) dst4[i] = src4[i];
         for (uint32_t i = n4 * 4 + threadIdx.x; i < T.filt_words; i += blockDim.x) rows32[i] = T.filt_bits[i];
     }
+    // LUT forms with the scalar filter: the class table as pages behind the rows, when it fits (acgpu_build.cpp 7b)
+    const uint32_t pg_off = (T.filt_words * 4u + 15u) & ~15u;
+    const bool cls_lds = !RANGE && !PK && T.cls_pages != nullptr && (uint64_t)pg_off + T.cls_pages_bytes <= sizeof(rows32) && !ACGPU_DBG(L, 1u << 14);
+    if (cls_lds)
+        for (uint32_t i = threadIdx.x; i < T.cls_pages_bytes / 16; i += blockDim.x)
+            reinterpret_cast<uint4 *>(rows32)[pg_off / 16 + i] = reinterpret_cast<const uint4 *>(T.cls_pages)[i];
+    const unsigned char *pg8 = rows8 + pg_off;
     constexpr int D2 = K + 2 < 6 ? K + 2 : 6; // depth of the second-level filter
     // tile geometry of this variant (the names hide the namespace-scope defaults)
     constexpr int kAcVec = L2 ? kL2Vec : acgpu::kAcVec;
@@ -797,6 +804,16 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                 } else {
                     // classes of units v-(K-1) .. v+kAcLaneUnits-1
                     uint32_t a[kAcLaneUnits + K - 1];
+                    if (!RANGE && cls_lds) { // (wave-uniform) two LDS reads per unit: page index, class byte
+                        auto cls_of = [&](uint32_t unit) -> uint32_t { return pg8[256u + ((uint32_t)pg8[unit >> 8] << 8) + (unit & 255u)]; };
+#pragma unroll
+                        for (int j = 0; j < K - 1; ++j) {
+                            const int u = 8 - (K - 1) + j;
+                            a[j] = cls_of((pp[u >> 1] >> (16 * (u & 1))) & 0xffffu);
+                        }
+#pragma unroll
+                        for (int j = 0; j < kAcLaneUnits; ++j) a[K - 1 + j] = cls_of((ww[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+                    } else {
 #pragma unroll
                     for (int j = 0; j < K - 1; ++j) {
                         const int u = 8 - (K - 1) + j; // unit index inside the previous 8
@@ -805,6 +822,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
 #pragma unroll
                     for (int j = 0; j < kAcLaneUnits; ++j)
                         a[K - 1 + j] = tile_class_t<RANGE>(T, (ww[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+                    }
                     // byte offset of the filter row of position v+j = ROWB * index of its (K-1)-gram a[j .. j+K-2],
                     // rolling; every factor is < 2^24, so the full-rate 24-bit multiplies are exact modulo 2^32
                     uint32_t hs = 0;

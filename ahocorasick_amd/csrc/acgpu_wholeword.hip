@@ -897,7 +897,7 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
             probing = probing && ((F.bloom[b1 >> 5] >> (b1 & 31)) & (F.bloom[b2 >> 5] >> (b2 & 31)) & 1u);
         }
         fl.s1 = probing ? ww_slot1(h, T.ww_fat_mask) : 0u;
-        fl.s2 = probing ? ww_slot2(h, g, T.ww_fat_mask) : 0u;
+        fl.s2 = probing ? (ACGPU_DBG(L, 16u) ? fl.s1 ^ 1u : ww_slot2(h, g, T.ww_fat_mask)) : 0u; // 16: ablation (timing only), both slots in one line
         fl.n = cnt > b0 ? min(cnt - b0, (uint32_t)kWave) : 0u;
         fl.probing = probing;
         fl.s = tile0 + j * kTileUnits + p;
