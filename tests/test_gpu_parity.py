@@ -1591,6 +1591,25 @@ def test_large_alphabets_bucketed_classes(seed, ac_kernel):
     from oracle.oracle import FAM_SHORTEST
     assert (Automaton(N.MODE_SHORTEST, kws, False).match_host(hay, True) ==
             Oracle(FAM_SHORTEST, kws, case_sensitive=False, lower=LOWER).match(hay)).all()
+    # round 4: the class table comes from LDS pages (acgpu_build.cpp 7b) -- the same records with the table in global memory
+    # (builder knob no_class_pages), and with a dictionary whose units lie in all 256 pages: 64 KB of pages do not fit behind
+    # the filter rows, the kernel keeps the global table
+    N.set_tunable("no_class_pages", 1)
+    try:
+        a = Automaton(N.MODE_ALL, kws, True)
+    finally:
+        N.set_tunable("no_class_pages", 0)
+    assert (a.match_host(hay, True) == Oracle(FAM_AC, kws, case_sensitive=True, lower=LOWER).match(hay)).all()
+    spread = (np.arange(256, dtype=np.uint32) * 256 + rng.integers(1, 255, 256)).astype(np.uint16)
+    spread = spread[(spread < 0xD800) | (spread > 0xDFFF)]
+    kws2 = [spread[rng.integers(0, len(spread), int(rng.integers(3, 7)))] for _ in range(800)]
+    hay2 = np.concatenate([kws2[int(rng.integers(0, len(kws2)))] if rng.integers(0, 2) else spread[rng.integers(0, len(spread), 3)]
+                           for _ in range(8000)]).astype(np.uint16)
+    a2 = Automaton(N.MODE_ALL, kws2, True)
+    assert a2.info()["n_classes"] > 64 and a2.info()["filter_k"] == 3
+    want2 = Oracle(FAM_AC, kws2, case_sensitive=True, lower=LOWER).match(hay2)
+    got2 = a2.match_host(hay2, True)
+    assert got2.shape == want2.shape and (got2 == want2).all()
 
 
 def test_scratch_slice_overflow_is_redone_with_one_slice():
