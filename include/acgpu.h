@@ -398,10 +398,12 @@ int acgpu_stream_probe(const void *d_buf, uint64_t n_bytes, void *stream, int re
 /* tuning knobs: DEVELOPMENT AND TEST HOOK, not part of the product surface a JVM binds.  Process-wide, read when a call
  * is enqueued; set them only while no match call is running (each knob is a relaxed atomic, so a concurrent reader sees
  * the old or the new value, never a torn one, but a call may then mix settings).  name: "chunk_units",
- * "blocks_per_cu", "lds_table_bytes", "force_sparse", "dense_budget_bytes", "force_kernel" (0 auto, 1 DFA chunk
+ * "blocks_per_cu", "lds_table_bytes" (rows of the state x class table the DFA chunk scan keeps in LDS: default and maximum
+ * 127 KB), "force_sparse", "dense_budget_bytes", "force_kernel" (0 auto, 1 DFA chunk
  * scan, 2 K-gram tile scan), "region_units", "filter_max_bytes", "ww_first_seed" (WHOLEWORD builder: index of the first
  * hash seed tried), and the builder's A/B switches "no_merged_ranges" (dictionaries over several ranges keep the class-table
- * filter), "no_short_keywords" (the filter's K stays at most the shortest keyword); "reserve_cus" (the scan kernels size their
+ * filter), "no_short_keywords" (the filter's K stays at most the shortest keyword), "no_class_pages" (the class-table forms of
+ * the tile kernel look classes up in global memory instead of LDS pages); "reserve_cus" (the scan kernels size their
  * grids for that many CUs fewer: a scan workgroup holds a whole CU's LDS, so k CUs stay free for the kernels of a collective
  * that runs under the scan -- RCCL's all-gather in a multi-GPU job).  Returns the previous value, -1 for an unknown name. */
 int64_t acgpu_set_tunable(const char *name, int64_t value);

@@ -17,9 +17,11 @@ for name, mode, kw in (("AhoCorasick C2 dict", N.MODE_ALL, {}), ("Longest", N.MO
     for n in (64, 4096, 1 << 16, 1 << 20):
         hay = synth.haystack(5, n)
         a.match_host(hay, True)
-        t0 = time.perf_counter()
         reps = 200 if n < (1 << 20) else 50
+        ts = []
         for _ in range(reps):
+            t0 = time.perf_counter()
             r = a.match_host(hay, True)
-        dt = (time.perf_counter() - t0) / reps
-        print("%-20s n=%8d  %8.1f us per call  (%d matches)" % (name, n, dt * 1e6, len(r)))
+            ts.append(time.perf_counter() - t0)
+        ts = np.array(ts) * 1e6  # (the median: one call in a few hundred meets a 50 ms stall of the runtime behind a fresh automaton)
+        print("%-20s n=%8d  %8.1f us per call (median; mean %.1f, max %.1f)  (%d matches)" % (name, n, np.median(ts), ts.mean(), ts.max(), len(r)))
