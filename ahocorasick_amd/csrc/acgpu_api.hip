@@ -46,6 +46,10 @@ uint32_t lds_states_for(const HostTables &t) {
     int64_t budget = tunables().lds_table_bytes;
     const int64_t max_budget = 160 * 1024 - (int64_t)scan_queue_bytes(scan_block_threads()) - 1024;
     budget = std::max<int64_t>(0, std::min(budget, max_budget));
+    // table classes: k_ac_dfa keeps the class pages behind the rows when they are small next to them (at most a quarter of the
+    // budget: 3000 CJK units are 3.5 KB of pages)
+    if (!t.range_cls && !t.dfa_pages.empty() && (int64_t)t.dfa_pages.size() * 2 + 16 <= budget / 4)
+        budget -= (int64_t)t.dfa_pages.size() * 2 + 16;
     uint64_t row = (uint64_t)t.n_cls * t.entry_bytes;
     uint64_t s = row ? (uint64_t)budget / row : 0;
     return (uint32_t)std::min<uint64_t>(s, t.n_states);
@@ -127,6 +131,8 @@ int ensure_device(acgpu_automaton *a, DeviceState **out, int lane) {
     if ((rc = upload(*d, t.tile_lut, &T.tile_lut))) return rc;
     T.cls_pages = nullptr; T.cls_pages_bytes = (uint32_t)t.cls_pages.size();
     if (!t.cls_pages.empty() && (rc = upload(*d, t.cls_pages, &T.cls_pages))) return rc;
+    T.dfa_pages = nullptr; T.dfa_pages_bytes = (uint32_t)t.dfa_pages.size() * 2;
+    if (!t.dfa_pages.empty() && (rc = upload(*d, t.dfa_pages, &T.dfa_pages))) return rc;
     if ((rc = upload(*d, t.kg_keys, &T.kg_keys))) return rc;
     if ((rc = upload(*d, t.kg_vals, &T.kg_vals))) return rc;
     T.kg_mask = t.kg_mask; T.hashk = t.hashk;

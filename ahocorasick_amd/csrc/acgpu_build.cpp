@@ -898,6 +898,25 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
             }
         }
     }
+    // ---- 7c. the same for the DFA chunk scan: cls_lut (any number of classes: 16-bit entries) as pages for k_ac_dfa ----
+    t.dfa_pages.clear();
+    if (t.dense && !t.range_cls && !tunables().no_class_pages) {
+        t.dfa_pages.assign(128, 0); // (uint16 words: the 256-byte index, one byte per page, first)
+        uint8_t *index = reinterpret_cast<uint8_t *>(t.dfa_pages.data());
+        uint32_t n_pages = 0;
+        for (uint32_t pg = 0; pg < 256; pg++) {
+            uint32_t same = n_pages;
+            for (uint32_t q = 0; q < n_pages && same == n_pages; q++)
+                if (std::memcmp(&t.dfa_pages[128 + (size_t)q * 256], &t.cls_lut[pg * 256], 512) == 0) same = q;
+            if (same == n_pages) {
+                t.dfa_pages.insert(t.dfa_pages.end(), t.cls_lut.begin() + pg * 256, t.cls_lut.begin() + pg * 256 + 256);
+                index = reinterpret_cast<uint8_t *>(t.dfa_pages.data());
+                n_pages++;
+            }
+            index[pg] = (uint8_t)same;
+        }
+        if (t.dfa_pages.size() * 2 > 32 * 1024) t.dfa_pages.clear(); // (units all over the plane: the table in global memory it is)
+    }
     return ACGPU_OK;
 }
 

@@ -190,6 +190,7 @@ struct HostTables {
     bool hashk = false;
     std::vector<uint16_t> tile_lut;    // 65536: raw unit -> tile class (== cls_lut when the classes are injective)
     std::vector<uint8_t> cls_pages;    // the same table as [256-byte page index][distinct 256-byte pages] (acgpu_build.cpp 7b); empty: none
+    std::vector<uint16_t> dfa_pages;   // cls_lut as [256-byte page index][distinct pages of 256 uint16] (7c: k_ac_dfa); empty: none
     std::vector<uint64_t> kg_keys;
     std::vector<uint32_t> kg_vals;
     uint32_t kg_mask = 0;
@@ -252,6 +253,8 @@ struct DevTables {
     const uint16_t *tile_lut;  // tile classes of the LUT mode (cls_lut, or the bucket table)
     const uint8_t *cls_pages;  // HostTables::cls_pages (nullptr: none), cls_pages_bytes a multiple of 256
     uint32_t cls_pages_bytes;
+    const uint16_t *dfa_pages; // HostTables::dfa_pages (nullptr: none)
+    uint32_t dfa_pages_bytes;
     const uint64_t *kg_keys;
     const uint32_t *kg_vals;
     uint32_t kg_mask;

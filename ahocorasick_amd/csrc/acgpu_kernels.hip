@@ -210,10 +210,19 @@ __global__ __launch_bounds__(kScanBlock) void k_ac_dfa(DevTables T, ScanLaunch L
     E *tab = reinterpret_cast<E *>(tab8);
     const E *glob = reinterpret_cast<const E *>(T.dfa);
     for (uint32_t i = threadIdx.x; i < T.lds_entries; i += blockDim.x) tab[i] = glob[i];
-    __syncthreads();
-    WaveQueue wq{queues + (threadIdx.x / kWave) * kQueueCap, 0};
     const uint32_t row_bytes = T.n_cls * (uint32_t)sizeof(E), fo = T.first_out;
     const uint32_t lds_bytes = T.lds_entries * (uint32_t)sizeof(E);
+    // table classes: the class table as pages behind the rows (acgpu_build.cpp 7b; the host leaves the room) -- two LDS reads
+    // per unit instead of a gather from the 128 KB table in global memory
+    const uint32_t pg_off = (lds_bytes + 15u) & ~15u;
+    const bool cls_lds = !RANGE && T.dfa_pages != nullptr && (uint64_t)pg_off + T.dfa_pages_bytes <= (uint64_t)kDfaLdsBytes;
+    if (cls_lds)
+        for (uint32_t i = threadIdx.x; i < T.dfa_pages_bytes / 16; i += blockDim.x)
+            reinterpret_cast<uint4 *>(tab8 + pg_off)[i] = reinterpret_cast<const uint4 *>(T.dfa_pages)[i];
+    const unsigned char *pg8 = tab8 + pg_off;                                  // the page index: one byte per 256 units
+    const uint16_t *pg16 = reinterpret_cast<const uint16_t *>(tab8 + pg_off + 256); // the pages
+    __syncthreads();
+    WaveQueue wq{queues + (threadIdx.x / kWave) * kQueueCap, 0};
     const uint32_t lds_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_bytes ? lds_bytes - (uint32_t)sizeof(E) : 0u));
     const uint32_t base = T.cls_base, span = T.cls_span;
     const uint16_t *lut = T.cls_lut;
@@ -275,6 +284,8 @@ __global__ __launch_bounds__(kScanBlock) void k_ac_dfa(DevTables T, ScanLaunch L
                         if (RANGE) { // (classes as byte offsets into a row)
                             const uint32_t d = unit - base;
                             cls[c][j] = d < span ? (d + 1u) * (uint32_t)sizeof(E) : 0u;
+                        } else if (cls_lds) { // (wave-uniform)
+                            cls[c][j] = (uint32_t)pg16[((uint32_t)pg8[unit >> 8] << 8) + (unit & 255u)] * (uint32_t)sizeof(E);
                         } else {
                             cls[c][j] = (uint32_t)lut[unit] * (uint32_t)sizeof(E);
                         }
