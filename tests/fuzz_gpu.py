@@ -108,7 +108,12 @@ def one_case(rng, it):
             ok = [c for c in alpha if wc[c]] or [ord("A")]
             kws = [np.array(rng.choice(ok, max(1, len(k))), dtype=np.uint16) for k in kws]
             wc[ord("A")] = 1
-    a = Automaton(mode, kws, cs, word_chars=wc)
+    no_pages = int(rng.integers(0, 4) == 0)  # builder knob: class tables in global memory instead of LDS pages
+    N.set_tunable("no_class_pages", no_pages)
+    try:
+        a = Automaton(mode, kws, cs, word_chars=wc)
+    finally:
+        N.set_tunable("no_class_pages", 0)
     orc = Oracle(ofam, kws, case_sensitive=cs, lower=LOWER, word_chars=wc, map_flavour=(fam == 4 and with_ids))
     want = orc.match(hay)
     if fam in (2, 4) and n and rng.integers(0, 3) == 0:
