@@ -44,4 +44,15 @@ python3 bench.py --config README --steps 5 --warmup 1 > "$OUT/bench_readme.json"
 python3 tools/kbench.py --rounds 9 --variants '{"reserve_cus=0":{},"reserve_cus=4":{"reserve_cus":4},"reserve_cus=8":{"reserve_cus":8},"reserve_cus=16":{"reserve_cus":16},"reserve_cus=32":{"reserve_cus":32}}' > "$OUT/reserve_cus.txt" 2>&1
 python3 tools/stream_rate.py > "$OUT/stream_rate.txt" 2>&1
 python3 tools/latency.py > "$OUT/latency.txt" 2>&1
+# round 4, later: the DFA chunk scan (k_ac_dfa against the one-chain kernel of rounds 1-3), wide alphabets, other dictionary shapes
+python3 tools/kbench.py --rounds 5 --variants '{"tile":{},"dfa":{"force_kernel":1},"dfa_one_chain_r3":{"force_kernel":1,"tile_debug":8796093022208,"lds_table_bytes":98304}}' > "$OUT/dfa.txt" 2>&1
+python3 tools/wide_alphabets.py > "$OUT/wide_alphabets.txt" 2>&1
+python3 tools/longest_shapes.py > "$OUT/longest_shapes.txt" 2>&1
+python3 tools/shapes.py > "$OUT/shapes.txt" 2>&1
+# the three bench lines once more with this collection's traffic attached (bench.py attaches profiles/latest_traffic.json only
+# when it was measured on the sources it runs; the copy of the repository on this box is scratch)
+cp "$OUT/latest_traffic.json" profiles/latest_traffic.json
+python3 bench.py --steps 20 --warmup 3 > "$OUT/bench_c2.json" 2> "$OUT/bench_c2.err"
+python3 bench.py --config C4 --steps 10 --warmup 2 > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err"
+python3 bench.py --config C5 --steps 20 --warmup 3 > "$OUT/bench_c5.json" 2> "$OUT/bench_c5.err"
 cat "$OUT/bench_c2.json"
