@@ -807,14 +807,19 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
     S.own_end = (uint32_t)sh->own_end;
     S.len_bytes = t.max_len < 65536 ? 2 : 4;
     uint32_t lds_rows = 0;
-    if (t.dense && t.n_cls) lds_rows = (uint32_t)std::min<uint64_t>(t.n_states, (72 * 1024) / ((uint64_t)t.n_cls * 4));
+    // (table classes: the general walk keeps the class pages behind its rows -- acgpu_build.cpp 7c -- when they are small)
+    // (measured, tools/longest_shapes.py: the README word list case-insensitive, 27 classes: 8.13 -> 6.08 ms per 2^28 units; 3000 CJK
+    // units, where a row is 12 KB and the walk waits for the table in global memory anyway: 4.74 -> 5.05 -- so: small alphabets only)
+    const size_t walk_pages = (t.dense && !t.range_cls && !t.dfa_pages.empty() && t.dfa_pages.size() * 2 <= 16 * 1024 && t.n_cls <= 512) ? t.dfa_pages.size() * 2 + 16 : 0;
+    if (t.dense && t.n_cls) lds_rows = (uint32_t)std::min<uint64_t>(t.n_states, (72 * 1024 - walk_pages) / ((uint64_t)t.n_cls * 4));
     // range classes (case sensitive, keyword units within a span of 63) take the lean walk; tunable force_kernel=1
     // keeps the general one
     S.pairs = t.dense && t.range_cls && t.n_cls == t.cls_span + 1 && tunables().force_kernel != 1 &&
               (uint64_t)t.n_states * t.n_cls * 4 < (1ull << 31);
     if (S.pairs) lds_rows = (uint32_t)std::min<uint64_t>(t.n_states, (72 * 1024) / ((uint64_t)t.n_cls * 4) - 2);
     S.lds_rows = lds_rows;
-    S.lds_bytes = std::max<size_t>((size_t)(lds_rows + (S.pairs ? 2 : 0)) * t.n_cls * 4, 16);
+    S.lds_bytes = std::max<size_t>((size_t)(lds_rows + (S.pairs ? 2 : 0)) * t.n_cls * 4, 16) + (S.pairs ? 0 : walk_pages);
+    S.pages_bytes = S.pairs ? 0u : (uint32_t)walk_pages; // (0: classes from the table in global memory)
     // the work-list form of the range-class walk (tunable force_kernel=4 keeps the lock-step form): 16-bit lengths, LDS rows
     // below 64 KiB (the row offset is the low word of an entry), two workgroups per CU
     if (S.pairs && S.len_bytes == 2 && t.max_len < 64000 && tunables().force_kernel != 4) {

@@ -186,6 +186,7 @@ struct LongestScanLaunch {
     const uint8_t *d_todo;          // k_longest_walk_list: only the chunks (1024 positions) flagged here; nullptr = all
     uint8_t *d_todo_w;              // k_longest_block: one flag per chunk
     uint32_t span_chunks;           // k_longest_block: chunks per wave (contiguous)
+    uint32_t pages_bytes;           // k_longest_walk: DevTables::dfa_pages copied behind the LDS rows (0: classes from cls_lut in global memory)
     uint32_t debug;                 // ACGPU_ABLATION builds: timing experiments (results are wrong)
 };
 hipError_t launch_longest_block(const DevTables &t, const LongestScanLaunch &l, hipStream_t stream, const char **kernel_name);

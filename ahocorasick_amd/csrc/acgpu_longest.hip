@@ -47,6 +47,15 @@ __global__ __launch_bounds__(kLScanBlock) void k_longest_walk(DevTables T, Longe
         const uint32_t e = glob[i];
         rows[i] = e ? ((e & 0x80000000u) | ((e & 0x7fffffffu) * row_bytes)) : 0u;
     }
+    // table classes: the class pages (acgpu_build.cpp 7c) behind the rows -- two LDS reads per unit instead of a gather from
+    // the 128 KB class table, in front of every step's row lookup
+    const uint32_t pg_off = (max(lds_bytes, 16u) + 15u) & ~15u;
+    const bool cls_lds = DENSE && L.pages_bytes != 0 && T.dfa_pages != nullptr;
+    if (cls_lds)
+        for (uint32_t i = threadIdx.x; i < T.dfa_pages_bytes / 16; i += blockDim.x)
+            reinterpret_cast<uint4 *>(smem + pg_off)[i] = reinterpret_cast<const uint4 *>(T.dfa_pages)[i];
+    const unsigned char *pg8 = smem + pg_off;
+    const uint16_t *pg16 = reinterpret_cast<const uint16_t *>(smem + pg_off + 256);
     __syncthreads();
     LenT *out_len = reinterpret_cast<LenT *>(L.d_len);
     const uint16_t *hay = L.d_hay;
@@ -79,6 +88,8 @@ __global__ __launch_bounds__(kLScanBlock) void k_longest_walk(DevTables T, Longe
                     if (T.range_cls) {
                         const uint32_t dlt = unit - T.cls_base;
                         cls4 = dlt < T.cls_span ? dlt * 4u + 4u : 0u;
+                    } else if (cls_lds) { // (uniform)
+                        cls4 = (uint32_t)pg16[((uint32_t)pg8[unit >> 8] << 8) + (unit & 255u)] * 4u;
                     } else {
                         cls4 = (uint32_t)T.cls_lut[unit] * 4u;
                     }

@@ -504,7 +504,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
     }
     // LUT forms with the scalar filter: the class table as pages behind the rows, when it fits (acgpu_build.cpp 7b)
     const uint32_t pg_off = (T.filt_words * 4u + 15u) & ~15u;
-    const bool cls_lds = !RANGE && !PK && T.cls_pages != nullptr && (uint64_t)pg_off + T.cls_pages_bytes <= sizeof(rows32) && !ACGPU_DBG(L, 1u << 14);
+    const bool cls_lds = !RANGE && !PK && T.cls_pages != nullptr && (uint64_t)pg_off + T.cls_pages_bytes <= sizeof(rows32) && !ACGPU_DBG(L, 1u << 15); // (ablation build, tile_debug bit 32768: the class table in global memory on the same tables)
     if (cls_lds)
         for (uint32_t i = threadIdx.x; i < T.cls_pages_bytes / 16; i += blockDim.x)
             reinterpret_cast<uint4 *>(rows32)[pg_off / 16 + i] = reinterpret_cast<const uint4 *>(T.cls_pages)[i];
