@@ -5,7 +5,9 @@
 //               root (max_keyword_len-1) units before the chunk so that every match ending inside the
 //               chunk is seen; transition rows of the shallow states staged in LDS; match records
 //               compacted with a wavefront ballot into a per-wave LDS queue and appended to HBM in
-//               batches with one atomic per batch.
+//               batches with one atomic per batch.  Dense tables: k_ac_dfa (round 4: two chunks per lane,
+//               branch-free steps); hashed edges + fail links: k_ac_scan_sparse; k_ac_scan_dense is the
+//               one-chain form of rounds 1-3 (haystacks below 64 units, A/B).
 // k_scan_*    : exclusive prefix sum of the per-chunk match counts.
 // k_permute   : scatters the unordered records to their final, reference-ordered slots.
 #include <hip/hip_runtime.h>

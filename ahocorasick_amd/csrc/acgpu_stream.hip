@@ -4,10 +4,11 @@
 //
 // Two forms of acgpu_stream_feed:
 //  * synchronous (default): copy in, scan, copy out -- a feed returns the records ITS chunk made decidable;
-//  * pipelined (acgpu_stream_set_pipelined): the chunk is copied into a pinned staging buffer by several host threads, each
-//    of which enqueues the DMA of its piece as soon as it has copied it, while the calling thread scans the PREVIOUS chunk
-//    (whose transfer was enqueued by the previous feed) and returns ITS records: copy, transfer and scan of neighbouring
-//    chunks overlap, a feed costs the slowest of them instead of their sum.  The last feed (final != 0) returns the records
+//  * pipelined (acgpu_stream_set_pipelined): the chunk is copied into a pinned staging buffer by several host threads while the
+//    calling thread scans the PREVIOUS chunk (whose transfer the previous feed enqueued) and returns ITS records; when the
+//    copy is done the calling thread enqueues ONE transfer of the whole chunk (transfers enqueued piece by piece from
+//    several threads made the launches of the scan slow): copy, transfer and scan of neighbouring chunks overlap, a feed
+//    costs the slowest of them instead of their sum.  The last feed (final != 0) returns the records
 //    of both the previous and its own chunk.  The concatenation over all feeds is the same in both forms.
 #include <hip/hip_runtime.h>
 
