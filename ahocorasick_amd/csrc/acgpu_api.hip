@@ -107,6 +107,8 @@ int ensure_device(acgpu_automaton *a, DeviceState **out, int lane) {
     }
     T.root_tab = nullptr; T.root_b = t.root_b; T.root_rk = t.root_rk;
     if (t.root_b && (rc = upload(*d, t.root_tab, &T.root_tab))) return rc;
+    T.bits_tab = nullptr; T.bits_rk = t.bits_rk;
+    if (t.bits_rk && (rc = upload(*d, t.bits_tab, &T.bits_tab))) return rc;
     if ((rc = upload(*d, t.filt_bits, &T.filt_bits))) return rc;
     if ((rc = upload(*d, t.kgram_node, &T.kgram_node))) return rc;
     T.fold_range = t.fold_range; T.fr_base = t.fr_base; T.fr_span = t.fr_span; T.fr_base2 = t.fr_base2; T.fr_himask = t.fr_himask;
@@ -765,7 +767,7 @@ int match_longest_sparse(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, in
 // LONGEST-mode pipeline on one shard: reverse scan -> chain count -> prefix sum -> chain write.
 // With a ticket (the walk pipeline only: want_async_longest) the call returns after enqueueing; acgpu_match_device_end collects it.
 int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_kind, void *d_out, uint64_t cap,
-                  uint64_t *n_out, hipStream_t stream, acgpu_profile *prof, Ticket *tk = nullptr) {
+                  uint64_t *n_out, hipStream_t stream, acgpu_profile *prof, Ticket *tk = nullptr, bool no_bits = false) {
     const HostTables &t = a->t;
     hipEvent_t *ev = tk ? tk->ev : d.ev;
     const bool timed = tk ? tk->profiled : prof != nullptr;
@@ -793,6 +795,100 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
         const int src = match_longest_sparse(a, d, sh, record_kind, d_out, cap, n_out, stream, prof, entry);
         if (src != ACGPU_E_UNSUPPORTED) return src;
         sh->chain_exit = (int64_t)std::max<uint64_t>(entry, sh->own_end); // dense in matches after all: the walk
+    }
+    // Set records over a two-letter alphabet in which every letter is a keyword: the text as one bit per unit, the chain's own
+    // positions only (k_longest_bits, acgpu_longest_bits.hip) -- no length array, no synchronisation pass.  The kernel checks
+    // its own result (every segment's exit against the next one's entry) and raises the bail flag -- also for a unit outside
+    // the alphabet --: the call is then redone right here, or in acgpu_match_device_end, by the walk pipeline below.
+    // Tunable tile_debug bit 33554432: never; bit 67108864: also for short texts (tests).
+    const bool bits_form = !no_bits && record_kind == ACGPU_REC_SET && d.T.bits_rk != 0 && !(tunables().tile_debug & 33554432) &&
+                           (own_len >= (1ull << 21) || (tunables().tile_debug & 67108864)) && tunables().force_kernel == 0;
+    if (bits_form) {
+        int rc;
+        LongestBitsLaunch Bl{};
+        Bl.d_hay = sh->d_hay;
+        Bl.n_units = (uint32_t)sh->n_units;
+        Bl.own_end = (uint32_t)sh->own_end;
+        Bl.entry = (uint32_t)entry;
+        Bl.g0 = (uint32_t)entry & ~31u;
+        const uint32_t region_units = longest_bits_region_units();
+        Bl.n_regions = (uint32_t)((sh->own_end - Bl.g0 + region_units - 1) / region_units);
+        Bl.tile_log2 = 2; // emit tiles of four segments (4096 positions)
+        Bl.max_len = t.max_len;
+        const uint32_t n_tiles = (Bl.n_regions * (region_units / longest_bits_seg_units())) >> Bl.tile_log2;
+        if ((rc = d.counter.ensure(64))) return rc;
+        if ((rc = d.chunk_counts.ensure((size_t)n_tiles * 4))) return rc;
+        if ((rc = d.offsets.ensure((size_t)n_tiles * 8))) return rc;
+        if ((rc = d.scan_tmp.ensure(((size_t)n_tiles / 2048 + 2) * 8))) return rc;
+        if ((rc = d.chain.ensure((size_t)n_tiles * 4 + 64))) return rc;
+        if ((rc = d.blockmax.ensure((size_t)Bl.n_regions * 8 + 64))) return rc;
+        const size_t bit_bytes = ((size_t)sh->n_units / 128 + 2) * 16;
+        if ((rc = d.chainbits.ensure(bit_bytes * 2))) return rc;
+        Bl.d_bits = (uint32_t *)d.chainbits.p;
+        Bl.d_ebits = Bl.d_bits + bit_bytes / 4;
+        Bl.d_sync = (uint32_t *)d.chain.p;
+        Bl.d_counts = (uint32_t *)d.chunk_counts.p;
+        Bl.d_exit = (unsigned long long *)d.counter.p;
+        Bl.d_pred = (uint32_t *)d.blockmax.p;
+        Bl.d_true = Bl.d_pred + Bl.n_regions;
+        Bl.grid = (int)std::min<uint64_t>((uint64_t)d.n_cu, (Bl.n_regions + 15) / 16);
+        HIP_TRY(hipMemsetAsync(d.counter.p, 0, 64, stream));
+        d.cclean[0] = false; // (match_all's first set of slot counters lives here)
+        { // the words of the end bitmap behind the last one the kernel stores: the last match may end there (one atomicOr)
+            const size_t first = ((size_t)(sh->own_end - 1) >> 5) + 1, last = std::min<size_t>(bit_bytes / 4, (((size_t)sh->own_end + t.max_len) >> 5) + 2);
+            if (last > first) HIP_TRY(hipMemsetAsync(Bl.d_ebits + first, 0, (last - first) * 4, stream));
+        }
+        if (timed) HIP_TRY(hipEventRecord(ev[0], stream));
+        HIP_TRY(launch_longest_bits(d.T, Bl, stream, nullptr, nullptr));
+        if (timed) HIP_TRY(hipEventRecord(ev[1], stream));
+        LongestChainLaunch Cn{};
+        Cn.len_bytes = 1;
+        Cn.own_begin = (uint32_t)sh->own_begin;
+        Cn.own_end = (uint32_t)sh->own_end;
+        Cn.entry = (uint32_t)entry;
+        Cn.tile_units = longest_bits_seg_units() << Bl.tile_log2;
+        Cn.n_tiles = n_tiles;
+        Cn.max_len = t.max_len;
+        Cn.d_counts = Bl.d_counts;
+        Cn.d_offsets = (const uint64_t *)d.offsets.p;
+        Cn.d_out = d_out;
+        Cn.cap = cap;
+        Cn.record_kind = record_kind;
+        Cn.d_exit = Bl.d_exit;
+        Cn.len_units = (uint32_t)sh->n_units;
+        Cn.d_bits = Bl.d_bits;
+        Cn.d_ebits = Bl.d_ebits;
+        HIP_TRY(launch_exclusive_scan(Cn.d_counts, Cn.n_tiles, (uint64_t *)d.offsets.p, (uint64_t *)d.scan_tmp.p, stream));
+        HIP_TRY(launch_longest_emit(Cn, Bl.d_sync, stream));
+        if (timed) HIP_TRY(hipEventRecord(ev[2], stream));
+        unsigned long long *h_slot = tk ? tk->h_count : d.h_counter, *d_slot = nullptr;
+        HIP_TRY(hipHostGetDevicePointer((void **)&d_slot, h_slot, 0));
+        HIP_TRY(launch_publish_result((const unsigned long long *)d.scan_tmp.p + scan_tiles_for(Cn.n_tiles), (const unsigned long long *)d.counter.p,
+                                      d_slot, tk ? reinterpret_cast<acgpu_device_result *>(sh->d_result) : nullptr, stream));
+        if (tk) {
+            tk->stream = stream;
+            tk->shard = *sh;
+            tk->record_kind = record_kind;
+            tk->d_out = d_out;
+            HIP_TRY(hipEventRecord(tk->done, stream));
+            tk->scanned = own_len;
+            std::snprintf(tk->kname, sizeof(tk->kname), "k_longest_bits");
+            return ACGPU_OK;
+        }
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (d.h_counter[1] != 0) // (a unit outside the alphabet, or a chain that did not merge inside a segment)
+            return match_longest(a, d, sh, record_kind, d_out, cap, n_out, stream, prof, nullptr, true);
+        *n_out = d.h_counter[0];
+        sh->chain_exit = (int64_t)d.h_counter[2];
+        if (prof) {
+            HIP_TRY(hipEventElapsedTime(&prof->scan_ms, d.ev[0], d.ev[1]));
+            HIP_TRY(hipEventElapsedTime(&prof->finalize_ms, d.ev[1], d.ev[2]));
+            HIP_TRY(hipEventElapsedTime(&prof->total_ms, d.ev[0], d.ev[2]));
+            prof->scan_units = own_len;
+            prof->n_matches = *n_out;
+            std::snprintf(prof->scan_kernel, sizeof(prof->scan_kernel), "k_longest_bits");
+        }
+        return *n_out > cap ? ACGPU_E_OVERFLOW : ACGPU_OK;
     }
     LongestScanLaunch S{};
     S.block = 1024;
@@ -1342,6 +1438,7 @@ int64_t acgpu_set_tunable(const char *name, int64_t value) {
     else if (!std::strcmp(name, "no_merged_ranges")) slot = &t.no_merged_ranges;
     else if (!std::strcmp(name, "no_short_keywords")) slot = &t.no_short_keywords;
     else if (!std::strcmp(name, "reserve_cus")) slot = &t.reserve_cus;
+    else if (!std::strcmp(name, "no_bits_trie")) slot = &t.no_bits_trie;
     else if (!std::strcmp(name, "no_big_l2")) slot = &t.no_big_l2;
     else if (!std::strcmp(name, "no_class_pages")) slot = &t.no_class_pages;
     else if (!std::strcmp(name, "split_cand_div")) slot = &t.split_cand_div;
@@ -1523,6 +1620,14 @@ int end_ticket(const acgpu_automaton *ca, acgpu_ticket *ticket, uint64_t *n_out,
     if (tk->kind == 0 && (uint32_t)tk->h_count[1] != 0) { // a candidate slice / scratch slice was too small: redo with the fused kernel, one slice
         // (the redo shares the scratch with the tickets still in flight: same stream, so stream order keeps them apart)
         const int rc = match_all(a, *d, &tk->shard, tk->record_kind, tk->d_out, tk->cap, n_out, tk->stream, prof, nullptr, true);
+        tk->busy = false;
+        d->inflight--;
+        if (redone) *redone = true;
+        return rc;
+    }
+    if (tk->kind == 1 && tk->h_count[1] != 0) { // k_longest_bits bailed out (a unit outside the alphabet, a chain that did not merge): the walk pipeline
+        const int rc = match_longest(a, *d, &tk->shard, tk->record_kind, tk->d_out, tk->cap, n_out, tk->stream, prof, nullptr, true);
+        if (tk->user_shard) tk->user_shard->chain_exit = tk->shard.chain_exit;
         tk->busy = false;
         d->inflight--;
         if (redone) *redone = true;

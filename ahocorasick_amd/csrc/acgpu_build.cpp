@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <algorithm>
 #include <cstring>
+#include <deque>
 #include <unordered_map>
 
 #include "acgpu_internal.h"
@@ -488,6 +489,83 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
         }
         t.root_b = B;
         t.root_rk = RK;
+    }
+
+    // ---- 6c. LONGEST over a two-letter alphabet: the keyword trie, path compressed, for k_longest_bits ----
+    // The text is held as ONE BIT per unit, so a stretch of the trie without branching is a bit string that a walk compares
+    // with the text 31 units at a time (xor, count trailing zeros).  Entries of four words {label bits, terminal bits, meta,
+    // next}: the first 2^RK entries are indexed by the RK-gram of the text itself (what round one of the root table above
+    // is), an entry's label is the one-child path below its node (at most 31 units), and behind the label the walk either
+    // ends (leaf), goes on with one more entry (the path is longer) or branches (next + code of the following unit: the
+    // child's entry).  What does not fit kBitsTabEntries is marked "deep": the kernel walks those from the root through the
+    // table in global memory.  Only for dictionaries in which every letter of the alphabet is itself a keyword: then every
+    // position of a text over the alphabet starts a match, the chain's positions are the match starts, and one bitmap serves.
+    t.bits_tab.clear();
+    t.bits_rk = 0;
+    if (mode == ACGPU_MODE_LONGEST && t.dense && t.range_cls && t.n_cls == t.cls_span + 1 && t.cls_span == 2 && !tunables().no_bits_trie) {
+        bool all_letters = true;
+        for (uint32_t c = 0; c < t.cls_span; c++) all_letters = all_letters && (t.dfa[c + 1] >> 31);
+        if (all_letters) {
+            constexpr uint32_t RK = kBitsRK, NF = 1u << RK, UL = 31, kContMax = 3;
+            auto trie_edge = [&](uint32_t node, uint32_t code) -> uint32_t { return code < t.cls_span ? t.dfa[(uint64_t)node * t.n_cls + code + 1] : 0u; };
+            std::vector<uint32_t> &E = t.bits_tab;
+            E.assign((size_t)NF * 4, 0);
+            struct Todo { uint32_t entry, node, cont; }; // the label of `entry` is the path below `node`
+            std::deque<Todo> todo;
+            for (uint32_t i = 0; i < NF; i++) {
+                uint32_t node = 0, best = 0;
+                bool alive = true;
+                for (uint32_t j = 0; j < RK; j++) {
+                    const uint32_t e = trie_edge(node, (i >> j) & 1u);
+                    if (!e) { alive = false; break; }
+                    node = e & 0x7fffffffu;
+                    if (e >> 31) best = j + 1;
+                }
+                E[4 * i + 2] = (best << 8) | (alive ? kBitsAlive : 0u);
+                if (alive) todo.push_back({i, node, 0});
+            }
+            while (!todo.empty()) { // breadth first: what is near the root gets its entries first
+                const Todo td = todo.front();
+                todo.pop_front();
+                uint32_t node = td.node, len = 0, label = 0, term = 0;
+                auto children = [&](uint32_t v) { return (trie_edge(v, 0) ? 1u : 0u) + (trie_edge(v, 1) ? 1u : 0u); };
+                while (len < UL && children(node) == 1) {
+                    const uint32_t code = trie_edge(node, 0) ? 0u : 1u, e = trie_edge(node, code);
+                    label |= code << len;
+                    term |= (e >> 31) << len;
+                    node = e & 0x7fffffffu;
+                    len++;
+                }
+                uint32_t kind = kBitsLeaf, next = 0;
+                const uint32_t nch = children(node);
+                if (nch == 1) { // the path goes on
+                    if (td.cont < kContMax && E.size() / 4 + 1 <= kBitsTabEntries) {
+                        kind = kBitsCont;
+                        next = (uint32_t)(E.size() / 4);
+                        E.resize(E.size() + 4, 0);
+                        E[4 * next + 2] = kBitsAlive;
+                        todo.push_back({next, node, td.cont + 1});
+                    } else kind = kBitsDeep;
+                } else if (nch == 2) {
+                    if (E.size() / 4 + 2 <= kBitsTabEntries) {
+                        kind = kBitsJunction;
+                        next = (uint32_t)(E.size() / 4);
+                        E.resize(E.size() + 8, 0);
+                        for (uint32_t c = 0; c < 2; c++) {
+                            const uint32_t e = trie_edge(node, c);
+                            E[4 * (next + c) + 2] = kBitsAlive | ((e >> 31) << 8);
+                            todo.push_back({next + c, e & 0x7fffffffu, 0});
+                        }
+                    } else kind = kBitsDeep;
+                }
+                E[4 * td.entry + 0] = label;
+                E[4 * td.entry + 1] = term;
+                E[4 * td.entry + 2] |= len | (kind << 6);
+                E[4 * td.entry + 3] = next;
+            }
+            E.resize((size_t)kBitsTabEntries * 4, 0);
+            t.bits_rk = RK;
+        }
     }
 
     // ---- 7. suffix K-gram filter + reversed trie (ALL mode) ----

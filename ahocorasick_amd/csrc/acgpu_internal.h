@@ -96,6 +96,14 @@ ACGPU_HD inline uint32_t l2_rot(const uint32_t *c, uint32_t L, uint32_t K) { // 
 }
 ACGPU_HD inline uint32_t l2_rotr(uint32_t x, uint32_t r) { return (x >> (r & 31u)) | (x << ((32u - r) & 31u)); }
 
+// k_longest_bits (acgpu_longest_bits.hip) and its table (acgpu_build.cpp 6c).  An entry is four words {label, terminal bits,
+// meta, next}; meta = label length (bits 0-5) | kind (bits 6-7) | best (bits 8-15: a first-level entry's longest keyword
+// among the RK units, a junction child's "the child ends a keyword") | kBitsAlive.
+constexpr uint32_t kBitsRK = 9;            // first level: 2^9 entries indexed by the text's next 9 units
+constexpr uint32_t kBitsTabEntries = 1120; // 17.5 KiB of LDS: what 16 waves' text images leave
+constexpr uint32_t kBitsAlive = 1u << 16;
+constexpr uint32_t kBitsLeaf = 0, kBitsJunction = 1, kBitsCont = 2, kBitsDeep = 3;
+
 // Host-side automaton tables.  State numbering: root = 0; states WITHOUT any output (own or inherited
 // keyword) come first in BFS order, states WITH output after them in BFS order, so that
 // "state >= first_out" is the has-output test and a prefix of the numbering is the shallow, hot part.
@@ -133,6 +141,10 @@ struct HostTables {
     // LONGEST, small alphabets: root table of the walk's first round (acgpu_build.cpp 6b); root_b = 0: none
     std::vector<uint8_t> root_tab;
     uint32_t root_b = 0, root_rk = 0;
+    // LONGEST over a two-letter alphabet in which every letter is a keyword: the path-compressed trie of k_longest_bits
+    // (acgpu_build.cpp 6c): kBitsTabEntries entries of four words; bits_rk = 0: none
+    std::vector<uint32_t> bits_tab;
+    uint32_t bits_rk = 0;
     // hashed goto edges keyed by (state, folded unit): open addressing, linear probing
     std::vector<uint64_t> hkeys;
     std::vector<uint32_t> hvals;
@@ -269,6 +281,8 @@ struct DevTables {
     uint32_t ww_bloom_mask;
     const uint8_t *root_tab; // LONGEST: see HostTables::root_tab
     uint32_t root_b, root_rk;
+    const uint32_t *bits_tab; // LONGEST: see HostTables::bits_tab (nullptr: none)
+    uint32_t bits_rk;
 };
 
 // development/test knobs (acgpu_set_tunable): relaxed atomics, read when a call is enqueued
@@ -292,6 +306,7 @@ struct Tunables {
     std::atomic<int64_t> split_cand_div{8};   // split form: a wave's candidate slice holds one candidate per this many units of its span
     std::atomic<int64_t> no_class_pages{0};   // builder: 1 = the tile kernel's LUT forms look classes up in global memory (A/B)
     std::atomic<int64_t> no_big_l2{0};        // builder: 1 = large dictionaries keep the (saturated) second level in LDS (A/B)
+    std::atomic<int64_t> no_bits_trie{0};     // builder: 1 = no path-compressed trie for k_longest_bits (the walk pipeline instead: A/B)
     std::atomic<int64_t> reserve_cus{0};      // CUs left without a scan workgroup (room for a collective's kernels under the scan)
 };
 Tunables &tunables();

@@ -221,6 +221,23 @@ struct LongestChainLaunch {
                                 // not overlap, so the k-th set bit of d_bits and the k-th of d_ebits are one record and the
                                 // emit pass needs no length lookups (16-bit lengths through k_longest_chain_lds only)
 };
+// k_longest_bits (acgpu_longest_bits.hip): Set records, two-letter alphabets in which every letter is a keyword
+struct LongestBitsLaunch {
+    const uint16_t *d_hay;
+    uint32_t n_units, own_end, entry;
+    uint32_t g0;          // entry & ~31: first position of segment 0 of region 0
+    uint32_t n_regions;   // regions of longest_bits_region_units() positions from g0 on, up to own_end
+    uint32_t tile_log2;   // segments per tile of d_sync / d_counts (log2)
+    uint32_t max_len;
+    uint32_t *d_bits, *d_ebits;  // bit p: a match starts at p / a match ends at p + 1 (LongestChainLaunch)
+    uint32_t *d_sync, *d_counts; // per tile: its first match start (~0u: none), its matches
+    unsigned long long *d_exit;  // [0]: the chain's first position at or behind own_end, [1]: bail flag (both zeroed by the caller)
+    uint32_t *d_pred, *d_true;   // per region: the entry it assumed, the exit it found
+    int grid;
+};
+uint32_t longest_bits_region_units();
+uint32_t longest_bits_seg_units();
+hipError_t launch_longest_bits(const DevTables &t, const LongestBitsLaunch &l, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop);
 hipError_t launch_longest_sync(const LongestChainLaunch &l, uint32_t *d_sync, hipStream_t stream);
 hipError_t launch_longest_chain(const LongestChainLaunch &l, const uint32_t *d_sync, bool write_pass, hipStream_t stream);
 // count / write pass with the lengths staged through LDS in chunks (16-bit lengths)

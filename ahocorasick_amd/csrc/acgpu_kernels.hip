@@ -783,12 +783,12 @@ __global__ void k_write_result(acgpu_device_result *r, unsigned long long n) {
 __global__ void k_publish_result(const unsigned long long *d_total, const unsigned long long *d_exit, unsigned long long *h_slot,
                                  acgpu_device_result *r) {
     const unsigned long long n = *d_total;
-    h_slot[1] = 0;
+    h_slot[1] = d_exit[1]; // (k_longest_bits: the bail flag; 0 otherwise -- the caller zeroes the block)
     h_slot[2] = *d_exit;
     h_slot[0] = n;
     if (r) {
         r->n_records = n;
-        r->redone = 0;
+        r->redone = d_exit[1] != 0; // (the records are not there yet: acgpu_match_device_end redoes the call)
         r->reserved = 0;
     }
 }

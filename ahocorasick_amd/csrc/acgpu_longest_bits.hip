@@ -1,0 +1,356 @@
+// acgpu_longest_bits.hip -- LongestMatchSet over a two-letter alphabet: the text as ONE BIT per unit (gfx950).
+//
+// Replaces, for such dictionaries, the per-unit loop of LongestMatchSet.match (S/LongestMatchSet.java:192-265: the
+// automaton step and the pending-match queue S/SetMatchQueue.java:45-95).  What that loop reports is the greedy chain
+// pos -> pos + max(L[pos], 1), L[pos] = the longest keyword that starts at pos.  The walk pipeline of
+// acgpu_longest.hip computes L for EVERY position and writes it to memory (0.54 GB at config 4), then finds a
+// synchronisation point per tile and follows the chain through those lengths.  Here nothing but the chain's own positions
+// is ever looked up:
+//  * a wave owns a region of 64 segments of 1024 positions; it streams the region's text once and keeps it in LDS as one
+//    bit per unit (32 words per segment + copies of the next segment's first words, stride 35: lanes that walk their
+//    segments at the same pace sit in different banks);
+//  * L[p] comes from the path-compressed keyword trie (acgpu_build.cpp 6c, 17.5 KiB of LDS): the text's next 9 units
+//    index an entry {label, terminal bits, meta, next}; the label -- the one-child path below that node, 31 units -- is
+//    compared with the text by one xor and a count of trailing zeros; longer paths and branches take further entries (rare);
+//  * pass 1: lane j follows the chain of segment j-1 from that segment's FIRST position to its end.  Chains that start at
+//    different positions merge within a few matches, so where it leaves the segment is (with overwhelming probability) where
+//    the true chain does: lane j's entry;
+//  * pass 2: lane j follows the chain of its own segment from that entry, counts the matches and marks their starts -- in
+//    the place of the text words it has left behind.  Then every lane's exit is compared with its neighbour's entry (the
+//    first region's first entry is the call's chain entry, so equal everywhere means exact everywhere); a difference
+//    anywhere -- or a unit outside the alphabet -- raises the call's bail flag and the call is redone by the walk pipeline;
+//  * every position of a text over the alphabet starts a match (the builder checks that every letter is a keyword), so the
+//    chain's positions ARE the match starts and (starts >> 1) the match ends: both bitmaps leave as coalesced stores, with
+//    the count and the first start of every tile of segments, for the prefix sum and k_longest_emit_ends.
+// HBM-bound: 2 B per unit read once; the kernel writes two bits per unit.  No length array, no synchronisation pass.
+#include <hip/hip_runtime.h>
+
+#include "acgpu_device.h"
+#include "acgpu_kernels.h"
+
+namespace acgpu {
+
+constexpr int kBitsWaves = 16;                  // one workgroup of 16 waves per CU
+constexpr int kBitsBlock = kBitsWaves * kWave;
+constexpr uint32_t kBitsSegWords = 32;          // a lane's segment: 32 words = 1024 positions
+constexpr uint32_t kBitsSegUnits = 32 * kBitsSegWords;
+constexpr uint32_t kBitsLook = 3;               // copies of the next segment's first words behind a segment's own
+constexpr uint32_t kBitsStride = kBitsSegWords + kBitsLook; // 35 words: odd, so equal word numbers of 32 segments are 32 banks
+constexpr uint32_t kBitsSegs = 64;
+constexpr uint32_t kBitsRegionUnits = kBitsSegs * kBitsSegUnits;            // 65536 positions per wave and round
+constexpr uint32_t kBitsWaveWords = (kBitsSegs + 1) * kBitsStride + 1;      // segments -1 .. 63, and "segment 64, word 0"
+constexpr uint32_t kBitsTileUnits = 2048;                                   // 64 lanes x 32 units: one word per lane
+constexpr uint32_t kBitsTextMax = 33u * 32u;    // a 32-bit window may begin below this segment-relative position
+static_assert(kBitsWaves * kBitsWaveWords * 4 + kBitsTabEntries * 16 <= 160 * 1024, "LDS");
+static_assert(kBitsRK + 32 <= 64, "a first-level lookup reads three words");
+
+struct BitsCtx {
+    const uint16_t *hay;
+    const uint32_t *dfa;
+    uint32_t n_units, n_cls, base, span;
+};
+
+__device__ __forceinline__ uint32_t bits_pk_sub(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_sub_u16 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t bits_pk_max(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t bits_ffbl(uint32_t x) { // trailing zeros; all ones for x == 0
+    uint32_t r;
+    asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ uint32_t bits_ffbh(uint32_t x) { // leading zeros; all ones for x == 0
+    uint32_t r;
+    asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+// 32 units (16 registers of two) -> 32 bits, unit i at bit i; dmax collects the largest code met (packed)
+__device__ __forceinline__ uint32_t bits_pack(const uint32_t (&w)[16], uint32_t base2, uint32_t &dmax) {
+    uint32_t d[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) d[i] = bits_pk_sub(w[i], base2);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dmax = bits_pk_max(dmax, d[i]);
+    uint32_t a = d[0], b = d[8];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) {
+        a = (d[i] << (2 * i)) | a; // even units at bits 0, 2, .. 14; odd units at bits 16, 18, .. 30
+        b = (d[8 + i] << (2 * i)) | b;
+    }
+    const uint32_t pa = (a | (a >> 15)) & 0xffffu, pb = b | (b >> 15);
+    return (pb << 16) | pa;
+}
+
+// the longest keyword at absolute position p, through the trie in global memory (the rare ways out of the fast path)
+__device__ __noinline__ uint32_t bits_slow(const BitsCtx &c, uint32_t p) {
+    uint32_t node = 0, best = 0, j = p;
+    while (j < c.n_units) {
+        const uint32_t dlt = (uint32_t)c.hay[j] - c.base;
+        const uint32_t g = c.dfa[(uint64_t)node * c.n_cls + (dlt < c.span ? dlt + 1u : 0u)];
+        if (!g) break;
+        node = g & 0x7fffffffu;
+        ++j;
+        if (g >> 31) best = j - p;
+    }
+    return best;
+}
+
+// entry e's label against the 32 text bits tw behind the walk's first `depth` units; raises best to the longest keyword
+// that ends inside the matched part; true: the whole label matched
+__device__ __forceinline__ bool bits_label(const uint4 &e, uint32_t tw, uint32_t depth, uint32_t &best) {
+    const uint32_t len = e.z & 63u;                        // at most 31
+    const uint32_t m = min(bits_ffbl(tw ^ e.x), len);      // matched units of the label
+    const uint32_t tm = e.y & ((1u << m) - 1u);            // keywords that end inside them
+    const uint32_t h = bits_ffbh(tm);                      // (all ones: none)
+    best = tm ? depth + 32u - h : best;
+    return m == len;
+}
+
+// the longest keyword that starts at segment-relative position q (absolute position p): what LongestMatchSet's queue would
+// report from there.  seg: the lane's segment in the wave's LDS image (words behind the segment: the next segment's).
+__device__ __forceinline__ uint32_t bits_longest(const BitsCtx &c, const uint4 *tab, const uint32_t *seg, uint32_t q, uint32_t p) {
+    constexpr uint32_t RK = kBitsRK;
+    const uint32_t *w = seg + (q >> 5);
+    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], sh = q & 31u;
+    const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), mid = __builtin_amdgcn_alignbit(w2, w1, sh);
+    uint4 e = tab[lo & ((1u << RK) - 1u)];
+    uint32_t best = (e.z >> 8) & 0xffu; // the longest keyword among the first RK units
+    uint32_t depth = RK;
+    bool full = bits_label(e, __builtin_amdgcn_alignbit(mid, lo, RK), depth, best);
+    if (__builtin_expect(full && (e.z & 0xc0u) != 0u, 0)) { // the label matched whole and the trie goes on behind it: rare
+        for (;;) {
+            depth += e.z & 63u;
+            const uint32_t kind = (e.z >> 6) & 3u;
+            if (kind == kBitsLeaf) break;
+            uint32_t t = q + depth;
+            if (kind == kBitsDeep || t + 1u >= kBitsTextMax) { // beyond the table, or beyond the text this lane can read in LDS
+                best = bits_slow(c, p);
+                break;
+            }
+            if (kind == kBitsJunction) {
+                const uint32_t code = (seg[t >> 5] >> (t & 31u)) & 1u;
+                e = tab[e.w + code];
+                if (!(e.z & kBitsAlive)) break;
+                ++depth;
+                ++t;
+                if ((e.z >> 8) & 0xffu) best = depth;
+            } else {
+                e = tab[e.w];
+            }
+            const uint32_t *v = seg + (t >> 5);
+            if (!bits_label(e, __builtin_amdgcn_alignbit(v[1], v[0], t & 31u), depth, best)) break;
+        }
+    }
+    // (units behind the end of the buffer were packed as the first letter: a keyword that would end there is not one)
+    if (__builtin_expect((uint64_t)p + best > (uint64_t)c.n_units, 0)) best = bits_slow(c, p);
+    return max(best, 1u); // (0: a unit outside the alphabet -- the call bails out; the chain moves on whatever it reads)
+}
+
+__global__ __launch_bounds__(kBitsBlock) void k_longest_bits(DevTables T, LongestBitsLaunch L) {
+    __shared__ __attribute__((aligned(16))) uint4 tab[kBitsTabEntries];
+    __shared__ uint32_t img_all[kBitsWaves][kBitsWaveWords];
+    for (uint32_t i = threadIdx.x; i < kBitsTabEntries; i += blockDim.x) tab[i] = reinterpret_cast<const uint4 *>(T.bits_tab)[i];
+    __syncthreads();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const uint32_t lane = lane_id();
+    uint32_t *img = img_all[wave];
+    BitsCtx c;
+    c.hay = L.d_hay;
+    c.dfa = reinterpret_cast<const uint32_t *>(T.dfa);
+    c.n_units = L.n_units;
+    c.n_cls = T.n_cls;
+    c.base = T.cls_base;
+    c.span = T.cls_span;
+    const uint32_t base2 = c.base * 0x10001u;
+    const uint16_t *hay = L.d_hay;
+    const uint32_t nu = L.n_units;
+    const uint32_t last_w = (L.own_end - 1u) >> 5; // the last bitmap word this call writes
+
+    for (uint32_t r = blockIdx.x * kBitsWaves + wave; r < L.n_regions; r += gridDim.x * kBitsWaves) {
+        const uint32_t R0 = L.g0 + r * kBitsRegionUnits; // first position of segment 0
+        // ---- the region's text, one bit per unit: segments -1 .. 63 and the first words of segment 64 -----------------------
+        uint32_t dmax = 0;
+        // lane's 32 units from position u0 on; units behind the end of the buffer read as the first letter
+        auto load_careful = [&](uint32_t (&w)[16], uint32_t u0) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const uint32_t pos = u0 + 8u * v;
+                if ((uint64_t)pos + 8u <= nu) {
+                    const uint4 x = *reinterpret_cast<const uint4 *>(hay + pos);
+                    w[4 * v] = x.x; w[4 * v + 1] = x.y; w[4 * v + 2] = x.z; w[4 * v + 3] = x.w;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t a = pos + 2u * k < nu ? (uint32_t)hay[pos + 2u * k] : c.base;
+                        const uint32_t b = pos + 2u * k + 1u < nu ? (uint32_t)hay[pos + 2u * k + 1u] : c.base;
+                        w[4 * v + k] = a | (b << 16);
+                    }
+                }
+            }
+        };
+        auto load_fast = [&](uint32_t (&w)[16], uint32_t u0) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(hay + u0);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const uint4 x = src[v];
+                w[4 * v] = x.x; w[4 * v + 1] = x.y; w[4 * v + 2] = x.z; w[4 * v + 3] = x.w;
+            }
+        };
+        // word W of the region (W = -32 .. 2050) -> its place(s) in the image
+        auto put = [&](int32_t W, uint32_t word) {
+            const int32_t sg = W >> 5;
+            const uint32_t k = (uint32_t)W & 31u;
+            if (sg < (int32_t)kBitsSegs) img[(uint32_t)(sg + 1) * kBitsStride + k] = word;
+            if (k < kBitsLook && sg >= 0) img[(uint32_t)sg * kBitsStride + kBitsSegWords + k] = word; // (behind segment sg - 1)
+        };
+        {
+            uint32_t w[16];
+            if (r > 0 && lane >= 32) { // segment -1: the last 1024 positions before the region
+                load_careful(w, R0 - kBitsTileUnits + lane * 32u);
+                put((int32_t)lane - 64, bits_pack(w, base2, dmax));
+            }
+            if (lane < kBitsLook) { // the first words of the next region
+                load_careful(w, R0 + kBitsRegionUnits + lane * 32u);
+                put((int32_t)(kBitsRegionUnits / 32u + lane), bits_pack(w, base2, dmax));
+            }
+        }
+        if ((uint64_t)R0 + kBitsRegionUnits <= nu) { // every load inside the buffer: the stream, one tile ahead
+            uint32_t wa[16], wb[16];
+            load_fast(wa, R0 + lane * 32u);
+#pragma unroll 1
+            for (uint32_t tl = 0; tl < kBitsRegionUnits / kBitsTileUnits; tl += 2) {
+                load_fast(wb, R0 + (tl + 1u) * kBitsTileUnits + lane * 32u);
+                put((int32_t)(tl * 64u + lane), bits_pack(wa, base2, dmax));
+                if (tl + 2u < kBitsRegionUnits / kBitsTileUnits) load_fast(wa, R0 + (tl + 2u) * kBitsTileUnits + lane * 32u);
+                put((int32_t)((tl + 1u) * 64u + lane), bits_pack(wb, base2, dmax));
+            }
+        } else {
+            uint32_t w[16];
+#pragma unroll 1
+            for (uint32_t tl = 0; tl < kBitsRegionUnits / kBitsTileUnits; ++tl) {
+                load_careful(w, R0 + tl * kBitsTileUnits + lane * 32u);
+                put((int32_t)(tl * 64u + lane), bits_pack(w, base2, dmax));
+            }
+        }
+        const bool foreign = (dmax & 0xffffu) >= c.span || (dmax >> 16) >= c.span;
+        if (__any(foreign) && lane == 0) L.d_exit[1] = 1ull; // a unit outside the alphabet: not this kernel's text
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- pass 1: where the chain enters the lane's segment --------------------------------------------------------------
+        const uint32_t start = R0 + lane * kBitsSegUnits;
+        uint32_t e_in;
+        if (r == 0 && lane == 0) {
+            e_in = L.entry;
+        } else {
+            const uint32_t *seg = img + lane * kBitsStride; // segment lane - 1
+            const uint32_t ps = start - kBitsSegUnits;
+            const uint32_t p0 = max(ps, L.entry), lim = min(start, L.own_end);
+            uint32_t q = p0 - ps;
+            const uint32_t qlim = lim > ps ? lim - ps : 0u;
+            while (q < qlim) q += bits_longest(c, tab, seg, q, ps + q);
+            e_in = ps + q;
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- pass 2: the lane's own segment from there: count, and mark the starts in place of the text left behind ---------
+        uint32_t *seg = img + (lane + 1u) * kBitsStride;
+        const uint32_t bound = min(start + kBitsSegUnits, L.own_end);
+        const uint32_t qend = bound > start ? bound - start : 0u;
+        uint32_t q = e_in - start; // (an entry beyond the segment, or a segment beyond the owned range: no steps)
+        uint32_t cur = 0, cw = 0, cnt = 0;
+        while (q < qend) {
+            const uint32_t len = bits_longest(c, tab, seg, q, start + q);
+            const uint32_t k = q >> 5;
+            if (k != cur) { // the walk has left word cur: its marks take the text's place
+                seg[cur] = cw;
+                for (uint32_t z = cur + 1u; z < k; ++z) seg[z] = 0u;
+                cw = 0u;
+                cur = k;
+            }
+            cw |= 1u << (q & 31u);
+            ++cnt;
+            q += len;
+        }
+        seg[cur] = cw;
+        for (uint32_t z = cur + 1u; z < kBitsSegWords; ++z) seg[z] = 0u;
+        const uint32_t x_out = start + q; // the chain's first position at or behind min(segment end, own_end)
+        // every exit is the next lane's entry (boundaries inside the owned range)
+        const uint32_t e_next = __shfl_down(e_in, 1);
+        const bool differs = lane < 63u && (uint64_t)start + kBitsSegUnits < L.own_end && x_out != e_next;
+        if (__any(differs) && lane == 0) L.d_exit[1] = 1ull;
+        if (lane == 0) L.d_pred[r] = e_in;
+        if (lane == 63) {
+            L.d_true[r] = x_out;
+            img[kBitsWaveWords - 1u] = x_out == R0 + kBitsRegionUnits ? 1u : 0u; // "segment 64, word 0": is its first position a start
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (start < L.own_end && bound == L.own_end) { // this lane's segment holds the last owned position: its exit is the call's
+            L.d_exit[0] = (unsigned long long)x_out;
+            // the last match ends at x_out - 1: inside the last word this call stores -> through the image (the start bit of
+            // x_out, beyond the owned range, is masked from the starts below); in a later word -> straight into the bitmap,
+            // which the caller has zeroed from there on
+            const uint32_t ew = (x_out - 1u) >> 5;
+            if (ew > last_w) {
+                atomicOr(&L.d_ebits[ew], 1u << ((x_out - 1u) & 31u));
+            } else if (x_out < R0 + kBitsRegionUnits) {
+                const uint32_t rel = x_out - R0;
+                img[((rel >> 10) + 1u) * kBitsStride + ((rel >> 5) & 31u)] |= 1u << (rel & 31u);
+            } // (x_out == the region's end: lane 63's word above)
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- out: starts, ends (= starts >> 1), per tile of segments the first start and the count ---------------------------
+        const uint32_t gw0 = R0 >> 5;
+        const uint32_t cut = (L.own_end & 31u) ? ~(~0u << (L.own_end & 31u)) : ~0u; // positions of the last word inside the owned range
+#pragma unroll 4
+        for (uint32_t i = 0; i < kBitsRegionUnits / kBitsTileUnits; ++i) {
+            const uint32_t sg = 2u * i + (lane >> 5), k = lane & 31u;
+            const uint32_t slot = (sg + 1u) * kBitsStride + k;
+            const uint32_t cw0 = img[slot], cw1 = img[k == 31u ? (sg + 2u) * kBitsStride : slot + 1u];
+            const uint32_t gw = gw0 + i * 64u + lane;
+            if (gw <= last_w) {
+                L.d_bits[gw] = gw == last_w ? (cw0 & cut) : cw0;
+                L.d_ebits[gw] = __builtin_amdgcn_alignbit(cw1, cw0, 1);
+            }
+        }
+        {
+            const uint32_t ts = 1u << L.tile_log2; // segments per tile
+            uint32_t csum = cnt;
+            for (uint32_t d = 1; d < ts; d <<= 1) csum += __shfl_down(csum, d);
+            if ((lane & (ts - 1u)) == 0) {
+                const uint32_t tile = (r * kBitsSegs + lane) >> L.tile_log2;
+                const uint32_t tend = (uint32_t)min((uint64_t)L.own_end, (uint64_t)start + (uint64_t)ts * kBitsSegUnits);
+                L.d_sync[tile] = e_in < tend ? e_in : ~0u;
+                L.d_counts[tile] = csum;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// every region's entry is the exit of the region before it
+__global__ __launch_bounds__(256) void k_longest_bits_check(LongestBitsLaunch L) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r == 0 || r >= L.n_regions) return;
+    if (L.d_pred[r] != L.d_true[r - 1]) L.d_exit[1] = 1ull;
+}
+
+uint32_t longest_bits_region_units() { return kBitsRegionUnits; }
+uint32_t longest_bits_seg_units() { return kBitsSegUnits; }
+
+hipError_t launch_longest_bits(const DevTables &t, const LongestBitsLaunch &l, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    ACGPU_LAUNCH_EV(k_longest_bits, dim3(l.grid), dim3(kBitsBlock), 0, stream, ev_start, ev_stop, t, l);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (l.n_regions > 1) hipLaunchKernelGGL(k_longest_bits_check, dim3((l.n_regions + 255) / 256), dim3(256), 0, stream, l);
+    return hipGetLastError();
+}
+
+} // namespace acgpu
