@@ -810,7 +810,7 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
         Bl.n_units = (uint32_t)sh->n_units;
         Bl.own_end = (uint32_t)sh->own_end;
         Bl.entry = (uint32_t)entry;
-        Bl.g0 = (uint32_t)entry & ~31u;
+        Bl.g0 = (uint32_t)entry & ~127u; // (bitmap words in groups of four: 16-byte stores)
         const uint32_t region_units = longest_bits_region_units();
         Bl.n_regions = (uint32_t)((sh->own_end - Bl.g0 + region_units - 1) / region_units);
         Bl.tile_log2 = 2; // emit tiles of four segments (4096 positions)
@@ -832,6 +832,7 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
         Bl.d_pred = (uint32_t *)d.blockmax.p;
         Bl.d_true = Bl.d_pred + Bl.n_regions;
         Bl.grid = (int)std::min<uint64_t>((uint64_t)d.n_cu, (Bl.n_regions + 15) / 16);
+        Bl.debug = (uint32_t)(tunables().tile_debug >> 32);
         HIP_TRY(hipMemsetAsync(d.counter.p, 0, 64, stream));
         d.cclean[0] = false; // (match_all's first set of slot counters lives here)
         { // the words of the end bitmap behind the last one the kernel stores: the last match may end there (one atomicOr)
@@ -876,6 +877,13 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
             return ACGPU_OK;
         }
         HIP_TRY(hipStreamSynchronize(stream));
+#ifdef ACGPU_ABLATION
+        if (Bl.debug) {
+            unsigned long long mism = 0;
+            (void)hipMemcpy(&mism, (const char *)d.counter.p + 24, 8, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[k_longest_bits debug %u] segments whose assumed entry was not the exit before them: %llu\n", Bl.debug, mism);
+        }
+#endif
         if (d.h_counter[1] != 0) // (a unit outside the alphabet, or a chain that did not merge inside a segment)
             return match_longest(a, d, sh, record_kind, d_out, cap, n_out, stream, prof, nullptr, true);
         *n_out = d.h_counter[0];

@@ -521,7 +521,7 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
                     node = e & 0x7fffffffu;
                     if (e >> 31) best = j + 1;
                 }
-                E[4 * i + 2] = (best << 8) | (alive ? kBitsAlive : 0u);
+                E[4 * i + 2] = (best << 8) | (alive ? kBitsAlive : 0u) | (alive ? 0u : 63u << 16);
                 if (alive) todo.push_back({i, node, 0});
             }
             while (!todo.empty()) { // breadth first: what is near the root gets its entries first
@@ -560,7 +560,7 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
                 }
                 E[4 * td.entry + 0] = label;
                 E[4 * td.entry + 1] = term;
-                E[4 * td.entry + 2] |= len | (kind << 6);
+                E[4 * td.entry + 2] |= len | (kind << 6) | ((kind != kBitsLeaf ? len : 63u) << 16); // (bits 16-21: bits_label)
                 E[4 * td.entry + 3] = next;
             }
             E.resize((size_t)kBitsTabEntries * 4, 0);

@@ -98,10 +98,11 @@ ACGPU_HD inline uint32_t l2_rotr(uint32_t x, uint32_t r) { return (x >> (r & 31u
 
 // k_longest_bits (acgpu_longest_bits.hip) and its table (acgpu_build.cpp 6c).  An entry is four words {label, terminal bits,
 // meta, next}; meta = label length (bits 0-5) | kind (bits 6-7) | best (bits 8-15: a first-level entry's longest keyword
-// among the RK units, a junction child's "the child ends a keyword") | kBitsAlive.
+// among the RK units, a junction child's "the child ends a keyword") | bits 16-21: the label's length if the trie goes on
+// behind the label, else 63 | kBitsAlive.
 constexpr uint32_t kBitsRK = 9;            // first level: 2^9 entries indexed by the text's next 9 units
 constexpr uint32_t kBitsTabEntries = 1120; // 17.5 KiB of LDS: what 16 waves' text images leave
-constexpr uint32_t kBitsAlive = 1u << 16;
+constexpr uint32_t kBitsAlive = 1u << 24;
 constexpr uint32_t kBitsLeaf = 0, kBitsJunction = 1, kBitsCont = 2, kBitsDeep = 3;
 
 // Host-side automaton tables.  State numbering: root = 0; states WITHOUT any output (own or inherited

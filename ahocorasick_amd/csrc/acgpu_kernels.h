@@ -225,7 +225,7 @@ struct LongestChainLaunch {
 struct LongestBitsLaunch {
     const uint16_t *d_hay;
     uint32_t n_units, own_end, entry;
-    uint32_t g0;          // entry & ~31: first position of segment 0 of region 0
+    uint32_t g0;          // entry & ~127: first position of segment 0 of region 0
     uint32_t n_regions;   // regions of longest_bits_region_units() positions from g0 on, up to own_end
     uint32_t tile_log2;   // segments per tile of d_sync / d_counts (log2)
     uint32_t max_len;
@@ -234,6 +234,7 @@ struct LongestBitsLaunch {
     unsigned long long *d_exit;  // [0]: the chain's first position at or behind own_end, [1]: bail flag (both zeroed by the caller)
     uint32_t *d_pred, *d_true;   // per region: the entry it assumed, the exit it found
     int grid;
+    uint32_t debug;              // ACGPU_ABLATION builds: timing experiments (results are wrong)
 };
 uint32_t longest_bits_region_units();
 uint32_t longest_bits_seg_units();

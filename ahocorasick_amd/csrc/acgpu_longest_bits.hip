@@ -41,7 +41,7 @@ constexpr uint32_t kBitsRegionUnits = kBitsSegs * kBitsSegUnits;            // 6
 constexpr uint32_t kBitsWaveWords = (kBitsSegs + 1) * kBitsStride + 1;      // segments -1 .. 63, and "segment 64, word 0"
 constexpr uint32_t kBitsTileUnits = 2048;                                   // 64 lanes x 32 units: one word per lane
 constexpr uint32_t kBitsTextMax = 33u * 32u;    // a 32-bit window may begin below this segment-relative position
-static_assert(kBitsWaves * kBitsWaveWords * 4 + kBitsTabEntries * 16 <= 160 * 1024, "LDS");
+static_assert(kBitsWaves * kBitsWaveWords * 4 + kBitsTabEntries * 16 + 4 <= 160 * 1024, "LDS");
 static_assert(kBitsRK + 32 <= 64, "a first-level lookup reads three words");
 
 struct BitsCtx {
@@ -103,60 +103,68 @@ __device__ __noinline__ uint32_t bits_slow(const BitsCtx &c, uint32_t p) {
 }
 
 // entry e's label against the 32 text bits tw behind the walk's first `depth` units; raises best to the longest keyword
-// that ends inside the matched part; true: the whole label matched
+// that ends inside the matched part; true: the whole label matched AND the trie goes on behind it (meta bits 16-21: the
+// label's length for such entries, 63 -- what no count of matched units equals -- for the others)
 __device__ __forceinline__ bool bits_label(const uint4 &e, uint32_t tw, uint32_t depth, uint32_t &best) {
     const uint32_t len = e.z & 63u;                        // at most 31
     const uint32_t m = min(bits_ffbl(tw ^ e.x), len);      // matched units of the label
     const uint32_t tm = e.y & ((1u << m) - 1u);            // keywords that end inside them
     const uint32_t h = bits_ffbh(tm);                      // (all ones: none)
     best = tm ? depth + 32u - h : best;
-    return m == len;
+    return m == ((e.z >> 16) & 63u);
 }
 
-// the longest keyword that starts at segment-relative position q (absolute position p): what LongestMatchSet's queue would
-// report from there.  seg: the lane's segment in the wave's LDS image (words behind the segment: the next segment's).
-__device__ __forceinline__ uint32_t bits_longest(const BitsCtx &c, const uint4 *tab, const uint32_t *seg, uint32_t q, uint32_t p) {
+// what follows a label that matched whole: further entries (the path is longer than 31 units, or branches), and the walk
+// through global memory where the table or the lane's text in LDS ends
+__device__ __noinline__ uint32_t bits_more(const BitsCtx &c, const uint4 *tab, const uint32_t *seg, uint32_t q, uint32_t p, uint4 e, uint32_t best) {
+    uint32_t depth = kBitsRK;
+    for (;;) {
+        depth += e.z & 63u;
+        const uint32_t kind = (e.z >> 6) & 3u;
+        if (kind == kBitsLeaf) return best;
+        uint32_t t = q + depth;
+        if (kind == kBitsDeep || t + 1u >= kBitsTextMax) return bits_slow(c, p);
+        if (kind == kBitsJunction) {
+            const uint32_t code = (seg[t >> 5] >> (t & 31u)) & 1u;
+            e = tab[e.w + code];
+            if (!(e.z & kBitsAlive)) return best;
+            ++depth;
+            ++t;
+            if ((e.z >> 8) & 0xffu) best = depth;
+        } else {
+            e = tab[e.w];
+        }
+        const uint32_t *v = seg + (t >> 5);
+        if (!bits_label(e, __builtin_amdgcn_alignbit(v[1], v[0], t & 31u), depth, best)) return best;
+    }
+}
+
+// One step of a chain: the longest keyword that starts at segment-relative position q (what LongestMatchSet's queue would
+// report from there), at least 1.  seg: the lane's segment in the wave's LDS image (the words behind it: the next segment's
+// first ones); seg_pos: the segment's absolute position; qsafe: matches that end behind this relative position may reach
+// beyond the buffer, whose missing units were packed as the first letter.
+__device__ __forceinline__ uint32_t bits_longest(const BitsCtx &c, const uint4 *tab, const uint32_t *seg, uint32_t q, uint32_t seg_pos, uint32_t qsafe) {
     constexpr uint32_t RK = kBitsRK;
     const uint32_t *w = seg + (q >> 5);
     const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], sh = q & 31u;
     const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), mid = __builtin_amdgcn_alignbit(w2, w1, sh);
-    uint4 e = tab[lo & ((1u << RK) - 1u)];
-    uint32_t best = (e.z >> 8) & 0xffu; // the longest keyword among the first RK units
-    uint32_t depth = RK;
-    bool full = bits_label(e, __builtin_amdgcn_alignbit(mid, lo, RK), depth, best);
-    if (__builtin_expect(full && (e.z & 0xc0u) != 0u, 0)) { // the label matched whole and the trie goes on behind it: rare
-        for (;;) {
-            depth += e.z & 63u;
-            const uint32_t kind = (e.z >> 6) & 3u;
-            if (kind == kBitsLeaf) break;
-            uint32_t t = q + depth;
-            if (kind == kBitsDeep || t + 1u >= kBitsTextMax) { // beyond the table, or beyond the text this lane can read in LDS
-                best = bits_slow(c, p);
-                break;
-            }
-            if (kind == kBitsJunction) {
-                const uint32_t code = (seg[t >> 5] >> (t & 31u)) & 1u;
-                e = tab[e.w + code];
-                if (!(e.z & kBitsAlive)) break;
-                ++depth;
-                ++t;
-                if ((e.z >> 8) & 0xffu) best = depth;
-            } else {
-                e = tab[e.w];
-            }
-            const uint32_t *v = seg + (t >> 5);
-            if (!bits_label(e, __builtin_amdgcn_alignbit(v[1], v[0], t & 31u), depth, best)) break;
-        }
+    const uint4 e = tab[lo & ((1u << RK) - 1u)];
+    uint32_t best = (e.z >> 8) & 0xffu; // the longest keyword among the first RK units: at least 1 (every letter is a keyword)
+    const bool more = bits_label(e, __builtin_amdgcn_alignbit(mid, lo, RK), RK, best);
+    if (__builtin_expect(more || q + best > qsafe, 0)) { // rare: the trie goes on behind the label; the end of the buffer
+        if (more) best = bits_more(c, tab, seg, q, seg_pos + q, e, best);
+        if (q + best > qsafe) best = bits_slow(c, seg_pos + q);
+        best = max(best, 1u); // (0: a unit outside the alphabet -- the call bails out; the chain moves on whatever it reads)
     }
-    // (units behind the end of the buffer were packed as the first letter: a keyword that would end there is not one)
-    if (__builtin_expect((uint64_t)p + best > (uint64_t)c.n_units, 0)) best = bits_slow(c, p);
-    return max(best, 1u); // (0: a unit outside the alphabet -- the call bails out; the chain moves on whatever it reads)
+    return best;
 }
 
 __global__ __launch_bounds__(kBitsBlock) void k_longest_bits(DevTables T, LongestBitsLaunch L) {
     __shared__ __attribute__((aligned(16))) uint4 tab[kBitsTabEntries];
     __shared__ uint32_t img_all[kBitsWaves][kBitsWaveWords];
+    __shared__ uint32_t gate; // waves of the first half that have their first region's text
     for (uint32_t i = threadIdx.x; i < kBitsTabEntries; i += blockDim.x) tab[i] = reinterpret_cast<const uint4 *>(T.bits_tab)[i];
+    if (threadIdx.x == 0) gate = 0u;
     __syncthreads();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const uint32_t lane = lane_id();
@@ -172,6 +180,15 @@ __global__ __launch_bounds__(kBitsBlock) void k_longest_bits(DevTables T, Longes
     const uint16_t *hay = L.d_hay;
     const uint32_t nu = L.n_units;
     const uint32_t last_w = (L.own_end - 1u) >> 5; // the last bitmap word this call writes
+    // A wave alternates between streaming text (memory) and following chains (instruction issue, LDS).  The second half of
+    // the workgroup starts when the first half has its text: from then on one half streams while the other walks.
+    bool first = true;
+    if (wave >= kBitsWaves / 2) {
+#ifdef ACGPU_ABLATION
+        if (!(L.debug & 16u))
+#endif
+        while (__hip_atomic_load(&gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (uint32_t)(kBitsWaves / 2)) __builtin_amdgcn_s_sleep(64);
+    }
 
     for (uint32_t r = blockIdx.x * kBitsWaves + wave; r < L.n_regions; r += gridDim.x * kBitsWaves) {
         const uint32_t R0 = L.g0 + r * kBitsRegionUnits; // first position of segment 0
@@ -210,20 +227,19 @@ __global__ __launch_bounds__(kBitsBlock) void k_longest_bits(DevTables T, Longes
             if (sg < (int32_t)kBitsSegs) img[(uint32_t)(sg + 1) * kBitsStride + k] = word;
             if (k < kBitsLook && sg >= 0) img[(uint32_t)sg * kBitsStride + kBitsSegWords + k] = word; // (behind segment sg - 1)
         };
-        {
-            uint32_t w[16];
-            if (r > 0 && lane >= 32) { // segment -1: the last 1024 positions before the region
-                load_careful(w, R0 - kBitsTileUnits + lane * 32u);
-                put((int32_t)lane - 64, bits_pack(w, base2, dmax));
-            }
-            if (lane < kBitsLook) { // the first words of the next region
-                load_careful(w, R0 + kBitsRegionUnits + lane * 32u);
-                put((int32_t)(kBitsRegionUnits / 32u + lane), bits_pack(w, base2, dmax));
-            }
-        }
-        if ((uint64_t)R0 + kBitsRegionUnits <= nu) { // every load inside the buffer: the stream, one tile ahead
+        // the words around the region in ONE more tile: lanes 32-63 the 1024 positions before it (segment -1), lanes 0-2 the
+        // first words of the next region; the other lanes read their words of tile 0 once more and drop them
+        const bool aux_lane = (r > 0 && lane >= 32) || lane < kBitsLook;
+        const int32_t aux_W = lane >= 32 ? (int32_t)lane - 64 : (int32_t)(kBitsRegionUnits / 32u + lane);
+        const uint32_t aux_pos = aux_lane ? R0 + (uint32_t)(aux_W * 32) : R0 + lane * 32u;
+        if ((uint64_t)R0 + kBitsRegionUnits + kBitsLook * 32u <= nu) { // every load inside the buffer: the stream, one tile ahead
             uint32_t wa[16], wb[16];
+            load_fast(wb, aux_pos);
             load_fast(wa, R0 + lane * 32u);
+            {
+                const uint32_t word = bits_pack(wb, base2, dmax);
+                if (aux_lane) put(aux_W, word);
+            }
 #pragma unroll 1
             for (uint32_t tl = 0; tl < kBitsRegionUnits / kBitsTileUnits; tl += 2) {
                 load_fast(wb, R0 + (tl + 1u) * kBitsTileUnits + lane * 32u);
@@ -233,6 +249,10 @@ __global__ __launch_bounds__(kBitsBlock) void k_longest_bits(DevTables T, Longes
             }
         } else {
             uint32_t w[16];
+            if (aux_lane) {
+                load_careful(w, aux_pos);
+                put(aux_W, bits_pack(w, base2, dmax));
+            }
 #pragma unroll 1
             for (uint32_t tl = 0; tl < kBitsRegionUnits / kBitsTileUnits; ++tl) {
                 load_careful(w, R0 + tl * kBitsTileUnits + lane * 32u);
@@ -242,6 +262,8 @@ __global__ __launch_bounds__(kBitsBlock) void k_longest_bits(DevTables T, Longes
         const bool foreign = (dmax & 0xffffu) >= c.span || (dmax >> 16) >= c.span;
         if (__any(foreign) && lane == 0) L.d_exit[1] = 1ull; // a unit outside the alphabet: not this kernel's text
         __builtin_amdgcn_wave_barrier();
+        if (first && wave < kBitsWaves / 2 && lane == 0) atomicAdd(&gate, 1u);
+        first = false;
 
         // ---- pass 1: where the chain enters the lane's segment --------------------------------------------------------------
         const uint32_t start = R0 + lane * kBitsSegUnits;
@@ -251,10 +273,18 @@ __global__ __launch_bounds__(kBitsBlock) void k_longest_bits(DevTables T, Longes
         } else {
             const uint32_t *seg = img + lane * kBitsStride; // segment lane - 1
             const uint32_t ps = start - kBitsSegUnits;
-            const uint32_t p0 = max(ps, L.entry), lim = min(start, L.own_end);
+            uint32_t p0 = max(ps, L.entry);
+            const uint32_t lim = min(start, L.own_end);
+#ifdef ACGPU_ABLATION
+            if ((L.debug & 8u) && lim > (L.debug >> 16)) p0 = max(p0, lim - (L.debug >> 16)); // a shorter run-up (how often does it fail?)
+#endif
             uint32_t q = p0 - ps;
             const uint32_t qlim = lim > ps ? lim - ps : 0u;
-            while (q < qlim) q += bits_longest(c, tab, seg, q, ps + q);
+            const uint32_t qsafe = nu - ps; // (ps < nu: the segment before one that begins inside the owned range)
+#ifdef ACGPU_ABLATION
+            if (L.debug & 1u) q = max(q, qlim); // no pass 1 (wrong entries: timing only)
+#endif
+            while (q < qlim) q += bits_longest(c, tab, seg, q, ps, qsafe);
             e_in = ps + q;
         }
         __builtin_amdgcn_wave_barrier();
@@ -263,10 +293,14 @@ __global__ __launch_bounds__(kBitsBlock) void k_longest_bits(DevTables T, Longes
         uint32_t *seg = img + (lane + 1u) * kBitsStride;
         const uint32_t bound = min(start + kBitsSegUnits, L.own_end);
         const uint32_t qend = bound > start ? bound - start : 0u;
+        const uint32_t qsafe = nu > start ? nu - start : 0u;
         uint32_t q = e_in - start; // (an entry beyond the segment, or a segment beyond the owned range: no steps)
         uint32_t cur = 0, cw = 0, cnt = 0;
+#ifdef ACGPU_ABLATION
+        if (L.debug & 2u) q = max(q, qend); // no pass 2
+#endif
         while (q < qend) {
-            const uint32_t len = bits_longest(c, tab, seg, q, start + q);
+            const uint32_t len = bits_longest(c, tab, seg, q, start, qsafe);
             const uint32_t k = q >> 5;
             if (k != cur) { // the walk has left word cur: its marks take the text's place
                 seg[cur] = cw;
@@ -284,6 +318,12 @@ __global__ __launch_bounds__(kBitsBlock) void k_longest_bits(DevTables T, Longes
         // every exit is the next lane's entry (boundaries inside the owned range)
         const uint32_t e_next = __shfl_down(e_in, 1);
         const bool differs = lane < 63u && (uint64_t)start + kBitsSegUnits < L.own_end && x_out != e_next;
+#ifdef ACGPU_ABLATION
+        if (L.debug) {
+            const uint64_t bd = __ballot(differs);
+            if (bd && lane == 0) atomicAdd(&L.d_exit[3], (unsigned long long)__popcll(bd));
+        } else
+#endif
         if (__any(differs) && lane == 0) L.d_exit[1] = 1ull;
         if (lane == 0) L.d_pred[r] = e_in;
         if (lane == 63) {
@@ -307,17 +347,30 @@ __global__ __launch_bounds__(kBitsBlock) void k_longest_bits(DevTables T, Longes
         __builtin_amdgcn_wave_barrier();
 
         // ---- out: starts, ends (= starts >> 1), per tile of segments the first start and the count ---------------------------
-        const uint32_t gw0 = R0 >> 5;
+        const uint32_t gw0 = R0 >> 5; // (a multiple of 4: g0 is a multiple of 128 positions)
         const uint32_t cut = (L.own_end & 31u) ? ~(~0u << (L.own_end & 31u)) : ~0u; // positions of the last word inside the owned range
-#pragma unroll 4
-        for (uint32_t i = 0; i < kBitsRegionUnits / kBitsTileUnits; ++i) {
-            const uint32_t sg = 2u * i + (lane >> 5), k = lane & 31u;
-            const uint32_t slot = (sg + 1u) * kBitsStride + k;
-            const uint32_t cw0 = img[slot], cw1 = img[k == 31u ? (sg + 2u) * kBitsStride : slot + 1u];
-            const uint32_t gw = gw0 + i * 64u + lane;
-            if (gw <= last_w) {
-                L.d_bits[gw] = gw == last_w ? (cw0 & cut) : cw0;
-                L.d_ebits[gw] = __builtin_amdgcn_alignbit(cw1, cw0, 1);
+#pragma unroll 2
+        for (uint32_t i = 0; i < kBitsRegionUnits / (4u * kBitsTileUnits); ++i) { // four words per lane: 16-byte stores
+#ifdef ACGPU_ABLATION
+            if (L.debug & 4u) break; // no bitmap stores
+#endif
+            const uint32_t g = i * 64u + lane, sg = g >> 3, k = (g & 7u) * 4u;
+            const uint32_t *sp = img + (sg + 1u) * kBitsStride + k;
+            const uint32_t c0 = sp[0], c1 = sp[1], c2 = sp[2], c3 = sp[3], c4 = k == 28u ? img[(sg + 2u) * kBitsStride] : sp[4];
+            const uint32_t e0 = __builtin_amdgcn_alignbit(c1, c0, 1), e1 = __builtin_amdgcn_alignbit(c2, c1, 1),
+                           e2 = __builtin_amdgcn_alignbit(c3, c2, 1), e3 = __builtin_amdgcn_alignbit(c4, c3, 1);
+            const uint32_t gw = gw0 + 4u * g;
+            if (gw + 3u < last_w) {
+                *reinterpret_cast<uint4 *>(L.d_bits + gw) = make_uint4(c0, c1, c2, c3);
+                *reinterpret_cast<uint4 *>(L.d_ebits + gw) = make_uint4(e0, e1, e2, e3);
+            } else if (gw <= last_w) { // the group with the last word
+                const uint32_t cs[4] = {c0, c1, c2, c3}, es[4] = {e0, e1, e2, e3};
+#pragma unroll
+                for (uint32_t z = 0; z < 4; ++z)
+                    if (gw + z <= last_w) {
+                        L.d_bits[gw + z] = gw + z == last_w ? (cs[z] & cut) : cs[z];
+                        L.d_ebits[gw + z] = es[z];
+                    }
             }
         }
         {
@@ -333,6 +386,7 @@ __global__ __launch_bounds__(kBitsBlock) void k_longest_bits(DevTables T, Longes
         }
         __builtin_amdgcn_wave_barrier();
     }
+    if (first && wave < kBitsWaves / 2 && lane == 0) atomicAdd(&gate, 1u); // (a wave without a region)
 }
 
 // every region's entry is the exit of the region before it
