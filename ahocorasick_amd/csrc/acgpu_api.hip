@@ -767,7 +767,7 @@ int match_longest_sparse(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, in
 // LONGEST-mode pipeline on one shard: reverse scan -> chain count -> prefix sum -> chain write.
 // With a ticket (the walk pipeline only: want_async_longest) the call returns after enqueueing; acgpu_match_device_end collects it.
 int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_kind, void *d_out, uint64_t cap,
-                  uint64_t *n_out, hipStream_t stream, acgpu_profile *prof, Ticket *tk = nullptr, bool no_bits = false) {
+                  uint64_t *n_out, hipStream_t stream, acgpu_profile *prof, Ticket *tk = nullptr, int bits_level = 0) {
     const HostTables &t = a->t;
     hipEvent_t *ev = tk ? tk->ev : d.ev;
     const bool timed = tk ? tk->profiled : prof != nullptr;
@@ -799,9 +799,10 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
     // Set records over a two-letter alphabet in which every letter is a keyword: the text as one bit per unit, the chain's own
     // positions only (k_longest_bits, acgpu_longest_bits.hip) -- no length array, no synchronisation pass.  The kernel checks
     // its own result (every segment's exit against the next one's entry) and raises the bail flag -- also for a unit outside
-    // the alphabet --: the call is then redone right here, or in acgpu_match_device_end, by the walk pipeline below.
+    // the alphabet --: the call is then redone right here, or in acgpu_match_device_end: once more with a run-up of a whole
+    // segment (bits_level 1), then by the walk pipeline below (bits_level 2).
     // Tunable tile_debug bit 33554432: never; bit 67108864: also for short texts (tests).
-    const bool bits_form = !no_bits && record_kind == ACGPU_REC_SET && d.T.bits_rk != 0 && !(tunables().tile_debug & 33554432) &&
+    const bool bits_form = bits_level < 2 && record_kind == ACGPU_REC_SET && d.T.bits_rk != 0 && !(tunables().tile_debug & 33554432) &&
                            (own_len >= (1ull << 21) || (tunables().tile_debug & 67108864)) && tunables().force_kernel == 0;
     if (bits_form) {
         int rc;
@@ -814,6 +815,7 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
         const uint32_t region_units = longest_bits_region_units();
         Bl.n_regions = (uint32_t)((sh->own_end - Bl.g0 + region_units - 1) / region_units);
         Bl.tile_log2 = 2; // emit tiles of four segments (4096 positions)
+        Bl.runup = bits_level == 0 ? longest_bits_seg_units() / 2 : longest_bits_seg_units();
         Bl.max_len = t.max_len;
         const uint32_t n_tiles = (Bl.n_regions * (region_units / longest_bits_seg_units())) >> Bl.tile_log2;
         if ((rc = d.counter.ensure(64))) return rc;
@@ -884,8 +886,8 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
             fprintf(stderr, "[k_longest_bits debug %u] segments whose assumed entry was not the exit before them: %llu\n", Bl.debug, mism);
         }
 #endif
-        if (d.h_counter[1] != 0) // (a unit outside the alphabet, or a chain that did not merge inside a segment)
-            return match_longest(a, d, sh, record_kind, d_out, cap, n_out, stream, prof, nullptr, true);
+        if (d.h_counter[1] != 0) // (1: a chain that did not merge inside the run-up; 2: a unit outside the alphabet)
+            return match_longest(a, d, sh, record_kind, d_out, cap, n_out, stream, prof, nullptr, d.h_counter[1] == 1 ? bits_level + 1 : 2);
         *n_out = d.h_counter[0];
         sh->chain_exit = (int64_t)d.h_counter[2];
         if (prof) {
@@ -1634,7 +1636,7 @@ int end_ticket(const acgpu_automaton *ca, acgpu_ticket *ticket, uint64_t *n_out,
         return rc;
     }
     if (tk->kind == 1 && tk->h_count[1] != 0) { // k_longest_bits bailed out (a unit outside the alphabet, a chain that did not merge): the walk pipeline
-        const int rc = match_longest(a, *d, &tk->shard, tk->record_kind, tk->d_out, tk->cap, n_out, tk->stream, prof, nullptr, true);
+        const int rc = match_longest(a, *d, &tk->shard, tk->record_kind, tk->d_out, tk->cap, n_out, tk->stream, prof, nullptr, tk->h_count[1] == 1 ? 1 : 2);
         if (tk->user_shard) tk->user_shard->chain_exit = tk->shard.chain_exit;
         tk->busy = false;
         d->inflight--;

@@ -228,6 +228,7 @@ struct LongestBitsLaunch {
     uint32_t g0;          // entry & ~127: first position of segment 0 of region 0
     uint32_t n_regions;   // regions of longest_bits_region_units() positions from g0 on, up to own_end
     uint32_t tile_log2;   // segments per tile of d_sync / d_counts (log2)
+    uint32_t runup;       // pass 1 follows a chain through this many positions in front of a segment (at most a segment)
     uint32_t max_len;
     uint32_t *d_bits, *d_ebits;  // bit p: a match starts at p / a match ends at p + 1 (LongestChainLaunch)
     uint32_t *d_sync, *d_counts; // per tile: its first match start (~0u: none), its matches

@@ -12,9 +12,11 @@
 //  * L[p] comes from the path-compressed keyword trie (acgpu_build.cpp 6c, 17.5 KiB of LDS): the text's next 9 units
 //    index an entry {label, terminal bits, meta, next}; the label -- the one-child path below that node, 31 units -- is
 //    compared with the text by one xor and a count of trailing zeros; longer paths and branches take further entries (rare);
-//  * pass 1: lane j follows the chain of segment j-1 from that segment's FIRST position to its end.  Chains that start at
-//    different positions merge within a few matches, so where it leaves the segment is (with overwhelming probability) where
-//    the true chain does: lane j's entry;
+//  * pass 1: lane j follows a chain through the last `runup` positions of segment j-1 (from wherever that stretch begins).
+//    Chains that start at different positions merge within a few matches, so where it leaves the segment is (with
+//    overwhelming probability) where the true chain does: lane j's entry.  Measured at config 4 (2^29 units, 524 288 segments):
+//    a run-up of 128 positions misses 2509 entries, 256 positions 18, 512 positions none (0.766 per step: 5e-10 per segment);
+//    the call starts with 512 and, should the check below fail, is redone once with the whole segment (1024);
 //  * pass 2: lane j follows the chain of its own segment from that entry, counts the matches and marks their starts -- in
 //    the place of the text words it has left behind.  Then every lane's exit is compared with its neighbour's entry (the
 //    first region's first entry is the call's chain entry, so equal everywhere means exact everywhere); a difference
@@ -23,6 +25,7 @@
 //    chain's positions ARE the match starts and (starts >> 1) the match ends: both bitmaps leave as coalesced stores, with
 //    the count and the first start of every tile of segments, for the prefix sum and k_longest_emit_ends.
 // HBM-bound: 2 B per unit read once; the kernel writes two bits per unit.  No length array, no synchronisation pass.
+#include <cstdio>
 #include <hip/hip_runtime.h>
 
 #include "acgpu_device.h"
@@ -139,26 +142,74 @@ __device__ __noinline__ uint32_t bits_more(const BitsCtx &c, const uint4 *tab, c
     }
 }
 
-// One step of a chain: the longest keyword that starts at segment-relative position q (what LongestMatchSet's queue would
-// report from there), at least 1.  seg: the lane's segment in the wave's LDS image (the words behind it: the next segment's
-// first ones); seg_pos: the segment's absolute position; qsafe: matches that end behind this relative position may reach
-// beyond the buffer, whose missing units were packed as the first letter.
-__device__ __forceinline__ uint32_t bits_longest(const BitsCtx &c, const uint4 *tab, const uint32_t *seg, uint32_t q, uint32_t seg_pos, uint32_t qsafe) {
+// A chain through one segment: from segment-relative position q to the first chain position at or behind qend (returned).
+// Every step is the longest keyword that starts at the current position -- what LongestMatchSet's queue would report from
+// there (at least 1: every letter is a keyword).  seg: the lane's segment in the wave's LDS image (the words behind it: the
+// next segment's first ones); seg_pos: its absolute position; qsafe: matches that end behind this relative position may
+// reach beyond the buffer, whose missing units were packed as the first letter.
+//  * The text comes through a window of registers -- the words k, k+1, k+2 of the segment, word k+3 on its way -- that moves
+//    on when the chain enters the next word: the step's dependent chain holds ONE LDS round trip (the table entry), not two.
+//  * MARK (pass 2): the step's position is counted and marked; the marks of a word are written in the place of its text when
+//    the chain has left it, the words the chain does not touch become zeros.
+template <bool MARK>
+__device__ __forceinline__ uint32_t bits_walk(const BitsCtx &c, const uint4 *tab, uint32_t *seg, uint32_t q, uint32_t qend, uint32_t seg_pos,
+                                              uint32_t qsafe, uint32_t &cnt) {
     constexpr uint32_t RK = kBitsRK;
-    const uint32_t *w = seg + (q >> 5);
-    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], sh = q & 31u;
-    const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), mid = __builtin_amdgcn_alignbit(w2, w1, sh);
-    const uint4 e = tab[lo & ((1u << RK) - 1u)];
-    uint32_t best = (e.z >> 8) & 0xffu; // the longest keyword among the first RK units: at least 1 (every letter is a keyword)
-    const bool more = bits_label(e, __builtin_amdgcn_alignbit(mid, lo, RK), RK, best);
-    if (__builtin_expect(more || q + best > qsafe, 0)) { // rare: the trie goes on behind the label; the end of the buffer
-        if (more) best = bits_more(c, tab, seg, q, seg_pos + q, e, best);
-        if (q + best > qsafe) best = bits_slow(c, seg_pos + q);
-        best = max(best, 1u); // (0: a unit outside the alphabet -- the call bails out; the chain moves on whatever it reads)
+    uint32_t cur = 0, cw = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    if (q < qend) {
+        cur = q >> 5;
+        if (MARK)
+            for (uint32_t z = 0; z < cur; ++z) seg[z] = 0u;
+        const uint32_t *p = seg + cur;
+        t0 = p[0]; t1 = p[1]; t2 = p[2]; t3 = p[3];
     }
-    return best;
+    while (q < qend) {
+        const uint32_t k = q >> 5;
+        if (k != cur) { // the chain has left word cur
+            if (MARK) {
+                seg[cur] = cw;
+                cw = 0u;
+            }
+            if (__builtin_expect(k != cur + 1u, 0)) { // (a match of 32 units or more)
+                if (MARK)
+                    for (uint32_t z = cur + 1u; z < k; ++z) seg[z] = 0u;
+                const uint32_t *p = seg + k;
+                t0 = p[0]; t1 = p[1]; t2 = p[2]; t3 = p[3];
+            } else {
+                t0 = t1; t1 = t2; t2 = t3;
+                t3 = seg[k + 3u];
+            }
+            cur = k;
+        }
+        const uint32_t sh = q & 31u;
+        const uint32_t lo = __builtin_amdgcn_alignbit(t1, t0, sh), mid = __builtin_amdgcn_alignbit(t2, t1, sh);
+        const uint4 e = tab[lo & ((1u << RK) - 1u)];
+        uint32_t best = (e.z >> 8) & 0xffu; // the longest keyword among the first RK units
+        const bool more = bits_label(e, __builtin_amdgcn_alignbit(mid, lo, RK), RK, best);
+        if (__builtin_expect(more || q + best > qsafe, 0)) { // rare: the trie goes on behind the label; the end of the buffer
+            if (more) best = bits_more(c, tab, seg, q, seg_pos + q, e, best);
+            if (q + best > qsafe) best = bits_slow(c, seg_pos + q);
+            best = max(best, 1u); // (0: a unit outside the alphabet -- the call bails out; the chain moves on whatever it reads)
+        }
+        if (MARK) {
+            cw |= 1u << sh;
+            ++cnt;
+        }
+        q += best;
+    }
+    if (MARK) {
+        seg[cur] = cw;
+        for (uint32_t z = cur + 1u; z < kBitsSegWords; ++z) seg[z] = 0u;
+    }
+    return q;
 }
 
+#ifdef ACGPU_TIMING
+__device__ unsigned long long g_bits_timing[8]; // per-wave sums: gate wait, text, pass 1, pass 2, out, total; waves
+#define BITS_MARK(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); bt[i] += t_ - bt0; bt0 = t_; }
+#else
+#define BITS_MARK(i)
+#endif
 __global__ __launch_bounds__(kBitsBlock) void k_longest_bits(DevTables T, LongestBitsLaunch L) {
     __shared__ __attribute__((aligned(16))) uint4 tab[kBitsTabEntries];
     __shared__ uint32_t img_all[kBitsWaves][kBitsWaveWords];
@@ -183,6 +234,10 @@ __global__ __launch_bounds__(kBitsBlock) void k_longest_bits(DevTables T, Longes
     // A wave alternates between streaming text (memory) and following chains (instruction issue, LDS).  The second half of
     // the workgroup starts when the first half has its text: from then on one half streams while the other walks.
     bool first = true;
+#ifdef ACGPU_TIMING
+    unsigned long long bt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bt0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long bstart = bt0;
+#endif
     if (wave >= kBitsWaves / 2) {
 #ifdef ACGPU_ABLATION
         if (!(L.debug & 16u))
@@ -190,6 +245,7 @@ __global__ __launch_bounds__(kBitsBlock) void k_longest_bits(DevTables T, Longes
         while (__hip_atomic_load(&gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (uint32_t)(kBitsWaves / 2)) __builtin_amdgcn_s_sleep(64);
     }
 
+    BITS_MARK(0)
     for (uint32_t r = blockIdx.x * kBitsWaves + wave; r < L.n_regions; r += gridDim.x * kBitsWaves) {
         const uint32_t R0 = L.g0 + r * kBitsRegionUnits; // first position of segment 0
         // ---- the region's text, one bit per unit: segments -1 .. 63 and the first words of segment 64 -----------------------
@@ -232,20 +288,28 @@ __global__ __launch_bounds__(kBitsBlock) void k_longest_bits(DevTables T, Longes
         const bool aux_lane = (r > 0 && lane >= 32) || lane < kBitsLook;
         const int32_t aux_W = lane >= 32 ? (int32_t)lane - 64 : (int32_t)(kBitsRegionUnits / 32u + lane);
         const uint32_t aux_pos = aux_lane ? R0 + (uint32_t)(aux_W * 32) : R0 + lane * 32u;
-        if ((uint64_t)R0 + kBitsRegionUnits + kBitsLook * 32u <= nu) { // every load inside the buffer: the stream, one tile ahead
-            uint32_t wa[16], wb[16];
-            load_fast(wb, aux_pos);
-            load_fast(wa, R0 + lane * 32u);
-            {
-                const uint32_t word = bits_pack(wb, base2, dmax);
-                if (aux_lane) put(aux_W, word);
-            }
+        if ((uint64_t)R0 + kBitsRegionUnits + kBitsLook * 32u <= nu) { // every load inside the buffer: the stream, two tiles ahead
+            // 33 tiles (the one above, then the region's 32) through three register sets: 8 KB per wave in flight, so that the
+            // half of the workgroup that streams keeps the memory busy on its own
+            uint32_t wa[16], wb[16], wc[16];
+            auto tile_pos = [&](int32_t t) { return t < 0 ? aux_pos : R0 + (uint32_t)t * kBitsTileUnits + lane * 32u; };
+            auto tile_put = [&](int32_t t, uint32_t word) {
+                if (t < 0) {
+                    if (aux_lane) put(aux_W, word);
+                } else put((int32_t)((uint32_t)t * 64u + lane), word);
+            };
+            constexpr int32_t kTiles = (int32_t)(kBitsRegionUnits / kBitsTileUnits);
+            static_assert((kTiles + 1) % 3 == 0, "three register sets in turn");
+            load_fast(wa, tile_pos(-1));
+            load_fast(wb, tile_pos(0));
 #pragma unroll 1
-            for (uint32_t tl = 0; tl < kBitsRegionUnits / kBitsTileUnits; tl += 2) {
-                load_fast(wb, R0 + (tl + 1u) * kBitsTileUnits + lane * 32u);
-                put((int32_t)(tl * 64u + lane), bits_pack(wa, base2, dmax));
-                if (tl + 2u < kBitsRegionUnits / kBitsTileUnits) load_fast(wa, R0 + (tl + 2u) * kBitsTileUnits + lane * 32u);
-                put((int32_t)((tl + 1u) * 64u + lane), bits_pack(wb, base2, dmax));
+            for (int32_t t0 = -1; t0 < kTiles; t0 += 3) {
+                load_fast(wc, tile_pos(t0 + 2));
+                tile_put(t0, bits_pack(wa, base2, dmax));
+                load_fast(wa, tile_pos(min(t0 + 3, kTiles - 1))); // (unconditional: the wait counts stay exact; the last tile's
+                tile_put(t0 + 1, bits_pack(wb, base2, dmax));     // words are read twice more and dropped)
+                load_fast(wb, tile_pos(min(t0 + 4, kTiles - 1)));
+                tile_put(t0 + 2, bits_pack(wc, base2, dmax));
             }
         } else {
             uint32_t w[16];
@@ -260,10 +324,11 @@ __global__ __launch_bounds__(kBitsBlock) void k_longest_bits(DevTables T, Longes
             }
         }
         const bool foreign = (dmax & 0xffffu) >= c.span || (dmax >> 16) >= c.span;
-        if (__any(foreign) && lane == 0) L.d_exit[1] = 1ull; // a unit outside the alphabet: not this kernel's text
+        if (__any(foreign) && lane == 0) L.d_exit[1] = 2ull; // a unit outside the alphabet: not this kernel's text
         __builtin_amdgcn_wave_barrier();
         if (first && wave < kBitsWaves / 2 && lane == 0) atomicAdd(&gate, 1u);
         first = false;
+        BITS_MARK(1)
 
         // ---- pass 1: where the chain enters the lane's segment --------------------------------------------------------------
         const uint32_t start = R0 + lane * kBitsSegUnits;
@@ -275,45 +340,30 @@ __global__ __launch_bounds__(kBitsBlock) void k_longest_bits(DevTables T, Longes
             const uint32_t ps = start - kBitsSegUnits;
             uint32_t p0 = max(ps, L.entry);
             const uint32_t lim = min(start, L.own_end);
-#ifdef ACGPU_ABLATION
-            if ((L.debug & 8u) && lim > (L.debug >> 16)) p0 = max(p0, lim - (L.debug >> 16)); // a shorter run-up (how often does it fail?)
-#endif
+            if (lim > L.runup) p0 = max(p0, lim - L.runup); // (the run-up: the last L.runup positions of the segment)
             uint32_t q = p0 - ps;
             const uint32_t qlim = lim > ps ? lim - ps : 0u;
             const uint32_t qsafe = nu - ps; // (ps < nu: the segment before one that begins inside the owned range)
 #ifdef ACGPU_ABLATION
             if (L.debug & 1u) q = max(q, qlim); // no pass 1 (wrong entries: timing only)
 #endif
-            while (q < qlim) q += bits_longest(c, tab, seg, q, ps, qsafe);
-            e_in = ps + q;
+            uint32_t none = 0;
+            e_in = ps + bits_walk<false>(c, tab, const_cast<uint32_t *>(seg), q, qlim, ps, qsafe, none);
         }
         __builtin_amdgcn_wave_barrier();
 
+        BITS_MARK(2)
         // ---- pass 2: the lane's own segment from there: count, and mark the starts in place of the text left behind ---------
         uint32_t *seg = img + (lane + 1u) * kBitsStride;
         const uint32_t bound = min(start + kBitsSegUnits, L.own_end);
         const uint32_t qend = bound > start ? bound - start : 0u;
         const uint32_t qsafe = nu > start ? nu - start : 0u;
         uint32_t q = e_in - start; // (an entry beyond the segment, or a segment beyond the owned range: no steps)
-        uint32_t cur = 0, cw = 0, cnt = 0;
+        uint32_t cnt = 0;
 #ifdef ACGPU_ABLATION
         if (L.debug & 2u) q = max(q, qend); // no pass 2
 #endif
-        while (q < qend) {
-            const uint32_t len = bits_longest(c, tab, seg, q, start, qsafe);
-            const uint32_t k = q >> 5;
-            if (k != cur) { // the walk has left word cur: its marks take the text's place
-                seg[cur] = cw;
-                for (uint32_t z = cur + 1u; z < k; ++z) seg[z] = 0u;
-                cw = 0u;
-                cur = k;
-            }
-            cw |= 1u << (q & 31u);
-            ++cnt;
-            q += len;
-        }
-        seg[cur] = cw;
-        for (uint32_t z = cur + 1u; z < kBitsSegWords; ++z) seg[z] = 0u;
+        q = bits_walk<true>(c, tab, seg, q, qend, start, qsafe, cnt);
         const uint32_t x_out = start + q; // the chain's first position at or behind min(segment end, own_end)
         // every exit is the next lane's entry (boundaries inside the owned range)
         const uint32_t e_next = __shfl_down(e_in, 1);
@@ -324,7 +374,7 @@ __global__ __launch_bounds__(kBitsBlock) void k_longest_bits(DevTables T, Longes
             if (bd && lane == 0) atomicAdd(&L.d_exit[3], (unsigned long long)__popcll(bd));
         } else
 #endif
-        if (__any(differs) && lane == 0) L.d_exit[1] = 1ull;
+        if (__any(differs) && lane == 0) atomicMax(&L.d_exit[1], 1ull);
         if (lane == 0) L.d_pred[r] = e_in;
         if (lane == 63) {
             L.d_true[r] = x_out;
@@ -346,6 +396,7 @@ __global__ __launch_bounds__(kBitsBlock) void k_longest_bits(DevTables T, Longes
         }
         __builtin_amdgcn_wave_barrier();
 
+        BITS_MARK(3)
         // ---- out: starts, ends (= starts >> 1), per tile of segments the first start and the count ---------------------------
         const uint32_t gw0 = R0 >> 5; // (a multiple of 4: g0 is a multiple of 128 positions)
         const uint32_t cut = (L.own_end & 31u) ? ~(~0u << (L.own_end & 31u)) : ~0u; // positions of the last word inside the owned range
@@ -385,7 +436,18 @@ __global__ __launch_bounds__(kBitsBlock) void k_longest_bits(DevTables T, Longes
             }
         }
         __builtin_amdgcn_wave_barrier();
+#ifdef ACGPU_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the stores are this phase's)
+#endif
+        BITS_MARK(4)
     }
+#ifdef ACGPU_TIMING
+    if (lane == 0) {
+        for (int i = 0; i < 5; ++i) atomicAdd(&g_bits_timing[i], bt[i]);
+        atomicAdd(&g_bits_timing[5], __builtin_amdgcn_s_memtime() - bstart);
+        atomicAdd(&g_bits_timing[6], 1ull);
+    }
+#endif
     if (first && wave < kBitsWaves / 2 && lane == 0) atomicAdd(&gate, 1u); // (a wave without a region)
 }
 
@@ -393,7 +455,7 @@ __global__ __launch_bounds__(kBitsBlock) void k_longest_bits(DevTables T, Longes
 __global__ __launch_bounds__(256) void k_longest_bits_check(LongestBitsLaunch L) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r == 0 || r >= L.n_regions) return;
-    if (L.d_pred[r] != L.d_true[r - 1]) L.d_exit[1] = 1ull;
+    if (L.d_pred[r] != L.d_true[r - 1]) atomicMax(&L.d_exit[1], 1ull);
 }
 
 uint32_t longest_bits_region_units() { return kBitsRegionUnits; }
@@ -403,6 +465,17 @@ hipError_t launch_longest_bits(const DevTables &t, const LongestBitsLaunch &l, h
     ACGPU_LAUNCH_EV(k_longest_bits, dim3(l.grid), dim3(kBitsBlock), 0, stream, ev_start, ev_stop, t, l);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+#ifdef ACGPU_TIMING
+    {
+        (void)hipStreamSynchronize(stream);
+        unsigned long long h[8] = {0};
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bits_timing), sizeof(h));
+        if (h[6]) fprintf(stderr, "[bits timing] waves %llu: total %.0f | gate %.0f | text %.0f | pass 1 %.0f | pass 2 %.0f | out %.0f (s_memtime ticks per wave)\n",
+                          h[6], (double)h[5] / h[6], (double)h[0] / h[6], (double)h[1] / h[6], (double)h[2] / h[6], (double)h[3] / h[6], (double)h[4] / h[6]);
+        unsigned long long z[8] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bits_timing), z, sizeof(z));
+    }
+#endif
     if (l.n_regions > 1) hipLaunchKernelGGL(k_longest_bits_check, dim3((l.n_regions + 255) / 256), dim3(256), 0, stream, l);
     return hipGetLastError();
 }
