@@ -6,6 +6,9 @@
 #include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <cctype>
+#include <pthread.h>
+#include <sched.h>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -1449,6 +1452,7 @@ int64_t acgpu_set_tunable(const char *name, int64_t value) {
     else if (!std::strcmp(name, "no_short_keywords")) slot = &t.no_short_keywords;
     else if (!std::strcmp(name, "reserve_cus")) slot = &t.reserve_cus;
     else if (!std::strcmp(name, "no_bits_trie")) slot = &t.no_bits_trie;
+    else if (!std::strcmp(name, "multi_min_share")) slot = &t.multi_min_share;
     else if (!std::strcmp(name, "no_big_l2")) slot = &t.no_big_l2;
     else if (!std::strcmp(name, "no_class_pages")) slot = &t.no_class_pages;
     else if (!std::strcmp(name, "split_cand_div")) slot = &t.split_cand_div;
@@ -1478,8 +1482,16 @@ int acgpu_build(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uint
     return ACGPU_OK;
 }
 
+void acgpu_stream_detach(acgpu_stream *s); // acgpu_stream.hip
+
 void acgpu_free(acgpu_automaton *a) {
     if (!a) return;
+    { // streams still open on it (include/acgpu.h asks for them to be closed first): detached -- their feeds return
+      // ACGPU_E_INVALID from now on and acgpu_stream_close touches nothing of the automaton
+        std::lock_guard<std::mutex> l(a->mu);
+        for (acgpu_stream *s : a->open_streams) acgpu_stream_detach(s);
+        a->open_streams.clear();
+    }
     int cur = -1;
     bool have = hipGetDevice(&cur) == hipSuccess;
     for (auto &kv : a->dev) {
@@ -1679,6 +1691,49 @@ namespace acgpu {
 // relative to the buffer.
 constexpr uint64_t kHostChunkUnits = 1ull << 24; // 32 MiB per chunk
 
+// The CPUs of the NUMA node a device hangs on (/sys/bus/pci/devices/<bdf>/numa_node, /sys/devices/system/node/node<N>/cpulist):
+// the threads that copy a share's text into pinned memory run there, so that on a two-socket host eight devices are fed by both
+// sockets' memory controllers, each from its own side.  false: unknown (node -1, a container without /sys, ...): no affinity is set.
+static bool device_numa_cpus(int dev, cpu_set_t *set) {
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), dev) != hipSuccess) return false;
+    for (char *p = bdf; *p; ++p) *p = (char)std::tolower((unsigned char)*p);
+    char path[160];
+    std::snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bdf);
+    FILE *f = std::fopen(path, "r");
+    if (!f) return false;
+    int node = -1;
+    const int got = std::fscanf(f, "%d", &node);
+    std::fclose(f);
+    if (got != 1 || node < 0) return false;
+    std::snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+    f = std::fopen(path, "r");
+    if (!f) return false;
+    char list[4096] = {0};
+    const bool have = std::fgets(list, (int)sizeof(list), f) != nullptr;
+    std::fclose(f);
+    if (!have) return false;
+    CPU_ZERO(set);
+    int n_set = 0;
+    for (char *p = list; *p;) { // "0-63,128-191"
+        char *end = nullptr;
+        const long a = std::strtol(p, &end, 10);
+        if (end == p) break;
+        long b = a;
+        p = end;
+        if (*p == '-') {
+            b = std::strtol(p + 1, &end, 10);
+            p = end;
+        }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c) {
+            CPU_SET((int)c, set);
+            ++n_set;
+        }
+        if (*p == ',') ++p;
+    }
+    return n_set > 0;
+}
+
 int scan_host_range(acgpu_automaton *a, DeviceState &d, const uint16_t *haystack, uint64_t n_units, uint64_t lo, uint64_t hi,
                     uint64_t own_lo, uint64_t own_hi, int record_kind, uint64_t cap, uint64_t *n_out, int64_t *chain_io) {
     const HostTables &t = a->t;
@@ -1692,14 +1747,21 @@ int scan_host_range(acgpu_automaton *a, DeviceState &d, const uint16_t *haystack
     if ((rc = d.stage_hay.ensure(nb * 2 + 16))) return rc;
     if ((rc = d.stage_out.ensure(cap * (uint64_t)record_kind + 16))) return rc;
     if (!d.copy_stream) HIP_TRY(hipStreamCreateWithFlags(&d.copy_stream, hipStreamNonBlocking));
-    if (d.pin_bytes < C * 2) {
+    // the ring: as many slots as this buffer has chunks (at most kPinSlots), each as large as its largest chunk -- a share of a
+    // few megabytes of a multi-device call, or a 40 MiB haystack, does not pin 8 x 32 MiB
+    const size_t slot_bytes = (((size_t)std::min<uint64_t>(nb, C) * 2 + (1u << 20) - 1) >> 20) << 20;
+    const int slots_needed = (int)std::min<uint32_t>(n_chunks, (uint32_t)DeviceState::kPinSlots);
+    if (d.pin_bytes < slot_bytes) {
         for (auto &q : d.pin) {
             if (q) (void)hipHostFree(q);
             q = nullptr;
         }
-        d.pin_bytes = 0;
-        for (auto &q : d.pin) HIP_TRY(hipHostMalloc(&q, C * 2, hipHostMallocDefault));
-        d.pin_bytes = C * 2;
+        d.pin_n = 0;
+        d.pin_bytes = slot_bytes;
+    }
+    while (d.pin_n < slots_needed) {
+        HIP_TRY(hipHostMalloc(&d.pin[d.pin_n], d.pin_bytes, hipHostMallocDefault));
+        d.pin_n++;
     }
     while (d.chunk_ev.size() < n_chunks) {
         hipEvent_t e = nullptr;
@@ -1713,7 +1775,10 @@ int scan_host_range(acgpu_automaton *a, DeviceState &d, const uint16_t *haystack
     std::vector<std::atomic<int>> ready(n_chunks); // 1: the chunk's DMA and event are enqueued
     for (auto &r : ready) r.store(0, std::memory_order_relaxed);
     const int dev = d.device;
+    cpu_set_t node_cpus;
+    const bool have_node = device_numa_cpus(dev, &node_cpus);
     auto worker = [&]() {
+        if (have_node) (void)pthread_setaffinity_np(pthread_self(), sizeof(node_cpus), &node_cpus); // (best effort)
         if (hipSetDevice(dev) != hipSuccess) {
             worker_rc.store(ACGPU_E_HIP);
             return;

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <map>
+#include <set>
 #include <memory>
 #include <mutex>
 #include <utility>
@@ -96,7 +97,9 @@ struct DeviceState {
     // pipelined host entry: pinned staging ring (one slot per chunk in flight), its copy stream, one event per chunk
     static constexpr int kPinSlots = 8;
     void *pin[kPinSlots] = {nullptr};
-    size_t pin_bytes = 0;
+    size_t pin_bytes = 0; // bytes per slot
+    int pin_n = 0;        // slots allocated
+    hipStream_t multi_stream = nullptr; // acgpu_match_u16_multi: this pool's stream for the duration of such a call (kept between calls)
     hipStream_t copy_stream = nullptr;
     std::vector<hipEvent_t> chunk_ev;
     DevBuf short_recs, short_nxt, short_tmp, short_mark; // SHORTEST: all-matches list + selection scratch
@@ -122,6 +125,7 @@ struct DeviceState {
         chain.release(); lenbuf.release(); statebuf.release(); stage_hay.release(); stage_out.release();
         multi_win.release(); multi_tail.release();
         if (call_stream) (void)hipStreamDestroy(call_stream);
+        if (multi_stream) (void)hipStreamDestroy(multi_stream);
         if (small_stream) (void)hipStreamDestroy(small_stream);
         if (small_pin) (void)hipHostFree(small_pin);
         short_recs.release(); short_nxt.release(); short_tmp.release(); short_mark.release();
@@ -185,7 +189,8 @@ struct StreamBufs {
 struct acgpu_automaton {
     acgpu::HostTables t;
     std::vector<acgpu::StreamBufs> stream_cache;                                 // guarded by mu
-    std::mutex mu;                                                               // guards `dev` and `stream_cache`
+    std::set<struct acgpu_stream *> open_streams;                                // guarded by mu: acgpu_free detaches them (acgpu_stream::a = nullptr)
+    std::mutex mu;                                                               // guards `dev`, `stream_cache` and `open_streams`
     std::map<std::pair<int, int>, std::unique_ptr<acgpu::DeviceState>> dev;      // (HIP device, lane) -> scratch pool + tables
 };
 

@@ -90,6 +90,7 @@ struct Share {
     int64_t exit_rel = 0;
     bool exit_valid = true; // SHORTEST: false = this share (and nothing before it) reported no match: "nothing comes in"
     int rc = ACGPU_OK;
+    int hip_error = 0; // g_last_hip_error of the host thread that worked on the share (thread_local: the caller's thread republishes it)
     uint64_t n_final() const { return repaired ? n_win + (n_spec - keep_from) : n_spec; }
 };
 
@@ -155,7 +156,8 @@ int repair_chains(acgpu_automaton *a, std::vector<Share> &sh, int record_kind) {
         s.n_win = 0;
         if (t.mode == ACGPU_MODE_SHORTEST) {
             // the state: the end of the last match reported so far (nothing reported: what came in)
-            s.exit_valid = s.n_spec > 0;
+            // (share 0 scanned from the CALLER's entry, which its chain_exit hands on when it reports nothing: always the truth)
+            s.exit_valid = s.n_spec > 0 || i == 0;
             s.exit_rel = s.spec_exit - (int64_t)s.own_end;
         } else {
             s.exit_valid = true;
@@ -332,10 +334,12 @@ int on_all_shares(std::vector<Share> &sh, F fn) {
     auto body = [&](size_t i) {
         Share &s = sh[i];
         if (hipSetDevice(s.device) != hipSuccess) {
+            s.hip_error = (int)hipGetLastError();
             s.rc = ACGPU_E_HIP;
             return;
         }
         s.rc = fn(i);
+        if (s.rc == ACGPU_E_HIP) s.hip_error = g_last_hip_error;
     };
     try {
         for (size_t i = 1; i < sh.size(); ++i) pool.emplace_back(body, i);
@@ -346,7 +350,10 @@ int on_all_shares(std::vector<Share> &sh, F fn) {
     body(0);
     for (auto &th : pool) th.join();
     for (auto &s : sh)
-        if (s.rc != ACGPU_OK) return s.rc;
+        if (s.rc != ACGPU_OK) {
+            if (s.rc == ACGPU_E_HIP && s.hip_error) g_last_hip_error = s.hip_error; // (acgpu_last_hip_error() reads the CALLER's thread)
+            return s.rc;
+        }
     return ACGPU_OK;
 }
 
@@ -373,7 +380,10 @@ int acgpu_match_u16_multi(const acgpu_automaton *ca, const uint16_t *haystack, u
     // fold-consistent), and texts too short to be worth cutting: one device, the single-device entry
     const bool sequential_only = (t.mode == ACGPU_MODE_WHOLEWORD && !t.fold_consistent) ||
                                  (t.mode == ACGPU_MODE_WWLONGEST && !t.fold_consistent && record_kind == ACGPU_REC_SET);
-    const uint64_t min_share = 1024;
+    // A share has to be worth its fixed costs -- a host thread, a staging ring, two extra synchronisations --: 2^22 units (8 MiB)
+    // at least, below that fewer devices or the single-device entry (a 100 KB string under -Dacgpu.devices=0..7 is ONE call on
+    // one device).  Tunable multi_min_share: the tests cut texts of a few thousand units.
+    const uint64_t min_share = (uint64_t)std::max<int64_t>(8, tunables().multi_min_share);
     const int K = sequential_only ? 1 : (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)n_devices, n_units / min_share));
     if (K == 1) {
         if ((rc = set_device(devices[0]))) return rc;
@@ -405,8 +415,9 @@ int acgpu_match_u16_multi(const acgpu_automaton *ca, const uint16_t *haystack, u
         if ((rc = device_for_call(a, &sh[i].d, sh[i].lane))) break;
         locks[i] = std::unique_lock<std::mutex>(sh[i].d->mu);
         if (sh[i].d->inflight > 0) rc = ACGPU_E_INVALID; // (stream rule: tickets of the asynchronous entry are in flight)
-        else if (hipStreamCreateWithFlags(&own_stream[i], hipStreamNonBlocking) != hipSuccess) rc = ACGPU_E_HIP;
+        else if (!sh[i].d->multi_stream && hipStreamCreateWithFlags(&sh[i].d->multi_stream, hipStreamNonBlocking) != hipSuccess) rc = ACGPU_E_HIP;
         else {
+            own_stream[i] = sh[i].d->multi_stream; // (the pool's own, created once)
             saved[i] = sh[i].d->call_stream;
             sh[i].d->call_stream = own_stream[i];
             sh[i].stream = own_stream[i];
@@ -418,7 +429,6 @@ int acgpu_match_u16_multi(const acgpu_automaton *ca, const uint16_t *haystack, u
                 (void)hipSetDevice(sh[i].device);
                 (void)hipStreamSynchronize(own_stream[i]);
                 sh[i].d->call_stream = saved[i];
-                (void)hipStreamDestroy(own_stream[i]);
             }
         }
     };
@@ -637,14 +647,18 @@ int acgpu_match_device_allgather(const acgpu_automaton *ca, acgpu_comm *c, acgpu
             if (counts[i] > gcap) over = true;
             shards[i].chain_exit = (int64_t)s.own_end + s.exit_rel;
         }
-        for (int i = 0; i < K && rc == ACGPU_OK && !over; ++i) {
+        // (from here to the synchronisation below the slots are filled by copies out of the pools' scratch -- multi_win,
+        // multi_tail, stage_out --: the pools stay locked until those copies have RUN, not just been enqueued, or a concurrent
+        // call on the same automaton and device could overwrite their sources)
+        auto fill_slot = [&](int i) -> int {
             Share &s = sh[i];
-            if ((rc = set_device(s.device))) break;
+            int rc = set_device(s.device);
+            if (rc) return rc;
             char *recs = slot_of(i) + 16;
             if (s.repaired) { // window ++ kept tail of the speculation (through a private copy: the ranges overlap)
                 const uint64_t n_tail = s.n_spec - s.keep_from, rk = (uint64_t)record_kind;
                 if (n_tail) {
-                    if ((rc = s.d->multi_tail.ensure(n_tail * rk + 16))) break;
+                    if ((rc = s.d->multi_tail.ensure(n_tail * rk + 16))) return rc;
                     HIP_TRY(hipMemcpyAsync(s.d->multi_tail.p, (const char *)s.spec + s.keep_from * rk, n_tail * rk, hipMemcpyDeviceToDevice, s.stream));
                 }
                 if (s.n_win) HIP_TRY(hipMemcpyAsync(recs, s.d->multi_win.p, s.n_win * rk, hipMemcpyDeviceToDevice, s.stream));
@@ -653,6 +667,15 @@ int acgpu_match_device_allgather(const acgpu_automaton *ca, acgpu_comm *c, acgpu
                 HIP_TRY(hipMemcpyAsync(recs, s.spec, s.n_spec * (uint64_t)record_kind, hipMemcpyDeviceToDevice, s.stream));
             }
             HIP_TRY(launch_write_result(reinterpret_cast<acgpu_device_result *>(slot_of(i)), counts[i], s.stream));
+            return ACGPU_OK;
+        };
+        for (int i = 0; i < K && rc == ACGPU_OK && !over; ++i) rc = fill_slot(i);
+        for (int i = 0; i < K; ++i) { // (on the error paths too: nothing of this call is left in flight when the locks go)
+            (void)hipSetDevice(c->devices[i]);
+            if (hipStreamSynchronize(c->streams[i]) != hipSuccess && rc == ACGPU_OK) {
+                g_last_hip_error = (int)hipGetLastError();
+                rc = ACGPU_E_HIP;
+            }
         }
         if (rc) return rc;
     }

@@ -186,6 +186,10 @@ struct acgpu_stream {
     bool redeliver = false;
     ~acgpu_stream() {
         delete pool;
+        if (a) { // (acgpu_free on an automaton with open streams detaches them: a == nullptr, nothing of it is touched here)
+            std::lock_guard<std::mutex> l(a->mu);
+            a->open_streams.erase(this);
+        }
         if (device >= 0) {
             int cur_dev = -1;
             const bool have = hipGetDevice(&cur_dev) == hipSuccess;
@@ -306,6 +310,16 @@ int scan_slot(acgpu_stream *s, Slot &sl, int record_kind, void *out, uint64_t ca
     return ACGPU_OK;
 }
 
+// The staging buffers, the copy stream and the events belong to the device of the FIRST feed (include/acgpu.h: every feed comes
+// from a thread whose current device is that one).  A feed from another device -- a worker thread that another call left on a
+// different device -- would scan device-A pointers with device-B tables: an error code instead.
+int check_feed_device(const acgpu_stream *s) {
+    if (s->device < 0) return ACGPU_OK;
+    int cur = -1;
+    HIP_TRY(hipGetDevice(&cur));
+    return cur == s->device ? ACGPU_OK : ACGPU_E_INVALID;
+}
+
 // the stream's buffers: those a closed stream on this device left to the automaton, or none yet (they grow on demand)
 int adopt_bufs(acgpu_stream *s) {
     if (s->b.device >= 0) return ACGPU_OK;
@@ -324,8 +338,10 @@ int adopt_bufs(acgpu_stream *s) {
 int feed_pipelined(acgpu_stream *s, const uint16_t *units, uint64_t n_units, int final, int record_kind, void *out, uint64_t cap,
                    uint64_t *n_out, int64_t *base) {
     acgpu_automaton *a = s->a;
+    if (!a) return ACGPU_E_INVALID; // (its automaton has been freed)
     const HostTables &t = a->t;
     *n_out = 0;
+    { const int drc = check_feed_device(s); if (drc) return drc; }
     if (s->redeliver) { // the same feed again, with the capacity the first call reported: its chunk was consumed then
         *base = s->undelivered_base;
         *n_out = s->undelivered_n;
@@ -449,11 +465,23 @@ int acgpu_stream_open(const acgpu_automaton *a, acgpu_stream **out) {
     acgpu_stream *s = new (std::nothrow) acgpu_stream();
     if (!s) return ACGPU_E_NOMEM;
     s->a = const_cast<acgpu_automaton *>(a);
+    try {
+        std::lock_guard<std::mutex> l(s->a->mu);
+        s->a->open_streams.insert(s);
+    } catch (...) {
+        s->a = nullptr;
+        delete s;
+        return ACGPU_E_NOMEM;
+    }
     *out = s;
     return ACGPU_OK;
 }
 
 void acgpu_stream_close(acgpu_stream *s) { delete s; }
+
+// acgpu_free with this stream still open (the caller holds the automaton's mutex): nothing of the stream refers to it any more;
+// the staging buffers stay the stream's own and go when it is closed
+void acgpu_stream_detach(acgpu_stream *s) { s->a = nullptr; }
 
 int acgpu_stream_set_pipelined(acgpu_stream *s, int on) {
     if (!s || s->started || s->carry_pos != 0 || !s->carry.empty() || s->own_from != 0) return ACGPU_E_INVALID; // before the first feed
@@ -465,7 +493,8 @@ int acgpu_stream_reserve(acgpu_stream *s, uint64_t n_units, uint16_t **buf) {
     if (!s || !buf || !s->pipelined || s->finished || s->redeliver) return ACGPU_E_INVALID;
     *buf = nullptr;
     const uint64_t n_carry = s->carry.size();
-    if (n_carry + n_units >= (1ull << 30)) return ACGPU_E_INVALID;
+    if (n_carry + n_units >= (1ull << 30) || !s->a) return ACGPU_E_INVALID;
+    { const int drc = check_feed_device(s); if (drc) return drc; }
     const int si = s->cur;
     { const int arc = adopt_bufs(s); if (arc) return arc; }
     if (s->b.pin_bytes[si] < (n_carry + n_units) * 2 + 64) {
@@ -484,6 +513,7 @@ int acgpu_stream_feed(acgpu_stream *s, const uint16_t *units, uint64_t n_units, 
                       uint64_t cap, uint64_t *n_out, int64_t *base) {
     if (!s || !n_out || !base || (n_units && !units) || (cap && !out) || s->finished) return ACGPU_E_INVALID;
     if (record_kind != ACGPU_REC_SET && record_kind != ACGPU_REC_MAP) return ACGPU_E_INVALID;
+    if (!s->a) return ACGPU_E_INVALID; // (its automaton has been freed)
     if (s->pipelined) return feed_pipelined(s, units, n_units, final, record_kind, out, cap, n_out, base);
     acgpu_automaton *a = s->a;
     const HostTables &t = a->t;

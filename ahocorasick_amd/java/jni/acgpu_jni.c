@@ -243,7 +243,10 @@ JNIEXPORT void JNICALL Java_com_roklenarcic_util_strings_gpu_NativeAutomaton_fre
 
 /* ---- match(Readable, ReadableMatchListener<T>): acgpu_stream_* ---- */
 /* pipelined (-Dacgpu.stream.pipelined=true): acgpu_stream_set_pipelined -- a feed returns the PREVIOUS chunk's records, the last
- * one both; the chunk is read out of the Java array straight into the library's pinned staging memory (acgpu_stream_reserve) */
+ * one both.  The chunk is copied out of the Java array into a buffer of this call (GetCharArrayRegion) and the library's pool of
+ * copy threads moves it into its pinned staging memory under the previous chunk's scan: 33 GB/s.  (Reading the Java array
+ * straight into the staging memory -- acgpu_stream_reserve -- makes that ONE single-threaded copy which no scan overlaps: 16 GB/s,
+ * profiles/r04/v6_stream_rate.txt; the entry stays in the ABI for callers that fill the memory with several threads.) */
 JNIEXPORT jlong JNICALL Java_com_roklenarcic_util_strings_gpu_NativeAutomaton_streamOpen(JNIEnv *env, jclass cls, jlong handle,
                                                                                            jboolean pipelined) {
     (void)cls;
@@ -266,18 +269,11 @@ JNIEXPORT jintArray JNICALL Java_com_roklenarcic_util_strings_gpu_NativeAutomato
         throw_new(env, "java/lang/ArrayIndexOutOfBoundsException", "length");
         return NULL;
     }
-    /* a copy (GetCharArrayRegion), for the same reason as in match(): the feed blocks on the GPU.  Pipelined streams: the copy
-     * goes straight into the stream's pinned staging memory, and the feed copies nothing */
+    /* a copy (GetCharArrayRegion), for the same reason as in match(): the feed blocks on the GPU */
+    (void)pipelined;
     jchar *units = NULL, *owned = NULL;
-    if (pipelined && length > 0) {
-        uint16_t *staging = NULL;
-        const int rrc = acgpu_stream_reserve(s, (uint64_t)length, &staging);
-        if (rrc != ACGPU_OK) { throw_rc(env, rrc); return NULL; }
-        units = (jchar *)staging;
-    } else {
-        units = owned = (jchar *)malloc((size_t)(length ? length : 1) * sizeof(jchar));
-        if (!units) { throw_oom(env, "chunk copy"); return NULL; }
-    }
+    units = owned = (jchar *)malloc((size_t)(length ? length : 1) * sizeof(jchar));
+    if (!units) { throw_oom(env, "chunk copy"); return NULL; }
     (*env)->GetCharArrayRegion(env, chunk, 0, length, units);
     uint64_t cap = (uint64_t)length / 64 + 4096, n_out = 0;
     int64_t base = 0;

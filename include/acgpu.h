@@ -276,8 +276,14 @@ int acgpu_match_device_abandon(const acgpu_automaton *a, acgpu_ticket *ticket);
  * reference's listener-call order for the WHOLE haystack with global positions: exactly what acgpu_match_u16 returns.
  *  devices   : n_devices HIP device ordinals.  A device may be named more than once (further shares on the same device get
  *              their own scratch pool and stream): how a one-GPU box tests the split.
- *  Haystacks too short to cut (under 1024 units per share) and the loops that only exist as one sequential scan (word
- *  matchers over a table that is not fold-consistent) run on devices[0] alone.
+ *  A share has fixed costs (a host thread, a pinned staging ring, two synchronisations), so a haystack is cut into at most
+ *  n_units / 2^22 shares (8 MiB of text each; development tunable "multi_min_share"); shorter ones, and the loops that only
+ *  exist as one sequential scan (word matchers over a table that is not fold-consistent), run on devices[0] alone through
+ *  acgpu_match_u16.
+ *  Scaling: every share is fed from the CALLER's memory by host threads copying pageable -> pinned memory (about 45 GB/s per
+ *  share on one socket), so this entry is bound by the host's copy bandwidth beyond about two devices per socket; the feeder
+ *  threads of a share are pinned to the NUMA node of its device where the platform reports one.  The form that scales with the
+ *  device count is acgpu_match_device_allgather below: shards resident in device memory, nothing of the text on the host.
  * The calling thread's current device is restored.  Errors and ACGPU_E_OVERFLOW as acgpu_match_u16.
  */
 int acgpu_match_u16_multi(const acgpu_automaton *a, const uint16_t *haystack, uint64_t n_units, const int *devices, int n_devices,
@@ -342,6 +348,9 @@ int acgpu_last_rccl_error(void); /* ncclResult_t of the last RCCL failure on thi
  *  carried units + n_units must stay below 2^31.
  *  Word-character tables that are not fold-consistent: the Readable loops fold in every lookup (see above), and so do
  *  the feeds.
+ *  Lifetime and device: close a stream BEFORE acgpu_free of its automaton (one that is still open then is detached: its
+ *  feeds return ACGPU_E_INVALID, acgpu_stream_close stays safe).  Every feed and acgpu_stream_reserve must come from a
+ *  thread whose current HIP device is the one of the stream's first feed: another device returns ACGPU_E_INVALID.
  */
 typedef struct acgpu_stream acgpu_stream;
 int acgpu_stream_open(const acgpu_automaton *a, acgpu_stream **out);

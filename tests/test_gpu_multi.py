@@ -22,8 +22,10 @@ FAMILIES = ["ac", "ac_ci", "wholeword", "longest", "longest_map", "shortest", "w
 
 @pytest.fixture(autouse=True)
 def _reset_tunables():
+    # (the product cuts a text only into shares of 2^22 units and more -- a share has fixed costs; these tests cut short texts)
+    N.set_tunable("multi_min_share", 1024)
     yield
-    for k, v in [("force_kernel", 0), ("region_units", 0), ("tile_debug", 0)]:
+    for k, v in [("force_kernel", 0), ("region_units", 0), ("tile_debug", 0), ("multi_min_share", 1 << 22)]:
         N.set_tunable(k, v)
 
 
@@ -313,3 +315,16 @@ def test_allgather_redoes_the_gather_when_a_scan_had_to_be_redone():
     got = _gathered_records(gbufs, k, gcap, 3, shards)
     assert (got == want).all()
     comm.close()
+
+
+def test_match_u16_multi_cuts_only_shares_worth_their_fixed_costs():
+    """The product's rule (tunable multi_min_share at its default): a text below 2^23 units under a device list of two is ONE
+    call on the first device -- no host thread, staging ring or extra synchronisation per share -- and gives the oracle's records;
+    2^23 units and more are cut."""
+    N.set_tunable("multi_min_share", 1 << 22)
+    auto, with_ids, hay, want = family_case("ac", (1 << 22) + 4096)
+    got = auto.match_host(hay, with_ids, devices=[0, 0])
+    assert got.shape == want.shape and (got == want).all()
+    auto, with_ids, hay, want = family_case("ac", (1 << 23) + 4096)
+    got = auto.match_host(hay, with_ids, devices=[0, 0])
+    assert got.shape == want.shape and (got == want).all()
