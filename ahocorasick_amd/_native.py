@@ -150,9 +150,35 @@ def lib():
     return _lib
 
 
+def _code_only(text):
+    """C / C++ / HIP source without comments and with runs of white space collapsed: what the compiler sees of it.  (String and
+    character literals are kept as they are; a comment marker inside one is left alone.)"""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c in "\"'":  # literal: copy to its closing quote
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            out.append(" ")
+        else:
+            out.append(c)
+            i += 1
+    return " ".join("".join(out).split())
+
+
 def source_hash():
-    """SHA-256 (first 16 hex digits) over the kernel and builder sources: what measured evidence (profiles/latest_traffic.json)
-    is keyed by, so that a counter figure is never attached to a kernel that has been edited since."""
+    """SHA-256 (first 16 hex digits) over the CODE of the kernel and builder sources -- comments and white space are not part of
+    it: what measured evidence (profiles/latest_traffic.json) is keyed by, so that a counter figure is never attached to a kernel
+    that has been edited since, while an edit of a comment does not ask for a new collection."""
     import glob
     import hashlib
     h = hashlib.sha256()
@@ -160,8 +186,8 @@ def source_hash():
                    glob.glob(os.path.join(_HERE, "csrc", "*.cpp")) + [os.path.join(os.path.dirname(_HERE), "include", "acgpu.h")])
     for f in files:
         h.update(os.path.basename(f).encode())
-        with open(f, "rb") as fh:
-            h.update(fh.read())
+        with open(f, "r", encoding="utf-8", errors="replace") as fh:
+            h.update(_code_only(fh.read()).encode())
     return h.hexdigest()[:16]
 
 
