@@ -817,59 +817,35 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
         Bl.g0 = (uint32_t)entry & ~127u; // (bitmap words in groups of four: 16-byte stores)
         const uint32_t region_units = longest_bits_region_units();
         Bl.n_regions = (uint32_t)((sh->own_end - Bl.g0 + region_units - 1) / region_units);
-        Bl.tile_log2 = 2; // emit tiles of four segments (4096 positions)
         Bl.runup = bits_level == 0 ? longest_bits_seg_units() / 2 : longest_bits_seg_units();
         Bl.max_len = t.max_len;
-        const uint32_t n_tiles = (Bl.n_regions * (region_units / longest_bits_seg_units())) >> Bl.tile_log2;
+        Bl.d_out = d_out;
+        Bl.cap = cap;
         if ((rc = d.counter.ensure(64))) return rc;
-        if ((rc = d.chunk_counts.ensure((size_t)n_tiles * 4))) return rc;
-        if ((rc = d.offsets.ensure((size_t)n_tiles * 8))) return rc;
-        if ((rc = d.scan_tmp.ensure(((size_t)n_tiles / 2048 + 2) * 8))) return rc;
-        if ((rc = d.chain.ensure((size_t)n_tiles * 4 + 64))) return rc;
+        const size_t n_blk = ((size_t)Bl.n_regions + 63) / 64, agg_words = (size_t)Bl.n_regions + n_blk + 2;
+        if ((rc = d.offsets.ensure(agg_words * 8))) return rc;  // a word per region, a word per block of 64 regions, the region counter
         if ((rc = d.blockmax.ensure((size_t)Bl.n_regions * 8 + 64))) return rc;
-        const size_t bit_bytes = ((size_t)sh->n_units / 128 + 2) * 16;
-        if ((rc = d.chainbits.ensure(bit_bytes * 2))) return rc;
-        Bl.d_bits = (uint32_t *)d.chainbits.p;
-        Bl.d_ebits = Bl.d_bits + bit_bytes / 4;
-        Bl.d_sync = (uint32_t *)d.chain.p;
-        Bl.d_counts = (uint32_t *)d.chunk_counts.p;
         Bl.d_exit = (unsigned long long *)d.counter.p;
+        Bl.d_agg = (unsigned long long *)d.offsets.p;
+        if ((rc = d.chainbits.ensure((size_t)Bl.n_regions * longest_bits_region_scratch_bytes() + 64))) return rc;
+        Bl.d_marks = (uint32_t *)d.chainbits.p;
+        Bl.d_xout = Bl.d_marks + (size_t)Bl.n_regions * (region_units / 32);
+        Bl.d_blk = Bl.d_agg + Bl.n_regions;
+        Bl.d_next = (uint32_t *)(Bl.d_blk + n_blk);
         Bl.d_pred = (uint32_t *)d.blockmax.p;
         Bl.d_true = Bl.d_pred + Bl.n_regions;
         Bl.grid = (int)std::min<uint64_t>((uint64_t)d.n_cu, (Bl.n_regions + 15) / 16);
         Bl.debug = (uint32_t)(tunables().tile_debug >> 32);
         HIP_TRY(hipMemsetAsync(d.counter.p, 0, 64, stream));
+        HIP_TRY(hipMemsetAsync(d.offsets.p, 0, agg_words * 8, stream));
         d.cclean[0] = false; // (match_all's first set of slot counters lives here)
-        { // the words of the end bitmap behind the last one the kernel stores: the last match may end there (one atomicOr)
-            const size_t first = ((size_t)(sh->own_end - 1) >> 5) + 1, last = std::min<size_t>(bit_bytes / 4, (((size_t)sh->own_end + t.max_len) >> 5) + 2);
-            if (last > first) HIP_TRY(hipMemsetAsync(Bl.d_ebits + first, 0, (last - first) * 4, stream));
-        }
         if (timed) HIP_TRY(hipEventRecord(ev[0], stream));
-        HIP_TRY(launch_longest_bits(d.T, Bl, stream, nullptr, nullptr));
+        HIP_TRY(launch_longest_bits(d.T, Bl, stream, nullptr, nullptr)); // (the whole pipeline: text in, records out; then the check of the region seams)
         if (timed) HIP_TRY(hipEventRecord(ev[1], stream));
-        LongestChainLaunch Cn{};
-        Cn.len_bytes = 1;
-        Cn.own_begin = (uint32_t)sh->own_begin;
-        Cn.own_end = (uint32_t)sh->own_end;
-        Cn.entry = (uint32_t)entry;
-        Cn.tile_units = longest_bits_seg_units() << Bl.tile_log2;
-        Cn.n_tiles = n_tiles;
-        Cn.max_len = t.max_len;
-        Cn.d_counts = Bl.d_counts;
-        Cn.d_offsets = (const uint64_t *)d.offsets.p;
-        Cn.d_out = d_out;
-        Cn.cap = cap;
-        Cn.record_kind = record_kind;
-        Cn.d_exit = Bl.d_exit;
-        Cn.len_units = (uint32_t)sh->n_units;
-        Cn.d_bits = Bl.d_bits;
-        Cn.d_ebits = Bl.d_ebits;
-        HIP_TRY(launch_exclusive_scan(Cn.d_counts, Cn.n_tiles, (uint64_t *)d.offsets.p, (uint64_t *)d.scan_tmp.p, stream));
-        HIP_TRY(launch_longest_emit(Cn, Bl.d_sync, stream));
         if (timed) HIP_TRY(hipEventRecord(ev[2], stream));
         unsigned long long *h_slot = tk ? tk->h_count : d.h_counter, *d_slot = nullptr;
         HIP_TRY(hipHostGetDevicePointer((void **)&d_slot, h_slot, 0));
-        HIP_TRY(launch_publish_result((const unsigned long long *)d.scan_tmp.p + scan_tiles_for(Cn.n_tiles), (const unsigned long long *)d.counter.p,
+        HIP_TRY(launch_publish_result((const unsigned long long *)d.counter.p + 2, (const unsigned long long *)d.counter.p,
                                       d_slot, tk ? reinterpret_cast<acgpu_device_result *>(sh->d_result) : nullptr, stream));
         if (tk) {
             tk->stream = stream;

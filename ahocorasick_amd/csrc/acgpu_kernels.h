@@ -227,18 +227,22 @@ struct LongestBitsLaunch {
     uint32_t n_units, own_end, entry;
     uint32_t g0;          // entry & ~127: first position of segment 0 of region 0
     uint32_t n_regions;   // regions of longest_bits_region_units() positions from g0 on, up to own_end
-    uint32_t tile_log2;   // segments per tile of d_sync / d_counts (log2)
     uint32_t runup;       // pass 1 follows a chain through this many positions in front of a segment (at most a segment)
     uint32_t max_len;
-    uint32_t *d_bits, *d_ebits;  // bit p: a match starts at p / a match ends at p + 1 (LongestChainLaunch)
-    uint32_t *d_sync, *d_counts; // per tile: its first match start (~0u: none), its matches
-    unsigned long long *d_exit;  // [0]: the chain's first position at or behind own_end, [1]: bail flag (both zeroed by the caller)
+    void *d_out;          // acgpu_set_match records, in text order
+    uint64_t cap;         // records d_out holds (further ones are counted, not stored)
+    unsigned long long *d_exit;  // [0]: the chain's first position at or behind own_end, [1]: bail flag, [2]: the record count ([0..3] zeroed by the caller)
+    unsigned long long *d_agg;   // per region: {published, matches}; d_blk, per 64 regions: {regions published, their matches} (zeroed by the caller)
+    unsigned long long *d_blk;
+    uint32_t *d_next;            // the next region to hand out (zeroed by the caller)
+    uint32_t *d_marks, *d_xout;  // per region: its marks (2048 words) and its 64 segment exits, between its walk and its records
     uint32_t *d_pred, *d_true;   // per region: the entry it assumed, the exit it found
     int grid;
     uint32_t debug;              // ACGPU_ABLATION builds: timing experiments (results are wrong)
 };
 uint32_t longest_bits_region_units();
 uint32_t longest_bits_seg_units();
+size_t longest_bits_region_scratch_bytes(); // d_marks + d_xout, per region
 hipError_t launch_longest_bits(const DevTables &t, const LongestBitsLaunch &l, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop);
 hipError_t launch_longest_sync(const LongestChainLaunch &l, uint32_t *d_sync, hipStream_t stream);
 hipError_t launch_longest_chain(const LongestChainLaunch &l, const uint32_t *d_sync, bool write_pass, hipStream_t stream);

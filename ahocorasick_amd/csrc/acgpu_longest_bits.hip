@@ -20,11 +20,14 @@
 //  * pass 2: lane j follows the chain of its own segment from that entry, counts the matches and marks their starts -- in
 //    the place of the text words it has left behind.  Then every lane's exit is compared with its neighbour's entry (the
 //    first region's first entry is the call's chain entry, so equal everywhere means exact everywhere); a difference
-//    anywhere -- or a unit outside the alphabet -- raises the call's bail flag and the call is redone by the walk pipeline;
+//    anywhere -- or a unit outside the alphabet -- raises the call's bail flag and the call is redone: once with a run-up of a
+//    whole segment, then by the walk pipeline;
 //  * every position of a text over the alphabet starts a match (the builder checks that every letter is a keyword), so the
-//    chain's positions ARE the match starts and (starts >> 1) the match ends: both bitmaps leave as coalesced stores, with
-//    the count and the first start of every tile of segments, for the prefix sum and k_longest_emit_ends.
-// HBM-bound: 2 B per unit read once; the kernel writes two bits per unit.  No length array, no synchronisation pass.
+//    chain's positions ARE the match starts and the next position of the chain is a match's end.  A region publishes its
+//    count, parks its marks in memory and, one region later, writes its records straight to their final place: ranks from
+//    the counts of the regions before it (two-level look-back), starts staged in LDS, 16-byte coalesced stores.
+// HBM-bound: 2 B per unit read once, 8 B per match written once (+ 2 x 1 bit per unit for the parked marks).  No length
+// array, no synchronisation pass, no separate prefix-sum or emit kernel.
 #include <cstdio>
 #include <hip/hip_runtime.h>
 
@@ -42,6 +45,8 @@ constexpr uint32_t kBitsStride = kBitsSegWords + kBitsLook; // 35 words: odd, so
 constexpr uint32_t kBitsSegs = 64;
 constexpr uint32_t kBitsRegionUnits = kBitsSegs * kBitsSegUnits;            // 65536 positions per wave and round
 constexpr uint32_t kBitsWaveWords = (kBitsSegs + 1) * kBitsStride + 1;      // segments -1 .. 63, and "segment 64, word 0"
+constexpr uint32_t kBitsRegionWords = kBitsRegionUnits / 32u;                // a region's marks: 2048 words
+constexpr unsigned long long kBitsPub = 1ull << 62, kBitsCount = (1ull << 40) - 1ull; // LongestBitsLaunch::d_agg / d_blk
 constexpr uint32_t kBitsTileUnits = 2048;                                   // 64 lanes x 32 units: one word per lane
 constexpr uint32_t kBitsTextMax = 33u * 32u;    // a 32-bit window may begin below this segment-relative position
 static_assert(kBitsWaves * kBitsWaveWords * 4 + kBitsTabEntries * 16 + 4 <= 160 * 1024, "LDS");
@@ -204,8 +209,24 @@ __device__ __forceinline__ uint32_t bits_walk(const BitsCtx &c, const uint4 *tab
     return q;
 }
 
+// wave64 inclusive prefix sum (DPP row shifts and row broadcasts), and sums over the wave
+__device__ __forceinline__ uint32_t bits_wave_scan(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true); // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true); // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true); // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true); // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1 and 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2 and 3
+    return x;
+}
+__device__ __forceinline__ uint32_t bits_wave_sum(uint32_t x) { return (uint32_t)__builtin_amdgcn_readlane((int)bits_wave_scan(x), 63); }
+__device__ __forceinline__ unsigned long long bits_wave_sum64(unsigned long long x) { // (values below 2^62; a wave's sum below 2^63)
+    for (int d = 32; d > 0; d >>= 1) x += (unsigned long long)__shfl_xor((long long)x, d);
+    return x;
+}
+
 #ifdef ACGPU_TIMING
-__device__ unsigned long long g_bits_timing[8]; // per-wave sums: gate wait, text, pass 1, pass 2, out, total; waves
+__device__ unsigned long long g_bits_timing[8]; // per-wave sums: gate wait, text, pass 1, pass 2, look-back, records, total; waves
 #define BITS_MARK(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); bt[i] += t_ - bt0; bt0 = t_; }
 #else
 #define BITS_MARK(i)
@@ -230,7 +251,6 @@ __global__ __launch_bounds__(kBitsBlock) void k_longest_bits(DevTables T, Longes
     const uint32_t base2 = c.base * 0x10001u;
     const uint16_t *hay = L.d_hay;
     const uint32_t nu = L.n_units;
-    const uint32_t last_w = (L.own_end - 1u) >> 5; // the last bitmap word this call writes
     // A wave alternates between streaming text (memory) and following chains (instruction issue, LDS).  The second half of
     // the workgroup starts when the first half has its text: from then on one half streams while the other walks.
     bool first = true;
@@ -246,7 +266,115 @@ __global__ __launch_bounds__(kBitsBlock) void k_longest_bits(DevTables T, Longes
     }
 
     BITS_MARK(0)
-    for (uint32_t r = blockIdx.x * kBitsWaves + wave; r < L.n_regions; r += gridDim.x * kBitsWaves) {
+    // The records of a finished region, straight to their final place.  They begin behind the matches of all regions before
+    // it: the regions before it in its block of 64 (one load of up to 63 words {published, count}) and the blocks before its
+    // own (one load per 64 blocks {regions published, their matches}, a block complete when all 64 have published); nothing
+    // but these words is handed over, so relaxed device-scope accesses suffice.  Every position of the chain is the start of a
+    // match and the NEXT position of the chain is its end.  Two segments per step (a word of marks per lane, text order =
+    // lane order): ranks from one wave prefix sum, the starts -- 16 bits, relative to the step -- into a staging list in LDS
+    // (the image is free: the region's marks come back from memory into registers), then the records {start k, start k + 1}
+    // as whole 16-byte stores, two per lane, 1 KB contiguous per instruction.  (A lane writing the records of its own word
+    // straight to memory -- 64 lanes, 64 places, 8 bytes each -- cost 250 k cycles per region and held up every other
+    // wave's memory operations: such stores saturate the store PATH.)  Behind a step's last start comes where the chain left
+    // the segment (the exit of the lane that walked it).
+    auto emit_region = [&](uint32_t r) {
+        unsigned long long before = 0;
+        {
+            const uint32_t blk = r >> 6, in_blk = r & 63u;
+#ifdef ACGPU_ABLATION
+            if (!(L.debug & 32u)) // 32: no look-back (every region writes from record 0: timing only)
+#endif
+            {
+                if (in_blk) {
+                    unsigned long long v;
+                    do {
+                        v = lane < in_blk ? __hip_atomic_load(&L.d_agg[(blk << 6) + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kBitsPub;
+                        if (__all((v & kBitsPub) != 0ull)) break;
+                        __builtin_amdgcn_s_sleep(8);
+                    } while (true);
+                    before += bits_wave_sum64(v & kBitsCount);
+                }
+                for (uint32_t b0 = 0; b0 < blk; b0 += 64u) { // (every block before it has 64 regions)
+                    unsigned long long v;
+                    do {
+                        v = b0 + lane < blk ? __hip_atomic_load(&L.d_blk[b0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (64ull << 40);
+                        if (__all((v >> 40) == 64ull)) break;
+                        __builtin_amdgcn_s_sleep(8);
+                    } while (true);
+                    before += bits_wave_sum64(v & kBitsCount);
+                }
+            }
+        }
+#ifdef ACGPU_ABLATION
+        if (L.debug & 4u) return; // 4: no record stores
+#endif
+        struct __attribute__((packed, aligned(4))) Rec2 { uint32_t s0, e0, s1, e1; };
+        int2 *outp = reinterpret_cast<int2 *>(L.d_out);
+        uint32_t *stg = img; // the starts of a step (at most 2048) and, twice, what comes behind them
+        static_assert(2u * kBitsSegUnits + 2u <= kBitsWaveWords, "a step's starts fit the image");
+        const uint32_t *gm = L.d_marks + (size_t)r * kBitsRegionWords;
+        const uint32_t xo = L.d_xout[(size_t)r * kBitsSegs + lane];
+        const uint32_t R0 = L.g0 + r * kBitsRegionUnits;
+        const uint32_t rel = R0 + (lane >> 5) * kBitsSegUnits + (lane & 31u) * 32u; // the lane's word in step 0
+        unsigned long long done = before;
+        uint32_t mk[16];
+#pragma unroll
+        for (uint32_t half = 0; half < 2; ++half) {
+#pragma unroll
+            for (uint32_t t = 0; t < 16; ++t) mk[t] = gm[(half * 16u + t) * 64u + lane];
+#pragma unroll
+            for (uint32_t t = 0; t < 16; ++t) {
+                const uint32_t i = half * 16u + t; // segments 2i and 2i + 1
+                uint32_t w = mk[t];
+                const uint32_t c = (uint32_t)__popc(w);
+                const uint32_t incl = bits_wave_scan(c);
+                const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                if (tot == 0u) continue; // wave-uniform
+                const uint32_t in_second = tot - (uint32_t)__builtin_amdgcn_readlane((int)incl, 31);
+                const uint32_t edge = in_second ? (uint32_t)__builtin_amdgcn_readlane((int)xo, (int)(2u * i + 1u))
+                                                : (uint32_t)__builtin_amdgcn_readlane((int)xo, (int)(2u * i));
+                const uint32_t pb = rel + i * 2u * kBitsSegUnits;
+                uint32_t *at = stg + (incl - c);
+                while (w) {
+                    *at++ = pb + (uint32_t)__builtin_ctz(w);
+                    w &= w - 1u;
+                }
+                if (lane == 0) {
+                    stg[tot] = edge;
+                    stg[tot + 1u] = edge;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (__builtin_expect(done + tot <= L.cap, 1)) { // wave-uniform: all of them fit
+                    // pairs of records on 16-byte boundaries of the output; a single one in front and / or behind them
+                    const uint32_t odd = (uint32_t)done & 1u;
+                    const uint32_t pairs_end = odd + ((tot - odd) & ~1u);
+                    for (uint32_t k = odd + 2u * lane; k < pairs_end; k += 2u * kWave) {
+                        const uint32_t s0 = stg[k], s1 = stg[k + 1u], s2 = stg[k + 2u];
+                        const Rec2 two = {s0, s1, s1, s2};
+                        *reinterpret_cast<Rec2 *>(outp + (done + k)) = two;
+                    }
+                    if (lane == 0 && odd) outp[done] = make_int2((int)stg[0], (int)stg[1]);
+                    if (lane == 1 && pairs_end < tot) outp[done + pairs_end] = make_int2((int)stg[pairs_end], (int)stg[pairs_end + 1u]);
+                } else {
+                    for (uint32_t k = lane; k < tot; k += kWave)
+                        if (done + k < L.cap) outp[done + k] = make_int2((int)stg[k], (int)stg[k + 1u]);
+                }
+                __builtin_amdgcn_wave_barrier();
+                done += tot;
+            }
+        }
+        if (r + 1u == L.n_regions && lane == 0) L.d_exit[2] = done; // the call's record count
+    };
+    bool have_prev = false;
+    uint32_t prev_r = 0;
+    // Regions are handed out in the order in which waves ask for them (one atomic per region): a region's records go behind
+    // those of every region before it, and every region before it belongs to a wave that is already running -- the look-back
+    // can wait for them whatever share of the grid is resident.
+    for (;;) {
+        uint32_t r = 0;
+        if (lane == 0) r = atomicAdd(L.d_next, 1u);
+        r = __builtin_amdgcn_readfirstlane(r);
+        if (r >= L.n_regions) break;
         const uint32_t R0 = L.g0 + r * kBitsRegionUnits; // first position of segment 0
         // ---- the region's text, one bit per unit: segments -1 .. 63 and the first words of segment 64 -----------------------
         uint32_t dmax = 0;
@@ -376,76 +504,48 @@ __global__ __launch_bounds__(kBitsBlock) void k_longest_bits(DevTables T, Longes
 #endif
         if (__any(differs) && lane == 0) atomicMax(&L.d_exit[1], 1ull);
         if (lane == 0) L.d_pred[r] = e_in;
-        if (lane == 63) {
-            L.d_true[r] = x_out;
-            img[kBitsWaveWords - 1u] = x_out == R0 + kBitsRegionUnits ? 1u : 0u; // "segment 64, word 0": is its first position a start
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (start < L.own_end && bound == L.own_end) { // this lane's segment holds the last owned position: its exit is the call's
-            L.d_exit[0] = (unsigned long long)x_out;
-            // the last match ends at x_out - 1: inside the last word this call stores -> through the image (the start bit of
-            // x_out, beyond the owned range, is masked from the starts below); in a later word -> straight into the bitmap,
-            // which the caller has zeroed from there on
-            const uint32_t ew = (x_out - 1u) >> 5;
-            if (ew > last_w) {
-                atomicOr(&L.d_ebits[ew], 1u << ((x_out - 1u) & 31u));
-            } else if (x_out < R0 + kBitsRegionUnits) {
-                const uint32_t rel = x_out - R0;
-                img[((rel >> 10) + 1u) * kBitsStride + ((rel >> 5) & 31u)] |= 1u << (rel & 31u);
-            } // (x_out == the region's end: lane 63's word above)
-        }
+        if (lane == 63) L.d_true[r] = x_out;
+        if (start < L.own_end && bound == L.own_end) L.d_exit[0] = (unsigned long long)x_out; // the segment with the last owned position: its exit is the call's
         __builtin_amdgcn_wave_barrier();
 
         BITS_MARK(3)
-        // ---- out: starts, ends (= starts >> 1), per tile of segments the first start and the count ---------------------------
-        const uint32_t gw0 = R0 >> 5; // (a multiple of 4: g0 is a multiple of 128 positions)
-        const uint32_t cut = (L.own_end & 31u) ? ~(~0u << (L.own_end & 31u)) : ~0u; // positions of the last word inside the owned range
-#pragma unroll 2
-        for (uint32_t i = 0; i < kBitsRegionUnits / (4u * kBitsTileUnits); ++i) { // four words per lane: 16-byte stores
-#ifdef ACGPU_ABLATION
-            if (L.debug & 4u) break; // no bitmap stores
-#endif
-            const uint32_t g = i * 64u + lane, sg = g >> 3, k = (g & 7u) * 4u;
-            const uint32_t *sp = img + (sg + 1u) * kBitsStride + k;
-            const uint32_t c0 = sp[0], c1 = sp[1], c2 = sp[2], c3 = sp[3], c4 = k == 28u ? img[(sg + 2u) * kBitsStride] : sp[4];
-            const uint32_t e0 = __builtin_amdgcn_alignbit(c1, c0, 1), e1 = __builtin_amdgcn_alignbit(c2, c1, 1),
-                           e2 = __builtin_amdgcn_alignbit(c3, c2, 1), e3 = __builtin_amdgcn_alignbit(c4, c3, 1);
-            const uint32_t gw = gw0 + 4u * g;
-            if (gw + 3u < last_w) {
-                *reinterpret_cast<uint4 *>(L.d_bits + gw) = make_uint4(c0, c1, c2, c3);
-                *reinterpret_cast<uint4 *>(L.d_ebits + gw) = make_uint4(e0, e1, e2, e3);
-            } else if (gw <= last_w) { // the group with the last word
-                const uint32_t cs[4] = {c0, c1, c2, c3}, es[4] = {e0, e1, e2, e3};
-#pragma unroll
-                for (uint32_t z = 0; z < 4; ++z)
-                    if (gw + z <= last_w) {
-                        L.d_bits[gw + z] = gw + z == last_w ? (cs[z] & cut) : cs[z];
-                        L.d_ebits[gw + z] = es[z];
-                    }
-            }
+        // ---- out ------------------------------------------------------------------------------------------------------------
+        // The region's count is published at once; its marks and exits go to memory (8.3 KB), and its RECORDS are written one
+        // region later (emit_region below): where they begin is the number of matches of ALL regions before it, and the 4096
+        // waves of a round finish their walks at about the same time -- a wave that waited for the slowest of them here stood
+        // still for a third of its time (measured), one that comes back after its next region finds every count there.
+        const uint32_t region_total = bits_wave_sum(cnt);
+        if (lane == 0) {
+            __hip_atomic_store(&L.d_agg[r], kBitsPub | region_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&L.d_blk[r >> 6], (1ull << 40) | region_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         {
-            const uint32_t ts = 1u << L.tile_log2; // segments per tile
-            uint32_t csum = cnt;
-            for (uint32_t d = 1; d < ts; d <<= 1) csum += __shfl_down(csum, d);
-            if ((lane & (ts - 1u)) == 0) {
-                const uint32_t tile = (r * kBitsSegs + lane) >> L.tile_log2;
-                const uint32_t tend = (uint32_t)min((uint64_t)L.own_end, (uint64_t)start + (uint64_t)ts * kBitsSegUnits);
-                L.d_sync[tile] = e_in < tend ? e_in : ~0u;
-                L.d_counts[tile] = csum;
+            uint32_t *gm = L.d_marks + (size_t)r * kBitsRegionWords;
+#pragma unroll 4
+            for (uint32_t i = 0; i < kBitsRegionWords / 256u; ++i) { // four words per lane: 16-byte stores
+                const uint32_t g = i * 64u + lane, sg = g >> 3, k = (g & 7u) * 4u;
+                const uint32_t *sp = img + (sg + 1u) * kBitsStride + k;
+                *reinterpret_cast<uint4 *>(gm + 4u * g) = make_uint4(sp[0], sp[1], sp[2], sp[3]);
             }
+            L.d_xout[(size_t)r * kBitsSegs + lane] = x_out;
         }
+        __builtin_amdgcn_wave_barrier();
+        BITS_MARK(4)
+        if (have_prev) emit_region(prev_r);
+        prev_r = r;
+        have_prev = true;
         __builtin_amdgcn_wave_barrier();
 #ifdef ACGPU_TIMING
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the stores are this phase's)
 #endif
-        BITS_MARK(4)
+        BITS_MARK(5)
     }
+    if (have_prev) emit_region(prev_r); // (the wave's last region: here it does wait for the regions before it)
 #ifdef ACGPU_TIMING
     if (lane == 0) {
-        for (int i = 0; i < 5; ++i) atomicAdd(&g_bits_timing[i], bt[i]);
-        atomicAdd(&g_bits_timing[5], __builtin_amdgcn_s_memtime() - bstart);
-        atomicAdd(&g_bits_timing[6], 1ull);
+        for (int i = 0; i < 6; ++i) atomicAdd(&g_bits_timing[i], bt[i]);
+        atomicAdd(&g_bits_timing[6], __builtin_amdgcn_s_memtime() - bstart);
+        atomicAdd(&g_bits_timing[7], 1ull);
     }
 #endif
     if (first && wave < kBitsWaves / 2 && lane == 0) atomicAdd(&gate, 1u); // (a wave without a region)
@@ -460,6 +560,7 @@ __global__ __launch_bounds__(256) void k_longest_bits_check(LongestBitsLaunch L)
 
 uint32_t longest_bits_region_units() { return kBitsRegionUnits; }
 uint32_t longest_bits_seg_units() { return kBitsSegUnits; }
+size_t longest_bits_region_scratch_bytes() { return (size_t)kBitsRegionWords * 4 + kBitsSegs * 4; }
 
 hipError_t launch_longest_bits(const DevTables &t, const LongestBitsLaunch &l, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     ACGPU_LAUNCH_EV(k_longest_bits, dim3(l.grid), dim3(kBitsBlock), 0, stream, ev_start, ev_stop, t, l);
@@ -470,8 +571,8 @@ hipError_t launch_longest_bits(const DevTables &t, const LongestBitsLaunch &l, h
         (void)hipStreamSynchronize(stream);
         unsigned long long h[8] = {0};
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bits_timing), sizeof(h));
-        if (h[6]) fprintf(stderr, "[bits timing] waves %llu: total %.0f | gate %.0f | text %.0f | pass 1 %.0f | pass 2 %.0f | out %.0f (s_memtime ticks per wave)\n",
-                          h[6], (double)h[5] / h[6], (double)h[0] / h[6], (double)h[1] / h[6], (double)h[2] / h[6], (double)h[3] / h[6], (double)h[4] / h[6]);
+        if (h[7]) fprintf(stderr, "[bits timing] waves %llu: total %.0f | gate %.0f | text %.0f | pass 1 %.0f | pass 2 %.0f | look-back %.0f | records %.0f (s_memtime ticks per wave)\n",
+                          h[7], (double)h[6] / h[7], (double)h[0] / h[7], (double)h[1] / h[7], (double)h[2] / h[7], (double)h[3] / h[7], (double)h[4] / h[7], (double)h[5] / h[7]);
         unsigned long long z[8] = {0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bits_timing), z, sizeof(z));
     }
