@@ -821,38 +821,45 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
         Bl.max_len = t.max_len;
         Bl.d_out = d_out;
         Bl.cap = cap;
-        if ((rc = d.counter.ensure(64))) return rc;
-        const size_t n_blk = ((size_t)Bl.n_regions + 63) / 64, agg_words = (size_t)Bl.n_regions + n_blk + 2;
-        if ((rc = d.offsets.ensure(agg_words * 8))) return rc;  // a word per region, a word per block of 64 regions, the region counter
+        const size_t n_blk = ((size_t)Bl.n_regions + 63) / 64, state_words = 8 + (size_t)Bl.n_regions + n_blk + 2;
+        // exit / flag / count, a word per region, a word per block of 64 regions, the region counter: zero at the start of a call --
+        // the call's last kernel leaves them so; a memset only for a fresh (or larger) buffer and after a call that failed half way
+        const size_t state_had = d.bits_state.bytes;
+        if ((rc = d.bits_state.ensure(state_words * 8))) return rc;
+        if (d.bits_state.p != d.bits_state_seen || d.bits_state.bytes != state_had) {
+            HIP_TRY(hipMemsetAsync(d.bits_state.p, 0, d.bits_state.bytes, stream));
+            d.bits_state_seen = d.bits_state.p;
+        }
         if ((rc = d.blockmax.ensure((size_t)Bl.n_regions * 8 + 64))) return rc;
-        Bl.d_exit = (unsigned long long *)d.counter.p;
-        Bl.d_agg = (unsigned long long *)d.offsets.p;
         if ((rc = d.chainbits.ensure((size_t)Bl.n_regions * longest_bits_region_scratch_bytes() + 64))) return rc;
-        Bl.d_marks = (uint32_t *)d.chainbits.p;
-        Bl.d_xout = Bl.d_marks + (size_t)Bl.n_regions * (region_units / 32);
+        Bl.d_exit = (unsigned long long *)d.bits_state.p;
+        Bl.d_agg = Bl.d_exit + 8;
         Bl.d_blk = Bl.d_agg + Bl.n_regions;
         Bl.d_next = (uint32_t *)(Bl.d_blk + n_blk);
+        Bl.d_marks = (uint32_t *)d.chainbits.p;
+        Bl.d_xout = Bl.d_marks + (size_t)Bl.n_regions * (region_units / 32);
         Bl.d_pred = (uint32_t *)d.blockmax.p;
         Bl.d_true = Bl.d_pred + Bl.n_regions;
         Bl.grid = (int)std::min<uint64_t>((uint64_t)d.n_cu, (Bl.n_regions + 15) / 16);
         Bl.debug = (uint32_t)(tunables().tile_debug >> 32);
-        HIP_TRY(hipMemsetAsync(d.counter.p, 0, 64, stream));
-        HIP_TRY(hipMemsetAsync(d.offsets.p, 0, agg_words * 8, stream));
-        d.cclean[0] = false; // (match_all's first set of slot counters lives here)
-        if (timed) HIP_TRY(hipEventRecord(ev[0], stream));
-        HIP_TRY(launch_longest_bits(d.T, Bl, stream, nullptr, nullptr)); // (the whole pipeline: text in, records out; then the check of the region seams)
-        if (timed) HIP_TRY(hipEventRecord(ev[1], stream));
-        if (timed) HIP_TRY(hipEventRecord(ev[2], stream));
         unsigned long long *h_slot = tk ? tk->h_count : d.h_counter, *d_slot = nullptr;
         HIP_TRY(hipHostGetDevicePointer((void **)&d_slot, h_slot, 0));
-        HIP_TRY(launch_publish_result((const unsigned long long *)d.counter.p + 2, (const unsigned long long *)d.counter.p,
-                                      d_slot, tk ? reinterpret_cast<acgpu_device_result *>(sh->d_result) : nullptr, stream));
+        void *const seen = d.bits_state_seen;
+        d.bits_state_seen = nullptr; // (until both kernels are enqueued: an error below leaves the words in an unknown state)
+        // the whole pipeline in two launches: text in, records out; then the seams, the result and the state for the next call.
+        // (Profiled calls take the dispatches' own start / stop timestamps: marker packets between the steps cost more than the
+        // second kernel does.)
+        HIP_TRY(launch_longest_bits(d.T, Bl, d_slot, tk ? reinterpret_cast<acgpu_device_result *>(sh->d_result) : nullptr,
+                                    (unsigned long long *)d.bits_state.p, (uint32_t)state_words, stream, timed ? ev[0] : nullptr,
+                                    timed ? ev[1] : nullptr, timed ? ev[2] : nullptr));
+        d.bits_state_seen = seen;
         if (tk) {
             tk->stream = stream;
             tk->shard = *sh;
             tk->record_kind = record_kind;
             tk->d_out = d_out;
-            HIP_TRY(hipEventRecord(tk->done, stream));
+            tk->done_is_ev2 = timed; // (the finish kernel's own end)
+            if (!timed) HIP_TRY(hipEventRecord(tk->done, stream));
             tk->scanned = own_len;
             std::snprintf(tk->kname, sizeof(tk->kname), "k_longest_bits");
             return ACGPU_OK;
@@ -861,7 +868,7 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
 #ifdef ACGPU_ABLATION
         if (Bl.debug) {
             unsigned long long mism = 0;
-            (void)hipMemcpy(&mism, (const char *)d.counter.p + 24, 8, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(&mism, (const char *)d.bits_state.p + 24, 8, hipMemcpyDeviceToHost); // (the finish kernel has zeroed it: kept for builds that skip it)
             fprintf(stderr, "[k_longest_bits debug %u] segments whose assumed entry was not the exit before them: %llu\n", Bl.debug, mism);
         }
 #endif

@@ -107,6 +107,8 @@ struct DeviceState {
     DevBuf blockmax;                                     // LONGEST: farthest landing per 64 positions
     DevBuf lenbig, todo;                                 // LONGEST: escaped lengths; root-table form: flagged chunks
     DevBuf chainbits;                                    // LONGEST: one bit per position, set where the chain reports a match
+    DevBuf bits_state;                                   // k_longest_bits: exit / flag / count, look-back words, region counter -- zero between calls
+    void *bits_state_seen = nullptr;                     // (a re-allocated buffer, or a call that failed half way, is zeroed by a memset)
     DevBuf cands, region_cands;                          // ALL, split form: candidate positions, {first, count} per region
     DevBuf wwl_rs, wwl_mend, wwl_mid, wwl_sel, wwl_stop, wwl_nxt0; // WWLONGEST: walk starts, what each would report, where it stops
     unsigned long long *h_counter = nullptr; // pinned
@@ -129,7 +131,7 @@ struct DeviceState {
         if (small_stream) (void)hipStreamDestroy(small_stream);
         if (small_pin) (void)hipHostFree(small_pin);
         short_recs.release(); short_nxt.release(); short_tmp.release(); short_mark.release();
-        wwl_rs.release(); wwl_mend.release(); wwl_mid.release(); wwl_sel.release(); wwl_stop.release(); wwl_nxt0.release(); ww_recs.release(); blockmax.release(); lenbig.release(); todo.release(); chainbits.release(); cands.release(); region_cands.release();
+        wwl_rs.release(); wwl_mend.release(); wwl_mid.release(); wwl_sel.release(); wwl_stop.release(); wwl_nxt0.release(); ww_recs.release(); blockmax.release(); lenbig.release(); todo.release(); chainbits.release(); bits_state.release(); cands.release(); region_cands.release();
         if (h_counter) (void)hipHostFree(h_counter);
         for (auto &q : pin) if (q) (void)hipHostFree(q);
         if (batch_pin) (void)hipHostFree(batch_pin);

@@ -231,7 +231,7 @@ struct LongestBitsLaunch {
     uint32_t max_len;
     void *d_out;          // acgpu_set_match records, in text order
     uint64_t cap;         // records d_out holds (further ones are counted, not stored)
-    unsigned long long *d_exit;  // [0]: the chain's first position at or behind own_end, [1]: bail flag, [2]: the record count ([0..3] zeroed by the caller)
+    unsigned long long *d_exit;  // [0]: the chain's first position at or behind own_end, [1]: bail flag, [2]: the record count (zero at the start)
     unsigned long long *d_agg;   // per region: {published, matches}; d_blk, per 64 regions: {regions published, their matches} (zeroed by the caller)
     unsigned long long *d_blk;
     uint32_t *d_next;            // the next region to hand out (zeroed by the caller)
@@ -243,7 +243,11 @@ struct LongestBitsLaunch {
 uint32_t longest_bits_region_units();
 uint32_t longest_bits_seg_units();
 size_t longest_bits_region_scratch_bytes(); // d_marks + d_xout, per region
-hipError_t launch_longest_bits(const DevTables &t, const LongestBitsLaunch &l, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop);
+// k_longest_bits, then k_longest_bits_finish: the seams between the regions checked, {count, bail flag, exit} to the pinned host
+// slot and to d_result (may be nullptr), the call's state words (d_exit, d_agg, d_blk, d_next: one allocation) zeroed for the next call
+hipError_t launch_longest_bits(const DevTables &t, const LongestBitsLaunch &l, unsigned long long *h_slot_dev, acgpu_device_result *d_result,
+                               unsigned long long *d_state, uint32_t state_words, hipStream_t stream, hipEvent_t ev_start = nullptr,
+                               hipEvent_t ev_mid = nullptr, hipEvent_t ev_stop = nullptr); // (profiled calls: the dispatches' own timestamps)
 hipError_t launch_longest_sync(const LongestChainLaunch &l, uint32_t *d_sync, hipStream_t stream);
 hipError_t launch_longest_chain(const LongestChainLaunch &l, const uint32_t *d_sync, bool write_pass, hipStream_t stream);
 // count / write pass with the lengths staged through LDS in chunks (16-bit lengths)

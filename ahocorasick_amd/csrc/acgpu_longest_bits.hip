@@ -551,19 +551,40 @@ __global__ __launch_bounds__(kBitsBlock) void k_longest_bits(DevTables T, Longes
     if (first && wave < kBitsWaves / 2 && lane == 0) atomicAdd(&gate, 1u); // (a wave without a region)
 }
 
-// every region's entry is the exit of the region before it
-__global__ __launch_bounds__(256) void k_longest_bits_check(LongestBitsLaunch L) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r == 0 || r >= L.n_regions) return;
-    if (L.d_pred[r] != L.d_true[r - 1]) atomicMax(&L.d_exit[1], 1ull);
+// The call's last kernel, one workgroup: every region's entry must be the exit of the region before it (else the bail flag);
+// then {count, bail flag, exit} to the call's pinned host slot and to acgpu_shard::d_result, in stream order; and the call's
+// state words -- look-back words, region counter, exit / flag / count -- are zeroed for the NEXT call (no memset operations
+// of its own on the stream: each is a launch gap).
+__global__ __launch_bounds__(1024) void k_longest_bits_finish(LongestBitsLaunch L, unsigned long long *h_slot, acgpu_device_result *res,
+                                                              unsigned long long *state, uint32_t state_words) {
+    int seam = 0;
+    for (uint32_t r = 1u + threadIdx.x; r < L.n_regions; r += blockDim.x) seam |= L.d_pred[r] != L.d_true[r - 1u] ? 1 : 0;
+    const int any_seam = __syncthreads_or(seam);
+    if (threadIdx.x == 0) {
+        unsigned long long flag = L.d_exit[1];
+        if (any_seam && flag == 0ull) flag = 1ull;
+        const unsigned long long n = L.d_exit[2], ex = L.d_exit[0];
+        h_slot[1] = flag;
+        h_slot[2] = ex;
+        h_slot[0] = n;
+        if (res) {
+            res->n_records = n;
+            res->redone = flag != 0ull; // (the records are not there yet: acgpu_match_device_end redoes the call)
+            res->reserved = 0;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < state_words; i += blockDim.x) state[i] = 0ull;
 }
 
 uint32_t longest_bits_region_units() { return kBitsRegionUnits; }
 uint32_t longest_bits_seg_units() { return kBitsSegUnits; }
 size_t longest_bits_region_scratch_bytes() { return (size_t)kBitsRegionWords * 4 + kBitsSegs * 4; }
 
-hipError_t launch_longest_bits(const DevTables &t, const LongestBitsLaunch &l, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
-    ACGPU_LAUNCH_EV(k_longest_bits, dim3(l.grid), dim3(kBitsBlock), 0, stream, ev_start, ev_stop, t, l);
+hipError_t launch_longest_bits(const DevTables &t, const LongestBitsLaunch &l, unsigned long long *h_slot_dev, acgpu_device_result *d_result,
+                               unsigned long long *d_state, uint32_t state_words, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_mid,
+                               hipEvent_t ev_stop) {
+    ACGPU_LAUNCH_EV(k_longest_bits, dim3(l.grid), dim3(kBitsBlock), 0, stream, ev_start, ev_mid, t, l);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
 #ifdef ACGPU_TIMING
@@ -571,13 +592,14 @@ hipError_t launch_longest_bits(const DevTables &t, const LongestBitsLaunch &l, h
         (void)hipStreamSynchronize(stream);
         unsigned long long h[8] = {0};
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bits_timing), sizeof(h));
-        if (h[7]) fprintf(stderr, "[bits timing] waves %llu: total %.0f | gate %.0f | text %.0f | pass 1 %.0f | pass 2 %.0f | look-back %.0f | records %.0f (s_memtime ticks per wave)\n",
+        if (h[7]) fprintf(stderr, "[bits timing] waves %llu: total %.0f | gate %.0f | text %.0f | pass 1 %.0f | pass 2 %.0f | publish + marks %.0f | records of the region before %.0f (s_memtime ticks per wave)\n",
                           h[7], (double)h[6] / h[7], (double)h[0] / h[7], (double)h[1] / h[7], (double)h[2] / h[7], (double)h[3] / h[7], (double)h[4] / h[7], (double)h[5] / h[7]);
         unsigned long long z[8] = {0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bits_timing), z, sizeof(z));
     }
 #endif
-    if (l.n_regions > 1) hipLaunchKernelGGL(k_longest_bits_check, dim3((l.n_regions + 255) / 256), dim3(256), 0, stream, l);
+    const hipEvent_t ev_none = nullptr;
+    ACGPU_LAUNCH_EV(k_longest_bits_finish, dim3(1), dim3(1024), 0, stream, ev_none, ev_stop, l, h_slot_dev, d_result, d_state, state_words);
     return hipGetLastError();
 }
 
