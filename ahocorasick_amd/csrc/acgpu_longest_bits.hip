@@ -226,7 +226,8 @@ __device__ __forceinline__ unsigned long long bits_wave_sum64(unsigned long long
 }
 
 #ifdef ACGPU_TIMING
-__device__ unsigned long long g_bits_timing[8]; // per-wave sums: gate wait, text, pass 1, pass 2, look-back, records, total; waves
+__device__ unsigned long long g_bits_timing[8];
+__device__ unsigned long long g_bits_tail[2]; // the last region of a wave: waiting for the counts before it, writing its records // per-wave sums: gate wait, text, pass 1, pass 2, look-back, records, total; waves
 #define BITS_MARK(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); bt[i] += t_ - bt0; bt0 = t_; }
 #else
 #define BITS_MARK(i)
@@ -277,6 +278,9 @@ __global__ __launch_bounds__(kBitsBlock) void k_longest_bits(DevTables T, Longes
     // straight to memory -- 64 lanes, 64 places, 8 bytes each -- cost 250 k cycles per region and held up every other
     // wave's memory operations: such stores saturate the store PATH.)  Behind a step's last start comes where the chain left
     // the segment (the exit of the lane that walked it).
+#ifdef ACGPU_TIMING
+    unsigned long long t_lookback_done = 0;
+#endif
     auto emit_region = [&](uint32_t r) {
         unsigned long long before = 0;
         {
@@ -307,6 +311,9 @@ __global__ __launch_bounds__(kBitsBlock) void k_longest_bits(DevTables T, Longes
         }
 #ifdef ACGPU_ABLATION
         if (L.debug & 4u) return; // 4: no record stores
+#endif
+#ifdef ACGPU_TIMING
+        t_lookback_done = __builtin_amdgcn_s_memtime();
 #endif
         struct __attribute__((packed, aligned(4))) Rec2 { uint32_t s0, e0, s1, e1; };
         int2 *outp = reinterpret_cast<int2 *>(L.d_out);
@@ -540,7 +547,16 @@ __global__ __launch_bounds__(kBitsBlock) void k_longest_bits(DevTables T, Longes
 #endif
         BITS_MARK(5)
     }
+#ifdef ACGPU_TIMING
+    const unsigned long long t_loop_end = __builtin_amdgcn_s_memtime();
+#endif
     if (have_prev) emit_region(prev_r); // (the wave's last region: here it does wait for the regions before it)
+#ifdef ACGPU_TIMING
+    if (have_prev && lane == 0) {
+        atomicAdd(&g_bits_tail[0], t_lookback_done - t_loop_end);
+        atomicAdd(&g_bits_tail[1], __builtin_amdgcn_s_memtime() - t_lookback_done);
+    }
+#endif
 #ifdef ACGPU_TIMING
     if (lane == 0) {
         for (int i = 0; i < 6; ++i) atomicAdd(&g_bits_timing[i], bt[i]);
@@ -594,8 +610,12 @@ hipError_t launch_longest_bits(const DevTables &t, const LongestBitsLaunch &l, u
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bits_timing), sizeof(h));
         if (h[7]) fprintf(stderr, "[bits timing] waves %llu: total %.0f | gate %.0f | text %.0f | pass 1 %.0f | pass 2 %.0f | publish + marks %.0f | records of the region before %.0f (s_memtime ticks per wave)\n",
                           h[7], (double)h[6] / h[7], (double)h[0] / h[7], (double)h[1] / h[7], (double)h[2] / h[7], (double)h[3] / h[7], (double)h[4] / h[7], (double)h[5] / h[7]);
+        unsigned long long tl[2] = {0, 0};
+        (void)hipMemcpyFromSymbol(tl, HIP_SYMBOL(g_bits_tail), sizeof(tl));
+        if (h[7]) fprintf(stderr, "[bits timing] last region of a wave: waits %.0f for the counts before it, writes its records in %.0f\n", (double)tl[0] / h[7], (double)tl[1] / h[7]);
         unsigned long long z[8] = {0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bits_timing), z, sizeof(z));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bits_tail), z, sizeof(tl));
     }
 #endif
     const hipEvent_t ev_none = nullptr;
