@@ -91,6 +91,8 @@ def one_case(rng, it):
         knobs["tile_debug"] = 4194304  # chain marking in one pass (Shortest, sparse Longest, WholeWordLongest) on small inputs too
     if rng.integers(0, 2):
         knobs["tile_debug"] |= 1 << 41  # short haystacks through the general path instead of the one-launch form
+    if fam == 1 and rng.integers(0, 2):
+        knobs["tile_debug"] |= 67108864  # k_longest_bits (two-letter alphabets, every letter a keyword) for short texts too
     for k, v in knobs.items():
         N.set_tunable(k, v)
     mode = [N.MODE_ALL, N.MODE_LONGEST, N.MODE_WHOLEWORD, N.MODE_SHORTEST, N.MODE_WWLONGEST][fam]
