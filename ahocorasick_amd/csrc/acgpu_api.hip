@@ -886,6 +886,111 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
         }
         return *n_out > cap ? ACGPU_E_OVERFLOW : ACGPU_OK;
     }
+    // Any other dense dictionary with range classes or small class pages, long texts, Set and Map records: the walks of the chain's own
+    // positions only (k_longest_follow, acgpu_longest_follow.hip) in place of the length array, the synchronisation points and the chain
+    // pass; the bitmaps, counts and first positions it leaves are what the prefix sum and k_longest_emit_ends below read.  It checks its
+    // own result like k_longest_bits and is redone the same way.  Tunable tile_debug bit 268435456 << 1 (536870912): never; bit
+    // 1073741824: also for short texts (tests).
+    const size_t fol_pages = (!t.range_cls && !t.dfa_pages.empty()) ? t.dfa_pages.size() * 2 : 0;
+    const bool fol_classes = t.dense && ((t.range_cls && t.n_cls == t.cls_span + 1) || fol_pages > 0);
+    const uint32_t fol_hot = fol_classes ? longest_follow_hot_rows(t.n_cls, t.n_states, (uint32_t)fol_pages) : 0;
+    const bool follow_form = bits_level < 2 && fol_hot > 0 && !(tunables().tile_debug & 536870912) &&
+                             (own_len >= (1ull << 20) || (tunables().tile_debug & 1073741824)) && tunables().force_kernel == 0;
+    if (follow_form) {
+        int rc;
+        LongestFollowLaunch F{};
+        F.d_hay = sh->d_hay;
+        F.n_units = (uint32_t)sh->n_units;
+        F.own_end = (uint32_t)sh->own_end;
+        F.entry = (uint32_t)entry;
+        F.g0 = (uint32_t)entry & ~31u;
+        const uint32_t region_units = longest_follow_region_units(), seg_units = longest_follow_seg_units();
+        F.n_regions = (uint32_t)((sh->own_end - F.g0 + region_units - 1) / region_units);
+        F.runup = bits_level == 0 ? seg_units / 2 : seg_units;
+        F.tile_log2 = 2;
+        F.hot_rows = fol_hot;
+        const uint32_t n_tiles = (F.n_regions * (region_units / seg_units)) >> F.tile_log2;
+        if ((rc = d.counter.ensure(64))) return rc;
+        if ((rc = d.chunk_counts.ensure((size_t)n_tiles * 4))) return rc;
+        if ((rc = d.offsets.ensure((size_t)n_tiles * 8))) return rc;
+        if ((rc = d.scan_tmp.ensure(((size_t)n_tiles / 2048 + 2) * 8))) return rc;
+        if ((rc = d.chain.ensure((size_t)n_tiles * 4 + 64))) return rc;
+        if ((rc = d.blockmax.ensure((size_t)F.n_regions * 8 + 64))) return rc;
+        const size_t bit_bytes = ((size_t)sh->n_units / 128 + 2) * 16;
+        if ((rc = d.chainbits.ensure(bit_bytes * 2))) return rc;
+        F.d_bits = (uint32_t *)d.chainbits.p;
+        F.d_ebits = F.d_bits + bit_bytes / 4;
+        F.d_state = nullptr;
+        if (record_kind == ACGPU_REC_MAP) {
+            if ((rc = d.statebuf.ensure((size_t)sh->n_units * 4 + 64))) return rc;
+            F.d_state = (uint32_t *)d.statebuf.p;
+        }
+        F.d_sync = (uint32_t *)d.chain.p;
+        F.d_counts = (uint32_t *)d.chunk_counts.p;
+        F.d_exit = (unsigned long long *)d.counter.p;
+        F.d_pred = (uint32_t *)d.blockmax.p;
+        F.d_true = F.d_pred + F.n_regions;
+        F.grid = (int)std::min<uint64_t>(2ull * d.n_cu, (F.n_regions + 15) / 16);
+        HIP_TRY(hipMemsetAsync(d.counter.p, 0, 64, stream));
+        d.cclean[0] = false; // (match_all's first set of slot counters lives here)
+        { // the end bits are merged with atomicOr: zeros from the first word the chain can touch to where its last match can end
+            const size_t first = F.g0 >> 5, last = std::min<size_t>(bit_bytes / 4, (((size_t)sh->own_end + t.max_len) >> 5) + 2);
+            if (last > first) HIP_TRY(hipMemsetAsync(F.d_ebits + first, 0, (last - first) * 4, stream));
+        }
+        if (timed) HIP_TRY(hipEventRecord(ev[0], stream));
+        HIP_TRY(launch_longest_follow(d.T, F, t.range_cls, record_kind == ACGPU_REC_MAP, stream));
+        if (timed) HIP_TRY(hipEventRecord(ev[1], stream));
+        LongestChainLaunch Cn{};
+        Cn.d_state = F.d_state;
+        Cn.d_out_id = d.T.term_id;
+        Cn.len_bytes = 1;
+        Cn.own_begin = (uint32_t)sh->own_begin;
+        Cn.own_end = (uint32_t)sh->own_end;
+        Cn.entry = (uint32_t)entry;
+        Cn.tile_units = seg_units << F.tile_log2;
+        Cn.n_tiles = n_tiles;
+        Cn.max_len = t.max_len;
+        Cn.d_counts = F.d_counts;
+        Cn.d_offsets = (const uint64_t *)d.offsets.p;
+        Cn.d_out = d_out;
+        Cn.cap = cap;
+        Cn.record_kind = record_kind;
+        Cn.d_exit = F.d_exit;
+        Cn.len_units = (uint32_t)sh->n_units;
+        Cn.d_bits = F.d_bits;
+        Cn.d_ebits = F.d_ebits;
+        HIP_TRY(launch_exclusive_scan(Cn.d_counts, Cn.n_tiles, (uint64_t *)d.offsets.p, (uint64_t *)d.scan_tmp.p, stream));
+        HIP_TRY(launch_longest_emit(Cn, F.d_sync, stream));
+        if (timed) HIP_TRY(hipEventRecord(ev[2], stream));
+        unsigned long long *h_slot = tk ? tk->h_count : d.h_counter, *d_slot = nullptr;
+        HIP_TRY(hipHostGetDevicePointer((void **)&d_slot, h_slot, 0));
+        HIP_TRY(launch_publish_result((const unsigned long long *)d.scan_tmp.p + scan_tiles_for(Cn.n_tiles), (const unsigned long long *)d.counter.p,
+                                      d_slot, tk ? reinterpret_cast<acgpu_device_result *>(sh->d_result) : nullptr, stream));
+        if (tk) {
+            tk->stream = stream;
+            tk->shard = *sh;
+            tk->record_kind = record_kind;
+            tk->d_out = d_out;
+            HIP_TRY(hipEventRecord(tk->done, stream));
+            tk->scanned = own_len;
+            std::snprintf(tk->kname, sizeof(tk->kname), "k_longest_follow");
+            return ACGPU_OK;
+        }
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (d.h_counter[1] != 0) // (a chain that did not merge inside the run-up)
+            return match_longest(a, d, sh, record_kind, d_out, cap, n_out, stream, prof, nullptr, bits_level + 1);
+        *n_out = d.h_counter[0];
+        sh->chain_exit = (int64_t)d.h_counter[2];
+        if (prof) {
+            HIP_TRY(hipEventElapsedTime(&prof->scan_ms, d.ev[0], d.ev[1]));
+            HIP_TRY(hipEventElapsedTime(&prof->finalize_ms, d.ev[1], d.ev[2]));
+            HIP_TRY(hipEventElapsedTime(&prof->total_ms, d.ev[0], d.ev[2]));
+            prof->scan_units = own_len;
+            prof->n_matches = *n_out;
+            std::snprintf(prof->scan_kernel, sizeof(prof->scan_kernel), "k_longest_follow");
+        }
+        return *n_out > cap ? ACGPU_E_OVERFLOW : ACGPU_OK;
+    }
     LongestScanLaunch S{};
     S.block = 1024;
     // two workgroups per CU share the LDS (hot trie rows: at most 72 KB each); a short haystack gets fewer (every

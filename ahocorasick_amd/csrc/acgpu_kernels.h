@@ -248,6 +248,27 @@ size_t longest_bits_region_scratch_bytes(); // d_marks + d_xout, per region
 hipError_t launch_longest_bits(const DevTables &t, const LongestBitsLaunch &l, unsigned long long *h_slot_dev, acgpu_device_result *d_result,
                                unsigned long long *d_state, uint32_t state_words, hipStream_t stream, hipEvent_t ev_start = nullptr,
                                hipEvent_t ev_mid = nullptr, hipEvent_t ev_stop = nullptr); // (profiled calls: the dispatches' own timestamps)
+// k_longest_follow (acgpu_longest_follow.hip): any dense dictionary with range classes or small class pages; Set and Map records;
+// fills what k_longest_emit_ends reads (both bitmaps, per tile the first chain position and the count, the node per match start)
+struct LongestFollowLaunch {
+    const uint16_t *d_hay;
+    uint32_t n_units, own_end, entry;
+    uint32_t g0;          // entry & ~31: first position of segment 0 of region 0
+    uint32_t n_regions;   // regions of longest_follow_region_units() positions from g0 on, up to own_end
+    uint32_t runup;       // pass 1 follows a chain through this many positions in front of a segment (at most a segment)
+    uint32_t tile_log2;   // segments per tile of d_sync / d_counts (log2)
+    uint32_t hot_rows;    // leading rows of the table kept in LDS
+    uint32_t *d_bits, *d_ebits;  // bit p: a match starts at p / ends at p + 1; d_ebits zeroed by the caller (ends are merged with atomicOr)
+    uint32_t *d_state;           // Map records: the trie node of the match that starts at p, or nullptr
+    uint32_t *d_sync, *d_counts; // per tile: the chain's first position in it (~0u: none), its matches
+    unsigned long long *d_exit;  // [0]: the chain's first position at or behind own_end, [1]: bail flag (zeroed by the caller)
+    uint32_t *d_pred, *d_true;   // per region: the entry it assumed, the exit it found
+    int grid;
+};
+uint32_t longest_follow_region_units();
+uint32_t longest_follow_seg_units();
+uint32_t longest_follow_hot_rows(uint32_t n_cls, uint32_t n_states, uint32_t page_bytes); // 0: does not fit
+hipError_t launch_longest_follow(const DevTables &t, const LongestFollowLaunch &l, bool range, bool state, hipStream_t stream);
 hipError_t launch_longest_sync(const LongestChainLaunch &l, uint32_t *d_sync, hipStream_t stream);
 hipError_t launch_longest_chain(const LongestChainLaunch &l, const uint32_t *d_sync, bool write_pass, hipStream_t stream);
 // count / write pass with the lengths staged through LDS in chunks (16-bit lengths)
