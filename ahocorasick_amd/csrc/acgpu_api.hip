@@ -804,9 +804,10 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
     // its own result (every segment's exit against the next one's entry) and raises the bail flag -- also for a unit outside
     // the alphabet --: the call is then redone right here, or in acgpu_match_device_end: once more with a run-up of a whole
     // segment (bits_level 1), then by the walk pipeline below (bits_level 2).
-    // Tunable tile_debug bit 33554432: never; bit 67108864: also for short texts (tests).
-    const bool bits_form = bits_level < 2 && record_kind == ACGPU_REC_SET && d.T.bits_rk != 0 && !(tunables().tile_debug & 33554432) &&
-                           (own_len >= (1ull << 21) || (tunables().tile_debug & 67108864)) && tunables().force_kernel == 0;
+    // Tunable longest_form, bits: 1 = never, 4 = also for short texts (tests).
+    const int64_t lform = tunables().longest_form;
+    const bool bits_form = bits_level < 2 && record_kind == ACGPU_REC_SET && d.T.bits_rk != 0 && !(lform & 1) &&
+                           (own_len >= (1ull << 21) || (lform & 4)) && tunables().force_kernel == 0;
     if (bits_form) {
         int rc;
         LongestBitsLaunch Bl{};
@@ -858,6 +859,7 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
             tk->shard = *sh;
             tk->record_kind = record_kind;
             tk->d_out = d_out;
+            tk->bits_level = bits_level;
             tk->done_is_ev2 = timed; // (the finish kernel's own end)
             if (!timed) HIP_TRY(hipEventRecord(tk->done, stream));
             tk->scanned = own_len;
@@ -889,13 +891,12 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
     // Any other dense dictionary with range classes or small class pages, long texts, Set and Map records: the walks of the chain's own
     // positions only (k_longest_follow, acgpu_longest_follow.hip) in place of the length array, the synchronisation points and the chain
     // pass; the bitmaps, counts and first positions it leaves are what the prefix sum and k_longest_emit_ends below read.  It checks its
-    // own result like k_longest_bits and is redone the same way.  Tunable tile_debug bit 268435456 << 1 (536870912): never; bit
-    // 1073741824: also for short texts (tests).
+    // own result like k_longest_bits and is redone the same way.  Tunable longest_form, bits: 2 = never, 4 = also for short texts.
     const size_t fol_pages = (!t.range_cls && !t.dfa_pages.empty()) ? t.dfa_pages.size() * 2 : 0;
     const bool fol_classes = t.dense && ((t.range_cls && t.n_cls == t.cls_span + 1) || fol_pages > 0);
     const uint32_t fol_hot = fol_classes ? longest_follow_hot_rows(t.n_cls, t.n_states, (uint32_t)fol_pages) : 0;
-    const bool follow_form = bits_level < 2 && fol_hot > 0 && !(tunables().tile_debug & 536870912) &&
-                             (own_len >= (1ull << 20) || (tunables().tile_debug & 1073741824)) && tunables().force_kernel == 0;
+    if (bits_level < d.fol_level && !bits_form) bits_level = d.fol_level; // (what earlier calls on this pool have learnt about its texts)
+    const bool follow_form = bits_level < 2 && fol_hot > 0 && !(lform & 2) && (own_len >= (1ull << 20) || (lform & 4)) && tunables().force_kernel == 0;
     if (follow_form) {
         int rc;
         LongestFollowLaunch F{};
@@ -904,10 +905,22 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
         F.own_end = (uint32_t)sh->own_end;
         F.entry = (uint32_t)entry;
         F.g0 = (uint32_t)entry & ~31u;
-        const uint32_t region_units = longest_follow_region_units(), seg_units = longest_follow_seg_units();
+        // a lane walks a segment of 1024 positions behind a run-up.  (Segments of 512 for texts that leave half the chip's lanes
+        // without one were measured: 4.95 against 3.30 ms per 2^28 units of the README word list -- the kernel is bound by the
+        // number of gathers, and a run-up of a whole segment is a third more of them.)  Tunable region_units (64 .. 1024): the first
+        // try's run-up, for A/B.
+        const uint32_t seg_units = longest_follow_seg_units();
+        F.seg_log2 = 10;
+        const uint32_t region_units = 64 * seg_units;
         F.n_regions = (uint32_t)((sh->own_end - F.g0 + region_units - 1) / region_units);
-        F.runup = bits_level == 0 ? seg_units / 2 : seg_units;
-        F.tile_log2 = 2;
+        // The first try's run-up is 128 positions: on a text with separators every chain lands on each of them (no keyword goes
+        // across), so chains merge within a word, and the run-up is a fifth of the gathers at 512 (measured on the README word
+        // list: 3.27 ms per 2^28 units at 512, 2.85 at 256, 2.65 at 128).  A text on which that fails -- the kernel notices --
+        // is redone with a whole segment, and this pool remembers it (d.fol_level): the next call starts there, or, if chains
+        // do not merge within 1024 positions either, with the walk pipeline.
+        const int64_t ru = tunables().region_units;
+        F.runup = bits_level == 0 ? (ru >= 64 && ru <= 1024 ? (uint32_t)ru : 128u) : seg_units;
+        F.tile_log2 = 2; // (emit tiles of 4096 positions)
         F.hot_rows = fol_hot;
         const uint32_t n_tiles = (F.n_regions * (region_units / seg_units)) >> F.tile_log2;
         if ((rc = d.counter.ensure(64))) return rc;
@@ -971,14 +984,17 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
             tk->shard = *sh;
             tk->record_kind = record_kind;
             tk->d_out = d_out;
+            tk->bits_level = bits_level;
             HIP_TRY(hipEventRecord(tk->done, stream));
             tk->scanned = own_len;
             std::snprintf(tk->kname, sizeof(tk->kname), "k_longest_follow");
             return ACGPU_OK;
         }
         HIP_TRY(hipStreamSynchronize(stream));
-        if (d.h_counter[1] != 0) // (a chain that did not merge inside the run-up)
+        if (d.h_counter[1] != 0) { // (a chain that did not merge inside the run-up)
+            d.fol_level = std::max(d.fol_level, bits_level + 1);
             return match_longest(a, d, sh, record_kind, d_out, cap, n_out, stream, prof, nullptr, bits_level + 1);
+        }
         *n_out = d.h_counter[0];
         sh->chain_exit = (int64_t)d.h_counter[2];
         if (prof) {
@@ -1540,6 +1556,7 @@ int64_t acgpu_set_tunable(const char *name, int64_t value) {
     else if (!std::strcmp(name, "no_short_keywords")) slot = &t.no_short_keywords;
     else if (!std::strcmp(name, "reserve_cus")) slot = &t.reserve_cus;
     else if (!std::strcmp(name, "no_bits_trie")) slot = &t.no_bits_trie;
+    else if (!std::strcmp(name, "longest_form")) slot = &t.longest_form;
     else if (!std::strcmp(name, "multi_min_share")) slot = &t.multi_min_share;
     else if (!std::strcmp(name, "no_big_l2")) slot = &t.no_big_l2;
     else if (!std::strcmp(name, "no_class_pages")) slot = &t.no_class_pages;
@@ -1735,8 +1752,10 @@ int end_ticket(const acgpu_automaton *ca, acgpu_ticket *ticket, uint64_t *n_out,
         if (redone) *redone = true;
         return rc;
     }
-    if (tk->kind == 1 && tk->h_count[1] != 0) { // k_longest_bits bailed out (a unit outside the alphabet, a chain that did not merge): the walk pipeline
-        const int rc = match_longest(a, *d, &tk->shard, tk->record_kind, tk->d_out, tk->cap, n_out, tk->stream, prof, nullptr, tk->h_count[1] == 1 ? 1 : 2);
+    if (tk->kind == 1 && tk->h_count[1] != 0) { // k_longest_bits / k_longest_follow bailed out (a unit outside the alphabet, a chain that did not merge)
+        if (!std::strcmp(tk->kname, "k_longest_follow")) d->fol_level = std::max(d->fol_level, tk->bits_level + 1);
+        const int rc = match_longest(a, *d, &tk->shard, tk->record_kind, tk->d_out, tk->cap, n_out, tk->stream, prof, nullptr,
+                                     tk->h_count[1] == 1 ? tk->bits_level + 1 : 2);
         if (tk->user_shard) tk->user_shard->chain_exit = tk->shard.chain_exit;
         tk->busy = false;
         d->inflight--;

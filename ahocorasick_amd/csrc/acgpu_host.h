@@ -69,6 +69,7 @@ struct Ticket {
     int record_kind = 0;
     void *d_out = nullptr;
     hipStream_t stream = nullptr;
+    int bits_level = 0; // LONGEST, k_longest_bits / k_longest_follow: the run-up level the call was enqueued with (0: short, 1: a whole segment)
 };
 
 struct DeviceState {
@@ -108,6 +109,7 @@ struct DeviceState {
     DevBuf lenbig, todo;                                 // LONGEST: escaped lengths; root-table form: flagged chunks
     DevBuf chainbits;                                    // LONGEST: one bit per position, set where the chain reports a match
     DevBuf bits_state;                                   // k_longest_bits: exit / flag / count, look-back words, region counter -- zero between calls
+    int fol_level = 0;                                   // k_longest_follow: 0 = run-up of 128 positions, 1 = of a whole segment (a call's chains had not merged), 2 = not for this pool's texts
     void *bits_state_seen = nullptr;                     // (a re-allocated buffer, or a call that failed half way, is zeroed by a memset)
     DevBuf cands, region_cands;                          // ALL, split form: candidate positions, {first, count} per region
     DevBuf wwl_rs, wwl_mend, wwl_mid, wwl_sel, wwl_stop, wwl_nxt0; // WWLONGEST: walk starts, what each would report, where it stops

@@ -308,6 +308,7 @@ struct Tunables {
     std::atomic<int64_t> no_class_pages{0};   // builder: 1 = the tile kernel's LUT forms look classes up in global memory (A/B)
     std::atomic<int64_t> no_big_l2{0};        // builder: 1 = large dictionaries keep the (saturated) second level in LDS (A/B)
     std::atomic<int64_t> multi_min_share{1ll << 22}; // acgpu_match_u16_multi: a share is at least this many units (tests: 1024)
+    std::atomic<int64_t> longest_form{0};     // LONGEST, bits: 1 = never k_longest_bits, 2 = never k_longest_follow, 4 = both also for short texts (tests, A/B)
     std::atomic<int64_t> no_bits_trie{0};     // builder: 1 = no path-compressed trie for k_longest_bits (the walk pipeline instead: A/B)
     std::atomic<int64_t> reserve_cus{0};      // CUs left without a scan workgroup (room for a collective's kernels under the scan)
 };

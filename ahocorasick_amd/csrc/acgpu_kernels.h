@@ -254,7 +254,8 @@ struct LongestFollowLaunch {
     const uint16_t *d_hay;
     uint32_t n_units, own_end, entry;
     uint32_t g0;          // entry & ~31: first position of segment 0 of region 0
-    uint32_t n_regions;   // regions of longest_follow_region_units() positions from g0 on, up to own_end
+    uint32_t seg_log2;    // a lane's segment: 2^seg_log2 positions (10; 9 for texts that would leave half the chip's lanes without one)
+    uint32_t n_regions;   // regions of 64 segments from g0 on, up to own_end
     uint32_t runup;       // pass 1 follows a chain through this many positions in front of a segment (at most a segment)
     uint32_t tile_log2;   // segments per tile of d_sync / d_counts (log2)
     uint32_t hot_rows;    // leading rows of the table kept in LDS
@@ -265,8 +266,8 @@ struct LongestFollowLaunch {
     uint32_t *d_pred, *d_true;   // per region: the entry it assumed, the exit it found
     int grid;
 };
-uint32_t longest_follow_region_units();
-uint32_t longest_follow_seg_units();
+uint32_t longest_follow_seg_units();   // the default segment (1024)
+uint32_t longest_follow_lanes_per_cu();
 uint32_t longest_follow_hot_rows(uint32_t n_cls, uint32_t n_states, uint32_t page_bytes); // 0: does not fit
 hipError_t launch_longest_follow(const DevTables &t, const LongestFollowLaunch &l, bool range, bool state, hipStream_t stream);
 hipError_t launch_longest_sync(const LongestChainLaunch &l, uint32_t *d_sync, hipStream_t stream);

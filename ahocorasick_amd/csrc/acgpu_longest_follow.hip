@@ -28,8 +28,7 @@
 namespace acgpu {
 
 constexpr int kFolBlock = 1024;                 // 16 waves; two workgroups per CU
-constexpr uint32_t kFolSegUnits = 1024;         // a lane's segment
-constexpr uint32_t kFolRegionUnits = 64 * kFolSegUnits;
+constexpr uint32_t kFolSegUnits = 1024;         // a lane's segment (LongestFollowLaunch::seg_log2 = 10; 9 for texts that would not fill the chip)
 constexpr uint32_t kFolRingWords = 4 * 64 * 4;  // per wave: [4 blocks][64 lanes] of 16 bytes
 constexpr uint32_t kFolRowBytesMax = 76 * 1024 - (kFolBlock / kWave) * kFolRingWords * 4; // LDS left for rows and pages: 12 KiB
 
@@ -68,6 +67,7 @@ __device__ __forceinline__ uint32_t fol_walk(const DevTables &T, const LongestFo
             }
         }
         const bool can_step = active && (xb < have_end || x >= nu);
+        bool keep = true; // the block that is on its way goes into the ring
         uint32_t e = 0;
         if (can_step && x < nu) {
             const uint32_t u = reinterpret_cast<const uint16_t *>(ring + (xb & 3u) * 64u + lane)[x & 7u];
@@ -112,6 +112,7 @@ __device__ __forceinline__ uint32_t fol_walk(const DevTables &T, const LongestFo
                 // the ring holds blocks [have_end - 4, have_end): a walk of more than 24 units has pushed the chain's next
                 // position out of it, a match of many units has jumped beyond it -- the blocks are asked for again from there
                 if ((p >> 3) + 4u < have_end || (p >> 3) > have_end) have_end = p >> 3;
+                else if ((p >> 3) + 4u == have_end) keep = false; // (it would take the slot of the block the chain goes on in)
                 active = p < plim;
             } else {
                 node = e & 0x7fffffffu;
@@ -122,7 +123,7 @@ __device__ __forceinline__ uint32_t fol_walk(const DevTables &T, const LongestFo
                 }
             }
         }
-        if (want_load && have_end == load_b) { // (behind the gather's wait: the block has arrived with it; not if the ring has just started over)
+        if (want_load && keep && have_end == load_b) { // (behind the gather's wait: the block has arrived with it; not if the ring has just started over)
             ring[(load_b & 3u) * 64u + lane] = blk;
             have_end = load_b + 1u;
         }
@@ -151,13 +152,14 @@ __global__ __launch_bounds__(kFolBlock, 8) void k_longest_follow(DevTables T, Lo
     uint4 *ring = reinterpret_cast<uint4 *>(smem + ((row_words + page_words + 3u) & ~3u)) + wave * (kFolRingWords / 4u);
     const uint32_t waves_total = gridDim.x * (kFolBlock / kWave);
     for (uint32_t r = blockIdx.x * (kFolBlock / kWave) + wave; r < L.n_regions; r += waves_total) {
-        const uint32_t start = L.g0 + (r * 64u + lane) * kFolSegUnits;
+        const uint32_t seg_units = 1u << L.seg_log2;
+        const uint32_t start = L.g0 + (r * 64u + lane) * seg_units;
         // ---- pass 1: where the chain enters the lane's segment ----
         uint32_t e_in, none = 0;
         if (r == 0 && lane == 0) {
             e_in = L.entry;
         } else {
-            const uint32_t ps = start - kFolSegUnits;
+            const uint32_t ps = start - seg_units;
             uint32_t p0 = max(ps, L.entry);
             const uint32_t lim = min(start, L.own_end);
             if (lim > L.runup) p0 = max(p0, lim - L.runup);
@@ -165,14 +167,14 @@ __global__ __launch_bounds__(kFolBlock, 8) void k_longest_follow(DevTables T, Lo
         }
         __builtin_amdgcn_wave_barrier();
         // ---- pass 2: the lane's own segment from there ----
-        const uint32_t bound = min(start + kFolSegUnits, L.own_end);
+        const uint32_t bound = min(start + seg_units, L.own_end);
         uint32_t cnt = 0;
         // the lane's words of the start bitmap: [first, end) -- all of them are written (zeros where the chain marks nothing)
         const uint32_t w_first = start >> 5, w_end = start < L.own_end ? ((bound - 1u) >> 5) + 1u : w_first;
         // (an entry at or beyond the bound -- the chain jumps over the segment, or the segment lies behind the owned range: no step)
         const uint32_t exit_pos = fol_walk<RANGE, STATE, true>(T, L, rows, pages, ring, lane, e_in, bound, w_first, w_end, cnt);
         const uint32_t e_next = __shfl_down(e_in, 1);
-        const bool differs = lane < 63u && (uint64_t)start + kFolSegUnits < L.own_end && exit_pos != e_next;
+        const bool differs = lane < 63u && (uint64_t)start + seg_units < L.own_end && exit_pos != e_next;
         if (__any(differs) && lane == 0) L.d_exit[1] = 1ull;
         if (lane == 0) L.d_pred[r] = e_in;
         if (lane == 63) L.d_true[r] = exit_pos;
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(kFolBlock, 8) void k_longest_follow(DevTables T, Lo
             for (uint32_t dd = 1; dd < ts; dd <<= 1) csum += __shfl_down(csum, dd);
             if ((lane & (ts - 1u)) == 0) {
                 const uint32_t tile = (r * 64u + lane) >> L.tile_log2;
-                const uint32_t tend = (uint32_t)min((uint64_t)L.own_end, (uint64_t)start + (uint64_t)ts * kFolSegUnits);
+                const uint32_t tend = (uint32_t)min((uint64_t)L.own_end, (uint64_t)start + (uint64_t)ts * seg_units);
                 L.d_sync[tile] = e_in < tend ? e_in : ~0u;
                 L.d_counts[tile] = csum;
             }
@@ -199,8 +201,8 @@ __global__ __launch_bounds__(256) void k_longest_follow_check(LongestFollowLaunc
     if (L.d_pred[r] != L.d_true[r - 1]) L.d_exit[1] = 1ull;
 }
 
-uint32_t longest_follow_region_units() { return kFolRegionUnits; }
 uint32_t longest_follow_seg_units() { return kFolSegUnits; }
+uint32_t longest_follow_lanes_per_cu() { return 2u * kFolBlock; }
 // rows of the table the kernel can keep in LDS next to `page_bytes` of class pages (0: range classes)
 uint32_t longest_follow_hot_rows(uint32_t n_cls, uint32_t n_states, uint32_t page_bytes) {
     if (!n_cls || page_bytes + 16u > kFolRowBytesMax) return 0u;

@@ -32,7 +32,7 @@ ALPHABETS = [
     [ord(c) for c in "abcdefikABCDEFIK 0129-"] + [0x0130, 0x212A],                           # phrases: merged stretches, fold exceptions
 ]
 DEFAULTS = {"chunk_units": 0, "lds_table_bytes": 127 * 1024, "force_sparse": 0, "force_kernel": 0, "region_units": 0,
-            "rdense_budget_bytes": 256 << 20, "tile_debug": 0}
+            "rdense_budget_bytes": 256 << 20, "tile_debug": 0, "longest_form": 0}
 
 
 def dev_match(a, d_hay, n, cap, with_ids=True, **kw):
@@ -92,7 +92,7 @@ def one_case(rng, it):
     if rng.integers(0, 2):
         knobs["tile_debug"] |= 1 << 41  # short haystacks through the general path instead of the one-launch form
     if fam == 1 and rng.integers(0, 2):
-        knobs["tile_debug"] |= 67108864  # k_longest_bits (two-letter alphabets, every letter a keyword) for short texts too
+        knobs["longest_form"] = int(rng.choice([4, 4, 5, 6]))  # k_longest_bits / k_longest_follow for short texts too (5, 6: one of them never)
     for k, v in knobs.items():
         N.set_tunable(k, v)
     mode = [N.MODE_ALL, N.MODE_LONGEST, N.MODE_WHOLEWORD, N.MODE_SHORTEST, N.MODE_WWLONGEST][fam]

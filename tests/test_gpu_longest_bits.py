@@ -11,15 +11,15 @@ from oracle.oracle import FAM_LONGEST, Oracle
 
 pytestmark = pytest.mark.gpu
 
-BITS_ALWAYS = 67108864  # tile_debug: k_longest_bits for short texts too
-BITS_NEVER = 33554432   # tile_debug: the walk pipeline
+BITS_ALWAYS = 4  # longest_form: k_longest_bits (and k_longest_follow) for short texts too
+BITS_NEVER = 1   # longest_form: never k_longest_bits
 A_, B_ = ord("a"), ord("b")
 
 
 @pytest.fixture(autouse=True)
 def _reset_tunables():
     yield
-    for k, v in [("force_kernel", 0), ("region_units", 0), ("tile_debug", 0), ("no_bits_trie", 0)]:
+    for k, v in [("force_kernel", 0), ("region_units", 0), ("tile_debug", 0), ("no_bits_trie", 0), ("longest_form", 0)]:
         N.set_tunable(k, v)
 
 
@@ -50,7 +50,7 @@ def test_bits_form_is_what_config_c4_shapes_take_and_equals_the_oracle_at_every_
     kws = _c4_like()
     a = Automaton(N.MODE_LONGEST, kws, True)
     orc = Oracle(FAM_LONGEST, kws)
-    N.set_tunable("tile_debug", BITS_ALWAYS)
+    N.set_tunable("longest_form", BITS_ALWAYS)
     whole = synth.haystack(2004, (1 << 21) + 77, table=synth.ALPHA_AB_75)
     for n in (1, 2, 31, 32, 33, 63, 64, 65, 1023, 1024, 1025, 2047, 2048, 2049, 65535, 65536, 65537, 65536 + 1024 + 33, 200001,
               3 * 65536, (1 << 21) + 77):
@@ -61,12 +61,12 @@ def test_bits_form_is_what_config_c4_shapes_take_and_equals_the_oracle_at_every_
         assert got.shape == want.shape and (got == want).all(), n
         assert ex >= n
     # without the switch: long texts take it by themselves, short ones the walk pipeline -- same records
-    N.set_tunable("tile_debug", 0)
+    N.set_tunable("longest_form", 0)
     got, kname, _ = _run(a, whole)
     assert kname == "k_longest_bits" and (got == orc.match(whole)[:, :2]).all()
     got, kname, _ = _run(a, whole[:70000])
     assert kname != "k_longest_bits" and (got == orc.match(whole[:70000])[:, :2]).all()
-    N.set_tunable("tile_debug", BITS_NEVER)
+    N.set_tunable("longest_form", BITS_NEVER)
     got, kname, _ = _run(a, whole)
     assert kname != "k_longest_bits" and (got == orc.match(whole)[:, :2]).all()
 
@@ -90,13 +90,13 @@ def test_bits_form_general_dictionaries_terminals_branches_and_long_paths(seed):
     for at in rng.integers(0, n - 1000, 40).tolist():  # runs of 'a' of every length up to the longest keyword and beyond
         hay[at:at + int(rng.integers(1, 450))] = A_
     a = Automaton(N.MODE_LONGEST, kws, True)
-    N.set_tunable("tile_debug", BITS_ALWAYS)
+    N.set_tunable("longest_form", BITS_ALWAYS)
     got, kname, _ = _run(a, hay)
     want = Oracle(FAM_LONGEST, kws).match(hay)[:, :2]
     assert kname == "k_longest_bits"
     assert got.shape == want.shape and (got == want).all()
     assert int((want[:, 1] - want[:, 0]).max()) > 100
-    N.set_tunable("tile_debug", BITS_NEVER)
+    N.set_tunable("longest_form", BITS_NEVER)
     old, kname, _ = _run(a, hay)
     assert kname != "k_longest_bits" and (old == want).all()
 
@@ -108,7 +108,7 @@ def test_bits_form_shards_chain_through_entry_and_exit_at_any_position():
     a = Automaton(N.MODE_LONGEST, kws, True)
     want = Oracle(FAM_LONGEST, kws).match(hay)[:, :2]
     d_hay = torch.from_numpy(hay.view(np.int16)).cuda()
-    N.set_tunable("tile_debug", BITS_ALWAYS)
+    N.set_tunable("longest_form", BITS_ALWAYS)
     for cuts in ([0, 65536, 131072, hay.size], [0, 70001, 70002, 70040, 333333, 600000 + 31, hay.size], [0, 1, 2, 33, hay.size]):
         parts, entry = [], 0
         for lo, hi in zip(cuts[:-1], cuts[1:]):
@@ -126,7 +126,7 @@ def test_bits_form_end_of_the_buffer_and_keywords_cut_off_by_it():
     kws = [utf16("a"), utf16("b"), np.full(50, A_, np.uint16), utf16("ab" * 30), utf16("ba" * 25 + "b")] + [np.full(k, A_, np.uint16) for k in range(2, 12)]
     a = Automaton(N.MODE_LONGEST, kws, True)
     orc = Oracle(FAM_LONGEST, kws)
-    N.set_tunable("tile_debug", BITS_ALWAYS)
+    N.set_tunable("longest_form", BITS_ALWAYS)
     rng = np.random.default_rng(5)
     for n in (40, 49, 50, 51, 1024 + 49, 65536 + 45, 65536 * 2 - 3, 65536 * 2 + 50):
         for tail in ("a" * 49, "ab" * 29 + "a", "ba" * 25, "b"):
@@ -151,7 +151,7 @@ def test_bits_form_bails_out_on_units_outside_the_alphabet_and_the_walk_pipeline
         hay[at] = oa[rng.integers(0, len(oa))]
     a = Automaton(N.MODE_LONGEST, kws, True)
     want = Oracle(FAM_LONGEST, kws).match(hay)[:, :2]
-    N.set_tunable("tile_debug", BITS_ALWAYS)
+    N.set_tunable("longest_form", BITS_ALWAYS)
     got, kname, ex = _run(a, hay)
     assert kname != "k_longest_bits"  # (the profile names the kernel that produced the records)
     assert got.shape == want.shape and (got == want).all() and ex >= n
@@ -174,7 +174,7 @@ def test_bits_form_enqueued_calls_tickets_and_the_device_result():
     kws = _c4_like(2500, 150)
     a = Automaton(N.MODE_LONGEST, kws, True)
     orc = Oracle(FAM_LONGEST, kws)
-    N.set_tunable("tile_debug", BITS_ALWAYS)
+    N.set_tunable("longest_form", BITS_ALWAYS)
     st = torch.cuda.current_stream().cuda_stream
     hays = [synth.haystack(300 + i, 250000 + 4097 * i, table=synth.ALPHA_AB_75) for i in range(3)]
     d_hays = [torch.from_numpy(h.view(np.int16)).cuda() for h in hays]
@@ -208,7 +208,7 @@ def test_bits_form_chains_that_never_merge_and_one_letter_alphabets():
     A dictionary over ONE letter never takes the bit form."""
     kws = [utf16("a"), utf16("b"), np.full(333, A_, np.uint16)]
     a = Automaton(N.MODE_LONGEST, kws, True)
-    N.set_tunable("tile_debug", BITS_ALWAYS)
+    N.set_tunable("longest_form", BITS_ALWAYS)
     hay = np.full(300000, A_, np.uint16)
     got, kname, _ = _run(a, hay)
     want = Oracle(FAM_LONGEST, kws).match(hay)[:, :2]

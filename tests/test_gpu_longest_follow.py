@@ -12,14 +12,14 @@ from tests.helpers import LOWER
 
 pytestmark = pytest.mark.gpu
 
-FOLLOW_ALWAYS = 1073741824  # tile_debug: k_longest_follow for short texts too
-FOLLOW_NEVER = 536870912    # tile_debug: the walk pipeline
+FOLLOW_ALWAYS = 4  # longest_form: k_longest_follow (and k_longest_bits) for short texts too
+FOLLOW_NEVER = 3    # longest_form: neither k_longest_follow nor k_longest_bits: the walk pipeline
 
 
 @pytest.fixture(autouse=True)
 def _reset_tunables():
     yield
-    for k, v in [("force_kernel", 0), ("region_units", 0), ("tile_debug", 0)]:
+    for k, v in [("force_kernel", 0), ("region_units", 0), ("tile_debug", 0), ("longest_form", 0)]:
         N.set_tunable(k, v)
 
 
@@ -51,7 +51,7 @@ def test_follow_form_on_a_word_list_equals_the_oracle_at_every_size_set_and_map(
     orc = Oracle(FAM_LONGEST, words)
     whole = synth.readme_text(4, (1 << 20) + 4099, words)
     assert a.info()["tile_kernel"] == 0  # (the single letters are words: no selective filter -- the walk family)
-    N.set_tunable("tile_debug", FOLLOW_ALWAYS)
+    N.set_tunable("longest_form", FOLLOW_ALWAYS)
     for n in (1, 2, 7, 8, 9, 31, 33, 1023, 1024, 1025, 4097, 65535, 65536, 65537, 200003, (1 << 20) + 4099):
         hay = whole[:n]
         want = orc.match(hay)
@@ -62,12 +62,12 @@ def test_follow_form_on_a_word_list_equals_the_oracle_at_every_size_set_and_map(
             assert got.shape == w.shape and (got == w).all(), (n, with_ids)
             assert ex >= n
     # long texts take it without the switch, short ones the walk pipeline -- same records
-    N.set_tunable("tile_debug", 0)
+    N.set_tunable("longest_form", 0)
     got, kname, _ = _run(a, whole, True)
     assert kname == "k_longest_follow" and (got == orc.match(whole)).all()
     got, kname, _ = _run(a, whole[:70000], True)
     assert kname != "k_longest_follow" and (got == orc.match(whole[:70000])).all()
-    N.set_tunable("tile_debug", FOLLOW_NEVER)
+    N.set_tunable("longest_form", FOLLOW_NEVER)
     got, kname, _ = _run(a, whole, True)
     assert kname != "k_longest_follow" and (got == orc.match(whole)).all()
 
@@ -79,7 +79,7 @@ def test_follow_form_case_insensitive_dictionary_classes_from_lds_pages(words):
     rng = np.random.default_rng(3)
     flip = rng.random(hay.size) < 0.2  # upper-case letters all over the text
     hay[flip & (hay >= 97) & (hay <= 122)] -= 32
-    N.set_tunable("tile_debug", FOLLOW_ALWAYS)
+    N.set_tunable("longest_form", FOLLOW_ALWAYS)
     got, kname, _ = _run(a, hay, True)
     want = orc.match(hay)
     assert kname == "k_longest_follow" and got.shape == want.shape and (got == want).all()
@@ -103,13 +103,13 @@ def test_follow_form_deep_walks_long_matches_and_texts_without_separators(seed):
     hay[n - len(tail) + 3:] = tail[: len(tail) - 3]  # a long keyword cut off by the end of the buffer
     a = Automaton(N.MODE_LONGEST, kws, True)
     want = Oracle(FAM_LONGEST, kws).match(hay)
-    N.set_tunable("tile_debug", FOLLOW_ALWAYS)
+    N.set_tunable("longest_form", FOLLOW_ALWAYS)
     for with_ids in (False, True):
         got, kname, _ = _run(a, hay, with_ids)
         w = want if with_ids else want[:, :2]
         assert kname == "k_longest_follow" and got.shape == w.shape and (got == w).all()
     assert int((want[:, 1] - want[:, 0]).max()) > 64
-    N.set_tunable("tile_debug", FOLLOW_NEVER)
+    N.set_tunable("longest_form", FOLLOW_NEVER)
     old, kname, _ = _run(a, hay, True)
     assert kname != "k_longest_follow" and (old == want).all()
 
@@ -120,7 +120,7 @@ def test_follow_form_shards_chains_that_never_merge_and_tickets(words):
     hay = synth.readme_text(5, 400001, words)
     want = Oracle(FAM_LONGEST, words).match(hay)
     d_hay = torch.from_numpy(hay.view(np.int16)).cuda()
-    N.set_tunable("tile_debug", FOLLOW_ALWAYS)
+    N.set_tunable("longest_form", FOLLOW_ALWAYS)
     for cuts in ([0, 65536, 131072, hay.size], [0, 70001, 70002, 70040, 333333, hay.size], [0, 1, 2, 33, hay.size]):
         parts, entry = [], 0
         for lo, hi in zip(cuts[:-1], cuts[1:]):
@@ -147,11 +147,28 @@ def test_follow_form_shards_chains_that_never_merge_and_tickets(words):
     # kernel has to notice (every step is 3, a chain keeps its residue), and the walk pipeline answers
     kw2 = [utf16("c"), np.full(3, ord("c"), np.uint16), utf16("d")]
     a2 = Automaton(N.MODE_LONGEST, kw2, True)
+    N.set_tunable("longest_form", FOLLOW_ALWAYS | 1)  # (every letter a keyword: k_longest_bits would take this one first)
     run = np.full(300000, ord("c"), np.uint16)
     got, kname, _ = _run(a2, run, False)
     want2 = Oracle(FAM_LONGEST, kw2).match(run)[:, :2]
     assert kname != "k_longest_follow" and got.shape == want2.shape and (got == want2).all()
+    # ... and the pool remembers: its next call does not try again (a fresh automaton does)
+    got, kname, _ = _run(a2, run[:200000], False)
+    assert kname != "k_longest_follow" and (got == Oracle(FAM_LONGEST, kw2).match(run[:200000])[:, :2]).all()
     run[::1000] = ord("d")
-    got, kname, _ = _run(a2, run, False)
+    a3 = Automaton(N.MODE_LONGEST, kw2, True)
+    got, kname, _ = _run(a3, run, False)
     want2 = Oracle(FAM_LONGEST, kw2).match(run)[:, :2]
     assert kname == "k_longest_follow" and got.shape == want2.shape and (got == want2).all()
+
+
+def test_follow_form_two_letter_text_walks_that_run_three_blocks_ahead_of_their_start():
+    """Over {a, b} with keywords of up to 40 units most walks are deep: one that ends with the block three ahead of its start on
+    its way used to take the ring slot of the block the chain goes on in (the next walk read the wrong text)."""
+    kws = synth.random_keywords(32, 300, 2, 40, table=synth.ALPHA_LOWER[:2])
+    n = (1 << 21) + 12345
+    hay = synth.haystack(403, n, table=synth.ALPHA_LOWER[:2])
+    a = Automaton(N.MODE_LONGEST, kws, True)
+    want = Oracle(FAM_LONGEST, kws).match(hay)
+    got, kname, _ = _run(a, hay, True)
+    assert kname == "k_longest_follow" and got.shape == want.shape and (got == want).all()

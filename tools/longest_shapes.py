@@ -25,12 +25,14 @@ cap = n
 d_out = torch.empty((cap, 2), dtype=torch.int32, device="cuda")
 for name, kws, cs, d_hay in cases:
     a = Automaton(N.MODE_LONGEST, kws, cs)
-    for form, knob in (("chain positions only", 0), ("walk from every position", 536870912)):  # tile_debug: k_longest_follow never
-        N.set_tunable("tile_debug", knob)
+    for form, knob, ru in (("chain positions only", 0, 0), ("... run-up 256", 0, 256), ("... run-up 128", 0, 128), ("walk from every position", 2, 0)):  # longest_form 2: k_longest_follow never
+        N.set_tunable("longest_form", knob)
+        N.set_tunable("region_units", ru)
         ms = []
         for i in range(3):
             nm, rc, prof, _ = a.match_device(d_hay.data_ptr(), n, False, d_out.data_ptr(), cap, stream=st, profile=True)
             assert rc == 0, rc
             ms.append((prof["scan_ms"] + prof["finalize_ms"], prof["scan_ms"]))
         print("%-58s %-26s %8.3f ms per 2^28 units (scan %.3f) %d records  %s" % (name, form, min(ms)[0], min(ms)[1], nm, prof["scan_kernel"]), flush=True)
-    N.set_tunable("tile_debug", 0)
+    N.set_tunable("longest_form", 0)
+    N.set_tunable("region_units", 0)
