@@ -112,6 +112,14 @@ int ensure_device(acgpu_automaton *a, DeviceState **out, int lane) {
     if (t.root_b && (rc = upload(*d, t.root_tab, &T.root_tab))) return rc;
     T.bits_tab = nullptr; T.bits_rk = t.bits_rk;
     if (t.bits_rk && (rc = upload(*d, t.bits_tab, &T.bits_tab))) return rc;
+    T.hy_dense = T.hy_nodes = T.hy_mask = T.hy_out = nullptr;
+    T.hy_n_dense = t.hy_n_dense; T.hy_n_states = t.hy_n_states;
+    if (t.hy_n_states) {
+        if ((rc = upload(*d, t.hy_dense, &T.hy_dense))) return rc;
+        if ((rc = upload(*d, t.hy_nodes, &T.hy_nodes))) return rc;
+        if ((rc = upload(*d, t.hy_mask, &T.hy_mask))) return rc;
+        if ((rc = upload(*d, t.hy_out, &T.hy_out))) return rc;
+    }
     if ((rc = upload(*d, t.filt_bits, &T.filt_bits))) return rc;
     if ((rc = upload(*d, t.kgram_node, &T.kgram_node))) return rc;
     T.fold_range = t.fold_range; T.fr_base = t.fr_base; T.fr_span = t.fr_span; T.fr_base2 = t.fr_base2; T.fr_himask = t.fr_himask;
@@ -240,6 +248,79 @@ DevTables folded_tables(const DeviceState &d) {
     return T;
 }
 
+// ALL-mode pipeline on one shard, the form for texts with dense matches: see match_all.
+constexpr double kStatesFormDensity = 0.05; // records per unit of the pool's last call from which k_ac_states is taken
+int match_all_states(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_kind, void *d_out, uint64_t cap, uint64_t *n_out,
+                     hipStream_t stream, acgpu_profile *prof, Ticket *tk, uint32_t hot_rows) {
+    const HostTables &t = a->t;
+    hipEvent_t *ev = tk ? tk->ev : d.ev;
+    const bool timed = tk ? tk->profiled : prof != nullptr;
+    const uint64_t own_len = sh->own_end - sh->own_begin;
+    int rc;
+    AcStatesLaunch S{};
+    S.d_hay = sh->d_hay;
+    S.n_units = (uint32_t)sh->n_units;
+    S.own_begin = (uint32_t)sh->own_begin;
+    S.own_end = (uint32_t)sh->own_end;
+    S.g0 = S.own_begin & ~3u;
+    S.halo = t.max_len - 1;
+    S.hot_rows = hot_rows;
+    const uint64_t span = sh->own_end - S.g0;
+    // a lane's chunk: 1024 units, shorter (down to 256) when the text would leave lanes of the chip without one
+    S.chunk_log2 = 10;
+    while (S.chunk_log2 > 8 && (span >> S.chunk_log2) < (uint64_t)ac_states_lanes_per_cu() * d.n_cu) --S.chunk_log2;
+    const uint64_t chunks = (span + (1ull << S.chunk_log2) - 1) >> S.chunk_log2;
+    S.n_waves = (uint32_t)((chunks + 63) / 64);
+    S.n_tiles = (uint32_t)((span + ac_states_tile_units() - 1) / ac_states_tile_units());
+    if ((rc = d.counter.ensure(64))) return rc;
+    if ((rc = d.statebuf.ensure((size_t)sh->own_end * 4 + 64))) return rc;
+    if ((rc = d.chunk_counts.ensure((size_t)S.n_tiles * 4))) return rc;
+    if ((rc = d.offsets.ensure((size_t)S.n_tiles * 8))) return rc;
+    if ((rc = d.scan_tmp.ensure(((size_t)S.n_tiles / 2048 + 2) * 8))) return rc;
+    S.d_state = (uint32_t *)d.statebuf.p;
+    S.d_counts = (uint32_t *)d.chunk_counts.p;
+    S.d_offsets = (const uint64_t *)d.offsets.p;
+    S.d_out = d_out;
+    S.cap = cap;
+    S.grid = (int)std::min<uint64_t>((uint64_t)d.n_cu, (S.n_waves + 15) / 16);
+    HIP_TRY(hipMemsetAsync(d.counter.p, 0, 64, stream)); // (word 1: the "redo" flag of the result -- never raised here)
+    d.cclean[0] = false; // (match_all's first set of slot counters lives here)
+    if (timed) HIP_TRY(hipEventRecord(ev[0], stream));
+    HIP_TRY(launch_ac_states(d.T, S, t.range_cls, stream));
+    if (timed) HIP_TRY(hipEventRecord(ev[1], stream));
+    HIP_TRY(launch_ac_states_out(d.T, S, record_kind == ACGPU_REC_MAP, false, stream));
+    HIP_TRY(launch_exclusive_scan(S.d_counts, S.n_tiles, (uint64_t *)d.offsets.p, (uint64_t *)d.scan_tmp.p, stream));
+    HIP_TRY(launch_ac_states_out(d.T, S, record_kind == ACGPU_REC_MAP, true, stream));
+    if (timed) HIP_TRY(hipEventRecord(ev[2], stream));
+    unsigned long long *h_slot = tk ? tk->h_count : d.h_counter, *d_slot = nullptr;
+    HIP_TRY(hipHostGetDevicePointer((void **)&d_slot, h_slot, 0));
+    HIP_TRY(launch_publish_result((const unsigned long long *)d.scan_tmp.p + scan_tiles_for(S.n_tiles), (const unsigned long long *)d.counter.p, d_slot,
+                                  reinterpret_cast<acgpu_device_result *>(sh->d_result), stream));
+    if (tk) {
+        tk->shard = *sh;
+        tk->record_kind = record_kind;
+        tk->d_out = d_out;
+        tk->stream = stream;
+        tk->done_is_ev2 = false;
+        HIP_TRY(hipEventRecord(tk->done, stream));
+        tk->scanned = own_len;
+        std::snprintf(tk->kname, sizeof(tk->kname), "k_ac_states");
+        return ACGPU_OK;
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+    *n_out = *d.h_counter;
+    d.all_density = (double)*n_out / (double)own_len;
+    if (prof) {
+        HIP_TRY(hipEventElapsedTime(&prof->scan_ms, d.ev[0], d.ev[1]));
+        HIP_TRY(hipEventElapsedTime(&prof->finalize_ms, d.ev[1], d.ev[2]));
+        HIP_TRY(hipEventElapsedTime(&prof->total_ms, d.ev[0], d.ev[2]));
+        prof->scan_units = own_len;
+        prof->n_matches = *n_out;
+        std::snprintf(prof->scan_kernel, sizeof(prof->scan_kernel), "k_ac_states");
+    }
+    return *n_out > cap ? ACGPU_E_OVERFLOW : ACGPU_OK;
+}
+
 // ALL-mode pipeline on one shard.
 // With a ticket the call returns after enqueueing (no host synchronisation); acgpu_match_device_end collects it.
 int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_kind, void *d_out, uint64_t cap,
@@ -272,6 +353,20 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         }
         *n_out = 0;
         return ACGPU_OK;
+    }
+    // Texts in which this dictionary matches densely (natural words in natural text: every filter passes, every verification walk
+    // is long): the automaton's state behind every unit (k_ac_states over the compact automaton of acgpu_build.cpp 6d), then the
+    // records from the states (acgpu_states.hip).  Its cost does not depend on the text (~ one gather per unit), the tile kernel's
+    // does: what this pool's last call found decides (records per unit; the first call of a pool takes the tile kernel).
+    // Tunable all_form, bits: 1 = never, 2 = whatever the last call found, 4 = also for short texts.
+    {
+        const int64_t aform = tunables().all_form;
+        const size_t st_pages = (!t.range_cls && !t.dfa_pages.empty()) ? t.dfa_pages.size() * 2 : 0;
+        const uint32_t st_hot = (!ww && !Tov && t.hy_n_states && (t.range_cls || st_pages > 0))
+                                    ? ac_states_hot_rows(t.n_cls, t.hy_n_dense, (uint32_t)st_pages) : 0;
+        if (st_hot > 0 && !(aform & 1) && tunables().force_kernel == 0 && !fused_only && (own_len >= (1ull << 20) || (aform & 4)) &&
+            ((aform & 2) || d.all_density >= kStatesFormDensity))
+            return match_all_states(a, d, sh, record_kind, d_out, cap, n_out, stream, prof, tk, st_hot);
     }
     int rc;
     const size_t counter_bytes = (size_t)kMaxSlices * kCounterStride * 8; // one set; layout: [set 0][set 1][overflow word]
@@ -613,6 +708,7 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
     if ((uint32_t)d.h_counter[1] != 0) // a candidate slice / scratch slice overflowed: fused kernel, one scratch slice
         return match_all(a, d, sh, record_kind, d_out, cap, n_out, stream, prof, nullptr, true, Tov);
     *n_out = *d.h_counter;
+    if (!ww) d.all_density = (double)*n_out / (double)own_len;
     if (prof) {
         HIP_TRY(hipEventElapsedTime(&prof->scan_ms, d.ev[0], d.ev[1]));
         HIP_TRY(hipEventElapsedTime(&prof->finalize_ms, d.ev[1], d.ev[2]));
@@ -1556,6 +1652,8 @@ int64_t acgpu_set_tunable(const char *name, int64_t value) {
     else if (!std::strcmp(name, "no_short_keywords")) slot = &t.no_short_keywords;
     else if (!std::strcmp(name, "reserve_cus")) slot = &t.reserve_cus;
     else if (!std::strcmp(name, "no_bits_trie")) slot = &t.no_bits_trie;
+    else if (!std::strcmp(name, "all_form")) slot = &t.all_form;
+    else if (!std::strcmp(name, "no_state_form")) slot = &t.no_state_form;
     else if (!std::strcmp(name, "longest_form")) slot = &t.longest_form;
     else if (!std::strcmp(name, "multi_min_share")) slot = &t.multi_min_share;
     else if (!std::strcmp(name, "no_big_l2")) slot = &t.no_big_l2;
@@ -1764,6 +1862,8 @@ int end_ticket(const acgpu_automaton *ca, acgpu_ticket *ticket, uint64_t *n_out,
     }
     *n_out = *tk->h_count;
     if (tk->kind == 1 && tk->user_shard) tk->user_shard->chain_exit = (int64_t)tk->h_count[2];
+    if (tk->kind == 0 && a->t.mode != ACGPU_MODE_WHOLEWORD && tk->shard.own_end > tk->shard.own_begin)
+        d->all_density = (double)*n_out / (double)(tk->shard.own_end - tk->shard.own_begin);
     tk->busy = false; // (whatever happens below, the ticket is collected)
     d->inflight--;
     if (prof) {

@@ -462,6 +462,62 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
         }
     }
 
+    // ---- 6d. ALL / SHORTEST: dense rows for the shallow and the branching states, 16-byte nodes for the rest (k_ac_states) ----
+    // Dictionaries of natural words match nearly everywhere in natural text: no filter helps, and the resolved table (a 128-byte
+    // row per state, nearly all of it copied from the fail state's row) misses every cache.  Here a state below depth 3 or
+    // with more than three children keeps its row; every other state is {fail, three edges}: 16 bytes, the whole automaton of the
+    // reference's README dictionary in 23 MB.
+    t.hy_n_states = 0;
+    if ((mode == ACGPU_MODE_ALL || mode == ACGPU_MODE_SHORTEST) && t.n_cls >= 2 && t.n_cls <= 255 && N > 1 && N < kHyOut && t.max_len <= 32 &&
+        !tunables().no_state_form) {
+        std::vector<uint16_t> cls_unit(t.n_cls, 0);
+        for (uint32_t u = 0; u < 65536; u++)
+            if (cls_of[u]) cls_unit[cls_of[u]] = (uint16_t)u;
+        auto is_dense = [&](uint32_t s) { return nodes[s].depth <= 2 || child_begin[s + 1] - child_begin[s] > 3; };
+        std::vector<uint32_t> hid(N);
+        uint32_t nd = 0;
+        for (uint32_t s : bfs) if (is_dense(s)) hid[s] = nd++;
+        t.hy_n_dense = nd;
+        for (uint32_t s : bfs) if (!is_dense(s)) hid[s] = nd++;
+        t.hy_n_states = N;
+        auto to = [&](uint32_t target) { return hid[target] | (olen[target] ? kHyOut : 0u); };
+        t.hy_dense.assign((size_t)t.hy_n_dense * t.n_cls, 0u);
+        t.hy_nodes.assign((size_t)(N - t.hy_n_dense) * 4, 0u);
+        t.hy_mask.assign(N, 0u);
+        t.hy_out.assign((size_t)N * 2, 0u);
+        for (uint32_t s : bfs) {
+            const uint32_t h = hid[s];
+            if (olen[s]) {
+                uint32_t m = 0;
+                for (uint32_t x = s; x != 0 && olen[x]; x = olink[x]) m |= 1u << (olen[x] - 1);
+                t.hy_mask[h] = m;
+                t.hy_out[(size_t)h * 2] = oid[s];
+                t.hy_out[(size_t)h * 2 + 1] = olink[s] ? hid[olink[s]] : 0u;
+            }
+            if (is_dense(s)) {
+                uint32_t *row = &t.hy_dense[(size_t)h * t.n_cls];
+                for (uint32_t c = 1; c < t.n_cls; c++) {
+                    uint32_t f = s, target = 0;
+                    for (;;) {
+                        const uint32_t m = find_child(f, cls_unit[c]);
+                        if (m != ~0u) { target = m; break; }
+                        if (f == 0) break;
+                        f = fail[f];
+                    }
+                    row[c] = target ? to(target) : 0u;
+                }
+            } else {
+                uint32_t *node = &t.hy_nodes[(size_t)(h - t.hy_n_dense) * 4];
+                node[0] = hid[fail[s]];
+                uint32_t k = 1;
+                for (uint32_t ci = child_begin[s]; ci < child_begin[s + 1]; ci++) {
+                    const uint32_t c = child_ids[ci];
+                    node[k++] = (cls_of[nodes[c].unit] << 24) | to(c);
+                }
+            }
+        }
+    }
+
     // ---- 6b. LONGEST: root table of the walk's first round (small alphabets) ----
     // Every walk starts at the root, so what the first RK units of a walk do is a function of those units alone: one byte
     // per RK-gram {bit 7: the walk is still alive after RK units | low bits: longest keyword among the RK steps}, indexed by
@@ -978,7 +1034,7 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
     }
     // ---- 7c. the same for the DFA chunk scan: cls_lut (any number of classes: 16-bit entries) as pages for k_ac_dfa ----
     t.dfa_pages.clear();
-    if (t.dense && !t.range_cls && !tunables().no_class_pages) {
+    if ((t.dense || t.hy_n_states) && !t.range_cls && !tunables().no_class_pages) {
         t.dfa_pages.assign(128, 0); // (uint16 words: the 256-byte index, one byte per page, first)
         uint8_t *index = reinterpret_cast<uint8_t *>(t.dfa_pages.data());
         uint32_t n_pages = 0;

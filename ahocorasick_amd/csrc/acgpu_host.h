@@ -109,6 +109,7 @@ struct DeviceState {
     DevBuf lenbig, todo;                                 // LONGEST: escaped lengths; root-table form: flagged chunks
     DevBuf chainbits;                                    // LONGEST: one bit per position, set where the chain reports a match
     DevBuf bits_state;                                   // k_longest_bits: exit / flag / count, look-back words, region counter -- zero between calls
+    double all_density = -1.0;                           // ALL: records per unit of this pool's last call (-1: none yet): k_ac_states or the tile kernel
     int fol_level = 0;                                   // k_longest_follow: 0 = run-up of 128 positions, 1 = of a whole segment (a call's chains had not merged), 2 = not for this pool's texts
     void *bits_state_seen = nullptr;                     // (a re-allocated buffer, or a call that failed half way, is zeroed by a memset)
     DevBuf cands, region_cands;                          // ALL, split form: candidate positions, {first, count} per region

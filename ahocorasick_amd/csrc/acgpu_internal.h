@@ -102,6 +102,8 @@ ACGPU_HD inline uint32_t l2_rotr(uint32_t x, uint32_t r) { return (x >> (r & 31u
 // behind the label, else 63 | kBitsAlive.
 constexpr uint32_t kBitsRK = 9;            // first level: 2^9 entries indexed by the text's next 9 units
 constexpr uint32_t kBitsTabEntries = 1120; // 17.5 KiB of LDS: what 16 waves' text images leave
+constexpr uint32_t kHyOut = 1u << 23;   // HostTables::hy_dense / hy_nodes: the target state reports matches
+constexpr uint32_t kHyIdMask = kHyOut - 1u;
 constexpr uint32_t kBitsAlive = 1u << 24;
 constexpr uint32_t kBitsLeaf = 0, kBitsJunction = 1, kBitsCont = 2, kBitsDeep = 3;
 
@@ -146,6 +148,16 @@ struct HostTables {
     // (acgpu_build.cpp 6c): kBitsTabEntries entries of four words; bits_rk = 0: none
     std::vector<uint32_t> bits_tab;
     uint32_t bits_rk = 0;
+    // ALL / SHORTEST: the automaton in the form k_ac_states walks (acgpu_build.cpp 6d; hy_n_states = 0: none).  States are numbered
+    // anew ("h-ids", 23 bits): the DENSE group first -- the root, depth 1 and 2, every state with more than three children -- in
+    // BFS order, each with a row of n_cls resolved transitions (fail links followed at build time); then the COMPACT group, one
+    // 16-byte node each: {fail state, three edges (class << 24 | child)} -- a miss goes to the fail state and looks at the same
+    // unit again.  Bit 23 (kHyOut) of a transition = the state it leads to reports matches.
+    std::vector<uint32_t> hy_dense;  // hy_n_dense * n_cls
+    std::vector<uint32_t> hy_nodes;  // 4 words per compact state
+    std::vector<uint32_t> hy_mask;   // per h-id: bit L-1 = a keyword of L units ends in this state (its own or a suffix's)
+    std::vector<uint32_t> hy_out;    // per h-id, two words: {keyword id of the longest such keyword, h-id of the next shorter one's state}
+    uint32_t hy_n_dense = 0, hy_n_states = 0;
     // hashed goto edges keyed by (state, folded unit): open addressing, linear probing
     std::vector<uint64_t> hkeys;
     std::vector<uint32_t> hvals;
@@ -284,6 +296,8 @@ struct DevTables {
     uint32_t root_b, root_rk;
     const uint32_t *bits_tab; // LONGEST: see HostTables::bits_tab (nullptr: none)
     uint32_t bits_rk;
+    const uint32_t *hy_dense, *hy_nodes, *hy_mask, *hy_out; // see HostTables::hy_dense (hy_n_states = 0: none)
+    uint32_t hy_n_dense, hy_n_states;
 };
 
 // development/test knobs (acgpu_set_tunable): relaxed atomics, read when a call is enqueued
@@ -309,6 +323,8 @@ struct Tunables {
     std::atomic<int64_t> no_big_l2{0};        // builder: 1 = large dictionaries keep the (saturated) second level in LDS (A/B)
     std::atomic<int64_t> multi_min_share{1ll << 22}; // acgpu_match_u16_multi: a share is at least this many units (tests: 1024)
     std::atomic<int64_t> longest_form{0};     // LONGEST, bits: 1 = never k_longest_bits, 2 = never k_longest_follow, 4 = both also for short texts (tests, A/B)
+    std::atomic<int64_t> all_form{0};         // ALL, bits: 1 = never k_ac_states, 2 = always (where its tables exist), 4 = also for short texts (tests, A/B)
+    std::atomic<int64_t> no_state_form{0};    // builder: 1 = no compact automaton for k_ac_states (A/B)
     std::atomic<int64_t> no_bits_trie{0};     // builder: 1 = no path-compressed trie for k_longest_bits (the walk pipeline instead: A/B)
     std::atomic<int64_t> reserve_cus{0};      // CUs left without a scan workgroup (room for a collective's kernels under the scan)
 };

@@ -1,0 +1,235 @@
+// acgpu_states.hip -- AhoCorasickSet/Map over dictionaries that match nearly everywhere: the automaton's state at every unit,
+// then the records from the states (gfx950).
+//
+// The reference's loop (S/AhoCorasickSet.java:204-226: one transition per unit, fail links until a node has the edge; output walk
+// :522-535: the node's own keyword, then its suffixes, longest first) is what runs here, chunk by chunk:
+//  * k_ac_states: a lane owns a chunk of 512 units, starts at the root max_len - 1 units before it (from there on its state is
+//    the sequential automaton's) and writes the state behind every unit -- 4 bytes per unit, the h-id of acgpu_build.cpp 6d with
+//    bit 23 = "reports matches".  A state of the DENSE group (the root, depth 1 and 2, more than three children) has a row of
+//    resolved transitions: the first rows in LDS, the others in L2; a COMPACT state is one 16-byte node {fail, three edges}: a
+//    miss moves to the fail state WITHOUT taking the unit (one more iteration) -- the automaton of the reference's README
+//    dictionary is 23 MB this way (345 MB as a resolved table, a cache miss per unit).  Every iteration is one step of every
+//    lane's own chain (no lock step: a lane that follows a fail link falls one iteration behind); the text comes through a
+//    ring of four 8-unit blocks per lane in LDS, one block ahead; all three lookups of a step (LDS row, row in memory, node) are
+//    issued for every lane with clamped addresses and selected afterwards: one wait per iteration.
+//  * k_ac_states_out<MAP, false>: records per tile of 4096 positions (the popcount of hy_mask[state] where bit 23 is set);
+//    a prefix sum over the tiles; k_ac_states_out<MAP, true>: the records, in text order, the lengths of a position from the
+//    mask's bits (longest first), Map records walk hy_out for the keyword ids.
+// Bound by the gathers of k_ac_states (one per unit and fail hop) and by the record stores, not by the text stream.
+#include <algorithm>
+
+#include <hip/hip_runtime.h>
+
+#include "acgpu_device.h"
+#include "acgpu_kernels.h"
+
+namespace acgpu {
+
+constexpr int kStBlock = 1024;                  // 16 waves, one workgroup per CU
+constexpr uint32_t kStChunkLog2 = 10;           // a lane's chunk: 1024 units
+constexpr uint32_t kStRingWords = 2 * 64 * 4;   // per wave: [2 blocks][64 lanes] of 16 bytes of text
+constexpr uint32_t kStStageWords = 16 * 64;     // per wave: [16 positions][64 lanes] of states on their way to memory
+constexpr uint32_t kStFlushEvery = 8;           // iterations between two flushes of the staged states (at most 3 + 8 of 16 slots are in use)
+constexpr uint32_t kStRowBytesMax = 159 * 1024 - (kStBlock / kWave) * (kStRingWords + kStStageWords) * 4; // LDS left for rows and pages: 63 KiB
+constexpr uint32_t kStTileUnits = 4096;         // positions per wave of the record passes
+
+struct __attribute__((packed, aligned(2))) StUnits8 {
+    uint32_t d[4];
+};
+
+template <bool RANGE>
+__global__ __launch_bounds__(kStBlock, 4) void k_ac_states(DevTables T, AcStatesLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    // [hot rows][class pages (table classes)][text rings][staged states]
+    const uint32_t n_cls = T.n_cls;
+    const uint32_t row_words = L.hot_rows * n_cls, page_words = RANGE ? 0u : (T.dfa_pages_bytes + 3u) / 4u;
+    for (uint32_t i = threadIdx.x; i < row_words; i += blockDim.x) smem[i] = T.hy_dense[i];
+    for (uint32_t i = threadIdx.x; i < page_words; i += blockDim.x) smem[row_words + i] = reinterpret_cast<const uint32_t *>(T.dfa_pages)[i];
+    __syncthreads();
+    const uint32_t *rows = smem;
+    const uint16_t *pages = reinterpret_cast<const uint16_t *>(smem + row_words);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave), lane = lane_id();
+    uint32_t *wave_mem = smem + ((row_words + page_words + 3u) & ~3u) + wave * (kStRingWords + kStStageWords);
+    uint4 *ring = reinterpret_cast<uint4 *>(wave_mem);
+    uint32_t *stage = wave_mem + kStRingWords;
+    const uint32_t waves_total = gridDim.x * (kStBlock / kWave);
+    const uint16_t *hay = L.d_hay;
+    const uint32_t nu = L.n_units, hot_last = row_words ? row_words - 1u : 0u, n_dense = T.hy_n_dense;
+    const uint32_t dense_last = n_dense * n_cls - 1u, node_last = T.hy_n_states - n_dense ? T.hy_n_states - n_dense - 1u : 0u;
+    const uint4 *nodes = reinterpret_cast<const uint4 *>(T.hy_nodes);
+    for (uint32_t w = blockIdx.x * (kStBlock / kWave) + wave; w < L.n_waves; w += waves_total) {
+        const uint64_t wb64 = (uint64_t)L.g0 + ((uint64_t)(w * 64u + lane) << L.chunk_log2);
+        const bool mine = wb64 < L.own_end;
+        const uint32_t wb = mine ? (uint32_t)wb64 : L.own_end;                   // the first position whose state the lane writes
+        const uint32_t we = (uint32_t)std::min<uint64_t>(wb64 + (1u << L.chunk_log2), L.own_end); // one past the last
+        uint32_t pos = wb > L.halo ? wb - L.halo : 0u;                           // the root stands here
+        uint32_t s = 0;
+        uint32_t have_end = pos >> 3;   // blocks [have_end - 2, have_end) are in the ring (none yet)
+        uint32_t flushed = wb;          // the states of [wb, flushed) are in memory, those of [flushed, pos) staged
+        bool active = mine && pos < we;
+        // The states go to memory through the staging slots, all lanes together every kStFlushEvery iterations: a store in the
+        // loop's body would be waited for (stores and loads count in one counter here, and a wait for a gather's data
+        // is a wait for every store issued before it: the acknowledgement of a store takes longer than a gather).
+        auto flush = [&]() {
+            while (__any(flushed + 4u <= pos && flushed + 4u <= we)) {
+                if (flushed + 4u <= pos && flushed + 4u <= we) {
+                    const uint32_t o = flushed - wb;
+                    const uint4 v = make_uint4(stage[((o + 0u) & 15u) * 64u + lane], stage[((o + 1u) & 15u) * 64u + lane],
+                                               stage[((o + 2u) & 15u) * 64u + lane], stage[((o + 3u) & 15u) * 64u + lane]);
+                    *reinterpret_cast<uint4 *>(L.d_state + flushed) = v;
+                    flushed += 4u;
+                }
+            }
+        };
+        uint32_t it = 0;
+        while (__any(active)) {
+            const uint32_t xb = pos >> 3;
+            const bool want_load = active && have_end <= xb + 1u && have_end * 8u < nu;
+            uint4 blk = make_uint4(0u, 0u, 0u, 0u);
+            if (want_load) {
+                const uint32_t b0 = have_end * 8u;
+                if (b0 + 8u <= nu) {
+                    const StUnits8 v = *reinterpret_cast<const StUnits8 *>(hay + b0);
+                    blk = make_uint4(v.d[0], v.d[1], v.d[2], v.d[3]);
+                } else { // the buffer's last, partial block
+                    uint32_t t4[4] = {0u, 0u, 0u, 0u};
+                    for (uint32_t k = 0; k < 8u && b0 + k < nu; ++k) t4[k >> 1] |= (uint32_t)hay[b0 + k] << (16u * (k & 1u));
+                    blk = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+                }
+            }
+            const bool can_step = active && xb < have_end;
+            if (can_step) {
+                const uint32_t u = reinterpret_cast<const uint16_t *>(ring + (xb & 1u) * 64u + lane)[pos & 7u];
+                uint32_t cls;
+                if (RANGE) {
+                    const uint32_t dlt = u - T.cls_base;
+                    cls = dlt < T.cls_span ? dlt + 1u : 0u;
+                } else {
+                    cls = pages[128u + ((uint32_t)reinterpret_cast<const unsigned char *>(pages)[u >> 8] << 8) + (u & 255u)];
+                }
+                // the three places a transition can come from, all asked (a lane that does not need one reads entry 0 of it)
+                const bool in_dense = s < n_dense;
+                const uint32_t idx = in_dense ? s * n_cls + cls : 0u;
+                const uint32_t e_lds = rows[std::min(idx, hot_last)];
+                const uint32_t e_glb = T.hy_dense[idx < row_words ? 0u : std::min(idx, dense_last)];
+                const uint4 nd = nodes[in_dense ? 0u : std::min(s - n_dense, node_last)];
+                uint32_t ns;
+                bool took = true;
+                if (in_dense) {
+                    ns = idx < row_words ? e_lds : e_glb;
+                } else if (cls == 0u) {
+                    ns = 0u; // (a unit of no keyword: the root, whatever the state)
+                } else if ((nd.y >> 24) == cls) {
+                    ns = nd.y & 0xffffffu;
+                } else if ((nd.z >> 24) == cls) {
+                    ns = nd.z & 0xffffffu;
+                } else if ((nd.w >> 24) == cls) {
+                    ns = nd.w & 0xffffffu;
+                } else {
+                    ns = nd.x; // the fail state looks at this unit again
+                    took = false;
+                }
+                s = ns & kHyIdMask;
+                if (took) {
+                    if (pos >= wb) stage[((pos - wb) & 15u) * 64u + lane] = ns;
+                    ++pos;
+                    active = pos < we;
+                }
+            }
+            if (want_load) { // (behind the gathers' wait: the block has arrived with them)
+                ring[(have_end & 1u) * 64u + lane] = blk;
+                ++have_end;
+            }
+            if ((++it & (kStFlushEvery - 1u)) == 0u) flush();
+        }
+        flush();
+        if (mine && (we & 3u) && flushed < we) // the chunk's last, partial group (only where the owned range ends)
+            for (uint32_t q = flushed; q < we; ++q) L.d_state[q] = stage[((q - wb) & 15u) * 64u + lane];
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// records of the tiles: EMIT = false counts them (d_counts), EMIT = true writes them behind the tiles' prefix sums (d_offsets)
+template <bool MAP, bool EMIT>
+__global__ __launch_bounds__(256) void k_ac_states_out(DevTables T, AcStatesLaunch L) {
+    const uint32_t lane = lane_id();
+    const uint32_t tile = blockIdx.x * (256u / kWave) + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    if (tile >= L.n_tiles) return;
+    const uint64_t t0 = (uint64_t)L.g0 + (uint64_t)tile * kStTileUnits;
+    const uint2 *outs = reinterpret_cast<const uint2 *>(T.hy_out);
+    unsigned long long base = EMIT ? L.d_offsets[tile] : 0ull;
+    uint32_t acc = 0;
+    for (uint32_t step = 0; step < kStTileUnits / kWave; ++step) {
+        const uint64_t p64 = t0 + step * kWave + lane;
+        if (t0 + step * kWave >= L.own_end) break; // wave-uniform
+        const uint32_t p = (uint32_t)p64;
+        uint32_t v = 0;
+        if (p64 >= L.own_begin && p64 < L.own_end) v = L.d_state[p];
+        uint32_t m = (v & kHyOut) ? T.hy_mask[v & kHyIdMask] : 0u;
+        const uint32_t c = (uint32_t)__popc(m);
+        if (!EMIT) {
+            acc += c;
+        } else {
+            const uint32_t incl = wave_inclusive_scan(c);
+            const uint32_t total = __builtin_amdgcn_readlane(incl, kWave - 1);
+            if (total == 0) continue; // wave-uniform
+            unsigned long long at = base + (incl - c);
+            uint32_t t = v & kHyIdMask;
+            while (m != 0u) { // (a lane's records: longest first)
+                const uint32_t len = 32u - (uint32_t)__clz(m);
+                m &= ~(1u << (len - 1u));
+                if (at < L.cap) {
+                    if (MAP) {
+                        const uint2 o = outs[t];
+                        int32_t *r = reinterpret_cast<int32_t *>(L.d_out) + at * 3;
+                        r[0] = (int32_t)(p + 1u - len);
+                        r[1] = (int32_t)(p + 1u);
+                        r[2] = (int32_t)o.x;
+                        t = o.y;
+                    } else {
+                        reinterpret_cast<int2 *>(L.d_out)[at] = make_int2((int)(p + 1u - len), (int)(p + 1u));
+                    }
+                }
+                ++at;
+            }
+            base += total;
+        }
+    }
+    if (!EMIT) {
+        for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+        if (lane == 0) L.d_counts[tile] = acc;
+    }
+}
+
+uint32_t ac_states_tile_units() { return kStTileUnits; }
+uint32_t ac_states_chunk_units() { return 1u << kStChunkLog2; }
+uint32_t ac_states_lanes_per_cu() { return kStBlock; }
+// rows of the dense group the kernel can keep in LDS next to `page_bytes` of class pages (0: range classes)
+uint32_t ac_states_hot_rows(uint32_t n_cls, uint32_t n_dense, uint32_t page_bytes) {
+    if (!n_cls || page_bytes + 16u > kStRowBytesMax) return 0u;
+    return (uint32_t)std::min<uint64_t>(n_dense, (kStRowBytesMax - page_bytes - 16u) / ((uint64_t)n_cls * 4u));
+}
+
+hipError_t launch_ac_states(const DevTables &t, const AcStatesLaunch &l, bool range, hipStream_t stream) {
+    const size_t lds = (((size_t)l.hot_rows * t.n_cls + (range ? 0 : (t.dfa_pages_bytes + 3) / 4) + 3) & ~(size_t)3) * 4 + (size_t)(kStBlock / kWave) * (kStRingWords + kStStageWords) * 4;
+    const void *fn = range ? reinterpret_cast<const void *>(&k_ac_states<true>) : reinterpret_cast<const void *>(&k_ac_states<false>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    if (range) hipLaunchKernelGGL((k_ac_states<true>), dim3(l.grid), dim3(kStBlock), lds, stream, t, l);
+    else hipLaunchKernelGGL((k_ac_states<false>), dim3(l.grid), dim3(kStBlock), lds, stream, t, l);
+    return hipGetLastError();
+}
+
+hipError_t launch_ac_states_out(const DevTables &t, const AcStatesLaunch &l, bool map, bool emit, hipStream_t stream) {
+    const dim3 grid((l.n_tiles + 3) / 4), block(256);
+    if (map) {
+        if (emit) hipLaunchKernelGGL((k_ac_states_out<true, true>), grid, block, 0, stream, t, l);
+        else hipLaunchKernelGGL((k_ac_states_out<true, false>), grid, block, 0, stream, t, l);
+    } else {
+        if (emit) hipLaunchKernelGGL((k_ac_states_out<false, true>), grid, block, 0, stream, t, l);
+        else hipLaunchKernelGGL((k_ac_states_out<false, false>), grid, block, 0, stream, t, l);
+    }
+    return hipGetLastError();
+}
+
+} // namespace acgpu

@@ -1,0 +1,158 @@
+"""GPU parity tests of k_ac_states / k_ac_states_out (csrc/acgpu_states.hip): AhoCorasickSet/Map over dictionaries that match densely
+-- the automaton's state behind every unit over the compact automaton of acgpu_build.cpp 6d, then the records from the states --
+through the C ABI, against the CPU oracle's restatement of S/AhoCorasickSet.java:193-252 (output walk :522-535), bit for bit and in
+listener-call order; and against the tile kernel it stands in for."""
+import numpy as np
+import pytest
+
+from ahocorasick_amd import _native as N
+from ahocorasick_amd import synth
+from ahocorasick_amd.strings import Automaton, utf16
+from oracle.oracle import FAM_AC, FAM_SHORTEST, Oracle
+from tests.helpers import LOWER
+
+pytestmark = pytest.mark.gpu
+
+STATES_ALWAYS = 6  # all_form: k_ac_states whatever the pool's last call found, for short texts too
+STATES_NEVER = 1
+
+
+@pytest.fixture(autouse=True)
+def _reset_tunables():
+    yield
+    for k, v in [("force_kernel", 0), ("tile_debug", 0), ("all_form", 0)]:
+        N.set_tunable(k, v)
+
+
+def _run(a, hay, with_ids, own=None, d_hay=None, cap=None, text_begin=True):
+    import torch
+    if d_hay is None:
+        d_hay = torch.from_numpy(np.ascontiguousarray(hay).view(np.int16)).cuda()
+    cap = hay.size * 4 + 8 if cap is None else cap
+    cols = 3 if with_ids else 2
+    d_out = torch.empty((cap, cols), dtype=torch.int32, device="cuda")
+    kw = {}
+    if own is not None:
+        kw["own"] = own
+    n_out, rc, prof, _ = a.match_device(d_hay.data_ptr(), hay.size, with_ids, d_out.data_ptr(), cap, profile=True,
+                                        stream=torch.cuda.current_stream().cuda_stream, **kw)
+    assert rc == N.OK, rc
+    return d_out[:n_out].cpu().numpy(), prof["scan_kernel"]
+
+
+@pytest.fixture(scope="module")
+def words():
+    return synth.readme_dictionary(n=30000)
+
+
+def test_states_form_on_a_word_list_equals_the_oracle_at_every_size_set_and_map(words):
+    a = Automaton(N.MODE_ALL, words, True)
+    orc = Oracle(FAM_AC, words)
+    whole = synth.readme_text(4, (1 << 20) + 4099, words)
+    N.set_tunable("all_form", STATES_ALWAYS)
+    for n in (1, 2, 3, 4, 5, 7, 8, 9, 31, 33, 511, 512, 513, 1023, 1025, 4095, 4096, 4097, 32767, 32768, 32769, 200003, (1 << 20) + 4099):
+        hay = whole[:n]
+        want = orc.match(hay)
+        for with_ids in (False, True):
+            got, kname = _run(a, hay, with_ids)
+            assert kname == "k_ac_states", (n, kname)
+            w = want if with_ids else want[:, :2]
+            assert got.shape == w.shape and (got == w).all(), (n, with_ids)
+    N.set_tunable("all_form", STATES_NEVER)
+    got, kname = _run(a, whole, True)
+    assert kname != "k_ac_states" and (got == orc.match(whole)).all()
+
+
+def test_states_form_is_taken_when_the_pools_last_call_found_dense_matches(words):
+    a = Automaton(N.MODE_ALL, words, True)
+    orc = Oracle(FAM_AC, words)
+    hay = synth.readme_text(11, (1 << 20) + 77, words)
+    want = orc.match(hay)
+    got, kname = _run(a, hay, True)
+    assert kname != "k_ac_states" and (got == want).all()  # (a pool's first call: the tile kernel)
+    got, kname = _run(a, hay, True)
+    assert kname == "k_ac_states" and got.shape == want.shape and (got == want).all()
+    got, kname = _run(a, hay[:70000], True)  # short texts keep the tile kernel
+    assert kname != "k_ac_states" and (got == orc.match(hay[:70000])).all()
+    # a text in which nothing matches sends the pool back
+    blank = np.full((1 << 20) + 5, ord("#"), np.uint16)
+    got, kname = _run(a, blank, True)
+    assert kname == "k_ac_states" and got.shape[0] == 0
+    got, kname = _run(a, blank, True)
+    assert kname != "k_ac_states" and got.shape[0] == 0
+
+
+def test_states_form_case_insensitive_dictionary_classes_from_lds_pages(words):
+    a = Automaton(N.MODE_ALL, words, False)
+    orc = Oracle(FAM_AC, words, case_sensitive=False, lower=LOWER)
+    hay = synth.readme_text(9, 300001, words).copy()
+    rng = np.random.default_rng(3)
+    flip = rng.random(hay.size) < 0.2
+    hay[flip & (hay >= 97) & (hay <= 122)] -= 32
+    N.set_tunable("all_form", STATES_ALWAYS)
+    got, kname = _run(a, hay, True)
+    want = orc.match(hay)
+    assert kname == "k_ac_states" and got.shape == want.shape and (got == want).all()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_states_form_fail_hops_over_small_alphabets_and_keywords_of_up_to_32_units(seed):
+    """Texts of letters only over 2-8 letters: the walk leaves compact states through their fail links all the time (several hops
+    per unit), keywords nest in each other (several records per position), the longest have 32 units (bit 31 of the mask)."""
+    rng = np.random.default_rng(900 + seed)
+    letters = np.array([ord(c) for c in "abcdefgh"[: [2, 3, 5, 8][seed]]], dtype=np.uint16)
+    n = 400000 + int(rng.integers(0, 999))
+    hay = letters[rng.integers(0, len(letters), n)]
+    kws = [hay[o:o + ln].copy() for o, ln in zip(rng.integers(0, n - 40, 300).tolist(), rng.integers(1, 33, 300).tolist())]
+    kws += [letters[rng.integers(0, len(letters), int(rng.integers(1, 10)))] for _ in range(500)]
+    kws.append(hay[1000:1032].copy())
+    a = Automaton(N.MODE_ALL, kws, True)
+    want = Oracle(FAM_AC, kws).match(hay)
+    N.set_tunable("all_form", STATES_ALWAYS)
+    for with_ids in (False, True):
+        got, kname = _run(a, hay, with_ids, cap=len(want) + 8)
+        w = want if with_ids else want[:, :2]
+        assert kname == "k_ac_states" and got.shape == w.shape and (got == w).all()
+    assert int((want[:, 1] - want[:, 0]).max()) == 32
+    # a keyword of 33 units: no mask bit for it, the dictionary keeps the other kernels
+    a2 = Automaton(N.MODE_ALL, kws + [hay[2000:2033].copy()], True)
+    got, kname = _run(a2, hay[:100000], True, cap=len(want) + 8)
+    assert kname != "k_ac_states"
+
+
+def test_states_form_shards_tickets_and_overflow(words):
+    import torch
+    a = Automaton(N.MODE_ALL, words, True)
+    hay = synth.readme_text(5, 400001, words)
+    want = Oracle(FAM_AC, words).match(hay)
+    d_hay = torch.from_numpy(hay.view(np.int16)).cuda()
+    N.set_tunable("all_form", STATES_ALWAYS)
+    for cuts in ([0, 65536, 131072, hay.size], [0, 70001, 70002, 70040, 333333, hay.size], [0, 1, 2, 33, hay.size]):
+        parts = []
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            got, kname = _run(a, hay, True, own=(lo, hi), d_hay=d_hay)
+            assert kname == "k_ac_states"
+            parts.append(got)
+        got = np.concatenate(parts)
+        assert got.shape == want.shape and (got == want).all(), cuts
+    st = torch.cuda.current_stream().cuda_stream
+    cap = len(want) + 8
+    out = torch.empty((cap, 3), dtype=torch.int32, device="cuda")
+    tk, rc = a.match_device_begin(d_hay.data_ptr(), hay.size, True, out.data_ptr(), cap, stream=st, profile=True)
+    assert rc == N.OK
+    n, rc, prof = a.match_device_end(tk, profile=True)
+    assert rc == N.OK and n == len(want) and prof["scan_kernel"] == "k_ac_states" and (out[:n].cpu().numpy() == want).all()
+    out.fill_(-7)
+    tk, rc = a.match_device_begin(d_hay.data_ptr(), hay.size, True, out.data_ptr(), 5, stream=st)
+    n, rc, _ = a.match_device_end(tk)
+    assert rc == N.E_OVERFLOW and n == len(want)
+    assert (out[:5].cpu().numpy() == want[:5]).all() and (out[5:].cpu().numpy() == -7).all()
+
+
+def test_shortest_over_the_states_form(words):
+    a = Automaton(N.MODE_SHORTEST, words, True)
+    hay = synth.readme_text(6, 300007, words)
+    want = Oracle(FAM_SHORTEST, words).match(hay)
+    N.set_tunable("all_form", STATES_ALWAYS)
+    got, _ = _run(a, hay, True)
+    assert got.shape == want.shape and (got == want).all()

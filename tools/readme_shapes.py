@@ -12,8 +12,9 @@ d_hay = torch.from_numpy(block.view(np.int16)).cuda().repeat(n // block.size)
 st = torch.cuda.current_stream().cuda_stream
 for label, kws in (("all 235886", words), ("without the single letters", [w for w in words if len(w) > 1]), ("lengths >= 3", [w for w in words if len(w) > 2]),
                    ("lower-case, lengths >= 4", [w for w in words if len(w) > 3 and w[0] >= 97])):
-    for fk in (0, 1, 2):
-        N.set_tunable("force_kernel", fk)
+    for fk in (0, 1, 2, 9):  # 9: k_ac_states (all_form 2)
+        N.set_tunable("force_kernel", fk if fk < 9 else 0)
+        N.set_tunable("all_form", 2 if fk == 9 else 1)
         a = Automaton(N.MODE_ALL, kws, True)
         info = a.info()
         cap = int(n * 1.75)
@@ -24,5 +25,6 @@ for label, kws in (("all 235886", words), ("without the single letters", [w for 
             assert rc == 0, rc
             ms.append(prof["scan_ms"] + prof["finalize_ms"])
         print("%-28s force_kernel=%d K=%d density=%.3f tile=%d: %8.3f ms per 2^28 units (scan %.3f) %d records %s" % (
-            label, fk, info["filter_k"], info["filter_density"], info["tile_kernel"], min(ms), prof["scan_ms"], nm, prof["scan_kernel"]), flush=True)
+            label, fk, info["filter_k"], info["filter_density"], info["tile_kernel"], min(ms), prof["scan_ms"], nm, prof["scan_kernel"][:40]), flush=True)
         del a, d_out
+N.set_tunable("all_form", 0)
