@@ -271,12 +271,12 @@ int match_all_states(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int re
     while (S.chunk_log2 > 8 && (span >> S.chunk_log2) < (uint64_t)ac_states_lanes_per_cu() * d.n_cu) --S.chunk_log2;
     const uint64_t chunks = (span + (1ull << S.chunk_log2) - 1) >> S.chunk_log2;
     S.n_waves = (uint32_t)((chunks + 63) / 64);
-    S.n_tiles = (uint32_t)((span + ac_states_tile_units() - 1) / ac_states_tile_units());
+    S.n_chunks = (uint32_t)chunks;
     if ((rc = d.counter.ensure(64))) return rc;
     if ((rc = d.statebuf.ensure((size_t)sh->own_end * 4 + 64))) return rc;
-    if ((rc = d.chunk_counts.ensure((size_t)S.n_tiles * 4))) return rc;
-    if ((rc = d.offsets.ensure((size_t)S.n_tiles * 8))) return rc;
-    if ((rc = d.scan_tmp.ensure(((size_t)S.n_tiles / 2048 + 2) * 8))) return rc;
+    if ((rc = d.chunk_counts.ensure((size_t)S.n_chunks * 4))) return rc;
+    if ((rc = d.offsets.ensure((size_t)S.n_chunks * 8))) return rc;
+    if ((rc = d.scan_tmp.ensure(((size_t)S.n_chunks / 2048 + 2) * 8))) return rc;
     S.d_state = (uint32_t *)d.statebuf.p;
     S.d_counts = (uint32_t *)d.chunk_counts.p;
     S.d_offsets = (const uint64_t *)d.offsets.p;
@@ -288,13 +288,12 @@ int match_all_states(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int re
     if (timed) HIP_TRY(hipEventRecord(ev[0], stream));
     HIP_TRY(launch_ac_states(d.T, S, t.range_cls, stream));
     if (timed) HIP_TRY(hipEventRecord(ev[1], stream));
-    HIP_TRY(launch_ac_states_out(d.T, S, record_kind == ACGPU_REC_MAP, false, stream));
-    HIP_TRY(launch_exclusive_scan(S.d_counts, S.n_tiles, (uint64_t *)d.offsets.p, (uint64_t *)d.scan_tmp.p, stream));
-    HIP_TRY(launch_ac_states_out(d.T, S, record_kind == ACGPU_REC_MAP, true, stream));
+    HIP_TRY(launch_exclusive_scan(S.d_counts, S.n_chunks, (uint64_t *)d.offsets.p, (uint64_t *)d.scan_tmp.p, stream));
+    HIP_TRY(launch_ac_states_out(d.T, S, record_kind == ACGPU_REC_MAP, stream));
     if (timed) HIP_TRY(hipEventRecord(ev[2], stream));
     unsigned long long *h_slot = tk ? tk->h_count : d.h_counter, *d_slot = nullptr;
     HIP_TRY(hipHostGetDevicePointer((void **)&d_slot, h_slot, 0));
-    HIP_TRY(launch_publish_result((const unsigned long long *)d.scan_tmp.p + scan_tiles_for(S.n_tiles), (const unsigned long long *)d.counter.p, d_slot,
+    HIP_TRY(launch_publish_result((const unsigned long long *)d.scan_tmp.p + scan_tiles_for(S.n_chunks), (const unsigned long long *)d.counter.p, d_slot,
                                   reinterpret_cast<acgpu_device_result *>(sh->d_result), stream));
     if (tk) {
         tk->shard = *sh;

@@ -480,6 +480,11 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
         t.hy_n_dense = nd;
         for (uint32_t s : bfs) if (!is_dense(s)) hid[s] = nd++;
         t.hy_n_states = N;
+        // what a state reports: the lengths of the keywords that end in it (bit L - 1), their number
+        std::vector<uint32_t> omask(N, 0u);
+        for (uint32_t s : bfs)
+            if (olen[s]) omask[s] = (1u << (olen[s] - 1)) | (olink[s] ? omask[olink[s]] : 0u); // (a suffix state comes earlier in BFS order)
+        auto n_out_of = [&](uint32_t target) { return (uint32_t)__builtin_popcount(omask[target]); };
         auto to = [&](uint32_t target) { return hid[target] | (olen[target] ? kHyOut : 0u); };
         t.hy_dense.assign((size_t)t.hy_n_dense * t.n_cls, 0u);
         t.hy_nodes.assign((size_t)(N - t.hy_n_dense) * 4, 0u);
@@ -488,9 +493,7 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
         for (uint32_t s : bfs) {
             const uint32_t h = hid[s];
             if (olen[s]) {
-                uint32_t m = 0;
-                for (uint32_t x = s; x != 0 && olen[x]; x = olink[x]) m |= 1u << (olen[x] - 1);
-                t.hy_mask[h] = m;
+                t.hy_mask[h] = omask[s];
                 t.hy_out[(size_t)h * 2] = oid[s];
                 t.hy_out[(size_t)h * 2 + 1] = olink[s] ? hid[olink[s]] : 0u;
             }
@@ -504,15 +507,16 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
                         if (f == 0) break;
                         f = fail[f];
                     }
-                    row[c] = target ? to(target) : 0u;
+                    row[c] = target ? to(target) | (n_out_of(target) << kHyDenseCountShift) : 0u; // (at most 32 keywords end in a state)
                 }
             } else {
                 uint32_t *node = &t.hy_nodes[(size_t)(h - t.hy_n_dense) * 4];
                 node[0] = hid[fail[s]];
                 uint32_t k = 1;
-                for (uint32_t ci = child_begin[s]; ci < child_begin[s + 1]; ci++) {
+                for (uint32_t ci = child_begin[s]; ci < child_begin[s + 1]; ci++, k++) {
                     const uint32_t c = child_ids[ci];
-                    node[k++] = (cls_of[nodes[c].unit] << 24) | to(c);
+                    node[k] = (cls_of[nodes[c].unit] << 24) | to(c);
+                    node[0] |= std::min(n_out_of(c), kHyNodeCountMany) << (kHyNodeCountShift + 3u * (k - 1u)); // (3 bits per edge)
                 }
             }
         }

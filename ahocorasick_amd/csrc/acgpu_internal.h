@@ -104,6 +104,9 @@ constexpr uint32_t kBitsRK = 9;            // first level: 2^9 entries indexed b
 constexpr uint32_t kBitsTabEntries = 1120; // 17.5 KiB of LDS: what 16 waves' text images leave
 constexpr uint32_t kHyOut = 1u << 23;   // HostTables::hy_dense / hy_nodes: the target state reports matches
 constexpr uint32_t kHyIdMask = kHyOut - 1u;
+constexpr uint32_t kHyDenseCountShift = 24;   // hy_dense: bits 24..29 = how many keywords the target state reports
+constexpr uint32_t kHyNodeCountShift = 23;    // hy_nodes word 0 (the fail state's h-id in bits 0..22): 3 bits per edge, the same number ...
+constexpr uint32_t kHyNodeCountMany = 7u;     // ... or this: seven and more (hy_mask says how many)
 constexpr uint32_t kBitsAlive = 1u << 24;
 constexpr uint32_t kBitsLeaf = 0, kBitsJunction = 1, kBitsCont = 2, kBitsDeep = 3;
 
@@ -151,7 +154,7 @@ struct HostTables {
     // ALL / SHORTEST: the automaton in the form k_ac_states walks (acgpu_build.cpp 6d; hy_n_states = 0: none).  States are numbered
     // anew ("h-ids", 23 bits): the DENSE group first -- the root, depth 1 and 2, every state with more than three children -- in
     // BFS order, each with a row of n_cls resolved transitions (fail links followed at build time); then the COMPACT group, one
-    // 16-byte node each: {fail state, three edges (class << 24 | child)} -- a miss goes to the fail state and looks at the same
+    // 16-byte node each: {fail state | counts, three edges (class << 24 | child)} -- a miss goes to the fail state and looks at the same
     // unit again.  Bit 23 (kHyOut) of a transition = the state it leads to reports matches.
     std::vector<uint32_t> hy_dense;  // hy_n_dense * n_cls
     std::vector<uint32_t> hy_nodes;  // 4 words per compact state

@@ -283,25 +283,24 @@ namespace acgpu {
 struct AcStatesLaunch {
     const uint16_t *d_hay;
     uint32_t n_units, own_begin, own_end;
-    uint32_t g0;          // own_begin & ~3: chunk k of k_ac_states covers [g0 + (k << chunk_log2), g0 + ((k + 1) << chunk_log2)), tile k of the record passes 4096 positions
+    uint32_t g0;          // own_begin & ~3: chunk k of k_ac_states covers [g0 + (k << chunk_log2), g0 + ((k + 1) << chunk_log2)), the record pass takes a chunk per wave
     uint32_t chunk_log2;  // k_ac_states: a lane's chunk (log2 units)
     uint32_t n_waves;     // k_ac_states: waves of 64 chunks from g0 on, up to own_end
     uint32_t halo;        // max_len - 1: a chunk's walk starts at the root this many units before it
     uint32_t hot_rows;    // leading rows of hy_dense kept in LDS
     uint32_t *d_state;    // per position: h-id of the automaton's state behind the unit | kHyOut
-    uint32_t n_tiles;
-    uint32_t *d_counts;            // per tile: its records
+    uint32_t n_chunks;
+    uint32_t *d_counts;            // per chunk: its records (k_ac_states)
     const uint64_t *d_offsets;     // their exclusive prefix sums
     void *d_out;
     uint64_t cap;
     int grid;
 };
-uint32_t ac_states_tile_units();
 uint32_t ac_states_chunk_units();
 uint32_t ac_states_lanes_per_cu();
 uint32_t ac_states_hot_rows(uint32_t n_cls, uint32_t n_dense, uint32_t page_bytes); // 0: does not fit
 hipError_t launch_ac_states(const DevTables &t, const AcStatesLaunch &l, bool range, hipStream_t stream);
-hipError_t launch_ac_states_out(const DevTables &t, const AcStatesLaunch &l, bool map, bool emit, hipStream_t stream);
+hipError_t launch_ac_states_out(const DevTables &t, const AcStatesLaunch &l, bool map, hipStream_t stream);
 } // namespace acgpu
 
 namespace acgpu {

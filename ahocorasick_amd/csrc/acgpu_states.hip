@@ -31,7 +31,6 @@ constexpr uint32_t kStRingWords = 2 * 64 * 4;   // per wave: [2 blocks][64 lanes
 constexpr uint32_t kStStageWords = 16 * 64;     // per wave: [16 positions][64 lanes] of states on their way to memory
 constexpr uint32_t kStFlushEvery = 8;           // iterations between two flushes of the staged states (at most 3 + 8 of 16 slots are in use)
 constexpr uint32_t kStRowBytesMax = 159 * 1024 - (kStBlock / kWave) * (kStRingWords + kStStageWords) * 4; // LDS left for rows and pages: 63 KiB
-constexpr uint32_t kStTileUnits = 4096;         // positions per wave of the record passes
 
 struct __attribute__((packed, aligned(2))) StUnits8 {
     uint32_t d[4];
@@ -66,6 +65,8 @@ __global__ __launch_bounds__(kStBlock, 4) void k_ac_states(DevTables T, AcStates
         uint32_t s = 0;
         uint32_t have_end = pos >> 3;   // blocks [have_end - 2, have_end) are in the ring (none yet)
         uint32_t flushed = wb;          // the states of [wb, flushed) are in memory, those of [flushed, pos) staged
+        uint32_t cnt = 0;               // records of the chunk
+        const uint32_t count_from = std::max(wb, L.own_begin);
         bool active = mine && pos < we;
         // The states go to memory through the staging slots, all lanes together every kStFlushEvery iterations: a store in the
         // loop's body would be waited for (stores and loads count in one counter here, and a wait for a gather's data
@@ -113,24 +114,33 @@ __global__ __launch_bounds__(kStBlock, 4) void k_ac_states(DevTables T, AcStates
                 const uint32_t e_lds = rows[std::min(idx, hot_last)];
                 const uint32_t e_glb = T.hy_dense[idx < row_words ? 0u : std::min(idx, dense_last)];
                 const uint4 nd = nodes[in_dense ? 0u : std::min(s - n_dense, node_last)];
-                uint32_t ns;
+                uint32_t ns, n_rep; // the state behind the unit (| kHyOut), how many keywords it reports
                 bool took = true;
                 if (in_dense) {
-                    ns = idx < row_words ? e_lds : e_glb;
+                    const uint32_t e = idx < row_words ? e_lds : e_glb;
+                    ns = e & 0xffffffu;
+                    n_rep = e >> kHyDenseCountShift;
                 } else if (cls == 0u) {
                     ns = 0u; // (a unit of no keyword: the root, whatever the state)
+                    n_rep = 0u;
                 } else if ((nd.y >> 24) == cls) {
                     ns = nd.y & 0xffffffu;
+                    n_rep = (nd.x >> kHyNodeCountShift) & 7u;
                 } else if ((nd.z >> 24) == cls) {
                     ns = nd.z & 0xffffffu;
+                    n_rep = (nd.x >> (kHyNodeCountShift + 3u)) & 7u;
                 } else if ((nd.w >> 24) == cls) {
                     ns = nd.w & 0xffffffu;
+                    n_rep = (nd.x >> (kHyNodeCountShift + 6u)) & 7u;
                 } else {
-                    ns = nd.x; // the fail state looks at this unit again
+                    ns = nd.x & kHyIdMask; // the fail state looks at this unit again
+                    n_rep = 0u;
                     took = false;
                 }
                 s = ns & kHyIdMask;
                 if (took) {
+                    if (!in_dense && n_rep == kHyNodeCountMany) n_rep = (uint32_t)__popc(T.hy_mask[s]); // (rare)
+                    if (pos >= count_from) cnt += n_rep;
                     if (pos >= wb) stage[((pos - wb) & 15u) * 64u + lane] = ns;
                     ++pos;
                     active = pos < we;
@@ -145,63 +155,110 @@ __global__ __launch_bounds__(kStBlock, 4) void k_ac_states(DevTables T, AcStates
         flush();
         if (mine && (we & 3u) && flushed < we) // the chunk's last, partial group (only where the owned range ends)
             for (uint32_t q = flushed; q < we; ++q) L.d_state[q] = stage[((q - wb) & 15u) * 64u + lane];
+        if (mine) L.d_counts[w * 64u + lane] = cnt;
         __builtin_amdgcn_wave_barrier();
     }
 }
 
-// records of the tiles: EMIT = false counts them (d_counts), EMIT = true writes them behind the tiles' prefix sums (d_offsets)
-template <bool MAP, bool EMIT>
+// the records of the chunks, behind the prefix sums of their counts: a wave per chunk, 256 positions per step (four per lane);
+// the states and masks of all (up to four) steps are asked for before the first is used
+template <bool MAP>
 __global__ __launch_bounds__(256) void k_ac_states_out(DevTables T, AcStatesLaunch L) {
+    constexpr int kSteps = (1 << kStChunkLog2) / 256;
     const uint32_t lane = lane_id();
-    const uint32_t tile = blockIdx.x * (256u / kWave) + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    if (tile >= L.n_tiles) return;
-    const uint64_t t0 = (uint64_t)L.g0 + (uint64_t)tile * kStTileUnits;
+    const uint32_t chunk = blockIdx.x * (256u / kWave) + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    if (chunk >= L.n_chunks) return;
+    const uint64_t cb = (uint64_t)L.g0 + ((uint64_t)chunk << L.chunk_log2);
     const uint2 *outs = reinterpret_cast<const uint2 *>(T.hy_out);
-    unsigned long long base = EMIT ? L.d_offsets[tile] : 0ull;
-    uint32_t acc = 0;
-    for (uint32_t step = 0; step < kStTileUnits / kWave; ++step) {
-        const uint64_t p64 = t0 + step * kWave + lane;
-        if (t0 + step * kWave >= L.own_end) break; // wave-uniform
-        const uint32_t p = (uint32_t)p64;
-        uint32_t v = 0;
-        if (p64 >= L.own_begin && p64 < L.own_end) v = L.d_state[p];
-        uint32_t m = (v & kHyOut) ? T.hy_mask[v & kHyIdMask] : 0u;
-        const uint32_t c = (uint32_t)__popc(m);
-        if (!EMIT) {
-            acc += c;
-        } else {
-            const uint32_t incl = wave_inclusive_scan(c);
-            const uint32_t total = __builtin_amdgcn_readlane(incl, kWave - 1);
-            if (total == 0) continue; // wave-uniform
-            unsigned long long at = base + (incl - c);
-            uint32_t t = v & kHyIdMask;
-            while (m != 0u) { // (a lane's records: longest first)
-                const uint32_t len = 32u - (uint32_t)__clz(m);
-                m &= ~(1u << (len - 1u));
+    unsigned long long base = L.d_offsets[chunk];
+    const uint32_t steps = (1u << L.chunk_log2) / 256u;
+    uint32_t sv[kSteps][4], m[kSteps][4];
+#pragma unroll
+    for (int st = 0; st < kSteps; ++st) {
+        const uint64_t p64 = cb + (uint32_t)st * 256u + lane * 4u;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if ((uint32_t)st < steps) {
+            if (p64 + 4u <= L.own_end) {
+                v = *reinterpret_cast<const uint4 *>(L.d_state + p64);
+            } else if (p64 < L.own_end) { // the owned range's last, partial group
+                v.x = L.d_state[p64];
+                if (p64 + 1u < L.own_end) v.y = L.d_state[p64 + 1u];
+                if (p64 + 2u < L.own_end) v.z = L.d_state[p64 + 2u];
+            }
+            if (p64 < L.own_begin) { // (the first group reaches up to three positions in front of the owned range)
+                if (p64 + 0u < L.own_begin) v.x = 0u;
+                if (p64 + 1u < L.own_begin) v.y = 0u;
+                if (p64 + 2u < L.own_begin) v.z = 0u;
+                if (p64 + 3u < L.own_begin) v.w = 0u;
+            }
+        }
+        sv[st][0] = v.x; sv[st][1] = v.y; sv[st][2] = v.z; sv[st][3] = v.w;
+    }
+#pragma unroll
+    for (int st = 0; st < kSteps; ++st)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m[st][k] = T.hy_mask[(sv[st][k] & kHyOut) ? (sv[st][k] & kHyIdMask) : 0u]; // (the root reports nothing)
+    // A step's records are written by ROUNDS of 64 consecutive records, one per lane (coalesced stores, no loop over a lane's own
+    // records: with 0.3 to 6 records per four positions such a loop runs as long as the busiest of 64 lanes): record j of the step
+    // belongs to the lane whose prefix interval holds j (binary search over the prefix sums by lane reads), is the
+    // (j - prefix)-th of that lane's four masks in order, longest first within a mask.
+    int32_t *out = reinterpret_cast<int32_t *>(L.d_out);
+#pragma unroll
+    for (int st = 0; st < kSteps; ++st) {
+        const uint32_t c0 = (uint32_t)__popc(m[st][0]), c1 = c0 + (uint32_t)__popc(m[st][1]), c2 = c1 + (uint32_t)__popc(m[st][2]),
+                       c = c2 + (uint32_t)__popc(m[st][3]);
+        const uint32_t incl = wave_inclusive_scan(c);
+        const uint32_t total = __builtin_amdgcn_readlane(incl, kWave - 1);
+        if (total == 0) continue; // wave-uniform
+        const uint32_t p_step = (uint32_t)(cb + (uint32_t)st * 256u);
+        for (uint32_t j0 = 0; j0 < total; j0 += kWave) {
+            const uint32_t j = j0 + lane;
+            uint32_t src = 0; // the first lane whose inclusive prefix exceeds j (lanes beyond the step's records: 63, unused)
+#pragma unroll
+            for (uint32_t b = 32; b >= 1; b >>= 1) {
+                const uint32_t v = (uint32_t)__shfl((int)incl, (int)(src + b - 1u));
+                if (v <= j && src + b < kWave) src += b;
+            }
+            const uint32_t s_incl = (uint32_t)__shfl((int)incl, (int)src), s_c = (uint32_t)__shfl((int)c, (int)src);
+            const uint32_t s_c0 = (uint32_t)__shfl((int)c0, (int)src), s_c1 = (uint32_t)__shfl((int)c1, (int)src), s_c2 = (uint32_t)__shfl((int)c2, (int)src);
+            uint32_t r = j - (s_incl - s_c); // the record's rank among the source lane's
+            const uint32_t k = r < s_c0 ? 0u : r < s_c1 ? 1u : r < s_c2 ? 2u : 3u;
+            r -= k == 0u ? 0u : k == 1u ? s_c0 : k == 2u ? s_c1 : s_c2;
+            // (a lane reads the mask / state number k of ITS source: k differs from lane to lane, so the four candidates travel)
+            uint32_t mk, t;
+            {
+                const uint32_t a0 = (uint32_t)__shfl((int)m[st][0], (int)src), a1 = (uint32_t)__shfl((int)m[st][1], (int)src);
+                const uint32_t a2 = (uint32_t)__shfl((int)m[st][2], (int)src), a3 = (uint32_t)__shfl((int)m[st][3], (int)src);
+                mk = k == 0u ? a0 : k == 1u ? a1 : k == 2u ? a2 : a3;
+            }
+            if (MAP) {
+                const uint32_t b0 = (uint32_t)__shfl((int)sv[st][0], (int)src), b1 = (uint32_t)__shfl((int)sv[st][1], (int)src);
+                const uint32_t b2 = (uint32_t)__shfl((int)sv[st][2], (int)src), b3 = (uint32_t)__shfl((int)sv[st][3], (int)src);
+                t = (k == 0u ? b0 : k == 1u ? b1 : k == 2u ? b2 : b3) & kHyIdMask;
+            }
+            if (j < total) {
+                for (uint32_t i = 0; i < r; ++i) { // the r longer keywords that end here come first
+                    mk &= ~(0x80000000u >> __clz(mk));
+                    if (MAP) t = outs[t].y;
+                }
+                const uint32_t len = 32u - (uint32_t)__clz(mk);
+                const uint32_t end = p_step + src * 4u + k + 1u;
+                const unsigned long long at = base + j;
                 if (at < L.cap) {
                     if (MAP) {
-                        const uint2 o = outs[t];
-                        int32_t *r = reinterpret_cast<int32_t *>(L.d_out) + at * 3;
-                        r[0] = (int32_t)(p + 1u - len);
-                        r[1] = (int32_t)(p + 1u);
-                        r[2] = (int32_t)o.x;
-                        t = o.y;
+                        out[at * 3] = (int32_t)(end - len);
+                        out[at * 3 + 1] = (int32_t)end;
+                        out[at * 3 + 2] = (int32_t)outs[t].x;
                     } else {
-                        reinterpret_cast<int2 *>(L.d_out)[at] = make_int2((int)(p + 1u - len), (int)(p + 1u));
+                        reinterpret_cast<int2 *>(out)[at] = make_int2((int)(end - len), (int)end);
                     }
                 }
-                ++at;
             }
-            base += total;
         }
-    }
-    if (!EMIT) {
-        for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
-        if (lane == 0) L.d_counts[tile] = acc;
+        base += total;
     }
 }
 
-uint32_t ac_states_tile_units() { return kStTileUnits; }
 uint32_t ac_states_chunk_units() { return 1u << kStChunkLog2; }
 uint32_t ac_states_lanes_per_cu() { return kStBlock; }
 // rows of the dense group the kernel can keep in LDS next to `page_bytes` of class pages (0: range classes)
@@ -220,15 +277,10 @@ hipError_t launch_ac_states(const DevTables &t, const AcStatesLaunch &l, bool ra
     return hipGetLastError();
 }
 
-hipError_t launch_ac_states_out(const DevTables &t, const AcStatesLaunch &l, bool map, bool emit, hipStream_t stream) {
-    const dim3 grid((l.n_tiles + 3) / 4), block(256);
-    if (map) {
-        if (emit) hipLaunchKernelGGL((k_ac_states_out<true, true>), grid, block, 0, stream, t, l);
-        else hipLaunchKernelGGL((k_ac_states_out<true, false>), grid, block, 0, stream, t, l);
-    } else {
-        if (emit) hipLaunchKernelGGL((k_ac_states_out<false, true>), grid, block, 0, stream, t, l);
-        else hipLaunchKernelGGL((k_ac_states_out<false, false>), grid, block, 0, stream, t, l);
-    }
+hipError_t launch_ac_states_out(const DevTables &t, const AcStatesLaunch &l, bool map, hipStream_t stream) {
+    const dim3 grid((l.n_chunks + 3) / 4), block(256);
+    if (map) hipLaunchKernelGGL((k_ac_states_out<true>), grid, block, 0, stream, t, l);
+    else hipLaunchKernelGGL((k_ac_states_out<false>), grid, block, 0, stream, t, l);
     return hipGetLastError();
 }
 

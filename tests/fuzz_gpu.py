@@ -32,7 +32,7 @@ ALPHABETS = [
     [ord(c) for c in "abcdefikABCDEFIK 0129-"] + [0x0130, 0x212A],                           # phrases: merged stretches, fold exceptions
 ]
 DEFAULTS = {"chunk_units": 0, "lds_table_bytes": 127 * 1024, "force_sparse": 0, "force_kernel": 0, "region_units": 0,
-            "rdense_budget_bytes": 256 << 20, "tile_debug": 0, "longest_form": 0}
+            "rdense_budget_bytes": 256 << 20, "tile_debug": 0, "longest_form": 0, "all_form": 0}
 
 
 def dev_match(a, d_hay, n, cap, with_ids=True, **kw):
@@ -91,6 +91,8 @@ def one_case(rng, it):
         knobs["tile_debug"] = 4194304  # chain marking in one pass (Shortest, sparse Longest, WholeWordLongest) on small inputs too
     if rng.integers(0, 2):
         knobs["tile_debug"] |= 1 << 41  # short haystacks through the general path instead of the one-launch form
+    if fam in (0, 3) and rng.integers(0, 2):
+        knobs["all_form"] = int(rng.choice([6, 6, 4, 1]))  # k_ac_states for short texts too, whatever / only by what the pool's last call found / never
     if fam == 1 and rng.integers(0, 2):
         knobs["longest_form"] = int(rng.choice([4, 4, 5, 6]))  # k_longest_bits / k_longest_follow for short texts too (5, 6: one of them never)
     for k, v in knobs.items():
