@@ -273,7 +273,7 @@ int match_all_states(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int re
     S.n_waves = (uint32_t)((chunks + 63) / 64);
     S.n_chunks = (uint32_t)chunks;
     if ((rc = d.counter.ensure(64))) return rc;
-    if ((rc = d.statebuf.ensure((size_t)sh->own_end * 4 + 64))) return rc;
+    if ((rc = d.statebuf.ensure((((size_t)S.n_waves * 64) << S.chunk_log2) * 4 + 64))) return rc;
     if ((rc = d.chunk_counts.ensure((size_t)S.n_chunks * 4))) return rc;
     if ((rc = d.offsets.ensure((size_t)S.n_chunks * 8))) return rc;
     if ((rc = d.scan_tmp.ensure(((size_t)S.n_chunks / 2048 + 2) * 8))) return rc;

@@ -474,11 +474,30 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
         for (uint32_t u = 0; u < 65536; u++)
             if (cls_of[u]) cls_unit[cls_of[u]] = (uint16_t)u;
         auto is_dense = [&](uint32_t s) { return nodes[s].depth <= 2 || child_begin[s + 1] - child_begin[s] > 3; };
+        // numbering: the dense group by the size of the subtree below the state (the first rows are the ones kept in LDS); the compact group in the order
+        // of a depth-first walk that takes the child with the most keywords below it first -- a walk down a word's tail then
+        // reads consecutive nodes (two per 32-byte sector, eight per line) instead of one line per unit
         std::vector<uint32_t> hid(N);
         uint32_t nd = 0;
-        for (uint32_t s : bfs) if (is_dense(s)) hid[s] = nd++;
-        t.hy_n_dense = nd;
-        for (uint32_t s : bfs) if (!is_dense(s)) hid[s] = nd++;
+        {
+            std::vector<uint32_t> below(N, 1u); // nodes of the subtree: what a text of the dictionary's words visits most has most below it
+            for (size_t i = bfs.size(); i-- > 1;) below[nodes[bfs[i]].parent] += below[bfs[i]];
+            std::vector<uint32_t> dn;
+            for (uint32_t s : bfs) if (is_dense(s)) dn.push_back(s);
+            std::stable_sort(dn.begin(), dn.end(), [&](uint32_t a, uint32_t b) { return below[a] > below[b]; }); // (the root first)
+            for (uint32_t s : dn) hid[s] = nd++;
+            t.hy_n_dense = nd;
+            std::vector<uint32_t> stack, kids;
+            stack.push_back(0);
+            while (!stack.empty()) {
+                const uint32_t s = stack.back();
+                stack.pop_back();
+                if (!is_dense(s)) hid[s] = nd++;
+                kids.assign(child_ids.begin() + child_begin[s], child_ids.begin() + child_begin[s + 1]);
+                std::sort(kids.begin(), kids.end(), [&](uint32_t a, uint32_t b) { return below[a] != below[b] ? below[a] < below[b] : a > b; });
+                for (uint32_t c : kids) stack.push_back(c); // (the heaviest child is popped first)
+            }
+        }
         t.hy_n_states = N;
         // what a state reports: the lengths of the keywords that end in it (bit L - 1), their number
         std::vector<uint32_t> omask(N, 0u);

@@ -288,7 +288,7 @@ struct AcStatesLaunch {
     uint32_t n_waves;     // k_ac_states: waves of 64 chunks from g0 on, up to own_end
     uint32_t halo;        // max_len - 1: a chunk's walk starts at the root this many units before it
     uint32_t hot_rows;    // leading rows of hy_dense kept in LDS
-    uint32_t *d_state;    // per position: h-id of the automaton's state behind the unit | kHyOut
+    uint32_t *d_state;    // per position: h-id of the automaton's state behind the unit | kHyOut, in the order [wave][group of 4 units][lane][4] (st_index)
     uint32_t n_chunks;
     uint32_t *d_counts;            // per chunk: its records (k_ac_states)
     const uint64_t *d_offsets;     // their exclusive prefix sums

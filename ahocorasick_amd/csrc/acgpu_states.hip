@@ -32,6 +32,13 @@ constexpr uint32_t kStStageWords = 16 * 64;     // per wave: [16 positions][64 l
 constexpr uint32_t kStFlushEvery = 8;           // iterations between two flushes of the staged states (at most 3 + 8 of 16 slots are in use)
 constexpr uint32_t kStRowBytesMax = 159 * 1024 - (kStBlock / kWave) * (kStRingWords + kStStageWords) * 4; // LDS left for rows and pages: 63 KiB
 
+// Where the state behind the o-th unit of the chunk of lane l of wave w lies: [wave][group of four units][lane][4] -- lanes that
+// walk at the same pace store a kilobyte of consecutive memory with one instruction (64 x 16 bytes), where chunk-major order
+// would touch 64 lines; the record pass reads a chunk's groups a kilobyte apart (the 64 chunks of a wave on one XCD: its L2 holds the rows).
+__device__ __forceinline__ size_t st_index(uint32_t chunk_log2, uint32_t w, uint32_t l, uint32_t o) {
+    return ((((size_t)w << (chunk_log2 - 2u)) + (o >> 2)) * 64u + l) * 4u + (o & 3u);
+}
+
 struct __attribute__((packed, aligned(2))) StUnits8 {
     uint32_t d[4];
 };
@@ -77,7 +84,7 @@ __global__ __launch_bounds__(kStBlock, 4) void k_ac_states(DevTables T, AcStates
                     const uint32_t o = flushed - wb;
                     const uint4 v = make_uint4(stage[((o + 0u) & 15u) * 64u + lane], stage[((o + 1u) & 15u) * 64u + lane],
                                                stage[((o + 2u) & 15u) * 64u + lane], stage[((o + 3u) & 15u) * 64u + lane]);
-                    *reinterpret_cast<uint4 *>(L.d_state + flushed) = v;
+                    *reinterpret_cast<uint4 *>(L.d_state + st_index(L.chunk_log2, w, lane, o)) = v;
                     flushed += 4u;
                 }
             }
@@ -154,7 +161,7 @@ __global__ __launch_bounds__(kStBlock, 4) void k_ac_states(DevTables T, AcStates
         }
         flush();
         if (mine && (we & 3u) && flushed < we) // the chunk's last, partial group (only where the owned range ends)
-            for (uint32_t q = flushed; q < we; ++q) L.d_state[q] = stage[((q - wb) & 15u) * 64u + lane];
+            for (uint32_t q = flushed; q < we; ++q) L.d_state[st_index(L.chunk_log2, w, lane, q - wb)] = stage[((q - wb) & 15u) * 64u + lane];
         if (mine) L.d_counts[w * 64u + lane] = cnt;
         __builtin_amdgcn_wave_barrier();
     }
@@ -166,7 +173,10 @@ template <bool MAP>
 __global__ __launch_bounds__(256) void k_ac_states_out(DevTables T, AcStatesLaunch L) {
     constexpr int kSteps = (1 << kStChunkLog2) / 256;
     const uint32_t lane = lane_id();
-    const uint32_t chunk = blockIdx.x * (256u / kWave) + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    // the 16 workgroups that take the 64 chunks of one wave of k_ac_states sit on ONE XCD (workgroups go round the eight XCDs)
+    const uint32_t bq = blockIdx.x / 8u;
+    const uint32_t kw = (bq / 16u) * 8u + blockIdx.x % 8u, kl = (bq % 16u) * 4u + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const uint32_t chunk = kw * 64u + kl;
     if (chunk >= L.n_chunks) return;
     const uint64_t cb = (uint64_t)L.g0 + ((uint64_t)chunk << L.chunk_log2);
     const uint2 *outs = reinterpret_cast<const uint2 *>(T.hy_out);
@@ -178,12 +188,13 @@ __global__ __launch_bounds__(256) void k_ac_states_out(DevTables T, AcStatesLaun
         const uint64_t p64 = cb + (uint32_t)st * 256u + lane * 4u;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if ((uint32_t)st < steps) {
+            const size_t at = st_index(L.chunk_log2, kw, kl, (uint32_t)st * 256u + lane * 4u);
             if (p64 + 4u <= L.own_end) {
-                v = *reinterpret_cast<const uint4 *>(L.d_state + p64);
+                v = *reinterpret_cast<const uint4 *>(L.d_state + at);
             } else if (p64 < L.own_end) { // the owned range's last, partial group
-                v.x = L.d_state[p64];
-                if (p64 + 1u < L.own_end) v.y = L.d_state[p64 + 1u];
-                if (p64 + 2u < L.own_end) v.z = L.d_state[p64 + 2u];
+                v.x = L.d_state[at];
+                if (p64 + 1u < L.own_end) v.y = L.d_state[at + 1u];
+                if (p64 + 2u < L.own_end) v.z = L.d_state[at + 2u];
             }
             if (p64 < L.own_begin) { // (the first group reaches up to three positions in front of the owned range)
                 if (p64 + 0u < L.own_begin) v.x = 0u;
@@ -278,7 +289,7 @@ hipError_t launch_ac_states(const DevTables &t, const AcStatesLaunch &l, bool ra
 }
 
 hipError_t launch_ac_states_out(const DevTables &t, const AcStatesLaunch &l, bool map, hipStream_t stream) {
-    const dim3 grid((l.n_chunks + 3) / 4), block(256);
+    const dim3 grid(((l.n_waves + 7) / 8) * 8 * 16), block(256); // (16 workgroups per wave of k_ac_states, waves in groups of eight: see the kernel)
     if (map) hipLaunchKernelGGL((k_ac_states_out<true>), grid, block, 0, stream, t, l);
     else hipLaunchKernelGGL((k_ac_states_out<false>), grid, block, 0, stream, t, l);
     return hipGetLastError();
