@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 def _reset_tunables():
     yield
     for k, v in [("chunk_units", 0), ("blocks_per_cu", 1), ("lds_table_bytes", 127 * 1024), ("force_sparse", 0),
-                 ("force_kernel", 0), ("region_units", 0), ("ww_first_seed", 0), ("tile_debug", 0)]:
+                 ("force_kernel", 0), ("region_units", 0), ("ww_first_seed", 0), ("tile_debug", 0), ("all_form", 0)]:
         N.set_tunable(k, v)
 
 
@@ -2175,6 +2175,7 @@ def test_large_dictionaries_second_level_in_global_memory(shape):
     want = oracle_parallel(orc, hay, "ac", 12, cap_per_unit=0.3)
     a = Automaton(N.MODE_ALL, kws, cs)
     d_hay = torch.from_numpy(hay.view(np.int16)).cuda()
+    N.set_tunable("all_form", 1)  # (the forms of the tile kernel are the subject: not k_ac_states, whatever a call finds -- "k" is a keyword)
     got, prof = _dev_match(a, d_hay, n, True, len(want) + 16, profile=True)
     assert prof["scan_kernel"].startswith("k_ac_tile<4, ") and len(prof["scan_kernel"]) == 63, prof["scan_kernel"]  # (the BIG form: ten arguments)
     assert got.shape == want.shape and (got == want).all()
