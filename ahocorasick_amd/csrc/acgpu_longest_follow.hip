@@ -30,6 +30,7 @@ namespace acgpu {
 constexpr int kFolBlock = 1024;                 // 16 waves; two workgroups per CU
 constexpr uint32_t kFolSegUnits = 1024;         // a lane's segment (LongestFollowLaunch::seg_log2 = 10; 9 for texts that would not fill the chip)
 constexpr uint32_t kFolRingWords = 4 * 64 * 4;  // per wave: [4 blocks][64 lanes] of 16 bytes
+constexpr uint32_t kFolFlushEvery = 8;          // iterations between two flushes of the finished bitmap words
 constexpr uint32_t kFolRowBytesMax = 76 * 1024 - (kFolBlock / kWave) * kFolRingWords * 4; // LDS left for rows and pages: 12 KiB
 
 struct __attribute__((packed, aligned(2))) FolUnits8 { // 8 UTF-16 units at a unit address that is a multiple of 8 (16-byte aligned buffers)
@@ -48,6 +49,10 @@ __device__ __forceinline__ uint32_t fol_walk(const DevTables &T, const LongestFo
     uint32_t have_end = p >> 3;              // blocks [have_end - 4, have_end) are in the ring (none yet)
     uint32_t sw = 0, swi = seg_first_word;   // MARK: the word of start bits being collected, its index; words below it are written
     uint32_t ew = 0, ewi = seg_first_word;   // the same for the end bits (merged with atomicOr: an end may lie in another lane's word)
+    // MARK: a finished bitmap word waits here for the next flush -- all lanes store together every kFolFlushEvery iterations: a
+    // store in the body would be waited for by the next gather (loads and stores share one counter, and a store's
+    // acknowledgement takes longer than a gather), and with 64 chains at 64 different places some lane stores in every iteration
+    uint32_t pend_sw = 0, pend_swi = ~0u, pend_ew = 0, pend_ewi = ~0u, it = 0;
     bool active = p < plim;
     while (__any(active)) {
         const uint32_t x = p + d, xb = x >> 3;
@@ -88,7 +93,9 @@ __device__ __forceinline__ uint32_t fol_walk(const DevTables &T, const LongestFo
                         ++cnt;
                         const uint32_t wi = p >> 5;
                         if (wi != swi) {
-                            L.d_bits[swi] = sw;
+                            if (pend_swi != ~0u) L.d_bits[pend_swi] = pend_sw; // (rare: two words within one flush interval)
+                            pend_sw = sw;
+                            pend_swi = swi;
                             for (uint32_t z = swi + 1u; z < wi; ++z) L.d_bits[z] = 0u;
                             sw = 0u;
                             swi = wi;
@@ -96,7 +103,11 @@ __device__ __forceinline__ uint32_t fol_walk(const DevTables &T, const LongestFo
                         sw |= 1u << (p & 31u);
                         const uint32_t q = p + best - 1u, qi = q >> 5;
                         if (qi != ewi) {
-                            if (ew) atomicOr(&L.d_ebits[ewi], ew);
+                            if (ew) {
+                                if (pend_ewi != ~0u) atomicOr(&L.d_ebits[pend_ewi], pend_ew);
+                                pend_ew = ew;
+                                pend_ewi = ewi;
+                            }
                             ew = 0u;
                             ewi = qi;
                         }
@@ -123,12 +134,20 @@ __device__ __forceinline__ uint32_t fol_walk(const DevTables &T, const LongestFo
                 }
             }
         }
+        if (MARK && (++it & (kFolFlushEvery - 1u)) == 0u) {
+            if (pend_swi != ~0u) L.d_bits[pend_swi] = pend_sw;
+            if (pend_ewi != ~0u) atomicOr(&L.d_ebits[pend_ewi], pend_ew);
+            pend_swi = ~0u;
+            pend_ewi = ~0u;
+        }
         if (want_load && keep && have_end == load_b) { // (behind the gather's wait: the block has arrived with it; not if the ring has just started over)
             ring[(load_b & 3u) * 64u + lane] = blk;
             have_end = load_b + 1u;
         }
     }
     if (MARK) {
+        if (pend_swi != ~0u) L.d_bits[pend_swi] = pend_sw;
+        if (pend_ewi != ~0u) atomicOr(&L.d_ebits[pend_ewi], pend_ew);
         if (swi < seg_end_word) {
             L.d_bits[swi] = sw;
             for (uint32_t z = swi + 1u; z < seg_end_word; ++z) L.d_bits[z] = 0u;

@@ -50,6 +50,7 @@ def stdout_to_stderr():
 
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+ATTAINABLE_GBPS = 6200.0  # the best pure read of a shard measured on the chip (roofline.attainable of the default run): what a floor is priced at
 
 
 def main():
@@ -399,8 +400,10 @@ def main_readme(args):
                 kern = prof["scan_kernel"]
         gib = n_units * 2 / float(1 << 30)
         ab = 2 * n_units + 8 * nm
+        # floor: the algorithmic bytes (2 per unit read + 8 per record written) at the best pure read rate measured on this chip
         r.update(ms_per_gib=round(float(np.median(ms)) / gib, 4), kernel=kern, matches_per_gib=int(nm / gib),
-                 roofline_frac=round(ab / (float(np.median(ms)) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4))
+                 roofline_frac=round(ab / (float(np.median(ms)) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                 floor_ms_per_gib=round(ab / gib / (ATTAINABLE_GBPS * 1e9) * 1e3, 3))
         if not args.no_cpu_baseline:  # the device records of a prefix against the oracle
             k = min(n_units, 1 << 22)
             want = orc.match(block[:k], cap=4 * k)[:, :2]
