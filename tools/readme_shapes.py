@@ -12,7 +12,7 @@ d_hay = torch.from_numpy(block.view(np.int16)).cuda().repeat(n // block.size)
 st = torch.cuda.current_stream().cuda_stream
 for label, kws in (("all 235886", words), ("without the single letters", [w for w in words if len(w) > 1]), ("lengths >= 3", [w for w in words if len(w) > 2]),
                    ("lower-case, lengths >= 4", [w for w in words if len(w) > 3 and w[0] >= 97])):
-    for fk in (0, 9):  # 9: k_ac_states (all_form 2); 1, 2: the DFA chunk scan, the tile kernel whatever the automatic choice
+    for fk in (0, 1, 9):  # 0: the tile kernel (all_form 1: never k_ac_states), 1: the DFA chunk scan, 9: k_ac_states (all_form 2)
         N.set_tunable("force_kernel", fk if fk < 9 else 0)
         N.set_tunable("all_form", 2 if fk == 9 else 1)
         a = Automaton(N.MODE_ALL, kws, True)
