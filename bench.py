@@ -378,10 +378,13 @@ def main_readme(args):
             r["cpu_port_us_per_call"] = round((time.perf_counter() - t0) / 2000 * 1e6, 2)
         # (ii) 10 000 paragraphs through the batch entry
         hs = [para] * 10000
-        auto.match_batch(hs[:100], False)
-        t0 = time.perf_counter()
-        b = auto.match_batch(hs, False, cap=len(got) * 10000 + 16)
-        r["us_per_haystack_batched"] = round((time.perf_counter() - t0) / 10000 * 1e6, 3)
+        b = auto.match_batch(hs, False, cap=len(got) * 10000 + 16)  # (the first call of a size allocates its staging buffers)
+        tb = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            b = auto.match_batch(hs, False, cap=len(got) * 10000 + 16)
+            tb.append((time.perf_counter() - t0) / 10000)
+        r["us_per_haystack_batched"] = round(float(np.median(tb)) * 1e6, 3)
         assert len(b) == len(got) * 10000
         # (iii) a device-resident text of dictionary words
         # (the word list holds the 52 single letters: AhoCorasickSet reports every letter of the text, as the reference does)
