@@ -356,15 +356,26 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
     // Texts in which this dictionary matches densely (natural words in natural text: every filter passes, every verification walk
     // is long): the automaton's state behind every unit (k_ac_states over the compact automaton of acgpu_build.cpp 6d), then the
     // records from the states (acgpu_states.hip).  Its cost does not depend on the text (~ one gather per unit), the tile kernel's
-    // does: what this pool's last call found decides (records per unit; the first call of a pool takes the tile kernel).
+    // does: what this pool's last call found decides (records per unit; a pool's first call looks at the beginning of a long text,
+    // and takes the tile kernel for a short one or when it may not wait).
     // Tunable all_form, bits: 1 = never, 2 = whatever the last call found, 4 = also for short texts.
     {
         const int64_t aform = tunables().all_form;
         const size_t st_pages = (!t.range_cls && !t.dfa_pages.empty()) ? t.dfa_pages.size() * 2 : 0;
         const uint32_t st_hot = (!ww && !Tov && t.hy_n_states && (t.range_cls || st_pages > 0))
                                     ? ac_states_hot_rows(t.n_cls, t.hy_n_dense, (uint32_t)st_pages) : 0;
-        if (st_hot > 0 && !(aform & 1) && tunables().force_kernel == 0 && !fused_only && (own_len >= (1ull << 20) || (aform & 4)) &&
-            ((aform & 2) || d.all_density >= kStatesFormDensity))
+        const bool usable = st_hot > 0 && !(aform & 1) && tunables().force_kernel == 0 && !fused_only && (own_len >= (1ull << 20) || (aform & 4));
+        // a pool that knows nothing yet and a long text (a call that may wait): the first 2^20 units of the shard are counted
+        // first (this form, no records written: 60 us) -- the whole text then takes the form its beginning suggests
+        if (usable && !tk && d.all_density < 0.0 && !(aform & 2) && own_len >= (1ull << 23)) {
+            acgpu_shard head = *sh;
+            head.own_end = head.own_begin + (1ull << 20);
+            head.d_result = nullptr;
+            uint64_t n_head = 0;
+            const int prc = match_all_states(a, d, &head, record_kind, d_out, 0, &n_head, stream, nullptr, nullptr, st_hot);
+            if (prc != ACGPU_OK && prc != ACGPU_E_OVERFLOW) return prc;
+        }
+        if (usable && ((aform & 2) || d.all_density >= kStatesFormDensity))
             return match_all_states(a, d, sh, record_kind, d_out, cap, n_out, stream, prof, tk, st_hot);
     }
     int rc;

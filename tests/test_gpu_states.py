@@ -82,6 +82,20 @@ def test_states_form_is_taken_when_the_pools_last_call_found_dense_matches(words
     assert kname != "k_ac_states" and got.shape[0] == 0
 
 
+def test_states_form_a_pools_first_call_on_a_long_text_counts_its_beginning(words):
+    a = Automaton(N.MODE_ALL, words, True)
+    hay = synth.readme_text(12, (1 << 23) + 4321, words)
+    got, kname = _run(a, hay, False, cap=hay.size * 2)
+    want = Oracle(FAM_AC, words).match(hay, cap=hay.size * 2)[:, :2]
+    assert kname == "k_ac_states" and got.shape == want.shape and (got == want).all()
+    b = Automaton(N.MODE_ALL, words, True)  # ... and a text that begins without matches keeps the tile kernel
+    hay2 = hay.copy()
+    hay2[: (1 << 20) + 100] = ord("#")
+    got, kname = _run(b, hay2, False, cap=hay.size * 2)
+    want = Oracle(FAM_AC, words).match(hay2, cap=hay.size * 2)[:, :2]
+    assert kname != "k_ac_states" and got.shape == want.shape and (got == want).all()
+
+
 def test_states_form_case_insensitive_dictionary_classes_from_lds_pages(words):
     a = Automaton(N.MODE_ALL, words, False)
     orc = Oracle(FAM_AC, words, case_sensitive=False, lower=LOWER)
