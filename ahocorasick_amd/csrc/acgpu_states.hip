@@ -17,6 +17,7 @@
 //    mask's bits (longest first), Map records walk hy_out for the keyword ids.
 // Bound by the gathers of k_ac_states (one per unit and fail hop) and by the record stores, not by the text stream.
 #include <algorithm>
+#include <cstdio>
 
 #include <hip/hip_runtime.h>
 
@@ -27,10 +28,11 @@ namespace acgpu {
 
 constexpr int kStBlock = 1024;                  // 16 waves, one workgroup per CU
 constexpr uint32_t kStChunkLog2 = 10;           // a lane's chunk: 1024 units
-constexpr uint32_t kStRingWords = 2 * 64 * 4;   // per wave: [2 blocks][64 lanes] of 16 bytes of text
+constexpr uint32_t kStRingWords = 4 * 64 * 4;   // per wave: [4 blocks][64 lanes] of 16 bytes of text
+constexpr uint32_t kStRefillEvery = 16;         // iterations between two refills of the rings
 constexpr uint32_t kStStageWords = 16 * 64;     // per wave: [16 positions][64 lanes] of states on their way to memory
 constexpr uint32_t kStFlushEvery = 8;           // iterations between two flushes of the staged states (at most 3 + 8 of 16 slots are in use)
-constexpr uint32_t kStRowBytesMax = 159 * 1024 - (kStBlock / kWave) * (kStRingWords + kStStageWords) * 4; // LDS left for rows and pages: 63 KiB
+constexpr uint32_t kStRowBytesMax = 159 * 1024 - (kStBlock / kWave) * (kStRingWords + kStStageWords) * 4; // LDS left for rows and pages: 31 KiB
 
 // Where the state behind the o-th unit of the chunk of lane l of wave w lies: [wave][group of four units][lane][4] -- lanes that
 // walk at the same pace store a kilobyte of consecutive memory with one instruction (64 x 16 bytes), where chunk-major order
@@ -42,6 +44,15 @@ __device__ __forceinline__ size_t st_index(uint32_t chunk_log2, uint32_t w, uint
 struct __attribute__((packed, aligned(2))) StUnits8 {
     uint32_t d[4];
 };
+
+#ifdef ACGPU_TIMING
+__device__ unsigned long long g_st_timing[8]; // s_memtime ticks (100 MHz) per wave: refills, flushes, steps up to the transition, the rest, total, iterations, waves
+#define ST_T0() const unsigned long long t0_ = __builtin_amdgcn_s_memtime()
+#define ST_ACC(i) tm[i] += __builtin_amdgcn_s_memtime() - t0_
+#else
+#define ST_T0()
+#define ST_ACC(i)
+#endif
 
 template <bool RANGE>
 __global__ __launch_bounds__(kStBlock, 4) void k_ac_states(DevTables T, AcStatesLaunch L) {
@@ -70,7 +81,7 @@ __global__ __launch_bounds__(kStBlock, 4) void k_ac_states(DevTables T, AcStates
         const uint32_t we = (uint32_t)std::min<uint64_t>(wb64 + (1u << L.chunk_log2), L.own_end); // one past the last
         uint32_t pos = wb > L.halo ? wb - L.halo : 0u;                           // the root stands here
         uint32_t s = 0;
-        uint32_t have_end = pos >> 3;   // blocks [have_end - 2, have_end) are in the ring (none yet)
+        uint32_t have_end = pos >> 3;   // blocks [have_end - 4, have_end) are in the ring (none yet)
         uint32_t flushed = wb;          // the states of [wb, flushed) are in memory, those of [flushed, pos) staged
         uint32_t cnt = 0;               // records of the chunk
         const uint32_t count_from = std::max(wb, L.own_begin);
@@ -89,25 +100,54 @@ __global__ __launch_bounds__(kStBlock, 4) void k_ac_states(DevTables T, AcStates
                 }
             }
         };
-        uint32_t it = 0;
-        while (__any(active)) {
-            const uint32_t xb = pos >> 3;
-            const bool want_load = active && have_end <= xb + 1u && have_end * 8u < nu;
-            uint4 blk = make_uint4(0u, 0u, 0u, 0u);
-            if (want_load) {
-                const uint32_t b0 = have_end * 8u;
-                if (b0 + 8u <= nu) {
-                    const StUnits8 v = *reinterpret_cast<const StUnits8 *>(hay + b0);
-                    blk = make_uint4(v.d[0], v.d[1], v.d[2], v.d[3]);
-                } else { // the buffer's last, partial block
-                    uint32_t t4[4] = {0u, 0u, 0u, 0u};
-                    for (uint32_t k = 0; k < 8u && b0 + k < nu; ++k) t4[k >> 1] |= (uint32_t)hay[b0 + k] << (16u * (k & 1u));
-                    blk = make_uint4(t4[0], t4[1], t4[2], t4[3]);
-                }
+        // The text comes through the ring, ALL lanes topping theirs up together every kStRefillEvery iterations (to four blocks
+        // from the one the lane stands in: 25 units and more, a lane takes at most one per iteration).  A lane that fetched its
+        // next block whenever it needed one made every iteration wait for memory: 64 lanes at 64 phases, so in every iteration
+        // some lane's block is the first of a 128-byte line -- a miss of 2 us that the whole wave waits for.
+        auto load_block = [&](uint32_t b) -> uint4 {
+            const uint32_t b0 = b * 8u;
+            if (b0 + 8u <= nu) {
+                const StUnits8 v = *reinterpret_cast<const StUnits8 *>(hay + b0);
+                return make_uint4(v.d[0], v.d[1], v.d[2], v.d[3]);
             }
+            uint32_t t4[4] = {0u, 0u, 0u, 0u}; // the buffer's last, partial block
+            for (uint32_t k = 0; k < 8u && b0 + k < nu; ++k) t4[k >> 1] |= (uint32_t)hay[b0 + k] << (16u * (k & 1u));
+            return make_uint4(t4[0], t4[1], t4[2], t4[3]);
+        };
+        auto refill = [&]() {
+            const uint32_t want_end = (pos >> 3) + 4u;
+            uint4 blk[4];
+            bool take[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) {
+                take[k] = active && have_end + k < want_end && (have_end + k) * 8u < nu;
+                blk[k] = take[k] ? load_block(have_end + k) : make_uint4(0u, 0u, 0u, 0u);
+            }
+            uint32_t got = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k)
+                if (take[k]) {
+                    ring[((have_end + k) & 3u) * 64u + lane] = blk[k];
+                    ++got;
+                }
+            have_end += got;
+        };
+        uint32_t it = 0;
+#ifdef ACGPU_TIMING
+        unsigned long long tm[4] = {0, 0, 0, 0};
+        const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
+#endif
+        while (__any(active)) {
+            if ((it & (kStRefillEvery - 1u)) == 0u) {
+                ST_T0();
+                refill();
+                ST_ACC(0);
+            }
+            ST_T0();
+            const uint32_t xb = pos >> 3;
             const bool can_step = active && xb < have_end;
             if (can_step) {
-                const uint32_t u = reinterpret_cast<const uint16_t *>(ring + (xb & 1u) * 64u + lane)[pos & 7u];
+                const uint32_t u = reinterpret_cast<const uint16_t *>(ring + (xb & 3u) * 64u + lane)[pos & 7u];
                 uint32_t cls;
                 if (RANGE) {
                     const uint32_t dlt = u - T.cls_base;
@@ -145,6 +185,10 @@ __global__ __launch_bounds__(kStBlock, 4) void k_ac_states(DevTables T, AcStates
                     took = false;
                 }
                 s = ns & kHyIdMask;
+#ifdef ACGPU_TIMING
+                asm volatile("s_nop 0" :: "v"(s));
+                tm[2] += __builtin_amdgcn_s_memtime() - t0_;
+#endif
                 if (took) {
                     if (!in_dense && n_rep == kHyNodeCountMany) n_rep = (uint32_t)__popc(T.hy_mask[s]); // (rare)
                     if (pos >= count_from) cnt += n_rep;
@@ -153,13 +197,23 @@ __global__ __launch_bounds__(kStBlock, 4) void k_ac_states(DevTables T, AcStates
                     active = pos < we;
                 }
             }
-            if (want_load) { // (behind the gathers' wait: the block has arrived with them)
-                ring[(have_end & 1u) * 64u + lane] = blk;
-                ++have_end;
+            if ((++it & (kStFlushEvery - 1u)) == 0u) {
+                ST_T0();
+                flush();
+                ST_ACC(1);
             }
-            if ((++it & (kStFlushEvery - 1u)) == 0u) flush();
         }
         flush();
+#ifdef ACGPU_TIMING
+        if (lane == 0) {
+            atomicAdd(&g_st_timing[0], tm[0]);
+            atomicAdd(&g_st_timing[1], tm[1]);
+            atomicAdd(&g_st_timing[2], tm[2]);
+            atomicAdd(&g_st_timing[4], __builtin_amdgcn_s_memtime() - tw0);
+            atomicAdd(&g_st_timing[5], (unsigned long long)it);
+            atomicAdd(&g_st_timing[6], 1ull);
+        }
+#endif
         if (mine && (we & 3u) && flushed < we) // the chunk's last, partial group (only where the owned range ends)
             for (uint32_t q = flushed; q < we; ++q) L.d_state[st_index(L.chunk_log2, w, lane, q - wb)] = stage[((q - wb) & 15u) * 64u + lane];
         if (mine) L.d_counts[w * 64u + lane] = cnt;
@@ -285,6 +339,16 @@ hipError_t launch_ac_states(const DevTables &t, const AcStatesLaunch &l, bool ra
     if (e != hipSuccess) return e;
     if (range) hipLaunchKernelGGL((k_ac_states<true>), dim3(l.grid), dim3(kStBlock), lds, stream, t, l);
     else hipLaunchKernelGGL((k_ac_states<false>), dim3(l.grid), dim3(kStBlock), lds, stream, t, l);
+#ifdef ACGPU_TIMING
+    {
+        (void)hipStreamSynchronize(stream);
+        unsigned long long h[8] = {0}, z[8] = {0};
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_st_timing), sizeof(h));
+        if (h[6]) fprintf(stderr, "[states timing] waves %llu, %.0f iterations each: total %.0f | refills %.0f | flushes %.0f | step to the transition %.0f (s_memtime ticks per wave)\n",
+                          h[6], (double)h[5] / h[6], (double)h[4] / h[6], (double)h[0] / h[6], (double)h[1] / h[6], (double)h[2] / h[6]);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_st_timing), z, sizeof(z));
+    }
+#endif
     return hipGetLastError();
 }
 
