@@ -1656,6 +1656,7 @@ int64_t acgpu_set_tunable(const char *name, int64_t value) {
     else if (!std::strcmp(name, "region_units")) slot = &t.region_units;
     else if (!std::strcmp(name, "tile_debug")) slot = &t.tile_debug;
     else if (!std::strcmp(name, "ww_first_seed")) slot = &t.ww_first_seed;
+    else if (!std::strcmp(name, "ww_no_bloom")) slot = &t.ww_no_bloom;
     else if (!std::strcmp(name, "rdense_budget_bytes")) slot = &t.rdense_budget_bytes;
     else if (!std::strcmp(name, "filter_max_bytes")) slot = &t.filter_max_bytes;
     else if (!std::strcmp(name, "no_merged_ranges")) slot = &t.no_merged_ranges;

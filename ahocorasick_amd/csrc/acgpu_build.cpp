@@ -317,7 +317,7 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
         uint64_t bits = 1024;
         // (WWLONGEST: 256 Kbit, so that three workgroups of its walk kernel share a CU)
         const uint64_t max_bits = mode == ACGPU_MODE_WWLONGEST ? (256u << 10) : (512u << 10);
-        while (bits < 16 * (uint64_t)keys.size() && bits < max_bits) bits <<= 1;
+        while (bits < 16 * (uint64_t)keys.size() && bits < max_bits && !tunables().ww_no_bloom) bits <<= 1;
         t.ww_bloom_mask = (uint32_t)(bits - 1);
         uint64_t cap = 16;
         while (cap < 2 * (uint64_t)keys.size() + 2) cap <<= 1;

@@ -320,6 +320,7 @@ struct Tunables {
     std::atomic<int64_t> filter_max_bytes{ACGPU_FILTER_MAX_BYTES};  // the filter rows must fit LDS next to the candidate queues
     std::atomic<int64_t> no_short_keywords{0}; // builder: 1 = the filter's K stays at most the shortest keyword (A/B)
     std::atomic<int64_t> no_merged_ranges{0}; // builder: 1 = mixed-case dictionaries keep the 8-byte-row scalar filter (A/B)
+    std::atomic<int64_t> ww_no_bloom{0};      // WHOLEWORD builder: 1 = no Bloom filter in front of the keyword table (every run of keyword length probes it)
     std::atomic<int64_t> ww_first_seed{0};    // WHOLEWORD builder: first hash seed tried (tests: the fallback seeds end to end)
     std::atomic<int64_t> split_cand_div{8};   // split form: a wave's candidate slice holds one candidate per this many units of its span
     std::atomic<int64_t> no_class_pages{0};   // builder: 1 = the tile kernel's LUT forms look classes up in global memory (A/B)

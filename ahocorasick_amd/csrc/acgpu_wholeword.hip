@@ -67,7 +67,10 @@ constexpr int kWwBlocksPerCu = ACGPU_WW_BLOCKS; // resident blocks per CU the re
 constexpr int kWwCandCap = kWwBatches * 64 + 256 + 64;
 
 int ww_blocks_per_cu() { return kWwBlocksPerCu; }
-constexpr uint32_t kFoldPagesMax = 64; // 32 KB of LDS; Unicode 13 simple lower-casing needs 18 pages
+#ifndef ACGPU_FOLD_PAGES_MAX
+#define ACGPU_FOLD_PAGES_MAX 64
+#endif
+constexpr uint32_t kFoldPagesMax = ACGPU_FOLD_PAGES_MAX; // 32 KB of LDS; Unicode 13 simple lower-casing needs 18 pages
 
 uint32_t ww_fold_pages_in_lds(const DevTables &t) { return (!t.cs && t.fold_n_pages <= kFoldPagesMax) ? t.fold_n_pages : 0u; }
 
