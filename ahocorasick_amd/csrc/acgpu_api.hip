@@ -115,8 +115,15 @@ int ensure_device(acgpu_automaton *a, DeviceState **out, int lane) {
     T.hy_dense = T.hy_nodes = T.hy_mask = T.hy_out = nullptr;
     T.hy_n_dense = t.hy_n_dense; T.hy_n_states = t.hy_n_states;
     if (t.hy_n_states) {
-        if ((rc = upload(*d, t.hy_dense, &T.hy_dense))) return rc;
-        if ((rc = upload(*d, t.hy_nodes, &T.hy_nodes))) return rc;
+        { // one allocation, rows first (padded to 16 bytes), nodes behind them: k_ac_states reads either with ONE 16-byte gather
+            std::vector<uint32_t> all(t.hy_dense);
+            all.resize((all.size() + 3) & ~(size_t)3, 0u);
+            const size_t node_at = all.size();
+            all.insert(all.end(), t.hy_nodes.begin(), t.hy_nodes.end());
+            all.resize(all.size() + 4, 0u);
+            if ((rc = upload(*d, all, &T.hy_dense))) return rc;
+            T.hy_nodes = T.hy_dense + node_at;
+        }
         if ((rc = upload(*d, t.hy_mask, &T.hy_mask))) return rc;
         if ((rc = upload(*d, t.hy_out, &T.hy_out))) return rc;
     }

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(kStBlock, 4) void k_ac_states(DevTables T, AcStates
     const uint16_t *hay = L.d_hay;
     const uint32_t nu = L.n_units, hot_last = row_words ? row_words - 1u : 0u, n_dense = T.hy_n_dense;
     const uint32_t dense_last = n_dense * n_cls - 1u, node_last = T.hy_n_states - n_dense ? T.hy_n_states - n_dense - 1u : 0u;
-    const uint4 *nodes = reinterpret_cast<const uint4 *>(T.hy_nodes);
+    const uint32_t node_quad0 = (uint32_t)((T.hy_nodes - T.hy_dense) >> 2);
     for (uint32_t w = blockIdx.x * (kStBlock / kWave) + wave; w < L.n_waves; w += waves_total) {
         const uint64_t wb64 = (uint64_t)L.g0 + ((uint64_t)(w * 64u + lane) << L.chunk_log2);
         const bool mine = wb64 < L.own_end;
@@ -159,8 +159,11 @@ __global__ __launch_bounds__(kStBlock, 4) void k_ac_states(DevTables T, AcStates
                 const bool in_dense = s < n_dense;
                 const uint32_t idx = in_dense ? s * n_cls + cls : 0u;
                 const uint32_t e_lds = rows[std::min(idx, hot_last)];
-                const uint32_t e_glb = T.hy_dense[idx < row_words ? 0u : std::min(idx, dense_last)];
-                const uint4 nd = nodes[in_dense ? 0u : std::min(s - n_dense, node_last)];
+                // (rows and nodes lie in one allocation, the nodes node_quad0 16-byte groups behind the first row: one gather serves either)
+                const uint32_t quad = in_dense ? (idx < row_words ? 0u : std::min(idx, dense_last) >> 2) : node_quad0 + std::min(s - n_dense, node_last);
+                const uint4 nd = reinterpret_cast<const uint4 *>(T.hy_dense)[quad];
+                const uint32_t iw = idx & 3u;
+                const uint32_t e_glb = iw == 0u ? nd.x : iw == 1u ? nd.y : iw == 2u ? nd.z : nd.w;
                 uint32_t ns, n_rep; // the state behind the unit (| kHyOut), how many keywords it reports
                 bool took = true;
                 if (in_dense) {
