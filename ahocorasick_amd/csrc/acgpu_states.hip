@@ -41,6 +41,21 @@ __device__ __forceinline__ size_t st_index(uint32_t chunk_log2, uint32_t w, uint
     return ((((size_t)w << (chunk_log2 - 2u)) + (o >> 2)) * 64u + l) * 4u + (o & 3u);
 }
 
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, d));
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d));
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ uint32_t st_sel(bool c, uint32_t a, uint32_t b) { // c ? a : b without control flow
+    const uint32_t m = 0u - (uint32_t)c;
+    return (a & m) | (b & ~m);
+}
+
 struct __attribute__((packed, aligned(2))) StUnits8 {
     uint32_t d[4];
 };
@@ -82,23 +97,30 @@ __global__ __launch_bounds__(kStBlock, 4) void k_ac_states(DevTables T, AcStates
         uint32_t pos = wb > L.halo ? wb - L.halo : 0u;                           // the root stands here
         uint32_t s = 0;
         uint32_t have_end = pos >> 3;   // blocks [have_end - 4, have_end) are in the ring (none yet)
-        uint32_t flushed = wb;          // the states of [wb, flushed) are in memory, those of [flushed, pos) staged
         uint32_t cnt = 0;               // records of the chunk
         const uint32_t count_from = std::max(wb, L.own_begin);
         bool active = mine && pos < we;
-        // The states go to memory through the staging slots, all lanes together every kStFlushEvery iterations: a store in the
-        // loop's body would be waited for (stores and loads count in one counter here, and a wait for a gather's data
-        // is a wait for every store issued before it: the acknowledgement of a store takes longer than a gather).
-        auto flush = [&]() {
-            while (__any(flushed + 4u <= pos && flushed + 4u <= we)) {
-                if (flushed + 4u <= pos && flushed + 4u <= we) {
-                    const uint32_t o = flushed - wb;
+        // The states go to memory through the staging slots, ROW by row: group g of four units of all 64 lanes is one kilobyte of
+        // consecutive memory (st_index), written by one instruction once every lane that is still walking has passed it --
+        // whole lines, and only every kStFlushEvery iterations: a store in the loop's body would be waited for (stores and loads
+        // count in one counter here, a wait for a gather's data is a wait for every store issued before it, and the
+        // acknowledgement of a store -- of a partly written line above all -- takes longer than a gather).  A lane that runs ahead
+        // of the slowest by the staging's depth waits for it (the wave lasts as long as its slowest lane anyway).
+        uint32_t rows_out = 0; // wave-uniform: groups [0, rows_out) of every lane are in memory
+        auto flush = [&](bool last) {
+            const uint32_t o_done = pos > wb ? pos - wb : 0u;
+            uint32_t lim = wave_min_u32((active && !last) ? (o_done >> 2) : ~0u);
+            const uint32_t top = wave_max_u32(mine ? ((we - wb) >> 2) : 0u); // (complete groups of the longest chunk)
+            lim = std::min(lim, top);
+            for (uint32_t g = rows_out; g < lim; ++g) {
+                if (mine && (g + 1u) * 4u <= we - wb) {
+                    const uint32_t o = g * 4u;
                     const uint4 v = make_uint4(stage[((o + 0u) & 15u) * 64u + lane], stage[((o + 1u) & 15u) * 64u + lane],
                                                stage[((o + 2u) & 15u) * 64u + lane], stage[((o + 3u) & 15u) * 64u + lane]);
                     *reinterpret_cast<uint4 *>(L.d_state + st_index(L.chunk_log2, w, lane, o)) = v;
-                    flushed += 4u;
                 }
             }
+            rows_out = std::max(rows_out, lim);
         };
         // The text comes through the ring, ALL lanes topping theirs up together every kStRefillEvery iterations (to four blocks
         // from the one the lane stands in: 25 units and more, a lane takes at most one per iteration).  A lane that fetched its
@@ -145,7 +167,7 @@ __global__ __launch_bounds__(kStBlock, 4) void k_ac_states(DevTables T, AcStates
             }
             ST_T0();
             const uint32_t xb = pos >> 3;
-            const bool can_step = active && xb < have_end;
+            const bool can_step = active && xb < have_end && (pos < wb || pos - wb < rows_out * 4u + 16u); // (text there, a staging slot free)
             if (can_step) {
                 const uint32_t u = reinterpret_cast<const uint16_t *>(ring + (xb & 3u) * 64u + lane)[pos & 7u];
                 uint32_t cls;
@@ -159,34 +181,31 @@ __global__ __launch_bounds__(kStBlock, 4) void k_ac_states(DevTables T, AcStates
                 const bool in_dense = s < n_dense;
                 const uint32_t idx = in_dense ? s * n_cls + cls : 0u;
                 const uint32_t e_lds = rows[std::min(idx, hot_last)];
-                // (rows and nodes lie in one allocation, the nodes node_quad0 16-byte groups behind the first row: one gather serves either)
-                const uint32_t quad = in_dense ? (idx < row_words ? 0u : std::min(idx, dense_last) >> 2) : node_quad0 + std::min(s - n_dense, node_last);
+                // (rows and nodes lie in one allocation, the nodes node_quad0 16-byte groups behind the first row: one gather serves
+                // either.  Everything below is selects on purpose: as if / else chains the compiler built twenty branches per step.)
+                const bool in_lds = idx < row_words;
+                const uint32_t quad = st_sel(in_dense, st_sel(in_lds, 0u, std::min(idx, dense_last) >> 2), node_quad0 + std::min(s - n_dense, node_last));
+#ifdef ACGPU_TIMING
+                asm volatile("s_nop 0" :: "v"(quad), "v"(e_lds));
+                const unsigned long long tg_ = __builtin_amdgcn_s_memtime();
+#endif
                 const uint4 nd = reinterpret_cast<const uint4 *>(T.hy_dense)[quad];
+#ifdef ACGPU_TIMING
+                asm volatile("s_nop 0" :: "v"(nd.x));
+                tm[3] += __builtin_amdgcn_s_memtime() - tg_;
+#endif
                 const uint32_t iw = idx & 3u;
-                const uint32_t e_glb = iw == 0u ? nd.x : iw == 1u ? nd.y : iw == 2u ? nd.z : nd.w;
-                uint32_t ns, n_rep; // the state behind the unit (| kHyOut), how many keywords it reports
-                bool took = true;
-                if (in_dense) {
-                    const uint32_t e = idx < row_words ? e_lds : e_glb;
-                    ns = e & 0xffffffu;
-                    n_rep = e >> kHyDenseCountShift;
-                } else if (cls == 0u) {
-                    ns = 0u; // (a unit of no keyword: the root, whatever the state)
-                    n_rep = 0u;
-                } else if ((nd.y >> 24) == cls) {
-                    ns = nd.y & 0xffffffu;
-                    n_rep = (nd.x >> kHyNodeCountShift) & 7u;
-                } else if ((nd.z >> 24) == cls) {
-                    ns = nd.z & 0xffffffu;
-                    n_rep = (nd.x >> (kHyNodeCountShift + 3u)) & 7u;
-                } else if ((nd.w >> 24) == cls) {
-                    ns = nd.w & 0xffffffu;
-                    n_rep = (nd.x >> (kHyNodeCountShift + 6u)) & 7u;
-                } else {
-                    ns = nd.x & kHyIdMask; // the fail state looks at this unit again
-                    n_rep = 0u;
-                    took = false;
-                }
+                const uint32_t e_glb = st_sel(iw == 0u, nd.x, st_sel(iw == 1u, nd.y, st_sel(iw == 2u, nd.z, nd.w)));
+                const uint32_t e_d = st_sel(in_lds, e_lds, e_glb);
+                const bool m1 = (nd.y >> 24) == cls, m2 = (nd.z >> 24) == cls, m3 = (nd.w >> 24) == cls;
+                const bool hit = cls != 0u && (m1 || m2 || m3);
+                const uint32_t edge = st_sel(m1, nd.y, st_sel(m2, nd.z, nd.w));
+                const uint32_t shift = st_sel(m1, kHyNodeCountShift, st_sel(m2, kHyNodeCountShift + 3u, kHyNodeCountShift + 6u));
+                // a node: the edge's child; a unit of no keyword: the root, whatever the state; else the fail state, which looks at this unit again
+                const uint32_t ns_c = st_sel(hit, edge & 0xffffffu, st_sel(cls == 0u, 0u, nd.x & kHyIdMask));
+                const uint32_t ns = st_sel(in_dense, e_d & 0xffffffu, ns_c); // the state behind the unit (| kHyOut)
+                uint32_t n_rep = st_sel(in_dense, e_d >> kHyDenseCountShift, st_sel(hit, (nd.x >> shift) & 7u, 0u)); // how many keywords it reports
+                const bool took = in_dense || hit || cls == 0u;
                 s = ns & kHyIdMask;
 #ifdef ACGPU_TIMING
                 asm volatile("s_nop 0" :: "v"(s));
@@ -202,23 +221,24 @@ __global__ __launch_bounds__(kStBlock, 4) void k_ac_states(DevTables T, AcStates
             }
             if ((++it & (kStFlushEvery - 1u)) == 0u) {
                 ST_T0();
-                flush();
+                flush(false);
                 ST_ACC(1);
             }
         }
-        flush();
+        flush(true);
 #ifdef ACGPU_TIMING
         if (lane == 0) {
             atomicAdd(&g_st_timing[0], tm[0]);
             atomicAdd(&g_st_timing[1], tm[1]);
             atomicAdd(&g_st_timing[2], tm[2]);
+            atomicAdd(&g_st_timing[3], tm[3]);
             atomicAdd(&g_st_timing[4], __builtin_amdgcn_s_memtime() - tw0);
             atomicAdd(&g_st_timing[5], (unsigned long long)it);
             atomicAdd(&g_st_timing[6], 1ull);
         }
 #endif
-        if (mine && (we & 3u) && flushed < we) // the chunk's last, partial group (only where the owned range ends)
-            for (uint32_t q = flushed; q < we; ++q) L.d_state[st_index(L.chunk_log2, w, lane, q - wb)] = stage[((q - wb) & 15u) * 64u + lane];
+        if (mine && ((we - wb) & 3u)) // the chunk's last, partial group (only where the owned range ends)
+            for (uint32_t q = wb + ((we - wb) & ~3u); q < we; ++q) L.d_state[st_index(L.chunk_log2, w, lane, q - wb)] = stage[((q - wb) & 15u) * 64u + lane];
         if (mine) L.d_counts[w * 64u + lane] = cnt;
         __builtin_amdgcn_wave_barrier();
     }
@@ -347,8 +367,8 @@ hipError_t launch_ac_states(const DevTables &t, const AcStatesLaunch &l, bool ra
         (void)hipStreamSynchronize(stream);
         unsigned long long h[8] = {0}, z[8] = {0};
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_st_timing), sizeof(h));
-        if (h[6]) fprintf(stderr, "[states timing] waves %llu, %.0f iterations each: total %.0f | refills %.0f | flushes %.0f | step to the transition %.0f (s_memtime ticks per wave)\n",
-                          h[6], (double)h[5] / h[6], (double)h[4] / h[6], (double)h[0] / h[6], (double)h[1] / h[6], (double)h[2] / h[6]);
+        if (h[6]) fprintf(stderr, "[states timing] waves %llu, %.0f iterations each: total %.0f | refills %.0f | flushes %.0f | step to the transition %.0f, of it the gather %.0f (s_memtime ticks per wave)\n",
+                          h[6], (double)h[5] / h[6], (double)h[4] / h[6], (double)h[0] / h[6], (double)h[1] / h[6], (double)h[2] / h[6], (double)h[3] / h[6]);
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_st_timing), z, sizeof(z));
     }
 #endif
