@@ -154,6 +154,16 @@ __global__ __launch_bounds__(kStBlock, 4) void k_ac_states(DevTables T, AcStates
                 }
             have_end += got;
         };
+        auto class_at = [&](uint32_t p) -> uint32_t {
+            const uint32_t u = reinterpret_cast<const uint16_t *>(ring + ((p >> 3) & 3u) * 64u + lane)[p & 7u];
+            if (RANGE) {
+                const uint32_t dlt = u - T.cls_base;
+                return dlt < T.cls_span ? dlt + 1u : 0u;
+            }
+            return pages[128u + ((uint32_t)reinterpret_cast<const unsigned char *>(pages)[u >> 8] << 8) + (u & 255u)];
+        };
+        uint32_t cls_next = 0;
+        bool cls_ok = false;
         uint32_t it = 0;
 #ifdef ACGPU_TIMING
         unsigned long long tm[4] = {0, 0, 0, 0};
@@ -169,14 +179,8 @@ __global__ __launch_bounds__(kStBlock, 4) void k_ac_states(DevTables T, AcStates
             const uint32_t xb = pos >> 3;
             const bool can_step = active && xb < have_end && (pos < wb || pos - wb < rows_out * 4u + 16u); // (text there, a staging slot free)
             if (can_step) {
-                const uint32_t u = reinterpret_cast<const uint16_t *>(ring + (xb & 3u) * 64u + lane)[pos & 7u];
-                uint32_t cls;
-                if (RANGE) {
-                    const uint32_t dlt = u - T.cls_base;
-                    cls = dlt < T.cls_span ? dlt + 1u : 0u;
-                } else {
-                    cls = pages[128u + ((uint32_t)reinterpret_cast<const unsigned char *>(pages)[u >> 8] << 8) + (u & 255u)];
-                }
+                // the unit's class: looked up during the step before (under its gather) if the lane took a unit then
+                const uint32_t cls = cls_ok ? cls_next : class_at(pos);
                 // the three places a transition can come from, all asked (a lane that does not need one reads entry 0 of it)
                 const bool in_dense = s < n_dense;
                 const uint32_t idx = in_dense ? s * n_cls + cls : 0u;
@@ -190,6 +194,9 @@ __global__ __launch_bounds__(kStBlock, 4) void k_ac_states(DevTables T, AcStates
                 const unsigned long long tg_ = __builtin_amdgcn_s_memtime();
 #endif
                 const uint4 nd = reinterpret_cast<const uint4 *>(T.hy_dense)[quad];
+                // (while the gather is on its way: the class of the NEXT unit -- one to three LDS round trips off the chain of the next step)
+                const bool have1 = ((pos + 1u) >> 3) < have_end;
+                const uint32_t cls1 = have1 ? class_at(pos + 1u) : 0u;
 #ifdef ACGPU_TIMING
                 asm volatile("s_nop 0" :: "v"(nd.x));
                 tm[3] += __builtin_amdgcn_s_memtime() - tg_;
@@ -207,6 +214,8 @@ __global__ __launch_bounds__(kStBlock, 4) void k_ac_states(DevTables T, AcStates
                 uint32_t n_rep = st_sel(in_dense, e_d >> kHyDenseCountShift, st_sel(hit, (nd.x >> shift) & 7u, 0u)); // how many keywords it reports
                 const bool took = in_dense || hit || cls == 0u;
                 s = ns & kHyIdMask;
+                cls_next = st_sel(took, cls1, cls); // (a fail state looks at the same unit again)
+                cls_ok = took ? have1 : true;
 #ifdef ACGPU_TIMING
                 asm volatile("s_nop 0" :: "v"(s));
                 tm[2] += __builtin_amdgcn_s_memtime() - t0_;
