@@ -41,6 +41,16 @@ __device__ __forceinline__ size_t st_index(uint32_t chunk_log2, uint32_t w, uint
     return ((((size_t)w << (chunk_log2 - 2u)) + (o >> 2)) * 64u + l) * 4u + (o & 3u);
 }
 
+// wave64 inclusive prefix sum with DPP row shifts and row broadcasts (as in the tile kernels)
+__device__ __forceinline__ uint32_t wave_inclusive_scan_dpp(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
+    return x;
+}
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, d));
@@ -304,7 +314,7 @@ __global__ __launch_bounds__(256) void k_ac_states_out(DevTables T, AcStatesLaun
     for (int st = 0; st < kSteps; ++st) {
         const uint32_t c0 = (uint32_t)__popc(m[st][0]), c1 = c0 + (uint32_t)__popc(m[st][1]), c2 = c1 + (uint32_t)__popc(m[st][2]),
                        c = c2 + (uint32_t)__popc(m[st][3]);
-        const uint32_t incl = wave_inclusive_scan(c);
+        const uint32_t incl = wave_inclusive_scan_dpp(c);
         const uint32_t total = __builtin_amdgcn_readlane(incl, kWave - 1);
         if (total == 0) continue; // wave-uniform
         const uint32_t p_step = (uint32_t)(cb + (uint32_t)st * 256u);
