@@ -191,8 +191,8 @@ def main():
         # LongestMatch: the walk kernel writes no record -- the records come out of the chain passes behind it -- so the
         # algorithmic bytes (text in, records out) are divided by the SUM of the family's kernels (HIP events around all of them)
         kernel_ms = float(np.mean(scan_ms)) + float(np.mean(fin_ms))
-        if matcher.last_kernel == "k_longest_bits":  # (csrc/acgpu_longest_bits.hip: no length array, no synchronisation pass)
-            kernel_what = "k_longest_bits + k_longest_bits_check + k_scan_* + k_longest_emit_ends (whole pipeline)"
+        if matcher.last_kernel == "k_longest_bits":  # (csrc/acgpu_longest_bits.hip: no length array, no synchronisation pass, no emit pass)
+            kernel_what = "k_longest_bits + k_longest_bits_finish (whole pipeline: the walk kernel writes the records itself)"
         else:
             kernel_what = matcher.last_kernel + " + k_longest_sync + k_longest_chain_lds + k_scan_* + k_longest_emit_ends (whole pipeline)"
     if cfg_name == "C5":
