@@ -31,6 +31,7 @@ constexpr uint32_t kStChunkLog2 = 10;           // a lane's chunk: 1024 units
 constexpr uint32_t kStRingWords = 4 * 64 * 4;   // per wave: [4 blocks][64 lanes] of 16 bytes of text
 constexpr uint32_t kStRefillEvery = 16;         // iterations between two refills of the rings
 constexpr uint32_t kStStageWords = 16 * 64;     // per wave: [16 positions][64 lanes] of states on their way to memory
+constexpr uint32_t kStWindow = 1024;            // records a wave of the record pass stages in LDS at a time
 constexpr uint32_t kStFlushEvery = 8;           // iterations between two flushes of the staged states (at most 3 + 8 of 16 slots are in use)
 constexpr uint32_t kStRowBytesMax = 159 * 1024 - (kStBlock / kWave) * (kStRingWords + kStStageWords) * 4; // LDS left for rows and pages: 31 KiB
 
@@ -305,62 +306,78 @@ __global__ __launch_bounds__(256) void k_ac_states_out(DevTables T, AcStatesLaun
     for (int st = 0; st < kSteps; ++st)
 #pragma unroll
         for (int k = 0; k < 4; ++k) m[st][k] = T.hy_mask[(sv[st][k] & kHyOut) ? (sv[st][k] & kHyIdMask) : 0u]; // (the root reports nothing)
-    // A step's records are written by ROUNDS of 64 consecutive records, one per lane (coalesced stores, no loop over a lane's own
-    // records: with 0.3 to 6 records per four positions such a loop runs as long as the busiest of 64 lanes): record j of the step
-    // belongs to the lane whose prefix interval holds j (binary search over the prefix sums by lane reads), is the
-    // (j - prefix)-th of that lane's four masks in order, longest first within a mask.
+    // A step's records go through LDS: every lane writes those of its four positions into the wave's staging window at their
+    // place among the step's records (one per iteration: the masks of positions 0/1 and 2/3 as two 64-bit words whose bits, taken
+    // from the top, come in the records' order -- position, then longest first), then the wave copies the window out, 64
+    // consecutive records per store.  (Lanes storing their own records straight to memory: scattered 8-byte stores, 2.2 ms on
+    // the README word list; rounds of 64 records with a binary search for each record's lane: 80 instructions per round, 1.5 ms.)
+    __shared__ int2 win_all[256 / kWave][kStWindow];
+    __shared__ int32_t wid_all[MAP ? 256 / kWave : 1][MAP ? kStWindow : 1];
+    int2 *win = win_all[threadIdx.x / kWave];
+    int32_t *wid = wid_all[MAP ? threadIdx.x / kWave : 0];
     int32_t *out = reinterpret_cast<int32_t *>(L.d_out);
 #pragma unroll
     for (int st = 0; st < kSteps; ++st) {
-        const uint32_t c0 = (uint32_t)__popc(m[st][0]), c1 = c0 + (uint32_t)__popc(m[st][1]), c2 = c1 + (uint32_t)__popc(m[st][2]),
-                       c = c2 + (uint32_t)__popc(m[st][3]);
+        const uint32_t c = (uint32_t)(__popc(m[st][0]) + __popc(m[st][1]) + __popc(m[st][2]) + __popc(m[st][3]));
         const uint32_t incl = wave_inclusive_scan_dpp(c);
         const uint32_t total = __builtin_amdgcn_readlane(incl, kWave - 1);
         if (total == 0) continue; // wave-uniform
-        const uint32_t p_step = (uint32_t)(cb + (uint32_t)st * 256u);
-        for (uint32_t j0 = 0; j0 < total; j0 += kWave) {
-            const uint32_t j = j0 + lane;
-            uint32_t src = 0; // the first lane whose inclusive prefix exceeds j (lanes beyond the step's records: 63, unused)
-#pragma unroll
-            for (uint32_t b = 32; b >= 1; b >>= 1) {
-                const uint32_t v = (uint32_t)__shfl((int)incl, (int)(src + b - 1u));
-                if (v <= j && src + b < kWave) src += b;
-            }
-            const uint32_t s_incl = (uint32_t)__shfl((int)incl, (int)src), s_c = (uint32_t)__shfl((int)c, (int)src);
-            const uint32_t s_c0 = (uint32_t)__shfl((int)c0, (int)src), s_c1 = (uint32_t)__shfl((int)c1, (int)src), s_c2 = (uint32_t)__shfl((int)c2, (int)src);
-            uint32_t r = j - (s_incl - s_c); // the record's rank among the source lane's
-            const uint32_t k = r < s_c0 ? 0u : r < s_c1 ? 1u : r < s_c2 ? 2u : 3u;
-            r -= k == 0u ? 0u : k == 1u ? s_c0 : k == 2u ? s_c1 : s_c2;
-            // (a lane reads the mask / state number k of ITS source: k differs from lane to lane, so the four candidates travel)
-            uint32_t mk, t;
-            {
-                const uint32_t a0 = (uint32_t)__shfl((int)m[st][0], (int)src), a1 = (uint32_t)__shfl((int)m[st][1], (int)src);
-                const uint32_t a2 = (uint32_t)__shfl((int)m[st][2], (int)src), a3 = (uint32_t)__shfl((int)m[st][3], (int)src);
-                mk = k == 0u ? a0 : k == 1u ? a1 : k == 2u ? a2 : a3;
-            }
-            if (MAP) {
-                const uint32_t b0 = (uint32_t)__shfl((int)sv[st][0], (int)src), b1 = (uint32_t)__shfl((int)sv[st][1], (int)src);
-                const uint32_t b2 = (uint32_t)__shfl((int)sv[st][2], (int)src), b3 = (uint32_t)__shfl((int)sv[st][3], (int)src);
-                t = (k == 0u ? b0 : k == 1u ? b1 : k == 2u ? b2 : b3) & kHyIdMask;
-            }
-            if (j < total) {
-                for (uint32_t i = 0; i < r; ++i) { // the r longer keywords that end here come first
-                    mk &= ~(0x80000000u >> __clz(mk));
-                    if (MAP) t = outs[t].y;
+        const uint32_t p0 = (uint32_t)(cb + (uint32_t)st * 256u) + lane * 4u;
+        const uint32_t ex = incl - c;
+        for (uint32_t w0 = 0; w0 < total; w0 += kStWindow) { // (one window unless 256 positions hold more than kStWindow records)
+            uint32_t at = ex;
+            unsigned long long cur = ((unsigned long long)m[st][0] << 32) | m[st][1], nxt = ((unsigned long long)m[st][2] << 32) | m[st][3];
+            if (ex + c <= w0 || ex >= w0 + kStWindow) cur = nxt = 0ull; // none of the lane's records in this window
+            uint32_t pair = 0;          // 0: positions 0 and 1, 2: positions 2 and 3
+            uint32_t t = 0, tpos = ~0u; // Map records: the state whose keyword the next record names, the position it belongs to
+            while (__any((cur | nxt) != 0ull)) {
+                if (cur == 0ull && nxt != 0ull) {
+                    cur = nxt;
+                    nxt = 0ull;
+                    pair = 2u;
                 }
-                const uint32_t len = 32u - (uint32_t)__clz(mk);
-                const uint32_t end = p_step + src * 4u + k + 1u;
-                const unsigned long long at = base + j;
-                if (at < L.cap) {
+                if (cur != 0ull) {
+                    const uint32_t b = 63u - (uint32_t)__clzll((long long)cur);
+                    cur &= ~(1ull << b);
+                    const uint32_t k = pair + (b < 32u ? 1u : 0u), len = (b & 31u) + 1u;
+                    const uint32_t end = p0 + k + 1u;
+                    uint32_t id = 0;
                     if (MAP) {
-                        out[at * 3] = (int32_t)(end - len);
-                        out[at * 3 + 1] = (int32_t)end;
-                        out[at * 3 + 2] = (int32_t)outs[t].x;
+                        if (tpos != k) { // the first (longest) keyword of this position: the state itself
+                            t = sv[st][0];
+                            t = k == 1u ? sv[st][1] : t;
+                            t = k == 2u ? sv[st][2] : t;
+                            t = k == 3u ? sv[st][3] : t;
+                            t &= kHyIdMask;
+                            tpos = k;
+                        }
+                        const uint2 o = outs[t];
+                        id = o.x;
+                        t = o.y;
+                    }
+                    if (at >= w0 && at < w0 + kStWindow) {
+                        win[at - w0] = make_int2((int)(end - len), (int)end);
+                        if (MAP) wid[at - w0] = (int32_t)id;
+                    }
+                    ++at;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t n_win = min(total - w0, kStWindow);
+            for (uint32_t j = lane; j < n_win; j += kWave) {
+                const unsigned long long dst = base + w0 + j;
+                if (dst < L.cap) {
+                    const int2 r = win[j];
+                    if (MAP) {
+                        out[dst * 3] = r.x;
+                        out[dst * 3 + 1] = r.y;
+                        out[dst * 3 + 2] = wid[j];
                     } else {
-                        reinterpret_cast<int2 *>(out)[at] = make_int2((int)(end - len), (int)end);
+                        reinterpret_cast<int2 *>(out)[dst] = r;
                     }
                 }
             }
+            __builtin_amdgcn_wave_barrier();
         }
         base += total;
     }
