@@ -112,7 +112,7 @@ int ensure_device(acgpu_automaton *a, DeviceState **out, int lane) {
     if (t.root_b && (rc = upload(*d, t.root_tab, &T.root_tab))) return rc;
     T.bits_tab = nullptr; T.bits_rk = t.bits_rk;
     if (t.bits_rk && (rc = upload(*d, t.bits_tab, &T.bits_tab))) return rc;
-    T.hy_dense = T.hy_nodes = T.hy_mask = T.hy_out = nullptr;
+    T.hy_dense = T.hy_nodes = T.hy_mask = T.hy_out = T.hy_ids = nullptr;
     T.hy_n_dense = t.hy_n_dense; T.hy_n_states = t.hy_n_states;
     if (t.hy_n_states) {
         { // one allocation, rows first (padded to 16 bytes), nodes behind them: k_ac_states reads either with ONE 16-byte gather
@@ -126,6 +126,7 @@ int ensure_device(acgpu_automaton *a, DeviceState **out, int lane) {
         }
         if ((rc = upload(*d, t.hy_mask, &T.hy_mask))) return rc;
         if ((rc = upload(*d, t.hy_out, &T.hy_out))) return rc;
+        if ((rc = upload(*d, t.hy_ids, &T.hy_ids))) return rc;
     }
     if ((rc = upload(*d, t.filt_bits, &T.filt_bits))) return rc;
     if ((rc = upload(*d, t.kgram_node, &T.kgram_node))) return rc;

@@ -509,12 +509,18 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
         t.hy_nodes.assign((size_t)(N - t.hy_n_dense) * 4, 0u);
         t.hy_mask.assign(N, 0u);
         t.hy_out.assign((size_t)N * 2, 0u);
+        t.hy_ids.clear();
         for (uint32_t s : bfs) {
             const uint32_t h = hid[s];
             if (olen[s]) {
                 t.hy_mask[h] = omask[s];
-                t.hy_out[(size_t)h * 2] = oid[s];
-                t.hy_out[(size_t)h * 2 + 1] = olink[s] ? hid[olink[s]] : 0u;
+                t.hy_out[(size_t)h * 2] = omask[s];
+                if ((omask[s] & (omask[s] - 1u)) == 0u && oid[s] < 0x80000000u) { // one keyword: its id itself
+                    t.hy_out[(size_t)h * 2 + 1] = oid[s] | 0x80000000u;
+                } else {
+                    t.hy_out[(size_t)h * 2 + 1] = (uint32_t)t.hy_ids.size();
+                    for (uint32_t x = s; x != 0 && olen[x]; x = olink[x]) t.hy_ids.push_back(oid[x]); // (longest first: the order of the mask's bits from the top)
+                }
             }
             if (is_dense(s)) {
                 uint32_t *row = &t.hy_dense[(size_t)h * t.n_cls];

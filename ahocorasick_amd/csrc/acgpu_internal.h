@@ -159,7 +159,8 @@ struct HostTables {
     std::vector<uint32_t> hy_dense;  // hy_n_dense * n_cls
     std::vector<uint32_t> hy_nodes;  // 4 words per compact state
     std::vector<uint32_t> hy_mask;   // per h-id: bit L-1 = a keyword of L units ends in this state (its own or a suffix's)
-    std::vector<uint32_t> hy_out;    // per h-id, two words: {keyword id of the longest such keyword, h-id of the next shorter one's state}
+    std::vector<uint32_t> hy_out;    // per h-id, two words: {hy_mask again, where the state's keyword ids begin in hy_ids -- or, bit 31 set, the id of its only keyword} (Map records: one gather for both)
+    std::vector<uint32_t> hy_ids;    // the keyword ids of what a state reports, longest first, state after state
     uint32_t hy_n_dense = 0, hy_n_states = 0;
     // hashed goto edges keyed by (state, folded unit): open addressing, linear probing
     std::vector<uint64_t> hkeys;
@@ -299,7 +300,7 @@ struct DevTables {
     uint32_t root_b, root_rk;
     const uint32_t *bits_tab; // LONGEST: see HostTables::bits_tab (nullptr: none)
     uint32_t bits_rk;
-    const uint32_t *hy_dense, *hy_nodes, *hy_mask, *hy_out; // see HostTables::hy_dense (hy_n_states = 0: none)
+    const uint32_t *hy_dense, *hy_nodes, *hy_mask, *hy_out, *hy_ids; // see HostTables::hy_dense (hy_n_states = 0: none)
     uint32_t hy_n_dense, hy_n_states;
 };
 

@@ -53,6 +53,7 @@ __device__ __forceinline__ uint32_t fol_walk(const DevTables &T, const LongestFo
     // store in the body would be waited for by the next gather (loads and stores share one counter, and a store's
     // acknowledgement takes longer than a gather), and with 64 chains at 64 different places some lane stores in every iteration
     uint32_t pend_sw = 0, pend_swi = ~0u, pend_ew = 0, pend_ewi = ~0u, it = 0;
+    uint32_t sp0 = 0, sb0 = 0, sp1 = 0, sb1 = 0, sp2 = 0, sb2 = 0, sp3 = 0, sb3 = 0, n_sp = 0; // STATE: {position, node} of the matches since the last flush
     bool active = p < plim;
     while (__any(active)) {
         const uint32_t x = p + d, xb = x >> 3;
@@ -112,7 +113,18 @@ __device__ __forceinline__ uint32_t fol_walk(const DevTables &T, const LongestFo
                             ewi = qi;
                         }
                         ew |= 1u << (q & 31u);
-                        if (STATE) L.d_state[p] = bnode;
+                        if (STATE) { // (Map records: the matched node, stored with the next flush like the bitmap words -- four waiting at most)
+                            if (n_sp == 4u) { // (cannot happen between two flushes of 8 iterations: a match takes two at least)
+                                L.d_state[sp0] = sb0;
+                                sp0 = sp1; sb0 = sb1; sp1 = sp2; sb1 = sb2; sp2 = sp3; sb2 = sb3;
+                                n_sp = 3u;
+                            }
+                            sp0 = n_sp == 0u ? p : sp0; sb0 = n_sp == 0u ? bnode : sb0;
+                            sp1 = n_sp == 1u ? p : sp1; sb1 = n_sp == 1u ? bnode : sb1;
+                            sp2 = n_sp == 2u ? p : sp2; sb2 = n_sp == 2u ? bnode : sb2;
+                            sp3 = n_sp == 3u ? p : sp3; sb3 = n_sp == 3u ? bnode : sb3;
+                            ++n_sp;
+                        }
                     }
                 }
                 p += best ? best : 1u;
@@ -139,6 +151,13 @@ __device__ __forceinline__ uint32_t fol_walk(const DevTables &T, const LongestFo
             if (pend_ewi != ~0u) atomicOr(&L.d_ebits[pend_ewi], pend_ew);
             pend_swi = ~0u;
             pend_ewi = ~0u;
+            if (STATE) {
+                if (n_sp > 0u) L.d_state[sp0] = sb0;
+                if (n_sp > 1u) L.d_state[sp1] = sb1;
+                if (n_sp > 2u) L.d_state[sp2] = sb2;
+                if (n_sp > 3u) L.d_state[sp3] = sb3;
+                n_sp = 0u;
+            }
         }
         if (want_load && keep && have_end == load_b) { // (behind the gather's wait: the block has arrived with it; not if the ring has just started over)
             ring[(load_b & 3u) * 64u + lane] = blk;
@@ -146,6 +165,12 @@ __device__ __forceinline__ uint32_t fol_walk(const DevTables &T, const LongestFo
         }
     }
     if (MARK) {
+        if (STATE) {
+            if (n_sp > 0u) L.d_state[sp0] = sb0;
+            if (n_sp > 1u) L.d_state[sp1] = sb1;
+            if (n_sp > 2u) L.d_state[sp2] = sb2;
+            if (n_sp > 3u) L.d_state[sp3] = sb3;
+        }
         if (pend_swi != ~0u) L.d_bits[pend_swi] = pend_sw;
         if (pend_ewi != ~0u) atomicOr(&L.d_ebits[pend_ewi], pend_ew);
         if (swi < seg_end_word) {
@@ -157,8 +182,9 @@ __device__ __forceinline__ uint32_t fol_walk(const DevTables &T, const LongestFo
     return p;
 }
 
+// (Map records keep four {position, node} pairs waiting for the next flush: that form takes the registers of one workgroup per CU)
 template <bool RANGE, bool STATE>
-__global__ __launch_bounds__(kFolBlock, 8) void k_longest_follow(DevTables T, LongestFollowLaunch L) {
+__global__ __launch_bounds__(kFolBlock, STATE ? 4 : 8) void k_longest_follow(DevTables T, LongestFollowLaunch L) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     // [hot rows][class pages (table classes)][rings]
     const uint32_t row_words = L.hot_rows * T.n_cls, page_words = RANGE ? 0u : (T.dfa_pages_bytes + 3u) / 4u;

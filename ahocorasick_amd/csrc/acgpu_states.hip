@@ -305,7 +305,16 @@ __global__ __launch_bounds__(256) void k_ac_states_out(DevTables T, AcStatesLaun
 #pragma unroll
     for (int st = 0; st < kSteps; ++st)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) m[st][k] = T.hy_mask[(sv[st][k] & kHyOut) ? (sv[st][k] & kHyIdMask) : 0u]; // (the root reports nothing)
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t at = (sv[st][k] & kHyOut) ? (sv[st][k] & kHyIdMask) : 0u; // (the root reports nothing)
+            if (MAP) { // (the mask and where the state's keyword ids begin: one gather)
+                const uint2 o = outs[at];
+                m[st][k] = o.x;
+                sv[st][k] = o.y;
+            } else {
+                m[st][k] = T.hy_mask[at];
+            }
+        }
     // A step's records go through LDS: every lane writes those of its four positions into the wave's staging window at their
     // place among the step's records (one per iteration: the masks of positions 0/1 and 2/3 as two 64-bit words whose bits, taken
     // from the top, come in the records' order -- position, then longest first), then the wave copies the window out, 64
@@ -329,7 +338,7 @@ __global__ __launch_bounds__(256) void k_ac_states_out(DevTables T, AcStatesLaun
             unsigned long long cur = ((unsigned long long)m[st][0] << 32) | m[st][1], nxt = ((unsigned long long)m[st][2] << 32) | m[st][3];
             if (ex + c <= w0 || ex >= w0 + kStWindow) cur = nxt = 0ull; // none of the lane's records in this window
             uint32_t pair = 0;          // 0: positions 0 and 1, 2: positions 2 and 3
-            uint32_t t = 0, tpos = ~0u; // Map records: the state whose keyword the next record names, the position it belongs to
+            uint32_t idx = 0, ipos = ~0u; // Map records: where the next record's keyword id stands in hy_ids, the position it belongs to
             while (__any((cur | nxt) != 0ull)) {
                 if (cur == 0ull && nxt != 0ull) {
                     cur = nxt;
@@ -341,24 +350,18 @@ __global__ __launch_bounds__(256) void k_ac_states_out(DevTables T, AcStatesLaun
                     cur &= ~(1ull << b);
                     const uint32_t k = pair + (b < 32u ? 1u : 0u), len = (b & 31u) + 1u;
                     const uint32_t end = p0 + k + 1u;
-                    uint32_t id = 0;
-                    if (MAP) {
-                        if (tpos != k) { // the first (longest) keyword of this position: the state itself
-                            t = sv[st][0];
-                            t = k == 1u ? sv[st][1] : t;
-                            t = k == 2u ? sv[st][2] : t;
-                            t = k == 3u ? sv[st][3] : t;
-                            t &= kHyIdMask;
-                            tpos = k;
-                        }
-                        const uint2 o = outs[t];
-                        id = o.x;
-                        t = o.y;
+                    if (MAP && ipos != k) { // the first (longest) keyword of this position
+                        idx = sv[st][0];
+                        idx = k == 1u ? sv[st][1] : idx;
+                        idx = k == 2u ? sv[st][2] : idx;
+                        idx = k == 3u ? sv[st][3] : idx;
+                        ipos = k;
                     }
                     if (at >= w0 && at < w0 + kStWindow) {
                         win[at - w0] = make_int2((int)(end - len), (int)end);
-                        if (MAP) wid[at - w0] = (int32_t)id;
+                        if (MAP) wid[at - w0] = (int32_t)idx; // (the id itself is fetched when the window is copied out: 64 independent gathers)
                     }
+                    ++idx;
                     ++at;
                 }
             }
@@ -371,7 +374,8 @@ __global__ __launch_bounds__(256) void k_ac_states_out(DevTables T, AcStatesLaun
                     if (MAP) {
                         out[dst * 3] = r.x;
                         out[dst * 3 + 1] = r.y;
-                        out[dst * 3 + 2] = wid[j];
+                        const uint32_t iw = (uint32_t)wid[j]; // (bit 31: the id itself -- the only keyword of its state)
+                        out[dst * 3 + 2] = (iw & 0x80000000u) ? (int32_t)(iw & 0x7fffffffu) : (int32_t)T.hy_ids[iw];
                     } else {
                         reinterpret_cast<int2 *>(out)[dst] = r;
                     }
