@@ -281,6 +281,7 @@ int match_all_states(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int re
     S.n_waves = (uint32_t)((chunks + 63) / 64);
     S.n_chunks = (uint32_t)chunks;
     if ((rc = d.counter.ensure(64))) return rc;
+    if (tunables().tile_debug & (1ll << 40)) return ACGPU_E_NOMEM; // (tests: the allocation "fails", the caller falls back)
     if ((rc = d.statebuf.ensure((((size_t)S.n_waves * 64) << S.chunk_log2) * 4 + 64))) return rc;
     if ((rc = d.chunk_counts.ensure((size_t)S.n_chunks * 4))) return rc;
     if ((rc = d.offsets.ensure((size_t)S.n_chunks * 8))) return rc;
@@ -383,8 +384,10 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
             const int prc = match_all_states(a, d, &head, record_kind, d_out, 0, &n_head, stream, nullptr, nullptr, st_hot);
             if (prc != ACGPU_OK && prc != ACGPU_E_OVERFLOW) return prc;
         }
-        if (usable && ((aform & 2) || d.all_density >= kStatesFormDensity))
-            return match_all_states(a, d, sh, record_kind, d_out, cap, n_out, stream, prof, tk, st_hot);
+        if (usable && ((aform & 2) || d.all_density >= kStatesFormDensity)) {
+            const int src = match_all_states(a, d, sh, record_kind, d_out, cap, n_out, stream, prof, tk, st_hot);
+            if (src != ACGPU_E_NOMEM) return src; // (no room for 4 bytes of state per unit -- before anything was launched: the tile kernel it is)
+        }
     }
     int rc;
     const size_t counter_bytes = (size_t)kMaxSlices * kCounterStride * 8; // one set; layout: [set 0][set 1][overflow word]

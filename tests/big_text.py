@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Position arithmetic at the size limit (under tests/ because it checks against the oracle; also runnable on its own).  A haystack of just under 2^31 units (the ABI's limit) is scanned whole
 and as four shards by the same automaton (records must concatenate to the same list), and the last 2^20 units are compared with
-the oracle.  AhoCorasick (config 2's dictionary), WholeWord (config 5's dictionary on letters + spaces), Longest (config 4)."""
+the oracle.  AhoCorasick (config 2's dictionary: the tile kernel, and k_ac_states with its 8 GB of states), WholeWord (config 5's dictionary on letters + spaces), Longest (config 4)."""
 import ctypes, os, sys, hashlib
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -35,6 +35,7 @@ def main():
   d_hay = torch.empty(n, dtype=torch.int16, device="cuda")
   cases = [
       ("AhoCorasick C2", N.MODE_ALL, synth.config_keywords("C2"), True, synth.ALPHA_LOWER, FAM_AC, n // 200),
+      ("AhoCorasick C2 through k_ac_states", N.MODE_ALL, synth.config_keywords("C2"), True, synth.ALPHA_LOWER, FAM_AC, n // 200),
       ("WholeWord C5 words on letters+space", N.MODE_WHOLEWORD, synth.config_keywords("C5"), False,
        list(synth.ALPHA_LOWER[:8]) + [32, 32], FAM_WHOLEWORD, n // 4),
       ("Longest C4", N.MODE_LONGEST, synth.config_keywords("C4"), True, synth.ALPHA_AB_75, FAM_LONGEST, n // 4),
@@ -43,6 +44,7 @@ def main():
       fill(tab, 4242)
       wc = default_word_chars() if mode == N.MODE_WHOLEWORD else None
       a = Automaton(mode, kws, cs, word_chars=wc)
+      N.set_tunable("all_form", 2 if "k_ac_states" in name else 0)  # (2: the state form whatever the text's density of matches)
       whole = run(a, cap)
       cuts = [0, n // 4 + 3, n // 2 + 1, 3 * (n // 4) + 5, n]
       if mode != N.MODE_LONGEST:
@@ -75,6 +77,7 @@ def main():
       print("%-40s n=%d records=%d max_end=%d sha(last 2^20 records)=%s" % (name, n, len(whole), int(whole[:, 1].max()),
                                                                         hashlib.sha256(whole[-(1 << 20):].cpu().numpy().tobytes()).hexdigest()[:12]), flush=True)
       del whole, parts
+      N.set_tunable("all_form", 0)
       torch.cuda.empty_cache()
   print("big text ok")
   d_hay = None

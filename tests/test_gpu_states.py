@@ -170,3 +170,13 @@ def test_shortest_over_the_states_form(words):
     N.set_tunable("all_form", STATES_ALWAYS)
     got, _ = _run(a, hay, True)
     assert got.shape == want.shape and (got == want).all()
+
+
+def test_states_form_without_room_for_the_states_falls_back_to_the_tile_kernel(words):
+    a = Automaton(N.MODE_ALL, words, True)
+    hay = synth.readme_text(13, 300001, words)
+    want = Oracle(FAM_AC, words).match(hay)
+    N.set_tunable("all_form", STATES_ALWAYS)
+    N.set_tunable("tile_debug", 1 << 40)  # the buffer of 4 bytes per unit "cannot be had"
+    got, kname = _run(a, hay, True)
+    assert kname != "k_ac_states" and got.shape == want.shape and (got == want).all()
