@@ -291,7 +291,7 @@ int match_all_states(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int re
     S.d_offsets = (const uint64_t *)d.offsets.p;
     S.d_out = d_out;
     S.cap = cap;
-    S.grid = (int)std::min<uint64_t>((uint64_t)d.n_cu, (S.n_waves + 15) / 16);
+    S.grid = (int)std::min<uint64_t>((uint64_t)d.n_cu * (ac_states_lanes_per_cu() / 1024u), (S.n_waves + 15) / 16);
     HIP_TRY(hipMemsetAsync(d.counter.p, 0, 64, stream)); // (word 1: the "redo" flag of the result -- never raised here)
     d.cclean[0] = false; // (match_all's first set of slot counters lives here)
     if (timed) HIP_TRY(hipEventRecord(ev[0], stream));

@@ -26,14 +26,21 @@
 
 namespace acgpu {
 
-constexpr int kStBlock = 1024;                  // 16 waves, one workgroup per CU
-constexpr uint32_t kStChunkLog2 = 10;           // a lane's chunk: 1024 units
-constexpr uint32_t kStRingWords = 4 * 64 * 4;   // per wave: [4 blocks][64 lanes] of 16 bytes of text
-constexpr uint32_t kStRefillEvery = 16;         // iterations between two refills of the rings
-constexpr uint32_t kStStageWords = 16 * 64;     // per wave: [16 positions][64 lanes] of states on their way to memory
+// Two shapes of the walk kernel (ACGPU_ST_WGS workgroups of 16 waves per CU): one with deep rings and staging, two with half of each
+#ifndef ACGPU_ST_WGS
+#define ACGPU_ST_WGS 1
+#endif
+constexpr int kStBlock = 1024;                  // 16 waves
+constexpr int kStWgsPerCu = ACGPU_ST_WGS;
+constexpr uint32_t kStChunkLog2 = 10;           // a lane's chunk: 1024 units (less for texts that would not fill the chip)
+constexpr uint32_t kStRingBlocks = kStWgsPerCu == 1 ? 4 : 2;   // 8-unit blocks of text per lane in LDS
+constexpr uint32_t kStRingWords = kStRingBlocks * 64 * 4;      // per wave: [block][64 lanes] of 16 bytes of text
+constexpr uint32_t kStRefillEvery = kStWgsPerCu == 1 ? 16 : 4; // iterations between two refills of the rings (a lane takes at most one unit per iteration)
+constexpr uint32_t kStStageSlots = kStWgsPerCu == 1 ? 16 : 8;  // staged states per lane
+constexpr uint32_t kStStageWords = kStStageSlots * 64;         // per wave: [slot][64 lanes] of states on their way to memory
 constexpr uint32_t kStWindow = 1024;            // records a wave of the record pass stages in LDS at a time
-constexpr uint32_t kStFlushEvery = 8;           // iterations between two flushes of the staged states (at most 3 + 8 of 16 slots are in use)
-constexpr uint32_t kStRowBytesMax = 159 * 1024 - (kStBlock / kWave) * (kStRingWords + kStStageWords) * 4; // LDS left for rows and pages: 31 KiB
+constexpr uint32_t kStFlushEvery = kStWgsPerCu == 1 ? 8 : 4;   // iterations between two flushes of the staged states
+constexpr uint32_t kStRowBytesMax = (kStWgsPerCu == 1 ? 159 : 79) * 1024 - (kStBlock / kWave) * (kStRingWords + kStStageWords) * 4; // LDS left for rows and pages: 31 / 15 KiB
 
 // Where the state behind the o-th unit of the chunk of lane l of wave w lies: [wave][group of four units][lane][4] -- lanes that
 // walk at the same pace store a kilobyte of consecutive memory with one instruction (64 x 16 bytes), where chunk-major order
@@ -81,7 +88,7 @@ __device__ unsigned long long g_st_timing[8]; // s_memtime ticks (100 MHz) per w
 #endif
 
 template <bool RANGE>
-__global__ __launch_bounds__(kStBlock, 4) void k_ac_states(DevTables T, AcStatesLaunch L) {
+__global__ __launch_bounds__(kStBlock, 4 * kStWgsPerCu) void k_ac_states(DevTables T, AcStatesLaunch L) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     // [hot rows][class pages (table classes)][text rings][staged states]
     const uint32_t n_cls = T.n_cls;
@@ -126,8 +133,8 @@ __global__ __launch_bounds__(kStBlock, 4) void k_ac_states(DevTables T, AcStates
             for (uint32_t g = rows_out; g < lim; ++g) {
                 if (mine && (g + 1u) * 4u <= we - wb) {
                     const uint32_t o = g * 4u;
-                    const uint4 v = make_uint4(stage[((o + 0u) & 15u) * 64u + lane], stage[((o + 1u) & 15u) * 64u + lane],
-                                               stage[((o + 2u) & 15u) * 64u + lane], stage[((o + 3u) & 15u) * 64u + lane]);
+                    const uint4 v = make_uint4(stage[((o + 0u) & (kStStageSlots - 1u)) * 64u + lane], stage[((o + 1u) & (kStStageSlots - 1u)) * 64u + lane],
+                                               stage[((o + 2u) & (kStStageSlots - 1u)) * 64u + lane], stage[((o + 3u) & (kStStageSlots - 1u)) * 64u + lane]);
                     *reinterpret_cast<uint4 *>(L.d_state + st_index(L.chunk_log2, w, lane, o)) = v;
                 }
             }
@@ -148,25 +155,25 @@ __global__ __launch_bounds__(kStBlock, 4) void k_ac_states(DevTables T, AcStates
             return make_uint4(t4[0], t4[1], t4[2], t4[3]);
         };
         auto refill = [&]() {
-            const uint32_t want_end = (pos >> 3) + 4u;
-            uint4 blk[4];
-            bool take[4];
+            const uint32_t want_end = (pos >> 3) + kStRingBlocks;
+            uint4 blk[kStRingBlocks];
+            bool take[kStRingBlocks];
 #pragma unroll
-            for (uint32_t k = 0; k < 4u; ++k) {
+            for (uint32_t k = 0; k < kStRingBlocks; ++k) {
                 take[k] = active && have_end + k < want_end && (have_end + k) * 8u < nu;
                 blk[k] = take[k] ? load_block(have_end + k) : make_uint4(0u, 0u, 0u, 0u);
             }
             uint32_t got = 0;
 #pragma unroll
-            for (uint32_t k = 0; k < 4u; ++k)
+            for (uint32_t k = 0; k < kStRingBlocks; ++k)
                 if (take[k]) {
-                    ring[((have_end + k) & 3u) * 64u + lane] = blk[k];
+                    ring[((have_end + k) & (kStRingBlocks - 1u)) * 64u + lane] = blk[k];
                     ++got;
                 }
             have_end += got;
         };
         auto class_at = [&](uint32_t p) -> uint32_t {
-            const uint32_t u = reinterpret_cast<const uint16_t *>(ring + ((p >> 3) & 3u) * 64u + lane)[p & 7u];
+            const uint32_t u = reinterpret_cast<const uint16_t *>(ring + ((p >> 3) & (kStRingBlocks - 1u)) * 64u + lane)[p & 7u];
             if (RANGE) {
                 const uint32_t dlt = u - T.cls_base;
                 return dlt < T.cls_span ? dlt + 1u : 0u;
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(kStBlock, 4) void k_ac_states(DevTables T, AcStates
             }
             ST_T0();
             const uint32_t xb = pos >> 3;
-            const bool can_step = active && xb < have_end && (pos < wb || pos - wb < rows_out * 4u + 16u); // (text there, a staging slot free)
+            const bool can_step = active && xb < have_end && (pos < wb || pos - wb < rows_out * 4u + kStStageSlots); // (text there, a staging slot free)
             if (can_step) {
                 // the unit's class: looked up during the step before (under its gather) if the lane took a unit then
                 const uint32_t cls = cls_ok ? cls_next : class_at(pos);
@@ -234,7 +241,7 @@ __global__ __launch_bounds__(kStBlock, 4) void k_ac_states(DevTables T, AcStates
                 if (took) {
                     if (!in_dense && n_rep == kHyNodeCountMany) n_rep = (uint32_t)__popc(T.hy_mask[s]); // (rare)
                     if (pos >= count_from) cnt += n_rep;
-                    if (pos >= wb) stage[((pos - wb) & 15u) * 64u + lane] = ns;
+                    if (pos >= wb) stage[((pos - wb) & (kStStageSlots - 1u)) * 64u + lane] = ns;
                     ++pos;
                     active = pos < we;
                 }
@@ -258,7 +265,7 @@ __global__ __launch_bounds__(kStBlock, 4) void k_ac_states(DevTables T, AcStates
         }
 #endif
         if (mine && ((we - wb) & 3u)) // the chunk's last, partial group (only where the owned range ends)
-            for (uint32_t q = wb + ((we - wb) & ~3u); q < we; ++q) L.d_state[st_index(L.chunk_log2, w, lane, q - wb)] = stage[((q - wb) & 15u) * 64u + lane];
+            for (uint32_t q = wb + ((we - wb) & ~3u); q < we; ++q) L.d_state[st_index(L.chunk_log2, w, lane, q - wb)] = stage[((q - wb) & (kStStageSlots - 1u)) * 64u + lane];
         if (mine) L.d_counts[w * 64u + lane] = cnt;
         __builtin_amdgcn_wave_barrier();
     }
@@ -388,7 +395,7 @@ __global__ __launch_bounds__(256) void k_ac_states_out(DevTables T, AcStatesLaun
 }
 
 uint32_t ac_states_chunk_units() { return 1u << kStChunkLog2; }
-uint32_t ac_states_lanes_per_cu() { return kStBlock; }
+uint32_t ac_states_lanes_per_cu() { return (uint32_t)kStWgsPerCu * kStBlock; }
 // rows of the dense group the kernel can keep in LDS next to `page_bytes` of class pages (0: range classes)
 uint32_t ac_states_hot_rows(uint32_t n_cls, uint32_t n_dense, uint32_t page_bytes) {
     if (!n_cls || page_bytes + 16u > kStRowBytesMax) return 0u;
