@@ -180,3 +180,25 @@ def test_states_form_without_room_for_the_states_falls_back_to_the_tile_kernel(w
     N.set_tunable("tile_debug", 1 << 40)  # the buffer of 4 bytes per unit "cannot be had"
     got, kname = _run(a, hay, True)
     assert kname != "k_ac_states" and got.shape == want.shape and (got == want).all()
+
+
+def test_states_form_two_hundred_classes_from_pages_and_ids_of_nested_keywords():
+    """200 distinct units spread over three blocks of the plane (classes from LDS pages, class numbers up to 200 in a node's edge byte), keywords of 1-4
+    units that nest (several per position: the id lists of Map records), duplicates (the last one's index is the id)."""
+    rng = np.random.default_rng(77)
+    units = np.concatenate([rng.choice(np.arange(0x4E00, 0x5200), 120, replace=False), rng.choice(np.arange(0x0400, 0x0460), 50, replace=False),
+                            rng.choice(np.arange(0x61, 0x7B), 20, replace=False), [0x3042, 0x3044, 0x3046, 0xFF21, 0xFF22, 0x1F00, 0x2000, 0x00E9, 0x0131, 0x20AC]]).astype(np.uint16)
+    assert len(set(units.tolist())) == 200
+    kws = [units[rng.integers(0, 200, int(rng.integers(1, 5)))] for _ in range(3000)]
+    kws += [kws[i].copy() for i in range(0, 300, 7)]  # duplicates
+    n = 300000 + 17
+    hay = units[rng.integers(0, 200, n)]
+    hay[::97] = 0x0020
+    a = Automaton(N.MODE_ALL, kws, True)
+    want = Oracle(FAM_AC, kws).match(hay)
+    N.set_tunable("all_form", STATES_ALWAYS)
+    for with_ids in (False, True):
+        got, kname = _run(a, hay, with_ids, cap=len(want) + 8)
+        w = want if with_ids else want[:, :2]
+        assert kname == "k_ac_states" and got.shape == w.shape and (got == w).all()
+    assert a.info()["n_classes"] == 201
