@@ -56,7 +56,7 @@ class Profile(ctypes.Structure):
 # every symbol include/acgpu.h declares
 SYMBOLS = ["acgpu_build", "acgpu_free", "acgpu_get_info", "acgpu_match_u16", "acgpu_match_batch_u16", "acgpu_match_device",
            "acgpu_match_device_begin", "acgpu_match_device_end", "acgpu_match_device_abandon", "acgpu_synth_fill", "acgpu_synth_tokens", "acgpu_stream_probe",
-           "acgpu_set_tunable", "acgpu_strerror", "acgpu_last_hip_error", "acgpu_abi_version", "acgpu_debug_tables",
+           "acgpu_set_tunable", "acgpu_strerror", "acgpu_last_hip_error", "acgpu_abi_version", "acgpu_debug_tables", "acgpu_debug_states",
            "acgpu_debug_wordhash", "acgpu_stream_open", "acgpu_stream_feed", "acgpu_stream_close",
            "acgpu_match_u16_multi", "acgpu_comm_open", "acgpu_comm_close", "acgpu_comm_transport", "acgpu_comm_stream",
            "acgpu_match_device_allgather", "acgpu_last_rccl_error", "acgpu_gather_slot_bytes",
@@ -112,6 +112,8 @@ def lib():
         L.acgpu_strerror.argtypes = [ci]
         L.acgpu_last_hip_error.restype = ci
         L.acgpu_abi_version.restype = u32
+        L.acgpu_debug_states.restype = ci
+        L.acgpu_debug_states.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         L.acgpu_debug_tables.restype = ci
         L.acgpu_debug_tables.argtypes = [vp, vp, vp, vp, vp, vp, vp, ctypes.POINTER(u32)]
         L.acgpu_stream_open.restype = ci

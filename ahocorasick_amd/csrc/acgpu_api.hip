@@ -1773,6 +1773,26 @@ int acgpu_debug_tables(const acgpu_automaton *a, uint16_t *cls_lut, uint32_t *df
     return ACGPU_OK;
 }
 
+int acgpu_debug_states(const acgpu_automaton *a, uint64_t sizes[6], uint32_t *rows, uint32_t *nodes, uint32_t *mask, uint32_t *out,
+                       uint32_t *ids) {
+    if (!a || !sizes) return ACGPU_E_INVALID;
+    const HostTables &t = a->t;
+    const bool have = t.hy_n_states != 0 && (t.mode == ACGPU_MODE_ALL || t.mode == ACGPU_MODE_SHORTEST);
+    sizes[0] = have ? t.hy_n_states : 0;
+    sizes[1] = have ? t.hy_n_dense : 0;
+    sizes[2] = t.n_cls;
+    sizes[3] = have ? t.hy_dense.size() : 0;
+    sizes[4] = have ? t.hy_nodes.size() : 0;
+    sizes[5] = have ? t.hy_ids.size() : 0;
+    if (!have) return ACGPU_OK;
+    if (rows) std::memcpy(rows, t.hy_dense.data(), t.hy_dense.size() * sizeof(uint32_t));
+    if (nodes) std::memcpy(nodes, t.hy_nodes.data(), t.hy_nodes.size() * sizeof(uint32_t));
+    if (mask) std::memcpy(mask, t.hy_mask.data(), t.hy_mask.size() * sizeof(uint32_t));
+    if (out) std::memcpy(out, t.hy_out.data(), t.hy_out.size() * sizeof(uint32_t));
+    if (ids) std::memcpy(ids, t.hy_ids.data(), t.hy_ids.size() * sizeof(uint32_t));
+    return ACGPU_OK;
+}
+
 int acgpu_debug_wordhash(const acgpu_automaton *a, uint32_t *n_slots, uint32_t *slots, uint64_t *n_rec_words, uint32_t *recs,
                          uint8_t *fold_pgidx, uint32_t *n_pages, uint16_t *fold_pages, uint32_t *seed) {
     if (!a) return ACGPU_E_INVALID;

@@ -427,6 +427,16 @@ uint32_t acgpu_abi_version(void);
 int acgpu_debug_tables(const acgpu_automaton *a, uint16_t *cls_lut /*65536*/, uint32_t *dfa, uint32_t *out_len,
                        uint32_t *out_link, uint32_t *out_id, uint32_t *depth, uint32_t *first_out_state);
 
+/* Test hook (ACGPU_MODE_ALL / ACGPU_MODE_SHORTEST): the compact automaton k_ac_states walks (csrc/acgpu_build.cpp 6d), if the
+ * dictionary has one (at most 255 classes, keywords of at most 32 units, fewer than 2^23 states).  sizes[6] is always written:
+ * {states, states of the dense group, classes, words of rows, words of nodes, words of ids}; 0 states = none.  Arrays are copied
+ * when the pointer is non-NULL: rows = dense-group rows of `classes` resolved transitions (target state | bit 23 "reports
+ * matches" | its number of keywords << 24); nodes = 4 words per other state {fail state | 3 bits per edge: the child's number of
+ * keywords (7 = more), then three edges class << 24 | bit 23 | child}; mask[state] = bit L - 1 per keyword length L ending there;
+ * out = 2 words per state {mask, index of its keyword ids in ids -- or bit 31 | the id of its only keyword}; ids. */
+int acgpu_debug_states(const acgpu_automaton *a, uint64_t sizes[6], uint32_t *rows, uint32_t *nodes, uint32_t *mask, uint32_t *out,
+                       uint32_t *ids);
+
 /* Test hook (ACGPU_MODE_WHOLEWORD): the whole-keyword hash table the device kernel probes.  Sizes and the seed are always
  * written; arrays are copied when the pointer is non-NULL.
  * Hashes of a folded keyword over its max(8, ceil(length/2)) packed words w (two units per word, zero beyond the keyword):

@@ -307,3 +307,77 @@ def test_stream_argument_checks_without_a_device():
         rc = L.acgpu_stream_feed(h, vp(buf), 4, 1, N.REC_MAP, vp(out), 4, ctypes.byref(n_out), ctypes.byref(base))
         assert rc in (N.E_NODEVICE, N.E_HIP)
     L.acgpu_stream_close(h)
+
+
+def _states_tables(a):
+    sizes = (ctypes.c_uint64 * 6)()
+    N.check(N.lib().acgpu_debug_states(a.handle, sizes, None, None, None, None, None), "debug_states")
+    n, n_dense, n_cls, w_rows, w_nodes, w_ids = (int(x) for x in sizes)
+    if n == 0:
+        return None
+    rows, nodes, mask, out, ids = (np.zeros(max(k, 1), np.uint32) for k in (w_rows, w_nodes, n, 2 * n, w_ids))
+    vp = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+    N.check(N.lib().acgpu_debug_states(a.handle, sizes, vp(rows), vp(nodes), vp(mask), vp(out), vp(ids)), "debug_states")
+    return n, n_dense, n_cls, rows.reshape(n_dense, n_cls), nodes[:w_nodes].reshape(-1, 4), mask, out.reshape(n, 2), ids
+
+
+def _simulate_states(a, hay):
+    """Test-only restatement of what k_ac_states / k_ac_states_out do with the compact automaton (csrc/acgpu_states.hip): one step per
+    unit, a miss in a node goes to the fail state and looks at the unit again; records from the mask's bits, longest first; the
+    counts that ride in the transitions must be the masks' popcounts."""
+    n, n_dense, n_cls, rows, nodes, mask, out, ids = _states_tables(a)
+    cls = _tables(a)[1]
+    s, recs = 0, []
+    for i, u in enumerate(hay.tolist()):
+        c = int(cls[u])
+        while True:
+            if s < n_dense:
+                e = int(rows[s, c])
+                ns, flag, rep = e & 0x7FFFFF, (e >> 23) & 1, e >> 24
+                break
+            nd = [int(x) for x in nodes[s - n_dense]]
+            if c == 0:
+                ns, flag, rep = 0, 0, 0
+                break
+            hit = [k for k in (1, 2, 3) if nd[k] >> 24 == c]
+            if hit:
+                k = hit[0]
+                ns, flag, rep = nd[k] & 0x7FFFFF, (nd[k] >> 23) & 1, (nd[0] >> (23 + 3 * (k - 1))) & 7
+                break
+            s = nd[0] & 0x7FFFFF
+        s = ns
+        m = int(mask[s])
+        assert (m != 0) == bool(flag) and (rep == bin(m).count("1") or (rep == 7 and bin(m).count("1") >= 7)), (i, s, m, rep)
+        assert int(out[s, 0]) == m
+        at, k = int(out[s, 1]), 0
+        for L in range(32, 0, -1):
+            if m >> (L - 1) & 1:
+                kid = (at & 0x7FFFFFFF) if at >> 31 else int(ids[at + k])
+                recs.append([i + 1 - L, i + 1, kid])
+                k += 1
+    return recs
+
+
+def test_compact_automaton_of_the_state_form_reproduces_the_oracle(fixtures):
+    """acgpu_build.cpp 6d on the CPU: fixtures, a fuzz over small alphabets (fail hops, nested keywords, duplicates), both case modes."""
+    done = 0
+    for fx in fixtures:
+        if "keywords_gen" in fx:
+            continue
+        hay, kws = fixture_inputs(fx)
+        a = Automaton(N.MODE_ALL, kws, True)
+        if _states_tables(a) is None:
+            continue  # (a keyword of more than 32 units)
+        assert _simulate_states(a, hay) == fx["AC"], fx["name"]
+        done += 1
+    assert done >= 3
+    rng = np.random.default_rng(11)
+    alpha = [ord(c) for c in "abcAB"] + [0x00E9, 0x00C9]
+    for _ in range(40):
+        hay, kws = rand_case(rng, alpha, int(rng.integers(1, 25)), 7, int(rng.integers(0, 400)))
+        for cs in (True, False):
+            a = Automaton(N.MODE_ALL, kws, cs)
+            want = Oracle(FAM_AC, kws, case_sensitive=cs, lower=LOWER).match(hay).tolist()
+            assert _simulate_states(a, hay) == want
+    long_kw = [np.full(33, ord("a"), np.uint16)]
+    assert _states_tables(Automaton(N.MODE_ALL, long_kw, True)) is None  # no mask bit for 33 units: no compact automaton
