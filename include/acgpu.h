@@ -20,7 +20,15 @@
  *    concurrent matches on one automaton are safe (they serialise on its
  *    per-device scratch pool);
  *  - there is NO CPU matching backend: every acgpu_match_* call needs a HIP
- *    device and fails with ACGPU_E_NODEVICE / ACGPU_E_HIP without one.
+ *    device and fails with ACGPU_E_NODEVICE / ACGPU_E_HIP without one;
+ *  - device memory: the tables of an automaton (built once per device; the
+ *    reference's 235 886-word README dictionary: 0.5 GB) and a grow-only scratch
+ *    pool per automaton and device -- up to 16 bytes per record of the largest
+ *    call, and for the matchers that keep a value per haystack unit
+ *    (LongestMatch: 1-4 bytes; AhoCorasick on texts with dense matches,
+ *    csrc/acgpu_states.hip: 4 bytes) that much per unit of the largest shard.
+ *    A pool that cannot grow makes the call take a form that needs less, or
+ *    fail with ACGPU_E_NOMEM; acgpu_free releases everything.
  */
 #ifndef ACGPU_H
 #define ACGPU_H
