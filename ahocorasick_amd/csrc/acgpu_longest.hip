@@ -1311,7 +1311,6 @@ __global__ __launch_bounds__(kEmitBlock, 8) void k_longest_emit_ends(LongestChai
     // hide each other's start-up loads); the start carried over a step boundary lives in a scalar register
     constexpr int kCap = 1024 + 8;
     __shared__ uint16_t st_x[kEmitBlock / kWave][kCap], st_y[kEmitBlock / kWave][kCap];
-    __shared__ int st_id[REC == ACGPU_REC_MAP ? kEmitBlock / kWave : 1][REC == ACGPU_REC_MAP ? kCap : 1];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const uint32_t t = blockIdx.x * (kEmitBlock / kWave) + wave;
     if (t >= L.n_tiles) return;
@@ -1358,8 +1357,7 @@ __global__ __launch_bounds__(kEmitBlock, 8) void k_longest_emit_ends(LongestChai
             const uint32_t r = r0 + (uint32_t)__builtin_ctz(b);
             b &= b - 1u;
             if (k < (uint32_t)kCap) { // (always, with consistent bitmaps)
-                mine[k] = (uint16_t)r;
-                if (REC == ACGPU_REC_MAP && !half) st_id[wave][k] = (int)L.d_out_id[L.d_state[step_base + r]];
+                mine[k] = (uint16_t)r; // (Map records: the keyword's id is fetched when the record is written -- 64 independent gathers, not a chain per lane here)
             }
             ++k;
         }
@@ -1374,13 +1372,13 @@ __global__ __launch_bounds__(kEmitBlock, 8) void k_longest_emit_ends(LongestChai
                 reinterpret_cast<int2 *>(L.d_out)[dst] = make_int2(x, y);
             } else {
                 int32_t *o = reinterpret_cast<int32_t *>(L.d_out) + dst * 3;
-                o[0] = x; o[1] = y; o[2] = carried ? (int)carry_id : st_id[wave][j];
+                o[0] = x; o[1] = y; o[2] = carried ? (int)carry_id : (int)L.d_out_id[L.d_state[x]];
             }
         }
         const uint32_t open = carry + total_m - m; // 0 or 1
         if (open && !(carry && m == 0)) {           // the open start is this step's last one (slot m)
             carry_start = __builtin_amdgcn_readfirstlane(step_base + sx[m]);
-            if (REC == ACGPU_REC_MAP) carry_id = __builtin_amdgcn_readfirstlane((uint32_t)st_id[wave][m]);
+            if (REC == ACGPU_REC_MAP) carry_id = __builtin_amdgcn_readfirstlane(L.d_out_id[L.d_state[carry_start]]);
         }
         __builtin_amdgcn_wave_barrier();
         carry = open ? 1u : 0u;
