@@ -202,3 +202,25 @@ def test_states_form_two_hundred_classes_from_pages_and_ids_of_nested_keywords()
         w = want if with_ids else want[:, :2]
         assert kname == "k_ac_states" and got.shape == w.shape and (got == w).all()
     assert a.info()["n_classes"] == 201
+
+
+def test_host_entry_and_stream_over_a_dense_text_change_to_the_states_form_on_the_way(words):
+    """acgpu_match_u16 on a text of more than one 2^24-unit chunk, and the chunked match(Readable) entry: the first chunk runs the tile
+    kernel, what it finds sends the later ones through k_ac_states; the records are the oracle's whatever form each chunk took."""
+    from ahocorasick_amd.strings import Stream
+    kws = [w for w in words if len(w) > 2]
+    a = Automaton(N.MODE_ALL, kws, True)
+    block = synth.readme_text(21, (1 << 22) + 12345, words)
+    hay = np.tile(block, 5)[: (1 << 24) + (1 << 21) + 777]
+    want = Oracle(FAM_AC, kws).match(hay, cap=hay.size)
+    got = a.match_host(hay, True, cap=len(want) + 16)
+    assert got.shape == want.shape and (got == want).all()
+    st = Stream(a, with_ids=True)
+    parts, step = [], (1 << 22) + 4321
+    for lo in range(0, 1 << 24, step):
+        hi = min(lo + step, 1 << 24)
+        parts.append(st.feed(hay[lo:hi], final=(hi == 1 << 24), cap=1 << 22))
+    st.close()
+    got_s = np.concatenate(parts)
+    w16 = want[want[:, 1] <= (1 << 24)]
+    assert got_s.shape == w16.shape and (got_s == w16.astype(np.int64)).all()
