@@ -3,19 +3,23 @@
 //
 // The reference's loop (S/AhoCorasickSet.java:204-226: one transition per unit, fail links until a node has the edge; output walk
 // :522-535: the node's own keyword, then its suffixes, longest first) is what runs here, chunk by chunk:
-//  * k_ac_states: a lane owns a chunk of 512 units, starts at the root max_len - 1 units before it (from there on its state is
-//    the sequential automaton's) and writes the state behind every unit -- 4 bytes per unit, the h-id of acgpu_build.cpp 6d with
-//    bit 23 = "reports matches".  A state of the DENSE group (the root, depth 1 and 2, more than three children) has a row of
-//    resolved transitions: the first rows in LDS, the others in L2; a COMPACT state is one 16-byte node {fail, three edges}: a
-//    miss moves to the fail state WITHOUT taking the unit (one more iteration) -- the automaton of the reference's README
-//    dictionary is 23 MB this way (345 MB as a resolved table, a cache miss per unit).  Every iteration is one step of every
-//    lane's own chain (no lock step: a lane that follows a fail link falls one iteration behind); the text comes through a
-//    ring of four 8-unit blocks per lane in LDS, one block ahead; all three lookups of a step (LDS row, row in memory, node) are
-//    issued for every lane with clamped addresses and selected afterwards: one wait per iteration.
-//  * k_ac_states_out<MAP, false>: records per tile of 4096 positions (the popcount of hy_mask[state] where bit 23 is set);
-//    a prefix sum over the tiles; k_ac_states_out<MAP, true>: the records, in text order, the lengths of a position from the
-//    mask's bits (longest first), Map records walk hy_out for the keyword ids.
-// Bound by the gathers of k_ac_states (one per unit and fail hop) and by the record stores, not by the text stream.
+//  * k_ac_states: a lane owns a chunk of 1024 units (fewer for texts that would not fill the chip), starts at the root max_len - 1
+//    units before it (from there on its state is the sequential automaton's) and leaves the state behind every unit -- 4 bytes
+//    per unit, the h-id of acgpu_build.cpp 6d with bit 23 = "reports matches".  A state of the DENSE group (the root, depth 1
+//    and 2, more than three children) has a row of resolved transitions: the first rows in LDS, the others in memory; a COMPACT
+//    state is one 16-byte node {fail | counts, three edges}: a miss moves to the fail state WITHOUT taking the unit (one more
+//    iteration) -- the automaton of the reference's README dictionary is 29 MB this way (345 MB as a resolved table, a cache miss
+//    per unit).  Every iteration is one step of every lane's own chain (no lock step: a lane that follows a fail link falls one
+//    iteration behind), written as selects; ONE 16-byte gather serves a row in memory and a node alike.  Text: a ring of 8-unit
+//    blocks per lane in LDS, topped up by all lanes together; states: staged in LDS and stored ROW by row -- group g of all 64
+//    lanes is a kilobyte of consecutive memory (st_index) -- once every walking lane has passed the group.  The number of keywords
+//    a state reports rides in the transitions: the kernel leaves its chunks' record counts.
+//  * (a prefix sum over the chunks' counts: launch_exclusive_scan)
+//  * k_ac_states_out<MAP>: a wave per chunk; states -> hy_mask (Map: {mask, id list} in one gather) -> every lane writes the records
+//    of its four positions into an LDS window at their place among the step's records (the masks' bits from the top: position,
+//    then longest first) -> the window is copied out, 64 consecutive records per store; Map records fetch their ids then.
+// Bound by the rate of L2 requests -- one gather per lane and step in k_ac_states, one per position (Map: and per record) in
+// k_ac_states_out -- not by the text stream and not by latency (two workgroups per CU are slower: EXPERIMENTS.md, round 5).
 #include <algorithm>
 #include <cstdio>
 
@@ -79,7 +83,7 @@ struct __attribute__((packed, aligned(2))) StUnits8 {
 };
 
 #ifdef ACGPU_TIMING
-__device__ unsigned long long g_st_timing[8]; // s_memtime ticks (100 MHz) per wave: refills, flushes, steps up to the transition, the rest, total, iterations, waves
+__device__ unsigned long long g_st_timing[8]; // s_memtime ticks (core clocks here) summed over the waves: refills, flushes, steps up to the transition, of them the gather, total, iterations, waves
 #define ST_T0() const unsigned long long t0_ = __builtin_amdgcn_s_memtime()
 #define ST_ACC(i) tm[i] += __builtin_amdgcn_s_memtime() - t0_
 #else
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(kStBlock, 4 * kStWgsPerCu) void k_ac_states(DevTabl
         const uint32_t we = (uint32_t)std::min<uint64_t>(wb64 + (1u << L.chunk_log2), L.own_end); // one past the last
         uint32_t pos = wb > L.halo ? wb - L.halo : 0u;                           // the root stands here
         uint32_t s = 0;
-        uint32_t have_end = pos >> 3;   // blocks [have_end - 4, have_end) are in the ring (none yet)
+        uint32_t have_end = pos >> 3;   // blocks [have_end - kStRingBlocks, have_end) are in the ring (none yet)
         uint32_t cnt = 0;               // records of the chunk
         const uint32_t count_from = std::max(wb, L.own_begin);
         bool active = mine && pos < we;
