@@ -34,7 +34,7 @@ def _run(a, hay, with_ids, own=None, d_hay=None, cap=None, text_begin=True):
     kw = {}
     if own is not None:
         kw["own"] = own
-    n_out, rc, prof, _ = a.match_device(d_hay.data_ptr(), hay.size, with_ids, d_out.data_ptr(), cap, profile=True,
+    n_out, rc, prof, _ = a.match_device(d_hay.data_ptr(), hay.size, with_ids, d_out.data_ptr(), cap, profile=True, text_begin=text_begin,
                                         stream=torch.cuda.current_stream().cuda_stream, **kw)
     assert rc == N.OK, rc
     return d_out[:n_out].cpu().numpy(), prof["scan_kernel"]
@@ -224,3 +224,19 @@ def test_host_entry_and_stream_over_a_dense_text_change_to_the_states_form_on_th
     got_s = np.concatenate(parts)
     w16 = want[want[:, 1] <= (1 << 24)]
     assert got_s.shape == w16.shape and (got_s == w16.astype(np.int64)).all()
+
+
+def test_states_form_on_a_rank_buffer_that_begins_inside_the_text(words):
+    """What one rank of the multi-GPU drivers holds: [max_len - 1 units of left halo | its own range], not the text's beginning --
+    the walk of the first chunk starts at the buffer's first unit, a match belongs to the range that owns its last unit."""
+    a = Automaton(N.MODE_ALL, words, True)
+    hay = synth.readme_text(17, 700001, words)
+    want = Oracle(FAM_AC, words).match(hay)
+    halo = a.info()["max_keyword_len"] - 1
+    N.set_tunable("all_form", STATES_ALWAYS)
+    for lo, hi in ((123457, 400003), (halo, 5000), (halo + 1, halo + 2), (350000, 700001)):
+        buf = hay[lo - halo:hi]
+        got, kname = _run(a, buf, True, own=(halo, halo + hi - lo), text_begin=False)
+        w = want[(want[:, 1] > lo) & (want[:, 1] <= hi)].copy()
+        w[:, :2] -= lo - halo
+        assert kname == "k_ac_states" and got.shape == w.shape and (got == w).all(), (lo, hi)
