@@ -49,6 +49,9 @@ python3 tools/kbench.py --rounds 5 --variants '{"tile":{},"dfa":{"force_kernel":
 python3 tools/wide_alphabets.py > "$OUT/wide_alphabets.txt" 2>&1
 python3 tools/longest_shapes.py > "$OUT/longest_shapes.txt" 2>&1
 python3 tools/shapes.py > "$OUT/shapes.txt" 2>&1
+# round 5: the README word list through the tile kernel, the DFA chunk scan and k_ac_states; Set against Map records
+python3 tools/readme_shapes.py 2>&1 | grep -v amdgpu.ids > "$OUT/readme_shapes.txt"
+python3 tools/map_flavours.py 2>&1 | grep -v amdgpu.ids > "$OUT/map_flavours.txt"
 # the three bench lines once more with this collection's traffic attached (bench.py attaches profiles/latest_traffic.json only
 # when it was measured on the sources it runs; the copy of the repository on this box is scratch)
 cp "$OUT/latest_traffic.json" profiles/latest_traffic.json

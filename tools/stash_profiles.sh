@@ -13,6 +13,6 @@ done
 cp $src/pmc_traffic.json $dst/${pre}_pmc_traffic.json
 cp $src/pmc_traffic_all.json $dst/${pre}_pmc_traffic_all.json
 for f in pmc_sq pmc_sq_c4 pmc_sq_c5; do [ -f $src/$f.txt ] && cp $src/$f.txt $dst/${pre}_$f.txt; done
-for f in bench_c3_single_process_rccl.json bench_c3_single_process_peer2.json bench_readme.json reserve_cus.txt stream_rate.txt latency.txt dfa.txt wide_alphabets.txt longest_shapes.txt shapes.txt; do [ -f $src/$f ] && grep -v amdgpu.ids $src/$f > $dst/${pre}_$f; done
+for f in bench_c3_single_process_rccl.json bench_c3_single_process_peer2.json bench_readme.json reserve_cus.txt stream_rate.txt latency.txt dfa.txt wide_alphabets.txt longest_shapes.txt shapes.txt readme_shapes.txt map_flavours.txt; do [ -f $src/$f ] && grep -v amdgpu.ids $src/$f > $dst/${pre}_$f; done
 cp $src/latest_traffic.json profiles/latest_traffic.json
 ls $dst | grep "^${pre}_" | wc -l
