@@ -18,8 +18,11 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-STREAMING = ("k_longest_chain_lds", "k_longest_emit_ends", "k_scan_", "k_stream_probe")        # reads: 16 B/lane streams only
-MIXED = ("k_ww_tile", "k_ww_pp", "k_ac_tile", "k_longest_block", "k_longest_walk_list", "k_permute")       # a stream plus gathers
+STREAMING = ("k_longest_chain_lds", "k_longest_emit_ends", "k_scan_", "k_stream_probe", "k_longest_bits")   # reads: 16 B/lane streams only
+# (k_longest_bits: the text as 16-byte pieces, the trie sits in LDS; its parked marks come back as whole 16-byte words)
+MIXED = ("k_ww_tile", "k_ww_pp", "k_ac_tile", "k_longest_block", "k_longest_walk_list", "k_permute",
+         "k_ac_states", "k_longest_follow")       # a stream plus gathers
+RECORD_BYTES = {"C2": 12, "C4": 8, "C5": 12}   # what collect_profiles.sh runs: Map records, config 4 with --set
 
 
 GENERATORS = ("k_synth", "k_token")  # the benchmark's input generators (and everything dispatched before them: their prefix sums)
@@ -43,8 +46,19 @@ def last_per_kernel(path, counter):
     return per
 
 
+def algorithmic_bytes(d, cfg, units):
+    """2 B per unit + R per record, as bench.py counts them; the record count is what tools/kbench.py printed in the counter pass."""
+    import re
+    try:
+        m = re.findall(r"n_out=(\d+) rc=0", open("%s/pmc_fetch_%s.log" % (d, cfg)).read())
+    except OSError:
+        m = []
+    return 2 * units + RECORD_BYTES[cfg] * int(m[-1]) if m else None
+
+
 def main():
     d = sys.argv[1]
+    impossible = []
     from ahocorasick_amd import _native as N
     src = N.source_hash()
     out = {"csrc_sha256": src}
@@ -67,7 +81,10 @@ def main():
             ks[k] = {"FETCH_SIZE_bytes_as_reported": f, "WRITE_SIZE_bytes": w, "reads": kind, "traffic_bytes_range": [a, b]}
             lo += a
             hi += b
-        out[cfg] = {"units": units, "kernels": ks, "pipeline_traffic_bytes_range": [lo, hi]}
+        alg = algorithmic_bytes(d, cfg, units)
+        out[cfg] = {"units": units, "kernels": ks, "pipeline_traffic_bytes_range": [lo, hi], "algorithmic_bytes": alg}
+        if alg is not None and hi < 0.98 * alg:  # a pipeline cannot move less than the text it reads plus the records it writes
+            impossible.append("%s: traffic %.3f GB < algorithmic %.3f GB (a kernel is missing from STREAMING / MIXED?)" % (cfg, hi / 1e9, alg / 1e9))
         latest.append({"config": cfg, "units_per_gpu": units, "csrc_sha256": src, "traffic_bytes": hi, "traffic_bytes_range": [lo, hi],
                        "source": "%s: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tools/kbench.py, summed over the "
                                  "configuration's kernels; FETCH_SIZE x2 (gfx950 half-count of wide streaming reads, MI355X_MICROARCH.md) per "
@@ -85,6 +102,8 @@ def main():
                 ent["source"] += "; config 2: `traffic` is the tile kernel's, from the calibrated passes of tools/pmc_traffic.py (" + cal["calibration"] + ")"
         out["C2"]["tile_kernel_calibrated"] = cal
     print(json.dumps(out, indent=1))
+    if impossible:
+        raise SystemExit("pmc_traffic_all: " + "; ".join(impossible))
     if "--latest" in sys.argv:
         json.dump(latest, open(sys.argv[sys.argv.index("--latest") + 1], "w"), indent=1)
 
