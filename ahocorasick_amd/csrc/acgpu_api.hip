@@ -418,7 +418,7 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
     uint64_t scanned = 0;
     uint32_t n_chunks = 0, chunk_units = 0, perm_base = (uint32_t)sh->own_begin;
     const uint32_t *id_map = nullptr;
-    bool split = false, fused_finalize = false, ww_direct = false, ext_timed = false;
+    bool split = false, fused_finalize = false, ww_direct = false, ext_timed = false, fused_tail = false;
     uint32_t regions_per_wg = 0, ww_region_cap = 0;
     int by_start = 0;
     if (ww) {
@@ -592,6 +592,23 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
                          (uint64_t)waves_per_block * L.regions_per_wave <= kPermuteWgRegions && !(L.debug & 262144u);
         L.wg_sums = fused_finalize ? 1u : 0u;
         regions_per_wg = (uint32_t)waves_per_block * L.regions_per_wave;
+        // The fused tail (TileLaunch::fused_tail): no finalize launch at all -- the scan's workgroups put their own slices in order
+        // when their spans are scanned, each behind the counts of the workgroups that started before it, and the last one
+        // reports the call's result.  Same conditions as the one-launch finalize.  Tunable tile_form bit 1: never (A/B, tests).
+        if (fused_finalize && !(tunables().tile_form & 1)) {
+            fused_tail = true;
+            L.fused_tail = 1;
+            L.wg_sums = 0; // (the workgroups' sums go through their own LDS)
+            L.d_out = d_out;
+            L.out_cap = cap;
+            L.out_map = record_kind == ACGPU_REC_MAP ? 1 : 0;
+            L.d_id_map = id_map;
+            unsigned long long *h_slot_t = tk ? tk->h_count : d.h_counter, *d_slot_t = nullptr;
+            HIP_TRY(hipHostGetDevicePointer((void **)&d_slot_t, h_slot_t, 0));
+            L.tail_result = d_slot_t;
+            L.tail_d_result = reinterpret_cast<acgpu_device_result *>(sh->d_result);
+            L.tail_zero_counters = counters_next;
+        }
 #ifdef ACGPU_TIMING
         static DevBuf timing;
         if ((rc = timing.ensure((size_t)L.grid * 16 * 8 * 8))) return rc;
@@ -609,6 +626,7 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
                 L.ev_stop = ev[1];
                 ext_timed = true;
             }
+            if (fused_tail) L.ev_stop = (timed || tk) ? ev[2] : nullptr; // the scan is the call's only kernel: its end is the call's
             HIP_TRY(launch_ac_tile(d.T, L, stream, &kname));
         }
 #ifdef ACGPU_TIMING
@@ -685,6 +703,35 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         n_chunks = L.n_chunks;
         chunk_units = L.chunk_units;
         scanned = own_len + (uint64_t)L.n_chunks * halo;
+    }
+    if (fused_tail) { // nothing behind the scan kernel: it has ordered its records, reports the count and has zeroed the other counter set
+        d.cclean[1 - cs] = true;
+        d.cset = 1 - cs;
+        if (tk) {
+            tk->shard = *sh;
+            tk->record_kind = record_kind;
+            tk->d_out = d_out;
+            tk->stream = stream;
+            tk->done_is_ev2 = true;
+            tk->one_kernel = true;
+            tk->scanned = scanned;
+            std::snprintf(tk->kname, sizeof(tk->kname), "%s", kname);
+            return ACGPU_OK;
+        }
+        HIP_TRY(hipStreamSynchronize(stream));
+        if ((uint32_t)d.h_counter[1] != 0) // a scratch slice overflowed: fused kernel, one scratch slice
+            return match_all(a, d, sh, record_kind, d_out, cap, n_out, stream, prof, nullptr, true, Tov);
+        *n_out = *d.h_counter;
+        d.all_density = (double)*n_out / (double)own_len;
+        if (prof) {
+            HIP_TRY(hipEventElapsedTime(&prof->scan_ms, d.ev[0], d.ev[2]));
+            prof->finalize_ms = 0.0f;
+            prof->total_ms = prof->scan_ms;
+            prof->scan_units = scanned;
+            prof->n_matches = *n_out;
+            std::snprintf(prof->scan_kernel, sizeof(prof->scan_kernel), "%s", kname);
+        }
+        return *n_out > cap ? ACGPU_E_OVERFLOW : ACGPU_OK;
     }
     if (!fused_finalize)
         HIP_TRY(launch_exclusive_scan((const uint32_t *)d.chunk_counts.p, n_chunks, (uint64_t *)d.offsets.p,
@@ -1592,6 +1639,7 @@ int begin_shard(acgpu_automaton *a, DeviceState &dd, acgpu_shard *sh, int record
     if (!tk) return ACGPU_E_INVALID; // too many calls in flight: collect one first
     tk->profiled = want_profile != 0;
     tk->done_is_ev2 = false;
+    tk->one_kernel = false;
     tk->cap = cap;
     tk->user_shard = sh;
     tk->kname[0] = 0;
@@ -1665,6 +1713,7 @@ int64_t acgpu_set_tunable(const char *name, int64_t value) {
     else if (!std::strcmp(name, "dense_budget_bytes")) slot = &t.dense_budget_bytes;
     else if (!std::strcmp(name, "force_kernel")) slot = &t.force_kernel;
     else if (!std::strcmp(name, "region_units")) slot = &t.region_units;
+    else if (!std::strcmp(name, "tile_form")) slot = &t.tile_form;
     else if (!std::strcmp(name, "tile_debug")) slot = &t.tile_debug;
     else if (!std::strcmp(name, "ww_first_seed")) slot = &t.ww_first_seed;
     else if (!std::strcmp(name, "ww_no_bloom")) slot = &t.ww_no_bloom;
@@ -1910,7 +1959,10 @@ int end_ticket(const acgpu_automaton *ca, acgpu_ticket *ticket, uint64_t *n_out,
     d->inflight--;
     if (prof) {
         std::memset(prof, 0, sizeof(*prof));
-        if (tk->profiled) {
+        if (tk->profiled && tk->one_kernel) {
+            HIP_TRY(hipEventElapsedTime(&prof->scan_ms, tk->ev[0], tk->ev[2]));
+            prof->total_ms = prof->scan_ms;
+        } else if (tk->profiled) {
             HIP_TRY(hipEventElapsedTime(&prof->scan_ms, tk->ev[0], tk->ev[1]));
             HIP_TRY(hipEventElapsedTime(&prof->finalize_ms, tk->ev[1], tk->ev[2]));
             HIP_TRY(hipEventElapsedTime(&prof->total_ms, tk->ev[0], tk->ev[2]));

@@ -53,6 +53,7 @@ struct Ticket {
     unsigned long long *h_count = nullptr; // pinned, 64 bytes
     bool busy = false, profiled = false;
     bool done_is_ev2 = false; // the completion to wait for is ev[2] (the finalize kernel's own end), not `done`
+    bool one_kernel = false;  // the call was one kernel (the tile kernel with the fused tail): ev[0] .. ev[2] is its dispatch, ev[1] is not recorded
     // how _end collects it: 0 = the AhoCorasick / WholeWord pipeline (count and overflow word in h_count), 1 = a chain pipeline
     // that was enqueued (LONGEST walk: count in h_count[0], chain exit in h_count[2]), 2 = the call ran synchronously inside
     // _begin (the other families): everything is in the fields below

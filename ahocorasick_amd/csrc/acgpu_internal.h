@@ -332,6 +332,7 @@ struct Tunables {
     std::atomic<int64_t> no_state_form{0};    // builder: 1 = no compact automaton for k_ac_states (A/B)
     std::atomic<int64_t> no_bits_trie{0};     // builder: 1 = no path-compressed trie for k_longest_bits (the walk pipeline instead: A/B)
     std::atomic<int64_t> reserve_cus{0};      // CUs left without a scan workgroup (room for a collective's kernels under the scan)
+    std::atomic<int64_t> tile_form{0};        // ALL, tile kernel, bits: 1 = never the fused tail (a finalize launch behind the scan: tests, A/B)
 };
 Tunables &tunables();
 

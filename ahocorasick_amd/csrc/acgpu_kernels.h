@@ -79,6 +79,21 @@ struct TileLaunch {
     // Profiled calls: the scan kernel's own dispatch timestamps instead of two hipEventRecord markers around it (host side only;
     // nullptr = a plain launch).  A marker is a packet of its own with a barrier: three of them cost 13-20 us per step at config 2.
     hipEvent_t ev_start, ev_stop;
+    // Fused tail (k_ac_tile, the fused forms; `fused_tail` != 0): no finalize launch.  Workgroups take a number in the order in
+    // which they start (d_counter[3] of the call's counter set; the number names the workgroup's span, slice and counters), so
+    // every workgroup with a lower number is running or done.  When its waves have scanned their regions a workgroup publishes
+    // {done, its records} (d_counter[number * kCounterStride + 2]), waits for the words of the workgroups before it -- their
+    // sum is where its records begin -- and puts the records of its own scratch slice in their final place in d_out
+    // (region offsets through LDS, which is free by then).  The workgroup with the last number knows the call's count: it
+    // reports {count, overflow word} (tail_result / tail_d_result), clears the word and zeroes the other counter set.
+    uint32_t fused_tail;
+    void *d_out;
+    uint64_t out_cap;
+    int out_map;              // 1: {start, end, id} records (12 bytes), 0: {start, end}
+    const uint32_t *d_id_map; // reversed-trie node -> keyword id (or nullptr)
+    unsigned long long *tail_result;       // device-visible pinned host memory: [0] = count, [1] = overflow word
+    acgpu_device_result *tail_d_result;    // acgpu_shard::d_result or nullptr
+    unsigned long long *tail_zero_counters; // the counter set of the NEXT call (kMaxSlices x words 0..3), or nullptr
     int32_t *d_region_recs; // nullptr: the scratch slices + k_permute
     uint32_t region_cap;
     unsigned long long *d_timing; // -DACGPU_TIMING builds only: 8 cycle counters per wave (tools/build_variant.sh timing)

@@ -536,6 +536,8 @@ __global__ __launch_bounds__(256) void k_permute(const ScratchRec *scratch, cons
             for (uint32_t i = threadIdx.x; i < (uint32_t)kMaxSlices; i += blockDim.x) {
                 tail.zero_counters[(size_t)i * kCounterStride] = 0;
                 tail.zero_counters[(size_t)i * kCounterStride + 1] = 0; // (the workgroup sums of the fused finalize)
+                tail.zero_counters[(size_t)i * kCounterStride + 2] = 0; // (the fused tail's words: a workgroup's {done, records}, the start tickets)
+                tail.zero_counters[(size_t)i * kCounterStride + 3] = 0;
             }
         if (tail.result && threadIdx.x == 0) {
             const unsigned long long total = *tail.total;
@@ -586,6 +588,8 @@ __global__ __launch_bounds__(256) void k_ww_compact(const int32_t *recs, uint32_
             for (uint32_t i = threadIdx.x; i < (uint32_t)kMaxSlices; i += blockDim.x) {
                 tail.zero_counters[(size_t)i * kCounterStride] = 0;
                 tail.zero_counters[(size_t)i * kCounterStride + 1] = 0;
+                tail.zero_counters[(size_t)i * kCounterStride + 2] = 0; // (the fused tail's words: a workgroup's {done, records}, the start tickets)
+                tail.zero_counters[(size_t)i * kCounterStride + 3] = 0;
             }
         if (tail.result && threadIdx.x == 0) {
             const unsigned long long total = *tail.total;
@@ -723,6 +727,8 @@ __global__ __launch_bounds__(256) void k_permute_wg(const ScratchRec *scratch, c
             for (uint32_t i = threadIdx.x; i < (uint32_t)kMaxSlices; i += blockDim.x) {
                 tail.zero_counters[(size_t)i * kCounterStride] = 0;
                 tail.zero_counters[(size_t)i * kCounterStride + 1] = 0;
+                tail.zero_counters[(size_t)i * kCounterStride + 2] = 0; // (the fused tail's words: a workgroup's {done, records}, the start tickets)
+                tail.zero_counters[(size_t)i * kCounterStride + 3] = 0;
             }
         if (tail.result && threadIdx.x == 0) {
             const uint32_t flag = tail.flag ? *tail.flag : 0u;

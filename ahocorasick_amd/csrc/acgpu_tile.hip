@@ -471,6 +471,124 @@ __device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) {
 }
 #endif
 
+// The fused tail (TileLaunch::fused_tail): what k_permute_wg did in a launch of its own, by the scan's workgroups themselves.
+// Every wave of the workgroup calls it when its span is scanned.  A record's rank counts through its wave's whole span, so
+// its final index is (records of the workgroups before this one) + (records of the workgroup's waves before its wave) + rank:
+// nothing but the sixteen wave totals and the slice's fill mark is handed over, through LDS -- the tail is a chain of memory
+// round trips behind the slowest workgroup's scan, and every word that stays in LDS is one of them less.
+constexpr unsigned long long kFtDone = 1ull << 62;
+constexpr uint32_t kFtWords = 2 + kTileBlock / kWave; // [0] the workgroup's number, [1] the slice's fill mark, [2 + w] wave w's records
+__device__ __forceinline__ uint32_t ft_wave_sum(uint32_t x) { return __builtin_amdgcn_readlane(wave_inclusive_scan_dpp(x), kWave - 1); }
+__device__ __forceinline__ void tile_fused_tail(const TileLaunch &L, uint32_t wg, uint32_t *wg_words, uint32_t wave_total, uint32_t res_cur,
+                                                uint32_t res_left, uint32_t slot_limit) {
+    const uint32_t lane = lane_id(), wave = threadIdx.x / kWave;
+    constexpr uint32_t kWaves = kTileBlock / kWave;
+    const ScratchRec *slice = L.d_scratch + (size_t)wg * L.slice_slots;
+    // the wave's unused reservation: holes the loop below skips; the slice is filled up to the end of the last reservation
+    for (uint32_t i = lane; i < res_left; i += kWave)
+        if (res_cur + i < slot_limit) store_rec(L, res_cur + i, 0, 0, 0, ~0u);
+    if (lane == 0) {
+        wg_words[2 + wave] = wave_total;
+        if (slot_limit != 0) atomicMax(&wg_words[1], min(res_cur + res_left, slot_limit) - wg * L.slice_slots); // (0: the wave never reserved)
+    }
+    // every record of this workgroup has been written when all of its waves are here (the stores of a wave are acknowledged by
+    // the cache all of its CU's waves read through)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const uint32_t m = wg_words[1];
+    const uint32_t wv = lane < kWaves ? wg_words[2 + lane] : 0u;
+    const uint32_t wv_incl = wave_inclusive_scan_dpp(wv);
+    const uint32_t wv_excl = wv_incl - wv;                                  // lane w: records of the waves before wave w
+    const uint32_t mine = __builtin_amdgcn_readlane(wv_incl, kWaves - 1);  // the workgroup's records
+    if (threadIdx.x == 0)
+        __hip_atomic_store(L.d_counter + (size_t)wg * kCounterStride + 2, kFtDone | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // Where this workgroup's records begin: the records of every workgroup that started before it.  ONE wave asks for them (a
+    // grid of waiting workgroups that all poll takes the memory system away from the workgroups still scanning), and only when
+    // the first records of the slice are in registers: a workgroup that is done before the ones it waits for has read its
+    // slice by the time their counts arrive.  The sum reaches the other waves through LDS (the word that held the number).
+    uint32_t below = 0;
+    bool have_below = false;
+    auto wait_below = [&]() {
+        if (wave == 0) {
+            for (uint32_t w0 = 0; w0 < wg; w0 += kWave) {
+                unsigned long long v;
+                do {
+                    v = w0 + lane < wg ? __hip_atomic_load(L.d_counter + (size_t)(w0 + lane) * kCounterStride + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kFtDone;
+                    if (__all((v & kFtDone) != 0ull)) break;
+                    __builtin_amdgcn_s_sleep(16);
+                } while (true);
+                below += ft_wave_sum((uint32_t)v); // (record counts fit 32 bits: the scratch holds fewer than 2^32 records)
+            }
+            if (lane == 0) wg_words[0] = below;
+        }
+        __syncthreads();
+        below = wg_words[0];
+        have_below = true;
+    };
+    // the slice, every slot below its fill mark: (wave, rank) -> final index
+    const uint32_t base8 = L.own_begin & ~7u;
+    const uint32_t span_units = L.region_units * L.regions_per_wave, w0g = wg * kWaves;
+    constexpr uint32_t kPer = 8; // records per thread and step: their loads (and id lookups) go out together
+    for (uint32_t i0 = 0; i0 < m; i0 += kPer * kTileBlock) {
+        uint4 raw[kPer];
+        uint32_t id[kPer], dst[kPer];
+#pragma unroll
+        for (uint32_t q = 0; q < kPer; ++q) {
+            const uint32_t i = i0 + q * kTileBlock + threadIdx.x;
+            raw[q] = make_uint4(0u, 8u, 0u, ~0u);
+            if (i < m) raw[q] = *reinterpret_cast<const uint4 *>(&slice[i]);
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < kPer; ++q) {
+            const bool hole = raw[q].w == ~0u; // beyond the mark, or left by a slot reservation
+            id[q] = raw[q].z;
+            if (L.out_map && L.d_id_map && !hole) id[q] = L.d_id_map[raw[q].z];
+            const uint32_t w = hole ? 0u : (raw[q].y - 1u - base8) / span_units - w0g; // the wave that owns the match's last unit
+            dst[q] = (uint32_t)__shfl((int)wv_excl, (int)(w & (kWaves - 1))) + raw[q].w;
+            if (hole) dst[q] = ~0u;
+        }
+        if (!have_below) wait_below(); // (m is the same for every wave: all of them come here, or none)
+#pragma unroll
+        for (uint32_t q = 0; q < kPer; ++q) {
+            const uint32_t at = below + dst[q];
+            if (dst[q] == ~0u || at >= L.out_cap) continue;
+            if (L.out_map) {
+                typedef int32_t v3i __attribute__((ext_vector_type(3)));
+                const v3i rec = {(int32_t)raw[q].x, (int32_t)raw[q].y, (int32_t)id[q]};
+                *reinterpret_cast<v3i *>(reinterpret_cast<int32_t *>(L.d_out) + (size_t)at * 3) = rec;
+            } else {
+                reinterpret_cast<int2 *>(L.d_out)[at] = make_int2((int)raw[q].x, (int)raw[q].y);
+            }
+        }
+    }
+    if (!have_below) wait_below();
+    // the workgroup with the last number has waited for all the others' counts: the call's count, the overflow word (final: a
+    // workgroup publishes its count when its scan is over), and the NEXT call's counter set zeroed -- no copy, no memset and
+    // no further launch on the stream
+    if (wg + 1u == gridDim.x) {
+        if (threadIdx.x == 0) {
+            const unsigned long long total = (unsigned long long)below + mine;
+            const uint32_t flag = __hip_atomic_load(L.d_overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (L.tail_d_result) {
+                L.tail_d_result->n_records = total;
+                L.tail_d_result->redone = flag;
+                L.tail_d_result->reserved = 0;
+            }
+            if (L.tail_result) {
+                L.tail_result[0] = total;
+                L.tail_result[1] = flag;
+            }
+            __hip_atomic_store(L.d_overflow, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+        }
+        if (L.tail_zero_counters)
+            for (uint32_t i = threadIdx.x; i < (uint32_t)kMaxSlices; i += blockDim.x) {
+                unsigned long long *z = L.tail_zero_counters + (size_t)i * kCounterStride;
+                z[0] = 0; z[1] = 0; z[2] = 0; z[3] = 0;
+            }
+    }
+}
+
 // A wave owns a contiguous SPAN of regions.  Region boundaries sit at base8 + r * region_units (base8 = own_begin
 // rounded down to 8 units, region_units a multiple of the 2048-unit tile group), so a tile group never straddles two
 // regions and the tile stream -- with its double-buffered register groups and the cross-lane carry -- runs through the
@@ -493,6 +611,12 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
     // the candidate queues are the dynamic part behind it
     __shared__ __attribute__((aligned(16))) uint32_t rows32[SPLIT ? kFilterWordsSplit : (L2 ? kFilterWordsL2 : kFilterWordsMax)];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ uint32_t wg_words[kFtWords]; // fused tail: the workgroup's number, its slice's fill mark, its waves' records
+    const bool FT = !SPLIT && L.fused_tail != 0; // kernel-uniform
+    if (FT && threadIdx.x == 0) { // (the answer is there when the tables are: the barrier below)
+        wg_words[0] = (uint32_t)atomicAdd(L.d_counter + 3, 1ull);
+        wg_words[1] = 0u;
+    }
     const unsigned char *rows8 = reinterpret_cast<const unsigned char *>(rows32);
     uint32_t *cand_all = reinterpret_cast<uint32_t *>(smem);
     { // the filter rows, 16 bytes per thread and step (the kernel does not stream before this is done)
@@ -534,8 +658,11 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
     __syncthreads();
 
     const uint32_t lane = lane_id();
-    const uint32_t wave_global = blockIdx.x * (kTileBlock / kWave) + wave_in_block;
+    // (the fused tail orders the workgroups by their start, not by blockIdx: the number names span, slice and counters)
+    const uint32_t wg = FT ? __builtin_amdgcn_readfirstlane(wg_words[0]) : blockIdx.x;
+    const uint32_t wave_global = wg * (kTileBlock / kWave) + wave_in_block;
     TileCtx c{&T, &L, SPLIT ? L.d_cands + (size_t)wave_global * L.cands_per_wave : cand_all + wave_in_block * kQueueCap, 0, 0, 0u, 0};
+    c.wg = wg;
     if (L2) c.pos16 = pos16_all + wave_in_block * kL2Cap;
     uint32_t lane0 = 0; // L2: lanes below it have been enqueued already (a dense tile taken in pieces); wave-uniform
     const uint32_t slice_base = SPLIT ? wave_global * L.cands_per_wave : 0u; // (< 2^32: the host sizes the slices)
@@ -551,7 +678,8 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
     constexpr int NP = L2 ? D2 / 2 : K / 2;
 
     const uint32_t first_region = wave_global * L.regions_per_wave;
-    if (first_region >= L.n_regions) return; // wave-uniform
+    const bool has_work = first_region < L.n_regions; // wave-uniform
+    if (!has_work && !FT) return; // (fused tail: a wave without a region passes through the loop and joins the workgroup's tail)
     const uint32_t last_region = min(first_region + L.regions_per_wave, L.n_regions);
     const uint32_t base8 = L.own_begin & ~7u;
     const uint32_t R = L.region_units;
@@ -573,8 +701,8 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
     c.pos_base = boundary - R; // L2: queue positions are relative to the start of the current region
     uint32_t tile = base8 + first_region * R;
 
-    bool vec_todo = tile < hi;          // tile groups left in the vector part of the span
-    bool tail_todo = span_end > nfull;  // the units behind the last full vector of the buffer (fewer than 8)
+    bool vec_todo = has_work && tile < hi;          // tile groups left in the vector part of the span
+    bool tail_todo = has_work && span_end > nfull;  // the units behind the last full vector of the buffer (fewer than 8)
     uint32_t d0 = 0;                    // tile of the current group to resume at (after a mid-group drain)
     uint32_t prio_turn = 0;             // passes so far (issue priority rotation)
     bool mid = false;                   // the current group is being resumed (its registers are live, its loads are out)
@@ -654,11 +782,13 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                     if (SPLIT) {
                         if (lane == 0) L.d_region_cands[region] = make_uint2(slice_base + region_first, c.cand_n - region_first);
                         region_first = c.cand_n;
-                    } else if (lane == 0) {
+                    } else if (lane == 0 && !FT) {
                         L.d_region_counts[region] = c.rank_base;
                     }
-                    wave_total += c.rank_base;
-                    c.rank_base = 0;
+                    if (!FT) { // (fused tail: a record's rank counts through the wave's whole span -- no region counts)
+                        wave_total += c.rank_base;
+                        c.rank_base = 0;
+                    }
                     ++region;
                     rb = boundary;
                     c.pos_base = boundary;
@@ -1064,11 +1194,13 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                 if (SPLIT) {
                     if (lane == 0) L.d_region_cands[region] = make_uint2(slice_base + region_first, c.cand_n - region_first);
                     region_first = c.cand_n;
-                } else if (lane == 0) {
+                } else if (lane == 0 && !FT) {
                     L.d_region_counts[region] = c.rank_base;
                 }
-                wave_total += c.rank_base;
-                c.rank_base = 0;
+                if (!FT) {
+                    wave_total += c.rank_base;
+                    c.rank_base = 0;
+                }
                 ++region;
                 c.pos_base = boundary;
             }
@@ -1114,11 +1246,15 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
         L.d_timing[(size_t)wave_global * 8 + 7] = c.vt[2] | (c.vt[3] << 32);
     }
 #endif
-    if (lane == 0) L.d_region_counts[region] = c.rank_base;
+    if (lane == 0 && has_work && !FT) L.d_region_counts[region] = c.rank_base;
     // the workgroup's record count, next to its slot counter: the fused permute pass (k_permute_wg) turns the per-workgroup
     // sums and the region counts into offsets itself, so no prefix-sum kernels run between the scan and the permutation
     wave_total += c.rank_base;
-    if (lane == 0 && L.wg_sums && wave_total) atomicAdd(L.d_counter + (size_t)blockIdx.x * kCounterStride + 1, (unsigned long long)wave_total);
+    if (lane == 0 && L.wg_sums && wave_total) atomicAdd(L.d_counter + (size_t)wg * kCounterStride + 1, (unsigned long long)wave_total);
+    if (FT) {
+        tile_fused_tail(L, wg, wg_words, wave_total, c.res_cur, c.res_left, c.slot_limit);
+        return;
+    }
     // hand back the unused tail of the last reservation as holes the permute pass skips
     for (uint32_t i = lane; i < c.res_left; i += kWave)
         if (c.res_cur + i < c.slot_limit) store_rec(L, c.res_cur + i, 0, 0, 0, ~0u);

@@ -19,7 +19,10 @@ constexpr int kTileUnits = 512;                // units per wave tile (64 lanes 
 constexpr int kVerifyBatches = ACGPU_NB;              // candidates verified per lane and call (independent load chains in flight)
 constexpr int kCandCap = 1024;                 // candidate queue entries per wave; a tile adds at most 512
 constexpr int kPrefetch = ACGPU_PREFETCH;                   // tiles per group; one group of loads is in flight per wave
-constexpr uint32_t kReserve = 256;             // scratch slots a wave reserves per atomic
+#ifndef ACGPU_RESERVE
+#define ACGPU_RESERVE 256
+#endif
+constexpr uint32_t kReserve = ACGPU_RESERVE;             // scratch slots a wave reserves per atomic
 
 // The ablation switches of TileLaunch::debug exist only in builds with -DACGPU_ABLATION (tools/build_variant.sh abl
 // -DACGPU_ABLATION; tools/kbench.py and tools/collect_profiles.sh select that library for their ablation variants): in
@@ -46,6 +49,7 @@ struct TileCtx {
     uint16_t *pos16 = nullptr;
     uint32_t pos_base = 0;
     uint32_t region = 0; // WholeWord, region-local records: the region the queued run starts belong to (wave-uniform)
+    uint32_t wg = 0;     // the workgroup's number: its scratch slice and counters (blockIdx.x, or the start ticket of the fused tail)
 #ifdef ACGPU_TIMING
     unsigned long long vt[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // verification phases (k_ac_tile: windows, K-gram nodes, walks, emission;
                                                           // k_ww_tile: windows, chunk 1, chunk 2, hash + Bloom, probes, emission, calls)
@@ -125,7 +129,7 @@ __device__ __forceinline__ SlotRange reserve_slots(TileCtx &c, uint32_t total) {
         const uint32_t need = total - r.old_left;
         const uint32_t take = need > kReserve ? need : kReserve;
         // this workgroup's slice of the scratch and its counter (see TileLaunch::n_slices)
-        const uint32_t slice = c.Lp->n_slices > 1 ? blockIdx.x % c.Lp->n_slices : 0u;
+        const uint32_t slice = c.Lp->n_slices > 1 ? c.wg % c.Lp->n_slices : 0u;
         const uint32_t S = c.Lp->slice_slots, base = slice * S; // (n_slices * S <= scratch capacity < 2^32)
         uint32_t fresh = 0;
         if (lane_id() == 0) {

@@ -482,6 +482,7 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
     const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave); // (scalar bookkeeping: see k_ac_tile)
     const uint32_t wave_global = blockIdx.x * (kTileBlock / kWave) + wave_in_block;
     TileCtx c{&T, &L, cand_all + wave_in_block * kWwCandCap, 0, 0, 0u, 0};
+    c.wg = blockIdx.x;
 
     const uint32_t first_region = wave_global * L.regions_per_wave;
     if (first_region >= L.n_regions) return;
@@ -767,6 +768,7 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
     unsigned char *bits = mine + kPpRingUnits * 2;
     uint16_t *list = reinterpret_cast<uint16_t *>(mine + kPpRingUnits * 2 + kPpBitBytes);
     TileCtx c{&T, &L, nullptr, 0, 0, 0u, 0};
+    c.wg = blockIdx.x;
 
     const uint32_t first_region = wave_global * L.regions_per_wave;
     if (first_region >= L.n_regions) return;

@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 def _reset_tunables():
     yield
     for k, v in [("chunk_units", 0), ("blocks_per_cu", 1), ("lds_table_bytes", 127 * 1024), ("force_sparse", 0),
-                 ("force_kernel", 0), ("region_units", 0), ("ww_first_seed", 0), ("tile_debug", 0), ("all_form", 0)]:
+                 ("force_kernel", 0), ("region_units", 0), ("ww_first_seed", 0), ("tile_debug", 0), ("all_form", 0), ("tile_form", 0)]:
         N.set_tunable(k, v)
 
 

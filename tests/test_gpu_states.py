@@ -20,7 +20,7 @@ STATES_NEVER = 1
 @pytest.fixture(autouse=True)
 def _reset_tunables():
     yield
-    for k, v in [("force_kernel", 0), ("tile_debug", 0), ("all_form", 0)]:
+    for k, v in [("force_kernel", 0), ("tile_debug", 0), ("all_form", 0), ("tile_form", 0)]:
         N.set_tunable(k, v)
 
 

@@ -64,7 +64,7 @@ def main():
     d_out = torch.empty((cap, 3), dtype=torch.int32, device="cuda")
     variants = json.loads(args.variants) if args.variants else dflt
     defaults = {"force_kernel": 0, "tile_debug": 0, "region_units": 0, "chunk_units": 0, "lds_table_bytes": 127 * 1024,
-                "blocks_per_cu": 1, "reserve_cus": 0, "longest_form": 0, "all_form": 0}
+                "blocks_per_cu": 1, "reserve_cus": 0, "longest_form": 0, "all_form": 0, "tile_form": 0}
     res = {k: [] for k in variants}
     info = {}
     for r in range(args.rounds + 1):
