@@ -373,6 +373,65 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
             }
         }
         if (!placed) return ACGPU_E_UNSUPPORTED;
+        // The perfect hash (HostTables::ww_ph; WHOLEWORD, what k_ww_pp probes).  Hash and displace: buckets of about four
+        // keywords, the fullest first; a bucket takes the first displacement (of 65536) that sends all of its keywords to free
+        // slots.  The last, single keywords find one of the 3 % free slots within a few hundred tries.
+        if (mode == ACGPU_MODE_WHOLEWORD && !tunables().ww_no_ph && !keys.empty() && t.max_len <= 32) {
+            const uint64_t n = keys.size();
+            const uint64_t lambda = tunables().ww_ph_lambda > 0 ? (uint64_t)tunables().ww_ph_lambda : 4;
+            const uint64_t nb = (n + lambda - 1) / lambda, m = std::max<uint64_t>(n + n / 32 + 1, 8);
+            if (nb * 2 <= (60u << 10) && m < (1ull << 31)) { // the displacements share LDS with the word bits, the fold pages and the waves' rings
+                std::vector<uint32_t> head(nb, kWwEmpty), next(n, kWwEmpty), size(nb, 0u);
+                for (uint32_t ki = 0; ki < n; ki++) {
+                    const uint32_t b = ww_ph_bucket(keys[ki].h, (uint32_t)nb);
+                    next[ki] = head[b];
+                    head[b] = ki;
+                    size[b]++;
+                }
+                std::vector<uint32_t> order(nb);
+                for (uint32_t b = 0; b < nb; b++) order[b] = b;
+                std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return size[x] > size[y]; });
+                std::vector<uint32_t> owner(m, kWwEmpty);
+                std::vector<uint16_t> disp((nb + 7) / 8 * 8, 0);
+                std::vector<uint32_t> pos;
+                bool ok = true;
+                for (uint32_t oi = 0; oi < nb && ok; oi++) {
+                    const uint32_t b = order[oi];
+                    if (!size[b]) break;
+                    uint32_t d = 0;
+                    for (; d < 65536; d++) {
+                        pos.clear();
+                        bool fits = true;
+                        for (uint32_t ki = head[b]; ki != kWwEmpty && fits; ki = next[ki]) {
+                            const uint32_t s = ww_ph_slot(keys[ki].g, keys[ki].h, d, (uint32_t)m);
+                            fits = owner[s] == kWwEmpty && std::find(pos.begin(), pos.end(), s) == pos.end();
+                            pos.push_back(s);
+                        }
+                        if (fits) break;
+                    }
+                    if (d == 65536) { ok = false; break; } // (two keywords of a bucket with both hashes equal, or no luck: no perfect hash)
+                    disp[b] = (uint16_t)d;
+                    uint32_t j = 0;
+                    for (uint32_t ki = head[b]; ki != kWwEmpty; ki = next[ki]) owner[pos[j++]] = ki;
+                }
+                if (ok) {
+                    t.ww_ph.assign((size_t)m * 8, 0u);
+                    for (uint64_t slot = 0; slot < m; slot++) {
+                        if (owner[slot] == kWwEmpty) continue;
+                        const WwKey &k = keys[owner[slot]];
+                        const uint32_t *rec = &t.ww_recs[(size_t)k.off16 * 4];
+                        uint32_t *fat = &t.ww_ph[slot * 8];
+                        const uint32_t len = rec[1];
+                        fat[0] = ww_tag(k.h, len);
+                        fat[1] = len <= kWwInlineUnits ? rec[0] : k.off16;
+                        for (uint32_t i = 0; i < kWwInlineUnits / 2; i++) fat[2 + i] = i < (len + 1) / 2 ? rec[2 + i] : 0u;
+                    }
+                    t.ww_ph_disp = std::move(disp);
+                    t.ww_ph_n = (uint32_t)m;
+                    t.ww_ph_buckets = (uint32_t)nb;
+                }
+            }
+        }
         t.ww_bloom.assign(bits / 32, 0u);
         for (const WwKey &k : keys) {
             const uint32_t b1 = ww_bloom_bit1(k.h, t.ww_bloom_mask), b2 = ww_bloom_bit2(k.h, t.ww_bloom_mask);

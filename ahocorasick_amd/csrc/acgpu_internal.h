@@ -54,6 +54,17 @@ ACGPU_HD inline uint32_t ww_slot2(uint32_t h, uint32_t g, uint32_t mask) {
     const uint32_t s = ((x * 0x2C1B3C6Du) >> 11) & mask;
     return s != (h & mask) ? s : s ^ 1u;
 }
+// The perfect hash of the whole keywords ("hash and displace"): bucket = ww_ph_bucket(hash), slot = ww_ph_slot(hash2, hash,
+// displacement of the bucket) -- every keyword in a slot of its own, found with ONE probe
+ACGPU_HD inline uint32_t ww_mulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); }
+ACGPU_HD inline uint32_t ww_ph_bucket(uint32_t h, uint32_t n_buckets) { return ww_mulhi(h, n_buckets); }
+ACGPU_HD inline uint32_t ww_ph_slot(uint32_t g, uint32_t h, uint32_t d, uint32_t n_slots) {
+    uint32_t t = (g ^ (h << 7)) + d * 0x9E3779B9u;
+    t ^= t >> 15;
+    t *= 0x2C1B3C6Du;
+    t ^= t >> 13;
+    return ww_mulhi(t, n_slots);
+}
 // two bit positions of the Bloom filter in front of the table (the filter sits in LDS)
 ACGPU_HD inline uint32_t ww_bloom_bit1(uint32_t h, uint32_t mask) { return (h >> 7) & mask; }
 ACGPU_HD inline uint32_t ww_bloom_bit2(uint32_t h, uint32_t mask) { return ((h >> 19) | (h << 13)) & mask; }
@@ -236,6 +247,14 @@ struct HostTables {
     // takes the id's place, is compared as well.
     std::vector<uint32_t> ww_fat;   // 8 u32 per slot
     uint32_t ww_fat_mask = 0;
+    // The same slots behind a PERFECT hash (WHOLEWORD, keywords of at most 32 units: k_ww_pp): ww_ph_n slots for the keywords at
+    // a load of 0.97 -- 3.3 MB for 100 k keywords where the two-choice table has 8.4 MB, so it stays in an XCD's L2 cache --
+    // and one 16-bit displacement per bucket of about four keywords (50 KB: the kernel keeps them in LDS where the Bloom filter
+    // was).  A run of word characters reads ONE slot; a run that is no keyword reads some keyword's slot and fails the compare.
+    // Empty: not built (too many keywords for the displacements' LDS, or two keywords with both hashes equal).
+    std::vector<uint32_t> ww_ph;        // 8 u32 per slot
+    std::vector<uint16_t> ww_ph_disp;   // per bucket; padded to a multiple of 8 entries
+    uint32_t ww_ph_n = 0, ww_ph_buckets = 0;
     uint32_t ww_seed = kWwHashSeed; // start value of both hashes (another one if the two-choice table cannot be built)
     // fold table as pages of 256 deltas (lower[u] - u mod 2^16), identical pages shared: fits LDS for real tables
     std::vector<uint8_t> fold_pgidx;   // 256
@@ -290,6 +309,9 @@ struct DevTables {
     // WholeWord word hash
     const uint32_t *ww_fat;   // 8 u32 per slot (see HostTables::ww_fat)
     uint32_t ww_fat_mask, ww_seed;
+    const uint32_t *ww_ph;    // HostTables::ww_ph (nullptr: none)
+    const uint16_t *ww_ph_disp;
+    uint32_t ww_ph_n, ww_ph_buckets;
     const uint32_t *ww_recs;  // 16-byte aligned records
     const uint8_t *fold_pgidx;
     const uint16_t *fold_pages;
@@ -321,6 +343,8 @@ struct Tunables {
     std::atomic<int64_t> filter_max_bytes{ACGPU_FILTER_MAX_BYTES};  // the filter rows must fit LDS next to the candidate queues
     std::atomic<int64_t> no_short_keywords{0}; // builder: 1 = the filter's K stays at most the shortest keyword (A/B)
     std::atomic<int64_t> no_merged_ranges{0}; // builder: 1 = mixed-case dictionaries keep the 8-byte-row scalar filter (A/B)
+    std::atomic<int64_t> ww_no_ph{0};         // WHOLEWORD builder: 1 = no perfect hash (the two-choice table behind the Bloom filter: A/B, tests)
+    std::atomic<int64_t> ww_ph_lambda{0};     // WHOLEWORD builder: keywords per bucket of the perfect hash (0 = 4; tests: large buckets, many displacements tried)
     std::atomic<int64_t> ww_no_bloom{0};      // WHOLEWORD builder: 1 = no Bloom filter in front of the keyword table (every run of keyword length probes it)
     std::atomic<int64_t> ww_first_seed{0};    // WHOLEWORD builder: first hash seed tried (tests: the fallback seeds end to end)
     std::atomic<int64_t> split_cand_div{8};   // split form: a wave's candidate slice holds one candidate per this many units of its span

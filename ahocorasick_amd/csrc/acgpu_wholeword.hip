@@ -638,8 +638,11 @@ constexpr int kPpListCap = kTileUnits / 2; // a run start needs a unit that is n
 constexpr int kPpWaveBytes = (kPpRingUnits * 2 + kPpBitBytes + kPpListCap * 2 + 15) & ~15;
 constexpr uint32_t kPpMaxLen = 32; // longer keywords: k_ww_tile (up to 16 units: the LONG = false form, one 32-byte ring read per run)
 
-static size_t ww_pp_lds_bytes(int block_threads, const DevTables &t) {
-    return ww_bloom_bytes(t) + (size_t)(block_threads / kWave) * kPpWaveBytes;
+// the perfect hash's displacements take the Bloom filter's place in LDS (tile_debug bit 2^29: the two-choice table behind the filter, A/B)
+static bool ww_pp_perfect(const DevTables &t, const TileLaunch &l) { return t.ww_ph != nullptr && !(l.debug & (1u << 29)); }
+static size_t ww_pp_front_bytes(const DevTables &t, bool ph) { return ph ? ((size_t)t.ww_ph_buckets + 7) / 8 * 16 : ww_bloom_bytes(t); }
+static size_t ww_pp_lds_bytes(int block_threads, const DevTables &t, bool ph) {
+    return ww_pp_front_bytes(t, ph) + (size_t)(block_threads / kWave) * kPpWaveBytes;
 }
 
 // One batch of run starts, hashed and ready to probe: everything but the probed slots (registers; PpBatch travels from the
@@ -657,14 +660,19 @@ struct PpProbe {
 
 // the four probe loads of a batch, unconditional (a lane that does not probe reads slot 0: one cached line): the number of
 // memory operations of a pass is then the same on every path, and the compiler's waits can count
-template <int NW>
+// PH: the perfect hash -- ONE slot per run (HostTables::ww_ph)
+template <int NW, bool PH>
 __device__ __forceinline__ PpProbe pp_issue(const DevTables &T, const PpFlight<NW> &fl) {
-    const uint4 *fat = reinterpret_cast<const uint4 *>(T.ww_fat);
+    const uint4 *fat = reinterpret_cast<const uint4 *>(PH ? T.ww_ph : T.ww_fat);
     PpProbe pr;
     pr.ea0 = fat[2 * fl.s1];
     pr.ea1 = fat[2 * fl.s1 + 1];
-    pr.eb0 = fat[2 * fl.s2];
-    pr.eb1 = fat[2 * fl.s2 + 1];
+    if (!PH) {
+        pr.eb0 = fat[2 * fl.s2];
+        pr.eb1 = fat[2 * fl.s2 + 1];
+    } else {
+        pr.eb0 = pr.eb1 = make_uint4(0u, 0u, 0u, 0u);
+    }
     return pr;
 }
 
@@ -686,7 +694,7 @@ __device__ __forceinline__ bool pp_tail_same(const PpFlight<NW> &fl, const uint4
 }
 
 // compare the probed slots with the runs of the batch and emit its records (text order: lane order)
-template <int NW>
+template <int NW, bool PH>
 __device__ __forceinline__ void pp_consume(TileCtx &c, const PpFlight<NW> &fl, const PpProbe &pr) {
     if (fl.n == 0) return; // wave-uniform
     const DevTables &T = *c.Tp;
@@ -695,7 +703,7 @@ __device__ __forceinline__ void pp_consume(TileCtx &c, const PpFlight<NW> &fl, c
     const uint32_t ida = a0.y, idb = b0.y;
     const bool in_a = a0.x == fl.tag && a0.z == fl.fw[0] && a0.w == fl.fw[1] && a1.x == fl.fw[2] && a1.y == fl.fw[3] &&
                       a1.z == fl.fw[4] && a1.w == fl.fw[5];
-    const bool in_b = b0.x == fl.tag && b0.z == fl.fw[0] && b0.w == fl.fw[1] && b1.x == fl.fw[2] && b1.y == fl.fw[3] &&
+    const bool in_b = !PH && b0.x == fl.tag && b0.z == fl.fw[0] && b0.w == fl.fw[1] && b1.x == fl.fw[2] && b1.y == fl.fw[3] &&
                       b1.z == fl.fw[4] && b1.w == fl.fw[5];
     uint32_t id = ~0u;
     if (fl.probing && (in_a || in_b)) id = in_a ? ida : idb;
@@ -735,7 +743,7 @@ __device__ __forceinline__ void pp_consume(TileCtx &c, const PpFlight<NW> &fl, c
     c.rank_base += total;
 }
 
-template <int FOLD, bool LONG>
+template <int FOLD, bool LONG, bool PH>
 __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) void k_ww_pp(DevTables T, TileLaunch L) {
     static_assert(FOLD == 0 || FOLD == 1, "the fold table sits in LDS");
     constexpr int NW = LONG ? 16 : 8;           // words of folded units per run
@@ -745,10 +753,12 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
     __shared__ __attribute__((aligned(16))) unsigned char fold_base[FOLD == 1 ? 256 : 16];
     __shared__ __attribute__((aligned(16))) uint16_t pages[FOLD == 1 ? kFoldPagesMax * 256 : 8];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t bloom_bytes = (T.ww_bloom_mask + 1u) / 8u;
+    // in front of the waves' rings: the Bloom filter over the keyword hashes, or (PH) the displacements of the perfect hash
+    const uint32_t bloom_bytes = PH ? (T.ww_ph_buckets + 7u) / 8u * 16u : (T.ww_bloom_mask + 1u) / 8u;
     uint32_t *bloom = reinterpret_cast<uint32_t *>(smem);
+    const uint16_t *disp = reinterpret_cast<const uint16_t *>(smem);
     for (uint32_t w = threadIdx.x; w < bloom_bytes / 16; w += blockDim.x)
-        reinterpret_cast<uint4 *>(bloom)[w] = reinterpret_cast<const uint4 *>(T.ww_bloom)[w];
+        reinterpret_cast<uint4 *>(bloom)[w] = reinterpret_cast<const uint4 *>(PH ? reinterpret_cast<const uint32_t *>(T.ww_ph_disp) : T.ww_bloom)[w];
     for (uint32_t w = threadIdx.x; w < 2048 / 4; w += blockDim.x)
         reinterpret_cast<uint4 *>(wbits)[w] = reinterpret_cast<const uint4 *>(T.wbits)[w];
     FoldLds F{bloom, T.ww_bloom_mask, fold_base, pages};
@@ -897,12 +907,18 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
         }
         h = ww_hash_final(h);
         bool probing = act && r <= T.max_len && !ACGPU_DBG(L, 2u); // 2: ablation, no table lookup
+        if (PH) { // the bucket's displacement (LDS) names the one slot a keyword with these hashes would sit in
+            const uint32_t d = disp[ww_ph_bucket(h, T.ww_ph_buckets)];
+            fl.s1 = probing ? ww_ph_slot(g, h, d, T.ww_ph_n) : 0u;
+            fl.s2 = 0u;
+        } else {
         if (!ACGPU_DBG(L, 4u)) { // 4: ablation, no Bloom filter in front of the table
             const uint32_t b1 = ww_bloom_bit1(h, F.bloom_mask), b2 = ww_bloom_bit2(h, F.bloom_mask);
             probing = probing && ((F.bloom[b1 >> 5] >> (b1 & 31)) & (F.bloom[b2 >> 5] >> (b2 & 31)) & 1u);
         }
         fl.s1 = probing ? ww_slot1(h, T.ww_fat_mask) : 0u;
         fl.s2 = probing ? (ACGPU_DBG(L, 16u) ? fl.s1 ^ 1u : ww_slot2(h, g, T.ww_fat_mask)) : 0u; // 16: ablation (timing only), both slots in one line
+        }
         fl.n = cnt > b0 ? min(cnt - b0, (uint32_t)kWave) : 0u;
         fl.probing = probing;
         fl.s = tile0 + j * kTileUnits + p;
@@ -915,7 +931,7 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
     auto early_batches = [&](uint32_t j, uint32_t cnt, uint32_t b_last) {
         for (uint32_t b0 = 0; b0 < b_last; b0 += kWave) {
             const Flight now = batch(j, cnt, b0);
-            pp_consume(c, now, pp_issue(T, now));
+            pp_consume<NW, PH>(c, now, pp_issue<NW, PH>(T, now));
         }
     };
     // Pass j: the probes of tile j's last batch go out first; then tile j+2 is staged, tile j+1's run starts are listed and its
@@ -946,13 +962,13 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
         default: __builtin_amdgcn_s_setprio(3); break;
         }
 #endif
-        const PpProbe pr = pp_issue(T, fl);
+        const PpProbe pr = pp_issue<NW, PH>(T, fl);
         const uint32_t sm2 = stage(j + 2, nx);
         nx = load_tile(cur + 3 * kTileUnits);
         const uint32_t cnt = build_list(sm_next); // tile j + 1 (none beyond the span: its start mask is empty)
         const uint32_t b_last = cnt ? ((cnt - 1) & ~(uint32_t)(kWave - 1)) : 0u;
         const Flight nf = batch(j + 1, cnt, b_last);
-        pp_consume(c, fl, pr);
+        pp_consume<NW, PH>(c, fl, pr);
         if (cur + kTileUnits >= boundary && cur + kTileUnits < span_end) { // tile j + 1 opens the next region
             if (lane == 0) L.d_region_counts[region] = c.rank_base;
             c.rank_base = 0;
@@ -1015,24 +1031,34 @@ __global__ void k_ww_sequential(DevTables T, const uint16_t *hay, uint32_t len, 
 static bool ww_pp_usable(const DevTables &t, const TileLaunch &l) {
     const int fold = t.cs ? 0 : (ww_fold_pages_in_lds(t) ? 1 : 2);
     return fold != 2 && t.max_len <= kPpMaxLen && !(l.debug & (256u | 268435456u)) &&
-           ww_pp_lds_bytes(l.block, t) + 8192 + 256 + kFoldPagesMax * 512 <= 160 * 1024;
+           ww_pp_lds_bytes(l.block, t, ww_pp_perfect(t, l)) + 8192 + 256 + kFoldPagesMax * 512 <= 160 * 1024;
 }
 
 hipError_t launch_ww_tile(const DevTables &t, const TileLaunch &l, hipStream_t stream, const char **kernel_name) {
     const int fold = t.cs ? 0 : (ww_fold_pages_in_lds(t) ? 1 : 2);
     if (ww_pp_usable(t, l)) {
-        const size_t lds = ww_pp_lds_bytes(l.block, t);
+        const bool ph = ww_pp_perfect(t, l);
+        const size_t lds = ww_pp_lds_bytes(l.block, t, ph);
         const bool lng = t.max_len > 16;
-        const void *fn = fold == 0 ? (lng ? reinterpret_cast<const void *>(&k_ww_pp<0, true>) : reinterpret_cast<const void *>(&k_ww_pp<0, false>))
-                                   : (lng ? reinterpret_cast<const void *>(&k_ww_pp<1, true>) : reinterpret_cast<const void *>(&k_ww_pp<1, false>));
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        if (fold == 0 && lng) ACGPU_LAUNCH_EV((k_ww_pp<0, true>), dim3(l.grid), dim3(l.block), lds, stream, l.ev_start, l.ev_stop, t, l);
-        else if (fold == 0) ACGPU_LAUNCH_EV((k_ww_pp<0, false>), dim3(l.grid), dim3(l.block), lds, stream, l.ev_start, l.ev_stop, t, l);
-        else if (lng) ACGPU_LAUNCH_EV((k_ww_pp<1, true>), dim3(l.grid), dim3(l.block), lds, stream, l.ev_start, l.ev_stop, t, l);
-        else ACGPU_LAUNCH_EV((k_ww_pp<1, false>), dim3(l.grid), dim3(l.block), lds, stream, l.ev_start, l.ev_stop, t, l);
-        if (kernel_name) *kernel_name = fold == 0 ? (lng ? "k_ww_pp<0, true>" : "k_ww_pp<0, false>") : (lng ? "k_ww_pp<1, true>" : "k_ww_pp<1, false>");
-        return hipGetLastError();
+        static thread_local char name[48];
+        std::snprintf(name, sizeof(name), "k_ww_pp<%d, %s, %s>", fold, lng ? "true" : "false", ph ? "true" : "false");
+        if (kernel_name) *kernel_name = name;
+#define ACGPU_WW_PP(F, LG, PHV)                                                                                              \
+    do {                                                                                                                     \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ww_pp<F, LG, PHV>),                             \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
+        if (e != hipSuccess) return e;                                                                                       \
+        ACGPU_LAUNCH_EV((k_ww_pp<F, LG, PHV>), dim3(l.grid), dim3(l.block), lds, stream, l.ev_start, l.ev_stop, t, l);       \
+        return hipGetLastError();                                                                                            \
+    } while (0)
+        if (fold == 0) {
+            if (lng) { if (ph) ACGPU_WW_PP(0, true, true); else ACGPU_WW_PP(0, true, false); }
+            else { if (ph) ACGPU_WW_PP(0, false, true); else ACGPU_WW_PP(0, false, false); }
+        } else {
+            if (lng) { if (ph) ACGPU_WW_PP(1, true, true); else ACGPU_WW_PP(1, true, false); }
+            else { if (ph) ACGPU_WW_PP(1, false, true); else ACGPU_WW_PP(1, false, false); }
+        }
+#undef ACGPU_WW_PP
     }
     const void *fn = fold == 0 ? reinterpret_cast<const void *>(&k_ww_tile<0>)
                    : fold == 1 ? reinterpret_cast<const void *>(&k_ww_tile<1>) : reinterpret_cast<const void *>(&k_ww_tile<2>);
