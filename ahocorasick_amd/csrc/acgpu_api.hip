@@ -159,6 +159,9 @@ int ensure_device(acgpu_automaton *a, DeviceState **out, int lane) {
     T.kg_mask = t.kg_mask; T.hashk = t.hashk;
     if ((rc = upload(*d, t.ww_fat, &T.ww_fat))) return rc;
     if ((rc = upload(*d, t.ww_recs, &T.ww_recs))) return rc;
+    T.ww_bp_idx = nullptr; T.ww_bp_pages = nullptr; T.ww_bp_delta = nullptr; T.ww_bp_n = t.ww_bp_n; T.ww_bp_wbits = T.wbits;
+    if (t.ww_bp_n && ((rc = upload(*d, t.ww_bp_idx, &T.ww_bp_idx)) || (rc = upload(*d, t.ww_bp_pages, &T.ww_bp_pages)) ||
+                      (rc = upload(*d, t.ww_bp_delta, &T.ww_bp_delta)))) return rc;
     T.ww_ph = nullptr; T.ww_ph_disp = nullptr; T.ww_ph_n = t.ww_ph_n; T.ww_ph_buckets = t.ww_ph_buckets;
     if (!t.ww_ph.empty() && ((rc = upload(*d, t.ww_ph, &T.ww_ph)) || (rc = upload(*d, t.ww_ph_disp, &T.ww_ph_disp)))) return rc;
     if ((rc = upload(*d, t.fold_pgidx, &T.fold_pgidx))) return rc;
@@ -1720,6 +1723,7 @@ int64_t acgpu_set_tunable(const char *name, int64_t value) {
     else if (!std::strcmp(name, "ww_first_seed")) slot = &t.ww_first_seed;
     else if (!std::strcmp(name, "ww_no_bloom")) slot = &t.ww_no_bloom;
     else if (!std::strcmp(name, "ww_no_ph")) slot = &t.ww_no_ph;
+    else if (!std::strcmp(name, "ww_no_byte_pages")) slot = &t.ww_no_byte_pages;
     else if (!std::strcmp(name, "ww_ph_lambda")) slot = &t.ww_ph_lambda;
     else if (!std::strcmp(name, "rdense_budget_bytes")) slot = &t.rdense_budget_bytes;
     else if (!std::strcmp(name, "filter_max_bytes")) slot = &t.filter_max_bytes;

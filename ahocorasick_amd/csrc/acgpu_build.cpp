@@ -458,6 +458,41 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
         }
         t.fold_direct_n = 0;
         for (uint32_t pg = 0; pg < 8; pg++) if (t.fold_pgidx[pg] != 0) t.fold_direct_n = (pg + 1) * 256;
+        // word-character bit and fold delta in one byte per unit (HostTables::ww_bp_*)
+        if (mode == ACGPU_MODE_WHOLEWORD && !case_sensitive && t.fold_consistent && !tunables().ww_no_byte_pages) {
+            std::vector<uint16_t> deltas;
+            std::vector<uint8_t> pages, idx(256, 0);
+            bool ok = true;
+            for (uint32_t pg = 0; pg < 256 && ok; pg++) {
+                uint8_t page[256];
+                for (uint32_t i = 0; i < 256 && ok; i++) {
+                    const uint32_t u = pg * 256 + i;
+                    const uint16_t d = (uint16_t)(t.lower[u] - u);
+                    size_t k = std::find(deltas.begin(), deltas.end(), d) - deltas.begin();
+                    if (k == deltas.size()) {
+                        if (deltas.size() == 128) { ok = false; break; }
+                        deltas.push_back(d);
+                    }
+                    page[i] = (uint8_t)((k << 1) | (t.wflags[u] & 1u));
+                }
+                if (!ok) break;
+                size_t found = pages.size() / 256;
+                for (size_t q = 0; q < pages.size() / 256; q++)
+                    if (!std::memcmp(&pages[q * 256], page, 256)) { found = q; break; }
+                if (found == pages.size() / 256) {
+                    if (found == 64) { ok = false; break; } // (what the kernel's LDS array holds)
+                    pages.insert(pages.end(), page, page + 256);
+                }
+                idx[pg] = (uint8_t)found;
+            }
+            if (ok) {
+                deltas.resize(128, 0);
+                t.ww_bp_idx = std::move(idx);
+                t.ww_bp_pages = std::move(pages);
+                t.ww_bp_delta = std::move(deltas);
+                t.ww_bp_n = (uint32_t)(t.ww_bp_pages.size() / 256);
+            }
+        }
     }
 
     // ---- 6. character classes + dense delta table (AC/LONGEST only) ----

@@ -261,6 +261,15 @@ struct HostTables {
     std::vector<uint16_t> fold_pages;  // fold_n_pages * 256
     uint32_t fold_n_pages = 0;
     uint32_t fold_direct_n = 0;        // units below this fold through a direct table (the cased scripts of the low pages)
+    // Word-character bit and fold of a unit in ONE page entry (k_ww_pp, case-insensitive, fold-consistent tables): pages of 256
+    // bytes {index of the unit's fold delta << 1 | word character}, identical pages shared, and the table of the (at most 128)
+    // distinct deltas.  Unicode's simple lower-casing with Character.isLetterOrDigit: 79 deltas, 54 pages = 13.5 KB where the
+    // word bits (8 KB) and the delta pages (9 KB) took two lookups with their own address arithmetic.  Empty: more deltas or
+    // pages than that (the two tables serve).
+    std::vector<uint8_t> ww_bp_idx;    // 256: page of the units u >> 8
+    std::vector<uint8_t> ww_bp_pages;  // ww_bp_n * 256
+    std::vector<uint16_t> ww_bp_delta; // 128
+    uint32_t ww_bp_n = 0;
     std::vector<uint32_t> ww_bloom;    // 2-hash Bloom filter over the keyword hashes, a power of two of bits (<= 64 KB)
     uint32_t ww_bloom_mask = 0;        // bits - 1
 };
@@ -316,6 +325,10 @@ struct DevTables {
     const uint8_t *fold_pgidx;
     const uint16_t *fold_pages;
     uint32_t fold_n_pages, fold_direct_n;
+    const uint8_t *ww_bp_idx, *ww_bp_pages; // HostTables::ww_bp_* (nullptr: none)
+    const uint16_t *ww_bp_delta;
+    uint32_t ww_bp_n;
+    const uint32_t *ww_bp_wbits;            // the word bits the byte pages hold (a scan over other ones -- folded_tables -- does not take them)
     const uint32_t *ww_bloom;
     uint32_t ww_bloom_mask;
     const uint8_t *root_tab; // LONGEST: see HostTables::root_tab
@@ -343,6 +356,7 @@ struct Tunables {
     std::atomic<int64_t> filter_max_bytes{ACGPU_FILTER_MAX_BYTES};  // the filter rows must fit LDS next to the candidate queues
     std::atomic<int64_t> no_short_keywords{0}; // builder: 1 = the filter's K stays at most the shortest keyword (A/B)
     std::atomic<int64_t> no_merged_ranges{0}; // builder: 1 = mixed-case dictionaries keep the 8-byte-row scalar filter (A/B)
+    std::atomic<int64_t> ww_no_byte_pages{0}; // WHOLEWORD builder: 1 = no combined word-bit / fold pages (A/B, tests)
     std::atomic<int64_t> ww_no_ph{0};         // WHOLEWORD builder: 1 = no perfect hash (the two-choice table behind the Bloom filter: A/B, tests)
     std::atomic<int64_t> ww_ph_lambda{0};     // WHOLEWORD builder: keywords per bucket of the perfect hash (0 = 4; tests: large buckets, many displacements tried)
     std::atomic<int64_t> ww_no_bloom{0};      // WHOLEWORD builder: 1 = no Bloom filter in front of the keyword table (every run of keyword length probes it)

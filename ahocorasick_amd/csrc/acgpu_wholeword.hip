@@ -71,6 +71,7 @@ int ww_blocks_per_cu() { return kWwBlocksPerCu; }
 #define ACGPU_FOLD_PAGES_MAX 64
 #endif
 constexpr uint32_t kFoldPagesMax = ACGPU_FOLD_PAGES_MAX; // 32 KB of LDS; Unicode 13 simple lower-casing needs 18 pages
+constexpr uint32_t kBytePagesMax = 64;                    // k_ww_pp, FOLD 3: 16 KB (acgpu_build.cpp caps HostTables::ww_bp_n at this)
 
 uint32_t ww_fold_pages_in_lds(const DevTables &t) { return (!t.cs && t.fold_n_pages <= kFoldPagesMax) ? t.fold_n_pages : 0u; }
 
@@ -745,13 +746,16 @@ __device__ __forceinline__ void pp_consume(TileCtx &c, const PpFlight<NW> &fl, c
 
 template <int FOLD, bool LONG, bool PH>
 __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) void k_ww_pp(DevTables T, TileLaunch L) {
-    static_assert(FOLD == 0 || FOLD == 1, "the fold table sits in LDS");
+    static_assert(FOLD == 0 || FOLD == 1 || FOLD == 3, "the fold table sits in LDS");
+    // FOLD 3: word-character bit and fold delta of a unit in one byte of a page (HostTables::ww_bp_*): no word bits, no delta pages
     constexpr int NW = LONG ? 16 : 8;           // words of folded units per run
     constexpr uint32_t kRunCap = 2 * NW + 1;    // run lengths are counted up to here: longer than every keyword
     typedef PpFlight<NW> Flight;
-    __shared__ __attribute__((aligned(16))) uint32_t wbits[2048];
-    __shared__ __attribute__((aligned(16))) unsigned char fold_base[FOLD == 1 ? 256 : 16];
+    __shared__ __attribute__((aligned(16))) uint32_t wbits[FOLD == 3 ? 4 : 2048];
+    __shared__ __attribute__((aligned(16))) unsigned char fold_base[FOLD != 0 ? 256 : 16];
     __shared__ __attribute__((aligned(16))) uint16_t pages[FOLD == 1 ? kFoldPagesMax * 256 : 8];
+    __shared__ __attribute__((aligned(16))) unsigned char bp_pages[FOLD == 3 ? kBytePagesMax * 256 : 16];
+    __shared__ __attribute__((aligned(16))) uint16_t bp_delta[FOLD == 3 ? 128 : 8];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // in front of the waves' rings: the Bloom filter over the keyword hashes, or (PH) the displacements of the perfect hash
     const uint32_t bloom_bytes = PH ? (T.ww_ph_buckets + 7u) / 8u * 16u : (T.ww_bloom_mask + 1u) / 8u;
@@ -759,8 +763,9 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
     const uint16_t *disp = reinterpret_cast<const uint16_t *>(smem);
     for (uint32_t w = threadIdx.x; w < bloom_bytes / 16; w += blockDim.x)
         reinterpret_cast<uint4 *>(bloom)[w] = reinterpret_cast<const uint4 *>(PH ? reinterpret_cast<const uint32_t *>(T.ww_ph_disp) : T.ww_bloom)[w];
-    for (uint32_t w = threadIdx.x; w < 2048 / 4; w += blockDim.x)
-        reinterpret_cast<uint4 *>(wbits)[w] = reinterpret_cast<const uint4 *>(T.wbits)[w];
+    if (FOLD != 3)
+        for (uint32_t w = threadIdx.x; w < 2048 / 4; w += blockDim.x)
+            reinterpret_cast<uint4 *>(wbits)[w] = reinterpret_cast<const uint4 *>(T.wbits)[w];
     FoldLds F{bloom, T.ww_bloom_mask, fold_base, pages};
     if (FOLD == 1) {
         for (uint32_t i = threadIdx.x; i < 256 / 16; i += blockDim.x)
@@ -768,7 +773,20 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
         for (uint32_t i = threadIdx.x; i < T.fold_n_pages * 32u; i += blockDim.x)
             reinterpret_cast<uint4 *>(pages)[i] = reinterpret_cast<const uint4 *>(T.fold_pages)[i];
     }
+    if (FOLD == 3) {
+        for (uint32_t i = threadIdx.x; i < 256 / 16; i += blockDim.x)
+            reinterpret_cast<uint4 *>(fold_base)[i] = reinterpret_cast<const uint4 *>(T.ww_bp_idx)[i];
+        for (uint32_t i = threadIdx.x; i < T.ww_bp_n * 16u; i += blockDim.x) // (a page = 256 bytes)
+            reinterpret_cast<uint4 *>(bp_pages)[i] = reinterpret_cast<const uint4 *>(T.ww_bp_pages)[i];
+        for (uint32_t i = threadIdx.x; i < 256 / 16; i += blockDim.x)
+            reinterpret_cast<uint4 *>(bp_delta)[i] = reinterpret_cast<const uint4 *>(T.ww_bp_delta)[i];
+    }
     __syncthreads();
+    // word-character bit of one unit (the tile loop has its own, eight units at a time)
+    auto is_word = [&](uint32_t u) -> uint32_t {
+        if (FOLD == 3) return bp_pages[((uint32_t)fold_base[u >> 8] << 8) | (u & 255u)] & 1u;
+        return word_bit(wbits, u);
+    };
 
     const uint32_t lane = lane_id();
     const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -795,7 +813,7 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
     uint32_t region = first_region;
     c.region = region;
     uint32_t boundary = tile0 + R;
-    uint32_t carry = tile0 >= 1 && tile0 - 1 < n ? word_bit(wbits, hay[tile0 - 1]) : 0u; // bit of the unit before the tile
+    uint32_t carry = tile0 >= 1 && tile0 - 1 < n ? is_word(hay[tile0 - 1]) : 0u; // bit of the unit before the tile
 
     // the lane's 8 units of the tile at `cur` (zeros beyond the buffer)
     auto load_tile = [&](uint32_t cur) -> uint4 {
@@ -819,7 +837,29 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
     auto stage = [&](uint32_t j, const uint4 w) -> uint32_t {
         const uint32_t cur = tile0 + j * kTileUnits, v = cur + lane * 8, slot = j & 1u;
         const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-        uint32_t wm = ACGPU_DBG(L, 8u) ? ((ww[0] ^ ww[2]) & 0xbfu) | 1u : word_bits8<8>(wbits, ww); // 8: ablation, no word-bit lookups (timing only)
+        uint32_t wm, fdw[4]; // word-character bits of the lane's 8 units; (FOLD 3) their folded units, two per word
+        if (FOLD == 3) {
+            // one byte per unit {delta index << 1 | word character}: page index, page byte, delta -- three dependent LDS reads per
+            // unit, eight units in flight; the pieces of the addresses come straight out of the packed words
+            uint32_t e[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t d = ww[k >> 1];
+                const uint32_t hi8 = (k & 1) ? d >> 24 : (d >> 8) & 0xffu, lo8 = (k & 1) ? (d >> 16) & 0xffu : d & 0xffu;
+                e[k] = bp_pages[((uint32_t)fold_base[hi8] << 8) | lo8];
+            }
+            wm = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) wm |= (e[k] & 1u) << k;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t d2 = (uint32_t)bp_delta[e[2 * k] >> 1] | ((uint32_t)bp_delta[e[2 * k + 1] >> 1] << 16);
+                typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+                fdw[k] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, ww[k]) + __builtin_bit_cast(u16x2, d2));
+            }
+        } else {
+            wm = ACGPU_DBG(L, 8u) ? ((ww[0] ^ ww[2]) & 0xbfu) | 1u : word_bits8<8>(wbits, ww); // 8: ablation, no word-bit lookups (timing only)
+        }
         if (cur + kTileUnits > n) wm &= (1u << (v < n ? min(n - v, 8u) : 0u)) - 1u; // (wave-uniform) nothing beyond the buffer is a word
         const uint32_t prev = from_prev_lane(wm >> 7, carry);
         carry = __builtin_amdgcn_readlane(wm, 63) >> 7;
@@ -829,10 +869,15 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
             const uint32_t last = span_end > v ? min(span_end - v, 8u) : 0u;
             sm &= ((1u << last) - 1u) & ~((1u << first) - 1u);
         }
-        uint32_t f[8];
+        uint4 fd;
+        if (FOLD == 3) {
+            fd = make_uint4(fdw[0], fdw[1], fdw[2], fdw[3]);
+        } else {
+            uint32_t f[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) f[k] = ww_fold<FOLD>(T, F, (ww[k >> 1] >> (16 * (k & 1))) & 0xffffu);
-        const uint4 fd = make_uint4(f[0] | (f[1] << 16), f[2] | (f[3] << 16), f[4] | (f[5] << 16), f[6] | (f[7] << 16));
+            for (int k = 0; k < 8; ++k) f[k] = ww_fold<FOLD == 3 ? 0 : FOLD>(T, F, (ww[k >> 1] >> (16 * (k & 1))) & 0xffffu);
+            fd = make_uint4(f[0] | (f[1] << 16), f[2] | (f[3] << 16), f[4] | (f[5] << 16), f[6] | (f[7] << 16));
+        }
         *reinterpret_cast<uint4 *>(ring + slot * kTileUnits + lane * 8) = fd;
         bits[slot * (kTileUnits / 8) + lane] = (unsigned char)wm;
         if (slot == 0 && lane < 8) { // the copy behind slot 1
@@ -882,9 +927,12 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
         for (int i = 0; i < 8; ++i) {
             // units 2i and 2i+1 of the run, zero from unit r on.  (Plain C on purpose: a packed-arithmetic version of this in
             // inline assembly, and a two-instruction h*33+w, made the kernel slower -- see DESIGN.md 4.4.)
+            // (The first 16 units are hashed as 8 words whatever the length.  Skipping the words that are zero for every run that
+            // can be a keyword -- config 5: words 6 and 7 -- behind wave-uniform branches, one multiplication and one rotation
+            // in their place, made the kernel 20 % SLOWER on the same box, 0.455 against 0.374 ms: EXPERIMENTS.md, round 6.)
             const int m = (int)r - 2 * i;
             fl.fw[i] = m >= 2 ? run.d[i] : (m == 1 ? (run.d[i] & 0xffffu) : 0u);
-            h = ww_hash_step(h, fl.fw[i]); // (the first 16 units are hashed as 8 words whatever the length)
+            h = ww_hash_step(h, fl.fw[i]);
             g = ww_hash2_step(g, fl.fw[i]);
         }
         if (LONG) {
@@ -1028,15 +1076,19 @@ __global__ void k_ww_sequential(DevTables T, const uint16_t *hay, uint32_t len, 
 
 // the position-parallel form serves keywords of at most 16 units whose fold table (if any) fits LDS, when its LDS fits next
 // to the Bloom filter (tile_debug bit 268435456 keeps k_ww_tile: A/B; bit 256, the trie-walk verification, exists only there)
+// the byte pages serve the scan they were built for (case-insensitive, the automaton's own word bits)
+static bool ww_pp_byte_pages(const DevTables &t) { return !t.cs && t.ww_bp_n != 0 && t.ww_bp_n <= kBytePagesMax && t.wbits == t.ww_bp_wbits; }
 static bool ww_pp_usable(const DevTables &t, const TileLaunch &l) {
-    const int fold = t.cs ? 0 : (ww_fold_pages_in_lds(t) ? 1 : 2);
+    const int fold = t.cs ? 0 : (ww_pp_byte_pages(t) ? 3 : ww_fold_pages_in_lds(t) ? 1 : 2);
+    const size_t fixed = fold == 3 ? 16 + 256 + 8 + kBytePagesMax * 256 + 256 : 8192 + 256 + kFoldPagesMax * 512 + 32; // the kernel's static LDS
     return fold != 2 && t.max_len <= kPpMaxLen && !(l.debug & (256u | 268435456u)) &&
-           ww_pp_lds_bytes(l.block, t, ww_pp_perfect(t, l)) + 8192 + 256 + kFoldPagesMax * 512 <= 160 * 1024;
+           ww_pp_lds_bytes(l.block, t, ww_pp_perfect(t, l)) + fixed <= 160 * 1024;
 }
 
 hipError_t launch_ww_tile(const DevTables &t, const TileLaunch &l, hipStream_t stream, const char **kernel_name) {
-    const int fold = t.cs ? 0 : (ww_fold_pages_in_lds(t) ? 1 : 2);
+    int fold = t.cs ? 0 : (ww_fold_pages_in_lds(t) ? 1 : 2);
     if (ww_pp_usable(t, l)) {
+        if (ww_pp_byte_pages(t)) fold = 3;
         const bool ph = ww_pp_perfect(t, l);
         const size_t lds = ww_pp_lds_bytes(l.block, t, ph);
         const bool lng = t.max_len > 16;
@@ -1054,11 +1106,15 @@ hipError_t launch_ww_tile(const DevTables &t, const TileLaunch &l, hipStream_t s
         if (fold == 0) {
             if (lng) { if (ph) ACGPU_WW_PP(0, true, true); else ACGPU_WW_PP(0, true, false); }
             else { if (ph) ACGPU_WW_PP(0, false, true); else ACGPU_WW_PP(0, false, false); }
+        } else if (fold == 3) {
+            if (lng) { if (ph) ACGPU_WW_PP(3, true, true); else ACGPU_WW_PP(3, true, false); }
+            else { if (ph) ACGPU_WW_PP(3, false, true); else ACGPU_WW_PP(3, false, false); }
         } else {
             if (lng) { if (ph) ACGPU_WW_PP(1, true, true); else ACGPU_WW_PP(1, true, false); }
             else { if (ph) ACGPU_WW_PP(1, false, true); else ACGPU_WW_PP(1, false, false); }
         }
 #undef ACGPU_WW_PP
+        fold = t.cs ? 0 : (ww_fold_pages_in_lds(t) ? 1 : 2); // (not reached: every branch above returns)
     }
     const void *fn = fold == 0 ? reinterpret_cast<const void *>(&k_ww_tile<0>)
                    : fold == 1 ? reinterpret_cast<const void *>(&k_ww_tile<1>) : reinterpret_cast<const void *>(&k_ww_tile<2>);
