@@ -485,7 +485,37 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
                 return rc;
             }
         }
-        HIP_TRY(hipMemsetAsync(d.chunk_counts.p, 0, (size_t)L.n_regions * 4, stream));
+        // The fused tail of k_ww_pp (TileLaunch::fused_tail, ft_total16): no counts, prefix sums or copy pass behind the scan -- a
+        // wave's records go to its own area and, when the workgroups with lower numbers are done, from there to their final
+        // place.  (Tunable ww_ramp_pm: spans that grow with the workgroup's number, so that copies would run while later
+        // workgroups still scan -- measured slower at every slope, 0 by default: EXPERIMENTS.md, round 6.)
+        // Tunable tile_form bit 2: never (the region-local slots + k_ww_compact: A/B, tests).
+        if (ww_direct && !fused_only && !(tunables().tile_form & 2) && ww_pp_serves(Tov ? *Tov : d.T, L)) {
+            const uint64_t tiles = (sh->own_end - base8 + 511) / 512, total16 = (tiles + 15) / 16;
+            const uint64_t G = std::min<uint64_t>((uint64_t)d.n_cu * ww_blocks_per_cu(), total16);
+            const uint64_t area_recs = total16 * 16 * 512 / 2 + G * 16 + 8;
+            if (G >= 1 && G <= (uint64_t)kMaxSlices && area_recs < (1ull << 32) && (rc = d.ww_recs.ensure(area_recs * 12 + 64)) == ACGPU_OK) {
+                fused_tail = true;
+                L.d_region_recs = (int32_t *)d.ww_recs.p;
+                L.fused_tail = 1;
+                L.grid = (int)G;
+                L.ft_total16 = (uint32_t)total16;
+                const int64_t ramp = tunables().ww_ramp_pm;
+                L.ft_ramp_pm = (uint32_t)(ramp < 0 ? 0 : std::min<int64_t>(ramp, 1000));
+                L.d_out = d_out;
+                L.out_cap = cap;
+                L.out_map = record_kind == ACGPU_REC_MAP ? 1 : 0;
+                L.d_id_map = nullptr;
+                unsigned long long *h_slot_t = tk ? tk->h_count : d.h_counter, *d_slot_t = nullptr;
+                HIP_TRY(hipHostGetDevicePointer((void **)&d_slot_t, h_slot_t, 0));
+                L.tail_result = d_slot_t;
+                L.tail_d_result = reinterpret_cast<acgpu_device_result *>(sh->d_result);
+                L.tail_zero_counters = counters_next;
+            } else if (rc != ACGPU_OK && rc != ACGPU_E_NOMEM) {
+                return rc;
+            }
+        }
+        if (!fused_tail) HIP_TRY(hipMemsetAsync(d.chunk_counts.p, 0, (size_t)L.n_regions * 4, stream));
 #ifdef ACGPU_TIMING
         static DevBuf ww_timing;
         if ((rc = ww_timing.ensure((size_t)L.grid * 16 * 8 * 8))) return rc;
@@ -497,6 +527,7 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
             L.ev_stop = ev[1];
             ext_timed = true;
         }
+        if (fused_tail) L.ev_stop = (timed || tk) ? ev[2] : nullptr; // the scan is the call's only kernel: its end is the call's
         HIP_TRY(launch_ww_tile(Tov ? *Tov : d.T, L, stream, &kname));
 #ifdef ACGPU_TIMING
         if (!tk) { // where a wave's time goes (s_memtime ticks, 100 MHz), averaged over the waves
@@ -509,6 +540,17 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
                 nw++;
                 for (int i = 0; i < 8; ++i) sum[i] += (double)h[w * 8 + i];
             }
+            if (fused_tail) { // the workgroups in the order of their numbers: scan end, counts there, copy done (s_memtime ticks from the first scan end)
+                unsigned long long t0 = ~0ull;
+                for (size_t w = 0; w < h.size() / 8; ++w) if (h[w * 8]) t0 = std::min(t0, h[w * 8]);
+                const size_t G = (size_t)L.grid;
+                for (size_t b0 = 0; b0 < G; b0 += std::max<size_t>(G / 16, 1)) {
+                    double se = 0, be = 0, ce = 0; size_t k = 0;
+                    for (size_t b = b0; b < std::min(G, b0 + std::max<size_t>(G / 16, 1)); ++b)
+                        for (size_t w = b * 16; w < b * 16 + 16; ++w) if (h[w * 8]) { se = std::max(se, (double)(h[w * 8] - t0)); be = std::max(be, (double)(h[w * 8 + 1] - t0)); ce = std::max(ce, (double)(h[w * 8 + 2] - t0)); k++; }
+                    fprintf(stderr, "[ww fused tail] workgroups %3zu..: last scan end %8.0f | counts below there %8.0f | last copy done %8.0f\n", b0, se, be, ce);
+                }
+            } else
             if (nw) fprintf(stderr, "[ww timing] waves %zu total %.0f | windows %.0f | chunk1 %.0f | chunk2 %.0f | hash+bloom %.0f | probes %.0f | emission %.0f | calls %.1f\n",
                             nw, sum[0] / nw, sum[1] / nw, sum[2] / nw, sum[3] / nw, sum[4] / nw, sum[5] / nw, sum[6] / nw, sum[7] / nw);
         }
@@ -727,7 +769,7 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         if ((uint32_t)d.h_counter[1] != 0) // a scratch slice overflowed: fused kernel, one scratch slice
             return match_all(a, d, sh, record_kind, d_out, cap, n_out, stream, prof, nullptr, true, Tov);
         *n_out = *d.h_counter;
-        d.all_density = (double)*n_out / (double)own_len;
+        if (!ww) d.all_density = (double)*n_out / (double)own_len;
         if (prof) {
             HIP_TRY(hipEventElapsedTime(&prof->scan_ms, d.ev[0], d.ev[2]));
             prof->finalize_ms = 0.0f;
@@ -1724,6 +1766,7 @@ int64_t acgpu_set_tunable(const char *name, int64_t value) {
     else if (!std::strcmp(name, "ww_no_bloom")) slot = &t.ww_no_bloom;
     else if (!std::strcmp(name, "ww_no_ph")) slot = &t.ww_no_ph;
     else if (!std::strcmp(name, "ww_no_byte_pages")) slot = &t.ww_no_byte_pages;
+    else if (!std::strcmp(name, "ww_ramp_pm")) slot = &t.ww_ramp_pm;
     else if (!std::strcmp(name, "ww_ph_lambda")) slot = &t.ww_ph_lambda;
     else if (!std::strcmp(name, "rdense_budget_bytes")) slot = &t.rdense_budget_bytes;
     else if (!std::strcmp(name, "filter_max_bytes")) slot = &t.filter_max_bytes;

@@ -94,6 +94,11 @@ struct TileLaunch {
     unsigned long long *tail_result;       // device-visible pinned host memory: [0] = count, [1] = overflow word
     acgpu_device_result *tail_d_result;    // acgpu_shard::d_result or nullptr
     unsigned long long *tail_zero_counters; // the counter set of the NEXT call (kMaxSlices x words 0..3), or nullptr
+    // k_ww_pp with the fused tail: no regions -- wave w of workgroup b scans the tiles ww_ft_tiles_before(b) + w * q .. + q
+    // (ft_total16 = tiles of the shard / 16, rounded up; ft_ramp_pm: see there), its records go to its own area of
+    // d_region_recs (from record (first unit of the span - base8) / 2 + wave number on: a span of U units holds at most
+    // U / 2 + 1 words) and, when the workgroups before it are done, from there to their final place
+    uint32_t ft_total16, ft_ramp_pm;
     int32_t *d_region_recs; // nullptr: the scratch slices + k_permute
     uint32_t region_cap;
     unsigned long long *d_timing; // -DACGPU_TIMING builds only: 8 cycle counters per wave (tools/build_variant.sh timing)
@@ -355,6 +360,7 @@ uint32_t ww_fold_pages_in_lds(const DevTables &t); // 0: the fold table is not s
 size_t ww_lds_bytes(int block_threads, const DevTables &t);
 int ww_blocks_per_cu();
 hipError_t launch_ww_tile(const DevTables &t, const TileLaunch &l, hipStream_t stream, const char **kernel_name);
+bool ww_pp_serves(const DevTables &t, const TileLaunch &l); // launch_ww_tile would take k_ww_pp (the kernel that has the fused tail)
 hipError_t launch_ww_sequential(const DevTables &t, const uint16_t *d_hay, uint32_t len, void *d_out, uint64_t cap,
                                 int record_kind, unsigned long long *d_counter, hipStream_t stream);
 } // namespace acgpu

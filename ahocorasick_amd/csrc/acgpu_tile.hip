@@ -476,9 +476,6 @@ __device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) {
 // its final index is (records of the workgroups before this one) + (records of the workgroup's waves before its wave) + rank:
 // nothing but the sixteen wave totals and the slice's fill mark is handed over, through LDS -- the tail is a chain of memory
 // round trips behind the slowest workgroup's scan, and every word that stays in LDS is one of them less.
-constexpr unsigned long long kFtDone = 1ull << 62;
-constexpr uint32_t kFtWords = 2 + kTileBlock / kWave; // [0] the workgroup's number, [1] the slice's fill mark, [2 + w] wave w's records
-__device__ __forceinline__ uint32_t ft_wave_sum(uint32_t x) { return __builtin_amdgcn_readlane(wave_inclusive_scan_dpp(x), kWave - 1); }
 __device__ __forceinline__ void tile_fused_tail(const TileLaunch &L, uint32_t wg, uint32_t *wg_words, uint32_t wave_total, uint32_t res_cur,
                                                 uint32_t res_left, uint32_t slot_limit) {
     const uint32_t lane = lane_id(), wave = threadIdx.x / kWave;
@@ -500,29 +497,14 @@ __device__ __forceinline__ void tile_fused_tail(const TileLaunch &L, uint32_t wg
     const uint32_t wv_incl = wave_inclusive_scan_dpp(wv);
     const uint32_t wv_excl = wv_incl - wv;                                  // lane w: records of the waves before wave w
     const uint32_t mine = __builtin_amdgcn_readlane(wv_incl, kWaves - 1);  // the workgroup's records
-    if (threadIdx.x == 0)
-        __hip_atomic_store(L.d_counter + (size_t)wg * kCounterStride + 2, kFtDone | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // Where this workgroup's records begin: the records of every workgroup that started before it.  ONE wave asks for them (a
-    // grid of waiting workgroups that all poll takes the memory system away from the workgroups still scanning), and only when
-    // the first records of the slice are in registers: a workgroup that is done before the ones it waits for has read its
-    // slice by the time their counts arrive.  The sum reaches the other waves through LDS (the word that held the number).
+    if (threadIdx.x == 0) ft_publish(L, wg, mine);
+    // Where this workgroup's records begin: the records of every workgroup that started before it (ft_below), asked for only
+    // when the first records of the slice are in registers: a workgroup that is done before the ones it waits for has read
+    // its slice by the time their counts arrive.
     uint32_t below = 0;
     bool have_below = false;
     auto wait_below = [&]() {
-        if (wave == 0) {
-            for (uint32_t w0 = 0; w0 < wg; w0 += kWave) {
-                unsigned long long v;
-                do {
-                    v = w0 + lane < wg ? __hip_atomic_load(L.d_counter + (size_t)(w0 + lane) * kCounterStride + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kFtDone;
-                    if (__all((v & kFtDone) != 0ull)) break;
-                    __builtin_amdgcn_s_sleep(16);
-                } while (true);
-                below += ft_wave_sum((uint32_t)v); // (record counts fit 32 bits: the scratch holds fewer than 2^32 records)
-            }
-            if (lane == 0) wg_words[0] = below;
-        }
-        __syncthreads();
-        below = wg_words[0];
+        below = ft_below(L, wg, wg_words);
         have_below = true;
     };
     // the slice, every slot below its fill mark: (wave, rank) -> final index
@@ -562,31 +544,7 @@ __device__ __forceinline__ void tile_fused_tail(const TileLaunch &L, uint32_t wg
         }
     }
     if (!have_below) wait_below();
-    // the workgroup with the last number has waited for all the others' counts: the call's count, the overflow word (final: a
-    // workgroup publishes its count when its scan is over), and the NEXT call's counter set zeroed -- no copy, no memset and
-    // no further launch on the stream
-    if (wg + 1u == gridDim.x) {
-        if (threadIdx.x == 0) {
-            const unsigned long long total = (unsigned long long)below + mine;
-            const uint32_t flag = __hip_atomic_load(L.d_overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (L.tail_d_result) {
-                L.tail_d_result->n_records = total;
-                L.tail_d_result->redone = flag;
-                L.tail_d_result->reserved = 0;
-            }
-            if (L.tail_result) {
-                L.tail_result[0] = total;
-                L.tail_result[1] = flag;
-            }
-            __hip_atomic_store(L.d_overflow, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __threadfence_system();
-        }
-        if (L.tail_zero_counters)
-            for (uint32_t i = threadIdx.x; i < (uint32_t)kMaxSlices; i += blockDim.x) {
-                unsigned long long *z = L.tail_zero_counters + (size_t)i * kCounterStride;
-                z[0] = 0; z[1] = 0; z[2] = 0; z[3] = 0;
-            }
-    }
+    ft_report(L, wg, (unsigned long long)below + mine);
 }
 
 // A wave owns a contiguous SPAN of regions.  Region boundaries sit at base8 + r * region_units (base8 = own_begin
@@ -613,10 +571,7 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint32_t wg_words[kFtWords]; // fused tail: the workgroup's number, its slice's fill mark, its waves' records
     const bool FT = !SPLIT && L.fused_tail != 0; // kernel-uniform
-    if (FT && threadIdx.x == 0) { // (the answer is there when the tables are: the barrier below)
-        wg_words[0] = (uint32_t)atomicAdd(L.d_counter + 3, 1ull);
-        wg_words[1] = 0u;
-    }
+    if (FT && threadIdx.x == 0) ft_take_number(L, wg_words); // (the answer is there when the tables are: the barrier below)
     const unsigned char *rows8 = reinterpret_cast<const unsigned char *>(rows32);
     uint32_t *cand_all = reinterpret_cast<uint32_t *>(smem);
     { // the filter rows, 16 bytes per thread and step (the kernel does not stream before this is done)

@@ -49,6 +49,7 @@ struct TileCtx {
     uint16_t *pos16 = nullptr;
     uint32_t pos_base = 0;
     uint32_t region = 0; // WholeWord, region-local records: the region the queued run starts belong to (wave-uniform)
+    uint32_t area = 0;   // k_ww_pp: record index in TileLaunch::d_region_recs of the current region's (fused tail: the wave's) first record
     uint32_t wg = 0;     // the workgroup's number: its scratch slice and counters (blockIdx.x, or the start ticket of the fused tail)
 #ifdef ACGPU_TIMING
     unsigned long long vt[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // verification phases (k_ac_tile: windows, K-gram nodes, walks, emission;
@@ -148,6 +149,71 @@ __device__ __forceinline__ SlotRange reserve_slots(TileCtx &c, uint32_t total) {
         c.res_left = r.old_left - total;
     }
     return r;
+}
+
+// ---- fused tail (TileLaunch::fused_tail): what the tile kernels' workgroups hand each other ------------------------------------
+constexpr unsigned long long kFtDone = 1ull << 62; // d_counter[number * kCounterStride + 2]: {done, the workgroup's records}
+constexpr uint32_t kFtWords = 2 + kTileBlock / kWave; // LDS: [0] the workgroup's number (later: the records below it), [1] the slice's fill mark, [2 + w] wave w's records
+__device__ __forceinline__ uint32_t ft_wave_sum(uint32_t x) { return __builtin_amdgcn_readlane(wave_inclusive_scan_dpp(x), kWave - 1); }
+
+// The workgroup's number: workgroups are numbered in the order in which they start, so that every lower number is running or
+// done whatever share of the grid is resident.  Thread 0, before the kernel's first barrier; read wg_words[0] behind it.
+__device__ __forceinline__ void ft_take_number(const TileLaunch &L, uint32_t *wg_words) {
+    wg_words[0] = (uint32_t)atomicAdd(L.d_counter + 3, 1ull);
+    wg_words[1] = 0u;
+}
+
+// this workgroup is done scanning and has `mine` records (one thread)
+__device__ __forceinline__ void ft_publish(const TileLaunch &L, uint32_t wg, uint32_t mine) {
+    __hip_atomic_store(L.d_counter + (size_t)wg * kCounterStride + 2, kFtDone | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The records of all workgroups with a lower number; waits for them.  Every wave of the workgroup calls it (a barrier inside):
+// ONE wave asks -- a grid of waiting workgroups that all poll takes the memory system away from the workgroups still scanning --
+// and the sum reaches the others through the LDS word that held the number.
+__device__ __forceinline__ uint32_t ft_below(const TileLaunch &L, uint32_t wg, uint32_t *wg_words) {
+    const uint32_t lane = lane_id();
+    if (threadIdx.x / kWave == 0) {
+        uint32_t below = 0;
+        for (uint32_t w0 = 0; w0 < wg; w0 += kWave) {
+            unsigned long long v;
+            do {
+                v = w0 + lane < wg ? __hip_atomic_load(L.d_counter + (size_t)(w0 + lane) * kCounterStride + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kFtDone;
+                if (__all((v & kFtDone) != 0ull)) break;
+                __builtin_amdgcn_s_sleep(16);
+            } while (true);
+            below += ft_wave_sum((uint32_t)v); // (record counts fit 32 bits: the scratch holds fewer than 2^32 records)
+        }
+        if (lane == 0) wg_words[0] = below;
+    }
+    __syncthreads();
+    return wg_words[0];
+}
+
+// The workgroup with the last number has waited for all the others' counts: the call's count, the overflow word (final: a
+// workgroup publishes its count when its scan is over), and the NEXT call's counter set zeroed -- no copy, no memset and no
+// further launch on the stream.  Every thread of every workgroup calls it.
+__device__ __forceinline__ void ft_report(const TileLaunch &L, uint32_t wg, unsigned long long total) {
+    if (wg + 1u != gridDim.x) return;
+    if (threadIdx.x == 0) {
+        const uint32_t flag = __hip_atomic_load(L.d_overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (L.tail_d_result) {
+            L.tail_d_result->n_records = total;
+            L.tail_d_result->redone = flag;
+            L.tail_d_result->reserved = 0;
+        }
+        if (L.tail_result) {
+            L.tail_result[0] = total;
+            L.tail_result[1] = flag;
+        }
+        __hip_atomic_store(L.d_overflow, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence_system();
+    }
+    if (L.tail_zero_counters)
+        for (uint32_t i = threadIdx.x; i < (uint32_t)kMaxSlices; i += blockDim.x) {
+            unsigned long long *z = L.tail_zero_counters + (size_t)i * kCounterStride;
+            z[0] = 0; z[1] = 0; z[2] = 0; z[3] = 0;
+        }
 }
 
 } // namespace acgpu

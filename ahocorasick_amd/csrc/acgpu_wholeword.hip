@@ -731,7 +731,7 @@ __device__ __forceinline__ void pp_consume(TileCtx &c, const PpFlight<NW> &fl, c
     if (total == 0) return;
     const uint32_t prefix = incl - m;
     if (L.d_region_recs) {
-        int32_t *base = L.d_region_recs + ((size_t)c.region * L.region_cap + c.rank_base) * 3;
+        int32_t *base = L.d_region_recs + ((size_t)c.area + c.rank_base) * 3;
         if (m) {
             typedef int32_t v3i __attribute__((ext_vector_type(3)));
             const v3i rec = {(int32_t)fl.s, (int32_t)(fl.s + fl.r), (int32_t)id};
@@ -756,6 +756,9 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
     __shared__ __attribute__((aligned(16))) uint16_t pages[FOLD == 1 ? kFoldPagesMax * 256 : 8];
     __shared__ __attribute__((aligned(16))) unsigned char bp_pages[FOLD == 3 ? kBytePagesMax * 256 : 16];
     __shared__ __attribute__((aligned(16))) uint16_t bp_delta[FOLD == 3 ? 128 : 8];
+    __shared__ uint32_t wg_words[kFtWords]; // fused tail (acgpu_tile_common.h)
+    const bool FT = L.fused_tail != 0;      // kernel-uniform
+    if (FT && threadIdx.x == 0) ft_take_number(L, wg_words); // (the answer is there when the tables are: the barrier below)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // in front of the waves' rings: the Bloom filter over the keyword hashes, or (PH) the displacements of the perfect hash
     const uint32_t bloom_bytes = PH ? (T.ww_ph_buckets + 7u) / 8u * 16u : (T.ww_bloom_mask + 1u) / 8u;
@@ -790,29 +793,46 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
 
     const uint32_t lane = lane_id();
     const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    const uint32_t wave_global = blockIdx.x * (kTileBlock / kWave) + wave_in_block;
+    const uint32_t wg = FT ? __builtin_amdgcn_readfirstlane(wg_words[0]) : blockIdx.x; // (fused tail: workgroups are numbered by their start)
+    const uint32_t wave_global = wg * (kTileBlock / kWave) + wave_in_block;
     unsigned char *mine = smem + bloom_bytes + wave_in_block * kPpWaveBytes;
     uint16_t *ring = reinterpret_cast<uint16_t *>(mine);
     unsigned char *bits = mine + kPpRingUnits * 2;
     uint16_t *list = reinterpret_cast<uint16_t *>(mine + kPpRingUnits * 2 + kPpBitBytes);
     TileCtx c{&T, &L, nullptr, 0, 0, 0u, 0};
-    c.wg = blockIdx.x;
+    c.wg = wg;
 
-    const uint32_t first_region = wave_global * L.regions_per_wave;
-    if (first_region >= L.n_regions) return;
-    const uint32_t last_region = min(first_region + L.regions_per_wave, L.n_regions);
     const uint32_t base8 = L.own_begin & ~7u;
     const uint32_t R = L.region_units;
-    const uint32_t span_begin = max(L.own_begin, base8 + first_region * R);
-    uint32_t span_end = base8 + last_region * R;
-    if (span_end > L.own_end || last_region == L.n_regions) span_end = L.own_end;
     const uint32_t n = L.n_units;
     const uint16_t *hay = L.d_hay;
-    const uint32_t tile0 = base8 + first_region * R;
+    // the wave's span: regions_per_wave regions, or (fused tail) its share of the workgroup's tiles (TileLaunch::ft_total16)
+    uint32_t first_region = wave_global * L.regions_per_wave, tile0, span_begin, span_end, boundary;
+    bool has_work;
+    if (FT) {
+        const uint32_t tb = ww_ft_tiles_before(wg, gridDim.x, L.ft_total16, L.ft_ramp_pm);
+        const uint32_t q = (ww_ft_tiles_before(wg + 1u, gridDim.x, L.ft_total16, L.ft_ramp_pm) - tb) / (kTileBlock / kWave);
+        tile0 = base8 + (tb + wave_in_block * q) * kTileUnits;
+        has_work = q != 0u && tile0 < L.own_end;
+        span_begin = max(L.own_begin, tile0);
+        span_end = min(L.own_end, tile0 + q * kTileUnits);
+        boundary = ~0u; // (no regions: ranks count through the span, records go to the wave's own area)
+        first_region = 0;
+        c.area = (tile0 - base8) / 2u + wave_global;
+    } else {
+        has_work = first_region < L.n_regions;
+        if (!has_work) return;
+        const uint32_t last_region = min(first_region + L.regions_per_wave, L.n_regions);
+        span_begin = max(L.own_begin, base8 + first_region * R);
+        span_end = base8 + last_region * R;
+        if (span_end > L.own_end || last_region == L.n_regions) span_end = L.own_end;
+        tile0 = base8 + first_region * R;
+        boundary = tile0 + R;
+        c.area = first_region * L.region_cap;
+    }
 
     uint32_t region = first_region;
     c.region = region;
-    uint32_t boundary = tile0 + R;
     uint32_t carry = tile0 >= 1 && tile0 - 1 < n ? is_word(hay[tile0 - 1]) : 0u; // bit of the unit before the tile
 
     // the lane's 8 units of the tile at `cur` (zeros beyond the buffer)
@@ -987,6 +1007,7 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
     // emitted.  The stream runs one tile ahead of the staging in ONE set of registers (the load goes out right after the
     // registers are staged and has a whole pass to arrive; rotating register sets would copy registers whose loads are in
     // flight, and such a copy waits for everything issued before it).
+    if (has_work) {
     Flight fl;
     uint32_t sm_next;
     {
@@ -1022,11 +1043,79 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
             c.rank_base = 0;
             ++region;
             c.region = region;
+            c.area = region * L.region_cap;
             boundary += R;
         }
         early_batches(j + 1, cnt, b_last);
         fl = nf;
         sm_next = sm2;
+    }
+    } // has_work
+    if (FT) {
+        // The fused tail (see acgpu_tile_common.h and k_ac_tile): the wave's records lie in its own area, in the reference's
+        // order; they go behind those of the workgroups with lower numbers and of the workgroup's waves before this one.
+        // A wave copies what it wrote itself: nothing of another wave's is read but sixteen counts in LDS.
+        constexpr uint32_t kWaves = kTileBlock / kWave;
+        const uint32_t cnt = c.rank_base;
+#ifdef ACGPU_TIMING
+        const unsigned long long ft_t_scan = __builtin_amdgcn_s_memtime(); // (one clock for the whole chip)
+#endif
+        if (lane == 0) wg_words[2 + wave_in_block] = cnt;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the wave's own record stores)
+        __syncthreads();
+        const uint32_t wv = lane < kWaves ? wg_words[2 + lane] : 0u;
+        const uint32_t wv_incl = wave_inclusive_scan_dpp(wv);
+        const uint32_t total_wg = __builtin_amdgcn_readlane(wv_incl, kWaves - 1);
+        const uint32_t before_me = __builtin_amdgcn_readlane(wv_incl - wv, wave_in_block);
+        if (threadIdx.x == 0) ft_publish(L, wg, total_wg);
+        // the first records of the area are asked for before the wait for the lower numbers: they are there when it ends.  Two
+        // sets of registers in turn, the next set's loads in front of this set's stores: a wait for loads is a wait for every
+        // older store's acknowledgement as well (one counter), so a loop of load-then-store pays both latencies per step
+        typedef int32_t v3i __attribute__((ext_vector_type(3)));
+        const int32_t *src = L.d_region_recs + (size_t)c.area * 3; // (12-byte records: a v3i is 16 bytes wide as an array element)
+        constexpr uint32_t kPer = 8, kStep = kPer * kWave;
+        v3i ra[kPer], rb[kPer];
+        auto load_set = [&](v3i (&r)[kPer], uint32_t k0) {
+#pragma unroll
+            for (uint32_t q = 0; q < kPer; ++q) {
+                const uint32_t k = k0 + q * kWave + lane;
+                r[q] = v3i{0, 0, 0};
+                if (k < cnt) r[q] = __builtin_nontemporal_load(reinterpret_cast<const v3i *>(src + (size_t)k * 3));
+            }
+        };
+        load_set(ra, 0);
+        const uint32_t below = ft_below(L, wg, wg_words);
+#ifdef ACGPU_TIMING
+        const unsigned long long ft_t_below = __builtin_amdgcn_s_memtime();
+#endif
+        const unsigned long long at0 = (unsigned long long)below + before_me;
+        auto store_set = [&](const v3i (&r)[kPer], uint32_t k0) {
+#pragma unroll
+            for (uint32_t q = 0; q < kPer; ++q) {
+                const uint32_t k = k0 + q * kWave + lane;
+                const unsigned long long at = at0 + k;
+                if (k >= cnt || at >= L.out_cap) continue;
+                if (L.out_map) *reinterpret_cast<v3i *>(reinterpret_cast<int32_t *>(L.d_out) + at * 3) = r[q];
+                else reinterpret_cast<int2 *>(L.d_out)[at] = make_int2(r[q].x, r[q].y);
+            }
+        };
+        for (uint32_t k0 = 0; k0 < cnt; k0 += 2 * kStep) {
+            if (k0 + kStep < cnt) load_set(rb, k0 + kStep);
+            store_set(ra, k0);
+            if (k0 + 2 * kStep < cnt) load_set(ra, k0 + 2 * kStep);
+            if (k0 + kStep < cnt) store_set(rb, k0 + kStep);
+        }
+#ifdef ACGPU_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0 && L.d_timing) { // per wave: when its scan ended, when the counts before it were there, when its copy was done
+            L.d_timing[(size_t)wave_global * 8 + 0] = ft_t_scan;
+            L.d_timing[(size_t)wave_global * 8 + 1] = ft_t_below;
+            L.d_timing[(size_t)wave_global * 8 + 2] = __builtin_amdgcn_s_memtime();
+            L.d_timing[(size_t)wave_global * 8 + 3] = cnt;
+        }
+#endif
+        ft_report(L, wg, (unsigned long long)below + total_wg);
+        return;
     }
     if (lane == 0) L.d_region_counts[region] = c.rank_base;
     for (uint32_t i = lane; i < c.res_left; i += kWave)
@@ -1084,6 +1173,8 @@ static bool ww_pp_usable(const DevTables &t, const TileLaunch &l) {
     return fold != 2 && t.max_len <= kPpMaxLen && !(l.debug & (256u | 268435456u)) &&
            ww_pp_lds_bytes(l.block, t, ww_pp_perfect(t, l)) + fixed <= 160 * 1024;
 }
+
+bool ww_pp_serves(const DevTables &t, const TileLaunch &l) { return ww_pp_usable(t, l); }
 
 hipError_t launch_ww_tile(const DevTables &t, const TileLaunch &l, hipStream_t stream, const char **kernel_name) {
     int fold = t.cs ? 0 : (ww_fold_pages_in_lds(t) ? 1 : 2);

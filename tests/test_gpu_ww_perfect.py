@@ -13,7 +13,8 @@ from tests.helpers import LOWER, WORD, oracle_parallel
 
 pytestmark = pytest.mark.gpu
 
-KNOBS = [("force_kernel", 0), ("tile_debug", 0), ("ww_no_ph", 0), ("ww_ph_lambda", 0), ("ww_first_seed", 0), ("region_units", 0)]
+KNOBS = [("force_kernel", 0), ("tile_debug", 0), ("ww_no_ph", 0), ("ww_ph_lambda", 0), ("ww_first_seed", 0), ("region_units", 0), ("tile_form", 0),
+         ("ww_ramp_pm", -1), ("ww_no_byte_pages", 0)]
 
 
 @pytest.fixture(autouse=True)
@@ -135,3 +136,71 @@ def test_listener_api_over_the_perfect_hash():
     seen = []
     WholeWordMatchSet(kws, False).match(hay, lambda h, s, e: (seen.append(h[s:e]) or len(seen) < 3))
     assert seen == ["zürich", "ZURICH", "αθηνα"]
+
+
+def test_fused_tail_of_the_word_kernel_in_every_form():
+    """k_ww_pp with the ordering fused into its tail (csrc/acgpu_wholeword.hip, TileLaunch::fused_tail): spans with and without a
+    ramp, the copy pass of its own (tile_form 2), Set and Map records, a capacity smaller than the matches, shards with halos,
+    short texts after long ones on one pool, tickets in flight, the delta pages instead of the byte pages -- all the oracle's."""
+    import torch
+    words = synth.mixed_script_words(91, 5000)
+    hay = synth.token_stream_haystack(92, (1 << 21) + 77, words, synth.swapcase_table())
+    orc = Oracle(FAM_WHOLEWORD, words, case_sensitive=False, lower=LOWER, word_chars=WORD)
+    want = oracle_parallel(orc, hay, "wholeword", 13)
+    d_hay = torch.from_numpy(hay.view(np.int16)).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(a, n, with_ids, cap, **kw):
+        d_out = torch.full((max(cap, 1), 3 if with_ids else 2), -7, dtype=torch.int32, device="cuda")
+        n_out, rc, prof, _ = a.match_device(d_hay.data_ptr(), n, with_ids, d_out.data_ptr(), cap, stream=st, profile=True, **kw)
+        return d_out, n_out, rc, prof
+
+    a = Automaton(N.MODE_WHOLEWORD, words, False, word_chars=WORD, lower=LOWER)
+    for ramp in (-1, 0, 90, 1000):
+        N.set_tunable("ww_ramp_pm", ramp)
+        for with_ids in (True, False):
+            d_out, n_out, rc, prof = run(a, hay.size, with_ids, len(want) + 50)
+            assert rc == N.OK and n_out == len(want) and prof["finalize_ms"] == 0.0, (ramp, with_ids)
+            assert (d_out[:n_out].cpu().numpy() == (want if with_ids else want[:, :2])).all(), (ramp, with_ids)
+            assert (d_out[n_out:].cpu().numpy() == -7).all()
+    N.set_tunable("ww_ramp_pm", -1)
+    N.set_tunable("tile_form", 2)
+    d_out, n_out, rc, prof = run(a, hay.size, True, len(want) + 50)
+    assert rc == N.OK and n_out == len(want) and prof["finalize_ms"] > 0.0 and (d_out[:n_out].cpu().numpy() == want).all()
+    N.set_tunable("tile_form", 0)
+    cap = len(want) // 2
+    d_out, n_out, rc, _ = run(a, hay.size, True, cap)
+    assert rc == N.E_OVERFLOW and n_out == len(want) and (d_out[:cap].cpu().numpy() == want[:cap]).all()
+    # shards of the buffer; a rank's buffer with one unit of left context and max_len + 1 units of right halo
+    cuts = [0, 600_001, 600_002, 1_500_000, hay.size]
+    parts = []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        d_out, n_out, rc, _ = run(a, hay.size, True, len(want) + 50, own=(lo, hi))
+        assert rc == N.OK
+        parts.append(d_out[:n_out].cpu().numpy())
+    assert (np.concatenate(parts) == want).all()
+    # short texts after long ones (fewer workgroups, a text shorter than a tile): the counters were left clean
+    for m in (3, 511, 513, 8200, 1 << 18):
+        w = orc.match(hay[:m], cap=1 << 20)
+        d_out, n_out, rc, _ = run(a, m, True, len(w) + 8)
+        assert rc == N.OK and n_out == len(w) and (d_out[:n_out].cpu().numpy() == w).all(), m
+    # three tickets one behind the other
+    outs = [torch.empty((len(want) + 8, 3), dtype=torch.int32, device="cuda") for _ in range(3)]
+    tks = []
+    for o in outs:
+        tk, rc = a.match_device_begin(d_hay.data_ptr(), hay.size, True, o.data_ptr(), len(want) + 8, stream=st)
+        assert rc == N.OK
+        tks.append(tk)
+    for tk, o in zip(tks, outs):
+        n_out, rc, _ = a.match_device_end(tk)
+        assert rc == N.OK and n_out == len(want) and (o[:n_out].cpu().numpy() == want).all()
+    # the delta pages + word bits (FOLD 1) and the case-sensitive form under the same tail
+    N.set_tunable("ww_no_byte_pages", 1)
+    b = Automaton(N.MODE_WHOLEWORD, words, False, word_chars=WORD, lower=LOWER)
+    N.set_tunable("ww_no_byte_pages", 0)
+    d_out, n_out, rc, prof = run(b, hay.size, True, len(want) + 50)
+    assert rc == N.OK and prof["scan_kernel"].startswith("k_ww_pp<1") and (d_out[:n_out].cpu().numpy() == want).all()
+    cs = Automaton(N.MODE_WHOLEWORD, words, True, word_chars=WORD)
+    want_cs = oracle_parallel(Oracle(FAM_WHOLEWORD, words, word_chars=WORD), hay, "wholeword", 13)
+    d_out, n_out, rc, prof = run(cs, hay.size, True, len(want_cs) + 50)
+    assert rc == N.OK and prof["scan_kernel"].startswith("k_ww_pp<0") and n_out == len(want_cs) and (d_out[:n_out].cpu().numpy() == want_cs).all()
