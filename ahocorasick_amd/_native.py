@@ -45,7 +45,7 @@ class DeviceResult(ctypes.Structure):  # acgpu_device_result: what Shard.d_resul
     _fields_ = [("n_records", ctypes.c_uint64), ("redone", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
 
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class Profile(ctypes.Structure):
@@ -57,7 +57,7 @@ class Profile(ctypes.Structure):
 SYMBOLS = ["acgpu_build", "acgpu_free", "acgpu_get_info", "acgpu_match_u16", "acgpu_match_batch_u16", "acgpu_match_device",
            "acgpu_match_device_begin", "acgpu_match_device_end", "acgpu_match_device_abandon", "acgpu_synth_fill", "acgpu_synth_tokens", "acgpu_stream_probe",
            "acgpu_set_tunable", "acgpu_strerror", "acgpu_last_hip_error", "acgpu_abi_version", "acgpu_debug_tables", "acgpu_debug_states",
-           "acgpu_debug_wordhash", "acgpu_stream_open", "acgpu_stream_feed", "acgpu_stream_close",
+           "acgpu_debug_wordhash", "acgpu_debug_wordhash_perfect", "acgpu_stream_open", "acgpu_stream_feed", "acgpu_stream_close",
            "acgpu_match_u16_multi", "acgpu_comm_open", "acgpu_comm_close", "acgpu_comm_transport", "acgpu_comm_stream",
            "acgpu_match_device_allgather", "acgpu_last_rccl_error", "acgpu_gather_slot_bytes",
            "acgpu_stream_set_pipelined", "acgpu_stream_reserve"]
@@ -126,6 +126,8 @@ def lib():
         L.acgpu_stream_set_pipelined.argtypes = [vp, ci]
         L.acgpu_stream_reserve.restype = ci
         L.acgpu_stream_reserve.argtypes = [vp, u64, ctypes.POINTER(vp)]
+        L.acgpu_debug_wordhash_perfect.restype = ci
+        L.acgpu_debug_wordhash_perfect.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         L.acgpu_debug_wordhash.restype = ci
         L.acgpu_debug_wordhash.argtypes = [vp, ctypes.POINTER(u32), vp, ctypes.POINTER(u64), vp, vp, ctypes.POINTER(u32), vp,
                                            ctypes.POINTER(u32)]
@@ -158,7 +160,17 @@ def _code_only(text):
     out, i, n = [], 0, len(text)
     while i < n:
         c = text[i]
-        if c in "\"'":  # literal: copy to its closing quote
+        if c == '"' and i > 0 and text[i - 1] == "R" and not (i > 1 and (text[i - 2].isalnum() or text[i - 2] == "_")):
+            # raw string literal R"delim( ... )delim": copied whole
+            k = text.find("(", i)
+            end = text.find(")" + text[i + 1:k] + '"', k) if k >= 0 else -1
+            j = n - 1 if end < 0 else end + (k - i)
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif c == "'" and i > 0 and text[i - 1].isalnum():  # a digit separator (1'000'000), not a character literal
+            out.append(c)
+            i += 1
+        elif c in "\"'":  # literal: copy to its closing quote
             j = i + 1
             while j < n and text[j] != c:
                 j += 2 if text[j] == "\\" else 1

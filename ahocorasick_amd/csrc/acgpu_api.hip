@@ -387,7 +387,9 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
             head.d_result = nullptr;
             uint64_t n_head = 0;
             const int prc = match_all_states(a, d, &head, record_kind, d_out, 0, &n_head, stream, nullptr, nullptr, st_hot);
-            if (prc != ACGPU_OK && prc != ACGPU_E_OVERFLOW) return prc;
+            // (no room for the probe's state words: like the call itself below, the tile kernel it is -- the pool stays without a
+            // density, so a later call asks again)
+            if (prc != ACGPU_OK && prc != ACGPU_E_OVERFLOW && prc != ACGPU_E_NOMEM) return prc;
         }
         if (usable && ((aform & 2) || d.all_density >= kStatesFormDensity)) {
             const int src = match_all_states(a, d, sh, record_kind, d_out, cap, n_out, stream, prof, tk, st_hot);
@@ -1890,6 +1892,22 @@ int acgpu_debug_states(const acgpu_automaton *a, uint64_t sizes[6], uint32_t *ro
     if (mask) std::memcpy(mask, t.hy_mask.data(), t.hy_mask.size() * sizeof(uint32_t));
     if (out) std::memcpy(out, t.hy_out.data(), t.hy_out.size() * sizeof(uint32_t));
     if (ids) std::memcpy(ids, t.hy_ids.data(), t.hy_ids.size() * sizeof(uint32_t));
+    return ACGPU_OK;
+}
+
+int acgpu_debug_wordhash_perfect(const acgpu_automaton *a, uint32_t sizes[3], uint32_t *slots, uint16_t *disp, uint8_t *bp_idx,
+                                 uint8_t *bp_pages, uint16_t *bp_delta) {
+    if (!a || !sizes) return ACGPU_E_INVALID;
+    const HostTables &t = a->t;
+    if (t.mode != ACGPU_MODE_WHOLEWORD) return ACGPU_E_UNSUPPORTED;
+    sizes[0] = t.ww_ph_n;
+    sizes[1] = t.ww_ph_buckets;
+    sizes[2] = t.ww_bp_n;
+    if (slots && !t.ww_ph.empty()) std::memcpy(slots, t.ww_ph.data(), t.ww_ph.size() * sizeof(uint32_t));
+    if (disp && !t.ww_ph_disp.empty()) std::memcpy(disp, t.ww_ph_disp.data(), (size_t)t.ww_ph_buckets * sizeof(uint16_t));
+    if (bp_idx && t.ww_bp_n) std::memcpy(bp_idx, t.ww_bp_idx.data(), 256);
+    if (bp_pages && t.ww_bp_n) std::memcpy(bp_pages, t.ww_bp_pages.data(), t.ww_bp_pages.size());
+    if (bp_delta && t.ww_bp_n) std::memcpy(bp_delta, t.ww_bp_delta.data(), 128 * sizeof(uint16_t));
     return ACGPU_OK;
 }
 

@@ -29,6 +29,27 @@
  *    csrc/acgpu_states.hip: 4 bytes) that much per unit of the largest shard.
  *    A pool that cannot grow makes the call take a form that needs less, or
  *    fail with ACGPU_E_NOMEM; acgpu_free releases everything.
+ *    Worst case per shard of N units and a caller capacity of C records, by
+ *    the form a call takes (what a rank of a sharded text must be able to spare
+ *    beside its text and its output; 8 GiB over 8 ranks: N = 2^29):
+ *      AhoCorasick, tile kernel (the default)   20 C + 17 MB  (16-byte slots for
+ *        1.25 C records + the waves' reservations)       C = N/128: 0.1 GB
+ *      AhoCorasick, states form (texts with dense matches: 0.05 records per
+ *        unit or more in the pool's last call)  4 N + N/128      N = 2^29: 2.0 GB
+ *        -> without room: the tile kernel (nothing is launched before the
+ *           buffers are there), also for the probe of a pool's first call
+ *      AhoCorasick, DFA chunk scan              20 C
+ *      LongestMatch, k_longest_bits             N/8 + N/1024      (marks, exits)
+ *      LongestMatch, k_longest_follow           N/4 (+ 4 N for Map records)
+ *      LongestMatch, walk pipeline              1.25 N .. 4.25 N  (lengths,
+ *        block maxima, two bitmaps; states for Map records)
+ *        -> a pool that cannot hold a form's buffers fails the call with
+ *           ACGPU_E_NOMEM (the forms are not tried in turn)
+ *      WholeWord                                6 N + 0.2 MB      (a 12-byte slot
+ *        per two units)
+ *        -> without room: 20 C + 17 MB (scratch slices + ordering pass)
+ *      Shortest / WholeWordLongest              the AhoCorasick / WholeWord form
+ *        + 16 bytes per record of the all-matches list / per walk start
  */
 #ifndef ACGPU_H
 #define ACGPU_H
@@ -39,7 +60,7 @@
 extern "C" {
 #endif
 
-#define ACGPU_ABI_VERSION 4
+#define ACGPU_ABI_VERSION 5
 
 /* error codes */
 #define ACGPU_OK 0
@@ -254,6 +275,11 @@ int acgpu_match_device(const acgpu_automaton *a, acgpu_shard *shard, int record_
  *  - The other families (and LONGEST over a dictionary with a selective suffix filter, whose sparse form decides on the
  *    host) run inside _begin: the ticket is complete when _begin returns and _end only hands the result over.
  *
+ *  - ACGPU_MODE_ALL chooses between the tile kernel and the states form by what the pool's LAST call found (records per
+ *    unit).  A pool's first call asks the text itself -- the first 2^20 units are counted first -- only when it is
+ *    synchronous and the text has 2^23 units or more: a first call through _begin, or on a shorter text, takes the tile
+ *    kernel.  The records are the same either way; on a word list in natural text the first enqueued call is the slow one.
+ *
  * STREAM RULE.  All calls on one automaton and device share that automaton's scratch pool; stream order is what keeps
  * them apart.  While tickets are in flight, EVERY call on that automaton and device -- another _begin, a synchronous
  * acgpu_match_device, acgpu_match_u16 or acgpu_stream_feed (both use the NULL stream) -- must use the stream of the
@@ -459,6 +485,19 @@ int acgpu_debug_states(const acgpu_automaton *a, uint64_t sizes[6], uint32_t *ro
  * page 0 is all zero. */
 int acgpu_debug_wordhash(const acgpu_automaton *a, uint32_t *n_slots, uint32_t *slots, uint64_t *n_rec_words, uint32_t *recs,
                          uint8_t *fold_pgidx, uint32_t *n_pages, uint16_t *fold_pages, uint32_t *seed);
+
+/* Test hook (ACGPU_MODE_WHOLEWORD): what the position-parallel word kernel (k_ww_pp) probes in place of the two-choice table and
+ * looks units up in.  sizes = {slots of the perfect hash, its buckets, byte pages}; 0 slots / 0 pages = not built.  Arrays are
+ * copied when the pointer is non-NULL.
+ * Perfect hash ("hash and displace") over the same hashes h, g as acgpu_debug_wordhash:
+ *   bucket = (h * n_buckets) >> 32;  d = disp[bucket];
+ *   t = (g ^ (h << 7)) + d * 0x9E3779B9;  t ^= t >> 15;  t *= 0x2C1B3C6D;  t ^= t >> 13;  slot = (t * n_slots) >> 32
+ * every keyword sits in the slot its hashes name (slots: 8 uint32 each, the two-choice table's format); a run of word characters
+ * that is no keyword reads some slot and fails the comparison of tag and units.
+ * Byte pages (case-insensitive automata whose word-character table is fold-consistent): e = pages[idx[u >> 8] * 256 + (u & 255)];
+ * word character = e & 1, lower[u] = (u + delta[e >> 1]) & 0xffff (delta: 128 entries). */
+int acgpu_debug_wordhash_perfect(const acgpu_automaton *a, uint32_t sizes[3], uint32_t *slots, uint16_t *disp, uint8_t *bp_idx,
+                                 uint8_t *bp_pages, uint16_t *bp_delta);
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,7 @@ from ahocorasick_amd import _native as N
 from ahocorasick_amd import synth
 from ahocorasick_amd.strings import Automaton, utf16
 from oracle.oracle import FAM_AC, FAM_SHORTEST, Oracle
-from tests.helpers import LOWER
+from tests.helpers import LOWER, oracle_parallel
 
 pytestmark = pytest.mark.gpu
 
@@ -180,6 +180,20 @@ def test_states_form_without_room_for_the_states_falls_back_to_the_tile_kernel(w
     N.set_tunable("tile_debug", 1 << 40)  # the buffer of 4 bytes per unit "cannot be had"
     got, kname = _run(a, hay, True)
     assert kname != "k_ac_states" and got.shape == want.shape and (got == want).all()
+
+
+def test_first_calls_density_probe_without_room_falls_back_too(words):
+    """A pool's first call on a text of 2^23 units or more counts the records of its first 2^20 units through the states form
+    (all_form 0).  If the probe's buffer of 4 bytes per unit cannot be had the call is the tile kernel's, not an error."""
+    a = Automaton(N.MODE_ALL, words[:3000], True)
+    hay = synth.readme_text(14, (1 << 23) + 5, words[:3000])
+    want = oracle_parallel(Oracle(FAM_AC, words[:3000]), hay, "ac", a.info()["max_keyword_len"], cap_per_unit=2.0)
+    N.set_tunable("tile_debug", 1 << 40)
+    got, kname = _run(a, hay, True)
+    assert kname != "k_ac_states" and got.shape == want.shape and (got == want).all()
+    N.set_tunable("tile_debug", 0)
+    got, kname = _run(a, hay, True)  # (the pool kept no density from the failed probe... but the call above left one: whichever form, the records are the same)
+    assert got.shape == want.shape and (got == want).all()
 
 
 def test_states_form_two_hundred_classes_from_pages_and_ids_of_nested_keywords():

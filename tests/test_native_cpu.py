@@ -268,6 +268,146 @@ def test_wordhash_two_choice_table_holds_config5_dictionary():
     assert len(want) >= 3000 and got == want
 
 
+# ---- WholeWord: the perfect hash and the byte pages (what k_ww_pp probes and looks units up in) -----------------------------------
+
+def _perfect_tables(a):
+    sizes = (ctypes.c_uint32 * 3)()
+    f = N.lib().acgpu_debug_wordhash_perfect
+    N.check(f(a.handle, sizes, None, None, None, None, None), "sizes")
+    n_slots, n_buckets, n_pages = int(sizes[0]), int(sizes[1]), int(sizes[2])
+    slots = np.zeros(8 * max(n_slots, 1), np.uint32)
+    disp = np.zeros(max(n_buckets, 1), np.uint16)
+    idx, pages, delta = np.zeros(256, np.uint8), np.zeros(max(n_pages, 1) * 256, np.uint8), np.zeros(128, np.uint16)
+    vp = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+    N.check(f(a.handle, sizes, vp(slots), vp(disp), vp(idx), vp(pages), vp(delta)), "tables")
+    return n_slots, n_buckets, n_pages, slots.reshape(-1, 8), disp, idx, pages, delta
+
+
+def _simulate_wholeword_perfect(a, hay, cs):
+    """Test-only restatement of k_ww_pp's lookups: word character and fold of a unit from the byte pages (case-insensitive)
+    or the word table (case-sensitive), the run's two hashes, ONE slot of the perfect hash (acgpu.h: acgpu_debug_wordhash_perfect)."""
+    n_slots, n_buckets, n_pages, slots, disp, idx, pages, delta = _perfect_tables(a)
+    _, recs, _, _, seed = _wordhash_tables(a)
+    assert n_slots > 0
+    if cs:
+        word, fold = (lambda u: bool(WORD[u])), (lambda u: u)
+    else:
+        assert n_pages > 0
+        ent = lambda u: int(pages[int(idx[u >> 8]) * 256 + (u & 255)])
+        word, fold = (lambda u: bool(ent(u) & 1)), (lambda u: (u + int(delta[ent(u) >> 1])) & 0xffff)
+    out, i, n = [], 0, len(hay)
+    h_list = hay.tolist()
+    M = 0xffffffff
+    while i < n:
+        if not word(h_list[i]):
+            i += 1
+            continue
+        j = i
+        while j < n and word(h_list[j]):
+            j += 1
+        f = [fold(u) for u in h_list[i:j]]
+        packed = [f[k] | ((f[k + 1] if k + 1 < len(f) else 0) << 16) for k in range(0, len(f), 2)]
+        packed += [0] * (8 - len(packed))
+        h = g = seed
+        for d in packed:
+            h = (h * 33 + d) & M
+            g = (((g << 5) | (g >> 27)) & M) ^ d
+        h ^= h >> 16
+        h = (h * 0x85EBCA6B) & M
+        h ^= h >> 13
+        h = (h * 0xC2B2AE35) & M
+        h ^= h >> 16
+        tag = (h & 0xffffff00) | min(len(f), 255)
+        d = int(disp[(h * n_buckets) >> 32])
+        t = ((g ^ ((h << 7) & M)) + d * 0x9E3779B9) & M
+        t ^= t >> 15
+        t = (t * 0x2C1B3C6D) & M
+        t ^= t >> 13
+        e = [int(x) for x in slots[(t * n_slots) >> 32]]
+        if e[0] == tag and e[2:8] == (packed + [0] * 6)[:6]:
+            if len(f) <= 12:
+                out.append([i, j, e[1]])
+            else:
+                off = e[1] * 4
+                ln = int(recs[off + 1])
+                units = [(int(recs[off + 2 + (k >> 1)]) >> (16 * (k & 1))) & 0xffff for k in range(ln)]
+                if units == f:
+                    out.append([i, j, int(recs[off])])
+        i = j
+    return out
+
+
+def test_byte_pages_equal_the_word_table_and_the_fold_table():
+    a = Automaton(N.MODE_WHOLEWORD, ["a"], False, word_chars=WORD)
+    _, _, n_pages, _, _, idx, pages, delta = _perfect_tables(a)
+    u = np.arange(65536)
+    e = pages[idx[u >> 8].astype(np.int64) * 256 + (u & 255)].astype(np.int64)
+    assert ((e & 1) == (np.asarray(WORD) != 0)).all()
+    assert (((u + delta[e >> 1]) & 0xffff) == LOWER).all()
+    assert 0 < n_pages <= 64  # (Unicode's simple lower-casing with isLetterOrDigit: 54 pages, 79 deltas)
+    # a case-sensitive automaton, or a table that is not fold-consistent, has none
+    assert _perfect_tables(Automaton(N.MODE_WHOLEWORD, ["a"], True, word_chars=WORD))[2] == 0
+    wc = np.asarray(WORD).copy()
+    wc[ord("A")] = 0
+    assert _perfect_tables(Automaton(N.MODE_WHOLEWORD, ["b"], False, word_chars=wc))[2] == 0
+
+
+def test_perfect_hash_tables_reproduce_oracle(fixtures):
+    from oracle.oracle import FAM_WHOLEWORD
+    for fx in fixtures:
+        if fx["WW"] == "IllegalArgumentException":
+            continue
+        hay, kws = fixture_inputs(fx)
+        if max(len(k) for k in kws) > 32:
+            continue  # (the perfect hash is k_ww_pp's: keywords of at most 32 units)
+        a = Automaton(N.MODE_WHOLEWORD, kws, True, word_chars=WORD)
+        assert _simulate_wholeword_perfect(a, hay, True) == fx["WW"], fx["name"]
+    rng = np.random.default_rng(6)
+    alpha = [ord(c) for c in "abAB -_."] + [0x00E9, 0x00C9, 0x0130, 0x3002]
+    for it in range(40):
+        hay, kws = rand_case(rng, alpha, int(rng.integers(1, 60)), int(rng.choice([3, 6, 20, 32])), int(rng.integers(0, 400)))
+        kws = [k for k in kws if all(WORD[c] for c in k.tolist())] or [np.array([97], np.uint16)]
+        for cs in (True, False):
+            a = Automaton(N.MODE_WHOLEWORD, kws, cs, word_chars=WORD)
+            want = Oracle(FAM_WHOLEWORD, kws, case_sensitive=cs, lower=LOWER, word_chars=WORD).match(hay).tolist()
+            assert _simulate_wholeword_perfect(a, hay, cs) == want, (it, cs)
+
+
+def test_perfect_hash_holds_config5_dictionary_in_a_table_that_fits_the_l2_cache():
+    """Config 5's 100 k mixed-script words: 103 126 slots of 32 bytes (3.3 MB: an XCD's L2 holds it, where the two-choice table
+    has 8.4 MB), 25 000 displacements (50 KB of LDS).  Every keyword sits where its hashes say, every slot holds at most one."""
+    from ahocorasick_amd import synth
+    from oracle.oracle import FAM_WHOLEWORD
+    words = synth.mixed_script_words(1005, 100000)
+    a = Automaton(N.MODE_WHOLEWORD, words, False, word_chars=WORD)
+    n_slots, n_buckets, _, slots, _, _, _, _ = _perfect_tables(a)
+    n_kw = a.info()["n_keywords"]
+    assert int((slots[:, 0] != 0).sum()) == n_kw and n_kw < n_slots <= n_kw + n_kw // 32 + 8 and n_slots * 32 < (4 << 20)
+    assert n_buckets * 2 <= 60 * 1024 and (n_kw + 3) // 4 == n_buckets
+    rng = np.random.default_rng(9)
+    pick = rng.choice(len(words), 3000, replace=False)
+    sep = np.array([32], np.uint16)
+    toks = []
+    for i in pick:
+        toks += [np.asarray(words[int(i)], dtype=np.uint16), sep, np.asarray(words[int(i)], dtype=np.uint16)[::-1].copy(), sep]
+    hay = np.concatenate(toks)
+    got = _simulate_wholeword_perfect(a, hay, False)
+    want = Oracle(FAM_WHOLEWORD, words, case_sensitive=False, lower=LOWER, word_chars=WORD).match(hay).tolist()
+    assert len(want) >= 3000 and got == want
+
+
+def test_perfect_hash_is_left_out_where_it_cannot_be_built():
+    # more keywords than 16-bit displacements fit LDS for (4 per bucket: beyond 122 880); buckets too large to place; keywords beyond 32 units
+    N.set_tunable("ww_ph_lambda", 4096)
+    try:
+        a = Automaton(N.MODE_WHOLEWORD, ["w%d" % i for i in range(9000)], True, word_chars=WORD)
+    finally:
+        N.set_tunable("ww_ph_lambda", 0)
+    assert _perfect_tables(a)[0] == 0
+    assert _perfect_tables(Automaton(N.MODE_WHOLEWORD, ["a" * 33, "b"], True, word_chars=WORD))[0] == 0
+    assert _perfect_tables(Automaton(N.MODE_WHOLEWORD, ["a" * 32, "b"], True, word_chars=WORD))[0] > 0
+
+
 def test_wordhash_fallback_seed_tables_reproduce_oracle():
     """Tables built from a later hash seed (test hook ww_first_seed; the builder goes there by itself when a dictionary
     cannot be placed) still find exactly the oracle's matches."""
@@ -381,3 +521,14 @@ def test_compact_automaton_of_the_state_form_reproduces_the_oracle(fixtures):
             assert _simulate_states(a, hay) == want
     long_kw = [np.full(33, ord("a"), np.uint16)]
     assert _states_tables(Automaton(N.MODE_ALL, long_kw, True)) is None  # no mask bit for 33 units: no compact automaton
+
+
+def test_source_hash_ignores_comments_and_nothing_else():
+    """profiles/latest_traffic.json is keyed by a hash of the kernel sources without their comments (ahocorasick_amd/_native.py):
+    a comment edit must not ask for a new counter collection, a code edit must -- also around digit separators and raw strings."""
+    f = N._code_only
+    assert f("a /* x */ b // y\n c") == "a b c"
+    assert f("int n = 1'000'000; // c'd\nchar q = '\\''; x") == "int n = 1'000'000; char q = '\\''; x"
+    assert f('const char *s = R"ab(// not a comment )" /* nor this */)ab"; /* gone */ y') == 'const char *s = R"ab(// not a comment )" /* nor this */)ab"; y'
+    assert f('s = "a // b"; // c') == 's = "a // b";'
+    assert f("x = 1; // one") == f("x = 1; /* uno */") != f("x = 2;")
