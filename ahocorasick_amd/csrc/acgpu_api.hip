@@ -1109,7 +1109,11 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
     const bool fol_classes = t.dense && ((t.range_cls && t.n_cls == t.cls_span + 1) || fol_pages > 0);
     const uint32_t fol_hot = fol_classes ? longest_follow_hot_rows(t.n_cls, t.n_states, (uint32_t)fol_pages) : 0;
     if (bits_level < d.fol_level && !bits_form) bits_level = d.fol_level; // (what earlier calls on this pool have learnt about its texts)
-    const bool follow_form = bits_level < 2 && fol_hot > 0 && !(lform & 2) && (own_len >= (1ull << 20) || (lform & 4)) && tunables().force_kernel == 0;
+    // (Not over alphabets of up to four letters, where the walk pipeline has its root table -- 14 or 7 units decided by one lookup:
+    // config 4's dictionary with Map records 3.71 against 5.79 ms per 2^29 units, {a,c,g,t} prefix-closed 2.54 against 2.91 (Set) and
+    // 3.93 against 6.02 (Map); tools/longest_shapes.py, profiles/r06.  Tunable longest_form bit 8: there too, for A/B.)
+    const bool follow_form = bits_level < 2 && fol_hot > 0 && !(lform & 2) && (own_len >= (1ull << 20) || (lform & 4)) && tunables().force_kernel == 0 &&
+                             (t.root_b == 0 || (lform & 8));
     if (follow_form) {
         int rc;
         LongestFollowLaunch F{};

@@ -72,6 +72,9 @@ def main():
                          "shape a JVM calls (INTEGRATION.md)")
     ap.add_argument("--devices", default=None, help="--single-process: comma-separated device list (default 0..N-1; a device may "
                                                     "be named twice on a box with fewer GPUs: peer-copy transport)")
+    ap.add_argument("--tunable", action="append", default=[], metavar="NAME=VALUE",
+                    help="development: an acgpu_set_tunable knob for A/B on one box (e.g. tile_form=1: a finalize launch behind the scan); "
+                         "recorded in config.tunables")
     args = ap.parse_args()
 
     if args.config == "README":
@@ -98,6 +101,8 @@ def main():
     assert args.backend == "gloo" or local_rank < n_dev, \
         "--backend nccl (RCCL) needs one GPU per rank: %d GPUs visible, local rank %d (use --backend gloo to share a GPU)" % (n_dev, local_rank)
     torch.cuda.set_device(local_rank % n_dev if args.backend == "gloo" else local_rank)
+    for kv in args.tunable:
+        N.set_tunable(kv.split("=")[0], int(kv.split("=")[1]))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         with stdout_to_stderr():
@@ -224,6 +229,7 @@ def main():
                 "C4": "BASELINE config 4: LongestMatchSet, 50k prefix-closed keywords over {a,b} (max len 1000), 2^%d units P(a)=0.75",
                 "C5": "BASELINE config 5: WholeWordMatchMap case-insensitive, 100k mixed-script words, 2^%d units per GPU",
             }[cfg_name] % args.units_log2,
+            **({"tunables": list(args.tunable)} if args.tunable else {}),
             "keywords": len(kws), "states": info["n_states"], "classes": info["n_classes"],
             "table": ("dense u%d" % (8 * info["entry_bytes"])) if info["dense"] else "hashed",
             "lds_states": info["lds_states"], "units_per_gpu": n_units, "matches_per_gpu": n_matches_local,

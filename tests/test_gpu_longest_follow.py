@@ -147,7 +147,7 @@ def test_follow_form_shards_chains_that_never_merge_and_tickets(words):
     # kernel has to notice (every step is 3, a chain keeps its residue), and the walk pipeline answers
     kw2 = [utf16("c"), np.full(3, ord("c"), np.uint16), utf16("d")]
     a2 = Automaton(N.MODE_LONGEST, kw2, True)
-    N.set_tunable("longest_form", FOLLOW_ALWAYS | 1)  # (every letter a keyword: k_longest_bits would take this one first)
+    N.set_tunable("longest_form", FOLLOW_ALWAYS | 1 | 8)  # (1: every letter a keyword, k_longest_bits would take this one first; 8: k_longest_follow over an alphabet of up to four letters too)
     run = np.full(300000, ord("c"), np.uint16)
     got, kname, _ = _run(a2, run, False)
     want2 = Oracle(FAM_LONGEST, kw2).match(run)[:, :2]
@@ -170,5 +170,8 @@ def test_follow_form_two_letter_text_walks_that_run_three_blocks_ahead_of_their_
     hay = synth.haystack(403, n, table=synth.ALPHA_LOWER[:2])
     a = Automaton(N.MODE_LONGEST, kws, True)
     want = Oracle(FAM_LONGEST, kws).match(hay)
+    got, kname, _ = _run(a, hay, True)  # (alphabets of up to four letters take the walk pipeline's root table by default)
+    assert kname != "k_longest_follow" and got.shape == want.shape and (got == want).all()
+    N.set_tunable("longest_form", 8)  # ... k_longest_follow there too
     got, kname, _ = _run(a, hay, True)
     assert kname == "k_longest_follow" and got.shape == want.shape and (got == want).all()
