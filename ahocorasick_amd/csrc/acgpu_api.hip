@@ -493,14 +493,21 @@ int match_all(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int record_ki
         // workgroups still scan -- measured slower at every slope, 0 by default: EXPERIMENTS.md, round 6.)
         // Tunable tile_form bit 2: never (the region-local slots + k_ww_compact: A/B, tests).
         if (ww_direct && !fused_only && !(tunables().tile_form & 2) && ww_pp_serves(Tov ? *Tov : d.T, L)) {
-            const uint64_t tiles = (sh->own_end - base8 + 511) / 512, total16 = (tiles + 15) / 16;
-            const uint64_t G = std::min<uint64_t>((uint64_t)d.n_cu * ww_blocks_per_cu(), total16);
-            const uint64_t area_recs = total16 * 16 * 512 / 2 + G * 16 + 8;
+            // (tunable ww_block: workgroups of fewer waves, two to a CU when their LDS allows -- A/B)
+            const int64_t wb = tunables().ww_block;
+            const int block_ft = (wb >= 64 && wb <= 1024 && wb % 64 == 0) ? (int)wb : L.block;
+            const uint64_t wpb = (uint64_t)block_ft / 64;
+            // (two workgroups: when each needs at most half the LDS, and for the 16-unit form only -- the 32-unit form's registers allow four waves per SIMD)
+            const uint64_t per_cu = wb > 0 && t.max_len <= 16 && ww_pp_lds_total(Tov ? *Tov : d.T, L, block_ft) <= 80 * 1024 ? 2 : 1;
+            const uint64_t tiles = (sh->own_end - base8 + 511) / 512, total16 = (tiles + wpb - 1) / wpb;
+            const uint64_t G = std::min<uint64_t>((uint64_t)d.n_cu * per_cu, total16);
+            const uint64_t area_recs = total16 * wpb * 512 / 2 + G * wpb + 8;
             if (G >= 1 && G <= (uint64_t)kMaxSlices && area_recs < (1ull << 32) && (rc = d.ww_recs.ensure(area_recs * 12 + 64)) == ACGPU_OK) {
                 fused_tail = true;
                 L.d_region_recs = (int32_t *)d.ww_recs.p;
                 L.fused_tail = 1;
                 L.grid = (int)G;
+                L.block = block_ft;
                 L.ft_total16 = (uint32_t)total16;
                 const int64_t ramp = tunables().ww_ramp_pm;
                 L.ft_ramp_pm = (uint32_t)(ramp < 0 ? 0 : std::min<int64_t>(ramp, 1000));
@@ -1773,6 +1780,7 @@ int64_t acgpu_set_tunable(const char *name, int64_t value) {
     else if (!std::strcmp(name, "ww_no_ph")) slot = &t.ww_no_ph;
     else if (!std::strcmp(name, "ww_no_byte_pages")) slot = &t.ww_no_byte_pages;
     else if (!std::strcmp(name, "ww_ramp_pm")) slot = &t.ww_ramp_pm;
+    else if (!std::strcmp(name, "ww_block")) slot = &t.ww_block;
     else if (!std::strcmp(name, "ww_ph_lambda")) slot = &t.ww_ph_lambda;
     else if (!std::strcmp(name, "rdense_budget_bytes")) slot = &t.rdense_budget_bytes;
     else if (!std::strcmp(name, "filter_max_bytes")) slot = &t.filter_max_bytes;

@@ -70,10 +70,11 @@ ACGPU_HD inline uint32_t ww_ph_slot(uint32_t g, uint32_t h, uint32_t d, uint32_t
 // product -- the copies are bound by memory bandwidth and fastest when all workgroups copy together).  Tiles (512 units) in front of
 // workgroup b of G: 16 * floor(total16 * F(b / G)), F(x) = (1 - r/2) x + (r/2) x^2, r = ramp_pm / 1000 (the spans of the
 // first and the last workgroup differ by r of the average); every wave of workgroup b takes (before(b + 1) - before(b)) / 16.
-ACGPU_HD inline uint32_t ww_ft_tiles_before(uint32_t b, uint32_t G, uint32_t total16, uint32_t ramp_pm) {
+ACGPU_HD inline uint32_t ww_ft_tiles_before(uint32_t b, uint32_t G, uint32_t total16, uint32_t ramp_pm, uint32_t waves = 16u) {
+    // (total16: the shard's tiles / waves of a workgroup, rounded up -- 16 waves unless the launch says otherwise)
     const uint64_t num = (uint64_t)b * ((uint64_t)(2000u - ramp_pm) * G + (uint64_t)ramp_pm * b); // <= 2000 G^2
     const uint64_t den = 2000ull * G * G;
-    return b >= G ? 16u * total16 : 16u * (uint32_t)(((uint64_t)total16 * num) / den);
+    return b >= G ? waves * total16 : waves * (uint32_t)(((uint64_t)total16 * num) / den);
 }
 // two bit positions of the Bloom filter in front of the table (the filter sits in LDS)
 ACGPU_HD inline uint32_t ww_bloom_bit1(uint32_t h, uint32_t mask) { return (h >> 7) & mask; }
@@ -366,6 +367,7 @@ struct Tunables {
     std::atomic<int64_t> filter_max_bytes{ACGPU_FILTER_MAX_BYTES};  // the filter rows must fit LDS next to the candidate queues
     std::atomic<int64_t> no_short_keywords{0}; // builder: 1 = the filter's K stays at most the shortest keyword (A/B)
     std::atomic<int64_t> no_merged_ranges{0}; // builder: 1 = mixed-case dictionaries keep the 8-byte-row scalar filter (A/B)
+    std::atomic<int64_t> ww_block{0};         // k_ww_pp, fused tail: threads per workgroup (0 = 1024; a multiple of 64 -- two workgroups share a CU when their LDS allows: A/B)
     std::atomic<int64_t> ww_ramp_pm{-1};      // k_ww_pp, fused tail: the spans' ramp in thousandths of the average span (-1 = the default)
     std::atomic<int64_t> ww_no_byte_pages{0}; // WHOLEWORD builder: 1 = no combined word-bit / fold pages (A/B, tests)
     std::atomic<int64_t> ww_no_ph{0};         // WHOLEWORD builder: 1 = no perfect hash (the two-choice table behind the Bloom filter: A/B, tests)

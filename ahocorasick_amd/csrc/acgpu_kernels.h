@@ -360,6 +360,7 @@ uint32_t ww_fold_pages_in_lds(const DevTables &t); // 0: the fold table is not s
 size_t ww_lds_bytes(int block_threads, const DevTables &t);
 int ww_blocks_per_cu();
 hipError_t launch_ww_tile(const DevTables &t, const TileLaunch &l, hipStream_t stream, const char **kernel_name);
+size_t ww_pp_lds_total(const DevTables &t, const TileLaunch &l, int block_threads); // k_ww_pp's LDS, static + dynamic, for a workgroup of that size
 bool ww_pp_serves(const DevTables &t, const TileLaunch &l); // launch_ww_tile would take k_ww_pp (the kernel that has the fused tail)
 hipError_t launch_ww_sequential(const DevTables &t, const uint16_t *d_hay, uint32_t len, void *d_out, uint64_t cap,
                                 int record_kind, unsigned long long *d_counter, hipStream_t stream);

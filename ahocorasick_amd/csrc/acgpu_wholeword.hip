@@ -735,7 +735,11 @@ __device__ __forceinline__ void pp_consume(TileCtx &c, const PpFlight<NW> &fl, c
         if (m) {
             typedef int32_t v3i __attribute__((ext_vector_type(3)));
             const v3i rec = {(int32_t)fl.s, (int32_t)(fl.s + fl.r), (int32_t)id};
+#ifdef ACGPU_WW_PLAIN_RECS
+            *reinterpret_cast<v3i *>(base + (size_t)prefix * 3) = rec;
+#else
             __builtin_nontemporal_store(rec, reinterpret_cast<v3i *>(base + (size_t)prefix * 3));
+#endif
         }
     } else {
         const SlotRange sr = reserve_slots(c, total);
@@ -794,7 +798,8 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
     const uint32_t lane = lane_id();
     const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const uint32_t wg = FT ? __builtin_amdgcn_readfirstlane(wg_words[0]) : blockIdx.x; // (fused tail: workgroups are numbered by their start)
-    const uint32_t wave_global = wg * (kTileBlock / kWave) + wave_in_block;
+    const uint32_t n_waves_wg = blockDim.x / kWave; // (16; the fused tail's launch may say otherwise: tunable ww_block)
+    const uint32_t wave_global = wg * n_waves_wg + wave_in_block;
     unsigned char *mine = smem + bloom_bytes + wave_in_block * kPpWaveBytes;
     uint16_t *ring = reinterpret_cast<uint16_t *>(mine);
     unsigned char *bits = mine + kPpRingUnits * 2;
@@ -810,8 +815,8 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
     uint32_t first_region = wave_global * L.regions_per_wave, tile0, span_begin, span_end, boundary;
     bool has_work;
     if (FT) {
-        const uint32_t tb = ww_ft_tiles_before(wg, gridDim.x, L.ft_total16, L.ft_ramp_pm);
-        const uint32_t q = (ww_ft_tiles_before(wg + 1u, gridDim.x, L.ft_total16, L.ft_ramp_pm) - tb) / (kTileBlock / kWave);
+        const uint32_t tb = ww_ft_tiles_before(wg, gridDim.x, L.ft_total16, L.ft_ramp_pm, n_waves_wg);
+        const uint32_t q = (ww_ft_tiles_before(wg + 1u, gridDim.x, L.ft_total16, L.ft_ramp_pm, n_waves_wg) - tb) / n_waves_wg;
         tile0 = base8 + (tb + wave_in_block * q) * kTileUnits;
         has_work = q != 0u && tile0 < L.own_end;
         span_begin = max(L.own_begin, tile0);
@@ -1055,7 +1060,7 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
         // The fused tail (see acgpu_tile_common.h and k_ac_tile): the wave's records lie in its own area, in the reference's
         // order; they go behind those of the workgroups with lower numbers and of the workgroup's waves before this one.
         // A wave copies what it wrote itself: nothing of another wave's is read but sixteen counts in LDS.
-        constexpr uint32_t kWaves = kTileBlock / kWave;
+        const uint32_t kWaves = n_waves_wg;
         const uint32_t cnt = c.rank_base;
 #ifdef ACGPU_TIMING
         const unsigned long long ft_t_scan = __builtin_amdgcn_s_memtime(); // (one clock for the whole chip)
@@ -1065,7 +1070,7 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
         __syncthreads();
         const uint32_t wv = lane < kWaves ? wg_words[2 + lane] : 0u;
         const uint32_t wv_incl = wave_inclusive_scan_dpp(wv);
-        const uint32_t total_wg = __builtin_amdgcn_readlane(wv_incl, kWaves - 1);
+        const uint32_t total_wg = __builtin_amdgcn_readlane(wv_incl, kWave - 1); // (lanes beyond the workgroup's waves hold 0)
         const uint32_t before_me = __builtin_amdgcn_readlane(wv_incl - wv, wave_in_block);
         if (threadIdx.x == 0) ft_publish(L, wg, total_wg);
         // the first records of the area are asked for before the wait for the lower numbers: they are there when it ends.  Two
@@ -1080,7 +1085,11 @@ __global__ __launch_bounds__(kTileBlock, kWwBlocksPerCu * (kTileBlock / 256)) vo
             for (uint32_t q = 0; q < kPer; ++q) {
                 const uint32_t k = k0 + q * kWave + lane;
                 r[q] = v3i{0, 0, 0};
+#ifdef ACGPU_WW_PLAIN_RECS
+                if (k < cnt) r[q] = *reinterpret_cast<const v3i *>(src + (size_t)k * 3);
+#else
                 if (k < cnt) r[q] = __builtin_nontemporal_load(reinterpret_cast<const v3i *>(src + (size_t)k * 3));
+#endif
             }
         };
         load_set(ra, 0);
@@ -1167,11 +1176,16 @@ __global__ void k_ww_sequential(DevTables T, const uint16_t *hay, uint32_t len, 
 // to the Bloom filter (tile_debug bit 268435456 keeps k_ww_tile: A/B; bit 256, the trie-walk verification, exists only there)
 // the byte pages serve the scan they were built for (case-insensitive, the automaton's own word bits)
 static bool ww_pp_byte_pages(const DevTables &t) { return !t.cs && t.ww_bp_n != 0 && t.ww_bp_n <= kBytePagesMax && t.wbits == t.ww_bp_wbits; }
+static size_t ww_pp_fixed_lds(const DevTables &t) { // the kernel's static LDS
+    const int fold = t.cs ? 0 : (ww_pp_byte_pages(t) ? 3 : ww_fold_pages_in_lds(t) ? 1 : 2);
+    return (fold == 3 ? 16 + 256 + 16 + kBytePagesMax * 256 + 256 : fold == 1 ? 8192 + 256 + kFoldPagesMax * 512 + 32 : 8192 + 64) + kFtWords * 4;
+}
+size_t ww_pp_lds_total(const DevTables &t, const TileLaunch &l, int block_threads) {
+    return ww_pp_lds_bytes(block_threads, t, ww_pp_perfect(t, l)) + ww_pp_fixed_lds(t);
+}
 static bool ww_pp_usable(const DevTables &t, const TileLaunch &l) {
     const int fold = t.cs ? 0 : (ww_pp_byte_pages(t) ? 3 : ww_fold_pages_in_lds(t) ? 1 : 2);
-    const size_t fixed = fold == 3 ? 16 + 256 + 8 + kBytePagesMax * 256 + 256 : 8192 + 256 + kFoldPagesMax * 512 + 32; // the kernel's static LDS
-    return fold != 2 && t.max_len <= kPpMaxLen && !(l.debug & (256u | 268435456u)) &&
-           ww_pp_lds_bytes(l.block, t, ww_pp_perfect(t, l)) + fixed <= 160 * 1024;
+    return fold != 2 && t.max_len <= kPpMaxLen && !(l.debug & (256u | 268435456u)) && ww_pp_lds_total(t, l, l.block) <= 160 * 1024;
 }
 
 bool ww_pp_serves(const DevTables &t, const TileLaunch &l) { return ww_pp_usable(t, l); }

@@ -204,7 +204,10 @@ def main():
         # WholeWord: the scan leaves region-local records; they are in the reference's order only when k_ww_compact has run, so the
         # fraction is taken over scan + ordering pass, as for config 4 (the scan kernel alone is reported beside it)
         kernel_ms = float(np.mean(scan_ms)) + float(np.mean(fin_ms))
-        kernel_what = matcher.last_kernel + " + k_scan_* + k_ww_compact (whole pipeline)"
+        kernel_what = matcher.last_kernel + (" + k_scan_* + k_ww_compact (whole pipeline)" if float(np.mean(fin_ms)) > 0 else
+                                             " (one kernel: the scan puts its records in order itself -- the fused tail, csrc/acgpu_wholeword.hip)")
+    if cfg_name in ("C2", "C3") and float(np.mean(fin_ms)) == 0.0 and matcher.last_kernel.startswith("k_ac_tile"):
+        kernel_what = matcher.last_kernel + " (one kernel: scan + ordering of the records -- the fused tail, csrc/acgpu_tile.hip)"
     alg_bytes = 2 * n_units + rec_bytes * n_matches_local  # per launch of the dominant kernel (one rank's shard)
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
 
@@ -269,6 +272,23 @@ def main():
     if N.lib().acgpu_stream_probe(matcher.own_ptr(), n_units * 2, cur, 7, 0, ctypes.byref(ms)) == N.OK and ms.value > 0:
         out["roofline"]["kernel_pattern_read_gbps"] = round(n_units * 2 / (ms.value * 1e-3) / 1e9, 1)
         out["roofline"]["kernel_pattern_what"] = "k_stream_probe: the tile kernels' own pattern as a pure read (one span per wave, 64 B per lane and tile)"
+
+    # The same steps with the ordering of the records in launches of their own behind the scan (tile_form 3: what rounds 2-5
+    # timed), a few of them, outside the timed region: the scan kernel ALONE against the roofline, for comparison with those
+    # rounds' figures -- `frac` above is of the whole call, which is one kernel now.
+    if not multi and cfg_name in ("C2", "C3", "C5") and float(np.mean(fin_ms)) == 0.0 and not any(t.startswith("tile_form") for t in args.tunable):
+        N.set_tunable("tile_form", 3)
+        sep = []
+        for _ in range(7):
+            sep.append(step(profile=True))
+        sep.append(matcher.finish())
+        N.set_tunable("tile_form", 0)
+        sep = [r for r in sep if r is not None][2:]
+        s_ms, f_ms = float(np.mean([r["scan_ms"] for r in sep])), float(np.mean([r["finalize_ms"] for r in sep]))
+        out["roofline"]["separate_launches"] = {
+            "scan_ms": round(s_ms, 4), "finalize_ms": round(f_ms, 4), "frac_scan_alone": round(alg_bytes / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+            "frac_scan_and_finalize": round(alg_bytes / ((s_ms + f_ms) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+            "what": "tunable tile_form = 3: the scan kernel, then the ordering of its records in launches of their own (the form of rounds 2-5)"}
 
     # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (counters cannot be read from inside
     # this process); the committed measurement is attached when it is for THIS configuration, this size and these kernel

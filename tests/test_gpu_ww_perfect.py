@@ -14,7 +14,7 @@ from tests.helpers import LOWER, WORD, oracle_parallel
 pytestmark = pytest.mark.gpu
 
 KNOBS = [("force_kernel", 0), ("tile_debug", 0), ("ww_no_ph", 0), ("ww_ph_lambda", 0), ("ww_first_seed", 0), ("region_units", 0), ("tile_form", 0),
-         ("ww_ramp_pm", -1), ("ww_no_byte_pages", 0)]
+         ("ww_ramp_pm", -1), ("ww_no_byte_pages", 0), ("ww_block", 0)]
 
 
 @pytest.fixture(autouse=True)
@@ -164,6 +164,11 @@ def test_fused_tail_of_the_word_kernel_in_every_form():
             assert (d_out[:n_out].cpu().numpy() == (want if with_ids else want[:, :2])).all(), (ramp, with_ids)
             assert (d_out[n_out:].cpu().numpy() == -7).all()
     N.set_tunable("ww_ramp_pm", -1)
+    for block in (64, 640, 896):  # workgroups of 1, 10 and 14 waves (the spans are dealt by waves per workgroup)
+        N.set_tunable("ww_block", block)
+        d_out, n_out, rc, _ = run(a, hay.size, True, len(want) + 50)
+        assert rc == N.OK and n_out == len(want) and (d_out[:n_out].cpu().numpy() == want).all(), block
+    N.set_tunable("ww_block", 0)
     N.set_tunable("tile_form", 2)
     d_out, n_out, rc, prof = run(a, hay.size, True, len(want) + 50)
     assert rc == N.OK and n_out == len(want) and prof["finalize_ms"] > 0.0 and (d_out[:n_out].cpu().numpy() == want).all()

@@ -1,12 +1,17 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): the bench lines and rocprofv3 evidence that profiles/<round>/ keeps.
-# usage: bash tools/collect_profiles.sh <out-dir under gpurun_out/> <round dir under profiles/> [<file prefix in it>]
+# usage: [PART=A|B] bash tools/collect_profiles.sh <out-dir under gpurun_out/> <round dir under profiles/> [<file prefix in it>]
 # (the last two only name, inside latest_traffic.json, the file tools/stash_profiles.sh will copy the traffic summary to)
+# PART: a gpurun call lasts 20 minutes at most -- A = bench lines, kernel statistics, counters; B = the tools' tables and the
+# bench lines once more with the traffic attached (needs A's latest_traffic.json, which travels in gpurun_out/ only: B copies
+# profiles/latest_traffic.json from where the caller has put A's); unset: everything in one call.
 set -u
 OUT=gpurun_out/${1:-final}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
+PART=${PART:-all}
+if [ "$PART" != B ]; then
 python3 bench.py --steps 20 --warmup 3 > "$OUT/bench_c2.json" 2> "$OUT/bench_c2.err"
 python3 bench.py --config C4 --steps 10 --warmup 2 > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err"
 python3 bench.py --config C5 --steps 20 --warmup 3 > "$OUT/bench_c5.json" 2> "$OUT/bench_c5.err"
@@ -36,6 +41,8 @@ for c in C2 C4 C5; do
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_$c" -- python3 tools/kbench.py --rounds 1 --config $c $extra --variants '{"k":{}}' > "$OUT/pmc_write_$c.log" 2>&1
 done
 python3 tools/pmc_traffic_all.py "$OUT" --c2-calibrated "$OUT/pmc_traffic.json" --latest "$OUT/latest_traffic.json" --tag "profiles/${2:-rNN}/${3:-${1:-final}}_pmc_traffic_all.json" > "$OUT/pmc_traffic_all.json" 2> "$OUT/pmc_traffic_all.err"
+fi
+if [ "$PART" = A ]; then cat "$OUT/bench_c2.json"; exit 0; fi
 # round 4: the multi-device entries through ONE host process (a one-GPU box: RCCL over a world of one; peer copies over the
 # device named twice), the reference's own published workload, the CU reserve, the chunked entry
 python3 bench.py --gpus 1 --single-process --config C3 --steps 20 --warmup 3 > "$OUT/bench_c3_single_process_rccl.json" 2> "$OUT/bench_c3_sp.err"
@@ -54,7 +61,7 @@ python3 tools/readme_shapes.py 2>&1 | grep -v amdgpu.ids > "$OUT/readme_shapes.t
 python3 tools/map_flavours.py 2>&1 | grep -v amdgpu.ids > "$OUT/map_flavours.txt"
 # the three bench lines once more with this collection's traffic attached (bench.py attaches profiles/latest_traffic.json only
 # when it was measured on the sources it runs; the copy of the repository on this box is scratch)
-cp "$OUT/latest_traffic.json" profiles/latest_traffic.json
+[ -f "$OUT/latest_traffic.json" ] && cp "$OUT/latest_traffic.json" profiles/latest_traffic.json
 python3 bench.py --steps 20 --warmup 3 > "$OUT/bench_c2.json" 2> "$OUT/bench_c2.err"
 python3 bench.py --config C4 --steps 10 --warmup 2 > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err"
 python3 bench.py --config C5 --steps 20 --warmup 3 > "$OUT/bench_c5.json" 2> "$OUT/bench_c5.err"
