@@ -32,7 +32,7 @@ ALPHABETS = [
     [ord(c) for c in "abcdefikABCDEFIK 0129-"] + [0x0130, 0x212A],                           # phrases: merged stretches, fold exceptions
 ]
 DEFAULTS = {"chunk_units": 0, "lds_table_bytes": 127 * 1024, "force_sparse": 0, "force_kernel": 0, "region_units": 0,
-            "rdense_budget_bytes": 256 << 20, "tile_debug": 0, "longest_form": 0, "all_form": 0}
+            "rdense_budget_bytes": 256 << 20, "tile_debug": 0, "longest_form": 0, "all_form": 0, "tile_form": 0, "ww_block": 0, "ww_ramp_pm": -1}
 
 
 def dev_match(a, d_hay, n, cap, with_ids=True, **kw):
@@ -94,7 +94,13 @@ def one_case(rng, it):
     if fam in (0, 3) and rng.integers(0, 2):
         knobs["all_form"] = int(rng.choice([6, 6, 4, 1]))  # k_ac_states for short texts too, whatever / only by what the pool's last call found / never
     if fam == 1 and rng.integers(0, 2):
-        knobs["longest_form"] = int(rng.choice([4, 4, 5, 6]))  # k_longest_bits / k_longest_follow for short texts too (5, 6: one of them never)
+        knobs["longest_form"] = int(rng.choice([4, 4, 5, 6, 12]))  # k_longest_bits / k_longest_follow for short texts too (5, 6: one of them never; 12: follow over small alphabets too)
+    if rng.integers(0, 3) == 0:
+        knobs["tile_form"] = int(rng.integers(1, 4))  # the ordering of the records in launches of their own (k_ac_tile / k_ww_pp / both) instead of the fused tails
+    if fam == 2 and rng.integers(0, 3) == 0:
+        knobs["ww_block"] = int(rng.choice([64, 320, 640, 896]))  # k_ww_pp's fused tail with workgroups of other sizes
+    if fam == 2 and rng.integers(0, 3) == 0:
+        knobs["ww_ramp_pm"] = int(rng.choice([0, 50, 400, 1000]))  # ... and spans that grow with the workgroup's number
     for k, v in knobs.items():
         N.set_tunable(k, v)
     mode = [N.MODE_ALL, N.MODE_LONGEST, N.MODE_WHOLEWORD, N.MODE_SHORTEST, N.MODE_WWLONGEST][fam]
@@ -114,10 +120,16 @@ def one_case(rng, it):
             wc[ord("A")] = 1
     no_pages = int(rng.integers(0, 4) == 0)  # builder knob: class tables in global memory instead of LDS pages
     N.set_tunable("no_class_pages", no_pages)
+    # builder knobs of the word kernel: no perfect hash (the two-choice table behind the Bloom filter), other bucket sizes, no byte pages
+    ww_build = {"ww_no_ph": int(rng.integers(0, 4) == 0), "ww_ph_lambda": int(rng.choice([0, 0, 1, 6, 300])), "ww_no_byte_pages": int(rng.integers(0, 3) == 0)}
+    for k, v in ww_build.items():
+        N.set_tunable(k, v)
     try:
         a = Automaton(mode, kws, cs, word_chars=wc)
     finally:
         N.set_tunable("no_class_pages", 0)
+        for k in ww_build:
+            N.set_tunable(k, 0)
     orc = Oracle(ofam, kws, case_sensitive=cs, lower=LOWER, word_chars=wc, map_flavour=(fam == 4 and with_ids))
     want = orc.match(hay)
     if fam in (2, 4) and n and rng.integers(0, 3) == 0:
