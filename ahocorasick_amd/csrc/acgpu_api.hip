@@ -112,6 +112,8 @@ int ensure_device(acgpu_automaton *a, DeviceState **out, int lane) {
     if (t.root_b && (rc = upload(*d, t.root_tab, &T.root_tab))) return rc;
     T.bits_tab = nullptr; T.bits_rk = t.bits_rk;
     if (t.bits_rk && (rc = upload(*d, t.bits_tab, &T.bits_tab))) return rc;
+    T.bits_idkeys = nullptr; T.bits_idmask = t.bits_idmask;
+    if (t.bits_rk && !t.bits_idkeys.empty() && (rc = upload(*d, t.bits_idkeys, &T.bits_idkeys))) return rc;
     T.hy_dense = T.hy_nodes = T.hy_mask = T.hy_out = T.hy_ids = nullptr;
     T.hy_n_dense = t.hy_n_dense; T.hy_n_states = t.hy_n_states;
     if (t.hy_n_states) {
@@ -1019,14 +1021,15 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
         if (src != ACGPU_E_UNSUPPORTED) return src;
         sh->chain_exit = (int64_t)std::max<uint64_t>(entry, sh->own_end); // dense in matches after all: the walk
     }
-    // Set records over a two-letter alphabet in which every letter is a keyword: the text as one bit per unit, the chain's own
-    // positions only (k_longest_bits, acgpu_longest_bits.hip) -- no length array, no synchronisation pass.  The kernel checks
+    // A two-letter alphabet in which every letter is a keyword: the text as one bit per unit, the chain's own positions only
+    // (k_longest_bits, acgpu_longest_bits.hip) -- no length array, no synchronisation pass; Map records look their keyword ids up
+    // by the matched text's own bits when they are written (keywords of up to 32 units; the rare longer ones by a walk).  The kernel checks
     // its own result (every segment's exit against the next one's entry) and raises the bail flag -- also for a unit outside
     // the alphabet --: the call is then redone right here, or in acgpu_match_device_end: once more with a run-up of a whole
     // segment (bits_level 1), then by the walk pipeline below (bits_level 2).
     // Tunable longest_form, bits: 1 = never, 4 = also for short texts (tests).
     const int64_t lform = tunables().longest_form;
-    const bool bits_form = bits_level < 2 && record_kind == ACGPU_REC_SET && d.T.bits_rk != 0 && !(lform & 1) &&
+    const bool bits_form = bits_level < 2 && (record_kind == ACGPU_REC_SET || d.T.bits_idkeys != nullptr) && d.T.bits_rk != 0 && !(lform & 1) &&
                            (own_len >= (1ull << 21) || (lform & 4)) && tunables().force_kernel == 0;
     if (bits_form) {
         int rc;
@@ -1059,6 +1062,11 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
         Bl.d_next = (uint32_t *)(Bl.d_blk + n_blk);
         Bl.d_marks = (uint32_t *)d.chainbits.p;
         Bl.d_xout = Bl.d_marks + (size_t)Bl.n_regions * (region_units / 32);
+        Bl.d_text = nullptr;
+        if (record_kind == ACGPU_REC_MAP) { // the regions' text bits, parked for the keyword ids (acgpu_longest_bits.hip)
+            if ((rc = d.lenbuf.ensure((size_t)Bl.n_regions * longest_bits_region_text_bytes() + 64))) return rc;
+            Bl.d_text = (uint32_t *)d.lenbuf.p;
+        }
         Bl.d_pred = (uint32_t *)d.blockmax.p;
         Bl.d_true = Bl.d_pred + Bl.n_regions;
         Bl.grid = (int)std::min<uint64_t>((uint64_t)d.n_cu, (Bl.n_regions + 15) / 16);
@@ -1116,9 +1124,9 @@ int match_longest(acgpu_automaton *a, DeviceState &d, acgpu_shard *sh, int recor
     const bool fol_classes = t.dense && ((t.range_cls && t.n_cls == t.cls_span + 1) || fol_pages > 0);
     const uint32_t fol_hot = fol_classes ? longest_follow_hot_rows(t.n_cls, t.n_states, (uint32_t)fol_pages) : 0;
     if (bits_level < d.fol_level && !bits_form) bits_level = d.fol_level; // (what earlier calls on this pool have learnt about its texts)
-    // (Not over alphabets of up to four letters, where the walk pipeline has its root table -- 14 or 7 units decided by one lookup:
-    // config 4's dictionary with Map records 3.71 against 5.79 ms per 2^29 units, {a,c,g,t} prefix-closed 2.54 against 2.91 (Set) and
-    // 3.93 against 6.02 (Map); tools/longest_shapes.py, profiles/r06.  Tunable longest_form bit 8: there too, for A/B.)
+    // (Not where the walk pipeline has its root table -- dictionaries over up to four letters whose first 14 or 7 units one lookup
+    // decides: config 4's dictionary with Map records 3.71 against 5.79 ms per 2^29 units, tools/longest_shapes.py.  Tunable
+    // longest_form bit 8: there too, for A/B.)
     const bool follow_form = bits_level < 2 && fol_hot > 0 && !(lform & 2) && (own_len >= (1ull << 20) || (lform & 4)) && tunables().force_kernel == 0 &&
                              (t.root_b == 0 || (lform & 8));
     if (follow_form) {

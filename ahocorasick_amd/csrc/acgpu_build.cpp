@@ -744,6 +744,34 @@ int build_tables(int mode, const uint16_t *kw_units, const uint64_t *kw_off, uin
             }
             E.resize((size_t)kBitsTabEntries * 4, 0);
             t.bits_rk = RK;
+            // Map records: keyword ids by the keyword's own bits (HostTables::bits_idkeys), keywords of up to 32 units
+            {
+                struct At { uint32_t node, len, bits; };
+                std::vector<At> stack{{0u, 0u, 0u}};
+                std::vector<std::pair<uint64_t, uint32_t>> found;
+                while (!stack.empty()) {
+                    const At a = stack.back();
+                    stack.pop_back();
+                    if (a.len == 32) continue;
+                    for (uint32_t c = 0; c < 2; c++) {
+                        const uint32_t e = trie_edge(a.node, c);
+                        if (!e) continue;
+                        const At b{e & 0x7fffffffu, a.len + 1, a.bits | (c << a.len)};
+                        if (e >> 31) found.push_back({((uint64_t)b.len << 32) | b.bits, t.term_id[b.node]});
+                        stack.push_back(b);
+                    }
+                }
+                uint64_t capk = 16;
+                while (capk < 2 * (uint64_t)found.size() + 2) capk <<= 1;
+                t.bits_idkeys.assign(2 * capk, kEmptyKey);
+                t.bits_idmask = (uint32_t)(capk - 1);
+                for (const auto &kv : found) {
+                    uint32_t slot = bits_id_hash(kv.first) & t.bits_idmask;
+                    while (t.bits_idkeys[2 * (size_t)slot] != kEmptyKey) slot = (slot + 1) & t.bits_idmask;
+                    t.bits_idkeys[2 * (size_t)slot] = kv.first;
+                    t.bits_idkeys[2 * (size_t)slot + 1] = kv.second;
+                }
+            }
         }
     }
 

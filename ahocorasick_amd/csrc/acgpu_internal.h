@@ -130,6 +130,12 @@ constexpr uint32_t kHyDenseCountShift = 24;   // hy_dense: bits 24..29 = how man
 constexpr uint32_t kHyNodeCountShift = 23;    // hy_nodes word 0 (the fail state's h-id in bits 0..22): 3 bits per edge, the same number ...
 constexpr uint32_t kHyNodeCountMany = 7u;     // ... or this: seven and more (hy_mask says how many)
 constexpr uint32_t kBitsAlive = 1u << 24;
+ACGPU_HD inline uint32_t bits_id_hash(uint64_t key) { // (key = length << 32 | bits: see HostTables::bits_idkeys)
+    key ^= key >> 29;
+    key *= 0xBF58476D1CE4E5B9ull;
+    key ^= key >> 32;
+    return (uint32_t)key;
+}
 constexpr uint32_t kBitsLeaf = 0, kBitsJunction = 1, kBitsCont = 2, kBitsDeep = 3;
 
 // Host-side automaton tables.  State numbering: root = 0; states WITHOUT any output (own or inherited
@@ -173,6 +179,11 @@ struct HostTables {
     // (acgpu_build.cpp 6c): kBitsTabEntries entries of four words; bits_rk = 0: none
     std::vector<uint32_t> bits_tab;
     uint32_t bits_rk = 0;
+    // ... and, for Map records, the keyword id of every keyword of at most 32 units by its text: key = length << 32 | the
+    // keyword as bits (unit i at bit i), open addressing (bits_id_hash), at most half full.  Longer keywords: the kernel walks
+    // the table in global memory for their node.
+    std::vector<uint64_t> bits_idkeys; // two words per slot: {key, keyword id} -- one 16-byte gather answers a probe
+    uint32_t bits_idmask = 0;
     // ALL / SHORTEST: the automaton in the form k_ac_states walks (acgpu_build.cpp 6d; hy_n_states = 0: none).  States are numbered
     // anew ("h-ids", 23 bits): the DENSE group first -- the root, depth 1 and 2, every state with more than three children -- in
     // BFS order, each with a row of n_cls resolved transitions (fail links followed at build time); then the COMPACT group, one
@@ -346,6 +357,8 @@ struct DevTables {
     uint32_t root_b, root_rk;
     const uint32_t *bits_tab; // LONGEST: see HostTables::bits_tab (nullptr: none)
     uint32_t bits_rk;
+    const uint64_t *bits_idkeys; // HostTables::bits_idkeys (nullptr: none)
+    uint32_t bits_idmask;
     const uint32_t *hy_dense, *hy_nodes, *hy_mask, *hy_out, *hy_ids; // see HostTables::hy_dense (hy_n_states = 0: none)
     uint32_t hy_n_dense, hy_n_states;
 };

@@ -256,6 +256,7 @@ struct LongestBitsLaunch {
     unsigned long long *d_blk;
     uint32_t *d_next;            // the next region to hand out (zeroed by the caller)
     uint32_t *d_marks, *d_xout;  // per region: its marks (2048 words) and its 64 segment exits, between its walk and its records
+    uint32_t *d_text;            // Map records: per region its text bits (longest_bits_region_text_bytes()); nullptr: Set records
     uint32_t *d_pred, *d_true;   // per region: the entry it assumed, the exit it found
     int grid;
     uint32_t debug;              // ACGPU_ABLATION builds: timing experiments (results are wrong)
@@ -263,6 +264,7 @@ struct LongestBitsLaunch {
 uint32_t longest_bits_region_units();
 uint32_t longest_bits_seg_units();
 size_t longest_bits_region_scratch_bytes(); // d_marks + d_xout, per region
+size_t longest_bits_region_text_bytes();    // d_text, per region
 // k_longest_bits, then k_longest_bits_finish: the seams between the regions checked, {count, bail flag, exit} to the pinned host
 // slot and to d_result (may be nullptr), the call's state words (d_exit, d_agg, d_blk, d_next: one allocation) zeroed for the next call
 hipError_t launch_longest_bits(const DevTables &t, const LongestBitsLaunch &l, unsigned long long *h_slot_dev, acgpu_device_result *d_result,

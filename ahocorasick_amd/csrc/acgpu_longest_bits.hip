@@ -46,6 +46,7 @@ constexpr uint32_t kBitsSegs = 64;
 constexpr uint32_t kBitsRegionUnits = kBitsSegs * kBitsSegUnits;            // 65536 positions per wave and round
 constexpr uint32_t kBitsWaveWords = (kBitsSegs + 1) * kBitsStride + 1;      // segments -1 .. 63, and "segment 64, word 0"
 constexpr uint32_t kBitsRegionWords = kBitsRegionUnits / 32u;                // a region's marks: 2048 words
+constexpr uint32_t kBitsTextWords = kBitsRegionWords + 8u;                   // MAP: a region's parked text, the words behind it, padding to 32 bytes
 constexpr unsigned long long kBitsPub = 1ull << 62, kBitsCount = (1ull << 40) - 1ull; // LongestBitsLaunch::d_agg / d_blk
 constexpr uint32_t kBitsTileUnits = 2048;                                   // 64 lanes x 32 units: one word per lane
 constexpr uint32_t kBitsTextMax = 33u * 32u;    // a 32-bit window may begin below this segment-relative position
@@ -232,6 +233,10 @@ __device__ unsigned long long g_bits_tail[2]; // the last region of a wave: wait
 #else
 #define BITS_MARK(i)
 #endif
+// MAP: {start, end, keyword id} records.  The region's text bits are parked in memory beside its marks (they are overwritten by
+// the marks in LDS); when the records are written, one region later, a record's keyword is its own bits in that text: one
+// lookup of (length, bits) in HostTables::bits_idkeys per record (keywords beyond 32 units: a walk through the table in memory).
+template <bool MAP>
 __global__ __launch_bounds__(kBitsBlock) void k_longest_bits(DevTables T, LongestBitsLaunch L) {
     __shared__ __attribute__((aligned(16))) uint4 tab[kBitsTabEntries];
     __shared__ uint32_t img_all[kBitsWaves][kBitsWaveWords];
@@ -282,6 +287,7 @@ __global__ __launch_bounds__(kBitsBlock) void k_longest_bits(DevTables T, Longes
     unsigned long long t_lookback_done = 0;
 #endif
     auto emit_region = [&](uint32_t r) {
+        const BitsCtx &bc = c; // (a step's count is called c below)
         unsigned long long before = 0;
         {
             const uint32_t blk = r >> 6, in_blk = r & 63u;
@@ -324,14 +330,24 @@ __global__ __launch_bounds__(kBitsBlock) void k_longest_bits(DevTables T, Longes
         const uint32_t R0 = L.g0 + r * kBitsRegionUnits;
         const uint32_t rel = R0 + (lane >> 5) * kBitsSegUnits + (lane & 31u) * 32u; // the lane's word in step 0
         unsigned long long done = before;
-        uint32_t mk[16];
+        // the marks of kCh steps at a time (MAP: and the text words under them and one word on, for the keywords' bits)
+        constexpr uint32_t kCh = MAP ? 8u : 16u;
+        uint32_t mk[kCh], txa[MAP ? kCh : 1u], txb[MAP ? kCh : 1u];
+        const uint32_t *tx = MAP ? L.d_text + (size_t)r * kBitsTextWords : nullptr;
 #pragma unroll
-        for (uint32_t half = 0; half < 2; ++half) {
+        for (uint32_t half = 0; half < 32u / kCh; ++half) {
 #pragma unroll
-            for (uint32_t t = 0; t < 16; ++t) mk[t] = gm[(half * 16u + t) * 64u + lane];
+            for (uint32_t t = 0; t < kCh; ++t) mk[t] = gm[(half * kCh + t) * 64u + lane];
+            if (MAP) {
 #pragma unroll
-            for (uint32_t t = 0; t < 16; ++t) {
-                const uint32_t i = half * 16u + t; // segments 2i and 2i + 1
+                for (uint32_t t = 0; t < kCh; ++t) {
+                    txa[t] = tx[(half * kCh + t) * 64u + lane];
+                    txb[t] = tx[(half * kCh + t) * 64u + lane + 1u];
+                }
+            }
+#pragma unroll
+            for (uint32_t t = 0; t < kCh; ++t) {
+                const uint32_t i = half * kCh + t; // segments 2i and 2i + 1
                 uint32_t w = mk[t];
                 const uint32_t c = (uint32_t)__popc(w);
                 const uint32_t incl = bits_wave_scan(c);
@@ -351,6 +367,94 @@ __global__ __launch_bounds__(kBitsBlock) void k_longest_bits(DevTables T, Longes
                     stg[tot + 1u] = edge;
                 }
                 __builtin_amdgcn_wave_barrier();
+                if (MAP) {
+                    // A record per lane and round.  Its keyword's id: the keyword's own bits -- out of the step's text words, which
+                    // the lanes hold (a shuffle, no memory access) -- looked up in HostTables::bits_idkeys (one 16-byte gather; the
+                    // text's few hundred frequent keywords stay in the L1).  The round's 64 records are then written as ONE stream
+                    // of dwords through LDS: whole aligned 16-byte pieces, 16 per lane -- lanes storing their own 12 bytes each
+                    // cost five times the Set records' pairs (measured: 0.26 against 0.055 ms for the 84 M records of config 4).
+                    int32_t *out32 = reinterpret_cast<int32_t *>(L.d_out);
+                    uint32_t *spare = img + 2u * kBitsSegUnits + 4u; // (behind the starts: 192 words)
+                    static_assert(2u * kBitsSegUnits + 4u + 3u * kWave <= kBitsWaveWords, "a round's records fit the image behind the starts");
+                    typedef unsigned long long v2ul __attribute__((ext_vector_type(2)));
+                    const v2ul *slots = reinterpret_cast<const v2ul *>(T.bits_idkeys);
+                    constexpr uint32_t kRounds = 1; // rounds whose lookups are in flight together (2: measured slower, 1.40 against 1.13 ms -- the kernel sits at its register limit)
+                    for (uint32_t k0 = 0; k0 < tot; k0 += kRounds * kWave) {
+                        uint32_t s0[kRounds], e0[kRounds], id[kRounds], slot[kRounds];
+                        unsigned long long key[kRounds];
+                        v2ul kk[kRounds];
+#pragma unroll
+                        for (uint32_t q = 0; q < kRounds; ++q) {
+                            const uint32_t k = min(k0 + q * kWave + lane, tot - 1u); // (a lane beyond the list repeats the last record)
+                            s0[q] = stg[k];
+                            e0[q] = stg[k + 1u];
+                            const uint32_t len = e0[q] - s0[q], rl = s0[q] - R0;
+                            const uint32_t j = (rl >> 5) - i * 64u; // the lane that holds the start's text word
+                            const uint32_t t0 = (uint32_t)__shfl((int)txa[t], (int)j), t1 = (uint32_t)__shfl((int)txb[t], (int)j);
+                            const uint32_t bits = __builtin_amdgcn_alignbit(t1, t0, rl & 31u) & (len < 32u ? (1u << (len & 31u)) - 1u : ~0u);
+                            key[q] = ((unsigned long long)len << 32) | bits;
+                            slot[q] = bits_id_hash(key[q]) & T.bits_idmask;
+                            kk[q] = slots[slot[q]];
+                        }
+#pragma unroll
+                        for (uint32_t q = 0; q < kRounds; ++q) {
+                            const uint32_t len = e0[q] - s0[q];
+                            id[q] = ~0u;
+#ifdef ACGPU_ABLATION
+                            if (L.debug & 64u) continue; // 64: no id lookups (timing only)
+#endif
+                            if (__builtin_expect(len <= 32u, 1)) {
+                                for (uint32_t probe = 0; probe < 64u; ++probe) { // (a call that bails out -- units outside the alphabet -- may ask for what is no keyword)
+                                    if (kk[q].x == key[q]) {
+                                        id[q] = (uint32_t)kk[q].y;
+                                        break;
+                                    }
+                                    if (kk[q].x == kEmptyKey) break;
+                                    slot[q] = (slot[q] + 1u) & T.bits_idmask;
+                                    kk[q] = slots[slot[q]];
+                                }
+                            } else { // a keyword of more than 32 units: its node by the walk
+                                uint32_t node = 0;
+                                for (uint32_t u = s0[q]; u < e0[q] && u < nu; ++u) {
+                                    const uint32_t dlt = (uint32_t)hay[u] - bc.base;
+                                    const uint32_t g = bc.dfa[(uint64_t)node * bc.n_cls + (dlt < bc.span ? dlt + 1u : 0u)];
+                                    if (!g) break;
+                                    node = g & 0x7fffffffu;
+                                }
+                                id[q] = T.term_id[node];
+                            }
+                        }
+#pragma unroll
+                        for (uint32_t q = 0; q < kRounds; ++q) {
+                            const uint32_t kq = k0 + q * kWave;
+                            if (kq >= tot) break; // wave-uniform
+                            const uint32_t n = min(tot - kq, (uint32_t)kWave);
+                            if (lane < n) {
+                                spare[3u * lane] = s0[q];
+                                spare[3u * lane + 1u] = e0[q];
+                                spare[3u * lane + 2u] = id[q];
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                            const unsigned long long first = done + kq; // the round's first record
+                            if (__builtin_expect(first + n <= L.cap, 1)) { // wave-uniform: all of them fit
+                                const unsigned long long d0 = first * 3ull;
+                                // (dwords in front of the first 16-byte boundary of the output: whatever alignment the caller's buffer has)
+                                const uint32_t nd = 3u * n, head = min(((16u - (uint32_t)(reinterpret_cast<uintptr_t>(out32 + d0) & 15u)) & 15u) / 4u, nd), body = (nd - head) & ~3u;
+                                if (lane < head) out32[d0 + lane] = (int32_t)spare[lane];
+                                if (4u * lane < body) {
+                                    const uint32_t *sp = spare + head + 4u * lane;
+                                    *reinterpret_cast<uint4 *>(out32 + d0 + head + 4u * lane) = make_uint4(sp[0], sp[1], sp[2], sp[3]);
+                                }
+                                if (lane < nd - head - body) out32[d0 + head + body + lane] = (int32_t)spare[head + body + lane];
+                            } else if (lane < n && first + lane < L.cap) {
+                                out32[(first + lane) * 3ull] = (int32_t)s0[q];
+                                out32[(first + lane) * 3ull + 1ull] = (int32_t)e0[q];
+                                out32[(first + lane) * 3ull + 2ull] = (int32_t)id[q];
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                    }
+                } else
                 if (__builtin_expect(done + tot <= L.cap, 1)) { // wave-uniform: all of them fit
                     // pairs of records on 16-byte boundaries of the output; a single one in front and / or behind them
                     const uint32_t odd = (uint32_t)done & 1u;
@@ -461,6 +565,20 @@ __global__ __launch_bounds__(kBitsBlock) void k_longest_bits(DevTables T, Longes
         const bool foreign = (dmax & 0xffffu) >= c.span || (dmax >> 16) >= c.span;
         if (__any(foreign) && lane == 0) L.d_exit[1] = 2ull; // a unit outside the alphabet: not this kernel's text
         __builtin_amdgcn_wave_barrier();
+#ifdef ACGPU_ABLATION
+        if (!(L.debug & 128u)) // 128: the text is not parked (timing only)
+#endif
+        if (MAP) { // the region's text bits (and the three words behind it) to memory: pass 2 writes its marks in their place
+            uint32_t *tx = L.d_text + (size_t)r * kBitsTextWords;
+#pragma unroll 4
+            for (uint32_t i = 0; i < kBitsRegionWords / 256u; ++i) {
+                const uint32_t g = i * 64u + lane, sg = g >> 3, k = (g & 7u) * 4u;
+                const uint32_t *sp = img + (sg + 1u) * kBitsStride + k;
+                *reinterpret_cast<uint4 *>(tx + 4u * g) = make_uint4(sp[0], sp[1], sp[2], sp[3]);
+            }
+            if (lane < kBitsLook) tx[kBitsRegionWords + lane] = img[kBitsSegs * kBitsStride + kBitsSegWords + lane];
+            if (lane == kBitsLook) tx[kBitsRegionWords + lane] = 0u;
+        }
         if (first && wave < kBitsWaves / 2 && lane == 0) atomicAdd(&gate, 1u);
         first = false;
         BITS_MARK(1)
@@ -596,11 +714,13 @@ __global__ __launch_bounds__(1024) void k_longest_bits_finish(LongestBitsLaunch 
 uint32_t longest_bits_region_units() { return kBitsRegionUnits; }
 uint32_t longest_bits_seg_units() { return kBitsSegUnits; }
 size_t longest_bits_region_scratch_bytes() { return (size_t)kBitsRegionWords * 4 + kBitsSegs * 4; }
+size_t longest_bits_region_text_bytes() { return (size_t)kBitsTextWords * 4; }
 
 hipError_t launch_longest_bits(const DevTables &t, const LongestBitsLaunch &l, unsigned long long *h_slot_dev, acgpu_device_result *d_result,
                                unsigned long long *d_state, uint32_t state_words, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_mid,
                                hipEvent_t ev_stop) {
-    ACGPU_LAUNCH_EV(k_longest_bits, dim3(l.grid), dim3(kBitsBlock), 0, stream, ev_start, ev_mid, t, l);
+    if (l.d_text) ACGPU_LAUNCH_EV(k_longest_bits<true>, dim3(l.grid), dim3(kBitsBlock), 0, stream, ev_start, ev_mid, t, l);
+    else ACGPU_LAUNCH_EV(k_longest_bits<false>, dim3(l.grid), dim3(kBitsBlock), 0, stream, ev_start, ev_mid, t, l);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
 #ifdef ACGPU_TIMING

@@ -23,19 +23,19 @@ def _reset_tunables():
         N.set_tunable(k, v)
 
 
-def _run(a, hay, own=None, entry=None, d_hay=None):
-    """One synchronous device call with Set records: (records, kernel name, chain exit)."""
+def _run(a, hay, own=None, entry=None, d_hay=None, with_ids=False):
+    """One synchronous device call with Set (or, with_ids, Map) records: (records, kernel name, chain exit)."""
     import torch
     if d_hay is None:
         d_hay = torch.from_numpy(np.ascontiguousarray(hay).view(np.int16)).cuda()
     cap = hay.size + 8
-    d_out = torch.empty((cap, 2), dtype=torch.int32, device="cuda")
+    d_out = torch.empty((cap, 3 if with_ids else 2), dtype=torch.int32, device="cuda")
     kw = {}
     if own is not None:
         kw["own"] = own
     if entry is not None:
         kw["chain_entry"] = entry
-    n_out, rc, prof, chain_exit = a.match_device(d_hay.data_ptr(), hay.size, False, d_out.data_ptr(), cap, profile=True,
+    n_out, rc, prof, chain_exit = a.match_device(d_hay.data_ptr(), hay.size, with_ids, d_out.data_ptr(), cap, profile=True,
                                                  stream=torch.cuda.current_stream().cuda_stream, **kw)
     assert rc == N.OK
     return d_out[:n_out].cpu().numpy(), prof["scan_kernel"], chain_exit
@@ -223,3 +223,55 @@ def test_bits_form_chains_that_never_merge_and_one_letter_alphabets():
     got, kname, _ = _run(a1, hay1)
     want = Oracle(FAM_LONGEST, kws1).match(hay1)[:, :2]
     assert kname != "k_longest_bits" and got.shape == want.shape and (got == want).all()
+
+
+def test_bits_form_map_records_ids_from_the_keywords_own_bits():
+    """LongestMatchMap through k_longest_bits (S/LongestMatchMap.java:288-360): the id of a record is looked up by the matched text's
+    own bits when the records are written, one region later -- keywords of up to 32 units in the table, longer ones by a walk;
+    duplicates (the LAST one's index is the id), every size across segment and region seams, shards, a capacity that is too
+    small, an enqueued call."""
+    import torch
+    rng = np.random.default_rng(4242)
+    kws = _c4_like(2500, 250)
+    kws += [np.array([A_, B_][::-1] * k, dtype=np.uint16) for k in (1, 5, 16, 17, 30)]        # 'baba...' of 2 .. 60 units: around 32
+    kws += [kws[i].copy() for i in rng.integers(0, len(kws), 200).tolist()]                  # duplicates: the last index is the id
+    a = Automaton(N.MODE_LONGEST, kws, True)
+    orc = Oracle(FAM_LONGEST, kws)
+    whole = synth.haystack(2005, (1 << 21) + 4099, table=synth.ALPHA_AB_75).copy()
+    for at in rng.integers(0, whole.size - 200, 300).tolist():                              # planted 'baba' runs and long runs of 'a'
+        whole[at:at + 60] = np.array([B_, A_] * 30, dtype=np.uint16)
+    for at in rng.integers(0, whole.size - 400, 100).tolist():
+        whole[at:at + int(rng.integers(20, 300))] = A_
+    N.set_tunable("longest_form", BITS_ALWAYS)
+    for n in (1, 2, 33, 1024, 1025, 65535, 65536, 65537, 131072 + 31, 700001, whole.size):
+        hay = whole[:n]
+        got, kname, ex = _run(a, hay, with_ids=True)
+        want = orc.match(hay)
+        assert kname == "k_longest_bits", (n, kname)
+        assert got.shape == want.shape and (got == want).all(), n
+    want = orc.match(whole)
+    assert int((want[:, 1] - want[:, 0]).max()) > 40 and len(set(want[:, 2].tolist())) > 100
+    # shards: every shard's records carry the ids
+    d_hay = torch.from_numpy(whole.view(np.int16)).cuda()
+    parts, entry = [], 0
+    for lo, hi in ((0, 333_333), (333_333, 333_400), (333_400, 1_500_001), (1_500_001, whole.size)):
+        got, kname, ex = _run(a, whole, own=(lo, hi), entry=max(entry, lo), d_hay=d_hay, with_ids=True)
+        assert kname == "k_longest_bits"
+        parts.append(got)
+        entry = ex
+    assert (np.concatenate(parts) == want).all()
+    # a capacity that is too small: the exact count, the first records; then through a ticket
+    st = torch.cuda.current_stream().cuda_stream
+    cap = len(want) // 2
+    out = torch.full((cap, 3), -7, dtype=torch.int32, device="cuda")
+    n_out, rc, _, _ = a.match_device(d_hay.data_ptr(), whole.size, True, out.data_ptr(), cap, stream=st)
+    assert rc == N.E_OVERFLOW and n_out == len(want) and (out.cpu().numpy() == want[:cap]).all()
+    out = torch.empty((len(want) + 8, 3), dtype=torch.int32, device="cuda")
+    tk, rc = a.match_device_begin(d_hay.data_ptr(), whole.size, True, out.data_ptr(), len(want) + 8, stream=st, profile=True)
+    assert rc == N.OK
+    n_out, rc, prof = a.match_device_end(tk, profile=True)
+    assert rc == N.OK and n_out == len(want) and prof["scan_kernel"] == "k_longest_bits" and (out[:n_out].cpu().numpy() == want).all()
+    # and the walk pipeline gives the same records
+    N.set_tunable("longest_form", 3)
+    got, kname, _ = _run(a, whole, with_ids=True)
+    assert kname != "k_longest_bits" and (got == want).all()
