@@ -72,6 +72,9 @@ def main():
                          "shape a JVM calls (INTEGRATION.md)")
     ap.add_argument("--devices", default=None, help="--single-process: comma-separated device list (default 0..N-1; a device may "
                                                     "be named twice on a box with fewer GPUs: peer-copy transport)")
+    ap.add_argument("--no-separate-launches", action="store_true",
+                    help="skip the roofline.separate_launches diagnostic (a few extra steps with the ordering in launches of their own): "
+                         "what the rocprofv3 --stats evidence is collected with, so that the kernel's average is of the timed form alone")
     ap.add_argument("--tunable", action="append", default=[], metavar="NAME=VALUE",
                     help="development: an acgpu_set_tunable knob for A/B on one box (e.g. tile_form=1: a finalize launch behind the scan); "
                          "recorded in config.tunables")
@@ -284,7 +287,8 @@ def main():
     # The same steps with the ordering of the records in launches of their own behind the scan (tile_form 3: what rounds 2-5
     # timed), a few of them, outside the timed region: the scan kernel ALONE against the roofline, for comparison with those
     # rounds' figures -- `frac` above is of the whole call, which is one kernel now.
-    if not multi and cfg_name in ("C2", "C3", "C5") and float(np.mean(fin_ms)) == 0.0 and not any(t.startswith("tile_form") for t in args.tunable):
+    if not multi and cfg_name in ("C2", "C3", "C5") and float(np.mean(fin_ms)) == 0.0 and not args.no_separate_launches and \
+            not any(t.startswith("tile_form") for t in args.tunable):
         N.set_tunable("tile_form", 3)
         sep = []
         for _ in range(7):

@@ -16,9 +16,9 @@ python3 bench.py --steps 20 --warmup 3 > "$OUT/bench_c2.json" 2> "$OUT/bench_c2.
 python3 bench.py --config C4 --steps 10 --warmup 2 > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err"
 python3 bench.py --config C5 --steps 20 --warmup 3 > "$OUT/bench_c5.json" 2> "$OUT/bench_c5.err"
 # per-kernel time: the program itself after "--"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c2" -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/stats_c2.log" 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c4" -- python3 bench.py --config C4 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/stats_c4.log" 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c5" -- python3 bench.py --config C5 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/stats_c5.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c2" -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-separate-launches > "$OUT/stats_c2.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c4" -- python3 bench.py --config C4 --steps 3 --warmup 1 --no-cpu-baseline --no-separate-launches > "$OUT/stats_c4.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c5" -- python3 bench.py --config C5 --steps 3 --warmup 1 --no-cpu-baseline --no-separate-launches > "$OUT/stats_c5.log" 2>&1
 # HBM traffic counters: separate passes, counters only (no other trace domains).  The no-verify / stream-only variants are
 # ablation switches, which only the -DACGPU_ABLATION build has (tools/build_variant.sh abl -DACGPU_ABLATION, built before the
 # gpurun call: ahocorasick_amd/lib_abl/ travels with the snapshot); its full build is the product kernel plus the switches.
