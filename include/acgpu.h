@@ -448,7 +448,14 @@ int acgpu_stream_probe(const void *d_buf, uint64_t n_bytes, void *stream, int re
  * filter), "no_short_keywords" (the filter's K stays at most the shortest keyword), "no_class_pages" (the class-table forms of
  * the tile kernel look classes up in global memory instead of LDS pages); "reserve_cus" (the scan kernels size their
  * grids for that many CUs fewer: a scan workgroup holds a whole CU's LDS, so k CUs stay free for the kernels of a collective
- * that runs under the scan -- RCCL's all-gather in a multi-GPU job).  Returns the previous value, -1 for an unknown name. */
+ * that runs under the scan -- RCCL's all-gather in a multi-GPU job); "tile_form" (bit 0: the K-gram tile scan leaves the
+ * ordering of its records to a second kernel instead of its own tail, bit 1: the same for the WHOLEWORD kernel -- the
+ * separate launches bench.py times beside the one-kernel call); the WHOLEWORD builder's and kernel's A/B switches
+ * "ww_no_ph" (two-choice hash table instead of the perfect one), "ww_ph_lambda" (keys per bucket of the perfect hash,
+ * default 4), "ww_no_byte_pages" (units staged as class codes, not as one byte each), "ww_block" (threads of a workgroup,
+ * a multiple of 64) and "ww_ramp_pm" (per mille by which the spans of the last workgroups shrink); "longest_form" (bits:
+ * 1 no k_longest_bits, 2 no k_longest_follow, 4 both for short texts too, 8 k_longest_follow over alphabets of up to four
+ * letters).  Returns the previous value, -1 for an unknown name. */
 int64_t acgpu_set_tunable(const char *name, int64_t value);
 
 const char *acgpu_strerror(int code);
