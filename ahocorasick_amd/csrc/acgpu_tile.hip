@@ -865,8 +865,10 @@ __global__ __launch_bounds__(kTileBlock) void k_ac_tile(DevTables T, TileLaunch 
                                 const int S = S0 + t;
                                 H = pk_mad(H, n2, (S & 1) ? MM[(S + 1) / 2] : CC[S / 2]);
                             }
-                            const uint32_t row_lo = rows32[H & 0xffffu];
-                            const uint32_t row_hi = rows32[H >> 16];
+                            // (8192: ablation, timing only -- every lane reads a word of its own bank, 32 rows around the right one:
+                            // what the rows' bank conflicts cost)
+                            const uint32_t row_lo = rows32[ACGPU_DBG(L, 8192u) ? ((H & 0xffe0u) | (lane & 31u)) : (H & 0xffffu)];
+                            const uint32_t row_hi = rows32[ACGPU_DBG(L, 8192u) ? (((H >> 16) & 0xffe0u) | (lane & 31u)) : (H >> 16)];
                             acc = __builtin_amdgcn_alignbit(row_lo >> (CC[D] & 31u), acc, 1);
                             acc = __builtin_amdgcn_alignbit(row_hi >> ((CC[D] >> 16) & 31u), acc, 1);
                         }
